@@ -1,0 +1,66 @@
+/* tcmi.h -- C ABI of libtcmi.so, the MI355X (gfx950) executor for the tensorcircuit-ng
+ * state-vector / expectation hot path.
+ *
+ * The reference is pure Python: its "FFI" for this path is the backend plug-in
+ * (tensorcircuit/backends/backend_factory.py:26-59) whose tensordot/transpose/reshape methods are
+ * called by the contractor loop (tensorcircuit/cons.py:937-960).  A reference maintainer binds this
+ * library with ctypes from a new backend class; every entry point below names
+ * the reference interface it replaces.
+ *
+ * Conventions: all pointers are DEVICE pointers unless the name ends in _host; the caller owns every
+ * buffer; `stream` is a hipStream_t passed as void* (NULL = default stream); every function returns
+ * 0 (TCMI_OK) or a negative error code and never throws; tcmi_last_error() gives the message of the
+ * calling thread's last failure.  dtype: TCMI_C64 = complex64 (interleaved float re,im),
+ * TCMI_C128 = complex128.  State index convention: qubit 0 is the most significant bit of the flat
+ * index (reference tests/test_circuit.py:47-53); a batched state is [batch][2^n] with
+ * `state_stride` amplitudes between batch elements.
+ */
+#ifndef TCMI_H
+#define TCMI_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TCMI_VERSION 1
+#define TCMI_OK 0
+#define TCMI_ERR_ARG (-1)
+#define TCMI_ERR_HIP (-2)
+#define TCMI_C64 0
+#define TCMI_C128 1
+
+/* library / runtime probes */
+int tcmi_version(void);
+const char* tcmi_last_error(void);
+int tcmi_device_count(void);
+
+/* |0...0> for every batch element.
+ * Replaces: Circuit.__init__ -> BaseCircuit.all_zero_nodes (tensorcircuit/circuit.py:44-131,
+ * tensorcircuit/basecircuit.py:51-66). */
+int tcmi_init_zero_state(void* state, long long state_stride, int batch, int n, int dtype, void* stream);
+
+/* Gate-table builder: per batch element, turn the flat real parameter vector into the dense gate
+ * matrices  M = C0 + cos(k*theta+o) C1 + sin(k*theta+o) C2  and the diagonal phase coefficients the
+ * pass programs reference.  `ginfo` = int32[nrec][8] records {kind, out_slot, param_index, dim,
+ * cpool_offset, 0,0,0}; `cpool` = float64 constants; params are float (C64) / double (C128).
+ * Replaces: the gate factories rx/ry/rz/exp1/rzz/phase/... evaluated per call
+ * (tensorcircuit/gates.py:584-603, 692-743, 920-978). */
+int tcmi_build_tables(const int* ginfo, int nrec, const double* cpool, const void* params,
+                      long long params_stride, void* ptab, long long ptab_stride, int batch,
+                      int dtype, void* stream);
+
+/* One pass of a compiled plan over the (batched) state, in place: every workgroup loads a tile of
+ * 2^(R+LT) amplitudes, applies the pass program `desc` (int32 words, layout in
+ * tensorcircuit-ng_amd/csrc/tcmi_vm.h) and stores the tile back.  `ctab` = shared constant table,
+ * `ptab` = per-batch table written by tcmi_build_tables (real values of the state's precision).
+ * Replaces: the pairwise loop  tn.contract_between -> backend.tensordot  plus the final
+ * Node.reorder_edges -> backend.transpose  (tensorcircuit/cons.py:937-960), i.e. what
+ * Circuit.wavefunction executes (tensorcircuit/circuit.py:701-721). */
+int tcmi_run_pass(void* state, long long state_stride, int batch, int n, int R, int LT,
+                  const int* desc, const void* ctab, const void* ptab, long long ptab_stride,
+                  int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TCMI_H */

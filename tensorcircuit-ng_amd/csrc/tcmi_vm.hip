@@ -1,0 +1,503 @@
+// tcmi tile-VM: the state-vector pass kernel for gfx950 (MI355X).
+//
+// One launch = one "pass" of the compiled plan (tcmi/plan.py): every workgroup loads a tile of
+// 2^T amplitudes straight into registers (2^R per thread, 16-byte coalesced accesses), runs the
+// pass program -- dense 1-/2-qubit gates on register bits, diagonal phase polynomials evaluated
+// from the global index, LDS exchanges that re-map which tile bits are register bits -- and
+// writes the tile back in place.  It replaces the reference's per-gate
+// tn.contract_between -> backend.tensordot chain and the final reorder_edges transpose
+// (reference tensorcircuit/cons.py:937-960, tensorcircuit/circuit.py:701-721).
+//
+// Written for CDNA4 only: wave64, 160 KiB LDS (64 KiB per 8192-amplitude tile -> 2 workgroups
+// per CU), scalar (SGPR) gate coefficients, bank-conflict-free LDS exchange maps chosen on the
+// host per exchange.  Descriptor layout: see tcmi_vm.h / tcmi/plan.py.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "tcmi_vm.h"
+
+namespace tcmi {
+
+template <typename F> struct Cx;
+template <> struct Cx<float> { using type = float2; };
+template <> struct Cx<double> { using type = double2; };
+
+template <typename F> __device__ __forceinline__ void sincos_turns(F x, F* s, F* c);
+template <> __device__ __forceinline__ void sincos_turns<float>(float x, float* s, float* c) {
+#ifdef TCMI_PRECISE_SINCOS
+  sincospif(2.0f * x, s, c);
+#else
+  // v_sin_f32 / v_cos_f32 take their argument in turns; reduce to [-0.5, 0.5] first
+  x -= __builtin_rintf(x);
+  *s = __builtin_amdgcn_sinf(x);
+  *c = __builtin_amdgcn_cosf(x);
+#endif
+}
+template <> __device__ __forceinline__ void sincos_turns<double>(double x, double* s, double* c) {
+  sincospi(2.0 * x, s, c);
+}
+
+// Tables and descriptors are read-only for the whole launch and every access is wave-uniform:
+// read them through the constant address space so they become s_load (SGPR) operands.
+#define TCMI_K __attribute__((address_space(4)))
+template <typename F> using KPtr = const F TCMI_K*;
+using KInt = const int TCMI_K*;
+
+template <typename F>
+__device__ __forceinline__ KPtr<F> tab_ptr(int slot, KPtr<F> ctab, KPtr<F> ptab) {
+  return (slot & TCMI_CONST_FLAG) ? ctab + (slot & ~TCMI_CONST_FLAG) : ptab + slot;
+}
+
+// XOR of mask[i] over the set bits of v (wave-uniform masks, per-lane v)
+template <int NB>
+__device__ __forceinline__ uint32_t xor_masks(uint32_t v, KInt masks) {
+  uint32_t out = 0;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) out ^= (0u - ((v >> i) & 1u)) & (uint32_t)masks[i];
+  return out;
+}
+
+// XOR of mask[j] over the set bits of a compile-time register index
+template <int R>
+__device__ __forceinline__ uint32_t reg_mask(int r, const uint32_t (&m)[R]) {
+  uint32_t out = 0;
+#pragma unroll
+  for (int j = 0; j < R; ++j)
+    if ((r >> j) & 1) out ^= m[j];
+  return out;
+}
+
+template <typename F> __device__ __forceinline__ F fma_(F a, F b, F c);
+template <> __device__ __forceinline__ float fma_<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+template <> __device__ __forceinline__ double fma_<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// acc += m * v (complex), 4 FMAs
+template <typename F, typename C>
+__device__ __forceinline__ void cfma(F mr, F mi, const C& v, F& re, F& im) {
+  re = fma_<F>(mr, v.x, re);
+  re = fma_<F>(-mi, v.y, re);
+  im = fma_<F>(mr, v.y, im);
+  im = fma_<F>(mi, v.x, im);
+}
+
+// KIND 0: general complex 2x2 (16 FMA per pair)
+// KIND 1: real matrix (h, ry, x, z ...)                         (8 per pair)
+// KIND 2: real diagonal, imaginary off-diagonal (rx, y ...)     (8 per pair)
+template <typename F, int NR, int J, int KIND>
+__device__ __forceinline__ void apply_g1(typename Cx<F>::type (&a)[NR], const F (&m)[8]) {
+  const F m00r = m[0], m00i = m[1], m01r = m[2], m01i = m[3];
+  const F m10r = m[4], m10i = m[5], m11r = m[6], m11i = m[7];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    if ((r >> J) & 1) continue;
+    const int r1 = r | (1 << J);
+    const auto x = a[r];
+    const auto y = a[r1];
+    if constexpr (KIND == 1) {
+      a[r].x = fma_<F>(m01r, y.x, m00r * x.x);
+      a[r].y = fma_<F>(m01r, y.y, m00r * x.y);
+      a[r1].x = fma_<F>(m11r, y.x, m10r * x.x);
+      a[r1].y = fma_<F>(m11r, y.y, m10r * x.y);
+    } else if constexpr (KIND == 2) {
+      a[r].x = fma_<F>(-m01i, y.y, m00r * x.x);
+      a[r].y = fma_<F>(m01i, y.x, m00r * x.y);
+      a[r1].x = fma_<F>(-m10i, x.y, m11r * y.x);
+      a[r1].y = fma_<F>(m10i, x.x, m11r * y.y);
+    } else {
+      F re0 = m00r * x.x, im0 = m00r * x.y, re1 = m10r * x.x, im1 = m10r * x.y;
+      re0 = fma_<F>(-m00i, x.y, re0);
+      im0 = fma_<F>(m00i, x.x, im0);
+      re1 = fma_<F>(-m10i, x.y, re1);
+      im1 = fma_<F>(m10i, x.x, im1);
+      cfma<F>(m01r, m01i, y, re0, im0);
+      cfma<F>(m11r, m11i, y, re1, im1);
+      a[r].x = re0; a[r].y = im0; a[r1].x = re1; a[r1].y = im1;
+    }
+  }
+}
+
+template <typename F, int NR, int JA, int JB>
+__device__ __forceinline__ void apply_g2(typename Cx<F>::type (&a)[NR], const F (&m)[32]) {
+  // matrix index = (bit JA << 1) | bit JB, JA < JB
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    if (((r >> JA) & 1) || ((r >> JB) & 1)) continue;
+    const int i0 = r, i1 = r | (1 << JB), i2 = r | (1 << JA), i3 = r | (1 << JA) | (1 << JB);
+    const typename Cx<F>::type v[4] = {a[i0], a[i1], a[i2], a[i3]};
+    typename Cx<F>::type o[4];
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+      F re = m[8 * row] * v[0].x, im = m[8 * row] * v[0].y;
+      re = fma_<F>(-m[8 * row + 1], v[0].y, re);
+      im = fma_<F>(m[8 * row + 1], v[0].x, im);
+#pragma unroll
+      for (int col = 1; col < 4; ++col) cfma<F>(m[2 * (4 * row + col)], m[2 * (4 * row + col) + 1], v[col], re, im);
+      o[row].x = re;
+      o[row].y = im;
+    }
+    a[i0] = o[0];
+    a[i1] = o[1];
+    a[i2] = o[2];
+    a[i3] = o[3];
+  }
+}
+
+template <typename F, int NR, int R, int KIND>
+__device__ __forceinline__ void dispatch_g1k(typename Cx<F>::type (&a)[NR], int j, const F (&m)[8]) {
+  switch (j) {
+    case 0: apply_g1<F, NR, 0, KIND>(a, m); break;
+    case 1: if constexpr (R > 1) apply_g1<F, NR, 1, KIND>(a, m); break;
+    case 2: if constexpr (R > 2) apply_g1<F, NR, 2, KIND>(a, m); break;
+    case 3: if constexpr (R > 3) apply_g1<F, NR, 3, KIND>(a, m); break;
+    case 4: if constexpr (R > 4) apply_g1<F, NR, 4, KIND>(a, m); break;
+    case 5: if constexpr (R > 5) apply_g1<F, NR, 5, KIND>(a, m); break;
+    default: break;
+  }
+}
+
+template <typename F, int NR, int R>
+__device__ __forceinline__ void dispatch_g1(typename Cx<F>::type (&a)[NR], int jk, const F (&m)[8]) {
+  const int j = jk & 0xff, kind = jk >> 8;
+  if (kind == 1) dispatch_g1k<F, NR, R, 1>(a, j, m);
+  else if (kind == 2) dispatch_g1k<F, NR, R, 2>(a, j, m);
+  else dispatch_g1k<F, NR, R, 0>(a, j, m);
+}
+
+#define TCMI_G2_CASE(A, B)                                         \
+  case (A * 8 + B):                                                \
+    if constexpr (R > B) apply_g2<F, NR, A, B>(a, m);              \
+    break;
+
+template <typename F, int NR, int R>
+__device__ __forceinline__ void dispatch_g2(typename Cx<F>::type (&a)[NR], int ja, int jb, const F (&m)[32]) {
+  switch (ja * 8 + jb) {
+    TCMI_G2_CASE(0, 1) TCMI_G2_CASE(0, 2) TCMI_G2_CASE(0, 3) TCMI_G2_CASE(0, 4) TCMI_G2_CASE(0, 5)
+    TCMI_G2_CASE(1, 2) TCMI_G2_CASE(1, 3) TCMI_G2_CASE(1, 4) TCMI_G2_CASE(1, 5)
+    TCMI_G2_CASE(2, 3) TCMI_G2_CASE(2, 4) TCMI_G2_CASE(2, 5)
+    TCMI_G2_CASE(3, 4) TCMI_G2_CASE(3, 5)
+    TCMI_G2_CASE(4, 5)
+    default: break;
+  }
+}
+
+template <typename F, int R, int LT>
+__global__ __launch_bounds__(1 << LT) void pass_kernel(typename Cx<F>::type* __restrict__ state,
+                                                        long long state_stride,
+                                                        const int* __restrict__ desc_g,
+                                                        const F* __restrict__ ctab_g,
+                                                        const F* __restrict__ ptab_g,
+                                                        long long ptab_stride) {
+  using C = typename Cx<F>::type;
+  constexpr int NR = 1 << R;
+  constexpr int T = R + LT;
+  constexpr int VEC = (sizeof(F) == 4) ? 2 : 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  C* lds = reinterpret_cast<C*>(smem);
+
+  const uint32_t tid = threadIdx.x;
+  state += (long long)blockIdx.y * state_stride;
+  const KInt desc = (KInt)desc_g;
+  const KPtr<F> ctab = (KPtr<F>)ctab_g;
+  const KPtr<F> ptab = (KPtr<F>)(ptab_g + (long long)blockIdx.y * ptab_stride);
+
+  const int nrounds = desc[5];
+  // workgroup base index: deposit blockIdx.x into the non-tile bit positions
+  unsigned long long x = blockIdx.x;
+#pragma unroll 1
+  for (int i = 0; i < T; ++i) {
+    const int p = desc[8 + i];
+    const unsigned long long low = (1ull << p) - 1ull;
+    x = ((x & ~low) << 1) | (x & low);
+  }
+  const uint32_t wg_base = (uint32_t)x;
+
+  C a[NR];
+  int pc = TCMI_HDR_WORDS;
+#pragma unroll 1
+  for (int k = 0; k < nrounds; ++k) {
+    const KInt rr = desc + pc;
+    const int nops = rr[0];
+    const uint32_t tphys = xor_masks<LT>(tid, rr + 8);
+    uint32_t rpm[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) rpm[j] = (uint32_t)rr[2 + j];
+
+    if (k == 0) {
+      const C* __restrict__ src = state + (wg_base | tphys);
+#pragma unroll
+      for (int r = 0; r < NR; r += VEC) {
+        const uint32_t off = reg_mask<R>(r, rpm);
+        if constexpr (VEC == 2) {
+          const float4 v = *reinterpret_cast<const float4*>(src + off);
+          a[r].x = v.x; a[r].y = v.y; a[r + 1].x = v.z; a[r + 1].y = v.w;
+        } else {
+          a[r] = src[off];
+        }
+      }
+    } else {
+      const uint32_t tslot = xor_masks<LT>(tid, rr + 24);
+      uint32_t rsm[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) rsm[j] = (uint32_t)rr[18 + j];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) a[r] = lds[tslot ^ reg_mask<R>(r, rsm)];
+      __syncthreads();  // all reads done before the next exchange overwrites the tile
+    }
+
+    // ---- ops of this round ----
+    int q = pc + TCMI_RR_WORDS;
+#pragma unroll 1
+    for (int o = 0; o < nops; ++o) {
+      const int op = desc[q];
+      if (op == TCMI_OP_G1) {
+        const KPtr<F> mp = tab_ptr<F>(desc[q + 2], ctab, ptab);
+        F m[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m[i] = mp[i];
+        dispatch_g1<F, NR, R>(a, desc[q + 1], m);
+        q += 3;
+      } else if (op == TCMI_OP_G2) {
+        const KPtr<F> mp = tab_ptr<F>(desc[q + 3], ctab, ptab);
+        F m[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) m[i] = mp[i];
+        dispatch_g2<F, NR, R>(a, desc[q + 1], desc[q + 2], m);
+        q += 4;
+      } else if (op == TCMI_OP_DIAG) {
+        const int nA = desc[q + 1], nB = desc[q + 2], nC = desc[q + 3];
+        q += 4;
+        const uint32_t tidx = wg_base | tphys;
+        double phi = 0.0;
+#pragma unroll 1
+        for (int e = 0; e < nA; ++e) {
+          const uint32_t mask = (uint32_t)desc[q];
+          const double c = (double)*tab_ptr<F>(desc[q + 1], ctab, ptab);
+          phi += (__popc(tidx & mask) & 1) ? -c : c;
+          q += 2;
+        }
+        double cj[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) cj[j] = 0.0;
+#pragma unroll 1
+        for (int e = 0; e < nB; ++e) {
+          const int jj = desc[q];
+          const uint32_t mask = (uint32_t)desc[q + 1];
+          const double c = (double)*tab_ptr<F>(desc[q + 2], ctab, ptab);
+          const double s = (__popc(tidx & mask) & 1) ? -c : c;
+#pragma unroll
+          for (int j = 0; j < R; ++j) cj[j] += (j == jj) ? s : 0.0;
+          q += 3;
+        }
+        F ph[NR];
+        ph[0] = (F)(phi - rint(phi));
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const F c = (F)(cj[j] - rint(cj[j]));
+#pragma unroll
+          for (int r = 0; r < (1 << j); ++r) {
+            ph[r | (1 << j)] = ph[r] - c;
+            ph[r] += c;
+          }
+        }
+#pragma unroll 1
+        for (int e = 0; e < nC; ++e) {
+          const uint32_t rmask = (uint32_t)desc[q];
+          const F c = *tab_ptr<F>(desc[q + 1], ctab, ptab);
+#pragma unroll
+          for (int r = 0; r < NR; ++r) ph[r] += (__popc((uint32_t)r & rmask) & 1) ? -c : c;
+          q += 2;
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          F s, c;
+          sincos_turns<F>(ph[r], &s, &c);
+          const C v = a[r];
+          a[r].x = v.x * c - v.y * s;
+          a[r].y = v.x * s + v.y * c;
+        }
+      } else {
+        break;  // unknown opcode: host validates descriptors, never reached
+      }
+    }
+    pc += TCMI_RR_WORDS + rr[1];
+
+    if (k < nrounds - 1) {
+      const uint32_t tslot = xor_masks<LT>(tid, rr + 40);
+      uint32_t wsm[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) wsm[j] = (uint32_t)rr[34 + j];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) lds[tslot ^ reg_mask<R>(r, wsm)] = a[r];
+      __syncthreads();
+    } else {
+      C* __restrict__ dst = state + (wg_base | tphys);
+#pragma unroll
+      for (int r = 0; r < NR; r += VEC) {
+        const uint32_t off = reg_mask<R>(r, rpm);
+        if constexpr (VEC == 2) {
+          float4 v;
+          v.x = a[r].x; v.y = a[r].y; v.z = a[r + 1].x; v.w = a[r + 1].y;
+          *reinterpret_cast<float4*>(dst + off) = v;
+        } else {
+          dst[off] = a[r];
+        }
+      }
+    }
+  }
+}
+
+// ---- builder: parameters -> per-batch gate tables (reference gates.py:692-743, 920-953) -------
+template <typename F>
+__global__ void build_kernel(const int* __restrict__ ginfo, int nrec, const double* __restrict__ cpool,
+                             const F* __restrict__ params, long long pstride, F* __restrict__ ptab,
+                             long long tstride, int batch) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (g >= nrec || b >= batch) return;
+  const int* rec = ginfo + 8 * g;
+  const int kind = rec[0], slot = rec[1], pidx = rec[2], dim = rec[3], off = rec[4];
+  const double theta = (double)params[(long long)b * pstride + pidx];
+  const double ang = cpool[off] * theta + cpool[off + 1];
+  F* out = ptab + (long long)b * tstride + slot;
+  if (kind == TCMI_BK_TRIG) {
+    double s, c;
+    sincos(ang, &s, &c);
+    const int nn = 2 * dim * dim;
+    const double* c0 = cpool + off + 2;
+    const double* c1 = c0 + nn;
+    const double* c2 = c1 + nn;
+    for (int i = 0; i < nn; ++i) out[i] = (F)(c0[i] + c * c1[i] + s * c2[i]);
+  } else if (kind == TCMI_BK_COEF) {
+    out[0] = (F)(ang - rint(ang));  // phase coefficient in turns, reduced to [-0.5, 0.5]
+  }
+}
+
+template <typename F>
+__global__ void zero_state_kernel(typename Cx<F>::type* __restrict__ state, long long stride,
+                                  unsigned long long nelem) {
+  using C = typename Cx<F>::type;
+  C* s = state + (long long)blockIdx.y * stride;
+  const unsigned long long i0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = i0; i < nelem; i += step) {
+    C v;
+    v.x = (i == 0) ? (F)1 : (F)0;
+    v.y = (F)0;
+    s[i] = v;
+  }
+}
+
+}  // namespace tcmi
+
+// ---- C ABI ------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int set_err(const char* what, hipError_t e) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+  return TCMI_ERR_HIP;
+}
+static int set_msg(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+
+template <typename F, int R, int LT>
+static int launch_pass(void* state, long long state_stride, int batch, int n, const int* desc,
+                       const void* ctab, const void* ptab, long long ptab_stride, hipStream_t st) {
+  using C = typename tcmi::Cx<F>::type;
+  constexpr int T = R + LT;
+  if (n < T) return set_msg(TCMI_ERR_ARG, "tcmi_run_pass: n smaller than the tile");
+  const size_t lds = sizeof(C) << T;
+  auto kern = tcmi::pass_kernel<F, R, LT>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return set_err("hipFuncSetAttribute", e);
+  }
+  dim3 grid(1u << (n - T), (unsigned)batch, 1), block(1u << LT, 1, 1);
+  hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<C*>(state), state_stride, desc,
+                     reinterpret_cast<const F*>(ctab), reinterpret_cast<const F*>(ptab), ptab_stride);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_err("pass_kernel launch", e);
+  return TCMI_OK;
+}
+
+extern "C" {
+
+int tcmi_version(void) { return TCMI_VERSION; }
+
+const char* tcmi_last_error(void) { return g_err; }
+
+int tcmi_device_count(void) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+  return c;
+}
+
+int tcmi_run_pass(void* state, long long state_stride, int batch, int n, int R, int LT,
+                  const int* desc_dev, const void* ctab_dev, const void* ptab_dev,
+                  long long ptab_stride, int dtype, void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!state || !desc_dev || batch < 1) return set_msg(TCMI_ERR_ARG, "tcmi_run_pass: bad argument");
+  if (n > 32) return set_msg(TCMI_ERR_ARG, "tcmi_run_pass: n > 32 unsupported");
+#define TCMI_CASE(FT, RR, LL) \
+  if (R == RR && LT == LL)    \
+    return launch_pass<FT, RR, LL>(state, state_stride, batch, n, desc_dev, ctab_dev, ptab_dev, ptab_stride, st);
+  if (dtype == TCMI_C64) {
+    TCMI_CASE(float, 5, 8)
+    TCMI_CASE(float, 4, 8)
+    TCMI_CASE(float, 5, 9)
+    TCMI_CASE(float, 4, 9)
+    TCMI_CASE(float, 2, 6)
+  } else if (dtype == TCMI_C128) {
+    TCMI_CASE(double, 4, 8)
+    TCMI_CASE(double, 3, 8)
+    TCMI_CASE(double, 2, 6)
+  }
+#undef TCMI_CASE
+  return set_msg(TCMI_ERR_ARG, "tcmi_run_pass: unsupported (dtype, R, LT) variant");
+}
+
+int tcmi_build_tables(const int* ginfo_dev, int nrec, const double* cpool_dev, const void* params_dev,
+                      long long params_stride, void* ptab_dev, long long ptab_stride, int batch,
+                      int dtype, void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (nrec == 0) return TCMI_OK;
+  if (!ginfo_dev || !cpool_dev || !params_dev || !ptab_dev || batch < 1)
+    return set_msg(TCMI_ERR_ARG, "tcmi_build_tables: bad argument");
+  dim3 block(128, 1, 1), grid((nrec + 127) / 128, batch, 1);
+  if (dtype == TCMI_C64)
+    hipLaunchKernelGGL(tcmi::build_kernel<float>, grid, block, 0, st, ginfo_dev, nrec, cpool_dev,
+                       reinterpret_cast<const float*>(params_dev), params_stride,
+                       reinterpret_cast<float*>(ptab_dev), ptab_stride, batch);
+  else if (dtype == TCMI_C128)
+    hipLaunchKernelGGL(tcmi::build_kernel<double>, grid, block, 0, st, ginfo_dev, nrec, cpool_dev,
+                       reinterpret_cast<const double*>(params_dev), params_stride,
+                       reinterpret_cast<double*>(ptab_dev), ptab_stride, batch);
+  else
+    return set_msg(TCMI_ERR_ARG, "tcmi_build_tables: bad dtype");
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_err("build_kernel launch", e);
+  return TCMI_OK;
+}
+
+int tcmi_init_zero_state(void* state, long long state_stride, int batch, int n, int dtype, void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!state || batch < 1 || n < 0 || n > 34) return set_msg(TCMI_ERR_ARG, "tcmi_init_zero_state: bad argument");
+  const unsigned long long nelem = 1ull << n;
+  unsigned gx = (unsigned)((nelem + 255) / 256 > 4096 ? 4096 : (nelem + 255) / 256);
+  dim3 grid(gx, batch, 1), block(256, 1, 1);
+  if (dtype == TCMI_C64)
+    hipLaunchKernelGGL(tcmi::zero_state_kernel<float>, grid, block, 0, st,
+                       reinterpret_cast<float2*>(state), state_stride, nelem);
+  else if (dtype == TCMI_C128)
+    hipLaunchKernelGGL(tcmi::zero_state_kernel<double>, grid, block, 0, st,
+                       reinterpret_cast<double2*>(state), state_stride, nelem);
+  else
+    return set_msg(TCMI_ERR_ARG, "tcmi_init_zero_state: bad dtype");
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_err("zero_state_kernel launch", e);
+  return TCMI_OK;
+}
+
+}  // extern "C"

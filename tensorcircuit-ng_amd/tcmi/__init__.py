@@ -1,0 +1,30 @@
+"""tcmi -- an MI355X-native executor for the tensorcircuit-ng state-vector / expectation hot path.
+
+Drop-in surface (reference ``tensorcircuit/__init__.py``): ``set_backend`` / ``set_dtype`` /
+``set_contractor``, ``Circuit``, ``gates``, ``backend``.  Compute happens in hand-written HIP kernels
+behind the C ABI of ``include/tcmi.h``; there is no CPU fallback.
+"""
+
+__version__ = "0.1.0"
+
+from . import cons
+from .cons import (  # noqa: F401
+    set_backend, set_dtype, set_contractor, set_function_backend, set_function_dtype,
+    set_function_contractor, runtime_backend, runtime_dtype, runtime_contractor, get_dtype,
+)
+
+backend = None
+dtypestr = cons.dtypestr
+rdtypestr = cons.rdtypestr
+idtypestr = cons.idtypestr
+npdtype = cons.npdtype
+contractor = None
+
+from . import gates  # noqa: E402,F401
+from . import plan  # noqa: E402,F401
+from .circuit import Circuit  # noqa: E402,F401
+from . import backends  # noqa: E402,F401
+from .backends import get_backend  # noqa: E402,F401
+
+set_backend("hip")
+set_contractor("greedy")

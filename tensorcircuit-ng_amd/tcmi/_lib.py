@@ -1,0 +1,72 @@
+"""ctypes binding of ``libtcmi.so`` (the C ABI declared in ``include/tcmi.h``).
+
+The library is built in-tree by ``tensorcircuit-ng_amd/csrc/Makefile`` (``__graft_entry__.build()``).
+There is no fallback: if the shared object is missing or a call fails, the product raises.
+"""
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libtcmi.so")
+
+TCMI_C64 = 0
+TCMI_C128 = 1
+
+_lib = None
+
+
+class TcmiError(RuntimeError):
+    pass
+
+
+_SIGNATURES = {
+    "tcmi_version": (ctypes.c_int, []),
+    "tcmi_last_error": (ctypes.c_char_p, []),
+    "tcmi_device_count": (ctypes.c_int, []),
+    "tcmi_init_zero_state": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p],
+    ),
+    "tcmi_build_tables": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong,
+         ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_void_p],
+    ),
+    "tcmi_run_pass": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int,
+         ctypes.c_void_p],
+    ),
+}
+
+
+def exported_symbols():
+    """Names every build of libtcmi.so must export (kept in sync with include/tcmi.h)."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises TcmiError if the HIP library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TcmiError(
+                f"HIP extension not built: {LIB_PATH} is missing. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C "
+                "tensorcircuit-ng_amd/csrc`). There is no CPU fallback."
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().tcmi_last_error()
+        raise TcmiError(f"{what} failed ({code}): {msg.decode() if msg else ''}")

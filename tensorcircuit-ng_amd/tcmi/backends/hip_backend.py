@@ -1,0 +1,444 @@
+"""``HipBackend``: the backend object ``tc.set_backend("hip")`` returns.
+
+Mirrors the reference's backend plug-in contract (``tensorcircuit/backends/abstract_backend.py:305-2595``,
+``pytorch_backend.py`` as the closest sibling, ``cupy_backend.py:37-120`` as the from-scratch template):
+PyTorch-ROCm tensors are the array container (device memory, streams, autograd plumbing); circuit
+contraction itself never runs through these methods -- ``Circuit.wavefunction/expectation`` go to
+the HIP plan executor (``tcmi/executor.py``).  Unsupported methods raise ``NotImplementedError``
+with the reference's message format (``abstract_backend.py:2225-2227``).
+"""
+
+from functools import partial
+from typing import Any, Callable, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+Tensor = Any
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self) -> None:
+        self._torch = _torch()
+        self.minor = 0
+
+    # ---- device / dtype helpers ----------------------------------------------------------
+    @property
+    def device(self):
+        torch = self._torch
+        if torch.cuda.is_available():
+            return torch.device("cuda", torch.cuda.current_device())
+        return torch.device("cpu")  # tensor plumbing only; circuits need the GPU
+
+    def _dt(self, dtype):
+        torch = self._torch
+        if dtype is None:
+            from .. import cons
+
+            dtype = cons.dtypestr
+        if isinstance(dtype, str):
+            return getattr(torch, dtype)
+        return dtype
+
+    def _not_impl(self, method):
+        raise NotImplementedError("Backend '{}' has not implemented `{}`.".format(self.name, method))
+
+    # ---- creation / conversion ----------------------------------------------------------------
+    def convert_to_tensor(self, a: Any, dtype: Optional[str] = None) -> Tensor:
+        torch = self._torch
+        if isinstance(a, torch.Tensor):
+            t = a
+        else:
+            t = torch.as_tensor(np.asarray(a) if not isinstance(a, (int, float, complex)) else a)
+        if t.device != self.device and not _is_wrapped(t):
+            t = t.to(self.device)
+        if dtype is not None:
+            t = t.to(self._dt(dtype))
+        return t
+
+    def cast(self, a: Tensor, dtype: str) -> Tensor:
+        torch = self._torch
+        a = self.convert_to_tensor(a)
+        dt = self._dt(dtype)
+        if a.is_complex() and not dt.is_complex:
+            a = a.real
+        return a.to(dt)
+
+    def numpy(self, a: Tensor) -> np.ndarray:
+        torch = self._torch
+        if isinstance(a, torch.Tensor):
+            return a.detach().cpu().resolve_conj().numpy()
+        return np.asarray(a)
+
+    def is_tensor(self, a: Any) -> bool:
+        return isinstance(a, self._torch.Tensor)
+
+    def dtype(self, a: Tensor) -> str:
+        return str(a.dtype).split(".")[-1]
+
+    def i(self, dtype: Optional[str] = None) -> Tensor:
+        return self._torch.tensor(1j, dtype=self._dt(dtype), device=self.device)
+
+    def zeros(self, shape, dtype: Optional[str] = None) -> Tensor:
+        return self._torch.zeros(tuple(shape), dtype=self._dt(dtype), device=self.device)
+
+    def ones(self, shape, dtype: Optional[str] = None) -> Tensor:
+        return self._torch.ones(tuple(shape), dtype=self._dt(dtype), device=self.device)
+
+    def eye(self, N: int, dtype: Optional[str] = None, M: Optional[int] = None) -> Tensor:
+        return self._torch.eye(N, M if M is not None else N, dtype=self._dt(dtype), device=self.device)
+
+    def arange(self, start: int, stop: Optional[int] = None, step: int = 1) -> Tensor:
+        if stop is None:
+            return self._torch.arange(start=0, end=start, step=step, device=self.device)
+        return self._torch.arange(start=start, end=stop, step=step, device=self.device)
+
+    def onehot(self, a: Tensor, num: int) -> Tensor:
+        return self._torch.nn.functional.one_hot(self.convert_to_tensor(a).long(), num)
+
+    one_hot = onehot
+
+    def copy(self, a: Tensor) -> Tensor:
+        return a.clone()
+
+    # ---- shapes -------------------------------------------------------------------------------
+    def shape_tuple(self, a: Tensor) -> Tuple[int, ...]:
+        return tuple(a.shape)
+
+    def shape_tensor(self, a: Tensor) -> Tensor:
+        return self._torch.tensor(tuple(a.shape))
+
+    def sizen(self, a: Tensor) -> int:
+        return int(np.prod(tuple(a.shape))) if len(a.shape) else 1
+
+    size = sizen
+
+    def reshape(self, a: Tensor, shape) -> Tensor:
+        return self.convert_to_tensor(a).reshape(tuple(int(s) for s in shape))
+
+    def reshape2(self, a: Tensor) -> Tensor:
+        """reference abstract_backend.py:773-787."""
+        nleg = int(np.log2(self.sizen(a)))
+        return self.reshape(a, [2] * nleg)
+
+    def reshaped(self, a: Tensor, d: int) -> Tensor:
+        nleg = int(round(np.log(self.sizen(a)) / np.log(d)))
+        return self.reshape(a, [d] * nleg)
+
+    def reshapem(self, a: Tensor) -> Tensor:
+        """reference abstract_backend.py:805-822."""
+        n = int(round(np.sqrt(self.sizen(a))))
+        return self.reshape(a, [n, n])
+
+    def transpose(self, a: Tensor, perm: Optional[Sequence[int]] = None) -> Tensor:
+        if perm is None:
+            perm = tuple(range(a.dim() - 1, -1, -1))
+        return a.permute(*perm)
+
+    def adjoint(self, a: Tensor) -> Tensor:
+        return a.conj().transpose(-1, -2) if a.dim() >= 2 else a.conj()
+
+    def expand_dims(self, a: Tensor, axis: int) -> Tensor:
+        return self._torch.unsqueeze(a, axis)
+
+    def stack(self, a: Sequence[Tensor], axis: int = 0) -> Tensor:
+        return self._torch.stack([self.convert_to_tensor(x) for x in a], dim=axis)
+
+    def concat(self, a: Sequence[Tensor], axis: int = 0) -> Tensor:
+        return self._torch.cat([self.convert_to_tensor(x) for x in a], dim=axis)
+
+    def tile(self, a: Tensor, rep: Tensor) -> Tensor:
+        return self._torch.tile(a, tuple(int(r) for r in rep))
+
+    # ---- math ---------------------------------------------------------------------------------
+    def real(self, a: Tensor) -> Tensor:
+        a = self.convert_to_tensor(a)
+        return a.real if a.is_complex() else a
+
+    def imag(self, a: Tensor) -> Tensor:
+        a = self.convert_to_tensor(a)
+        return a.imag if a.is_complex() else self._torch.zeros_like(a)
+
+    def conj(self, a: Tensor) -> Tensor:
+        return self._torch.conj(a).resolve_conj() if self._torch.is_tensor(a) else np.conj(a)
+
+    def abs(self, a: Tensor) -> Tensor:
+        return self._torch.abs(a)
+
+    def sign(self, a: Tensor) -> Tensor:
+        return self._torch.sign(a)
+
+    def sum(self, a: Tensor, axis=None, keepdims: bool = False) -> Tensor:
+        if axis is None:
+            return self._torch.sum(a)
+        return self._torch.sum(a, dim=axis, keepdim=keepdims)
+
+    def mean(self, a: Tensor, axis=None, keepdims: bool = False) -> Tensor:
+        if axis is None:
+            return self._torch.mean(a)
+        return self._torch.mean(a, dim=axis, keepdim=keepdims)
+
+    def max(self, a: Tensor, axis: Optional[int] = None) -> Tensor:
+        return self._torch.max(a) if axis is None else self._torch.max(a, dim=axis).values
+
+    def min(self, a: Tensor, axis: Optional[int] = None) -> Tensor:
+        return self._torch.min(a) if axis is None else self._torch.min(a, dim=axis).values
+
+    def norm(self, a: Tensor) -> Tensor:
+        return self._torch.linalg.norm(a)
+
+    def multiply(self, a: Tensor, b: Tensor) -> Tensor:
+        return a * b
+
+    def addition(self, a: Tensor, b: Tensor) -> Tensor:
+        return a + b
+
+    def subtraction(self, a: Tensor, b: Tensor) -> Tensor:
+        return a - b
+
+    def divide(self, a: Tensor, b: Tensor) -> Tensor:
+        return a / b
+
+    def sqrt(self, a: Tensor) -> Tensor:
+        return self._torch.sqrt(self.convert_to_tensor(a))
+
+    def sin(self, a: Tensor) -> Tensor:
+        return self._torch.sin(self.convert_to_tensor(a))
+
+    def cos(self, a: Tensor) -> Tensor:
+        return self._torch.cos(self.convert_to_tensor(a))
+
+    def tan(self, a: Tensor) -> Tensor:
+        return self._torch.tan(self.convert_to_tensor(a))
+
+    def exp(self, a: Tensor) -> Tensor:
+        return self._torch.exp(self.convert_to_tensor(a))
+
+    def log(self, a: Tensor) -> Tensor:
+        return self._torch.log(self.convert_to_tensor(a))
+
+    def expm(self, a: Tensor) -> Tensor:
+        return self._torch.linalg.matrix_exp(a)
+
+    def kron(self, a: Tensor, b: Tensor) -> Tensor:
+        return self._torch.kron(a, b)
+
+    def matmul(self, a: Tensor, b: Tensor) -> Tensor:
+        return self._torch.matmul(a, b)
+
+    def tensordot(self, a: Tensor, b: Tensor, axes) -> Tensor:
+        return self._torch.tensordot(a, b, dims=axes)
+
+    def outer_product(self, a: Tensor, b: Tensor) -> Tensor:
+        return self._torch.tensordot(a, b, dims=0)
+
+    def einsum(self, expression: str, *tensors: Tensor, optimize: bool = True) -> Tensor:
+        return self._torch.einsum(expression, *tensors)
+
+    def trace(self, a: Tensor) -> Tensor:
+        return self._torch.trace(a)
+
+    def diagflat(self, a: Tensor, k: int = 0) -> Tensor:
+        return self._torch.diag_embed(a.reshape(-1), offset=k)
+
+    def svd(self, a: Tensor, **kws: Any):
+        u, s, vh = self._torch.linalg.svd(a, full_matrices=False)
+        return u, s, vh, s[:0]
+
+    def qr(self, a: Tensor, **kws: Any):
+        return self._torch.linalg.qr(a)
+
+    def eigh(self, a: Tensor):
+        return self._torch.linalg.eigh(a)
+
+    def where(self, condition: Tensor, x: Tensor, y: Tensor) -> Tensor:
+        return self._torch.where(condition, x, y)
+
+    def argmax(self, a: Tensor, axis: int = 0) -> Tensor:
+        return self._torch.argmax(a, dim=axis)
+
+    def argmin(self, a: Tensor, axis: int = 0) -> Tensor:
+        return self._torch.argmin(a, dim=axis)
+
+    def cumsum(self, a: Tensor, axis: Optional[int] = None) -> Tensor:
+        if axis is None:
+            a, axis = a.reshape(-1), 0
+        return self._torch.cumsum(a, dim=axis)
+
+    def scatter(self, operand: Tensor, indices: Tensor, updates: Tensor) -> Tensor:
+        operand = operand.clone()
+        operand[tuple(indices.long().t())] = updates
+        return operand
+
+    def stop_gradient(self, a: Tensor) -> Tensor:
+        return a.detach()
+
+    # ---- random -------------------------------------------------------------------------------
+    def set_random_state(self, seed: Optional[int] = None, get_only: bool = False) -> Any:
+        g = self._torch.Generator(device=self.device)
+        if seed is not None:
+            g.manual_seed(seed)
+        if not get_only:
+            self._generator = g
+        return g
+
+    def _gen(self):
+        if not hasattr(self, "_generator"):
+            self.set_random_state()
+        return self._generator
+
+    def implicit_randn(self, shape=1, mean: float = 0, stddev: float = 1, dtype: str = "32") -> Tensor:
+        if isinstance(shape, int):
+            shape = (shape,)
+        dt = self._dt("float" + dtype if dtype in ("32", "64") else dtype)
+        return self._torch.randn(tuple(shape), generator=self._gen(), device=self.device, dtype=dt) * stddev + mean
+
+    def implicit_randu(self, shape=1, low: float = 0, high: float = 1, dtype: str = "32") -> Tensor:
+        if isinstance(shape, int):
+            shape = (shape,)
+        dt = self._dt("float" + dtype if dtype in ("32", "64") else dtype)
+        return self._torch.rand(tuple(shape), generator=self._gen(), device=self.device, dtype=dt) * (high - low) + low
+
+    # ---- pytree utils (reference abstract_backend.py:19-300) -------------------------------
+    def tree_map(self, f: Callable[..., Any], *pytrees: Any) -> Any:
+        t0 = pytrees[0]
+        if isinstance(t0, (list, tuple)):
+            out = [self.tree_map(f, *[p[k] for p in pytrees]) for k in range(len(t0))]
+            return type(t0)(out) if not hasattr(t0, "_fields") else type(t0)(*out)
+        if isinstance(t0, dict):
+            return {k: self.tree_map(f, *[p[k] for p in pytrees]) for k in t0}
+        if t0 is None:
+            return None
+        return f(*pytrees)
+
+    def tree_flatten(self, pytree: Any):
+        leaves = []
+
+        def rec(t):
+            if isinstance(t, (list, tuple)):
+                return ("seq", type(t), [rec(x) for x in t])
+            if isinstance(t, dict):
+                return ("dict", None, {k: rec(v) for k, v in t.items()})
+            leaves.append(t)
+            return ("leaf", None, None)
+
+        return leaves, rec(pytree)
+
+    # ---- function transforms -----------------------------------------------------------------
+    def jit(self, f: Callable[..., Any], static_argnums=None, jit_compile=None, **kws: Any) -> Any:
+        """Plans are compiled and cached per circuit structure by the executor; there is nothing to
+        trace (reference pytorch_backend.py:830-842 also returns ``f``)."""
+        return f
+
+    def value_and_grad(self, f: Callable[..., Any], argnums: Union[int, Sequence[int]] = 0,
+                       has_aux: bool = False) -> Callable[..., Tuple[Any, Any]]:
+        """reference abstract_backend.py:2262-2293 / pytorch_backend.py:775-786."""
+        torch = self._torch
+
+        def wrapper(*args: Any, **kws: Any) -> Any:
+            args = tuple(
+                self.convert_to_tensor(a) if (i in _as_tuple(argnums)) else a for i, a in enumerate(args)
+            )
+            g, v = torch.func.grad_and_value(f, argnums=argnums, has_aux=has_aux)(*args, **kws)
+            return v, g
+
+        return wrapper
+
+    def grad(self, f: Callable[..., Any], argnums: Union[int, Sequence[int]] = 0,
+             has_aux: bool = False) -> Callable[..., Any]:
+        def wrapper(*args: Any, **kws: Any) -> Any:
+            y, gr = self.value_and_grad(f, argnums, has_aux)(*args, **kws)
+            if has_aux:
+                return gr, y[1:]
+            return gr
+
+        return wrapper
+
+    def vmap(self, f: Callable[..., Any], vectorized_argnums: Union[int, Sequence[int]] = 0) -> Any:
+        """reference abstract_backend.py:2520-2539 / pytorch_backend.py:816-828."""
+        torch = self._torch
+        vectorized_argnums = _as_tuple(vectorized_argnums)
+
+        def wrapper(*args: Any, **kws: Any) -> Tensor:
+            in_axes = tuple(0 if i in vectorized_argnums else None for i in range(len(args)))
+            return torch.vmap(f, in_axes, 0)(*args, **kws)
+
+        return wrapper
+
+    def vectorized_value_and_grad(self, f: Callable[..., Any], argnums: Union[int, Sequence[int]] = 0,
+                                  vectorized_argnums: Union[int, Sequence[int]] = 0,
+                                  has_aux: bool = False) -> Callable[..., Tuple[Any, Any]]:
+        """reference abstract_backend.py:2541-2591: grads of non-vectorised args are summed over the
+        batch (jax_backend.py:945-947)."""
+        torch = self._torch
+        vectorized_argnums = _as_tuple(vectorized_argnums)
+
+        def wrapper(*args: Any, **kws: Any):
+            jf = self.value_and_grad(f, argnums=argnums, has_aux=has_aux)
+            jf = self.vmap(jf, vectorized_argnums=vectorized_argnums)
+            vs, gs = jf(*args, **kws)
+            if isinstance(argnums, int):
+                argnums_list, gs_l = [argnums], [gs]
+            else:
+                argnums_list, gs_l = list(argnums), list(gs)
+            for i, (j, g) in enumerate(zip(argnums_list, gs_l)):
+                if j not in vectorized_argnums:
+                    gs_l[i] = self.tree_map(partial(torch.sum, dim=0), g)
+            gs = gs_l[0] if isinstance(argnums, int) else tuple(gs_l)
+            return vs, gs
+
+        return wrapper
+
+    vvag = vectorized_value_and_grad
+
+    # ---- executor glue ------------------------------------------------------------------------
+    def _stack_params(self, values) -> Tensor:
+        """Recorded gate angles (python numbers / 0-d tensors) -> one real parameter vector."""
+        torch = self._torch
+        from .. import cons
+
+        rdt = self._dt(cons.rdtypestr)
+        if all(not isinstance(v, torch.Tensor) for v in values):
+            return torch.tensor([float(np.real(v)) for v in values], dtype=rdt, device=self.device)
+        out = []
+        for v in values:
+            if not isinstance(v, torch.Tensor):
+                v = torch.tensor(float(np.real(v)), dtype=rdt, device=self.device)
+            else:
+                if v.is_complex():
+                    v = v.real
+                v = v.to(rdt).reshape(())
+                if v.device != self.device and not _is_wrapped(v):
+                    v = v.to(self.device)
+            out.append(v)
+        return torch.stack(out)
+
+    def __getattr__(self, name: str) -> Any:
+        if name.startswith("_"):
+            raise AttributeError(name)
+
+        def missing(*a: Any, **k: Any) -> Any:
+            self._not_impl(name)
+
+        return missing
+
+
+def _as_tuple(x):
+    return (x,) if isinstance(x, int) else tuple(x)
+
+
+def _is_wrapped(t) -> bool:
+    """True for functorch-wrapped tensors (inside torch.func transforms)."""
+    import torch
+
+    try:
+        return torch._C._functorch.is_functorch_wrapped_tensor(t)
+    except Exception:
+        return False

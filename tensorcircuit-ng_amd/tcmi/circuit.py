@@ -1,0 +1,362 @@
+"""``Circuit`` for the hip backend: the reference ``tc.Circuit`` surface of the state-vector /
+expectation hot path (reference ``tensorcircuit/circuit.py:44-131, 701-721, 833-913``,
+``tensorcircuit/basecircuit.py:183-371, 393-447, 562-624``,
+``tensorcircuit/abstractcircuit.py:114-373, 1523-1603``).
+
+Design difference (MI355X-first): the reference appends a ``tn.Node`` per gate and
+contracts the network with a path found at call time.  Here a gate call only *records* the gate;
+``wavefunction`` / ``expectation`` lower the recorded structure once to a cached tile-VM plan
+(``tcmi/plan.py``) and launch it through the C ABI with the current parameter values.  Conventions
+(qubit 0 = most significant bit, gate axes ``[out.., in..]``, negative indices, error messages)
+follow the reference.
+"""
+
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import cons
+from . import gates as G
+from . import plan as P
+
+Tensor = Any
+
+sgates = (
+    ["i", "x", "y", "z", "h", "t", "s", "td", "sd", "wroot"]
+    + ["cnot", "cz", "swap", "cy", "ox", "oy", "oz"]
+    + ["toffoli", "fredkin"]
+)
+vgates = [
+    "r", "cr", "u", "cu", "rx", "ry", "rz", "phase", "rxx", "ryy", "rzz", "cphase", "crx", "cry",
+    "crz", "orx", "ory", "orz", "iswap", "any", "exp", "exp1", "su4",
+]
+gate_aliases = [
+    ["cnot", "cx"], ["fredkin", "cswap"], ["toffoli", "ccnot"], ["toffoli", "ccx"],
+    ["any", "unitary"], ["sd", "sdg"], ["td", "tdg"],
+]
+
+_SGATE_MATRICES = dict(G._CONST_GATES)
+_SGATE_MATRICES["ox"] = G._kron(G._i00, G._x_matrix) + G._kron(G._i11, G._i_matrix)
+_SGATE_MATRICES["oy"] = G._kron(G._i00, G._y_matrix) + G._kron(G._i11, G._i_matrix)
+_SGATE_MATRICES["oz"] = G._kron(G._i00, G._z_matrix) + G._kron(G._i11, G._i_matrix)
+
+
+def _is_tensor(v):
+    return not G.is_concrete(v)
+
+
+class _Op:
+    __slots__ = ("qubits", "matrix", "spec", "pidx", "name")
+
+    def __init__(self, qubits, matrix=None, spec=None, pidx=None, name=""):
+        self.qubits = qubits
+        self.matrix = matrix
+        self.spec = spec
+        self.pidx = pidx
+        self.name = name
+
+
+class Circuit:
+    """``Circuit`` class: state-vector simulator front end of the hip backend."""
+
+    is_dm = False
+    is_mps = False
+    sgates = sgates
+    vgates = vgates
+    gate_aliases = gate_aliases
+
+    def __init__(self, nqubits: int, inputs: Optional[Tensor] = None,
+                 mps_inputs: Optional[Any] = None, split: Optional[Dict[str, Any]] = None,
+                 dim: Optional[int] = None):
+        if dim not in (None, 2):
+            raise NotImplementedError("the hip backend supports qubits (dim=2) only")
+        if mps_inputs is not None:
+            raise NotImplementedError("mps_inputs is not supported on the hip backend")
+        self._nqubits = int(nqubits)
+        self._d = 2
+        self.inputs = inputs
+        self.split = split
+        self._ops: List[_Op] = []
+        self._params: List[Any] = []
+        self._qir: List[Dict[str, Any]] = []
+        self.state_tensor = None
+        self.circuit_param = {"nqubits": nqubits, "inputs": inputs, "mps_inputs": None, "split": split}
+
+    # ---- recording (reference basecircuit.py:183-371) ---------------------------------------
+    def _norm_index(self, index: Sequence[int]) -> Tuple[int, ...]:
+        if len(index) != len(set(index)):
+            raise ValueError(
+                f"gate index {list(index)} has duplicate qubits; "
+                "each qubit may appear at most once"
+            )
+        out = tuple(int(i) if i >= 0 else self._nqubits + int(i) for i in index)
+        for q in out:
+            if not 0 <= q < self._nqubits:
+                raise ValueError(f"qubit index {q} out of range for {self._nqubits} qubits")
+        return out
+
+    def _record_const(self, matrix, index, name):
+        index = self._norm_index(index)
+        m = np.asarray(matrix, dtype=np.complex128)
+        d = 2 ** len(index)
+        if m.size != d * d:
+            raise ValueError(f"gate tensor of size {m.size} does not act on {len(index)} qubits")
+        self._ops.append(_Op(index, matrix=m.reshape(d, d), name=name))
+        self._qir.append({"gate": None, "index": index, "name": name, "parameters": {}})
+        self.state_tensor = None
+
+    def _record_specs(self, specs, index, name, parameters):
+        index = self._norm_index(index)
+        for s in specs:
+            # concrete angles are parameters too: the cached plan is keyed by structure only, so a
+            # python-float VQE loop re-uses one plan instead of recompiling per value
+            self._params.append(s.theta)
+            self._ops.append(_Op(index, spec=s, pidx=len(self._params) - 1, name=name))
+        self._qir.append({"gate": None, "index": index, "name": name, "parameters": parameters})
+        self.state_tensor = None
+
+    def apply_general_gate(self, gate, *index: int, name: Optional[str] = None, **kws: Any) -> None:
+        """Apply an arbitrary gate given as ``Gate`` / matrix / tensor (reference
+        basecircuit.py:183-371; mpo / diagonal / split forms are outside the hot path)."""
+        if kws.get("mpo") or kws.get("diagonal"):
+            raise NotImplementedError("mpo / diagonal gate formats are not supported on the hip backend")
+        t = gate.tensor if isinstance(gate, G.Gate) else gate
+        if _is_tensor(t) and not isinstance(t, np.ndarray):
+            t = cons.backend.numpy(t)
+        self._record_const(t, index, name or "")
+
+    apply = apply_general_gate
+
+    @staticmethod
+    def _bcast(index):
+        """Gate methods accept ints or equal-length lists (reference abstractcircuit.py:161-183)."""
+        lists = [i for i in index if isinstance(i, (list, tuple, range))]
+        if not lists:
+            return [tuple(index)]
+        ln = len(lists[0])
+        out = []
+        for k in range(ln):
+            out.append(tuple(i[k] if isinstance(i, (list, tuple, range)) else i for i in index))
+        return out
+
+    # ---- variable gates ------------------------------------------------------------------------
+    def _vgate(self, name, index, kw):
+        get = lambda k, default=0.0: kw.get(k, default)
+        if name == "rx":
+            specs = G.rx_spec(get("theta"))
+        elif name == "ry":
+            specs = G.ry_spec(get("theta"))
+        elif name == "rz":
+            specs = G.rz_spec(get("theta"))
+        elif name == "phase":
+            specs = G.phase_spec(get("theta"))
+        elif name == "cphase":
+            specs = G.cphase_spec(get("theta"))
+        elif name in ("crx", "cry", "crz"):
+            specs = G.controlled_rot_spec(G._pauli["xyz".index(name[2]) + 1], get("theta"), name)
+        elif name in ("orx", "ory", "orz"):
+            p = G._pauli["xyz".index(name[2]) + 1]
+            specs = [G.TrigSpec(G._kron(G._i11, G._i_matrix), G._kron(G._i00, G._i_matrix),
+                                -1j * G._kron(G._i00, p), get("theta"), 0.5, name=name)]
+        elif name == "rzz":
+            specs = G.exp1_spec(G._zz_matrix, get("theta"), half=True, name="rzz")
+        elif name == "rxx":
+            specs = G.exp1_spec(G._xx_matrix, get("theta"), half=True, name="rxx")
+        elif name == "ryy":
+            specs = G.exp1_spec(G._yy_matrix, get("theta"), half=True, name="ryy")
+        elif name == "iswap":
+            specs = G.iswap_spec(get("theta", 1.0))
+        elif name == "r":
+            specs = G.r_spec(get("theta"), get("alpha"), get("phi"))
+        elif name == "cr":
+            specs = G.cr_spec(get("theta"), get("alpha"), get("phi"))
+        elif name == "u":
+            specs = G.u_spec(get("theta"), get("phi"), get("lbd"))
+        elif name == "exp1":
+            unitary = kw.get("unitary", kw.get("hermitian", kw.get("hamiltonian")))
+            specs = G.exp1_spec(self._np(unitary), get("theta"), half=bool(kw.get("half", False)))
+        elif name == "exp":
+            unitary = self._np(kw.get("unitary", kw.get("hermitian", kw.get("hamiltonian"))))
+            theta = get("theta")
+            d = int(round(np.sqrt(unitary.size)))
+            u2 = unitary.reshape(d, d)
+            if G.is_concrete(theta):
+                return self._record_const(G.matrix_for_gate(G.exponential_gate(u2, theta)), index, "exp")
+            if np.abs(u2 @ u2 - np.eye(d)).max() < 1e-12:
+                specs = G.exp1_spec(u2, theta, name="exp")
+            else:
+                raise NotImplementedError(
+                    "exp gate with a tensor-valued theta needs unitary^2 = I on the hip backend"
+                )
+        elif name == "any":
+            unitary = kw.get("unitary")
+            return self.apply_general_gate(unitary, *index, name=kw.get("name", "any"))
+        elif name == "su4":
+            theta = kw.get("theta")
+            if _is_tensor(theta) and not isinstance(theta, np.ndarray):
+                theta = cons.backend.numpy(theta)
+            return self._record_const(G.matrix_for_gate(G.su4_gate(theta)), index, "su4")
+        elif name == "cu":
+            vals = [get("theta"), get("phi"), get("lbd")]
+            if not all(G.is_concrete(v) for v in vals):
+                raise NotImplementedError("cu gate with tensor parameters is not supported on the hip backend")
+            u = G._concrete(G.u_spec(*vals))
+            return self._record_const(G._kron(G._i00, G._i_matrix) + G._kron(G._i11, u), index, "cu")
+        else:
+            raise NotImplementedError(f"gate {name}")
+        self._record_specs(specs, index, name, dict(kw))
+
+    @staticmethod
+    def _np(t):
+        if isinstance(t, G.Gate):
+            t = t.tensor
+        if isinstance(t, np.ndarray) or G.is_concrete(t):
+            return np.asarray(t, dtype=np.complex128)
+        return np.asarray(cons.backend.numpy(t), dtype=np.complex128)
+
+    # ---- lowering -----------------------------------------------------------------------------
+    def _gate_records(self) -> List[P.GateRec]:
+        recs = []
+        for op in self._ops:
+            if op.matrix is not None:
+                recs.append(P.GateRec(op.qubits, c0=op.matrix, name=op.name,
+                                      diag=P.diag_terms_const(op.matrix, op.qubits)))
+            else:
+                s = op.spec
+                pr = P.ParamRef(op.pidx, s.scale, s.offset)
+                recs.append(P.GateRec(op.qubits, c0=s.c0, c1=s.c1, c2=s.c2, param=pr, name=op.name,
+                                      diag=P.diag_terms_trig(s.c0, s.c1, s.c2, op.qubits, pr)))
+        return recs
+
+    def _compiled(self):
+        from .executor import get_compiled
+
+        return get_compiled(self._nqubits, self._gate_records(), len(self._params), cons.dtypestr,
+                            cons._plan_options)
+
+    def _param_tensor(self):
+        if not self._params:
+            return None
+        return cons.backend._stack_params(self._params)
+
+    # ---- outputs ------------------------------------------------------------------------------
+    def wavefunction(self, form: str = "default") -> Tensor:
+        """reference circuit.py:701-721."""
+        from .functional import circuit_state
+
+        cc = self._compiled()
+        psi = circuit_state(cc, self._param_tensor(), self._input_tensor())
+        if form == "ket":
+            psi = psi.reshape(-1, 1)
+        elif form == "bra":
+            psi = psi.reshape(1, -1)
+        return psi
+
+    state = wavefunction
+
+    def _input_tensor(self):
+        if self.inputs is None:
+            return None
+        return cons.backend.cast(cons.backend.convert_to_tensor(self.inputs), cons.dtypestr).reshape(-1)
+
+    def amplitude(self, l) -> Tensor:
+        """reference basecircuit.py:562-624: <l|psi>."""
+        if isinstance(l, str):
+            bits = [int(ch) for ch in l]
+        else:
+            bits = [int(round(float(b))) for b in cons.backend.numpy(cons.backend.convert_to_tensor(l)).reshape(-1)]
+        if len(bits) != self._nqubits:
+            raise ValueError("bitstring length does not match the number of qubits")
+        idx = 0
+        for b in bits:
+            idx = (idx << 1) | b
+        return self.wavefunction()[..., idx]
+
+    def expectation(self, *ops: Tuple[Any, List[int]], reuse: bool = True, **kws: Any) -> Tensor:
+        """reference circuit.py:833-913 (noise-free branch): complex scalar <psi| prod ops |psi>."""
+        from .functional import circuit_expectation
+
+        nq = self._nqubits
+        occupied = set()
+        norm_ops = []
+        for op, index in ops:
+            if isinstance(index, int):
+                index = [index]
+            index = tuple(i if i >= 0 else nq + i for i in index)
+            for e in index:
+                if e in occupied:
+                    raise ValueError(
+                        f"Cannot measure two operators in one index: qubit {e} "
+                        f"is already occupied by a previous operator in this "
+                        f"measurement, index={index}"
+                    )
+                occupied.add(e)
+            m = self._np(op)
+            d = 2 ** len(index)
+            norm_ops.append((m.reshape(d, d), index))
+        return circuit_expectation(self, norm_ops)
+
+    def expectation_ps(self, x=None, y=None, z=None, ps=None, reuse: bool = True, **kws) -> Tensor:
+        """reference abstractcircuit.py:1523-1603."""
+        ops = []
+        if ps is not None:
+            x, y, z = [], [], []
+            for i, p in enumerate(ps):
+                if int(p) == 1:
+                    x.append(i)
+                elif int(p) == 2:
+                    y.append(i)
+                elif int(p) == 3:
+                    z.append(i)
+        for lst, m in ((x, G._x_matrix), (y, G._y_matrix), (z, G._z_matrix)):
+            if lst is not None:
+                for i in lst:
+                    ops.append((m, [i]))
+        return self.expectation(*ops, reuse=reuse, **kws)
+
+    def to_qir(self):
+        return self._qir
+
+    def gate_count(self):
+        return len(self._ops)
+
+
+def _make_sgate(name):
+    def f(self, *index, **kw):
+        for idx in Circuit._bcast(index):
+            self._record_const(_SGATE_MATRICES[name], idx, name)
+
+    f.__name__ = name
+    f.__doc__ = f"Apply the constant gate ``{name}`` (reference abstractcircuit.py:242-293)."
+    return f
+
+
+def _make_vgate(name):
+    def f(self, *index, **kw):
+        idxs = Circuit._bcast(index)
+        if len(idxs) == 1:
+            self._vgate(name, idxs[0], kw)
+        else:
+            for k, idx in enumerate(idxs):
+                kk = {key: (v[k] if isinstance(v, (list, tuple)) else v) for key, v in kw.items()}
+                self._vgate(name, idx, kk)
+
+    f.__name__ = name
+    f.__doc__ = f"Apply the parametrised gate ``{name}`` (reference abstractcircuit.py:295-373)."
+    return f
+
+
+def _install_gate_methods():
+    for n in sgates:
+        if n in _SGATE_MATRICES:
+            setattr(Circuit, n, _make_sgate(n))
+            setattr(Circuit, n.upper(), _make_sgate(n))
+    for n in vgates:
+        setattr(Circuit, n, _make_vgate(n))
+        setattr(Circuit, n.upper(), _make_vgate(n))
+    for present, alias in gate_aliases:
+        setattr(Circuit, alias, getattr(Circuit, present))
+        setattr(Circuit, alias.upper(), getattr(Circuit, present))
+
+
+_install_gate_methods()

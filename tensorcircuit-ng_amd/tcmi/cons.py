@@ -1,0 +1,197 @@
+"""Process-global runtime configuration, mirroring the reference ``tensorcircuit/cons.py``:
+``set_backend`` (``:90-135``), ``set_dtype`` (``:185-239``), ``set_contractor`` (``:1123-1261``) and
+their function-decorator / context-manager variants (``:143-182, 247-284, 1269-1314``).
+
+As in the reference, the setters broadcast the new value into every already-imported module of the
+package (reference ``cons.py:84-87,131-134,229-234``), so ``tcmi.backend`` / ``tcmi.dtypestr`` follow.
+"""
+
+import sys
+from contextlib import contextmanager
+from functools import wraps
+from typing import Any, Callable, Dict, Iterator, Optional
+
+import numpy as np
+
+package_name = "tcmi"
+thismodule = sys.modules[__name__]
+
+dtypestr = "complex64"
+rdtypestr = "float32"
+idtypestr = "int32"
+npdtype = np.complex64
+backend: Any = None
+contractor: Any = None
+_contractor_name = "greedy"
+_plan_options: Dict[str, Any] = {}
+
+
+def _broadcast(name: str, value: Any) -> None:
+    for modname, mod in list(sys.modules.items()):
+        if mod is not None and (modname == package_name or modname.startswith(package_name + ".")):
+            if hasattr(mod, name):
+                setattr(mod, name, value)
+    setattr(thismodule, name, value)
+
+
+def set_backend(backend_name: Optional[str] = None, set_global: bool = True) -> Any:
+    """reference cons.py:90-135.  The only registered backend is ``"hip"``."""
+    from .backends import get_backend
+
+    if backend_name is None:
+        backend_name = "hip"
+    b = get_backend(backend_name)
+    if set_global:
+        _broadcast("backend", b)
+    return b
+
+
+set_tensornetwork_backend = set_backend
+
+
+def set_dtype(dtype: Optional[str] = None, set_global: bool = True):
+    """reference cons.py:185-239: complex64/complex128 (or the matching float names)."""
+    if not dtype:
+        dtype = "complex64"
+    if dtype == "complex64" or dtype == "float32":
+        c, r, i = "complex64", "float32", "int32"
+    elif dtype == "complex128" or dtype == "float64":
+        c, r, i = "complex128", "float64", "int64"
+    else:
+        raise ValueError(f"Unsupported data type: {dtype}")
+    if set_global:
+        _broadcast("dtypestr", c)
+        _broadcast("rdtypestr", r)
+        _broadcast("idtypestr", i)
+        _broadcast("npdtype", getattr(np, c))
+    return c, r
+
+
+get_dtype = lambda: (dtypestr, rdtypestr)
+
+_KNOWN_CONTRACTORS = (
+    "auto", "greedy", "branch", "optimal", "plain", "plain-experimental", "tng", "custom",
+    "custom_stateful", "tilevm",
+)
+
+
+def set_contractor(method: Optional[str] = None, optimizer: Any = None, memory_limit: Any = None,
+                   opt_conf: Any = None, set_global: bool = True, contraction_info: bool = False,
+                   debug_level: int = 0, **kws: Any) -> Callable[..., Any]:
+    """reference cons.py:1123-1261.
+
+    On the hip backend a state-vector contraction always executes as a compiled tile-VM plan
+    (state-vector order with cache/register blocking, see ``tcmi/plan.py``); the result is
+    path-independent up to rounding, so the reference's path-finder names are accepted for API
+    compatibility and select that executor.  Plan tuning knobs may be passed as keywords:
+    ``lowbits`` (coalescing run, default 5), ``R`` / ``LT`` (register / thread bits).
+    ``cotengra-*`` / ``omeco-*`` strings are accepted likewise (reference cons.py:1166-1219)."""
+    if not method:
+        method = "greedy"
+    base = method.split("-")[0]
+    if method not in _KNOWN_CONTRACTORS and base not in ("cotengra", "omeco"):
+        raise ValueError("Unknown contractor type: %s" % method)
+    opts = {k: v for k, v in kws.items() if k in ("lowbits", "R", "LT")}
+    opts["debug_level"] = debug_level
+    opts["contraction_info"] = contraction_info
+
+    def cf(*args: Any, **kwargs: Any) -> Any:
+        raise NotImplementedError(
+            "the hip backend contracts whole circuits through its plan executor; a node-list "
+            "contractor call is only available on the reference's CPU backends"
+        )
+
+    cf.method = method  # type: ignore
+    cf.plan_options = opts  # type: ignore
+    if set_global:
+        _broadcast("contractor", cf)
+        _broadcast("_contractor_name", method)
+        _broadcast("_plan_options", opts)
+    return cf
+
+
+def set_function_backend(backend_name: Optional[str] = None) -> Callable[..., Any]:
+    """reference cons.py:143-166."""
+
+    def wrapper(f: Callable[..., Any]) -> Callable[..., Any]:
+        @wraps(f)
+        def newf(*args: Any, **kws: Any) -> Any:
+            old = backend.name if backend is not None else None
+            set_backend(backend_name)
+            try:
+                return f(*args, **kws)
+            finally:
+                set_backend(old)
+
+        return newf
+
+    return wrapper
+
+
+@contextmanager
+def runtime_backend(backend_name: Optional[str] = None) -> Iterator[Any]:
+    """reference cons.py:169-182."""
+    old = backend.name if backend is not None else None
+    K = set_backend(backend_name)
+    try:
+        yield K
+    finally:
+        set_backend(old)
+
+
+def set_function_dtype(dtype: Optional[str] = None) -> Callable[..., Any]:
+    """reference cons.py:247-268."""
+
+    def wrapper(f: Callable[..., Any]) -> Callable[..., Any]:
+        @wraps(f)
+        def newf(*args: Any, **kws: Any) -> Any:
+            old = dtypestr
+            set_dtype(dtype)
+            try:
+                return f(*args, **kws)
+            finally:
+                set_dtype(old)
+
+        return newf
+
+    return wrapper
+
+
+@contextmanager
+def runtime_dtype(dtype: Optional[str] = None) -> Iterator[Any]:
+    """reference cons.py:271-284."""
+    old = dtypestr
+    r = set_dtype(dtype)
+    try:
+        yield r
+    finally:
+        set_dtype(old)
+
+
+def set_function_contractor(*confargs: Any, **confkws: Any) -> Callable[..., Any]:
+    """reference cons.py:1269-1294."""
+
+    def wrapper(f: Callable[..., Any]) -> Callable[..., Any]:
+        @wraps(f)
+        def newf(*args: Any, **kws: Any) -> Any:
+            old_name, old_opts = _contractor_name, dict(_plan_options)
+            set_contractor(*confargs, **confkws)
+            try:
+                return f(*args, **kws)
+            finally:
+                set_contractor(old_name, **{k: v for k, v in old_opts.items() if k in ("lowbits", "R", "LT")})
+
+        return newf
+
+    return wrapper
+
+
+@contextmanager
+def runtime_contractor(*confargs: Any, **confkws: Any) -> Iterator[Any]:
+    """reference cons.py:1297-1314."""
+    old_name, old_opts = _contractor_name, dict(_plan_options)
+    r = set_contractor(*confargs, **confkws)
+    try:
+        yield r
+    finally:
+        set_contractor(old_name, **{k: v for k, v in old_opts.items() if k in ("lowbits", "R", "LT")})

@@ -1,0 +1,580 @@
+"""Plan compiler: gate list -> tile-VM pass programs for the HIP executor.
+
+This replaces, for the state-vector hot path, what the reference does on every call in
+Python: ``tn.copy`` of the network, ``_merge_single_gates``, the opt_einsum greedy search and
+the ``contract_between`` loop (reference ``tensorcircuit/cons.py:298-374, 773-800, 845-961``;
+``tensorcircuit/circuit.py:701-721``).  The result of those pairwise contractions for a circuit
+acting on |0..0> is the state vector, so the plan executes it as a *state-vector-order* chain
+(reference ``plain_contractor`` semantics, ``cons.py:429-463``) with two MI355X-specific
+transformations:
+
+* cache blocking: one HBM round trip (a "pass") loads a tile of 2^T amplitudes per workgroup
+  (T tile bits = the low ``lowbits`` physical bits for coalescing + arbitrary others) and
+  applies *every* gate that is executable on those qubits before writing the tile back;
+* register blocking: inside a pass the tile lives in registers (2^R amplitudes per thread);
+  gates act on "register bits" only, and an LDS exchange re-maps which tile bits are register
+  bits between "rounds".  Diagonal gates (rz / phase / cz / exp1(ZZ) ...) never need their qubits
+  local: they are phase polynomials evaluated from the global index.
+
+Index conventions: qubit q <-> physical bit p = n-1-q of the flat state index (qubit 0 is the
+most significant bit, reference ``tests/test_circuit.py:47-53``).
+
+The descriptor layout written by :func:`encode_pass` is the C-ABI contract of
+``tcmi_run_pass`` (``include/tcmi.h``); ``oracle/plan_emulator.py`` re-implements it in numpy for
+the CPU test-suite.
+"""
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+# ---- descriptor constants (mirrored in csrc/tcmi_vm.h) ---------------------------------
+MAGIC = 0x54434D31  # "TCM1"
+HDR_WORDS = 24
+RR_WORDS = 50
+R_MAX = 6
+LT_MAX = 10
+T_MAX = 16
+OP_G1 = 1
+OP_G2 = 2
+OP_DIAG = 3
+CONST_FLAG = 1 << 30
+
+# builder kinds
+BK_TRIG = 1  # M = C0 + cos(k*theta + off) C1 + sin(k*theta + off) C2
+BK_COEF = 2  # phase coefficient in turns = k*theta + off
+
+
+@dataclass
+class ParamRef:
+    """Angle = scale * params[index] + offset (params = flat per-batch parameter vector)."""
+
+    index: int
+    scale: float = 1.0
+    offset: float = 0.0
+
+
+@dataclass
+class DiagTerm:
+    """phase += coef * (-1)^{parity(bits of the listed qubits)} ; coef in radians.
+    coef = const + (scale * params[index]) if param is not None."""
+
+    qubits: Tuple[int, ...]
+    const: float = 0.0
+    param: Optional[ParamRef] = None
+
+
+@dataclass
+class GateRec:
+    """One gate of the recorded circuit.
+
+    Dense form: ``M = c0 + cos(a) c1 + sin(a) c2`` with ``a = param.scale*theta + param.offset``
+    (``param is None`` -> constant gate ``c0``).  Matrices are ``U[out, in]`` over ``qubits`` in
+    the listed order.  ``diag`` (list of DiagTerm) is set iff the gate is a unit-modulus diagonal.
+    """
+
+    qubits: Tuple[int, ...]
+    c0: Optional[np.ndarray] = None
+    c1: Optional[np.ndarray] = None
+    c2: Optional[np.ndarray] = None
+    param: Optional[ParamRef] = None
+    diag: Optional[List[DiagTerm]] = None
+    name: str = ""
+
+    @property
+    def is_diag(self):
+        return self.diag is not None
+
+    def matrix(self, params=None):
+        m = np.array(self.c0, dtype=np.complex128)
+        if self.param is not None:
+            a = self.param.scale * float(params[self.param.index]) + self.param.offset
+            m = m + np.cos(a) * self.c1 + np.sin(a) * self.c2
+        return m
+
+
+# ---- diagonal analysis -----------------------------------------------------------------
+def walsh_terms(phases: np.ndarray, qubits: Sequence[int]):
+    """phases[x] (x = bits of ``qubits`` in listed order, first = MSB) -> list of
+    (qubit subset, coefficient) with phase(x) = sum coef * (-1)^{parity(x & subset)}."""
+    k = len(qubits)
+    out = []
+    for s in range(2**k):
+        c = 0.0
+        for x in range(2**k):
+            c += phases[x] * (-1) ** bin(x & s).count("1")
+        c /= 2**k
+        if abs(c) > 1e-15:
+            sub = tuple(qubits[i] for i in range(k) if (s >> (k - 1 - i)) & 1)
+            out.append((sub, c))
+    return out
+
+
+def diag_terms_const(matrix: np.ndarray, qubits: Sequence[int], tol=1e-12):
+    """Unit-modulus diagonal constant matrix -> DiagTerm list, else None."""
+    m = np.asarray(matrix, dtype=np.complex128)
+    d = np.diag(m)
+    if np.abs(m - np.diag(d)).max() > tol or np.abs(np.abs(d) - 1).max() > tol:
+        return None
+    return [DiagTerm(sub, const=c) for sub, c in walsh_terms(np.angle(d), qubits)]
+
+
+def diag_terms_trig(c0, c1, c2, qubits, param: ParamRef, tol=1e-12):
+    """``c0 + cos(a) c1 + sin(a) c2`` is a unit-modulus diagonal for every a iff it can be written
+    diag(exp(i(f_x a + g_x))).  Recognised forms: c0 = 0, c1 = diag(e^{i g}), c2 = diag(i f e^{i g})
+    with f = +-1 (covers rz / exp1(diagonal Pauli product) / rzz), and c0 = diag(p), c1 = diag(q),
+    c2 = i c1 with disjoint supports (phase gate)."""
+    c0, c1, c2 = (np.asarray(x, dtype=np.complex128) for x in (c0, c1, c2))
+    for m in (c0, c1, c2):
+        if np.abs(m - np.diag(np.diag(m))).max() > tol:
+            return None
+    d0, d1, d2 = np.diag(c0), np.diag(c1), np.diag(c2)
+    dim = d0.size
+    f = np.zeros(dim)
+    g = np.zeros(dim)
+    for x in range(dim):
+        if abs(d0[x]) < tol and abs(abs(d1[x]) - 1) < tol:
+            ratio = d2[x] / d1[x]  # must be +-i
+            if abs(ratio - 1j) < tol:
+                f[x] = 1.0
+            elif abs(ratio + 1j) < tol:
+                f[x] = -1.0
+            else:
+                return None
+            g[x] = np.angle(d1[x])
+        elif abs(abs(d0[x]) - 1) < tol and abs(d1[x]) < tol and abs(d2[x]) < tol:
+            f[x] = 0.0
+            g[x] = np.angle(d0[x])
+        else:
+            return None
+    terms = {}
+    for sub, c in walsh_terms(g, qubits):
+        terms[sub] = [c, 0.0]
+    for sub, c in walsh_terms(f, qubits):
+        terms.setdefault(sub, [0.0, 0.0])[1] = c
+    out = []
+    for sub, (cg, cf) in terms.items():
+        if cf != 0.0:
+            out.append(
+                DiagTerm(sub, const=cg + cf * param.offset,
+                         param=ParamRef(param.index, cf * param.scale, 0.0))
+            )
+        else:
+            out.append(DiagTerm(sub, const=cg))
+    return out
+
+
+# ---- scheduling ------------------------------------------------------------------------
+def _scan(gates, order, qbits_of, res_of, capacity, forced, allowed):
+    """One greedy scan over pending gates (program order).  Returns (chosen resource-bit set,
+    chosen gate ids).  ``qbits_of(g)`` = the qubits' physical bits (ordering), ``res_of(g)`` = the
+    resource bits the gate needs inside the chosen set (phys bits for the tile choice, tile bits
+    for the register choice; empty for diagonal gates, which only respect ordering against the
+    non-commuting dense gates)."""
+    S = set(forced)
+    blocked_all = set()
+    blocked_dense = set()
+    chosen = []
+    for gi in order:
+        g = gates[gi]
+        qs = set(qbits_of(gi))
+        if g.is_diag:
+            if qs & blocked_all:
+                blocked_dense |= qs
+            else:
+                chosen.append(gi)
+            continue
+        rs = set(res_of(gi))
+        if qs & (blocked_all | blocked_dense) or not rs <= allowed or len(S | rs) > capacity:
+            blocked_all |= qs
+            continue
+        S |= rs
+        chosen.append(gi)
+    return S, chosen
+
+
+@dataclass
+class Round:
+    reg_tb: List[int]  # tile-bit index of each register bit
+    thr_tb: List[int]  # tile-bit index of each thread bit
+    gates: List[int]   # gate ids executed in this round (program order)
+
+
+@dataclass
+class PassPlan:
+    tile_bits: List[int]  # physical bit positions, ascending
+    rounds: List[Round] = field(default_factory=list)
+    gate_ids: List[int] = field(default_factory=list)
+
+
+@dataclass
+class PlanConfig:
+    R: int = 5          # register bits (2^R amplitudes per thread)
+    LT: int = 8         # log2(threads per workgroup)
+    lowbits: int = 5    # physical low bits always in the tile (coalescing run = 2^lowbits amps)
+    vec: int = 2        # amplitudes per 16-byte global access (2 for complex64, 1 for complex128)
+
+    @property
+    def T(self):
+        return self.R + self.LT
+
+
+def schedule(gates: List[GateRec], n: int, cfg: PlanConfig) -> List[PassPlan]:
+    T, R = cfg.T, cfg.R
+    if n < T:
+        raise ValueError(f"n={n} smaller than tile bits T={T}")
+    L = min(cfg.lowbits, T)
+    for g in gates:
+        if not g.is_diag and len(g.qubits) > min(R, 2):
+            raise NotImplementedError(
+                f"dense gates on more than {min(R, 2)} qubits are not supported by the HIP tile-VM"
+            )
+    phys = lambda gi: [n - 1 - q for q in gates[gi].qubits]
+    phys_res = lambda gi: [] if gates[gi].is_diag else phys(gi)
+    pending = list(range(len(gates)))
+    passes = []
+    all_bits = set(range(n))
+    while pending:
+        S, chosen = _scan(gates, pending, phys, phys_res, T, set(range(L)), all_bits)
+        if not chosen:
+            raise RuntimeError("scheduler made no progress")
+        # fill the tile with the lowest unused bits (better contiguity)
+        b = 0
+        while len(S) < T:
+            if b not in S:
+                S.add(b)
+            b += 1
+        tile_bits = sorted(S)
+        pp = PassPlan(tile_bits=tile_bits, gate_ids=list(chosen))
+        _schedule_rounds(gates, n, cfg, pp)
+        passes.append(pp)
+        cs = set(chosen)
+        pending = [gi for gi in pending if gi not in cs]
+    return passes
+
+
+def _schedule_rounds(gates, n, cfg: PlanConfig, pp: PassPlan):
+    T, R = cfg.T, cfg.R
+    tb_of_phys = {p: i for i, p in enumerate(pp.tile_bits)}
+
+    phys = lambda gi: [n - 1 - q for q in gates[gi].qubits]
+
+    def tb(gi):
+        g = gates[gi]
+        if g.is_diag:
+            return []  # diagonal gates need no register bits
+        return [tb_of_phys[n - 1 - q] for q in g.qubits]
+
+    # constrained (load/store) layout: tile bit 0 must be a register bit when vec == 2, and the
+    # low coalescing bits are pinned to the low lanes.
+    lc = min(cfg.lowbits, 5, T - R + (1 if cfg.vec == 2 else 0))
+    forced_c = {0} if cfg.vec == 2 else set()
+    pinned = set(range(lc)) - forced_c
+    allowed_c = set(range(T)) - pinned
+    allowed_u = set(range(T))
+
+    def finish_layout(S, allowed):
+        S = set(S)
+        for b in sorted(allowed, reverse=True):
+            if len(S) >= R:
+                break
+            S.add(b)
+        reg = sorted(S)
+        thr = [b for b in range(T) if b not in S]
+        assert len(reg) == R and len(thr) == T - R
+        return reg, thr
+
+    pending = list(pp.gate_ids)
+    rounds = []
+    # round 0: constrained
+    S, chosen = _scan(gates, pending, phys, tb, R, forced_c, allowed_c)
+    reg, thr = finish_layout(S, allowed_c)
+    rounds.append(Round(reg, thr, chosen))
+    cs = set(chosen)
+    pending = [g for g in pending if g not in cs]
+    while pending:
+        S, chosen = _scan(gates, pending, phys, tb, R, forced_c, allowed_c)
+        if len(chosen) == len(pending):
+            reg, thr = finish_layout(S, allowed_c)
+            rounds.append(Round(reg, thr, chosen))
+            pending = []
+            break
+        S, chosen = _scan(gates, pending, phys, tb, R, set(), allowed_u)
+        if not chosen:
+            raise RuntimeError("round scheduler made no progress")
+        # prefer pinned bits when filling (only unconstrained rounds can host them)
+        fill = sorted(allowed_u, key=lambda b: (b not in pinned, -b))
+        S = set(S)
+        for b in fill:
+            if len(S) >= R:
+                break
+            S.add(b)
+        reg = sorted(S)
+        thr = [b for b in range(T) if b not in S]
+        rounds.append(Round(reg, thr, chosen))
+        cs = set(chosen)
+        pending = [g for g in pending if g not in cs]
+        if not pending:
+            reg, thr = finish_layout(forced_c, allowed_c)
+            rounds.append(Round(reg, thr, []))
+    pp.rounds = rounds
+
+
+# ---- LDS exchange maps -----------------------------------------------------------------
+def exchange_masks(T, wr: Round, rd: Round):
+    """Linear bijection tile-index -> LDS slot for one exchange, chosen so that the 16-lane write
+    groups (ds_write_b64) and the 32-lane read groups (ds_read_b64) are bank-conflict free:
+    slot bits 0..4 <- the tile bits of the reading round's lanes 0..4; tile bits of the writing
+    round's lanes 0..3 that are not among them are XOR-folded into unused low slot bits."""
+    nlw = min(4, len(wr.thr_tb))
+    nlr = min(5, len(rd.thr_tb))
+    W = list(wr.thr_tb[:nlw])
+    Rd = list(rd.thr_tb[:nlr])
+    both = [x for x in Rd if x in W]
+    rd_only = [x for x in Rd if x not in W]
+    order = both + rd_only
+    pos = {x: i for i, x in enumerate(order)}
+    nxt = len(order)
+    for x in range(T):
+        if x not in pos:
+            pos[x] = nxt
+            nxt += 1
+    used_low = {pos[x] for x in both}
+    free_low = [m for m in range(4) if m not in used_low]
+    A = {x: 1 << pos[x] for x in range(T)}
+    for x in W:
+        if x not in Rd:
+            A[x] |= 1 << free_low.pop(0)
+    return A
+
+
+# ---- encoding --------------------------------------------------------------------------
+@dataclass
+class Tables:
+    """Accumulates the constant table and the builder program while passes are encoded."""
+
+    ctab: List[float] = field(default_factory=list)   # shared constants (real values)
+    ptab_size: int = 0                                 # per-batch table size (real values)
+    ginfo: List[List[int]] = field(default_factory=list)   # builder records
+    cpool: List[float] = field(default_factory=list)       # builder constants (float64)
+    _slot_cache: dict = field(default_factory=dict)
+
+    def const_complex(self, m):
+        off = len(self.ctab)
+        for z in np.asarray(m, dtype=np.complex128).reshape(-1):
+            self.ctab += [float(z.real), float(z.imag)]
+        return off | CONST_FLAG
+
+    def const_real(self, v):
+        off = len(self.ctab)
+        self.ctab.append(float(v))
+        return off | CONST_FLAG
+
+    def alloc(self, nreal):
+        off = self.ptab_size
+        self.ptab_size += nreal
+        return off
+
+
+TWO_PI = 2.0 * np.pi
+
+
+def g1_kind(g: GateRec, tol=1e-14) -> int:
+    """Structure class of a 1-qubit gate (valid for every parameter value): 1 = real matrix,
+    2 = real diagonal + imaginary off-diagonal (rx-like), 0 = general.  The kernel spends 8 instead
+    of 16 FMAs per amplitude pair on classes 1 and 2."""
+    ms = [np.asarray(m, dtype=np.complex128) for m in (g.c0, g.c1, g.c2) if m is not None]
+    if all(np.abs(m.imag).max() < tol for m in ms):
+        return 1
+    if all(
+        abs(m[0, 0].imag) < tol and abs(m[1, 1].imag) < tol and abs(m[0, 1].real) < tol and abs(m[1, 0].real) < tol
+        for m in ms
+    ):
+        return 2
+    return 0
+
+
+def _gate_slot(tables: Tables, gi: int, g: GateRec, swap: bool):
+    """Table slot holding the dense matrix of gate g (optionally with its two qubits swapped)."""
+    key = (gi, swap)
+    if key in tables._slot_cache:
+        return tables._slot_cache[key]
+    dim = 2 ** len(g.qubits)
+
+    def sw(m):
+        m = np.asarray(m, dtype=np.complex128).reshape(dim, dim)
+        if swap:
+            m = m.reshape(2, 2, 2, 2).transpose(1, 0, 3, 2).reshape(4, 4)
+        return m
+
+    if g.param is None:
+        slot = tables.const_complex(sw(g.c0))
+    else:
+        slot = tables.alloc(2 * dim * dim)
+        off = len(tables.cpool)
+        tables.cpool += [g.param.scale, g.param.offset]
+        for m in (g.c0, g.c1, g.c2):
+            for z in sw(m).reshape(-1):
+                tables.cpool += [float(z.real), float(z.imag)]
+        tables.ginfo.append([BK_TRIG, slot, g.param.index, dim, off, 0, 0, 0])
+    tables._slot_cache[key] = slot
+    return slot
+
+
+def _coef_slot(tables: Tables, gi: int, ti: int, t: DiagTerm):
+    key = (gi, "d", ti)
+    if key in tables._slot_cache:
+        return tables._slot_cache[key]
+    if t.param is None:
+        slot = tables.const_real(t.const / TWO_PI)
+    else:
+        slot = tables.alloc(1)
+        off = len(tables.cpool)
+        tables.cpool += [t.param.scale / TWO_PI, (t.const + t.param.offset) / TWO_PI]
+        tables.ginfo.append([BK_COEF, slot, t.param.index, 1, off, 0, 0, 0])
+    tables._slot_cache[key] = slot
+    return slot
+
+
+def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tables: Tables,
+                batch_diag: bool = True) -> np.ndarray:
+    T, R, LT = cfg.T, cfg.R, cfg.LT
+    assert R <= R_MAX and LT <= LT_MAX and T <= T_MAX
+    words = [0] * HDR_WORDS
+    words[0] = MAGIC
+    words[1] = n
+    words[2] = T
+    words[3] = R
+    words[4] = LT
+    words[5] = len(pp.rounds)
+    words[6] = 0
+    for i, p in enumerate(pp.tile_bits):
+        words[8 + i] = p
+    tb_of_phys = {p: i for i, p in enumerate(pp.tile_bits)}
+    nr = len(pp.rounds)
+    exch = [exchange_masks(T, pp.rounds[k], pp.rounds[k + 1]) for k in range(nr - 1)]
+    for k, rd in enumerate(pp.rounds):
+        rr = [0] * RR_WORDS
+        for j, b in enumerate(rd.reg_tb):
+            rr[2 + j] = 1 << pp.tile_bits[b]
+        for i, b in enumerate(rd.thr_tb):
+            rr[8 + i] = 1 << pp.tile_bits[b]
+        if k > 0:
+            A = exch[k - 1]
+            for j, b in enumerate(rd.reg_tb):
+                rr[18 + j] = A[b]
+            for i, b in enumerate(rd.thr_tb):
+                rr[24 + i] = A[b]
+        if k < nr - 1:
+            A = exch[k]
+            for j, b in enumerate(rd.reg_tb):
+                rr[34 + j] = A[b]
+            for i, b in enumerate(rd.thr_tb):
+                rr[40 + i] = A[b]
+        reg_of_tb = {b: j for j, b in enumerate(rd.reg_tb)}
+        regphys = {pp.tile_bits[b]: j for j, b in enumerate(rd.reg_tb)}
+        ops = []
+        nops = 0
+        # consecutive diagonal gates are merged into one DIAG op
+        pend_diag = []
+
+        def flush_diag():
+            nonlocal nops
+            if not pend_diag:
+                return
+            A_, B_, C_ = [], [], []
+            for gi in pend_diag:
+                for ti, t in enumerate(gates[gi].diag):
+                    slot = _coef_slot(tables, gi, ti, t)
+                    pbits = [n - 1 - q for q in t.qubits]
+                    rbits = [regphys[p] for p in pbits if p in regphys]
+                    nmask = 0
+                    for p in pbits:
+                        if p not in regphys:
+                            nmask |= 1 << p
+                    if len(rbits) == 0:
+                        A_.append((nmask, slot))
+                    elif len(rbits) == 1:
+                        B_.append((rbits[0], nmask, slot))
+                    elif nmask == 0:
+                        rm = 0
+                        for j in rbits:
+                            rm |= 1 << j
+                        C_.append((rm, slot))
+                    else:
+                        raise NotImplementedError(
+                            "diagonal term with >=2 register bits and non-register bits"
+                        )
+            ops.extend([OP_DIAG, len(A_), len(B_), len(C_)])
+            for m, s in A_:
+                ops.extend([m, s])
+            for j, m, s in B_:
+                ops.extend([j, m, s])
+            for m, s in C_:
+                ops.extend([m, s])
+            nops += 1
+            pend_diag.clear()
+
+        for gi in rd.gates:
+            g = gates[gi]
+            if g.is_diag:
+                pend_diag.append(gi)
+                if not batch_diag:
+                    flush_diag()
+                continue
+            flush_diag()
+            tbs = [tb_of_phys[n - 1 - q] for q in g.qubits]
+            js = [reg_of_tb[b] for b in tbs]
+            if len(js) == 1:
+                ops.extend([OP_G1, js[0] | (g1_kind(g) << 8), _gate_slot(tables, gi, g, False)])
+            elif len(js) == 2:
+                swap = js[0] > js[1]
+                ja, jb = (js[1], js[0]) if swap else (js[0], js[1])
+                ops.extend([OP_G2, ja, jb, _gate_slot(tables, gi, g, swap)])
+            else:
+                raise NotImplementedError
+            nops += 1
+        flush_diag()
+        rr[0] = nops
+        rr[1] = len(ops)
+        words += rr + ops
+    arr = np.array(words, dtype=np.int64)
+    # masks may use bit 31: store as uint32 bit patterns in int32
+    return arr.astype(np.uint32).view(np.int32)
+
+
+@dataclass
+class CompiledPlan:
+    n: int
+    cfg: PlanConfig
+    passes: List[PassPlan]
+    descs: List[np.ndarray]
+    ctab: np.ndarray       # float64 constants (cast to the state's real dtype on upload)
+    ptab_size: int
+    ginfo: np.ndarray      # int32 [G, 8]
+    cpool: np.ndarray      # float64
+    nparams: int
+
+    def stats(self, itemsize):
+        """Algorithmic bytes/flops of the executed plan: each pass reads
+        and writes the state once."""
+        npass = len(self.passes)
+        return {
+            "passes": npass,
+            "rounds": sum(len(p.rounds) for p in self.passes),
+            "bytes": npass * 2 * (2**self.n) * itemsize,
+        }
+
+
+def compile_plan(gates: List[GateRec], n: int, cfg: PlanConfig, nparams: int = 0) -> CompiledPlan:
+    passes = schedule(gates, n, cfg)
+    tables = Tables()
+    descs = [encode_pass(gates, n, cfg, pp, tables) for pp in passes]
+    ginfo = np.array(tables.ginfo, dtype=np.int32).reshape(-1, 8)
+    return CompiledPlan(
+        n=n, cfg=cfg, passes=passes, descs=descs,
+        ctab=np.array(tables.ctab, dtype=np.float64),
+        ptab_size=tables.ptab_size, ginfo=ginfo,
+        cpool=np.array(tables.cpool, dtype=np.float64), nparams=nparams,
+    )
