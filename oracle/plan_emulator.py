@@ -13,7 +13,8 @@ import numpy as np
 MAGIC = 0x54434D31
 HDR_WORDS = 24
 RR_WORDS = 50
-OP_G1, OP_G2, OP_DIAG = 1, 2, 3
+OP_G1, OP_G2, OP_DIAG, OP_G1M = 1, 2, 3, 4
+R_MAX = 6
 CONST_FLAG = 1 << 30
 BK_TRIG, BK_COEF = 1, 2
 
@@ -112,26 +113,38 @@ def run_pass(state, desc, ctab, ptab_row):
         q = pc + RR_WORDS
         for _ in range(nops):
             op = int(d[q])
-            if op == OP_G1:
-                j, kind, slot = int(d[q + 1]) & 0xFF, int(d[q + 1]) >> 8, d[q + 2]
-                m = tab(slot, 8)
-                m = (m[0::2] + 1j * m[1::2]).reshape(2, 2)
-                if kind == 1:      # the kernel reads only the real parts
-                    m = m.real.astype(np.complex128)
-                elif kind == 2:    # real diagonal, imaginary off-diagonal
-                    m = np.array([[m[0, 0].real, 1j * m[0, 1].imag], [1j * m[1, 0].imag, m[1, 1].real]])
-                bit = (rid >> j) & 1
-                r0 = rid[bit == 0]
-                r1 = r0 | (1 << j)
-                a0, a1 = regs[..., r0].copy(), regs[..., r1].copy()
-                regs[..., r0] = m[0, 0] * a0 + m[0, 1] * a1
-                regs[..., r1] = m[1, 0] * a0 + m[1, 1] * a1
-                q += 3
+            if op in (OP_G1, OP_G1M):
+                if op == OP_G1:
+                    todo = [(int(d[q + 1]) & 0xFF, int(d[q + 1]) >> 8, d[q + 2])]
+                    q += 3
+                else:
+                    mk, base_slot = int(d[q + 1]), int(d[q + 2])
+                    todo = [(j, (mk >> (8 + 2 * j)) & 3, base_slot + 8 * j) for j in range(R) if (mk >> j) & 1]
+                    q += 3
+                for j, kind, slot in todo:
+                    m = tab(slot, 8)
+                    m = (m[0::2] + 1j * m[1::2]).reshape(2, 2)
+                    if kind == 1:      # the kernel reads only the real parts
+                        m = m.real.astype(np.complex128)
+                    elif kind == 2:    # real diagonal, imaginary off-diagonal
+                        m = np.array([[m[0, 0].real, 1j * m[0, 1].imag], [1j * m[1, 0].imag, m[1, 1].real]])
+                    bit = (rid >> j) & 1
+                    r0 = rid[bit == 0]
+                    r1 = r0 | (1 << j)
+                    a0, a1 = regs[..., r0].copy(), regs[..., r1].copy()
+                    regs[..., r0] = m[0, 0] * a0 + m[0, 1] * a1
+                    regs[..., r1] = m[1, 0] * a0 + m[1, 1] * a1
             elif op == OP_G2:
-                ja, jb, slot = int(d[q + 1]), int(d[q + 2]), d[q + 3]
+                ja, kind, jb, slot = int(d[q + 1]) & 0xFF, int(d[q + 1]) >> 8, int(d[q + 2]), d[q + 3]
                 assert ja < jb
                 m = tab(slot, 32)
                 m = (m[0::2] + 1j * m[1::2]).reshape(4, 4)
+                if kind == 1:
+                    m = np.eye(4)[[0, 1, 3, 2]]
+                elif kind == 2:
+                    m = np.eye(4)[[0, 3, 2, 1]]
+                elif kind == 3:
+                    m = np.eye(4)[[0, 2, 1, 3]]
                 base = rid[(((rid >> ja) & 1) == 0) & (((rid >> jb) & 1) == 0)]
                 idx = [base | (xa << ja) | (xb << jb) for xa in (0, 1) for xb in (0, 1)]
                 a = [regs[..., ix].copy() for ix in idx]
@@ -139,29 +152,26 @@ def run_pass(state, desc, ctab, ptab_row):
                     regs[..., idx[o]] = sum(m[o, i] * a[i] for i in range(4))
                 q += 4
             elif op == OP_DIAG:
-                nA, nB, nC = int(d[q + 1]), int(d[q + 2]), int(d[q + 3])
-                q += 4
+                nA, nB, nC, base_slot = (int(x) for x in d[q + 1: q + 5])
+                assert nA % 8 == 0 and nB % 8 == 0
+                q += 5
+                cf = np.asarray(ptab_row)[base_slot: base_slot + nA + nB + nC]
                 tidx = (wg_base[:, None] | tphys[None, :]).astype(np.uint64)  # [nwg, nth]
                 phi = np.zeros((nwg, nth, NR), dtype=np.float64)
-                for _a in range(nA):
-                    mask, slot = int(d[q]), d[q + 1]
-                    c = float(tab(slot, 1)[0])
-                    sgn = 1 - 2 * _parity(tidx & np.uint64(mask))
-                    phi += (c * sgn)[:, :, None]
-                    q += 2
-                for _b in range(nB):
-                    j, mask, slot = int(d[q]), int(d[q + 1]), d[q + 2]
-                    c = float(tab(slot, 1)[0])
+                for e in range(nA):
+                    sgn = 1 - 2 * _parity(tidx & np.uint64(int(d[q + e])))
+                    phi += (float(cf[e]) * sgn)[:, :, None]
+                q += nA
+                for e in range(nB):
+                    mask, j = int(d[q + e]), int(d[q + nB + e])
                     sgn = 1 - 2 * _parity(tidx & np.uint64(mask))
                     z = 1 - 2 * ((rid >> j) & 1).astype(np.int64)
-                    phi += (c * sgn)[:, :, None] * z[None, None, :]
-                    q += 3
-                for _c in range(nC):
-                    rmask, slot = int(d[q]), d[q + 1]
-                    c = float(tab(slot, 1)[0])
-                    z = 1 - 2 * _parity(rid.astype(np.uint64) & np.uint64(rmask))
-                    phi += c * z[None, None, :]
-                    q += 2
+                    phi += (float(cf[nA + e]) * sgn)[:, :, None] * z[None, None, :]
+                q += 2 * nB
+                for e in range(nC):
+                    z = 1 - 2 * _parity(rid.astype(np.uint64) & np.uint64(int(d[q + e])))
+                    phi += float(cf[nA + nB + e]) * z[None, None, :]
+                q += nC
                 regs = regs * np.exp(2j * np.pi * phi).astype(regs.dtype)
             else:
                 raise ValueError(f"bad opcode {op} at word {q}")
@@ -183,6 +193,8 @@ def run_plan(plan, params=None, dtype=np.complex128, batch_index=0):
     state = np.zeros(2**plan.n, dtype=dtype)
     state[0] = 1.0
     if plan.ptab_size:
+        if params is None:
+            params = np.zeros(1)
         ptab = build_table(plan.ginfo, plan.cpool, params, plan.ptab_size)[batch_index]
     else:
         ptab = np.zeros(0)

@@ -25,6 +25,22 @@ def check(n, d, dtype, kind="b", opts=None):
     tc.set_contractor("greedy")
     return err
 
+def check_mixed(n, dtype):
+    from oracle import gates as G
+    tc.set_dtype(dtype)
+    d = 2
+    params = np.random.default_rng(n).uniform(0,2*np.pi,[2*d,n]); pa = np.random.default_rng(n+1).uniform(0,2*np.pi,[d,n])
+    pt = tc.backend.convert_to_tensor(params, dtype=tc.rdtypestr)
+    c = tc.Circuit(n); W.hea_b(c,n,d,pt, zz=tc.gates._zz_matrix); c.ry(0, theta=0.3); c.u(1, theta=0.2, phi=0.5, lbd=0.7); c.cnot(2,3); c.s(4); c.cz(5,1); c.swap(0,6); c.cnot(7,2)
+    W.hea_a(c, n, d, pa); c.cphase(3,7,theta=0.4); c.rzz(0,5,theta=0.9); c.iswap(1,2,theta=0.3); c.phase(4, theta=1.1)
+    c.any(1, 6, unitary=G.random_two_qubit_gate(5)); c.any(6, 2, unitary=G.random_two_qubit_gate(6)); c.r(3, theta=0.3, alpha=0.4, phi=0.5)
+    ops = W.hea_b_ops(n,d,params) + [(G.ry(0.3),[0]),(G.u(0.2,0.5,0.7),[1]),(G.CNOT,[2,3]),(G.S,[4]),(G.CZ,[5,1]),(G.SWAP,[0,6]),(G.CNOT,[7,2])] + W.hea_a_ops(n,d,pa) + [(G.controlled(G.phase(0.4)),[3,7]),(G.rzz(0.9),[0,5]),(G.iswap(0.3),[1,2]),(G.phase(1.1),[4]),(G.random_two_qubit_gate(5),[1,6]),(G.random_two_qubit_gate(6),[6,2]),(G.r(0.3,0.4,0.5),[3])]
+    psi = tc.backend.numpy(c.wavefunction()); ref = dense.run(n, ops)
+    print(f"mixed n={n} {dtype} err={np.abs(psi-ref).max():.3e}", flush=True)
+
+for dtype in ("complex64", "complex128"):
+    for n in (8, 11, 13, 15, 18):
+        check_mixed(n, dtype)
 for dtype in ("complex64", "complex128"):
     for (n, d, kind) in [(3,2,"b"),(8,2,"b"),(10,4,"b"),(12,3,"a"),(13,3,"b"),(14,3,"a"),(16,4,"b"),(18,3,"a"),(20,4,"b")]:
         check(n, d, dtype, kind)

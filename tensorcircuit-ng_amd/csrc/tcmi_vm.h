@@ -6,12 +6,16 @@
 //   [18..24) reg LDS-read masks  [24..34) thread LDS-read masks   (exchange into this round)
 //   [34..40) reg LDS-write masks [40..50) thread LDS-write masks  (exchange out of this round)
 // followed by the round's ops:
-//   G1   {1, j, slot}                 dense 1-qubit gate on register bit j
-//   G2   {2, ja, jb, slot}            dense 2-qubit gate, matrix index = (bit ja << 1) | bit jb, ja < jb
-//   DIAG {3, nA, nB, nC, A.., B.., C..}  phase polynomial in turns:
-//        A = {mask, slot}      coef * (-1)^parity(thread_index & mask)
-//        B = {j, mask, slot}   coef * (-1)^parity(thread_index & mask) * z_j(r)
-//        C = {rmask, slot}     coef * (-1)^parity(r & rmask)
+//   G1M  {4, mask | kinds<<8, base}   1-qubit gates on every register bit j in mask; matrix j at
+//                                     ptab[base + 8j ..]; 2 kind bits per j at bit 8+2j (0 general,
+//                                     1 real, 2 real-diagonal/imaginary-off-diagonal)
+//   G2   {2, ja | kind<<8, jb, slot}  2-qubit gate, matrix index = (bit ja << 1) | bit jb, ja < jb
+//                                     (kind: 0 dense, 1 CNOT control ja, 2 CNOT control jb, 3 SWAP)
+//   DIAG {3, nA, nB, nC, base, maskA[nA], maskB[nB], jB[nB], rmaskC[nC]}  phase polynomial in turns,
+//        coefficients contiguous at ptab[base ..] in the order A, B, C (nA, nB multiples of 8):
+//        A: coef * (-1)^parity(thread_index & mask)
+//        B: coef * (-1)^parity(thread_index & mask) * z_j(r)
+//        C: coef * (-1)^parity(r & rmask)
 // slot = offset (in reals) into the per-batch table, or into the constant table if TCMI_CONST_FLAG.
 #ifndef TCMI_VM_H
 #define TCMI_VM_H
@@ -24,6 +28,8 @@
 #define TCMI_OP_G1 1
 #define TCMI_OP_G2 2
 #define TCMI_OP_DIAG 3
+#define TCMI_OP_G1M 4
+#define TCMI_DIAG_CHUNK 8
 #define TCMI_CONST_FLAG (1 << 30)
 #define TCMI_BK_TRIG 1
 #define TCMI_BK_COEF 2

@@ -142,34 +142,52 @@ __device__ __forceinline__ void apply_g2(typename Cx<F>::type (&a)[NR], const F 
   }
 }
 
-template <typename F, int NR, int R, int KIND>
-__device__ __forceinline__ void dispatch_g1k(typename Cx<F>::type (&a)[NR], int j, const F (&m)[8]) {
+// permutation gates: CNOT (either orientation) and SWAP move amplitudes, no arithmetic
+template <typename F, int NR, int JA, int JB, int KIND>
+__device__ __forceinline__ void apply_perm2(typename Cx<F>::type (&a)[NR]) {
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    if (((r >> JA) & 1) || ((r >> JB) & 1)) continue;
+    const int i1 = r | (1 << JB), i2 = r | (1 << JA), i3 = r | (1 << JA) | (1 << JB);
+    if constexpr (KIND == 1) { const auto t = a[i2]; a[i2] = a[i3]; a[i3] = t; }       // control JA
+    else if constexpr (KIND == 2) { const auto t = a[i1]; a[i1] = a[i3]; a[i3] = t; }  // control JB
+    else { const auto t = a[i1]; a[i1] = a[i2]; a[i2] = t; }                            // SWAP
+  }
+}
+
+template <typename F, int NR, int R, int J>
+__device__ __forceinline__ void apply_g1_kind(typename Cx<F>::type (&a)[NR], int kind, const F (&m)[8]) {
+  if (kind == 1) apply_g1<F, NR, J, 1>(a, m);
+  else if (kind == 2) apply_g1<F, NR, J, 2>(a, m);
+  else apply_g1<F, NR, J, 0>(a, m);
+}
+
+template <typename F, int NR, int R>
+__device__ __forceinline__ void dispatch_g1m(typename Cx<F>::type (&a)[NR], int j, int kind, const F (&mm)[R][8]) {
   switch (j) {
-    case 0: apply_g1<F, NR, 0, KIND>(a, m); break;
-    case 1: if constexpr (R > 1) apply_g1<F, NR, 1, KIND>(a, m); break;
-    case 2: if constexpr (R > 2) apply_g1<F, NR, 2, KIND>(a, m); break;
-    case 3: if constexpr (R > 3) apply_g1<F, NR, 3, KIND>(a, m); break;
-    case 4: if constexpr (R > 4) apply_g1<F, NR, 4, KIND>(a, m); break;
-    case 5: if constexpr (R > 5) apply_g1<F, NR, 5, KIND>(a, m); break;
+    case 0: apply_g1_kind<F, NR, R, 0>(a, kind, mm[0]); break;
+    case 1: if constexpr (R > 1) apply_g1_kind<F, NR, R, 1>(a, kind, mm[1]); break;
+    case 2: if constexpr (R > 2) apply_g1_kind<F, NR, R, 2>(a, kind, mm[2]); break;
+    case 3: if constexpr (R > 3) apply_g1_kind<F, NR, R, 3>(a, kind, mm[3]); break;
+    case 4: if constexpr (R > 4) apply_g1_kind<F, NR, R, 4>(a, kind, mm[4]); break;
+    case 5: if constexpr (R > 5) apply_g1_kind<F, NR, R, 5>(a, kind, mm[5]); break;
     default: break;
   }
 }
 
-template <typename F, int NR, int R>
-__device__ __forceinline__ void dispatch_g1(typename Cx<F>::type (&a)[NR], int jk, const F (&m)[8]) {
-  const int j = jk & 0xff, kind = jk >> 8;
-  if (kind == 1) dispatch_g1k<F, NR, R, 1>(a, j, m);
-  else if (kind == 2) dispatch_g1k<F, NR, R, 2>(a, j, m);
-  else dispatch_g1k<F, NR, R, 0>(a, j, m);
-}
-
 #define TCMI_G2_CASE(A, B)                                         \
   case (A * 8 + B):                                                \
-    if constexpr (R > B) apply_g2<F, NR, A, B>(a, m);              \
+    if constexpr (R > B) {                                         \
+      if (kind == 0) apply_g2<F, NR, A, B>(a, m);                  \
+      else if (kind == 1) apply_perm2<F, NR, A, B, 1>(a);          \
+      else if (kind == 2) apply_perm2<F, NR, A, B, 2>(a);          \
+      else apply_perm2<F, NR, A, B, 3>(a);                         \
+    }                                                              \
     break;
 
 template <typename F, int NR, int R>
-__device__ __forceinline__ void dispatch_g2(typename Cx<F>::type (&a)[NR], int ja, int jb, const F (&m)[32]) {
+__device__ __forceinline__ void dispatch_g2(typename Cx<F>::type (&a)[NR], int jak, int jb, const F (&m)[32]) {
+  const int ja = jak & 0xff, kind = jak >> 8;
   switch (ja * 8 + jb) {
     TCMI_G2_CASE(0, 1) TCMI_G2_CASE(0, 2) TCMI_G2_CASE(0, 3) TCMI_G2_CASE(0, 4) TCMI_G2_CASE(0, 5)
     TCMI_G2_CASE(1, 2) TCMI_G2_CASE(1, 3) TCMI_G2_CASE(1, 4) TCMI_G2_CASE(1, 5)
@@ -249,45 +267,75 @@ __global__ __launch_bounds__(1 << LT) void pass_kernel(typename Cx<F>::type* __r
 #pragma unroll 1
     for (int o = 0; o < nops; ++o) {
       const int op = desc[q];
-      if (op == TCMI_OP_G1) {
-        const KPtr<F> mp = tab_ptr<F>(desc[q + 2], ctab, ptab);
-        F m[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) m[i] = mp[i];
-        dispatch_g1<F, NR, R>(a, desc[q + 1], m);
-        q += 3;
-      } else if (op == TCMI_OP_G2) {
+      if (op == TCMI_OP_G2) {
         const KPtr<F> mp = tab_ptr<F>(desc[q + 3], ctab, ptab);
         F m[32];
 #pragma unroll
         for (int i = 0; i < 32; ++i) m[i] = mp[i];
         dispatch_g2<F, NR, R>(a, desc[q + 1], desc[q + 2], m);
         q += 4;
+      } else if (op == TCMI_OP_G1M) {
+        // one-qubit gates on the register bits in mask; the R matrices sit contiguously in the
+        // per-batch table and are fetched with one burst of scalar loads
+        const int mk = desc[q + 1];
+        const KPtr<F> mp = ptab + desc[q + 2];
+        F mm[R][8];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) mm[j][i] = mp[8 * j + i];
+        }
+#pragma unroll 1
+        for (int j = 0; j < R; ++j) {
+          if (!((mk >> j) & 1)) continue;
+          dispatch_g1m<F, NR, R>(a, j, (mk >> (8 + 2 * j)) & 3, mm);
+        }
+        q += 3;
       } else if (op == TCMI_OP_DIAG) {
         const int nA = desc[q + 1], nB = desc[q + 2], nC = desc[q + 3];
-        q += 4;
+        const KPtr<F> cf = ptab + desc[q + 4];
+        q += 5;
         const uint32_t tidx = wg_base | tphys;
         double phi = 0.0;
 #pragma unroll 1
-        for (int e = 0; e < nA; ++e) {
-          const uint32_t mask = (uint32_t)desc[q];
-          const double c = (double)*tab_ptr<F>(desc[q + 1], ctab, ptab);
-          phi += (__popc(tidx & mask) & 1) ? -c : c;
-          q += 2;
+        for (int e = 0; e < nA; e += TCMI_DIAG_CHUNK) {
+          uint32_t mk[TCMI_DIAG_CHUNK];
+          F cc[TCMI_DIAG_CHUNK];
+#pragma unroll
+          for (int i = 0; i < TCMI_DIAG_CHUNK; ++i) {
+            mk[i] = (uint32_t)desc[q + e + i];
+            cc[i] = cf[e + i];
+          }
+#pragma unroll
+          for (int i = 0; i < TCMI_DIAG_CHUNK; ++i) {
+            const double c = (double)cc[i];
+            phi += (__popc(tidx & mk[i]) & 1) ? -c : c;
+          }
         }
+        q += nA;
         double cj[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) cj[j] = 0.0;
 #pragma unroll 1
-        for (int e = 0; e < nB; ++e) {
-          const int jj = desc[q];
-          const uint32_t mask = (uint32_t)desc[q + 1];
-          const double c = (double)*tab_ptr<F>(desc[q + 2], ctab, ptab);
-          const double s = (__popc(tidx & mask) & 1) ? -c : c;
+        for (int e = 0; e < nB; e += TCMI_DIAG_CHUNK) {
+          uint32_t mk[TCMI_DIAG_CHUNK];
+          int jj[TCMI_DIAG_CHUNK];
+          F cc[TCMI_DIAG_CHUNK];
 #pragma unroll
-          for (int j = 0; j < R; ++j) cj[j] += (j == jj) ? s : 0.0;
-          q += 3;
+          for (int i = 0; i < TCMI_DIAG_CHUNK; ++i) {
+            mk[i] = (uint32_t)desc[q + e + i];
+            jj[i] = desc[q + nB + e + i];
+            cc[i] = cf[nA + e + i];
+          }
+#pragma unroll
+          for (int i = 0; i < TCMI_DIAG_CHUNK; ++i) {
+            const double c = (double)cc[i];
+            const double sgn = (__popc(tidx & mk[i]) & 1) ? -c : c;
+#pragma unroll
+            for (int j = 0; j < R; ++j) cj[j] += (j == jj[i]) ? sgn : 0.0;
+          }
         }
+        q += 2 * nB;
         F ph[NR];
         ph[0] = (F)(phi - rint(phi));
 #pragma unroll
@@ -301,12 +349,12 @@ __global__ __launch_bounds__(1 << LT) void pass_kernel(typename Cx<F>::type* __r
         }
 #pragma unroll 1
         for (int e = 0; e < nC; ++e) {
-          const uint32_t rmask = (uint32_t)desc[q];
-          const F c = *tab_ptr<F>(desc[q + 1], ctab, ptab);
+          const uint32_t rmask = (uint32_t)desc[q + e];
+          const F c = cf[nA + nB + e];
 #pragma unroll
           for (int r = 0; r < NR; ++r) ph[r] += (__popc((uint32_t)r & rmask) & 1) ? -c : c;
-          q += 2;
         }
+        q += nC;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
           F s, c;

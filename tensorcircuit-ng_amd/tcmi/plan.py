@@ -39,6 +39,9 @@ T_MAX = 16
 OP_G1 = 1
 OP_G2 = 2
 OP_DIAG = 3
+OP_G1M = 4
+DIAG_CHUNK = 8
+# G2 kinds: 0 general, 1 = CNOT(control ja, target jb), 2 = CNOT(control jb, target ja), 3 = SWAP
 CONST_FLAG = 1 << 30
 
 # builder kinds
@@ -422,6 +425,53 @@ def _gate_slot(tables: Tables, gi: int, g: GateRec, swap: bool):
     return slot
 
 
+def g2_kind(g: GateRec, swap: bool, tol=1e-14) -> int:
+    """Permutation classes of constant 2-qubit gates (no flops in the kernel): in the canonical
+    register order (ja < jb, matrix MSB <-> ja): 1 = CNOT control ja, 2 = CNOT control jb, 3 = SWAP."""
+    if g.param is not None:
+        return 0
+    m = np.asarray(g.c0, dtype=np.complex128).reshape(4, 4)
+    if swap:
+        m = m.reshape(2, 2, 2, 2).transpose(1, 0, 3, 2).reshape(4, 4)
+    cx_a = np.eye(4)[[0, 1, 3, 2]]
+    cx_b = np.eye(4)[[0, 3, 2, 1]]
+    sw = np.eye(4)[[0, 2, 1, 3]]
+    for k, ref in ((1, cx_a), (2, cx_b), (3, sw)):
+        if np.abs(m - ref).max() < tol:
+            return k
+    return 0
+
+
+def _matrix_record(tables: Tables, slot: int, g: GateRec):
+    """Builder record writing the dense matrix of g to ptab[slot ..] (constant gates included, so
+    that the matrices of one op can sit contiguously)."""
+    dim = 2 ** len(g.qubits)
+    off = len(tables.cpool)
+    if g.param is None:
+        tables.cpool += [0.0, 0.0]
+        mats = (g.c0, np.zeros((dim, dim)), np.zeros((dim, dim)))
+        pidx = 0
+    else:
+        tables.cpool += [g.param.scale, g.param.offset]
+        mats = (g.c0, g.c1, g.c2)
+        pidx = g.param.index
+    for m in mats:
+        for z in np.asarray(m, dtype=np.complex128).reshape(-1):
+            tables.cpool += [float(z.real), float(z.imag)]
+    tables.ginfo.append([BK_TRIG, slot, pidx, dim, off, 0, 0, 0])
+
+
+def _coef_record(tables: Tables, slot: int, t: DiagTerm):
+    """Builder record writing the phase coefficient of term t (in turns) to ptab[slot]."""
+    off = len(tables.cpool)
+    if t.param is None:
+        tables.cpool += [0.0, t.const / TWO_PI]
+        tables.ginfo.append([BK_COEF, slot, 0, 1, off, 0, 0, 0])
+    else:
+        tables.cpool += [t.param.scale / TWO_PI, (t.const + t.param.offset) / TWO_PI]
+        tables.ginfo.append([BK_COEF, slot, t.param.index, 1, off, 0, 0, 0])
+
+
 def _coef_slot(tables: Tables, gi: int, ti: int, t: DiagTerm):
     key = (gi, "d", ti)
     if key in tables._slot_cache:
@@ -476,8 +526,24 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
         regphys = {pp.tile_bits[b]: j for j, b in enumerate(rd.reg_tb)}
         ops = []
         nops = 0
-        # consecutive diagonal gates are merged into one DIAG op
+        # consecutive diagonal gates are merged into one DIAG op; consecutive 1-qubit gates on
+        # distinct register bits into one G1M op (they commute)
         pend_diag = []
+        pend_g1 = {}
+
+        def flush_g1():
+            nonlocal nops
+            if not pend_g1:
+                return
+            mk = 0
+            base = tables.alloc(8 * R)  # the R matrices of one G1M op are contiguous
+            for j, gi in pend_g1.items():
+                g = gates[gi]
+                mk |= (1 << j) | (g1_kind(g) << (8 + 2 * j))
+                _matrix_record(tables, base + 8 * j, g)
+            ops.extend([OP_G1M, mk, base])
+            nops += 1
+            pend_g1.clear()
 
         def flush_diag():
             nonlocal nops
@@ -486,7 +552,6 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
             A_, B_, C_ = [], [], []
             for gi in pend_diag:
                 for ti, t in enumerate(gates[gi].diag):
-                    slot = _coef_slot(tables, gi, ti, t)
                     pbits = [n - 1 - q for q in t.qubits]
                     rbits = [regphys[p] for p in pbits if p in regphys]
                     nmask = 0
@@ -494,31 +559,40 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
                         if p not in regphys:
                             nmask |= 1 << p
                     if len(rbits) == 0:
-                        A_.append((nmask, slot))
+                        A_.append((nmask, t))
                     elif len(rbits) == 1:
-                        B_.append((rbits[0], nmask, slot))
+                        B_.append((rbits[0], nmask, t))
                     elif nmask == 0:
                         rm = 0
                         for j in rbits:
                             rm |= 1 << j
-                        C_.append((rm, slot))
+                        C_.append((rm, t))
                     else:
                         raise NotImplementedError(
                             "diagonal term with >=2 register bits and non-register bits"
                         )
-            ops.extend([OP_DIAG, len(A_), len(B_), len(C_)])
-            for m, s in A_:
-                ops.extend([m, s])
-            for j, m, s in B_:
-                ops.extend([j, m, s])
-            for m, s in C_:
-                ops.extend([m, s])
+            # coefficients live contiguously in the per-batch table (bulk scalar loads), padded
+            # to a multiple of DIAG_CHUNK with zero terms
+            padA = (-len(A_)) % DIAG_CHUNK
+            padB = (-len(B_)) % DIAG_CHUNK
+            nA, nB, nC = len(A_) + padA, len(B_) + padB, len(C_)
+            base = tables.alloc(nA + nB + nC)
+            zero = DiagTerm((), 0.0, None)
+            terms = [t for _, t in A_] + [zero] * padA + [t for _, _, t in B_] + [zero] * padB + [t for _, t in C_]
+            for k_, t in enumerate(terms):
+                _coef_record(tables, base + k_, t)
+            ops.extend([OP_DIAG, nA, nB, nC, base])
+            ops.extend([m for m, _ in A_] + [0] * padA)
+            ops.extend([m for _, m, _ in B_] + [0] * padB)
+            ops.extend([j for j, _, _ in B_] + [0] * padB)
+            ops.extend([m for m, _ in C_])
             nops += 1
             pend_diag.clear()
 
         for gi in rd.gates:
             g = gates[gi]
             if g.is_diag:
+                flush_g1()
                 pend_diag.append(gi)
                 if not batch_diag:
                     flush_diag()
@@ -527,14 +601,18 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
             tbs = [tb_of_phys[n - 1 - q] for q in g.qubits]
             js = [reg_of_tb[b] for b in tbs]
             if len(js) == 1:
-                ops.extend([OP_G1, js[0] | (g1_kind(g) << 8), _gate_slot(tables, gi, g, False)])
+                if js[0] in pend_g1:
+                    flush_g1()
+                pend_g1[js[0]] = gi
             elif len(js) == 2:
+                flush_g1()
                 swap = js[0] > js[1]
                 ja, jb = (js[1], js[0]) if swap else (js[0], js[1])
-                ops.extend([OP_G2, ja, jb, _gate_slot(tables, gi, g, swap)])
+                ops.extend([OP_G2, ja | (g2_kind(g, swap) << 8), jb, _gate_slot(tables, gi, g, swap)])
+                nops += 1
             else:
                 raise NotImplementedError
-            nops += 1
+        flush_g1()
         flush_diag()
         rr[0] = nops
         rr[1] = len(ops)
@@ -570,6 +648,7 @@ class CompiledPlan:
 def compile_plan(gates: List[GateRec], n: int, cfg: PlanConfig, nparams: int = 0) -> CompiledPlan:
     passes = schedule(gates, n, cfg)
     tables = Tables()
+    tables.ctab += [0.0] * 8  # dummy matrix for the unused slots of G1M ops
     descs = [encode_pass(gates, n, cfg, pp, tables) for pp in passes]
     ginfo = np.array(tables.ginfo, dtype=np.int32).reshape(-1, 8)
     return CompiledPlan(

@@ -1,0 +1,202 @@
+"""Parity tests proper (run with -m gpu on an MI355X): the HIP path, called through the public
+Circuit API -> ctypes C ABI -> libtcmi.so, against the CPU oracle on the same seeded inputs and
+against the committed golden vectors.  Tolerances are BASELINE.json's: complex128 1e-10,
+complex64 1e-5 (max-abs on amplitudes)."""
+
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dense, gates as G, tn, workloads as W  # noqa: E402
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "hea_golden.npz"))
+TOL = {"complex64": 1e-5, "complex128": 1e-10}
+
+
+@pytest.fixture(params=["complex64", "complex128"])
+def tcd(request):
+    import torch
+    import tcmi as tc
+    from tcmi import _lib
+
+    assert torch.cuda.is_available()
+    _lib.lib()  # the HIP extension must be the thing that runs
+    tc.set_backend("hip")
+    tc.set_dtype(request.param)
+    tc.set_contractor("greedy")
+    yield tc
+    tc.set_dtype("complex64")
+    tc.set_contractor("greedy")
+
+
+def _np(tc, t):
+    return tc.backend.numpy(t)
+
+
+def test_reference_kats_through_product(tcd):
+    """reference tests/test_circuit.py:22-53, 95-99, 111-115, 397-401."""
+    tc = tcd
+    g = np.arange(16).reshape(2, 2, 2, 2)
+    qc = tc.Circuit(2); qc.unitary(0, 1, unitary=tc.gates.Gate(g))
+    assert np.real(_np(tc, qc.wavefunction())[2]) == 8
+    qc = tc.Circuit(2); qc.unitary(1, 0, unitary=tc.gates.Gate(g))
+    assert np.real(_np(tc, qc.wavefunction())[2]) == 4
+    qc = tc.Circuit(2); qc.unitary(0, unitary=tc.gates.Gate(np.arange(4).reshape(2, 2)))
+    assert np.real(_np(tc, qc.wavefunction())[2]) == 2
+    c = tc.Circuit(2); c.x(0)
+    np.testing.assert_allclose(_np(tc, c.amplitude("10")), 1.0)
+    c.CNOT(0, 1)
+    np.testing.assert_allclose(_np(tc, c.amplitude("11")), 1.0)
+    c = tc.Circuit(2, inputs=np.eye(4)[2]); c.iswap(0, 1)
+    np.testing.assert_allclose(_np(tc, c.state()), G.iswap(1.0)[:, 2], atol=1e-6)
+    c = tc.Circuit(1); c.X(0); c.SD(0)
+    np.testing.assert_allclose(_np(tc, c.state()), np.array([0.0, -1.0j]), atol=1e-6)
+    c = tc.Circuit(1); c.H(0)
+    np.testing.assert_allclose(_np(tc, c.state()), np.array([1, 1]) / np.sqrt(2), atol=1e-6)
+    assert tuple(c.wavefunction("ket").shape) == (2, 1) and tuple(c.wavefunction("bra").shape) == (1, 2)
+
+
+@pytest.mark.parametrize("n,d", [(4, 2), (8, 3), (10, 4), (12, 4)])
+def test_golden_hea_b(tcd, n, d):
+    tc = tcd
+    params = GOLD[f"hea_b_{n}_{d}_params"]
+    c = tc.Circuit(n)
+    W.hea_b(c, n, d, tc.backend.convert_to_tensor(params, dtype=tc.rdtypestr), zz=tc.gates._zz_matrix)
+    psi = _np(tc, c.wavefunction())
+    np.testing.assert_allclose(psi, GOLD[f"hea_b_{n}_{d}_state"], atol=TOL[tc.dtypestr])
+
+
+def test_golden_config1_and_hea_a(tcd):
+    tc = tcd
+    c = tc.Circuit(10)
+    W.hea_b(c, 10, 4, tc.backend.ones([8, 10], dtype=tc.rdtypestr), zz=tc.gates._zz_matrix)
+    np.testing.assert_allclose(_np(tc, c.wavefunction()), GOLD["hea_b_10_4_ones_state"], atol=TOL[tc.dtypestr])
+    c = tc.Circuit(9)
+    W.hea_a(c, 9, 3, GOLD["hea_a_9_3_params"])  # python-float parameters
+    np.testing.assert_allclose(_np(tc, c.wavefunction()), GOLD["hea_a_9_3_state"], atol=TOL[tc.dtypestr])
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 8, 11, 13, 15, 18])
+def test_mixed_gate_set_vs_oracle(tcd, n):
+    """Every supported gate family, arbitrary qubit pairs, both orientations; ragged sizes from a
+    single qubit (padded tile) to multi-pass plans."""
+    tc = tcd
+    rng = np.random.default_rng(n)
+    c = tc.Circuit(n)
+    ops = []
+
+    def both(name, qs, mat, **kw):
+        getattr(c, name)(*qs, **kw)
+        ops.append((mat, list(qs)))
+
+    for layer in range(3):
+        for q in range(n):
+            t = float(rng.uniform(0, 2 * np.pi))
+            kind = (q + layer) % 6
+            if kind == 0: both("rx", [q], G.rx(t), theta=t)
+            elif kind == 1: both("ry", [q], G.ry(t), theta=t)
+            elif kind == 2: both("rz", [q], G.rz(t), theta=t)
+            elif kind == 3: both("h", [q], G.H)
+            elif kind == 4: both("phase", [q], G.phase(t), theta=t)
+            else: both("u", [q], G.u(t, 0.3, 0.9), theta=t, phi=0.3, lbd=0.9)
+        if n >= 2:
+            for k in range(n):
+                a, b = (int(x) for x in rng.choice(n, 2, replace=False))
+                t = float(rng.uniform(0, 2 * np.pi))
+                kind = (k + layer) % 9
+                if kind == 0: both("cnot", [a, b], G.CNOT)
+                elif kind == 1: both("cz", [a, b], G.CZ)
+                elif kind == 2: both("swap", [a, b], G.SWAP)
+                elif kind == 3: both("rzz", [a, b], G.rzz(t), theta=t)
+                elif kind == 4: both("rxx", [a, b], G.rxx(t), theta=t)
+                elif kind == 5: both("iswap", [a, b], G.iswap(0.4), theta=0.4)
+                elif kind == 6: both("crx", [a, b], G.controlled(G.rx(t)), theta=t)
+                elif kind == 7: both("cphase", [a, b], G.controlled(G.phase(t)), theta=t)
+                else:
+                    u = G.random_two_qubit_gate(100 * n + k)
+                    c.any(a, b, unitary=u)
+                    ops.append((u, [a, b]))
+    psi = _np(tc, c.wavefunction())
+    np.testing.assert_allclose(psi, dense.run(n, ops), atol=TOL[tc.dtypestr])
+
+
+def test_inputs_and_negative_index(tcd):
+    tc = tcd
+    n = 6
+    rng = np.random.default_rng(0)
+    inp = rng.normal(size=2**n) + 1j * rng.normal(size=2**n)
+    inp /= np.linalg.norm(inp)
+    c = tc.Circuit(n, inputs=inp)
+    c.rx(-1, theta=0.4); c.cnot(-2, 0)
+    ref = dense.run(n, [(G.rx(0.4), [n - 1]), (G.CNOT, [n - 2, 0])], inputs=inp)
+    np.testing.assert_allclose(_np(tc, c.state()), ref, atol=TOL[tc.dtypestr])
+
+
+@pytest.mark.parametrize("opts", [{"lowbits": 3}, {"lowbits": 7}, {"R": 4, "LT": 8}, {"R": 5, "LT": 9}, {"R": 4, "LT": 9}])
+def test_plan_variants_on_device(opts):
+    import tcmi as tc
+
+    tc.set_backend("hip"); tc.set_dtype("complex64")
+    tc.set_contractor("greedy", **opts)
+    try:
+        n, d = 16, 3
+        params = np.random.default_rng(16).uniform(0, 2 * np.pi, [2 * d, n])
+        c = tc.Circuit(n)
+        W.hea_b(c, n, d, params, zz=tc.gates._zz_matrix)
+        c.cnot(0, 15); c.swap(3, 9)
+        ref = dense.run(n, W.hea_b_ops(n, d, params) + [(G.CNOT, [0, 15]), (G.SWAP, [3, 9])])
+        np.testing.assert_allclose(tc.backend.numpy(c.state()), ref, atol=1e-5)
+    finally:
+        tc.set_contractor("greedy")
+
+
+def test_vmap_batched_states(tcd):
+    """reference abstract_backend.py:2520-2539: vmap over the leading axis == per-sample calls,
+    executed as ONE batched launch per pass."""
+    tc = tcd
+    n, d, B = 10, 2, 5
+    pbs = np.random.default_rng(9).uniform(0, 2 * np.pi, [B, 2 * d, n])
+
+    def f(p):
+        c = tc.Circuit(n)
+        W.hea_b(c, n, d, p, zz=tc.gates._zz_matrix)
+        return c.state()
+
+    out = _np(tc, tc.backend.vmap(f)(tc.backend.convert_to_tensor(pbs, dtype=tc.rdtypestr)))
+    assert out.shape == (B, 2**n)
+    for b in range(B):
+        np.testing.assert_allclose(out[b], dense.run(n, W.hea_b_ops(n, d, pbs[b])), atol=TOL[tc.dtypestr])
+
+
+def test_full_size_config2_vs_oracle_and_properties():
+    """BASELINE config 2 at full size (n=24, d=8, complex64): max-abs parity with the oracle's TN
+    contraction (complex128), unit norm, and linearity of the executor in the input state."""
+    import torch
+    import tcmi as tc
+
+    tc.set_backend("hip"); tc.set_dtype("complex64")
+    n, d, params = W.config_params(2)
+    c = tc.Circuit(n)
+    W.hea_b(c, n, d, tc.backend.convert_to_tensor(params), zz=tc.gates._zz_matrix)
+    psi = c.state()
+    assert abs(float((psi.abs().double() ** 2).sum()) - 1.0) < 1e-5
+    oc = tn.Circuit(n, dtype=np.complex128)
+    W.hea_b(oc, n, d, params.astype(np.float64))
+    ref = oc.wavefunction()
+    assert np.abs(tc.backend.numpy(psi) - ref).max() < 1e-5
+    # linearity: U(a x + b y) = a U x + b U y on random inputs (size-independent property)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(2**n, dtype=torch.complex64, device="cuda", generator=g)
+    y = torch.randn(2**n, dtype=torch.complex64, device="cuda", generator=g)
+    cc = c._compiled()
+    p = c._param_tensor()
+    ux = cc.state(p, inputs=x)[0].clone()
+    uy = cc.state(p, inputs=y)[0].clone()
+    uxy = cc.state(p, inputs=0.3 * x - 1.7j * y)[0]
+    rel = float((uxy - (0.3 * ux - 1.7j * uy)).abs().max() / uxy.abs().max())
+    assert rel < 1e-5
+    # unitarity: norms are preserved
+    assert abs(float(torch.linalg.vector_norm(ux) / torch.linalg.vector_norm(x)) - 1) < 1e-5

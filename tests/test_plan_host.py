@@ -1,0 +1,154 @@
+"""Host logic on CPU: the plan compiler's pass descriptors are executed by the numpy emulator
+(oracle/plan_emulator.py, test infrastructure) and compared with the dense oracle."""
+
+import numpy as np
+import pytest
+
+import tcmi as tc
+from tcmi import plan as P
+from tcmi.executor import pick_variant, structure_digest
+from oracle import dense, gates as G, plan_emulator as E, workloads as W
+
+
+def _mixed(n, d, seed):
+    rng = np.random.default_rng(seed)
+    pb = rng.uniform(0, 2 * np.pi, [2 * d, n])
+    pa = rng.uniform(0, 2 * np.pi, [d, n])
+    c = tc.Circuit(n)
+    W.hea_b(c, n, d, pb, zz=tc.gates._zz_matrix)
+    c.ry(0, theta=0.3)
+    c.u(1, theta=0.2, phi=0.5, lbd=0.7)
+    c.cnot(2, 3)
+    c.s(4)
+    c.cz(5, 1)
+    c.swap(0, 6)
+    c.cnot(7, 2)
+    W.hea_a(c, n, d, pa)
+    c.cphase(3, 7, theta=0.4)
+    c.rzz(0, 5, theta=0.9)
+    c.iswap(1, 2, theta=0.3)
+    c.phase(4, theta=1.1)
+    c.any(1, 6, unitary=G.random_two_qubit_gate(5))
+    ops = (
+        W.hea_b_ops(n, d, pb)
+        + [(G.ry(0.3), [0]), (G.u(0.2, 0.5, 0.7), [1]), (G.CNOT, [2, 3]), (G.S, [4]), (G.CZ, [5, 1]),
+           (G.SWAP, [0, 6]), (G.CNOT, [7, 2])]
+        + W.hea_a_ops(n, d, pa)
+        + [(G.controlled(G.phase(0.4)), [3, 7]), (G.rzz(0.9), [0, 5]), (G.iswap(0.3), [1, 2]),
+           (G.phase(1.1), [4]), (G.random_two_qubit_gate(5), [1, 6])]
+    )
+    return c, ops
+
+
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+@pytest.mark.parametrize("n,d", [(8, 2), (10, 3), (13, 2), (14, 2)])
+def test_plan_emulated_matches_dense(dtype, n, d):
+    c, ops = _mixed(n, d, seed=n)
+    ne, cfg = pick_variant(n, dtype)
+    assert ne == n
+    pl = P.compile_plan(c._gate_records(), n, cfg, nparams=len(c._params))
+    psi = E.run_plan(pl, np.array([float(x) for x in c._params]))
+    np.testing.assert_allclose(psi, dense.run(n, ops), atol=1e-12)
+    # every LDS exchange the planner emits is bank-conflict free for 8-byte elements
+    if dtype == "complex64":
+        for desc in pl.descs:
+            assert all(w == 1 and r == 1 for w, r in E.lds_conflicts(desc))
+
+
+@pytest.mark.parametrize("lowbits,R,LT", [(3, 2, 6), (5, 4, 8), (7, 5, 8), (5, 5, 9), (4, 3, 8)])
+def test_plan_variants(lowbits, R, LT):
+    n, d = max(R + LT, 12), 2
+    rng = np.random.default_rng(1)
+    pb = rng.uniform(0, 2 * np.pi, [2 * d, n])
+    c = tc.Circuit(n)
+    W.hea_b(c, n, d, pb, zz=tc.gates._zz_matrix)
+    c.cnot(0, n - 1)
+    c.any(n - 1, 1, unitary=G.random_two_qubit_gate(3))
+    cfg = P.PlanConfig(R=R, LT=LT, lowbits=lowbits, vec=2)
+    pl = P.compile_plan(c._gate_records(), n, cfg, nparams=len(c._params))
+    psi = E.run_plan(pl, np.array([float(x) for x in c._params]))
+    ref = dense.run(n, W.hea_b_ops(n, d, pb) + [(G.CNOT, [0, n - 1]), (G.random_two_qubit_gate(3), [n - 1, 1])])
+    np.testing.assert_allclose(psi, ref, atol=1e-12)
+    for pp in pl.passes:
+        assert pp.tile_bits[: min(lowbits, cfg.T)] == list(range(min(lowbits, cfg.T)))  # coalescing run
+        assert pp.rounds[0].reg_tb[0] == 0 and pp.rounds[-1].reg_tb[0] == 0          # 16-byte accesses
+
+
+def test_batched_table_builder():
+    n, d = 10, 2
+    rng = np.random.default_rng(2)
+    pbs = rng.uniform(0, 2 * np.pi, [3, 2 * d, n])
+    c = tc.Circuit(n)
+    W.hea_b(c, n, d, pbs[0], zz=tc.gates._zz_matrix)
+    _, cfg = pick_variant(n, "complex64")
+    pl = P.compile_plan(c._gate_records(), n, cfg, nparams=len(c._params))
+    order = []
+    for j in range(d):
+        order += [(2 * j) * n + i for i in range(n - 1)] + [(2 * j + 1) * n + i for i in range(n)]
+    pmat = pbs.reshape(3, -1)[:, order]
+    for b in range(3):
+        psi = E.run_plan(pl, pmat, batch_index=b)
+        np.testing.assert_allclose(psi, dense.run(n, W.hea_b_ops(n, d, pbs[b])), atol=1e-12)
+
+
+def test_diag_analysis():
+    """rz / phase / exp1(ZZ) / cz / cphase are recognised as phase polynomials; rx / h are not."""
+    pr = P.ParamRef(0, 1.0, 0.0)
+    s = tc.gates.rz_spec(0.0)[0]
+    t = P.diag_terms_trig(s.c0, s.c1, s.c2, (3,), P.ParamRef(0, s.scale, s.offset))
+    assert len(t) == 1 and t[0].qubits == (3,) and abs(t[0].param.scale + 0.5) < 1e-15
+    s = tc.gates.exp1_spec(tc.gates._zz_matrix, 0.0)[0]
+    t = P.diag_terms_trig(s.c0, s.c1, s.c2, (1, 2), P.ParamRef(0, s.scale, s.offset))
+    assert len(t) == 1 and t[0].qubits == (1, 2) and abs(t[0].param.scale + 1.0) < 1e-15
+    s = tc.gates.phase_spec(0.0)[0]
+    t = P.diag_terms_trig(s.c0, s.c1, s.c2, (0,), P.ParamRef(0, s.scale, s.offset))
+    assert {x.qubits for x in t} == {(), (0,)}
+    assert P.diag_terms_const(G.CZ, (0, 1)) is not None
+    assert P.diag_terms_const(G.H, (0,)) is None
+    s = tc.gates.rx_spec(0.0)[0]
+    assert P.diag_terms_trig(s.c0, s.c1, s.c2, (0,), pr) is None
+    # walsh coefficients reproduce the phases
+    ph = np.array([0.1, -0.4, 0.9, 2.0])
+    terms = P.walsh_terms(ph, (5, 7))
+    for x in range(4):
+        bits = {5: (x >> 1) & 1, 7: x & 1}
+        tot = sum(c * (-1) ** sum(bits[q] for q in sub) for sub, c in terms)
+        assert abs(tot - ph[x]) < 1e-14
+
+
+def test_gate_kinds():
+    recs = tc.Circuit(2)
+    c = tc.Circuit(3)
+    c.h(0); c.rx(1, theta=0.1); c.ry(2, theta=0.2); c.t(0); c.cnot(0, 1); c.cnot(2, 1); c.swap(0, 2)
+    r = c._gate_records()
+    assert P.g1_kind(r[0]) == 1 and P.g1_kind(r[1]) == 2 and P.g1_kind(r[2]) == 1
+    assert r[3].is_diag
+    assert P.g2_kind(r[4], False) == 1 and P.g2_kind(r[4], True) == 2 and P.g2_kind(r[6], False) == 3
+
+
+def test_structure_cache_key():
+    def build(theta):
+        c = tc.Circuit(4)
+        c.h(0); c.rx(1, theta=theta); c.cnot(0, 1)
+        return c
+    a, b = build(0.1), build(0.7)
+    assert structure_digest(4, "complex64", a._gate_records()) == structure_digest(4, "complex64", b._gate_records())
+    c3 = build(0.1); c3.x(2)
+    assert structure_digest(4, "complex64", a._gate_records()) != structure_digest(4, "complex64", c3._gate_records())
+
+
+def test_unsupported_gates_raise():
+    c = tc.Circuit(14)
+    c.toffoli(0, 1, 2)
+    _, cfg = pick_variant(14, "complex64")
+    with pytest.raises(NotImplementedError):
+        P.compile_plan(c._gate_records(), 14, cfg)
+
+
+def test_small_circuits_are_padded():
+    ne, cfg = pick_variant(3, "complex64")
+    assert ne == 8 and cfg.T == 8
+    ne, cfg = pick_variant(28, "complex64")
+    assert ne == 28 and (cfg.R, cfg.LT) == (5, 8)
+    ne, cfg = pick_variant(28, "complex128")
+    assert (cfg.R, cfg.LT) == (4, 8) and cfg.vec == 1
