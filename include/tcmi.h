@@ -55,10 +55,15 @@ int tcmi_build_tables(const int* ginfo, int nrec, const double* cpool, const voi
  * `ptab` = per-batch table written by tcmi_build_tables (real values of the state's precision).
  * Replaces: the pairwise loop  tn.contract_between -> backend.tensordot  plus the final
  * Node.reorder_edges -> backend.transpose  (tensorcircuit/cons.py:937-960), i.e. what
- * Circuit.wavefunction executes (tensorcircuit/circuit.py:701-721). */
+ * Circuit.wavefunction executes (tensorcircuit/circuit.py:701-721).
+ * Measurement passes (programs containing EXPECT ops, built by tcmi.plan.compile_measure_plan)
+ * accumulate the Pauli-string values <psi|P_t|psi> into eout[batch][2*t] (re, im; float64; the
+ * caller zeroes it) instead of storing the tile.  They replace the 2n-1 separate
+ * contractor([psi, psi*, op...]) reductions of Circuit.expectation
+ * (tensorcircuit/circuit.py:899-902, basecircuit.py:393-447); eout may be NULL otherwise. */
 int tcmi_run_pass(void* state, long long state_stride, int batch, int n, int R, int LT,
                   const int* desc, const void* ctab, const void* ptab, long long ptab_stride,
-                  int dtype, void* stream);
+                  double* eout, long long eout_stride, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

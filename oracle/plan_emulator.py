@@ -13,7 +13,7 @@ import numpy as np
 MAGIC = 0x54434D31
 HDR_WORDS = 24
 RR_WORDS = 50
-OP_G1, OP_G2, OP_DIAG, OP_G1M = 1, 2, 3, 4
+OP_G1, OP_G2, OP_DIAG, OP_G1M, OP_EXPECT = 1, 2, 3, 4, 5
 R_MAX = 6
 CONST_FLAG = 1 << 30
 BK_TRIG, BK_COEF = 1, 2
@@ -61,11 +61,13 @@ def _parity(x):
     return (x & np.uint64(1)).astype(np.int64)
 
 
-def run_pass(state, desc, ctab, ptab_row):
-    """Apply one pass descriptor in place to ``state`` (complex array of 2^n)."""
+def run_pass(state, desc, ctab, ptab_row, eout=None):
+    """Apply one pass descriptor in place to ``state`` (complex array of 2^n).  Measurement passes
+    accumulate into ``eout`` (complex array, one entry per Pauli term) and do not store."""
     d = np.asarray(desc).view(np.uint32).astype(np.int64)
     assert d[0] == MAGIC
     n, T, R, LT, nrounds = (int(x) for x in d[1:6])
+    flags = int(d[6])
     assert T == R + LT and state.size == 2**n
     tile_bits = [int(x) for x in d[8: 8 + T]]
     assert tile_bits == sorted(set(tile_bits))
@@ -173,6 +175,23 @@ def run_pass(state, desc, ctab, ptab_row):
                     phi += float(cf[nA + nB + e]) * z[None, None, :]
                 q += nC
                 regs = regs * np.exp(2j * np.pi * phi).astype(regs.dtype)
+            elif op == OP_EXPECT:
+                nZ, nX = int(d[q + 1]), int(d[q + 2])
+                q += 3
+                tidx = (wg_base[:, None] | tphys[None, :]).astype(np.uint64)
+                for _z in range(nZ):
+                    zr, zm, oi = int(d[q]), int(d[q + 1]), int(d[q + 2])
+                    sr = 1 - 2 * _parity(rid.astype(np.uint64) & np.uint64(zr))
+                    st = 1 - 2 * _parity(tidx & np.uint64(zm))
+                    eout[oi] += np.sum((np.abs(regs) ** 2) * sr[None, None, :] * st[:, :, None])
+                    q += 3
+                for _x in range(nX):
+                    xr, zr, zm, oi = (int(v) for v in d[q: q + 4])
+                    assert bin(xr).count("1") in (1, 2)
+                    sr = 1 - 2 * _parity(rid.astype(np.uint64) & np.uint64(zr))
+                    st = 1 - 2 * _parity(tidx & np.uint64(zm))
+                    eout[oi] += np.sum(np.conj(regs[..., rid ^ xr]) * regs * sr[None, None, :] * st[:, :, None])
+                    q += 4
             else:
                 raise ValueError(f"bad opcode {op} at word {q}")
         assert q == pc + RR_WORDS + opwords
@@ -182,7 +201,7 @@ def run_pass(state, desc, ctab, ptab_row):
             assert np.unique(slot).size == nth * NR and slot.max() < nth * NR
             lds = np.zeros((nwg, nth * NR), dtype=regs.dtype)
             lds[:, slot] = regs
-        else:
+        elif not (flags & 1):
             state[gidx] = regs
     assert pc == d.size
     return state
@@ -234,3 +253,12 @@ def lds_conflicts(desc, elem_bytes=8):
         r_ = ways(recs[k + 1][24: 24 + LT], recs[k + 1][18: 18 + R], 32, 32)
         out.append((w, r_))
     return out
+
+
+def run_measure_plan(mplan, state):
+    """Execute a MeasurePlan on a flat state; returns <psi|P_t|psi> per term (complex128)."""
+    eout = np.zeros(len(mplan.terms), dtype=np.complex128)
+    st = np.array(state, dtype=np.complex128)
+    for desc in mplan.descs:
+        run_pass(st, desc, np.zeros(8), np.zeros(0), eout)
+    return np.array([eout[i] * (1j) ** t.ny for i, t in enumerate(mplan.terms)])

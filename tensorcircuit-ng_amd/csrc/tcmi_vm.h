@@ -16,6 +16,11 @@
 //        A: coef * (-1)^parity(thread_index & mask)
 //        B: coef * (-1)^parity(thread_index & mask) * z_j(r)
 //        C: coef * (-1)^parity(r & rmask)
+//   EXPECT {5, nZ, nX, Z[nZ] = {zr, zmask, out}, X[nX] = {xr, zr, zmask, out}}  Pauli-string partial sums
+//        sum_r (-1)^parity(r & zr) (-1)^parity(thread_index & zmask) conj(a[r ^ xr]) a[r]  accumulated
+//        (atomicAdd, double) into eout[2*out], eout[2*out+1]; xr = register-bit mask of the X/Y bits
+//        (one or two bits), zr / zmask = sign bits (Z and Y) inside / outside the register bits.
+// desc[6] flags: bit 0 = do not store the tile (measurement pass).
 // slot = offset (in reals) into the per-batch table, or into the constant table if TCMI_CONST_FLAG.
 #ifndef TCMI_VM_H
 #define TCMI_VM_H
@@ -30,6 +35,8 @@
 #define TCMI_OP_DIAG 3
 #define TCMI_OP_G1M 4
 #define TCMI_DIAG_CHUNK 8
+#define TCMI_OP_EXPECT 5
+#define TCMI_FLAG_NOSTORE 1
 #define TCMI_CONST_FLAG (1 << 30)
 #define TCMI_BK_TRIG 1
 #define TCMI_BK_COEF 2

@@ -198,13 +198,56 @@ __device__ __forceinline__ void dispatch_g2(typename Cx<F>::type (&a)[NR], int j
   }
 }
 
-template <typename F, int R, int LT>
+// ---- fused Pauli-sum expectation (K4) ------------------------------------------------------------
+template <typename F>
+__device__ __forceinline__ F wave_sum(F v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// sum_r sgn(r & zr) * conj(a[r ^ XR]) * a[r]   (XR = compile-time register-bit mask of the X/Y bits)
+template <typename F, int NR, int XR>
+__device__ __forceinline__ void expect_x(const typename Cx<F>::type (&a)[NR], uint32_t zr, F& re, F& im) {
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const auto b = a[r ^ XR];
+    const auto v = a[r];
+    const F sr = (__popc((uint32_t)r & zr) & 1) ? (F)-1 : (F)1;
+    const F tr = fma_<F>(b.y, v.y, b.x * v.x);
+    const F ti = fma_<F>(-b.y, v.x, b.x * v.y);
+    re = fma_<F>(sr, tr, re);
+    im = fma_<F>(sr, ti, im);
+  }
+}
+
+#define TCMI_EX_CASE(X) \
+  case X:               \
+    if constexpr (X < NR) expect_x<F, NR, X>(a, zr, re, im); \
+    break;
+
+template <typename F, int NR>
+__device__ __forceinline__ void dispatch_expect_x(const typename Cx<F>::type (&a)[NR], int xr, uint32_t zr, F& re, F& im) {
+  switch (xr) {  // one or two X/Y bits among the register bits
+    TCMI_EX_CASE(1) TCMI_EX_CASE(2) TCMI_EX_CASE(4) TCMI_EX_CASE(8) TCMI_EX_CASE(16) TCMI_EX_CASE(32)
+    TCMI_EX_CASE(3) TCMI_EX_CASE(5) TCMI_EX_CASE(6) TCMI_EX_CASE(9) TCMI_EX_CASE(10) TCMI_EX_CASE(12)
+    TCMI_EX_CASE(17) TCMI_EX_CASE(18) TCMI_EX_CASE(20) TCMI_EX_CASE(24)
+    TCMI_EX_CASE(33) TCMI_EX_CASE(34) TCMI_EX_CASE(36) TCMI_EX_CASE(40) TCMI_EX_CASE(48)
+    default: break;
+  }
+}
+
+// MODE 0: gate passes (G1M / G2 / DIAG).  MODE 1: measurement passes (EXPECT only).  Separate
+// instantiations keep each kernel's control-flow graph (and register allocation) small.
+template <typename F, int R, int LT, int MODE>
 __global__ __launch_bounds__(1 << LT) void pass_kernel(typename Cx<F>::type* __restrict__ state,
                                                         long long state_stride,
                                                         const int* __restrict__ desc_g,
                                                         const F* __restrict__ ctab_g,
                                                         const F* __restrict__ ptab_g,
-                                                        long long ptab_stride) {
+                                                        long long ptab_stride,
+                                                        double* __restrict__ eout,
+                                                        long long eout_stride) {
   using C = typename Cx<F>::type;
   constexpr int NR = 1 << R;
   constexpr int T = R + LT;
@@ -219,6 +262,8 @@ __global__ __launch_bounds__(1 << LT) void pass_kernel(typename Cx<F>::type* __r
   const KPtr<F> ptab = (KPtr<F>)(ptab_g + (long long)blockIdx.y * ptab_stride);
 
   const int nrounds = desc[5];
+  const int flags = desc[6];
+  if (eout) eout += (long long)blockIdx.y * eout_stride;
   // workgroup base index: deposit blockIdx.x into the non-tile bit positions
   unsigned long long x = blockIdx.x;
 #pragma unroll 1
@@ -267,14 +312,14 @@ __global__ __launch_bounds__(1 << LT) void pass_kernel(typename Cx<F>::type* __r
 #pragma unroll 1
     for (int o = 0; o < nops; ++o) {
       const int op = desc[q];
-      if (op == TCMI_OP_G2) {
+      if (MODE == 0 && op == TCMI_OP_G2) {
         const KPtr<F> mp = tab_ptr<F>(desc[q + 3], ctab, ptab);
         F m[32];
 #pragma unroll
         for (int i = 0; i < 32; ++i) m[i] = mp[i];
         dispatch_g2<F, NR, R>(a, desc[q + 1], desc[q + 2], m);
         q += 4;
-      } else if (op == TCMI_OP_G1M) {
+      } else if (MODE == 0 && op == TCMI_OP_G1M) {
         // one-qubit gates on the register bits in mask; the R matrices sit contiguously in the
         // per-batch table and are fetched with one burst of scalar loads
         const int mk = desc[q + 1];
@@ -291,7 +336,7 @@ __global__ __launch_bounds__(1 << LT) void pass_kernel(typename Cx<F>::type* __r
           dispatch_g1m<F, NR, R>(a, j, (mk >> (8 + 2 * j)) & 3, mm);
         }
         q += 3;
-      } else if (op == TCMI_OP_DIAG) {
+      } else if (MODE == 0 && op == TCMI_OP_DIAG) {
         const int nA = desc[q + 1], nB = desc[q + 2], nC = desc[q + 3];
         const KPtr<F> cf = ptab + desc[q + 4];
         q += 5;
@@ -363,6 +408,44 @@ __global__ __launch_bounds__(1 << LT) void pass_kernel(typename Cx<F>::type* __r
           a[r].x = v.x * c - v.y * s;
           a[r].y = v.x * s + v.y * c;
         }
+      } else if (MODE == 1 && op == TCMI_OP_EXPECT) {
+        // <psi|P_t|psi> partial sums for Pauli strings whose X/Y bits are register bits of this round
+        const int nZ = desc[q + 1], nX = desc[q + 2];
+        q += 3;
+        const uint32_t tidx = wg_base | tphys;
+        if (nZ > 0) {
+          F p[NR];
+#pragma unroll
+          for (int r = 0; r < NR; ++r) p[r] = fma_<F>(a[r].x, a[r].x, a[r].y * a[r].y);
+#pragma unroll 1
+          for (int e = 0; e < nZ; ++e) {
+            const uint32_t zr = (uint32_t)desc[q], zm = (uint32_t)desc[q + 1];
+            const int oi = desc[q + 2];
+            F acc = 0;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) acc += (__popc((uint32_t)r & zr) & 1) ? -p[r] : p[r];
+            if (__popc(tidx & zm) & 1) acc = -acc;
+            acc = wave_sum<F>(acc);
+            if ((tid & 63) == 0) atomicAdd(eout + 2 * oi, (double)acc);
+            q += 3;
+          }
+        }
+#pragma unroll 1
+        for (int e = 0; e < nX; ++e) {
+          const int xr = desc[q];
+          const uint32_t zr = (uint32_t)desc[q + 1], zm = (uint32_t)desc[q + 2];
+          const int oi = desc[q + 3];
+          F re = 0, im = 0;
+          dispatch_expect_x<F, NR>(a, xr, zr, re, im);
+          if (__popc(tidx & zm) & 1) { re = -re; im = -im; }
+          re = wave_sum<F>(re);
+          im = wave_sum<F>(im);
+          if ((tid & 63) == 0) {
+            atomicAdd(eout + 2 * oi, (double)re);
+            atomicAdd(eout + 2 * oi + 1, (double)im);
+          }
+          q += 4;
+        }
       } else {
         break;  // unknown opcode: host validates descriptors, never reached
       }
@@ -377,7 +460,7 @@ __global__ __launch_bounds__(1 << LT) void pass_kernel(typename Cx<F>::type* __r
 #pragma unroll
       for (int r = 0; r < NR; ++r) lds[tslot ^ reg_mask<R>(r, wsm)] = a[r];
       __syncthreads();
-    } else {
+    } else if (!(flags & TCMI_FLAG_NOSTORE)) {
       C* __restrict__ dst = state + (wg_base | tphys);
 #pragma unroll
       for (int r = 0; r < NR; r += VEC) {
@@ -449,14 +532,15 @@ static int set_msg(int code, const char* msg) {
   return code;
 }
 
-template <typename F, int R, int LT>
-static int launch_pass(void* state, long long state_stride, int batch, int n, const int* desc,
-                       const void* ctab, const void* ptab, long long ptab_stride, hipStream_t st) {
+template <typename F, int R, int LT, int MODE>
+static int launch_pass_mode(void* state, long long state_stride, int batch, int n, const int* desc,
+                       const void* ctab, const void* ptab, long long ptab_stride, double* eout,
+                       long long eout_stride, hipStream_t st) {
   using C = typename tcmi::Cx<F>::type;
   constexpr int T = R + LT;
   if (n < T) return set_msg(TCMI_ERR_ARG, "tcmi_run_pass: n smaller than the tile");
   const size_t lds = sizeof(C) << T;
-  auto kern = tcmi::pass_kernel<F, R, LT>;
+  auto kern = tcmi::pass_kernel<F, R, LT, MODE>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -464,10 +548,20 @@ static int launch_pass(void* state, long long state_stride, int batch, int n, co
   }
   dim3 grid(1u << (n - T), (unsigned)batch, 1), block(1u << LT, 1, 1);
   hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<C*>(state), state_stride, desc,
-                     reinterpret_cast<const F*>(ctab), reinterpret_cast<const F*>(ptab), ptab_stride);
+                     reinterpret_cast<const F*>(ctab), reinterpret_cast<const F*>(ptab), ptab_stride,
+                     eout, eout_stride);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_err("pass_kernel launch", e);
   return TCMI_OK;
+}
+
+template <typename F, int R, int LT>
+static int launch_pass(void* state, long long state_stride, int batch, int n, const int* desc,
+                       const void* ctab, const void* ptab, long long ptab_stride, double* eout,
+                       long long eout_stride, hipStream_t st) {
+  if (eout)
+    return launch_pass_mode<F, R, LT, 1>(state, state_stride, batch, n, desc, ctab, ptab, ptab_stride, eout, eout_stride, st);
+  return launch_pass_mode<F, R, LT, 0>(state, state_stride, batch, n, desc, ctab, ptab, ptab_stride, eout, eout_stride, st);
 }
 
 extern "C" {
@@ -484,13 +578,14 @@ int tcmi_device_count(void) {
 
 int tcmi_run_pass(void* state, long long state_stride, int batch, int n, int R, int LT,
                   const int* desc_dev, const void* ctab_dev, const void* ptab_dev,
-                  long long ptab_stride, int dtype, void* stream) {
+                  long long ptab_stride, double* eout_dev, long long eout_stride, int dtype,
+                  void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!state || !desc_dev || batch < 1) return set_msg(TCMI_ERR_ARG, "tcmi_run_pass: bad argument");
   if (n > 32) return set_msg(TCMI_ERR_ARG, "tcmi_run_pass: n > 32 unsupported");
 #define TCMI_CASE(FT, RR, LL) \
   if (R == RR && LT == LL)    \
-    return launch_pass<FT, RR, LL>(state, state_stride, batch, n, desc_dev, ctab_dev, ptab_dev, ptab_stride, st);
+    return launch_pass<FT, RR, LL>(state, state_stride, batch, n, desc_dev, ctab_dev, ptab_dev, ptab_stride, eout_dev, eout_stride, st);
   if (dtype == TCMI_C64) {
     TCMI_CASE(float, 5, 8)
     TCMI_CASE(float, 4, 8)

@@ -36,8 +36,8 @@ _SIGNATURES = {
     "tcmi_run_pass": (
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int,
-         ctypes.c_void_p],
+         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p,
+         ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p],
     ),
 }
 

@@ -242,10 +242,10 @@ class Circuit:
     # ---- outputs ------------------------------------------------------------------------------
     def wavefunction(self, form: str = "default") -> Tensor:
         """reference circuit.py:701-721."""
-        from .functional import circuit_state
+        from .expectation import _circuit_full_state
 
-        cc = self._compiled()
-        psi = circuit_state(cc, self._param_tensor(), self._input_tensor())
+        full = _circuit_full_state(self)  # cached until the next gate is applied
+        psi = full[..., : 2**self._nqubits] if full.shape[-1] != 2**self._nqubits else full
         if form == "ket":
             psi = psi.reshape(-1, 1)
         elif form == "bra":

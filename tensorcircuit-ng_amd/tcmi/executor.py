@@ -90,7 +90,7 @@ class CompiledCircuit:
         return P.GateRec(tuple(q + pad for q in g.qubits), g.c0, g.c1, g.c2, g.param, diag, g.name)
 
     # ------------------------------------------------------------------------------------
-    def state(self, params=None, inputs=None, out=None):
+    def state(self, params=None, inputs=None, out=None, full=False):
         """Run the plan.  ``params``: real tensor [B, P] (or [P]) on the device, or None when the
         circuit has no parameters.  Returns a complex tensor [B, 2^n]."""
         import torch
@@ -131,7 +131,7 @@ class CompiledCircuit:
                 "tcmi_build_tables",
             )
         self.run_passes(out, ptab, B, stream)
-        if self.n_exec != self.n:
+        if self.n_exec != self.n and not full:
             return out[:, : 2**self.n]
         return out
 
@@ -142,7 +142,7 @@ class CompiledCircuit:
             _lib.check(
                 lib.tcmi_run_pass(
                     state.data_ptr(), nel, B, self.n_exec, self.cfg.R, self.cfg.LT, d.data_ptr(),
-                    self.ctab.data_ptr(), ptab.data_ptr(), ptab.stride(0), self.code, stream,
+                    self.ctab.data_ptr(), ptab.data_ptr(), ptab.stride(0), None, 0, self.code, stream,
                 ),
                 "tcmi_run_pass",
             )
@@ -150,6 +150,75 @@ class CompiledCircuit:
     def stats(self):
         item = 8 if self.dtypestr == "complex64" else 16
         return self.plan.stats(item)
+
+
+def pick_measure_variant(n_exec: int, dtypestr: str) -> P.PlanConfig:
+    """Measurement passes use a smaller register tile than the gate passes (the EXPECT op keeps
+    |a|^2 and cross products live next to the amplitudes)."""
+    c64 = dtypestr == "complex64"
+    for R, LT in ([(4, 8), (2, 6)] if c64 else [(3, 8), (2, 6)]):
+        if R + LT <= n_exec:
+            return P.PlanConfig(R=R, LT=LT, lowbits=min(5, R + LT), vec=2 if c64 else 1)
+    raise ValueError("no measurement variant fits")
+
+
+class CompiledMeasure:
+    """A set of Pauli strings lowered to read-only measurement passes (fused K4 kernel)."""
+
+    def __init__(self, n: int, n_exec: int, strings, dtypestr: str, device=None):
+        import torch
+
+        self.n, self.n_exec, self.dtypestr = n, n_exec, dtypestr
+        pad = n_exec - n
+        terms = []
+        for ps in strings:
+            t = P.pauli_term_from_string(ps)
+            terms.append(P.PauliTerm(tuple(q + pad for q in t.x), tuple(q + pad for q in t.z)))
+        self.cfg = pick_measure_variant(n_exec, dtypestr)
+        self.plan = P.compile_measure_plan(terms, n_exec, self.cfg)
+        self.nterms = len(terms)
+        self.code = _lib.TCMI_C64 if dtypestr == "complex64" else _lib.TCMI_C128
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        self._lib = _lib.lib()
+        self.descs = [torch.from_numpy(np.ascontiguousarray(d)).to(self.device) for d in self.plan.descs]
+        rdt = torch.float32 if dtypestr == "complex64" else torch.float64
+        self.dummy = torch.zeros(8, dtype=rdt, device=self.device)
+        self.phase = torch.tensor([(1j) ** t.ny for t in terms], dtype=torch.complex128, device=self.device)
+
+    def run(self, state):
+        """state: complex tensor [B, 2^n_exec] (full executor buffer).  Returns complex128 [B, nterms]
+        with <psi|P_t|psi> for every term."""
+        import torch
+
+        B = state.shape[0]
+        assert state.shape[1] == 2**self.n_exec and state.is_contiguous()
+        out = torch.zeros(B, 2 * self.nterms, dtype=torch.float64, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        for d in self.descs:
+            _lib.check(
+                self._lib.tcmi_run_pass(
+                    state.data_ptr(), state.shape[1], B, self.n_exec, self.cfg.R, self.cfg.LT,
+                    d.data_ptr(), self.dummy.data_ptr(), self.dummy.data_ptr(), 0, out.data_ptr(),
+                    out.stride(0), self.code, stream,
+                ),
+                "tcmi_run_pass(measure)",
+            )
+        return torch.view_as_complex(out.reshape(B, self.nterms, 2)) * self.phase
+
+
+_MCACHE: Dict[Tuple, "CompiledMeasure"] = {}
+
+
+def get_measure(n, n_exec, strings, dtypestr) -> CompiledMeasure:
+    import torch
+
+    key = (n, n_exec, dtypestr, tuple(tuple(int(p) for p in ps) for ps in strings),
+           torch.cuda.current_device() if torch.cuda.is_available() else -1)
+    m = _MCACHE.get(key)
+    if m is None:
+        m = CompiledMeasure(n, n_exec, strings, dtypestr)
+        _MCACHE[key] = m
+    return m
 
 
 _CACHE: Dict[Tuple, CompiledCircuit] = {}

@@ -2,8 +2,16 @@
 
 ``torch.autograd.Function`` is used as plumbing only: it lets the reference's
 ``backend.value_and_grad / vmap / vvag`` contracts (``abstract_backend.py:2262-2293, 2520-2591``)
-compose with the HIP executor -- ``vmap`` maps to the executor's batch dimension (one launch over
-``[B, 2^n]``), ``grad`` to the adjoint-sweep kernels.
+compose with the HIP executor.  Two primitives:
+
+* ``StateFn``   params [P] -> full executor state [2^n_exec]; VJP = adjoint (reverse) sweep of the
+  compiled plan (``CompiledCircuit.vjp``): O(1) extra states instead of the reference's
+  store-every-intermediate reverse mode, which is infeasible at 28 qubits.
+* ``MeasureFn`` state -> <psi|P_t|psi> for a set of Pauli strings (fused measurement passes);
+  VJP = 2 * sum_t Re(g_t) P_t |psi>  (``tcmi_apply_pauli_sum``).
+
+Under ``torch.vmap`` both map the batch axis onto the executor's batch dimension (one launch per
+pass over ``[B, 2^n]``).
 """
 
 from typing import Any, List, Optional, Tuple
@@ -12,6 +20,8 @@ import numpy as np
 
 from . import cons
 
+_FNS = {}
+
 
 def _torch():
     import torch
@@ -19,35 +29,30 @@ def _torch():
     return torch
 
 
-_StateFn = None
-
-
-def _state_fn():
-    global _StateFn
-    if _StateFn is not None:
-        return _StateFn
+def _fns():
+    if _FNS:
+        return _FNS
     torch = _torch()
 
     class StateFn(torch.autograd.Function):
-        """params [P] -> state [2^n]; under vmap params [B, P] -> [B, 2^n] in one batched launch."""
-
         generate_vmap_rule = False
 
         @staticmethod
         def forward(params, cc, inputs):
-            out = cc.state(params, inputs)
+            out = cc.state(params, inputs, full=True)
             return out[0] if params.dim() == 1 else out
 
         @staticmethod
         def setup_context(ctx, inputs, output):
-            ctx.cc = inputs[1]
+            params, cc, inp = inputs
+            ctx.cc = cc
+            ctx.has_inputs = inp is not None
+            ctx.save_for_backward(params, output)
 
         @staticmethod
         def backward(ctx, grad_out):
-            raise NotImplementedError(
-                "Backend 'hip' has not implemented the VJP of `wavefunction`; differentiate "
-                "`expectation` outputs (adjoint sweep) instead."
-            )
+            params, psi = ctx.saved_tensors
+            return StateVjpFn.apply(params, psi, grad_out, ctx.cc), None, None
 
         @staticmethod
         def vmap(info, in_dims, params, cc, inputs):
@@ -56,18 +61,135 @@ def _state_fn():
                 return out.unsqueeze(0).expand(info.batch_size, *out.shape), 0
             p = params.movedim(in_dims[0], 0)
             lead = p.shape[:-1]
-            out = cc.state(p.reshape(-1, p.shape[-1]), inputs)
+            out = StateFn.apply(p.reshape(-1, p.shape[-1]), cc, inputs)
             return out.reshape(*lead, out.shape[-1]), 0
 
-    _StateFn = StateFn
-    return StateFn
+    class StateVjpFn(torch.autograd.Function):
+        """(params, psi, g) -> dL/dparams = Re <g | d psi / d params> via the adjoint sweep."""
+
+        generate_vmap_rule = False
+
+        @staticmethod
+        def forward(params, psi, g, cc):
+            single = params.dim() == 1
+            gp = cc.vjp(params.reshape(-1, params.shape[-1]), psi.reshape(-1, psi.shape[-1]),
+                        g.reshape(-1, g.shape[-1]))
+            return gp[0] if single else gp
+
+        @staticmethod
+        def setup_context(ctx, inputs, output):
+            pass
+
+        @staticmethod
+        def backward(ctx, *a):
+            raise NotImplementedError("Backend 'hip' has not implemented second-order derivatives.")
+
+        @staticmethod
+        def vmap(info, in_dims, params, psi, g, cc):
+            B = info.batch_size
+
+            def lift(t, d):
+                if d is None:
+                    return t.unsqueeze(0).expand(B, *t.shape)
+                return t.movedim(d, 0)
+
+            p, s, gg = lift(params, in_dims[0]), lift(psi, in_dims[1]), lift(g, in_dims[2])
+            lead = p.shape[:-1]
+            out = StateVjpFn.apply(p.reshape(-1, p.shape[-1]), s.reshape(-1, s.shape[-1]).contiguous(),
+                                   gg.reshape(-1, gg.shape[-1]).contiguous(), cc)
+            return out.reshape(*lead, out.shape[-1]), 0
+
+    class MeasureFn(torch.autograd.Function):
+        generate_vmap_rule = False
+
+        @staticmethod
+        def forward(state, cm):
+            single = state.dim() == 1
+            vals = cm.run(state.reshape(-1, state.shape[-1]).contiguous())
+            return vals[0] if single else vals
+
+        @staticmethod
+        def setup_context(ctx, inputs, output):
+            ctx.cm = inputs[1]
+            ctx.save_for_backward(inputs[0])
+
+        @staticmethod
+        def backward(ctx, grad_vals):
+            (state,) = ctx.saved_tensors
+            return MeasureVjpFn.apply(state, grad_vals, ctx.cm), None
+
+        @staticmethod
+        def vmap(info, in_dims, state, cm):
+            if in_dims[0] is None:
+                out = MeasureFn.apply(state, cm)
+                return out.unsqueeze(0).expand(info.batch_size, *out.shape), 0
+            s = state.movedim(in_dims[0], 0)
+            lead = s.shape[:-1]
+            out = MeasureFn.apply(s.reshape(-1, s.shape[-1]), cm)
+            return out.reshape(*lead, out.shape[-1]), 0
+
+    class MeasureVjpFn(torch.autograd.Function):
+        """(state, g_vals) -> cotangent of the state: 2 * sum_t Re(g_t) P_t |psi>."""
+
+        generate_vmap_rule = False
+
+        @staticmethod
+        def forward(state, g, cm):
+            single = state.dim() == 1
+            out = cm.apply_sum(state.reshape(-1, state.shape[-1]).contiguous(),
+                               g.reshape(-1, g.shape[-1]))
+            return out[0] if single else out
+
+        @staticmethod
+        def setup_context(ctx, inputs, output):
+            pass
+
+        @staticmethod
+        def backward(ctx, *a):
+            raise NotImplementedError("Backend 'hip' has not implemented second-order derivatives.")
+
+        @staticmethod
+        def vmap(info, in_dims, state, g, cm):
+            B = info.batch_size
+
+            def lift(t, d):
+                if d is None:
+                    return t.unsqueeze(0).expand(B, *t.shape)
+                return t.movedim(d, 0)
+
+            s, gg = lift(state, in_dims[0]), lift(g, in_dims[1])
+            lead = s.shape[:-1]
+            out = MeasureVjpFn.apply(s.reshape(-1, s.shape[-1]).contiguous(), gg.reshape(-1, gg.shape[-1]).contiguous(), cm)
+            return out.reshape(*lead, out.shape[-1]), 0
+
+    _FNS.update(StateFn=StateFn, StateVjpFn=StateVjpFn, MeasureFn=MeasureFn, MeasureVjpFn=MeasureVjpFn)
+    return _FNS
 
 
-def circuit_state(cc, params, inputs=None):
-    """State of a compiled circuit; ``params`` None (no parameters) or a real tensor [P]."""
+def circuit_state_full(circuit):
+    """Full executor buffer [2^n_exec] of the circuit state (differentiable w.r.t. the parameters)."""
+    cc = circuit._compiled()
+    params = circuit._param_tensor()
+    inputs = circuit._input_tensor()
     if params is None:
-        return cc.state(None, inputs)[0]
-    return _state_fn().apply(params, cc, inputs)
+        return cc.state(None, inputs, full=True)[0]
+    return _fns()["StateFn"].apply(params, cc, inputs)
+
+
+def circuit_state(circuit):
+    full = circuit_state_full(circuit)
+    n = circuit._nqubits
+    return full[..., : 2**n] if full.shape[-1] != 2**n else full
+
+
+def circuit_pauli_values(circuit, strings):
+    from .executor import get_measure
+    from .expectation import _circuit_full_state
+
+    cc = circuit._compiled()
+    cm = get_measure(circuit._nqubits, cc.n_exec, strings, cons.dtypestr)
+    state = _circuit_full_state(circuit)
+    return _fns()["MeasureFn"].apply(state, cm)
 
 
 def circuit_expectation(circuit, ops: List[Tuple[np.ndarray, Tuple[int, ...]]]):

@@ -40,6 +40,8 @@ OP_G1 = 1
 OP_G2 = 2
 OP_DIAG = 3
 OP_G1M = 4
+OP_EXPECT = 5
+FLAG_NOSTORE = 1
 DIAG_CHUNK = 8
 # G2 kinds: 0 general, 1 = CNOT(control ja, target jb), 2 = CNOT(control jb, target ja), 3 = SWAP
 CONST_FLAG = 1 << 30
@@ -223,7 +225,9 @@ class PlanConfig:
         return self.R + self.LT
 
 
-def schedule(gates: List[GateRec], n: int, cfg: PlanConfig) -> List[PassPlan]:
+def schedule(gates, n: int, cfg: PlanConfig, independent: bool = False) -> List[PassPlan]:
+    """``independent=True``: the items commute pairwise (measurement terms), nothing is ever blocked
+    by ordering and no store layout is needed."""
     T, R = cfg.T, cfg.R
     if n < T:
         raise ValueError(f"n={n} smaller than tile bits T={T}")
@@ -235,11 +239,12 @@ def schedule(gates: List[GateRec], n: int, cfg: PlanConfig) -> List[PassPlan]:
             )
     phys = lambda gi: [n - 1 - q for q in gates[gi].qubits]
     phys_res = lambda gi: [] if gates[gi].is_diag else phys(gi)
+    order_bits = (lambda gi: []) if independent else phys
     pending = list(range(len(gates)))
     passes = []
     all_bits = set(range(n))
     while pending:
-        S, chosen = _scan(gates, pending, phys, phys_res, T, set(range(L)), all_bits)
+        S, chosen = _scan(gates, pending, order_bits, phys_res, T, set(range(L)), all_bits)
         if not chosen:
             raise RuntimeError("scheduler made no progress")
         # fill the tile with the lowest unused bits (better contiguity)
@@ -250,18 +255,18 @@ def schedule(gates: List[GateRec], n: int, cfg: PlanConfig) -> List[PassPlan]:
             b += 1
         tile_bits = sorted(S)
         pp = PassPlan(tile_bits=tile_bits, gate_ids=list(chosen))
-        _schedule_rounds(gates, n, cfg, pp)
+        _schedule_rounds(gates, n, cfg, pp, independent)
         passes.append(pp)
         cs = set(chosen)
         pending = [gi for gi in pending if gi not in cs]
     return passes
 
 
-def _schedule_rounds(gates, n, cfg: PlanConfig, pp: PassPlan):
+def _schedule_rounds(gates, n, cfg: PlanConfig, pp: PassPlan, independent: bool = False):
     T, R = cfg.T, cfg.R
     tb_of_phys = {p: i for i, p in enumerate(pp.tile_bits)}
 
-    phys = lambda gi: [n - 1 - q for q in gates[gi].qubits]
+    phys = (lambda gi: []) if independent else (lambda gi: [n - 1 - q for q in gates[gi].qubits])
 
     def tb(gi):
         g = gates[gi]
@@ -318,7 +323,7 @@ def _schedule_rounds(gates, n, cfg: PlanConfig, pp: PassPlan):
         rounds.append(Round(reg, thr, chosen))
         cs = set(chosen)
         pending = [g for g in pending if g not in cs]
-        if not pending:
+        if not pending and not independent:
             reg, thr = finish_layout(forced_c, allowed_c)
             rounds.append(Round(reg, thr, []))
     pp.rounds = rounds
@@ -657,3 +662,104 @@ def compile_plan(gates: List[GateRec], n: int, cfg: PlanConfig, nparams: int = 0
         ptab_size=tables.ptab_size, ginfo=ginfo,
         cpool=np.array(tables.cpool, dtype=np.float64), nparams=nparams,
     )
+
+
+# ---- measurement plans (fused Pauli-sum expectation) ---------------------------------------------
+@dataclass
+class PauliTerm:
+    """One Pauli string: ``x`` = qubits carrying X or Y, ``z`` = qubits carrying Z or Y (a Y qubit is
+    in both).  <psi|P|psi> = i^{nY} * sum_idx (-1)^{popc(idx & zmask)} conj(psi[idx ^ xmask]) psi[idx];
+    the kernel returns the sum, the host applies i^{nY}."""
+
+    x: Tuple[int, ...]
+    z: Tuple[int, ...]
+
+    @property
+    def qubits(self):
+        return self.x
+
+    is_diag = False
+
+    @property
+    def ny(self):
+        return len(set(self.x) & set(self.z))
+
+
+def pauli_term_from_string(ps: Sequence[int]) -> PauliTerm:
+    """ps[i] in {0,1,2,3} = I,X,Y,Z on qubit i (reference abstractcircuit.py:1583-1603)."""
+    x = tuple(i for i, p in enumerate(ps) if p in (1, 2))
+    z = tuple(i for i, p in enumerate(ps) if p in (2, 3))
+    return PauliTerm(x, z)
+
+
+def encode_measure_pass(terms: List[PauliTerm], n: int, cfg: PlanConfig, pp: PassPlan) -> np.ndarray:
+    T, R, LT = cfg.T, cfg.R, cfg.LT
+    words = [0] * HDR_WORDS
+    words[0:7] = [MAGIC, n, T, R, LT, len(pp.rounds), FLAG_NOSTORE]
+    for i, p in enumerate(pp.tile_bits):
+        words[8 + i] = p
+    nr = len(pp.rounds)
+    exch = [exchange_masks(T, pp.rounds[k], pp.rounds[k + 1]) for k in range(nr - 1)]
+    for k, rd in enumerate(pp.rounds):
+        rr = [0] * RR_WORDS
+        for j, b in enumerate(rd.reg_tb):
+            rr[2 + j] = 1 << pp.tile_bits[b]
+        for i, b in enumerate(rd.thr_tb):
+            rr[8 + i] = 1 << pp.tile_bits[b]
+        if k > 0:
+            A = exch[k - 1]
+            for j, b in enumerate(rd.reg_tb):
+                rr[18 + j] = A[b]
+            for i, b in enumerate(rd.thr_tb):
+                rr[24 + i] = A[b]
+        if k < nr - 1:
+            A = exch[k]
+            for j, b in enumerate(rd.reg_tb):
+                rr[34 + j] = A[b]
+            for i, b in enumerate(rd.thr_tb):
+                rr[40 + i] = A[b]
+        regphys = {pp.tile_bits[b]: j for j, b in enumerate(rd.reg_tb)}
+        zs, xs = [], []
+        for ti in rd.gates:
+            t = terms[ti]
+            xr = 0
+            for q in t.x:
+                xr |= 1 << regphys[n - 1 - q]
+            zr, zm = 0, 0
+            for q in t.z:
+                p = n - 1 - q
+                if p in regphys:
+                    zr |= 1 << regphys[p]
+                else:
+                    zm |= 1 << p
+            if xr == 0:
+                zs += [zr, zm, ti]
+            else:
+                xs += [xr, zr, zm, ti]
+        ops = []
+        if zs or xs:
+            ops = [OP_EXPECT, len(zs) // 3, len(xs) // 4] + zs + xs
+        rr[0] = 1 if ops else 0
+        rr[1] = len(ops)
+        words += rr + ops
+    return np.array(words, dtype=np.int64).astype(np.uint32).view(np.int32)
+
+
+@dataclass
+class MeasurePlan:
+    n: int
+    cfg: PlanConfig
+    terms: List[PauliTerm]
+    passes: List[PassPlan]
+    descs: List[np.ndarray]
+
+
+def compile_measure_plan(terms: List[PauliTerm], n: int, cfg: PlanConfig) -> MeasurePlan:
+    for t in terms:
+        if len(t.x) > 2:
+            raise NotImplementedError(
+                "Pauli strings with more than two X/Y factors are not supported by the hip expectation kernel"
+            )
+    passes = schedule(terms, n, cfg, independent=True)
+    descs = [encode_measure_pass(terms, n, cfg, pp) for pp in passes]
+    return MeasurePlan(n, cfg, list(terms), passes, descs)

@@ -200,3 +200,57 @@ def test_full_size_config2_vs_oracle_and_properties():
     assert rel < 1e-5
     # unitarity: norms are preserved
     assert abs(float(torch.linalg.vector_norm(ux) / torch.linalg.vector_norm(x)) - 1) < 1e-5
+
+
+# ---- expectation (fused measurement passes, K4) ---------------------------------------------------
+def test_expectation_kats(tcd):
+    """reference tests/test_circuit.py:102-108, 317-323, 448-468, 550-564, 1501-1504."""
+    tc = tcd
+    atol = 1e-5 if tc.dtypestr == "complex64" else 1e-10
+    c = tc.Circuit(2); c.x(1); c.crx(1, 0, theta=0.3)
+    np.testing.assert_allclose(_np(tc, c.expectation([tc.gates._z_matrix, 0])), np.cos(0.3), atol=atol)
+    np.testing.assert_allclose(_np(tc, c.expectation([tc.gates._z_matrix, 0])), 0.95533645, atol=1e-5)
+    c = tc.Circuit(2); c.H(0)
+    np.testing.assert_allclose(_np(tc, c.expectation((tc.gates.z(), [0]))), 0, atol=1e-7)
+    for inp, want in (([0, 0, 0, 1.0], 1.0), ([0, 0, 1.0, 0], 1.0), ([1.0, 0, 0, 0], -1.0)):
+        c = tc.Circuit(2, inputs=np.array(inp)); c.X(0)
+        assert _np(tc, c.expectation((tc.gates.z(), [0]))) == want
+    c = tc.Circuit(2); c.x(0)
+    np.testing.assert_allclose(_np(tc, c.expectation_ps(z=[0])), -1, atol=atol)
+    np.testing.assert_allclose(_np(tc, c.expectation_ps(z=[1])), 1, atol=atol)
+    np.testing.assert_allclose(_np(tc, c.expectation_ps(ps=[3, 3])), -1, atol=atol)
+    c = tc.Circuit(1); c.h(0); c.sd(0)
+    np.testing.assert_allclose(_np(tc, c.expectation_ps(y=[0])), -1, atol=atol)
+    with pytest.raises(ValueError, match="Cannot measure two operators in one index"):
+        c.expectation((tc.gates.z(), [0]), (tc.gates.x(), [0]))
+
+
+@pytest.mark.parametrize("n,d", [(6, 2), (10, 4), (13, 2), (16, 2)])
+def test_tfim_energy_vs_oracle(tcd, n, d):
+    """The reference's TFIM loop (benchmarks/scripts/vqe_tc.py:75-81), term by term, plus random
+    Pauli strings with X/Y/Z factors and a generic (non-Pauli) two-qubit operator."""
+    tc = tcd
+    atol = 1e-5 if tc.dtypestr == "complex64" else 1e-10
+    rng = np.random.default_rng(7 * n + d)
+    params = GOLD[f"tfim_{n}_{d}_params"] if f"tfim_{n}_{d}_params" in GOLD.files else rng.normal(0, 0.5, [2 * d, n])
+    c = tc.Circuit(n)
+    W.hea_b(c, n, d, tc.backend.convert_to_tensor(params, dtype=tc.rdtypestr), zz=tc.gates._zz_matrix)
+    e = 0.0
+    for i in range(n):
+        e += -1.0 * c.expectation((tc.gates.x(), [i]))
+    for i in range(n - 1):
+        e += 1.0 * c.expectation((tc.gates.z(), [i]), (tc.gates.z(), [i + 1]))
+    psi = dense.run(n, W.hea_b_ops(n, d, params))
+    want = W.tfim_energy_dense(psi, n)
+    np.testing.assert_allclose(_np(tc, tc.backend.real(e)), want, atol=atol * n)
+    if f"tfim_{n}_{d}_energy" in GOLD.files:
+        np.testing.assert_allclose(_np(tc, tc.backend.real(e)), GOLD[f"tfim_{n}_{d}_energy"], atol=atol * n)
+    for k in range(6):
+        ps = [0] * n
+        qs = rng.choice(n, 3, replace=False)
+        ps[qs[0]] = int(rng.integers(1, 3)); ps[qs[1]] = int(rng.integers(1, 4)); ps[qs[2]] = 3
+        got = _np(tc, c.expectation_ps(ps=ps))
+        np.testing.assert_allclose(got, dense.pauli_string_expectation(psi, n, ps), atol=atol)
+    m = G.random_two_qubit_gate(3) + 0.3 * G.random_two_qubit_gate(4)
+    got = _np(tc, c.expectation((m, [n - 1, 1])))
+    np.testing.assert_allclose(got, dense.expectation(psi, n, (m, [n - 1, 1])), atol=atol)
