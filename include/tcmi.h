@@ -65,6 +65,33 @@ int tcmi_run_pass(void* state, long long state_stride, int batch, int n, int R, 
                   const int* desc, const void* ctab, const void* ptab, long long ptab_stride,
                   double* eout, long long eout_stride, int dtype, void* stream);
 
+/* ---- reverse mode (value_and_grad) -----------------------------------------------------------------
+ * Replaces the framework AD the reference relies on -- backend.value_and_grad / vvag
+ * (tensorcircuit/backends/abstract_backend.py:2262-2293, 2541-2591; jax_backend.py:854-952;
+ * pytorch_backend.py:775-878) -- for functions of the form  params -> Circuit -> expectation. */
+
+/* (sum_t w[b][t] P_t) |in>  ->  out, both [batch][2^n]; terms = int32[nterms][3] {xmask, zmask, nY}
+ * sorted by xmask (bit p = physical bit p of the flat index), w = float64[batch][nterms].
+ * With w = 2 Re(dL/d<P_t>) this is the cotangent of psi for L = f(<psi|P_t|psi>): the backward of
+ * Circuit.expectation (tensorcircuit/circuit.py:899-902). */
+int tcmi_apply_pauli_sum(const void* in, void* out, long long state_stride, int batch, int n,
+                         const int* terms, int nterms, const double* weights, long long weights_stride,
+                         int dtype, void* stream);
+
+/* Adjoint-sweep tables: U^dagger and K = (dU/dtheta) U^dagger per gate (records as in
+ * tcmi_build_tables with kinds TCMI_BK_UDAG / TCMI_BK_KMAT / TCMI_BK_COEF). */
+int tcmi_build_adjoint_tables(const int* ginfo, int nrec, const double* cpool, const void* params,
+                              long long params_stride, void* ptab, long long ptab_stride, int batch,
+                              int dtype, void* stream);
+
+/* One pass of the reversed plan over (psi, lambda), both updated in place:
+ * gout[batch][slot] += Re <lambda| K_g |psi> for every parametrised gate g of the pass (float64,
+ * caller zeroes it), then psi <- U_g^dagger psi, lambda <- U_g^dagger lambda.  After the last pass
+ * psi is the circuit's input state and gout holds dL/dtheta per gate slot. */
+int tcmi_run_adjoint_pass(void* psi, void* lam, long long state_stride, int batch, int n, int R, int LT,
+                          const int* desc, const void* ctab, const void* ptab, long long ptab_stride,
+                          double* gout, long long gout_stride, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -262,3 +262,165 @@ def run_measure_plan(mplan, state):
     for desc in mplan.descs:
         run_pass(st, desc, np.zeros(8), np.zeros(0), eout)
     return np.array([eout[i] * (1j) ** t.ny for i, t in enumerate(mplan.terms)])
+
+
+# ---- adjoint sweep (tcmi_run_adjoint_pass / tcmi_build_adjoint_tables) -----------------------------
+BK_UDAG, BK_KMAT = 3, 4
+
+
+def build_adjoint_table(ginfo, cpool, params, ptab_size):
+    params = np.atleast_2d(np.asarray(params, dtype=np.float64))
+    B = params.shape[0]
+    ptab = np.zeros((B, ptab_size), dtype=np.float64)
+    for rec in np.asarray(ginfo).reshape(-1, 8):
+        kind, slot, pidx, dim, off = (int(x) for x in rec[:5])
+        k, o = cpool[off], cpool[off + 1]
+        for b in range(B):
+            a = k * params[b, pidx] + o
+            if kind == BK_COEF:
+                ptab[b, slot] = a
+                continue
+            nn = dim * dim
+            c = [(cpool[off + 2 + 2 * nn * i: off + 2 + 2 * nn * (i + 1)]).reshape(nn, 2) for i in range(3)]
+            c = [(x[:, 0] + 1j * x[:, 1]).reshape(dim, dim) for x in c]
+            u = c[0] + np.cos(a) * c[1] + np.sin(a) * c[2]
+            du = k * (-np.sin(a) * c[1] + np.cos(a) * c[2])
+            m = u.conj().T if kind == BK_UDAG else du @ u.conj().T
+            ptab[b, slot: slot + 2 * nn: 2] = m.real.reshape(-1)
+            ptab[b, slot + 1: slot + 2 * nn: 2] = m.imag.reshape(-1)
+    return ptab
+
+
+def run_adjoint_pass(psi, lam, desc, ctab, ptab_row, gout):
+    """One backward pass on (psi, lam) in place; gradient slots accumulate into ``gout``."""
+    d = np.asarray(desc).view(np.uint32).astype(np.int64)
+    dsig = np.asarray(desc).astype(np.int64)  # signed view (slots may be -1)
+    n, T, R, LT, nrounds = (int(x) for x in d[1:6])
+    nwg, nth, NR = 2 ** (n - T), 2**LT, 2**R
+    tile_bits = [int(x) for x in d[8: 8 + T]]
+    wg = np.arange(nwg, dtype=np.uint64)
+    for p in tile_bits:
+        low = np.uint64((1 << p) - 1)
+        wg = ((wg & ~low) << np.uint64(1)) | (wg & low)
+    wg_base = wg.astype(np.uint32)
+    tid = np.arange(nth, dtype=np.uint32)
+    rid = np.arange(NR, dtype=np.uint32)
+
+    def tab(slot, cnt):
+        slot = int(slot)
+        if slot & CONST_FLAG:
+            return np.asarray(ctab)[(slot & ~CONST_FLAG): (slot & ~CONST_FLAG) + cnt]
+        return np.asarray(ptab_row)[slot: slot + cnt]
+
+    def cm(slot, dim):
+        m = tab(slot, 2 * dim * dim)
+        return (m[0::2] + 1j * m[1::2]).reshape(dim, dim)
+
+    pc = HDR_WORDS
+    regs = None  # [2, nwg, nth, NR]: psi, lambda
+    lds = None
+    for k in range(nrounds):
+        rr = d[pc: pc + RR_WORDS]
+        nops, opwords = int(rr[0]), int(rr[1])
+        tphys = _xor_masks(tid, rr[8: 8 + LT])
+        rphys = _xor_masks(rid, rr[2: 2 + R])
+        gidx = (wg_base[:, None, None] | tphys[None, :, None] | rphys[None, None, :]).astype(np.int64)
+        if k == 0:
+            regs = np.stack([psi[gidx], lam[gidx]])
+        else:
+            slot = (_xor_masks(tid, rr[24: 24 + LT])[:, None] ^ _xor_masks(rid, rr[18: 18 + R])[None, :]).astype(np.int64)
+            regs = lds[:, :, slot]
+        q = pc + RR_WORDS
+        tidx = (wg_base[:, None] | tphys[None, :]).astype(np.uint64)
+        for _ in range(nops):
+            op = int(d[q])
+            if op == OP_G1M:
+                mk, ubase, kmask, kbase = int(d[q + 1]), int(d[q + 2]), int(d[q + 3]), int(d[q + 4])
+                for j in range(R):
+                    if not (mk >> j) & 1:
+                        continue
+                    ud = cm(ubase + 8 * j, 2)
+                    r0 = rid[((rid >> j) & 1) == 0]
+                    r1 = r0 | (1 << j)
+                    if (kmask >> j) & 1:
+                        kk = cm(kbase + 8 * j, 2)
+                        a0, a1 = regs[0][..., r0], regs[0][..., r1]
+                        t0, t1 = kk[0, 0] * a0 + kk[0, 1] * a1, kk[1, 0] * a0 + kk[1, 1] * a1
+                        gout[int(dsig[q + 5 + j])] += np.sum(np.real(np.conj(regs[1][..., r0]) * t0 + np.conj(regs[1][..., r1]) * t1))
+                    x0, x1 = regs[..., r0].copy(), regs[..., r1].copy()
+                    regs[..., r0] = ud[0, 0] * x0 + ud[0, 1] * x1
+                    regs[..., r1] = ud[1, 0] * x0 + ud[1, 1] * x1
+                q += 5 + R
+            elif op == OP_G2:
+                ja, kind, jb = int(d[q + 1]) & 0xFF, int(d[q + 1]) >> 8, int(d[q + 2])
+                uslot, kslot, gslot = int(dsig[q + 3]), int(dsig[q + 4]), int(dsig[q + 5])
+                ud = cm(uslot, 4)
+                if kind == 1:
+                    ud = np.eye(4)[[0, 1, 3, 2]]
+                elif kind == 2:
+                    ud = np.eye(4)[[0, 3, 2, 1]]
+                elif kind == 3:
+                    ud = np.eye(4)[[0, 2, 1, 3]]
+                base = rid[(((rid >> ja) & 1) == 0) & (((rid >> jb) & 1) == 0)]
+                idx = [base | (xa << ja) | (xb << jb) for xa in (0, 1) for xb in (0, 1)]
+                if kslot >= 0:
+                    kk = cm(kslot, 4)
+                    a = [regs[0][..., ix] for ix in idx]
+                    acc = 0.0
+                    for row in range(4):
+                        t = sum(kk[row, col] * a[col] for col in range(4))
+                        acc += np.sum(np.real(np.conj(regs[1][..., idx[row]]) * t))
+                    gout[gslot] += acc
+                x = [regs[..., ix].copy() for ix in idx]
+                for row in range(4):
+                    regs[..., idx[row]] = sum(ud[row, col] * x[col] for col in range(4))
+                q += 6
+            elif op == OP_DIAG:
+                nA, nB, nC, base_slot = (int(x) for x in d[q + 1: q + 5])
+                q += 5
+                cf = np.asarray(ptab_row)[base_slot: base_slot + nA + nB + nC]
+                mA, mB, jB, mC = d[q: q + nA], d[q + nA: q + nA + nB], d[q + nA + nB: q + nA + 2 * nB], d[q + nA + 2 * nB: q + nA + 2 * nB + nC]
+                g0 = q + nA + 2 * nB + nC
+                gs = dsig[g0: g0 + nA + nB + nC]
+                q = g0 + nA + nB + nC
+                w = np.imag(np.conj(regs[1]) * regs[0])  # [nwg, nth, NR]
+                phi = np.zeros((nwg, nth, NR))
+                for e in range(nA + nB + nC):
+                    if e < nA:
+                        sgn = (1 - 2 * _parity(tidx & np.uint64(int(mA[e]))))[:, :, None] * np.ones(NR)[None, None, :]
+                    elif e < nA + nB:
+                        z = 1 - 2 * ((rid >> int(jB[e - nA])) & 1).astype(np.int64)
+                        sgn = (1 - 2 * _parity(tidx & np.uint64(int(mB[e - nA]))))[:, :, None] * z[None, None, :]
+                    else:
+                        z = 1 - 2 * _parity(rid.astype(np.uint64) & np.uint64(int(mC[e - nA - nB])))
+                        sgn = np.ones((nwg, nth))[:, :, None] * z[None, None, :]
+                    phi += float(cf[e]) * sgn
+                    if int(gs[e]) >= 0:
+                        gout[int(gs[e])] += np.sum(sgn * w)
+                regs = regs * np.exp(-2j * np.pi * phi)[None]
+            else:
+                raise ValueError(f"bad backward opcode {op}")
+        assert q == pc + RR_WORDS + opwords
+        pc = q
+        if k < nrounds - 1:
+            slot = (_xor_masks(tid, rr[40: 40 + LT])[:, None] ^ _xor_masks(rid, rr[34: 34 + R])[None, :]).astype(np.int64)
+            lds = np.zeros((2, nwg, nth * NR), dtype=regs.dtype)
+            lds[:, :, slot] = regs
+        else:
+            psi[gidx] = regs[0]
+            lam[gidx] = regs[1]
+    assert pc == d.size
+
+
+def run_adjoint_plan(aplan, params, psi, lam, nparams):
+    """Returns (dL/dparams, psi_in): Re<lam | d psi / d params> by the adjoint sweep (float64)."""
+    psi = np.array(psi, dtype=np.complex128)
+    lam = np.array(lam, dtype=np.complex128)
+    params = np.asarray(params, dtype=np.float64).reshape(-1) if nparams else np.zeros(1)
+    ptab = build_adjoint_table(aplan.ginfo, aplan.cpool, params, max(1, aplan.ptab_size))[0]
+    gout = np.zeros(len(aplan.gslot_param))
+    for desc in aplan.descs:
+        run_adjoint_pass(psi, lam, desc, aplan.ctab, ptab, gout)
+    g = np.zeros(max(nparams, 1))
+    np.add.at(g, aplan.gslot_param, gout * aplan.gslot_factor)
+    return g[:nparams], psi

@@ -1,0 +1,543 @@
+// tcmi adjoint sweep: the reverse-mode (VJP) kernel of the state-vector path for gfx950.
+//
+// The reference differentiates through the stored intermediates of every tensordot
+// (framework AD: jax.value_and_grad / torch.func.grad_and_value, reference
+// tensorcircuit/backends/jax_backend.py:854-952, pytorch_backend.py:775-786); at 28 qubits that
+// means hundreds of 2 GiB states.  Here the backward pass is an *adjoint sweep*: the forward plan
+// is replayed in reverse on two vectors at once -- psi (un-computed gate by gate with U^dagger) and
+// the cotangent lambda -- and every parametrised gate contributes
+//        dL/dtheta += Re < lambda_after | K | psi_after >,   K = (dU/dtheta) U^dagger
+// before both vectors are multiplied by U^dagger.  Memory: two states, independent of depth.
+//
+// Same tile-VM structure as tcmi_vm.hip (tile in registers, LDS exchanges between rounds), with both
+// vectors resident: 2 x 2^R amplitudes per thread.  Descriptor layout: tcmi_vm.h ("backward ops").
+
+#include "tcmi_dev.h"
+
+namespace tcmi {
+
+// Re sum conj(l) * (K a) over a pair on register bit J, then nothing is modified
+template <typename F, int NR, int J>
+__device__ __forceinline__ F grad_g1(const typename Cx<F>::type (&a)[NR], const typename Cx<F>::type (&l)[NR],
+                                     const F (&k)[8]) {
+  F acc = 0;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    if ((r >> J) & 1) continue;
+    const int r1 = r | (1 << J);
+    F t0r = k[0] * a[r].x, t0i = k[0] * a[r].y, t1r = k[4] * a[r].x, t1i = k[4] * a[r].y;
+    t0r = fma_<F>(-k[1], a[r].y, t0r);
+    t0i = fma_<F>(k[1], a[r].x, t0i);
+    t1r = fma_<F>(-k[5], a[r].y, t1r);
+    t1i = fma_<F>(k[5], a[r].x, t1i);
+    cfma<F>(k[2], k[3], a[r1], t0r, t0i);
+    cfma<F>(k[6], k[7], a[r1], t1r, t1i);
+    acc = fma_<F>(l[r].x, t0r, acc);
+    acc = fma_<F>(l[r].y, t0i, acc);
+    acc = fma_<F>(l[r1].x, t1r, acc);
+    acc = fma_<F>(l[r1].y, t1i, acc);
+  }
+  return acc;
+}
+
+template <typename F, int NR, int JA, int JB>
+__device__ __forceinline__ F grad_g2(const typename Cx<F>::type (&a)[NR], const typename Cx<F>::type (&l)[NR],
+                                     const F (&k)[32]) {
+  F acc = 0;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    if (((r >> JA) & 1) || ((r >> JB) & 1)) continue;
+    const int idx[4] = {r, r | (1 << JB), r | (1 << JA), r | (1 << JA) | (1 << JB)};
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+      F re = 0, im = 0;
+#pragma unroll
+      for (int col = 0; col < 4; ++col) cfma<F>(k[2 * (4 * row + col)], k[2 * (4 * row + col) + 1], a[idx[col]], re, im);
+      acc = fma_<F>(l[idx[row]].x, re, acc);
+      acc = fma_<F>(l[idx[row]].y, im, acc);
+    }
+  }
+  return acc;
+}
+
+template <typename F, int NR, int R, int J>
+__device__ __forceinline__ void bw_g1_bit(typename Cx<F>::type (&a)[NR], typename Cx<F>::type (&l)[NR], int kind,
+                                          bool has_k, const F (&ud)[8], const F (&kk)[8], double* gslot,
+                                          uint32_t tid) {
+  if (has_k) {
+    F g = grad_g1<F, NR, J>(a, l, kk);
+    g = wave_sum<F>(g);
+    if ((tid & 63) == 0) atomicAdd(gslot, (double)g);
+  }
+  if (kind == 1) { apply_g1<F, NR, J, 1>(a, ud); apply_g1<F, NR, J, 1>(l, ud); }
+  else if (kind == 2) { apply_g1<F, NR, J, 2>(a, ud); apply_g1<F, NR, J, 2>(l, ud); }
+  else { apply_g1<F, NR, J, 0>(a, ud); apply_g1<F, NR, J, 0>(l, ud); }
+}
+
+#define TCMI_BG2_CASE(A, B)                                                           \
+  case (A * 8 + B):                                                                   \
+    if constexpr (R > B) {                                                            \
+      if (has_k) {                                                                    \
+        F g = grad_g2<F, NR, A, B>(a, l, kk);                                         \
+        g = wave_sum<F>(g);                                                           \
+        if ((tid & 63) == 0) atomicAdd(gslot, (double)g);                             \
+      }                                                                               \
+      if (kind == 0) { apply_g2<F, NR, A, B>(a, ud); apply_g2<F, NR, A, B>(l, ud); }  \
+      else if (kind == 1) { apply_perm2<F, NR, A, B, 1>(a); apply_perm2<F, NR, A, B, 1>(l); } \
+      else if (kind == 2) { apply_perm2<F, NR, A, B, 2>(a); apply_perm2<F, NR, A, B, 2>(l); } \
+      else { apply_perm2<F, NR, A, B, 3>(a); apply_perm2<F, NR, A, B, 3>(l); }        \
+    }                                                                                 \
+    break;
+
+template <typename F, int R, int LT>
+__global__ __launch_bounds__(1 << LT) void adjoint_kernel(typename Cx<F>::type* __restrict__ psi,
+                                                           typename Cx<F>::type* __restrict__ lam,
+                                                           long long state_stride,
+                                                           const int* __restrict__ desc_g,
+                                                           const F* __restrict__ ctab_g,
+                                                           const F* __restrict__ ptab_g,
+                                                           long long ptab_stride,
+                                                           double* __restrict__ gout,
+                                                           long long gout_stride) {
+  using C = typename Cx<F>::type;
+  constexpr int NR = 1 << R;
+  constexpr int T = R + LT;
+  constexpr int VEC = (sizeof(F) == 4) ? 2 : 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  C* lds = reinterpret_cast<C*>(smem);
+  C* lds2 = lds + (1 << T);
+
+  const uint32_t tid = threadIdx.x;
+  psi += (long long)blockIdx.y * state_stride;
+  lam += (long long)blockIdx.y * state_stride;
+  gout += (long long)blockIdx.y * gout_stride;
+  const KInt desc = (KInt)desc_g;
+  const KPtr<F> ctab = (KPtr<F>)ctab_g;
+  const KPtr<F> ptab = (KPtr<F>)(ptab_g + (long long)blockIdx.y * ptab_stride);
+
+  const int nrounds = desc[5];
+  unsigned long long x = blockIdx.x;
+#pragma unroll 1
+  for (int i = 0; i < T; ++i) {
+    const int p = desc[8 + i];
+    const unsigned long long low = (1ull << p) - 1ull;
+    x = ((x & ~low) << 1) | (x & low);
+  }
+  const uint32_t wg_base = (uint32_t)x;
+
+  C a[NR], l[NR];
+  int pc = TCMI_HDR_WORDS;
+#pragma unroll 1
+  for (int k = 0; k < nrounds; ++k) {
+    const KInt rr = desc + pc;
+    const int nops = rr[0];
+    const uint32_t tphys = xor_masks<LT>(tid, rr + 8);
+    uint32_t rpm[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) rpm[j] = (uint32_t)rr[2 + j];
+
+    if (k == 0) {
+      const C* __restrict__ sa = psi + (wg_base | tphys);
+      const C* __restrict__ sl = lam + (wg_base | tphys);
+#pragma unroll
+      for (int r = 0; r < NR; r += VEC) {
+        const uint32_t off = reg_mask<R>(r, rpm);
+        if constexpr (VEC == 2) {
+          const float4 v = *reinterpret_cast<const float4*>(sa + off);
+          const float4 w = *reinterpret_cast<const float4*>(sl + off);
+          a[r].x = v.x; a[r].y = v.y; a[r + 1].x = v.z; a[r + 1].y = v.w;
+          l[r].x = w.x; l[r].y = w.y; l[r + 1].x = w.z; l[r + 1].y = w.w;
+        } else {
+          a[r] = sa[off];
+          l[r] = sl[off];
+        }
+      }
+    } else {
+      const uint32_t tslot = xor_masks<LT>(tid, rr + 24);
+      uint32_t rsm[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) rsm[j] = (uint32_t)rr[18 + j];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const uint32_t s = tslot ^ reg_mask<R>(r, rsm);
+        a[r] = lds[s];
+        l[r] = lds2[s];
+      }
+      __syncthreads();
+    }
+
+    int q = pc + TCMI_RR_WORDS;
+#pragma unroll 1
+    for (int o = 0; o < nops; ++o) {
+      const int op = desc[q];
+      if (op == TCMI_OP_G1M) {
+        // {4, mask|kinds<<8, ubase, kmask, kbase, gslot[R]}
+        const int mk = desc[q + 1], kmask = desc[q + 3];
+        const KPtr<F> up = ptab + desc[q + 2];
+        const KPtr<F> kp = ptab + desc[q + 4];
+#pragma unroll 1
+        for (int j = 0; j < R; ++j) {
+          if (!((mk >> j) & 1)) continue;
+          F ud[8], kk[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { ud[i] = up[8 * j + i]; kk[i] = kp[8 * j + i]; }
+          const int kind = (mk >> (8 + 2 * j)) & 3;
+          const bool has_k = (kmask >> j) & 1;
+          double* gs = gout + desc[q + 5 + j];
+          switch (j) {
+            case 0: bw_g1_bit<F, NR, R, 0>(a, l, kind, has_k, ud, kk, gs, tid); break;
+            case 1: if constexpr (R > 1) bw_g1_bit<F, NR, R, 1>(a, l, kind, has_k, ud, kk, gs, tid); break;
+            case 2: if constexpr (R > 2) bw_g1_bit<F, NR, R, 2>(a, l, kind, has_k, ud, kk, gs, tid); break;
+            case 3: if constexpr (R > 3) bw_g1_bit<F, NR, R, 3>(a, l, kind, has_k, ud, kk, gs, tid); break;
+            default: break;
+          }
+        }
+        q += 5 + R;
+      } else if (op == TCMI_OP_G2) {
+        // {2, ja|kind<<8, jb, uslot, kslot(-1 = none), gslot}
+        const int ja = desc[q + 1] & 0xff, kind = desc[q + 1] >> 8, jb = desc[q + 2];
+        const KPtr<F> up = tab_ptr<F>(desc[q + 3], ctab, ptab);
+        const bool has_k = desc[q + 4] >= 0;
+        const KPtr<F> kp = ptab + (has_k ? desc[q + 4] : 0);
+        double* gslot = gout + desc[q + 5];
+        F ud[32], kk[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { ud[i] = up[i]; kk[i] = has_k ? kp[i] : (F)0; }
+        switch (ja * 8 + jb) {
+          TCMI_BG2_CASE(0, 1) TCMI_BG2_CASE(0, 2) TCMI_BG2_CASE(0, 3)
+          TCMI_BG2_CASE(1, 2) TCMI_BG2_CASE(1, 3) TCMI_BG2_CASE(2, 3)
+          default: break;
+        }
+        q += 6;
+      } else if (op == TCMI_OP_DIAG) {
+        // {3, nA, nB, nC, base, maskA[nA], maskB[nB], jB[nB], rmaskC[nC], gsA[nA], gsB[nB], gsC[nC]}
+        // The table holds the FORWARD coefficients; the inverse phase is applied (conjugate).
+        const int nA = desc[q + 1], nB = desc[q + 2], nC = desc[q + 3];
+        const KPtr<F> cf = ptab + desc[q + 4];
+        q += 5;
+        const KInt mA = desc + q, mB = desc + q + nA, jB = desc + q + nA + nB, mC = desc + q + nA + 2 * nB;
+        const KInt gA = mC + nC, gB = gA + nA, gC = gB + nB;
+        q += 2 * nA + 3 * nB + 2 * nC;
+        const uint32_t tidx = wg_base | tphys;
+        // w[r] = Im(conj(lambda) psi): every term's gradient is a signed sum of w
+        F w[NR];
+        F w0 = 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          w[r] = fma_<F>(l[r].x, a[r].y, -l[r].y * a[r].x);
+          w0 += w[r];
+        }
+        F wj[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          F s = 0;
+#pragma unroll
+          for (int r = 0; r < NR; ++r) s += ((r >> j) & 1) ? -w[r] : w[r];
+          wj[j] = s;
+        }
+        double phi = 0.0;
+#pragma unroll 1
+        for (int e = 0; e < nA; ++e) {
+          const uint32_t m = (uint32_t)mA[e];
+          const bool neg = __popc(tidx & m) & 1;
+          const double c = (double)cf[e];
+          phi += neg ? -c : c;
+          const int gs = gA[e];
+          if (gs >= 0) {  // wave-uniform
+            F v = wave_sum<F>(neg ? -w0 : w0);
+            if ((tid & 63) == 0) atomicAdd(gout + gs, (double)v);
+          }
+        }
+        double cj[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) cj[j] = 0.0;
+#pragma unroll 1
+        for (int e = 0; e < nB; ++e) {
+          const uint32_t m = (uint32_t)mB[e];
+          const int jj = jB[e];
+          const bool neg = __popc(tidx & m) & 1;
+          const double c = (double)cf[nA + e];
+          const double sgn = neg ? -c : c;
+          F wsel = 0;
+#pragma unroll
+          for (int j = 0; j < R; ++j) {
+            cj[j] += (j == jj) ? sgn : 0.0;
+            wsel = (j == jj) ? wj[j] : wsel;
+          }
+          const int gs = gB[e];
+          if (gs >= 0) {
+            F v = wave_sum<F>(neg ? -wsel : wsel);
+            if ((tid & 63) == 0) atomicAdd(gout + gs, (double)v);
+          }
+        }
+        F ph[NR];
+        ph[0] = (F)(phi - rint(phi));
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const F c = (F)(cj[j] - rint(cj[j]));
+#pragma unroll
+          for (int r = 0; r < (1 << j); ++r) {
+            ph[r | (1 << j)] = ph[r] - c;
+            ph[r] += c;
+          }
+        }
+#pragma unroll 1
+        for (int e = 0; e < nC; ++e) {
+          const uint32_t rmask = (uint32_t)mC[e];
+          const F c = cf[nA + nB + e];
+          F s = 0;
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            const bool neg = __popc((uint32_t)r & rmask) & 1;
+            ph[r] += neg ? -c : c;
+            s += neg ? -w[r] : w[r];
+          }
+          const int gs = gC[e];
+          if (gs >= 0) {
+            F v = wave_sum<F>(s);
+            if ((tid & 63) == 0) atomicAdd(gout + gs, (double)v);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          F s, c;
+          sincos_turns<F>(ph[r], &s, &c);
+          const C v = a[r], u = l[r];
+          a[r].x = v.x * c + v.y * s;   // multiply by exp(-i phi)
+          a[r].y = v.y * c - v.x * s;
+          l[r].x = u.x * c + u.y * s;
+          l[r].y = u.y * c - u.x * s;
+        }
+      } else {
+        break;
+      }
+    }
+    pc += TCMI_RR_WORDS + rr[1];
+
+    if (k < nrounds - 1) {
+      const uint32_t tslot = xor_masks<LT>(tid, rr + 40);
+      uint32_t wsm[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) wsm[j] = (uint32_t)rr[34 + j];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const uint32_t s = tslot ^ reg_mask<R>(r, wsm);
+        lds[s] = a[r];
+        lds2[s] = l[r];
+      }
+      __syncthreads();
+    } else {
+      C* __restrict__ da = psi + (wg_base | tphys);
+      C* __restrict__ dl = lam + (wg_base | tphys);
+#pragma unroll
+      for (int r = 0; r < NR; r += VEC) {
+        const uint32_t off = reg_mask<R>(r, rpm);
+        if constexpr (VEC == 2) {
+          float4 v, w;
+          v.x = a[r].x; v.y = a[r].y; v.z = a[r + 1].x; v.w = a[r + 1].y;
+          w.x = l[r].x; w.y = l[r].y; w.z = l[r + 1].x; w.w = l[r + 1].y;
+          *reinterpret_cast<float4*>(da + off) = v;
+          *reinterpret_cast<float4*>(dl + off) = w;
+        } else {
+          da[off] = a[r];
+          dl[off] = l[r];
+        }
+      }
+    }
+  }
+}
+
+// out[idx] = sum_t w_t * i^{ny_t} * (-1)^{popc((idx ^ xm_t) & zm_t)} * in[idx ^ xm_t]
+// (= (sum_t w_t P_t) |in>): the cotangent of <psi|H|psi> w.r.t. psi, reference circuit.py:899-902.
+template <typename F>
+__global__ void pauli_sum_kernel(const typename Cx<F>::type* __restrict__ in,
+                                 typename Cx<F>::type* __restrict__ out, long long stride,
+                                 unsigned long long nelem, const int* __restrict__ terms, int nterms,
+                                 const double* __restrict__ w, long long wstride) {
+  using C = typename Cx<F>::type;
+  in += (long long)blockIdx.y * stride;
+  out += (long long)blockIdx.y * stride;
+  w += (long long)blockIdx.y * wstride;
+  const KInt tm = (KInt)terms;
+  const unsigned long long i0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long idx = i0; idx < nelem; idx += step) {
+    F re = 0, im = 0;
+    uint32_t last_xm = 0xffffffffu;
+    C v;
+    v.x = 0; v.y = 0;
+    for (int t = 0; t < nterms; ++t) {
+      const uint32_t xm = (uint32_t)tm[3 * t], zm = (uint32_t)tm[3 * t + 1];
+      const int ny = tm[3 * t + 2] & 3;
+      if (xm != last_xm) { v = in[idx ^ xm]; last_xm = xm; }  // terms are sorted by xmask
+      F c = (F)w[t];
+      if (__popc(((uint32_t)idx ^ xm) & zm) & 1) c = -c;
+      // multiply by i^ny
+      F pr = v.x, pi = v.y;
+      if (ny == 1) { pr = -v.y; pi = v.x; }
+      else if (ny == 2) { pr = -v.x; pi = -v.y; }
+      else if (ny == 3) { pr = v.y; pi = -v.x; }
+      re = fma_<F>(c, pr, re);
+      im = fma_<F>(c, pi, im);
+    }
+    C o;
+    o.x = re; o.y = im;
+    out[idx] = o;
+  }
+}
+
+// adjoint builder: U^dagger tables and K = (dU/dtheta) U^dagger for parametrised gates
+template <typename F>
+__global__ void build_adjoint_kernel(const int* __restrict__ ginfo, int nrec, const double* __restrict__ cpool,
+                                     const F* __restrict__ params, long long pstride, F* __restrict__ ptab,
+                                     long long tstride, int batch) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (g >= nrec || b >= batch) return;
+  const int* rec = ginfo + 8 * g;
+  const int kind = rec[0], slot = rec[1], pidx = rec[2], dim = rec[3], off = rec[4];
+  const double theta = (double)params[(long long)b * pstride + pidx];
+  const double kap = cpool[off];
+  const double ang = kap * theta + cpool[off + 1];
+  F* out = ptab + (long long)b * tstride + slot;
+  if (kind == TCMI_BK_COEF) {
+    out[0] = (F)(ang - rint(ang));
+    return;
+  }
+  double s, c;
+  sincos(ang, &s, &c);
+  const int nn = dim * dim;
+  const double* c0 = cpool + off + 2;
+  const double* c1 = c0 + 2 * nn;
+  const double* c2 = c1 + 2 * nn;
+  // U and dU (dim <= 4)
+  double ur[16], ui[16], dr[16], di[16];
+  for (int i = 0; i < nn; ++i) {
+    ur[i] = c0[2 * i] + c * c1[2 * i] + s * c2[2 * i];
+    ui[i] = c0[2 * i + 1] + c * c1[2 * i + 1] + s * c2[2 * i + 1];
+    dr[i] = kap * (-s * c1[2 * i] + c * c2[2 * i]);
+    di[i] = kap * (-s * c1[2 * i + 1] + c * c2[2 * i + 1]);
+  }
+  if (kind == TCMI_BK_UDAG) {
+    for (int r = 0; r < dim; ++r)
+      for (int q = 0; q < dim; ++q) {
+        out[2 * (r * dim + q)] = (F)ur[q * dim + r];
+        out[2 * (r * dim + q) + 1] = (F)(-ui[q * dim + r]);
+      }
+  } else if (kind == TCMI_BK_KMAT) {
+    // K = dU * U^dagger : K[r][q] = sum_m dU[r][m] * conj(U[q][m])
+    for (int r = 0; r < dim; ++r)
+      for (int q = 0; q < dim; ++q) {
+        double kr = 0, ki = 0;
+        for (int m = 0; m < dim; ++m) {
+          const double ar = dr[r * dim + m], ai = di[r * dim + m];
+          const double br = ur[q * dim + m], bi = -ui[q * dim + m];
+          kr += ar * br - ai * bi;
+          ki += ar * bi + ai * br;
+        }
+        out[2 * (r * dim + q)] = (F)kr;
+        out[2 * (r * dim + q) + 1] = (F)ki;
+      }
+  }
+}
+
+}  // namespace tcmi
+
+// ---- C ABI ------------------------------------------------------------------------------------
+extern "C" const char* tcmi_last_error(void);
+extern "C" int tcmi_set_error_(int code, const char* msg);
+
+template <typename F, int R, int LT>
+static int launch_adjoint(void* psi, void* lam, long long stride, int batch, int n, const int* desc,
+                          const void* ctab, const void* ptab, long long ptab_stride, double* gout,
+                          long long gout_stride, hipStream_t st) {
+  using C = typename tcmi::Cx<F>::type;
+  constexpr int T = R + LT;
+  if (n < T) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_run_adjoint_pass: n smaller than the tile");
+  const size_t lds = 2 * (sizeof(C) << T);
+  auto kern = tcmi::adjoint_kernel<F, R, LT>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));
+  }
+  dim3 grid(1u << (n - T), (unsigned)batch, 1), block(1u << LT, 1, 1);
+  hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<C*>(psi), reinterpret_cast<C*>(lam), stride,
+                     desc, reinterpret_cast<const F*>(ctab), reinterpret_cast<const F*>(ptab), ptab_stride,
+                     gout, gout_stride);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));
+  return TCMI_OK;
+}
+
+extern "C" {
+
+int tcmi_run_adjoint_pass(void* psi, void* lam, long long state_stride, int batch, int n, int R, int LT,
+                          const int* desc_dev, const void* ctab_dev, const void* ptab_dev,
+                          long long ptab_stride, double* gout_dev, long long gout_stride, int dtype,
+                          void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!psi || !lam || !desc_dev || !gout_dev || batch < 1 || n > 32)
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_run_adjoint_pass: bad argument");
+#define TCMI_CASE(FT, RR, LL) \
+  if (R == RR && LT == LL)    \
+    return launch_adjoint<FT, RR, LL>(psi, lam, state_stride, batch, n, desc_dev, ctab_dev, ptab_dev, ptab_stride, gout_dev, gout_stride, st);
+  if (dtype == TCMI_C64) {
+    TCMI_CASE(float, 4, 8)
+    TCMI_CASE(float, 2, 6)
+  } else if (dtype == TCMI_C128) {
+    TCMI_CASE(double, 3, 8)
+    TCMI_CASE(double, 2, 6)
+  }
+#undef TCMI_CASE
+  return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_run_adjoint_pass: unsupported (dtype, R, LT) variant");
+}
+
+int tcmi_build_adjoint_tables(const int* ginfo_dev, int nrec, const double* cpool_dev, const void* params_dev,
+                              long long params_stride, void* ptab_dev, long long ptab_stride, int batch,
+                              int dtype, void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (nrec == 0) return TCMI_OK;
+  if (!ginfo_dev || !cpool_dev || !params_dev || !ptab_dev || batch < 1)
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_build_adjoint_tables: bad argument");
+  dim3 block(128, 1, 1), grid((nrec + 127) / 128, batch, 1);
+  if (dtype == TCMI_C64)
+    hipLaunchKernelGGL(tcmi::build_adjoint_kernel<float>, grid, block, 0, st, ginfo_dev, nrec, cpool_dev,
+                       reinterpret_cast<const float*>(params_dev), params_stride,
+                       reinterpret_cast<float*>(ptab_dev), ptab_stride, batch);
+  else if (dtype == TCMI_C128)
+    hipLaunchKernelGGL(tcmi::build_adjoint_kernel<double>, grid, block, 0, st, ginfo_dev, nrec, cpool_dev,
+                       reinterpret_cast<const double*>(params_dev), params_stride,
+                       reinterpret_cast<double*>(ptab_dev), ptab_stride, batch);
+  else
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_build_adjoint_tables: bad dtype");
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));
+  return TCMI_OK;
+}
+
+int tcmi_apply_pauli_sum(const void* in, void* out, long long state_stride, int batch, int n,
+                         const int* terms_dev, int nterms, const double* weights_dev,
+                         long long weights_stride, int dtype, void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!in || !out || !terms_dev || !weights_dev || batch < 1 || n < 0 || n > 32 || nterms < 0)
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_apply_pauli_sum: bad argument");
+  const unsigned long long nelem = 1ull << n;
+  unsigned gx = (unsigned)((nelem + 255) / 256 > 8192 ? 8192 : (nelem + 255) / 256);
+  dim3 grid(gx, batch, 1), block(256, 1, 1);
+  if (dtype == TCMI_C64)
+    hipLaunchKernelGGL(tcmi::pauli_sum_kernel<float>, grid, block, 0, st, reinterpret_cast<const float2*>(in),
+                       reinterpret_cast<float2*>(out), state_stride, nelem, terms_dev, nterms, weights_dev,
+                       weights_stride);
+  else if (dtype == TCMI_C128)
+    hipLaunchKernelGGL(tcmi::pauli_sum_kernel<double>, grid, block, 0, st, reinterpret_cast<const double2*>(in),
+                       reinterpret_cast<double2*>(out), state_stride, nelem, terms_dev, nterms, weights_dev,
+                       weights_stride);
+  else
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_apply_pauli_sum: bad dtype");
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));
+  return TCMI_OK;
+}
+
+}  // extern "C"

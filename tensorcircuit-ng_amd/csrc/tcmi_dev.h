@@ -1,0 +1,157 @@
+// Device-side helpers shared by the tile-VM kernels (gate passes, measurement passes, adjoint sweep).
+#ifndef TCMI_DEV_H
+#define TCMI_DEV_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "tcmi_vm.h"
+
+namespace tcmi {
+
+template <typename F> struct Cx;
+template <> struct Cx<float> { using type = float2; };
+template <> struct Cx<double> { using type = double2; };
+
+template <typename F> __device__ __forceinline__ void sincos_turns(F x, F* s, F* c);
+template <> __device__ __forceinline__ void sincos_turns<float>(float x, float* s, float* c) {
+#ifdef TCMI_PRECISE_SINCOS
+  sincospif(2.0f * x, s, c);
+#else
+  // v_sin_f32 / v_cos_f32 take their argument in turns; reduce to [-0.5, 0.5] first
+  x -= __builtin_rintf(x);
+  *s = __builtin_amdgcn_sinf(x);
+  *c = __builtin_amdgcn_cosf(x);
+#endif
+}
+template <> __device__ __forceinline__ void sincos_turns<double>(double x, double* s, double* c) {
+  sincospi(2.0 * x, s, c);
+}
+
+// Tables and descriptors are read-only for the whole launch and every access is wave-uniform:
+// read them through the constant address space so they become s_load (SGPR) operands.
+#define TCMI_K __attribute__((address_space(4)))
+template <typename F> using KPtr = const F TCMI_K*;
+using KInt = const int TCMI_K*;
+
+template <typename F>
+__device__ __forceinline__ KPtr<F> tab_ptr(int slot, KPtr<F> ctab, KPtr<F> ptab) {
+  return (slot & TCMI_CONST_FLAG) ? ctab + (slot & ~TCMI_CONST_FLAG) : ptab + slot;
+}
+
+// XOR of mask[i] over the set bits of v (wave-uniform masks, per-lane v)
+template <int NB>
+__device__ __forceinline__ uint32_t xor_masks(uint32_t v, KInt masks) {
+  uint32_t out = 0;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) out ^= (0u - ((v >> i) & 1u)) & (uint32_t)masks[i];
+  return out;
+}
+
+// XOR of mask[j] over the set bits of a compile-time register index
+template <int R>
+__device__ __forceinline__ uint32_t reg_mask(int r, const uint32_t (&m)[R]) {
+  uint32_t out = 0;
+#pragma unroll
+  for (int j = 0; j < R; ++j)
+    if ((r >> j) & 1) out ^= m[j];
+  return out;
+}
+
+template <typename F> __device__ __forceinline__ F fma_(F a, F b, F c);
+template <> __device__ __forceinline__ float fma_<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+template <> __device__ __forceinline__ double fma_<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// acc += m * v (complex), 4 FMAs
+template <typename F, typename C>
+__device__ __forceinline__ void cfma(F mr, F mi, const C& v, F& re, F& im) {
+  re = fma_<F>(mr, v.x, re);
+  re = fma_<F>(-mi, v.y, re);
+  im = fma_<F>(mr, v.y, im);
+  im = fma_<F>(mi, v.x, im);
+}
+
+// KIND 0: general complex 2x2 (16 FMA per pair)
+// KIND 1: real matrix (h, ry, x, z ...)                         (8 per pair)
+// KIND 2: real diagonal, imaginary off-diagonal (rx, y ...)     (8 per pair)
+template <typename F, int NR, int J, int KIND>
+__device__ __forceinline__ void apply_g1(typename Cx<F>::type (&a)[NR], const F (&m)[8]) {
+  const F m00r = m[0], m00i = m[1], m01r = m[2], m01i = m[3];
+  const F m10r = m[4], m10i = m[5], m11r = m[6], m11i = m[7];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    if ((r >> J) & 1) continue;
+    const int r1 = r | (1 << J);
+    const auto x = a[r];
+    const auto y = a[r1];
+    if constexpr (KIND == 1) {
+      a[r].x = fma_<F>(m01r, y.x, m00r * x.x);
+      a[r].y = fma_<F>(m01r, y.y, m00r * x.y);
+      a[r1].x = fma_<F>(m11r, y.x, m10r * x.x);
+      a[r1].y = fma_<F>(m11r, y.y, m10r * x.y);
+    } else if constexpr (KIND == 2) {
+      a[r].x = fma_<F>(-m01i, y.y, m00r * x.x);
+      a[r].y = fma_<F>(m01i, y.x, m00r * x.y);
+      a[r1].x = fma_<F>(-m10i, x.y, m11r * y.x);
+      a[r1].y = fma_<F>(m10i, x.x, m11r * y.y);
+    } else {
+      F re0 = m00r * x.x, im0 = m00r * x.y, re1 = m10r * x.x, im1 = m10r * x.y;
+      re0 = fma_<F>(-m00i, x.y, re0);
+      im0 = fma_<F>(m00i, x.x, im0);
+      re1 = fma_<F>(-m10i, x.y, re1);
+      im1 = fma_<F>(m10i, x.x, im1);
+      cfma<F>(m01r, m01i, y, re0, im0);
+      cfma<F>(m11r, m11i, y, re1, im1);
+      a[r].x = re0; a[r].y = im0; a[r1].x = re1; a[r1].y = im1;
+    }
+  }
+}
+
+template <typename F, int NR, int JA, int JB>
+__device__ __forceinline__ void apply_g2(typename Cx<F>::type (&a)[NR], const F (&m)[32]) {
+  // matrix index = (bit JA << 1) | bit JB, JA < JB
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    if (((r >> JA) & 1) || ((r >> JB) & 1)) continue;
+    const int i0 = r, i1 = r | (1 << JB), i2 = r | (1 << JA), i3 = r | (1 << JA) | (1 << JB);
+    const typename Cx<F>::type v[4] = {a[i0], a[i1], a[i2], a[i3]};
+    typename Cx<F>::type o[4];
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+      F re = m[8 * row] * v[0].x, im = m[8 * row] * v[0].y;
+      re = fma_<F>(-m[8 * row + 1], v[0].y, re);
+      im = fma_<F>(m[8 * row + 1], v[0].x, im);
+#pragma unroll
+      for (int col = 1; col < 4; ++col) cfma<F>(m[2 * (4 * row + col)], m[2 * (4 * row + col) + 1], v[col], re, im);
+      o[row].x = re;
+      o[row].y = im;
+    }
+    a[i0] = o[0];
+    a[i1] = o[1];
+    a[i2] = o[2];
+    a[i3] = o[3];
+  }
+}
+
+// permutation gates: CNOT (either orientation) and SWAP move amplitudes, no arithmetic
+template <typename F, int NR, int JA, int JB, int KIND>
+__device__ __forceinline__ void apply_perm2(typename Cx<F>::type (&a)[NR]) {
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    if (((r >> JA) & 1) || ((r >> JB) & 1)) continue;
+    const int i1 = r | (1 << JB), i2 = r | (1 << JA), i3 = r | (1 << JA) | (1 << JB);
+    if constexpr (KIND == 1) { const auto t = a[i2]; a[i2] = a[i3]; a[i3] = t; }       // control JA
+    else if constexpr (KIND == 2) { const auto t = a[i1]; a[i1] = a[i3]; a[i3] = t; }  // control JB
+    else { const auto t = a[i1]; a[i1] = a[i2]; a[i2] = t; }                            // SWAP
+  }
+}
+
+template <typename F>
+__device__ __forceinline__ F wave_sum(F v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+
+}  // namespace tcmi
+#endif

@@ -20,6 +20,14 @@
 //        sum_r (-1)^parity(r & zr) (-1)^parity(thread_index & zmask) conj(a[r ^ xr]) a[r]  accumulated
 //        (atomicAdd, double) into eout[2*out], eout[2*out+1]; xr = register-bit mask of the X/Y bits
 //        (one or two bits), zr / zmask = sign bits (Z and Y) inside / outside the register bits.
+// Backward (adjoint sweep) programs, executed by tcmi_run_adjoint_pass on (psi, lambda):
+//   G1M  {4, mask | kinds<<8, ubase, kmask, kbase, gslot[R]}   U^dagger_j at ptab[ubase + 8j], K_j at
+//        ptab[kbase + 8j] for the bits in kmask; gout[gslot[j]] += Re <lambda|K_j|psi>, then both
+//        vectors are multiplied by U^dagger_j
+//   G2   {2, ja | kind<<8, jb, uslot, kslot (-1: constant gate), gslot}
+//   DIAG {3, nA, nB, nC, base, maskA, maskB, jB, rmaskC, gsA[nA], gsB[nB], gsC[nC]}  forward
+//        coefficients at ptab[base..]; gout[gs] += sum_idx s_t(idx) Im(conj(lambda) psi) for gs >= 0,
+//        then both vectors are multiplied by the conjugate phase
 // desc[6] flags: bit 0 = do not store the tile (measurement pass).
 // slot = offset (in reals) into the per-batch table, or into the constant table if TCMI_CONST_FLAG.
 #ifndef TCMI_VM_H
@@ -40,5 +48,7 @@
 #define TCMI_CONST_FLAG (1 << 30)
 #define TCMI_BK_TRIG 1
 #define TCMI_BK_COEF 2
+#define TCMI_BK_UDAG 3  /* U^dagger of C0 + cos C1 + sin C2 */
+#define TCMI_BK_KMAT 4  /* K = (dU/dtheta) U^dagger */
 
 #endif

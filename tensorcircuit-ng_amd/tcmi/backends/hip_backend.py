@@ -331,6 +331,20 @@ class HipBackend:
 
         return leaves, rec(pytree)
 
+    def tree_unflatten(self, spec: Any, leaves: Any) -> Any:
+        it = iter(leaves)
+
+        def rec(sp):
+            kind, typ, children = sp
+            if kind == "leaf":
+                return next(it)
+            if kind == "seq":
+                out = [rec(c) for c in children]
+                return typ(out) if not hasattr(typ, "_fields") else typ(*out)
+            return {k: rec(v) for k, v in children.items()}
+
+        return rec(spec)
+
     # ---- function transforms -----------------------------------------------------------------
     def jit(self, f: Callable[..., Any], static_argnums=None, jit_compile=None, **kws: Any) -> Any:
         """Plans are compiled and cached per circuit structure by the executor; there is nothing to
@@ -346,8 +360,27 @@ class HipBackend:
             args = tuple(
                 self.convert_to_tensor(a) if (i in _as_tuple(argnums)) else a for i, a in enumerate(args)
             )
-            g, v = torch.func.grad_and_value(f, argnums=argnums, has_aux=has_aux)(*args, **kws)
-            return v, g
+            if not has_aux:
+                g, v = torch.func.grad_and_value(f, argnums=argnums)(*args, **kws)
+                return v, g
+            # aux may hold non-tensor leaves (e.g. the python float ``fd`` of
+            # benchmarks/scripts/vqe_tc.py:128-133); torch.func only carries tensors, so tensor
+            # leaves travel through has_aux and the rest through a closure
+            box = {}
+
+            def f2(*a: Any, **k: Any) -> Any:
+                out = f(*a, **k)
+                value, aux = out[0], (out[1] if len(out) == 2 else tuple(out[1:]))
+                leaves, spec = self.tree_flatten(aux)
+                box["spec"] = spec
+                box["static"] = [None if torch.is_tensor(x) else x for x in leaves]
+                return value, [x for x in leaves if torch.is_tensor(x)]
+
+            g, (v, tleaves) = torch.func.grad_and_value(f2, argnums=argnums, has_aux=True)(*args, **kws)
+            it = iter(tleaves)
+            leaves = [next(it) if x is None else x for x in box["static"]]
+            aux = self.tree_unflatten(box["spec"], leaves)
+            return (v, aux), g
 
         return wrapper
 

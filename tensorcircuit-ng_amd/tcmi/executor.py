@@ -19,6 +19,22 @@ from . import plan as P
 _T_MIN = 8
 
 
+def _dev(array, device, dtype=None):
+    """Upload a numpy array as a plain device tensor.  Plans are compiled lazily, possibly inside a
+    ``torch.func`` transform, where every op output (including ``.to(device)``) is a functorch
+    wrapper without storage; cached plan tensors must be the underlying plain tensors."""
+    import torch
+
+    t = torch.from_numpy(np.ascontiguousarray(array))
+    if dtype is not None:
+        t = t.to(dtype)
+    t = t.to(device)
+    F = torch._C._functorch
+    while F.is_functorch_wrapped_tensor(t):
+        t = F.get_unwrapped(t)
+    return t
+
+
 def pick_variant(n: int, dtypestr: str, opts: Optional[dict] = None) -> Tuple[int, P.PlanConfig]:
     """Choose (n_exec, PlanConfig) for a circuit of n qubits: the largest tile variant that fits;
     tiny circuits are padded with spectator qubits (as most-significant bits, left in |0>)."""
@@ -66,6 +82,7 @@ class CompiledCircuit:
         pad = self.n_exec - n
         if pad:
             gates = [self._shift(g, pad) for g in gates]
+        self._exec_gates = gates
         self.plan = P.compile_plan(gates, self.n_exec, self.cfg, nparams=nparams)
         self.tdtype = torch.complex64 if dtypestr == "complex64" else torch.complex128
         self.rdtype = torch.float32 if dtypestr == "complex64" else torch.float64
@@ -73,12 +90,10 @@ class CompiledCircuit:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
         self._lib = _lib.lib()  # raises if the HIP extension is missing
         dev = self.device
-        self.descs = [torch.from_numpy(np.ascontiguousarray(d)).to(dev) for d in self.plan.descs]
-        self.ctab = torch.from_numpy(self.plan.ctab).to(self.rdtype).to(dev)
-        if self.ctab.numel() == 0:
-            self.ctab = torch.zeros(1, dtype=self.rdtype, device=dev)
-        self.ginfo = torch.from_numpy(np.ascontiguousarray(self.plan.ginfo)).to(dev)
-        self.cpool = torch.from_numpy(self.plan.cpool).to(dev)
+        self.descs = [_dev(d, dev) for d in self.plan.descs]
+        self.ctab = _dev(self.plan.ctab if self.plan.ctab.size else np.zeros(8), dev, self.rdtype)
+        self.ginfo = _dev(self.plan.ginfo, dev)
+        self.cpool = _dev(self.plan.cpool if self.plan.cpool.size else np.zeros(1), dev)
         self.nrec = int(self.plan.ginfo.shape[0])
         self.ptab_size = max(1, self.plan.ptab_size)
 
@@ -151,6 +166,71 @@ class CompiledCircuit:
         item = 8 if self.dtypestr == "complex64" else 16
         return self.plan.stats(item)
 
+    # ---- reverse mode ------------------------------------------------------------------------
+    def _adjoint(self):
+        """Adjoint-sweep plan (compiled lazily, own tile config: two vectors live in registers)."""
+        import torch
+
+        if getattr(self, "_adj", None) is None:
+            cfg = pick_measure_variant(self.n_exec, self.dtypestr)
+            gates = self._exec_gates
+            ap = P.compile_adjoint_plan(gates, self.n_exec, cfg)
+            dev = self.device
+            self._adj = {
+                "plan": ap, "cfg": cfg,
+                "descs": [_dev(d, dev) for d in ap.descs],
+                "ctab": _dev(ap.ctab, dev, self.rdtype),
+                "ginfo": _dev(ap.ginfo, dev),
+                "cpool": _dev(ap.cpool if ap.cpool.size else np.zeros(1), dev),
+                "gparam": _dev(ap.gslot_param, dev),
+                "gfactor": _dev(ap.gslot_factor, dev),
+                "nslots": len(ap.gslot_param),
+            }
+        return self._adj
+
+    def vjp(self, params, psi, g, chunk_bytes=48 << 30):
+        """dL/dparams = Re <g | d psi / d params> for every batch row, by the adjoint sweep.
+        params [B, P] real, psi / g [B, 2^n_exec] complex (psi = the forward output).  The sweep
+        works on copies (psi is un-computed in place), processed in batch chunks to bound memory."""
+        import torch
+
+        adj = self._adjoint()
+        lib = self._lib
+        B = params.shape[0]
+        nel = 2**self.n_exec
+        out = torch.zeros(B, max(self.nparams, 1), dtype=torch.float64, device=self.device)
+        if adj["nslots"] == 0 or self.nparams == 0:
+            return out[:, : self.nparams].to(self.rdtype)
+        params = params.to(device=self.device, dtype=self.rdtype).contiguous()
+        item = 8 if self.dtypestr == "complex64" else 16
+        cb = max(1, int(chunk_bytes // (2 * nel * item)))
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        cfg = adj["cfg"]
+        for b0 in range(0, B, cb):
+            b1 = min(B, b0 + cb)
+            nb = b1 - b0
+            a = psi[b0:b1].to(self.tdtype).clone().contiguous()
+            lam = g[b0:b1].to(self.tdtype).clone().contiguous()
+            p = params[b0:b1]
+            ptab = torch.empty(nb, max(1, adj["plan"].ptab_size), dtype=self.rdtype, device=self.device)
+            _lib.check(
+                lib.tcmi_build_adjoint_tables(
+                    adj["ginfo"].data_ptr(), int(adj["ginfo"].shape[0]), adj["cpool"].data_ptr(),
+                    p.data_ptr(), p.stride(0), ptab.data_ptr(), ptab.stride(0), nb, self.code, stream),
+                "tcmi_build_adjoint_tables",
+            )
+            gout = torch.zeros(nb, adj["nslots"], dtype=torch.float64, device=self.device)
+            for d in adj["descs"]:
+                _lib.check(
+                    lib.tcmi_run_adjoint_pass(
+                        a.data_ptr(), lam.data_ptr(), nel, nb, self.n_exec, cfg.R, cfg.LT, d.data_ptr(),
+                        adj["ctab"].data_ptr(), ptab.data_ptr(), ptab.stride(0), gout.data_ptr(),
+                        gout.stride(0), self.code, stream),
+                    "tcmi_run_adjoint_pass",
+                )
+            out[b0:b1].index_add_(1, adj["gparam"], gout * adj["gfactor"])
+        return out[:, : self.nparams].to(self.rdtype)
+
 
 def pick_measure_variant(n_exec: int, dtypestr: str) -> P.PlanConfig:
     """Measurement passes use a smaller register tile than the gate passes (the EXPECT op keeps
@@ -180,10 +260,10 @@ class CompiledMeasure:
         self.code = _lib.TCMI_C64 if dtypestr == "complex64" else _lib.TCMI_C128
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
         self._lib = _lib.lib()
-        self.descs = [torch.from_numpy(np.ascontiguousarray(d)).to(self.device) for d in self.plan.descs]
+        self.descs = [_dev(d, self.device) for d in self.plan.descs]
         rdt = torch.float32 if dtypestr == "complex64" else torch.float64
-        self.dummy = torch.zeros(8, dtype=rdt, device=self.device)
-        self.phase = torch.tensor([(1j) ** t.ny for t in terms], dtype=torch.complex128, device=self.device)
+        self.dummy = _dev(np.zeros(8), self.device, rdt)
+        self.phase = _dev(np.array([(1j) ** t.ny for t in terms], dtype=np.complex128), self.device)
 
     def run(self, state):
         """state: complex tensor [B, 2^n_exec] (full executor buffer).  Returns complex128 [B, nterms]
@@ -204,6 +284,38 @@ class CompiledMeasure:
                 "tcmi_run_pass(measure)",
             )
         return torch.view_as_complex(out.reshape(B, self.nterms, 2)) * self.phase
+
+    def apply_sum(self, state, gvals):
+        """Cotangent of the state for L = f(<psi|P_t|psi>): 2 * sum_t Re(g_t) P_t |psi>
+        (``tcmi_apply_pauli_sum``).  state [B, 2^n_exec], gvals [B, nterms] complex."""
+        import torch
+
+        if getattr(self, "_sum_terms", None) is None:
+            n = self.n_exec
+            rows = []
+            for k, t in enumerate(self.plan.terms):
+                xm = 0
+                for q in t.x:
+                    xm |= 1 << (n - 1 - q)
+                zm = 0
+                for q in t.z:
+                    zm |= 1 << (n - 1 - q)
+                rows.append((xm, zm, t.ny, k))
+            rows.sort(key=lambda r: r[0])
+            arr = np.array([[r[0], r[1], r[2]] for r in rows], dtype=np.int64).astype(np.uint32).view(np.int32)
+            self._sum_terms = _dev(arr.reshape(-1, 3), self.device)
+            self._sum_order = _dev(np.array([r[3] for r in rows], dtype=np.int64), self.device)
+        B = state.shape[0]
+        w = (2.0 * gvals.real.to(torch.float64))[:, self._sum_order].contiguous()
+        out = torch.empty_like(state)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(
+            self._lib.tcmi_apply_pauli_sum(
+                state.data_ptr(), out.data_ptr(), state.shape[1], B, self.n_exec,
+                self._sum_terms.data_ptr(), self.nterms, w.data_ptr(), w.stride(0), self.code, stream),
+            "tcmi_apply_pauli_sum",
+        )
+        return out
 
 
 _MCACHE: Dict[Tuple, "CompiledMeasure"] = {}

@@ -49,6 +49,8 @@ CONST_FLAG = 1 << 30
 # builder kinds
 BK_TRIG = 1  # M = C0 + cos(k*theta + off) C1 + sin(k*theta + off) C2
 BK_COEF = 2  # phase coefficient in turns = k*theta + off
+BK_UDAG = 3  # U^dagger (adjoint sweep)
+BK_KMAT = 4  # K = (dU/dtheta) U^dagger (adjoint sweep)
 
 
 @dataclass
@@ -367,6 +369,13 @@ class Tables:
     ginfo: List[List[int]] = field(default_factory=list)   # builder records
     cpool: List[float] = field(default_factory=list)       # builder constants (float64)
     _slot_cache: dict = field(default_factory=dict)
+    gslot_param: List[int] = field(default_factory=list)     # adjoint: parameter index per slot
+    gslot_factor: List[float] = field(default_factory=list)  # adjoint: d(theta)/d(slot value)
+
+    def grad_slot(self, pidx: int, factor: float) -> int:
+        self.gslot_param.append(pidx)
+        self.gslot_factor.append(factor)
+        return len(self.gslot_param) - 1
 
     def const_complex(self, m):
         off = len(self.ctab)
@@ -447,10 +456,18 @@ def g2_kind(g: GateRec, swap: bool, tol=1e-14) -> int:
     return 0
 
 
-def _matrix_record(tables: Tables, slot: int, g: GateRec):
-    """Builder record writing the dense matrix of g to ptab[slot ..] (constant gates included, so
-    that the matrices of one op can sit contiguously)."""
+def _matrix_record(tables: Tables, slot: int, g: GateRec, kind: int = BK_TRIG, swap: bool = False):
+    """Builder record writing a dense matrix derived from g to ptab[slot ..]: the gate itself
+    (BK_TRIG), its adjoint (BK_UDAG) or K = dU U^dagger (BK_KMAT).  Constant gates included, so that
+    the matrices of one op can sit contiguously."""
     dim = 2 ** len(g.qubits)
+
+    def sw(m):
+        m = np.asarray(m, dtype=np.complex128).reshape(dim, dim)
+        if swap:
+            m = m.reshape(2, 2, 2, 2).transpose(1, 0, 3, 2).reshape(4, 4)
+        return m
+
     off = len(tables.cpool)
     if g.param is None:
         tables.cpool += [0.0, 0.0]
@@ -461,9 +478,9 @@ def _matrix_record(tables: Tables, slot: int, g: GateRec):
         mats = (g.c0, g.c1, g.c2)
         pidx = g.param.index
     for m in mats:
-        for z in np.asarray(m, dtype=np.complex128).reshape(-1):
+        for z in sw(m).reshape(-1):
             tables.cpool += [float(z.real), float(z.imag)]
-    tables.ginfo.append([BK_TRIG, slot, pidx, dim, off, 0, 0, 0])
+    tables.ginfo.append([kind, slot, pidx, dim, off, 0, 0, 0])
 
 
 def _coef_record(tables: Tables, slot: int, t: DiagTerm):
@@ -493,7 +510,9 @@ def _coef_slot(tables: Tables, gi: int, ti: int, t: DiagTerm):
 
 
 def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tables: Tables,
-                batch_diag: bool = True) -> np.ndarray:
+                batch_diag: bool = True, backward: bool = False) -> np.ndarray:
+    """``backward=True`` encodes an adjoint-sweep pass: ``gates`` is the reversed gate list, every op
+    carries U^dagger (+ K and a gradient slot for parametrised gates), see csrc/tcmi_vm.h."""
     T, R, LT = cfg.T, cfg.R, cfg.LT
     assert R <= R_MAX and LT <= LT_MAX and T <= T_MAX
     words = [0] * HDR_WORDS
@@ -542,11 +561,23 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
                 return
             mk = 0
             base = tables.alloc(8 * R)  # the R matrices of one G1M op are contiguous
+            if backward:
+                kmask, kbase, gs = 0, tables.alloc(8 * R), [0] * R
             for j, gi in pend_g1.items():
                 g = gates[gi]
                 mk |= (1 << j) | (g1_kind(g) << (8 + 2 * j))
-                _matrix_record(tables, base + 8 * j, g)
-            ops.extend([OP_G1M, mk, base])
+                if not backward:
+                    _matrix_record(tables, base + 8 * j, g)
+                else:
+                    _matrix_record(tables, base + 8 * j, g, BK_UDAG)
+                    if g.param is not None:
+                        kmask |= 1 << j
+                        _matrix_record(tables, kbase + 8 * j, g, BK_KMAT)
+                        gs[j] = tables.grad_slot(g.param.index, 1.0)
+            if backward:
+                ops.extend([OP_G1M, mk, base, kmask, kbase] + gs)
+            else:
+                ops.extend([OP_G1M, mk, base])
             nops += 1
             pend_g1.clear()
 
@@ -591,6 +622,12 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
             ops.extend([m for _, m, _ in B_] + [0] * padB)
             ops.extend([j for j, _, _ in B_] + [0] * padB)
             ops.extend([m for m, _ in C_])
+            if backward:
+                # d(phase)/d(theta) = scale * s_t(idx); dL/dtheta = -scale * sum s_t Im(conj(lambda) psi)
+                ops.extend([
+                    tables.grad_slot(t.param.index, -t.param.scale) if t.param is not None else -1
+                    for t in terms
+                ])
             nops += 1
             pend_diag.clear()
 
@@ -613,7 +650,17 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
                 flush_g1()
                 swap = js[0] > js[1]
                 ja, jb = (js[1], js[0]) if swap else (js[0], js[1])
-                ops.extend([OP_G2, ja | (g2_kind(g, swap) << 8), jb, _gate_slot(tables, gi, g, swap)])
+                if not backward:
+                    ops.extend([OP_G2, ja | (g2_kind(g, swap) << 8), jb, _gate_slot(tables, gi, g, swap)])
+                else:
+                    uslot = tables.alloc(32)
+                    _matrix_record(tables, uslot, g, BK_UDAG, swap)
+                    kslot, gslot = -1, 0
+                    if g.param is not None:
+                        kslot = tables.alloc(32)
+                        _matrix_record(tables, kslot, g, BK_KMAT, swap)
+                        gslot = tables.grad_slot(g.param.index, 1.0)
+                    ops.extend([OP_G2, ja | (g2_kind(g, swap) << 8), jb, uslot, kslot, gslot])
                 nops += 1
             else:
                 raise NotImplementedError
@@ -763,3 +810,36 @@ def compile_measure_plan(terms: List[PauliTerm], n: int, cfg: PlanConfig) -> Mea
     passes = schedule(terms, n, cfg, independent=True)
     descs = [encode_measure_pass(terms, n, cfg, pp) for pp in passes]
     return MeasurePlan(n, cfg, list(terms), passes, descs)
+
+
+# ---- adjoint (reverse sweep) plans -----------------------------------------------------------------
+@dataclass
+class AdjointPlan:
+    n: int
+    cfg: PlanConfig
+    passes: List[PassPlan]
+    descs: List[np.ndarray]
+    ctab: np.ndarray
+    ptab_size: int
+    ginfo: np.ndarray
+    cpool: np.ndarray
+    gslot_param: np.ndarray   # int64 [nslots]: parameter index of each gradient slot
+    gslot_factor: np.ndarray  # float64 [nslots]
+
+
+def compile_adjoint_plan(gates: List[GateRec], n: int, cfg: PlanConfig) -> AdjointPlan:
+    """Plan of the reversed circuit: gates in reverse order, each applied as U^dagger to both psi and
+    the cotangent lambda, with one gradient slot per parametrised gate / diagonal term.  Valid for
+    unitary gates (psi is un-computed, not stored)."""
+    rev = list(reversed(gates))
+    passes = schedule(rev, n, cfg)
+    tables = Tables()
+    tables.ctab += [0.0] * 8
+    descs = [encode_pass(rev, n, cfg, pp, tables, backward=True) for pp in passes]
+    return AdjointPlan(
+        n=n, cfg=cfg, passes=passes, descs=descs, ctab=np.array(tables.ctab, dtype=np.float64),
+        ptab_size=tables.ptab_size, ginfo=np.array(tables.ginfo, dtype=np.int32).reshape(-1, 8),
+        cpool=np.array(tables.cpool, dtype=np.float64),
+        gslot_param=np.array(tables.gslot_param, dtype=np.int64),
+        gslot_factor=np.array(tables.gslot_factor, dtype=np.float64),
+    )

@@ -1,0 +1,213 @@
+"""Reverse mode on the GPU (adjoint sweep + Pauli-sum cotangent kernels) through the reference's
+backend API: value_and_grad / grad / vmap / vectorized_value_and_grad
+(reference abstract_backend.py:2262-2293, 2520-2591)."""
+
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dense, gates as G, workloads as W  # noqa: E402
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "hea_golden.npz"))
+
+
+@pytest.fixture(params=["complex64", "complex128"])
+def tcd(request):
+    import tcmi as tc
+
+    tc.set_backend("hip")
+    tc.set_dtype(request.param)
+    yield tc
+    tc.set_dtype("complex64")
+
+
+def _tfim(tc, c, n, j=1.0, h=-1.0):
+    e = 0.0
+    for i in range(n):
+        e += h * c.expectation((tc.gates.x(), [i]))
+    for i in range(n - 1):
+        e += j * c.expectation((tc.gates.z(), [i]), (tc.gates.z(), [i + 1]))
+    return tc.backend.real(e)
+
+
+def test_operator_measurement_kat(tcd):
+    """reference tests/test_templates.py:191-211: value 0.84147, gradient 0.54032 (atol 1e-4)."""
+    tc = tcd
+
+    def f(theta):
+        c = tc.Circuit(2)
+        c.ry(0, theta=theta)
+        c.H(1)
+        return tc.backend.real(c.expectation((tc.gates.x(), [0])))
+
+    v, g = tc.backend.jit(tc.backend.value_and_grad(f))(tc.backend.ones([], dtype=tc.rdtypestr))
+    np.testing.assert_allclose(tc.backend.numpy(v), 0.84147, atol=1e-4)
+    np.testing.assert_allclose(tc.backend.numpy(g), 0.54032, atol=1e-4)
+
+
+@pytest.mark.parametrize("n,d", [(6, 2), (10, 4)])
+def test_tfim_value_and_grad_golden(tcd, n, d):
+    """HEA-B + TFIM energy (benchmarks/scripts/vqe_tc.py:107-141) against the committed
+    central-difference gradients of the oracle."""
+    tc = tcd
+    params = GOLD[f"tfim_{n}_{d}_params"]
+
+    def f(p):
+        c = tc.Circuit(n)
+        W.hea_b(c, n, d, p, zz=tc.gates._zz_matrix)
+        return _tfim(tc, c, n)
+
+    v, g = tc.backend.value_and_grad(f)(tc.backend.convert_to_tensor(params, dtype=tc.rdtypestr))
+    tol = 2e-4 if tc.dtypestr == "complex64" else 1e-7
+    np.testing.assert_allclose(tc.backend.numpy(v), GOLD[f"tfim_{n}_{d}_energy"], atol=tol)
+    assert tuple(g.shape) == params.shape
+    np.testing.assert_allclose(tc.backend.numpy(g), GOLD[f"tfim_{n}_{d}_grad"], atol=tol)
+
+
+def test_two_argument_grad_and_aux(tcd):
+    """argnums=(0, 1), has_aux=True exactly as benchmarks/scripts/vqe_tc.py:107-141."""
+    tc = tcd
+    n, nlayer = 5, 2
+    rng = np.random.default_rng(0)
+    px, pzz = rng.normal(size=nlayer * n), rng.normal(size=nlayer * n)
+
+    def energy_raw(paramx, paramzz):
+        c = tc.Circuit(n)
+        for i in range(n):
+            c.H(i)
+        for j in range(nlayer):
+            for i in range(n - 1):
+                c.exp1(i, i + 1, theta=paramzz[j * n + i], unitary=tc.gates._zz_matrix)
+            for i in range(n):
+                c.rx(i, theta=paramx[j * n + i])
+        return _tfim(tc, c, n), 1.0
+
+    vag = tc.backend.jit(tc.backend.value_and_grad(energy_raw, argnums=(0, 1), has_aux=True))
+    (e, fd), (gx, gzz) = vag(tc.backend.convert_to_tensor(px, dtype=tc.rdtypestr),
+                             tc.backend.convert_to_tensor(pzz, dtype=tc.rdtypestr))
+    assert fd == 1.0
+
+    def ref(px_, pzz_):
+        ops = [(G.H, [i]) for i in range(n)]
+        for j in range(nlayer):
+            ops += [(G.exp1(G.ZZ, pzz_[j * n + i]), [i, i + 1]) for i in range(n - 1)]
+            ops += [(G.rx(px_[j * n + i]), [i]) for i in range(n)]
+        return W.tfim_energy_dense(dense.run(n, ops), n)
+
+    eps = 1e-6
+    fgx = np.array([(ref(px + eps * np.eye(px.size)[i], pzz) - ref(px - eps * np.eye(px.size)[i], pzz)) / (2 * eps) for i in range(px.size)])
+    fgz = np.array([(ref(px, pzz + eps * np.eye(px.size)[i]) - ref(px, pzz - eps * np.eye(px.size)[i])) / (2 * eps) for i in range(px.size)])
+    tol = 2e-4 if tc.dtypestr == "complex64" else 1e-7
+    np.testing.assert_allclose(tc.backend.numpy(e), ref(px, pzz), atol=tol)
+    np.testing.assert_allclose(tc.backend.numpy(gx), fgx, atol=tol)
+    np.testing.assert_allclose(tc.backend.numpy(gzz), fgz, atol=tol)
+    assert abs(fgz[n - 1]) < 1e-12 and abs(tc.backend.numpy(gzz)[n - 1]) < 1e-12  # unused parameter
+
+
+def test_mixed_gates_gradient(tcd):
+    """Every differentiable gate family + constant gates in between, multi-pass plan (n = 14)."""
+    tc = tcd
+    n = 14
+    rng = np.random.default_rng(5)
+    p0 = rng.uniform(0, 2 * np.pi, 12)
+
+    def build(c, p, api):
+        for i in range(n):
+            c.h(i)
+        c.rx(0, theta=p[0]); c.ry(13, theta=p[1]); c.rz(5, theta=p[2]); c.cnot(0, 13)
+        c.rzz(2, 9, theta=p[3]); c.rxx(12, 1, theta=p[4]); c.ryy(3, 4, theta=p[5])
+        c.phase(7, theta=p[6]); c.crx(8, 6, theta=p[7]); c.swap(1, 10)
+        c.cphase(11, 2, theta=p[8]); c.iswap(6, 7, theta=p[9]); c.u(4, theta=p[10], phi=p[11], lbd=0.4)
+        c.exp1(0, 5, unitary=api["xz"], theta=p[0] * 0.5 + 0.1); c.cz(3, 12)
+
+    def f(p):
+        c = tc.Circuit(n)
+        build(c, p, {"xz": np.kron(G.X, G.Z)})
+        return tc.backend.real(
+            c.expectation_ps(x=[0, 5]) + 0.7 * c.expectation_ps(z=[13], y=[2]) - 0.3 * c.expectation_ps(z=[4, 9, 12])
+        )
+
+    def ref(p):
+        ops = [(G.H, [i]) for i in range(n)]
+        ops += [(G.rx(p[0]), [0]), (G.ry(p[1]), [13]), (G.rz(p[2]), [5]), (G.CNOT, [0, 13]),
+                (G.rzz(p[3]), [2, 9]), (G.rxx(p[4]), [12, 1]), (G.ryy(p[5]), [3, 4]), (G.phase(p[6]), [7]),
+                (G.controlled(G.rx(p[7])), [8, 6]), (G.SWAP, [1, 10]), (G.controlled(G.phase(p[8])), [11, 2]),
+                (G.iswap(p[9]), [6, 7]), (G.u(p[10], p[11], 0.4), [4]),
+                (G.exp1(np.kron(G.X, G.Z), p[0] * 0.5 + 0.1), [0, 5]), (G.CZ, [3, 12])]
+        psi = dense.run(n, ops)
+        pe = lambda ps: dense.pauli_string_expectation(psi, n, ps).real
+        s1 = [0] * n; s1[0] = 1; s1[5] = 1
+        s2 = [0] * n; s2[13] = 3; s2[2] = 2
+        s3 = [0] * n; s3[4] = 3; s3[9] = 3; s3[12] = 3
+        return pe(s1) + 0.7 * pe(s2) - 0.3 * pe(s3)
+
+    v, g = tc.backend.value_and_grad(f)(tc.backend.convert_to_tensor(p0, dtype=tc.rdtypestr))
+    eps = 1e-6
+    fd = np.array([(ref(p0 + eps * np.eye(12)[i]) - ref(p0 - eps * np.eye(12)[i])) / (2 * eps) for i in range(12)])
+    tol = 2e-4 if tc.dtypestr == "complex64" else 1e-7
+    np.testing.assert_allclose(tc.backend.numpy(v), ref(p0), atol=tol)
+    np.testing.assert_allclose(tc.backend.numpy(g), fd, atol=tol)
+
+
+def test_vvag_semantics(tcd):
+    """reference tests/test_backends.py:890-939: vvag == per-sample value_and_grad; gradients of the
+    non-vectorised argument are summed over the batch (g11 / batch == g01)."""
+    tc = tcd
+    n, d, B = 6, 2, 4
+    rng = np.random.default_rng(11)
+    w = tc.backend.convert_to_tensor(rng.normal(size=[2 * d, n]), dtype=tc.rdtypestr)
+    xs = tc.backend.convert_to_tensor(rng.normal(size=[B, n]), dtype=tc.rdtypestr)
+
+    def f(x, weights):
+        c = tc.Circuit(n)
+        for i in range(n):
+            c.rx(i, theta=x[i])
+        W.hea_b(c, n, d, weights, zz=tc.gates._zz_matrix)
+        return _tfim(tc, c, n)
+
+    vs, (gx, gw) = tc.backend.vvag(f, argnums=(0, 1), vectorized_argnums=0)(xs, w)
+    assert tuple(vs.shape) == (B,) and tuple(gx.shape) == (B, n) and tuple(gw.shape) == (2 * d, n)
+    vag = tc.backend.value_and_grad(f, argnums=(0, 1))
+    gw_sum = 0
+    tol = 2e-4 if tc.dtypestr == "complex64" else 1e-8
+    for b in range(B):
+        v1, (g1x, g1w) = vag(xs[b], w)
+        np.testing.assert_allclose(tc.backend.numpy(vs[b]), tc.backend.numpy(v1), atol=tol)
+        np.testing.assert_allclose(tc.backend.numpy(gx[b]), tc.backend.numpy(g1x), atol=tol)
+        gw_sum = gw_sum + tc.backend.numpy(g1w)
+    np.testing.assert_allclose(tc.backend.numpy(gw), gw_sum, atol=tol * B)
+    # identical samples: summed shared gradient / batch == single gradient
+    same = tc.backend.stack([xs[0]] * B)
+    _, (_, gw_same) = tc.backend.vvag(f, argnums=(0, 1), vectorized_argnums=0)(same, w)
+    _, (_, g01) = vag(xs[0], w)
+    np.testing.assert_allclose(tc.backend.numpy(gw_same) / B, tc.backend.numpy(g01), atol=tol)
+
+
+def test_grad_at_scale_vs_single_precision_pair():
+    """n = 20, d = 3: complex64 gradient against the complex128 gradient of the same kernels
+    (self-consistency at a size the dense oracle's finite differences cannot reach in seconds)."""
+    import tcmi as tc
+
+    tc.set_backend("hip")
+    n, d = 20, 3
+    params = np.random.default_rng(20).normal(0, 0.3, [2 * d, n])
+    outs = {}
+    for dt in ("complex64", "complex128"):
+        tc.set_dtype(dt)
+
+        def f(p):
+            c = tc.Circuit(n)
+            W.hea_b(c, n, d, p, zz=tc.gates._zz_matrix)
+            return _tfim(tc, c, n)
+
+        v, g = tc.backend.value_and_grad(f)(tc.backend.convert_to_tensor(params, dtype=tc.rdtypestr))
+        outs[dt] = (float(tc.backend.numpy(v)), tc.backend.numpy(g).astype(np.float64))
+    tc.set_dtype("complex64")
+    assert abs(outs["complex64"][0] - outs["complex128"][0]) < 1e-4
+    assert np.abs(outs["complex64"][1] - outs["complex128"][1]).max() < 5e-4
+    # energy against the dense oracle
+    want = W.tfim_energy_dense(dense.run(n, W.hea_b_ops(n, d, params)), n)
+    assert abs(outs["complex128"][0] - want) < 1e-9

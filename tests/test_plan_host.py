@@ -152,3 +152,70 @@ def test_small_circuits_are_padded():
     assert ne == 28 and (cfg.R, cfg.LT) == (5, 8)
     ne, cfg = pick_variant(28, "complex128")
     assert (cfg.R, cfg.LT) == (4, 8) and cfg.vec == 1
+
+
+# ---- measurement and adjoint plans (emulated) -------------------------------------------------------
+@pytest.mark.parametrize("n,R,LT", [(8, 2, 6), (12, 4, 8), (14, 4, 8), (13, 3, 8)])
+def test_measure_plan_emulated(n, R, LT):
+    rng = np.random.default_rng(n)
+    psi = rng.normal(size=2**n) + 1j * rng.normal(size=2**n)
+    psi /= np.linalg.norm(psi)
+    strings = [ps for _, ps in W.tfim_terms(n)]
+    for k in range(10):
+        ps = [0] * n
+        qs = rng.choice(n, 3, replace=False)
+        ps[qs[0]] = int(rng.integers(1, 3)); ps[qs[1]] = int(rng.integers(1, 4)); ps[qs[2]] = 3
+        strings.append(ps)
+    strings.append([0] * n)  # identity
+    terms = [P.pauli_term_from_string(ps) for ps in strings]
+    mp = P.compile_measure_plan(terms, n, P.PlanConfig(R=R, LT=LT, lowbits=5, vec=2))
+    got = E.run_measure_plan(mp, psi)
+    ref = np.array([dense.pauli_string_expectation(psi, n, ps) for ps in strings])
+    np.testing.assert_allclose(got, ref, atol=1e-12)
+    with pytest.raises(NotImplementedError):
+        P.compile_measure_plan([P.pauli_term_from_string([1, 1, 1] + [0] * (n - 3))], n, P.PlanConfig(R=R, LT=LT))
+
+
+@pytest.mark.parametrize("n,R,LT", [(8, 2, 6), (12, 4, 8), (13, 3, 8)])
+def test_adjoint_plan_emulated(n, R, LT):
+    """Adjoint sweep == central finite differences of the emulated forward plan; psi is un-computed
+    back to |0..0>; shared parameters accumulate."""
+    rng = np.random.default_rng(n)
+
+    def build(p):
+        c = tc.Circuit(n)
+        k = 0
+        for i in range(n):
+            c.h(i)
+        for i in range(n - 1):
+            c.exp1(i, i + 1, unitary=tc.gates._zz_matrix, theta=p[k]); k += 1
+        for i in range(n):
+            c.rx(i, theta=p[k]); k += 1
+        c.cnot(0, n - 1); c.ry(1, theta=p[k]); k += 1
+        c.rzz(0, n - 2, theta=p[k]); k += 1
+        c.phase(2, theta=p[k]); k += 1
+        c.crx(n - 1, 1, theta=p[k]); k += 1
+        c.rxx(2, 0, theta=p[k]); k += 1
+        c.u(3, theta=p[k], phi=p[k + 1], lbd=0.3); k += 2
+        c.swap(1, 4); c.rz(1, theta=p[0])  # p[0] is shared with the first exp1
+        return c, k
+
+    _, npar = build(np.zeros(200))
+    c, _ = build(rng.uniform(0, 2 * np.pi, npar))
+    recs = c._gate_records()
+    vals = np.array([float(x) for x in c._params])
+    cfg = P.PlanConfig(R=R, LT=LT, lowbits=min(5, R + LT), vec=2)
+    pl = P.compile_plan(recs, n, cfg, nparams=len(vals))
+    psi = E.run_plan(pl, vals)
+    g = rng.normal(size=2**n) + 1j * rng.normal(size=2**n)
+    ap = P.compile_adjoint_plan(recs, n, cfg)
+    grad, psi_in = E.run_adjoint_plan(ap, vals, psi, g, len(vals))
+    e0 = np.zeros(2**n); e0[0] = 1
+    np.testing.assert_allclose(psi_in, e0, atol=1e-12)
+    eps = 1e-6
+    picks = rng.choice(len(vals), 8, replace=False)
+    for i in picks:
+        vp, vm = vals.copy(), vals.copy()
+        vp[i] += eps; vm[i] -= eps
+        fd = (np.real(np.vdot(g, E.run_plan(pl, vp))) - np.real(np.vdot(g, E.run_plan(pl, vm)))) / (2 * eps)
+        assert abs(grad[i] - fd) < 1e-7
