@@ -60,10 +60,13 @@ int tcmi_build_tables(const int* ginfo, int nrec, const double* cpool, const voi
  * accumulate the Pauli-string values <psi|P_t|psi> into eout[batch][2*t] (re, im; float64; the
  * caller zeroes it) instead of storing the tile.  They replace the 2n-1 separate
  * contractor([psi, psi*, op...]) reductions of Circuit.expectation
- * (tensorcircuit/circuit.py:899-902, basecircuit.py:393-447); eout may be NULL otherwise. */
+ * (tensorcircuit/circuit.py:899-902, basecircuit.py:393-447); eout may be NULL otherwise.
+ * eout is replicated `ecopies` times (`ecopy_stride` doubles apart; workgroup w adds into copy
+ * w % ecopies) so that same-address atomics spread over the L2 channels; the caller sums the copies. */
 int tcmi_run_pass(void* state, long long state_stride, int batch, int n, int R, int LT,
                   const int* desc, const void* ctab, const void* ptab, long long ptab_stride,
-                  double* eout, long long eout_stride, int dtype, void* stream);
+                  double* eout, long long eout_stride, int ecopies, long long ecopy_stride, int dtype,
+                  void* stream);
 
 /* ---- reverse mode (value_and_grad) -----------------------------------------------------------------
  * Replaces the framework AD the reference relies on -- backend.value_and_grad / vvag
@@ -87,10 +90,12 @@ int tcmi_build_adjoint_tables(const int* ginfo, int nrec, const double* cpool, c
 /* One pass of the reversed plan over (psi, lambda), both updated in place:
  * gout[batch][slot] += Re <lambda| K_g |psi> for every parametrised gate g of the pass (float64,
  * caller zeroes it), then psi <- U_g^dagger psi, lambda <- U_g^dagger lambda.  After the last pass
- * psi is the circuit's input state and gout holds dL/dtheta per gate slot. */
+ * psi is the circuit's input state and gout holds dL/dtheta per gate slot (replicated `gcopies`
+ * times like eout above; the caller sums the copies). */
 int tcmi_run_adjoint_pass(void* psi, void* lam, long long state_stride, int batch, int n, int R, int LT,
                           const int* desc, const void* ctab, const void* ptab, long long ptab_stride,
-                          double* gout, long long gout_stride, int dtype, void* stream);
+                          double* gout, long long gout_stride, int gcopies, long long gcopy_stride,
+                          int dtype, void* stream);
 
 #ifdef __cplusplus
 }

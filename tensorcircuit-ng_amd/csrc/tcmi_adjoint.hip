@@ -98,7 +98,8 @@ __global__ __launch_bounds__(1 << LT) void adjoint_kernel(typename Cx<F>::type* 
                                                            const F* __restrict__ ptab_g,
                                                            long long ptab_stride,
                                                            double* __restrict__ gout,
-                                                           long long gout_stride) {
+                                                           long long gout_stride, int gcopies,
+                                                           long long gcopy_stride) {
   using C = typename Cx<F>::type;
   constexpr int NR = 1 << R;
   constexpr int T = R + LT;
@@ -110,7 +111,8 @@ __global__ __launch_bounds__(1 << LT) void adjoint_kernel(typename Cx<F>::type* 
   const uint32_t tid = threadIdx.x;
   psi += (long long)blockIdx.y * state_stride;
   lam += (long long)blockIdx.y * state_stride;
-  gout += (long long)blockIdx.y * gout_stride;
+  // gradient slots are replicated gcopies times to spread same-address atomics over L2 channels
+  gout += (long long)blockIdx.y * gout_stride + (long long)(blockIdx.x % (unsigned)gcopies) * gcopy_stride;
   const KInt desc = (KInt)desc_g;
   const KPtr<F> ctab = (KPtr<F>)ctab_g;
   const KPtr<F> ptab = (KPtr<F>)(ptab_g + (long long)blockIdx.y * ptab_stride);
@@ -450,7 +452,7 @@ extern "C" int tcmi_set_error_(int code, const char* msg);
 template <typename F, int R, int LT>
 static int launch_adjoint(void* psi, void* lam, long long stride, int batch, int n, const int* desc,
                           const void* ctab, const void* ptab, long long ptab_stride, double* gout,
-                          long long gout_stride, hipStream_t st) {
+                          long long gout_stride, int gcopies, long long gcopy_stride, hipStream_t st) {
   using C = typename tcmi::Cx<F>::type;
   constexpr int T = R + LT;
   if (n < T) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_run_adjoint_pass: n smaller than the tile");
@@ -464,7 +466,7 @@ static int launch_adjoint(void* psi, void* lam, long long stride, int batch, int
   dim3 grid(1u << (n - T), (unsigned)batch, 1), block(1u << LT, 1, 1);
   hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<C*>(psi), reinterpret_cast<C*>(lam), stride,
                      desc, reinterpret_cast<const F*>(ctab), reinterpret_cast<const F*>(ptab), ptab_stride,
-                     gout, gout_stride);
+                     gout, gout_stride, gcopies, gcopy_stride);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));
   return TCMI_OK;
@@ -474,14 +476,14 @@ extern "C" {
 
 int tcmi_run_adjoint_pass(void* psi, void* lam, long long state_stride, int batch, int n, int R, int LT,
                           const int* desc_dev, const void* ctab_dev, const void* ptab_dev,
-                          long long ptab_stride, double* gout_dev, long long gout_stride, int dtype,
-                          void* stream) {
+                          long long ptab_stride, double* gout_dev, long long gout_stride, int gcopies,
+                          long long gcopy_stride, int dtype, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (!psi || !lam || !desc_dev || !gout_dev || batch < 1 || n > 32)
+  if (!psi || !lam || !desc_dev || !gout_dev || batch < 1 || n > 32 || gcopies < 1)
     return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_run_adjoint_pass: bad argument");
 #define TCMI_CASE(FT, RR, LL) \
   if (R == RR && LT == LL)    \
-    return launch_adjoint<FT, RR, LL>(psi, lam, state_stride, batch, n, desc_dev, ctab_dev, ptab_dev, ptab_stride, gout_dev, gout_stride, st);
+    return launch_adjoint<FT, RR, LL>(psi, lam, state_stride, batch, n, desc_dev, ctab_dev, ptab_dev, ptab_stride, gout_dev, gout_stride, gcopies, gcopy_stride, st);
   if (dtype == TCMI_C64) {
     TCMI_CASE(float, 4, 8)
     TCMI_CASE(float, 2, 6)

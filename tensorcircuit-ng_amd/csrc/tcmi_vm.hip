@@ -104,7 +104,8 @@ __global__ __launch_bounds__(1 << LT) void pass_kernel(typename Cx<F>::type* __r
                                                         const F* __restrict__ ptab_g,
                                                         long long ptab_stride,
                                                         double* __restrict__ eout,
-                                                        long long eout_stride) {
+                                                        long long eout_stride, int ecopies,
+                                                        long long ecopy_stride) {
   using C = typename Cx<F>::type;
   constexpr int NR = 1 << R;
   constexpr int T = R + LT;
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(1 << LT) void pass_kernel(typename Cx<F>::type* __r
 
   const int nrounds = desc[5];
   const int flags = desc[6];
-  if (eout) eout += (long long)blockIdx.y * eout_stride;
+  if (eout) eout += (long long)blockIdx.y * eout_stride + (long long)(blockIdx.x % (unsigned)ecopies) * ecopy_stride;
   // workgroup base index: deposit blockIdx.x into the non-tile bit positions
   unsigned long long x = blockIdx.x;
 #pragma unroll 1
@@ -392,7 +393,7 @@ static int set_msg(int code, const char* msg) {
 template <typename F, int R, int LT, int MODE>
 static int launch_pass_mode(void* state, long long state_stride, int batch, int n, const int* desc,
                        const void* ctab, const void* ptab, long long ptab_stride, double* eout,
-                       long long eout_stride, hipStream_t st) {
+                       long long eout_stride, int ecopies, long long ecopy_stride, hipStream_t st) {
   using C = typename tcmi::Cx<F>::type;
   constexpr int T = R + LT;
   if (n < T) return set_msg(TCMI_ERR_ARG, "tcmi_run_pass: n smaller than the tile");
@@ -406,7 +407,7 @@ static int launch_pass_mode(void* state, long long state_stride, int batch, int 
   dim3 grid(1u << (n - T), (unsigned)batch, 1), block(1u << LT, 1, 1);
   hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<C*>(state), state_stride, desc,
                      reinterpret_cast<const F*>(ctab), reinterpret_cast<const F*>(ptab), ptab_stride,
-                     eout, eout_stride);
+                     eout, eout_stride, ecopies < 1 ? 1 : ecopies, ecopy_stride);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_err("pass_kernel launch", e);
   return TCMI_OK;
@@ -415,10 +416,10 @@ static int launch_pass_mode(void* state, long long state_stride, int batch, int 
 template <typename F, int R, int LT>
 static int launch_pass(void* state, long long state_stride, int batch, int n, const int* desc,
                        const void* ctab, const void* ptab, long long ptab_stride, double* eout,
-                       long long eout_stride, hipStream_t st) {
+                       long long eout_stride, int ecopies, long long ecopy_stride, hipStream_t st) {
   if (eout)
-    return launch_pass_mode<F, R, LT, 1>(state, state_stride, batch, n, desc, ctab, ptab, ptab_stride, eout, eout_stride, st);
-  return launch_pass_mode<F, R, LT, 0>(state, state_stride, batch, n, desc, ctab, ptab, ptab_stride, eout, eout_stride, st);
+    return launch_pass_mode<F, R, LT, 1>(state, state_stride, batch, n, desc, ctab, ptab, ptab_stride, eout, eout_stride, ecopies, ecopy_stride, st);
+  return launch_pass_mode<F, R, LT, 0>(state, state_stride, batch, n, desc, ctab, ptab, ptab_stride, eout, eout_stride, ecopies, ecopy_stride, st);
 }
 
 extern "C" int tcmi_set_error_(int code, const char* msg) { return set_msg(code, msg); }
@@ -437,14 +438,14 @@ int tcmi_device_count(void) {
 
 int tcmi_run_pass(void* state, long long state_stride, int batch, int n, int R, int LT,
                   const int* desc_dev, const void* ctab_dev, const void* ptab_dev,
-                  long long ptab_stride, double* eout_dev, long long eout_stride, int dtype,
-                  void* stream) {
+                  long long ptab_stride, double* eout_dev, long long eout_stride, int ecopies,
+                  long long ecopy_stride, int dtype, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!state || !desc_dev || batch < 1) return set_msg(TCMI_ERR_ARG, "tcmi_run_pass: bad argument");
   if (n > 32) return set_msg(TCMI_ERR_ARG, "tcmi_run_pass: n > 32 unsupported");
 #define TCMI_CASE(FT, RR, LL) \
   if (R == RR && LT == LL)    \
-    return launch_pass<FT, RR, LL>(state, state_stride, batch, n, desc_dev, ctab_dev, ptab_dev, ptab_stride, eout_dev, eout_stride, st);
+    return launch_pass<FT, RR, LL>(state, state_stride, batch, n, desc_dev, ctab_dev, ptab_dev, ptab_stride, eout_dev, eout_stride, ecopies, ecopy_stride, st);
   if (dtype == TCMI_C64) {
     TCMI_CASE(float, 5, 8)
     TCMI_CASE(float, 4, 8)

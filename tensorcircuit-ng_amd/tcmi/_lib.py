@@ -37,7 +37,7 @@ _SIGNATURES = {
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p,
-         ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p],
+         ctypes.c_longlong, ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p],
     ),
     "tcmi_apply_pauli_sum": (
         ctypes.c_int,
@@ -53,7 +53,7 @@ _SIGNATURES = {
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int,
          ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong,
-         ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p],
+         ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p],
     ),
 }
 

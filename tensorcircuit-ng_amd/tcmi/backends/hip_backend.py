@@ -53,6 +53,7 @@ class HipBackend:
     # ---- creation / conversion ----------------------------------------------------------------
     def convert_to_tensor(self, a: Any, dtype: Optional[str] = None) -> Tensor:
         torch = self._torch
+        a = _resolve(a)
         if isinstance(a, torch.Tensor):
             t = a
         else:
@@ -73,6 +74,7 @@ class HipBackend:
 
     def numpy(self, a: Tensor) -> np.ndarray:
         torch = self._torch
+        a = _resolve(a)
         if isinstance(a, torch.Tensor):
             return a.detach().cpu().resolve_conj().numpy()
         return np.asarray(a)
@@ -159,6 +161,8 @@ class HipBackend:
 
     # ---- math ---------------------------------------------------------------------------------
     def real(self, a: Tensor) -> Tensor:
+        if _is_lazy(a):
+            return a.real_part()
         a = self.convert_to_tensor(a)
         return a.real if a.is_complex() else a
 
@@ -361,7 +365,7 @@ class HipBackend:
                 self.convert_to_tensor(a) if (i in _as_tuple(argnums)) else a for i, a in enumerate(args)
             )
             if not has_aux:
-                g, v = torch.func.grad_and_value(f, argnums=argnums)(*args, **kws)
+                g, v = torch.func.grad_and_value(lambda *a, **k: _resolve(f(*a, **k)), argnums=argnums)(*args, **kws)
                 return v, g
             # aux may hold non-tensor leaves (e.g. the python float ``fd`` of
             # benchmarks/scripts/vqe_tc.py:128-133); torch.func only carries tensors, so tensor
@@ -369,7 +373,7 @@ class HipBackend:
             box = {}
 
             def f2(*a: Any, **k: Any) -> Any:
-                out = f(*a, **k)
+                out = _resolve(f(*a, **k))
                 value, aux = out[0], (out[1] if len(out) == 2 else tuple(out[1:]))
                 leaves, spec = self.tree_flatten(aux)
                 box["spec"] = spec
@@ -401,7 +405,7 @@ class HipBackend:
 
         def wrapper(*args: Any, **kws: Any) -> Tensor:
             in_axes = tuple(0 if i in vectorized_argnums else None for i in range(len(args)))
-            return torch.vmap(f, in_axes, 0)(*args, **kws)
+            return torch.vmap(lambda *a, **k: _resolve(f(*a, **k)), in_axes, 0)(*args, **kws)
 
         return wrapper
 
@@ -461,6 +465,18 @@ class HipBackend:
             self._not_impl(name)
 
         return missing
+
+
+def _is_lazy(x) -> bool:
+    from ..expectation import LazyExpectation
+
+    return isinstance(x, LazyExpectation)
+
+
+def _resolve(x):
+    from ..expectation import resolve
+
+    return resolve(x)
 
 
 def _as_tuple(x):

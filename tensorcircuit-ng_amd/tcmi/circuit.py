@@ -80,6 +80,7 @@ class Circuit:
         self._params: List[Any] = []
         self._qir: List[Dict[str, Any]] = []
         self.state_tensor = None
+        self._pending = {}  # id -> weakref of unevaluated LazyExpectation objects referring to this circuit
         self.circuit_param = {"nqubits": nqubits, "inputs": inputs, "mps_inputs": None, "split": split}
 
     # ---- recording (reference basecircuit.py:183-371) ---------------------------------------
@@ -95,7 +96,16 @@ class Circuit:
                 raise ValueError(f"qubit index {q} out of range for {self._nqubits} qubits")
         return out
 
+    def _flush_pending(self):
+        """A circuit about to change first evaluates the expectations that refer to its current state."""
+        for ref in list(self._pending.values()):
+            lazy = ref()
+            if lazy is not None:
+                lazy.materialize()
+        self._pending.clear()
+
     def _record_const(self, matrix, index, name):
+        self._flush_pending()
         index = self._norm_index(index)
         m = np.asarray(matrix, dtype=np.complex128)
         d = 2 ** len(index)
@@ -106,6 +116,7 @@ class Circuit:
         self.state_tensor = None
 
     def _record_specs(self, specs, index, name, parameters):
+        self._flush_pending()
         index = self._norm_index(index)
         for s in specs:
             # concrete angles are parameters too: the cached plan is keyed by structure only, so a

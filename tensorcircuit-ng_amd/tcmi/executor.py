@@ -17,6 +17,7 @@ from . import _lib
 from . import plan as P
 
 _T_MIN = 8
+ATOMIC_COPIES = 64  # replication of atomically accumulated outputs (spreads same-address atomics)
 
 
 def _dev(array, device, dtype=None):
@@ -157,7 +158,7 @@ class CompiledCircuit:
             _lib.check(
                 lib.tcmi_run_pass(
                     state.data_ptr(), nel, B, self.n_exec, self.cfg.R, self.cfg.LT, d.data_ptr(),
-                    self.ctab.data_ptr(), ptab.data_ptr(), ptab.stride(0), None, 0, self.code, stream,
+                    self.ctab.data_ptr(), ptab.data_ptr(), ptab.stride(0), None, 0, 1, 0, self.code, stream,
                 ),
                 "tcmi_run_pass",
             )
@@ -219,16 +220,16 @@ class CompiledCircuit:
                     p.data_ptr(), p.stride(0), ptab.data_ptr(), ptab.stride(0), nb, self.code, stream),
                 "tcmi_build_adjoint_tables",
             )
-            gout = torch.zeros(nb, adj["nslots"], dtype=torch.float64, device=self.device)
+            gout = torch.zeros(nb, ATOMIC_COPIES, adj["nslots"], dtype=torch.float64, device=self.device)
             for d in adj["descs"]:
                 _lib.check(
                     lib.tcmi_run_adjoint_pass(
                         a.data_ptr(), lam.data_ptr(), nel, nb, self.n_exec, cfg.R, cfg.LT, d.data_ptr(),
                         adj["ctab"].data_ptr(), ptab.data_ptr(), ptab.stride(0), gout.data_ptr(),
-                        gout.stride(0), self.code, stream),
+                        gout.stride(0), ATOMIC_COPIES, gout.stride(1), self.code, stream),
                     "tcmi_run_adjoint_pass",
                 )
-            out[b0:b1].index_add_(1, adj["gparam"], gout * adj["gfactor"])
+            out[b0:b1].index_add_(1, adj["gparam"], gout.sum(1) * adj["gfactor"])
         return out[:, : self.nparams].to(self.rdtype)
 
 
@@ -272,18 +273,18 @@ class CompiledMeasure:
 
         B = state.shape[0]
         assert state.shape[1] == 2**self.n_exec and state.is_contiguous()
-        out = torch.zeros(B, 2 * self.nterms, dtype=torch.float64, device=self.device)
+        out = torch.zeros(B, ATOMIC_COPIES, 2 * self.nterms, dtype=torch.float64, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         for d in self.descs:
             _lib.check(
                 self._lib.tcmi_run_pass(
                     state.data_ptr(), state.shape[1], B, self.n_exec, self.cfg.R, self.cfg.LT,
                     d.data_ptr(), self.dummy.data_ptr(), self.dummy.data_ptr(), 0, out.data_ptr(),
-                    out.stride(0), self.code, stream,
+                    out.stride(0), ATOMIC_COPIES, out.stride(1), self.code, stream,
                 ),
                 "tcmi_run_pass(measure)",
             )
-        return torch.view_as_complex(out.reshape(B, self.nterms, 2)) * self.phase
+        return torch.view_as_complex(out.sum(1).reshape(B, self.nterms, 2)) * self.phase
 
     def apply_sum(self, state, gvals):
         """Cotangent of the state for L = f(<psi|P_t|psi>): 2 * sum_t Re(g_t) P_t |psi>

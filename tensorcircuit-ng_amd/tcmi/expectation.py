@@ -70,12 +70,190 @@ def pauli_sum_values(circuit, strings):
     return circuit_pauli_values(circuit, tuple(tuple(int(p) for p in s) for s in strings))
 
 
+class LazyExpectation:
+    """A linear combination  const + sum_k coef_k <psi_c| P_k |psi_c>  that has not been evaluated yet.
+
+    ``Circuit.expectation`` returns one of these, and ``+ - * /`` with numbers / tensors and
+    ``backend.real`` keep it lazy, so the reference's idiom -- a python loop summing 2n-1
+    ``c.expectation`` calls (``benchmarks/scripts/vqe_tc.py:75-81``) -- is evaluated by ONE fused
+    measurement (all Pauli strings in a couple of read-only passes over psi, one cotangent kernel
+    in the backward pass) instead of 2n-1 separate reductions.  It materialises transparently the
+    first time a value is needed (numpy conversion, any torch function, printing, comparison, or
+    when the circuit it refers to is modified)."""
+
+    __slots__ = ("terms", "const", "is_real", "_value", "__weakref__")
+    __array_priority__ = 1000
+
+    def __init__(self, terms, const=0.0, is_real=False):
+        self.terms = terms          # list of (circuit, pauli string tuple, coefficient)
+        self.const = const
+        self.is_real = is_real
+        self._value = None
+        import weakref
+
+        for c in {id(t[0]): t[0] for t in terms}.values():
+            c._pending[id(self)] = weakref.ref(self)
+
+    # ---- algebra (stays lazy) ------------------------------------------------------------------
+    @staticmethod
+    def _is_scalar(x):
+        import torch
+
+        return G.is_concrete(x) or (torch.is_tensor(x) and x.dim() == 0) or _is_batched_scalar(x)
+
+    def _scaled(self, k):
+        return LazyExpectation([(c, s, k * w) for c, s, w in self.terms], k * self.const, self.is_real and _is_real_number(k))
+
+    def __add__(self, o):
+        if self._value is not None:
+            return self._value + (o.materialize() if isinstance(o, LazyExpectation) else o)
+        if isinstance(o, LazyExpectation):
+            if o._value is not None:
+                return self.materialize() + o._value
+            return LazyExpectation(self.terms + o.terms, self.const + o.const, self.is_real and o.is_real)
+        if self._is_scalar(o):
+            return LazyExpectation(list(self.terms), self.const + o, self.is_real and _is_real_number(o))
+        return self.materialize() + o
+
+    __radd__ = __add__
+
+    def __neg__(self):
+        return self._scaled(-1.0)
+
+    def __sub__(self, o):
+        return self + (-o)
+
+    def __rsub__(self, o):
+        return (-self) + o
+
+    def __mul__(self, o):
+        if self._value is None and not isinstance(o, LazyExpectation) and self._is_scalar(o):
+            return self._scaled(o)
+        return self.materialize() * (o.materialize() if isinstance(o, LazyExpectation) else o)
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, o):
+        if self._value is None and not isinstance(o, LazyExpectation) and self._is_scalar(o):
+            return self._scaled(1.0 / o)
+        return self.materialize() / (o.materialize() if isinstance(o, LazyExpectation) else o)
+
+    def real_part(self):
+        """real(sum c_k <P_k>) = sum Re(c_k) <P_k>: Pauli-string expectations are real."""
+        if self._value is not None:
+            return cons.backend.real(self._value)
+        return LazyExpectation([(c, s, _real(w)) for c, s, w in self.terms], _real(self.const), True)
+
+    # ---- evaluation ------------------------------------------------------------------------------
+    def materialize(self):
+        import torch
+
+        if self._value is not None:
+            return self._value
+        total = None
+        by_circuit = {}
+        for c, s, w in self.terms:
+            by_circuit.setdefault(id(c), (c, {}))[1].setdefault(s, []).append(w)
+        for c, smap in by_circuit.values():
+            strings = list(smap.keys())
+            vals = pauli_sum_values(c, strings)          # [..., nterms] complex128
+            ws = [sum(v[1:], v[0]) for v in smap.values()]
+            if all(G.is_concrete(w) for w in ws):
+                wt = torch.as_tensor(np.array(ws, dtype=np.complex128), device=vals.device)
+                part = (vals * wt).sum(-1)
+            else:
+                part = sum(vals[..., k] * w for k, w in enumerate(ws))
+            total = part if total is None else total + part
+            c._pending.pop(id(self), None)
+        if total is None:
+            total = torch.zeros((), dtype=torch.complex128, device=cons.backend.device)
+        total = total + self.const
+        if self.is_real:
+            total = total.real.to(getattr(torch, cons.rdtypestr))
+        else:
+            total = total.to(getattr(torch, cons.dtypestr))
+        self._value = total
+        self.terms = []
+        return total
+
+    # ---- tensor-like surface -----------------------------------------------------------------------
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        import torch
+
+        conv = lambda x: x.materialize() if isinstance(x, LazyExpectation) else x
+        args = torch.utils._pytree.tree_map(conv, args)
+        kwargs = torch.utils._pytree.tree_map(conv, kwargs or {})
+        return func(*args, **kwargs)
+
+    def __array__(self, dtype=None, copy=None):
+        a = cons.backend.numpy(self.materialize())
+        return a.astype(dtype) if dtype is not None else a
+
+    def __float__(self):
+        return float(self.materialize().real)
+
+    def __complex__(self):
+        return complex(self.materialize())
+
+    def __repr__(self):
+        return f"LazyExpectation({self.materialize()!r})"
+
+    def __eq__(self, o):
+        return self.materialize() == (o.materialize() if isinstance(o, LazyExpectation) else o)
+
+    def __lt__(self, o):
+        return self.materialize() < o
+
+    def __gt__(self, o):
+        return self.materialize() > o
+
+    def __hash__(self):
+        return id(self)
+
+    def __getattr__(self, name):
+        # anything else (shape, dtype, item(), real, imag, detach(), ...) comes from the tensor
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return getattr(self.materialize(), name)
+
+
+def _is_batched_scalar(x):
+    import torch
+
+    return torch.is_tensor(x) and torch._C._functorch.is_functorch_wrapped_tensor(x) and x.dim() == 0
+
+
+def _is_real_number(x):
+    import torch
+
+    if torch.is_tensor(x):
+        return not x.is_complex()
+    return not isinstance(x, (complex, np.complexfloating))
+
+
+def _real(x):
+    import torch
+
+    if torch.is_tensor(x):
+        return x.real if x.is_complex() else x
+    return float(np.real(x))
+
+
+def resolve(x):
+    """Materialise LazyExpectation leaves of a pytree (used at the boundaries of function
+    transforms and by backend conversion helpers)."""
+    if isinstance(x, LazyExpectation):
+        return x.materialize()
+    if isinstance(x, (list, tuple)):
+        out = [resolve(v) for v in x]
+        return type(x)(out) if not hasattr(x, "_fields") else type(x)(*out)
+    if isinstance(x, dict):
+        return {k: resolve(v) for k, v in x.items()}
+    return x
+
+
 def expectation_of_ops(circuit, ops):
     n = circuit._nqubits
     strings, coefs = ops_to_pauli_sum(n, ops)
-    vals = pauli_sum_values(circuit, strings)
-    import torch
-
-    w = torch.as_tensor(coefs, device=vals.device)
-    out = (vals * w).sum(-1)
-    return out.to(getattr(torch, cons.dtypestr))
+    return LazyExpectation([(circuit, s, complex(c)) for s, c in zip(strings, coefs)])

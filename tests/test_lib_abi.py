@@ -36,7 +36,7 @@ def test_argument_validation_without_gpu():
     from tcmi import _lib
 
     lib = _lib.lib()
-    rc = lib.tcmi_run_pass(None, 0, 1, 10, 5, 8, None, None, None, 0, None, 0, 0, None)
+    rc = lib.tcmi_run_pass(None, 0, 1, 10, 5, 8, None, None, None, 0, None, 0, 1, 0, 0, None)
     assert rc == -1
     assert b"tcmi_run_pass" in lib.tcmi_last_error()
     assert lib.tcmi_init_zero_state(None, 0, 1, 10, 0, None) == -1
