@@ -70,6 +70,82 @@ def cpu_baseline(n_sample, d, seed, budget_s=25.0):
     }
 
 
+def vqe_leg(tc, torch, dist, args, rank, world, dev):
+    """BASELINE config 3: one VQE step = vectorized value_and_grad of the 2n-1 term TFIM energy
+    (reference benchmarks/scripts/vqe_tc.py:75-81,107-141) over a vmap batch of HEA-B circuits,
+    batch sharded over the ranks, followed by ONE packed all-reduce of [sum of energies || summed
+    gradient] (the reference's jnp.sum over devices, tensorcircuit/experimental.py:1145-1152)."""
+    import numpy as np
+    from tcmi import distributed as D
+
+    n, d, Bg = args.vqe_qubits, args.vqe_depth, args.vqe_batch
+    lo, hi = D.shard_range(Bg, rank, world)
+    params_np = np.random.default_rng(28).normal(0, 0.1, [Bg, 2 * d, n]).astype(np.float32)
+    params = torch.from_numpy(params_np[lo:hi]).to(dev)
+
+    def energy(p):
+        c = tc.Circuit(n)
+        for i in range(n):
+            c.h(i)
+        for j in range(d):
+            for i in range(n - 1):
+                c.exp1(i, i + 1, unitary=tc.gates._zz_matrix, theta=p[2 * j, i])
+            for i in range(n):
+                c.rx(i, theta=p[2 * j + 1, i])
+        e = 0.0
+        for i in range(n):
+            e += -1.0 * c.expectation((tc.gates.x(), [i]))
+        for i in range(n - 1):
+            e += 1.0 * c.expectation((tc.gates.z(), [i]), (tc.gates.z(), [i + 1]))
+        return tc.backend.real(e)
+
+    vvag = tc.backend.vvag(energy, argnums=0, vectorized_argnums=0)
+    mb = max(1, args.vqe_microbatch)
+
+    def step():
+        vals, grads = [], []
+        for b0 in range(0, hi - lo, mb):
+            v, g = vvag(params[b0: b0 + mb])
+            vals.append(v)
+            grads.append(g)
+        v = torch.cat(vals) if vals else torch.zeros(0, device=dev)
+        g = torch.cat(grads) if grads else torch.zeros(0, 2 * d, n, device=dev)
+        esum, gsum = D.allreduce_sum_packed([v.sum().reshape(1), g.sum(0)])
+        return v, g, esum, gsum
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t0 = time.perf_counter()
+    step()  # staging: plan + adjoint plan + measurement plan compile, first launch
+    sync()
+    staging = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(args.vqe_steps):
+        v, g, esum, gsum = step()
+    sync()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    return {
+        "workload": f"HEA-B n={n} depth={d} TFIM value_and_grad (55-term style energy), vmap batch {Bg} "
+                    f"(SURVEY 8d config 3), complex64",
+        "ms_per_step": el / args.vqe_steps * 1e3,
+        "steps": args.vqe_steps,
+        "samples_per_s": Bg * args.vqe_steps / el,
+        "batch_per_gpu": hi - lo,
+        "staging_s": round(staging, 3),
+        "mean_energy": float(esum.item()) / Bg,
+        "grad_norm": float(gsum.norm().item()),
+        "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 1),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,6 +156,11 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="circuits per GPU per step (vmap batch)")
     ap.add_argument("--cpu-qubits", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--vqe-qubits", type=int, default=28, help="VQE leg (config 3): qubits; 0 disables the leg")
+    ap.add_argument("--vqe-depth", type=int, default=12)
+    ap.add_argument("--vqe-batch", type=int, default=32, help="VQE leg: global vmap batch (sharded over ranks)")
+    ap.add_argument("--vqe-steps", type=int, default=2)
+    ap.add_argument("--vqe-microbatch", type=int, default=8, help="samples per vvag call (bounds HBM use)")
     ap.add_argument("--lowbits", type=int, default=None)
     ap.add_argument("--R", type=int, default=None)
     ap.add_argument("--LT", type=int, default=None)
@@ -178,6 +259,12 @@ def main():
 
     # sanity: the state is normalised (cheap property check at full size)
     nrm = float((state[0].abs() ** 2).sum().item())
+    del state
+    torch.cuda.empty_cache()
+
+    vqe = None
+    if args.vqe_qubits:
+        vqe = vqe_leg(tc, torch, dist, args, rank, world, dev)
 
     if rank == 0:
         amps = float(world) * B * (2**n) * args.steps
@@ -220,6 +307,8 @@ def main():
                 "canonical_sv_plan_GBs": ((d - 1) * (n - 1) + 2) * 2 * (2**n) * 8 * B / (pass_ms * 1e-3) / 1e9,
             },
         }
+        if vqe is not None:
+            out["vqe_step"] = vqe
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_qubits, d, seed=n)
         print(json.dumps(out))
