@@ -272,6 +272,13 @@ def main():
         bytes_per_launch = 2.0 * B * (2**cc.n_exec) * 8  # read + write the batched state once
         avg_launch_s = pass_ms * 1e-3 / npass
         achieved = bytes_per_launch / avg_launch_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01b_traffic.json")
+        if os.path.exists(tpath):
+            # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE),
+            # scaled from the profiled batch-1 launch to this run's batch
+            tj = json.load(open(tpath))
+            traffic = tj["hbm_bytes_per_amplitude_per_launch"] * B * (2**cc.n_exec)
         out = {
             "metric": "amplitudes/sec",
             "value": value,
@@ -300,7 +307,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": "profiles/r01b_traffic.json (rocprofv3 PMC, scaled by batch)" if traffic else None,
                 "launches_per_step": npass,
                 "avg_launch_us": avg_launch_s * 1e6,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
