@@ -97,6 +97,23 @@ int tcmi_run_adjoint_pass(void* psi, void* lam, long long state_stride, int batc
                           double* gout, long long gout_stride, int gcopies, long long gcopy_stride,
                           int dtype, void* stream);
 
+/* ---- pairwise contraction engine (closed networks, sliced contraction) -------------------------------
+ * tn.contract_between(a, b) -> backend.tensordot(a, b, axes) (tensorcircuit/cons.py:396,413,450,948 via
+ * tensornetwork) is lowered by tcmi/tn.py to  permute(A) -> [M x K],  permute(B) -> [K x N],
+ * C = A.B  (axes free_A + free_B, no output permute). */
+
+/* Axis permutation of a tensor whose axes all have dimension 2 (rank <= 34), out-of-place:
+ * out[o] = in[src(o)], src(o) = OR_b ((o >> b) & 1) << srcbit[b].  srcbit = int32[rank] on the device.
+ * Replaces Node.reorder_edges -> backend.transpose (tensorcircuit/cons.py:425,462,761,924,960). */
+int tcmi_permute_bits(const void* in, void* out, int rank, const int* srcbit, int batch,
+                      long long batch_stride, int dtype, void* stream);
+
+/* Batched complex GEMM C[M x N] = A[M x K] . B[K x N], row-major interleaved complex, strides in
+ * elements between batch members.  complex64 runs on the f32 MFMA pipe (exact f32 FMA);
+ * complex128 on fp64 VALU.  Replaces backend.tensordot's GEMM (numpy/jax/torch BLAS in the reference). */
+int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch,
+               long long strideA, long long strideB, long long strideC, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,193 @@
+// tcmi pairwise contraction engine (K1b / K2 of SURVEY.md section 2.2) for gfx950.
+//
+// tn.contract_between(a, b) == backend.tensordot(a, b, axes) (reference tensorcircuit/cons.py:948 via
+// tensornetwork) is lowered on the host (tcmi/tn.py) to
+//     permute(A) -> [free_A..., contracted...]   = M x K row-major
+//     permute(B) -> [contracted..., free_B...]   = K x N row-major
+//     C = A . B   (complex GEMM)                 = axes free_A + free_B, no output permute
+// This file holds the two device kernels: a bit-permutation copy for tensors whose axes all have
+// dimension 2 (every circuit tensor network) and a complex GEMM on the f32 MFMA pipe
+// (v_mfma_f32_32x32x2_f32: exact f32 FMA, 4 real MFMAs per complex k-pair).
+
+#include "tcmi_dev.h"
+
+namespace tcmi {
+
+// out[o] = in[src(o)], src(o) = OR_b ((o >> b) & 1) << srcbit[b]   (axis permutation of a [2]^rank tensor)
+template <typename C>
+__global__ void permute_bits_kernel(const C* __restrict__ in, C* __restrict__ out, int rank,
+                                    const int* __restrict__ srcbit, long long batch_stride) {
+  const KInt sb = (KInt)srcbit;
+  in += (long long)blockIdx.y * batch_stride;
+  out += (long long)blockIdx.y * batch_stride;
+  const unsigned long long nelem = 1ull << rank;
+  const unsigned long long i0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long step = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long o = i0; o < nelem; o += step) {
+    unsigned long long s = 0;
+    for (int b = 0; b < rank; ++b) s |= ((o >> b) & 1ull) << sb[b];
+    out[o] = in[s];
+  }
+}
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// C[M x N] = A[M x K] . B[K x N], row-major interleaved complex64, one 64x64 tile per workgroup,
+// 4 waves x (32x32 MFMA tile), K step 8.  LDS holds planar (re / im) operand tiles, k-major, padded
+// by one float per row (bank = (k + i) mod 32: conflict-free fragment reads).
+#define TCMI_BM 64
+#define TCMI_BN 64
+#define TCMI_BK 8
+#define TCMI_LDP (TCMI_BM + 1)
+
+__global__ __launch_bounds__(256) void cgemm_mfma_kernel(const float2* __restrict__ A,
+                                                          const float2* __restrict__ B,
+                                                          float2* __restrict__ C, int M, int N, int K,
+                                                          long long sA, long long sB, long long sC) {
+  __shared__ float As_re[TCMI_BK][TCMI_LDP], As_im[TCMI_BK][TCMI_LDP];
+  __shared__ float Bs_re[TCMI_BK][TCMI_LDP], Bs_im[TCMI_BK][TCMI_LDP];
+  A += (long long)blockIdx.z * sA;
+  B += (long long)blockIdx.z * sB;
+  C += (long long)blockIdx.z * sC;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const long long m0 = (long long)blockIdx.y * TCMI_BM, n0 = (long long)blockIdx.x * TCMI_BN;
+  f32x16 cre = {0}, cim = {0};
+  // loader coordinates: A tile 64 rows x 8 k (two complex per thread along k);
+  //                     B tile 8 k x 64 cols (two complex per thread along n)
+  const int ai = tid >> 2, ak = (tid & 3) * 2;
+  const int bk = tid >> 5, bj = (tid & 31) * 2;
+  for (int k0 = 0; k0 < K; k0 += TCMI_BK) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      float2 v = {0.f, 0.f};
+      const long long r = m0 + ai;
+      const int kk = k0 + ak + e;
+      if (r < M && kk < K) v = A[r * K + kk];
+      As_re[ak + e][ai] = v.x;
+      As_im[ak + e][ai] = v.y;
+      float2 w = {0.f, 0.f};
+      const long long c = n0 + bj + e;
+      const int kb = k0 + bk;
+      if (kb < K && c < N) w = B[(long long)kb * N + c];
+      Bs_re[bk][bj + e] = w.x;
+      Bs_im[bk][bj + e] = w.y;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < TCMI_BK; kk += 2) {
+      const int kr = kk + (lane >> 5);
+      const float are = As_re[kr][wr * 32 + (lane & 31)], aim = As_im[kr][wr * 32 + (lane & 31)];
+      const float bre = Bs_re[kr][wc * 32 + (lane & 31)], bim = Bs_im[kr][wc * 32 + (lane & 31)];
+      cre = __builtin_amdgcn_mfma_f32_32x32x2f32(are, bre, cre, 0, 0, 0);
+      cre = __builtin_amdgcn_mfma_f32_32x32x2f32(-aim, bim, cre, 0, 0, 0);
+      cim = __builtin_amdgcn_mfma_f32_32x32x2f32(are, bim, cim, 0, 0, 0);
+      cim = __builtin_amdgcn_mfma_f32_32x32x2f32(aim, bre, cim, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  const long long col = n0 + wc * 32 + (lane & 31);
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const long long row = m0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    if (row < M && col < N) {
+      float2 o;
+      o.x = cre[reg];
+      o.y = cim[reg];
+      C[row * N + col] = o;
+    }
+  }
+}
+
+// complex128 (and tiny shapes): one output element per thread, fp64 FMA chain
+template <typename F>
+__global__ void cgemm_simple_kernel(const typename Cx<F>::type* __restrict__ A,
+                                    const typename Cx<F>::type* __restrict__ B,
+                                    typename Cx<F>::type* __restrict__ C, long long M, long long N, int K,
+                                    long long sA, long long sB, long long sC) {
+  using Ct = typename Cx<F>::type;
+  A += (long long)blockIdx.z * sA;
+  B += (long long)blockIdx.z * sB;
+  C += (long long)blockIdx.z * sC;
+  const long long total = M * N;
+  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  for (long long o = i0; o < total; o += step) {
+    const long long r = o / N, c = o - r * N;
+    F re = 0, im = 0;
+    for (int k = 0; k < K; ++k) {
+      const Ct a = A[r * K + k];
+      const Ct b = B[(long long)k * N + c];
+      re = fma_<F>(a.x, b.x, re);
+      re = fma_<F>(-a.y, b.y, re);
+      im = fma_<F>(a.x, b.y, im);
+      im = fma_<F>(a.y, b.x, im);
+    }
+    Ct v;
+    v.x = re;
+    v.y = im;
+    C[o] = v;
+  }
+}
+
+}  // namespace tcmi
+
+extern "C" int tcmi_set_error_(int code, const char* msg);
+
+extern "C" {
+
+int tcmi_permute_bits(const void* in, void* out, int rank, const int* srcbit_dev, int batch,
+                      long long batch_stride, int dtype, void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!in || !out || !srcbit_dev || rank < 0 || rank > 34 || batch < 1 || in == out)
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_permute_bits: bad argument");
+  const unsigned long long nelem = 1ull << rank;
+  unsigned gx = (unsigned)((nelem + 255) / 256 > 16384 ? 16384 : (nelem + 255) / 256);
+  dim3 grid(gx, batch, 1), block(256, 1, 1);
+  if (dtype == TCMI_C64)
+    hipLaunchKernelGGL(tcmi::permute_bits_kernel<float2>, grid, block, 0, st, reinterpret_cast<const float2*>(in),
+                       reinterpret_cast<float2*>(out), rank, srcbit_dev, batch_stride);
+  else if (dtype == TCMI_C128)
+    hipLaunchKernelGGL(tcmi::permute_bits_kernel<double2>, grid, block, 0, st, reinterpret_cast<const double2*>(in),
+                       reinterpret_cast<double2*>(out), rank, srcbit_dev, batch_stride);
+  else
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_permute_bits: bad dtype");
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));
+  return TCMI_OK;
+}
+
+int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch,
+               long long strideA, long long strideB, long long strideC, int dtype, void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!A || !B || !C || M < 1 || N < 1 || K < 1 || batch < 1 || K > (1ll << 30))
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm: bad argument");
+  if (dtype == TCMI_C64 && M * N >= 1024) {
+    const long long gx = (N + TCMI_BN - 1) / TCMI_BN, gy = (M + TCMI_BM - 1) / TCMI_BM;
+    if (gy > 65535 || batch > 65535) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm: grid too large");
+    dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)batch), block(256, 1, 1);
+    hipLaunchKernelGGL(tcmi::cgemm_mfma_kernel, grid, block, 0, st, reinterpret_cast<const float2*>(A),
+                       reinterpret_cast<const float2*>(B), reinterpret_cast<float2*>(C), (int)M, (int)N, (int)K,
+                       strideA, strideB, strideC);
+  } else {
+    const long long total = M * N;
+    unsigned gx = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    dim3 grid(gx, 1, (unsigned)batch), block(256, 1, 1);
+    if (dtype == TCMI_C64)
+      hipLaunchKernelGGL(tcmi::cgemm_simple_kernel<float>, grid, block, 0, st, reinterpret_cast<const float2*>(A),
+                         reinterpret_cast<const float2*>(B), reinterpret_cast<float2*>(C), M, N, (int)K, strideA,
+                         strideB, strideC);
+    else if (dtype == TCMI_C128)
+      hipLaunchKernelGGL(tcmi::cgemm_simple_kernel<double>, grid, block, 0, st, reinterpret_cast<const double2*>(A),
+                         reinterpret_cast<const double2*>(B), reinterpret_cast<double2*>(C), M, N, (int)K, strideA,
+                         strideB, strideC);
+    else
+      return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm: bad dtype");
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));
+  return TCMI_OK;
+}
+
+}  // extern "C"

@@ -57,7 +57,7 @@ class HipBackend:
         if isinstance(a, torch.Tensor):
             t = a
         else:
-            t = torch.as_tensor(np.asarray(a) if not isinstance(a, (int, float, complex)) else a)
+            t = torch.as_tensor(np.asarray(a))  # python floats stay float64 (torch's default would be float32)
         if t.device != self.device and not _is_wrapped(t):
             t = t.to(self.device)
         if dtype is not None:
@@ -362,7 +362,8 @@ class HipBackend:
 
         def wrapper(*args: Any, **kws: Any) -> Any:
             args = tuple(
-                self.convert_to_tensor(a) if (i in _as_tuple(argnums)) else a for i, a in enumerate(args)
+                self.tree_map(self.convert_to_tensor, a) if (i in _as_tuple(argnums)) else a
+                for i, a in enumerate(args)
             )
             if not has_aux:
                 g, v = torch.func.grad_and_value(lambda *a, **k: _resolve(f(*a, **k)), argnums=argnums)(*args, **kws)

@@ -325,6 +325,118 @@ class Circuit:
                     ops.append((m, [i]))
         return self.expectation(*ops, reuse=reuse, **kws)
 
+    # ---- tensor-network form (closed networks, sliced / distributed contraction) ------------------
+    def _tn_nodes(self, conj: bool = False):
+        """The circuit as a node list (reference ``BaseCircuit._copy``, basecircuit.py:150-181):
+        n rank-1 |0> nodes (or one input node) followed by one node per gate, wired
+        ``gate[i+k] ^ front[q_i]; front[q_i] = gate[i]`` (basecircuit.py:288-290).  Returns
+        (nodes, front edges).  Gate tensors are built on the device from the current parameters
+        (differentiable)."""
+        import torch
+        from . import tn
+
+        K = cons.backend
+        dt = getattr(torch, cons.dtypestr)
+        dev = K.device
+        n = self._nqubits
+        nodes, front = [], []
+        if self.inputs is None:
+            z = torch.tensor([1.0, 0.0], dtype=dt, device=dev)
+            for q in range(n):
+                e = tn.new_edge()
+                nodes.append(tn.Node(z, [e], name=f"qb-{q}"))
+                front.append(e)
+        else:
+            t = self._input_tensor().to(dt).reshape([2] * n)
+            front = [tn.new_edge() for _ in range(n)]
+            nodes.append(tn.Node(t.conj().resolve_conj() if conj else t, list(front), name="inputs"))
+        for op in self._ops:
+            k = len(op.qubits)
+            if op.matrix is not None:
+                m = torch.as_tensor(op.matrix, dtype=dt, device=dev)
+            else:
+                s = op.spec
+                th = self._params[op.pidx]
+                th = K.convert_to_tensor(th) if not torch.is_tensor(th) else th
+                th = th.real if th.is_complex() else th
+                a = th.to(getattr(torch, cons.rdtypestr)) * s.scale + s.offset
+                c0, c1, c2 = (torch.as_tensor(x, dtype=dt, device=dev) for x in (s.c0, s.c1, s.c2))
+                m = c0 + torch.cos(a) * c1 + torch.sin(a) * c2
+            t = m.reshape([2] * (2 * k))
+            if conj:
+                t = t.conj().resolve_conj()
+            out_e = [tn.new_edge() for _ in range(k)]
+            nodes.append(tn.Node(t, out_e + [front[q] for q in op.qubits], name=op.name))
+            for j, q in enumerate(op.qubits):
+                front[q] = out_e[j]
+        return nodes, front
+
+    def expectation_before(self, *ops: Tuple[Any, List[int]], reuse: bool = True, **kws: Any):
+        """reference basecircuit.py:393-447: the uncontracted <psi| ops |psi> network as a node list
+        (``bra[q] ^ op[j]``, ``ket[q] ^ op[j+k]``, untouched qubits ``ket[j] ^ bra[j]``).  With
+        ``reuse=True`` the ket/bra are the (cached) contracted state tensor, otherwise all gate nodes."""
+        import torch
+        from . import tn
+
+        nq = self._nqubits
+        dt = getattr(torch, cons.dtypestr)
+        if reuse:
+            from .expectation import _circuit_full_state
+
+            full = _circuit_full_state(self)
+            psi = (full[..., : 2**nq] if full.shape[-1] != 2**nq else full).reshape([2] * nq)
+            e1 = [tn.new_edge() for _ in range(nq)]
+            e2 = [tn.new_edge() for _ in range(nq)]
+            nodes = [tn.Node(psi, list(e1), "psi"), tn.Node(psi.conj().resolve_conj(), list(e2), "psi*")]
+        else:
+            n1, e1 = self._tn_nodes()
+            n2, e2 = self._tn_nodes(conj=True)
+            nodes = n1 + n2
+        newdang = list(e1) + list(e2)
+        occupied = set()
+        rename = {}
+        for op, index in ops:
+            if isinstance(index, int):
+                index = [index]
+            index = tuple(i if i >= 0 else nq + i for i in index)
+            for q in index:
+                if q in occupied:
+                    raise ValueError(
+                        f"Cannot measure two operators in one index: qubit {q} "
+                        f"is already occupied by a previous operator in this "
+                        f"measurement, index={index}"
+                    )
+                occupied.add(q)
+            k = len(index)
+            t = torch.as_tensor(self._np(op), dtype=dt, device=cons.backend.device).reshape([2] * (2 * k))
+            nodes.append(tn.Node(t, [newdang[q + nq] for q in index] + [newdang[q] for q in index], "operator"))
+        for j in range(nq):
+            if j not in occupied:
+                rename[newdang[j + nq]] = newdang[j]
+        for nd in nodes:
+            nd.edges = [rename.get(e, e) for e in nd.edges]
+        return nodes
+
+    def amplitude_before(self, l):
+        """reference basecircuit.py:562-598: every output leg capped with onehot(l_i)
+        (quantum.py:166-182); returns the closed network's node list."""
+        import torch
+        from . import tn
+
+        if isinstance(l, str):
+            bits = [int(ch) for ch in l]
+        else:
+            bits = [int(round(float(b))) for b in cons.backend.numpy(cons.backend.convert_to_tensor(l)).reshape(-1)]
+        if len(bits) != self._nqubits:
+            raise ValueError("bitstring length does not match the number of qubits")
+        nodes, front = self._tn_nodes()
+        dt = getattr(torch, cons.dtypestr)
+        for b, e in zip(bits, front):
+            v = torch.zeros(2, dtype=dt, device=cons.backend.device)
+            v[b] = 1.0
+            nodes.append(tn.Node(v, [e], "onehot"))
+        return nodes
+
     def to_qir(self):
         return self._qir
 
@@ -348,9 +460,19 @@ def _make_vgate(name):
         if len(idxs) == 1:
             self._vgate(name, idxs[0], kw)
         else:
+            def pick(key, v, k):
+                # vectorised parameters broadcast with the index list (abstractcircuit.py:161-183);
+                # ``unitary`` stays a matrix
+                if key in ("unitary", "hermitian", "hamiltonian"):
+                    return v
+                if isinstance(v, (list, tuple)):
+                    return v[k]
+                if hasattr(v, "shape") and len(getattr(v, "shape", ())) >= 1 and v.shape[0] == len(idxs):
+                    return v[k]
+                return v
+
             for k, idx in enumerate(idxs):
-                kk = {key: (v[k] if isinstance(v, (list, tuple)) else v) for key, v in kw.items()}
-                self._vgate(name, idx, kk)
+                self._vgate(name, idx, {key: pick(key, v, k) for key, v in kw.items()})
 
     f.__name__ = name
     f.__doc__ = f"Apply the parametrised gate ``{name}`` (reference abstractcircuit.py:295-373)."

@@ -1,0 +1,156 @@
+"""``DistributedContractor`` for the hip backend (reference ``tensorcircuit/experimental.py:760-1249``).
+
+Same constructor / methods / ``tree_data`` format as the reference.  MI355X-first differences:
+
+* one process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI) instead of one JAX
+  process driving all devices; without an initialised process group the single rank runs every slice;
+* every rank computes the same deterministic plan (greedy path + greedy slicing), so the reference's
+  rank-0 search + broadcast (``experimental.py:850-857``) is unnecessary inside one node;
+* slices are contracted by the HIP tensordot engine (``tcmi/tn.py``) and the per-rank partial
+  ``[value || flattened gradients]`` is summed with ONE packed all-reduce
+  (reference ``jnp.sum(device_values, axis=0)``, ``experimental.py:1145-1152``).
+"""
+
+import pickle
+from typing import Any, Callable, Dict, List, Optional
+
+import numpy as np
+
+from . import cons
+from . import distributed as D
+from . import tn
+
+Tensor = Any
+
+
+class DistributedContractor:
+    def __init__(self, nodes_fn: Callable[[Any], List[tn.Node]], params: Any,
+                 cotengra_options: Optional[Dict[str, Any]] = None, devices: Optional[List[Any]] = None,
+                 mesh: Optional[Any] = None, tree_data: Optional[Dict[str, Any]] = None) -> None:
+        import torch.distributed as dist
+
+        self.nodes_fn = nodes_fn
+        self._backend = "hip"
+        self.rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+        self.num_devices = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        if tree_data is None:
+            tree_data = self._get_tree_data(nodes_fn, params, cotengra_options)
+        self.tree = tn.ContractionTree.from_data(tree_data)
+        self._report_tree_info()
+        # reference experimental.py:881-890: [num_devices, ceil(S / num_devices)], padded with -1
+        self.slice_table = D.slice_table(self.tree.nslices, self.num_devices)
+        self.my_slices = [int(s) for s in self.slice_table[self.rank] if s >= 0]
+
+    # ---- path search / persistence (reference experimental.py:923-991) --------------------------
+    @staticmethod
+    def _target_size(cotengra_options: Optional[Dict[str, Any]]) -> int:
+        opts = cotengra_options or {}
+        for key in ("slicing_reconf_opts", "slicing_opts"):
+            if key in opts and "target_size" in opts[key]:
+                return int(opts[key]["target_size"])
+        return 2**28  # reference default (experimental.py:936-942)
+
+    @staticmethod
+    def _get_tree_data(nodes_fn, params, cotengra_options) -> Dict[str, Any]:
+        nodes = nodes_fn(params)
+        inputs, output, size_dict = tn.get_tn_info(nodes)
+        # edge labels are renumbered 0..E-1 in first-appearance order: valid for every re-trace
+        ren: Dict[int, int] = {}
+        for s in inputs:
+            for e in s:
+                ren.setdefault(e, len(ren))
+        inputs = [[ren[e] for e in s] for s in inputs]
+        output = [ren[e] for e in output]
+        size_dict = {ren[e]: d for e, d in size_dict.items()}
+        tree = tn.ContractionTree.from_path(inputs, output, size_dict)
+        tree.slice_to(DistributedContractor._target_size(cotengra_options))
+        return tree.to_data()
+
+    @staticmethod
+    def find_path(nodes_fn: Callable[[Any], List[tn.Node]], params: Any,
+                  cotengra_options: Optional[Dict[str, Any]] = None, filepath: Optional[str] = None) -> Dict[str, Any]:
+        data = DistributedContractor._get_tree_data(nodes_fn, params, cotengra_options)
+        if filepath is not None:
+            with open(filepath, "wb") as f:
+                pickle.dump(data, f)
+        return data
+
+    @classmethod
+    def from_path(cls, filepath: str, nodes_fn: Callable[[Any], List[tn.Node]], devices: Optional[List[Any]] = None,
+                  mesh: Optional[Any] = None, params: Any = None) -> "DistributedContractor":
+        with open(filepath, "rb") as f:
+            data = pickle.load(f)
+        return cls(nodes_fn, params, devices=devices, mesh=mesh, tree_data=data)
+
+    def _report_tree_info(self) -> None:
+        """reference experimental.py:909-920."""
+        t = self.tree
+        item = 8 if cons.dtypestr == "complex64" else 16
+        self.tree_info = {
+            "nslices": t.nslices, "sliced_inds": len(t.sliced_inds), "log2_max_size": t.contraction_width(),
+            "log10_flops": float(np.log10(max(1, t.total_flops()))), "log2_write": float(np.log2(max(1, t.total_write()))),
+            "algorithmic_bytes": t.algorithmic_bytes(item),
+        }
+
+    # ---- evaluation -----------------------------------------------------------------------------------
+    def _arrays(self, params):
+        nodes = self.nodes_fn(params)
+        return [n.tensor for n in nodes]
+
+    def _local_sum(self, params, op):
+        total = None
+        arrays = self._arrays(params)
+        for i in self.my_slices:
+            r = self.tree.contract_core(self.tree.slice_arrays(arrays, i))
+            total = r if total is None else total + r
+        if total is None:  # this rank only holds padding
+            import torch
+
+            total = torch.zeros([2] * (len(self.tree.output)), dtype=getattr(torch, cons.dtypestr), device=cons.backend.device)
+        return total
+
+    def value(self, params: Any, op: Optional[Callable[[Tensor], Tensor]] = None, output_dtype: Optional[str] = None) -> Tensor:
+        """Sum over all slices and ranks; default ``op`` = sum of the result (complex), reference
+        experimental.py:1065-1100."""
+        import torch
+
+        with torch.no_grad():
+            part = self._local_sum(params, op)
+            re, im = D.allreduce_sum_packed([part.real.contiguous(), part.imag.contiguous()])
+            full = torch.complex(re, im)
+        out = op(full) if op is not None else full.sum()
+        if output_dtype is not None:
+            out = cons.backend.cast(out, output_dtype)
+        return out
+
+    def value_and_grad(self, params: Any, op: Optional[Callable[[Tensor], Tensor]] = None, output_dtype: Optional[str] = None):
+        """(value, grads) with grads shaped like ``params``; default op = real(sum(x))
+        (reference experimental.py:1018,1182-1211).  The op must be linear in the contraction result
+        for the slice sum to commute with it (as in the reference, which applies op per slice)."""
+        import torch
+
+        K = cons.backend
+        leaves, spec = K.tree_flatten(params)
+        leaves = [K.convert_to_tensor(x).detach().clone().requires_grad_(True) for x in leaves]
+        p = K.tree_unflatten(spec, leaves)
+        fop = op if op is not None else (lambda x: x.sum().real)
+        arrays = self._arrays(p)
+        value = None
+        for i in self.my_slices:
+            r = fop(self.tree.contract_core(self.tree.slice_arrays(arrays, i)))
+            value = r if value is None else value + r
+        if value is None:
+            value = sum((x.sum() * 0 for x in leaves)).real
+        grads = torch.autograd.grad(value, leaves, allow_unused=True)
+        grads = [g if g is not None else torch.zeros_like(x) for g, x in zip(grads, leaves)]
+        packed = D.allreduce_sum_packed([value.detach().reshape(1).real.to(torch.float64)] + [g.to(torch.float64) if not g.is_complex() else g.real.to(torch.float64) for g in grads])
+        v = packed[0].reshape(())
+        gs = [g.to(x.dtype) for g, x in zip(packed[1:], leaves)]
+        if output_dtype is not None:
+            v = K.cast(v, output_dtype)
+        else:
+            v = v.to(getattr(torch, cons.rdtypestr))
+        return v, K.tree_unflatten(spec, gs)
+
+    def grad(self, params: Any, op: Optional[Callable[[Tensor], Tensor]] = None, output_dtype: Optional[str] = None) -> Any:
+        return self.value_and_grad(params, op, output_dtype)[1]

@@ -1,0 +1,481 @@
+"""Tensor-network layer of the hip backend: nodes, path search, slicing and the pairwise contraction
+executor that drives the HIP tensordot engine (``tcmi_permute_bits`` + ``tcmi_cgemm``).
+
+Counterpart of what the reference gets from third parties: ``tensornetwork`` nodes and
+``contract_between`` (``tensorcircuit/cons.py:937-950``), ``opt_einsum.paths.greedy``
+(``cons.py:1246-1258``) and cotengra's slicing (``tensorcircuit/experimental.py:863-872,1007-1008``).
+Host side is symbolic (integers only) and testable without a GPU; tensors are torch-ROCm tensors
+of shape ``[2] * rank`` (every circuit network has dimension-2 edges).
+"""
+
+import heapq
+import itertools
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from . import cons
+
+_edge_ids = itertools.count()
+
+
+def new_edge() -> int:
+    return next(_edge_ids)
+
+
+class Node:
+    """A tensor with integer edge labels (a label shared by two nodes is a contracted edge, a label
+    appearing once is dangling).  ``node.tensor`` mirrors ``tn.Node.tensor``."""
+
+    __slots__ = ("tensor", "edges", "name")
+
+    def __init__(self, tensor, edges: Sequence[int], name: str = ""):
+        self.tensor = tensor
+        self.edges = list(edges)
+        self.name = name
+
+    def __repr__(self):
+        return f"Node(name={self.name!r}, edges={self.edges})"
+
+
+# ---- symbolic part: network info, greedy path, slicing ---------------------------------------------
+def get_tn_info(nodes: Sequence[Node]):
+    """``cons.get_tn_info`` (reference cons.py:804): (input_sets, output_set, size_dict) with the
+    nodes in their list order (the deterministic order the reference gets from ``_stable_id_``)."""
+    inputs = [list(n.edges) for n in nodes]
+    count: Dict[int, int] = {}
+    for s in inputs:
+        for e in s:
+            count[e] = count.get(e, 0) + 1
+    output = [e for s in inputs for e in s if count[e] == 1]
+    size_dict = {e: 2 for e in count}
+    return inputs, output, size_dict
+
+
+def greedy_path(inputs: Sequence[Sequence[int]], output: Sequence[int], size_dict: Dict[int, int],
+                memory_limit=None) -> List[Tuple[int, int]]:
+    """Greedy pairwise path in opt_einsum's linear format (reference cons.py:937-950: each (a, b)
+    indexes the current list, both are removed, the result is appended).  Candidate pairs share an
+    index; score = size(out) - size(a) - size(b); leftovers are outer-multiplied smallest first."""
+    out_set = frozenset(output)
+    live: Dict[int, frozenset] = {i: frozenset(s) for i, s in enumerate(inputs)}
+    uses: Dict[int, int] = {}
+    owners: Dict[int, set] = {}
+    for i, s in live.items():
+        for e in s:
+            uses[e] = uses.get(e, 0) + 1
+            owners.setdefault(e, set()).add(i)
+
+    def sz(s):
+        r = 1
+        for e in s:
+            r *= size_dict[e]
+        return r
+
+    def merged(a, b):
+        sa, sb = live[a], live[b]
+        keep = []
+        for e in sa | sb:
+            rest = uses[e] - (e in sa) - (e in sb)
+            if rest > 0 or e in out_set:
+                keep.append(e)
+        return frozenset(keep)
+
+    heap: List[Tuple[int, int, int]] = []
+
+    def push(i):
+        seen = set()
+        for e in live[i]:
+            for j in owners.get(e, ()):
+                if j != i and j in live and j not in seen:
+                    seen.add(j)
+                    a, b = (i, j) if i < j else (j, i)
+                    m = merged(a, b)
+                    heapq.heappush(heap, (sz(m) - sz(live[a]) - sz(live[b]), a, b))
+
+    for i in list(live):
+        push(i)
+    nxt = len(live)
+    ssa: List[Tuple[int, int]] = []
+    while heap:
+        cost, a, b = heapq.heappop(heap)
+        if a not in live or b not in live:
+            continue
+        m = merged(a, b)
+        real = sz(m) - sz(live[a]) - sz(live[b])
+        if real != cost:
+            heapq.heappush(heap, (real, a, b))
+            continue
+        for x in (a, b):
+            for e in live[x]:
+                uses[e] -= 1
+                owners[e].discard(x)
+            del live[x]
+        live[nxt] = m
+        for e in m:
+            uses[e] = uses.get(e, 0) + 1
+            owners.setdefault(e, set()).add(nxt)
+        ssa.append((a, b))
+        push(nxt)
+        nxt += 1
+    rest = sorted(live, key=lambda i: sz(live[i]))
+    while len(rest) > 1:
+        a, b = rest[0], rest[1]
+        live[nxt] = live[a] | live[b]
+        ssa.append((a, b))
+        rest = sorted([nxt] + rest[2:], key=lambda i: sz(live[i]))
+        nxt += 1
+    ids = list(range(len(inputs)))
+    path = []
+    k = len(inputs)
+    for a, b in ssa:
+        ia, ib = ids.index(a), ids.index(b)
+        path.append((min(ia, ib), max(ia, ib)))
+        for i in sorted((ia, ib), reverse=True):
+            ids.pop(i)
+        ids.append(k)
+        k += 1
+    return path
+
+
+@dataclass
+class ContractionTree:
+    """Path + slicing of one network (the part of cotengra's ``ContractionTree`` the reference uses:
+    ``from_path``, ``remove_ind_``, ``sliced_inds``, ``nslices``, ``slice_arrays``, ``contract_core``,
+    ``total_flops / total_write / max_size``; reference experimental.py:863-872,909-919,1007-1008)."""
+
+    inputs: List[List[int]]
+    output: List[int]
+    size_dict: Dict[int, int]
+    path: List[Tuple[int, int]]
+    sliced_inds: List[int] = field(default_factory=list)
+
+    @classmethod
+    def from_path(cls, inputs, output, size_dict, path=None):
+        inputs = [list(s) for s in inputs]
+        if path is None:
+            path = greedy_path(inputs, output, size_dict)
+        return cls(inputs, list(output), dict(size_dict), [tuple(p) for p in path])
+
+    # -- cost model ---------------------------------------------------------------------------------
+    def _walk(self):
+        """Yield (set_a, set_b, set_out) of every pairwise step with the sliced indices removed."""
+        sl = set(self.sliced_inds)
+        cur = [frozenset(e for e in s if e not in sl) for s in self.inputs]
+        uses: Dict[int, int] = {}
+        for s in cur:
+            for e in s:
+                uses[e] = uses.get(e, 0) + 1
+        out = frozenset(e for e in self.output if e not in sl)
+        for a, b in self.path:
+            sa, sb = cur[a], cur[b]
+            keep = frozenset(e for e in sa | sb if uses[e] - (e in sa) - (e in sb) > 0 or e in out)
+            for e in sa:
+                uses[e] -= 1
+            for e in sb:
+                uses[e] -= 1
+            for e in keep:
+                uses[e] += 1
+            yield sa, sb, keep
+            cur = [s for k, s in enumerate(cur) if k not in (a, b)] + [keep]
+
+    def _size(self, s):
+        r = 1
+        for e in s:
+            r *= self.size_dict[e]
+        return r
+
+    @property
+    def nslices(self) -> int:
+        return self._size(self.sliced_inds)
+
+    def max_size(self) -> int:
+        return max([self._size(k) for _, _, k in self._walk()] + [1])
+
+    def contraction_width(self) -> float:
+        return float(np.log2(self.max_size()))
+
+    def total_write(self) -> int:
+        return self.nslices * sum(self._size(k) for _, _, k in self._walk())
+
+    def total_flops(self) -> int:
+        """Real flops (8 per complex multiply-add), all slices."""
+        return self.nslices * sum(8 * self._size(sa | sb) for sa, sb, _ in self._walk())
+
+    def algorithmic_bytes(self, itemsize: int) -> int:
+        """itemsize * sum(size(A) + size(B) + size(C)) over the executed steps."""
+        return self.nslices * itemsize * sum(self._size(a) + self._size(b) + self._size(c) for a, b, c in self._walk())
+
+    # -- slicing -------------------------------------------------------------------------------------
+    def remove_ind_(self, ind: int) -> None:
+        if ind not in self.sliced_inds:
+            self.sliced_inds.append(ind)
+
+    def _repath(self) -> None:
+        """Re-run the greedy search on the network with the sliced indices removed (the sliced
+        network is smaller, so the path should adapt to it: cotengra's "slicing + reconfiguration")."""
+        sl = set(self.sliced_inds)
+        inputs = [[e for e in s if e not in sl] for s in self.inputs]
+        output = [e for e in self.output if e not in sl]
+        self.path = greedy_path(inputs, output, self.size_dict)
+
+    def slice_to(self, target_size: int, max_slices: int = 1 << 16, max_candidates: int = 12) -> "ContractionTree":
+        """Slice until the largest intermediate fits ``target_size`` elements.  Each step tries the
+        (non-output) indices of the largest intermediates, re-paths the sliced network for every
+        candidate and keeps the one with the smallest (max_size, total flops)."""
+        out = set(self.output)
+        while self.max_size() > target_size:
+            if self.nslices * 2 > max_slices:
+                raise RuntimeError(
+                    f"slicing to target_size={target_size} needs more than {max_slices} slices"
+                )
+            score: Dict[int, int] = {}
+            for _, _, k in self._walk():
+                s = self._size(k)
+                if s > target_size:
+                    for e in k:
+                        if e not in out:
+                            score[e] = score.get(e, 0) + s
+            if not score:
+                break
+            cands = sorted(score, key=lambda e: (-score[e], e))[:max_candidates]
+            best = None
+            base_sliced, base_path = list(self.sliced_inds), list(self.path)
+            for e in cands:
+                self.sliced_inds = base_sliced + [e]
+                self._repath()
+                sizes = [self._size(k) for _, _, k in self._walk()]
+                over = sum(x for x in sizes if x > target_size)   # smooth potential: progress even
+                key = (max(sizes + [1]) > target_size, over, self.total_flops())  # when max stays
+                if best is None or key < best[0]:
+                    best = (key, e, list(self.path))
+            self.sliced_inds = base_sliced + [best[1]]
+            self.path = best[2]
+        return self
+
+    def slice_index_values(self, i: int) -> Dict[int, int]:
+        """Mixed-radix digits of slice ``i`` (first sliced index = most significant)."""
+        vals = {}
+        for e in reversed(self.sliced_inds):
+            d = self.size_dict[e]
+            vals[e] = i % d
+            i //= d
+        return vals
+
+    def slice_arrays(self, arrays: Sequence[Any], i: int) -> List[Any]:
+        """Fix every sliced index to its value in slice ``i`` (host-side view selection, K8)."""
+        vals = self.slice_index_values(i)
+        out = []
+        for arr, edges in zip(arrays, self.inputs):
+            idx = tuple(vals[e] if e in vals else slice(None) for e in edges)
+            out.append(arr[idx] if any(e in vals for e in edges) else arr)
+        return out
+
+    def contract_core(self, arrays: Sequence[Any]):
+        """Pairwise contraction of (already sliced) arrays along the path; returns the result with
+        axes in ``output`` order (minus sliced indices)."""
+        sl = set(self.sliced_inds)
+        tens = list(arrays)
+        edges = [[e for e in s if e not in sl] for s in self.inputs]
+        uses: Dict[int, int] = {}
+        for s in edges:
+            for e in s:
+                uses[e] = uses.get(e, 0) + 1
+        out = [e for e in self.output if e not in sl]
+        outset = set(out)
+        for a, b in self.path:
+            ea, eb = edges[a], edges[b]
+            shared = [e for e in ea if e in eb and uses[e] == 2 and e not in outset]
+            t = tensordot(tens[a], tens[b], [ea.index(e) for e in shared], [eb.index(e) for e in shared])
+            ne = [e for e in ea if e not in shared] + [e for e in eb if e not in shared]
+            for e in shared:
+                uses[e] -= 2
+            tens = [x for k, x in enumerate(tens) if k not in (a, b)] + [t]
+            edges = [x for k, x in enumerate(edges) if k not in (a, b)] + [ne]
+        res, re_ = tens[0], edges[0]
+        if list(re_) != out:
+            res = permute(res, [re_.index(e) for e in out])
+        return res
+
+    def to_data(self) -> Dict[str, Any]:
+        """``tree_data`` dictionary of the reference (experimental.py:957-991)."""
+        return {"inputs": self.inputs, "output": self.output, "size_dict": self.size_dict,
+                "path": self.path, "sliced_inds": self.sliced_inds}
+
+    @classmethod
+    def from_data(cls, d):
+        t = cls.from_path(d["inputs"], d["output"], d["size_dict"], d["path"])
+        for e in d.get("sliced_inds", []):
+            t.remove_ind_(e)
+        return t
+
+
+# ---- device part: permute / tensordot through the C ABI --------------------------------------------
+_SRCBIT_CACHE: Dict[Tuple, Any] = {}
+
+
+def _code(t):
+    import torch
+
+    if t.dtype == torch.complex64:
+        return _lib.TCMI_C64
+    if t.dtype == torch.complex128:
+        return _lib.TCMI_C128
+    raise TypeError(f"tcmi tensordot engine needs complex64/complex128 tensors, got {t.dtype}")
+
+
+def _permute_raw(t, perm):
+    """out axis i = in axis perm[i], for a contiguous [2]*rank device tensor (HIP kernel)."""
+    import torch
+
+    rank = t.dim()
+    perm = tuple(int(p) for p in perm)
+    if perm == tuple(range(rank)):
+        return t
+    assert all(s == 2 for s in t.shape), "the hip tensordot engine handles dimension-2 axes"
+    key = (perm, t.device.index)
+    sb = _SRCBIT_CACHE.get(key)
+    if sb is None:
+        from .executor import _dev
+
+        src = np.zeros(rank, dtype=np.int32)
+        for i, p in enumerate(perm):
+            src[rank - 1 - i] = rank - 1 - p
+        sb = _dev(src, t.device)
+        _SRCBIT_CACHE[key] = sb
+    t = t.contiguous()
+    out = torch.empty_like(t)
+    stream = torch.cuda.current_stream(t.device).cuda_stream
+    _lib.check(_lib.lib().tcmi_permute_bits(t.data_ptr(), out.data_ptr(), rank, sb.data_ptr(), 1, 0, _code(t), stream),
+               "tcmi_permute_bits")
+    return out
+
+
+def _gemm_raw(a2, b2, M, N, K):
+    import torch
+
+    a2, b2 = a2.contiguous(), b2.contiguous()
+    c = torch.empty(M * N, dtype=a2.dtype, device=a2.device)
+    stream = torch.cuda.current_stream(a2.device).cuda_stream
+    _lib.check(_lib.lib().tcmi_cgemm(a2.data_ptr(), b2.data_ptr(), c.data_ptr(), M, N, K, 1, 0, 0, 0, _code(a2), stream),
+               "tcmi_cgemm")
+    return c
+
+
+_FN = {}
+
+
+def _fns():
+    if _FN:
+        return _FN
+    import torch
+
+    class PermuteFn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t, perm):
+            ctx.perm = tuple(perm)
+            return _permute_raw(t, perm)
+
+        @staticmethod
+        def backward(ctx, g):
+            inv = [0] * len(ctx.perm)
+            for i, p in enumerate(ctx.perm):
+                inv[p] = i
+            return PermuteFn.apply(g.contiguous(), tuple(inv)), None
+
+    class GemmFn(torch.autograd.Function):
+        """C[M,N] = A[M,K] B[K,N] on flat [2]*r tensors already in GEMM layout."""
+
+        @staticmethod
+        def forward(ctx, a, b, M, N, K):
+            ctx.save_for_backward(a, b)
+            ctx.dims = (M, N, K)
+            return _gemm_raw(a, b, M, N, K)
+
+        @staticmethod
+        def backward(ctx, g):
+            a, b = ctx.saved_tensors
+            M, N, K = ctx.dims
+            ga = gb = None
+            g = g.contiguous()
+            if ctx.needs_input_grad[0]:
+                # gA = g . B^H : (M x N)(N x K); B^H = conj(transpose(B)) via the bit-permute kernel
+                bh = _transpose2(b.conj().resolve_conj(), K, N)
+                ga = _gemm_raw(g, bh, M, K, N).reshape(a.shape)
+            if ctx.needs_input_grad[1]:
+                ah = _transpose2(a.conj().resolve_conj(), M, K)
+                gb = _gemm_raw(ah, g, K, N, M).reshape(b.shape)
+            return ga, gb, None, None, None
+
+    _FN.update(PermuteFn=PermuteFn, GemmFn=GemmFn)
+    return _FN
+
+
+def _transpose2(t, rows, cols):
+    """[rows x cols] -> [cols x rows] for power-of-two shapes, through the bit-permute kernel."""
+    r, c = int(np.log2(rows)), int(np.log2(cols))
+    flat = t.reshape([2] * (r + c)) if r + c > 0 else t.reshape([])
+    if r == 0 or c == 0:
+        return t.reshape(-1)
+    return _permute_raw(flat, tuple(range(r, r + c)) + tuple(range(r))).reshape(-1)
+
+
+def permute(t, perm):
+    """Differentiable axis permutation on the device (K2)."""
+    perm = tuple(int(p) for p in perm)
+    if perm == tuple(range(t.dim())):
+        return t
+    return _fns()["PermuteFn"].apply(t.contiguous(), perm)
+
+
+def tensordot(a, b, axes_a: Sequence[int], axes_b: Sequence[int]):
+    """``backend.tensordot(a, b, [axes_a, axes_b])`` on the HIP engine (K1b): result axes = a's free
+    axes in order, then b's (the ``contract_between`` convention)."""
+    import torch
+
+    if a.dtype != b.dtype:
+        dt = torch.promote_types(a.dtype, b.dtype)
+        a, b = a.to(dt), b.to(dt)
+    axes_a, axes_b = [int(x) for x in axes_a], [int(x) for x in axes_b]
+    fa = [i for i in range(a.dim()) if i not in axes_a]
+    fb = [i for i in range(b.dim()) if i not in axes_b]
+    a2 = permute(a, fa + axes_a)
+    b2 = permute(b, axes_b + fb)
+    M, K, N = 2 ** len(fa), 2 ** len(axes_a), 2 ** len(fb)
+    c = _fns()["GemmFn"].apply(a2, b2, M, N, K)
+    return c.reshape([2] * (len(fa) + len(fb)))
+
+
+def contract_between(na: Node, nb: Node) -> Node:
+    shared = [e for e in na.edges if e in nb.edges]
+    t = tensordot(na.tensor, nb.tensor, [na.edges.index(e) for e in shared], [nb.edges.index(e) for e in shared])
+    return Node(t, [e for e in na.edges if e not in shared] + [e for e in nb.edges if e not in shared])
+
+
+def contract_nodes(nodes: Sequence[Node], output_edge_order: Optional[Sequence[int]] = None,
+                   target_size: Optional[int] = None):
+    """The contractor call of the reference (``contractor(nodes, output_edge_order=...)``,
+    cons.py:845-961) on the HIP engine: greedy path, optional slicing, pairwise GEMMs.  Returns a Node."""
+    inputs, output, size_dict = get_tn_info(nodes)
+    if output_edge_order is None:
+        if len(output) > 1:
+            raise ValueError(
+                "The final node after contraction has more than one remaining edge. "
+                "In this case `output_edge_order` has to be provided."
+            )
+        output_edge_order = output
+    if set(output_edge_order) != set(output):
+        raise ValueError("output edges are not equal to the remaining non-contracted edges of the final node.")
+    tree = ContractionTree.from_path(inputs, list(output_edge_order), size_dict)
+    arrays = [n.tensor for n in nodes]
+    if target_size is not None:
+        tree.slice_to(target_size)
+    if not tree.sliced_inds:
+        return Node(tree.contract_core(arrays), list(output_edge_order))
+    total = None
+    for i in range(tree.nslices):
+        r = tree.contract_core(tree.slice_arrays(arrays, i))
+        total = r if total is None else total + r
+    return Node(total, [e for e in output_edge_order if e not in tree.sliced_inds])

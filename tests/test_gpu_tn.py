@@ -1,0 +1,180 @@
+"""The HIP pairwise-contraction engine (tcmi_permute_bits / tcmi_cgemm), closed networks built by
+Circuit.amplitude_before / expectation_before, and DistributedContractor (single process = all
+slices on one GPU) against the oracle and against the state-vector path."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dense, gates as G, workloads as W  # noqa: E402
+
+
+@pytest.fixture(params=["complex64", "complex128"])
+def tcd(request):
+    import tcmi as tc
+
+    tc.set_backend("hip")
+    tc.set_dtype(request.param)
+    yield tc
+    tc.set_dtype("complex64")
+
+
+def test_permute_and_tensordot_kernels(tcd):
+    import torch
+    from tcmi import tn
+
+    tc = tcd
+    dt = getattr(torch, tc.dtypestr)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for rank, perm in [(3, (2, 0, 1)), (6, (5, 3, 0, 1, 4, 2)), (12, tuple(np.random.default_rng(1).permutation(12)))]:
+        t = torch.randn([2] * rank, dtype=dt, device="cuda", generator=g)
+        got = tn.permute(t, perm)
+        assert torch.equal(got, t.permute(*perm).contiguous())
+    tol = 1e-4 if tc.dtypestr == "complex64" else 1e-11
+    for ra, rb, xa, xb in [(2, 2, [1], [0]), (4, 6, [3, 0], [1, 4]), (10, 9, [9, 2, 4, 0], [0, 8, 3, 5]),
+                           (14, 14, list(range(7, 14)), list(range(7))), (8, 8, [], []), (5, 5, [0, 1, 2, 3, 4], [4, 3, 2, 1, 0])]:
+        a = torch.randn([2] * ra, dtype=dt, device="cuda", generator=g)
+        b = torch.randn([2] * rb, dtype=dt, device="cuda", generator=g)
+        got = tn.tensordot(a, b, xa, xb)
+        want = torch.tensordot(a.to(torch.complex128), b.to(torch.complex128), dims=(xa, xb))
+        scale = float(want.abs().max()) + 1e-30
+        assert float((got.to(torch.complex128) - want).abs().max()) / scale < tol, (ra, rb, xa, xb)
+
+
+def test_tensordot_gradients(tcd):
+    """VJP of the engine (two GEMMs with conjugate-transposed operands) against torch.autograd on
+    torch.tensordot."""
+    import torch
+    from tcmi import tn
+
+    tc = tcd
+    dt = getattr(torch, tc.dtypestr)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a = torch.randn([2] * 7, dtype=dt, device="cuda", generator=g, requires_grad=True)
+    b = torch.randn([2] * 6, dtype=dt, device="cuda", generator=g, requires_grad=True)
+    w = torch.randn([2] * 7, dtype=dt, device="cuda", generator=g)
+    xa, xb = [6, 1, 3], [0, 5, 2]
+    (tn.tensordot(a, b, xa, xb) * w).sum().real.backward()
+    ga, gb = a.grad.clone(), b.grad.clone()
+    a.grad = b.grad = None
+    (torch.tensordot(a, b, dims=(xa, xb)) * w).sum().real.backward()
+    tol = 1e-4 if tc.dtypestr == "complex64" else 1e-11
+    assert float((ga - a.grad).abs().max()) < tol * 10 and float((gb - b.grad).abs().max()) < tol * 10
+
+
+@pytest.mark.parametrize("n,depth", [(6, 3), (12, 4)])
+def test_closed_network_amplitude_and_expectation(tcd, n, depth):
+    """amplitude_before / expectation_before contracted by the HIP engine == oracle, and == the
+    state-vector path (reference basecircuit.py:562-624, 393-447)."""
+    from tcmi import tn
+
+    tc = tcd
+    rng = np.random.default_rng(n)
+    c = tc.Circuit(n)
+    ops = []
+    for d in range(depth):
+        for i in range(d % 2, n - 1, 2):
+            u = G.random_two_qubit_gate(int(rng.integers(1 << 30)))
+            c.any(i, i + 1, unitary=u)
+            ops.append((u, [i, i + 1]))
+        for i in range(n):
+            t = float(rng.uniform(0, 6))
+            c.rx(i, theta=t)
+            ops.append((G.rx(t), [i]))
+    psi = dense.run(n, ops)
+    tol = 1e-5 if tc.dtypestr == "complex64" else 1e-10
+    bits = "".join(str(int(b)) for b in rng.integers(0, 2, n))
+    amp = tn.contract_nodes(c.amplitude_before(bits)).tensor
+    np.testing.assert_allclose(tc.backend.numpy(amp), dense.amplitude(psi, n, bits), atol=tol)
+    np.testing.assert_allclose(tc.backend.numpy(c.amplitude(bits)), dense.amplitude(psi, n, bits), atol=tol)
+    for reuse in (True, False):
+        nodes = c.expectation_before((tc.gates.z(), [n - 1]), (tc.gates.x(), [0]), reuse=reuse)
+        e = tn.contract_nodes(nodes).tensor
+        want = dense.expectation(psi, n, (G.Z, [n - 1]), (G.X, [0]))
+        np.testing.assert_allclose(tc.backend.numpy(e), want, atol=tol)
+    # sliced contraction == unsliced
+    nodes = c.expectation_before((tc.gates.z(), [n - 1]), reuse=False)
+    e = tn.contract_nodes(nodes, target_size=2**5).tensor
+    np.testing.assert_allclose(tc.backend.numpy(e), dense.expectation(psi, n, (G.Z, [n - 1])), atol=tol * 4)
+
+
+def test_reference_distributed_contractor_kat(tcd):
+    """reference tests/test_miscs.py:275-304 verbatim: 4 qubits, rx / cnot ladder / ry, target_size 2**3;
+    value == expectation_ps(z=[-1]) at 1e-6, grad["y"].shape == (4,)."""
+    tc = tcd
+
+    def nodes_fn(params):
+        c = tc.Circuit(4)
+        c.rx(range(4), theta=params["x"])
+        c.cnot([0, 1, 2], [1, 2, 3])
+        c.ry(range(4), theta=params["y"])
+        return c.expectation_before([tc.gates.z(), [-1]], reuse=False)
+
+    params = {"x": np.ones([4]), "y": 0.3 * np.ones([4])}
+    dc = tc.experimental.DistributedContractor(
+        nodes_fn, params,
+        {"slicing_reconf_opts": {"target_size": 2**3}, "max_repeats": 8, "minimize": "write", "parallel": False},
+    )
+    value, grad = dc.value_and_grad(params)
+    assert tuple(grad["y"].shape) == (4,)
+
+    def baseline(params):
+        c = tc.Circuit(4)
+        c.rx(range(4), theta=params["x"])
+        c.cnot([0, 1, 2], [1, 2, 3])
+        c.ry(range(4), theta=params["y"])
+        return c.expectation_ps(z=[-1])
+
+    np.testing.assert_allclose(tc.backend.numpy(value), tc.backend.numpy(baseline(params)).real, atol=1e-6)
+
+
+def test_distributed_contractor_single_process(tcd, tmp_path):
+    """reference tests/test_miscs.py:275-304: target_size = 2**3 forces real slicing; the summed value
+    equals expectation_ps(z=[-1]) (atol 1e-6 in the reference) and grads have the parameter shapes."""
+    import torch
+
+    tc = tcd
+    n, nlayers = 6, 3
+    rng = np.random.default_rng(0)
+    params = {"x": tc.backend.convert_to_tensor(rng.normal(size=[nlayers, n]), dtype=tc.rdtypestr),
+              "y": tc.backend.convert_to_tensor(rng.normal(size=[n]), dtype=tc.rdtypestr)}
+
+    def build(p):
+        c = tc.Circuit(n)
+        for i in range(n):
+            c.h(i)
+        for j in range(nlayers):
+            for i in range(n - 1):
+                c.cnot(i, i + 1)
+            for i in range(n):
+                c.rx(i, theta=p["x"][j, i])
+        for i in range(n):
+            c.ry(i, theta=p["y"][i])
+        return c
+
+    def nodes_fn(p):
+        return build(p).expectation_before([tc.gates.z(), [-1]], reuse=False)
+
+    dc = tc.experimental.DistributedContractor(nodes_fn, params, {"slicing_reconf_opts": {"target_size": 2**4}})
+    assert 2 <= dc.tree.nslices <= 64 and dc.tree.max_size() <= 2**4
+    v = dc.value(params)
+    want = build(params).expectation_ps(z=[-1])
+    tol = 1e-5 if tc.dtypestr == "complex64" else 1e-10
+    np.testing.assert_allclose(tc.backend.numpy(v), tc.backend.numpy(want), atol=tol)
+    v2, g = dc.value_and_grad(params)
+    np.testing.assert_allclose(tc.backend.numpy(v2), tc.backend.numpy(tc.backend.real(want)), atol=tol)
+    assert tuple(g["x"].shape) == (nlayers, n) and tuple(g["y"].shape) == (n,)
+    # gradient == adjoint-sweep gradient of the state-vector path
+    def f(p):
+        return tc.backend.real(build(p).expectation_ps(z=[-1]))
+    _, g_sv = tc.backend.value_and_grad(f)(params)
+    gtol = 2e-4 if tc.dtypestr == "complex64" else 1e-8
+    np.testing.assert_allclose(tc.backend.numpy(g["x"]), tc.backend.numpy(g_sv["x"]), atol=gtol)
+    np.testing.assert_allclose(tc.backend.numpy(g["y"]), tc.backend.numpy(g_sv["y"]), atol=gtol)
+    # path persistence (reference experimental.py:947-991)
+    fp = str(tmp_path / "tree.pkl")
+    data = tc.experimental.DistributedContractor.find_path(nodes_fn, params, {"slicing_reconf_opts": {"target_size": 2**4}}, fp)
+    assert set(data) == {"inputs", "output", "size_dict", "path", "sliced_inds"}
+    dc2 = tc.experimental.DistributedContractor.from_path(fp, nodes_fn, params=params)
+    np.testing.assert_allclose(tc.backend.numpy(dc2.value(params)), tc.backend.numpy(v), atol=tol)
