@@ -23,6 +23,7 @@ sys.path.insert(0, os.path.join(ROOT, "tensorcircuit-ng_amd"))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md chip table (spec; 6.29 TB/s measured copy)
+MFMA_F32_PEAK_TFS = 157.3  # dense FP32 (f32-input) MFMA peak, same table
 
 
 def build_circuit(tc, n, d, params_row):
@@ -161,6 +162,8 @@ def main():
     ap.add_argument("--vqe-batch", type=int, default=32, help="VQE leg: global vmap batch (sharded over ranks)")
     ap.add_argument("--vqe-steps", type=int, default=2)
     ap.add_argument("--vqe-microbatch", type=int, default=8, help="samples per vvag call (bounds HBM use)")
+    ap.add_argument("--contractor", default="greedy",
+                    help="greedy/auto: cost model picks the contraction order; plain: state-vector plan; cut: cut contraction")
     ap.add_argument("--lowbits", type=int, default=None)
     ap.add_argument("--R", type=int, default=None)
     ap.add_argument("--LT", type=int, default=None)
@@ -188,7 +191,7 @@ def main():
     tc.set_backend("hip")
     tc.set_dtype("complex64")
     opts = {k: getattr(args, k) for k in ("lowbits", "R", "LT") if getattr(args, k) is not None}
-    tc.set_contractor("greedy", **opts)
+    tc.set_contractor(args.contractor, **opts)
     n, d, B = args.qubits, args.depth, args.batch
 
     # synthetic parameters: SURVEY 8(d) config-2 generator, one independent row per batch element
@@ -214,27 +217,20 @@ def main():
     assert torch.equal(flat0[gather], idx)
     pmat = params.reshape(B, -1)[:, gather].contiguous()
 
+    from tcmi.executor import CutCircuit
+
+    is_cut = isinstance(cc, CutCircuit)
     state = torch.empty(B, 2**cc.n_exec, dtype=torch.complex64, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    npass = len(cc.descs)
     st = cc.stats()
 
     def step(ev=None):
-        # identical to CompiledCircuit.state(), with events around the pass launches
-        from tcmi import _lib
-
-        lib = cc._lib
-        nel = 2**cc.n_exec
-        _lib.check(lib.tcmi_init_zero_state(state.data_ptr(), nel, B, cc.n_exec, cc.code, stream), "init")
-        _lib.check(lib.tcmi_build_tables(cc.ginfo.data_ptr(), cc.nrec, cc.cpool.data_ptr(), pmat.data_ptr(),
-                                         pmat.stride(0), ptab.data_ptr(), ptab.stride(0), B, cc.code, stream), "build")
-        if ev is not None:
-            ev[0].record()
-        cc.run_passes(state, ptab, B, stream)
-        if ev is not None:
-            ev[1].record()
-
-    ptab = torch.empty(B, cc.ptab_size, dtype=torch.float32, device=dev)
+        # the product call: CompiledCircuit.state / CutCircuit.state on resident parameters, with HIP
+        # events around the dominant kernel's launches (pass kernels, or the join GEMM of a cut plan)
+        if is_cut:
+            cc.gemm_events = ev
+        else:
+            cc.pass_events = ev
+        cc.state(pmat, out=state)
 
     def sync():
         torch.cuda.synchronize()
@@ -251,11 +247,12 @@ def main():
         step(events[k])
     sync()
     elapsed = time.perf_counter() - t0
+    cc.gemm_events = cc.pass_events = None
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    pass_ms = sum(a.elapsed_time(b) for a, b in events) / args.steps  # all passes of one step
+    kern_ms = sum(a.elapsed_time(b_) for a, b_ in events) / args.steps  # dominant-kernel time per step
 
     # sanity: the state is normalised (cheap property check at full size)
     nrm = float((state[0].abs() ** 2).sum().item())
@@ -269,16 +266,42 @@ def main():
     if rank == 0:
         amps = float(world) * B * (2**n) * args.steps
         value = amps / elapsed
-        bytes_per_launch = 2.0 * B * (2**cc.n_exec) * 8  # read + write the batched state once
-        avg_launch_s = pass_ms * 1e-3 / npass
-        achieved = bytes_per_launch / avg_launch_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01b_traffic.json")
-        if os.path.exists(tpath):
-            # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE),
-            # scaled from the profiled batch-1 launch to this run's batch
-            tj = json.load(open(tpath))
-            traffic = tj["hbm_bytes_per_amplitude_per_launch"] * B * (2**cc.n_exec)
+        if is_cut:
+            M, N, K = 2**cc.spec.n_left, 2 ** (n - cc.spec.n_left), cc.K
+            flops_per_launch = 8.0 * M * N * K * B          # complex MAC = 8 real flops
+            achieved = flops_per_launch / (kern_ms * 1e-3) / 1e12
+            roof = {
+                "bound": "mfma", "kernel": "tcmi::cgemm_mfma_kernel<true> (cut-contraction join GEMM)",
+                "achieved": achieved, "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s",
+                "frac": achieved / MFMA_F32_PEAK_TFS, "traffic": None,
+                "launches_per_step": 1, "avg_launch_us": kern_ms * 1e3,
+                "algorithmic_flops_per_launch": flops_per_launch,
+                "algorithmic_bytes_per_launch": 8.0 * B * (K * (M + N) + M * N),
+                "gemm_shape": {"M": M, "N": N, "K": K, "batch": B},
+            }
+            plan_info = {"contraction": "cut", "bond": K, "n_left": cc.spec.n_left,
+                         "half_circuit_passes": len(cc.left.descs) + len(cc.right.descs),
+                         "staging_s": round(staging_s, 4)}
+        else:
+            npass = len(cc.descs)
+            bytes_per_launch = 2.0 * B * (2**cc.n_exec) * 8  # read + write the batched state once
+            avg_launch_s = kern_ms * 1e-3 / npass
+            achieved = bytes_per_launch / avg_launch_s / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01b_traffic.json")
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                traffic = tj["hbm_bytes_per_amplitude_per_launch"] * B * (2**cc.n_exec)
+            roof = {
+                "bound": "hbm", "kernel": "tcmi::pass_kernel<float,%d,%d,0>" % (cc.cfg.R, cc.cfg.LT),
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "traffic_source": "profiles/r01b_traffic.json (rocprofv3 PMC, scaled by batch)" if traffic else None,
+                "launches_per_step": npass, "avg_launch_us": avg_launch_s * 1e6,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+            }
+            plan_info = {"contraction": "state-vector", "passes": npass, "rounds": st["rounds"], "R": cc.cfg.R,
+                         "LT": cc.cfg.LT, "lowbits": cc.cfg.lowbits, "staging_s": round(staging_s, 4)}
         out = {
             "metric": "amplitudes/sec",
             "value": value,
@@ -296,24 +319,9 @@ def main():
                 "workload": f"HEA-B statevector contraction n={n} depth={d} complex64 (SURVEY 8d config 2), "
                             f"vmap batch {B} per GPU",
                 "qubits": n, "depth": d, "batch_per_gpu": B, "parallelism": f"batch-shard x{world}",
-                "plan": {"passes": npass, "rounds": st["rounds"], "R": cc.cfg.R, "LT": cc.cfg.LT,
-                         "lowbits": cc.cfg.lowbits, "staging_s": round(staging_s, 4)},
-                "state_norm": nrm,
+                "contractor": args.contractor, "plan": plan_info, "state_norm": nrm,
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "tcmi::pass_kernel<float,%d,%d>" % (cc.cfg.R, cc.cfg.LT),
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_source": "profiles/r01b_traffic.json (rocprofv3 PMC, scaled by batch)" if traffic else None,
-                "launches_per_step": npass,
-                "avg_launch_us": avg_launch_s * 1e6,
-                "algorithmic_bytes_per_launch": bytes_per_launch,
-                "canonical_sv_plan_GBs": ((d - 1) * (n - 1) + 2) * 2 * (2**n) * 8 * B / (pass_ms * 1e-3) / 1e9,
-            },
+            "roofline": roof,
         }
         if vqe is not None:
             out["vqe_step"] = vqe

@@ -109,10 +109,11 @@ int tcmi_permute_bits(const void* in, void* out, int rank, const int* srcbit, in
                       long long batch_stride, int dtype, void* stream);
 
 /* Batched complex GEMM C[M x N] = A[M x K] . B[K x N], row-major interleaved complex, strides in
- * elements between batch members.  complex64 runs on the f32 MFMA pipe (exact f32 FMA);
+ * elements between batch members; trans_a != 0: A is stored [K x M] (k-major).  complex64 runs on the f32 MFMA pipe (exact f32 FMA);
  * complex128 on fp64 VALU.  Replaces backend.tensordot's GEMM (numpy/jax/torch BLAS in the reference). */
 int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch,
-               long long strideA, long long strideB, long long strideC, int dtype, void* stream);
+               long long strideA, long long strideB, long long strideC, int trans_a, int dtype,
+               void* stream);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ RR_WORDS = 50
 OP_G1, OP_G2, OP_DIAG, OP_G1M, OP_EXPECT = 1, 2, 3, 4, 5
 R_MAX = 6
 CONST_FLAG = 1 << 30
-BK_TRIG, BK_COEF = 1, 2
+BK_TRIG, BK_COEF, BK_SELECT = 1, 2, 5
 
 
 def build_table(ginfo, cpool, params, ptab_size):
@@ -41,6 +41,12 @@ def build_table(ginfo, cpool, params, ptab_size):
             ptab[:, slot + 1: slot + 2 * nn: 2] = m.imag
         elif kind == BK_COEF:
             ptab[:, slot] = k * th + o
+        elif kind == BK_SELECT:
+            nn = dim * dim
+            for b in range(B):
+                idx = int(np.clip(np.rint(th[b]), 0, int(k) - 1))
+                t = cpool[off + 2 + 2 * nn * idx: off + 2 + 2 * nn * (idx + 1)]
+                ptab[b, slot: slot + 2 * nn] = t
         else:
             raise ValueError(kind)
     return ptab

@@ -40,6 +40,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define TCMI_BK 8
 #define TCMI_LDP (TCMI_BM + 1)
 
+template <bool TRANS_A>
 __global__ __launch_bounds__(256) void cgemm_mfma_kernel(const float2* __restrict__ A,
                                                           const float2* __restrict__ B,
                                                           float2* __restrict__ C, int M, int N, int K,
@@ -55,17 +56,26 @@ __global__ __launch_bounds__(256) void cgemm_mfma_kernel(const float2* __restric
   f32x16 cre = {0}, cim = {0};
   // loader coordinates: A tile 64 rows x 8 k (two complex per thread along k);
   //                     B tile 8 k x 64 cols (two complex per thread along n)
-  const int ai = tid >> 2, ak = (tid & 3) * 2;
+  // TRANS_A: A is stored [K][M] (k-major), loaded like B (coalesced along m)
+  const int ai = TRANS_A ? (tid & 31) * 2 : tid >> 2, ak = TRANS_A ? tid >> 5 : (tid & 3) * 2;
   const int bk = tid >> 5, bj = (tid & 31) * 2;
   for (int k0 = 0; k0 < K; k0 += TCMI_BK) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       float2 v = {0.f, 0.f};
-      const long long r = m0 + ai;
-      const int kk = k0 + ak + e;
-      if (r < M && kk < K) v = A[r * K + kk];
-      As_re[ak + e][ai] = v.x;
-      As_im[ak + e][ai] = v.y;
+      if constexpr (TRANS_A) {
+        const long long r = m0 + ai + e;
+        const int kk = k0 + ak;
+        if (r < M && kk < K) v = A[(long long)kk * M + r];
+        As_re[ak][ai + e] = v.x;
+        As_im[ak][ai + e] = v.y;
+      } else {
+        const long long r = m0 + ai;
+        const int kk = k0 + ak + e;
+        if (r < M && kk < K) v = A[r * K + kk];
+        As_re[ak + e][ai] = v.x;
+        As_im[ak + e][ai] = v.y;
+      }
       float2 w = {0.f, 0.f};
       const long long c = n0 + bj + e;
       const int kb = k0 + bk;
@@ -105,7 +115,7 @@ template <typename F>
 __global__ void cgemm_simple_kernel(const typename Cx<F>::type* __restrict__ A,
                                     const typename Cx<F>::type* __restrict__ B,
                                     typename Cx<F>::type* __restrict__ C, long long M, long long N, int K,
-                                    long long sA, long long sB, long long sC) {
+                                    long long sA, long long sB, long long sC, int trans_a) {
   using Ct = typename Cx<F>::type;
   A += (long long)blockIdx.z * sA;
   B += (long long)blockIdx.z * sB;
@@ -117,7 +127,7 @@ __global__ void cgemm_simple_kernel(const typename Cx<F>::type* __restrict__ A,
     const long long r = o / N, c = o - r * N;
     F re = 0, im = 0;
     for (int k = 0; k < K; ++k) {
-      const Ct a = A[r * K + k];
+      const Ct a = trans_a ? A[(long long)k * M + r] : A[r * K + k];
       const Ct b = B[(long long)k * N + c];
       re = fma_<F>(a.x, b.x, re);
       re = fma_<F>(-a.y, b.y, re);
@@ -159,7 +169,8 @@ int tcmi_permute_bits(const void* in, void* out, int rank, const int* srcbit_dev
 }
 
 int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch,
-               long long strideA, long long strideB, long long strideC, int dtype, void* stream) {
+               long long strideA, long long strideB, long long strideC, int trans_a, int dtype,
+               void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!A || !B || !C || M < 1 || N < 1 || K < 1 || batch < 1 || K > (1ll << 30))
     return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm: bad argument");
@@ -167,9 +178,14 @@ int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, 
     const long long gx = (N + TCMI_BN - 1) / TCMI_BN, gy = (M + TCMI_BM - 1) / TCMI_BM;
     if (gy > 65535 || batch > 65535) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm: grid too large");
     dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)batch), block(256, 1, 1);
-    hipLaunchKernelGGL(tcmi::cgemm_mfma_kernel, grid, block, 0, st, reinterpret_cast<const float2*>(A),
-                       reinterpret_cast<const float2*>(B), reinterpret_cast<float2*>(C), (int)M, (int)N, (int)K,
-                       strideA, strideB, strideC);
+    if (trans_a)
+      hipLaunchKernelGGL(tcmi::cgemm_mfma_kernel<true>, grid, block, 0, st, reinterpret_cast<const float2*>(A),
+                         reinterpret_cast<const float2*>(B), reinterpret_cast<float2*>(C), (int)M, (int)N, (int)K,
+                         strideA, strideB, strideC);
+    else
+      hipLaunchKernelGGL(tcmi::cgemm_mfma_kernel<false>, grid, block, 0, st, reinterpret_cast<const float2*>(A),
+                         reinterpret_cast<const float2*>(B), reinterpret_cast<float2*>(C), (int)M, (int)N, (int)K,
+                         strideA, strideB, strideC);
   } else {
     const long long total = M * N;
     unsigned gx = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
@@ -177,11 +193,11 @@ int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, 
     if (dtype == TCMI_C64)
       hipLaunchKernelGGL(tcmi::cgemm_simple_kernel<float>, grid, block, 0, st, reinterpret_cast<const float2*>(A),
                          reinterpret_cast<const float2*>(B), reinterpret_cast<float2*>(C), M, N, (int)K, strideA,
-                         strideB, strideC);
+                         strideB, strideC, trans_a);
     else if (dtype == TCMI_C128)
       hipLaunchKernelGGL(tcmi::cgemm_simple_kernel<double>, grid, block, 0, st, reinterpret_cast<const double2*>(A),
                          reinterpret_cast<const double2*>(B), reinterpret_cast<double2*>(C), M, N, (int)K, strideA,
-                         strideB, strideC);
+                         strideB, strideC, trans_a);
     else
       return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm: bad dtype");
   }

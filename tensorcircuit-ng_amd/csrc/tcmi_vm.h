@@ -50,5 +50,6 @@
 #define TCMI_BK_COEF 2
 #define TCMI_BK_UDAG 3  /* U^dagger of C0 + cos C1 + sin C2 */
 #define TCMI_BK_KMAT 4  /* K = (dU/dtheta) U^dagger */
+#define TCMI_BK_SELECT 5 /* M = table[round(theta)]: cpool = {count, 0, matrices...} */
 
 #endif

@@ -358,6 +358,14 @@ __global__ void build_kernel(const int* __restrict__ ginfo, int nrec, const doub
     for (int i = 0; i < nn; ++i) out[i] = (F)(c0[i] + c * c1[i] + s * c2[i]);
   } else if (kind == TCMI_BK_COEF) {
     out[0] = (F)(ang - rint(ang));  // phase coefficient in turns, reduced to [-0.5, 0.5]
+  } else if (kind == TCMI_BK_SELECT) {
+    // one of cpool[off] constant matrices, chosen by the (integer-valued) parameter
+    const int nsel = (int)cpool[off];
+    int idx = (int)rint(theta);
+    idx = idx < 0 ? 0 : (idx >= nsel ? nsel - 1 : idx);
+    const int nn = 2 * dim * dim;
+    const double* tbl = cpool + off + 2 + (long long)idx * nn;
+    for (int i = 0; i < nn; ++i) out[i] = (F)tbl[i];
   }
 }
 

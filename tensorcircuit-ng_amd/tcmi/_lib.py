@@ -64,7 +64,7 @@ _SIGNATURES = {
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_longlong,
          ctypes.c_longlong, ctypes.c_int, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong,
-         ctypes.c_int, ctypes.c_void_p],
+         ctypes.c_int, ctypes.c_int, ctypes.c_void_p],
     ),
 }
 

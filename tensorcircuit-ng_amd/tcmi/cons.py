@@ -71,7 +71,7 @@ get_dtype = lambda: (dtypestr, rdtypestr)
 
 _KNOWN_CONTRACTORS = (
     "auto", "greedy", "branch", "optimal", "plain", "plain-experimental", "tng", "custom",
-    "custom_stateful", "tilevm",
+    "custom_stateful", "tilevm", "cut",
 )
 
 

@@ -146,7 +146,12 @@ class CompiledCircuit:
                 ),
                 "tcmi_build_tables",
             )
+        ev = getattr(self, "pass_events", None)  # bench.py: HIP events around the pass launches
+        if ev is not None:
+            ev[0].record()
         self.run_passes(out, ptab, B, stream)
+        if ev is not None:
+            ev[1].record()
         if self.n_exec != self.n and not full:
             return out[:, : 2**self.n]
         return out
@@ -334,19 +339,172 @@ def get_measure(n, n_exec, strings, dtypestr) -> CompiledMeasure:
     return m
 
 
+# ---- cost model (microseconds per 2^24 amplitudes, fitted on MI355X: profiles/r01b) -------------------
+VM_COST = {"pass": 19.5, "g1": 2.25, "g2": 9.0, "diag": 11.5, "exchange": 10.75}
+GEMM_TFLOPS = 95.0  # tcmi_cgemm on 4096 x 256 x 4096 (scripts/gpu_tn_bench.py)
+
+
+def vm_cost_us(plan: "P.CompiledPlan") -> float:
+    """Estimated time of a tile-VM plan for one state (linear op-count model)."""
+    t = 0.0
+    for pp, desc in zip(plan.passes, plan.descs):
+        d = np.asarray(desc).view(np.uint32).astype(np.int64)
+        pc = P.HDR_WORDS
+        t += VM_COST["pass"] + VM_COST["exchange"] * (int(d[5]) - 1)
+        for _ in range(int(d[5])):
+            rr = d[pc: pc + P.RR_WORDS]
+            q = pc + P.RR_WORDS
+            for _o in range(int(rr[0])):
+                op = int(d[q])
+                if op == P.OP_G1M:
+                    t += VM_COST["g1"] * bin(int(d[q + 1]) & 0xFF).count("1")
+                    q += 3
+                elif op == P.OP_G2:
+                    t += VM_COST["g2"] if (int(d[q + 1]) >> 8) == 0 else VM_COST["g1"]
+                    q += 4
+                elif op == P.OP_DIAG:
+                    nA, nB, nC = (int(x) for x in d[q + 1: q + 4])
+                    t += VM_COST["diag"]
+                    q += 5 + nA + 2 * nB + nC
+                else:
+                    raise ValueError(op)
+            pc = q
+    return t * (2.0 ** plan.n) / 2.0**24
+
+
+class CutCircuit:
+    """Wavefunction by cut contraction (``tcmi/cut.py``): two half-circuit batches through the
+    tile-VM and one MFMA complex GEMM.  Same interface as ``CompiledCircuit`` (the adjoint sweep
+    is delegated to the state-vector plan of the full circuit)."""
+
+    def __init__(self, n, gates, nparams, dtypestr, opts, spec, full_cc):
+        import torch
+
+        self.n, self.n_exec, self.nparams, self.dtypestr = n, n, nparams, dtypestr
+        self.spec = spec
+        self.full = full_cc            # state-vector plan (adjoint sweep, inputs != |0>, stats)
+        self.cfg = full_cc.cfg
+        nb = len(spec.bonds)
+        self.left = CompiledCircuit(spec.n_left, spec.left, nparams + nb, dtypestr, opts)
+        self.right = CompiledCircuit(n - spec.n_left, spec.right, nparams + nb, dtypestr, opts)
+        self.tdtype, self.rdtype, self.code = full_cc.tdtype, full_cc.rdtype, full_cc.code
+        self.device = full_cc.device
+        self._lib = _lib.lib()
+        self.K = spec.bond_dim
+        radices = [len(b.terms) for b in spec.bonds]
+        digits = np.zeros((self.K, nb), dtype=np.float64)
+        for b in range(self.K):
+            x = b
+            for k in reversed(range(nb)):
+                digits[b, k] = x % radices[k]
+                x //= radices[k]
+        self.digits = _dev(digits, self.device, self.rdtype)          # [K, nb]
+        self.descs = self.left.descs + self.right.descs               # for bookkeeping / stats
+
+    def _weights(self, params):
+        """w[B, K] = prod_k coef_k(digit_k, theta) (tiny; torch ops on [B, r_k] vectors)."""
+        import torch
+
+        B = params.shape[0]
+        w = torch.ones(B, 1, dtype=self.tdtype, device=self.device)
+        for bond in self.spec.bonds:
+            cols = []
+            for _, _, (kind, ref) in bond.terms:
+                if kind == "const":
+                    cols.append(torch.full((B,), complex(ref), dtype=self.tdtype, device=self.device))
+                else:
+                    a = params[:, ref.index].to(torch.float64) * ref.scale + ref.offset
+                    cols.append((torch.cos(a) if kind == "cos" else torch.sin(a)).to(self.tdtype))
+            v = torch.stack(cols, dim=1)                                # [B, r_k]
+            w = (w[:, :, None] * v[:, None, :]).reshape(B, -1)
+        return w
+
+    def state(self, params=None, inputs=None, out=None, full=False):
+        import torch
+
+        if inputs is not None:
+            return self.full.state(params, inputs, out, full)
+        if params is None:
+            params = torch.zeros(1, max(1, self.nparams), dtype=self.rdtype, device=self.device)
+        p = params.reshape(-1, params.shape[-1]) if params.dim() > 1 else params.reshape(1, -1)
+        p = p.to(device=self.device, dtype=self.rdtype)
+        B, K = p.shape[0], self.K
+        pfull = torch.cat([p[:, : self.nparams].unsqueeze(1).expand(B, K, self.nparams),
+                           self.digits.unsqueeze(0).expand(B, K, -1)], dim=2).reshape(B * K, -1).contiguous()
+        L = self.left.state(pfull)                                      # [B*K, M]
+        R = self.right.state(pfull)                                     # [B*K, N]
+        R = R * self._weights(p).reshape(B * K, 1)
+        M, N = 2**self.spec.n_left, 2 ** (self.n - self.spec.n_left)
+        if out is None:
+            out = torch.empty(B, M * N, dtype=self.tdtype, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        ev = getattr(self, "gemm_events", None)
+        if ev is not None:
+            ev[0].record()
+        _lib.check(
+            self._lib.tcmi_cgemm(L.data_ptr(), R.data_ptr(), out.data_ptr(), M, N, K, B, K * M, K * N, M * N,
+                                 1, self.code, stream),
+            "tcmi_cgemm(cut)",
+        )
+        if ev is not None:
+            ev[1].record()
+        return out
+
+    def vjp(self, params, psi, g, **kw):
+        return self.full.vjp(params, psi, g, **kw)
+
+    def stats(self):
+        item = 8 if self.dtypestr == "complex64" else 16
+        M, N = 2**self.spec.n_left, 2 ** (self.n - self.spec.n_left)
+        return {"passes": len(self.descs), "rounds": 0, "bond": self.K,
+                "bytes": item * (self.K * (M + N) + M * N), "flops": 8.0 * M * N * self.K}
+
+
 _CACHE: Dict[Tuple, CompiledCircuit] = {}
 
 
 def get_compiled(n, gates, nparams, dtypestr, opts) -> CompiledCircuit:
     import torch
 
+    from . import cons as _cons
+
     key = (
         structure_digest(n, dtypestr, gates), nparams,
         tuple(sorted((k, v) for k, v in (opts or {}).items() if k in ("lowbits", "R", "LT"))),
         torch.cuda.current_device() if torch.cuda.is_available() else -1,
+        getattr(_cons, "_contractor_name", "greedy"),
     )
     cc = _CACHE.get(key)
     if cc is None:
         cc = CompiledCircuit(n, gates, nparams, dtypestr, opts)
+        cc = _maybe_cut(cc, n, gates, nparams, dtypestr, opts)
         _CACHE[key] = cc
+    return cc
+
+
+def _maybe_cut(cc, n, gates, nparams, dtypestr, opts):
+    """Pick the cheaper contraction order for ``wavefunction``: state-vector plan or cut contraction.
+    ``set_contractor("plain")`` / ``"tilevm"`` forces the former, ``"cut"`` the latter."""
+    from . import cons
+    from . import cut as C
+
+    method = getattr(cons, "_contractor_name", "greedy")
+    if method in ("plain", "plain-experimental", "tilevm") or n < 16 or dtypestr != "complex64":
+        return cc
+    best = None
+    for nl in {n // 2, (n + 1) // 2, n // 2 - 1, n // 2 + 1}:
+        if nl < 8 or n - nl < 8:
+            continue
+        spec = C.make_cut(gates, n, nl, nparams)
+        if spec is not None and len(spec.bonds) > 0 and (best is None or spec.bond_dim < best.bond_dim):
+            best = spec
+    if best is None:
+        if method == "cut":
+            raise ValueError("set_contractor('cut'): this circuit cannot be cut (see tcmi/cut.py)")
+        return cc
+    t_vm = vm_cost_us(cc.plan)
+    t_gemm = 8.0 * 2.0**n * best.bond_dim / (GEMM_TFLOPS * 1e6)      # microseconds
+    t_halves = 2 * 40.0 + best.bond_dim * 2.0 ** max(best.n_left, n - best.n_left) / 2.0**24 * 400.0
+    if method == "cut" or (t_gemm + t_halves) < 0.7 * t_vm:
+        return CutCircuit(n, gates, nparams, dtypestr, opts, best, cc)
     return cc

@@ -51,6 +51,7 @@ BK_TRIG = 1  # M = C0 + cos(k*theta + off) C1 + sin(k*theta + off) C2
 BK_COEF = 2  # phase coefficient in turns = k*theta + off
 BK_UDAG = 3  # U^dagger (adjoint sweep)
 BK_KMAT = 4  # K = (dU/dtheta) U^dagger (adjoint sweep)
+BK_SELECT = 5  # M = table[round(param)]: one of several constant matrices (cut contraction bonds)
 
 
 @dataclass
@@ -88,12 +89,15 @@ class GateRec:
     param: Optional[ParamRef] = None
     diag: Optional[List[DiagTerm]] = None
     name: str = ""
+    select: Optional[List[np.ndarray]] = None  # M = select[round(params[param.index])] (constant alternatives)
 
     @property
     def is_diag(self):
         return self.diag is not None
 
     def matrix(self, params=None):
+        if self.select is not None:
+            return np.array(self.select[int(round(float(params[self.param.index])))], dtype=np.complex128)
         m = np.array(self.c0, dtype=np.complex128)
         if self.param is not None:
             a = self.param.scale * float(params[self.param.index]) + self.param.offset
@@ -402,6 +406,8 @@ def g1_kind(g: GateRec, tol=1e-14) -> int:
     2 = real diagonal + imaginary off-diagonal (rx-like), 0 = general.  The kernel spends 8 instead
     of 16 FMAs per amplitude pair on classes 1 and 2."""
     ms = [np.asarray(m, dtype=np.complex128) for m in (g.c0, g.c1, g.c2) if m is not None]
+    if g.select is not None:
+        ms = [np.asarray(m, dtype=np.complex128) for m in g.select]
     if all(np.abs(m.imag).max() < tol for m in ms):
         return 1
     if all(
@@ -424,6 +430,16 @@ def _gate_slot(tables: Tables, gi: int, g: GateRec, swap: bool):
         if swap:
             m = m.reshape(2, 2, 2, 2).transpose(1, 0, 3, 2).reshape(4, 4)
         return m
+
+    if g.select is not None:
+        assert kind == BK_TRIG, "select gates exist in forward plans only"
+        off = len(tables.cpool)
+        tables.cpool += [float(len(g.select)), 0.0]
+        for m in g.select:
+            for z in sw(m).reshape(-1):
+                tables.cpool += [float(z.real), float(z.imag)]
+        tables.ginfo.append([BK_SELECT, slot, g.param.index, dim, off, 0, 0, 0])
+        return
 
     if g.param is None:
         slot = tables.const_complex(sw(g.c0))
@@ -467,6 +483,16 @@ def _matrix_record(tables: Tables, slot: int, g: GateRec, kind: int = BK_TRIG, s
         if swap:
             m = m.reshape(2, 2, 2, 2).transpose(1, 0, 3, 2).reshape(4, 4)
         return m
+
+    if g.select is not None:
+        assert kind == BK_TRIG, "select gates exist in forward plans only"
+        off = len(tables.cpool)
+        tables.cpool += [float(len(g.select)), 0.0]
+        for m in g.select:
+            for z in sw(m).reshape(-1):
+                tables.cpool += [float(z.real), float(z.imag)]
+        tables.ginfo.append([BK_SELECT, slot, g.param.index, dim, off, 0, 0, 0])
+        return
 
     off = len(tables.cpool)
     if g.param is None:

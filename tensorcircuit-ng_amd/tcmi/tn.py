@@ -359,7 +359,7 @@ def _gemm_raw(a2, b2, M, N, K):
     a2, b2 = a2.contiguous(), b2.contiguous()
     c = torch.empty(M * N, dtype=a2.dtype, device=a2.device)
     stream = torch.cuda.current_stream(a2.device).cuda_stream
-    _lib.check(_lib.lib().tcmi_cgemm(a2.data_ptr(), b2.data_ptr(), c.data_ptr(), M, N, K, 1, 0, 0, 0, _code(a2), stream),
+    _lib.check(_lib.lib().tcmi_cgemm(a2.data_ptr(), b2.data_ptr(), c.data_ptr(), M, N, K, 1, 0, 0, 0, 0, _code(a2), stream),
                "tcmi_cgemm")
     return c
 

@@ -219,3 +219,35 @@ def test_adjoint_plan_emulated(n, R, LT):
         vp[i] += eps; vm[i] -= eps
         fd = (np.real(np.vdot(g, E.run_plan(pl, vp))) - np.real(np.vdot(g, E.run_plan(pl, vm)))) / (2 * eps)
         assert abs(grad[i] - fd) < 1e-7
+
+
+def test_cut_spec_and_selector_gates():
+    """Cut contraction spec (tcmi/cut.py): the cut formula reproduces the dense oracle, and the
+    half-circuits with selector gates (BK_SELECT) run through the emulated tile-VM."""
+    from tcmi import cut
+
+    n, d = 10, 2
+    params = np.random.default_rng(0).uniform(0, 2 * np.pi, [2 * d, n])
+    c = tc.Circuit(n)
+    W.hea_b(c, n, d, params, zz=tc.gates._zz_matrix)
+    c.cnot(4, 5); c.cz(5, 4); c.any(4, 5, unitary=G.random_two_qubit_gate(1)); c.rzz(5, 4, theta=0.7)
+    recs = c._gate_records()
+    pv = np.array([float(x) for x in c._params])
+    spec = cut.make_cut(recs, n, 5, len(pv))
+    assert [len(b.terms) for b in spec.bonds] == [2, 2, 2, 2, 4, 2] and spec.bond_dim == 128
+    ops = W.hea_b_ops(n, d, params) + [(G.CNOT, [4, 5]), (G.CZ, [5, 4]), (G.random_two_qubit_gate(1), [4, 5]), (G.rzz(0.7), [5, 4])]
+    np.testing.assert_allclose(cut.reference_state(spec, pv), dense.run(n, ops), atol=1e-12)
+    # one bond configuration of the left half through the plan compiler + emulator
+    nb = len(spec.bonds)
+    digits = np.array([1, 0, 1, 1, 3, 0], dtype=np.float64)
+    pvec = np.concatenate([pv, digits])
+    left8 = [P.GateRec(tuple(q + 3 for q in g.qubits), g.c0, g.c1, g.c2, g.param,
+                       None if g.diag is None else [P.DiagTerm(tuple(q + 3 for q in t.qubits), t.const, t.param) for t in g.diag],
+                       g.name, g.select) for g in spec.left]       # pad 5 -> 8 qubits
+    pl = P.compile_plan(left8, 8, P.PlanConfig(R=2, LT=6, lowbits=5, vec=2), nparams=len(pvec))
+    got = E.run_plan(pl, pvec)[: 2**5]
+    want = np.zeros(2**5, dtype=np.complex128); want[0] = 1
+    for g in spec.left:
+        want = dense.apply_gate(want, 5, g.matrix(pvec), list(g.qubits))
+    np.testing.assert_allclose(got, want, atol=1e-12)
+    assert cut.make_cut([P.GateRec((0, 5, 9), c0=np.eye(8))], n, 5, 0) is None
