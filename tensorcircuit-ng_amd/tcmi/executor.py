@@ -491,13 +491,17 @@ def _maybe_cut(cc, n, gates, nparams, dtypestr, opts):
     method = getattr(cons, "_contractor_name", "greedy")
     if method in ("plain", "plain-experimental", "tilevm") or n < 16 or dtypestr != "complex64":
         return cc
-    best = None
-    for nl in {n // 2, (n + 1) // 2, n // 2 - 1, n // 2 + 1}:
+    best, best_key = None, None
+    for nl in sorted({n // 2, (n + 1) // 2, n // 2 - 1, n // 2 + 1}):
         if nl < 8 or n - nl < 8:
             continue
         spec = C.make_cut(gates, n, nl, nparams)
-        if spec is not None and len(spec.bonds) > 0 and (best is None or spec.bond_dim < best.bond_dim):
-            best = spec
+        if spec is None or len(spec.bonds) == 0:
+            continue
+        # smallest bond first; then halves that fit the 12-bit tile (one pass each); then balance
+        key = (spec.bond_dim, int(min(nl, n - nl) < 12), abs(2 * nl - n))
+        if best is None or key < best_key:
+            best, best_key = spec, key
     if best is None:
         if method == "cut":
             raise ValueError("set_contractor('cut'): this circuit cannot be cut (see tcmi/cut.py)")
