@@ -115,6 +115,37 @@ int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, 
                long long strideA, long long strideB, long long strideC, int trans_a, int dtype,
                void* stream);
 
+/* ---- MPS / TEBD (K7): reference tensorcircuit/mps_base.py:33-175 (FiniteMPS.apply_two_site_gate),
+ * mpscircuit.py:35-64 (split_tensor), backend.svd truncation rule (backends/jax_backend.py:62-112),
+ * backend.qr (tensornetwork decompositions). ---- */
+
+/* Workspace size in bytes for tcmi_svd_trunc_batched (-1 on bad arguments). */
+long long tcmi_svd_work_bytes(int m, int n, int batch, int dtype);
+
+/* Batched thin SVD with the reference's truncation rule, one launch per <=256 workgroups.
+ *   a   [batch][m][n] row-major complex, m <= n (callers pass the transpose otherwise)
+ *   u   [batch][m][kmax], s [batch][m] real (descending, all m values), vh [batch][kmax][n]
+ *   keep_out [batch] int  : min(max_singular_values (<=0: none), #{k : sqrt(sum_{j>=k} s_j^2) > err})
+ *                           with err = max_truncation_err (* s_0 if relative); max_truncation_err < 0: none
+ *   tw2_out  [batch] real : sum of the squared discarded singular values (fidelity factor 1 - tw2)
+ *   absorb 0: u, vh isometries; 1: u <- u*s; 2: vh <- s*vh.   max_sweeps <= 0: default 30.
+ * keep_out / tw2_out may be NULL.  One-sided Jacobi; work from tcmi_svd_work_bytes. */
+int tcmi_svd_trunc_batched(const void* a, void* u, void* s, void* vh, int* keep_out, void* tw2_out, int m, int n,
+                           int kmax, int batch, int max_singular_values, double max_truncation_err, int relative,
+                           int absorb, int max_sweeps, void* work, long long work_bytes, int dtype, void* stream);
+
+long long tcmi_qr_work_bytes(int m, int n, int batch, int dtype);
+
+/* Batched Householder QR: a [batch][m][n] -> q [batch][m][K], r [batch][K][n], K = min(m, n);
+ * q is a complete isometry also for rank-deficient a. */
+int tcmi_qr_batched(const void* a, void* q, void* r, int m, int n, int batch, void* work, long long work_bytes,
+                    int dtype, void* stream);
+
+/* theta[l,a',b',r] = sum_{a,b} gate[a',b',a,b] t[l,a,b,r]; t, out [batch][L][2][2][R]; gate [16] complex per
+ * batch element (gate_stride elements apart, 0 = shared). */
+int tcmi_mps_gate_mix(const void* t, const void* gate, void* out, int L, int R, int batch, long long gate_stride,
+                      int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

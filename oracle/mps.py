@@ -224,7 +224,7 @@ def split_rules(max_singular_values=None, max_truncation_err=None, relative=Fals
         r["max_singular_values"] = max_singular_values
     if max_truncation_err is not None:
         r["max_truncation_err"] = max_truncation_err
-    if relative is not False:
+    if relative is not None:  # as the reference (cons.py:1337): the key is always present
         r["relative"] = relative
     return r
 

@@ -1,0 +1,603 @@
+// MPS / TEBD kernels for gfx950 (SURVEY.md §8a last row, K7): the decompositions behind
+// reference tensorcircuit/mps_base.py:33-175 (FiniteMPS.apply_two_site_gate), mpscircuit.py:35-64
+// (split_tensor) and the tensornetwork FiniteMPS.position sweeps.
+//
+//  * svd_jacobi_kernel  — thin SVD of a row-major p x q matrix (p <= q) by one-sided (Hestenes) Jacobi
+//    in *row* form: unitary rotations from the left make the rows of W = Y a mutually orthogonal,
+//    W = Sigma Vh, U = Y^H.  Rows are contiguous, so every wave streams its two rows coalesced.  One wave
+//    owns one row pair per round (round-robin tournament, p-1 rounds per sweep); the rounds of one
+//    matrix are separated by a device-scope barrier between the (few) workgroups of that matrix, so a
+//    whole SVD is ONE launch.  Sorting, truncation count (reference jax_backend.py:62-112) and the
+//    optional absorption of S into U or Vh are fused into the tail of the same kernel.
+//  * qr_householder_kernel — Householder QR (complete isometry even for rank-deficient input, which
+//    |0..0> product states are), one workgroup per matrix.
+//  * mps_gate_mix_kernel — theta[l,a',b',r] = sum_ab G[a',b',a,b] T[l,a,b,r] (the 4x4 gate on the two
+//    physical legs after the A.B bond GEMM).
+#include <hip/hip_runtime.h>
+
+#include "../../include/tcmi.h"
+#include "tcmi_dev.h"
+
+namespace tcmi {
+
+constexpr int SVD_WAVES = 8;
+constexpr int SVD_THREADS = SVD_WAVES * 64;
+constexpr int SVD_CTL_WORDS = 64;     // [0] barrier counter, [1] error flag, [2..] rotations per sweep
+constexpr int SVD_MAX_SWEEPS = 60;
+constexpr unsigned SPIN_LIMIT = 1u << 21;
+
+template <typename F>
+struct Eps;
+template <>
+struct Eps<float> {
+  static constexpr float v = 5.9604645e-8f;
+};
+template <>
+struct Eps<double> {
+  static constexpr double v = 1.1102230246251565e-16;
+};
+
+// Device-scope barrier between the nwg workgroups of one matrix (all resident: the host caps the grid).
+// Every thread fences its own stores (agent scope: L2 write-back / L1 invalidate across XCDs) around it.
+__device__ __forceinline__ bool grid_barrier(unsigned* ctl, unsigned nwg, unsigned& epoch, unsigned* s_dead) {
+  if (nwg == 1) {
+    __syncthreads();
+    return true;
+  }
+  ++epoch;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(&ctl[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned target = epoch * nwg;
+    unsigned spins = 0, dead = 0;
+    while (__hip_atomic_load(&ctl[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > SPIN_LIMIT || __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_store(&ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dead = 1;
+        break;
+      }
+    }
+    *s_dead = dead;
+  }
+  __syncthreads();
+  __threadfence();
+  return *s_dead == 0;
+}
+
+template <typename F, int E>
+__global__ __launch_bounds__(SVD_THREADS) void svd_jacobi_kernel(
+    const typename Cx<F>::type* __restrict__ a, long long a_stride, typename Cx<F>::type* __restrict__ u,
+    F* __restrict__ s, typename Cx<F>::type* __restrict__ vh, int* __restrict__ keep_out,
+    F* __restrict__ tw2_out, int p, int q, int kmax, typename Cx<F>::type* work, long long work_stride,
+    unsigned* ctl_base, int max_sweeps, int max_sv, F max_err, int relative, int absorb, int batch0) {
+  using Ct = typename Cx<F>::type;
+  const int b = blockIdx.y;
+  const int pp = p + (p & 1);
+  const int npairs = pp >> 1;
+  const unsigned nwg = gridDim.x;
+  a += (long long)(b + batch0) * a_stride;
+  u += (long long)(b + batch0) * p * kmax;
+  s += (long long)(b + batch0) * p;
+  vh += (long long)(b + batch0) * (long long)kmax * q;
+  Ct* W = work + (long long)b * work_stride;
+  Ct* Y = W + (long long)pp * q;
+  F* sq = reinterpret_cast<F*>(Y + (long long)pp * pp);
+  unsigned* ctl = ctl_base + (long long)b * SVD_CTL_WORDS;
+  unsigned epoch = 0;
+  __shared__ unsigned s_dead;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gw = blockIdx.x * SVD_WAVES + wave;
+  const bool active = gw < npairs;
+
+  {  // W = a (zero pad row), Y = I
+    const long long t0 = (long long)blockIdx.x * SVD_THREADS + threadIdx.x, step = (long long)nwg * SVD_THREADS;
+    const long long nW = (long long)pp * q, nA = (long long)p * q, nY = (long long)pp * pp;
+    Ct zero;
+    zero.x = 0;
+    zero.y = 0;
+    for (long long i = t0; i < nW; i += step) {
+      Ct v = zero;
+      if (i < nA) v = a[i];
+      W[i] = v;
+    }
+    for (long long i = t0; i < nY; i += step) {
+      Ct v = zero;
+      if (i / pp == i % pp) v.x = 1;
+      Y[i] = v;
+    }
+  }
+  if (!grid_barrier(ctl, nwg, epoch, &s_dead)) return;
+
+  const F tol2 = Eps<F>::v * Eps<F>::v * (F)q;
+  const int M = pp - 1;
+  if (max_sweeps > SVD_MAX_SWEEPS) max_sweeps = SVD_MAX_SWEEPS;
+  for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+    for (int r = 0; r < M; ++r) {
+      if (active) {
+        int i = gw == 0 ? r : (r + gw) % M;
+        int j = gw == 0 ? M : (r - gw + M) % M;
+        if (i > j) {
+          const int t = i;
+          i = j;
+          j = t;
+        }
+        Ct* wi = W + (long long)i * q;
+        Ct* wj = W + (long long)j * q;
+        Ct x[E], y[E];
+        F al = 0, be = 0, gr = 0, gi = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int c = lane + 64 * e;
+          if (c < q) {
+            x[e] = wi[c];
+            y[e] = wj[c];
+          } else {
+            x[e].x = x[e].y = y[e].x = y[e].y = 0;
+          }
+          al = fma_<F>(x[e].x, x[e].x, fma_<F>(x[e].y, x[e].y, al));
+          be = fma_<F>(y[e].x, y[e].x, fma_<F>(y[e].y, y[e].y, be));
+          // gamma += x conj(y)
+          gr = fma_<F>(x[e].x, y[e].x, fma_<F>(x[e].y, y[e].y, gr));
+          gi = fma_<F>(x[e].y, y[e].x, fma_<F>(-x[e].x, y[e].y, gi));
+        }
+        al = wave_sum<F>(al);
+        be = wave_sum<F>(be);
+        gr = wave_sum<F>(gr);
+        gi = wave_sum<F>(gi);
+        const F g2 = gr * gr + gi * gi;
+        if (g2 > tol2 * al * be && g2 > 0) {
+          const F ag = sqrt(g2);
+          const F pr = gr / ag, pi = gi / ag;  // e^{i phi}
+          const F zeta = (be - al) / (2 * ag);
+          const F t = (zeta >= 0 ? (F)1 : (F)-1) / (fabs(zeta) + sqrt(1 + zeta * zeta));
+          const F c = 1 / sqrt(1 + t * t), sn = c * t;
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const int col = lane + 64 * e;
+            if (col < q) {
+              const F yr = pr * y[e].x - pi * y[e].y, yi = pr * y[e].y + pi * y[e].x;  // e^{i phi} y
+              Ct nx, ny;
+              nx.x = c * x[e].x - sn * yr;
+              nx.y = c * x[e].y - sn * yi;
+              ny.x = sn * x[e].x + c * yr;
+              ny.y = sn * x[e].y + c * yi;
+              wi[col] = nx;
+              wj[col] = ny;
+            }
+          }
+          Ct* yi_ = Y + (long long)i * pp;
+          Ct* yj_ = Y + (long long)j * pp;
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const int col = lane + 64 * e;
+            if (col < pp) {
+              const Ct xx = yi_[col], yy = yj_[col];
+              const F yr = pr * yy.x - pi * yy.y, yi = pr * yy.y + pi * yy.x;
+              Ct nx, ny;
+              nx.x = c * xx.x - sn * yr;
+              nx.y = c * xx.y - sn * yi;
+              ny.x = sn * xx.x + c * yr;
+              ny.y = sn * xx.y + c * yi;
+              yi_[col] = nx;
+              yj_[col] = ny;
+            }
+          }
+          if (lane == 0) __hip_atomic_fetch_add(&ctl[2 + sweep], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (!grid_barrier(ctl, nwg, epoch, &s_dead)) return;
+    }
+    if (__hip_atomic_load(&ctl[2 + sweep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) break;
+  }
+
+  // squared row norms
+  if (active) {
+    for (int k = 0; k < 2; ++k) {
+      const int row = 2 * gw + k;
+      const Ct* w = W + (long long)row * q;
+      F acc = 0;
+      for (int c = lane; c < q; c += 64) {
+        const Ct v = w[c];
+        acc = fma_<F>(v.x, v.x, fma_<F>(v.y, v.y, acc));
+      }
+      acc = wave_sum<F>(acc);
+      if (lane == 0) sq[row] = acc;
+    }
+  }
+  if (!grid_barrier(ctl, nwg, epoch, &s_dead)) return;
+
+  // rank (descending, ties by row index), then write s / vh / u in sorted order
+  if (active) {
+    for (int k = 0; k < 2; ++k) {
+      const int row = 2 * gw + k;
+      if (row >= p) continue;
+      const F v = sq[row];
+      int cnt = 0;
+      for (int j = lane; j < pp; j += 64) {
+        const F o = sq[j];
+        cnt += (o > v || (o == v && j < row)) ? 1 : 0;
+      }
+      const int rank = wave_sum<int>(cnt);
+      const F sig = sqrt(v);
+      if (lane == 0) s[rank] = sig;
+      if (rank < kmax) {
+        const F inv = sig > 0 ? 1 / sig : 0;
+        const F sv = absorb == 2 ? (F)1 : inv;
+        const F su = absorb == 1 ? sig : (F)1;
+        const Ct* w = W + (long long)row * q;
+        Ct* o = vh + (long long)rank * q;
+        for (int c = lane; c < q; c += 64) {
+          Ct t = w[c];
+          t.x *= sv;
+          t.y *= sv;
+          o[c] = t;
+        }
+        const Ct* yr = Y + (long long)row * pp;
+        for (int c = lane; c < p; c += 64) {
+          Ct t = yr[c];
+          t.x *= su;
+          t.y *= -su;
+          u[(long long)c * kmax + rank] = t;
+        }
+      }
+    }
+  }
+  if (!grid_barrier(ctl, nwg, epoch, &s_dead)) return;
+
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int keep = (max_sv > 0 && max_sv < p) ? max_sv : p;
+    if (max_err >= 0) {
+      const F abs_err = relative ? max_err * s[0] : max_err;
+      F acc = 0;
+      int nerr = 0;
+      for (int k = p - 1; k >= 0; --k) {
+        acc += s[k] * s[k];
+        if (sqrt(acc) > abs_err) ++nerr;
+      }
+      if (nerr < keep) keep = nerr;
+    }
+    F tw2 = 0;
+    for (int k = p - 1; k >= keep; --k) tw2 += s[k] * s[k];
+    if (keep_out) keep_out[b + batch0] = keep;
+    if (tw2_out) tw2_out[b + batch0] = tw2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- QR
+constexpr int QR_TX = 64, QR_TY = 16, QR_THREADS = QR_TX * QR_TY;
+
+template <typename F>
+__device__ __forceinline__ F block_sum(F v, F* red) {
+  v = wave_sum<F>(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  F t = 0;
+#pragma unroll
+  for (int w = 0; w < QR_THREADS / 64; ++w) t += red[w];
+  return t;
+}
+
+// X[k:, c_begin:c_end] -= u (2/un2) (u^H X[k:, c_begin:c_end]),  u = Aw[k:, k]
+template <typename F>
+__device__ __forceinline__ void reflect(typename Cx<F>::type* X, int ldx, const typename Cx<F>::type* Aw, int lda,
+                                        int k, int m, int c_begin, int c_end, F scale,
+                                        typename Cx<F>::type (*wbuf)[QR_TX]) {
+  using Ct = typename Cx<F>::type;
+  const int tx = threadIdx.x & (QR_TX - 1), ty = threadIdx.x / QR_TX;
+  for (int c0 = c_begin; c0 < c_end; c0 += QR_TX) {
+    const int j = c0 + tx;
+    F ar = 0, ai = 0;
+    if (j < c_end)
+      for (int i = k + ty; i < m; i += QR_TY) {
+        const Ct uu = Aw[(long long)i * lda + k], xx = X[(long long)i * ldx + j];
+        // conj(u) * x
+        ar = fma_<F>(uu.x, xx.x, fma_<F>(uu.y, xx.y, ar));
+        ai = fma_<F>(uu.x, xx.y, fma_<F>(-uu.y, xx.x, ai));
+      }
+    wbuf[ty][tx].x = ar;
+    wbuf[ty][tx].y = ai;
+    __syncthreads();
+    if (ty == 0) {
+      F sr = 0, si = 0;
+#pragma unroll
+      for (int t = 0; t < QR_TY; ++t) {
+        sr += wbuf[t][tx].x;
+        si += wbuf[t][tx].y;
+      }
+      wbuf[0][tx].x = sr * scale;
+      wbuf[0][tx].y = si * scale;
+    }
+    __syncthreads();
+    const Ct w = wbuf[0][tx];
+    if (j < c_end)
+      for (int i = k + ty; i < m; i += QR_TY) {
+        const Ct uu = Aw[(long long)i * lda + k];
+        Ct xx = X[(long long)i * ldx + j];
+        xx.x -= uu.x * w.x - uu.y * w.y;
+        xx.y -= uu.x * w.y + uu.y * w.x;
+        X[(long long)i * ldx + j] = xx;
+      }
+    __syncthreads();
+  }
+}
+
+template <typename F>
+__global__ __launch_bounds__(QR_THREADS) void qr_householder_kernel(const typename Cx<F>::type* __restrict__ a,
+                                                                    typename Cx<F>::type* __restrict__ qout,
+                                                                    typename Cx<F>::type* __restrict__ rout, int m,
+                                                                    int n, typename Cx<F>::type* work,
+                                                                    long long work_stride) {
+  using Ct = typename Cx<F>::type;
+  const int K = m < n ? m : n;
+  const int b = blockIdx.x;
+  a += (long long)b * m * n;
+  qout += (long long)b * m * K;
+  rout += (long long)b * K * n;
+  Ct* Aw = work + (long long)b * work_stride;      // [m][n]
+  Ct* diag = Aw + (long long)m * n;                // [K]
+  F* un2 = reinterpret_cast<F*>(diag + K);         // [K]
+  __shared__ F red[QR_THREADS / 64];
+  __shared__ Ct wbuf[QR_TY][QR_TX];
+  __shared__ F s_scale;
+  const int tid = threadIdx.x;
+  for (long long i = tid; i < (long long)m * n; i += QR_THREADS) Aw[i] = a[i];
+  __syncthreads();
+  for (int k = 0; k < K; ++k) {
+    F part = 0;
+    for (int i = k + tid; i < m; i += QR_THREADS) {
+      const Ct v = Aw[(long long)i * n + k];
+      part = fma_<F>(v.x, v.x, fma_<F>(v.y, v.y, part));
+    }
+    const F nx2 = block_sum<F>(part, red);
+    if (tid == 0) {
+      const Ct alpha = Aw[(long long)k * n + k];
+      const F nx = sqrt(nx2);
+      Ct d;
+      d.x = d.y = 0;
+      F u2 = 0;
+      if (nx > 0) {
+        const F aa = sqrt(alpha.x * alpha.x + alpha.y * alpha.y);
+        const F pr = aa > 0 ? alpha.x / aa : (F)1, pi = aa > 0 ? alpha.y / aa : (F)0;
+        d.x = -pr * nx;
+        d.y = -pi * nx;
+        Ct u0;
+        u0.x = alpha.x - d.x;
+        u0.y = alpha.y - d.y;
+        Aw[(long long)k * n + k] = u0;
+        u2 = 2 * nx * (nx + aa);
+      }
+      diag[k] = d;
+      un2[k] = u2;
+      s_scale = u2 > 0 ? 2 / u2 : 0;
+    }
+    __syncthreads();
+    const F scale = s_scale;
+    if (scale > 0) reflect<F>(Aw, n, Aw, n, k, m, k + 1, n, scale, wbuf);
+    __syncthreads();
+  }
+  // R
+  for (long long i = tid; i < (long long)K * n; i += QR_THREADS) {
+    const int r = (int)(i / n), c = (int)(i % n);
+    Ct v;
+    v.x = v.y = 0;
+    if (c == r)
+      v = diag[r];
+    else if (c > r)
+      v = Aw[(long long)r * n + c];
+    rout[i] = v;
+  }
+  // Q = H_0 ... H_{K-1} [I]
+  for (long long i = tid; i < (long long)m * K; i += QR_THREADS) {
+    Ct v;
+    v.x = (i / K == i % K) ? 1 : 0;
+    v.y = 0;
+    qout[i] = v;
+  }
+  __syncthreads();
+  for (int k = K - 1; k >= 0; --k) {
+    const F u2 = un2[k];
+    if (u2 > 0) reflect<F>(qout, K, Aw, n, k, m, k, K, 2 / u2, wbuf);
+    __syncthreads();
+  }
+}
+
+// theta[l,a',b',r] = sum_{a,b} G[a',b',a,b] T[l,a,b,r]
+template <typename F>
+__global__ void mps_gate_mix_kernel(const typename Cx<F>::type* __restrict__ T,
+                                    const typename Cx<F>::type* __restrict__ G,
+                                    typename Cx<F>::type* __restrict__ out, int L, int R, long long batch_stride,
+                                    long long gate_stride) {
+  using Ct = typename Cx<F>::type;
+  const long long b = blockIdx.y;
+  T += b * batch_stride;
+  out += b * batch_stride;
+  G += b * gate_stride;
+  __shared__ Ct g[16];
+  if (threadIdx.x < 16) g[threadIdx.x] = G[threadIdx.x];
+  __syncthreads();
+  const long long total = (long long)L * R;
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const long long l = t / R, r = t - l * R;
+    Ct in[4];
+#pragma unroll
+    for (int ab = 0; ab < 4; ++ab) in[ab] = T[(l * 4 + ab) * R + r];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      F re = 0, im = 0;
+#pragma unroll
+      for (int ab = 0; ab < 4; ++ab) {
+        const Ct c = g[o * 4 + ab];
+        re = fma_<F>(c.x, in[ab].x, fma_<F>(-c.y, in[ab].y, re));
+        im = fma_<F>(c.x, in[ab].y, fma_<F>(c.y, in[ab].x, im));
+      }
+      Ct v;
+      v.x = re;
+      v.y = im;
+      out[(l * 4 + o) * R + r] = v;
+    }
+  }
+}
+
+template <typename F>
+static long long svd_work_elems(int p, int q) {
+  const long long pp = p + (p & 1);
+  const long long f_as_c = (pp * (long long)sizeof(F) + sizeof(typename Cx<F>::type) - 1) / sizeof(typename Cx<F>::type);
+  return pp * q + pp * pp + f_as_c + 8;
+}
+
+template <typename F, int E>
+static void launch_svd(dim3 grid, hipStream_t st, const void* a, long long a_stride, void* u, void* s, void* vh,
+                       int* keep, void* tw2, int p, int q, int kmax, void* work, long long wstride, unsigned* ctl,
+                       int max_sweeps, int max_sv, double max_err, int relative, int absorb, int batch0) {
+  using Ct = typename Cx<F>::type;
+  hipLaunchKernelGGL((svd_jacobi_kernel<F, E>), grid, dim3(SVD_THREADS), 0, st, reinterpret_cast<const Ct*>(a),
+                     a_stride, reinterpret_cast<Ct*>(u), reinterpret_cast<F*>(s), reinterpret_cast<Ct*>(vh), keep,
+                     reinterpret_cast<F*>(tw2), p, q, kmax, reinterpret_cast<Ct*>(work), wstride, ctl, max_sweeps,
+                     max_sv, (F)max_err, relative, absorb, batch0);
+}
+
+template <typename F>
+static int dispatch_svd(int E, dim3 grid, hipStream_t st, const void* a, long long a_stride, void* u, void* s,
+                        void* vh, int* keep, void* tw2, int p, int q, int kmax, void* work, long long wstride,
+                        unsigned* ctl, int max_sweeps, int max_sv, double max_err, int relative, int absorb,
+                        int batch0) {
+#define TCMI_SVD_CASE(EE)                                                                                          \
+  case EE:                                                                                                         \
+    launch_svd<F, EE>(grid, st, a, a_stride, u, s, vh, keep, tw2, p, q, kmax, work, wstride, ctl, max_sweeps,      \
+                      max_sv, max_err, relative, absorb, batch0);                                                  \
+    return 0;
+  switch (E) {
+    TCMI_SVD_CASE(1)
+    TCMI_SVD_CASE(2)
+    TCMI_SVD_CASE(4)
+    TCMI_SVD_CASE(8)
+    TCMI_SVD_CASE(16)
+  }
+#undef TCMI_SVD_CASE
+  return -1;
+}
+
+}  // namespace tcmi
+
+extern "C" int tcmi_set_error_(int code, const char* msg);
+
+extern "C" {
+
+long long tcmi_svd_work_bytes(int m, int n, int batch, int dtype) {
+  if (m < 1 || n < m || batch < 1) return -1;
+  const int wgs = ((m + 1) / 2 + tcmi::SVD_WAVES - 1) / tcmi::SVD_WAVES;
+  int chunk = 256 / wgs;
+  if (chunk < 1) chunk = 1;
+  if (chunk > batch) chunk = batch;
+  const long long ctl = (long long)chunk * tcmi::SVD_CTL_WORDS * 4;
+  if (dtype == TCMI_C64) return ctl + chunk * tcmi::svd_work_elems<float>(m, n) * 8;
+  if (dtype == TCMI_C128) return ctl + chunk * tcmi::svd_work_elems<double>(m, n) * 16;
+  return -1;
+}
+
+int tcmi_svd_trunc_batched(const void* a, void* u, void* s, void* vh, int* keep_out, void* tw2_out, int m, int n,
+                           int kmax, int batch, int max_singular_values, double max_truncation_err, int relative,
+                           int absorb, int max_sweeps, void* work, long long work_bytes, int dtype, void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!a || !u || !s || !vh || !work || m < 1 || n < m || kmax < 1 || kmax > m || batch < 1 || absorb < 0 ||
+      absorb > 2)
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_svd_trunc_batched: bad argument (needs m <= n, 1 <= kmax <= m)");
+  if (n > 1024) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_svd_trunc_batched: n > 1024 not supported");
+  const long long need = tcmi_svd_work_bytes(m, n, batch, dtype);
+  if (need < 0 || work_bytes < need) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_svd_trunc_batched: workspace too small");
+  if (max_sweeps <= 0) max_sweeps = 30;
+  const int pp = m + (m & 1);
+  const int wgs = (pp / 2 + tcmi::SVD_WAVES - 1) / tcmi::SVD_WAVES;
+  int chunk = 256 / wgs;  // co-resident workgroups per launch (one per CU is always resident)
+  if (chunk < 1) chunk = 1;
+  if (chunk > batch) chunk = batch;
+  const int span = n > pp ? n : pp;
+  int E = 1;
+  while (64 * E < span) E *= 2;
+  unsigned* ctl = reinterpret_cast<unsigned*>(work);
+  char* wbase = reinterpret_cast<char*>(work) + (long long)chunk * tcmi::SVD_CTL_WORDS * 4;
+  for (int b0 = 0; b0 < batch; b0 += chunk) {
+    const int nb = batch - b0 < chunk ? batch - b0 : chunk;
+    hipError_t e = hipMemsetAsync(ctl, 0, (size_t)chunk * tcmi::SVD_CTL_WORDS * 4, st);
+    if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));
+    dim3 grid(wgs, nb, 1);
+    int rc;
+    if (dtype == TCMI_C64)
+      rc = tcmi::dispatch_svd<float>(E, grid, st, a, (long long)m * n, u, s, vh, keep_out, tw2_out, m, n, kmax, wbase,
+                                     tcmi::svd_work_elems<float>(m, n), ctl, max_sweeps, max_singular_values,
+                                     max_truncation_err, relative, absorb, b0);
+    else if (dtype == TCMI_C128)
+      rc = tcmi::dispatch_svd<double>(E, grid, st, a, (long long)m * n, u, s, vh, keep_out, tw2_out, m, n, kmax,
+                                      wbase, tcmi::svd_work_elems<double>(m, n), ctl, max_sweeps,
+                                      max_singular_values, max_truncation_err, relative, absorb, b0);
+    else
+      return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_svd_trunc_batched: bad dtype");
+    if (rc != 0) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_svd_trunc_batched: unsupported size");
+    e = hipGetLastError();
+    if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));
+  }
+  return TCMI_OK;
+}
+
+long long tcmi_qr_work_bytes(int m, int n, int batch, int dtype) {
+  if (m < 1 || n < 1 || batch < 1) return -1;
+  const long long K = m < n ? m : n;
+  const long long elems = (long long)m * n + 2 * K + 8;
+  if (dtype == TCMI_C64) return batch * elems * 8;
+  if (dtype == TCMI_C128) return batch * elems * 16;
+  return -1;
+}
+
+int tcmi_qr_batched(const void* a, void* q, void* r, int m, int n, int batch, void* work, long long work_bytes,
+                    int dtype, void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!a || !q || !r || !work || m < 1 || n < 1 || batch < 1)
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_qr_batched: bad argument");
+  const long long need = tcmi_qr_work_bytes(m, n, batch, dtype);
+  if (need < 0 || work_bytes < need) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_qr_batched: workspace too small");
+  const long long K = m < n ? m : n;
+  const long long stride = (long long)m * n + 2 * K + 8;
+  if (dtype == TCMI_C64)
+    hipLaunchKernelGGL(tcmi::qr_householder_kernel<float>, dim3(batch), dim3(tcmi::QR_THREADS), 0, st,
+                       reinterpret_cast<const float2*>(a), reinterpret_cast<float2*>(q),
+                       reinterpret_cast<float2*>(r), m, n, reinterpret_cast<float2*>(work), stride);
+  else if (dtype == TCMI_C128)
+    hipLaunchKernelGGL(tcmi::qr_householder_kernel<double>, dim3(batch), dim3(tcmi::QR_THREADS), 0, st,
+                       reinterpret_cast<const double2*>(a), reinterpret_cast<double2*>(q),
+                       reinterpret_cast<double2*>(r), m, n, reinterpret_cast<double2*>(work), stride);
+  else
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_qr_batched: bad dtype");
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));
+  return TCMI_OK;
+}
+
+int tcmi_mps_gate_mix(const void* t, const void* gate, void* out, int L, int R, int batch, long long gate_stride,
+                      int dtype, void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!t || !gate || !out || L < 1 || R < 1 || batch < 1 || batch > 65535)
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_mps_gate_mix: bad argument");
+  const long long total = (long long)L * R;
+  unsigned gx = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  dim3 grid(gx, batch, 1), block(256, 1, 1);
+  if (dtype == TCMI_C64)
+    hipLaunchKernelGGL(tcmi::mps_gate_mix_kernel<float>, grid, block, 0, st, reinterpret_cast<const float2*>(t),
+                       reinterpret_cast<const float2*>(gate), reinterpret_cast<float2*>(out), L, R, total * 4,
+                       gate_stride);
+  else if (dtype == TCMI_C128)
+    hipLaunchKernelGGL(tcmi::mps_gate_mix_kernel<double>, grid, block, 0, st, reinterpret_cast<const double2*>(t),
+                       reinterpret_cast<const double2*>(gate), reinterpret_cast<double2*>(out), L, R, total * 4,
+                       gate_stride);
+  else
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_mps_gate_mix: bad dtype");
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));
+  return TCMI_OK;
+}
+
+}  // extern "C"

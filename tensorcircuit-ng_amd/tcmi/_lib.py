@@ -66,6 +66,24 @@ _SIGNATURES = {
          ctypes.c_longlong, ctypes.c_int, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong,
          ctypes.c_int, ctypes.c_int, ctypes.c_void_p],
     ),
+    "tcmi_svd_work_bytes": (ctypes.c_longlong, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "tcmi_svd_trunc_batched": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int,
+         ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p],
+    ),
+    "tcmi_qr_work_bytes": (ctypes.c_longlong, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "tcmi_qr_batched": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+         ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p],
+    ),
+    "tcmi_mps_gate_mix": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+         ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p],
+    ),
 }
 
 

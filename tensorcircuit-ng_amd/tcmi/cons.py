@@ -110,6 +110,19 @@ def set_contractor(method: Optional[str] = None, optimizer: Any = None, memory_l
     return cf
 
 
+def split_rules(max_singular_values: Optional[int] = None, max_truncation_err: Optional[float] = None,
+                relative: bool = False) -> Dict[str, Any]:
+    """reference cons.py ``split_rules``: truncation options for SVD splits (only given keys set)."""
+    rules: Dict[str, Any] = {}
+    if max_singular_values is not None:
+        rules["max_singular_values"] = max_singular_values
+    if max_truncation_err is not None:
+        rules["max_truncation_err"] = max_truncation_err
+    if relative is not None:  # as the reference (cons.py:1337): the key is always present
+        rules["relative"] = relative
+    return rules
+
+
 def set_function_backend(backend_name: Optional[str] = None) -> Callable[..., Any]:
     """reference cons.py:143-166."""
 

@@ -1,0 +1,658 @@
+"""``MPSCircuit``: matrix-product-state simulator front end of the hip backend.
+
+Mirrors reference ``tensorcircuit/mpscircuit.py`` (``split_tensor`` :35-64, ``MPSCircuit`` :72-1049) and
+``tensorcircuit/mps_base.py:33-175`` (``FiniteMPS.apply_two_site_gate``) — same method names, argument
+meaning, centre-position bookkeeping and error messages — plus the parts of ``tensornetwork.FiniteMPS``
+those rely on (``position`` QR/RQ sweeps, ``apply_one_site_gate``, ``check_canonical``,
+``canonicalize``, ``bond_dimensions``).  MPS tensors are device tensors ``[left, phys, right]``; every
+contraction, SVD (with the reference truncation rule) and QR runs through the C ABI
+(``tcmi/linalg.py`` -> ``tcmi_cgemm / tcmi_svd_trunc_batched / tcmi_qr_batched / tcmi_mps_gate_mix``);
+there is no host linear algebra and no fallback.  Qubits only (d = 2).
+"""
+
+from functools import reduce
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import cons
+from . import gates as G
+from . import linalg as LA
+
+Tensor = Any
+
+
+def split_rules(max_singular_values: Optional[int] = None, max_truncation_err: Optional[float] = None,
+                relative: bool = False) -> Dict[str, Any]:
+    """reference cons.py ``split_rules``: only the given keys are present."""
+    rules: Dict[str, Any] = {}
+    if max_singular_values is not None:
+        rules["max_singular_values"] = max_singular_values
+    if max_truncation_err is not None:
+        rules["max_truncation_err"] = max_truncation_err
+    if relative is not None:  # as the reference (cons.py:1337): the key is always present
+        rules["relative"] = relative
+    return rules
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def _dtype():
+    torch = _torch()
+    return torch.complex64 if cons.dtypestr == "complex64" else torch.complex128
+
+
+def _device():
+    b = cons.backend
+    if b is not None and hasattr(b, "device"):
+        return b.device
+    torch = _torch()
+    return torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+
+
+def _t(x):
+    """numpy / Gate / tensor -> device tensor of the global complex dtype."""
+    torch = _torch()
+    if isinstance(x, G.Gate):
+        x = x.tensor
+    if torch.is_tensor(x):
+        return x.to(device=_device(), dtype=_dtype())
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=cons.npdtype))).to(_device())
+
+
+def split_tensor(tensor: Tensor, center_left: bool = True, split: Optional[Dict[str, Any]] = None):
+    """reference mpscircuit.py:35-64: SVD when truncation rules are given, QR / RQ otherwise."""
+    split = split or {}
+    if len(split) > 0:
+        u, _, vh, _ = LA.svd_trunc(tensor, absorb=1 if center_left else 2, **split)
+        return u, vh
+    if center_left:
+        return LA.rq(tensor)
+    return LA.qr(tensor)
+
+
+class FiniteMPS:
+    """The slice of ``tensornetwork.FiniteMPS`` + ``tensorcircuit.mps_base.FiniteMPS`` on the path."""
+
+    def __init__(self, tensors: Sequence[Tensor], center_position: Optional[int] = None,
+                 canonicalize: bool = True):
+        self.tensors = [_t(t) for t in tensors]
+        self.center_position = center_position
+        if canonicalize:
+            if self.center_position is None:
+                self.center_position = 0
+            pos = self.center_position
+            self.position(len(self.tensors) - 1, normalize=False)
+            self.position(0, normalize=False)
+            self.position(pos, normalize=True)
+
+    def __len__(self) -> int:
+        return len(self.tensors)
+
+    @property
+    def bond_dimensions(self) -> List[int]:
+        return [int(self.tensors[0].shape[0])] + [int(t.shape[2]) for t in self.tensors]
+
+    def position(self, site: int, normalize: bool = True):
+        torch = _torch()
+        if self.center_position is None:
+            raise ValueError("BaseMPS.center_position is `None`, cannot shift `center_position`.")
+        if site >= len(self.tensors) or site < 0:
+            raise ValueError("site = {} not between values 0 < site < N = {}".format(site, len(self)))
+        z = None
+        if site == self.center_position:
+            if normalize:
+                z = torch.linalg.vector_norm(self.tensors[site])
+                self.tensors[site] = self.tensors[site] / z
+            return z
+        if site > self.center_position:
+            for n in range(self.center_position, site):
+                t = self.tensors[n]
+                l, d, r = t.shape
+                q, rr = LA.qr(t.reshape(l * d, r))
+                self.tensors[n] = q.reshape(l, d, -1)
+                nxt = self.tensors[n + 1]
+                r2, d2, r3 = nxt.shape
+                nxt = LA.matmul(rr, nxt.reshape(r2, d2 * r3)).reshape(-1, d2, r3)
+                if normalize:
+                    nxt = nxt / torch.linalg.vector_norm(rr)
+                self.tensors[n + 1] = nxt
+        else:
+            for n in reversed(range(site + 1, self.center_position + 1)):
+                t = self.tensors[n]
+                l, d, r = t.shape
+                rr, q = LA.rq(t.reshape(l, d * r))
+                self.tensors[n] = q.reshape(-1, d, r)
+                prv = self.tensors[n - 1]
+                l0, d0, _ = prv.shape
+                prv = LA.matmul(prv.reshape(l0 * d0, l), rr).reshape(l0, d0, -1)
+                if normalize:
+                    prv = prv / torch.linalg.vector_norm(rr)
+                self.tensors[n - 1] = prv
+        self.center_position = site
+        return z
+
+    def apply_one_site_gate(self, gate: Tensor, site: int) -> None:
+        if site < 0 or site >= len(self):
+            raise ValueError("site = {} is not between 0 <= site < N={}".format(site, len(self)))
+        self.tensors[site] = LA.site_gate(_t(gate).reshape(2, 2), self.tensors[site])
+
+    def apply_two_site_gate(self, gate: Tensor, site1: int, site2: int,
+                            max_singular_values: Optional[int] = None,
+                            max_truncation_err: Optional[float] = None,
+                            center_position: Optional[int] = None, relative: bool = False) -> Tensor:
+        """reference mps_base.py:33-175 (TEBD update).  Returns the discarded singular values."""
+        gate = _t(gate)
+        if gate.dim() != 4:
+            raise ValueError("rank of gate is {} but has to be 4".format(gate.dim()))
+        if site1 < 0 or site1 >= len(self) - 1:
+            raise ValueError("site1 = {} is not between 0 <= site < N - 1 = {}".format(site1, len(self)))
+        if site2 < 1 or site2 >= len(self):
+            raise ValueError("site2 = {} is not between 1 <= site < N = {}".format(site2, len(self)))
+        if site2 <= site1:
+            raise ValueError("site2 = {} has to be larger than site2 = {}".format(site2, site1))
+        if site2 != site1 + 1:
+            raise ValueError("Found site2 ={}, site1={}. Only nearest neighbor gates are currently"
+                             "supported".format(site2, site1))
+        if center_position is not None and center_position not in (site1, site2):
+            raise ValueError(f"center_position = {center_position} not in {(site1, site2)} ")
+        if (max_singular_values or max_truncation_err) and self.center_position not in (site1, site2):
+            raise ValueError(
+                "center_position = {}, but gate is applied at sites {}, {}. Truncation should only be done if the "
+                "gate is applied at the center position of the MPS".format(self.center_position, site1, site2))
+        use_svd = (max_truncation_err is not None) or (max_singular_values is not None)
+        a, b = self.tensors[site1], self.tensors[site2]
+        l, d, m = a.shape
+        _, _, r = b.shape
+        # theta = ncon([A, B, gate], [[-1,1,2],[2,3,-4],[-2,-3,1,3]]): bond GEMM, then the 4x4 gate
+        ab = LA.matmul(a.reshape(l * d, m), b.reshape(m, d * r))
+        theta = LA.gate_mix(ab.reshape(-1), gate.reshape(-1), l, r).reshape(l * d, d * r)
+
+        def set_center(site: int) -> None:
+            if self.center_position is not None:
+                if self.center_position in (site1, site2):
+                    self.center_position = site
+                else:
+                    self.center_position = None
+
+        if center_position is None:
+            center_position = site1
+        if use_svd:
+            absorb = 2 if center_position == site2 else 1
+            left, _, right, tw = LA.svd_trunc(theta, max_singular_values, max_truncation_err, relative, absorb)
+            set_center(site2 if center_position == site2 else site1)
+        else:
+            tw = _torch().zeros(1, dtype=theta.dtype, device=theta.device)
+            if center_position == site1:
+                left, right = LA.rq(theta)
+                set_center(site1)
+            else:
+                left, right = LA.qr(theta)
+                set_center(site2)
+        self.tensors[site1] = left.reshape(l, d, -1)
+        self.tensors[site2] = right.reshape(-1, d, r)
+        return tw
+
+    def check_canonical(self) -> Tensor:
+        torch = _torch()
+        devs = []
+        for site, t in enumerate(self.tensors):
+            l, d, r = t.shape
+            if site < self.center_position:
+                mat = t.reshape(l * d, r)
+                m = LA.matmul(mat.conj().t().resolve_conj(), mat)
+            elif site > self.center_position:
+                mat = t.reshape(l, d * r)
+                m = LA.matmul(mat, mat.conj().t().resolve_conj())
+            else:
+                continue
+            devs.append(torch.linalg.matrix_norm(m - torch.eye(m.shape[0], dtype=m.dtype, device=m.device)))
+        if not devs:
+            return torch.zeros((), device=_device())
+        return torch.linalg.vector_norm(torch.stack(devs))
+
+    def copy(self) -> "FiniteMPS":
+        r = FiniteMPS([t.clone() for t in self.tensors], canonicalize=False)
+        r.center_position = self.center_position
+        return r
+
+    def conj(self) -> "FiniteMPS":
+        r = FiniteMPS([t.conj().resolve_conj() for t in self.tensors], canonicalize=False)
+        r.center_position = self.center_position
+        return r
+
+
+_SGATES = ["i", "x", "y", "z", "h", "t", "s", "td", "sd", "wroot", "cnot", "cx", "cz", "swap", "cy", "toffoli",
+           "ccnot", "ccx", "fredkin", "cswap"]
+_VGATES = {
+    "rx": G.rx_gate, "ry": G.ry_gate, "rz": G.rz_gate, "phase": G.phase_gate, "r": G.r_gate, "u": G.u_gate,
+    "cr": G.cr_gate, "iswap": G.iswap_gate, "rxx": G.rxx_gate, "ryy": G.ryy_gate, "rzz": G.rzz_gate,
+    "exp": G.exponential_gate, "exp1": G.exponential_gate_unity, "su4": G.su4_gate, "any": G.any_gate,
+    "unitary": G.any_gate,
+}
+
+
+class MPSCircuit:
+    """``MPSCircuit`` class (reference mpscircuit.py:72-1049): gates are absorbed into the MPS as they are
+    applied; double gates on non-adjacent qubits move through consecutive SWAPs, n >= 3 qubit gates
+    through an MPO."""
+
+    is_mps = True
+
+    def __init__(self, nqubits: int, center_position: Optional[int] = None,
+                 tensors: Optional[Sequence[Tensor]] = None, wavefunction: Optional[Tensor] = None,
+                 split: Optional[Dict[str, Any]] = None, dim: Optional[int] = None) -> None:
+        if dim not in (None, 2):
+            raise NotImplementedError("the hip MPSCircuit handles qubits (dim = 2) only")
+        self._d = 2
+        self.split = split if split is not None else {}
+        if wavefunction is not None:
+            if tensors is not None:
+                raise ValueError("tensors and wavefunction cannot be used at input simultaneously")
+            tensors = self.wavefunction_to_tensors(wavefunction, split=self.split)
+            if len(tensors) != nqubits:
+                raise ValueError(f"number of MPS tensors ({len(tensors)}) must match nqubits ({nqubits})")
+            self._mps = FiniteMPS(tensors, canonicalize=False)
+            self._mps.center_position = 0
+            if center_position is not None:
+                self.position(center_position)
+        elif tensors is not None:
+            if center_position is not None:
+                self._mps = FiniteMPS(tensors, canonicalize=False)
+                self._mps.center_position = center_position
+            else:
+                self._mps = FiniteMPS(tensors, canonicalize=True, center_position=0)
+        else:
+            one = np.zeros((1, 2, 1), dtype=cons.npdtype)
+            one[0, 0, 0] = 1.0
+            self._mps = FiniteMPS([one for _ in range(nqubits)], canonicalize=False)
+            self._mps.center_position = 0 if center_position is None else center_position
+        self._nqubits = nqubits
+        self._fidelity: Any = 1.0
+        self._qir: List[Dict[str, Any]] = []
+
+    # ---- bookkeeping (reference :199-248)
+    def get_bond_dimensions(self) -> List[int]:
+        return self._mps.bond_dimensions
+
+    def get_tensors(self) -> List[Tensor]:
+        return self._mps.tensors
+
+    def get_center_position(self) -> Optional[int]:
+        return self._mps.center_position
+
+    def set_split_rules(self, split: Dict[str, Any]) -> None:
+        self.split = split
+
+    def position(self, site: int) -> None:
+        self._mps.position(site, normalize=False)
+
+    # ---- gates (reference :250-383)
+    def apply_single_gate(self, gate: Any, index: int) -> None:
+        if self._mps.center_position != index:
+            self.position(index)
+        self._mps.apply_one_site_gate(_t(gate), index)
+
+    def apply_adjacent_double_gate(self, gate: Any, index1: int, index2: int,
+                                   center_position: Optional[int] = None,
+                                   split: Optional[Dict[str, Any]] = None) -> None:
+        if split is None:
+            split = self.split
+        if index2 - index1 != 1:
+            raise ValueError(f"two-qubit gate indices must be adjacent, got index1={index1}, index2={index2}")
+        diff1 = abs(index1 - self._mps.center_position)
+        diff2 = abs(index2 - self._mps.center_position)
+        if diff1 < diff2:
+            if self._mps.center_position != index1:
+                self.position(index1)
+        else:
+            if self._mps.center_position != index2:
+                self.position(index2)
+        err = self._mps.apply_two_site_gate(_t(gate).reshape(2, 2, 2, 2), index1, index2,
+                                            center_position=center_position, **split)
+        self._fidelity = self._fidelity * (1 - (err.real ** 2 + err.imag ** 2).sum())
+
+    def consecutive_swap(self, index_from: int, index_to: int, split: Optional[Dict[str, Any]] = None) -> None:
+        if split is None:
+            split = self.split
+        self.position(index_from)
+        swap = G.swap()
+        if index_from < index_to:
+            for i in range(index_from, index_to):
+                self.apply_adjacent_double_gate(swap, i, i + 1, center_position=i + 1, split=split)
+        elif index_from > index_to:
+            for i in range(index_from, index_to, -1):
+                self.apply_adjacent_double_gate(swap, i - 1, i, center_position=i - 1, split=split)
+        assert self._mps.center_position == index_to
+
+    def apply_double_gate(self, gate: Any, index1: int, index2: int,
+                          split: Optional[Dict[str, Any]] = None) -> None:
+        gate = _t(gate).reshape(2, 2, 2, 2)
+        assert index1 != index2
+        if index1 > index2:
+            # as in the reference (:364-367) the recursion does not forward ``split``
+            self.apply_double_gate(gate.permute(1, 0, 3, 2).contiguous(), index2, index1)
+            return
+        if split is None:
+            split = self.split
+        diff1 = abs(index1 - self._mps.center_position)
+        diff2 = abs(index2 - self._mps.center_position)
+        if diff1 < diff2:
+            self.consecutive_swap(index1, index2 - 1, split=split)
+            self.apply_adjacent_double_gate(gate, index2 - 1, index2, center_position=index2 - 1, split=split)
+            self.consecutive_swap(index2 - 1, index1, split=split)
+        else:
+            self.consecutive_swap(index2, index1 + 1, split=split)
+            self.apply_adjacent_double_gate(gate, index1, index1 + 1, center_position=index1 + 1, split=split)
+            self.consecutive_swap(index1 + 1, index2, split=split)
+
+    # ---- MPO route for n >= 3 qubit gates (reference :386-668)
+    @classmethod
+    def gate_to_MPO(cls, gate: Any, *index: int) -> Tuple[List[Tensor], int]:
+        torch = _torch()
+        if len(index) == 0:
+            raise ValueError("`index` must contain at least one site.")
+        if not all(index[i] < index[i + 1] for i in range(len(index) - 1)):
+            raise ValueError("`index` must be strictly increasing.")
+        index_left = int(np.min(index))
+        nindex = len(index)
+        dim = 2
+        gate = _t(gate).reshape((dim,) * (2 * nindex))
+        order = tuple(np.arange(2 * nindex).reshape(2, nindex).T.flatten().tolist())
+        gate = gate.permute(order).contiguous().reshape((dim * dim,) * nindex)
+        main_tensors = cls.wavefunction_to_tensors(gate, dim_phys=dim * dim, norm=False)
+        tensors: List[Tensor] = []
+        previous_i = None
+        for i, main in zip(np.array(index, dtype=int) - index_left, main_tensors):
+            if previous_i is not None:
+                for _ in range(int(previous_i) + 1, int(i)):
+                    bond = int(tensors[-1].shape[-1])
+                    eye = torch.eye(bond * dim, dtype=tensors[-1].dtype, device=tensors[-1].device)
+                    tensors.append(eye.reshape(bond, dim, bond, dim).permute(0, 1, 3, 2).contiguous())
+            nleft, _, nright = main.shape
+            tensors.append(main.reshape(nleft, dim, dim, nright))
+            previous_i = int(i)
+        return tensors, index_left
+
+    @classmethod
+    def reduce_tensor_dimension(cls, tensor_left: Tensor, tensor_right: Tensor, center_left: bool = True,
+                                split: Optional[Dict[str, Any]] = None) -> Tuple[Tensor, Tensor]:
+        split = split or {}
+        ni, di = tensor_left.shape[0], tensor_right.shape[1]
+        nk, dk = tensor_right.shape[-1], tensor_right.shape[-2]
+        nj = tensor_left.shape[-1]
+        t = LA.matmul(tensor_left.reshape(-1, nj), tensor_right.reshape(nj, -1)).reshape(ni * di, nk * dk)
+        nl, nr = split_tensor(t, center_left=center_left, split=split)
+        return nl.reshape(ni, di, -1), nr.reshape(-1, dk, nk)
+
+    def reduce_dimension(self, index_left: int, center_left: bool = True,
+                         split: Optional[Dict[str, Any]] = None) -> None:
+        if split is None:
+            split = self.split
+        index_right = index_left + 1
+        assert self._mps.center_position in [index_left, index_right]
+        nl, nr = self.reduce_tensor_dimension(self._mps.tensors[index_left], self._mps.tensors[index_right],
+                                              center_left=center_left, split=split)
+        self._mps.tensors[index_left] = nl
+        self._mps.tensors[index_right] = nr
+        self._mps.center_position = index_left if center_left else index_right
+
+    def apply_MPO(self, tensors: Sequence[Tensor], index_left: int, center_left: bool = True,
+                  split: Optional[Dict[str, Any]] = None) -> None:
+        if split is None:
+            split = self.split
+        tensors = [_t(t) for t in tensors]
+        nindex = len(tensors)
+        index_right = index_left + nindex - 1
+        if center_left:
+            end1, end2, step = index_left, index_right, 1
+        else:
+            end1, end2, step = index_right, index_left, -1
+        n_list = np.arange(nindex)[::step]
+        idx_list = np.arange(index_left, index_right + 1)[::step]
+        self.position(end1)
+        residue = None
+        for i, idx in zip(n_list, idx_list):
+            idx = int(idx)
+            o = tensors[int(i)]
+            t = self._mps.tensors[idx]
+            ni, d_out, _, nj = o.shape
+            nk, _, nl = t.shape
+            ot = LA.einsum2("iabj,kbl->ikajl", o, t).reshape(ni * nk, d_out, nj * nl)
+            if residue is not None:
+                if step == 1:
+                    ot = LA.matmul(residue, ot.reshape(ni * nk, -1)).reshape(-1, d_out, nj * nl)
+                else:
+                    ot = LA.matmul(ot.reshape(-1, nj * nl), residue).reshape(ni * nk, d_out, -1)
+            s0, s1, s2 = ot.shape
+            if idx != end2:
+                if step == 1:
+                    q, r = LA.qr(ot.reshape(s0 * s1, -1))
+                    self._mps.tensors[idx] = q.reshape(s0, s1, -1)
+                    residue = r
+                    self._mps.center_position = idx + 1
+                else:
+                    q_t, r_t = LA.qr(ot.permute(2, 1, 0).contiguous().reshape(s2 * s1, -1))
+                    self._mps.tensors[idx] = q_t.reshape(s2, s1, -1).permute(2, 1, 0).contiguous()
+                    residue = r_t.t().contiguous()
+                    self._mps.center_position = idx - 1
+            else:
+                self._mps.tensors[idx] = ot.contiguous()
+                self._mps.center_position = end2
+        for i in idx_list[::-1][:-1]:
+            i = int(i)
+            self.reduce_dimension(min(i, i - step), center_left=center_left, split=split)
+
+    def apply_nqubit_gate(self, gate: Any, *index: int, split: Optional[Dict[str, Any]] = None) -> None:
+        gate = _t(gate)
+        if not np.all(np.diff(index) > 0):
+            order = np.argsort(index)
+            order_all = order.tolist() + (order + len(index)).tolist()
+            gate = gate.reshape((2,) * (2 * len(index))).permute(order_all).contiguous()
+            self.apply_nqubit_gate(gate, *np.sort(index).tolist(), split=split)
+            return
+        if split is None:
+            split = self.split
+        mpo, index_left = self.gate_to_MPO(gate, *index)
+        index_right = index_left + len(mpo) - 1
+        diff_left = abs(index_left - self._mps.center_position)
+        diff_right = abs(index_right - self._mps.center_position)
+        self.apply_MPO(mpo, index_left, center_left=diff_left < diff_right, split=split)
+
+    def apply_general_gate(self, gate: Any, *index: int, name: Optional[str] = None,
+                           split: Optional[Dict[str, Any]] = None, mpo: bool = False,
+                           diagonal: bool = False, ir_dict: Optional[Dict[str, Any]] = None) -> None:
+        """reference :670-724."""
+        if split is None:
+            split = self.split
+        self._qir.append({"gate": gate, "index": index, "name": name or "", "split": split, "mpo": mpo})
+        if len(index) != len(set(index)):
+            raise ValueError(f"gate index {list(index)} has duplicate qubits; each qubit may appear at most once")
+        if mpo is not False:
+            raise NotImplementedError("MPO not implemented for MPS")
+        if diagonal is not False:
+            raise NotImplementedError("diagonal hyperedge not implemented for MPS")
+        noe = len(index)
+        if noe == 1:
+            self.apply_single_gate(gate, *index)
+        elif noe == 2:
+            self.apply_double_gate(gate, *index, split=split)
+        else:
+            self.apply_nqubit_gate(gate, *index, split=split)
+
+    apply = apply_general_gate
+
+    def mid_measurement(self, index: int, keep: int = 0) -> None:
+        """reference :726-744: z-basis projector, state left unnormalised."""
+        gate = np.zeros((2, 2), dtype=cons.npdtype)
+        gate[keep, keep] = 1.0
+        self.apply_single_gate(gate, index)
+
+    def is_valid(self) -> bool:
+        mps = self._mps
+        if len(mps) != self._nqubits:
+            return False
+        for i in range(self._nqubits):
+            if mps.tensors[i].dim() != 3:
+                return False
+        for i in range(self._nqubits - 1):
+            if mps.tensors[i].shape[-1] != mps.tensors[i + 1].shape[0]:
+                return False
+        return True
+
+    # ---- outputs (reference :765-1049)
+    @classmethod
+    def wavefunction_to_tensors(cls, wavefunction: Tensor, dim_phys: Optional[int] = None, norm: bool = True,
+                                split: Optional[Dict[str, Any]] = None) -> List[Tensor]:
+        dim_phys = dim_phys if dim_phys is not None else 2
+        split = split or {}
+        w = _t(wavefunction).reshape(-1, 1)
+        n_tensors = int(np.round(np.log(w.shape[0]) / np.log(dim_phys)))
+        tensors: List[Tensor] = []
+        for _ in range(n_tensors):
+            nright = w.shape[1]
+            w = w.reshape(-1, nright * dim_phys)
+            w, q = split_tensor(w, center_left=True, split=split)
+            tensors.insert(0, q.reshape(-1, dim_phys, nright))
+        if tuple(w.shape) != (1, 1):
+            raise ValueError(f"expected scalar wavefunction of shape (1, 1), got {tuple(w.shape)}")
+        if not norm:
+            tensors[0] = tensors[0] * w[0, 0]
+        return tensors
+
+    def wavefunction(self, form: str = "default") -> Tensor:
+        torch = _torch()
+        result = torch.ones((1, 1), dtype=_dtype(), device=_device())
+        for t in self._mps.tensors:
+            j, b, k = t.shape
+            result = LA.matmul(result, t.reshape(j, b * k)).reshape(-1, k)
+        shape = {"default": [-1], "ket": [-1, 1], "bra": [1, -1]}[form]
+        return result.reshape(shape)
+
+    state = wavefunction
+
+    def copy_without_tensor(self) -> "MPSCircuit":
+        r = MPSCircuit.__new__(MPSCircuit)
+        r._d = self._d
+        r.split = dict(self.split)
+        r._nqubits = self._nqubits
+        r._fidelity = self._fidelity
+        r._qir = list(self._qir)
+        return r
+
+    def copy(self) -> "MPSCircuit":
+        r = self.copy_without_tensor()
+        r._mps = self._mps.copy()
+        return r
+
+    def conj(self) -> "MPSCircuit":
+        r = self.copy_without_tensor()
+        r._mps = self._mps.conj()
+        return r
+
+    def get_norm(self) -> Tensor:
+        return _torch().linalg.vector_norm(self._mps.tensors[self._mps.center_position])
+
+    def normalize(self) -> None:
+        c = self._mps.center_position
+        self._mps.tensors[c] = self._mps.tensors[c] / self.get_norm()
+
+    def amplitude(self, l: str) -> Tensor:
+        assert len(l) == self._nqubits
+        mats = [self._mps.tensors[i][:, int(ch), :] for i, ch in enumerate(l)]
+        return reduce(LA.matmul, mats)[0, 0]
+
+    def proj_with_mps(self, other: "MPSCircuit", conj: bool = True) -> Tensor:
+        """<other|self> (reference :905-939), contracted from the right end."""
+        bra = other.conj() if conj else other.copy()
+        ket = self.copy()
+        assert bra._nqubits == ket._nqubits
+        for _ in range(bra._nqubits, 1, -1):
+            bra_b = bra._mps.tensors[-1]
+            ket_a, ket_b = ket._mps.tensors[-2:]
+            k = bra_b.shape[0]
+            l = ket_b.shape[0]
+            proj_b = LA.matmul(bra_b.reshape(k, -1), ket_b.reshape(l, -1).t())        # "kbm,lbm->kl"
+            j, a, _ = ket_a.shape
+            new_ka = LA.matmul(ket_a.reshape(j * a, l), proj_b.t()).reshape(j, a, k)  # "jal,kl->jak"
+            bra._mps.tensors.pop()
+            ket._mps.tensors.pop()
+            ket._mps.tensors[-1] = new_ka
+        return (bra._mps.tensors[0] * ket._mps.tensors[0]).sum()
+
+    def slice(self, begin: int, end: int) -> "MPSCircuit":
+        nq = end - begin + 1
+        tensors = [t.clone() for t in self._mps.tensors[begin:end + 1]]
+        cp = None
+        c = self._mps.center_position
+        if c is not None and begin <= c <= end:
+            cp = c - begin
+        return self.__class__(nq, tensors=tensors, center_position=cp, split=dict(self.split))
+
+    def expectation(self, *ops: Tuple[Any, List[int]], reuse: bool = True, other: Optional["MPSCircuit"] = None,
+                    conj: bool = True, normalize: bool = False, split: Optional[Dict[str, Any]] = None,
+                    **kws: Any) -> Tensor:
+        if split is None:
+            split = {}
+        ops2 = [[op[0], [op[1]] if isinstance(op[1], int) else list(op[1])] for op in ops]
+        all_sites = np.concatenate([op[1] for op in ops2])
+        if other is None:
+            site_begin, site_end = int(np.min(all_sites)), int(np.max(all_sites))
+            if self._mps.center_position < site_begin:
+                self.position(site_begin)
+            elif self._mps.center_position > site_end:
+                self.position(site_end)
+        else:
+            assert isinstance(other, MPSCircuit), "the bra has to be a MPSCircuit"
+        mps = self.copy()
+        mps.set_split_rules(split)
+        for gate, index in ops2:
+            mps.apply(gate, *index)
+        if other is None:
+            ket = mps.slice(site_begin, site_end)
+            bra = self.slice(site_begin, site_end)
+        else:
+            ket, bra = mps, other
+        value = ket.proj_with_mps(bra, conj=conj)
+        if normalize:
+            n1 = self.get_norm()
+            n2 = n1 if other is None else other.get_norm()
+            value = value / (n1 * n2).sqrt()
+        return value
+
+    def expectation_ps(self, x: Optional[Sequence[int]] = None, y: Optional[Sequence[int]] = None,
+                       z: Optional[Sequence[int]] = None, **kws: Any) -> Tensor:
+        """reference abstractcircuit.py:1523-1603."""
+        ops = []
+        for mk, idx in ((G.x, x), (G.y, y), (G.z, z)):
+            for i in (idx or []):
+                ops.append((mk(), [i]))
+        return self.expectation(*ops, **kws)
+
+
+def _make_sgate(name):
+    def f(self, *index, **kw):
+        self.apply_general_gate(getattr(G, name)(), *index, name=name, **kw)
+
+    f.__name__ = name
+    return f
+
+
+def _make_vgate(name, factory):
+    def f(self, *index, split=None, **kw):
+        self.apply_general_gate(factory(**kw), *index, name=name, split=split)
+
+    f.__name__ = name
+    return f
+
+
+for _n in _SGATES:
+    setattr(MPSCircuit, _n, _make_sgate(_n))
+    setattr(MPSCircuit, _n.upper(), _make_sgate(_n))
+for _n, _f in _VGATES.items():
+    setattr(MPSCircuit, _n, _make_vgate(_n, _f))
+    setattr(MPSCircuit, _n.upper(), _make_vgate(_n, _f))

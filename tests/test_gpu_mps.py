@@ -1,0 +1,185 @@
+"""GPU parity of the MPS / TEBD row (SURVEY §8a last row, config 5) through the C ABI:
+tcmi_svd_trunc_batched / tcmi_qr_batched / tcmi_mps_gate_mix / tcmi_cgemm vs numpy, and tcmi.MPSCircuit
+vs oracle/mps.py + the reference's KAT (tests/test_mpscircuit.py:380)."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import tcmi as tc
+from tcmi import linalg as LA
+from oracle import mps as omps
+
+from test_oracle_mps import D, N, dense_state, gate_list
+
+TOL = {"complex64": 2e-5, "complex128": 1e-11}
+
+
+def _rand(rng, m, n, dt, rank=None):
+    a = rng.normal(size=(m, n)) + 1j * rng.normal(size=(m, n))
+    if rank is not None:
+        a = (rng.normal(size=(m, rank)) + 1j * rng.normal(size=(m, rank))) @ (
+            rng.normal(size=(rank, n)) + 1j * rng.normal(size=(rank, n)))
+    return a.astype(dt)
+
+
+@pytest.mark.parametrize("dt", ["complex64", "complex128"])
+@pytest.mark.parametrize("shape", [(2, 2), (4, 4), (3, 5), (5, 3), (16, 16), (17, 33), (64, 40), (128, 128),
+                                   (256, 256), (100, 300)])
+def test_svd_matches_lapack(dt, shape):
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    a = _rand(rng, *shape, dt)
+    u, s, vh, rest = LA.svd_trunc(torch.from_numpy(a).cuda())
+    u, s, vh = u.cpu().numpy(), s.cpu().numpy(), vh.cpu().numpy()
+    assert rest.numel() == 0
+    s_ref = np.linalg.svd(a.astype(np.complex128), compute_uv=False)
+    tol = TOL[dt] * max(1.0, s_ref[0])
+    np.testing.assert_allclose(s.real, s_ref, atol=tol)
+    assert np.all(np.diff(s.real) <= 1e-6 * s_ref[0])
+    np.testing.assert_allclose((u * s) @ vh, a, atol=4 * tol)
+    k = min(shape)
+    np.testing.assert_allclose(u.conj().T @ u, np.eye(k), atol=4 * TOL[dt] * 10)
+    np.testing.assert_allclose(vh @ vh.conj().T, np.eye(k), atol=4 * TOL[dt] * 10)
+
+
+@pytest.mark.parametrize("dt", ["complex64", "complex128"])
+def test_svd_truncation_rule_and_absorb(dt):
+    rng = np.random.default_rng(5)
+    a = _rand(rng, 48, 64, dt)
+    ag = torch.from_numpy(a).cuda()
+    for kw in (dict(max_singular_values=10), dict(max_truncation_err=3.0), dict(max_truncation_err=0.2, relative=True),
+               dict(max_singular_values=20, max_truncation_err=1.0)):
+        u_o, s_o, vh_o, rest_o = omps.svd_trunc(a.astype(np.complex128), kw.get("max_singular_values"),
+                                                kw.get("max_truncation_err"), kw.get("relative", False))
+        for absorb in (0, 1, 2):
+            u, s, vh, rest = LA.svd_trunc(ag, absorb=absorb, **kw)
+            assert s.numel() == s_o.size and rest.numel() == rest_o.size
+            np.testing.assert_allclose(s.cpu().numpy().real, s_o.real, atol=TOL[dt] * 20)
+            np.testing.assert_allclose(rest.cpu().numpy().real, rest_o.real, atol=TOL[dt] * 20)
+            rec = u.cpu().numpy() @ vh.cpu().numpy() if absorb else (u.cpu().numpy() * s.cpu().numpy()) @ vh.cpu().numpy()
+            np.testing.assert_allclose(rec, (u_o * s_o) @ vh_o, atol=TOL[dt] * 100)
+
+
+def test_svd_rank_deficient_and_zero():
+    rng = np.random.default_rng(9)
+    a = _rand(rng, 32, 32, "complex128", rank=5)
+    u, s, vh, _ = LA.svd_trunc(torch.from_numpy(a).cuda())
+    s = s.cpu().numpy().real
+    assert np.all(s[5:] < 1e-10 * s[0])
+    np.testing.assert_allclose((u.cpu().numpy() * s) @ vh.cpu().numpy(), a, atol=1e-10)
+    np.testing.assert_allclose(u.cpu().numpy().conj().T @ u.cpu().numpy(), np.eye(32), atol=1e-10)
+    z = torch.zeros((4, 6), dtype=torch.complex64, device="cuda")
+    u, s, vh, _ = LA.svd_trunc(z)
+    assert float(s.abs().max()) == 0.0 and bool(torch.isfinite(vh.abs()).all())
+
+
+@pytest.mark.parametrize("dt", ["complex64", "complex128"])
+@pytest.mark.parametrize("shape", [(2, 1), (2, 2), (4, 2), (6, 9), (64, 32), (256, 128), (130, 70)])
+def test_qr_and_rq(dt, shape):
+    rng = np.random.default_rng(shape[0] + 31 * shape[1])
+    a = _rand(rng, *shape, dt)
+    ag = torch.from_numpy(a).cuda()
+    q, r = LA.qr(ag)
+    q, r = q.cpu().numpy(), r.cpu().numpy()
+    k = min(shape)
+    tol = TOL[dt] * 20
+    np.testing.assert_allclose(q @ r, a, atol=tol * np.abs(a).max() * 4)
+    np.testing.assert_allclose(q.conj().T @ q, np.eye(k), atol=tol)
+    assert np.abs(np.tril(r, -1)).max() == 0
+    rr, qq = LA.rq(ag)
+    rr, qq = rr.cpu().numpy(), qq.cpu().numpy()
+    np.testing.assert_allclose(rr @ qq, a, atol=tol * np.abs(a).max() * 4)
+    np.testing.assert_allclose(qq @ qq.conj().T, np.eye(k), atol=tol)
+
+
+def test_qr_rank_deficient_isometry():
+    a = np.zeros((8, 4), dtype=np.complex128)
+    a[0, 0] = 1.0
+    a[:, 2] = a[:, 0] * 2
+    q, r = LA.qr(torch.from_numpy(a).cuda())
+    q, r = q.cpu().numpy(), r.cpu().numpy()
+    np.testing.assert_allclose(q.conj().T @ q, np.eye(4), atol=1e-13)
+    np.testing.assert_allclose(q @ r, a, atol=1e-13)
+
+
+@pytest.mark.parametrize("dt", ["complex64", "complex128"])
+def test_gate_mix_and_site_gate(dt):
+    rng = np.random.default_rng(3)
+    L, R = 7, 13
+    t = (rng.normal(size=(L, 2, 2, R)) + 1j * rng.normal(size=(L, 2, 2, R))).astype(dt)
+    g = (rng.normal(size=(2, 2, 2, 2)) + 1j * rng.normal(size=(2, 2, 2, 2))).astype(dt)
+    out = LA.gate_mix(torch.from_numpy(t).cuda().reshape(-1), torch.from_numpy(g).cuda().reshape(-1), L, R)
+    np.testing.assert_allclose(out.cpu().numpy().reshape(L, 2, 2, R), np.einsum("xyab,labr->lxyr", g, t),
+                               atol=TOL[dt] * 10)
+    a = (rng.normal(size=(L, 2, R)) + 1j * rng.normal(size=(L, 2, R))).astype(dt)
+    g1 = (rng.normal(size=(2, 2)) + 1j * rng.normal(size=(2, 2))).astype(dt)
+    o1 = LA.site_gate(torch.from_numpy(g1).cuda(), torch.from_numpy(a).cuda())
+    np.testing.assert_allclose(o1.cpu().numpy(), np.einsum("ab,lbr->lar", g1, a), atol=TOL[dt] * 10)
+
+
+def _run(ops, split=None):
+    m = tc.MPSCircuit(N, split=split)
+    for g, idx in ops:
+        m.apply(tc.gates.Gate(np.asarray(g)), *idx)
+    return m
+
+
+def test_reference_truncation_kat_on_gpu():
+    """reference tests/test_mpscircuit.py:380 (N=8, D=6, complex128)."""
+    tc.set_dtype("complex128")
+    try:
+        ops = gate_list()
+        w_c = dense_state(ops)
+        m = _run(ops, tc.cons.split_rules(max_singular_values=D))
+        m.normalize()
+        real_fid = abs(np.vdot(m.wavefunction().cpu().numpy(), w_c)) ** 2
+        np.testing.assert_allclose(real_fid, 0.902663090851, atol=1e-5)
+        np.testing.assert_allclose(float(m._fidelity), 0.910305380327, atol=1e-5)
+        assert float(m._mps.check_canonical()) < 1e-10
+        ex = _run(ops)
+        np.testing.assert_allclose(ex.wavefunction().cpu().numpy(), w_c, atol=1e-10)
+        assert float(ex._mps.check_canonical()) < 1e-10
+        e = ex.expectation_ps(x=[0, 2], y=[5, 3, 1], z=[6, 4])
+        o = omps.MPSCircuit(N)
+        for g, idx in ops:
+            o.apply(g, *idx)
+        np.testing.assert_allclose(complex(e), o.expectation_ps(x=[0, 2], y=[5, 3, 1], z=[6, 4]), atol=1e-9)
+    finally:
+        tc.set_dtype("complex64")
+
+
+@pytest.mark.parametrize("dt,chi", [("complex64", 8), ("complex128", 8), ("complex64", None)])
+def test_tebd_sweeps_match_oracle(dt, chi):
+    """Config-5 shaped workload at a size the oracle finishes in seconds: brickwork + left-to-right sweeps of
+    random SU(4) gates with max_singular_values = chi, compared with oracle/mps.py gate by gate."""
+    from oracle import gates as OG
+
+    n = 12
+    tc.set_dtype(dt)
+    try:
+        split = tc.cons.split_rules(max_singular_values=chi) if chi else None
+        osplit = omps.split_rules(max_singular_values=chi) if chi else None
+        m = tc.MPSCircuit(n, split=split)
+        o = omps.MPSCircuit(n, split=osplit)
+        k = 0
+        for sweep in range(3):
+            for i in range(n - 1):
+                g = OG.random_two_qubit_gate(1000 + k)
+                k += 1
+                m.apply(tc.gates.Gate(g.reshape(2, 2, 2, 2)), i, i + 1)
+                o.apply(g, i, i + 1)
+            m.rx(sweep, theta=0.3 + sweep)
+            o.rx(sweep, theta=0.3 + sweep)
+        assert m.get_bond_dimensions() == o.get_bond_dimensions()
+        tol = 5e-5 if dt == "complex64" else 1e-9
+        # compare gauge-invariant quantities: fidelity estimate, state overlap, norm
+        wm = m.wavefunction().cpu().numpy().astype(np.complex128)
+        wo = o.wavefunction()
+        np.testing.assert_allclose(float(m._fidelity), o._fidelity, atol=tol * 10)
+        np.testing.assert_allclose(abs(np.vdot(wm, wo)), np.linalg.norm(wo) ** 2, atol=tol * 10)
+        np.testing.assert_allclose(float(m.get_norm()), o.get_norm(), atol=tol * 10)
+    finally:
+        tc.set_dtype("complex64")
