@@ -37,24 +37,64 @@ struct Eps<double> {
   static constexpr double v = 1.1102230246251565e-16;
 };
 
-// Device-scope barrier between the nwg workgroups of one matrix (all resident: the host caps the grid).
-// Every thread fences its own stores (agent scope: L2 write-back / L1 invalidate across XCDs) around it.
+// Inter-workgroup data (rows of W / Y, norms, sorted s) is exchanged INSIDE the launch.  Per-XCD L2s are
+// not coherent and a CU's L1 is never refreshed by other CUs, so every shared word is written with
+// write-through agent-scope stores (sc1) and read with agent-scope loads (sc1, L1 bypass) — the
+// "8-byte agent atomics on both sides" form of the hand-off rules; no release/acquire fences (3.5 us
+// each) are needed, the barrier only has to drain the stores of every wave before it arrives.
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned int gu32;
+#define TCMI_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+__device__ __forceinline__ float2 ld_sc1(const float2* p) {
+  const unsigned long long v = __hip_atomic_load((gu64*)p, TCMI_RLX);
+  float2 r;
+  r.x = __uint_as_float((unsigned)v);
+  r.y = __uint_as_float((unsigned)(v >> 32));
+  return r;
+}
+__device__ __forceinline__ void st_sc1(float2* p, float2 v) {
+  __hip_atomic_store((gu64*)p, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x), TCMI_RLX);
+}
+__device__ __forceinline__ double2 ld_sc1(const double2* p) {
+  double2 r;
+  r.x = __longlong_as_double((long long)__hip_atomic_load((gu64*)p, TCMI_RLX));
+  r.y = __longlong_as_double((long long)__hip_atomic_load((gu64*)p + 1, TCMI_RLX));
+  return r;
+}
+__device__ __forceinline__ void st_sc1(double2* p, double2 v) {
+  __hip_atomic_store((gu64*)p, (unsigned long long)__double_as_longlong(v.x), TCMI_RLX);
+  __hip_atomic_store((gu64*)p + 1, (unsigned long long)__double_as_longlong(v.y), TCMI_RLX);
+}
+__device__ __forceinline__ float ld_sc1(const float* p) { return __uint_as_float(__hip_atomic_load((gu32*)p, TCMI_RLX)); }
+__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store((gu32*)p, __float_as_uint(v), TCMI_RLX); }
+__device__ __forceinline__ double ld_sc1(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load((gu64*)p, TCMI_RLX));
+}
+__device__ __forceinline__ void st_sc1(double* p, double v) {
+  __hip_atomic_store((gu64*)p, (unsigned long long)__double_as_longlong(v), TCMI_RLX);
+}
+
+// Barrier between the nwg workgroups of one matrix (all resident: the host caps the grid at 256 WGs).
+// Every wave drains its write-through stores, one lane arrives on a monotonic counter and polls it
+// relaxed with s_sleep; the spin is bounded (a timeout sets ctl[1] and ends the kernel).
 __device__ __forceinline__ bool grid_barrier(unsigned* ctl, unsigned nwg, unsigned& epoch, unsigned* s_dead) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (nwg == 1) {
     __syncthreads();
     return true;
   }
   ++epoch;
-  __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) {
-    __hip_atomic_fetch_add(&ctl[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    gu32* c = (gu32*)ctl;
+    __hip_atomic_fetch_add(c, 1u, TCMI_RLX);
     const unsigned target = epoch * nwg;
     unsigned spins = 0, dead = 0;
-    while (__hip_atomic_load(&ctl[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    while (__hip_atomic_load(c, TCMI_RLX) < target) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > SPIN_LIMIT || __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-        __hip_atomic_store(&ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (++spins > SPIN_LIMIT || __hip_atomic_load(c + 1, TCMI_RLX)) {
+        __hip_atomic_store(c + 1, 1u, TCMI_RLX);
         dead = 1;
         break;
       }
@@ -62,14 +102,29 @@ __device__ __forceinline__ bool grid_barrier(unsigned* ctl, unsigned nwg, unsign
     *s_dead = dead;
   }
   __syncthreads();
-  __threadfence();
+  asm volatile("" ::: "memory");
   return *s_dead == 0;
+}
+
+// Rotation (c, s e^{i phi}) annihilating <x, y> = gr + i gi between rows of squared norms al, be; computed
+// in double so that c^2 + s^2 = 1 to 1e-16 before rounding (no systematic norm drift over ~10^3 rotations).
+template <typename F>
+__device__ __forceinline__ void jacobi_rotation(F al, F be, F gr, F gi, F& c, F& sn, F& pr, F& pi) {
+  const double g2 = (double)gr * gr + (double)gi * gi;
+  const double ag = sqrt(g2);
+  const double zeta = ((double)be - (double)al) / (2 * ag);
+  const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
+  const double cc = 1 / sqrt(1 + t * t);
+  c = (F)cc;
+  sn = (F)(cc * t);
+  pr = (F)(gr / ag);
+  pi = (F)(gi / ag);
 }
 
 template <typename F, int E>
 __global__ __launch_bounds__(SVD_THREADS) void svd_jacobi_kernel(
     const typename Cx<F>::type* __restrict__ a, long long a_stride, typename Cx<F>::type* __restrict__ u,
-    F* __restrict__ s, typename Cx<F>::type* __restrict__ vh, int* __restrict__ keep_out,
+    F* s, typename Cx<F>::type* __restrict__ vh, int* __restrict__ keep_out,
     F* __restrict__ tw2_out, int p, int q, int kmax, typename Cx<F>::type* work, long long work_stride,
     unsigned* ctl_base, int max_sweeps, int max_sv, F max_err, int relative, int absorb, int batch0) {
   using Ct = typename Cx<F>::type;
@@ -83,7 +138,8 @@ __global__ __launch_bounds__(SVD_THREADS) void svd_jacobi_kernel(
   vh += (long long)(b + batch0) * (long long)kmax * q;
   Ct* W = work + (long long)b * work_stride;
   Ct* Y = W + (long long)pp * q;
-  F* sq = reinterpret_cast<F*>(Y + (long long)pp * pp);
+  F* sq = reinterpret_cast<F*>(Y + (long long)pp * pp);  // [pp] squared singular values, [pp] 1/|Y_i|
+  F* yn = sq + pp;
   unsigned* ctl = ctl_base + (long long)b * SVD_CTL_WORDS;
   unsigned epoch = 0;
   __shared__ unsigned s_dead;
@@ -101,12 +157,12 @@ __global__ __launch_bounds__(SVD_THREADS) void svd_jacobi_kernel(
     for (long long i = t0; i < nW; i += step) {
       Ct v = zero;
       if (i < nA) v = a[i];
-      W[i] = v;
+      st_sc1(W + i, v);
     }
     for (long long i = t0; i < nY; i += step) {
       Ct v = zero;
       if (i / pp == i % pp) v.x = 1;
-      Y[i] = v;
+      st_sc1(Y + i, v);
     }
   }
   if (!grid_barrier(ctl, nwg, epoch, &s_dead)) return;
@@ -126,17 +182,27 @@ __global__ __launch_bounds__(SVD_THREADS) void svd_jacobi_kernel(
         }
         Ct* wi = W + (long long)i * q;
         Ct* wj = W + (long long)j * q;
-        Ct x[E], y[E];
+        Ct* yi_ = Y + (long long)i * pp;
+        Ct* yj_ = Y + (long long)j * pp;
+        Ct x[E], y[E], yx[E], yy[E];
         F al = 0, be = 0, gr = 0, gi = 0;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
           const int c = lane + 64 * e;
+          x[e].x = x[e].y = y[e].x = y[e].y = 0;
+          yx[e] = x[e];
+          yy[e] = x[e];
           if (c < q) {
-            x[e] = wi[c];
-            y[e] = wj[c];
-          } else {
-            x[e].x = x[e].y = y[e].x = y[e].y = 0;
+            x[e] = ld_sc1(wi + c);
+            y[e] = ld_sc1(wj + c);
           }
+          if (c < pp) {  // issued with the W loads: one memory round trip per round
+            yx[e] = ld_sc1(yi_ + c);
+            yy[e] = ld_sc1(yj_ + c);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
           al = fma_<F>(x[e].x, x[e].x, fma_<F>(x[e].y, x[e].y, al));
           be = fma_<F>(y[e].x, y[e].x, fma_<F>(y[e].y, y[e].y, be));
           // gamma += x conj(y)
@@ -149,62 +215,62 @@ __global__ __launch_bounds__(SVD_THREADS) void svd_jacobi_kernel(
         gi = wave_sum<F>(gi);
         const F g2 = gr * gr + gi * gi;
         if (g2 > tol2 * al * be && g2 > 0) {
-          const F ag = sqrt(g2);
-          const F pr = gr / ag, pi = gi / ag;  // e^{i phi}
-          const F zeta = (be - al) / (2 * ag);
-          const F t = (zeta >= 0 ? (F)1 : (F)-1) / (fabs(zeta) + sqrt(1 + zeta * zeta));
-          const F c = 1 / sqrt(1 + t * t), sn = c * t;
+          F c, sn, pr, pi;  // y~ = e^{i phi} y;  x' = c x - s y~;  y' = s x + c y~
+          jacobi_rotation<F>(al, be, gr, gi, c, sn, pr, pi);
 #pragma unroll
           for (int e = 0; e < E; ++e) {
             const int col = lane + 64 * e;
             if (col < q) {
-              const F yr = pr * y[e].x - pi * y[e].y, yi = pr * y[e].y + pi * y[e].x;  // e^{i phi} y
+              const F tr = pr * y[e].x - pi * y[e].y, ti = pr * y[e].y + pi * y[e].x;
               Ct nx, ny;
-              nx.x = c * x[e].x - sn * yr;
-              nx.y = c * x[e].y - sn * yi;
-              ny.x = sn * x[e].x + c * yr;
-              ny.y = sn * x[e].y + c * yi;
-              wi[col] = nx;
-              wj[col] = ny;
+              nx.x = c * x[e].x - sn * tr;
+              nx.y = c * x[e].y - sn * ti;
+              ny.x = sn * x[e].x + c * tr;
+              ny.y = sn * x[e].y + c * ti;
+              st_sc1(wi + col, nx);
+              st_sc1(wj + col, ny);
             }
-          }
-          Ct* yi_ = Y + (long long)i * pp;
-          Ct* yj_ = Y + (long long)j * pp;
-#pragma unroll
-          for (int e = 0; e < E; ++e) {
-            const int col = lane + 64 * e;
             if (col < pp) {
-              const Ct xx = yi_[col], yy = yj_[col];
-              const F yr = pr * yy.x - pi * yy.y, yi = pr * yy.y + pi * yy.x;
+              const F tr = pr * yy[e].x - pi * yy[e].y, ti = pr * yy[e].y + pi * yy[e].x;
               Ct nx, ny;
-              nx.x = c * xx.x - sn * yr;
-              nx.y = c * xx.y - sn * yi;
-              ny.x = sn * xx.x + c * yr;
-              ny.y = sn * xx.y + c * yi;
-              yi_[col] = nx;
-              yj_[col] = ny;
+              nx.x = c * yx[e].x - sn * tr;
+              nx.y = c * yx[e].y - sn * ti;
+              ny.x = sn * yx[e].x + c * tr;
+              ny.y = sn * yx[e].y + c * ti;
+              st_sc1(yi_ + col, nx);
+              st_sc1(yj_ + col, ny);
             }
           }
-          if (lane == 0) __hip_atomic_fetch_add(&ctl[2 + sweep], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane == 0) __hip_atomic_fetch_add((gu32*)&ctl[2 + sweep], 1u, TCMI_RLX);
         }
       }
       if (!grid_barrier(ctl, nwg, epoch, &s_dead)) return;
     }
-    if (__hip_atomic_load(&ctl[2 + sweep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) break;
+    if (__hip_atomic_load((gu32*)&ctl[2 + sweep], TCMI_RLX) == 0) break;
   }
 
-  // squared row norms
+  // squared row norms of W and Y: sigma_i = |W_i| / |Y_i| (W = Y a holds to rounding whatever the
+  // accumulated non-unitarity of the rotations; dividing it out removes the common drift)
   if (active) {
     for (int k = 0; k < 2; ++k) {
       const int row = 2 * gw + k;
       const Ct* w = W + (long long)row * q;
-      F acc = 0;
+      const Ct* yr = Y + (long long)row * pp;
+      F acc = 0, accy = 0;
       for (int c = lane; c < q; c += 64) {
-        const Ct v = w[c];
+        const Ct v = ld_sc1(w + c);
         acc = fma_<F>(v.x, v.x, fma_<F>(v.y, v.y, acc));
       }
+      for (int c = lane; c < pp; c += 64) {
+        const Ct v = ld_sc1(yr + c);
+        accy = fma_<F>(v.x, v.x, fma_<F>(v.y, v.y, accy));
+      }
       acc = wave_sum<F>(acc);
-      if (lane == 0) sq[row] = acc;
+      accy = wave_sum<F>(accy);
+      if (lane == 0) {
+        st_sc1(sq + row, acc / accy);
+        st_sc1(yn + row, 1 / sqrt(accy));
+      }
     }
   }
   if (!grid_barrier(ctl, nwg, epoch, &s_dead)) return;
@@ -214,30 +280,32 @@ __global__ __launch_bounds__(SVD_THREADS) void svd_jacobi_kernel(
     for (int k = 0; k < 2; ++k) {
       const int row = 2 * gw + k;
       if (row >= p) continue;
-      const F v = sq[row];
+      const F v = ld_sc1(sq + row);
+      const F iy = ld_sc1(yn + row);
       int cnt = 0;
       for (int j = lane; j < pp; j += 64) {
-        const F o = sq[j];
+        const F o = ld_sc1(sq + j);
         cnt += (o > v || (o == v && j < row)) ? 1 : 0;
       }
       const int rank = wave_sum<int>(cnt);
       const F sig = sqrt(v);
-      if (lane == 0) s[rank] = sig;
+      if (lane == 0) st_sc1(s + rank, sig);
       if (rank < kmax) {
-        const F inv = sig > 0 ? 1 / sig : 0;
-        const F sv = absorb == 2 ? (F)1 : inv;
-        const F su = absorb == 1 ? sig : (F)1;
+        // W_row = |Y_row| sigma vh: vh = W_row iy / sigma
+        const F inv = sig > 0 ? iy / sig : 0;
+        const F sv = absorb == 2 ? iy : inv;
+        const F su = (absorb == 1 ? sig : (F)1) * iy;
         const Ct* w = W + (long long)row * q;
         Ct* o = vh + (long long)rank * q;
         for (int c = lane; c < q; c += 64) {
-          Ct t = w[c];
+          Ct t = ld_sc1(w + c);
           t.x *= sv;
           t.y *= sv;
           o[c] = t;
         }
         const Ct* yr = Y + (long long)row * pp;
         for (int c = lane; c < p; c += 64) {
-          Ct t = yr[c];
+          Ct t = ld_sc1(yr + c);
           t.x *= su;
           t.y *= -su;
           u[(long long)c * kmax + rank] = t;
@@ -250,17 +318,21 @@ __global__ __launch_bounds__(SVD_THREADS) void svd_jacobi_kernel(
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     int keep = (max_sv > 0 && max_sv < p) ? max_sv : p;
     if (max_err >= 0) {
-      const F abs_err = relative ? max_err * s[0] : max_err;
+      const F abs_err = relative ? max_err * ld_sc1(s) : max_err;
       F acc = 0;
       int nerr = 0;
       for (int k = p - 1; k >= 0; --k) {
-        acc += s[k] * s[k];
+        const F sk = ld_sc1(s + k);
+        acc += sk * sk;
         if (sqrt(acc) > abs_err) ++nerr;
       }
       if (nerr < keep) keep = nerr;
     }
     F tw2 = 0;
-    for (int k = p - 1; k >= keep; --k) tw2 += s[k] * s[k];
+    for (int k = p - 1; k >= keep; --k) {
+      const F sk = ld_sc1(s + k);
+      tw2 += sk * sk;
+    }
     if (keep_out) keep_out[b + batch0] = keep;
     if (tw2_out) tw2_out[b + batch0] = tw2;
   }
@@ -447,7 +519,7 @@ template <typename F>
 static long long svd_work_elems(int p, int q) {
   const long long pp = p + (p & 1);
   const long long f_as_c = (pp * (long long)sizeof(F) + sizeof(typename Cx<F>::type) - 1) / sizeof(typename Cx<F>::type);
-  return pp * q + pp * pp + f_as_c + 8;
+  return pp * q + pp * pp + 2 * f_as_c + 8;
 }
 
 template <typename F, int E>
