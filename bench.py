@@ -147,6 +147,49 @@ def vqe_leg(tc, torch, dist, args, rank, world, dev):
     }
 
 
+def mps_leg(tc, torch, args):
+    """BASELINE config 5: MPSCircuit n=64, chi=128 (max_singular_values), one TEBD sweep = 63 adjacent random
+    SU(4) gates left to right on a chi-saturated random MPS, complex64.  Latency-bound: per bond
+    one QR (centre move), one bond GEMM, one gate mix, one Jacobi-SVD launch; no host synchronisation."""
+    import numpy as np
+    from scipy.stats import unitary_group
+
+    n, chi = args.mps_qubits, args.mps_chi
+    rng = np.random.default_rng(64)
+    dims = [min(2 ** i, 2 ** (n - i), chi) for i in range(n + 1)]
+    tensors = [((rng.normal(size=(dims[i], 2, dims[i + 1])) + 1j * rng.normal(size=(dims[i], 2, dims[i + 1])))
+                / np.sqrt(2 * dims[i])).astype(np.complex64) for i in range(n)]
+    gates = [tc.gates.Gate(unitary_group.rvs(4, random_state=5000 + i).reshape(2, 2, 2, 2).astype(np.complex64))
+             for i in range(n - 1)]
+    t0 = time.perf_counter()
+    m = tc.MPSCircuit(n, tensors=tensors, split=tc.cons.split_rules(max_singular_values=chi))
+
+    def sweep():
+        for i in range(n - 1):
+            m.apply(gates[i], i, i + 1)
+
+    sweep()
+    m.position(0)
+    torch.cuda.synchronize()
+    staging = time.perf_counter() - t0
+    times = []
+    for _ in range(max(1, args.mps_sweeps)):
+        t0 = time.perf_counter()
+        sweep()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        m.position(0)
+    torch.cuda.synchronize()
+    t = sum(times) / len(times)
+    return {
+        "workload": f"MPSCircuit n={n} chi={chi} TEBD sweep of {n - 1} adjacent random SU(4) gates, complex64 "
+                    f"(SURVEY 8d config 5)",
+        "sweeps_per_s": 1.0 / t, "us_per_bond": t / (n - 1) * 1e6, "sweeps": len(times),
+        "max_bond": int(max(m.get_bond_dimensions())), "staging_s": round(staging, 3),
+        "fidelity_estimate": float(m._fidelity),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,6 +205,9 @@ def main():
     ap.add_argument("--vqe-batch", type=int, default=32, help="VQE leg: global vmap batch (sharded over ranks)")
     ap.add_argument("--vqe-steps", type=int, default=2)
     ap.add_argument("--vqe-microbatch", type=int, default=8, help="samples per vvag call (bounds HBM use)")
+    ap.add_argument("--mps-qubits", type=int, default=64, help="MPS TEBD leg (config 5): qubits; 0 disables the leg")
+    ap.add_argument("--mps-chi", type=int, default=128)
+    ap.add_argument("--mps-sweeps", type=int, default=2)
     ap.add_argument("--contractor", default="greedy",
                     help="greedy/auto: cost model picks the contraction order; plain: state-vector plan; cut: cut contraction")
     ap.add_argument("--lowbits", type=int, default=None)
@@ -325,6 +371,8 @@ def main():
         }
         if vqe is not None:
             out["vqe_step"] = vqe
+        if args.mps_qubits > 0 and world == 1:
+            out["mps_tebd"] = mps_leg(tc, torch, args)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_qubits, d, seed=n)
         print(json.dumps(out))
