@@ -62,7 +62,10 @@ class DistributedContractor:
         inputs = [[ren[e] for e in s] for s in inputs]
         output = [ren[e] for e in output]
         size_dict = {ren[e]: d for e, d in size_dict.items()}
-        tree = tn.ContractionTree.from_path(inputs, output, size_dict)
+        # reference default max_repeats = 128 (experimental.py:936-942): trials of the random-greedy search
+        opts = cotengra_options or {}
+        tree = tn.ContractionTree.from_path(inputs, output, size_dict, trials=int(opts.get("max_repeats", 128)),
+                                            seed=int(opts.get("seed", 0)))
         tree.slice_to(DistributedContractor._target_size(cotengra_options))
         return tree.to_data()
 

@@ -55,10 +55,13 @@ def get_tn_info(nodes: Sequence[Node]):
 
 
 def greedy_path(inputs: Sequence[Sequence[int]], output: Sequence[int], size_dict: Dict[int, int],
-                memory_limit=None) -> List[Tuple[int, int]]:
+                memory_limit=None, temperature: float = 0.0, alpha: float = 1.0, nbranch: int = 8,
+                rng=None) -> List[Tuple[int, int]]:
     """Greedy pairwise path in opt_einsum's linear format (reference cons.py:937-950: each (a, b)
     indexes the current list, both are removed, the result is appended).  Candidate pairs share an
-    index; score = size(out) - size(a) - size(b); leftovers are outer-multiplied smallest first."""
+    index; score = size(out) - alpha (size(a) + size(b)); leftovers are outer-multiplied smallest
+    first.  ``temperature > 0`` turns it into opt_einsum's random-greedy: the next pair is drawn from
+    the ``nbranch`` best candidates with Boltzmann weights (relative temperature)."""
     out_set = frozenset(output)
     live: Dict[int, frozenset] = {i: frozenset(s) for i, s in enumerate(inputs)}
     uses: Dict[int, int] = {}
@@ -93,21 +96,47 @@ def greedy_path(inputs: Sequence[Sequence[int]], output: Sequence[int], size_dic
                     seen.add(j)
                     a, b = (i, j) if i < j else (j, i)
                     m = merged(a, b)
-                    heapq.heappush(heap, (sz(m) - sz(live[a]) - sz(live[b]), a, b))
+                    heapq.heappush(heap, (sz(m) - alpha * (sz(live[a]) + sz(live[b])), a, b))
 
     for i in list(live):
         push(i)
     nxt = len(live)
     ssa: List[Tuple[int, int]] = []
+    def pop_valid():
+        while heap:
+            cost, a, b = heapq.heappop(heap)
+            if a not in live or b not in live:
+                continue
+            m = merged(a, b)
+            real = sz(m) - alpha * (sz(live[a]) + sz(live[b]))
+            if real != cost:
+                heapq.heappush(heap, (real, a, b))
+                continue
+            return cost, a, b, m
+        return None
+
     while heap:
-        cost, a, b = heapq.heappop(heap)
-        if a not in live or b not in live:
-            continue
-        m = merged(a, b)
-        real = sz(m) - sz(live[a]) - sz(live[b])
-        if real != cost:
-            heapq.heappush(heap, (real, a, b))
-            continue
+        first = pop_valid()
+        if first is None:
+            break
+        if temperature > 0 and rng is not None:
+            cands = [first]
+            while len(cands) < nbranch:
+                c = pop_valid()
+                if c is None:
+                    break
+                if any(c[1] == o[1] and c[2] == o[2] for o in cands):
+                    continue
+                cands.append(c)
+            c0 = cands[0][0]
+            scale = temperature * max(1.0, abs(c0))
+            w = np.array([np.exp(-(c[0] - c0) / scale) for c in cands])
+            k = int(rng.choice(len(cands), p=w / w.sum()))
+            for i, c in enumerate(cands):
+                if i != k:
+                    heapq.heappush(heap, (c[0], c[1], c[2]))
+            first = cands[k]
+        cost, a, b, m = first
         for x in (a, b):
             for e in live[x]:
                 uses[e] -= 1
@@ -140,6 +169,58 @@ def greedy_path(inputs: Sequence[Sequence[int]], output: Sequence[int], size_dic
     return path
 
 
+def _path_stats(inputs, output, size_dict, path):
+    """(max intermediate size, total flops) of a linear-format path, without building a tree object."""
+    cur = [frozenset(x) for x in inputs]
+    uses: Dict[int, int] = {}
+    for x in cur:
+        for e in x:
+            uses[e] = uses.get(e, 0) + 1
+    out = frozenset(output)
+    mx, flops = 1, 0
+    for a, b in path:
+        sb = cur.pop(b)
+        sa = cur.pop(a)
+        keep = frozenset(e for e in sa | sb if uses[e] - (e in sa) - (e in sb) > 0 or e in out)
+        for e in sa:
+            uses[e] -= 1
+        for e in sb:
+            uses[e] -= 1
+        for e in keep:
+            uses[e] += 1
+        f = 1
+        for e in sa | sb:
+            f *= size_dict[e]
+        k = 1
+        for e in keep:
+            k *= size_dict[e]
+        flops += 8 * f
+        mx = max(mx, k)
+        cur.append(keep)
+    return mx, flops
+
+
+def search_path(inputs, output, size_dict, trials: int = 0, seed: int = 0, target_size: Optional[int] = None):
+    """Best of the deterministic greedy path and ``trials`` random-greedy paths (opt_einsum's
+    ``RandomGreedy``; the reference reaches it through cotengra's ``greedy`` method,
+    cons.py:1168-1190).  Objective: (oversize w.r.t. ``target_size``, flops)."""
+    def key(st):
+        mx, fl = st
+        return (max(mx, target_size) if target_size else 0, fl, mx)
+
+    best = greedy_path(inputs, output, size_dict)
+    best_key = key(_path_stats(inputs, output, size_dict, best))
+    rng = np.random.default_rng(seed)
+    for _ in range(trials):
+        t = float(10 ** rng.uniform(-2.5, 0.0))
+        al = float(rng.choice([0.0, 0.5, 1.0, 1.0, 1.5]))
+        p = greedy_path(inputs, output, size_dict, temperature=t, alpha=al, rng=rng)
+        k = key(_path_stats(inputs, output, size_dict, p))
+        if k < best_key:
+            best, best_key = p, k
+    return best
+
+
 @dataclass
 class ContractionTree:
     """Path + slicing of one network (the part of cotengra's ``ContractionTree`` the reference uses:
@@ -153,11 +234,13 @@ class ContractionTree:
     sliced_inds: List[int] = field(default_factory=list)
 
     @classmethod
-    def from_path(cls, inputs, output, size_dict, path=None):
+    def from_path(cls, inputs, output, size_dict, path=None, trials: int = 0, seed: int = 0):
         inputs = [list(s) for s in inputs]
         if path is None:
-            path = greedy_path(inputs, output, size_dict)
-        return cls(inputs, list(output), dict(size_dict), [tuple(p) for p in path])
+            path = search_path(inputs, output, size_dict, trials=trials, seed=seed)
+        t = cls(inputs, list(output), dict(size_dict), [tuple(p) for p in path])
+        t.trials, t.seed = trials, seed
+        return t
 
     # -- cost model ---------------------------------------------------------------------------------
     def _walk(self):
@@ -219,13 +302,119 @@ class ContractionTree:
         sl = set(self.sliced_inds)
         inputs = [[e for e in s if e not in sl] for s in self.inputs]
         output = [e for e in self.output if e not in sl]
-        self.path = greedy_path(inputs, output, self.size_dict)
+        trials = getattr(self, "trials", 0)
+        self.path = search_path(inputs, output, self.size_dict, trials=max(0, trials // 8),
+                                seed=getattr(self, "seed", 0) + len(sl), target_size=getattr(self, "_target", None))
+
+    def _steps_full(self, path):
+        """(union of operand indices, output indices) of every step of ``path`` on the UNSLICED network."""
+        cur = [frozenset(x) for x in self.inputs]
+        uses: Dict[int, int] = {}
+        for x in cur:
+            for e in x:
+                uses[e] = uses.get(e, 0) + 1
+        out = frozenset(self.output)
+        steps = []
+        for a, b in path:
+            sb = cur.pop(b)
+            sa = cur.pop(a)
+            keep = frozenset(e for e in sa | sb if uses[e] - (e in sa) - (e in sb) > 0 or e in out)
+            for e in sa:
+                uses[e] -= 1
+            for e in sb:
+                uses[e] -= 1
+            for e in keep:
+                uses[e] += 1
+            steps.append((sa | sb, keep))
+            cur.append(keep)
+        return steps
+
+    def _slice_fixed(self, path, target_size: int, max_slices: int, max_candidates: int):
+        """Greedy slicing of a FIXED tree: repeatedly remove the index (of the oversize intermediates)
+        that leaves the smallest (total oversize, flops).  Returns (sliced indices, total flops over all
+        slices) or None if ``max_slices`` is exceeded."""
+        lw = {e: float(np.log2(d)) for e, d in self.size_dict.items()}
+        steps = self._steps_full(path)
+        out = set(self.output)
+        ltarget = float(np.log2(target_size)) + 1e-9
+        sliced: List[int] = []
+        sl: set = set()
+
+        def stats(extra):
+            over, flops, mx = 0.0, 0.0, 0.0
+            for un, keep in steps:
+                lk = sum(lw[e] for e in keep if e not in sl and e != extra)
+                lf = sum(lw[e] for e in un if e not in sl and e != extra)
+                flops += 2.0 ** lf
+                if lk > ltarget:
+                    over += 2.0 ** lk
+                if lk > mx:
+                    mx = lk
+            return over, flops, mx
+
+        nsl = 1
+        while True:
+            over, flops, mx = stats(None)
+            if mx <= ltarget:
+                return sliced, 8.0 * flops * nsl
+            score: Dict[int, float] = {}
+            for _, keep in steps:
+                lk = sum(lw[e] for e in keep if e not in sl)
+                if lk > ltarget:
+                    for e in keep:
+                        if e not in sl and e not in out:
+                            score[e] = score.get(e, 0.0) + 2.0 ** lk
+            if not score:
+                return None
+            cands = sorted(score, key=lambda e: (-score[e], e))[:max_candidates]
+            best = None
+            for e in cands:
+                o, f, _ = stats(e)
+                key = (o, f)
+                if best is None or key < best[0]:
+                    best = (key, e)
+            e = best[1]
+            nsl *= self.size_dict[e]
+            if nsl > max_slices:
+                return None
+            sliced.append(e)
+            sl.add(e)
 
     def slice_to(self, target_size: int, max_slices: int = 1 << 16, max_candidates: int = 12) -> "ContractionTree":
-        """Slice until the largest intermediate fits ``target_size`` elements.  Each step tries the
-        (non-output) indices of the largest intermediates, re-paths the sliced network for every
-        candidate and keeps the one with the smallest (max_size, total flops)."""
+        """Slice until the largest intermediate fits ``target_size`` elements (the role of cotengra's
+        ``slicing_opts`` in reference experimental.py:936-953).  Every candidate path — the current one
+        plus ``self.trials`` random-greedy paths — is sliced as a fixed tree; the (path, sliced indices)
+        with the smallest total flops over all slices wins.  If no trial fits within ``max_slices`` the
+        slice-and-re-path search (slower) is used."""
+        if self.max_size() <= target_size:
+            return self
+        trials = getattr(self, "trials", 0)
+        rng = np.random.default_rng(getattr(self, "seed", 0) + 7919)
+        best = None
+        paths = [list(self.path)]
+        for t in range(trials + 1):
+            if t > 0:
+                temp = float(10 ** rng.uniform(-2.5, 0.0))
+                al = float(rng.choice([0.0, 0.5, 1.0, 1.0, 1.5]))
+                path = greedy_path(self.inputs, self.output, self.size_dict, temperature=temp, alpha=al, rng=rng)
+            else:
+                path = paths[0]
+            r = self._slice_fixed(path, target_size, max_slices, max_candidates)
+            if r is None:
+                continue
+            if best is None or r[1] < best[0]:
+                best = (r[1], path, r[0])
+        if best is not None:
+            self.path = [tuple(x) for x in best[1]]
+            self.sliced_inds = list(best[2])
+            return self
+        return self._slice_repath(target_size, max_slices, max_candidates)
+
+    def _slice_repath(self, target_size: int, max_slices: int = 1 << 16, max_candidates: int = 12) -> "ContractionTree":
+        """Each step tries the (non-output) indices of the largest intermediates, re-paths the sliced
+        network for every candidate and keeps the one with the smallest (oversize, total flops)."""
         out = set(self.output)
+        self._target = target_size
         while self.max_size() > target_size:
             if self.nslices * 2 > max_slices:
                 raise RuntimeError(
