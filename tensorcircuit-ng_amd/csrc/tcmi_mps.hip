@@ -2,13 +2,14 @@
 // reference tensorcircuit/mps_base.py:33-175 (FiniteMPS.apply_two_site_gate), mpscircuit.py:35-64
 // (split_tensor) and the tensornetwork FiniteMPS.position sweeps.
 //
-//  * svd_jacobi_kernel  — thin SVD of a row-major p x q matrix (p <= q) by one-sided (Hestenes) Jacobi
+//  * svd_block_kernel  — thin SVD of a row-major p x q matrix (p <= q) by one-sided (Hestenes) Jacobi
 //    in *row* form: unitary rotations from the left make the rows of W = Y a mutually orthogonal,
-//    W = Sigma Vh, U = Y^H.  Rows are contiguous, so every wave streams its two rows coalesced.  One wave
-//    owns one row pair per round (round-robin tournament, p-1 rounds per sweep); the rounds of one
-//    matrix are separated by a device-scope barrier between the (few) workgroups of that matrix, so a
-//    whole SVD is ONE launch.  Sorting, truncation count (reference jax_backend.py:62-112) and the
-//    optional absorption of S into U or Vh are fused into the tail of the same kernel.
+//    W = Sigma Vh, U = Y^H.  Rows are contiguous (coalesced).  Blocked: a workgroup keeps two blocks of B
+//    rows of [W | Y] in LDS, one wave per row pair, B pair-rounds per block pairing between
+//    __syncthreads; the block pairings form a round-robin tournament whose rounds are separated by a
+//    device-scope barrier between the (few) workgroups of that matrix, so a whole SVD is ONE launch.
+//    Sorting, truncation count (reference jax_backend.py:62-112) and the optional absorption of S into
+//    U or Vh are fused into the tail of the same kernel.
 //  * qr_householder_kernel — Householder QR (complete isometry even for rank-deficient input, which
 //    |0..0> product states are), one workgroup per matrix.
 //  * mps_gate_mix_kernel — theta[l,a',b',r] = sum_ab G[a',b',a,b] T[l,a,b,r] (the 4x4 gate on the two
@@ -20,8 +21,6 @@
 
 namespace tcmi {
 
-constexpr int SVD_WAVES = 8;
-constexpr int SVD_THREADS = SVD_WAVES * 64;
 constexpr int SVD_CTL_WORDS = 64;     // [0] barrier counter, [1] error flag, [2..] rotations per sweep
 constexpr int SVD_MAX_SWEEPS = 60;
 constexpr unsigned SPIN_LIMIT = 1u << 21;
@@ -121,36 +120,80 @@ __device__ __forceinline__ void jacobi_rotation(F al, F be, F gr, F gi, F& c, F&
   pi = (F)(gi / ag);
 }
 
-template <typename F, int E>
-__global__ __launch_bounds__(SVD_THREADS) void svd_jacobi_kernel(
-    const typename Cx<F>::type* __restrict__ a, long long a_stride, typename Cx<F>::type* __restrict__ u,
-    F* s, typename Cx<F>::type* __restrict__ vh, int* __restrict__ keep_out,
-    F* __restrict__ tw2_out, int p, int q, int kmax, typename Cx<F>::type* work, long long work_stride,
-    unsigned* ctl_base, int max_sweeps, int max_sv, F max_err, int relative, int absorb, int batch0) {
+// One pair of LDS-resident rows [W row (q) | Y row (P2)], stride ld: measure <x, y> on the W part, rotate
+// the whole row.  Returns 1 if a rotation was applied (wave-uniform).
+template <typename F>
+__device__ __forceinline__ int rotate_pair(typename Cx<F>::type* x, typename Cx<F>::type* y, int q, int ld, int lane,
+                                           F tol2) {
   using Ct = typename Cx<F>::type;
+  F al = 0, be = 0, gr = 0, gi = 0;
+  for (int c = lane; c < q; c += 64) {
+    const Ct xv = x[c], yv = y[c];
+    al = fma_<F>(xv.x, xv.x, fma_<F>(xv.y, xv.y, al));
+    be = fma_<F>(yv.x, yv.x, fma_<F>(yv.y, yv.y, be));
+    gr = fma_<F>(xv.x, yv.x, fma_<F>(xv.y, yv.y, gr));   // gamma += x conj(y)
+    gi = fma_<F>(xv.y, yv.x, fma_<F>(-xv.x, yv.y, gi));
+  }
+  al = wave_sum<F>(al);
+  be = wave_sum<F>(be);
+  gr = wave_sum<F>(gr);
+  gi = wave_sum<F>(gi);
+  const F g2 = gr * gr + gi * gi;
+  if (!(g2 > tol2 * al * be && g2 > 0)) return 0;
+  F c, sn, pr, pi;  // y~ = e^{i phi} y;  x' = c x - s y~;  y' = s x + c y~
+  jacobi_rotation<F>(al, be, gr, gi, c, sn, pr, pi);
+  for (int col = lane; col < ld; col += 64) {
+    const Ct xv = x[col], yv = y[col];
+    const F tr = pr * yv.x - pi * yv.y, ti = pr * yv.y + pi * yv.x;
+    Ct nx, ny;
+    nx.x = c * xv.x - sn * tr;
+    nx.y = c * xv.y - sn * ti;
+    ny.x = sn * xv.x + c * tr;
+    ny.y = sn * xv.y + c * ti;
+    x[col] = nx;
+    y[col] = ny;
+  }
+  return 1;
+}
+
+// Blocked one-sided Jacobi.  The P2 (padded) rows are cut into NB = P2 / B blocks of B rows; workgroup g
+// holds TWO blocks (2B rows of [W | Y]) in LDS and owns B waves.  A sweep is a round-robin tournament
+// of the blocks (NB - 1 global rounds); inside a round the B x B cross pairs are done in B LDS rounds
+// separated only by __syncthreads (round 0 also does the intra-block pairs), then the rows go back to
+// global memory (write-through) and the workgroups of the matrix meet at one grid barrier.  p - 1 pair
+// rounds per sweep as in the flat scheme, but only NB - 1 of them cross the chip.
+template <typename F, int B>
+__global__ __launch_bounds__(64 * B) void svd_block_kernel(
+    const typename Cx<F>::type* __restrict__ a, long long a_stride, typename Cx<F>::type* __restrict__ u, F* s,
+    typename Cx<F>::type* __restrict__ vh, int* __restrict__ keep_out, F* __restrict__ tw2_out, int p, int q,
+    int kmax, int P2, typename Cx<F>::type* work, long long work_stride, unsigned* ctl_base, int max_sweeps,
+    int max_sv, F max_err, int relative, int absorb, int batch0) {
+  using Ct = typename Cx<F>::type;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  Ct* L = reinterpret_cast<Ct*>(smem_raw);  // no static LDS in this kernel: the dynamic base stays 16-B aligned
+  constexpr int T = 64 * B;
   const int b = blockIdx.y;
-  const int pp = p + (p & 1);
-  const int npairs = pp >> 1;
-  const unsigned nwg = gridDim.x;
+  const int ld = q + P2;
+  const int NB = P2 / B;
+  const unsigned nwg = gridDim.x;  // NB / 2
+  const int g = blockIdx.x;
   a += (long long)(b + batch0) * a_stride;
   u += (long long)(b + batch0) * p * kmax;
   s += (long long)(b + batch0) * p;
   vh += (long long)(b + batch0) * (long long)kmax * q;
   Ct* W = work + (long long)b * work_stride;
-  Ct* Y = W + (long long)pp * q;
-  F* sq = reinterpret_cast<F*>(Y + (long long)pp * pp);  // [pp] squared singular values, [pp] 1/|Y_i|
-  F* yn = sq + pp;
+  Ct* Y = W + (long long)P2 * q;
+  F* sq = reinterpret_cast<F*>(Y + (long long)P2 * P2);  // [P2] squared singular values, [P2] 1/|Y_i|
+  F* yn = sq + P2;
   unsigned* ctl = ctl_base + (long long)b * SVD_CTL_WORDS;
   unsigned epoch = 0;
-  __shared__ unsigned s_dead;
+  unsigned& s_dead = *reinterpret_cast<unsigned*>(smem_raw + 2ll * B * ld * (long long)sizeof(Ct));
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int gw = blockIdx.x * SVD_WAVES + wave;
-  const bool active = gw < npairs;
 
-  {  // W = a (zero pad row), Y = I
-    const long long t0 = (long long)blockIdx.x * SVD_THREADS + threadIdx.x, step = (long long)nwg * SVD_THREADS;
-    const long long nW = (long long)pp * q, nA = (long long)p * q, nY = (long long)pp * pp;
+  {  // W = a (zero pad rows), Y = I
+    const long long t0 = (long long)g * T + threadIdx.x, step = (long long)nwg * T;
+    const long long nW = (long long)P2 * q, nA = (long long)p * q, nY = (long long)P2 * P2;
     Ct zero;
     zero.x = 0;
     zero.y = 0;
@@ -161,161 +204,124 @@ __global__ __launch_bounds__(SVD_THREADS) void svd_jacobi_kernel(
     }
     for (long long i = t0; i < nY; i += step) {
       Ct v = zero;
-      if (i / pp == i % pp) v.x = 1;
+      if (i / P2 == i % P2) v.x = 1;
       st_sc1(Y + i, v);
     }
   }
   if (!grid_barrier(ctl, nwg, epoch, &s_dead)) return;
 
   const F tol2 = Eps<F>::v * Eps<F>::v * (F)q;
-  const int M = pp - 1;
+  const int M = NB - 1;
   if (max_sweeps > SVD_MAX_SWEEPS) max_sweeps = SVD_MAX_SWEEPS;
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
-    for (int r = 0; r < M; ++r) {
-      if (active) {
-        int i = gw == 0 ? r : (r + gw) % M;
-        int j = gw == 0 ? M : (r - gw + M) % M;
-        if (i > j) {
-          const int t = i;
-          i = j;
-          j = t;
-        }
-        Ct* wi = W + (long long)i * q;
-        Ct* wj = W + (long long)j * q;
-        Ct* yi_ = Y + (long long)i * pp;
-        Ct* yj_ = Y + (long long)j * pp;
-        Ct x[E], y[E], yx[E], yy[E];
-        F al = 0, be = 0, gr = 0, gi = 0;
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-          const int c = lane + 64 * e;
-          x[e].x = x[e].y = y[e].x = y[e].y = 0;
-          yx[e] = x[e];
-          yy[e] = x[e];
-          if (c < q) {
-            x[e] = ld_sc1(wi + c);
-            y[e] = ld_sc1(wj + c);
-          }
-          if (c < pp) {  // issued with the W loads: one memory round trip per round
-            yx[e] = ld_sc1(yi_ + c);
-            yy[e] = ld_sc1(yj_ + c);
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-          al = fma_<F>(x[e].x, x[e].x, fma_<F>(x[e].y, x[e].y, al));
-          be = fma_<F>(y[e].x, y[e].x, fma_<F>(y[e].y, y[e].y, be));
-          // gamma += x conj(y)
-          gr = fma_<F>(x[e].x, y[e].x, fma_<F>(x[e].y, y[e].y, gr));
-          gi = fma_<F>(x[e].y, y[e].x, fma_<F>(-x[e].x, y[e].y, gi));
-        }
-        al = wave_sum<F>(al);
-        be = wave_sum<F>(be);
-        gr = wave_sum<F>(gr);
-        gi = wave_sum<F>(gi);
-        const F g2 = gr * gr + gi * gi;
-        if (g2 > tol2 * al * be && g2 > 0) {
-          F c, sn, pr, pi;  // y~ = e^{i phi} y;  x' = c x - s y~;  y' = s x + c y~
-          jacobi_rotation<F>(al, be, gr, gi, c, sn, pr, pi);
-#pragma unroll
-          for (int e = 0; e < E; ++e) {
-            const int col = lane + 64 * e;
-            if (col < q) {
-              const F tr = pr * y[e].x - pi * y[e].y, ti = pr * y[e].y + pi * y[e].x;
-              Ct nx, ny;
-              nx.x = c * x[e].x - sn * tr;
-              nx.y = c * x[e].y - sn * ti;
-              ny.x = sn * x[e].x + c * tr;
-              ny.y = sn * x[e].y + c * ti;
-              st_sc1(wi + col, nx);
-              st_sc1(wj + col, ny);
-            }
-            if (col < pp) {
-              const F tr = pr * yy[e].x - pi * yy[e].y, ti = pr * yy[e].y + pi * yy[e].x;
-              Ct nx, ny;
-              nx.x = c * yx[e].x - sn * tr;
-              nx.y = c * yx[e].y - sn * ti;
-              ny.x = sn * yx[e].x + c * tr;
-              ny.y = sn * yx[e].y + c * ti;
-              st_sc1(yi_ + col, nx);
-              st_sc1(yj_ + col, ny);
-            }
-          }
-          if (lane == 0) __hip_atomic_fetch_add((gu32*)&ctl[2 + sweep], 1u, TCMI_RLX);
+    int rot = 0;
+    for (int R = 0; R < M; ++R) {
+      const int bA = g == 0 ? R : (R + g) % M;
+      const int bB = g == 0 ? M : (R - g + M) % M;
+      // rows of the two blocks -> LDS (wave w carries local rows w and B + w)
+      for (int h = 0; h < 2; ++h) {
+        const int lr = h * B + wave;
+        const long long gr = (long long)(h == 0 ? bA : bB) * B + wave;
+        Ct* dst = L + (long long)lr * ld;
+        const Ct* wsrc = W + gr * q;
+        const Ct* ysrc = Y + gr * P2;
+        for (int c = lane; c < q; c += 64) dst[c] = ld_sc1(wsrc + c);
+        for (int c = lane; c < P2; c += 64) dst[q + c] = ld_sc1(ysrc + c);
+      }
+      __syncthreads();
+      if (R == 0 && B > 1) {  // intra-block pairs, both blocks at once (B/2 waves each)
+        constexpr int H = B > 1 ? B / 2 : 1;
+        const int blk = wave / H, idx = wave % H, Mb = B - 1;
+        for (int k = 0; k < Mb; ++k) {
+          const int i = idx == 0 ? k : (k + idx) % Mb;
+          const int j = idx == 0 ? Mb : (k - idx + Mb) % Mb;
+          rot += rotate_pair<F>(L + (long long)(blk * B + i) * ld, L + (long long)(blk * B + j) * ld, q, ld, lane, tol2);
+          __syncthreads();
         }
       }
+      for (int k = 0; k < B; ++k) {
+        rot += rotate_pair<F>(L + (long long)wave * ld, L + (long long)(B + (wave + k) % B) * ld, q, ld, lane, tol2);
+        __syncthreads();
+      }
+      for (int h = 0; h < 2; ++h) {
+        const int lr = h * B + wave;
+        const long long gr = (long long)(h == 0 ? bA : bB) * B + wave;
+        const Ct* src = L + (long long)lr * ld;
+        Ct* wdst = W + gr * q;
+        Ct* ydst = Y + gr * P2;
+        for (int c = lane; c < q; c += 64) st_sc1(wdst + c, src[c]);
+        for (int c = lane; c < P2; c += 64) st_sc1(ydst + c, src[q + c]);
+      }
+      if (R == M - 1 && rot > 0 && lane == 0) __hip_atomic_fetch_add((gu32*)&ctl[2 + sweep], 1u, TCMI_RLX);
       if (!grid_barrier(ctl, nwg, epoch, &s_dead)) return;
     }
     if (__hip_atomic_load((gu32*)&ctl[2 + sweep], TCMI_RLX) == 0) break;
   }
 
+  const int gw = g * B + wave;  // P2 / 2 waves in total, two rows each
   // squared row norms of W and Y: sigma_i = |W_i| / |Y_i| (W = Y a holds to rounding whatever the
   // accumulated non-unitarity of the rotations; dividing it out removes the common drift)
-  if (active) {
-    for (int k = 0; k < 2; ++k) {
-      const int row = 2 * gw + k;
+  for (int k = 0; k < 2; ++k) {
+    const int row = 2 * gw + k;
+    const Ct* w = W + (long long)row * q;
+    const Ct* yr = Y + (long long)row * P2;
+    F acc = 0, accy = 0;
+    for (int c = lane; c < q; c += 64) {
+      const Ct v = ld_sc1(w + c);
+      acc = fma_<F>(v.x, v.x, fma_<F>(v.y, v.y, acc));
+    }
+    for (int c = lane; c < P2; c += 64) {
+      const Ct v = ld_sc1(yr + c);
+      accy = fma_<F>(v.x, v.x, fma_<F>(v.y, v.y, accy));
+    }
+    acc = wave_sum<F>(acc);
+    accy = wave_sum<F>(accy);
+    if (lane == 0) {
+      st_sc1(sq + row, acc / accy);
+      st_sc1(yn + row, 1 / sqrt(accy));
+    }
+  }
+  if (!grid_barrier(ctl, nwg, epoch, &s_dead)) return;
+
+  // rank (descending, ties by row index; the zero pad rows sort last), then write s / vh / u sorted
+  for (int k = 0; k < 2; ++k) {
+    const int row = 2 * gw + k;
+    if (row >= p) continue;
+    const F v = ld_sc1(sq + row);
+    const F iy = ld_sc1(yn + row);
+    int cnt = 0;
+    for (int j = lane; j < P2; j += 64) {
+      const F o = ld_sc1(sq + j);
+      cnt += (o > v || (o == v && j < row)) ? 1 : 0;
+    }
+    const int rank = wave_sum<int>(cnt);
+    const F sig = sqrt(v);
+    if (lane == 0) st_sc1(s + rank, sig);
+    if (rank < kmax) {
+      // W_row = |Y_row| sigma vh: vh = W_row iy / sigma
+      const F inv = sig > 0 ? iy / sig : 0;
+      const F sv = absorb == 2 ? iy : inv;
+      const F su = (absorb == 1 ? sig : (F)1) * iy;
       const Ct* w = W + (long long)row * q;
-      const Ct* yr = Y + (long long)row * pp;
-      F acc = 0, accy = 0;
+      Ct* o = vh + (long long)rank * q;
       for (int c = lane; c < q; c += 64) {
-        const Ct v = ld_sc1(w + c);
-        acc = fma_<F>(v.x, v.x, fma_<F>(v.y, v.y, acc));
+        Ct t = ld_sc1(w + c);
+        t.x *= sv;
+        t.y *= sv;
+        o[c] = t;
       }
-      for (int c = lane; c < pp; c += 64) {
-        const Ct v = ld_sc1(yr + c);
-        accy = fma_<F>(v.x, v.x, fma_<F>(v.y, v.y, accy));
-      }
-      acc = wave_sum<F>(acc);
-      accy = wave_sum<F>(accy);
-      if (lane == 0) {
-        st_sc1(sq + row, acc / accy);
-        st_sc1(yn + row, 1 / sqrt(accy));
-      }
-    }
-  }
-  if (!grid_barrier(ctl, nwg, epoch, &s_dead)) return;
-
-  // rank (descending, ties by row index), then write s / vh / u in sorted order
-  if (active) {
-    for (int k = 0; k < 2; ++k) {
-      const int row = 2 * gw + k;
-      if (row >= p) continue;
-      const F v = ld_sc1(sq + row);
-      const F iy = ld_sc1(yn + row);
-      int cnt = 0;
-      for (int j = lane; j < pp; j += 64) {
-        const F o = ld_sc1(sq + j);
-        cnt += (o > v || (o == v && j < row)) ? 1 : 0;
-      }
-      const int rank = wave_sum<int>(cnt);
-      const F sig = sqrt(v);
-      if (lane == 0) st_sc1(s + rank, sig);
-      if (rank < kmax) {
-        // W_row = |Y_row| sigma vh: vh = W_row iy / sigma
-        const F inv = sig > 0 ? iy / sig : 0;
-        const F sv = absorb == 2 ? iy : inv;
-        const F su = (absorb == 1 ? sig : (F)1) * iy;
-        const Ct* w = W + (long long)row * q;
-        Ct* o = vh + (long long)rank * q;
-        for (int c = lane; c < q; c += 64) {
-          Ct t = ld_sc1(w + c);
-          t.x *= sv;
-          t.y *= sv;
-          o[c] = t;
-        }
-        const Ct* yr = Y + (long long)row * pp;
-        for (int c = lane; c < p; c += 64) {
-          Ct t = ld_sc1(yr + c);
-          t.x *= su;
-          t.y *= -su;
-          u[(long long)c * kmax + rank] = t;
-        }
+      const Ct* yr = Y + (long long)row * P2;
+      for (int c = lane; c < p; c += 64) {
+        Ct t = ld_sc1(yr + c);
+        t.x *= su;
+        t.y *= -su;
+        u[(long long)c * kmax + rank] = t;
       }
     }
   }
   if (!grid_barrier(ctl, nwg, epoch, &s_dead)) return;
 
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (g == 0 && threadIdx.x == 0) {
     int keep = (max_sv > 0 && max_sv < p) ? max_sv : p;
     if (max_err >= 0) {
       const F abs_err = relative ? max_err * ld_sc1(s) : max_err;
@@ -477,6 +483,221 @@ __global__ __launch_bounds__(QR_THREADS) void qr_householder_kernel(const typena
   }
 }
 
+// Register-resident Householder QR for m <= 256, n <= 64 * C (C = 2 for complex64, 1 for complex128):
+// thread (ty = tid / 64, tx = tid % 64) owns rows ty + 16 t (t < 16) of columns tx + 64 c.  The matrix never
+// leaves the register file during the factorisation: per step only the reflector goes through LDS
+// (norm -> u -> per-column dot -> update, 4 __syncthreads), no global traffic inside the loop.  The
+// reflectors are parked in the workspace and re-read (one 2 KB column per step) to form Q the same way.
+template <typename F, int C>
+__global__ __launch_bounds__(QR_THREADS) void qr_reg_kernel(const typename Cx<F>::type* __restrict__ a,
+                                                            typename Cx<F>::type* __restrict__ qout,
+                                                            typename Cx<F>::type* __restrict__ rout, int m, int n,
+                                                            typename Cx<F>::type* work, long long work_stride) {
+  using Ct = typename Cx<F>::type;
+  constexpr int TR = 16;  // rows per thread
+  const int K = m < n ? m : n;
+  const int b = blockIdx.x;
+  a += (long long)b * m * n;
+  qout += (long long)b * m * K;
+  rout += (long long)b * K * n;
+  Ct* U = work + (long long)b * work_stride;  // [K][m] reflectors (row k = u_k, zero above k)
+  __shared__ Ct ubuf[256];
+  __shared__ Ct wbuf[QR_TY][QR_TX * C];
+  __shared__ F red[QR_TY];
+  __shared__ F s_scale[256];
+  __shared__ Ct s_diag[256];
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+  Ct A[TR][C];
+#pragma unroll
+  for (int t = 0; t < TR; ++t)
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int i = ty + 16 * t, j = tx + 64 * c;
+      Ct v;
+      v.x = v.y = 0;
+      if (i < m && j < n) v = a[(long long)i * n + j];
+      A[t][c] = v;
+    }
+  for (int k = 0; k < K; ++k) {
+    const int kc = k >> 6, kx = k & 63;
+    // column k below the diagonal -> ubuf, partial norms
+    if (tx == kx) {
+      F part = 0;
+#pragma unroll
+      for (int t = 0; t < TR; ++t)
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+          if (c == kc) {
+            const int i = ty + 16 * t;
+            Ct v = A[t][c];
+            if (i < k || i >= m) v.x = v.y = 0;
+            if (i < 256) ubuf[i] = v;
+            part = fma_<F>(v.x, v.x, fma_<F>(v.y, v.y, part));
+          }
+      red[ty] = part;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      F nx2 = 0;
+#pragma unroll
+      for (int w = 0; w < QR_TY; ++w) nx2 += red[w];
+      const Ct alpha = ubuf[k];
+      const F nx = sqrt(nx2);
+      Ct d;
+      d.x = d.y = 0;
+      F sc = 0;
+      if (nx > 0) {
+        const F aa = sqrt(alpha.x * alpha.x + alpha.y * alpha.y);
+        const F pr = aa > 0 ? alpha.x / aa : (F)1, pi = aa > 0 ? alpha.y / aa : (F)0;
+        d.x = -pr * nx;
+        d.y = -pi * nx;
+        Ct u0;
+        u0.x = alpha.x - d.x;
+        u0.y = alpha.y - d.y;
+        ubuf[k] = u0;
+        sc = 1 / (nx * (nx + aa));  // 2 / |u|^2
+      }
+      s_diag[k] = d;
+      s_scale[k] = sc;
+    }
+    __syncthreads();
+    const F scale = s_scale[k];
+    // park the reflector (coalesced row of U)
+    if (tid < m) U[(long long)k * m + tid] = ubuf[tid];
+    if (scale > 0) {
+      // w_j = scale * sum_i conj(u_i) A[i][j] for the columns j > k this thread touches
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        F ar = 0, ai = 0;
+#pragma unroll
+        for (int t = 0; t < TR; ++t) {
+          const int i = ty + 16 * t;
+          if (i >= k && i < m) {
+            const Ct uu = ubuf[i], xx = A[t][c];
+            ar = fma_<F>(uu.x, xx.x, fma_<F>(uu.y, xx.y, ar));
+            ai = fma_<F>(uu.x, xx.y, fma_<F>(-uu.y, xx.x, ai));
+          }
+        }
+        wbuf[ty][tx + 64 * c].x = ar;
+        wbuf[ty][tx + 64 * c].y = ai;
+      }
+      __syncthreads();
+      if (ty < C) {  // wave ty reduces column chunk ty
+        F sr = 0, si = 0;
+#pragma unroll
+        for (int t = 0; t < QR_TY; ++t) {
+          sr += wbuf[t][tx + 64 * ty].x;
+          si += wbuf[t][tx + 64 * ty].y;
+        }
+        wbuf[0][tx + 64 * ty].x = sr * scale;
+        wbuf[0][tx + 64 * ty].y = si * scale;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const int j = tx + 64 * c;
+        if (j > k) {
+          const Ct w = wbuf[0][j];
+#pragma unroll
+          for (int t = 0; t < TR; ++t) {
+            const int i = ty + 16 * t;
+            if (i >= k && i < m) {
+              const Ct uu = ubuf[i];
+              A[t][c].x -= uu.x * w.x - uu.y * w.y;
+              A[t][c].y -= uu.x * w.y + uu.y * w.x;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // R: upper triangle from the registers, diagonal from s_diag
+#pragma unroll
+  for (int t = 0; t < TR; ++t)
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int i = ty + 16 * t, j = tx + 64 * c;
+      if (i < K && j < n) {
+        Ct v;
+        v.x = v.y = 0;
+        if (j == i)
+          v = s_diag[i];
+        else if (j > i)
+          v = A[t][c];
+        rout[(long long)i * n + j] = v;
+      }
+    }
+  // Q = H_0 ... H_{K-1} [I] in the same register layout (columns < K)
+#pragma unroll
+  for (int t = 0; t < TR; ++t)
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int i = ty + 16 * t, j = tx + 64 * c;
+      A[t][c].x = (i == j && j < K) ? 1 : 0;
+      A[t][c].y = 0;
+    }
+  __syncthreads();
+  for (int k = K - 1; k >= 0; --k) {
+    const F scale = s_scale[k];
+    if (scale > 0) {
+      if (tid < m) ubuf[tid] = U[(long long)k * m + tid];
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        F ar = 0, ai = 0;
+#pragma unroll
+        for (int t = 0; t < TR; ++t) {
+          const int i = ty + 16 * t;
+          if (i >= k && i < m) {
+            const Ct uu = ubuf[i], xx = A[t][c];
+            ar = fma_<F>(uu.x, xx.x, fma_<F>(uu.y, xx.y, ar));
+            ai = fma_<F>(uu.x, xx.y, fma_<F>(-uu.y, xx.x, ai));
+          }
+        }
+        wbuf[ty][tx + 64 * c].x = ar;
+        wbuf[ty][tx + 64 * c].y = ai;
+      }
+      __syncthreads();
+      if (ty < C) {
+        F sr = 0, si = 0;
+#pragma unroll
+        for (int t = 0; t < QR_TY; ++t) {
+          sr += wbuf[t][tx + 64 * ty].x;
+          si += wbuf[t][tx + 64 * ty].y;
+        }
+        wbuf[0][tx + 64 * ty].x = sr * scale;
+        wbuf[0][tx + 64 * ty].y = si * scale;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const int j = tx + 64 * c;
+        if (j >= k && j < K) {
+          const Ct w = wbuf[0][j];
+#pragma unroll
+          for (int t = 0; t < TR; ++t) {
+            const int i = ty + 16 * t;
+            if (i >= k && i < m) {
+              const Ct uu = ubuf[i];
+              A[t][c].x -= uu.x * w.x - uu.y * w.y;
+              A[t][c].y -= uu.x * w.y + uu.y * w.x;
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TR; ++t)
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int i = ty + 16 * t, j = tx + 64 * c;
+      if (i < m && j < K) qout[(long long)i * K + j] = A[t][c];
+    }
+}
+
 // theta[l,a',b',r] = sum_{a,b} G[a',b',a,b] T[l,a,b,r]
 template <typename F>
 __global__ void mps_gate_mix_kernel(const typename Cx<F>::type* __restrict__ T,
@@ -515,43 +736,67 @@ __global__ void mps_gate_mix_kernel(const typename Cx<F>::type* __restrict__ T,
   }
 }
 
+// Block geometry: B rows per block (= waves per workgroup), P2 = p rounded up to a multiple of 2B.
+// 2B rows of [W | Y] must fit the 64 KiB of LDS a workgroup gets without opting in to more.
+struct SvdGeom {
+  int B, P2, wgs;
+  long long lds_bytes, work_elems;
+};
+
 template <typename F>
-static long long svd_work_elems(int p, int q) {
-  const long long pp = p + (p & 1);
-  const long long f_as_c = (pp * (long long)sizeof(F) + sizeof(typename Cx<F>::type) - 1) / sizeof(typename Cx<F>::type);
-  return pp * q + pp * pp + 2 * f_as_c + 8;
+static SvdGeom svd_geom(int p, int q) {
+  using Ct = typename Cx<F>::type;
+  int B = p >= 16 ? 8 : p >= 8 ? 4 : p >= 4 ? 2 : 1;
+  SvdGeom gm;
+  for (;; B /= 2) {
+    const int P2 = (p + 2 * B - 1) / (2 * B) * (2 * B);
+    gm.B = B;
+    gm.P2 = P2;
+    gm.lds_bytes = 2ll * B * (q + P2) * (long long)sizeof(Ct);
+    if (gm.lds_bytes <= 65536 || B == 1) break;
+  }
+  gm.wgs = gm.P2 / gm.B / 2;
+  const long long f_as_c = ((long long)gm.P2 * sizeof(F) + sizeof(Ct) - 1) / sizeof(Ct);
+  gm.work_elems = (long long)gm.P2 * q + (long long)gm.P2 * gm.P2 + 2 * f_as_c + 8;
+  return gm;
 }
 
-template <typename F, int E>
-static void launch_svd(dim3 grid, hipStream_t st, const void* a, long long a_stride, void* u, void* s, void* vh,
-                       int* keep, void* tw2, int p, int q, int kmax, void* work, long long wstride, unsigned* ctl,
+template <typename F, int B>
+static void launch_svd(const SvdGeom& gm, int nb, hipStream_t st, const void* a, long long a_stride, void* u, void* s,
+                       void* vh, int* keep, void* tw2, int p, int q, int kmax, void* work, unsigned* ctl,
                        int max_sweeps, int max_sv, double max_err, int relative, int absorb, int batch0) {
   using Ct = typename Cx<F>::type;
-  hipLaunchKernelGGL((svd_jacobi_kernel<F, E>), grid, dim3(SVD_THREADS), 0, st, reinterpret_cast<const Ct*>(a),
-                     a_stride, reinterpret_cast<Ct*>(u), reinterpret_cast<F*>(s), reinterpret_cast<Ct*>(vh), keep,
-                     reinterpret_cast<F*>(tw2), p, q, kmax, reinterpret_cast<Ct*>(work), wstride, ctl, max_sweeps,
-                     max_sv, (F)max_err, relative, absorb, batch0);
+  hipLaunchKernelGGL((svd_block_kernel<F, B>), dim3(gm.wgs, nb, 1), dim3(64 * B), (size_t)gm.lds_bytes + 16, st,
+                     reinterpret_cast<const Ct*>(a), a_stride, reinterpret_cast<Ct*>(u), reinterpret_cast<F*>(s),
+                     reinterpret_cast<Ct*>(vh), keep, reinterpret_cast<F*>(tw2), p, q, kmax, gm.P2,
+                     reinterpret_cast<Ct*>(work), gm.work_elems, ctl, max_sweeps, max_sv, (F)max_err, relative,
+                     absorb, batch0);
 }
 
 template <typename F>
-static int dispatch_svd(int E, dim3 grid, hipStream_t st, const void* a, long long a_stride, void* u, void* s,
-                        void* vh, int* keep, void* tw2, int p, int q, int kmax, void* work, long long wstride,
-                        unsigned* ctl, int max_sweeps, int max_sv, double max_err, int relative, int absorb,
-                        int batch0) {
-#define TCMI_SVD_CASE(EE)                                                                                          \
-  case EE:                                                                                                         \
-    launch_svd<F, EE>(grid, st, a, a_stride, u, s, vh, keep, tw2, p, q, kmax, work, wstride, ctl, max_sweeps,      \
-                      max_sv, max_err, relative, absorb, batch0);                                                  \
+static int dispatch_svd(const SvdGeom& gm, int nb, hipStream_t st, const void* a, long long a_stride, void* u,
+                        void* s, void* vh, int* keep, void* tw2, int p, int q, int kmax, void* work, unsigned* ctl,
+                        int max_sweeps, int max_sv, double max_err, int relative, int absorb, int batch0) {
+#define TCMI_SVD_CASE(BB)                                                                                         \
+  case BB:                                                                                                        \
+    launch_svd<F, BB>(gm, nb, st, a, a_stride, u, s, vh, keep, tw2, p, q, kmax, work, ctl, max_sweeps, max_sv,    \
+                      max_err, relative, absorb, batch0);                                                         \
     return 0;
-  switch (E) {
+  switch (gm.B) {
     TCMI_SVD_CASE(1)
     TCMI_SVD_CASE(2)
     TCMI_SVD_CASE(4)
     TCMI_SVD_CASE(8)
-    TCMI_SVD_CASE(16)
   }
 #undef TCMI_SVD_CASE
   return -1;
+}
+
+static int svd_chunk(int wgs, int batch) {
+  int chunk = 256 / wgs;  // co-resident workgroups per launch (one per CU is always resident)
+  if (chunk < 1) chunk = 1;
+  if (chunk > batch) chunk = batch;
+  return chunk;
 }
 
 }  // namespace tcmi
@@ -562,13 +807,16 @@ extern "C" {
 
 long long tcmi_svd_work_bytes(int m, int n, int batch, int dtype) {
   if (m < 1 || n < m || batch < 1) return -1;
-  const int wgs = ((m + 1) / 2 + tcmi::SVD_WAVES - 1) / tcmi::SVD_WAVES;
-  int chunk = 256 / wgs;
-  if (chunk < 1) chunk = 1;
-  if (chunk > batch) chunk = batch;
-  const long long ctl = (long long)chunk * tcmi::SVD_CTL_WORDS * 4;
-  if (dtype == TCMI_C64) return ctl + chunk * tcmi::svd_work_elems<float>(m, n) * 8;
-  if (dtype == TCMI_C128) return ctl + chunk * tcmi::svd_work_elems<double>(m, n) * 16;
+  if (dtype == TCMI_C64) {
+    const tcmi::SvdGeom gm = tcmi::svd_geom<float>(m, n);
+    const int chunk = tcmi::svd_chunk(gm.wgs, batch);
+    return (long long)chunk * tcmi::SVD_CTL_WORDS * 4 + chunk * gm.work_elems * 8;
+  }
+  if (dtype == TCMI_C128) {
+    const tcmi::SvdGeom gm = tcmi::svd_geom<double>(m, n);
+    const int chunk = tcmi::svd_chunk(gm.wgs, batch);
+    return (long long)chunk * tcmi::SVD_CTL_WORDS * 4 + chunk * gm.work_elems * 16;
+  }
   return -1;
 }
 
@@ -579,36 +827,28 @@ int tcmi_svd_trunc_batched(const void* a, void* u, void* s, void* vh, int* keep_
   if (!a || !u || !s || !vh || !work || m < 1 || n < m || kmax < 1 || kmax > m || batch < 1 || absorb < 0 ||
       absorb > 2)
     return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_svd_trunc_batched: bad argument (needs m <= n, 1 <= kmax <= m)");
-  if (n > 1024) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_svd_trunc_batched: n > 1024 not supported");
+  if (dtype != TCMI_C64 && dtype != TCMI_C128)
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_svd_trunc_batched: bad dtype");
   const long long need = tcmi_svd_work_bytes(m, n, batch, dtype);
   if (need < 0 || work_bytes < need) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_svd_trunc_batched: workspace too small");
   if (max_sweeps <= 0) max_sweeps = 30;
-  const int pp = m + (m & 1);
-  const int wgs = (pp / 2 + tcmi::SVD_WAVES - 1) / tcmi::SVD_WAVES;
-  int chunk = 256 / wgs;  // co-resident workgroups per launch (one per CU is always resident)
-  if (chunk < 1) chunk = 1;
-  if (chunk > batch) chunk = batch;
-  const int span = n > pp ? n : pp;
-  int E = 1;
-  while (64 * E < span) E *= 2;
+  const tcmi::SvdGeom gm = dtype == TCMI_C64 ? tcmi::svd_geom<float>(m, n) : tcmi::svd_geom<double>(m, n);
+  if (gm.lds_bytes > 65536)
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_svd_trunc_batched: matrix too wide for the LDS-resident kernel");
+  const int chunk = tcmi::svd_chunk(gm.wgs, batch);
   unsigned* ctl = reinterpret_cast<unsigned*>(work);
   char* wbase = reinterpret_cast<char*>(work) + (long long)chunk * tcmi::SVD_CTL_WORDS * 4;
   for (int b0 = 0; b0 < batch; b0 += chunk) {
     const int nb = batch - b0 < chunk ? batch - b0 : chunk;
     hipError_t e = hipMemsetAsync(ctl, 0, (size_t)chunk * tcmi::SVD_CTL_WORDS * 4, st);
     if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));
-    dim3 grid(wgs, nb, 1);
     int rc;
     if (dtype == TCMI_C64)
-      rc = tcmi::dispatch_svd<float>(E, grid, st, a, (long long)m * n, u, s, vh, keep_out, tw2_out, m, n, kmax, wbase,
-                                     tcmi::svd_work_elems<float>(m, n), ctl, max_sweeps, max_singular_values,
-                                     max_truncation_err, relative, absorb, b0);
-    else if (dtype == TCMI_C128)
-      rc = tcmi::dispatch_svd<double>(E, grid, st, a, (long long)m * n, u, s, vh, keep_out, tw2_out, m, n, kmax,
-                                      wbase, tcmi::svd_work_elems<double>(m, n), ctl, max_sweeps,
-                                      max_singular_values, max_truncation_err, relative, absorb, b0);
+      rc = tcmi::dispatch_svd<float>(gm, nb, st, a, (long long)m * n, u, s, vh, keep_out, tw2_out, m, n, kmax, wbase,
+                                     ctl, max_sweeps, max_singular_values, max_truncation_err, relative, absorb, b0);
     else
-      return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_svd_trunc_batched: bad dtype");
+      rc = tcmi::dispatch_svd<double>(gm, nb, st, a, (long long)m * n, u, s, vh, keep_out, tw2_out, m, n, kmax, wbase,
+                                      ctl, max_sweeps, max_singular_values, max_truncation_err, relative, absorb, b0);
     if (rc != 0) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_svd_trunc_batched: unsupported size");
     e = hipGetLastError();
     if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));
@@ -619,7 +859,7 @@ int tcmi_svd_trunc_batched(const void* a, void* u, void* s, void* vh, int* keep_
 long long tcmi_qr_work_bytes(int m, int n, int batch, int dtype) {
   if (m < 1 || n < 1 || batch < 1) return -1;
   const long long K = m < n ? m : n;
-  const long long elems = (long long)m * n + 2 * K + 8;
+  const long long elems = (long long)m * n + 2 * K + 8;  // >= K * m, the reflector store of the register kernel
   if (dtype == TCMI_C64) return batch * elems * 8;
   if (dtype == TCMI_C128) return batch * elems * 16;
   return -1;
@@ -634,7 +874,15 @@ int tcmi_qr_batched(const void* a, void* q, void* r, int m, int n, int batch, vo
   if (need < 0 || work_bytes < need) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_qr_batched: workspace too small");
   const long long K = m < n ? m : n;
   const long long stride = (long long)m * n + 2 * K + 8;
-  if (dtype == TCMI_C64)
+  if (dtype == TCMI_C64 && m <= 256 && n <= 128)
+    hipLaunchKernelGGL((tcmi::qr_reg_kernel<float, 2>), dim3(batch), dim3(tcmi::QR_THREADS), 0, st,
+                       reinterpret_cast<const float2*>(a), reinterpret_cast<float2*>(q),
+                       reinterpret_cast<float2*>(r), m, n, reinterpret_cast<float2*>(work), stride);
+  else if (dtype == TCMI_C128 && m <= 256 && n <= 64)
+    hipLaunchKernelGGL((tcmi::qr_reg_kernel<double, 1>), dim3(batch), dim3(tcmi::QR_THREADS), 0, st,
+                       reinterpret_cast<const double2*>(a), reinterpret_cast<double2*>(q),
+                       reinterpret_cast<double2*>(r), m, n, reinterpret_cast<double2*>(work), stride);
+  else if (dtype == TCMI_C64)
     hipLaunchKernelGGL(tcmi::qr_householder_kernel<float>, dim3(batch), dim3(tcmi::QR_THREADS), 0, st,
                        reinterpret_cast<const float2*>(a), reinterpret_cast<float2*>(q),
                        reinterpret_cast<float2*>(r), m, n, reinterpret_cast<float2*>(work), stride);

@@ -180,6 +180,45 @@ def test_distributed_contractor_single_process(tcd, tmp_path):
     np.testing.assert_allclose(tc.backend.numpy(dc2.value(params)), tc.backend.numpy(v), atol=tol)
 
 
+def test_config4_grid_rqc_amplitude_sliced():
+    """SURVEY 8d config 4 at a size the oracle finishes in seconds: 4x5 grid, depth-8 brickwork of
+    Haar-random two-qubit gates (reference gates.py:852-863), amplitude <0..0|C|0..0> through
+    DistributedContractor with real slicing; equals the dense oracle and the unsliced contraction."""
+    import tcmi as tc
+    from oracle import dense, gates as OG
+
+    rows, cols, depth = 4, 5, 8
+    n = rows * cols
+    q = lambda r, c: r * cols + c
+    pairs = []
+    for d in range(depth):
+        pat = d % 4
+        if pat in (0, 1):
+            pairs += [(q(r, c), q(r, c + 1)) for r in range(rows) for c in range(pat, cols - 1, 2)]
+        else:
+            pairs += [(q(r, c), q(r + 1, c)) for r in range(pat - 2, rows - 1, 2) for c in range(cols)]
+    mats = [OG.random_two_qubit_gate(900 + k) for k in range(len(pairs))]
+    psi = dense.run(n, [(m, [a, b]) for m, (a, b) in zip(mats, pairs)])
+    bits = "0" * n
+    want = dense.amplitude(psi, n, [0] * n)
+
+    def nodes_fn(_):
+        c = tc.Circuit(n)
+        for m, (a, b) in zip(mats, pairs):
+            c.any(a, b, unitary=m.reshape(2, 2, 2, 2))
+        return c.amplitude_before(bits)
+
+    opts = {"slicing_opts": {"target_size": 2**9}, "max_repeats": 16}
+    dc = tc.experimental.DistributedContractor(nodes_fn, None, opts)
+    assert dc.tree.nslices >= 2 and dc.tree.max_size() <= 2**9
+    v = complex(dc.value(None, op=lambda x: x))
+    assert abs(v - want) < 2e-5 * max(abs(want), 1e-3), (v, want)
+    dc1 = tc.experimental.DistributedContractor(nodes_fn, None, {"slicing_opts": {"target_size": 2**30}, "max_repeats": 4})
+    assert dc1.tree.nslices == 1
+    v1 = complex(dc1.value(None, op=lambda x: x))
+    assert abs(v - v1) < 2e-5 * max(abs(want), 1e-3)
+
+
 # ---- cut contraction (half-circuit batches + one MFMA GEMM) ---------------------------------------
 @pytest.mark.parametrize("n,d", [(16, 3), (18, 4), (20, 5)])
 def test_cut_contraction_matches_oracle_and_statevector(n, d):
