@@ -105,19 +105,79 @@ __device__ __forceinline__ bool grid_barrier(unsigned* ctl, unsigned nwg, unsign
   return *s_dead == 0;
 }
 
-// Rotation (c, s e^{i phi}) annihilating <x, y> = gr + i gi between rows of squared norms al, be; computed
-// in double so that c^2 + s^2 = 1 to 1e-16 before rounding (no systematic norm drift over ~10^3 rotations).
+// Rotation annihilating <x, y> = gr + i gi between rows of squared norms al, be (all wave-uniform).
+// c^2 + s^2 = 1 only to rounding; the accumulated drift is common to W and Y and is divided out at the
+// end (sigma_i = |W_i| / |Y_i|).
 template <typename F>
 __device__ __forceinline__ void jacobi_rotation(F al, F be, F gr, F gi, F& c, F& sn, F& pr, F& pi) {
-  const double g2 = (double)gr * gr + (double)gi * gi;
-  const double ag = sqrt(g2);
-  const double zeta = ((double)be - (double)al) / (2 * ag);
-  const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
-  const double cc = 1 / sqrt(1 + t * t);
-  c = (F)cc;
-  sn = (F)(cc * t);
-  pr = (F)(gr / ag);
-  pi = (F)(gi / ag);
+  const F ag = sqrt(gr * gr + gi * gi);
+  const F zeta = (be - al) / (2 * ag);
+  const F t = (zeta >= 0 ? (F)1 : (F)-1) / (fabs(zeta) + sqrt(1 + zeta * zeta));
+  c = 1 / sqrt(1 + t * t);
+  sn = c * t;
+  const F ia = 1 / ag;
+  pr = gr * ia;
+  pi = gi * ia;
+}
+
+// Wave-wide sums of four values, result uniform.  float: DPP butterfly inside each row of 16 lanes,
+// row_bcast15 / row_bcast31 across rows, v_readlane 63 — no LDS crossbar traffic.  double: shuffles.
+template <int CTRL, int RM>
+__device__ __forceinline__ float dpp_add_c(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, RM, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_uniform(float v) {
+  v = dpp_add_c<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add_c<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add_c<0x141, 0xf>(v);  // row_half_mirror
+  v = dpp_add_c<0x140, 0xf>(v);  // row_mirror: every lane of a row holds the row sum
+  v = dpp_add_c<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3
+  v = dpp_add_c<0x143, 0xc>(v);  // row_bcast31 into rows 2 and 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ double wave_sum_uniform(double v) { return wave_sum<double>(v); }
+
+// Row transfer between global memory (write-through / L1-bypassing, see above) and LDS.  Rows whose byte
+// length is a multiple of 16 move as 16-byte units: global -> LDS by the DMA path (global_load_lds, no
+// VGPR round trip), LDS -> global by ds_read_b128 + global_store_dwordx4 sc1.
+typedef __attribute__((address_space(1))) const char gchar;
+typedef __attribute__((address_space(3))) char lchar;
+
+template <typename Ct>
+__device__ __forceinline__ void row_in(Ct* dst, const Ct* src, int nelem, int lane) {
+  const int nbytes = nelem * (int)sizeof(Ct);
+  int done = 0;
+  if ((nbytes & 15) == 0) {
+    const char* g = reinterpret_cast<const char*>(src);
+    char* l = reinterpret_cast<char*>(dst);
+    for (; done + 1024 <= nbytes; done += 1024)
+      __builtin_amdgcn_global_load_lds((gchar*)(g + done + lane * 16), (lchar*)(l + done), 16, 0, 16);
+    if (done < nbytes) {
+      if (lane * 16 < nbytes - done)
+        __builtin_amdgcn_global_load_lds((gchar*)(g + done + lane * 16), (lchar*)(l + done), 16, 0, 16);
+      done = nbytes;
+    }
+  }
+  for (int c = done / (int)sizeof(Ct) + lane; c < nelem; c += 64) dst[c] = ld_sc1(src + c);
+}
+
+template <typename Ct>
+__device__ __forceinline__ void row_out(Ct* dst, const Ct* src, int nelem, int lane) {
+  const int nbytes = nelem * (int)sizeof(Ct);
+  int done = 0;
+  if ((nbytes & 15) == 0) {
+    char* g = reinterpret_cast<char*>(dst);
+    const char* l = reinterpret_cast<const char*>(src);
+    for (; done < nbytes; done += 1024) {
+      if (done + lane * 16 < nbytes) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f v = *reinterpret_cast<const v4f*>(l + done + lane * 16);
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(g + done + lane * 16), "v"(v) : "memory");
+      }
+    }
+    done = nbytes;
+  }
+  for (int c = done / (int)sizeof(Ct) + lane; c < nelem; c += 64) st_sc1(dst + c, src[c]);
 }
 
 // One pair of LDS-resident rows [W row (q) | Y row (P2)], stride ld: measure <x, y> on the W part, rotate
@@ -134,10 +194,10 @@ __device__ __forceinline__ int rotate_pair(typename Cx<F>::type* x, typename Cx<
     gr = fma_<F>(xv.x, yv.x, fma_<F>(xv.y, yv.y, gr));   // gamma += x conj(y)
     gi = fma_<F>(xv.y, yv.x, fma_<F>(-xv.x, yv.y, gi));
   }
-  al = wave_sum<F>(al);
-  be = wave_sum<F>(be);
-  gr = wave_sum<F>(gr);
-  gi = wave_sum<F>(gi);
+  al = wave_sum_uniform(al);
+  be = wave_sum_uniform(be);
+  gr = wave_sum_uniform(gr);
+  gi = wave_sum_uniform(gi);
   const F g2 = gr * gr + gi * gi;
   if (!(g2 > tol2 * al * be && g2 > 0)) return 0;
   F c, sn, pr, pi;  // y~ = e^{i phi} y;  x' = c x - s y~;  y' = s x + c y~
@@ -223,11 +283,10 @@ __global__ __launch_bounds__(64 * B) void svd_block_kernel(
         const int lr = h * B + wave;
         const long long gr = (long long)(h == 0 ? bA : bB) * B + wave;
         Ct* dst = L + (long long)lr * ld;
-        const Ct* wsrc = W + gr * q;
-        const Ct* ysrc = Y + gr * P2;
-        for (int c = lane; c < q; c += 64) dst[c] = ld_sc1(wsrc + c);
-        for (int c = lane; c < P2; c += 64) dst[q + c] = ld_sc1(ysrc + c);
+        row_in<Ct>(dst, W + gr * q, q, lane);
+        row_in<Ct>(dst + q, Y + gr * P2, P2, lane);
       }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (R == 0 && B > 1) {  // intra-block pairs, both blocks at once (B/2 waves each)
         constexpr int H = B > 1 ? B / 2 : 1;
@@ -247,10 +306,8 @@ __global__ __launch_bounds__(64 * B) void svd_block_kernel(
         const int lr = h * B + wave;
         const long long gr = (long long)(h == 0 ? bA : bB) * B + wave;
         const Ct* src = L + (long long)lr * ld;
-        Ct* wdst = W + gr * q;
-        Ct* ydst = Y + gr * P2;
-        for (int c = lane; c < q; c += 64) st_sc1(wdst + c, src[c]);
-        for (int c = lane; c < P2; c += 64) st_sc1(ydst + c, src[q + c]);
+        row_out<Ct>(W + gr * q, src, q, lane);
+        row_out<Ct>(Y + gr * P2, src + q, P2, lane);
       }
       if (R == M - 1 && rot > 0 && lane == 0) __hip_atomic_fetch_add((gu32*)&ctl[2 + sweep], 1u, TCMI_RLX);
       if (!grid_barrier(ctl, nwg, epoch, &s_dead)) return;
