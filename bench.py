@@ -316,10 +316,15 @@ def main():
             M, N, K = 2**cc.spec.n_left, 2 ** (n - cc.spec.n_left), cc.K
             flops_per_launch = 8.0 * M * N * K * B          # complex MAC = 8 real flops
             achieved = flops_per_launch / (kern_ms * 1e-3) / 1e12
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r01e_traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath))["hbm_bytes_per_output_element"] * B * M * N
             roof = {
                 "bound": "mfma", "kernel": "tcmi::cgemm_mfma_kernel<true> (cut-contraction join GEMM)",
                 "achieved": achieved, "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s",
-                "frac": achieved / MFMA_F32_PEAK_TFS, "traffic": None,
+                "frac": achieved / MFMA_F32_PEAK_TFS, "traffic": traffic,
+                "traffic_source": "profiles/r01e_traffic.json (rocprofv3 PMC, scaled by output elements)" if traffic else None,
                 "launches_per_step": 1, "avg_launch_us": kern_ms * 1e3,
                 "algorithmic_flops_per_launch": flops_per_launch,
                 "algorithmic_bytes_per_launch": 8.0 * B * (K * (M + N) + M * N),
