@@ -115,6 +115,14 @@ int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, 
                long long strideA, long long strideB, long long strideC, int trans_a, int dtype,
                void* stream);
 
+/* <a|b> = sum conj(a_i) b_i per batch element (states [batch][2^n], stride elements apart), accumulated in
+ * float64 into `copies` replicated {re, im} pairs: out[b * out_batch_stride + 2 * copy + {0,1}] += ...; the
+ * caller zeroes `out` and sums the copies.  Used for <psi|P|psi> of Pauli strings with more than two X/Y
+ * factors (reference circuit.py:833-913 expectation of arbitrary operator lists): P|psi> by
+ * tcmi_apply_pauli_sum, then this. */
+int tcmi_vdot(const void* a, const void* b, double* out, long long state_stride, int batch, int n, int copies,
+              long long out_batch_stride, int dtype, void* stream);
+
 /* ---- MPS / TEBD (K7): reference tensorcircuit/mps_base.py:33-175 (FiniteMPS.apply_two_site_gate),
  * mpscircuit.py:35-64 (split_tensor), backend.svd truncation rule (backends/jax_backend.py:62-112),
  * backend.qr (tensornetwork decompositions). ---- */

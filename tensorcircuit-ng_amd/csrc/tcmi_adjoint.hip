@@ -443,6 +443,33 @@ __global__ void build_adjoint_kernel(const int* __restrict__ ginfo, int nrec, co
   }
 }
 
+// <a|b> per batch element: double accumulation, wave reduction, one f64 atomic pair per wave into one of
+// `copies` replicated accumulators (same-address atomics from every wave would serialise in one L2 channel).
+template <typename F>
+__global__ void vdot_kernel(const typename Cx<F>::type* __restrict__ a, const typename Cx<F>::type* __restrict__ b,
+                            double* __restrict__ out, long long stride, unsigned long long nelem, int copies,
+                            long long out_batch_stride) {
+  using Ct = typename Cx<F>::type;
+  const long long bi = blockIdx.y;
+  a += bi * stride;
+  b += bi * stride;
+  double re = 0, im = 0;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < nelem;
+       i += (unsigned long long)gridDim.x * blockDim.x) {
+    const Ct x = a[i], y = b[i];
+    re += (double)x.x * y.x + (double)x.y * y.y;
+    im += (double)x.x * y.y - (double)x.y * y.x;
+  }
+  re = wave_sum<double>(re);
+  im = wave_sum<double>(im);
+  if ((threadIdx.x & 63) == 0) {
+    const int c = (int)((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % (unsigned)copies);
+    double* o = out + bi * out_batch_stride + 2 * c;
+    atomicAdd(o, re);
+    atomicAdd(o + 1, im);
+  }
+}
+
 }  // namespace tcmi
 
 // ---- C ABI ------------------------------------------------------------------------------------
@@ -537,6 +564,27 @@ int tcmi_apply_pauli_sum(const void* in, void* out, long long state_stride, int 
                        weights_stride);
   else
     return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_apply_pauli_sum: bad dtype");
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));
+  return TCMI_OK;
+}
+
+int tcmi_vdot(const void* a, const void* b, double* out, long long state_stride, int batch, int n, int copies,
+              long long out_batch_stride, int dtype, void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!a || !b || !out || batch < 1 || n < 0 || n > 34 || copies < 1)
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_vdot: bad argument");
+  const unsigned long long nelem = 1ull << n;
+  unsigned gx = (unsigned)((nelem + 1023) / 1024 > 4096 ? 4096 : (nelem + 1023) / 1024);
+  dim3 grid(gx, batch, 1), block(256, 1, 1);
+  if (dtype == TCMI_C64)
+    hipLaunchKernelGGL(tcmi::vdot_kernel<float>, grid, block, 0, st, reinterpret_cast<const float2*>(a),
+                       reinterpret_cast<const float2*>(b), out, state_stride, nelem, copies, out_batch_stride);
+  else if (dtype == TCMI_C128)
+    hipLaunchKernelGGL(tcmi::vdot_kernel<double>, grid, block, 0, st, reinterpret_cast<const double2*>(a),
+                       reinterpret_cast<const double2*>(b), out, state_stride, nelem, copies, out_batch_stride);
+  else
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_vdot: bad dtype");
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));
   return TCMI_OK;

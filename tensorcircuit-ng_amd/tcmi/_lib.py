@@ -66,6 +66,11 @@ _SIGNATURES = {
          ctypes.c_longlong, ctypes.c_int, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong,
          ctypes.c_int, ctypes.c_int, ctypes.c_void_p],
     ),
+    "tcmi_vdot": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,
+         ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p],
+    ),
     "tcmi_svd_work_bytes": (ctypes.c_longlong, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "tcmi_svd_trunc_batched": (
         ctypes.c_int,

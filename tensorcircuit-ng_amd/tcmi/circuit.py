@@ -111,7 +111,20 @@ class Circuit:
         d = 2 ** len(index)
         if m.size != d * d:
             raise ValueError(f"gate tensor of size {m.size} does not act on {len(index)} qubits")
-        self._ops.append(_Op(index, matrix=m.reshape(d, d), name=name))
+        m = m.reshape(d, d)
+        if len(index) > 2:
+            # dense gates on > 2 qubits (toffoli, fredkin, any(...)): exact plan-time synthesis into
+            # <= 2-qubit dense + diagonal gates (tcmi/synth.py); unitary input required
+            if len(index) > 5:
+                raise NotImplementedError("dense gates on more than 5 qubits are not supported on the hip backend")
+            if np.abs(m @ m.conj().T - np.eye(d)).max() > 1e-9:
+                raise NotImplementedError("non-unitary gates on more than 2 qubits are not supported on the hip backend")
+            from .synth import decompose_dense, lower
+
+            for mat, qs in lower(decompose_dense(m, index)):
+                self._ops.append(_Op(tuple(qs), matrix=mat, name=name))
+        else:
+            self._ops.append(_Op(index, matrix=m, name=name))
         self._qir.append({"gate": None, "index": index, "name": name, "parameters": {}})
         self.state_tensor = None
 

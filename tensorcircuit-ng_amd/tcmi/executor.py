@@ -261,7 +261,12 @@ class CompiledMeasure:
             t = P.pauli_term_from_string(ps)
             terms.append(P.PauliTerm(tuple(q + pad for q in t.x), tuple(q + pad for q in t.z)))
         self.cfg = pick_measure_variant(n_exec, dtypestr)
-        self.plan = P.compile_measure_plan(terms, n_exec, self.cfg)
+        # strings with <= 2 X/Y factors go through the fused measurement passes; heavier ones are
+        # evaluated as <psi|(P psi)> (tcmi_apply_pauli_sum + tcmi_vdot), one state-sized temporary each
+        self.light = [k for k, t in enumerate(terms) if len(t.x) <= 2]
+        self.heavy = [k for k, t in enumerate(terms) if len(t.x) > 2]
+        self.all_terms = list(terms)
+        self.plan = P.compile_measure_plan([terms[k] for k in self.light], n_exec, self.cfg)
         self.nterms = len(terms)
         self.code = _lib.TCMI_C64 if dtypestr == "complex64" else _lib.TCMI_C128
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
@@ -269,7 +274,14 @@ class CompiledMeasure:
         self.descs = [_dev(d, self.device) for d in self.plan.descs]
         rdt = torch.float32 if dtypestr == "complex64" else torch.float64
         self.dummy = _dev(np.zeros(8), self.device, rdt)
-        self.phase = _dev(np.array([(1j) ** t.ny for t in terms], dtype=np.complex128), self.device)
+        self.phase = _dev(np.array([(1j) ** terms[k].ny for k in self.light], dtype=np.complex128), self.device)
+        self._heavy_rows = []
+        for k in self.heavy:
+            t = terms[k]
+            xm = sum(1 << (n_exec - 1 - q) for q in t.x)
+            zm = sum(1 << (n_exec - 1 - q) for q in t.z)
+            row = np.array([[xm, zm, t.ny]], dtype=np.int64).astype(np.uint32).view(np.int32)
+            self._heavy_rows.append(_dev(row.reshape(1, 3), self.device))
 
     def run(self, state):
         """state: complex tensor [B, 2^n_exec] (full executor buffer).  Returns complex128 [B, nterms]
@@ -278,7 +290,8 @@ class CompiledMeasure:
 
         B = state.shape[0]
         assert state.shape[1] == 2**self.n_exec and state.is_contiguous()
-        out = torch.zeros(B, ATOMIC_COPIES, 2 * self.nterms, dtype=torch.float64, device=self.device)
+        nl = len(self.light)
+        out = torch.zeros(B, ATOMIC_COPIES, 2 * max(nl, 1), dtype=torch.float64, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         for d in self.descs:
             _lib.check(
@@ -289,7 +302,26 @@ class CompiledMeasure:
                 ),
                 "tcmi_run_pass(measure)",
             )
-        return torch.view_as_complex(out.sum(1).reshape(B, self.nterms, 2)) * self.phase
+        vals_l = torch.view_as_complex(out.sum(1).reshape(B, max(nl, 1), 2))[:, :nl] * self.phase
+        if not self.heavy:
+            return vals_l
+        vals = torch.zeros(B, self.nterms, dtype=torch.complex128, device=self.device)
+        if nl:
+            vals[:, self.light] = vals_l
+        ones = torch.ones(B, 1, dtype=torch.float64, device=self.device)
+        tmp = torch.empty_like(state)
+        for k, row in zip(self.heavy, self._heavy_rows):
+            _lib.check(
+                self._lib.tcmi_apply_pauli_sum(state.data_ptr(), tmp.data_ptr(), state.shape[1], B, self.n_exec,
+                                               row.data_ptr(), 1, ones.data_ptr(), ones.stride(0), self.code, stream),
+                "tcmi_apply_pauli_sum")
+            acc = torch.zeros(B, ATOMIC_COPIES, 2, dtype=torch.float64, device=self.device)
+            _lib.check(
+                self._lib.tcmi_vdot(state.data_ptr(), tmp.data_ptr(), acc.data_ptr(), state.shape[1], B, self.n_exec,
+                                    ATOMIC_COPIES, acc.stride(0), self.code, stream),
+                "tcmi_vdot")
+            vals[:, k] = torch.view_as_complex(acc.sum(1))
+        return vals
 
     def apply_sum(self, state, gvals):
         """Cotangent of the state for L = f(<psi|P_t|psi>): 2 * sum_t Re(g_t) P_t |psi>
@@ -299,7 +331,7 @@ class CompiledMeasure:
         if getattr(self, "_sum_terms", None) is None:
             n = self.n_exec
             rows = []
-            for k, t in enumerate(self.plan.terms):
+            for k, t in enumerate(self.all_terms):
                 xm = 0
                 for q in t.x:
                     xm |= 1 << (n - 1 - q)

@@ -254,3 +254,74 @@ def test_tfim_energy_vs_oracle(tcd, n, d):
     m = G.random_two_qubit_gate(3) + 0.3 * G.random_two_qubit_gate(4)
     got = _np(tc, c.expectation((m, [n - 1, 1])))
     np.testing.assert_allclose(got, dense.expectation(psi, n, (m, [n - 1, 1])), atol=atol)
+
+
+@pytest.mark.parametrize("n", [8, 14])
+def test_three_qubit_dense_gates_and_heavy_pauli_strings(tcd, n):
+    """toffoli / fredkin / any on 3 qubits (reference sgates; tests/test_mpscircuit.py:38-60 uses a 3-qubit
+    dense gate) through the plan-time synthesis, and Pauli strings with more than two X/Y factors
+    (reference tests/test_mpscircuit.py:176-181: x=[0,2], y=[5,3,1], z=[6,4]) through
+    tcmi_apply_pauli_sum + tcmi_vdot; value and gradient against the dense oracle."""
+    from scipy.stats import unitary_group
+
+    tc = tcd
+    u3 = unitary_group.rvs(8, random_state=21)
+    rng = np.random.default_rng(n)
+    theta = rng.uniform(0, 2 * np.pi, size=n)
+
+    def build(c, p, ops=None):
+        for i in range(n):
+            c.h(i)
+            c.rx(i, theta=p[i])
+            if ops is not None:
+                ops += [(G.H, [i]), (G.rx(float(p[i])), [i])]
+        c.toffoli(0, 3, 6)
+        c.fredkin(7, 2, 4)
+        c.any(5, 1, 3, unitary=u3.reshape((2,) * 6))
+        c.cz(0, 7)
+        for i in range(n - 1):
+            c.rzz(i, i + 1, theta=0.3 * (i + 1))
+        if ops is not None:
+            ops += [(G.TOFFOLI, [0, 3, 6]), (G.FREDKIN, [7, 2, 4]), (u3, [5, 1, 3]), (G.CZ, [0, 7])]
+            ops += [(G.rzz(0.3 * (i + 1)), [i, i + 1]) for i in range(n - 1)]
+        return c
+
+    ops = []
+    c = build(tc.Circuit(n), theta, ops)
+    psi = dense.run(n, ops)
+    np.testing.assert_allclose(_np(tc, c.state()), psi, atol=TOL[tc.dtypestr] * 2)
+    ps = [0] * n
+    for q in (0, 2):
+        ps[q] = 1
+    for q in (5, 3, 1):
+        ps[q] = 2
+    for q in (6, 4):
+        ps[q] = 3
+    want = dense.pauli_string_expectation(psi, n, ps)
+    got = c.expectation_ps(x=[0, 2], y=[5, 3, 1], z=[6, 4])
+    np.testing.assert_allclose(_np(tc, got), want, atol=TOL[tc.dtypestr] * 10)
+    # mixed light + heavy strings in one fused evaluation, with gradient
+    def f(p):
+        cc = build(tc.Circuit(n), p)
+        e = cc.expectation_ps(x=[0, 2], y=[5, 3, 1], z=[6, 4]) + 0.5 * cc.expectation_ps(z=[0, 1]) \
+            - 0.25 * cc.expectation_ps(x=[1, 2, 3, 4])
+        return tc.backend.real(e)
+
+    v, g = tc.backend.value_and_grad(f)(tc.backend.convert_to_tensor(theta.astype(np.float64 if tc.rdtypestr == "float64" else np.float32)))
+    def f_ref(p):
+        o = []
+        build(tc.Circuit(n), p, o)
+        s = dense.run(n, o)
+        ps2 = [0] * n; ps2[0] = ps2[1] = 3
+        ps3 = [0] * n
+        for q in (1, 2, 3, 4):
+            ps3[q] = 1
+        return np.real(dense.pauli_string_expectation(s, n, ps) + 0.5 * dense.pauli_string_expectation(s, n, ps2)
+                       - 0.25 * dense.pauli_string_expectation(s, n, ps3))
+    np.testing.assert_allclose(_np(tc, v), f_ref(theta), atol=TOL[tc.dtypestr] * 10)
+    k, eps = 3, 1e-5
+    tp, tm = theta.copy(), theta.copy()
+    tp[k] += eps
+    tm[k] -= eps
+    fd = (f_ref(tp) - f_ref(tm)) / (2 * eps)
+    np.testing.assert_allclose(_np(tc, g)[k], fd, atol=2e-4 if tc.dtypestr == "complex64" else 1e-7)

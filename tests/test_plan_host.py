@@ -251,3 +251,44 @@ def test_cut_spec_and_selector_gates():
         want = dense.apply_gate(want, 5, g.matrix(pvec), list(g.qubits))
     np.testing.assert_allclose(got, want, atol=1e-12)
     assert cut.make_cut([P.GateRec((0, 5, 9), c0=np.eye(8))], n, 5, 0) is None
+
+
+def test_dense_three_qubit_gates_are_synthesised_exactly():
+    """toffoli / fredkin / any(3 qubits) (reference gates.py sgates, basecircuit.py:183-371) are rewritten
+    on the host into <= 2-qubit dense + diagonal gates (tcmi/synth.py); the compiled plan run through
+    the numpy emulator of the descriptor format equals the dense oracle."""
+    import tcmi as tc
+    from scipy.stats import unitary_group
+    from tcmi import plan as P, synth
+    from oracle import dense, gates as OG, plan_emulator as E
+
+    for u in (OG.TOFFOLI, OG.FREDKIN, unitary_group.rvs(8, random_state=3), unitary_group.rvs(16, random_state=4)):
+        k = int(np.log2(u.shape[0]))
+        qs = list(range(5, 5 + k))
+        assert np.abs(synth.expand(synth.decompose_dense(u, qs), qs) - u).max() < 1e-13
+        low = synth.lower(synth.decompose_dense(u, qs))
+        assert all(len(q) <= 2 for _, q in low)
+        assert np.abs(synth.expand(low, qs) - u).max() < 1e-12
+    n = 8
+    u3 = unitary_group.rvs(8, random_state=11)
+    c = tc.Circuit(n)
+    ops = []
+    for i in range(n):
+        c.h(i)
+        ops.append((OG.H, [i]))
+    c.rx(1, theta=0.4)
+    ops.append((OG.rx(0.4), [1]))
+    c.toffoli(0, 3, 6)
+    ops.append((OG.TOFFOLI, [0, 3, 6]))
+    c.fredkin(7, 2, 4)
+    ops.append((OG.FREDKIN, [7, 2, 4]))
+    c.any(5, 1, 3, unitary=u3.reshape((2,) * 6))
+    ops.append((u3, [5, 1, 3]))
+    c.cz(0, 7)
+    ops.append((OG.CZ, [0, 7]))
+    recs = c._gate_records()
+    assert all(r.is_diag or len(r.qubits) <= 2 for r in recs)
+    cfg = P.PlanConfig(R=2, LT=6, lowbits=3, vec=1)
+    plan = P.compile_plan(recs, n, cfg, nparams=len(c._params))
+    out = E.run_plan(plan, np.array([float(p) for p in c._params]))
+    np.testing.assert_allclose(out, dense.run(n, ops), atol=1e-12)
