@@ -138,11 +138,18 @@ def test_structure_cache_key():
 
 
 def test_unsupported_gates_raise():
+    """Dense gates on 3-5 qubits are synthesised (tcmi/synth.py); what stays unsupported fails loudly."""
     c = tc.Circuit(14)
     c.toffoli(0, 1, 2)
     _, cfg = pick_variant(14, "complex64")
+    P.compile_plan(c._gate_records(), 14, cfg)
     with pytest.raises(NotImplementedError):
-        P.compile_plan(c._gate_records(), 14, cfg)
+        c.any(0, 1, 2, unitary=np.arange(64).reshape((2,) * 6))          # non-unitary 3-qubit tensor
+    with pytest.raises(NotImplementedError):
+        c.any(0, 1, 2, 3, 4, 5, unitary=np.eye(64)[::-1].reshape((2,) * 12))  # dense on 6 qubits
+    raw = P.GateRec((0, 1, 2), c0=np.eye(8)[::-1].copy(), name="raw3")
+    with pytest.raises(NotImplementedError):
+        P.compile_plan([raw], 14, cfg)
 
 
 def test_small_circuits_are_padded():
