@@ -7,7 +7,7 @@
 //     C = A . B   (complex GEMM)                 = axes free_A + free_B, no output permute
 // This file holds the two device kernels: a bit-permutation copy for tensors whose axes all have
 // dimension 2 (every circuit tensor network) and a complex GEMM on the f32 MFMA pipe
-// (v_mfma_f32_32x32x2_f32: exact f32 FMA, 4 real MFMAs per complex k-pair).
+// (v_mfma_f32_32x32x2_f32: exact f32 FMA, 3 real MFMAs per complex k-pair, Gauss's 3-product form).
 
 #include "tcmi_dev.h"
 
@@ -33,55 +33,88 @@ __global__ void permute_bits_kernel(const C* __restrict__ in, C* __restrict__ ou
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // C[M x N] = A[M x K] . B[K x N], row-major interleaved complex64, one 64x64 tile per workgroup,
-// 4 waves x (32x32 MFMA tile), K step 8.  LDS holds planar (re / im) operand tiles, k-major, padded
-// by one float per row (bank = (k + i) mod 32: conflict-free fragment reads).
+// 4 waves x (32x32 MFMA tile), K step 8.  LDS holds planar (re / im) operand tiles, k-major.
+//  * 3 real products per complex product (Gauss): P1 = Ar Br, P2 = Ai Bi, P3 = (Ar + Ai)(Br + Bi);
+//    C_re = P1 - P2, C_im = P3 - P1 - P2 — 3 MFMAs per k-pair instead of 4 on the f32 matrix pipe,
+//    which is what bounds this kernel; the two operand sums are VALU adds on the fragments.
+//  * row pitch 68 floats: 8-byte aligned rows for the vector (ds_write_b64) loaders of k-major
+//    operands, and 2*68 = 8 (mod 32) makes the transposing loader of a row-major A hit 32 distinct
+//    banks per half-wave (r01c profile: 25 % of LDS cycles were bank conflicts with pitch 65).
 #define TCMI_BM 64
 #define TCMI_BN 64
 #define TCMI_BK 8
-#define TCMI_LDP (TCMI_BM + 1)
+#define TCMI_LDP 68
 
 template <bool TRANS_A>
 __global__ __launch_bounds__(256) void cgemm_mfma_kernel(const float2* __restrict__ A,
                                                           const float2* __restrict__ B,
                                                           float2* __restrict__ C, int M, int N, int K,
                                                           long long sA, long long sB, long long sC) {
-  __shared__ float As_re[TCMI_BK][TCMI_LDP], As_im[TCMI_BK][TCMI_LDP];
-  __shared__ float Bs_re[TCMI_BK][TCMI_LDP], Bs_im[TCMI_BK][TCMI_LDP];
+  __shared__ __attribute__((aligned(16))) float As_re[TCMI_BK][TCMI_LDP], As_im[TCMI_BK][TCMI_LDP];
+  __shared__ __attribute__((aligned(16))) float Bs_re[TCMI_BK][TCMI_LDP], Bs_im[TCMI_BK][TCMI_LDP];
   A += (long long)blockIdx.z * sA;
   B += (long long)blockIdx.z * sB;
   C += (long long)blockIdx.z * sC;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const long long m0 = (long long)blockIdx.y * TCMI_BM, n0 = (long long)blockIdx.x * TCMI_BN;
-  f32x16 cre = {0}, cim = {0};
+  f32x16 p1 = {0}, p2 = {0}, p3 = {0};
   // loader coordinates: A tile 64 rows x 8 k (two complex per thread along k);
   //                     B tile 8 k x 64 cols (two complex per thread along n)
   // TRANS_A: A is stored [K][M] (k-major), loaded like B (coalesced along m)
   const int ai = TRANS_A ? (tid & 31) * 2 : tid >> 2, ak = TRANS_A ? tid >> 5 : (tid & 3) * 2;
   const int bk = tid >> 5, bj = (tid & 31) * 2;
+  // 16-byte global loads need even leading dimensions (and 16-byte aligned batch bases)
+  const bool vecA = TRANS_A ? ((M & 1) == 0 && (sA & 1) == 0) : ((K & 1) == 0 && (sA & 1) == 0);
+  const bool vecB = (N & 1) == 0 && (sB & 1) == 0;
   for (int k0 = 0; k0 < K; k0 += TCMI_BK) {
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      float2 v = {0.f, 0.f};
+    {
+      float2 v0 = {0.f, 0.f}, v1 = {0.f, 0.f};
       if constexpr (TRANS_A) {
-        const long long r = m0 + ai + e;
+        const long long r = m0 + ai;
         const int kk = k0 + ak;
-        if (r < M && kk < K) v = A[(long long)kk * M + r];
-        As_re[ak][ai + e] = v.x;
-        As_im[ak][ai + e] = v.y;
+        if (kk < K) {
+          if (vecA && r + 1 < M) {
+            const float4 t = *reinterpret_cast<const float4*>(A + (long long)kk * M + r);
+            v0.x = t.x; v0.y = t.y; v1.x = t.z; v1.y = t.w;
+          } else {
+            if (r < M) v0 = A[(long long)kk * M + r];
+            if (r + 1 < M) v1 = A[(long long)kk * M + r + 1];
+          }
+        }
+        *reinterpret_cast<float2*>(&As_re[ak][ai]) = make_float2(v0.x, v1.x);
+        *reinterpret_cast<float2*>(&As_im[ak][ai]) = make_float2(v0.y, v1.y);
       } else {
         const long long r = m0 + ai;
-        const int kk = k0 + ak + e;
-        if (r < M && kk < K) v = A[r * K + kk];
-        As_re[ak + e][ai] = v.x;
-        As_im[ak + e][ai] = v.y;
+        const int kk = k0 + ak;
+        if (r < M) {
+          if (vecA && kk + 1 < K) {
+            const float4 t = *reinterpret_cast<const float4*>(A + r * K + kk);
+            v0.x = t.x; v0.y = t.y; v1.x = t.z; v1.y = t.w;
+          } else {
+            if (kk < K) v0 = A[r * K + kk];
+            if (kk + 1 < K) v1 = A[r * K + kk + 1];
+          }
+        }
+        As_re[ak][ai] = v0.x;
+        As_im[ak][ai] = v0.y;
+        As_re[ak + 1][ai] = v1.x;
+        As_im[ak + 1][ai] = v1.y;
       }
-      float2 w = {0.f, 0.f};
-      const long long c = n0 + bj + e;
+      float2 w0 = {0.f, 0.f}, w1 = {0.f, 0.f};
+      const long long c = n0 + bj;
       const int kb = k0 + bk;
-      if (kb < K && c < N) w = B[(long long)kb * N + c];
-      Bs_re[bk][bj + e] = w.x;
-      Bs_im[bk][bj + e] = w.y;
+      if (kb < K) {
+        if (vecB && c + 1 < N) {
+          const float4 t = *reinterpret_cast<const float4*>(B + (long long)kb * N + c);
+          w0.x = t.x; w0.y = t.y; w1.x = t.z; w1.y = t.w;
+        } else {
+          if (c < N) w0 = B[(long long)kb * N + c];
+          if (c + 1 < N) w1 = B[(long long)kb * N + c + 1];
+        }
+      }
+      *reinterpret_cast<float2*>(&Bs_re[bk][bj]) = make_float2(w0.x, w1.x);
+      *reinterpret_cast<float2*>(&Bs_im[bk][bj]) = make_float2(w0.y, w1.y);
     }
     __syncthreads();
 #pragma unroll
@@ -89,10 +122,9 @@ __global__ __launch_bounds__(256) void cgemm_mfma_kernel(const float2* __restric
       const int kr = kk + (lane >> 5);
       const float are = As_re[kr][wr * 32 + (lane & 31)], aim = As_im[kr][wr * 32 + (lane & 31)];
       const float bre = Bs_re[kr][wc * 32 + (lane & 31)], bim = Bs_im[kr][wc * 32 + (lane & 31)];
-      cre = __builtin_amdgcn_mfma_f32_32x32x2f32(are, bre, cre, 0, 0, 0);
-      cre = __builtin_amdgcn_mfma_f32_32x32x2f32(-aim, bim, cre, 0, 0, 0);
-      cim = __builtin_amdgcn_mfma_f32_32x32x2f32(are, bim, cim, 0, 0, 0);
-      cim = __builtin_amdgcn_mfma_f32_32x32x2f32(aim, bre, cim, 0, 0, 0);
+      p1 = __builtin_amdgcn_mfma_f32_32x32x2f32(are, bre, p1, 0, 0, 0);
+      p2 = __builtin_amdgcn_mfma_f32_32x32x2f32(aim, bim, p2, 0, 0, 0);
+      p3 = __builtin_amdgcn_mfma_f32_32x32x2f32(are + aim, bre + bim, p3, 0, 0, 0);
     }
     __syncthreads();
   }
@@ -103,8 +135,8 @@ __global__ __launch_bounds__(256) void cgemm_mfma_kernel(const float2* __restric
     const long long row = m0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
     if (row < M && col < N) {
       float2 o;
-      o.x = cre[reg];
-      o.y = cim[reg];
+      o.x = p1[reg] - p2[reg];
+      o.y = p3[reg] - p1[reg] - p2[reg];
       C[row * N + col] = o;
     }
   }
