@@ -1,0 +1,15 @@
+#!/bin/bash
+# rocprofv3 capture of the VQE probe (adjoint sweep).  usage: scripts/gpu_profile_adjoint.sh <tag> n d B
+export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$1
+rm -rf $OUT; mkdir -p $OUT
+run() {
+  name=$1; shift
+  rocprofv3 "$@" --output-format csv -d $OUT/$name -o bench -- python3 scripts/gpu_adjoint_probe.py $N $D $B > $OUT/$name.log 2>&1
+  echo "== $name rc=$?"; tail -1 $OUT/$name.log | cut -c1-300
+}
+N=$2; D=$3; B=$4
+run trace --kernel-trace --stats
+run pmc_sq --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
+run pmc_sq2 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS
+python3 scripts/summarize_prof.py $OUT | grep -v "at::native\|rocclr" | cut -c1-400

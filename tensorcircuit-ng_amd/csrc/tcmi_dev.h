@@ -152,6 +152,22 @@ __device__ __forceinline__ F wave_sum(F v) {
   return v;
 }
 
+// Wave-wide sum with a wave-uniform result.  float: DPP butterfly inside each row of 16 lanes, row_bcast15 /
+// row_bcast31 across rows, v_readlane 63 — no LDS crossbar (ds_bpermute) traffic.  double: shuffles.
+template <int CTRL, int RM>
+__device__ __forceinline__ float dpp_add_c(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, RM, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_uniform(float v) {
+  v = dpp_add_c<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add_c<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add_c<0x141, 0xf>(v);  // row_half_mirror
+  v = dpp_add_c<0x140, 0xf>(v);  // row_mirror: every lane of a row holds the row sum
+  v = dpp_add_c<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3
+  v = dpp_add_c<0x143, 0xc>(v);  // row_bcast31 into rows 2 and 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ double wave_sum_uniform(double v) { return wave_sum<double>(v); }
 
 }  // namespace tcmi
 #endif
