@@ -283,7 +283,7 @@ __global__ __launch_bounds__(1 << LT) void pass_kernel(typename Cx<F>::type* __r
 #pragma unroll
             for (int r = 0; r < NR; ++r) acc += (__popc((uint32_t)r & zr) & 1) ? -p[r] : p[r];
             if (__popc(tidx & zm) & 1) acc = -acc;
-            acc = wave_sum<F>(acc);
+            acc = wave_sum_uniform(acc);
             if ((tid & 63) == 0) atomicAdd(eout + 2 * oi, (double)acc);
             q += 3;
           }
@@ -296,8 +296,8 @@ __global__ __launch_bounds__(1 << LT) void pass_kernel(typename Cx<F>::type* __r
           F re = 0, im = 0;
           dispatch_expect_x<F, NR>(a, xr, zr, re, im);
           if (__popc(tidx & zm) & 1) { re = -re; im = -im; }
-          re = wave_sum<F>(re);
-          im = wave_sum<F>(im);
+          re = wave_sum_uniform(re);
+          im = wave_sum_uniform(im);
           if ((tid & 63) == 0) {
             atomicAdd(eout + 2 * oi, (double)re);
             atomicAdd(eout + 2 * oi + 1, (double)im);
