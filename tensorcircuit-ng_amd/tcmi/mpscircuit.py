@@ -82,6 +82,9 @@ class FiniteMPS:
                  canonicalize: bool = True):
         self.tensors = [_t(t) for t in tensors]
         self.center_position = center_position
+        # (site, tensor, isometry, singular values) of the last truncating two-site update whose centre
+        # tensor is isometry * diag(s): moving the centre across that bond needs no QR (see position)
+        self._svd_hint = None
         if canonicalize:
             if self.center_position is None:
                 self.center_position = 0
@@ -113,6 +116,16 @@ class FiniteMPS:
             for n in range(self.center_position, site):
                 t = self.tensors[n]
                 l, d, r = t.shape
+                hint = self._svd_hint
+                if hint is not None and hint[0] == n and hint[1] is t and not normalize:
+                    # t = U diag(s) with U the isometry of the SVD that produced it: Q = U, R = diag(s)
+                    # (the Householder QR the reference runs here returns the same factors up to phases)
+                    _, _, u_iso, sv = hint
+                    self.tensors[n] = u_iso.reshape(l, d, -1)
+                    nxt = self.tensors[n + 1]
+                    self.tensors[n + 1] = sv.reshape(-1, 1, 1).to(nxt.dtype) * nxt
+                    self._svd_hint = None
+                    continue
                 q, rr = LA.qr(t.reshape(l * d, r))
                 self.tensors[n] = q.reshape(l, d, -1)
                 nxt = self.tensors[n + 1]
@@ -181,9 +194,15 @@ class FiniteMPS:
 
         if center_position is None:
             center_position = site1
+        hint = None
         if use_svd:
-            absorb = 2 if center_position == site2 else 1
-            left, _, right, tw = LA.svd_trunc(theta, max_singular_values, max_truncation_err, relative, absorb)
+            if center_position == site2:
+                left, _, right, tw = LA.svd_trunc(theta, max_singular_values, max_truncation_err, relative, 2)
+            else:
+                u_iso, sv, right, tw = LA.svd_trunc(theta, max_singular_values, max_truncation_err, relative, 0)
+                left = u_iso * sv.reshape(1, -1)
+                if theta.shape[0] <= theta.shape[1]:  # row-form SVD: u is a complete isometry even at rank loss
+                    hint = (u_iso, sv)
             set_center(site2 if center_position == site2 else site1)
         else:
             tw = _torch().zeros(1, dtype=theta.dtype, device=theta.device)
@@ -195,6 +214,7 @@ class FiniteMPS:
                 set_center(site2)
         self.tensors[site1] = left.reshape(l, d, -1)
         self.tensors[site2] = right.reshape(-1, d, r)
+        self._svd_hint = None if hint is None else (site1, self.tensors[site1], hint[0], hint[1])
         return tw
 
     def check_canonical(self) -> Tensor:
