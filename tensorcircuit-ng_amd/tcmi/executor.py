@@ -134,6 +134,8 @@ class CompiledCircuit:
                 lib.tcmi_init_zero_state(out.data_ptr(), nel, B, self.n_exec, self.code, stream),
                 "tcmi_init_zero_state",
             )
+        elif self.n_exec == self.n:
+            out.copy_(inp)
         else:
             out.zero_()
             out[:, : 2**self.n] = inp
@@ -404,6 +406,49 @@ def vm_cost_us(plan: "P.CompiledPlan") -> float:
     return t * (2.0 ** plan.n) / 2.0**24
 
 
+class _HalfBatch:
+    """The K = prod r_k selector variants of one half-circuit.  The variants share prefixes: with the
+    bond digits ordered like the crossing gates, every state whose first s digits agree is identical up
+    to the (s+1)-th selector gate.  Two levels: the prefix (gates before the (s+1)-th selector) runs once
+    per K_s = prod_{k<s} r_k digit prefixes, its states are replicated K / K_s times, and the suffix
+    runs on the replicas — K_s |prefix| + K |suffix| gate applications instead of K (|prefix| + |suffix|)."""
+
+    def __init__(self, nq, gates, nparams, nb, radices, dtypestr, opts):
+        self.nq, self.radices = nq, list(radices)
+        K = int(np.prod(radices)) if radices else 1
+        sel_pos = [i for i, g in enumerate(gates) if g.select is not None]
+        ordered = [gates[i].param.index - nparams for i in sel_pos] == list(range(len(sel_pos)))
+        best = (K * len(gates), 0)
+        if ordered and len(sel_pos) == nb:
+            for s_ in range(1, nb):
+                cut = sel_pos[s_]
+                ks = int(np.prod(radices[:s_]))
+                cost = ks * cut + K * (len(gates) - cut) + 0.02 * K * len(gates)  # + extra launches / copy
+                if cost < best[0]:
+                    best = (cost, s_)
+        self.s = best[1]
+        self.K = K
+        if self.s == 0:
+            self.single = CompiledCircuit(nq, gates, nparams + nb, dtypestr, opts)
+            self.descs = list(self.single.descs)
+        else:
+            cut = sel_pos[self.s]
+            self.Ks = int(np.prod(radices[: self.s]))
+            self.prefix = CompiledCircuit(nq, gates[:cut], nparams + nb, dtypestr, opts)
+            self.suffix = CompiledCircuit(nq, gates[cut:], nparams + nb, dtypestr, opts)
+            self.descs = list(self.prefix.descs) + list(self.suffix.descs)
+
+    def states(self, pfull, B):
+        """pfull [B*K, nparams + nb] (digits in the last nb columns) -> [B*K, 2^nq]."""
+        if self.s == 0:
+            return self.single.state(pfull)
+        K, Ks = self.K, self.Ks
+        ppre = pfull.reshape(B, Ks, K // Ks, -1)[:, :, 0, :].reshape(B * Ks, -1).contiguous()
+        pre = self.prefix.state(ppre)                                            # [B*Ks, 2^nq]
+        rep = pre.reshape(B, Ks, 1, -1).expand(B, Ks, K // Ks, pre.shape[-1]).reshape(B * K, -1)
+        return self.suffix.state(pfull, inputs=rep)
+
+
 class CutCircuit:
     """Wavefunction by cut contraction (``tcmi/cut.py``): two half-circuit batches through the
     tile-VM and one MFMA complex GEMM.  Same interface as ``CompiledCircuit`` (the adjoint sweep
@@ -417,13 +462,13 @@ class CutCircuit:
         self.full = full_cc            # state-vector plan (adjoint sweep, inputs != |0>, stats)
         self.cfg = full_cc.cfg
         nb = len(spec.bonds)
-        self.left = CompiledCircuit(spec.n_left, spec.left, nparams + nb, dtypestr, opts)
-        self.right = CompiledCircuit(n - spec.n_left, spec.right, nparams + nb, dtypestr, opts)
+        radices = [len(b.terms) for b in spec.bonds]
+        self.left = _HalfBatch(spec.n_left, spec.left, nparams, nb, radices, dtypestr, opts)
+        self.right = _HalfBatch(n - spec.n_left, spec.right, nparams, nb, radices, dtypestr, opts)
         self.tdtype, self.rdtype, self.code = full_cc.tdtype, full_cc.rdtype, full_cc.code
         self.device = full_cc.device
         self._lib = _lib.lib()
         self.K = spec.bond_dim
-        radices = [len(b.terms) for b in spec.bonds]
         digits = np.zeros((self.K, nb), dtype=np.float64)
         for b in range(self.K):
             x = b
@@ -463,8 +508,8 @@ class CutCircuit:
         B, K = p.shape[0], self.K
         pfull = torch.cat([p[:, : self.nparams].unsqueeze(1).expand(B, K, self.nparams),
                            self.digits.unsqueeze(0).expand(B, K, -1)], dim=2).reshape(B * K, -1).contiguous()
-        L = self.left.state(pfull)                                      # [B*K, M]
-        R = self.right.state(pfull)                                     # [B*K, N]
+        L = self.left.states(pfull, B)                                  # [B*K, M]
+        R = self.right.states(pfull, B)                                 # [B*K, N]
         R = R * self._weights(p).reshape(B * K, 1)
         M, N = 2**self.spec.n_left, 2 ** (self.n - self.spec.n_left)
         if out is None:
