@@ -142,153 +142,6 @@ __global__ __launch_bounds__(256) void cgemm_mfma_kernel(const float2* __restric
   }
 }
 
-// 128x128 tile variant (large M, N): 4 waves x (64x64 = 2x2 MFMA tiles), 12 accumulators per wave.
-// Halves the operand traffic from L2 per flop (the 64x64 kernel pulls 2 x 8 KB per 4 k-pairs per CU,
-// ~4.6 TB/s chip-wide at K = 256) and reuses every LDS fragment twice.
-#define TCMI_B2 128
-#define TCMI_LDP2 132
-
-template <bool TRANS_A>
-__global__ __launch_bounds__(256) void cgemm_mfma128_kernel(const float2* __restrict__ A,
-                                                             const float2* __restrict__ B,
-                                                             float2* __restrict__ C, int M, int N, int K,
-                                                             long long sA, long long sB, long long sC) {
-  __shared__ __attribute__((aligned(16))) float As_re[TCMI_BK][TCMI_LDP2], As_im[TCMI_BK][TCMI_LDP2];
-  __shared__ __attribute__((aligned(16))) float Bs_re[TCMI_BK][TCMI_LDP2], Bs_im[TCMI_BK][TCMI_LDP2];
-  A += (long long)blockIdx.z * sA;
-  B += (long long)blockIdx.z * sB;
-  C += (long long)blockIdx.z * sC;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const long long m0 = (long long)blockIdx.y * TCMI_B2, n0 = (long long)blockIdx.x * TCMI_B2;
-  f32x16 p1[2][2], p2[2][2], p3[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      p1[i][j] = f32x16{0};
-      p2[i][j] = f32x16{0};
-      p3[i][j] = f32x16{0};
-    }
-  const bool vecA = TRANS_A ? ((M & 1) == 0 && (sA & 1) == 0) : ((K & 1) == 0 && (sA & 1) == 0);
-  const bool vecB = (N & 1) == 0 && (sB & 1) == 0;
-  // k-major operands (B, and A when TRANS_A): thread -> (k = tid >> 5, 4 consecutive columns)
-  const int lk = tid >> 5, lc = (tid & 31) * 4;
-  // row-major A: thread -> (row = tid >> 1, 4 consecutive k)
-  const int ar = tid >> 1, ak = (tid & 1) * 4;
-  // software pipeline (one workgroup per CU at this register budget, so nothing else hides the
-  // operand latency): the global loads of tile k+1 are in flight while tile k is multiplied
-  float2 v[4], w[4];
-  auto load_tiles = [&](int k0) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      v[e] = make_float2(0.f, 0.f);
-      w[e] = make_float2(0.f, 0.f);
-    }
-    if constexpr (TRANS_A) {
-      const long long r = m0 + lc;
-      const int kk = k0 + lk;
-      if (kk < K) {
-        const float2* src = A + (long long)kk * M + r;
-        if (vecA && r + 3 < M) {
-          const float4 t0 = *reinterpret_cast<const float4*>(src), t1 = *reinterpret_cast<const float4*>(src + 2);
-          v[0] = make_float2(t0.x, t0.y); v[1] = make_float2(t0.z, t0.w);
-          v[2] = make_float2(t1.x, t1.y); v[3] = make_float2(t1.z, t1.w);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (r + e < M) v[e] = src[e];
-        }
-      }
-    } else {
-      const long long r = m0 + ar;
-      const int kk = k0 + ak;
-      if (r < M) {
-        const float2* src = A + r * K + kk;
-        if (vecA && kk + 3 < K) {
-          const float4 t0 = *reinterpret_cast<const float4*>(src), t1 = *reinterpret_cast<const float4*>(src + 2);
-          v[0] = make_float2(t0.x, t0.y); v[1] = make_float2(t0.z, t0.w);
-          v[2] = make_float2(t1.x, t1.y); v[3] = make_float2(t1.z, t1.w);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (kk + e < K) v[e] = src[e];
-        }
-      }
-    }
-    const long long c = n0 + lc;
-    const int kb = k0 + lk;
-    if (kb < K) {
-      const float2* src = B + (long long)kb * N + c;
-      if (vecB && c + 3 < N) {
-        const float4 t0 = *reinterpret_cast<const float4*>(src), t1 = *reinterpret_cast<const float4*>(src + 2);
-        w[0] = make_float2(t0.x, t0.y); w[1] = make_float2(t0.z, t0.w);
-        w[2] = make_float2(t1.x, t1.y); w[3] = make_float2(t1.z, t1.w);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (c + e < N) w[e] = src[e];
-      }
-    }
-  };
-  load_tiles(0);
-  for (int k0 = 0; k0 < K; k0 += TCMI_BK) {
-    if constexpr (TRANS_A) {
-      *reinterpret_cast<float4*>(&As_re[lk][lc]) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
-      *reinterpret_cast<float4*>(&As_im[lk][lc]) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        As_re[ak + e][ar] = v[e].x;
-        As_im[ak + e][ar] = v[e].y;
-      }
-    }
-    *reinterpret_cast<float4*>(&Bs_re[lk][lc]) = make_float4(w[0].x, w[1].x, w[2].x, w[3].x);
-    *reinterpret_cast<float4*>(&Bs_im[lk][lc]) = make_float4(w[0].y, w[1].y, w[2].y, w[3].y);
-    __syncthreads();
-    if (k0 + TCMI_BK < K) load_tiles(k0 + TCMI_BK);
-#pragma unroll
-    for (int kk = 0; kk < TCMI_BK; kk += 2) {
-      const int kr = kk + (lane >> 5);
-      float are[2], aim[2], asum[2], bre[2], bim[2], bsum[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        are[i] = As_re[kr][wr * 64 + i * 32 + (lane & 31)];
-        aim[i] = As_im[kr][wr * 64 + i * 32 + (lane & 31)];
-        asum[i] = are[i] + aim[i];
-        bre[i] = Bs_re[kr][wc * 64 + i * 32 + (lane & 31)];
-        bim[i] = Bs_im[kr][wc * 64 + i * 32 + (lane & 31)];
-        bsum[i] = bre[i] + bim[i];
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          p1[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(are[i], bre[j], p1[i][j], 0, 0, 0);
-          p2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aim[i], bim[j], p2[i][j], 0, 0, 0);
-          p3[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(asum[i], bsum[j], p3[i][j], 0, 0, 0);
-        }
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const long long col = n0 + wc * 64 + j * 32 + (lane & 31);
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const long long row = m0 + wr * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-        if (row < M && col < N) {
-          float2 o;
-          o.x = p1[i][j][reg] - p2[i][j][reg];
-          o.y = p3[i][j][reg] - p1[i][j][reg] - p2[i][j][reg];
-          C[row * N + col] = o;
-        }
-      }
-    }
-}
-
 // complex128 (and tiny shapes): one output element per thread, fp64 FMA chain
 template <typename F>
 __global__ void cgemm_simple_kernel(const typename Cx<F>::type* __restrict__ A,
@@ -353,19 +206,7 @@ int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!A || !B || !C || M < 1 || N < 1 || K < 1 || batch < 1 || K > (1ll << 30))
     return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm: bad argument");
-  if (dtype == TCMI_C64 && M >= 256 && N >= 256) {
-    const long long gx = (N + TCMI_B2 - 1) / TCMI_B2, gy = (M + TCMI_B2 - 1) / TCMI_B2;
-    if (gy > 65535 || batch > 65535) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm: grid too large");
-    dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)batch), block(256, 1, 1);
-    if (trans_a)
-      hipLaunchKernelGGL(tcmi::cgemm_mfma128_kernel<true>, grid, block, 0, st, reinterpret_cast<const float2*>(A),
-                         reinterpret_cast<const float2*>(B), reinterpret_cast<float2*>(C), (int)M, (int)N, (int)K,
-                         strideA, strideB, strideC);
-    else
-      hipLaunchKernelGGL(tcmi::cgemm_mfma128_kernel<false>, grid, block, 0, st, reinterpret_cast<const float2*>(A),
-                         reinterpret_cast<const float2*>(B), reinterpret_cast<float2*>(C), (int)M, (int)N, (int)K,
-                         strideA, strideB, strideC);
-  } else if (dtype == TCMI_C64 && M * N >= 1024) {
+  if (dtype == TCMI_C64 && M * N >= 1024) {
     const long long gx = (N + TCMI_BN - 1) / TCMI_BN, gy = (M + TCMI_BM - 1) / TCMI_BM;
     if (gy > 65535 || batch > 65535) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm: grid too large");
     dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)batch), block(256, 1, 1);
