@@ -252,12 +252,70 @@ class HipBackend:
     def diagflat(self, a: Tensor, k: int = 0) -> Tensor:
         return self._torch.diag_embed(a.reshape(-1), offset=k)
 
-    def svd(self, a: Tensor, **kws: Any):
-        u, s, vh = self._torch.linalg.svd(a, full_matrices=False)
-        return u, s, vh, s[:0]
+    def zeros_like(self, a: Tensor) -> Tensor:
+        return self._torch.zeros_like(self.convert_to_tensor(a))
 
-    def qr(self, a: Tensor, **kws: Any):
-        return self._torch.linalg.qr(a)
+    def is_sparse(self, a: Any) -> bool:
+        return bool(getattr(a, "is_pauli_sum", False))
+
+    def sparse_dense_matmul(self, sp_a: Any, b: Tensor) -> Tensor:
+        """reference abstract_backend ``sparse_dense_matmul``: the hip backend's sparse operators are
+        matrix-free Pauli sums (tc.quantum.PauliStringSum2COO) applied by ``tcmi_apply_pauli_sum``."""
+        if not self.is_sparse(sp_a):
+            raise NotImplementedError("Backend 'hip' has not implemented sparse_dense_matmul for this operand.")
+        b = self.convert_to_tensor(b)
+        if b.dim() == 2 and b.shape[1] == 1:
+            return sp_a.matvec(b.reshape(-1)).reshape(-1, 1)
+        return sp_a.matvec(b)
+
+    # ---- decompositions: the HIP kernels of tcmi/linalg.py (reference: tensornetwork backend ``svd`` /
+    # ``qr`` / ``rq`` with pivot_axis, truncation rule restated at backends/jax_backend.py:62-112) ----
+    def _as_device_matrix(self, a: Tensor, pivot_axis: int):
+        a = self.convert_to_tensor(a)
+        if not a.is_cuda:
+            from .._lib import TcmiError
+
+            raise TcmiError("Backend 'hip': svd / qr / rq run on the GPU only (no CPU fallback)")
+        left, right = tuple(a.shape[:pivot_axis]), tuple(a.shape[pivot_axis:])
+        m = int(np.prod(left)) if left else 1
+        n = int(np.prod(right)) if right else 1
+        real = not a.is_complex()
+        dt = a.dtype
+        if real:
+            a = a.to(self._torch.complex64 if dt == self._torch.float32 else self._torch.complex128)
+        return a.reshape(m, n), left, right, (dt if real else None)
+
+    def svd(self, a: Tensor, pivot_axis: int = -1, max_singular_values: Optional[int] = None,
+            max_truncation_error: Optional[float] = None, relative: Optional[bool] = False):
+        from .. import linalg as LA
+
+        mat, left, right, rdt = self._as_device_matrix(a, pivot_axis)
+        u, s, vh, rest = LA.svd_trunc(mat, max_singular_values, max_truncation_error, bool(relative))
+        k = s.shape[0]
+        u, vh = u.reshape(*left, k), vh.reshape(k, *right)
+        if rdt is not None:  # real input: singular vectors of a real matrix can be chosen real up to phases
+            return u, s.real.to(rdt), vh, rest.real.to(rdt)
+        return u, s, vh, rest
+
+    def qr(self, a: Tensor, pivot_axis: int = -1, non_negative_diagonal: bool = False):
+        from .. import linalg as LA
+
+        mat, left, right, _ = self._as_device_matrix(a, pivot_axis)
+        q, r = LA.qr(mat)
+        if non_negative_diagonal:
+            d = self._torch.diagonal(r)
+            ph = self._torch.where(d.abs() > 0, d / d.abs().clamp_min(1e-300), self._torch.ones_like(d))
+            q, r = q * ph.reshape(1, -1), ph.conj().reshape(-1, 1) * r
+        k = q.shape[1]
+        return q.reshape(*left, k), r.reshape(k, *right)
+
+    def rq(self, a: Tensor, pivot_axis: int = -1, non_negative_diagonal: bool = False):
+        from .. import linalg as LA
+
+        mat, left, right, _ = self._as_device_matrix(a, pivot_axis)
+        r, q = LA.rq(mat)
+        k = q.shape[0]
+        return r.reshape(*left, k), q.reshape(k, *right)
 
     def eigh(self, a: Tensor):
         return self._torch.linalg.eigh(a)

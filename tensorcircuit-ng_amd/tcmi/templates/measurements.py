@@ -1,0 +1,38 @@
+"""reference ``tensorcircuit/templates/measurements.py:156-191``: Hamiltonian expectation helpers."""
+
+from typing import Any
+
+from .. import cons
+from ..quantum import PauliSum
+
+Tensor = Any
+
+
+def sparse_expectation(c: Any, hamiltonian: PauliSum) -> Tensor:
+    """<psi|H|psi> for a matrix-free Pauli sum: every string goes through ``expectation_ps`` lazily, so the
+    whole sum is ONE fused measurement (and one Pauli-sum cotangent in the backward pass)."""
+    if not isinstance(hamiltonian, PauliSum):
+        raise TypeError("Backend 'hip': sparse Hamiltonians are PauliSum objects (tc.quantum.PauliStringSum2COO)")
+    if hamiltonian.n != c._nqubits:
+        raise ValueError("Hamiltonian and circuit act on different numbers of qubits")
+    e = 0.0
+    for s, w in zip(hamiltonian.structures, hamiltonian.weights):
+        x = [q for q, p in enumerate(s) if p == 1]
+        y = [q for q, p in enumerate(s) if p == 2]
+        z = [q for q, p in enumerate(s) if p == 3]
+        if not (x or y or z):
+            e = e + w
+        else:
+            e = e + w * c.expectation_ps(x=x, y=y, z=z)
+    return cons.backend.real(e)
+
+
+def operator_expectation(c: Any, hamiltonian: Any) -> Tensor:
+    """reference measurements.py:156-172: dense matrix or sparse (here: PauliSum) Hamiltonian."""
+    if isinstance(hamiltonian, PauliSum):
+        return sparse_expectation(c, hamiltonian)
+    b = cons.backend
+    w = c.state(form="ket")
+    h = b.cast(b.convert_to_tensor(hamiltonian), cons.dtypestr)
+    e = (b.adjoint(w) @ h @ w)[0, 0]
+    return b.real(e)

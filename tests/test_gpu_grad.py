@@ -211,3 +211,58 @@ def test_grad_at_scale_vs_single_precision_pair():
     # energy against the dense oracle
     want = W.tfim_energy_dense(dense.run(n, W.hea_b_ops(n, d, params)), n)
     assert abs(outs["complex128"][0] - want) < 1e-9
+
+
+def test_pauli_sum_hamiltonian_matrix_free(tcd):
+    """PauliStringSum2COO / PauliStringSum2MVP / operator_expectation (reference
+    quantum.py:2222-2358, templates/measurements.py:156-191) without materialising H: TFIM at n=12 against
+    the oracle energy, H|psi> against a dense Kronecker build at n=6, and the gradient through it."""
+    tc = tcd
+    n, d = 12, 3
+    structures, weights = [], []
+    for i in range(n):
+        s = [0] * n; s[i] = 1
+        structures.append(s); weights.append(-1.0)
+    for i in range(n - 1):
+        s = [0] * n; s[i] = 3; s[i + 1] = 3
+        structures.append(s); weights.append(1.0)
+    h = tc.quantum.PauliStringSum2COO(structures, weights)
+    assert tc.backend.is_sparse(h)
+    rng = np.random.default_rng(5)
+    params = rng.normal(0, 0.3, [2 * d, n])
+
+    def energy(p):
+        c = tc.Circuit(n)
+        W.hea_b(c, n, d, p, zz=tc.gates._zz_matrix)
+        return tc.templates.measurements.operator_expectation(c, h)
+
+    rdt = np.float32 if tc.rdtypestr == "float32" else np.float64
+    v, g = tc.backend.value_and_grad(energy)(tc.backend.convert_to_tensor(params.astype(rdt)))
+    def ref(p):
+        return W.tfim_energy_dense(dense.run(n, W.hea_b_ops(n, d, p)), n)
+
+    want = ref(params)
+    tol = 2e-5 if tc.dtypestr == "complex64" else 1e-10
+    np.testing.assert_allclose(_np(tc, v), want, atol=tol * 10)
+    eps = 1e-5
+    pp, pm = params.copy(), params.copy()
+    pp[1, 3] += eps; pm[1, 3] -= eps
+    fd = (ref(pp) - ref(pm)) / (2 * eps)
+    np.testing.assert_allclose(_np(tc, g)[1, 3], fd, atol=2e-4 if tc.dtypestr == "complex64" else 1e-7)
+    # matrix-vector product vs a dense Kronecker build
+    m = 6
+    st = [[1, 0, 2, 3, 0, 1], [3, 3, 0, 0, 2, 2], [0, 0, 0, 0, 0, 3]]
+    wt = [0.5, -1.25, 2.0]
+    mvp = tc.quantum.PauliStringSum2MVP(st, wt)
+    psi = rng.normal(size=2**m) + 1j * rng.normal(size=2**m)
+    dense_h = np.zeros((2**m, 2**m), dtype=np.complex128)
+    for s, w in zip(st, wt):
+        t = np.array([[1.0]])
+        for p in s:
+            t = np.kron(t, G.PAULI[p])
+        dense_h += w * t
+    got = _np(tc, mvp(tc.backend.cast(tc.backend.convert_to_tensor(psi), tc.dtypestr)))
+    np.testing.assert_allclose(got, dense_h @ psi, atol=tol * 50)
+    ket = tc.backend.cast(tc.backend.convert_to_tensor(psi.reshape(-1, 1)), tc.dtypestr)
+    got2 = _np(tc, tc.backend.sparse_dense_matmul(tc.quantum.PauliStringSum2COO(st, wt), ket))
+    np.testing.assert_allclose(got2[:, 0], dense_h @ psi, atol=tol * 50)

@@ -183,3 +183,30 @@ def test_tebd_sweeps_match_oracle(dt, chi):
         np.testing.assert_allclose(float(m.get_norm()), o.get_norm(), atol=tol * 10)
     finally:
         tc.set_dtype("complex64")
+
+
+def test_backend_svd_qr_rq_route_to_hip_kernels():
+    """backend.svd / qr / rq (tensornetwork backend signatures with pivot_axis; reference call sites
+    mps_base.py:123-168) resolve to the HIP kernels."""
+    tc.set_dtype("complex128")
+    try:
+        rng = np.random.default_rng(0)
+        a = (rng.normal(size=(3, 4, 5, 2)) + 1j * rng.normal(size=(3, 4, 5, 2)))
+        t = tc.backend.convert_to_tensor(a)
+        u, s, vh, rest = tc.backend.svd(t, pivot_axis=2, max_singular_values=7)
+        assert tuple(u.shape) == (3, 4, 7) and tuple(vh.shape) == (7, 5, 2) and rest.numel() == 3
+        uo, so, vho, resto = omps.svd_trunc(a.reshape(12, 10), 7)
+        np.testing.assert_allclose(s.cpu().numpy().real, so.real, atol=1e-10)
+        rec = np.tensordot(u.cpu().numpy() * s.cpu().numpy(), vh.cpu().numpy(), axes=(2, 0))
+        np.testing.assert_allclose(rec.reshape(12, 10), (uo * so) @ vho, atol=1e-9)
+        q, r = tc.backend.qr(t, pivot_axis=2, non_negative_diagonal=True)
+        np.testing.assert_allclose(np.tensordot(q.cpu().numpy(), r.cpu().numpy(), axes=(2, 0)), a, atol=1e-10)
+        d = np.diagonal(r.cpu().numpy().reshape(10, 10))
+        assert np.all(np.abs(d.imag) < 1e-12) and np.all(d.real >= 0)
+        r2, q2 = tc.backend.rq(t, pivot_axis=2)
+        np.testing.assert_allclose(np.tensordot(r2.cpu().numpy(), q2.cpu().numpy(), axes=(2, 0)), a, atol=1e-10)
+        x = rng.normal(size=(6, 4)).astype(np.float64)
+        ur, sr, vhr, _ = tc.backend.svd(tc.backend.convert_to_tensor(x), pivot_axis=1)
+        np.testing.assert_allclose(sr.cpu().numpy(), np.linalg.svd(x, compute_uv=False), atol=1e-10)
+    finally:
+        tc.set_dtype("complex64")
