@@ -262,7 +262,7 @@ class HipBackend:
         """reference abstract_backend ``sparse_dense_matmul``: the hip backend's sparse operators are
         matrix-free Pauli sums (tc.quantum.PauliStringSum2COO) applied by ``tcmi_apply_pauli_sum``."""
         if not self.is_sparse(sp_a):
-            raise NotImplementedError("Backend 'hip' has not implemented sparse_dense_matmul for this operand.")
+            raise NotImplementedError("Backend 'hip' has not implemented `sparse_dense_matmul`.")
         b = self.convert_to_tensor(b)
         if b.dim() == 2 and b.shape[1] == 1:
             return sp_a.matvec(b.reshape(-1)).reshape(-1, 1)

@@ -213,6 +213,10 @@ def test_grad_at_scale_vs_single_precision_pair():
     assert abs(outs["complex128"][0] - want) < 1e-9
 
 
+def _np(tc, t):
+    return tc.backend.numpy(t)
+
+
 def test_pauli_sum_hamiltonian_matrix_free(tcd):
     """PauliStringSum2COO / PauliStringSum2MVP / operator_expectation (reference
     quantum.py:2222-2358, templates/measurements.py:156-191) without materialising H: TFIM at n=12 against
