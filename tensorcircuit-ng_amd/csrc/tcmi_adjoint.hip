@@ -48,18 +48,6 @@ __device__ __forceinline__ F grad_g1(const typename Cx<F>::type (&a)[NR], const 
 template <typename F, int NR, int J>
 __device__ __forceinline__ F grad_g1_k2(const typename Cx<F>::type (&a)[NR], const typename Cx<F>::type (&l)[NR],
                                         const F (&k)[8]) {
-  if constexpr (sizeof(F) == 4) {
-    // Im(conj(l) a) = l.x a.y - l.y a.x: one packed FMA per term, halves summed at the end
-    v2f acc2 = {0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      if ((r >> J) & 1) continue;
-      const int r1 = r | (1 << J);
-      acc2 = acc2 + ld2(l[r]) * (swp(ld2(a[r1])) * v2f{1.f, -1.f});
-      acc2 = acc2 + ld2(l[r1]) * (swp(ld2(a[r])) * v2f{1.f, -1.f});
-    }
-    return -k[3] * (acc2.x + acc2.y);
-  }
   F acc = 0;
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
@@ -76,17 +64,6 @@ __device__ __forceinline__ F grad_g1_k2(const typename Cx<F>::type (&a)[NR], con
 template <typename F, int NR, int J>
 __device__ __forceinline__ F grad_g1_k1(const typename Cx<F>::type (&a)[NR], const typename Cx<F>::type (&l)[NR],
                                         const F (&k)[8]) {
-  if constexpr (sizeof(F) == 4) {
-    v2f s01 = {0.f, 0.f}, s10 = {0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      if ((r >> J) & 1) continue;
-      const int r1 = r | (1 << J);
-      s01 = s01 + ld2(l[r]) * ld2(a[r1]);
-      s10 = s10 + ld2(l[r1]) * ld2(a[r]);
-    }
-    return k[2] * (s01.x + s01.y) + k[4] * (s10.x + s10.y);
-  }
   F a01 = 0, a10 = 0;
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
@@ -364,16 +341,11 @@ __global__ __launch_bounds__(1 << LT) void adjoint_kernel(typename Cx<F>::type* 
         for (int r = 0; r < NR; ++r) {
           F s, c;
           sincos_turns<F>(ph[r], &s, &c);
-          if constexpr (sizeof(F) == 4) {
-            st2(a[r], cmul2(c, -s, ld2(a[r])));   // multiply by exp(-i phi)
-            st2(l[r], cmul2(c, -s, ld2(l[r])));
-          } else {
-            const C v = a[r], u = l[r];
-            a[r].x = v.x * c + v.y * s;   // multiply by exp(-i phi)
-            a[r].y = v.y * c - v.x * s;
-            l[r].x = u.x * c + u.y * s;
-            l[r].y = u.y * c - u.x * s;
-          }
+          const C v = a[r], u = l[r];
+          a[r].x = v.x * c + v.y * s;   // multiply by exp(-i phi)
+          a[r].y = v.y * c - v.x * s;
+          l[r].x = u.x * c + u.y * s;
+          l[r].y = u.y * c - u.x * s;
         }
       } else {
         break;

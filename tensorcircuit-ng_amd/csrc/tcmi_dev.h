@@ -61,21 +61,6 @@ template <typename F> __device__ __forceinline__ F fma_(F a, F b, F c);
 template <> __device__ __forceinline__ float fma_<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 template <> __device__ __forceinline__ double fma_<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
-// ---- packed complex arithmetic (complex64) -----------------------------------------------------------
-// A complex64 amplitude is a 64-bit VGPR pair, and gfx950's v_pk_mul_f32 / v_pk_fma_f32 operate on such
-// pairs with per-half operand selection (op_sel: swap re <-> im, broadcast a scalar) and per-half
-// negation (neg_lo / neg_hi).  (mr + i mi) * v = v * mr + swap(v) * (-mi, +mi) is therefore TWO
-// packed instructions instead of four scalar FMAs, with the matrix element still an SGPR operand.
-// Written with ext_vector types; clang folds the shuffle and the sign into op_sel / neg_lo.  The
-// VALU issues one wave instruction per 4 cycles and these kernels are issue-bound (rocprofv3:
-// 9-13k VALU instructions per wave and pass), so instruction count is what matters.
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f ld2(const float2& a) { return v2f{a.x, a.y}; }
-__device__ __forceinline__ void st2(float2& a, v2f v) { a.x = v.x; a.y = v.y; }
-__device__ __forceinline__ v2f swp(v2f a) { return __builtin_shufflevector(a, a, 1, 0); }
-__device__ __forceinline__ v2f cmul2(float mr, float mi, v2f v) { return v * mr + swp(v) * v2f{-mi, mi}; }
-__device__ __forceinline__ v2f cmac2(v2f acc, float mr, float mi, v2f v) { return acc + v * mr + swp(v) * v2f{-mi, mi}; }
-
 // acc += m * v (complex), 4 FMAs
 template <typename F, typename C>
 __device__ __forceinline__ void cfma(F mr, F mi, const C& v, F& re, F& im) {
@@ -92,28 +77,6 @@ template <typename F, int NR, int J, int KIND>
 __device__ __forceinline__ void apply_g1(typename Cx<F>::type (&a)[NR], const F (&m)[8]) {
   const F m00r = m[0], m00i = m[1], m01r = m[2], m01i = m[3];
   const F m10r = m[4], m10i = m[5], m11r = m[6], m11i = m[7];
-  if constexpr (sizeof(F) == 4) {
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      if ((r >> J) & 1) continue;
-      const int r1 = r | (1 << J);
-      const v2f x = ld2(a[r]), y = ld2(a[r1]);
-      v2f o0, o1;
-      if constexpr (KIND == 1) {
-        o0 = x * m00r + y * m01r;
-        o1 = x * m10r + y * m11r;
-      } else if constexpr (KIND == 2) {
-        o0 = x * m00r + swp(y) * v2f{-m01i, m01i};
-        o1 = y * m11r + swp(x) * v2f{-m10i, m10i};
-      } else {
-        o0 = cmac2(cmul2(m00r, m00i, x), m01r, m01i, y);
-        o1 = cmac2(cmul2(m10r, m10i, x), m11r, m11i, y);
-      }
-      st2(a[r], o0);
-      st2(a[r1], o1);
-    }
-    return;
-  }
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     if ((r >> J) & 1) continue;
@@ -150,22 +113,6 @@ __device__ __forceinline__ void apply_g2(typename Cx<F>::type (&a)[NR], const F 
   for (int r = 0; r < NR; ++r) {
     if (((r >> JA) & 1) || ((r >> JB) & 1)) continue;
     const int i0 = r, i1 = r | (1 << JB), i2 = r | (1 << JA), i3 = r | (1 << JA) | (1 << JB);
-    if constexpr (sizeof(F) == 4) {
-      const v2f w[4] = {ld2(a[i0]), ld2(a[i1]), ld2(a[i2]), ld2(a[i3])};
-      v2f q[4];
-#pragma unroll
-      for (int row = 0; row < 4; ++row) {
-        v2f acc = cmul2(m[8 * row], m[8 * row + 1], w[0]);
-#pragma unroll
-        for (int col = 1; col < 4; ++col) acc = cmac2(acc, m[2 * (4 * row + col)], m[2 * (4 * row + col) + 1], w[col]);
-        q[row] = acc;
-      }
-      st2(a[i0], q[0]);
-      st2(a[i1], q[1]);
-      st2(a[i2], q[2]);
-      st2(a[i3], q[3]);
-      continue;
-    }
     const typename Cx<F>::type v[4] = {a[i0], a[i1], a[i2], a[i3]};
     typename Cx<F>::type o[4];
 #pragma unroll

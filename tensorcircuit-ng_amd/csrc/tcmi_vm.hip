@@ -262,13 +262,9 @@ __global__ __launch_bounds__(1 << LT) void pass_kernel(typename Cx<F>::type* __r
         for (int r = 0; r < NR; ++r) {
           F s, c;
           sincos_turns<F>(ph[r], &s, &c);
-          if constexpr (sizeof(F) == 4) {
-            st2(a[r], cmul2(c, s, ld2(a[r])));
-          } else {
-            const C v = a[r];
-            a[r].x = v.x * c - v.y * s;
-            a[r].y = v.x * s + v.y * c;
-          }
+          const C v = a[r];
+          a[r].x = v.x * c - v.y * s;
+          a[r].y = v.x * s + v.y * c;
         }
       } else if (MODE == 1 && op == TCMI_OP_EXPECT) {
         // <psi|P_t|psi> partial sums for Pauli strings whose X/Y bits are register bits of this round
