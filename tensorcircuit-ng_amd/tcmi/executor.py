@@ -479,22 +479,35 @@ class CutCircuit:
         self.descs = self.left.descs + self.right.descs               # for bookkeeping / stats
 
     def _weights(self, params):
-        """w[B, K] = prod_k coef_k(digit_k, theta) (tiny; torch ops on [B, r_k] vectors)."""
+        """w[B, K] = prod_k coef_k(digit_k, theta): one gather + one product over the bond axis (the
+        per-bond coefficient table [B, nb, rmax] is built from one cos and one sin of all bond angles)."""
         import torch
 
+        tabs = getattr(self, "_wtabs", None)
+        if tabs is None:
+            nb = len(self.spec.bonds)
+            rmax = max(len(b.terms) for b in self.spec.bonds)
+            const = np.zeros((nb, rmax), dtype=np.complex128)
+            cmask = np.zeros((nb, rmax)); smask = np.zeros((nb, rmax))
+            pidx = np.zeros((nb, rmax), dtype=np.int64); scale = np.zeros((nb, rmax)); offs = np.zeros((nb, rmax))
+            for k, bond in enumerate(self.spec.bonds):
+                for j, (_, _, (kind, ref)) in enumerate(bond.terms):
+                    if kind == "const":
+                        const[k, j] = complex(ref)
+                    else:
+                        (cmask if kind == "cos" else smask)[k, j] = 1.0
+                        pidx[k, j], scale[k, j], offs[k, j] = ref.index, ref.scale, ref.offset
+            dig = self.digits.to(torch.int64)                                   # [K, nb]
+            tabs = dict(const=_dev(const, self.device), cmask=_dev(cmask, self.device), smask=_dev(smask, self.device),
+                        pidx=_dev(pidx.reshape(-1), self.device), scale=_dev(scale, self.device),
+                        offs=_dev(offs, self.device), dig=dig.t().contiguous().unsqueeze(0), nb=nb, rmax=rmax)
+            self._wtabs = tabs
         B = params.shape[0]
-        w = torch.ones(B, 1, dtype=self.tdtype, device=self.device)
-        for bond in self.spec.bonds:
-            cols = []
-            for _, _, (kind, ref) in bond.terms:
-                if kind == "const":
-                    cols.append(torch.full((B,), complex(ref), dtype=self.tdtype, device=self.device))
-                else:
-                    a = params[:, ref.index].to(torch.float64) * ref.scale + ref.offset
-                    cols.append((torch.cos(a) if kind == "cos" else torch.sin(a)).to(self.tdtype))
-            v = torch.stack(cols, dim=1)                                # [B, r_k]
-            w = (w[:, :, None] * v[:, None, :]).reshape(B, -1)
-        return w
+        nb, rmax = tabs["nb"], tabs["rmax"]
+        a = params[:, tabs["pidx"]].to(torch.float64).reshape(B, nb, rmax) * tabs["scale"] + tabs["offs"]
+        v = tabs["const"] + tabs["cmask"] * torch.cos(a) + tabs["smask"] * torch.sin(a)   # [B, nb, rmax] complex128
+        sel = torch.gather(v, 2, tabs["dig"].expand(B, nb, -1))                 # [B, nb, K]
+        return sel.prod(dim=1).to(self.tdtype)
 
     def state(self, params=None, inputs=None, out=None, full=False):
         import torch
