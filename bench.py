@@ -190,6 +190,66 @@ def mps_leg(tc, torch, args):
     }
 
 
+def rqc_leg(tc, torch, dist, args, rank, world):
+    """BASELINE config 4: single amplitude <0^32|C|0^32> of a 32-qubit random circuit on a 4x8 grid (brickwork
+    of Haar-random two-qubit gates, reference gates.py:852-863), complex64, through DistributedContractor:
+    random-greedy path search + slicing to 2^27 elements, slices sharded over the ranks as
+    reference experimental.py:881-890 and summed with one packed all-reduce."""
+    import numpy as np
+    from tcmi.experimental import DistributedContractor
+
+    rows, cols, depth = 4, 8, args.rqc_depth
+    gates = [tc.gates.random_two_qubit_gate(7000 + i).tensor for i in range(depth * rows * cols)]
+    q = lambda r, c: r * cols + c
+
+    def nodes_fn(_):
+        c = tc.Circuit(rows * cols)
+        k = 0
+        for d in range(depth):
+            pat = d % 4
+            if pat in (0, 1):
+                pairs = [(q(r, cc), q(r, cc + 1)) for r in range(rows) for cc in range(pat, cols - 1, 2)]
+            else:
+                pairs = [(q(r, cc), q(r + 1, cc)) for r in range(pat - 2, rows - 1, 2) for cc in range(cols)]
+            for a, b in pairs:
+                c.any(a, b, unitary=gates[k])
+                k += 1
+        return c.amplitude_before("0" * (rows * cols))
+
+    t0 = time.perf_counter()
+    dc = DistributedContractor(nodes_fn, None, cotengra_options={
+        "slicing_opts": {"target_size": 2 ** args.rqc_log2_target}, "max_repeats": 128})
+    search_s = time.perf_counter() - t0
+    v = dc.value(None, op=lambda x: x)          # staging run
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    v = dc.value(None, op=lambda x: x)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t = time.perf_counter() - t0
+    tree = dc.tree
+    flops = float(tree.total_flops()) * tree.nslices
+    return {
+        "workload": f"32-qubit 4x8 random circuit depth {depth}, amplitude <0|C|0>, complex64, sliced to "
+                    f"2^{args.rqc_log2_target} elements (SURVEY 8d config 4)",
+        "nslices": int(tree.nslices), "slices_per_gpu": int(-(-tree.nslices // world)),
+        "contraction_width": float(tree.contraction_width()), "log2_flops_total": float(np.log2(flops)),
+        "contract_s": t, "tflops": flops / t / 1e12, "path_search_s": round(search_s, 2),
+        "amplitude": [float(v.real), float(v.imag)],
+    }
+
+
+def _guard(name, fn, *a):
+    """Secondary legs must never take the headline line down with them."""
+    try:
+        return fn(*a)
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{name}: {type(e).__name__}: {e}"[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,6 +268,8 @@ def main():
     ap.add_argument("--mps-qubits", type=int, default=64, help="MPS TEBD leg (config 5): qubits; 0 disables the leg")
     ap.add_argument("--mps-chi", type=int, default=128)
     ap.add_argument("--mps-sweeps", type=int, default=2)
+    ap.add_argument("--rqc-depth", type=int, default=16, help="config 4 leg (32-qubit RQC amplitude): depth; 0 disables")
+    ap.add_argument("--rqc-log2-target", type=int, default=27)
     ap.add_argument("--contractor", default="greedy",
                     help="greedy/auto: cost model picks the contraction order; plain: state-vector plan; cut: cut contraction")
     ap.add_argument("--lowbits", type=int, default=None)
@@ -307,7 +369,11 @@ def main():
 
     vqe = None
     if args.vqe_qubits:
-        vqe = vqe_leg(tc, torch, dist, args, rank, world, dev)
+        vqe = _guard("vqe_step", vqe_leg, tc, torch, dist, args, rank, world, dev)
+    rqc = None
+    if args.rqc_depth:
+        torch.cuda.empty_cache()
+        rqc = _guard("rqc_amplitude", rqc_leg, tc, torch, dist, args, rank, world)
 
     if rank == 0:
         amps = float(world) * B * (2**n) * args.steps
@@ -376,8 +442,10 @@ def main():
         }
         if vqe is not None:
             out["vqe_step"] = vqe
+        if rqc is not None:
+            out["rqc_amplitude"] = rqc
         if args.mps_qubits > 0 and world == 1:
-            out["mps_tebd"] = mps_leg(tc, torch, args)
+            out["mps_tebd"] = _guard("mps_tebd", mps_leg, tc, torch, args)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_qubits, d, seed=n)
         print(json.dumps(out))

@@ -4,7 +4,7 @@
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$1
 rm -rf $OUT; mkdir -p $OUT
-ARGS="--steps 5 --warmup 2 --no-cpu-baseline ${@:2}"
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --rqc-depth 0 ${@:2}"
 run() {  # name, rocprof flags...
   name=$1; shift
   rocprofv3 "$@" --output-format csv -d $OUT/$name -o bench -- python3 bench.py $ARGS > $OUT/$name.log 2>&1

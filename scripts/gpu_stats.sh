@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/stats_$1
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --vqe-qubits 0 --mps-qubits 0 ${@:2} > $OUT/run.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --vqe-qubits 0 --mps-qubits 0 --rqc-depth 0 ${@:2} > $OUT/run.log 2>&1
 tail -1 $OUT/run.log | cut -c1-200
 python3 - <<PY
 import csv, glob
