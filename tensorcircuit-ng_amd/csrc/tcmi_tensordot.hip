@@ -173,6 +173,56 @@ __global__ void cgemm_simple_kernel(const typename Cx<F>::type* __restrict__ A,
   }
 }
 
+// Small output, long contraction (M N < 1024, K large: the closing steps of a sliced network reduce two
+// big tensors to a few numbers).  Split-K: a workgroup owns a K chunk, its 256 threads are
+// (k-lane, output slot) pairs, partial sums are reduced through LDS and added to the zero-initialised
+// C with float atomics.
+template <typename F>
+__global__ __launch_bounds__(256) void cgemm_splitk_kernel(const typename Cx<F>::type* __restrict__ A,
+                                                           const typename Cx<F>::type* __restrict__ B,
+                                                           typename Cx<F>::type* __restrict__ C, long long M,
+                                                           long long N, long long K, long long sA, long long sB,
+                                                           long long sC, int trans_a, long long kchunk, int to_log2) {
+  using Ct = typename Cx<F>::type;
+  __shared__ F red_re[256], red_im[256];
+  A += (long long)blockIdx.z * sA;
+  B += (long long)blockIdx.z * sB;
+  C += (long long)blockIdx.z * sC;
+  const int TO = 1 << to_log2, KL = 256 >> to_log2;
+  const int o = threadIdx.x & (TO - 1), kl = threadIdx.x >> to_log2;
+  const long long k0 = (long long)blockIdx.x * kchunk;
+  const long long k1 = k0 + kchunk < K ? k0 + kchunk : K;
+  const long long total = M * N;
+  for (long long base = 0; base < total; base += TO) {
+    const long long oo = base + o;
+    F re = 0, im = 0;
+    if (oo < total) {
+      const long long r = oo / N, c = oo - r * N;
+      for (long long k = k0 + kl; k < k1; k += KL) {
+        const Ct a = trans_a ? A[k * M + r] : A[r * K + k];
+        const Ct b = B[k * N + c];
+        re = fma_<F>(a.x, b.x, re);
+        re = fma_<F>(-a.y, b.y, re);
+        im = fma_<F>(a.x, b.y, im);
+        im = fma_<F>(a.y, b.x, im);
+      }
+    }
+    red_re[threadIdx.x] = re;
+    red_im[threadIdx.x] = im;
+    __syncthreads();
+    if (kl == 0 && oo < total) {
+      F sr = 0, si = 0;
+      for (int j = 0; j < KL; ++j) {
+        sr += red_re[j * TO + o];
+        si += red_im[j * TO + o];
+      }
+      atomicAdd(&C[oo].x, sr);
+      atomicAdd(&C[oo].y, si);
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace tcmi
 
 extern "C" int tcmi_set_error_(int code, const char* msg);
@@ -218,6 +268,27 @@ int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, 
       hipLaunchKernelGGL(tcmi::cgemm_mfma_kernel<false>, grid, block, 0, st, reinterpret_cast<const float2*>(A),
                          reinterpret_cast<const float2*>(B), reinterpret_cast<float2*>(C), (int)M, (int)N, (int)K,
                          strideA, strideB, strideC);
+  } else if (M * N < 1024 && K >= 2048 && (dtype == TCMI_C64 || dtype == TCMI_C128)) {
+    const long long total = M * N;
+    int to_log2 = 0;
+    while ((1 << to_log2) < total && to_log2 < 8) ++to_log2;
+    long long kchunk = (K + 4095) / 4096;
+    if (kchunk < 1024) kchunk = 1024;
+    const long long chunks = (K + kchunk - 1) / kchunk;
+    const size_t esz = dtype == TCMI_C64 ? 8 : 16;
+    for (int b = 0; b < batch; ++b) {
+      hipError_t me = hipMemsetAsync(reinterpret_cast<char*>(C) + (size_t)b * strideC * esz, 0, (size_t)total * esz, st);
+      if (me != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(me));
+    }
+    dim3 grid((unsigned)chunks, 1, (unsigned)batch), block(256, 1, 1);
+    if (dtype == TCMI_C64)
+      hipLaunchKernelGGL(tcmi::cgemm_splitk_kernel<float>, grid, block, 0, st, reinterpret_cast<const float2*>(A),
+                         reinterpret_cast<const float2*>(B), reinterpret_cast<float2*>(C), M, N, K, strideA, strideB,
+                         strideC, trans_a, kchunk, to_log2);
+    else
+      hipLaunchKernelGGL(tcmi::cgemm_splitk_kernel<double>, grid, block, 0, st, reinterpret_cast<const double2*>(A),
+                         reinterpret_cast<const double2*>(B), reinterpret_cast<double2*>(C), M, N, K, strideA,
+                         strideB, strideC, trans_a, kchunk, to_log2);
   } else {
     const long long total = M * N;
     unsigned gx = (unsigned)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);

@@ -33,7 +33,10 @@ def test_permute_and_tensordot_kernels(tcd):
         assert torch.equal(got, t.permute(*perm).contiguous())
     tol = 1e-4 if tc.dtypestr == "complex64" else 1e-11
     for ra, rb, xa, xb in [(2, 2, [1], [0]), (4, 6, [3, 0], [1, 4]), (10, 9, [9, 2, 4, 0], [0, 8, 3, 5]),
-                           (14, 14, list(range(7, 14)), list(range(7))), (8, 8, [], []), (5, 5, [0, 1, 2, 3, 4], [4, 3, 2, 1, 0])]:
+                           (14, 14, list(range(7, 14)), list(range(7))), (8, 8, [], []), (5, 5, [0, 1, 2, 3, 4], [4, 3, 2, 1, 0]),
+                           # small output, long contraction (split-K kernel): scalar, 2x2 and 8x4 outputs
+                           (16, 16, list(range(16)), list(range(16))), (14, 14, list(range(1, 14)), list(range(13))),
+                           (17, 16, list(range(3, 17)), list(range(2, 16)))]:
         a = torch.randn([2] * ra, dtype=dt, device="cuda", generator=g)
         b = torch.randn([2] * rb, dtype=dt, device="cuda", generator=g)
         got = tn.tensordot(a, b, xa, xb)
