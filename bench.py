@@ -231,7 +231,7 @@ def rqc_leg(tc, torch, dist, args, rank, world):
         dist.barrier()
     t = time.perf_counter() - t0
     tree = dc.tree
-    flops = float(tree.total_flops()) * tree.nslices
+    flops = float(tree.total_flops())          # all slices (ContractionTree.total_flops includes nslices)
     return {
         "workload": f"32-qubit 4x8 random circuit depth {depth}, amplitude <0|C|0>, complex64, sliced to "
                     f"2^{args.rqc_log2_target} elements (SURVEY 8d config 4)",

@@ -56,8 +56,9 @@ def main():
                                                                  "max_repeats": 128})
     out["path_search_s"] = time.perf_counter() - t0
     tree = dc.tree
-    out.update(nslices=tree.nslices, width=tree.contraction_width(), log2_flops_per_slice=float(np.log2(tree.total_flops())),
-               log2_flops_total=float(np.log2(tree.total_flops() * tree.nslices)))
+    out.update(nslices=tree.nslices, width=tree.contraction_width(),
+               log2_flops_per_slice=float(np.log2(tree.total_flops() / tree.nslices)),
+               log2_flops_total=float(np.log2(tree.total_flops())))
     t0 = time.perf_counter()
     v = dc.value(None, op=lambda x: x)
     torch.cuda.synchronize()
@@ -66,7 +67,7 @@ def main():
     v = dc.value(None, op=lambda x: x)
     torch.cuda.synchronize()
     t = time.perf_counter() - t0
-    out.update(contract_s=t, tflops=tree.total_flops() * tree.nslices / t / 1e12, amplitude=[float(v.real), float(v.imag)],
+    out.update(contract_s=t, tflops=tree.total_flops() / t / 1e12, amplitude=[float(v.real), float(v.imag)],
                peak_mem_GiB=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1))
     if os.environ.get("RQC_CHECK", "1") == "1":
         logt2 = int(os.environ.get("RQC_LOG2_CHECK", 30))
