@@ -270,6 +270,7 @@ def main():
     ap.add_argument("--mps-sweeps", type=int, default=2)
     ap.add_argument("--rqc-depth", type=int, default=16, help="config 4 leg (32-qubit RQC amplitude): depth; 0 disables")
     ap.add_argument("--rqc-log2-target", type=int, default=27)
+    ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph replay measurement")
     ap.add_argument("--contractor", default="greedy",
                     help="greedy/auto: cost model picks the contraction order; plain: state-vector plan; cut: cut contraction")
     ap.add_argument("--lowbits", type=int, default=None)
@@ -356,6 +357,27 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     cc.gemm_events = cc.pass_events = None
+    # the same step replayed from a hipGraph (launch overhead removed); reported next to the eager figure
+    graph_info = None
+    if not args.no_graph:
+        try:
+            from tcmi.executor import GraphedState
+
+            gs = GraphedState(cc, B)
+            for _ in range(args.warmup):
+                gs(pmat)
+            sync()
+            tg0 = time.perf_counter()
+            for _ in range(args.steps):
+                gs(pmat)
+            sync()
+            tg = time.perf_counter() - tg0
+            same = bool(torch.allclose(gs.out, state, atol=1e-6, rtol=0))
+            graph_info = {"ms_per_step": tg / args.steps * 1e3, "amplitudes_per_s_per_gpu": B * (2**n) * args.steps / tg,
+                          "matches_eager": same}
+            del gs
+        except Exception as e:  # noqa: BLE001
+            graph_info = {"error": f"{type(e).__name__}: {e}"[:200]}
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -440,6 +462,8 @@ def main():
             },
             "roofline": roof,
         }
+        if graph_info is not None:
+            out["hipgraph_replay"] = graph_info
         if vqe is not None:
             out["vqe_step"] = vqe
         if rqc is not None:

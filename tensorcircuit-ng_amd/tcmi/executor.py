@@ -550,6 +550,38 @@ class CutCircuit:
                 "bytes": item * (self.K * (M + N) + M * N), "flops": 8.0 * M * N * self.K}
 
 
+class GraphedState:
+    """One wavefunction evaluation (table build + every pass / GEMM launch) captured in a hipGraph
+    (``torch.cuda.CUDAGraph``) and replayed: the launch-bound regime (small batches: ~25 launches for
+    < 1 ms of kernels) pays one graph launch instead of a host round trip per kernel.  Static
+    buffers: ``params`` [B, P] in, ``out`` [B, 2^n] out; ``__call__(params)`` copies into the static
+    input and replays.  Works for ``CompiledCircuit`` and ``CutCircuit`` (anything with ``.state``)."""
+
+    def __init__(self, cc, batch: int):
+        import torch
+
+        self.cc, self.batch = cc, batch
+        npar = max(1, getattr(cc, "nparams", 1))
+        self.params = torch.zeros(batch, npar, dtype=cc.rdtype, device=cc.device)
+        self.out = torch.empty(batch, 2**cc.n_exec, dtype=cc.tdtype, device=cc.device)
+        cur = torch.cuda.current_stream(cc.device)
+        side = torch.cuda.Stream(device=cc.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):            # warm-up outside capture (lazy allocations, caches)
+            for _ in range(2):
+                cc.state(self.params, out=self.out)
+        cur.wait_stream(side)
+        torch.cuda.synchronize(cc.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            cc.state(self.params, out=self.out)
+
+    def __call__(self, params):
+        self.params.copy_(params.reshape(self.batch, -1)[:, : self.params.shape[1]])
+        self.graph.replay()
+        return self.out
+
+
 _CACHE: Dict[Tuple, CompiledCircuit] = {}
 
 
