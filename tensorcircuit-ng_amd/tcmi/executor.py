@@ -375,7 +375,7 @@ def get_measure(n, n_exec, strings, dtypestr) -> CompiledMeasure:
 
 # ---- cost model (microseconds per 2^24 amplitudes, fitted on MI355X: profiles/r01b) -------------------
 VM_COST = {"pass": 19.5, "g1": 2.25, "g2": 9.0, "diag": 11.5, "exchange": 10.75}
-GEMM_TFLOPS = 95.0  # tcmi_cgemm on 4096 x 256 x 4096 (scripts/gpu_tn_bench.py)
+GEMM_TFLOPS = 140.0  # tcmi_cgemm, batched cut join (3-product kernel, algorithmic flops; profiles/r01h)
 
 
 def vm_cost_us(plan: "P.CompiledPlan") -> float:
@@ -630,7 +630,7 @@ def _maybe_cut(cc, n, gates, nparams, dtypestr, opts):
         return cc
     t_vm = vm_cost_us(cc.plan)
     t_gemm = 8.0 * 2.0**n * best.bond_dim / (GEMM_TFLOPS * 1e6)      # microseconds
-    t_halves = 2 * 40.0 + best.bond_dim * 2.0 ** max(best.n_left, n - best.n_left) / 2.0**24 * 400.0
+    t_halves = 2 * 40.0 + best.bond_dim * 2.0 ** max(best.n_left, n - best.n_left) / 2.0**24 * 200.0  # two-level
     if method == "cut" or (t_gemm + t_halves) < 0.7 * t_vm:
         return CutCircuit(n, gates, nparams, dtypestr, opts, best, cc)
     return cc

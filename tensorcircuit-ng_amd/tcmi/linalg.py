@@ -11,6 +11,7 @@ from typing import Any, Dict, Optional, Tuple
 from . import _lib
 
 _WORK: Dict[Any, Any] = {}
+_CHECK_SVD = __import__("os").environ.get("TCMI_CHECK_SVD", "0") == "1"
 
 
 def _code(t):
@@ -113,6 +114,20 @@ def _svd_rows(mat, kmax, max_sv, max_err, relative, absorb):
     return u, s, vh, keep, tw2
 
 
+def last_svd_status(device=None) -> int:
+    """0 if the most recent SVD launch on ``device`` completed normally, 1 if its inter-workgroup barrier
+    timed out (results invalid).  Synchronises; meant for tests and debugging (``TCMI_CHECK_SVD=1`` makes
+    every ``svd_trunc`` call check it and raise)."""
+    import torch
+
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    w = _WORK.get(("svd", device))
+    if w is None:
+        return 0
+    return int(w[4:8].view(torch.int32).item())
+
+
 def svd_trunc(mat, max_singular_values: Optional[int] = None, max_truncation_err: Optional[float] = None,
               relative: bool = False, absorb: int = 0) -> Tuple[Any, Any, Any, Any]:
     """``backend.svd(mat, pivot_axis=1, ...)`` with the reference truncation rule.  Returns
@@ -130,6 +145,8 @@ def svd_trunc(mat, max_singular_values: Optional[int] = None, max_truncation_err
         sw = {0: 0, 1: 2, 2: 1}[absorb]
         u2, s, vh2, keep, _ = _svd_rows(mat.t(), static_keep, max_singular_values, max_truncation_err, relative, sw)
         u, vh = vh2.t().contiguous(), u2.t().contiguous()
+    if _CHECK_SVD and last_svd_status(mat.device) != 0:
+        raise _lib.TcmiError("tcmi_svd_trunc_batched: inter-workgroup barrier timed out")
     kk = static_keep
     if max_truncation_err is not None:
         kk = int(keep.item())

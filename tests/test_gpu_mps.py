@@ -43,6 +43,7 @@ def test_svd_matches_lapack(dt, shape):
     k = min(shape)
     np.testing.assert_allclose(u.conj().T @ u, np.eye(k), atol=4 * TOL[dt] * 10)
     np.testing.assert_allclose(vh @ vh.conj().T, np.eye(k), atol=4 * TOL[dt] * 10)
+    assert LA.last_svd_status() == 0
 
 
 @pytest.mark.parametrize("dt", ["complex64", "complex128"])
