@@ -211,3 +211,52 @@ def test_backend_svd_qr_rq_route_to_hip_kernels():
         np.testing.assert_allclose(sr.cpu().numpy(), np.linalg.svd(x, compute_uv=False), atol=1e-10)
     finally:
         tc.set_dtype("complex64")
+
+
+@pytest.mark.parametrize("dt", ["complex64", "complex128"])
+def test_batched_svd_and_qr_through_the_abi(dt):
+    """The batch argument of tcmi_svd_trunc_batched / tcmi_qr_batched (independent matrices along
+    blockIdx.y, one barrier counter each), called through ctypes directly."""
+    from tcmi import _lib
+
+    lib = _lib.lib()
+    code = _lib.TCMI_C64 if dt == "complex64" else _lib.TCMI_C128
+    rdt = torch.float32 if dt == "complex64" else torch.float64
+    rng = np.random.default_rng(11)
+    B, m, n, kmax = 5, 24, 40, 10
+    a = (rng.normal(size=(B, m, n)) + 1j * rng.normal(size=(B, m, n))).astype(dt)
+    ag = torch.from_numpy(a).cuda()
+    u = torch.empty((B, m, kmax), dtype=ag.dtype, device="cuda")
+    s = torch.empty((B, m), dtype=rdt, device="cuda")
+    vh = torch.empty((B, kmax, n), dtype=ag.dtype, device="cuda")
+    keep = torch.empty((B,), dtype=torch.int32, device="cuda")
+    tw2 = torch.empty((B,), dtype=rdt, device="cuda")
+    nbytes = lib.tcmi_svd_work_bytes(m, n, B, code)
+    work = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.tcmi_svd_trunc_batched(ag.data_ptr(), u.data_ptr(), s.data_ptr(), vh.data_ptr(), keep.data_ptr(),
+                                          tw2.data_ptr(), m, n, kmax, B, kmax, -1.0, 0, 1, 0, work.data_ptr(), nbytes,
+                                          code, st), "svd")
+    torch.cuda.synchronize()
+    tol = TOL[dt] * 50
+    for b in range(B):
+        uo, so, vho, rest = omps.svd_trunc(a[b].astype(np.complex128), kmax)
+        np.testing.assert_allclose(s[b].cpu().numpy(), np.linalg.svd(a[b].astype(np.complex128), compute_uv=False),
+                                   atol=tol)
+        np.testing.assert_allclose(u[b].cpu().numpy() @ vh[b].cpu().numpy(), (uo * so) @ vho, atol=tol * 4)
+        assert int(keep[b]) == kmax
+        np.testing.assert_allclose(float(tw2[b]), float(np.sum(np.abs(rest) ** 2)), rtol=1e-3, atol=tol)
+    mq, nq = 18, 7
+    aq = (rng.normal(size=(B, mq, nq)) + 1j * rng.normal(size=(B, mq, nq))).astype(dt)
+    aqg = torch.from_numpy(aq).cuda()
+    q = torch.empty((B, mq, nq), dtype=aqg.dtype, device="cuda")
+    r = torch.empty((B, nq, nq), dtype=aqg.dtype, device="cuda")
+    nb2 = lib.tcmi_qr_work_bytes(mq, nq, B, code)
+    work2 = torch.empty(nb2, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.tcmi_qr_batched(aqg.data_ptr(), q.data_ptr(), r.data_ptr(), mq, nq, B, work2.data_ptr(), nb2, code, st),
+               "qr")
+    torch.cuda.synchronize()
+    for b in range(B):
+        qq, rr = q[b].cpu().numpy(), r[b].cpu().numpy()
+        np.testing.assert_allclose(qq @ rr, aq[b], atol=tol)
+        np.testing.assert_allclose(qq.conj().T @ qq, np.eye(nq), atol=tol)
