@@ -21,6 +21,10 @@
 
 namespace tcmi {
 
+// convergence: a pair is rotated while |<x,y>| > TCMI_SVD_TOL_SCALE * sqrt(q) * eps * |x| |y|
+#ifndef TCMI_SVD_TOL_SCALE
+#define TCMI_SVD_TOL_SCALE 1.0
+#endif
 constexpr int SVD_CTL_WORDS = 64;     // [0] barrier counter, [1] error flag, [2..] rotations per sweep
 constexpr int SVD_MAX_SWEEPS = 60;
 constexpr unsigned SPIN_LIMIT = 1u << 21;
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(64 * B) void svd_block_kernel(
   }
   if (!grid_barrier(ctl, nwg, epoch, &s_dead)) return;
 
-  const F tol2 = Eps<F>::v * Eps<F>::v * (F)q;
+  const F tol2 = Eps<F>::v * Eps<F>::v * (F)q * (F)(TCMI_SVD_TOL_SCALE * TCMI_SVD_TOL_SCALE);
   const int M = NB - 1;
   if (max_sweeps > SVD_MAX_SWEEPS) max_sweeps = SVD_MAX_SWEEPS;
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
