@@ -190,6 +190,31 @@ class LazyExpectation:
         a = cons.backend.numpy(self.materialize())
         return a.astype(dtype) if dtype is not None else a
 
+    # every other arithmetic / indexing operator acts on the materialised tensor
+    def __pow__(self, o):
+        return self.materialize() ** (o.materialize() if isinstance(o, LazyExpectation) else o)
+
+    def __rpow__(self, o):
+        return o ** self.materialize()
+
+    def __rtruediv__(self, o):
+        return o / self.materialize()
+
+    def __abs__(self):
+        return abs(self.materialize())
+
+    def __getitem__(self, k):
+        return self.materialize()[k]
+
+    def __matmul__(self, o):
+        return self.materialize() @ o
+
+    def __le__(self, o):
+        return self.materialize() <= o
+
+    def __ge__(self, o):
+        return self.materialize() >= o
+
     def __float__(self):
         return float(self.materialize().real)
 

@@ -20,7 +20,10 @@ def torch_interface(fun: Callable[..., Any], jit: bool = False, enable_dlpack: b
     def wrapped(*args: Any, **kws: Any) -> Any:
         dev = cons.backend.device
         moved = [a.to(dev) if torch.is_tensor(a) and a.device != dev else a for a in args]
-        return fun(*moved, **kws)
+        from ..expectation import resolve
+
+        # lazily fused expectation sums become plain tensors at the torch boundary
+        return torch.utils._pytree.tree_map(resolve, fun(*moved, **kws))
 
     wrapped.__name__ = getattr(fun, "__name__", "torch_interface_fn")
     return wrapped
