@@ -559,6 +559,34 @@ class MPSCircuit:
             value = value / np.sqrt(n1 * n2)
         return value
 
+    def measure(self, *index, with_prob=False, status=None):
+        """mpscircuit.py:1061-1115 with the ``status`` branch of ``backend.probability_sample``
+        (abstract_backend.py:1849-1861): outcome = searchsorted(cumsum(p), status_k)."""
+        mps = self.copy()
+        p = 1.0
+        sample = []
+        for k, site in enumerate(index):
+            mps.position(site)
+            t = mps._mps.tensors[site]
+            ps = np.real(np.einsum("iaj,iaj->a", t, t.conj()))
+            ps = ps / np.sum(ps)
+            cum = np.cumsum(ps)
+            r = cum[-1] * float(status[k])
+            outcome = int(np.searchsorted(cum, r))
+            p = p * ps[outcome]
+            mps._mps.tensors[site] = t[:, outcome, :][:, None, :]
+            sample.append(outcome)
+        return np.array(sample, dtype=np.float64), (p if with_prob else -1.0)
+
+    def reduced_density_matrix(self, keep):
+        """mpscircuit.py:1117-1240 (dense restatement through the wavefunction)."""
+        n = self._nqubits
+        w = self.wavefunction().reshape([2] * n)
+        keep = list(keep)
+        rest = [i for i in range(n) if i not in keep]
+        m = np.transpose(w, keep + rest).reshape(2 ** len(keep), -1)
+        return m @ m.conj().T
+
     def expectation_ps(self, x=None, y=None, z=None, **kw):
         """abstractcircuit.py:1523-1603 (Pauli-string shortcut)."""
         ops = []

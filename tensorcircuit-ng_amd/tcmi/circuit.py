@@ -296,6 +296,86 @@ class Circuit:
             idx = (idx << 1) | b
         return self.wavefunction()[..., idx]
 
+    # ---- sampling (reference basecircuit.py:449-558, 1403-1512) -------------------
+    def probability(self) -> Tensor:
+        """reference basecircuit.py ``probability``: |psi|^2 in the computational basis."""
+        psi = self.wavefunction()
+        return psi.real ** 2 + psi.imag ** 2
+
+    def measure(self, *index: int, with_prob: bool = False, status: Optional[Tensor] = None):
+        """Sequential z-basis measurement of the given qubits (reference ``measure_jit``,
+        basecircuit.py:449-558).  The state comes from the HIP plan; the conditional marginals are
+        reductions of |psi|^2.  ``status``: one uniform number per measured qubit, consumed with the
+        ``backend.probability_sample`` rule (abstract_backend.py:1849-1861)."""
+        import torch
+
+        n = self._nqubits
+        idx = [int(i) % n for i in index]
+        cur = self.probability().to(torch.float64).reshape([2] * n)
+        if status is None:
+            status = cons.backend.implicit_randu(shape=[len(idx)])
+        st = cons.backend.numpy(cons.backend.convert_to_tensor(status)).reshape(-1)
+        rdt = torch.float32 if cons.rdtypestr == "float32" else torch.float64
+        prob = torch.ones((), dtype=torch.float64, device=cur.device)
+        outcomes = []
+        for k, site in enumerate(idx):
+            other = [a for a in range(n) if a != site]
+            ps = cur.sum(dim=other) if other else cur
+            ps = ps / ps.sum()
+            cum = torch.cumsum(ps, 0)
+            r = cum[-1] * float(st[k])
+            outcome = int(torch.searchsorted(cum, r).clamp(max=1).item())
+            prob = prob * ps[outcome]
+            cur = cur.narrow(site, outcome, 1)
+            outcomes.append(outcome)
+        sample = torch.tensor(outcomes, dtype=rdt, device=cur.device)
+        return (sample, prob.to(rdt)) if with_prob else (sample, -1.0)
+
+    measure_jit = measure
+
+    def perfect_sampling(self, status: Optional[Tensor] = None):
+        """reference basecircuit.py ``perfect_sampling``: one shot over all qubits, (bits, probability)."""
+        return self.measure(*range(self._nqubits), with_prob=True, status=status)
+
+    def sample(self, batch: Optional[int] = None, allow_state: bool = False, readout_error: Any = None,
+               format: Optional[str] = None, random_generator: Any = None, status: Optional[Tensor] = None,
+               jittable: bool = True) -> Any:
+        """reference basecircuit.py:1403-1512 (readout error is outside the hot path)."""
+        import torch
+        from .quantum import sample2all
+
+        if readout_error is not None:
+            raise NotImplementedError("Backend 'hip' has not implemented readout_error in sample.")
+        n = self._nqubits
+        if not allow_state:
+            if batch is None:
+                r = self.perfect_sampling(status)
+                if format is None:
+                    return r
+                rs = [r]
+            else:
+                if status is None:
+                    status = cons.backend.implicit_randu(shape=[batch, n])
+                st = cons.backend.convert_to_tensor(status)
+                assert st.shape[0] == batch
+                rs = [self.perfect_sampling(st[i]) for i in range(batch)]
+                if format is None:
+                    return rs
+            ch = torch.stack([ri[0] for ri in rs]).to(torch.int32)
+        else:
+            nbatch = 1 if batch is None else batch
+            p = self.probability().to(torch.float64)
+            if status is None:
+                status = cons.backend.implicit_randu(shape=[nbatch])
+            u = cons.backend.convert_to_tensor(status).to(torch.float64).reshape(-1)
+            cum = torch.cumsum(p / p.sum(), 0)
+            ch = torch.searchsorted(cum, (cum[-1] * (1 - u)).contiguous()).clamp(max=p.numel() - 1)
+            if format is None:
+                bits = (ch.unsqueeze(-1) >> torch.arange(n - 1, -1, -1, device=ch.device)) & 1
+                r = list(zip(bits, p[ch]))
+                return r[0] if batch is None else r
+        return sample2all(ch, n, format=format)
+
     def expectation(self, *ops: Tuple[Any, List[int]], reuse: bool = True, **kws: Any) -> Tensor:
         """reference circuit.py:833-913 (noise-free branch): complex scalar <psi| prod ops |psi>."""
         from .functional import circuit_expectation

@@ -644,6 +644,115 @@ class MPSCircuit:
             value = value / (n1 * n2).sqrt()
         return value
 
+    # ---- sampling and reduced states (reference :1061-1288) -------------------------------------------
+    def measure(self, *index: int, with_prob: bool = False, status: Optional[Tensor] = None):
+        """z-basis measurement of the given sites, one after the other on a copy of the MPS (the centre is
+        moved to the site, its tensor projected on the outcome).  ``status`` (one uniform number per site)
+        makes it deterministic, with the ``backend.probability_sample`` rule of the reference
+        (abstract_backend.py:1849-1861): outcome = searchsorted(cumsum(p), status_k)."""
+        torch = _torch()
+        mps = self.copy()
+        rdt = torch.float32 if cons.rdtypestr == "float32" else torch.float64
+        if status is None:
+            status = cons.backend.implicit_randu(shape=[len(index)])
+        st = cons.backend.numpy(cons.backend.convert_to_tensor(status)).reshape(-1)
+        p = torch.ones((), dtype=rdt, device=_device())
+        outcomes = []
+        for k, site in enumerate(index):
+            mps.position(site)
+            t = mps._mps.tensors[site]
+            ps = (t.real ** 2 + t.imag ** 2).sum(dim=(0, 2)).to(rdt)
+            ps = ps / ps.sum()
+            cum = torch.cumsum(ps, 0)
+            r = cum[-1] * float(st[k])
+            outcome = int(torch.searchsorted(cum, r).clamp(max=1).item())
+            p = p * ps[outcome]
+            mps._mps.tensors[site] = t[:, outcome, :].unsqueeze(1).contiguous()
+            outcomes.append(outcome)
+        sample = torch.tensor(outcomes, dtype=rdt, device=_device())
+        return (sample, p) if with_prob else (sample, -1.0)
+
+    def reduced_density_matrix(self, subsystem_to_keep: Optional[Sequence[int]] = None, *,
+                               subsystems_to_trace_out: Optional[Sequence[int]] = None) -> Tensor:
+        """rho over ``subsystem_to_keep`` (indices in the caller's order).  Contiguous subsystems use the
+        canonical form (centre moved inside: the environments are identities); otherwise the whole chain
+        is contracted, tracing the other sites.  Every contraction is a ``tcmi_cgemm``."""
+        torch = _torch()
+        n = self._nqubits
+        if (subsystem_to_keep is None) == (subsystems_to_trace_out is None):
+            raise ValueError("MPSCircuit.reduced_density_matrix: give exactly one of subsystem_to_keep / "
+                             "subsystems_to_trace_out")
+        if subsystem_to_keep is None:
+            tr = {int(i) % n for i in subsystems_to_trace_out}
+            keep = [i for i in range(n) if i not in tr]
+        else:
+            keep = [int(i) % n for i in subsystem_to_keep]
+        if not keep:
+            raise ValueError("Must keep at least one qubit index.")
+        ks = sorted(keep)
+        contiguous = all(ks[i + 1] - ks[i] == 1 for i in range(len(ks) - 1))
+        if contiguous:
+            cp = self._mps.center_position
+            if cp is None or cp < ks[0]:
+                self.position(ks[0])
+            elif cp > ks[-1]:
+                self.position(ks[-1])
+            sites = ks
+        else:
+            sites = list(range(n))
+        # R[x, y, j, k]: x / y = kept physical indices of ket / bra, j / k = open right bonds
+        first = self._mps.tensors[sites[0]]
+        l0 = first.shape[0]
+        eye = torch.eye(l0, dtype=first.dtype, device=first.device)
+        R = eye.reshape(1, 1, l0, l0)
+        for i in sites:
+            t = self._mps.tensors[i]
+            tc_ = t.conj().resolve_conj()
+            if i in ks:
+                tmp = LA.einsum2("xyjk,jcl->xykcl", R, t)
+                R = LA.einsum2("xykcl,kdm->xcydlm", tmp, tc_)
+                x, c, y, d, l, m = R.shape
+                R = R.reshape(x * c, y * d, l, m)
+            else:
+                tmp = LA.einsum2("xyjk,jcl->xykcl", R, t)
+                x, y, k, c, l = tmp.shape
+                R = LA.matmul(tmp.permute(0, 1, 4, 2, 3).reshape(x * y * l, k * c),
+                              tc_.reshape(k * c, -1)).reshape(x, y, l, -1)
+        rho = torch.diagonal(R, dim1=2, dim2=3).sum(-1)
+        nk = len(keep)
+        if keep != ks:
+            order = {v: i for i, v in enumerate(ks)}
+            perm = [order[q] for q in keep] + [nk + order[q] for q in keep]
+            rho = rho.reshape([2] * (2 * nk)).permute(perm).reshape(2 ** nk, 2 ** nk)
+        return rho.contiguous()
+
+    def sample(self, batch: Optional[int] = None, allow_state: bool = False, readout_error: Any = None,
+               format: Optional[str] = None, random_generator: Any = None, status: Optional[Tensor] = None,
+               jittable: bool = True) -> Any:
+        """reference :1241-1288: ``batch`` independent full measurements; formats of ``quantum.sample2all``."""
+        from .quantum import sample2all
+
+        torch = _torch()
+        if allow_state:
+            raise ValueError("MPSCircuit.sample does not support allow_state=True")
+        n = self._nqubits
+        if batch is None:
+            if status is None:
+                status = cons.backend.implicit_randu(shape=[n])
+            r = self.measure(*range(n), status=status)[0]
+            if format is None:
+                return r
+            ch = r.reshape(1, -1).to(torch.int32)
+        else:
+            if status is None:
+                status = cons.backend.implicit_randu(shape=[batch, n])
+            st = cons.backend.convert_to_tensor(status)
+            r = torch.stack([self.measure(*range(n), status=st[i])[0] for i in range(batch)])
+            if format is None:
+                return r
+            ch = r.to(torch.int32)
+        return sample2all(ch, n, format=format)
+
     def expectation_ps(self, x: Optional[Sequence[int]] = None, y: Optional[Sequence[int]] = None,
                        z: Optional[Sequence[int]] = None, **kws: Any) -> Tensor:
         """reference abstractcircuit.py:1523-1603."""

@@ -98,3 +98,63 @@ def PauliStringSum2MVP(structures: Sequence[Sequence[int]], weights: Sequence[fl
         return lambda psi: cons.backend.zeros_like(psi)
     h = PauliSum(structures, weights)
     return h.matvec
+
+
+def sample2all(sample: Tensor, n: int, format: str = "count_vector", jittable: bool = False, dim: Optional[int] = None) -> Any:
+    """reference quantum.py ``sample2all``: convert ``sample_int`` ([shots]) or ``sample_bin`` ([shots, n])
+    results to ``sample_int | sample_bin | count_vector | count_tuple | count_dict_bin | count_dict_int``."""
+    import torch
+    from collections import Counter
+
+    s = cons.backend.convert_to_tensor(sample)
+    if s.dim() == 2:
+        sample_bin = s.to(torch.int64)
+        if n > 62:
+            if format == "sample_bin":
+                return sample_bin
+            if format == "count_dict_bin":
+                return dict(Counter("".join(str(int(v)) for v in shot) for shot in sample_bin.cpu().tolist()))
+            raise ValueError(f"n={n} is too large for measurement representaion: {format}")
+        w = (2 ** torch.arange(n - 1, -1, -1, device=s.device, dtype=torch.int64))
+        sample_int = (sample_bin * w).sum(-1)
+    elif s.dim() == 1:
+        sample_int = s.to(torch.int64)
+        sample_bin = (sample_int.unsqueeze(-1) >> torch.arange(n - 1, -1, -1, device=s.device, dtype=torch.int64)) & 1
+    else:
+        raise ValueError("unrecognized tensor shape for sample")
+    if format == "sample_int":
+        return sample_int
+    if format == "sample_bin":
+        return sample_bin
+    vals, counts = torch.unique(sample_int, return_counts=True)
+    if format == "count_tuple":
+        return vals, counts
+    if format == "count_vector":
+        out = torch.zeros(2 ** n, dtype=torch.int64, device=s.device)
+        out[vals] = counts
+        return out
+    if format == "count_dict_bin":
+        return {format_bin(int(v), n): int(c) for v, c in zip(vals.cpu().tolist(), counts.cpu().tolist())}
+    if format == "count_dict_int":
+        return {int(v): int(c) for v, c in zip(vals.cpu().tolist(), counts.cpu().tolist())}
+    raise ValueError(f"unsupported format {format}")
+
+
+def format_bin(v: int, n: int) -> str:
+    return format(v, "0%db" % n)
+
+
+def reduced_density_matrix(state: Tensor, cut: Any, p: Optional[Tensor] = None) -> Tensor:
+    """reference quantum.py ``reduced_density_matrix`` for a pure state: trace out the qubits in ``cut`` (an
+    index list, or an int = the first ``cut`` qubits); the partial trace is one ``tcmi_cgemm``."""
+    import torch
+    from . import linalg as LA
+
+    psi = cons.backend.convert_to_tensor(state).reshape(-1)
+    n = int(round(np.log2(psi.numel())))
+    tr = list(range(cut)) if isinstance(cut, int) else [int(c) % n for c in cut]
+    keep = [i for i in range(n) if i not in tr]
+    m = psi.reshape([2] * n).permute(keep + tr).reshape(2 ** len(keep), -1).contiguous()
+    if p is not None:
+        m = m * cons.backend.cast(cons.backend.convert_to_tensor(p), cons.dtypestr).sqrt().reshape(1, -1)
+    return LA.matmul(m, m.conj().t().resolve_conj())

@@ -260,3 +260,46 @@ def test_batched_svd_and_qr_through_the_abi(dt):
         qq, rr = q[b].cpu().numpy(), r[b].cpu().numpy()
         np.testing.assert_allclose(qq @ rr, aq[b], atol=tol)
         np.testing.assert_allclose(qq.conj().T @ qq, np.eye(nq), atol=tol)
+
+
+def test_measure_sample_rdm_like_the_reference_mps_test():
+    """reference tests/test_mpscircuit.py:257-330 (do_test_measure / do_test_sample / do_test_rdm): with the
+    same ``status`` the MPS and the state-vector circuit measure the same bits with the same probability;
+    reduced density matrices (contiguous, non-contiguous, caller order) equal the dense ones."""
+    tc.set_dtype("complex128")
+    try:
+        ops = gate_list()
+        w_c = dense_state(ops)
+        m = _run(ops)
+        c = tc.Circuit(N)
+        for g, idx in ops:
+            c.any(*idx, unitary=np.asarray(g).reshape((2,) * (2 * len(idx))))
+        index = [6, 5, 2, 1]
+        status = tc.backend.convert_to_tensor(np.array([0.1, 0.3, 0.7, 0.9]))
+        rc = c.measure(*index, with_prob=True, status=status)
+        rm = m.measure(*index, with_prob=True, status=status)
+        ro = omps.MPSCircuit(N)
+        for g, idx in ops:
+            ro.apply(g, *idx)
+        so, po = ro.measure(*index, with_prob=True, status=[0.1, 0.3, 0.7, 0.9])
+        np.testing.assert_allclose(rm[0].cpu().numpy(), rc[0].cpu().numpy(), atol=1e-8)
+        np.testing.assert_allclose(float(rm[1]), float(rc[1]), atol=1e-8)
+        np.testing.assert_allclose(rm[0].cpu().numpy(), so, atol=1e-8)
+        np.testing.assert_allclose(float(rm[1]), po, atol=1e-8)
+        s = m.sample(batch=10, format="sample_bin")
+        assert len(s) == 10 and len(s[0]) == N
+        for keep in ([1, 2, 3], [1, 3, 5], [3, 1]):
+            rho = m.reduced_density_matrix(keep).cpu().numpy()
+            np.testing.assert_allclose(rho, ro.reduced_density_matrix(keep), atol=1e-10)
+        rho13 = m.reduced_density_matrix([1, 3]).cpu().numpy().reshape(2, 2, 2, 2)
+        rho31 = m.reduced_density_matrix([3, 1]).cpu().numpy().reshape(2, 2, 2, 2)
+        np.testing.assert_allclose(rho31, rho13.transpose(1, 0, 3, 2), atol=1e-12)
+        rho_c = tc.quantum.reduced_density_matrix(c.wavefunction(), [0, 4, 5, 6, 7]).cpu().numpy()
+        np.testing.assert_allclose(m.reduced_density_matrix([1, 2, 3]).cpu().numpy(), rho_c, atol=1e-10)
+        # state sampling: frequencies follow |psi|^2
+        cnt = c.sample(batch=4000, allow_state=True, format="count_vector").cpu().numpy()
+        p = np.abs(w_c) ** 2
+        assert np.abs(cnt / 4000.0 - p).max() < 0.05
+        assert len(c.sample(batch=3, allow_state=False, format="sample_bin")) == 3
+    finally:
+        tc.set_dtype("complex64")
