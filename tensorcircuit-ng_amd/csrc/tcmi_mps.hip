@@ -28,7 +28,6 @@ namespace tcmi {
 constexpr int SVD_CTL_WORDS = 64;     // [0] barrier counter, [1] error flag, [2..] rotations per sweep
 constexpr int SVD_MAX_SWEEPS = 60;
 constexpr unsigned SPIN_LIMIT = 1u << 21;
-constexpr long long SVD_LDS_MAX = 131072;  // of the 160 KiB per CU
 
 template <typename F>
 struct Eps;
@@ -794,16 +793,14 @@ struct SvdGeom {
 template <typename F>
 static SvdGeom svd_geom(int p, int q) {
   using Ct = typename Cx<F>::type;
-  // 16 rows per block (1024 threads, up to 128 KiB of LDS: opt-in above 64 KiB) halves the number of
-  // chip-wide rounds per sweep for the TEBD-sized matrices; smaller matrices use smaller blocks
-  int B = p >= 128 ? 16 : p >= 16 ? 8 : p >= 8 ? 4 : p >= 4 ? 2 : 1;
+  int B = p >= 16 ? 8 : p >= 8 ? 4 : p >= 4 ? 2 : 1;
   SvdGeom gm;
   for (;; B /= 2) {
     const int P2 = (p + 2 * B - 1) / (2 * B) * (2 * B);
     gm.B = B;
     gm.P2 = P2;
     gm.lds_bytes = 2ll * B * (q + P2) * (long long)sizeof(Ct);
-    if (gm.lds_bytes <= SVD_LDS_MAX || B == 1) break;
+    if (gm.lds_bytes <= 65536 || B == 1) break;
   }
   gm.wgs = gm.P2 / gm.B / 2;
   const long long f_as_c = ((long long)gm.P2 * sizeof(F) + sizeof(Ct) - 1) / sizeof(Ct);
@@ -816,14 +813,6 @@ static void launch_svd(const SvdGeom& gm, int nb, hipStream_t st, const void* a,
                        void* vh, int* keep, void* tw2, int p, int q, int kmax, void* work, unsigned* ctl,
                        int max_sweeps, int max_sv, double max_err, int relative, int absorb, int batch0) {
   using Ct = typename Cx<F>::type;
-  if (gm.lds_bytes + 16 > 65536) {
-    static bool opted = false;  // per (F, B) instantiation
-    if (!opted) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&svd_block_kernel<F, B>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)SVD_LDS_MAX + 16);
-      opted = true;
-    }
-  }
   hipLaunchKernelGGL((svd_block_kernel<F, B>), dim3(gm.wgs, nb, 1), dim3(64 * B), (size_t)gm.lds_bytes + 16, st,
                      reinterpret_cast<const Ct*>(a), a_stride, reinterpret_cast<Ct*>(u), reinterpret_cast<F*>(s),
                      reinterpret_cast<Ct*>(vh), keep, reinterpret_cast<F*>(tw2), p, q, kmax, gm.P2,
@@ -845,7 +834,6 @@ static int dispatch_svd(const SvdGeom& gm, int nb, hipStream_t st, const void* a
     TCMI_SVD_CASE(2)
     TCMI_SVD_CASE(4)
     TCMI_SVD_CASE(8)
-    TCMI_SVD_CASE(16)
   }
 #undef TCMI_SVD_CASE
   return -1;
@@ -892,7 +880,7 @@ int tcmi_svd_trunc_batched(const void* a, void* u, void* s, void* vh, int* keep_
   if (need < 0 || work_bytes < need) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_svd_trunc_batched: workspace too small");
   if (max_sweeps <= 0) max_sweeps = 30;
   const tcmi::SvdGeom gm = dtype == TCMI_C64 ? tcmi::svd_geom<float>(m, n) : tcmi::svd_geom<double>(m, n);
-  if (gm.lds_bytes > tcmi::SVD_LDS_MAX)
+  if (gm.lds_bytes > 65536)
     return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_svd_trunc_batched: matrix too wide for the LDS-resident kernel");
   const int chunk = tcmi::svd_chunk(gm.wgs, batch);
   unsigned* ctl = reinterpret_cast<unsigned*>(work);
