@@ -206,6 +206,56 @@ __device__ __forceinline__ int rotate_pair(typename Cx<F>::type* x, typename Cx<
   return 1;
 }
 
+// Cross rounds with the wave's own row held in registers (row length ld <= 64 * E): the partner row is
+// read from LDS once and written once per round, the own row only returns to LDS after the last round —
+// a third of the LDS traffic of rotate_pair.
+template <typename F, int E>
+__device__ __forceinline__ int rotate_pair_reg(typename Cx<F>::type (&x)[E], typename Cx<F>::type* yrow, int q, int ld,
+                                               int lane, F tol2) {
+  using Ct = typename Cx<F>::type;
+  Ct y[E];
+  F al = 0, be = 0, gr = 0, gi = 0;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int c = lane + 64 * e;
+    if (c < ld) {
+      y[e] = yrow[c];
+    } else {
+      y[e].x = 0;
+      y[e].y = 0;
+    }
+    if (c < q) {
+      al = fma_<F>(x[e].x, x[e].x, fma_<F>(x[e].y, x[e].y, al));
+      be = fma_<F>(y[e].x, y[e].x, fma_<F>(y[e].y, y[e].y, be));
+      gr = fma_<F>(x[e].x, y[e].x, fma_<F>(x[e].y, y[e].y, gr));
+      gi = fma_<F>(x[e].y, y[e].x, fma_<F>(-x[e].x, y[e].y, gi));
+    }
+  }
+  al = wave_sum_uniform(al);
+  be = wave_sum_uniform(be);
+  gr = wave_sum_uniform(gr);
+  gi = wave_sum_uniform(gi);
+  const F g2 = gr * gr + gi * gi;
+  if (!(g2 > tol2 * al * be && g2 > 0)) return 0;
+  F c, sn, pr, pi;
+  jacobi_rotation<F>(al, be, gr, gi, c, sn, pr, pi);
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int col = lane + 64 * e;
+    if (col < ld) {
+      const F tr = pr * y[e].x - pi * y[e].y, ti = pr * y[e].y + pi * y[e].x;
+      Ct nx, ny;
+      nx.x = c * x[e].x - sn * tr;
+      nx.y = c * x[e].y - sn * ti;
+      ny.x = sn * x[e].x + c * tr;
+      ny.y = sn * x[e].y + c * ti;
+      x[e] = nx;
+      yrow[col] = ny;
+    }
+  }
+  return 1;
+}
+
 // Blocked one-sided Jacobi.  The P2 (padded) rows are cut into NB = P2 / B blocks of B rows; workgroup g
 // holds TWO blocks (2B rows of [W | Y]) in LDS and owns B waves.  A sweep is a round-robin tournament
 // of the blocks (NB - 1 global rounds); inside a round the B x B cross pairs are done in B LDS rounds
@@ -288,9 +338,35 @@ __global__ __launch_bounds__(64 * B) void svd_block_kernel(
           __syncthreads();
         }
       }
-      for (int k = 0; k < B; ++k) {
-        rot += rotate_pair<F>(L + (long long)wave * ld, L + (long long)(B + (wave + k) % B) * ld, q, ld, lane, tol2);
+      if (ld <= 512) {  // own row in registers for the B cross rounds
+        constexpr int E = 8;
+        Ct* xrow = L + (long long)wave * ld;
+        Ct xr[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int c = lane + 64 * e;
+          if (c < ld) {
+            xr[e] = xrow[c];
+          } else {
+            xr[e].x = 0;
+            xr[e].y = 0;
+          }
+        }
+        for (int k = 0; k < B; ++k) {
+          rot += rotate_pair_reg<F, E>(xr, L + (long long)(B + (wave + k) % B) * ld, q, ld, lane, tol2);
+          __syncthreads();
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int c = lane + 64 * e;
+          if (c < ld) xrow[c] = xr[e];
+        }
         __syncthreads();
+      } else {
+        for (int k = 0; k < B; ++k) {
+          rot += rotate_pair<F>(L + (long long)wave * ld, L + (long long)(B + (wave + k) % B) * ld, q, ld, lane, tol2);
+          __syncthreads();
+        }
       }
       for (int h = 0; h < 2; ++h) {
         const int lr = h * B + wave;
