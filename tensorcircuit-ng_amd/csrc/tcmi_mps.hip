@@ -123,6 +123,21 @@ __device__ __forceinline__ void jacobi_rotation(F al, F be, F gr, F gi, F& c, F&
   pr = gr * ia;
   pi = gi * ia;
 }
+// complex64: the hardware reciprocal / rsqrt / sqrt approximations (1 ulp) instead of the IEEE
+// division and square-root expansions — this scalar chain sits on the critical path of every pair
+// round, and the 1e-7 loss of unitarity is what the final sigma = |W_i| / |Y_i| already divides out.
+template <>
+__device__ __forceinline__ void jacobi_rotation<float>(float al, float be, float gr, float gi, float& c, float& sn,
+                                                       float& pr, float& pi) {
+  const float ia = __builtin_amdgcn_rsqf(gr * gr + gi * gi);
+  const float zeta = (be - al) * 0.5f * ia;
+  const float az = fabsf(zeta);
+  const float t = __builtin_copysignf(__builtin_amdgcn_rcpf(az + __builtin_amdgcn_sqrtf(1.0f + zeta * zeta)), zeta);
+  c = __builtin_amdgcn_rsqf(1.0f + t * t);
+  sn = c * t;
+  pr = gr * ia;
+  pi = gi * ia;
+}
 
 // wave-wide sums (result uniform): wave_sum_uniform in tcmi_dev.h (DPP for float, shuffles for double)
 
