@@ -181,6 +181,8 @@ def mps_leg(tc, torch, args):
         m.position(0)
     torch.cuda.synchronize()
     t = sum(times) / len(times)
+    if not all(bool(torch.isfinite(x.abs()).all()) for x in m.get_tensors()):
+        raise FloatingPointError("non-finite MPS tensor after the TEBD sweeps")
     return {
         "workload": f"MPSCircuit n={n} chi={chi} TEBD sweep of {n - 1} adjacent random SU(4) gates, complex64 "
                     f"(SURVEY 8d config 5)",

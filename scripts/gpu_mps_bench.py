@@ -51,6 +51,7 @@ def main():
         times.append(time.perf_counter() - t0)
         m.position(0)
         torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(t.abs()).all()) for t in m.get_tensors()), "non-finite MPS tensor"
     best = min(times)
     out.update(sweep_s=best, sweeps_per_s=1 / best, us_per_bond=best / (n - 1) * 1e6,
                max_bond=max(m.get_bond_dimensions()), fidelity=float(m._fidelity))

@@ -34,10 +34,12 @@ struct Eps;
 template <>
 struct Eps<float> {
   static constexpr float v = 5.9604645e-8f;
+  static constexpr float tiny = 1e-30f;  // |<x,y>|^2 below this is zero (keeps rsq / rcp away from denormals)
 };
 template <>
 struct Eps<double> {
   static constexpr double v = 1.1102230246251565e-16;
+  static constexpr double tiny = 1e-280;
 };
 
 // Inter-workgroup data (rows of W / Y, norms, sorted s) is exchanged INSIDE the launch.  Per-XCD L2s are
@@ -204,7 +206,7 @@ __device__ __forceinline__ int rotate_pair(typename Cx<F>::type* x, typename Cx<
   gr = wave_sum_uniform(gr);
   gi = wave_sum_uniform(gi);
   const F g2 = gr * gr + gi * gi;
-  if (!(g2 > tol2 * al * be && g2 > 0)) return 0;
+  if (!(g2 > tol2 * al * be && g2 > Eps<F>::tiny)) return 0;
   F c, sn, pr, pi;  // y~ = e^{i phi} y;  x' = c x - s y~;  y' = s x + c y~
   jacobi_rotation<F>(al, be, gr, gi, c, sn, pr, pi);
   for (int col = lane; col < ld; col += 64) {
@@ -251,7 +253,7 @@ __device__ __forceinline__ int rotate_pair_reg(typename Cx<F>::type (&x)[E], typ
   gr = wave_sum_uniform(gr);
   gi = wave_sum_uniform(gi);
   const F g2 = gr * gr + gi * gi;
-  if (!(g2 > tol2 * al * be && g2 > 0)) return 0;
+  if (!(g2 > tol2 * al * be && g2 > Eps<F>::tiny)) return 0;
   F c, sn, pr, pi;
   jacobi_rotation<F>(al, be, gr, gi, c, sn, pr, pi);
 #pragma unroll

@@ -64,6 +64,21 @@ def test_svd_truncation_rule_and_absorb(dt):
             np.testing.assert_allclose(rec, (u_o * s_o) @ vh_o, atol=TOL[dt] * 100)
 
 
+@pytest.mark.parametrize("dt", ["complex64", "complex128"])
+def test_svd_tiny_rows_stay_finite(dt):
+    """Rows far below the float range of the rotation chain (truncated TEBD tensors carry singular values
+    down to 1e-20 and below): no NaN / inf, large singular values unaffected."""
+    rng = np.random.default_rng(3)
+    a = _rand(rng, 64, 64, dt)
+    scale = np.logspace(0, -30 if dt == "complex64" else -200, 64)
+    a = (a * scale[:, None]).astype(dt)
+    u, s, vh, _ = LA.svd_trunc(torch.from_numpy(a).cuda())
+    assert bool(torch.isfinite(u.abs()).all()) and bool(torch.isfinite(vh.abs()).all()) and bool(torch.isfinite(s.abs()).all())
+    s_ref = np.linalg.svd(a.astype(np.complex128), compute_uv=False)
+    np.testing.assert_allclose(s.cpu().numpy().real[:8], s_ref[:8], rtol=TOL[dt] * 20)
+    assert LA.last_svd_status() == 0
+
+
 def test_svd_rank_deficient_and_zero():
     rng = np.random.default_rng(9)
     a = _rand(rng, 32, 32, "complex128", rank=5)
