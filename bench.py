@@ -287,7 +287,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    # TCMI_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL init, barriers, all-reduces) with a
+    # world of one rank too (used to validate that path on a one-GPU box under torchrun)
+    if world > 1 or os.environ.get("TCMI_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
