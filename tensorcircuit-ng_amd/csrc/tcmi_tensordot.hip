@@ -142,6 +142,115 @@ __global__ __launch_bounds__(256) void cgemm_mfma_kernel(const float2* __restric
   }
 }
 
+// complex128 GEMM on the f64 matrix pipe (v_mfma_f64_16x16x4_f64): 64x64 tile per workgroup, 4 waves x
+// (32x32 = 2x2 MFMA tiles), K step 8, the same 3-product (Gauss) form and planar k-major LDS tiles as
+// the complex64 kernel.  Row pitch 66 doubles: 16-byte aligned rows for the vector loaders and
+// 2 * 66 = 4 (mod 16) double-banks for the transposing loader.  C/D layout of the f64 MFMA:
+// col = lane & 15, row = (lane >> 4) + 4 * reg.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+#define TCMI_ZLDP 66
+
+template <bool TRANS_A>
+__global__ __launch_bounds__(256) void zgemm_mfma_kernel(const double2* __restrict__ A,
+                                                          const double2* __restrict__ B,
+                                                          double2* __restrict__ C, int M, int N, int K,
+                                                          long long sA, long long sB, long long sC) {
+  __shared__ __attribute__((aligned(16))) double As_re[TCMI_BK][TCMI_ZLDP], As_im[TCMI_BK][TCMI_ZLDP];
+  __shared__ __attribute__((aligned(16))) double Bs_re[TCMI_BK][TCMI_ZLDP], Bs_im[TCMI_BK][TCMI_ZLDP];
+  A += (long long)blockIdx.z * sA;
+  B += (long long)blockIdx.z * sB;
+  C += (long long)blockIdx.z * sC;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const long long m0 = (long long)blockIdx.y * TCMI_BM, n0 = (long long)blockIdx.x * TCMI_BN;
+  f64x4 p1[2][2], p2[2][2], p3[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      p1[i][j] = f64x4{0, 0, 0, 0};
+      p2[i][j] = f64x4{0, 0, 0, 0};
+      p3[i][j] = f64x4{0, 0, 0, 0};
+    }
+  const int ai = TRANS_A ? (tid & 31) * 2 : tid >> 2, ak = TRANS_A ? tid >> 5 : (tid & 3) * 2;
+  const int bk = tid >> 5, bj = (tid & 31) * 2;
+  for (int k0 = 0; k0 < K; k0 += TCMI_BK) {
+    {
+      double2 v0 = {0., 0.}, v1 = {0., 0.};
+      if constexpr (TRANS_A) {
+        const long long r = m0 + ai;
+        const int kk = k0 + ak;
+        if (kk < K) {
+          if (r < M) v0 = A[(long long)kk * M + r];
+          if (r + 1 < M) v1 = A[(long long)kk * M + r + 1];
+        }
+        *reinterpret_cast<double2*>(&As_re[ak][ai]) = make_double2(v0.x, v1.x);
+        *reinterpret_cast<double2*>(&As_im[ak][ai]) = make_double2(v0.y, v1.y);
+      } else {
+        const long long r = m0 + ai;
+        const int kk = k0 + ak;
+        if (r < M) {
+          if (kk < K) v0 = A[r * K + kk];
+          if (kk + 1 < K) v1 = A[r * K + kk + 1];
+        }
+        As_re[ak][ai] = v0.x;
+        As_im[ak][ai] = v0.y;
+        As_re[ak + 1][ai] = v1.x;
+        As_im[ak + 1][ai] = v1.y;
+      }
+      double2 w0 = {0., 0.}, w1 = {0., 0.};
+      const long long c = n0 + bj;
+      const int kb = k0 + bk;
+      if (kb < K) {
+        if (c < N) w0 = B[(long long)kb * N + c];
+        if (c + 1 < N) w1 = B[(long long)kb * N + c + 1];
+      }
+      *reinterpret_cast<double2*>(&Bs_re[bk][bj]) = make_double2(w0.x, w1.x);
+      *reinterpret_cast<double2*>(&Bs_im[bk][bj]) = make_double2(w0.y, w1.y);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < TCMI_BK; kk += 4) {
+      const int kr = kk + (lane >> 4);
+      double are[2], aim[2], asum[2], bre[2], bim[2], bsum[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        are[i] = As_re[kr][wr * 32 + i * 16 + (lane & 15)];
+        aim[i] = As_im[kr][wr * 32 + i * 16 + (lane & 15)];
+        asum[i] = are[i] + aim[i];
+        bre[i] = Bs_re[kr][wc * 32 + i * 16 + (lane & 15)];
+        bim[i] = Bs_im[kr][wc * 32 + i * 16 + (lane & 15)];
+        bsum[i] = bre[i] + bim[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          p1[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(are[i], bre[j], p1[i][j], 0, 0, 0);
+          p2[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(aim[i], bim[j], p2[i][j], 0, 0, 0);
+          p3[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(asum[i], bsum[j], p3[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const long long col = n0 + wc * 32 + j * 16 + (lane & 15);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const long long row = m0 + wr * 32 + i * 16 + (lane >> 4) + 4 * reg;
+        if (row < M && col < N) {
+          double2 o;
+          o.x = p1[i][j][reg] - p2[i][j][reg];
+          o.y = p3[i][j][reg] - p1[i][j][reg] - p2[i][j][reg];
+          C[row * N + col] = o;
+        }
+      }
+    }
+}
+
 // complex128 (and tiny shapes): one output element per thread, fp64 FMA chain
 template <typename F>
 __global__ void cgemm_simple_kernel(const typename Cx<F>::type* __restrict__ A,
@@ -267,6 +376,18 @@ int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, 
     else
       hipLaunchKernelGGL(tcmi::cgemm_mfma_kernel<false>, grid, block, 0, st, reinterpret_cast<const float2*>(A),
                          reinterpret_cast<const float2*>(B), reinterpret_cast<float2*>(C), (int)M, (int)N, (int)K,
+                         strideA, strideB, strideC);
+  } else if (dtype == TCMI_C128 && M * N >= 1024) {
+    const long long gx = (N + TCMI_BN - 1) / TCMI_BN, gy = (M + TCMI_BM - 1) / TCMI_BM;
+    if (gy > 65535 || batch > 65535) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm: grid too large");
+    dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)batch), block(256, 1, 1);
+    if (trans_a)
+      hipLaunchKernelGGL(tcmi::zgemm_mfma_kernel<true>, grid, block, 0, st, reinterpret_cast<const double2*>(A),
+                         reinterpret_cast<const double2*>(B), reinterpret_cast<double2*>(C), (int)M, (int)N, (int)K,
+                         strideA, strideB, strideC);
+    else
+      hipLaunchKernelGGL(tcmi::zgemm_mfma_kernel<false>, grid, block, 0, st, reinterpret_cast<const double2*>(A),
+                         reinterpret_cast<const double2*>(B), reinterpret_cast<double2*>(C), (int)M, (int)N, (int)K,
                          strideA, strideB, strideC);
   } else if (M * N < 1024 && K >= 2048 && (dtype == TCMI_C64 || dtype == TCMI_C128)) {
     const long long total = M * N;
