@@ -27,6 +27,8 @@ from .mpscircuit import MPSCircuit  # noqa: E402,F401
 from . import linalg  # noqa: E402,F401
 from . import quantum, templates  # noqa: E402,F401
 from . import interfaces  # noqa: E402,F401
+from . import channels  # noqa: E402,F401
+from .densitymatrix import DMCircuit, DMCircuit2  # noqa: E402,F401
 from . import backends  # noqa: E402,F401
 from . import tn, experimental, distributed  # noqa: E402,F401
 from .backends import get_backend  # noqa: E402,F401

@@ -112,6 +112,8 @@ class Circuit:
         if m.size != d * d:
             raise ValueError(f"gate tensor of size {m.size} does not act on {len(index)} qubits")
         m = m.reshape(d, d)
+        if getattr(self, "_conj", False):   # bra side of a density-matrix circuit (tcmi/densitymatrix.py)
+            m = m.conj()
         if len(index) > 2:
             # dense gates on > 2 qubits (toffoli, fredkin, any(...)): exact plan-time synthesis into
             # <= 2-qubit dense + diagonal gates (tcmi/synth.py); unitary input required
@@ -131,6 +133,9 @@ class Circuit:
     def _record_specs(self, specs, index, name, parameters):
         self._flush_pending()
         index = self._norm_index(index)
+        if getattr(self, "_conj", False):
+            specs = [G.TrigSpec(np.conj(sp.c0), np.conj(sp.c1), np.conj(sp.c2), sp.theta, sp.scale, sp.offset, sp.name)
+                     for sp in specs]
         for s in specs:
             # concrete angles are parameters too: the cached plan is keyed by structure only, so a
             # python-float VQE loop re-uses one plan instead of recompiling per value

@@ -1,0 +1,79 @@
+"""DMCircuit (reference tensorcircuit/densitymatrix.py) on the doubled state-vector plan:
+density matrix, expectations and a gradient against the dense numpy oracle."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dm as odm, gates as G  # noqa: E402
+
+
+@pytest.fixture(params=["complex64", "complex128"])
+def tcd(request):
+    import tcmi as tc
+
+    tc.set_backend("hip")
+    tc.set_dtype(request.param)
+    yield tc
+    tc.set_dtype("complex64")
+
+
+def _build(tc, n, theta, ops=None):
+    c = tc.DMCircuit(n)
+    ch = tc.channels
+    rec = (lambda *a: ops.append(a)) if ops is not None else (lambda *a: None)
+    for i in range(n):
+        c.h(i); rec("u", G.H, [i])
+    c.cnot(0, 1); rec("u", G.CNOT, [0, 1])
+    c.rx(2, theta=theta); rec("u", G.rx(float(theta)), [2])
+    c.depolarizing(1, px=0.1, py=0.05, pz=0.02); rec("k", [k.tensor for k in ch.depolarizingchannel(0.1, 0.05, 0.02)], [1])
+    c.rzz(1, 2, theta=0.4); rec("u", G.rzz(0.4), [1, 2])
+    c.amplitudedamping(0, gamma=0.3, p=0.9); rec("k", [k.tensor for k in ch.amplitudedampingchannel(0.3, 0.9)], [0])
+    c.toffoli(0, 2, 3); rec("u", G.TOFFOLI, [0, 2, 3])
+    c.phasedamping(3, gamma=0.25); rec("k", [k.tensor for k in ch.phasedampingchannel(0.25)], [3])
+    c.ry(3, theta=0.7); rec("u", G.ry(0.7), [3])
+    c.reset(4) if n > 4 else None
+    if n > 4:
+        rec("k", [k.tensor for k in ch.resetchannel()], [4])
+    return c
+
+
+def test_density_matrix_and_expectations(tcd):
+    tc = tcd
+    n, theta = 5, 0.37
+    ops = []
+    c = _build(tc, n, theta, ops)
+    rho = odm.run(n, ops)
+    got = tc.backend.numpy(c.densitymatrix())
+    tol = 2e-6 if tc.dtypestr == "complex64" else 1e-12
+    np.testing.assert_allclose(got, rho, atol=tol)
+    c.check_density_matrix(c.densitymatrix())
+    e1 = complex(c.expectation((tc.gates.z(), [0])))
+    np.testing.assert_allclose(e1, odm.expectation(rho, n, (G.Z, [0])), atol=tol * 10)
+    e2 = complex(c.expectation_ps(x=[1], z=[2]))
+    np.testing.assert_allclose(e2, odm.expectation(rho, n, (G.X, [1]), (G.Z, [2])), atol=tol * 10)
+    for ks in (tc.channels.depolarizingchannel(0.1, 0.2, 0.3), tc.channels.amplitudedampingchannel(0.4, 0.7),
+               tc.channels.phasedampingchannel(0.6), tc.channels.resetchannel()):
+        tc.channels.kraus_identity_check(ks)
+
+
+def test_gradient_through_noisy_circuit(tcd):
+    tc = tcd
+    n = 4
+
+    def f(t):
+        return tc.backend.real(_build(tc, n, t).expectation((tc.gates.z(), [2])))
+
+    rdt = np.float32 if tc.rdtypestr == "float32" else np.float64
+    v, g = tc.backend.value_and_grad(f)(tc.backend.convert_to_tensor(np.array(0.37, dtype=rdt)))
+
+    def ref(t):
+        o = []
+        _build(tc, n, t, o)
+        return np.real(odm.expectation(odm.run(n, o), n, (G.Z, [2])))
+
+    tol = 2e-5 if tc.dtypestr == "complex64" else 1e-9
+    np.testing.assert_allclose(float(v), ref(0.37), atol=tol)
+    eps = 1e-5
+    np.testing.assert_allclose(float(g), (ref(0.37 + eps) - ref(0.37 - eps)) / (2 * eps), atol=2e-4 if tc.dtypestr == "complex64" else 1e-6)
