@@ -43,6 +43,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define TCMI_BM 64
 #define TCMI_BN 64
 #define TCMI_BK 8
+#define TCMI_CBK 16  // K step of the complex64 kernel: one barrier pair per 8 MFMA k-pairs
 #define TCMI_LDP 68
 
 template <bool TRANS_A>
@@ -50,8 +51,8 @@ __global__ __launch_bounds__(256) void cgemm_mfma_kernel(const float2* __restric
                                                           const float2* __restrict__ B,
                                                           float2* __restrict__ C, int M, int N, int K,
                                                           long long sA, long long sB, long long sC) {
-  __shared__ __attribute__((aligned(16))) float As_re[TCMI_BK][TCMI_LDP], As_im[TCMI_BK][TCMI_LDP];
-  __shared__ __attribute__((aligned(16))) float Bs_re[TCMI_BK][TCMI_LDP], Bs_im[TCMI_BK][TCMI_LDP];
+  __shared__ __attribute__((aligned(16))) float As_re[TCMI_CBK][TCMI_LDP], As_im[TCMI_CBK][TCMI_LDP];
+  __shared__ __attribute__((aligned(16))) float Bs_re[TCMI_CBK][TCMI_LDP], Bs_im[TCMI_CBK][TCMI_LDP];
   A += (long long)blockIdx.z * sA;
   B += (long long)blockIdx.z * sB;
   C += (long long)blockIdx.z * sC;
@@ -62,13 +63,15 @@ __global__ __launch_bounds__(256) void cgemm_mfma_kernel(const float2* __restric
   // loader coordinates: A tile 64 rows x 8 k (two complex per thread along k);
   //                     B tile 8 k x 64 cols (two complex per thread along n)
   // TRANS_A: A is stored [K][M] (k-major), loaded like B (coalesced along m)
-  const int ai = TRANS_A ? (tid & 31) * 2 : tid >> 2, ak = TRANS_A ? tid >> 5 : (tid & 3) * 2;
-  const int bk = tid >> 5, bj = (tid & 31) * 2;
+  const int ai = TRANS_A ? (tid & 31) * 2 : tid >> 2, ak0 = TRANS_A ? tid >> 5 : (tid & 3) * 2;
+  const int bk0 = tid >> 5, bj = (tid & 31) * 2;
   // 16-byte global loads need even leading dimensions (and 16-byte aligned batch bases)
   const bool vecA = TRANS_A ? ((M & 1) == 0 && (sA & 1) == 0) : ((K & 1) == 0 && (sA & 1) == 0);
   const bool vecB = (N & 1) == 0 && (sB & 1) == 0;
-  for (int k0 = 0; k0 < K; k0 += TCMI_BK) {
-    {
+  for (int k0 = 0; k0 < K; k0 += TCMI_CBK) {
+#pragma unroll
+    for (int h = 0; h < TCMI_CBK / 8; ++h) {
+      const int ak = ak0 + 8 * h, bk = bk0 + 8 * h;
       float2 v0 = {0.f, 0.f}, v1 = {0.f, 0.f};
       if constexpr (TRANS_A) {
         const long long r = m0 + ai;
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256) void cgemm_mfma_kernel(const float2* __restric
     }
     __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < TCMI_BK; kk += 2) {
+    for (int kk = 0; kk < TCMI_CBK; kk += 2) {
       const int kr = kk + (lane >> 5);
       const float are = As_re[kr][wr * 32 + (lane & 31)], aim = As_im[kr][wr * 32 + (lane & 31)];
       const float bre = Bs_re[kr][wc * 32 + (lane & 31)], bim = Bs_im[kr][wc * 32 + (lane & 31)];
