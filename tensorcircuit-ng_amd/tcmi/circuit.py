@@ -245,6 +245,9 @@ class Circuit:
 
     # ---- lowering -----------------------------------------------------------------------------
     def _gate_records(self) -> List[P.GateRec]:
+        cached = getattr(self, "_recs_cache", None)
+        if cached is not None and cached[0] == len(self._ops):
+            return cached[1]
         recs = []
         for op in self._ops:
             if op.matrix is not None:
@@ -255,13 +258,20 @@ class Circuit:
                 pr = P.ParamRef(op.pidx, s.scale, s.offset)
                 recs.append(P.GateRec(op.qubits, c0=s.c0, c1=s.c1, c2=s.c2, param=pr, name=op.name,
                                       diag=P.diag_terms_trig(s.c0, s.c1, s.c2, op.qubits, pr)))
+        self._recs_cache = (len(self._ops), recs)
         return recs
 
     def _compiled(self):
         from .executor import get_compiled
 
-        return get_compiled(self._nqubits, self._gate_records(), len(self._params), cons.dtypestr,
-                            cons._plan_options)
+        key = (len(self._ops), cons.dtypestr, cons._contractor_name, id(cons._plan_options))
+        cached = getattr(self, "_cc_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        cc = get_compiled(self._nqubits, self._gate_records(), len(self._params), cons.dtypestr,
+                          cons._plan_options)
+        self._cc_cache = (key, cc)
+        return cc
 
     def _param_tensor(self):
         if not self._params:

@@ -17,8 +17,22 @@ from . import gates as G
 _PAULIS = [G._i_matrix, G._x_matrix, G._y_matrix, G._z_matrix]
 
 
+_PAULI_DECOMP = {}
+
+
 def pauli_decompose(matrix: np.ndarray, tol: float = 1e-14):
-    """k-qubit matrix -> list of (pauli codes tuple, coefficient) with M = sum c * P."""
+    """k-qubit matrix -> list of (pauli codes tuple, coefficient) with M = sum c * P (memoised)."""
+    a = np.ascontiguousarray(matrix, dtype=np.complex128)
+    key = (a.shape, a.tobytes())
+    r = _PAULI_DECOMP.get(key)
+    if r is None:
+        r = _pauli_decompose(a, tol)
+        if len(_PAULI_DECOMP) < 4096:
+            _PAULI_DECOMP[key] = r
+    return r
+
+
+def _pauli_decompose(matrix: np.ndarray, tol: float = 1e-14):
     m = np.asarray(matrix, dtype=np.complex128)
     d = m.shape[0]
     k = int(round(np.log2(d)))

@@ -25,7 +25,7 @@ the CPU test-suite.
 """
 
 from dataclasses import dataclass, field
-from typing import List, Optional, Sequence, Tuple
+from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -123,7 +123,20 @@ def walsh_terms(phases: np.ndarray, qubits: Sequence[int]):
 
 
 def diag_terms_const(matrix: np.ndarray, qubits: Sequence[int], tol=1e-12):
-    """Unit-modulus diagonal constant matrix -> DiagTerm list, else None."""
+    """Unit-modulus diagonal constant matrix -> DiagTerm list, else None (memoised by matrix bytes)."""
+    a = np.ascontiguousarray(matrix, dtype=np.complex128)
+    key = a.tobytes()
+    tpl = _CONST_TEMPLATES.get(key)
+    if tpl is None:
+        res = _diag_terms_const(a, tuple(range(len(qubits))), tol)
+        tpl = False if res is None else [(t.qubits, t.const) for t in res]
+        _CONST_TEMPLATES[key] = tpl
+    if tpl is False:
+        return None
+    return [DiagTerm(tuple(qubits[i] for i in sub), const=c) for sub, c in tpl]
+
+
+def _diag_terms_const(matrix: np.ndarray, qubits: Sequence[int], tol=1e-12):
     m = np.asarray(matrix, dtype=np.complex128)
     d = np.diag(m)
     if np.abs(m - np.diag(d)).max() > tol or np.abs(np.abs(d) - 1).max() > tol:
@@ -131,7 +144,36 @@ def diag_terms_const(matrix: np.ndarray, qubits: Sequence[int], tol=1e-12):
     return [DiagTerm(sub, const=c) for sub, c in walsh_terms(np.angle(d), qubits)]
 
 
+_TRIG_TEMPLATES: Dict[Any, Any] = {}
+_CONST_TEMPLATES: Dict[Any, Any] = {}
+
+
 def diag_terms_trig(c0, c1, c2, qubits, param: ParamRef, tol=1e-12):
+    """Memoised front end of ``_diag_terms_trig``: the Walsh analysis depends only on the three matrices;
+    the cached template (terms on local positions, unit scale / zero offset) is remapped to ``qubits`` and
+    ``param`` — recording a circuit must not redo it per gate (host time of small-circuit VQE loops)."""
+    a0, a1, a2 = (np.ascontiguousarray(x, dtype=np.complex128) for x in (c0, c1, c2))
+    key = (a0.tobytes(), a1.tobytes(), a2.tobytes())
+    tpl = _TRIG_TEMPLATES.get(key)
+    if tpl is None:
+        k = len(qubits)
+        res = _diag_terms_trig(a0, a1, a2, tuple(range(k)), ParamRef(0, 1.0, 0.0), tol)
+        # with unit scale / zero offset: const = cg, param.scale = cf
+        tpl = False if res is None else [(t.qubits, t.const, None if t.param is None else t.param.scale) for t in res]
+        _TRIG_TEMPLATES[key] = tpl
+    if tpl is False:
+        return None
+    out = []
+    for sub, cg, cf in tpl:
+        qs = tuple(qubits[i] for i in sub)
+        if cf is None:
+            out.append(DiagTerm(qs, const=cg))
+        else:
+            out.append(DiagTerm(qs, const=cg + cf * param.offset, param=ParamRef(param.index, cf * param.scale, 0.0)))
+    return out
+
+
+def _diag_terms_trig(c0, c1, c2, qubits, param: ParamRef, tol=1e-12):
     """``c0 + cos(a) c1 + sin(a) c2`` is a unit-modulus diagonal for every a iff it can be written
     diag(exp(i(f_x a + g_x))).  Recognised forms: c0 = 0, c1 = diag(e^{i g}), c2 = diag(i f e^{i g})
     with f = +-1 (covers rz / exp1(diagonal Pauli product) / rzz), and c0 = diag(p), c1 = diag(q),
