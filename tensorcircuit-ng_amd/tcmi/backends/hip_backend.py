@@ -409,9 +409,16 @@ class HipBackend:
 
     # ---- function transforms -----------------------------------------------------------------
     def jit(self, f: Callable[..., Any], static_argnums=None, jit_compile=None, **kws: Any) -> Any:
-        """Plans are compiled and cached per circuit structure by the executor; there is nothing to
-        trace (reference pytorch_backend.py:830-842 also returns ``f``)."""
-        return f
+        """Device plans are compiled and cached per circuit structure by the executor.  For the variational
+        idiom ``jit(value_and_grad(f))`` / ``jit(vvag(f))`` the host side is traced too (``tcmi/jit.py``):
+        after the first calls the Python function is no longer executed per step.  Any other function
+        is returned unchanged (reference pytorch_backend.py:830-842 also returns ``f``)."""
+        spec = getattr(f, "_tcmi_vag", None)
+        if spec is None or static_argnums:
+            return f
+        from ..jit import TracedVag
+
+        return TracedVag(self, f, *spec)
 
     def value_and_grad(self, f: Callable[..., Any], argnums: Union[int, Sequence[int]] = 0,
                        has_aux: bool = False) -> Callable[..., Tuple[Any, Any]]:
@@ -445,6 +452,7 @@ class HipBackend:
             aux = self.tree_unflatten(box["spec"], leaves)
             return (v, aux), g
 
+        wrapper._tcmi_vag = (f, argnums, has_aux, None)  # lets ``jit`` trace the host side (tcmi/jit.py)
         return wrapper
 
     def grad(self, f: Callable[..., Any], argnums: Union[int, Sequence[int]] = 0,
@@ -490,6 +498,7 @@ class HipBackend:
             gs = gs_l[0] if isinstance(argnums, int) else tuple(gs_l)
             return vs, gs
 
+        wrapper._tcmi_vag = (f, argnums, has_aux, vectorized_argnums)
         return wrapper
 
     vvag = vectorized_value_and_grad

@@ -323,3 +323,74 @@ def test_torch_interface_and_quantumnet():
         opt.step()
         losses.append(float(loss))
     assert losses[-1] < losses[0] * 0.7
+
+
+@pytest.mark.parametrize("n,d", [(10, 3), (17, 2)])
+def test_jit_traced_value_and_grad(tcd, n, d):
+    """backend.jit(value_and_grad(f)) / jit(vvag(f)) (reference idiom benchmarks/scripts/vqe_tc.py:136-141): after
+    the first calls the host side is a traced pipeline (tcmi/jit.py); values and gradients equal the plain
+    path, untraceable functions silently keep the plain path."""
+    import torch
+    tc = tcd
+    rdt = np.float32 if tc.rdtypestr == "float32" else np.float64
+    rng = np.random.default_rng(n)
+
+    def energy(p, q):
+        c = tc.Circuit(n)
+        for i in range(n):
+            c.h(i)
+        for j in range(d):
+            for i in range(n - 1):
+                c.exp1(i, i + 1, unitary=tc.gates._zz_matrix, theta=p[2 * j, i])
+            for i in range(n):
+                c.rx(i, theta=p[2 * j + 1, i])
+        for i in range(n):
+            c.ry(i, theta=q[i])
+        c.rz(0, theta=0.3)                                   # a constant angle
+        e = 0.0
+        for i in range(n):
+            e += -1.0 * c.expectation_ps(x=[i])
+        for i in range(n - 1):
+            e += 0.5 * c.expectation_ps(z=[i, i + 1])
+        return tc.backend.real(e) + 0.25
+
+    tol = 2e-4 if tc.dtypestr == "complex64" else 1e-9
+    plain = tc.backend.value_and_grad(energy, argnums=(0, 1))
+    fast = tc.backend.jit(tc.backend.value_and_grad(energy, argnums=(0, 1)))
+    for trial in range(4):
+        p = tc.backend.convert_to_tensor(rng.normal(size=[2 * d, n]).astype(rdt))
+        q = tc.backend.convert_to_tensor(rng.normal(size=[n]).astype(rdt))
+        v0, (g0p, g0q) = plain(p, q)
+        v1, (g1p, g1q) = fast(p, q)
+        np.testing.assert_allclose(_np(tc, v1), _np(tc, v0), atol=tol)
+        np.testing.assert_allclose(_np(tc, g1p), _np(tc, g0p), atol=tol)
+        np.testing.assert_allclose(_np(tc, g1q), _np(tc, g0q), atol=tol)
+        assert g1p.dtype == g0p.dtype and tuple(g1p.shape) == tuple(g0p.shape)
+    assert fast.stats["fast"] >= 2
+    # single argnum + vvag: per-sample gradients for the vectorised argument, summed for the shared one
+    B = 3
+    vv_plain = tc.backend.vvag(energy, argnums=(0, 1), vectorized_argnums=0)
+    vv_fast = tc.backend.jit(tc.backend.vvag(energy, argnums=(0, 1), vectorized_argnums=0))
+    for trial in range(3):
+        pb = tc.backend.convert_to_tensor(rng.normal(size=[B, 2 * d, n]).astype(rdt))
+        q = tc.backend.convert_to_tensor(rng.normal(size=[n]).astype(rdt))
+        v0, (g0p, g0q) = vv_plain(pb, q)
+        v1, (g1p, g1q) = vv_fast(pb, q)
+        np.testing.assert_allclose(_np(tc, v1), _np(tc, v0), atol=tol)
+        np.testing.assert_allclose(_np(tc, g1p), _np(tc, g0p), atol=tol)
+        np.testing.assert_allclose(_np(tc, g1q), _np(tc, g0q), atol=tol * B)
+    assert vv_fast.stats["fast"] >= 1
+
+    def scaled(p):                                            # arithmetic on the argument: not traceable
+        c = tc.Circuit(n)
+        for i in range(n):
+            c.rx(i, theta=2.0 * p[i])
+        return tc.backend.real(c.expectation_ps(z=[0]))
+
+    js = tc.backend.jit(tc.backend.value_and_grad(scaled))
+    p1 = tc.backend.convert_to_tensor(rng.normal(size=[n]).astype(rdt))
+    for _ in range(3):
+        v, g = js(p1)
+    np.testing.assert_allclose(_np(tc, v), np.cos(2 * _np(tc, p1)[0]), atol=tol)
+    np.testing.assert_allclose(_np(tc, g)[0], -2 * np.sin(2 * _np(tc, p1)[0]), atol=tol)
+    assert js.stats["fast"] == 0
