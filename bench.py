@@ -100,7 +100,8 @@ def vqe_leg(tc, torch, dist, args, rank, world, dev):
             e += 1.0 * c.expectation((tc.gates.z(), [i]), (tc.gates.z(), [i + 1]))
         return tc.backend.real(e)
 
-    vvag = tc.backend.vvag(energy, argnums=0, vectorized_argnums=0)
+    # the reference harness jits the step (benchmarks/scripts/vqe_tc.py:136-141); here jit traces the host side
+    vvag = tc.backend.jit(tc.backend.vvag(energy, argnums=0, vectorized_argnums=0))
     mb = max(1, args.vqe_microbatch)
 
     def step():
