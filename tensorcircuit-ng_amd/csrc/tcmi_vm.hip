@@ -97,7 +97,7 @@ __device__ __forceinline__ void dispatch_expect_x(const typename Cx<F>::type (&a
 // MODE 0: gate passes (G1M / G2 / DIAG).  MODE 1: measurement passes (EXPECT only).  Separate
 // instantiations keep each kernel's control-flow graph (and register allocation) small.
 template <typename F, int R, int LT, int MODE>
-__global__ __launch_bounds__(1 << LT) void pass_kernel(typename Cx<F>::type* __restrict__ state,
+__global__ __launch_bounds__(1 << LT, (MODE == 1 && LT == 8) ? 2 : 1) void pass_kernel(typename Cx<F>::type* __restrict__ state,
                                                         long long state_stride,
                                                         const int* __restrict__ desc_g,
                                                         const F* __restrict__ ctab_g,
