@@ -145,92 +145,6 @@ __global__ __launch_bounds__(256) void cgemm_mfma_kernel(const float2* __restric
   }
 }
 
-// Pipelined variant for even leading dimensions (every plan-generated GEMM): all operand loads of a K step
-// are branch-free predicated 16-byte loads issued together, and the loads of step k+1 are in flight
-// while step k is multiplied (the plain kernel waits for each load before the next one is issued:
-// rocprofv3 shows the MFMA pipe busy only 75 % of the time with it).
-template <bool TRANS_A>
-__global__ __launch_bounds__(256) void cgemm_mfma_pipe_kernel(const float2* __restrict__ A,
-                                                               const float2* __restrict__ B,
-                                                               float2* __restrict__ C, int M, int N, int K,
-                                                               long long sA, long long sB, long long sC) {
-  __shared__ __attribute__((aligned(16))) float As_re[TCMI_CBK][TCMI_LDP], As_im[TCMI_CBK][TCMI_LDP];
-  __shared__ __attribute__((aligned(16))) float Bs_re[TCMI_CBK][TCMI_LDP], Bs_im[TCMI_CBK][TCMI_LDP];
-  A += (long long)blockIdx.z * sA;
-  B += (long long)blockIdx.z * sB;
-  C += (long long)blockIdx.z * sC;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const long long m0 = (long long)blockIdx.y * TCMI_BM, n0 = (long long)blockIdx.x * TCMI_BN;
-  f32x16 p1 = {0}, p2 = {0}, p3 = {0};
-  const int ai = TRANS_A ? (tid & 31) * 2 : tid >> 2, ak0 = TRANS_A ? tid >> 5 : (tid & 3) * 2;
-  const int bk0 = tid >> 5, bj = (tid & 31) * 2;
-  constexpr int H = TCMI_CBK / 8;
-  float4 ra[H], rb[H];
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto load_regs = [&](int k0) {
-#pragma unroll
-    for (int h = 0; h < H; ++h) {
-      const int ak = k0 + ak0 + 8 * h, bk = k0 + bk0 + 8 * h;
-      bool va, vb = bk < K && n0 + bj < N;            // N, M, K even: a pair is in or out as a whole
-      const float2* pa;
-      if constexpr (TRANS_A) {
-        va = ak < K && m0 + ai < M;
-        pa = A + (va ? (long long)ak * M + m0 + ai : 0);
-      } else {
-        va = m0 + ai < M && ak < K;
-        pa = A + (va ? (m0 + ai) * K + ak : 0);
-      }
-      const float2* pb = B + (vb ? (long long)bk * N + n0 + bj : 0);
-      const float4 ta = *reinterpret_cast<const float4*>(pa);
-      const float4 tb = *reinterpret_cast<const float4*>(pb);
-      ra[h] = va ? ta : zero4;
-      rb[h] = vb ? tb : zero4;
-    }
-  };
-  load_regs(0);
-  for (int k0 = 0; k0 < K; k0 += TCMI_CBK) {
-#pragma unroll
-    for (int h = 0; h < H; ++h) {
-      const int ak = ak0 + 8 * h, bk = bk0 + 8 * h;
-      if constexpr (TRANS_A) {
-        *reinterpret_cast<float2*>(&As_re[ak][ai]) = make_float2(ra[h].x, ra[h].z);
-        *reinterpret_cast<float2*>(&As_im[ak][ai]) = make_float2(ra[h].y, ra[h].w);
-      } else {
-        As_re[ak][ai] = ra[h].x;
-        As_im[ak][ai] = ra[h].y;
-        As_re[ak + 1][ai] = ra[h].z;
-        As_im[ak + 1][ai] = ra[h].w;
-      }
-      *reinterpret_cast<float2*>(&Bs_re[bk][bj]) = make_float2(rb[h].x, rb[h].z);
-      *reinterpret_cast<float2*>(&Bs_im[bk][bj]) = make_float2(rb[h].y, rb[h].w);
-    }
-    __syncthreads();
-    if (k0 + TCMI_CBK < K) load_regs(k0 + TCMI_CBK);
-#pragma unroll
-    for (int kk = 0; kk < TCMI_CBK; kk += 2) {
-      const int kr = kk + (lane >> 5);
-      const float are = As_re[kr][wr * 32 + (lane & 31)], aim = As_im[kr][wr * 32 + (lane & 31)];
-      const float bre = Bs_re[kr][wc * 32 + (lane & 31)], bim = Bs_im[kr][wc * 32 + (lane & 31)];
-      p1 = __builtin_amdgcn_mfma_f32_32x32x2f32(are, bre, p1, 0, 0, 0);
-      p2 = __builtin_amdgcn_mfma_f32_32x32x2f32(aim, bim, p2, 0, 0, 0);
-      p3 = __builtin_amdgcn_mfma_f32_32x32x2f32(are + aim, bre + bim, p3, 0, 0, 0);
-    }
-    __syncthreads();
-  }
-  const long long col = n0 + wc * 32 + (lane & 31);
-#pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    const long long row = m0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-    if (row < M && col < N) {
-      float2 o;
-      o.x = p1[reg] - p2[reg];
-      o.y = p3[reg] - p1[reg] - p2[reg];
-      C[row * N + col] = o;
-    }
-  }
-}
-
 // complex128 GEMM on the f64 matrix pipe (v_mfma_f64_16x16x4_f64): 64x64 tile per workgroup, 4 waves x
 // (32x32 = 2x2 MFMA tiles), K step 8, the same 3-product (Gauss) form and planar k-major LDS tiles as
 // the complex64 kernel.  Row pitch 66 doubles: 16-byte aligned rows for the vector loaders and
@@ -458,17 +372,7 @@ int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, 
     const long long gx = (N + TCMI_BN - 1) / TCMI_BN, gy = (M + TCMI_BM - 1) / TCMI_BM;
     if (gy > 65535 || batch > 65535) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm: grid too large");
     dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)batch), block(256, 1, 1);
-    const bool even = ((M | N | K | strideA | strideB) & 1) == 0 &&
-                      ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
-    if (even && trans_a)
-      hipLaunchKernelGGL(tcmi::cgemm_mfma_pipe_kernel<true>, grid, block, 0, st, reinterpret_cast<const float2*>(A),
-                         reinterpret_cast<const float2*>(B), reinterpret_cast<float2*>(C), (int)M, (int)N, (int)K,
-                         strideA, strideB, strideC);
-    else if (even)
-      hipLaunchKernelGGL(tcmi::cgemm_mfma_pipe_kernel<false>, grid, block, 0, st, reinterpret_cast<const float2*>(A),
-                         reinterpret_cast<const float2*>(B), reinterpret_cast<float2*>(C), (int)M, (int)N, (int)K,
-                         strideA, strideB, strideC);
-    else if (trans_a)
+    if (trans_a)
       hipLaunchKernelGGL(tcmi::cgemm_mfma_kernel<true>, grid, block, 0, st, reinterpret_cast<const float2*>(A),
                          reinterpret_cast<const float2*>(B), reinterpret_cast<float2*>(C), (int)M, (int)N, (int)K,
                          strideA, strideB, strideC);
