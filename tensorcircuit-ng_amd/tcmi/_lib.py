@@ -97,9 +97,19 @@ def exported_symbols():
     return sorted(_SIGNATURES)
 
 
+class TraceAbort(Exception):
+    """Raised instead of launching anything while ``backend.jit`` probes a function (tcmi/jit.py): a function
+    that needs device results during the probe is not a traceable energy and keeps the plain path."""
+
+
+TRACING = [False]
+
+
 def lib():
     """Load (once) and return the ctypes handle; raises TcmiError if the HIP library is absent."""
     global _lib
+    if TRACING[0]:
+        raise TraceAbort("device call while tracing")
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise TcmiError(

@@ -413,12 +413,19 @@ class HipBackend:
         idiom ``jit(value_and_grad(f))`` / ``jit(vvag(f))`` the host side is traced too (``tcmi/jit.py``):
         after the first calls the Python function is no longer executed per step.  Any other function
         is returned unchanged (reference pytorch_backend.py:830-842 also returns ``f``)."""
-        spec = getattr(f, "_tcmi_vag", None)
-        if spec is None or static_argnums:
-            return f
         from ..jit import TracedVag
 
-        return TracedVag(self, f, *spec)
+        if static_argnums:
+            return f
+        spec = getattr(f, "_tcmi_vag", None)
+        if spec is not None:
+            return TracedVag(self, f, *spec)
+        if getattr(f, "_tcmi_vmap", None) is not None:
+            g, vec = f._tcmi_vmap
+            return TracedVag(self, f, g, (), False, vec, value_only=True)
+        # a plain function: traced as a Pauli-sum energy of its tensor arguments if it is one (the probe
+        # calls f twice, like a tracing jit does); anything else runs unchanged
+        return TracedVag(self, f, f, (), False, None, value_only=True)
 
     def value_and_grad(self, f: Callable[..., Any], argnums: Union[int, Sequence[int]] = 0,
                        has_aux: bool = False) -> Callable[..., Tuple[Any, Any]]:
@@ -474,6 +481,7 @@ class HipBackend:
             in_axes = tuple(0 if i in vectorized_argnums else None for i in range(len(args)))
             return torch.vmap(lambda *a, **k: _resolve(f(*a, **k)), in_axes, 0)(*args, **kws)
 
+        wrapper._tcmi_vmap = (f, vectorized_argnums)
         return wrapper
 
     def vectorized_value_and_grad(self, f: Callable[..., Any], argnums: Union[int, Sequence[int]] = 0,

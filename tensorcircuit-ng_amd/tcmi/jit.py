@@ -34,8 +34,9 @@ def _as_tuple(x):
 
 class TracedVag:
     def __init__(self, backend, slow: Callable[..., Any], f: Callable[..., Any], argnums, has_aux: bool,
-                 vectorized_argnums=None):
+                 vectorized_argnums=None, value_only: bool = False):
         self.backend, self.slow, self.f = backend, slow, f
+        self.value_only = value_only
         self.argnums_raw = argnums
         self.argnums = _as_tuple(argnums)
         self.has_aux = has_aux
@@ -87,10 +88,15 @@ class TracedVag:
         runs = []
         for mult, add in ((1.0, 0.0), (2.0, 1.0)):
             pa, spans, total = self._probe(args, mult, add)
+            from . import _lib
+
+            _lib.TRACING[0] = True
             try:
                 out = self.f(*pa)
             except Exception:
                 return False
+            finally:
+                _lib.TRACING[0] = False
             if not isinstance(out, LazyExpectation) or out._value is not None or not out.is_real:
                 return False
             circuits = {id(t[0]): t[0] for t in out.terms}
@@ -174,6 +180,9 @@ class TracedVag:
         vals = cm.run(state)                                                  # [nb, T] complex128
         w = plan["weights"]
         value = (vals.real * w).sum(-1) + plan["const"]
+        if self.value_only:
+            value = value.to(rdt)
+            return value if batched else value[0]
         lam = cm.apply_sum(state, w.to(torch.complex128).reshape(1, -1).expand(nb, -1))
         gp = cc.vjp(params, state, lam).to(torch.float64)                     # [nb, P]
         gflat = torch.zeros(nb, plan["total"] + plan["consts"].numel(), dtype=torch.float64, device=dev)

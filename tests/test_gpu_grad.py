@@ -394,3 +394,46 @@ def test_jit_traced_value_and_grad(tcd, n, d):
     np.testing.assert_allclose(_np(tc, v), np.cos(2 * _np(tc, p1)[0]), atol=tol)
     np.testing.assert_allclose(_np(tc, g)[0], -2 * np.sin(2 * _np(tc, p1)[0]), atol=tol)
     assert js.stats["fast"] == 0
+
+
+def test_jit_plain_functions(tcd):
+    """jit(f) of a plain energy function is traced (value only); functions that need device results while
+    being probed (states, MPS, arithmetic on expectations) run unchanged."""
+    tc = tcd
+    n = 9
+    rdt = np.float32 if tc.rdtypestr == "float32" else np.float64
+    rng = np.random.default_rng(1)
+
+    def energy(p):
+        c = tc.Circuit(n)
+        for i in range(n):
+            c.ry(i, theta=p[i])
+        for i in range(n - 1):
+            c.cnot(i, i + 1)
+        return tc.backend.real(c.expectation_ps(z=[0, n - 1]) - 0.5 * c.expectation_ps(x=[3]))
+
+    def state(p):
+        c = tc.Circuit(n)
+        for i in range(n):
+            c.ry(i, theta=p[i])
+        return c.wavefunction()
+
+    def squared(p):
+        c = tc.Circuit(n)
+        for i in range(n):
+            c.ry(i, theta=p[i])
+        return tc.backend.real(c.expectation_ps(z=[0])) ** 2
+
+    je, js, jq = tc.backend.jit(energy), tc.backend.jit(state), tc.backend.jit(squared)
+    tol = 2e-5 if tc.dtypestr == "complex64" else 1e-10
+    for _ in range(3):
+        p = tc.backend.convert_to_tensor(rng.normal(size=[n]).astype(rdt))
+        np.testing.assert_allclose(_np(tc, je(p)), _np(tc, energy(p)), atol=tol)
+        np.testing.assert_allclose(_np(tc, js(p)), _np(tc, state(p)), atol=tol)
+        np.testing.assert_allclose(_np(tc, jq(p)), _np(tc, squared(p)), atol=tol)
+    assert je.stats["fast"] >= 1 and js.stats["fast"] == 0 and jq.stats["fast"] == 0
+    jv = tc.backend.jit(tc.backend.vmap(energy))
+    pb = tc.backend.convert_to_tensor(rng.normal(size=[4, n]).astype(rdt))
+    for _ in range(3):
+        np.testing.assert_allclose(_np(tc, jv(pb)), _np(tc, tc.backend.vmap(energy)(pb)), atol=tol)
+    assert jv.stats["fast"] >= 1
