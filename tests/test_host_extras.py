@@ -1,0 +1,89 @@
+"""Host-side logic that needs no GPU: Kraus channels, super-gates, DMCircuit recording on the doubled
+circuit, sample format conversion, Pauli-sum bookkeeping, jit dispatch."""
+
+import numpy as np
+import pytest
+
+import tcmi as tc
+from oracle import dm as odm, gates as OG
+
+
+def test_channels_are_trace_preserving_and_super_gate_matches_oracle():
+    ch = tc.channels
+    for ks in (ch.depolarizingchannel(0.1, 0.2, 0.3), ch.amplitudedampingchannel(0.4, 0.7),
+               ch.phasedampingchannel(0.6), ch.resetchannel(), ch.generaldepolarizingchannel(0.05),
+               ch.isotropicdepolarizingchannel(0.3)):
+        ch.kraus_identity_check(ks)
+        sup = ch.kraus_to_super_gate(ks)
+        rng = np.random.default_rng(0)
+        a = rng.normal(size=(2, 2)) + 1j * rng.normal(size=(2, 2))
+        rho = a @ a.conj().T
+        rho /= np.trace(rho)
+        want = sum(np.asarray(k.tensor) @ rho @ np.asarray(k.tensor).conj().T for k in ks)
+        got = (sup @ rho.reshape(-1)).reshape(2, 2)          # vec index = (ket, bra)
+        np.testing.assert_allclose(got, want, atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        ch.generaldepolarizingchannel(0.1, num_qubits=2)
+
+
+def test_dmcircuit_records_ket_and_conjugated_bra_gates():
+    n = 3
+    c = tc.DMCircuit(n)
+    c.h(0)
+    c.cnot(0, 1)
+    c.rx(2, theta=0.3)
+    c.s(1)
+    c.depolarizing(1, px=0.1, py=0.05, pz=0.02)
+    ops = c._c._ops
+    assert [o.qubits for o in ops] == [(0,), (3,), (0, 1), (3, 4), (2,), (5,), (1,), (4,), (1, 4)]
+    s_ket, s_bra = ops[6].matrix, ops[7].matrix
+    np.testing.assert_allclose(s_bra, np.conj(s_ket))
+    assert abs(s_ket[1, 1] - 1j) < 1e-12 and abs(s_bra[1, 1] + 1j) < 1e-12
+    rx_ket, rx_bra = ops[4].spec, ops[5].spec
+    np.testing.assert_allclose(rx_bra.c2, np.conj(rx_ket.c2))
+    with pytest.raises(NotImplementedError):
+        c.apply_general_kraus(tc.channels.depolarizingchannel(0.1, 0.1, 0.1), [0, 1])
+    # the same circuit on the dense oracle: the doubled state vector is vec(rho)
+    rho = odm.run(2, [("u", OG.H, [0]), ("u", OG.CNOT, [0, 1])])
+    np.testing.assert_allclose(np.trace(rho), 1.0)
+
+
+def test_sample2all_formats():
+    import torch
+
+    bits = torch.tensor([[1, 0, 1], [0, 0, 1], [1, 0, 1]])
+    q = tc.quantum
+    assert q.sample2all(bits, 3, format="sample_int").tolist() == [5, 1, 5]
+    assert q.sample2all(torch.tensor([5, 1, 5]), 3, format="sample_bin").tolist() == bits.tolist()
+    assert q.sample2all(bits, 3, format="count_dict_bin") == {"001": 1, "101": 2}
+    assert q.sample2all(bits, 3, format="count_dict_int") == {1: 1, 5: 2}
+    assert q.sample2all(bits, 3, format="count_vector").tolist() == [0, 1, 0, 0, 0, 2, 0, 0]
+    vals, counts = q.sample2all(bits, 3, format="count_tuple")
+    assert vals.tolist() == [1, 5] and counts.tolist() == [1, 2]
+    with pytest.raises(ValueError):
+        q.sample2all(bits, 3, format="nope")
+
+
+def test_pauli_sum_bookkeeping_and_jit_dispatch():
+    h = tc.quantum.PauliStringSum2COO([[1, 0, 3], [0, 2, 0]], [0.5, -2.0])
+    assert tc.backend.is_sparse(h) and len(h) == 2 and h.n == 3 and h.weights == [0.5, -2.0]
+    with pytest.raises(ValueError):
+        tc.quantum.PauliStringSum2COO([[1, 0]], [1.0, 2.0])
+    from tcmi.jit import TracedVag
+
+    f = lambda p: p
+    assert isinstance(tc.backend.jit(tc.backend.value_and_grad(f)), TracedVag)
+    assert isinstance(tc.backend.jit(tc.backend.vvag(f)), TracedVag)
+    assert tc.backend.jit(f, static_argnums=(0,)) is f
+    j = tc.backend.jit(f)
+    x = np.arange(3.0)
+    assert j(x) is x and j.stats["fast"] == 0       # not an energy: the plain function runs
+
+
+def test_three_qubit_synthesis_of_controlled_gates():
+    from tcmi import synth
+
+    for u in (OG.TOFFOLI, OG.FREDKIN, np.diag(np.exp(1j * np.arange(8)))):
+        ops = synth.lower(synth.decompose_dense(u, [2, 0, 1]))
+        assert all(len(q) <= 2 for _, q in ops)
+        np.testing.assert_allclose(synth.expand(ops, [2, 0, 1]), u, atol=1e-12)
