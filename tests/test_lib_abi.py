@@ -42,3 +42,18 @@ def test_argument_validation_without_gpu():
     assert lib.tcmi_init_zero_state(None, 0, 1, 10, 0, None) == -1
     with pytest.raises(_lib.TcmiError):
         _lib.check(rc, "tcmi_run_pass")
+
+
+def test_missing_extension_fails_loudly(monkeypatch, tmp_path):
+    """No CPU fallback: with the shared object absent every product entry point raises TcmiError."""
+    from tcmi import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libtcmi_absent.so"))
+    with pytest.raises(_lib.TcmiError, match="HIP extension not built"):
+        _lib.lib()
+    import torch
+    from tcmi import linalg as LA
+
+    with pytest.raises(_lib.TcmiError):
+        LA.matmul(torch.zeros(2, 2, dtype=torch.complex64), torch.zeros(2, 2, dtype=torch.complex64))
