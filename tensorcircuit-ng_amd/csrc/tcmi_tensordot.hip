@@ -47,7 +47,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define TCMI_LDP 68
 
 template <bool TRANS_A>
-__global__ __launch_bounds__(256) void cgemm_mfma_kernel(const float2* __restrict__ A,
+__global__ __launch_bounds__(256, 6) void cgemm_mfma_kernel(const float2* __restrict__ A,
                                                           const float2* __restrict__ B,
                                                           float2* __restrict__ C, int M, int N, int K,
                                                           long long sA, long long sB, long long sC) {
