@@ -154,7 +154,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 #define TCMI_ZLDP 66
 
 template <bool TRANS_A>
-__global__ __launch_bounds__(256) void zgemm_mfma_kernel(const double2* __restrict__ A,
+__global__ __launch_bounds__(256, 4) void zgemm_mfma_kernel(const double2* __restrict__ A,
                                                           const double2* __restrict__ B,
                                                           double2* __restrict__ C, int M, int N, int K,
                                                           long long sA, long long sB, long long sC) {
