@@ -318,3 +318,29 @@ def test_measure_sample_rdm_like_the_reference_mps_test():
         assert len(c.sample(batch=3, allow_state=False, format="sample_bin")) == 3
     finally:
         tc.set_dtype("complex64")
+
+
+def test_svd_qr_fuzz_shapes_scales_and_ranks():
+    """Randomised sweep over shapes (1..130), scales (1e-12..1e12), ranks and dtypes: the kernels stay finite,
+    the barrier never times out, U S Vh and Q R reconstruct the input."""
+    rng = np.random.default_rng(2024)
+    for trial in range(60):
+        dt = "complex64" if trial % 2 == 0 else "complex128"
+        m, n = int(rng.integers(1, 131)), int(rng.integers(1, 131))
+        rank = None if trial % 3 else int(rng.integers(1, min(m, n) + 1))
+        scale = 10.0 ** rng.uniform(-12, 12) if dt == "complex128" else 10.0 ** rng.uniform(-6, 6)
+        a = (_rand(rng, m, n, "complex128", rank=rank) * scale).astype(dt)
+        ag = torch.from_numpy(a).cuda()
+        u, s, vh, _ = LA.svd_trunc(ag)
+        assert LA.last_svd_status() == 0, (m, n, dt)
+        un, sn, vn = u.cpu().numpy(), s.cpu().numpy().real, vh.cpu().numpy()
+        assert np.isfinite(un).all() and np.isfinite(sn).all() and np.isfinite(vn).all(), (m, n, dt, scale)
+        amax = max(np.abs(a).max(), 1e-300)
+        tol = (2e-5 if dt == "complex64" else 1e-11) * amax * max(m, n) ** 0.5
+        np.testing.assert_allclose((un * sn) @ vn, a, atol=tol, err_msg=f"svd {m}x{n} {dt} rank={rank} scale={scale:.1e}")
+        assert np.all(np.diff(sn) <= 1e-5 * max(sn[0], 1e-300))
+        q, r = LA.qr(ag)
+        qn, rn = q.cpu().numpy(), r.cpu().numpy()
+        np.testing.assert_allclose(qn @ rn, a, atol=tol, err_msg=f"qr {m}x{n} {dt}")
+        k = min(m, n)
+        np.testing.assert_allclose(qn.conj().T @ qn, np.eye(k), atol=5e-5 if dt == "complex64" else 1e-11)
