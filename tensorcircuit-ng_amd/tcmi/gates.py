@@ -76,14 +76,25 @@ class Gate:
     shape ``[2] * 2k`` with axes ``[out.., in..]``."""
 
     def __init__(self, tensor, name="__unnamed_node__"):
-        self.tensor = np.asarray(tensor)
+        # a backend (device) tensor is kept as it is, so that it can stay on the autograd tape
+        self.tensor = tensor if _is_device_tensor(tensor) else np.asarray(tensor)
         self.name = name
+
+    def copy(self):
+        return Gate(self.tensor, self.name)
 
     def __repr__(self):
         return f"Gate(name={self.name!r}, tensor=\n{self.tensor!r})"
 
 
+def _is_device_tensor(x):
+    return hasattr(x, "data_ptr") and hasattr(x, "requires_grad")
+
+
 def _as_gate(m, name):
+    if _is_device_tensor(m):
+        k = int(round(np.log2(m.numel()))) // 2
+        return Gate(m.reshape([2] * (2 * k)), name=name)
     m = np.asarray(m)
     k = int(round(np.log2(m.size))) // 2
     return Gate(m.reshape([2] * (2 * k)), name=name)
@@ -298,6 +309,8 @@ def any_gate(unitary, name="any"):
     """reference gates.py:866-890."""
     if isinstance(unitary, Gate):
         return unitary
+    if _is_device_tensor(unitary):
+        return _as_gate(unitary, name)
     return _as_gate(np.asarray(unitary).astype(_npdtype()), name)
 
 
@@ -316,6 +329,14 @@ def random_single_qubit_gate(seed=None):
 
 def matrix_for_gate(gate):
     """reference gates.py: reshape a Gate tensor to its square matrix."""
-    t = np.asarray(gate.tensor)
+    t = gate.tensor
+    if _is_device_tensor(t):
+        t = t.detach().cpu().numpy()
+    t = np.asarray(t)
     d = int(round(np.sqrt(t.size)))
     return t.reshape(d, d)
+
+
+# short names of the parameterised gates (reference gates.py:1192-1232: tc.gates.rx, tc.gates.any ...)
+for _n in ("rx", "ry", "rz", "phase", "r", "u", "iswap", "cr", "exp", "exp1", "rzz", "rxx", "ryy", "su4", "any"):
+    globals().setdefault(_n, globals()[_n + "_gate"])

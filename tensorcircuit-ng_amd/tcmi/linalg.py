@@ -41,11 +41,35 @@ def _workspace(kind, nbytes, device):
     return w
 
 
-def matmul(a, b):
-    """[M,K] @ [K,N] (or batched [B,M,K] @ [B,K,N]) through ``tcmi_cgemm``."""
+def _tracked(*ts) -> bool:
+    """True when a result must stay on torch's autograd tape: an operand requires grad (and grad mode is
+    on) or is a ``torch.func`` wrapper, whose storage the C ABI cannot be handed directly."""
     import torch
 
-    a, b = a.contiguous(), b.contiguous()
+    for t in ts:
+        if torch.is_tensor(t):
+            if torch._C._functorch.is_functorch_wrapped_tensor(t):
+                return True
+            if t.requires_grad and torch.is_grad_enabled():
+                return True
+    return False
+
+
+def _h(x):
+    return x.mH.resolve_conj()
+
+
+def matmul(a, b):
+    """[M,K] @ [K,N] (or batched [B,M,K] @ [B,K,N]) through ``tcmi_cgemm``; differentiable."""
+    if _tracked(a, b):
+        return _ad()["matmul"](a, b)
+    return _matmul_raw(a, b)
+
+
+def _matmul_raw(a, b):
+    import torch
+
+    a, b = a.resolve_conj().contiguous(), b.resolve_conj().contiguous()
     if a.dim() == 2:
         M, K = a.shape
         K2, N = b.shape
@@ -68,8 +92,18 @@ def site_gate(gate, tensor):
     (d x d)(d x r) GEMM with the gate shared by every l (stride 0)."""
     import torch
 
-    tensor = tensor.contiguous()
-    gate = gate.contiguous()
+    if _tracked(gate, tensor):
+        l, d, r = tensor.shape
+        out = matmul(gate, tensor.permute(1, 0, 2).reshape(d, l * r))
+        return out.reshape(d, l, r).permute(1, 0, 2).contiguous()
+    return _site_gate_raw(gate, tensor)
+
+
+def _site_gate_raw(gate, tensor):
+    import torch
+
+    tensor = tensor.resolve_conj().contiguous()
+    gate = gate.resolve_conj().contiguous()
     l, d, r = tensor.shape
     out = torch.empty_like(tensor)
     _lib.check(_lib.lib().tcmi_cgemm(gate.data_ptr(), tensor.data_ptr(), out.data_ptr(), d, r, d, l, 0, d * r, d * r,
@@ -81,8 +115,17 @@ def gate_mix(t, gate, L, R):
     """theta[l,a',b',r] = sum_ab gate[a',b',a,b] t[l,a,b,r]; t flat [L*4*R]."""
     import torch
 
-    t = t.contiguous()
-    gate = gate.contiguous()
+    if _tracked(t, gate):
+        out = matmul(gate.reshape(4, 4), t.reshape(L, 4, R).permute(1, 0, 2).reshape(4, L * R))
+        return out.reshape(4, L, R).permute(1, 0, 2).reshape(-1)
+    return _gate_mix_raw(t, gate, L, R)
+
+
+def _gate_mix_raw(t, gate, L, R):
+    import torch
+
+    t = t.resolve_conj().contiguous()
+    gate = gate.resolve_conj().contiguous()
     out = torch.empty_like(t)
     _lib.check(_lib.lib().tcmi_mps_gate_mix(t.data_ptr(), gate.data_ptr(), out.data_ptr(), L, R, 1, 0, _code(t),
                                             _stream(t)), "tcmi_mps_gate_mix")
@@ -94,7 +137,7 @@ def _svd_rows(mat, kmax, max_sv, max_err, relative, absorb):
     [1]), tw2 (device real [1])."""
     import torch
 
-    mat = mat.contiguous()
+    mat = mat.resolve_conj().contiguous()
     m, n = mat.shape
     rdt = torch.float32 if mat.dtype == torch.complex64 else torch.float64
     code = _code(mat)
@@ -138,6 +181,8 @@ def svd_trunc(mat, max_singular_values: Optional[int] = None, max_truncation_err
     m, n = mat.shape
     k = min(m, n)
     static_keep = k if max_singular_values is None else min(int(max_singular_values), k)
+    if _tracked(mat):
+        return _svd_trunc_ad(mat, static_keep, max_truncation_err, relative, absorb)
     if m <= n:
         u, s, vh, keep, _ = _svd_rows(mat, static_keep, max_singular_values, max_truncation_err, relative, absorb)
     else:
@@ -156,10 +201,18 @@ def svd_trunc(mat, max_singular_values: Optional[int] = None, max_truncation_err
 
 
 def qr(mat):
-    """Householder QR: [m,n] -> q [m,K], r [K,n] (complete isometry also for rank-deficient input)."""
+    """Householder QR: [m,n] -> q [m,K], r [K,n] (complete isometry also for rank-deficient input).
+    On the autograd tape the factors are gauge-fixed to a real non-negative diagonal of ``r`` (the form
+    the backward rule assumes) and the rule of ``jax_ops.py:84-150`` applies."""
+    if _tracked(mat):
+        return _ad()["qr"](mat)
+    return _qr_raw(mat)
+
+
+def _qr_raw(mat):
     import torch
 
-    mat = mat.contiguous()
+    mat = mat.resolve_conj().contiguous()
     m, n = mat.shape
     K = min(m, n)
     code = _code(mat)
@@ -174,8 +227,194 @@ def qr(mat):
 
 def rq(mat):
     """mat = r q with q q^H = 1 (tensornetwork ``rq``: QR of the conjugate transpose)."""
-    q, r = qr(mat.conj().t().resolve_conj())
-    return r.conj().t().resolve_conj().contiguous(), q.conj().t().resolve_conj().contiguous()
+    q, r = qr(_h(mat))
+    return _h(r).contiguous(), _h(q).contiguous()
+
+
+# ----------------------------------------------------------------------------- reverse mode
+# The MPS path under ``backend.value_and_grad`` (reference tests/test_mpscircuit.py:437-497).  Forward
+# passes are the same kernels; the backward rules below are written in terms of ``matmul`` (so every
+# product is again ``tcmi_cgemm``) and elementwise torch ops.  Regularisation follows the reference's
+# AD-aware rules (``backends/jax_ops.py:24-25, 80, 107-113``): x / (x^2 + 1e-15) for the reciprocal
+# gaps and singular values, |r_ii| clamped from below at 1e-8 in the QR rule.
+_AD: Dict[str, Any] = {}
+_SVD_EPS = 1e-15
+_QR_EPS = 1e-8
+
+
+def _svd_full_raw(mat):
+    m, n = mat.shape
+    if m <= n:
+        u, s, vh, _, _ = _svd_rows(mat, m, None, None, False, 0)
+        return u, s, vh
+    u2, s, vh2, _, _ = _svd_rows(mat.t(), n, None, None, False, 0)
+    return vh2.t().contiguous(), s, u2.t().contiguous()
+
+
+def _svd_backward(u, s, vh, gu, gs, gvh):
+    """dL/dA of the thin SVD A = u diag(s) vh (u [m,k], vh [k,n]); arXiv:1909.02659 with the gauge term on
+    the diagonal, as in ``jax_ops.py:33-75``."""
+    import torch
+
+    m, k = u.shape
+    n = vh.shape[1]
+    cdt = u.dtype
+    v, gv, uh = _h(vh), _h(gvh), _h(u)
+    s2 = s * s
+    E = s2[None, :] - s2[:, None]                      # E_ij = s_j^2 - s_i^2, zero on the diagonal
+    F = (E / (E * E + _SVD_EPS)).to(cdt)
+    sinv = (s / (s * s + _SVD_EPS)).to(cdt)
+    sc = s.to(cdt)
+    GU = matmul(uh, gu)
+    GV = matmul(vh, gv)
+    core = ((GU - _h(GU)) * F) * sc[None, :] + sc[:, None] * ((GV - _h(GV)) * F)
+    dg = gs.to(cdt) + 1j * (torch.diagonal(GU).imag.to(cdt) * sinv)
+    core = core + torch.diag_embed(dg)
+    ga = matmul(matmul(u, core), vh)
+    if m > k:
+        ga = ga + matmul((gu - matmul(u, GU)) * sinv[None, :], vh)
+    if n > k:
+        ga = ga + matmul(u * sinv[None, :], _h(gv - matmul(v, GV)))
+    return ga
+
+
+def _triu_inv(r):
+    """Inverse of an upper-triangular [n,n] matrix by recursive doubling over its diagonal blocks:
+    inv([[A,B],[0,C]]) = [[A^-1, -A^-1 B C^-1],[0, C^-1]], every level one pair of batched GEMMs."""
+    import torch
+
+    n = r.shape[0]
+    N = 1
+    while N < n:
+        N *= 2
+    if N != n:
+        z = torch.zeros((n, N - n), dtype=r.dtype, device=r.device)
+        e = torch.eye(N - n, dtype=r.dtype, device=r.device)
+        r = torch.cat([torch.cat([r, z], 1), torch.cat([z.t(), e], 1)], 0)
+    X = (1.0 / torch.diagonal(r)).reshape(N, 1, 1)
+    b = 1
+    while b < N:
+        nb = N // (2 * b)
+        idx = torch.arange(nb, device=r.device)
+        B = r.reshape(nb, 2 * b, nb, 2 * b)[idx, :, idx, :][:, :b, b:]
+        A, C = X[0::2], X[1::2]
+        T = -(A * B * C) if b == 1 else -matmul(matmul(A, B), C)
+        X = torch.cat([torch.cat([A, T], 2), torch.cat([torch.zeros_like(A), C], 2)], 1)
+        b *= 2
+    return X[0][:n, :n]
+
+
+def _qr_backward_tall(q, r, gq, gr):
+    """m >= n, r [n,n] upper triangular with a real diagonal."""
+    import torch
+
+    d = torch.diagonal(r)
+    small = d.abs() < _QR_EPS
+    r = r + torch.diag_embed(torch.where(small, _QR_EPS - d, torch.zeros_like(d)))
+    M = matmul(r, _h(gr)) - matmul(_h(gq), q)
+    L = torch.tril(M, -1)
+    sym = L + _h(L) + torch.diag_embed(torch.diagonal(M).real.to(M.dtype))
+    B = gq + matmul(q, sym)
+    return matmul(B, _h(_triu_inv(r)))
+
+
+def _qr_backward(q, r, gq, gr):
+    import torch
+
+    m = q.shape[0]
+    n = r.shape[1]
+    if m >= n:
+        return _qr_backward_tall(q, r, gq, gr)
+    # wide: A = [X | Y] = q [U | V]
+    U, V = r[:, :m], r[:, m:]
+    gU, gV = gr[:, :m], gr[:, m:]
+    gx = _qr_backward_tall(q, U, gq + matmul(matmul(q, V), _h(gV)), gU)
+    return torch.cat([gx, matmul(q, gV)], 1)
+
+
+def _svd_trunc_ad(mat, static_keep, max_truncation_err, relative, absorb):
+    import torch
+
+    u, s, vh = _ad()["svd"](mat)
+    kk = static_keep
+    if max_truncation_err is not None:
+        sd = s.detach()
+        errs = torch.sqrt(torch.cumsum(torch.flip(sd, [0]) ** 2, 0))
+        bound = max_truncation_err * sd[0] if relative else max_truncation_err
+        kk = min(kk, int((errs > bound).sum().item()))
+    sc = s.to(mat.dtype)
+    uk, sk, vk = u[:, :kk], sc[:kk], vh[:kk, :]
+    if absorb == 1:
+        uk = uk * sk[None, :]
+    elif absorb == 2:
+        vk = sk[:, None] * vk
+    return uk.contiguous(), sk, vk.contiguous(), sc[kk:]
+
+
+def _ad():
+    if _AD:
+        return _AD
+    import torch
+
+    class Matmul(torch.autograd.Function):
+        generate_vmap_rule = False
+
+        @staticmethod
+        def forward(a, b):
+            return _matmul_raw(a, b)
+
+        @staticmethod
+        def setup_context(ctx, inputs, output):
+            ctx.save_for_backward(*inputs)
+
+        @staticmethod
+        def backward(ctx, g):
+            a, b = ctx.saved_tensors
+            ga = matmul(g, _h(b)) if ctx.needs_input_grad[0] else None
+            gb = matmul(_h(a), g) if ctx.needs_input_grad[1] else None
+            return ga, gb
+
+    class Svd(torch.autograd.Function):
+        generate_vmap_rule = False
+
+        @staticmethod
+        def forward(mat):
+            return _svd_full_raw(mat.contiguous())
+
+        @staticmethod
+        def setup_context(ctx, inputs, output):
+            ctx.save_for_backward(*output)
+
+        @staticmethod
+        def backward(ctx, gu, gs, gvh):
+            u, s, vh = ctx.saved_tensors
+            return _svd_backward(u, s, vh, gu, gs, gvh)
+
+    class Qr(torch.autograd.Function):
+        generate_vmap_rule = False
+
+        @staticmethod
+        def forward(mat):
+            q, r = _qr_raw(mat)
+            d = torch.diagonal(r)
+            a = d.abs()
+            ph = torch.where(a > 0, d / a.clamp_min(1e-300 if d.dtype == torch.complex128 else 1e-30),
+                             torch.ones_like(d))
+            return q * ph[None, :], ph.conj()[:, None] * r
+
+        @staticmethod
+        def setup_context(ctx, inputs, output):
+            ctx.save_for_backward(*output)
+
+        @staticmethod
+        def backward(ctx, gq, gr):
+            q, r = ctx.saved_tensors
+            return _qr_backward(q, r, gq, gr)
+
+    # the decompositions' saved tensors are their own outputs: under torch.func they arrive wrapped, and
+    # the rules above only use torch ops and ``matmul`` on them
+    _AD.update(matmul=Matmul.apply, svd=Svd.apply, qr=Qr.apply)
+    return _AD
 
 
 def einsum2(expr: str, a, b):

@@ -771,9 +771,47 @@ def _make_sgate(name):
     return f
 
 
+_SPECS = {
+    "rx": G.rx_spec, "ry": G.ry_spec, "rz": G.rz_spec, "phase": G.phase_spec, "r": G.r_spec, "u": G.u_spec,
+    "cr": G.cr_spec, "iswap": G.iswap_spec, "exp1": G.exp1_spec,
+    "rxx": lambda theta=0.0: G.exp1_spec(G._xx_matrix, theta, half=True),
+    "ryy": lambda theta=0.0: G.exp1_spec(G._yy_matrix, theta, half=True),
+    "rzz": lambda theta=0.0: G.exp1_spec(G._zz_matrix, theta, half=True),
+}
+
+
+def _tensor_gate(name: str, kw: Dict[str, Any]) -> Tensor:
+    """Gate matrix as a device tensor when a parameter is a tensor (so that it stays on the autograd
+    tape): the same ``C0 + cos(a) C1 + sin(a) C2`` factors the state-vector path records."""
+    torch = _torch()
+    if name in ("any", "unitary"):
+        return _t(kw["unitary"])
+    if name == "exp":
+        u = _t(kw["unitary"])
+        d = int(round(np.sqrt(u.numel())))
+        return torch.linalg.matrix_exp(-1j * _t(kw["theta"]) * u.reshape(d, d))
+    if name == "su4":
+        gen = torch.einsum("i,iab->ab", _t(kw["theta"]).reshape(15), _t(G._su4_generators))
+        return torch.linalg.matrix_exp(-1j * gen)
+    mat = None
+    for spec in _SPECS[name](**kw):
+        th = spec.theta
+        if torch.is_tensor(th):
+            a = spec.scale * th.to(_device()).real + spec.offset
+            m = _t(spec.c0) + torch.cos(a) * _t(spec.c1) + torch.sin(a) * _t(spec.c2)
+        else:
+            m = _t(spec.matrix())
+        mat = m if mat is None else LA.matmul(m, mat)
+    return mat
+
+
 def _make_vgate(name, factory):
     def f(self, *index, split=None, **kw):
-        self.apply_general_gate(factory(**kw), *index, name=name, split=split)
+        if any(_torch().is_tensor(v) for v in kw.values()):
+            gate = _tensor_gate(name, kw)
+        else:
+            gate = factory(**kw)
+        self.apply_general_gate(gate, *index, name=name, split=split)
 
     f.__name__ = name
     return f
