@@ -13,10 +13,10 @@ import numpy as np
 MAGIC = 0x54434D31
 HDR_WORDS = 24
 RR_WORDS = 50
-OP_G1, OP_G2, OP_DIAG, OP_G1M, OP_EXPECT = 1, 2, 3, 4, 5
+OP_G1, OP_G2, OP_DIAG, OP_G1M, OP_EXPECT, OP_DIAGC, OP_DIAGB = 1, 2, 3, 4, 5, 6, 7
 R_MAX = 6
 CONST_FLAG = 1 << 30
-BK_TRIG, BK_COEF, BK_SELECT = 1, 2, 5
+BK_TRIG, BK_COEF, BK_SELECT, BK_PHASE = 1, 2, 5, 6
 
 
 def build_table(ginfo, cpool, params, ptab_size):
@@ -28,7 +28,16 @@ def build_table(ginfo, cpool, params, ptab_size):
         kind, slot, pidx, dim, off = (int(x) for x in rec[:5])
         k, o = cpool[off], cpool[off + 1]
         th = params[:, pidx]
-        if kind == BK_TRIG:
+        if kind == BK_PHASE:
+            r = int(rec[5])
+            phi = np.zeros(B)
+            for t in range(dim):
+                kt, ot, pt, rm = cpool[off + 4 * t: off + 4 * t + 4]
+                sgn = -1.0 if bin(r & int(rm)).count("1") & 1 else 1.0
+                phi += sgn * (kt * params[:, int(pt)] + ot)
+            ptab[:, slot] = np.cos(2 * np.pi * phi)
+            ptab[:, slot + 1] = np.sin(2 * np.pi * phi)
+        elif kind == BK_TRIG:
             a = k * th + o
             nn = dim * dim
             c = [
@@ -181,6 +190,18 @@ def run_pass(state, desc, ctab, ptab_row, eout=None):
                     phi += float(cf[nA + nB + e]) * z[None, None, :]
                 q += nC
                 regs = regs * np.exp(2j * np.pi * phi).astype(regs.dtype)
+            elif op == OP_DIAGB:
+                j, mask, slot = int(d[q + 1]), int(d[q + 2]), int(d[q + 3])
+                tidx = (wg_base[:, None] | tphys[None, :]).astype(np.uint64)
+                sgn = (1 - 2 * _parity(tidx & np.uint64(mask)))[:, :, None] * (
+                    1 - 2 * ((rid >> j) & 1).astype(np.int64))[None, None, :]
+                cs, sn = float(ptab_row[slot]), float(ptab_row[slot + 1])
+                regs = regs * (cs + 1j * sn * sgn).astype(regs.dtype)
+                q += 4
+            elif op == OP_DIAGC:
+                tb = np.asarray(ptab_row)[int(d[q + 1]): int(d[q + 1]) + 2 * NR]
+                regs = regs * (tb[0::2] + 1j * tb[1::2]).astype(regs.dtype)[None, None, :]
+                q += 2
             elif op == OP_EXPECT:
                 nZ, nX = int(d[q + 1]), int(d[q + 2])
                 q += 3

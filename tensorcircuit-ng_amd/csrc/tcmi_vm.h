@@ -44,12 +44,15 @@
 #define TCMI_OP_G1M 4
 #define TCMI_DIAG_CHUNK 8
 #define TCMI_OP_EXPECT 5
+#define TCMI_OP_DIAGB 7 /* {7, j, thread mask, slot}: a[r] *= exp(+-i phi), sign = z_j(r) * parity(thread index & mask); table = {cos, sin} */
+#define TCMI_OP_DIAGC 6 /* {6, slot}: a[r] *= table[r], 2^R complex factors in the per-batch table */
 #define TCMI_FLAG_NOSTORE 1
 #define TCMI_CONST_FLAG (1 << 30)
 #define TCMI_BK_TRIG 1
 #define TCMI_BK_COEF 2
 #define TCMI_BK_UDAG 3  /* U^dagger of C0 + cos C1 + sin C2 */
 #define TCMI_BK_KMAT 4  /* K = (dU/dtheta) U^dagger */
+#define TCMI_BK_PHASE 6 /* exp(2 pi i sum_t +-(k_t theta_t + o_t)) for one register index: rec = {6, slot, 0, nterms, off, r}, cpool = {k, o, param index, register mask} per term */
 #define TCMI_BK_SELECT 5 /* M = table[round(theta)]: cpool = {count, 0, matrices...} */
 
 #endif

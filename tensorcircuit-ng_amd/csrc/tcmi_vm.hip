@@ -39,6 +39,35 @@ __device__ __forceinline__ void dispatch_g1m(typename Cx<F>::type (&a)[NR], int 
   }
 }
 
+// a[r] *= cs + i * z_J(r) * ys   (z_J = +1 / -1 for bit J of r clear / set)
+template <typename F, int NR, int J>
+__device__ __forceinline__ void apply_diagb(typename Cx<F>::type (&a)[NR], F cs, F ys) {
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const auto v = a[r];
+    if ((r >> J) & 1) {
+      a[r].x = fma_<F>(v.y, ys, v.x * cs);
+      a[r].y = fma_<F>(-v.x, ys, v.y * cs);
+    } else {
+      a[r].x = fma_<F>(-v.y, ys, v.x * cs);
+      a[r].y = fma_<F>(v.x, ys, v.y * cs);
+    }
+  }
+}
+
+template <typename F, int NR, int R>
+__device__ __forceinline__ void dispatch_diagb(typename Cx<F>::type (&a)[NR], int j, F cs, F ys) {
+  switch (j) {
+    case 0: apply_diagb<F, NR, 0>(a, cs, ys); break;
+    case 1: if constexpr (R > 1) apply_diagb<F, NR, 1>(a, cs, ys); break;
+    case 2: if constexpr (R > 2) apply_diagb<F, NR, 2>(a, cs, ys); break;
+    case 3: if constexpr (R > 3) apply_diagb<F, NR, 3>(a, cs, ys); break;
+    case 4: if constexpr (R > 4) apply_diagb<F, NR, 4>(a, cs, ys); break;
+    case 5: if constexpr (R > 5) apply_diagb<F, NR, 5>(a, cs, ys); break;
+    default: break;
+  }
+}
+
 #define TCMI_G2_CASE(A, B)                                         \
   case (A * 8 + B):                                                \
     if constexpr (R > B) {                                         \
@@ -266,6 +295,29 @@ __global__ __launch_bounds__(1 << LT, (MODE == 1 && LT == 8) ? 2 : 1) void pass_
           a[r].x = v.x * c - v.y * s;
           a[r].y = v.x * s + v.y * c;
         }
+      } else if (MODE == 0 && op == TCMI_OP_DIAGB) {
+        // one term on register bit j and thread bits: exp(i phi z_j(r) s(thread)), {cos, sin} from the builder
+        const int j = desc[q + 1];
+        const uint32_t m = (uint32_t)desc[q + 2];
+        const KPtr<F> tp = ptab + desc[q + 3];
+        q += 4;
+        const F cs = tp[0], sn = tp[1];
+        const F ys = (__popc((wg_base | tphys) & m) & 1) ? -sn : sn;
+        dispatch_diagb<F, NR, R>(a, j, cs, ys);
+      } else if (MODE == 0 && op == TCMI_OP_DIAGC) {
+        // diagonal terms on register bits only: the 2^R phase factors are wave-uniform and come from the
+        // builder (scalar loads), 4 lane-instructions per amplitude
+        const KPtr<F> tp = ptab + desc[q + 1];
+        q += 2;
+        F tb[2 * NR];
+#pragma unroll
+        for (int i = 0; i < 2 * NR; ++i) tb[i] = tp[i];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const C v = a[r];
+          a[r].x = v.x * tb[2 * r] - v.y * tb[2 * r + 1];
+          a[r].y = v.x * tb[2 * r + 1] + v.y * tb[2 * r];
+        }
       } else if (MODE == 1 && op == TCMI_OP_EXPECT) {
         // <psi|P_t|psi> partial sums for Pauli strings whose X/Y bits are register bits of this round
         const int nZ = desc[q + 1], nX = desc[q + 2];
@@ -356,6 +408,21 @@ __global__ void build_kernel(const int* __restrict__ ginfo, int nrec, const doub
     const double* c1 = c0 + nn;
     const double* c2 = c1 + nn;
     for (int i = 0; i < nn; ++i) out[i] = (F)(c0[i] + c * c1[i] + s * c2[i]);
+  } else if (kind == TCMI_BK_PHASE) {
+    // one entry of a DIAGC table: exp(2 pi i sum_t s_t(r) (k_t theta_t + o_t)), s_t = parity of r & mask_t
+    const int r = rec[5];
+    const double* tp = cpool + off;
+    double phi = 0.0;
+    for (int t = 0; t < dim; ++t) {
+      const double th = (double)params[(long long)b * pstride + (int)tp[4 * t + 2]];
+      const double v = tp[4 * t] * th + tp[4 * t + 1];
+      phi += (__popc((unsigned)r & (unsigned)tp[4 * t + 3]) & 1) ? -v : v;
+    }
+    phi -= rint(phi);
+    double s, c;
+    sincospi(2.0 * phi, &s, &c);
+    out[0] = (F)c;
+    out[1] = (F)s;
   } else if (kind == TCMI_BK_COEF) {
     out[0] = (F)(ang - rint(ang));  // phase coefficient in turns, reduced to [-0.5, 0.5]
   } else if (kind == TCMI_BK_SELECT) {

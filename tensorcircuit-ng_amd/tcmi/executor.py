@@ -400,6 +400,12 @@ def vm_cost_us(plan: "P.CompiledPlan") -> float:
                     nA, nB, nC = (int(x) for x in d[q + 1: q + 4])
                     t += VM_COST["diag"]
                     q += 5 + nA + 2 * nB + nC
+                elif op == P.OP_DIAGC:
+                    t += VM_COST["g1"]
+                    q += 2
+                elif op == P.OP_DIAGB:
+                    t += VM_COST["g1"]
+                    q += 4
                 else:
                     raise ValueError(op)
             pc = q

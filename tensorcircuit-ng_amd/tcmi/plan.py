@@ -41,8 +41,11 @@ OP_G2 = 2
 OP_DIAG = 3
 OP_G1M = 4
 OP_EXPECT = 5
+OP_DIAGB = 7   # one diagonal term on a register bit x thread bits: multiply by exp(+-i phi), sign per thread
+OP_DIAGC = 6   # diagonal terms on register bits only: multiply by a 2^R table of phase factors
 FLAG_NOSTORE = 1
 DIAG_CHUNK = 8
+MAX_DIAGB = 5  # more register-x-thread terms than this in one DIAG op: the per-thread sincos path is cheaper
 # G2 kinds: 0 general, 1 = CNOT(control ja, target jb), 2 = CNOT(control jb, target ja), 3 = SWAP
 CONST_FLAG = 1 << 30
 
@@ -51,6 +54,7 @@ BK_TRIG = 1  # M = C0 + cos(k*theta + off) C1 + sin(k*theta + off) C2
 BK_COEF = 2  # phase coefficient in turns = k*theta + off
 BK_UDAG = 3  # U^dagger (adjoint sweep)
 BK_KMAT = 4  # K = (dU/dtheta) U^dagger (adjoint sweep)
+BK_PHASE = 6  # one entry exp(2 pi i sum_t +-(k_t theta_t + o_t)) of a DIAGC table
 BK_SELECT = 5  # M = table[round(param)]: one of several constant matrices (cut contraction bonds)
 
 
@@ -578,7 +582,7 @@ def _coef_slot(tables: Tables, gi: int, ti: int, t: DiagTerm):
 
 
 def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tables: Tables,
-                batch_diag: bool = True, backward: bool = False) -> np.ndarray:
+                batch_diag: bool = True, backward: bool = False, phase_tables: bool = True) -> np.ndarray:
     """``backward=True`` encodes an adjoint-sweep pass: ``gates`` is the reversed gate list, every op
     carries U^dagger (+ K and a gradient slot for parametrised gates), see csrc/tcmi_vm.h."""
     T, R, LT = cfg.T, cfg.R, cfg.LT
@@ -675,6 +679,37 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
                         raise NotImplementedError(
                             "diagonal term with >=2 register bits and non-register bits"
                         )
+            if not backward and not A_ and len(B_) <= MAX_DIAGB and phase_tables:
+                # No per-thread sincos: the builder evaluates every phase factor once, in float64.
+                # Terms on register bits only -> one table of 2^R factors, the same for all threads
+                # (DIAGC); a term on one register bit and thread bits -> exp(+-i phi) with the sign
+                # z_j(r) * parity(thread & mask) (DIAGB).  4 lane-instructions per amplitude each.
+                def phase_terms(ts):
+                    off = len(tables.cpool)
+                    for rm, t in ts:
+                        if t.param is None:
+                            tables.cpool += [0.0, t.const / TWO_PI, 0.0, float(rm)]
+                        else:
+                            tables.cpool += [t.param.scale / TWO_PI, (t.const + t.param.offset) / TWO_PI,
+                                             float(t.param.index), float(rm)]
+                    return off
+
+                if C_:
+                    NR = 1 << R
+                    base = tables.alloc(2 * NR)
+                    off = phase_terms(C_)
+                    for r in range(NR):
+                        tables.ginfo.append([BK_PHASE, base + 2 * r, 0, len(C_), off, r, 0, 0])
+                    ops.extend([OP_DIAGC, base])
+                    nops += 1
+                for j, nmask, t in B_:
+                    base = tables.alloc(2)
+                    off = phase_terms([(0, t)])
+                    tables.ginfo.append([BK_PHASE, base, 0, 1, off, 0, 0, 0])
+                    ops.extend([OP_DIAGB, j, nmask, base])
+                    nops += 1
+                pend_diag.clear()
+                return
             # coefficients live contiguously in the per-batch table (bulk scalar loads), padded
             # to a multiple of DIAG_CHUNK with zero terms
             padA = (-len(A_)) % DIAG_CHUNK

@@ -40,6 +40,50 @@ def _mixed(n, d, seed):
     return c, ops
 
 
+def _op_histogram(pl):
+    seen = {}
+    for desc in pl.descs:
+        w = np.asarray(desc).view(np.int32)
+        pc = P.HDR_WORDS
+        for _ in range(int(w[5])):
+            nops, nw = int(w[pc]), int(w[pc + 1])
+            q = pc + P.RR_WORDS
+            for _o in range(nops):
+                op = int(w[q])
+                seen[op] = seen.get(op, 0) + 1
+                if op == P.OP_DIAG:
+                    q += 5 + int(w[q + 1]) + 2 * int(w[q + 2]) + int(w[q + 3])
+                else:
+                    q += {P.OP_G2: 4, P.OP_G1M: 3, P.OP_DIAGC: 2, P.OP_DIAGB: 4}[op]
+            assert q == pc + P.RR_WORDS + nw
+            pc = q
+    return seen
+
+
+def test_generic_diag_form_still_covered():
+    """Many register-x-thread terms in one diagonal layer keep the per-thread sincos op (OP_DIAG)."""
+    n = 12
+    c = tc.Circuit(n)
+    ops = []
+    for i in range(n):
+        c.h(i)
+        ops.append((G.H, [i]))
+    rng = np.random.default_rng(0)
+    for i in range(n):
+        for j in range(i + 1, n):
+            th = float(rng.uniform(0, 2 * np.pi))
+            c.rzz(i, j, theta=th)
+            ops.append((G.rzz(th), [i, j]))
+    for i in range(n):
+        c.rx(i, theta=0.1 * (i + 1))
+        ops.append((G.rx(0.1 * (i + 1)), [i]))
+    cfg = P.PlanConfig(R=3, LT=8, lowbits=5, vec=2)
+    pl = P.compile_plan(c._gate_records(), n, cfg, nparams=len(c._params))
+    assert _op_histogram(pl).get(P.OP_DIAG, 0) > 0
+    psi = E.run_plan(pl, np.array([float(x) for x in c._params]))
+    np.testing.assert_allclose(psi, dense.run(n, ops), atol=1e-12)
+
+
 @pytest.mark.parametrize("dtype", ["complex64", "complex128"])
 @pytest.mark.parametrize("n,d", [(8, 2), (10, 3), (13, 2), (14, 2)])
 def test_plan_emulated_matches_dense(dtype, n, d):
@@ -69,6 +113,12 @@ def test_plan_variants(lowbits, R, LT):
     psi = E.run_plan(pl, np.array([float(x) for x in c._params]))
     ref = dense.run(n, W.hea_b_ops(n, d, pb) + [(G.CNOT, [0, n - 1]), (G.random_two_qubit_gate(3), [n - 1, 1])])
     np.testing.assert_allclose(psi, ref, atol=1e-12)
+    # the diagonal layers are lowered to builder-evaluated phase tables (DIAGC: register bits only,
+    # DIAGB: one register bit x thread bits); the per-thread sincos form is the fallback
+    seen = _op_histogram(pl)
+    assert seen.get(P.OP_DIAGC, 0) > 0 and seen.get(P.OP_DIAGB, 0) > 0
+    kinds = {int(r[0]) for r in np.asarray(pl.ginfo).reshape(-1, 8)}
+    assert P.BK_PHASE in kinds
     for pp in pl.passes:
         assert pp.tile_bits[: min(lowbits, cfg.T)] == list(range(min(lowbits, cfg.T)))  # coalescing run
         assert pp.rounds[0].reg_tb[0] == 0 and pp.rounds[-1].reg_tb[0] == 0          # 16-byte accesses
