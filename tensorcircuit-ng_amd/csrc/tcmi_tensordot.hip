@@ -369,29 +369,41 @@ int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, 
   if (!A || !B || !C || M < 1 || N < 1 || K < 1 || batch < 1 || K > (1ll << 30))
     return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm: bad argument");
   if (dtype == TCMI_C64 && M * N >= 1024) {
-    const long long gx = (N + TCMI_BN - 1) / TCMI_BN, gy = (M + TCMI_BM - 1) / TCMI_BM;
-    if (gy > 65535 || batch > 65535) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm: grid too large");
-    dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)batch), block(256, 1, 1);
-    if (trans_a)
-      hipLaunchKernelGGL(tcmi::cgemm_mfma_kernel<true>, grid, block, 0, st, reinterpret_cast<const float2*>(A),
-                         reinterpret_cast<const float2*>(B), reinterpret_cast<float2*>(C), (int)M, (int)N, (int)K,
-                         strideA, strideB, strideC);
-    else
-      hipLaunchKernelGGL(tcmi::cgemm_mfma_kernel<false>, grid, block, 0, st, reinterpret_cast<const float2*>(A),
-                         reinterpret_cast<const float2*>(B), reinterpret_cast<float2*>(C), (int)M, (int)N, (int)K,
-                         strideA, strideB, strideC);
+    const long long gx = (N + TCMI_BN - 1) / TCMI_BN;
+    if (batch > 65535) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm: grid too large");
+    // gridDim.y holds the row tiles: more than 65535 of them (skinny products of a contraction tree, M up to
+    // 2^27) are issued as row chunks — plain pointer offsets for a row-major A
+    const long long mchunk = 65535ll * TCMI_BM / 2;
+    if (M > mchunk && trans_a) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm: grid too large (transposed A)");
+    for (long long m0 = 0; m0 < M; m0 += mchunk) {
+      const long long mm = (M - m0 < mchunk) ? (M - m0) : mchunk;
+      const float2* Ap = reinterpret_cast<const float2*>(A) + (trans_a ? 0 : m0 * K);
+      float2* Cp = reinterpret_cast<float2*>(C) + m0 * N;
+      dim3 grid((unsigned)gx, (unsigned)((mm + TCMI_BM - 1) / TCMI_BM), (unsigned)batch), block(256, 1, 1);
+      if (trans_a)
+        hipLaunchKernelGGL(tcmi::cgemm_mfma_kernel<true>, grid, block, 0, st, Ap, reinterpret_cast<const float2*>(B), Cp,
+                           (int)mm, (int)N, (int)K, strideA, strideB, strideC);
+      else
+        hipLaunchKernelGGL(tcmi::cgemm_mfma_kernel<false>, grid, block, 0, st, Ap, reinterpret_cast<const float2*>(B), Cp,
+                           (int)mm, (int)N, (int)K, strideA, strideB, strideC);
+    }
   } else if (dtype == TCMI_C128 && M * N >= 1024) {
-    const long long gx = (N + TCMI_BN - 1) / TCMI_BN, gy = (M + TCMI_BM - 1) / TCMI_BM;
-    if (gy > 65535 || batch > 65535) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm: grid too large");
-    dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)batch), block(256, 1, 1);
-    if (trans_a)
-      hipLaunchKernelGGL(tcmi::zgemm_mfma_kernel<true>, grid, block, 0, st, reinterpret_cast<const double2*>(A),
-                         reinterpret_cast<const double2*>(B), reinterpret_cast<double2*>(C), (int)M, (int)N, (int)K,
-                         strideA, strideB, strideC);
-    else
-      hipLaunchKernelGGL(tcmi::zgemm_mfma_kernel<false>, grid, block, 0, st, reinterpret_cast<const double2*>(A),
-                         reinterpret_cast<const double2*>(B), reinterpret_cast<double2*>(C), (int)M, (int)N, (int)K,
-                         strideA, strideB, strideC);
+    const long long gx = (N + TCMI_BN - 1) / TCMI_BN;
+    if (batch > 65535) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm: grid too large");
+    const long long mchunk = 65535ll * TCMI_BM / 2;
+    if (M > mchunk && trans_a) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm: grid too large (transposed A)");
+    for (long long m0 = 0; m0 < M; m0 += mchunk) {
+      const long long mm = (M - m0 < mchunk) ? (M - m0) : mchunk;
+      const double2* Ap = reinterpret_cast<const double2*>(A) + (trans_a ? 0 : m0 * K);
+      double2* Cp = reinterpret_cast<double2*>(C) + m0 * N;
+      dim3 grid((unsigned)gx, (unsigned)((mm + TCMI_BM - 1) / TCMI_BM), (unsigned)batch), block(256, 1, 1);
+      if (trans_a)
+        hipLaunchKernelGGL(tcmi::zgemm_mfma_kernel<true>, grid, block, 0, st, Ap, reinterpret_cast<const double2*>(B), Cp,
+                           (int)mm, (int)N, (int)K, strideA, strideB, strideC);
+      else
+        hipLaunchKernelGGL(tcmi::zgemm_mfma_kernel<false>, grid, block, 0, st, Ap, reinterpret_cast<const double2*>(B), Cp,
+                           (int)mm, (int)N, (int)K, strideA, strideB, strideC);
+    }
   } else if (M * N < 1024 && K >= 2048 && (dtype == TCMI_C64 || dtype == TCMI_C128)) {
     const long long total = M * N;
     int to_log2 = 0;

@@ -221,6 +221,197 @@ def search_path(inputs, output, size_dict, trials: int = 0, seed: int = 0, targe
     return best
 
 
+RECONF_SUBTREE = 10   # intermediates per re-optimised subtree (3^k / 2 splits per dynamic programme)
+RECONF_ALPHA = 0.0     # cost of a step = MACs + alpha * (elements read + written)
+
+
+def reconfigure_path(inputs, output, size_dict, path, subtree_size: int = 8, max_size: Optional[int] = None,
+                     max_passes: int = 4, time_limit: float = 30.0, alpha: Optional[float] = None):
+    """Subtree reconfiguration of a contraction path (the refinement cotengra applies to its trees,
+    reference cons.py:1168-1190 ``optimizer_reconf`` / experimental.py ``slicing_reconf_opts``): for every
+    internal node of the tree, the subtree below it is cut off at ``subtree_size`` intermediates and those are
+    re-contracted in the order that an exact dynamic programme over their subsets finds cheapest (flops);
+    intermediates larger than ``max_size`` elements are not allowed.  Passes repeat until nothing improves.
+    Index sets are bit masks (python ints).  Networks with an index on more than two tensors are returned
+    unchanged.  Returns a path in the same linear format."""
+    import math
+    import time
+
+    n = len(inputs)
+    if n < 3:
+        return list(path)
+    eid: Dict[int, int] = {}
+    occ: Dict[int, int] = {}
+    for s in inputs:
+        for e in s:
+            eid.setdefault(e, len(eid))
+            occ[e] = occ.get(e, 0) + 1
+    for e in output:
+        eid.setdefault(e, len(eid))
+        occ[e] = occ.get(e, 0) + 1
+    if any(v > 2 for v in occ.values()):
+        return list(path)
+    lw = [0.0] * len(eid)
+    for e, k in eid.items():
+        lw[k] = math.log2(size_dict[e])
+    uniform = all(abs(x - 1.0) < 1e-12 for x in lw)
+
+    def lsize(mask: int) -> float:
+        if uniform:
+            return float(mask.bit_count())
+        t = 0.0
+        while mask:
+            low = mask & -mask
+            t += lw[low.bit_length() - 1]
+            mask ^= low
+        return t
+
+    cap = float("inf") if max_size is None else math.log2(max_size) + 1e-9
+    if alpha is None:
+        alpha = RECONF_ALPHA
+    # SSA tree: an index kept by a contraction is one that occurs once below it (each index has two ends)
+    idx: Dict[int, int] = {}
+    kids: Dict[int, Tuple[int, int]] = {}
+    for i, s in enumerate(inputs):
+        m = 0
+        for e in s:
+            m ^= 1 << eid[e]
+        idx[i] = m
+    ids = list(range(n))
+    nxt = n
+    for a, b in path:
+        ib = ids.pop(max(a, b))
+        ia = ids.pop(min(a, b))
+        idx[nxt] = idx[ia] ^ idx[ib]
+        kids[nxt] = (ia, ib)
+        ids.append(nxt)
+        nxt += 1
+    root = ids[-1] if len(ids) == 1 else None
+    if root is None:          # disconnected leftovers: leave such paths alone
+        return list(path)
+
+    def step_cost(a: int, b: int) -> float:
+        c = 2.0 ** lsize(idx[a] | idx[b])
+        if alpha:
+            c += alpha * (2.0 ** lsize(idx[a]) + 2.0 ** lsize(idx[b]) + 2.0 ** lsize(idx[a] ^ idx[b]))
+        return c
+
+    def optimise(x: int) -> bool:
+        nonlocal nxt
+        # frontier: expand the most expensive internal node until subtree_size intermediates
+        front = [x]
+        inner = []
+        while len(front) < subtree_size:
+            cand = [f for f in front if f in kids]
+            if not cand:
+                break
+            f = max(cand, key=lambda v: step_cost(*kids[v]))
+            front.remove(f)
+            inner.append(f)
+            front.extend(kids[f])
+        k = len(front)
+        if k < 3:
+            return False
+        old = sum(step_cost(*kids[v]) for v in inner)
+        masks = [idx[f] for f in front]
+        full = (1 << k) - 1
+        sidx = [0] * (full + 1)
+        ssz = [0.0] * (full + 1)
+        best = [float("inf")] * (full + 1)
+        split = [0] * (full + 1)
+        for i in range(k):
+            sidx[1 << i] = masks[i]
+            ssz[1 << i] = 2.0 ** lsize(masks[i]) if alpha else 0.0
+            best[1 << i] = 0.0
+        order = sorted(range(1, full + 1), key=lambda v: v.bit_count())
+        for S in order:
+            if S & (S - 1) == 0:
+                continue
+            low = S & -S
+            sidx[S] = sidx[low] ^ sidx[S ^ low]
+            ls = lsize(sidx[S])
+            if alpha:
+                ssz[S] = 2.0 ** ls
+            if S != full and ls > cap:
+                continue                         # this intermediate would not fit
+            bS, sS = float("inf"), 0
+            A = (S - 1) & S
+            while A:
+                B = S ^ A
+                if A > B:
+                    ca, cb = best[A], best[B]
+                    if ca < float("inf") and cb < float("inf") and (sidx[A] & sidx[B]):
+                        c = ca + cb + 2.0 ** lsize(sidx[A] | sidx[B])
+                        if alpha:
+                            c += alpha * (ssz[A] + ssz[B] + ssz[S])
+                        if c < bS:
+                            bS, sS = c, A
+                A = (A - 1) & S
+            best[S], split[S] = bS, sS
+        if not best[full] < old * (1.0 - 1e-9):
+            return False
+        # rebuild the subtree (the root keeps its id so that its parent stays valid)
+        for v in inner:
+            del kids[v]
+            if v != x:
+                del idx[v]
+
+        def build(S: int, top: bool) -> int:
+            nonlocal nxt
+            if S & (S - 1) == 0:
+                return front[S.bit_length() - 1]
+            A = split[S]
+            l, r = build(A, False), build(S ^ A, False)
+            if top:
+                v = x
+            else:
+                v = nxt
+                nxt += 1
+                idx[v] = sidx[S]
+            kids[v] = (l, r)
+            return v
+
+        build(full, True)
+        return True
+
+    t0 = time.time()
+    for _ in range(max_passes):
+        changed = False
+        todo = sorted(kids, key=lambda v: -step_cost(*kids[v]))
+        for v in todo:
+            if v not in kids:
+                continue
+            if optimise(v):
+                changed = True
+            if time.time() - t0 > time_limit:
+                break
+        if not changed or time.time() - t0 > time_limit:
+            break
+    # back to the linear format (post-order)
+    out_path: List[Tuple[int, int]] = []
+    pos = list(range(n))
+    stack = [(root, False)]
+    order: List[int] = []
+    while stack:
+        v, done = stack.pop()
+        if v not in kids:
+            continue
+        if done:
+            order.append(v)
+        else:
+            stack.append((v, True))
+            stack.append((kids[v][1], False))
+            stack.append((kids[v][0], False))
+    for v in order:
+        l, r = kids[v]
+        ia, ib = pos.index(l), pos.index(r)
+        out_path.append((min(ia, ib), max(ia, ib)))
+        for i in sorted((ia, ib), reverse=True):
+            pos.pop(i)
+        pos.append(v)
+    return out_path
+
+
 @dataclass
 class ContractionTree:
     """Path + slicing of one network (the part of cotengra's ``ContractionTree`` the reference uses:
@@ -238,6 +429,8 @@ class ContractionTree:
         inputs = [list(s) for s in inputs]
         if path is None:
             path = search_path(inputs, output, size_dict, trials=trials, seed=seed)
+            if trials > 0:
+                path = reconfigure_path(inputs, output, size_dict, path, subtree_size=RECONF_SUBTREE)
         t = cls(inputs, list(output), dict(size_dict), [tuple(p) for p in path])
         t.trials, t.seed = trials, seed
         return t
@@ -407,8 +600,23 @@ class ContractionTree:
         if best is not None:
             self.path = [tuple(x) for x in best[1]]
             self.sliced_inds = list(best[2])
+            if trials > 0:
+                self._reconfigure_sliced(target_size)
             return self
         return self._slice_repath(target_size, max_slices, max_candidates)
+
+    def _reconfigure_sliced(self, target_size: int) -> None:
+        """Subtree reconfiguration of the sliced network under the size cap (what cotengra's
+        ``slicing_reconf_opts`` does after choosing the sliced indices)."""
+        sl = set(self.sliced_inds)
+        inputs = [[e for e in s if e not in sl] for s in self.inputs]
+        output = [e for e in self.output if e not in sl]
+        before = self.total_flops()
+        old = self.path
+        self.path = [tuple(x) for x in reconfigure_path(inputs, output, self.size_dict, old,
+                                                       subtree_size=RECONF_SUBTREE, max_size=target_size)]
+        if self.total_flops() > before or self.max_size() > target_size:
+            self.path = old
 
     def _slice_repath(self, target_size: int, max_slices: int = 1 << 16, max_candidates: int = 12) -> "ContractionTree":
         """Each step tries the (non-output) indices of the largest intermediates, re-paths the sliced

@@ -293,3 +293,24 @@ def test_cut_contraction_full_size_batch_and_grad():
         np.testing.assert_allclose(res["cut"][0][b], dense.run(n, W.hea_b_ops(n, d, pbs[b])), atol=1e-5)
     np.testing.assert_allclose(res["cut"][1], res["plain"][1], atol=1e-5)
     np.testing.assert_allclose(res["cut"][2], res["plain"][2], atol=2e-4)
+
+
+@pytest.mark.parametrize("dt", ["complex64", "complex128"])
+def test_tall_gemm_is_issued_in_row_chunks(dt):
+    """More than 65535 row tiles (skinny products of a reconfigured contraction tree): row chunks in the
+    launcher, same numbers."""
+    import torch
+    from tcmi import _lib
+
+    tdt = torch.complex64 if dt == "complex64" else torch.complex128
+    M, N, K = (1 << 22) + 192, 16, 4
+    g = torch.Generator(device="cuda").manual_seed(0)
+    a = torch.randn(M, K, dtype=tdt, device="cuda", generator=g)
+    b = torch.randn(K, N, dtype=tdt, device="cuda", generator=g)
+    c = torch.empty(M, N, dtype=tdt, device="cuda")
+    code = _lib.TCMI_C64 if dt == "complex64" else _lib.TCMI_C128
+    _lib.check(_lib.lib().tcmi_cgemm(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, 1, 0, 0, 0, 0, code,
+                                     torch.cuda.current_stream().cuda_stream), "tcmi_cgemm")
+    ref = a @ b
+    tol = 1e-5 if dt == "complex64" else 1e-12
+    assert float((c - ref).abs().max()) < tol * float(ref.abs().max())

@@ -130,3 +130,80 @@ def test_circuit_tn_structure():
         t = tn.ContractionTree.from_path([[0, 1], [1, 2], [2, 0]], [], {0: 2, 1: 2, 2: 2})
         assert len(t.path) == 2 and t.max_size() <= 4
         return
+
+
+# ---- subtree reconfiguration -------------------------------------------------------------------------
+def _rand_net(nt, deg, seed, dangling=2):
+    rng = np.random.default_rng(seed)
+    inputs = [[] for _ in range(nt)]
+    e = 0
+    stubs = [i for i in range(nt) for _ in range(deg)]
+    rng.shuffle(stubs)
+    for a, b in zip(stubs[0::2], stubs[1::2]):
+        if a != b:
+            inputs[a].append(e)
+            inputs[b].append(e)
+            e += 1
+    output = []
+    for i in range(dangling):
+        inputs[i].append(e)
+        output.append(e)
+        e += 1
+    return inputs, output, {k: 2 for k in range(e)}
+
+
+@pytest.mark.parametrize("nt,seed", [(12, 0), (30, 1), (60, 2)])
+def test_reconfigure_path_is_valid_and_not_worse(nt, seed):
+    from tcmi import tn
+
+    inputs, output, sd = _rand_net(nt, 3, seed)
+    p0 = tn.greedy_path(inputs, output, sd)
+    m0, f0 = tn._path_stats(inputs, output, sd, p0)
+    p1 = tn.reconfigure_path(inputs, output, sd, p0, subtree_size=8)
+    m1, f1 = tn._path_stats(inputs, output, sd, p1)
+    assert len(p1) == len(p0) and f1 <= f0
+    # same value: contract with numpy along both paths
+    rng = np.random.default_rng(seed)
+    arrays = [rng.normal(size=[2] * len(s)) + 1j * rng.normal(size=[2] * len(s)) for s in inputs]
+
+    def run(path):
+        cur = [(a, list(s)) for a, s in zip(arrays, inputs)]
+        for a, b in path:
+            (tb, sb), (ta, sa) = cur.pop(b), cur.pop(a)
+            live = {e for t, s in cur for e in s} | set(output)
+            con = [e for e in sa if e in sb and e not in live]
+            t = np.tensordot(ta, tb, ([sa.index(e) for e in con], [sb.index(e) for e in con]))
+            cur.append((t, [e for e in sa if e not in con] + [e for e in sb if e not in con]))
+        t, s = cur[0]
+        return np.transpose(t, [s.index(e) for e in output])
+
+    np.testing.assert_allclose(run(p1), run(p0), rtol=1e-9, atol=1e-9)
+    # with a size cap no intermediate exceeds it as long as the input path respected it
+    p2 = tn.reconfigure_path(inputs, output, sd, p0, subtree_size=8, max_size=m0)
+    m2, f2 = tn._path_stats(inputs, output, sd, p2)
+    assert m2 <= m0 and f2 <= f0
+
+
+def test_reconfigure_improves_a_poor_path():
+    from tcmi import tn
+
+    inputs, output, sd = _rand_net(80, 3, 5, dangling=0)
+    rng = np.random.default_rng(0)
+    p0 = tn.greedy_path(inputs, output, sd, temperature=1.0, alpha=0.0, rng=rng)
+    _, f0 = tn._path_stats(inputs, output, sd, p0)
+    _, f1 = tn._path_stats(inputs, output, sd, tn.reconfigure_path(inputs, output, sd, p0, subtree_size=8))
+    assert f1 < 0.5 * f0
+
+
+def test_sliced_tree_is_reconfigured_within_the_cap():
+    from tcmi import tn
+
+    inputs, output, sd = _rand_net(90, 3, 9, dangling=0)
+    tree = tn.ContractionTree.from_path(inputs, output, sd, trials=8, seed=1)
+    target = max(4, tree.max_size() // 16)
+    tree.slice_to(target)
+    assert tree.max_size() <= target and tree.nslices > 1
+    ref = tn.ContractionTree.from_path(inputs, output, sd, path=tn.greedy_path(inputs, output, sd))
+    ref.trials = 0
+    ref.slice_to(target)
+    assert tree.total_flops() <= ref.total_flops()
