@@ -410,14 +410,14 @@ def main():
             flops_per_launch = 8.0 * M * N * K * B          # complex MAC = 8 real flops
             achieved = flops_per_launch / (kern_ms * 1e-3) / 1e12
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01e_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r01l_traffic.json")
             if os.path.exists(tpath):
                 traffic = json.load(open(tpath))["hbm_bytes_per_output_element"] * B * M * N
             roof = {
                 "bound": "mfma", "kernel": "tcmi::cgemm_mfma_kernel<true> (cut-contraction join GEMM)",
                 "achieved": achieved, "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_F32_PEAK_TFS, "traffic": traffic,
-                "traffic_source": "profiles/r01e_traffic.json (rocprofv3 PMC, scaled by output elements)" if traffic else None,
+                "traffic_source": "profiles/r01l_traffic.json (rocprofv3 PMC, scaled by output elements)" if traffic else None,
                 "launches_per_step": 1, "avg_launch_us": kern_ms * 1e3,
                 "algorithmic_flops_per_launch": flops_per_launch,
                 "algorithmic_bytes_per_launch": 8.0 * B * (K * (M + N) + M * N),
