@@ -108,6 +108,15 @@ int tcmi_run_adjoint_pass(void* psi, void* lam, long long state_stride, int batc
 int tcmi_permute_bits(const void* in, void* out, int rank, const int* srcbit, int batch,
                       long long batch_stride, int dtype, void* stream);
 
+/* Contraction of a big [2]^rank tensor with a small one over `nk` (1..5, or 6..8 when n <= 16) of its axes at ARBITRARY bit positions
+ * (pos = host array, ascending bit indices, bit j of the small operand's row index <-> pos[j]; small = [2^nk][n]
+ * row-major, 2^nk * n <= 4096, n a power of two):  out[f][n] (big_first) or out[n][f], f = the free bits of the big
+ * tensor in their stored order.  The big-tensor x gate-like-tensor steps of a contraction tree
+ * (tensorcircuit/cons.py:948 contract_between on a boundary tensor) read the big operand once and write the
+ * result once instead of permute + skinny GEMM. */
+int tcmi_contract_scattered(const void* big, int rank, const int* pos, int nk, const void* small_operand, long long n,
+                            void* out, int big_first, int dtype, void* stream);
+
 /* Batched complex GEMM C[M x N] = A[M x K] . B[K x N], row-major interleaved complex, strides in
  * elements between batch members; trans_a != 0: A is stored [K x M] (k-major).  complex64 runs on the f32 MFMA pipe (exact f32 FMA);
  * complex128 on fp64 VALU.  Replaces backend.tensordot's GEMM (numpy/jax/torch BLAS in the reference). */

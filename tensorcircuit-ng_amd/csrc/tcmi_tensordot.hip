@@ -11,6 +11,8 @@
 
 #include "tcmi_dev.h"
 
+extern "C" int tcmi_set_error_(int code, const char* msg);
+
 namespace tcmi {
 
 // out[o] = in[src(o)], src(o) = OR_b ((o >> b) & 1) << srcbit[b]   (axis permutation of a [2]^rank tensor)
@@ -335,9 +337,193 @@ __global__ __launch_bounds__(256) void cgemm_splitk_kernel(const typename Cx<F>:
   }
 }
 
+
+// ---- big tensor x small tensor over scattered bit positions -------------------------------------------------
+// out[f][n] (big_first) or out[n][f] = sum_k big[deposit(f) | koff(k)] * small[k][n]: the contracted axes of the big
+// [2]^rank tensor sit at arbitrary bit positions pos[0] < pos[1] < ... (bit j of k <-> pos[j]); f runs over the free
+// bits in their stored order.  One thread per f: K gathered loads (coalesced across threads when the low bits are
+// free), the small operand broadcast from LDS, NT accumulators at a time, contiguous stores.  Reads the big
+// tensor once and writes the result once — the permute + skinny-GEMM route moves the big tensor three times.
+struct ScatPos { int p[8]; };
+
+template <typename F, int LK, int NT>
+__global__ __launch_bounds__(256) void contract_scattered_kernel(const typename Cx<F>::type* __restrict__ big,
+                                                                 const typename Cx<F>::type* __restrict__ small_,
+                                                                 typename Cx<F>::type* __restrict__ out, int rank,
+                                                                 ScatPos pos, int N, int big_first) {
+  using C = typename Cx<F>::type;
+  constexpr int K = 1 << LK;
+  extern __shared__ __attribute__((aligned(16))) char smem_[];
+  C* sB = reinterpret_cast<C*>(smem_);
+  __shared__ unsigned long long koff[K];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < K * N; i += 256) sB[i] = small_[i];
+  if (tid < K) {
+    unsigned long long off = 0;
+#pragma unroll
+    for (int j = 0; j < LK; ++j)
+      if ((tid >> j) & 1) off |= 1ull << pos.p[j];
+    koff[tid] = off;
+  }
+  __syncthreads();
+  const unsigned long long nf = 1ull << (rank - LK);
+  const unsigned long long step = (unsigned long long)gridDim.x * 256;
+  for (unsigned long long f = (unsigned long long)blockIdx.x * 256 + tid; f < nf; f += step) {
+    unsigned long long x = f;
+#pragma unroll
+    for (int j = 0; j < LK; ++j) {
+      const unsigned long long low = (1ull << pos.p[j]) - 1ull;
+      x = ((x & ~low) << 1) | (x & low);
+    }
+    C a[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) a[k] = big[x | koff[k]];
+    for (int n0 = 0; n0 < N; n0 += NT) {
+      C acc[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) { acc[n].x = 0; acc[n].y = 0; }
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const C b = sB[k * N + n0 + n];
+          acc[n].x = fma_<F>(a[k].x, b.x, acc[n].x);
+          acc[n].x = fma_<F>(-a[k].y, b.y, acc[n].x);
+          acc[n].y = fma_<F>(a[k].x, b.y, acc[n].y);
+          acc[n].y = fma_<F>(a[k].y, b.x, acc[n].y);
+        }
+      }
+      if (big_first) {
+        C* dst = out + f * (unsigned long long)N + n0;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) dst[n] = acc[n];
+      } else {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) out[(unsigned long long)(n0 + n) * nf + f] = acc[n];
+      }
+    }
+  }
+}
+
+template <typename F, int LK>
+static int launch_scattered(const void* big, const void* small_, void* out, int rank, const int* pos_host, long long N,
+                            int big_first, hipStream_t st) {
+  using C = typename Cx<F>::type;
+  ScatPos pos;
+  for (int j = 0; j < 8; ++j) pos.p[j] = j < LK ? pos_host[j] : 0;
+  const unsigned long long nf = 1ull << (rank - LK);
+  unsigned gx = (unsigned)((nf + 255) / 256 > 65536 ? 65536 : (nf + 255) / 256);
+  const size_t lds = sizeof(C) * (size_t)(1 << LK) * (size_t)N;
+  dim3 grid(gx, 1, 1), block(256, 1, 1);
+#define TCMI_SCAT(NTV)                                                                                              \
+  {                                                                                                                  \
+    auto kern = contract_scattered_kernel<F, LK, NTV>;                                                               \
+    if (lds > 48 * 1024) {                                                                                           \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));                               \
+    }                                                                                                                \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const C*>(big), reinterpret_cast<const C*>(small_), \
+                       reinterpret_cast<C*>(out), rank, pos, (int)N, big_first);                                    \
+  }
+  if (N >= 8) TCMI_SCAT(8)
+  else if (N == 4) TCMI_SCAT(4)
+  else if (N == 2) TCMI_SCAT(2)
+  else TCMI_SCAT(1)
+#undef TCMI_SCAT
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));
+  return TCMI_OK;
+}
+
+
+// Same contraction for few outputs per free index (N <= 16) and up to 2^8 contracted configurations: the N
+// accumulators stay in registers and the big operand is streamed over k (each element is read once).
+template <typename F, int NT>
+__global__ __launch_bounds__(256) void contract_scattered_stream_kernel(const typename Cx<F>::type* __restrict__ big,
+                                                                        const typename Cx<F>::type* __restrict__ small_,
+                                                                        typename Cx<F>::type* __restrict__ out, int rank,
+                                                                        ScatPos pos, int lk, int big_first) {
+  using C = typename Cx<F>::type;
+  extern __shared__ __attribute__((aligned(16))) char smem_[];
+  C* sB = reinterpret_cast<C*>(smem_);
+  __shared__ unsigned long long koff[256];
+  const int tid = threadIdx.x;
+  const int K = 1 << lk;
+  for (int i = tid; i < K * NT; i += 256) sB[i] = small_[i];
+  if (tid < K) {
+    unsigned long long off = 0;
+    for (int j = 0; j < lk; ++j)
+      if ((tid >> j) & 1) off |= 1ull << pos.p[j];
+    koff[tid] = off;
+  }
+  __syncthreads();
+  const unsigned long long nf = 1ull << (rank - lk);
+  const unsigned long long step = (unsigned long long)gridDim.x * 256;
+  for (unsigned long long f = (unsigned long long)blockIdx.x * 256 + tid; f < nf; f += step) {
+    unsigned long long x = f;
+    for (int j = 0; j < lk; ++j) {
+      const unsigned long long low = (1ull << pos.p[j]) - 1ull;
+      x = ((x & ~low) << 1) | (x & low);
+    }
+    C acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) { acc[n].x = 0; acc[n].y = 0; }
+#pragma unroll 4
+    for (int k = 0; k < K; ++k) {
+      const C a = big[x | koff[k]];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const C b = sB[k * NT + n];
+        acc[n].x = fma_<F>(a.x, b.x, acc[n].x);
+        acc[n].x = fma_<F>(-a.y, b.y, acc[n].x);
+        acc[n].y = fma_<F>(a.x, b.y, acc[n].y);
+        acc[n].y = fma_<F>(a.y, b.x, acc[n].y);
+      }
+    }
+    if (big_first) {
+      C* dst = out + f * (unsigned long long)NT;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) dst[n] = acc[n];
+    } else {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) out[(unsigned long long)n * nf + f] = acc[n];
+    }
+  }
+}
+
+template <typename F>
+static int launch_scattered_stream(const void* big, const void* small_, void* out, int rank, const int* pos_host, int lk,
+                                   long long N, int big_first, hipStream_t st) {
+  using C = typename Cx<F>::type;
+  ScatPos pos;
+  for (int j = 0; j < 8; ++j) pos.p[j] = j < lk ? pos_host[j] : 0;
+  const unsigned long long nf = 1ull << (rank - lk);
+  unsigned gx = (unsigned)((nf + 255) / 256 > 65536 ? 65536 : (nf + 255) / 256);
+  const size_t lds = sizeof(C) * ((size_t)N << lk);
+  dim3 grid(gx, 1, 1), block(256, 1, 1);
+#define TCMI_SCS(NTV)                                                                                                \
+  {                                                                                                                  \
+    auto kern = contract_scattered_stream_kernel<F, NTV>;                                                            \
+    if (lds > 48 * 1024) {                                                                                           \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));                               \
+    }                                                                                                                \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const C*>(big), reinterpret_cast<const C*>(small_), \
+                       reinterpret_cast<C*>(out), rank, pos, lk, big_first);                                        \
+  }
+  if (N == 16) TCMI_SCS(16)
+  else if (N == 8) TCMI_SCS(8)
+  else if (N == 4) TCMI_SCS(4)
+  else if (N == 2) TCMI_SCS(2)
+  else TCMI_SCS(1)
+#undef TCMI_SCS
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));
+  return TCMI_OK;
+}
+
 }  // namespace tcmi
 
-extern "C" int tcmi_set_error_(int code, const char* msg);
 
 extern "C" {
 
@@ -360,6 +546,31 @@ int tcmi_permute_bits(const void* in, void* out, int rank, const int* srcbit_dev
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));
   return TCMI_OK;
+}
+
+int tcmi_contract_scattered(const void* big, int rank, const int* pos_host, int nk, const void* small_, long long n,
+                            void* out, int big_first, int dtype, void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!big || !small_ || !out || !pos_host || nk < 1 || nk > 8 || rank < nk || rank > 34 || n < 1 || (n & (n - 1)) ||
+      ((long long)(1 << nk) * n) > 4096 || (nk > 5 && n > 16))
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_contract_scattered: bad argument");
+  for (int j = 0; j < nk; ++j)
+    if (pos_host[j] < 0 || pos_host[j] >= rank || (j > 0 && pos_host[j] <= pos_host[j - 1]))
+      return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_contract_scattered: positions must be ascending bit indices");
+  if (nk > 5) {   // many contracted configurations, few outputs: stream over k
+    if (dtype == TCMI_C64) return tcmi::launch_scattered_stream<float>(big, small_, out, rank, pos_host, nk, n, big_first, st);
+    if (dtype == TCMI_C128) return tcmi::launch_scattered_stream<double>(big, small_, out, rank, pos_host, nk, n, big_first, st);
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_contract_scattered: bad dtype");
+  }
+#define TCMI_SC(FT, LKV) \
+  if (nk == LKV) return tcmi::launch_scattered<FT, LKV>(big, small_, out, rank, pos_host, n, big_first, st);
+  if (dtype == TCMI_C64) {
+    TCMI_SC(float, 1) TCMI_SC(float, 2) TCMI_SC(float, 3) TCMI_SC(float, 4) TCMI_SC(float, 5)
+  } else if (dtype == TCMI_C128) {
+    TCMI_SC(double, 1) TCMI_SC(double, 2) TCMI_SC(double, 3) TCMI_SC(double, 4) TCMI_SC(double, 5)
+  }
+#undef TCMI_SC
+  return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_contract_scattered: bad dtype");
 }
 
 int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch,

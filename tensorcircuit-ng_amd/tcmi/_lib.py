@@ -39,6 +39,11 @@ _SIGNATURES = {
          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p,
          ctypes.c_longlong, ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p],
     ),
+    "tcmi_contract_scattered": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong,
+         ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p],
+    ),
     "tcmi_apply_pauli_sum": (
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int,

@@ -8,6 +8,7 @@ Host side is symbolic (integers only) and testable without a GPU; tensors are to
 of shape ``[2] * rank`` (every circuit network has dimension-2 edges).
 """
 
+import ctypes
 import heapq
 import itertools
 from dataclasses import dataclass, field
@@ -838,11 +839,56 @@ def tensordot(a, b, axes_a: Sequence[int], axes_b: Sequence[int]):
     axes_a, axes_b = [int(x) for x in axes_a], [int(x) for x in axes_b]
     fa = [i for i in range(a.dim()) if i not in axes_a]
     fb = [i for i in range(b.dim()) if i not in axes_b]
+    r = _tensordot_scattered(a, b, axes_a, axes_b, fa, fb)
+    if r is not None:
+        return r
     a2 = permute(a, fa + axes_a)
     b2 = permute(b, axes_b + fb)
     M, K, N = 2 ** len(fa), 2 ** len(axes_a), 2 ** len(fb)
     c = _fns()["GemmFn"].apply(a2, b2, M, N, K)
     return c.reshape([2] * (len(fa) + len(fb)))
+
+
+SCATTERED_MIN_RANK = 16    # big operand: at least 2^16 elements
+SCATTERED_MAX_SMALL = 4096  # small operand: at most this many elements (it lives in LDS)
+
+
+def _tensordot_scattered(a, b, axes_a, axes_b, fa, fb):
+    """Big tensor x small tensor without permuting the big one (``tcmi_contract_scattered``): used when no
+    gradient is needed, 1..5 axes are contracted and the small operand has at most 4096 elements.  Returns
+    None when the step does not qualify (the permute + GEMM route handles it)."""
+    import torch
+
+    nk = len(axes_a)
+    if nk < 1 or nk > 8:
+        return None
+    big_first = a.numel() >= b.numel()
+    big, small = (a, b) if big_first else (b, a)
+    if big.dim() < SCATTERED_MIN_RANK or small.numel() > SCATTERED_MAX_SMALL or small.numel() < (1 << nk):
+        return None
+    if nk > 5 and (small.numel() >> nk) > 16:
+        return None
+    if torch.is_grad_enabled() and (a.requires_grad or b.requires_grad):
+        return None
+    if torch._C._functorch.is_functorch_wrapped_tensor(a) or torch._C._functorch.is_functorch_wrapped_tensor(b):
+        return None
+    if any(d != 2 for d in big.shape) or any(d != 2 for d in small.shape):
+        return None
+    ax_big, ax_small = (axes_a, axes_b) if big_first else (axes_b, axes_a)
+    f_small = fb if big_first else fa
+    pairs = sorted(zip(ax_big, ax_small))                      # ascending big axis = descending bit position
+    small2 = permute(small, [p[1] for p in pairs] + list(f_small)).contiguous()
+    big = big.contiguous()
+    rank = big.dim()
+    pos = sorted(rank - 1 - p[0] for p in pairs)
+    n = small.numel() >> nk
+    out = torch.empty((1 << (rank - nk)) * n, dtype=big.dtype, device=big.device)
+    arr = (ctypes.c_int * nk)(*pos)
+    stream = torch.cuda.current_stream(big.device).cuda_stream
+    _lib.check(_lib.lib().tcmi_contract_scattered(big.data_ptr(), rank, ctypes.cast(arr, ctypes.c_void_p), nk,
+                                                  small2.data_ptr(), n, out.data_ptr(), int(big_first), _code(big),
+                                                  stream), "tcmi_contract_scattered")
+    return out.reshape([2] * (len(fa) + len(fb)))
 
 
 def contract_between(na: Node, nb: Node) -> Node:

@@ -314,3 +314,39 @@ def test_tall_gemm_is_issued_in_row_chunks(dt):
     ref = a @ b
     tol = 1e-5 if dt == "complex64" else 1e-12
     assert float((c - ref).abs().max()) < tol * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("dt", ["complex64", "complex128"])
+def test_scattered_contraction_matches_tensordot(dt):
+    """tcmi_contract_scattered (big tensor x small tensor over arbitrary axes, no permute of the big one) against
+    torch.tensordot: 1..5 contracted axes anywhere, either operand order, no free axes on the small side."""
+    import torch
+    from tcmi import tn
+
+    tdt = torch.complex64 if dt == "complex64" else torch.complex128
+    rng = np.random.default_rng(0)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    rank = 18
+    big = torch.randn([2] * rank, dtype=tdt, device="cuda", generator=g)
+    cases = 0
+    for nk in (1, 2, 3, 4, 5, 6, 7, 8):
+        for nfree in ((0, 1, 3, 5) if nk <= 5 else (0, 2, 4)):
+            for big_first in (True, False):
+                ax_big = sorted(rng.choice(rank, nk, replace=False).tolist(), key=lambda _: rng.random())
+                small = torch.randn([2] * (nk + nfree), dtype=tdt, device="cuda", generator=g)
+                ax_small = rng.permutation(nk + nfree)[:nk].tolist()
+                if big_first:
+                    got = tn.tensordot(big, small, ax_big, ax_small)
+                    ref = torch.tensordot(big, small, (ax_big, ax_small))
+                else:
+                    got = tn.tensordot(small, big, ax_small, ax_big)
+                    ref = torch.tensordot(small, big, (ax_small, ax_big))
+                assert got.shape == ref.shape
+                tol = 2e-5 if dt == "complex64" else 1e-12
+                assert float((got - ref).abs().max()) < tol * max(1.0, float(ref.abs().max())), (nk, nfree, big_first)
+                cases += 1
+    assert cases == 58
+    # the fast path was taken (no autograd, big operand of rank >= 16)
+    assert tn._tensordot_scattered(big, small, ax_big, ax_small,
+                                   [i for i in range(rank) if i not in ax_big],
+                                   [i for i in range(small.dim()) if i not in ax_small]) is not None
