@@ -227,16 +227,17 @@ RECONF_ALPHA = 0.0     # cost of a step = MACs + alpha * (elements read + writte
 
 
 def reconfigure_path(inputs, output, size_dict, path, subtree_size: int = 8, max_size: Optional[int] = None,
-                     max_passes: int = 4, time_limit: float = 30.0, alpha: Optional[float] = None):
+                     max_passes: int = 4, max_evals: int = 4000, alpha: Optional[float] = None):
     """Subtree reconfiguration of a contraction path (the refinement cotengra applies to its trees,
     reference cons.py:1168-1190 ``optimizer_reconf`` / experimental.py ``slicing_reconf_opts``): for every
     internal node of the tree, the subtree below it is cut off at ``subtree_size`` intermediates and those are
     re-contracted in the order that an exact dynamic programme over their subsets finds cheapest (flops);
-    intermediates larger than ``max_size`` elements are not allowed.  Passes repeat until nothing improves.
+    intermediates larger than ``max_size`` elements are not allowed.  Passes repeat until nothing improves
+    (at most ``max_evals`` subtree optimisations: a deterministic budget, every rank of a distributed run must
+    arrive at the same tree).
     Index sets are bit masks (python ints).  Networks with an index on more than two tensors are returned
     unchanged.  Returns a path in the same linear format."""
     import math
-    import time
 
     n = len(inputs)
     if n < 3:
@@ -375,18 +376,19 @@ def reconfigure_path(inputs, output, size_dict, path, subtree_size: int = 8, max
         build(full, True)
         return True
 
-    t0 = time.time()
+    evals = 0
     for _ in range(max_passes):
         changed = False
-        todo = sorted(kids, key=lambda v: -step_cost(*kids[v]))
+        todo = sorted(kids, key=lambda v: (-step_cost(*kids[v]), v))
         for v in todo:
             if v not in kids:
                 continue
             if optimise(v):
                 changed = True
-            if time.time() - t0 > time_limit:
+            evals += 1
+            if evals >= max_evals:
                 break
-        if not changed or time.time() - t0 > time_limit:
+        if not changed or evals >= max_evals:
             break
     # back to the linear format (post-order)
     out_path: List[Tuple[int, int]] = []
