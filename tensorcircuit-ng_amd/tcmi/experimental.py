@@ -103,8 +103,7 @@ class DistributedContractor:
     def _local_sum(self, params, op):
         total = None
         arrays = self._arrays(params)
-        for i in self.my_slices:
-            r = self.tree.contract_core(self.tree.slice_arrays(arrays, i))
+        for r in self.tree.contract_slices(arrays, self.my_slices):
             total = r if total is None else total + r
         if total is None:  # this rank only holds padding
             import torch
@@ -139,8 +138,8 @@ class DistributedContractor:
         fop = op if op is not None else (lambda x: x.sum().real)
         arrays = self._arrays(p)
         value = None
-        for i in self.my_slices:
-            r = fop(self.tree.contract_core(self.tree.slice_arrays(arrays, i)))
+        for r in self.tree.contract_slices(arrays, self.my_slices):
+            r = fop(r)
             value = r if value is None else value + r
         if value is None:
             value = sum((x.sum() * 0 for x in leaves)).real

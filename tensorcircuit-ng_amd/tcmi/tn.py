@@ -673,6 +673,72 @@ class ContractionTree:
             out.append(arr[idx] if any(e in vals for e in edges) else arr)
         return out
 
+    def _symbolic_steps(self):
+        """Static part of the contraction (cached): per step (id_a, id_b, axes_a, axes_b, id_out), the edge order of
+        every SSA tensor and which tensors depend on a sliced index."""
+        key = (tuple(self.path), tuple(self.sliced_inds))
+        cached = getattr(self, "_steps_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        sl = set(self.sliced_inds)
+        n = len(self.inputs)
+        edges = {i: [e for e in s if e not in sl] for i, s in enumerate(self.inputs)}
+        dep = {i: any(e in sl for e in s) for i, s in enumerate(self.inputs)}
+        uses: Dict[int, int] = {}
+        for s in edges.values():
+            for e in s:
+                uses[e] = uses.get(e, 0) + 1
+        out = [e for e in self.output if e not in sl]
+        outset = set(out)
+        ids = list(range(n))
+        steps = []
+        nxt = n
+        for a, b in self.path:
+            ia, ib = ids[a], ids[b]
+            ea, eb = edges[ia], edges[ib]
+            shared = [e for e in ea if e in eb and uses[e] == 2 and e not in outset]
+            steps.append((ia, ib, [ea.index(e) for e in shared], [eb.index(e) for e in shared], nxt))
+            edges[nxt] = [e for e in ea if e not in shared] + [e for e in eb if e not in shared]
+            dep[nxt] = dep[ia] or dep[ib]
+            for e in shared:
+                uses[e] -= 2
+            ids = [x for k, x in enumerate(ids) if k not in (a, b)] + [nxt]
+            nxt += 1
+        last = ids[0]
+        final_perm = None if list(edges[last]) == out else [edges[last].index(e) for e in out]
+        # last use of every tensor, to drop slice-dependent intermediates early
+        plan = (steps, dep, last, final_perm)
+        self._steps_cache = (key, plan)
+        return plan
+
+    def contract_slices(self, arrays: Sequence[Any], slice_ids: Sequence[int]):
+        """Yield ``contract_core(slice_arrays(arrays, i))`` for every i in ``slice_ids``.  Intermediates that do
+        not depend on a sliced index (most of the small early steps of a circuit network: only a few leaves carry
+        the sliced indices) are computed once and reused by every slice."""
+        steps, dep, last, final_perm = self._symbolic_steps()
+        shared_t: Dict[int, Any] = {}
+        n = len(self.inputs)
+        for i in slice_ids:
+            sliced = self.slice_arrays(arrays, i)
+            cur: Dict[int, Any] = {}
+            for k in range(n):
+                if dep[k]:
+                    cur[k] = sliced[k]
+                elif k not in shared_t:
+                    shared_t[k] = sliced[k]
+            for ia, ib, xa, xb, io in steps:
+                if not dep[io]:
+                    if io not in shared_t:
+                        shared_t[io] = tensordot(shared_t[ia], shared_t[ib], xa, xb)
+                    continue
+                ta = cur.pop(ia) if dep[ia] else shared_t[ia]
+                tb = cur.pop(ib) if dep[ib] else shared_t[ib]
+                cur[io] = tensordot(ta, tb, xa, xb)
+            res = cur[last] if dep[last] else shared_t[last]
+            if final_perm is not None:
+                res = permute(res, final_perm)
+            yield res
+
     def contract_core(self, arrays: Sequence[Any]):
         """Pairwise contraction of (already sliced) arrays along the path; returns the result with
         axes in ``output`` order (minus sliced indices)."""
@@ -920,7 +986,6 @@ def contract_nodes(nodes: Sequence[Node], output_edge_order: Optional[Sequence[i
     if not tree.sliced_inds:
         return Node(tree.contract_core(arrays), list(output_edge_order))
     total = None
-    for i in range(tree.nslices):
-        r = tree.contract_core(tree.slice_arrays(arrays, i))
+    for r in tree.contract_slices(arrays, range(tree.nslices)):
         total = r if total is None else total + r
     return Node(total, [e for e in output_edge_order if e not in tree.sliced_inds])

@@ -207,3 +207,34 @@ def test_sliced_tree_is_reconfigured_within_the_cap():
     ref.trials = 0
     ref.slice_to(target)
     assert tree.total_flops() <= ref.total_flops()
+
+
+def test_contract_slices_reuses_invariant_intermediates(monkeypatch):
+    """contract_slices == contract_core per slice, with every slice-independent product computed once."""
+    from tcmi import tn
+
+    inputs, output, sd = _rand_net(40, 3, 11, dangling=1)
+    tree = tn.ContractionTree.from_path(inputs, output, sd, trials=4, seed=0)
+    tree.slice_to(max(4, tree.max_size() // 8))
+    assert tree.nslices >= 4
+    rng = np.random.default_rng(3)
+    import torch
+    arrays = [torch.from_numpy(rng.normal(size=[2] * len(s)) + 1j * rng.normal(size=[2] * len(s))) for s in inputs]
+    calls = []
+
+    def td(a, b, xa, xb):
+        calls.append(1)
+        return torch.tensordot(a, b, (list(xa), list(xb)))
+
+    monkeypatch.setattr(tn, "tensordot", td)
+    monkeypatch.setattr(tn, "permute", lambda t, perm: t.permute(*perm).contiguous())
+    per_slice = [tree.contract_core(tree.slice_arrays(arrays, i)) for i in range(tree.nslices)]
+    n_plain = len(calls)
+    calls.clear()
+    got = list(tree.contract_slices(arrays, range(tree.nslices)))
+    assert len(calls) < n_plain            # shared subtrees were not recomputed
+    for a, b in zip(got, per_slice):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), atol=1e-12)
+    steps, dep, _, _ = tree._symbolic_steps()
+    n_shared = sum(1 for st in steps if not dep[st[4]])
+    assert len(calls) == n_shared + tree.nslices * (len(steps) - n_shared)
