@@ -235,12 +235,15 @@ def rqc_leg(tc, torch, dist, args, rank, world):
     t = time.perf_counter() - t0
     tree = dc.tree
     flops = float(tree.total_flops())          # all slices (ContractionTree.total_flops includes nslices)
+    steps, dep, _, _ = tree._symbolic_steps()
+    n_inv = sum(1 for st in steps if not dep[st[4]])   # slice-invariant steps: computed once per rank
     return {
         "workload": f"32-qubit 4x8 random circuit depth {depth}, amplitude <0|C|0>, complex64, sliced to "
                     f"2^{args.rqc_log2_target} elements (SURVEY 8d config 4)",
         "nslices": int(tree.nslices), "slices_per_gpu": int(-(-tree.nslices // world)),
         "contraction_width": float(tree.contraction_width()), "log2_flops_total": float(np.log2(flops)),
         "contract_s": t, "tflops": flops / t / 1e12, "path_search_s": round(search_s, 2),
+        "steps_per_slice": len(steps), "slice_invariant_steps": n_inv,
         "amplitude": [float(v.real), float(v.imag)],
     }
 
