@@ -238,3 +238,28 @@ def test_contract_slices_reuses_invariant_intermediates(monkeypatch):
     steps, dep, _, _ = tree._symbolic_steps()
     n_shared = sum(1 for st in steps if not dep[st[4]])
     assert len(calls) == n_shared + tree.nslices * (len(steps) - n_shared)
+
+
+def test_path_search_is_identical_across_processes():
+    """Every rank of a distributed contraction derives the tree itself: search, slicing and reconfiguration must
+    not depend on hash seeds or timing."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, json, hashlib; sys.path[:0] = %r\n"
+        "from test_tn_host import _rand_net\n"
+        "from tcmi import tn\n"
+        "inputs, output, sd = _rand_net(70, 3, 21, dangling=0)\n"
+        "t = tn.ContractionTree.from_path(inputs, output, sd, trials=6, seed=3)\n"
+        "t.slice_to(max(4, t.max_size() // 8))\n"
+        "print(hashlib.sha1(json.dumps([t.path, t.sliced_inds]).encode()).hexdigest())\n"
+    ) % ([os.path.dirname(__file__)] + [p for p in sys.path if p.endswith("tensorcircuit-ng_amd") or p.endswith("repo")],)
+    outs = []
+    for seed in ("1", "4242"):
+        env = dict(os.environ, PYTHONHASHSEED=seed)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1]
