@@ -356,12 +356,32 @@ def _ad():
         return _AD
     import torch
 
+    def vmap_loop(fn, info, in_dims, *args):
+        """vmap rule shared by the three primitives: one call per batch element (the products of one element are
+        already GPU-sized in the MPS path; 2-D GEMMs use the batched launch instead)."""
+        outs = []
+        for i in range(info.batch_size):
+            outs.append(fn(*[a.select(d, i) if d is not None else a for a, d in zip(args, in_dims)]))
+        if isinstance(outs[0], tuple):
+            res = tuple(torch.stack([o[k] for o in outs]) for k in range(len(outs[0])))
+            return res, tuple(0 for _ in res)
+        return torch.stack(outs), 0
+
     class Matmul(torch.autograd.Function):
         generate_vmap_rule = False
 
         @staticmethod
         def forward(a, b):
             return _matmul_raw(a, b)
+
+        @staticmethod
+        def vmap(info, in_dims, a, b):
+            if a.dim() - (in_dims[0] is not None) == 2 and b.dim() - (in_dims[1] is not None) == 2:
+                B = info.batch_size
+                a3 = a.movedim(in_dims[0], 0) if in_dims[0] is not None else a.unsqueeze(0).expand(B, *a.shape)
+                b3 = b.movedim(in_dims[1], 0) if in_dims[1] is not None else b.unsqueeze(0).expand(B, *b.shape)
+                return Matmul.apply(a3, b3), 0
+            return vmap_loop(Matmul.apply, info, in_dims, a, b)
 
         @staticmethod
         def setup_context(ctx, inputs, output):
@@ -380,6 +400,10 @@ def _ad():
         @staticmethod
         def forward(mat):
             return _svd_full_raw(mat.contiguous())
+
+        @staticmethod
+        def vmap(info, in_dims, mat):
+            return vmap_loop(Svd.apply, info, in_dims, mat)
 
         @staticmethod
         def setup_context(ctx, inputs, output):
@@ -401,6 +425,10 @@ def _ad():
             ph = torch.where(a > 0, d / a.clamp_min(1e-300 if d.dtype == torch.complex128 else 1e-30),
                              torch.ones_like(d))
             return q * ph[None, :], ph.conj()[:, None] * r
+
+        @staticmethod
+        def vmap(info, in_dims, mat):
+            return vmap_loop(Qr.apply, info, in_dims, mat)
 
         @staticmethod
         def setup_context(ctx, inputs, output):

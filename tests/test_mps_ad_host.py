@@ -191,3 +191,28 @@ def test_simple_circuits_ad(cpu_raw):
     _check_directional(expec, 1e-6)
     obs = dict(z=[2])
     _check_directional(expec, 1e-6)
+
+
+def test_vmap_and_vvag_over_mps_circuits(cpu_raw):
+    """backend.vmap / vvag of an MPSCircuit energy (the reference runs these under jax.vmap): the three primitives
+    carry vmap rules, everything else is torch."""
+    def expec(params):
+        mps = tc.MPSCircuit(N, split=dict(max_singular_values=D))
+        mps.rx(0, theta=params[0])
+        mps.cx(0, 1)
+        mps.cx(1, 2)
+        mps.ry(2, theta=params[1])
+        mps.rzz(1, 3, theta=params[2])
+        return tc.backend.real(mps.expectation_ps(z=[0, 3])) + tc.backend.real(mps.expectation_ps(z=[2]))
+
+    g0 = torch.Generator().manual_seed(0)
+    ps = torch.rand(4, 3, generator=g0, dtype=torch.float64) * 2.0 + 0.2
+    want = torch.stack([expec(p) for p in ps])
+    got = tc.backend.vmap(expec)(ps)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), atol=1e-12)
+    vs, gs = tc.backend.vvag(expec, argnums=0, vectorized_argnums=0)(ps)
+    np.testing.assert_allclose(vs.numpy(), want.numpy(), atol=1e-12)
+    vag = tc.backend.value_and_grad(expec)
+    for i in range(ps.shape[0]):
+        _, gi = vag(ps[i])
+        np.testing.assert_allclose(gs[i].numpy(), gi.numpy(), atol=1e-9)
