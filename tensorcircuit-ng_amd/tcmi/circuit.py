@@ -317,15 +317,24 @@ class Circuit:
         psi = self.wavefunction()
         return psi.real ** 2 + psi.imag ** 2
 
-    def measure(self, *index: int, with_prob: bool = False, status: Optional[Tensor] = None):
+    STATE_FREE_ABOVE = 30   # qubits: beyond this ``measure`` contracts closed networks instead of building psi
+
+    def measure(self, *index: int, with_prob: bool = False, status: Optional[Tensor] = None,
+                state_free: Optional[bool] = None):
         """Sequential z-basis measurement of the given qubits (reference ``measure_jit``,
-        basecircuit.py:449-558).  The state comes from the HIP plan; the conditional marginals are
-        reductions of |psi|^2.  ``status``: one uniform number per measured qubit, consumed with the
-        ``backend.probability_sample`` rule (abstract_backend.py:1849-1861)."""
+        basecircuit.py:449-558).  Up to ``STATE_FREE_ABOVE`` qubits the state comes from the HIP plan and the
+        conditional marginals are reductions of |psi|^2; beyond it (or with ``state_free=True``) every
+        conditional probability is a closed-network contraction, as in the reference.  ``status``: one
+        uniform number per measured qubit, consumed with the ``backend.probability_sample`` rule
+        (abstract_backend.py:1849-1861)."""
         import torch
 
         n = self._nqubits
         idx = [int(i) % n for i in index]
+        if state_free is None:
+            state_free = n > self.STATE_FREE_ABOVE
+        if state_free:
+            return self._measure_network(idx, with_prob, status)
         cur = self.probability().to(torch.float64).reshape([2] * n)
         if status is None:
             status = cons.backend.implicit_randu(shape=[len(idx)])
@@ -345,6 +354,32 @@ class Circuit:
             outcomes.append(outcome)
         sample = torch.tensor(outcomes, dtype=rdt, device=cur.device)
         return (sample, prob.to(rdt)) if with_prob else (sample, -1.0)
+
+    def _measure_network(self, idx: List[int], with_prob: bool, status: Optional[Tensor]):
+        """reference basecircuit.py:481-518: for the k-th measured qubit j, p(0 | earlier outcomes) is the closed
+        network <psi| P0_j (x) prod_{i<k} |s_i><s_i| |psi> / p(earlier outcomes), contracted by the HIP
+        pairwise engine (no state vector: works beyond the qubit count a state fits)."""
+        import torch
+        from . import tn
+
+        rdt = torch.float32 if cons.rdtypestr == "float32" else torch.float64
+        if status is None:
+            status = cons.backend.implicit_randu(shape=[len(idx)])
+        st = cons.backend.numpy(cons.backend.convert_to_tensor(status)).reshape(-1)
+        proj = [np.diag([1.0, 0.0]).astype(np.complex128), np.diag([0.0, 1.0]).astype(np.complex128)]
+        p = 1.0
+        outcomes: List[int] = []
+        for k, j in enumerate(idx):
+            ops = [(proj[outcomes[i]], [idx[i]]) for i in range(k)] + [(proj[0], [j])]
+            with torch.no_grad():
+                val = tn.contract_nodes(self.expectation_before(*ops, reuse=False)).tensor
+            pu = min(max(float(val.real) / p, 0.0), 1.0)
+            outcome = 1 if float(st[k]) - pu + 0.31415926e-12 > 0 else 0     # the reference's tie rule
+            p = p * (pu if outcome == 0 else 1.0 - pu)
+            outcomes.append(outcome)
+        dev = cons.backend.device
+        sample = torch.tensor(outcomes, dtype=rdt, device=dev)
+        return (sample, torch.tensor(p, dtype=rdt, device=dev)) if with_prob else (sample, -1.0)
 
     measure_jit = measure
 

@@ -350,3 +350,44 @@ def test_scattered_contraction_matches_tensordot(dt):
     assert tn._tensordot_scattered(big, small, ax_big, ax_small,
                                    [i for i in range(rank) if i not in ax_big],
                                    [i for i in range(small.dim()) if i not in ax_small]) is not None
+
+
+def test_state_free_measurement_matches_state_route_and_scales_past_the_state(tcd):
+    """measure / perfect_sampling by closed-network contractions (reference basecircuit.py:461-558) == the
+    state-vector route on the same random numbers; and a 36-qubit GHZ circuit (no state vector fits the tile-VM's
+    32-qubit limit) samples 00..0 / 11..1 with probability 1/2."""
+    import torch
+
+    tc = tcd
+    n = 8
+    rng = np.random.default_rng(5)
+    c = tc.Circuit(n)
+    for d in range(3):
+        for i in range(d % 2, n - 1, 2):
+            c.any(i, i + 1, unitary=G.random_two_qubit_gate(int(rng.integers(1 << 30))))
+        for i in range(n):
+            c.rx(i, theta=float(rng.uniform(0, 6)))
+    tol = 1e-5 if tc.dtypestr == "complex64" else 1e-10
+    for seed in range(4):
+        status = np.random.default_rng(seed).uniform(size=n)
+        s1, p1 = c.measure(*range(n), with_prob=True, status=status, state_free=False)
+        s2, p2 = c.measure(*range(n), with_prob=True, status=status, state_free=True)
+        assert torch.equal(s1.cpu(), s2.cpu())
+        np.testing.assert_allclose(float(p1), float(p2), rtol=20 * tol, atol=tol)
+    s3, _ = c.measure(5, 2, status=np.array([0.3, 0.9]), state_free=True)
+    s4, _ = c.measure(5, 2, status=np.array([0.3, 0.9]), state_free=False)
+    assert torch.equal(s3.cpu(), s4.cpu())
+
+    big = 36
+    g = tc.Circuit(big)
+    g.h(0)
+    for i in range(big - 1):
+        g.cnot(i, i + 1)
+    seen = set()
+    for seed in range(6):
+        bits, p = g.perfect_sampling(status=np.random.default_rng(100 + seed).uniform(size=big))
+        b = bits.cpu().numpy().astype(int)
+        assert b.min() == b.max()
+        np.testing.assert_allclose(float(p), 0.5, atol=1e-5)
+        seen.add(int(b[0]))
+    assert seen == {0, 1}
