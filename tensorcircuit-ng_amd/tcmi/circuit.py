@@ -390,12 +390,11 @@ class Circuit:
     def sample(self, batch: Optional[int] = None, allow_state: bool = False, readout_error: Any = None,
                format: Optional[str] = None, random_generator: Any = None, status: Optional[Tensor] = None,
                jittable: bool = True) -> Any:
-        """reference basecircuit.py:1403-1512 (readout error is outside the hot path)."""
+        """reference basecircuit.py:1403-1512.  ``readout_error`` acts on the bit-string probabilities of the
+        ``allow_state=True`` branch, as in the reference (:1498-1499)."""
         import torch
         from .quantum import sample2all
 
-        if readout_error is not None:
-            raise NotImplementedError("Backend 'hip' has not implemented readout_error in sample.")
         n = self._nqubits
         if not allow_state:
             if batch is None:
@@ -415,6 +414,8 @@ class Circuit:
         else:
             nbatch = 1 if batch is None else batch
             p = self.probability().to(torch.float64)
+            if readout_error is not None:
+                p = self.readouterror_bs(readout_error, p).to(torch.float64)
             if status is None:
                 status = cons.backend.implicit_randu(shape=[nbatch])
             u = cons.backend.convert_to_tensor(status).to(torch.float64).reshape(-1)
@@ -425,6 +426,75 @@ class Circuit:
                 r = list(zip(bits, p[ch]))
                 return r[0] if batch is None else r
         return sample2all(ch, n, format=format)
+
+    def readouterror_bs(self, readout_error: Any = None, p: Optional[Tensor] = None) -> Tensor:
+        """reference basecircuit.py:1656-1701: noisy bit-string probabilities p' = (M_0 x ... x M_{n-1}) p with
+        M_i = [[p(0|0), 1 - p(1|1)], [1 - p(0|0), p(1|1)]] from ``readout_error[i] = [p(0|0), p(1|1)]``.  Classical
+        post-processing of a real vector: one small contraction per qubit axis."""
+        import torch
+
+        n = self._nqubits
+        re = np.asarray(cons.backend.numpy(cons.backend.convert_to_tensor(readout_error)), dtype=np.float64)
+        nq = re.shape[0]
+        assert nq == n, "one [p(0|0), p(1|1)] pair per qubit"
+        if p is None:
+            p = self.probability()
+        t = p.to(torch.float64).reshape([2] * n)
+        for i in range(n):
+            m = torch.tensor([[re[i][0], 1.0 - re[i][1]], [1.0 - re[i][0], re[i][1]]], dtype=torch.float64,
+                             device=t.device)
+            t = torch.movedim(torch.tensordot(m, t, dims=([1], [i])), 0, i)
+        rdt = torch.float32 if cons.rdtypestr == "float32" else torch.float64
+        return t.reshape(-1).to(rdt)
+
+    def sample_expectation_ps(self, x: Optional[Sequence[int]] = None, y: Optional[Sequence[int]] = None,
+                              z: Optional[Sequence[int]] = None, shots: Optional[int] = None,
+                              random_generator: Any = None, status: Optional[Tensor] = None,
+                              readout_error: Any = None, noise_conf: Any = None, **kws: Any) -> Tensor:
+        """reference basecircuit.py:1522-1653 (noise-free branch): Pauli-string expectation from the measured
+        bit-string distribution — basis rotation (H on x, rx(pi/2) on y), |psi|^2, optional readout error, then the
+        exact correlation (``shots=None``) or the mean over ``shots`` samples."""
+        import torch
+
+        if noise_conf is not None:
+            raise NotImplementedError("Backend 'hip' has not implemented noise_conf in sample_expectation_ps.")
+        n = self._nqubits
+        x, y, z = list(x or []), list(y or []), list(z or [])
+        c = type(self)(n, inputs=self.wavefunction())
+        for i in x:
+            c.h(i)
+        for i in y:
+            c.rx(i, theta=np.pi / 2)
+        p = c.probability().to(torch.float64)
+        if readout_error is not None:
+            p = self.readouterror_bs(readout_error, p).to(torch.float64)
+        p = p / p.sum()
+        mask = 0
+        for i in x + y + z:
+            mask |= 1 << (n - 1 - (int(i) % n))
+        rdt = torch.float32 if cons.rdtypestr == "float32" else torch.float64
+
+        def spins(idx):
+            v = idx & mask
+            par = torch.zeros_like(v)
+            while True:                      # parity of the masked bits, log2(n) folding steps
+                par ^= v & 1
+                v = v >> 1
+                if not bool((v != 0).any()):
+                    break
+            return 1.0 - 2.0 * par.to(torch.float64)
+
+        if shots is None:
+            idx = torch.arange(p.numel(), device=p.device, dtype=torch.int64)
+            return (p * spins(idx)).sum().to(rdt)
+        if status is None:
+            status = cons.backend.implicit_randu(shape=[int(shots)])
+        u = cons.backend.convert_to_tensor(status).to(torch.float64).reshape(-1)
+        cum = torch.cumsum(p, 0)
+        ch = torch.searchsorted(cum, (cum[-1] * (1 - u)).contiguous()).clamp(max=p.numel() - 1)
+        return spins(ch).mean().to(rdt)
+
+    sexpps = sample_expectation_ps
 
     def expectation(self, *ops: Tuple[Any, List[int]], reuse: bool = True, **kws: Any) -> Tensor:
         """reference circuit.py:833-913 (noise-free branch): complex scalar <psi| prod ops |psi>."""

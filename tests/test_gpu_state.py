@@ -353,3 +353,37 @@ def test_hipgraph_replay_matches_eager():
                 assert float((got[:, : 2**n] - want[:, : 2**n]).abs().max()) < 1e-6
         finally:
             tc.set_contractor("greedy")
+
+
+def test_sample_expectation_ps_and_readout_error(tcd):
+    """reference tests/test_channels.py:158-196 (noise-free circuit, readout error on the measured distribution) and
+    agreement of the exact / sampled estimators with expectation_ps."""
+    tc = tcd
+    c = tc.Circuit(3)
+    c.X(0)
+    np.testing.assert_allclose(float(c.sample_expectation_ps(z=[0, 1, 2])), -1.0, atol=1e-3)
+    readout_error = [[0.9, 0.75], [0.4, 0.7], [0.7, 0.9]]
+    np.testing.assert_allclose(float(c.sample_expectation_ps(z=[0, 1, 2], readout_error=readout_error)), 0.04, atol=1e-6)
+    v = c.sample_expectation_ps(z=[0, 1, 2], readout_error=tc.backend.convert_to_tensor(np.array(readout_error)))
+    np.testing.assert_allclose(float(v), 0.04, atol=1e-6)
+    p = c.readouterror_bs(readout_error, c.probability())
+    np.testing.assert_allclose(float(p.sum()), 1.0, atol=1e-6)
+    r = c.sample(batch=2000, allow_state=True, readout_error=readout_error, format="sample_bin",
+                 status=np.random.default_rng(0).uniform(size=2000))
+    bits = tc.backend.numpy(r).astype(float)
+    np.testing.assert_allclose(bits.mean(0), [0.75, 0.6, 0.3], atol=0.04)      # p(read 1) per qubit for |100>
+
+    n = 6
+    rng = np.random.default_rng(3)
+    c = tc.Circuit(n)
+    for i in range(n):
+        c.ry(i, theta=float(rng.uniform(0, 3)))
+    for i in range(n - 1):
+        c.cnot(i, i + 1)
+    for i in range(n):
+        c.rx(i, theta=float(rng.uniform(0, 3)))
+    for kw in (dict(z=[0, 3]), dict(x=[1], z=[4]), dict(y=[2], x=[5], z=[0])):
+        exact = float(tc.backend.real(c.expectation_ps(**kw)))
+        np.testing.assert_allclose(float(c.sample_expectation_ps(**kw)), exact, atol=2e-5)
+        est = float(c.sample_expectation_ps(shots=20000, status=rng.uniform(size=20000), **kw))
+        assert abs(est - exact) < 0.03
