@@ -179,8 +179,8 @@ def mps_leg(tc, torch, args):
         sweep()
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
-        m.position(0)
-    torch.cuda.synchronize()
+        m.position(0)                    # back to the sweep's starting gauge: not part of the sweep, so it must
+        torch.cuda.synchronize()         # not run into the next timed sweep either
     t = sum(times) / len(times)
     if not all(bool(torch.isfinite(x.abs()).all()) for x in m.get_tensors()):
         raise FloatingPointError("non-finite MPS tensor after the TEBD sweeps")
