@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Generates tcmi_vm2_asm.inc: the hand-scheduled gfx950 instruction bodies of the complex64 tile-VM.
+
+Why assembly bodies (measured on MI355X, scripts/ubench/gen_operand_forms.py, profiles/r02a_*):
+  * a 32-bit VALU instruction with an SGPR (or constant) operand issues every 4 cycles per SIMD, the same
+    instruction with VGPR operands only every 2; `v_pk_*_f32` always takes 4 cycles for its two lanes'
+    worth of work.  Gate coefficients are wave-uniform (scalar loads), so the amplitude arithmetic is
+    written with packed f32 instructions on (re, im) register pairs: full FP32 rate with SGPR matrices.
+  * hipcc copies the whole amplitude register array at every control-flow merge that follows a
+    modification of it (64 `v_mov` per gate in the round-1 kernel).  Here every data-dependent choice (gate
+    kind, gate present or not, which register pair a two-qubit gate acts on) is a scalar branch INSIDE one
+    asm statement whose amplitude operands are tied ("+v"): the compiler sees straight-line code and the
+    amplitudes never move.
+
+Packed-operand conventions used below (V_PK_{MUL,FMA}_F32, CDNA3/4 ISA): result.lo uses source halves chosen
+by op_sel, result.hi by op_sel_hi; neg_lo / neg_hi negate a source for the lo / hi result.  With an amplitude
+A = (re, im) and a coefficient pair P:
+    c*A + C        v_pk_fma_f32 D, A, P, C op_sel_hi:[1,0,1]                              (c = P.lo)
+    s*(iA) + C     v_pk_fma_f32 D, A, P, C op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]  (s = P.hi, iA = (-im, re))
+
+    python3 gen_vm2_asm.py > tcmi_vm2_asm.inc
+"""
+
+
+def mul_re(D, A, P, hi=False):
+    """D = P.x * A   (x = hi / lo half of P)"""
+    h = 1 if hi else 0
+    return f"v_pk_mul_f32 {D}, {A}, {P} op_sel:[0,{h}] op_sel_hi:[1,{h}]"
+
+
+def mul_im(D, A, P, hi=True, conj=False):
+    """D = P.x * (iA)   (conj: P.x * (-iA))"""
+    h = 1 if hi else 0
+    neg = "neg_hi:[1,0]" if conj else "neg_lo:[1,0]"
+    return f"v_pk_mul_f32 {D}, {A}, {P} op_sel:[1,{h}] op_sel_hi:[0,{h}] {neg}"
+
+
+def fma_re(D, A, P, C, hi=False):
+    """D = P.x * A + C"""
+    h = 1 if hi else 0
+    return f"v_pk_fma_f32 {D}, {A}, {P}, {C} op_sel:[0,{h},0] op_sel_hi:[1,{h},1]"
+
+
+def fma_im(D, A, P, C, hi=True, conj=False):
+    """D = P.x * (iA) + C"""
+    h = 1 if hi else 0
+    neg = "neg_hi:[1,0,0]" if conj else "neg_lo:[1,0,0]"
+    return f"v_pk_fma_f32 {D}, {A}, {P}, {C} op_sel:[1,{h},0] op_sel_hi:[0,{h},1] {neg}"
+
+
+# ---- one-qubit gate on an amplitude pair (X, Y); P0..P3 = (m00, m01, m10, m11) as (re, im) pairs ------------
+def g1_rx(X, Y, T, U, P):
+    """real diagonal, imaginary off-diagonal (rx, y ...): x' = m00r x + m01i (iy), y' = m10i (ix) + m11r y"""
+    return [mul_im(T, Y, P[1]), mul_re(Y, Y, P[3]), fma_im(Y, X, P[2], Y), fma_re(X, X, P[0], T)]
+
+
+def g1_real(X, Y, T, U, P):
+    """real matrix (h, ry, x, z ...)"""
+    return [mul_re(T, Y, P[1]), mul_re(Y, Y, P[3]), fma_re(Y, X, P[2], Y), fma_re(X, X, P[0], T)]
+
+
+def g1_gen(X, Y, T, U, P):
+    """general complex 2x2: x' in T, y' in place through U, then X <- T"""
+    return [
+        mul_re(T, X, P[0]), mul_im(U, Y, P[3]),
+        fma_im(T, X, P[0], T), fma_re(U, Y, P[3], U),
+        fma_re(T, Y, P[1], T), fma_re(U, X, P[2], U),
+        fma_im(T, Y, P[1], T), fma_im(Y, X, P[2], U),
+        f"v_mov_b64 {X}, {T}",
+    ]
+
+
+def interleave(seqs):
+    """Round-robin merge of instruction sequences (independent chains back to back)."""
+    out = []
+    for i in range(max(len(s) for s in seqs)):
+        for s in seqs:
+            if i < len(s):
+                out.append(s[i])
+    return out
+
+
+def gen_gate4():
+    """Four amplitude pairs, one 2x2 matrix, kind in an SGPR: 2 rx-like, 1 real, 0 general, else nothing."""
+    NP = 4
+    P = [f"%[p{k}]" for k in range(4)]
+
+    def body(fn):
+        seqs = []
+        for g in range(0, NP, 2):
+            seqs.append(interleave([fn(f"%[x{p}]", f"%[y{p}]", f"%[t{p % 2}]", f"%[u{p % 2}]", P) for p in (g, g + 1)]))
+        return [l for s in seqs for l in s]
+
+    lines = (["s_cmp_lg_u32 %[kind], 2", "s_cbranch_scc1 1f"] + body(g1_rx) + ["s_branch 3f", "1:",
+             "s_cmp_lg_u32 %[kind], 1", "s_cbranch_scc1 2f"] + body(g1_real) + ["s_branch 3f", "2:",
+             "s_cmp_lg_u32 %[kind], 0", "s_cbranch_scc1 3f"] + body(g1_gen) + ["3:"])
+    args = ", ".join(f"v2f& x{p}, v2f& y{p}" for p in range(NP)) + ", v2f p0, v2f p1, v2f p2, v2f p3, int kind"
+    named_outs = []
+    for p in range(NP):
+        named_outs += [f'[x{p}] "+v"(x{p})', f'[y{p}] "+v"(y{p})']
+    named_outs += ['[t0] "=&v"(t0)', '[t1] "=&v"(t1)', '[u0] "=&v"(u0)', '[u1] "=&v"(u1)']
+    ins = [f'[p{k}] "s"(p{k})' for k in range(4)] + ['[kind] "s"(kind)']
+    emit_named("vm2_gate4", args, lines, named_outs, ins, ["t0", "t1", "u0", "u1"])
+
+
+def emit_named(name, args, lines, outs, ins, tmps, clobbers=("scc",)):
+    body = "\n".join(f'      "{l}\\n\\t"' for l in lines)
+    c = ", ".join(f'"{x}"' for x in clobbers)
+    print(f"__device__ __forceinline__ void {name}({args}) {{")
+    if tmps:
+        print("  v2f " + ", ".join(tmps) + ";")
+    print("  asm volatile(")
+    print(body)
+    print("      : " + ", ".join(outs))
+    print("      : " + ", ".join(ins))
+    print(f"      : {c});")
+    print("}\n")
+
+
+def gen_cmul8s():
+    """a_k *= (c_k + i s_k), coefficient pairs in SGPRs (DIAGC: one table entry per register index)."""
+    seqs = []
+    for k in range(8):
+        T = f"%[t{k % 2}]"
+        seqs.append([mul_im(T, f"%[a{k}]", f"%[p{k}]"), fma_re(f"%[a{k}]", f"%[a{k}]", f"%[p{k}]", T)])
+    lines = []
+    for g in range(0, 8, 2):
+        lines += interleave(seqs[g:g + 2])
+    args = ", ".join(f"v2f& a{k}" for k in range(8)) + ", " + ", ".join(f"v2f p{k}" for k in range(8))
+    outs = [f'[a{k}] "+v"(a{k})' for k in range(8)] + ['[t0] "=&v"(t0)', '[t1] "=&v"(t1)']
+    ins = [f'[p{k}] "s"(p{k})' for k in range(8)]
+    emit_named("vm2_cmul8s", args, lines, outs, ins, ["t0", "t1"], clobbers=())
+
+
+def gen_cmul8v():
+    """a_k *= (c_k + i s_k), per-thread coefficient pairs in VGPRs (general DIAG op)."""
+    seqs = []
+    for k in range(8):
+        T = f"%[t{k % 2}]"
+        seqs.append([mul_im(T, f"%[a{k}]", f"%[e{k}]"), fma_re(f"%[a{k}]", f"%[a{k}]", f"%[e{k}]", T)])
+    lines = []
+    for g in range(0, 8, 2):
+        lines += interleave(seqs[g:g + 2])
+    args = ", ".join(f"v2f& a{k}" for k in range(8)) + ", " + ", ".join(f"v2f e{k}" for k in range(8))
+    outs = [f'[a{k}] "+v"(a{k})' for k in range(8)] + ['[t0] "=&v"(t0)', '[t1] "=&v"(t1)']
+    ins = [f'[e{k}] "v"(e{k})' for k in range(8)]
+    emit_named("vm2_cmul8v", args, lines, outs, ins, ["t0", "t1"], clobbers=())
+
+
+def gen_cmul44v():
+    """a_k *= (c + i s) for the four a's, b_k *= (c - i s) for the four b's; (c, s) per thread (DIAGB)."""
+    seqs = []
+    for k in range(4):
+        T = f"%[t{k % 2}]"
+        seqs.append([mul_im(T, f"%[a{k}]", "%[e]"), fma_re(f"%[a{k}]", f"%[a{k}]", "%[e]", T)])
+    for k in range(4):
+        T = f"%[t{k % 2}]"
+        seqs.append([mul_im(T, f"%[b{k}]", "%[e]", conj=True), fma_re(f"%[b{k}]", f"%[b{k}]", "%[e]", T)])
+    lines = []
+    for g in range(0, 8, 2):
+        lines += interleave(seqs[g:g + 2])
+    args = ", ".join(f"v2f& a{k}" for k in range(4)) + ", " + ", ".join(f"v2f& b{k}" for k in range(4)) + ", v2f e"
+    outs = [f'[a{k}] "+v"(a{k})' for k in range(4)] + [f'[b{k}] "+v"(b{k})' for k in range(4)]
+    outs += ['[t0] "=&v"(t0)', '[t1] "=&v"(t1)']
+    emit_named("vm2_cmul44v", args, lines, outs, ['[e] "v"(e)'], ["t0", "t1"], clobbers=())
+
+
+def gen_g2():
+    """Dense two-qubit gate on two amplitude quads (index = (bit ja << 1) | bit jb): out_i = sum_j M[i][j] v_j,
+    16 coefficient pairs in SGPRs, 32 packed instructions + 4 moves per quad."""
+    lines = []
+    for qd in ("a", "b"):
+        rows = []
+        for i in range(4):
+            T = f"%[t{i}]"
+            seq = [mul_re(T, f"%[{qd}0]", f"%[m{4 * i}]"), fma_im(T, f"%[{qd}0]", f"%[m{4 * i}]", T)]
+            for j in range(1, 4):
+                seq += [fma_re(T, f"%[{qd}{j}]", f"%[m{4 * i + j}]", T), fma_im(T, f"%[{qd}{j}]", f"%[m{4 * i + j}]", T)]
+            rows.append(seq)
+        lines += interleave(rows)
+        lines += [f"v_mov_b64 %[{qd}{i}], %[t{i}]" for i in range(4)]
+    args = (", ".join(f"v2f& a{i}" for i in range(4)) + ", " + ", ".join(f"v2f& b{i}" for i in range(4)) + ", "
+            + ", ".join(f"v2f m{k}" for k in range(16)))
+    outs = [f'[a{i}] "+v"(a{i})' for i in range(4)] + [f'[b{i}] "+v"(b{i})' for i in range(4)]
+    outs += [f'[t{i}] "=&v"(t{i})' for i in range(4)]
+    ins = [f'[m{k}] "s"(m{k})' for k in range(16)]
+    emit_named("vm2_g2x2", args, lines, outs, ins, ["t0", "t1", "t2", "t3"], clobbers=())
+
+
+def gen_swap4():
+    """Four register swaps a_k <-> b_k (CNOT / SWAP on register bits)."""
+    lines = []
+    for k in range(4):
+        lines += [f"v_mov_b64 %[t{k % 2}], %[a{k}]", f"v_mov_b64 %[a{k}], %[b{k}]", f"v_mov_b64 %[b{k}], %[t{k % 2}]"]
+    args = ", ".join(f"v2f& a{k}, v2f& b{k}" for k in range(4))
+    outs = []
+    for k in range(4):
+        outs += [f'[a{k}] "+v"(a{k})', f'[b{k}] "+v"(b{k})']
+    outs += ['[t0] "=&v"(t0)', '[t1] "=&v"(t1)']
+    emit_named("vm2_swap4", args, lines, outs, [], ["t0", "t1"], clobbers=())
+
+
+if __name__ == "__main__":
+    print("// GENERATED by gen_vm2_asm.py -- do not edit; see that file for the conventions.")
+    print("#ifndef TCMI_VM2_ASM_INC\n#define TCMI_VM2_ASM_INC\n")
+    gen_gate4()
+    gen_cmul8s()
+    gen_cmul8v()
+    gen_cmul44v()
+    gen_g2()
+    gen_swap4()
+    print("#endif")

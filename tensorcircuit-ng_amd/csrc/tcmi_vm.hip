@@ -14,6 +14,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "tcmi_vm.h"
 #include "tcmi_dev.h"
 
@@ -451,6 +452,10 @@ __global__ void zero_state_kernel(typename Cx<F>::type* __restrict__ state, long
   }
 }
 
+// second-generation complex64 gate pass (tcmi_vm2.hip); -1 = no variant for this (R, LT)
+int run_pass2_c64(void* state, long long state_stride, int batch, int n, int R, int LT, const int* desc,
+                  const void* ctab, const void* ptab, long long ptab_stride, hipStream_t st);
+
 }  // namespace tcmi
 
 // ---- C ABI ------------------------------------------------------------------------------------
@@ -518,6 +523,14 @@ int tcmi_run_pass(void* state, long long state_stride, int batch, int n, int R, 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!state || !desc_dev || batch < 1) return set_msg(TCMI_ERR_ARG, "tcmi_run_pass: bad argument");
   if (n > 32) return set_msg(TCMI_ERR_ARG, "tcmi_run_pass: n > 32 unsupported");
+  if (dtype == TCMI_C64 && !eout_dev && n >= R + LT) {
+    static const bool vm1 = getenv("TCMI_VM1") != nullptr;  // A/B switch: force the first-generation kernel
+    if (!vm1) {
+      const int rc = tcmi::run_pass2_c64(state, state_stride, batch, n, R, LT, desc_dev, ctab_dev, ptab_dev, ptab_stride, st);
+      if (rc == TCMI_OK) return rc;
+      if (rc != -1) return set_err("pass2_kernel launch", hipGetLastError());
+    }
+  }
 #define TCMI_CASE(FT, RR, LL) \
   if (R == RR && LT == LL)    \
     return launch_pass<FT, RR, LL>(state, state_stride, batch, n, desc_dev, ctab_dev, ptab_dev, ptab_stride, eout_dev, eout_stride, ecopies, ecopy_stride, st);
