@@ -6,11 +6,10 @@ Why assembly bodies (measured on MI355X, scripts/ubench/gen_operand_forms.py, pr
     instruction with VGPR operands only every 2; `v_pk_*_f32` always takes 4 cycles for its two lanes'
     worth of work.  Gate coefficients are wave-uniform (scalar loads), so the amplitude arithmetic is
     written with packed f32 instructions on (re, im) register pairs: full FP32 rate with SGPR matrices.
-  * hipcc copies the whole amplitude register array at every control-flow merge that follows a
-    modification of it (64 `v_mov` per gate in the round-1 kernel).  Here every data-dependent choice (gate
-    kind, gate present or not, which register pair a two-qubit gate acts on) is a scalar branch INSIDE one
-    asm statement whose amplitude operands are tied ("+v"): the compiler sees straight-line code and the
-    amplitudes never move.
+  * hipcc copies the whole amplitude register array at every multi-way control-flow merge that follows a
+    modification of it (64 `v_mov` per gate in the round-1 kernel).  Here every body is one asm statement whose
+    amplitude operands are tied ("+v"), and the callers select bodies with chains of independent skip tests
+    (tcmi_vm2.hip): two-way merges of in-place updates, which the register coalescer resolves without copies.
 
 Packed-operand conventions used below (V_PK_{MUL,FMA}_F32, CDNA3/4 ISA): result.lo uses source halves chosen
 by op_sel, result.hi by op_sel_hi; neg_lo / neg_hi negate a source for the lo / hi result.  With an amplitude
@@ -80,27 +79,22 @@ def interleave(seqs):
     return out
 
 
-def gen_gate4():
-    """Four amplitude pairs, one 2x2 matrix, kind in an SGPR: 2 rx-like, 1 real, 0 general, else nothing."""
-    NP = 4
+def gen_gate8(name, fn, ntmp):
+    """Eight amplitude pairs through one 2x2 matrix of a fixed structure class (no branches: the class is chosen
+    by the caller with flag tests the optimiser cannot fuse into a switch)."""
+    NP = 8
     P = [f"%[p{k}]" for k in range(4)]
-
-    def body(fn):
-        seqs = []
-        for g in range(0, NP, 2):
-            seqs.append(interleave([fn(f"%[x{p}]", f"%[y{p}]", f"%[t{p % 2}]", f"%[u{p % 2}]", P) for p in (g, g + 1)]))
-        return [l for s in seqs for l in s]
-
-    lines = (["s_cmp_lg_u32 %[kind], 2", "s_cbranch_scc1 1f"] + body(g1_rx) + ["s_branch 3f", "1:",
-             "s_cmp_lg_u32 %[kind], 1", "s_cbranch_scc1 2f"] + body(g1_real) + ["s_branch 3f", "2:",
-             "s_cmp_lg_u32 %[kind], 0", "s_cbranch_scc1 3f"] + body(g1_gen) + ["3:"])
-    args = ", ".join(f"v2f& x{p}, v2f& y{p}" for p in range(NP)) + ", v2f p0, v2f p1, v2f p2, v2f p3, int kind"
-    named_outs = []
+    lines = []
+    for g in range(0, NP, 2):
+        lines += interleave([fn(f"%[x{p}]", f"%[y{p}]", f"%[t{p % 2}]", f"%[u{p % 2}]", P) for p in (g, g + 1)])
+    args = ", ".join(f"v2f& x{p}, v2f& y{p}" for p in range(NP)) + ", v2f p0, v2f p1, v2f p2, v2f p3"
+    outs = []
     for p in range(NP):
-        named_outs += [f'[x{p}] "+v"(x{p})', f'[y{p}] "+v"(y{p})']
-    named_outs += ['[t0] "=&v"(t0)', '[t1] "=&v"(t1)', '[u0] "=&v"(u0)', '[u1] "=&v"(u1)']
-    ins = [f'[p{k}] "s"(p{k})' for k in range(4)] + ['[kind] "s"(kind)']
-    emit_named("vm2_gate4", args, lines, named_outs, ins, ["t0", "t1", "u0", "u1"])
+        outs += [f'[x{p}] "+v"(x{p})', f'[y{p}] "+v"(y{p})']
+    tmps = ["t0", "t1"] + (["u0", "u1"] if ntmp == 4 else [])
+    outs += [f'[{t}] "=&v"({t})' for t in tmps]
+    ins = [f'[p{k}] "s"(p{k})' for k in range(4)]
+    emit_named(name, args, lines, outs, ins, tmps, clobbers=())
 
 
 def emit_named(name, args, lines, outs, ins, tmps, clobbers=("scc",)):
@@ -203,7 +197,9 @@ def gen_swap4():
 if __name__ == "__main__":
     print("// GENERATED by gen_vm2_asm.py -- do not edit; see that file for the conventions.")
     print("#ifndef TCMI_VM2_ASM_INC\n#define TCMI_VM2_ASM_INC\n")
-    gen_gate4()
+    gen_gate8("vm2_gate8_rx", g1_rx, 2)
+    gen_gate8("vm2_gate8_real", g1_real, 2)
+    gen_gate8("vm2_gate8_gen", g1_gen, 4)
     gen_cmul8s()
     gen_cmul8v()
     gen_cmul44v()

@@ -39,16 +39,43 @@ __device__ __forceinline__ int onehot(int v) {
   asm("s_lshl_b32 %0, 1, %1" : "=s"(f) : "s"(v) : "scc");
   return f;
 }
+// scheduling-region boundary: keeps the compiler from hoisting all 2^R slot addresses of an exchange phase ahead
+// of the accesses (32 extra live registers, which pushed the kernel over the 128-VGPR / 4-waves-per-SIMD budget)
+#define TCMI_SCHED_FENCE() asm volatile("" ::: "memory")
 
+// a wave-uniform value in a VGPR (keeps later VALU uses free of SGPR operands: 2 instead of 4 issue cycles)
+__device__ __forceinline__ uint32_t to_vgpr(uint32_t v) {
+  uint32_t r;
+  asm("v_mov_b32 %0, %1" : "=v"(r) : "s"(v));
+  return r;
+}
+__device__ __forceinline__ uint32_t to_vgpr_v(uint32_t v) {  // not CSE-able: bounds the live range to its phase
+  uint32_t r;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(v));
+  return r;
+}
+// on ? 1 << v : 0   (on = 0 / 1)
+__device__ __forceinline__ int onehot_if(int on, int v) {
+  int f;
+  asm("s_lshl_b32 %0, %1, %2" : "=s"(f) : "s"(on), "s"(v) : "scc");
+  return f;
+}
+
+// one-qubit gate on register bit J; kf = one-hot structure class (1 general, 2 real, 4 rx-like, 0 = no gate)
 template <int NR, int J>
-__device__ __forceinline__ void vm2_g1(v2f (&a)[NR], int kind, KV2 mp) {
-  const v2f p0 = mp[0], p1 = mp[1], p2 = mp[2], p3 = mp[3];
-#pragma unroll
-  for (int g = 0; g < NR / 2; g += 4) {
-    constexpr int B = 1 << J;
-    const int r0 = ins0(g, J), r1 = ins0(g + 1, J), r2 = ins0(g + 2, J), r3 = ins0(g + 3, J);
-    vm2_gate4(a[r0], a[r0 | B], a[r1], a[r1 | B], a[r2], a[r2 | B], a[r3], a[r3 | B], p0, p1, p2, p3, kind);
+__device__ __forceinline__ void vm2_g1(v2f (&a)[NR], int kf, v2f p0, v2f p1, v2f p2, v2f p3) {
+  constexpr int B = 1 << J;
+#define TCMI_G8(FN)                                                                                               \
+  _Pragma("unroll") for (int g = 0; g < NR / 2; g += 8) {                                                         \
+    const int r0 = ins0(g, J), r1 = ins0(g + 1, J), r2 = ins0(g + 2, J), r3 = ins0(g + 3, J);                     \
+    const int r4 = ins0(g + 4, J), r5 = ins0(g + 5, J), r6 = ins0(g + 6, J), r7 = ins0(g + 7, J);                 \
+    FN(a[r0], a[r0 | B], a[r1], a[r1 | B], a[r2], a[r2 | B], a[r3], a[r3 | B], a[r4], a[r4 | B], a[r5], a[r5 | B], \
+       a[r6], a[r6 | B], a[r7], a[r7 | B], p0, p1, p2, p3);                                                       \
   }
+  if (kf & 4) { TCMI_G8(vm2_gate8_rx) }
+  if (kf & 2) { TCMI_G8(vm2_gate8_real) }
+  if (kf & 1) { TCMI_G8(vm2_gate8_gen) }
+#undef TCMI_G8
 }
 
 template <int NR, int J>
@@ -98,15 +125,16 @@ __device__ __forceinline__ void vm2_g2(v2f (&a)[NR], int kflag, KV2 m) {
   }
 }
 
-template <int R, int LT>
-__global__ __launch_bounds__(1 << LT, 2) void pass2_kernel(v2f* __restrict__ state, long long state_stride,
+// TOFF: type of the per-thread byte offset (uint32_t while every tile bit is below bit 29, i.e. n <= 29)
+template <int R, int LT, typename TOFF>
+__global__ __launch_bounds__(1 << LT, (1024 >> LT)) void pass2_kernel(v2f* __restrict__ state, long long state_stride,
                                                            const int* __restrict__ desc_g,
                                                            const float* __restrict__ ctab_g,
                                                            const float* __restrict__ ptab_g, long long ptab_stride) {
   constexpr int NR = 1 << R;
   constexpr int T = R + LT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  v2f* lds = reinterpret_cast<v2f*>(smem);
+  float* lds = reinterpret_cast<float*>(smem);
 
   const uint32_t tid = threadIdx.x;
   state += (long long)blockIdx.y * state_stride;
@@ -127,16 +155,18 @@ __global__ __launch_bounds__(1 << LT, 2) void pass2_kernel(v2f* __restrict__ sta
   v2f a[NR];
   int pc = TCMI_HDR_WORDS;
   uint32_t tphys;
-  {  // tile load, layout of round 0 (register bit 0 = tile bit 0: two amplitudes per 16-byte access)
+  {  // tile load, layout of round 0 (register bit 0 = tile bit 0: two amplitudes per 16-byte access).
+     // Address = uniform base (workgroup + register-index part, SGPRs) + one 32-bit per-thread byte offset.
     const KInt rr = desc + pc;
     tphys = xor_masks<LT>(tid, rr + 8);
     uint32_t rpm[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) rpm[j] = (uint32_t)rr[2 + j];
-    const v2f* __restrict__ src = state + (wg_base | tphys);
+    const char* __restrict__ base = reinterpret_cast<const char*>(state + wg_base);
+    const TOFF toff = (TOFF)tphys * sizeof(v2f);
 #pragma unroll
     for (int r = 0; r < NR; r += 2) {
-      const v4f v = *reinterpret_cast<const v4f*>(src + reg_mask<R>(r, rpm));
+      const v4f v = *reinterpret_cast<const v4f*>(base + (unsigned long long)reg_mask<R>(r, rpm) * sizeof(v2f) + toff);
       a[r] = v.xy;
       a[r + 1] = v.zw;
     }
@@ -157,9 +187,13 @@ __global__ __launch_bounds__(1 << LT, 2) void pass2_kernel(v2f* __restrict__ sta
         const int mk = desc[q + 1];
         const KV2 mp = (KV2)(ptab + desc[q + 2]);
         qn = q + 3;
-        // kind per register bit: 0 general, 1 real, 2 rx-like, 3 = no gate on this bit
+        // every matrix of the op in one burst of scalar loads (one wait per op, not one per gate)
+        v2f cf[4 * R];
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) cf[i] = mp[i];
+        // structure class per register bit, one-hot and opaque: 1 general, 2 real, 4 rx-like, 0 = no gate on this bit
 #define TCMI_G1(J) \
-  if constexpr (R > J) vm2_g1<NR, J>(a, ((mk >> J) & 1) ? ((mk >> (8 + 2 * J)) & 3) : 3, mp + 4 * J);
+  if constexpr (R > J) vm2_g1<NR, J>(a, onehot_if((mk >> J) & 1, (mk >> (8 + 2 * J)) & 3), cf[4 * J], cf[4 * J + 1], cf[4 * J + 2], cf[4 * J + 3]);
         TCMI_G1(0) TCMI_G1(1) TCMI_G1(2) TCMI_G1(3) TCMI_G1(4) TCMI_G1(5)
 #undef TCMI_G1
       }
@@ -167,9 +201,15 @@ __global__ __launch_bounds__(1 << LT, 2) void pass2_kernel(v2f* __restrict__ sta
         const KV2 tp = (KV2)(ptab + desc[q + 1]);
         qn = q + 2;
 #pragma unroll
-        for (int r = 0; r < NR; r += 8)
-          vm2_cmul8s(a[r], a[r + 1], a[r + 2], a[r + 3], a[r + 4], a[r + 5], a[r + 6], a[r + 7], tp[r], tp[r + 1],
-                     tp[r + 2], tp[r + 3], tp[r + 4], tp[r + 5], tp[r + 6], tp[r + 7]);
+        for (int h = 0; h < NR; h += 16) {  // 32 scalar registers of table per burst
+          v2f t[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) t[i] = tp[h + i];
+#pragma unroll
+          for (int r = 0; r < 16; r += 8)
+            vm2_cmul8s(a[h + r], a[h + r + 1], a[h + r + 2], a[h + r + 3], a[h + r + 4], a[h + r + 5], a[h + r + 6],
+                       a[h + r + 7], t[r], t[r + 1], t[r + 2], t[r + 3], t[r + 4], t[r + 5], t[r + 6], t[r + 7]);
+        }
       }
       if (f & (1 << TCMI_OP_DIAGB)) {
         const int fj = onehot(desc[q + 1]);
@@ -231,38 +271,41 @@ __global__ __launch_bounds__(1 << LT, 2) void pass2_kernel(v2f* __restrict__ sta
           }
         }
         qq += 2 * nB;
-        float ph[NR];
-        ph[0] = (float)(phi - rint(phi));
+        // phases of eight register indices at a time (the full 2^R table would cost 32 more live registers)
+        const float ph0 = (float)(phi - rint(phi));
+        float cjf[R];
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
-          const float c = (float)(cj[j] - rint(cj[j]));
+        for (int j = 0; j < R; ++j) cjf[j] = (float)(cj[j] - rint(cj[j]));
+        const KInt mC = desc + qq;
+        const KPtr<float> cC = cf + nA + nB;
+        qn = qq + nC;
 #pragma unroll
-          for (int r = 0; r < (1 << j); ++r) {
-            ph[r | (1 << j)] = ph[r] - c;
-            ph[r] += c;
-          }
-        }
-#pragma unroll 1
-        for (int e = 0; e < nC; ++e) {
-          const uint32_t rmask = (uint32_t)desc[qq + e];
-          const float c = cf[nA + nB + e];
-#pragma unroll
-          for (int r = 0; r < NR; ++r) ph[r] += (__popc((uint32_t)r & rmask) & 1) ? -c : c;
-        }
-        qq += nC;
-        qn = qq;
-#pragma unroll
-        for (int r = 0; r < NR; r += 8) {
-          v2f e[8];
+        for (int h = 0; h < NR; h += 8) {
+          float ph[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            float s, c;
-            sincos_turns<float>(ph[r + i], &s, &c);
-            e[i].x = c;
-            e[i].y = s;
+            float v = ph0;
+#pragma unroll
+            for (int j = 0; j < R; ++j) v += (((h + i) >> j) & 1) ? -cjf[j] : cjf[j];
+            ph[i] = v;
           }
-          vm2_cmul8v(a[r], a[r + 1], a[r + 2], a[r + 3], a[r + 4], a[r + 5], a[r + 6], a[r + 7], e[0], e[1], e[2], e[3],
-                     e[4], e[5], e[6], e[7]);
+#pragma unroll 1
+          for (int e = 0; e < nC; ++e) {
+            const uint32_t rmask = (uint32_t)mC[e];
+            const float c = cC[e];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ph[i] += (__popc((uint32_t)(h + i) & rmask) & 1) ? -c : c;
+          }
+          v2f e8[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            float sn, cs;
+            sincos_turns<float>(ph[i], &sn, &cs);
+            e8[i].x = cs;
+            e8[i].y = sn;
+          }
+          vm2_cmul8v(a[h], a[h + 1], a[h + 2], a[h + 3], a[h + 4], a[h + 5], a[h + 6], a[h + 7], e8[0], e8[1], e8[2],
+                     e8[3], e8[4], e8[5], e8[6], e8[7]);
         }
       }
       if (f & (1 << TCMI_OP_G2)) {
@@ -286,27 +329,43 @@ __global__ __launch_bounds__(1 << LT, 2) void pass2_kernel(v2f* __restrict__ sta
     pc += TCMI_RR_WORDS + rr[1];
     if (k == nrounds - 1) break;
 
-    // ---- LDS exchange into the layout of round k + 1 ----
-    {
-      const uint32_t tslot = xor_masks<LT>(tid, rr + 40);
-      uint32_t wsm[R];
-#pragma unroll
-      for (int j = 0; j < R; ++j) wsm[j] = (uint32_t)rr[34 + j];
-#pragma unroll
-      for (int r = 0; r < NR; ++r) lds[tslot ^ reg_mask<R>(r, wsm)] = a[r];
-    }
-    __syncthreads();
+    // ---- LDS exchange into the layout of round k + 1: real parts, then imaginary parts, through one 2^T-float
+    // buffer (32 KiB at T = 13 -> four workgroups per CU; the 8-byte form allowed two).  Slot addresses follow a
+    // Gray-code walk over the register index: one VGPR-only v_xor per access (2 issue cycles; the same xor with
+    // the mask in an SGPR takes 4) and no table of 2^R addresses kept alive next to the amplitudes. ----
     {
       const KInt rn = desc + pc;
       tphys = xor_masks<LT>(tid, rn + 8);
-      const uint32_t tslot = xor_masks<LT>(tid, rn + 24);
-      uint32_t rsm[R];
-#pragma unroll
-      for (int j = 0; j < R; ++j) rsm[j] = (uint32_t)rn[18 + j];
-#pragma unroll
-      for (int r = 0; r < NR; ++r) a[r] = lds[tslot ^ reg_mask<R>(r, rsm)];
+      const uint32_t wslot = xor_masks<LT>(tid, rr + 40) << 2, rslot = xor_masks<LT>(tid, rn + 24) << 2;
+      char* const lb = reinterpret_cast<char*>(lds);
+      uint32_t ad;
+      uint32_t mv[R];  // the masks of the current phase in VGPRs (re-materialised per phase: 5 moves, 5 fewer live registers)
+#define TCMI_MASKS(SRC, OFF)                                                  \
+  _Pragma("unroll") for (int j = 0; j < R; ++j) mv[j] = to_vgpr_v((uint32_t)SRC[OFF + j] << 2);
+#define TCMI_WALK(BASE, STMT)                                                 \
+  ad = BASE;                                                                  \
+  _Pragma("unroll") for (int g = 0; g < NR; ++g) {                            \
+    if (g) ad ^= mv[__builtin_ctz(g)];                                        \
+    constexpr_for_r(g ^ (g >> 1));                                            \
+    STMT;                                                                     \
+  }
+#define constexpr_for_r(X) const int r = (X)
+      TCMI_MASKS(rr, 34)
+      TCMI_WALK(wslot, *reinterpret_cast<float*>(lb + ad) = a[r].x)
+      __syncthreads();
+      TCMI_MASKS(rn, 18)
+      TCMI_WALK(rslot, a[r].x = *reinterpret_cast<const float*>(lb + ad))
+      __syncthreads();
+      TCMI_MASKS(rr, 34)
+      TCMI_WALK(wslot, *reinterpret_cast<float*>(lb + ad) = a[r].y)
+      __syncthreads();
+      TCMI_MASKS(rn, 18)
+      TCMI_WALK(rslot, a[r].y = *reinterpret_cast<const float*>(lb + ad))
+      __syncthreads();  // all reads done before the next exchange overwrites the buffer
+#undef TCMI_MASKS
+#undef TCMI_WALK
+#undef constexpr_for_r
     }
-    __syncthreads();  // all reads done before the next exchange overwrites the tile
   }
 
   {  // tile store, layout of the last round (constrained like round 0)
@@ -314,13 +373,14 @@ __global__ __launch_bounds__(1 << LT, 2) void pass2_kernel(v2f* __restrict__ sta
     uint32_t rpm[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) rpm[j] = (uint32_t)rl[2 + j];
-    v2f* __restrict__ dst = state + (wg_base | tphys);
+    char* __restrict__ base = reinterpret_cast<char*>(state + wg_base);
+    const TOFF toff = (TOFF)tphys * sizeof(v2f);
 #pragma unroll
     for (int r = 0; r < NR; r += 2) {
       v4f v;
       v.xy = a[r];
       v.zw = a[r + 1];
-      *reinterpret_cast<v4f*>(dst + reg_mask<R>(r, rpm)) = v;
+      *reinterpret_cast<v4f*>(base + (unsigned long long)reg_mask<R>(r, rpm) * sizeof(v2f) + toff) = v;
     }
   }
 }
@@ -329,8 +389,8 @@ template <int R, int LT>
 static int launch_pass2(void* state, long long state_stride, int batch, int n, const int* desc, const void* ctab,
                         const void* ptab, long long ptab_stride, hipStream_t st) {
   constexpr int T = R + LT;
-  const size_t lds = sizeof(v2f) << T;
-  auto kern = pass2_kernel<R, LT>;
+  const size_t lds = sizeof(float) << T;
+  auto kern = n <= 29 ? pass2_kernel<R, LT, uint32_t> : pass2_kernel<R, LT, unsigned long long>;
   if (lds > 48 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
