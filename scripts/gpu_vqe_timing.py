@@ -27,7 +27,7 @@ def run(n, d, B, reps=3):
     print(f"VQE n={n} d={d} B={B}: first {t_first:.3f}s steady {t*1e3:.1f} ms/step  E0={float(v[0]):.5f} |g|={float(g.norm()):.4f} mem={torch.cuda.max_memory_allocated()/2**30:.1f}GiB", flush=True)
     # decomposition: forward only / measure only
     c = tc.Circuit(n); W.hea_b(c, n, d, params[0], zz=tc.gates._zz_matrix)
-    cc = c._compiled(); p = c._param_tensor().reshape(1, -1).repeat(B, 1)
+    cc = c._compiled(); cc = getattr(cc, 'full', cc); p = c._param_tensor().reshape(1, -1).repeat(B, 1)
     torch.cuda.synchronize(); t0 = time.time()
     for _ in range(reps): st = cc.state(p, full=True)
     torch.cuda.synchronize(); tf = (time.time() - t0) / reps
@@ -38,9 +38,7 @@ def run(n, d, B, reps=3):
     adj = cc._adjoint()
     print(f"   forward {tf*1e3:.1f} ms ({len(cc.descs)} passes)  adjoint sweep {tb*1e3:.1f} ms ({len(adj['descs'])} passes, cfg R{adj['cfg'].R})", flush=True)
 
-run(16, 4, 4)
-run(20, 6, 4)
-run(24, 8, 1)
-run(24, 8, 8)
-run(26, 10, 2)
-run(28, 12, 1, reps=2)
+import sys
+for a in (sys.argv[1:] or ['16,4,4', '20,6,4', '24,8,1', '24,8,8', '26,10,2', '28,12,1']):
+    n_, d_, b_ = (int(x) for x in a.split(','))
+    run(n_, d_, b_, reps=2 if n_ >= 28 else 3)

@@ -194,6 +194,82 @@ def gen_swap4():
     emit_named("vm2_swap4", args, lines, outs, [], ["t0", "t1"], clobbers=())
 
 
+# ---- adjoint sweep (tcmi_adjoint2.hip): gradient inner products and conjugate phases ----------------------------
+def gen_grad4(name, kind):
+    """Accumulate the gradient inner product of one gate over four amplitude pairs (x = index with the gate's bit
+    clear, y = set) of psi (ax, ay) and lambda (lx, ly); nothing is modified but the two accumulators.
+      rx-like  K = i kappa X:  acc0 += (lx.re ay.im, -lx.im ay.re), acc1 += (ly.re ax.im, -ly.im ax.re)
+      real     K = [[0, k01], [k10, 0]]:  acc0 += lx * ay (per component), acc1 += ly * ax
+    The caller combines the halves and scales by the generator coefficient."""
+    lines = []
+    for p in range(4):
+        if kind == "rx":
+            mods = "op_sel:[0,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]"
+        else:
+            mods = "op_sel:[0,0,0] op_sel_hi:[1,1,1]"
+        lines.append(f"v_pk_fma_f32 %[c0], %[lx{p}], %[ay{p}], %[c0] {mods}")
+        lines.append(f"v_pk_fma_f32 %[c1], %[ly{p}], %[ax{p}], %[c1] {mods}")
+    args = (", ".join(f"v2f ax{p}, v2f ay{p}" for p in range(4)) + ", " + ", ".join(f"v2f lx{p}, v2f ly{p}" for p in range(4))
+            + ", v2f& c0, v2f& c1")
+    outs = ['[c0] "+v"(c0)', '[c1] "+v"(c1)']
+    ins = []
+    for p in range(4):
+        ins += [f'[ax{p}] "v"(ax{p})', f'[ay{p}] "v"(ay{p})', f'[lx{p}] "v"(lx{p})', f'[ly{p}] "v"(ly{p})']
+    emit_named(name, args, lines, outs, ins, [], clobbers=())
+
+
+def gen_grad4_gen():
+    """General generator K (complex 2x2 in SGPR pairs k0..k3): acc0 += lx * (K (ax, ay))_0, acc1 += ly * (K (ax, ay))_1
+    componentwise (the real part of conj(lambda) K psi is the sum of the halves)."""
+    lines = []
+    K = [f"%[k{i}]" for i in range(4)]
+    for p in range(0, 4, 2):
+        seqs = []
+        for w in (0, 1):
+            X, Y, T, U = f"%[ax{p + w}]", f"%[ay{p + w}]", f"%[t{w}]", f"%[u{w}]"
+            seqs.append([
+                mul_re(T, X, K[0]), mul_re(U, X, K[2]),
+                fma_im(T, X, K[0], T), fma_im(U, X, K[2], U),
+                fma_re(T, Y, K[1], T), fma_re(U, Y, K[3], U),
+                fma_im(T, Y, K[1], T), fma_im(U, Y, K[3], U),
+                f"v_pk_fma_f32 %[c0], %[lx{p + w}], {T}, %[c0]",
+                f"v_pk_fma_f32 %[c1], %[ly{p + w}], {U}, %[c1]",
+            ])
+        lines += interleave(seqs)
+    args = (", ".join(f"v2f ax{p}, v2f ay{p}" for p in range(4)) + ", " + ", ".join(f"v2f lx{p}, v2f ly{p}" for p in range(4))
+            + ", v2f k0, v2f k1, v2f k2, v2f k3, v2f& c0, v2f& c1")
+    outs = ['[c0] "+v"(c0)', '[c1] "+v"(c1)'] + [f'[{t}] "=&v"({t})' for t in ("t0", "t1", "u0", "u1")]
+    ins = []
+    for p in range(4):
+        ins += [f'[ax{p}] "v"(ax{p})', f'[ay{p}] "v"(ay{p})', f'[lx{p}] "v"(lx{p})', f'[ly{p}] "v"(ly{p})']
+    ins += [f'[k{i}] "s"(k{i})' for i in range(4)]
+    emit_named("vm2_grad4_gen", args, lines, outs, ins, ["t0", "t1", "u0", "u1"], clobbers=())
+
+
+def gen_cross8():
+    """t_k = (l_k.re a_k.im, l_k.im a_k.re): Im(conj(l) a) = t.x - t.y (diagonal-term gradients)."""
+    lines = [f"v_pk_mul_f32 %[t{k}], %[l{k}], %[a{k}] op_sel:[0,1] op_sel_hi:[1,0]" for k in range(8)]
+    args = ", ".join(f"v2f a{k}" for k in range(8)) + ", " + ", ".join(f"v2f l{k}" for k in range(8)) + ", " + ", ".join(f"v2f& t{k}" for k in range(8))
+    outs = [f'[t{k}] "=v"(t{k})' for k in range(8)]
+    ins = [f'[a{k}] "v"(a{k})' for k in range(8)] + [f'[l{k}] "v"(l{k})' for k in range(8)]
+    emit_named("vm2_cross8", args, lines, outs, ins, [], clobbers=())
+
+
+def gen_cmul8v_conj():
+    """a_k *= (c_k - i s_k), per-thread coefficient pairs in VGPRs (inverse phases of the adjoint sweep)."""
+    seqs = []
+    for k in range(8):
+        T = f"%[t{k % 2}]"
+        seqs.append([mul_im(T, f"%[a{k}]", f"%[e{k}]", conj=True), fma_re(f"%[a{k}]", f"%[a{k}]", f"%[e{k}]", T)])
+    lines = []
+    for g in range(0, 8, 2):
+        lines += interleave(seqs[g:g + 2])
+    args = ", ".join(f"v2f& a{k}" for k in range(8)) + ", " + ", ".join(f"v2f e{k}" for k in range(8))
+    outs = [f'[a{k}] "+v"(a{k})' for k in range(8)] + ['[t0] "=&v"(t0)', '[t1] "=&v"(t1)']
+    ins = [f'[e{k}] "v"(e{k})' for k in range(8)]
+    emit_named("vm2_cmul8v_conj", args, lines, outs, ins, ["t0", "t1"], clobbers=())
+
+
 if __name__ == "__main__":
     print("// GENERATED by gen_vm2_asm.py -- do not edit; see that file for the conventions.")
     print("#ifndef TCMI_VM2_ASM_INC\n#define TCMI_VM2_ASM_INC\n")
@@ -205,4 +281,9 @@ if __name__ == "__main__":
     gen_cmul44v()
     gen_g2()
     gen_swap4()
+    gen_grad4("vm2_grad4_rx", "rx")
+    gen_grad4("vm2_grad4_real", "real")
+    gen_grad4_gen()
+    gen_cross8()
+    gen_cmul8v_conj()
     print("#endif")

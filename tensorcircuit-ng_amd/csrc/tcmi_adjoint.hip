@@ -552,6 +552,11 @@ __global__ void vdot_kernel(const typename Cx<F>::type* __restrict__ a, const ty
   }
 }
 
+// second-generation complex64 adjoint pass (tcmi_adjoint2.hip); -1 = no variant for this (R, LT)
+int run_adjoint2_c64(void* psi, void* lam, long long stride, int batch, int n, int R, int LT, const int* desc,
+                     const void* ctab, const void* ptab, long long ptab_stride, double* gout, long long gout_stride,
+                     int gcopies, long long gcopy_stride, hipStream_t st);
+
 }  // namespace tcmi
 
 // ---- C ABI ------------------------------------------------------------------------------------
@@ -594,6 +599,11 @@ int tcmi_run_adjoint_pass(void* psi, void* lam, long long state_stride, int batc
   if (R == RR && LT == LL)    \
     return launch_adjoint<FT, RR, LL>(psi, lam, state_stride, batch, n, desc_dev, ctab_dev, ptab_dev, ptab_stride, gout_dev, gout_stride, gcopies, gcopy_stride, st);
   if (dtype == TCMI_C64) {
+    // (4, 9): the packed-f32 kernel; its plans hold one-qubit gate ops and phase polynomials only (host-checked)
+    const int rc = tcmi::run_adjoint2_c64(psi, lam, state_stride, batch, n, R, LT, desc_dev, ctab_dev, ptab_dev, ptab_stride,
+                                          gout_dev, gout_stride, gcopies, gcopy_stride, st);
+    if (rc == TCMI_OK) return rc;
+    if (rc != -1) return tcmi_set_error_(TCMI_ERR_HIP, "adjoint2_kernel launch failed");
     TCMI_CASE(float, 4, 8)
     TCMI_CASE(float, 2, 6)
   } else if (dtype == TCMI_C128) {

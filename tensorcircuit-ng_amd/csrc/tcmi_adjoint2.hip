@@ -1,0 +1,364 @@
+// tcmi adjoint sweep, complex64, second generation (gfx950 / MI355X only).
+//
+// Same backward pass descriptors as tcmi_adjoint.hip (layout: tcmi_vm.h "backward ops"; semantics: psi is
+// un-computed gate by gate with U^dagger while the cotangent lambda follows, every parametrised gate adds
+// Re<lambda|K|psi> to its gradient slot -- the reverse-mode rule that replaces framework AD through stored
+// intermediates, reference tensorcircuit/backends/pytorch_backend.py:775-786), issued the way tcmi_vm2.hip
+// issues the forward pass: both vectors as (re, im) register pairs, packed-f32 instruction bodies with tied
+// operands (tcmi_vm2_asm.inc), no register-array copies at control-flow merges, planar LDS exchange.
+//
+// Tile: R = 4 register bits, 512 threads (16 + 16 amplitude pairs per thread, 8 waves per workgroup, two
+// workgroups per CU = 4 waves per SIMD).  Handles one-qubit gate ops and phase-polynomial ops; plans with dense
+// two-qubit gates stay on the first-generation kernel (the host checks, tcmi/executor.py).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "tcmi_vm.h"
+#include "tcmi_dev.h"
+
+namespace tcmi {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const v2f TCMI_K* KV2;
+
+#include "tcmi_vm2_asm.inc"
+
+__host__ __device__ constexpr int ains0(int k, int J) { return ((k >> J) << (J + 1)) | (k & ((1 << J) - 1)); }
+
+__device__ __forceinline__ int aonehot_if(int on, int v) {
+  int f;
+  asm("s_lshl_b32 %0, %1, %2" : "=s"(f) : "s"(on), "s"(v) : "scc");
+  return f;
+}
+__device__ __forceinline__ int aonehot(int v) {
+  int f;
+  asm("s_lshl_b32 %0, 1, %1" : "=s"(f) : "s"(v) : "scc");
+  return f;
+}
+__device__ __forceinline__ uint32_t ato_vgpr_v(uint32_t v) {
+  uint32_t r;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(v));
+  return r;
+}
+
+// U^dagger on register bit J of one vector; kf = one-hot structure class (1 general, 2 real, 4 rx-like)
+template <int NR, int J>
+__device__ __forceinline__ void adj_apply(v2f (&a)[NR], int kf, v2f p0, v2f p1, v2f p2, v2f p3) {
+  constexpr int B = 1 << J;
+  static_assert(NR == 16, "one asm statement covers the 8 pairs of a 16-amplitude register tile");
+  constexpr int r0 = ains0(0, J), r1 = ains0(1, J), r2 = ains0(2, J), r3 = ains0(3, J);
+  constexpr int r4 = ains0(4, J), r5 = ains0(5, J), r6 = ains0(6, J), r7 = ains0(7, J);
+#define TCMI_A8(FN)                                                                                                  \
+  FN(a[r0], a[r0 | B], a[r1], a[r1 | B], a[r2], a[r2 | B], a[r3], a[r3 | B], a[r4], a[r4 | B], a[r5], a[r5 | B], a[r6], \
+     a[r6 | B], a[r7], a[r7 | B], p0, p1, p2, p3);
+  if (kf & 4) { TCMI_A8(vm2_gate8_rx) }
+  if (kf & 2) { TCMI_A8(vm2_gate8_real) }
+  if (kf & 1) { TCMI_A8(vm2_gate8_gen) }
+#undef TCMI_A8
+}
+
+// gradient of the gate on register bit J: Re<lambda|K|psi> summed over this thread's pairs
+template <int NR, int J>
+__device__ __forceinline__ float adj_grad(const v2f (&a)[NR], const v2f (&l)[NR], int kf, v2f k0, v2f k1, v2f k2, v2f k3) {
+  constexpr int B = 1 << J;
+  constexpr int r0 = ains0(0, J), r1 = ains0(1, J), r2 = ains0(2, J), r3 = ains0(3, J);
+  constexpr int r4 = ains0(4, J), r5 = ains0(5, J), r6 = ains0(6, J), r7 = ains0(7, J);
+  v2f c0 = {0.f, 0.f}, c1 = {0.f, 0.f}, d0 = {0.f, 0.f}, d1 = {0.f, 0.f};
+  float g = 0.f;
+#define TCMI_GR(FN, ...)                                                                                          \
+  FN(a[r0], a[r0 | B], a[r1], a[r1 | B], a[r2], a[r2 | B], a[r3], a[r3 | B], l[r0], l[r0 | B], l[r1], l[r1 | B],   \
+     l[r2], l[r2 | B], l[r3], l[r3 | B], ##__VA_ARGS__, c0, c1);                                                  \
+  FN(a[r4], a[r4 | B], a[r5], a[r5 | B], a[r6], a[r6 | B], a[r7], a[r7 | B], l[r4], l[r4 | B], l[r5], l[r5 | B],   \
+     l[r6], l[r6 | B], l[r7], l[r7 | B], ##__VA_ARGS__, d0, d1);
+  if (kf & 4) {  // K = i kappa X, kappa = Im K01
+    TCMI_GR(vm2_grad4_rx)
+    g = -k1.y * ((c0.x + c0.y) + (c1.x + c1.y) + (d0.x + d0.y) + (d1.x + d1.y));
+  }
+  if (kf & 2) {  // real antisymmetric K = [[0, k01], [k10, 0]]
+    TCMI_GR(vm2_grad4_real)
+    g = k1.x * ((c0.x + c0.y) + (d0.x + d0.y)) + k2.x * ((c1.x + c1.y) + (d1.x + d1.y));
+  }
+  if (kf & 1) {
+    TCMI_GR(vm2_grad4_gen, k0, k1, k2, k3)
+    g = (c0.x + c0.y) + (c1.x + c1.y) + (d0.x + d0.y) + (d1.x + d1.y);
+  }
+#undef TCMI_GR
+  return g;
+}
+
+template <int R, int LT, typename TOFF>
+__global__ __launch_bounds__(1 << LT, (1024 >> LT)) void adjoint2_kernel(v2f* __restrict__ psi, v2f* __restrict__ lam,
+                                                                       long long state_stride,
+                                                                       const int* __restrict__ desc_g,
+                                                                       const float* __restrict__ ctab_g,
+                                                                       const float* __restrict__ ptab_g,
+                                                                       long long ptab_stride, double* __restrict__ gout,
+                                                                       long long gout_stride, int gcopies,
+                                                                       long long gcopy_stride) {
+  constexpr int NR = 1 << R;
+  constexpr int T = R + LT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* lds = reinterpret_cast<float*>(smem);
+
+  const uint32_t tid = threadIdx.x;
+  psi += (long long)blockIdx.y * state_stride;
+  lam += (long long)blockIdx.y * state_stride;
+  gout += (long long)blockIdx.y * gout_stride + (long long)(blockIdx.x % (unsigned)gcopies) * gcopy_stride;
+  const KInt desc = (KInt)desc_g;
+  const KPtr<float> ptab = (KPtr<float>)(ptab_g + (long long)blockIdx.y * ptab_stride);
+  const bool lane0 = (tid & 63) == 0;
+
+  const int nrounds = desc[5];
+  unsigned long long x = blockIdx.x;
+#pragma unroll 1
+  for (int i = 0; i < T; ++i) {
+    const int p = desc[8 + i];
+    const unsigned long long low = (1ull << p) - 1ull;
+    x = ((x & ~low) << 1) | (x & low);
+  }
+  const uint32_t wg_base = (uint32_t)x;
+
+  v2f a[NR], l[NR];
+  int pc = TCMI_HDR_WORDS;
+  uint32_t tphys;
+  {
+    const KInt rr = desc + pc;
+    tphys = xor_masks<LT>(tid, rr + 8);
+    uint32_t rpm[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) rpm[j] = (uint32_t)rr[2 + j];
+    const char* __restrict__ ba = reinterpret_cast<const char*>(psi + wg_base);
+    const char* __restrict__ bl = reinterpret_cast<const char*>(lam + wg_base);
+    const TOFF toff = (TOFF)tphys * sizeof(v2f);
+#pragma unroll
+    for (int r = 0; r < NR; r += 2) {
+      const unsigned long long ro = (unsigned long long)reg_mask<R>(r, rpm) * sizeof(v2f);
+      const v4f v = *reinterpret_cast<const v4f*>(ba + ro + toff);
+      const v4f w = *reinterpret_cast<const v4f*>(bl + ro + toff);
+      a[r] = v.xy;
+      a[r + 1] = v.zw;
+      l[r] = w.xy;
+      l[r + 1] = w.zw;
+    }
+  }
+
+  int pc_cur = pc;
+#pragma unroll 1
+  for (int k = 0;; ++k) {
+    pc_cur = pc;
+    const KInt rr = desc + pc;
+    const int nops = rr[0];
+    int q = pc + TCMI_RR_WORDS;
+#pragma unroll 1
+    for (int o = 0; o < nops; ++o) {
+      const int f = aonehot(desc[q]);
+      int qn = q;
+      if (f & (1 << TCMI_OP_G1M)) {
+        // {4, mask | kinds << 8, ubase, kmask, kbase, gslot[R]}
+        const int mk = desc[q + 1], kmask = desc[q + 3];
+        const KV2 up = (KV2)(ptab + desc[q + 2]);
+        const KV2 kp = (KV2)(ptab + desc[q + 4]);
+        qn = q + 5 + R;
+#define TCMI_BW(J)                                                                                           \
+  if constexpr (R > J) {                                                                                     \
+    const int kf = aonehot_if((mk >> J) & 1, (mk >> (8 + 2 * J)) & 3);                                       \
+    const int gf = ((kmask >> J) & 1) ? kf : 0;                                                              \
+    if (gf) {                                                                                                \
+      float g = adj_grad<NR, J>(a, l, gf, kp[4 * J], kp[4 * J + 1], kp[4 * J + 2], kp[4 * J + 3]);           \
+      g = wave_sum_uniform(g);                                                                               \
+      if (lane0) atomicAdd(gout + desc[q + 5 + J], (double)g);                                               \
+    }                                                                                                        \
+    const v2f u0 = up[4 * J], u1 = up[4 * J + 1], u2 = up[4 * J + 2], u3 = up[4 * J + 3];                    \
+    adj_apply<NR, J>(a, kf, u0, u1, u2, u3);                                                                 \
+    adj_apply<NR, J>(l, kf, u0, u1, u2, u3);                                                                 \
+  }
+        TCMI_BW(0) TCMI_BW(1) TCMI_BW(2) TCMI_BW(3)
+#undef TCMI_BW
+      }
+      if (f & (1 << TCMI_OP_DIAG)) {
+        // {3, nA, nB, nC, base, maskA[nA], maskB[nB], jB[nB], rmaskC[nC], gsA[nA], gsB[nB], gsC[nC]}; the table
+        // holds the FORWARD coefficients (turns), the inverse phase is applied
+        const int nA = desc[q + 1], nB = desc[q + 2], nC = desc[q + 3];
+        const KPtr<float> cf = ptab + desc[q + 4];
+        const int q0 = q + 5;
+        const KInt mA = desc + q0, mB = desc + q0 + nA, jB = desc + q0 + nA + nB, mC = desc + q0 + nA + 2 * nB;
+        const KInt gA = mC + nC, gB = gA + nA, gC = gB + nB;
+        qn = q0 + 2 * nA + 3 * nB + 2 * nC;
+        const uint32_t tidx = wg_base | tphys;
+        // w[r] = Im(conj(lambda) psi): every term's gradient is a signed sum of w
+        float w[NR];
+#pragma unroll
+        for (int h = 0; h < NR; h += 8) {
+          v2f t[8];
+          vm2_cross8(a[h], a[h + 1], a[h + 2], a[h + 3], a[h + 4], a[h + 5], a[h + 6], a[h + 7], l[h], l[h + 1], l[h + 2],
+                     l[h + 3], l[h + 4], l[h + 5], l[h + 6], l[h + 7], t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) w[h + i] = t[i].x - t[i].y;
+        }
+        float w0 = 0.f;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) w0 += w[r];
+        float wj[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          float s = 0.f;
+#pragma unroll
+          for (int r = 0; r < NR; ++r) s += ((r >> j) & 1) ? -w[r] : w[r];
+          wj[j] = s;
+        }
+        double phi = 0.0;
+#pragma unroll 1
+        for (int e = 0; e < nA; ++e) {
+          const bool neg = __popc(tidx & (uint32_t)mA[e]) & 1;
+          const double c = (double)cf[e];
+          phi += neg ? -c : c;
+          const int gs = gA[e];
+          if (gs >= 0) {  // wave-uniform
+            const float v = wave_sum_uniform(neg ? -w0 : w0);
+            if (lane0) atomicAdd(gout + gs, (double)v);
+          }
+        }
+        double cj[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) cj[j] = 0.0;
+#pragma unroll 1
+        for (int e = 0; e < nB; ++e) {
+          const int jj = jB[e];
+          const bool neg = __popc(tidx & (uint32_t)mB[e]) & 1;
+          const double c = (double)cf[nA + e];
+          const double sgn = neg ? -c : c;
+          float wsel = 0.f;
+#pragma unroll
+          for (int j = 0; j < R; ++j) {
+            cj[j] += (j == jj) ? sgn : 0.0;
+            wsel = (j == jj) ? wj[j] : wsel;
+          }
+          const int gs = gB[e];
+          if (gs >= 0) {
+            const float v = wave_sum_uniform(neg ? -wsel : wsel);
+            if (lane0) atomicAdd(gout + gs, (double)v);
+          }
+        }
+        float ph[NR];
+        ph[0] = (float)(phi - rint(phi));
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const float c = (float)(cj[j] - rint(cj[j]));
+#pragma unroll
+          for (int r = 0; r < (1 << j); ++r) {
+            ph[r | (1 << j)] = ph[r] - c;
+            ph[r] += c;
+          }
+        }
+#pragma unroll 1
+        for (int e = 0; e < nC; ++e) {
+          const uint32_t rmask = (uint32_t)mC[e];
+          const float c = cf[nA + nB + e];
+          float s = 0.f;
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            const bool neg = __popc((uint32_t)r & rmask) & 1;
+            ph[r] += neg ? -c : c;
+            s += neg ? -w[r] : w[r];
+          }
+          const int gs = gC[e];
+          if (gs >= 0) {
+            const float v = wave_sum_uniform(s);
+            if (lane0) atomicAdd(gout + gs, (double)v);
+          }
+        }
+#pragma unroll
+        for (int h = 0; h < NR; h += 8) {
+          v2f e8[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            float sn, cs;
+            sincos_turns<float>(ph[h + i], &sn, &cs);
+            e8[i].x = cs;
+            e8[i].y = sn;
+          }
+          vm2_cmul8v_conj(a[h], a[h + 1], a[h + 2], a[h + 3], a[h + 4], a[h + 5], a[h + 6], a[h + 7], e8[0], e8[1], e8[2],
+                          e8[3], e8[4], e8[5], e8[6], e8[7]);
+          vm2_cmul8v_conj(l[h], l[h + 1], l[h + 2], l[h + 3], l[h + 4], l[h + 5], l[h + 6], l[h + 7], e8[0], e8[1], e8[2],
+                          e8[3], e8[4], e8[5], e8[6], e8[7]);
+        }
+      }
+      q = qn;
+    }
+    pc += TCMI_RR_WORDS + rr[1];
+    if (k == nrounds - 1) break;
+
+    // ---- planar LDS exchange of the four real planes (psi.re, psi.im, lambda.re, lambda.im), one 2^T-float buffer ----
+    {
+      const KInt rn = desc + pc;
+      tphys = xor_masks<LT>(tid, rn + 8);
+      const uint32_t wslot = xor_masks<LT>(tid, rr + 40) << 2, rslot = xor_masks<LT>(tid, rn + 24) << 2;
+      char* const lb = reinterpret_cast<char*>(lds);
+      uint32_t ad;
+      uint32_t mv[R];
+#define TCMI_MASKS(SRC, OFF) \
+  _Pragma("unroll") for (int j = 0; j < R; ++j) mv[j] = ato_vgpr_v((uint32_t)SRC[OFF + j] << 2);
+#define TCMI_WALK(BASE, STMT)                      \
+  ad = BASE;                                       \
+  _Pragma("unroll") for (int g = 0; g < NR; ++g) { \
+    if (g) ad ^= mv[__builtin_ctz(g)];             \
+    const int r = g ^ (g >> 1);                    \
+    STMT;                                          \
+  }
+#define TCMI_PLANE(V, C)                                                      \
+  TCMI_MASKS(rr, 34)                                                          \
+  TCMI_WALK(wslot, *reinterpret_cast<float*>(lb + ad) = V[r].C)               \
+  __syncthreads();                                                            \
+  TCMI_MASKS(rn, 18)                                                          \
+  TCMI_WALK(rslot, V[r].C = *reinterpret_cast<const float*>(lb + ad))         \
+  __syncthreads();
+      TCMI_PLANE(a, x)
+      TCMI_PLANE(a, y)
+      TCMI_PLANE(l, x)
+      TCMI_PLANE(l, y)
+#undef TCMI_PLANE
+#undef TCMI_MASKS
+#undef TCMI_WALK
+    }
+  }
+
+  {
+    const KInt rl = desc + pc_cur;
+    uint32_t rpm[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) rpm[j] = (uint32_t)rl[2 + j];
+    char* __restrict__ ba = reinterpret_cast<char*>(psi + wg_base);
+    char* __restrict__ bl = reinterpret_cast<char*>(lam + wg_base);
+    const TOFF toff = (TOFF)tphys * sizeof(v2f);
+#pragma unroll
+    for (int r = 0; r < NR; r += 2) {
+      const unsigned long long ro = (unsigned long long)reg_mask<R>(r, rpm) * sizeof(v2f);
+      v4f v, w;
+      v.xy = a[r];
+      v.zw = a[r + 1];
+      w.xy = l[r];
+      w.zw = l[r + 1];
+      *reinterpret_cast<v4f*>(ba + ro + toff) = v;
+      *reinterpret_cast<v4f*>(bl + ro + toff) = w;
+    }
+  }
+}
+
+// complex64 adjoint pass, (R, LT) = (4, 9).  Returns -1 when there is no second-generation variant.
+int run_adjoint2_c64(void* psi, void* lam, long long stride, int batch, int n, int R, int LT, const int* desc,
+                     const void* ctab, const void* ptab, long long ptab_stride, double* gout, long long gout_stride,
+                     int gcopies, long long gcopy_stride, hipStream_t st) {
+  if (!(R == 4 && LT == 9)) return -1;
+  constexpr int T = 13;
+  if (n < T) return -1;
+  const size_t lds = sizeof(float) << T;
+  auto kern = n <= 29 ? adjoint2_kernel<4, 9, uint32_t> : adjoint2_kernel<4, 9, unsigned long long>;
+  dim3 grid(1u << (n - T), (unsigned)batch, 1), block(512, 1, 1);
+  hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<v2f*>(psi), reinterpret_cast<v2f*>(lam), stride, desc,
+                     reinterpret_cast<const float*>(ctab), reinterpret_cast<const float*>(ptab), ptab_stride, gout,
+                     gout_stride, gcopies, gcopy_stride);
+  return hipGetLastError() == hipSuccess ? TCMI_OK : TCMI_ERR_HIP;
+}
+
+}  // namespace tcmi

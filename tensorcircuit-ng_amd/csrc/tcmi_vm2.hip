@@ -13,7 +13,7 @@
 //     compiler: the gate-kind dispatch is a scalar branch inside the asm statements (tied operands), and the
 //     per-op-type sections are skipped with independent one-hot flags the optimiser cannot merge into a switch.
 //
-// The kernel is launched by tcmi_run_pass (tcmi_vm.hip) for complex64 gate passes with R = 5 (n >= 13).
+// The kernel is launched by tcmi_run_pass (tcmi_vm.hip) for complex64 gate passes with R >= 4 (n >= 12).
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -406,6 +406,8 @@ static int launch_pass2(void* state, long long state_stride, int batch, int n, c
 int run_pass2_c64(void* state, long long state_stride, int batch, int n, int R, int LT, const int* desc,
                   const void* ctab, const void* ptab, long long ptab_stride, hipStream_t st) {
   if (R == 5 && LT == 8) return launch_pass2<5, 8>(state, state_stride, batch, n, desc, ctab, ptab, ptab_stride, st);
+  if (R == 4 && LT == 8) return launch_pass2<4, 8>(state, state_stride, batch, n, desc, ctab, ptab, ptab_stride, st);
+  if (R == 4 && LT == 9) return launch_pass2<4, 9>(state, state_stride, batch, n, desc, ctab, ptab, ptab_stride, st);
   if (R == 5 && LT == 9) return launch_pass2<5, 9>(state, state_stride, batch, n, desc, ctab, ptab, ptab_stride, st);
   return -1;
 }

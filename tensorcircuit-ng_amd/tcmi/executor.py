@@ -180,8 +180,8 @@ class CompiledCircuit:
         import torch
 
         if getattr(self, "_adj", None) is None:
-            cfg = pick_measure_variant(self.n_exec, self.dtypestr)
             gates = self._exec_gates
+            cfg = pick_adjoint_variant(self.n_exec, self.dtypestr, gates)
             ap = P.compile_adjoint_plan(gates, self.n_exec, cfg)
             dev = self.device
             self._adj = {
@@ -248,6 +248,18 @@ def pick_measure_variant(n_exec: int, dtypestr: str) -> P.PlanConfig:
         if R + LT <= n_exec:
             return P.PlanConfig(R=R, LT=LT, lowbits=min(5, R + LT), vec=2 if c64 else 1)
     raise ValueError("no measurement variant fits")
+
+
+def pick_adjoint_variant(n_exec: int, dtypestr: str, gates) -> P.PlanConfig:
+    """Tile of the adjoint sweep (two vectors live in registers).  complex64 circuits of one-qubit gates and
+    diagonals on >= 13 qubits run on the packed-f32 kernel (csrc/tcmi_adjoint2.hip: R = 4, 512 threads, 13 tile
+    bits); dense two-qubit gates and small circuits keep the first-generation kernel."""
+    import os
+
+    dense2 = any((not g.is_diag) and len(g.qubits) > 1 for g in gates)
+    if dtypestr == "complex64" and n_exec >= 13 and not dense2 and not os.environ.get("TCMI_VM1"):
+        return P.PlanConfig(R=4, LT=9, lowbits=5, vec=2)
+    return pick_measure_variant(n_exec, dtypestr)
 
 
 class CompiledMeasure:
