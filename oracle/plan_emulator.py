@@ -14,6 +14,7 @@ MAGIC = 0x54434D31
 HDR_WORDS = 24
 RR_WORDS = 50
 OP_G1, OP_G2, OP_DIAG, OP_G1M, OP_EXPECT, OP_DIAGC, OP_DIAGB = 1, 2, 3, 4, 5, 6, 7
+OP_DIAGF, OP_DIAGB2 = 8, 9
 R_MAX = 6
 CONST_FLAG = 1 << 30
 BK_TRIG, BK_COEF, BK_SELECT, BK_PHASE = 1, 2, 5, 6
@@ -202,6 +203,16 @@ def run_pass(state, desc, ctab, ptab_row, eout=None):
                 tb = np.asarray(ptab_row)[int(d[q + 1]): int(d[q + 1]) + 2 * NR]
                 regs = regs * (tb[0::2] + 1j * tb[1::2]).astype(regs.dtype)[None, None, :]
                 q += 2
+            elif op == OP_DIAGB2:
+                # factor = table[s1 + 2 s2] for register bit clear, its conjugate for bit set
+                j, m1, m2, slot = int(d[q + 1]), int(d[q + 2]), int(d[q + 3]), int(d[q + 4])
+                tidx = (wg_base[:, None] | tphys[None, :]).astype(np.uint64)
+                c = (_parity(tidx & np.uint64(m1)) + 2 * _parity(tidx & np.uint64(m2))).astype(np.int64)
+                tb = np.asarray(ptab_row)[slot: slot + 8]
+                e = (tb[0::2] + 1j * tb[1::2])[c]                      # [nwg, nth]
+                bit = ((rid >> j) & 1).astype(bool)
+                regs = regs * np.where(bit[None, None, :], np.conj(e)[:, :, None], e[:, :, None]).astype(regs.dtype)
+                q += 5
             elif op == OP_EXPECT:
                 nZ, nX = int(d[q + 1]), int(d[q + 2])
                 q += 3
@@ -302,6 +313,16 @@ def build_adjoint_table(ginfo, cpool, params, ptab_size):
     for rec in np.asarray(ginfo).reshape(-1, 8):
         kind, slot, pidx, dim, off = (int(x) for x in rec[:5])
         k, o = cpool[off], cpool[off + 1]
+        if kind == BK_PHASE:
+            r = int(rec[5])
+            phi = np.zeros(B)
+            for t in range(dim):
+                kt, ot, pt, rm = cpool[off + 4 * t: off + 4 * t + 4]
+                sgn = -1.0 if bin(r & int(rm)).count("1") & 1 else 1.0
+                phi += sgn * (kt * params[:, int(pt)] + ot)
+            ptab[:, slot] = np.cos(2 * np.pi * phi)
+            ptab[:, slot + 1] = np.sin(2 * np.pi * phi)
+            continue
         for b in range(B):
             a = k * params[b, pidx] + o
             if kind == BK_COEF:
@@ -425,6 +446,34 @@ def run_adjoint_pass(psi, lam, desc, ctab, ptab_row, gout):
                     if int(gs[e]) >= 0:
                         gout[int(gs[e])] += np.sum(sgn * w)
                 regs = regs * np.exp(-2j * np.pi * phi)[None]
+            elif op == OP_DIAGF:
+                cslot, nC, nB, nA = int(dsig[q + 1]), int(d[q + 2]), int(d[q + 3]), int(d[q + 4])
+                q += 5
+                w = np.imag(np.conj(regs[1]) * regs[0])  # [nwg, nth, NR]
+                for e in range(nC):
+                    rm, gs = int(d[q]), int(dsig[q + 1])
+                    q += 2
+                    if gs >= 0:
+                        z = 1 - 2 * _parity(rid.astype(np.uint64) & np.uint64(rm))
+                        gout[gs] += np.sum(w * z[None, None, :])
+                if cslot >= 0:
+                    tb = np.asarray(ptab_row)[cslot: cslot + 2 * NR]
+                    regs = regs * np.conj(tb[0::2] + 1j * tb[1::2])[None, None, None, :]
+                for e in range(nB):
+                    j, mask, slot, gs = int(d[q]), int(d[q + 1]), int(dsig[q + 2]), int(dsig[q + 3])
+                    q += 4
+                    sgn = (1 - 2 * _parity(tidx & np.uint64(mask)))[:, :, None] * (
+                        1 - 2 * ((rid >> j) & 1).astype(np.int64))[None, None, :]
+                    if gs >= 0:
+                        gout[gs] += np.sum(w * sgn)
+                    if slot >= 0:
+                        cs, sn = float(ptab_row[slot]), float(ptab_row[slot + 1])
+                        regs = regs * (cs - 1j * sn * sgn)[None]
+                for e in range(nA):
+                    mask, gs = int(d[q]), int(dsig[q + 1])
+                    q += 2
+                    if gs >= 0:
+                        gout[gs] += np.sum(w * (1 - 2 * _parity(tidx & np.uint64(mask)))[:, :, None])
             else:
                 raise ValueError(f"bad backward opcode {op}")
         assert q == pc + RR_WORDS + opwords

@@ -23,6 +23,7 @@ def mix(desc):
             elif op == P.OP_DIAG: m["DIAG"] += 1; q += 5 + int(w[q + 1]) + 2 * int(w[q + 2]) + int(w[q + 3])
             elif op == P.OP_DIAGC: m["DIAGC"] += 1; q += 2
             elif op == P.OP_DIAGB: m["DIAGB"] += 1; q += 4
+            elif op == P.OP_DIAGB2: m["DIAGB"] += 1; q += 5
             elif op == P.OP_G2: m["G2"] += 1; q += 4
         pc = q
     return m

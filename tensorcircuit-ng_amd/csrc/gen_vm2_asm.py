@@ -126,6 +126,21 @@ def gen_cmul8s():
     emit_named("vm2_cmul8s", args, lines, outs, ins, ["t0", "t1"], clobbers=())
 
 
+def gen_cmul8s_conj():
+    """a_k *= (c_k - i s_k), coefficient pairs in SGPRs (inverse of a DIAGC table, adjoint sweep)."""
+    seqs = []
+    for k in range(8):
+        T = f"%[t{k % 2}]"
+        seqs.append([mul_im(T, f"%[a{k}]", f"%[p{k}]", conj=True), fma_re(f"%[a{k}]", f"%[a{k}]", f"%[p{k}]", T)])
+    lines = []
+    for g in range(0, 8, 2):
+        lines += interleave(seqs[g:g + 2])
+    args = ", ".join(f"v2f& a{k}" for k in range(8)) + ", " + ", ".join(f"v2f p{k}" for k in range(8))
+    outs = [f'[a{k}] "+v"(a{k})' for k in range(8)] + ['[t0] "=&v"(t0)', '[t1] "=&v"(t1)']
+    ins = [f'[p{k}] "s"(p{k})' for k in range(8)]
+    emit_named("vm2_cmul8s_conj", args, lines, outs, ins, ["t0", "t1"], clobbers=())
+
+
 def gen_cmul8v():
     """a_k *= (c_k + i s_k), per-thread coefficient pairs in VGPRs (general DIAG op)."""
     seqs = []
@@ -286,4 +301,5 @@ if __name__ == "__main__":
     gen_grad4_gen()
     gen_cross8()
     gen_cmul8v_conj()
+    gen_cmul8s_conj()
     print("#endif")

@@ -488,6 +488,23 @@ __global__ void build_adjoint_kernel(const int* __restrict__ ginfo, int nrec, co
     out[0] = (F)(ang - rint(ang));
     return;
   }
+  if (kind == TCMI_BK_PHASE) {
+    // one entry of a phase table of OP_DIAGF (same record as the forward builder, tcmi_vm.hip)
+    const int r = rec[5];
+    const double* tp = cpool + off;
+    double phi = 0.0;
+    for (int t = 0; t < dim; ++t) {
+      const double th = (double)params[(long long)b * pstride + (int)tp[4 * t + 2]];
+      const double v = tp[4 * t] * th + tp[4 * t + 1];
+      phi += (__popc((unsigned)r & (unsigned)tp[4 * t + 3]) & 1) ? -v : v;
+    }
+    phi -= rint(phi);
+    double ps, pc;
+    sincospi(2.0 * phi, &ps, &pc);
+    out[0] = (F)pc;
+    out[1] = (F)ps;
+    return;
+  }
   double s, c;
   sincos(ang, &s, &c);
   const int nn = dim * dim;

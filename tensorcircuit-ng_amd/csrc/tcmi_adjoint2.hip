@@ -8,7 +8,7 @@
 // operands (tcmi_vm2_asm.inc), no register-array copies at control-flow merges, planar LDS exchange.
 //
 // Tile: R = 4 register bits, 512 threads (16 + 16 amplitude pairs per thread, 8 waves per workgroup, two
-// workgroups per CU = 4 waves per SIMD).  Handles one-qubit gate ops and phase-polynomial ops; plans with dense
+// workgroups per CU = 4 waves per SIMD).  Handles one-qubit gate ops and table-form diagonal flushes (OP_DIAGF); plans with dense
 // two-qubit gates stay on the first-generation kernel (the host checks, tcmi/executor.py).
 
 #include <hip/hip_runtime.h>
@@ -56,6 +56,17 @@ __device__ __forceinline__ void adj_apply(v2f (&a)[NR], int kf, v2f p0, v2f p1, 
   if (kf & 2) { TCMI_A8(vm2_gate8_real) }
   if (kf & 1) { TCMI_A8(vm2_gate8_gen) }
 #undef TCMI_A8
+}
+
+// a[r] *= (e.x + i e.y) for z_J(r) = +1, the conjugate for z_J(r) = -1
+template <int NR, int J>
+__device__ __forceinline__ void adj_diagb(v2f (&a)[NR], v2f e) {
+  constexpr int B = 1 << J;
+#pragma unroll
+  for (int g = 0; g < NR / 2; g += 4) {
+    const int r0 = ains0(g, J), r1 = ains0(g + 1, J), r2 = ains0(g + 2, J), r3 = ains0(g + 3, J);
+    vm2_cmul44v(a[r0], a[r1], a[r2], a[r3], a[r0 | B], a[r1 | B], a[r2 | B], a[r3 | B], e);
+  }
 }
 
 // gradient of the gate on register bit J: Re<lambda|K|psi> summed over this thread's pairs
@@ -176,17 +187,13 @@ __global__ __launch_bounds__(1 << LT, (1024 >> LT)) void adjoint2_kernel(v2f* __
         TCMI_BW(0) TCMI_BW(1) TCMI_BW(2) TCMI_BW(3)
 #undef TCMI_BW
       }
-      if (f & (1 << TCMI_OP_DIAG)) {
-        // {3, nA, nB, nC, base, maskA[nA], maskB[nB], jB[nB], rmaskC[nC], gsA[nA], gsB[nB], gsC[nC]}; the table
-        // holds the FORWARD coefficients (turns), the inverse phase is applied
-        const int nA = desc[q + 1], nB = desc[q + 2], nC = desc[q + 3];
-        const KPtr<float> cf = ptab + desc[q + 4];
-        const int q0 = q + 5;
-        const KInt mA = desc + q0, mB = desc + q0 + nA, jB = desc + q0 + nA + nB, mC = desc + q0 + nA + 2 * nB;
-        const KInt gA = mC + nC, gB = gA + nA, gC = gB + nB;
-        qn = q0 + 2 * nA + 3 * nB + 2 * nC;
+      if (f & (1 << TCMI_OP_DIAGF)) {
+        // {8, cslot, nC, nB, nA, C: (rmask, gslot)*, B: (j, mask, slot, gslot)*, A: (mask, gslot)*}
+        const int cslot = desc[q + 1], nC = desc[q + 2], nB = desc[q + 3], nA = desc[q + 4];
+        int qq = q + 5;
+        qn = qq + 2 * nC + 4 * nB + 2 * nA;
         const uint32_t tidx = wg_base | tphys;
-        // w[r] = Im(conj(lambda) psi): every term's gradient is a signed sum of w
+        // w[r] = Im(conj(lambda) psi): invariant under the phases applied here, every term's gradient is a signed sum of it
         float w[NR];
 #pragma unroll
         for (int h = 0; h < NR; h += 8) {
@@ -196,92 +203,80 @@ __global__ __launch_bounds__(1 << LT, (1024 >> LT)) void adjoint2_kernel(v2f* __
 #pragma unroll
           for (int i = 0; i < 8; ++i) w[h + i] = t[i].x - t[i].y;
         }
-        float w0 = 0.f;
-#pragma unroll
-        for (int r = 0; r < NR; ++r) w0 += w[r];
-        float wj[R];
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-          float s = 0.f;
-#pragma unroll
-          for (int r = 0; r < NR; ++r) s += ((r >> j) & 1) ? -w[r] : w[r];
-          wj[j] = s;
-        }
-        double phi = 0.0;
 #pragma unroll 1
-        for (int e = 0; e < nA; ++e) {
-          const bool neg = __popc(tidx & (uint32_t)mA[e]) & 1;
-          const double c = (double)cf[e];
-          phi += neg ? -c : c;
-          const int gs = gA[e];
+        for (int e = 0; e < nC; ++e, qq += 2) {
+          const int gs = desc[qq + 1];
           if (gs >= 0) {  // wave-uniform
-            const float v = wave_sum_uniform(neg ? -w0 : w0);
-            if (lane0) atomicAdd(gout + gs, (double)v);
+            const uint32_t rmask = (uint32_t)desc[qq];
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) s += (__popc((uint32_t)r & rmask) & 1) ? -w[r] : w[r];
+            s = wave_sum_uniform(s);
+            if (lane0) atomicAdd(gout + gs, (double)s);
           }
         }
-        double cj[R];
+        if (cslot >= 0) {
+          const KV2 tp = (KV2)(ptab + cslot);
+          v2f t[NR];
 #pragma unroll
-        for (int j = 0; j < R; ++j) cj[j] = 0.0;
-#pragma unroll 1
-        for (int e = 0; e < nB; ++e) {
-          const int jj = jB[e];
-          const bool neg = __popc(tidx & (uint32_t)mB[e]) & 1;
-          const double c = (double)cf[nA + e];
-          const double sgn = neg ? -c : c;
-          float wsel = 0.f;
+          for (int i = 0; i < NR; ++i) t[i] = tp[i];
+#pragma unroll
+          for (int h = 0; h < NR; h += 8) {
+            vm2_cmul8s_conj(a[h], a[h + 1], a[h + 2], a[h + 3], a[h + 4], a[h + 5], a[h + 6], a[h + 7], t[h], t[h + 1],
+                            t[h + 2], t[h + 3], t[h + 4], t[h + 5], t[h + 6], t[h + 7]);
+            vm2_cmul8s_conj(l[h], l[h + 1], l[h + 2], l[h + 3], l[h + 4], l[h + 5], l[h + 6], l[h + 7], t[h], t[h + 1],
+                            t[h + 2], t[h + 3], t[h + 4], t[h + 5], t[h + 6], t[h + 7]);
+          }
+        }
+        if (nB > 0 || nA > 0) {
+          float w0 = 0.f, wj[R];
+#pragma unroll
+          for (int r = 0; r < NR; ++r) w0 += w[r];
 #pragma unroll
           for (int j = 0; j < R; ++j) {
-            cj[j] += (j == jj) ? sgn : 0.0;
-            wsel = (j == jj) ? wj[j] : wsel;
-          }
-          const int gs = gB[e];
-          if (gs >= 0) {
-            const float v = wave_sum_uniform(neg ? -wsel : wsel);
-            if (lane0) atomicAdd(gout + gs, (double)v);
-          }
-        }
-        float ph[NR];
-        ph[0] = (float)(phi - rint(phi));
+            float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
-          const float c = (float)(cj[j] - rint(cj[j]));
-#pragma unroll
-          for (int r = 0; r < (1 << j); ++r) {
-            ph[r | (1 << j)] = ph[r] - c;
-            ph[r] += c;
+            for (int r = 0; r < NR; ++r) s += ((r >> j) & 1) ? -w[r] : w[r];
+            wj[j] = s;
           }
-        }
 #pragma unroll 1
-        for (int e = 0; e < nC; ++e) {
-          const uint32_t rmask = (uint32_t)mC[e];
-          const float c = cf[nA + nB + e];
-          float s = 0.f;
+          for (int e = 0; e < nB; ++e, qq += 4) {
+            const int jj = desc[qq], slot = desc[qq + 2], gs = desc[qq + 3];
+            const bool neg = __popc(tidx & (uint32_t)desc[qq + 1]) & 1;
+            if (gs >= 0) {
+              float ws = wj[0];
 #pragma unroll
-          for (int r = 0; r < NR; ++r) {
-            const bool neg = __popc((uint32_t)r & rmask) & 1;
-            ph[r] += neg ? -c : c;
-            s += neg ? -w[r] : w[r];
+              for (int j = 1; j < R; ++j) ws = (j == jj) ? wj[j] : ws;
+              ws = wave_sum_uniform(neg ? -ws : ws);
+              if (lane0) atomicAdd(gout + gs, (double)ws);
+            }
+            if (slot >= 0) {
+              const KPtr<float> tp = ptab + slot;
+              v2f ev;
+              ev.x = tp[0];
+              const float sn = tp[1];
+              ev.y = neg ? sn : -sn;  // the inverse phase: (cs - i ys) on z = +1
+              const int fj = aonehot(jj);
+#define TCMI_DB(J)                                                   \
+  if constexpr (R > J) {                                             \
+    if (fj & (1 << J)) {                                             \
+      adj_diagb<NR, J>(a, ev);                                       \
+      adj_diagb<NR, J>(l, ev);                                       \
+    }                                                                \
+  }
+              TCMI_DB(0) TCMI_DB(1) TCMI_DB(2) TCMI_DB(3)
+#undef TCMI_DB
+            }
           }
-          const int gs = gC[e];
-          if (gs >= 0) {
-            const float v = wave_sum_uniform(s);
-            if (lane0) atomicAdd(gout + gs, (double)v);
+#pragma unroll 1
+          for (int e = 0; e < nA; ++e, qq += 2) {
+            const int gs = desc[qq + 1];
+            if (gs >= 0) {
+              const bool neg = __popc(tidx & (uint32_t)desc[qq]) & 1;
+              const float v = wave_sum_uniform(neg ? -w0 : w0);
+              if (lane0) atomicAdd(gout + gs, (double)v);
+            }
           }
-        }
-#pragma unroll
-        for (int h = 0; h < NR; h += 8) {
-          v2f e8[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            float sn, cs;
-            sincos_turns<float>(ph[h + i], &sn, &cs);
-            e8[i].x = cs;
-            e8[i].y = sn;
-          }
-          vm2_cmul8v_conj(a[h], a[h + 1], a[h + 2], a[h + 3], a[h + 4], a[h + 5], a[h + 6], a[h + 7], e8[0], e8[1], e8[2],
-                          e8[3], e8[4], e8[5], e8[6], e8[7]);
-          vm2_cmul8v_conj(l[h], l[h + 1], l[h + 2], l[h + 3], l[h + 4], l[h + 5], l[h + 6], l[h + 7], e8[0], e8[1], e8[2],
-                          e8[3], e8[4], e8[5], e8[6], e8[7]);
         }
       }
       q = qn;

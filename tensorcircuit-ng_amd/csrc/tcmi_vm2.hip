@@ -225,6 +225,23 @@ __global__ __launch_bounds__(1 << LT, (1024 >> LT)) void pass2_kernel(v2f* __res
         TCMI_DB(0) TCMI_DB(1) TCMI_DB(2) TCMI_DB(3) TCMI_DB(4) TCMI_DB(5)
 #undef TCMI_DB
       }
+      if (f & (1 << TCMI_OP_DIAGB2)) {
+        // two sign functions on one register bit: factor = table[s1 + 2 s2] (4 builder-evaluated entries)
+        const int fj = onehot(desc[q + 1]);
+        const uint32_t m1 = (uint32_t)desc[q + 2], m2 = (uint32_t)desc[q + 3];
+        const KV2 tp = (KV2)(ptab + desc[q + 4]);
+        qn = q + 5;
+        const v2f t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
+        const uint32_t tidx = wg_base | tphys;
+        const bool s1 = __popc(tidx & m1) & 1, s2 = __popc(tidx & m2) & 1;
+        v2f e;
+        e.x = s2 ? (s1 ? t3.x : t2.x) : (s1 ? t1.x : t0.x);
+        e.y = s2 ? (s1 ? t3.y : t2.y) : (s1 ? t1.y : t0.y);
+#define TCMI_DB(J) \
+  if constexpr (R > J) { if (fj & (1 << J)) vm2_diagb<NR, J>(a, e); }
+        TCMI_DB(0) TCMI_DB(1) TCMI_DB(2) TCMI_DB(3) TCMI_DB(4) TCMI_DB(5)
+#undef TCMI_DB
+      }
       if (f & (1 << TCMI_OP_DIAG)) {
         // general phase polynomial (many thread x register terms): per-thread phases in turns, hardware sin / cos
         const int nA = desc[q + 1], nB = desc[q + 2], nC = desc[q + 3];

@@ -9,6 +9,7 @@ Python on every call, ``cons.py:1036,927``).
 """
 
 import hashlib
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -52,7 +53,9 @@ def pick_variant(n: int, dtypestr: str, opts: Optional[dict] = None) -> Tuple[in
         if R + LT <= n_exec:
             low = int(opts.get("lowbits", 5))
             low = max(1, min(low, R + LT))
-            return n_exec, P.PlanConfig(R=R, LT=LT, lowbits=low, vec=2 if c64 else 1)
+            # complex64 tiles with R >= 4 run on the packed-f32 kernel (csrc/tcmi_vm2.hip), which knows OP_DIAGB2
+            gen = 2 if (c64 and R >= 4 and not os.environ.get("TCMI_VM1")) else 1
+            return n_exec, P.PlanConfig(R=R, LT=LT, lowbits=low, vec=2 if c64 else 1, gen=gen)
     raise ValueError("no tile variant fits")
 
 
@@ -182,7 +185,7 @@ class CompiledCircuit:
         if getattr(self, "_adj", None) is None:
             gates = self._exec_gates
             cfg = pick_adjoint_variant(self.n_exec, self.dtypestr, gates)
-            ap = P.compile_adjoint_plan(gates, self.n_exec, cfg)
+            ap = P.compile_adjoint_plan(gates, self.n_exec, cfg, factorized=cfg.gen >= 2)
             dev = self.device
             self._adj = {
                 "plan": ap, "cfg": cfg,
@@ -254,11 +257,9 @@ def pick_adjoint_variant(n_exec: int, dtypestr: str, gates) -> P.PlanConfig:
     """Tile of the adjoint sweep (two vectors live in registers).  complex64 circuits of one-qubit gates and
     diagonals on >= 13 qubits run on the packed-f32 kernel (csrc/tcmi_adjoint2.hip: R = 4, 512 threads, 13 tile
     bits); dense two-qubit gates and small circuits keep the first-generation kernel."""
-    import os
-
     dense2 = any((not g.is_diag) and len(g.qubits) > 1 for g in gates)
     if dtypestr == "complex64" and n_exec >= 13 and not dense2 and not os.environ.get("TCMI_VM1"):
-        return P.PlanConfig(R=4, LT=9, lowbits=5, vec=2)
+        return P.PlanConfig(R=4, LT=9, lowbits=5, vec=2, gen=2)
     return pick_measure_variant(n_exec, dtypestr)
 
 
@@ -418,6 +419,9 @@ def vm_cost_us(plan: "P.CompiledPlan") -> float:
                 elif op == P.OP_DIAGB:
                     t += VM_COST["g1"]
                     q += 4
+                elif op == P.OP_DIAGB2:
+                    t += VM_COST["g1"]
+                    q += 5
                 else:
                     raise ValueError(op)
             pc = q

@@ -43,6 +43,8 @@ OP_G1M = 4
 OP_EXPECT = 5
 OP_DIAGB = 7   # one diagonal term on a register bit x thread bits: multiply by exp(+-i phi), sign per thread
 OP_DIAGC = 6   # diagonal terms on register bits only: multiply by a 2^R table of phase factors
+OP_DIAGB2 = 9  # two register-x-thread terms on the same register bit: {9, j, mask1, mask2, slot}, table of 4 factors (gen 2)
+OP_DIAGF = 8   # backward (adjoint sweep) flush of diagonal terms in table form: see encode_pass
 FLAG_NOSTORE = 1
 DIAG_CHUNK = 8
 MAX_DIAGB = 5  # more register-x-thread terms than this in one DIAG op: the per-thread sincos path is cheaper
@@ -271,6 +273,7 @@ class PlanConfig:
     LT: int = 8         # log2(threads per workgroup)
     lowbits: int = 5    # physical low bits always in the tile (coalescing run = 2^lowbits amps)
     vec: int = 2        # amplitudes per 16-byte global access (2 for complex64, 1 for complex128)
+    gen: int = 1        # kernel generation executing the plan: 2 = packed-f32 kernels (tcmi_vm2 / tcmi_adjoint2): extra ops
 
     @property
     def T(self):
@@ -419,6 +422,7 @@ class Tables:
     ginfo: List[List[int]] = field(default_factory=list)   # builder records
     cpool: List[float] = field(default_factory=list)       # builder constants (float64)
     _slot_cache: dict = field(default_factory=dict)
+    pending: list = field(default_factory=list)               # diagonal terms not emitted yet (lazy flush)
     gslot_param: List[int] = field(default_factory=list)     # adjoint: parameter index per slot
     gslot_factor: List[float] = field(default_factory=list)  # adjoint: d(theta)/d(slot value)
 
@@ -582,9 +586,18 @@ def _coef_slot(tables: Tables, gi: int, ti: int, t: DiagTerm):
 
 
 def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tables: Tables,
-                batch_diag: bool = True, backward: bool = False, phase_tables: bool = True) -> np.ndarray:
+                backward: bool = False, phase_tables: bool = True, final: bool = True,
+                factorized_bw: bool = False) -> np.ndarray:
     """``backward=True`` encodes an adjoint-sweep pass: ``gates`` is the reversed gate list, every op
-    carries U^dagger (+ K and a gradient slot for parametrised gates), see csrc/tcmi_vm.h."""
+    carries U^dagger (+ K and a gradient slot for parametrised gates), see csrc/tcmi_vm.h.
+
+    Diagonal gates are *lazy*: their terms go to ``tables.pending`` (which survives rounds and passes -- a phase
+    polynomial is a function of the global index, not of a layout) and a term is emitted only when a dense gate is
+    about to act on one of its qubits.  At that moment the qubit is a register bit, so every emitted term is of
+    the register-only (table) or register-x-thread (sign) form and no per-thread sin / cos is evaluated; all the
+    terms due before one group of one-qubit gates share a single table.  ``final`` (last pass of the plan) flushes
+    what is still pending at the end.  ``factorized_bw``: backward passes use OP_DIAGF (tables from the builder,
+    gradients per term) instead of the generic OP_DIAG -- only csrc/tcmi_adjoint2.hip executes it."""
     T, R, LT = cfg.T, cfg.R, cfg.LT
     assert R <= R_MAX and LT <= LT_MAX and T <= T_MAX
     words = [0] * HDR_WORDS
@@ -622,10 +635,8 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
         regphys = {pp.tile_bits[b]: j for j, b in enumerate(rd.reg_tb)}
         ops = []
         nops = 0
-        # consecutive diagonal gates are merged into one DIAG op; consecutive 1-qubit gates on
-        # distinct register bits into one G1M op (they commute)
-        pend_diag = []
-        pend_g1 = {}
+        pend_g1 = {}      # register bit -> gate id: one-qubit gates on distinct bits, emitted as one G1M op
+        pend_flush = []   # diagonal terms due before that group
 
         def flush_g1():
             nonlocal nops
@@ -653,47 +664,97 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
             nops += 1
             pend_g1.clear()
 
-        def flush_diag():
+        def phase_terms(ts):
+            """Builder constants of one table entry: {k, o, param index, register mask} per term (in turns)."""
+            off = len(tables.cpool)
+            for rm, t in ts:
+                if t.param is None:
+                    tables.cpool += [0.0, t.const / TWO_PI, 0.0, float(rm)]
+                else:
+                    tables.cpool += [t.param.scale / TWO_PI, (t.const + t.param.offset) / TWO_PI,
+                                     float(t.param.index), float(rm)]
+            return off
+
+        def emit_diag(terms):
+            """Emit the diagonal terms ``terms`` (DiagTerm list) at the current point of this round."""
             nonlocal nops
-            if not pend_diag:
+            if not terms:
                 return
             A_, B_, C_ = [], [], []
-            for gi in pend_diag:
-                for ti, t in enumerate(gates[gi].diag):
-                    pbits = [n - 1 - q for q in t.qubits]
-                    rbits = [regphys[p] for p in pbits if p in regphys]
-                    nmask = 0
-                    for p in pbits:
-                        if p not in regphys:
-                            nmask |= 1 << p
-                    if len(rbits) == 0:
-                        A_.append((nmask, t))
-                    elif len(rbits) == 1:
-                        B_.append((rbits[0], nmask, t))
-                    elif nmask == 0:
-                        rm = 0
-                        for j in rbits:
-                            rm |= 1 << j
-                        C_.append((rm, t))
-                    else:
-                        raise NotImplementedError(
-                            "diagonal term with >=2 register bits and non-register bits"
-                        )
-            if not backward and not A_ and len(B_) <= MAX_DIAGB and phase_tables:
+            for t in terms:
+                pbits = [n - 1 - q for q in t.qubits]
+                rbits = [regphys[p] for p in pbits if p in regphys]
+                nmask = 0
+                for p in pbits:
+                    if p not in regphys:
+                        nmask |= 1 << p
+                if len(rbits) == 0:
+                    A_.append((nmask, t))
+                elif len(rbits) == 1:
+                    B_.append((rbits[0], nmask, t))
+                elif nmask == 0:
+                    rm = 0
+                    for j in rbits:
+                        rm |= 1 << j
+                    C_.append((rm, t))
+                else:
+                    raise NotImplementedError(
+                        "diagonal term with >=2 register bits and non-register bits"
+                    )
+            # register-x-thread terms with the same sign function share one phase factor
+            bgroups = {}
+            for j, nmask, t in B_:
+                bgroups.setdefault((j, nmask), []).append(t)
+
+            def gslot(t):
+                # d(phase)/d(theta) = scale * s_t(idx); dL/dtheta = -scale * sum s_t Im(conj(lambda) psi)
+                return tables.grad_slot(t.param.index, -t.param.scale) if t.param is not None else -1
+
+            if backward and factorized_bw:
+                # {8, cslot (-1: none), nC, nB, nA, C: (rmask, gslot)*, B: (j, mask, slot (-1: already applied), gslot)*,
+                #  A: (mask, gslot)*}: tables hold the FORWARD phase factors, the kernel applies the conjugate;
+                #  A terms (no register bit: only the final flush has them) contribute gradients only.
+                cslot = -1
+                if C_:
+                    NR = 1 << R
+                    cslot = tables.alloc(2 * NR)
+                    off = phase_terms(C_)
+                    for r in range(NR):
+                        tables.ginfo.append([BK_PHASE, cslot + 2 * r, 0, len(C_), off, r, 0, 0])
+                body = []
+                for rm, t in C_:
+                    body += [rm, gslot(t)]
+                nB = 0
+                for (j, nmask), ts in bgroups.items():
+                    slot = tables.alloc(2)
+                    off = phase_terms([(0, t) for t in ts])
+                    tables.ginfo.append([BK_PHASE, slot, 0, len(ts), off, 0, 0, 0])
+                    for i_, t in enumerate(ts):
+                        body += [j, nmask, slot if i_ == 0 else -1, gslot(t)]
+                        nB += 1
+                for nmask, t in A_:
+                    body += [nmask, gslot(t)]
+                ops.extend([OP_DIAGF, cslot, len(C_), nB, len(A_)] + body)
+                nops += 1
+                return
+            # gen-2 kernels pair the sign functions that share a register bit (a chain qubit has two neighbours)
+            bops = []
+            if cfg.gen >= 2:
+                byj = {}
+                for (j, nmask), ts in bgroups.items():
+                    byj.setdefault(j, []).append((nmask, ts))
+                for j, lst in byj.items():
+                    for i_ in range(0, len(lst) - 1, 2):
+                        bops.append((j, lst[i_], lst[i_ + 1]))
+                    if len(lst) % 2:
+                        bops.append(((j, lst[-1][0]), lst[-1][1]))
+            else:
+                bops = [((j, nmask), ts) for (j, nmask), ts in bgroups.items()]
+            if not backward and not A_ and len(bops) <= MAX_DIAGB and phase_tables:
                 # No per-thread sincos: the builder evaluates every phase factor once, in float64.
                 # Terms on register bits only -> one table of 2^R factors, the same for all threads
-                # (DIAGC); a term on one register bit and thread bits -> exp(+-i phi) with the sign
+                # (DIAGC); terms on one register bit and thread bits -> exp(+-i phi) with the sign
                 # z_j(r) * parity(thread & mask) (DIAGB).  4 lane-instructions per amplitude each.
-                def phase_terms(ts):
-                    off = len(tables.cpool)
-                    for rm, t in ts:
-                        if t.param is None:
-                            tables.cpool += [0.0, t.const / TWO_PI, 0.0, float(rm)]
-                        else:
-                            tables.cpool += [t.param.scale / TWO_PI, (t.const + t.param.offset) / TWO_PI,
-                                             float(t.param.index), float(rm)]
-                    return off
-
                 if C_:
                     NR = 1 << R
                     base = tables.alloc(2 * NR)
@@ -702,23 +763,33 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
                         tables.ginfo.append([BK_PHASE, base + 2 * r, 0, len(C_), off, r, 0, 0])
                     ops.extend([OP_DIAGC, base])
                     nops += 1
-                for j, nmask, t in B_:
-                    base = tables.alloc(2)
-                    off = phase_terms([(0, t)])
-                    tables.ginfo.append([BK_PHASE, base, 0, 1, off, 0, 0, 0])
-                    ops.extend([OP_DIAGB, j, nmask, base])
+                for it in bops:
+                    if len(it) == 2:
+                        (j, nmask), ts = it[0], it[1]
+                        base = tables.alloc(2)
+                        off = phase_terms([(0, t) for t in ts])
+                        tables.ginfo.append([BK_PHASE, base, 0, len(ts), off, 0, 0, 0])
+                        ops.extend([OP_DIAGB, j, nmask, base])
+                    else:
+                        # two sign functions on one register bit: factor = table[s1 + 2 s2], entry c holds
+                        # exp(i(+-phi1 +- phi2)) with the signs of the bits of c (BK_PHASE: "register mask" = 1 << group)
+                        j, (m1, ts1), (m2, ts2) = it
+                        base = tables.alloc(8)
+                        off = phase_terms([(1, t) for t in ts1] + [(2, t) for t in ts2])
+                        for c_ in range(4):
+                            tables.ginfo.append([BK_PHASE, base + 2 * c_, 0, len(ts1) + len(ts2), off, c_, 0, 0])
+                        ops.extend([OP_DIAGB2, j, m1, m2, base])
                     nops += 1
-                pend_diag.clear()
                 return
-            # coefficients live contiguously in the per-batch table (bulk scalar loads), padded
+            # generic form: coefficients live contiguously in the per-batch table (bulk scalar loads), padded
             # to a multiple of DIAG_CHUNK with zero terms
             padA = (-len(A_)) % DIAG_CHUNK
             padB = (-len(B_)) % DIAG_CHUNK
             nA, nB, nC = len(A_) + padA, len(B_) + padB, len(C_)
             base = tables.alloc(nA + nB + nC)
             zero = DiagTerm((), 0.0, None)
-            terms = [t for _, t in A_] + [zero] * padA + [t for _, _, t in B_] + [zero] * padB + [t for _, t in C_]
-            for k_, t in enumerate(terms):
+            tl = [t for _, t in A_] + [zero] * padA + [t for _, _, t in B_] + [zero] * padB + [t for _, t in C_]
+            for k_, t in enumerate(tl):
                 _coef_record(tables, base + k_, t)
             ops.extend([OP_DIAG, nA, nB, nC, base])
             ops.extend([m for m, _ in A_] + [0] * padA)
@@ -726,31 +797,42 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
             ops.extend([j for j, _, _ in B_] + [0] * padB)
             ops.extend([m for m, _ in C_])
             if backward:
-                # d(phase)/d(theta) = scale * s_t(idx); dL/dtheta = -scale * sum s_t Im(conj(lambda) psi)
-                ops.extend([
-                    tables.grad_slot(t.param.index, -t.param.scale) if t.param is not None else -1
-                    for t in terms
-                ])
+                ops.extend([gslot(t) for t in tl])
             nops += 1
-            pend_diag.clear()
+
+        def flush_group():
+            emit_diag(pend_flush)
+            pend_flush.clear()
+            flush_g1()
+
+        def take_pending(qubits):
+            """Remove and return the pending terms that touch one of ``qubits``."""
+            qs = set(qubits)
+            hit = [t for t in tables.pending if qs & set(t.qubits)]
+            if hit:
+                tables.pending = [t for t in tables.pending if not (qs & set(t.qubits))]
+            return hit
 
         for gi in rd.gates:
             g = gates[gi]
             if g.is_diag:
-                flush_g1()
-                pend_diag.append(gi)
-                if not batch_diag:
-                    flush_diag()
+                tables.pending.extend(g.diag)
                 continue
-            flush_diag()
             tbs = [tb_of_phys[n - 1 - q] for q in g.qubits]
             js = [reg_of_tb[b] for b in tbs]
             if len(js) == 1:
-                if js[0] in pend_g1:
-                    flush_g1()
+                due = take_pending(g.qubits)
+                group_qubits = set()
+                for gj in pend_g1.values():
+                    group_qubits |= set(gates[gj].qubits)
+                # a due term that also touches a qubit of the open group comes AFTER that group's gate
+                if js[0] in pend_g1 or any(group_qubits & set(t.qubits) for t in due):
+                    flush_group()
+                pend_flush.extend(due)
                 pend_g1[js[0]] = gi
             elif len(js) == 2:
-                flush_g1()
+                flush_group()
+                emit_diag(take_pending(g.qubits))
                 swap = js[0] > js[1]
                 ja, jb = (js[1], js[0]) if swap else (js[0], js[1])
                 if not backward:
@@ -758,17 +840,19 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
                 else:
                     uslot = tables.alloc(32)
                     _matrix_record(tables, uslot, g, BK_UDAG, swap)
-                    kslot, gslot = -1, 0
+                    kslot, gslot_ = -1, 0
                     if g.param is not None:
                         kslot = tables.alloc(32)
                         _matrix_record(tables, kslot, g, BK_KMAT, swap)
-                        gslot = tables.grad_slot(g.param.index, 1.0)
-                    ops.extend([OP_G2, ja | (g2_kind(g, swap) << 8), jb, uslot, kslot, gslot])
+                        gslot_ = tables.grad_slot(g.param.index, 1.0)
+                    ops.extend([OP_G2, ja | (g2_kind(g, swap) << 8), jb, uslot, kslot, gslot_])
                 nops += 1
             else:
                 raise NotImplementedError
-        flush_g1()
-        flush_diag()
+        flush_group()
+        if final and k == nr - 1 and tables.pending:
+            emit_diag(tables.pending)
+            tables.pending = []
         rr[0] = nops
         rr[1] = len(ops)
         words += rr + ops
@@ -804,7 +888,7 @@ def compile_plan(gates: List[GateRec], n: int, cfg: PlanConfig, nparams: int = 0
     passes = schedule(gates, n, cfg)
     tables = Tables()
     tables.ctab += [0.0] * 8  # dummy matrix for the unused slots of G1M ops
-    descs = [encode_pass(gates, n, cfg, pp, tables) for pp in passes]
+    descs = [encode_pass(gates, n, cfg, pp, tables, final=(i == len(passes) - 1)) for i, pp in enumerate(passes)]
     ginfo = np.array(tables.ginfo, dtype=np.int32).reshape(-1, 8)
     return CompiledPlan(
         n=n, cfg=cfg, passes=passes, descs=descs,
@@ -930,15 +1014,17 @@ class AdjointPlan:
     gslot_factor: np.ndarray  # float64 [nslots]
 
 
-def compile_adjoint_plan(gates: List[GateRec], n: int, cfg: PlanConfig) -> AdjointPlan:
+def compile_adjoint_plan(gates: List[GateRec], n: int, cfg: PlanConfig, factorized: bool = False) -> AdjointPlan:
     """Plan of the reversed circuit: gates in reverse order, each applied as U^dagger to both psi and
     the cotangent lambda, with one gradient slot per parametrised gate / diagonal term.  Valid for
-    unitary gates (psi is un-computed, not stored)."""
+    unitary gates (psi is un-computed, not stored).  ``factorized``: diagonal terms as OP_DIAGF (the
+    packed-f32 kernel csrc/tcmi_adjoint2.hip) instead of the generic OP_DIAG."""
     rev = list(reversed(gates))
     passes = schedule(rev, n, cfg)
     tables = Tables()
     tables.ctab += [0.0] * 8
-    descs = [encode_pass(rev, n, cfg, pp, tables, backward=True) for pp in passes]
+    descs = [encode_pass(rev, n, cfg, pp, tables, backward=True, final=(i == len(passes) - 1), factorized_bw=factorized)
+             for i, pp in enumerate(passes)]
     return AdjointPlan(
         n=n, cfg=cfg, passes=passes, descs=descs, ctab=np.array(tables.ctab, dtype=np.float64),
         ptab_size=tables.ptab_size, ginfo=np.array(tables.ginfo, dtype=np.int32).reshape(-1, 8),
