@@ -253,6 +253,76 @@ def _scan(gates, order, qbits_of, res_of, capacity, forced, allowed):
     return S, chosen
 
 
+def _scan_fixed(gates, order, qmask, rmask, S, count_only=False):
+    """Gates of ``order`` (program order) executable with the resource bits ``S`` (bit mask): a dense gate runs if
+    its resource bits are in S and no earlier gate on its qubits was left behind; diagonal gates need no resources.
+    ``qmask[gi]`` = ordering bits of the gate, ``rmask[gi]`` = resource bits it needs (0 for diagonal gates).
+    ``count_only``: return the weighted number of dense gates only (and stop once every bit of S is blocked)."""
+    blocked_all = 0
+    blocked_dense = 0
+    chosen = []
+    cnt = 0
+    for gi in order:
+        qs = qmask[gi]
+        rs = rmask[gi]
+        if gates[gi].is_diag:
+            if qs & blocked_all:
+                blocked_dense |= qs
+            elif not count_only:
+                chosen.append(gi)
+            continue
+        if (qs & (blocked_all | blocked_dense)) or (rs & ~S):
+            blocked_all |= qs
+            if count_only and (S & ~blocked_all) == 0:
+                break
+            continue
+        if count_only:
+            cnt += 1 if (rs & (rs - 1)) == 0 else 3
+        else:
+            chosen.append(gi)
+    return cnt if count_only else chosen
+
+
+def _grow(gates, order, qmask, rmask, capacity, forced, allowed, window=600):
+    """Choose up to ``capacity`` resource bits (bit mask, superset of ``forced``, subset of ``allowed``) greedily by
+    marginal gain: the bit -- or the pair of bits of one pending two-qubit gate -- that makes the most additional
+    dense gates executable per bit added.  Returns the mask (possibly with fewer than ``capacity`` bits when nothing
+    more helps)."""
+    S = forced
+    win = order[:window]
+    base = _scan_fixed(gates, win, qmask, rmask, S, True)
+    while bin(S).count("1") < capacity:
+        room = capacity - bin(S).count("1")
+        cands = set()
+        free = allowed & ~S
+        b = 0
+        f = free
+        while f:
+            if f & 1:
+                cands.add(1 << b)
+            f >>= 1
+            b += 1
+        if room >= 2:
+            for gi in win:
+                rs = rmask[gi]
+                if rs and (rs & (rs - 1)) and not (rs & ~allowed) and bin(rs & ~S).count("1") == 2:
+                    cands.add(rs & ~S)
+        best, best_key = 0, None
+        for c in cands:
+            gain = _scan_fixed(gates, win, qmask, rmask, S | c, True) - base
+            if gain <= 0:
+                continue
+            k = bin(c).count("1")
+            key = (gain / k, -k, -c)
+            if best_key is None or key > best_key:
+                best, best_key = c, key
+        if not best:
+            break
+        S |= best
+        base = _scan_fixed(gates, win, qmask, rmask, S, True)
+    return S
+
+
 @dataclass
 class Round:
     reg_tb: List[int]  # tile-bit index of each register bit
@@ -298,8 +368,24 @@ def schedule(gates, n: int, cfg: PlanConfig, independent: bool = False) -> List[
     pending = list(range(len(gates)))
     passes = []
     all_bits = set(range(n))
+    qmask = [0] * len(gates)
+    rmask = [0] * len(gates)
+    if not independent:
+        for gi, g in enumerate(gates):
+            for q in g.qubits:
+                qmask[gi] |= 1 << (n - 1 - q)
+            if not g.is_diag:
+                rmask[gi] = qmask[gi]
     while pending:
-        S, chosen = _scan(gates, pending, order_bits, phys_res, T, set(range(L)), all_bits)
+        if independent:
+            S, chosen = _scan(gates, pending, order_bits, phys_res, T, set(range(L)), all_bits)
+        else:
+            Sm = _grow(gates, pending, qmask, rmask, T, (1 << L) - 1, (1 << n) - 1)
+            chosen = _scan_fixed(gates, pending, qmask, rmask, Sm)
+            S = {b for b in range(n) if (Sm >> b) & 1}
+            if not any(not gates[gi].is_diag for gi in chosen) and any(not gates[gi].is_diag for gi in pending):
+                # nothing dense became executable (should not happen): first-fit fallback
+                S, chosen = _scan(gates, pending, order_bits, phys_res, T, set(range(L)), all_bits)
         if not chosen:
             raise RuntimeError("scheduler made no progress")
         # fill the tile with the lowest unused bits (better contiguity)
