@@ -47,6 +47,9 @@ def build_table(ginfo, cpool, params, ptab_size):
             ]
             c = [x[:, 0] + 1j * x[:, 1] for x in c]
             m = c[0][None, :] + np.cos(a)[:, None] * c[1][None, :] + np.sin(a)[:, None] * c[2][None, :]
+            if int(rec[5]):
+                ptab[:, slot: slot + 8] = _shear_params(m, int(rec[5]))
+                continue
             ptab[:, slot: slot + 2 * nn: 2] = m.real
             ptab[:, slot + 1: slot + 2 * nn: 2] = m.imag
         elif kind == BK_COEF:
@@ -60,6 +63,34 @@ def build_table(ginfo, cpool, params, ptab_size):
         else:
             raise ValueError(kind)
     return ptab
+
+
+def _shear_params(m, flavor):
+    """{u, v, sign, 0...} of the three-shear form of the rotation matrices m [B, 4] (row-major 2x2), as the builder
+    kernels write them: sign * m = S(u) L(v) S(u) on (x, y) (flavor 1) or on (x, i y) (flavor 2)."""
+    m = np.asarray(m).reshape(-1, 4)
+    out = np.zeros((m.shape[0], 8))
+    a = m[:, 0].real
+    c = m[:, 2].real if flavor == 1 else m[:, 2].imag
+    sg = np.where(a < 0, -1.0, 1.0)
+    a, c = a * sg, c * sg
+    safe = np.abs(c) > 1e-30
+    num = (a - 1.0) if flavor == 1 else (1.0 - a)
+    out[:, 0] = np.where(safe, num / np.where(safe, c, 1.0), 0.0)
+    out[:, 1] = c
+    out[:, 2] = sg
+    return out
+
+
+def _apply_shear(regs, r0, r1, u, v, flavor):
+    """x += u y', y' += v x, x += u y' with y' = y (flavor 1) or i y (flavor 2: y += v (i x))."""
+    f = 1.0 if flavor == 1 else 1j
+    x, y = regs[..., r0].copy(), regs[..., r1].copy()
+    x = x + u * f * y
+    y = y + v * f * x
+    x = x + u * f * y
+    regs[..., r0] = x
+    regs[..., r1] = y
 
 
 def _xor_masks(idx, masks):
@@ -105,6 +136,7 @@ def run_pass(state, desc, ctab, ptab_row, eout=None):
     pc = HDR_WORDS
     regs = None
     lds = None
+    pass_sign = 1.0   # product of the signs pulled out of the shear-form gates, applied before the store
     for k in range(nrounds):
         rr = d[pc: pc + RR_WORDS]
         nops, opwords = int(rr[0]), int(rr[1])
@@ -140,6 +172,13 @@ def run_pass(state, desc, ctab, ptab_row, eout=None):
                     todo = [(j, (mk >> (8 + 2 * j)) & 3, base_slot + 8 * j) for j in range(R) if (mk >> j) & 1]
                     q += 3
                 for j, kind, slot in todo:
+                    if op == OP_G1M and (mk >> (20 + j)) & 1:   # three-shear form {u, v, sign}
+                        tb8 = tab(slot, 8)
+                        bit = (rid >> j) & 1
+                        r0 = rid[bit == 0]
+                        _apply_shear(regs, r0, r0 | (1 << j), tb8[0], tb8[1], kind)
+                        pass_sign *= tb8[2]
+                        continue
                     m = tab(slot, 8)
                     m = (m[0::2] + 1j * m[1::2]).reshape(2, 2)
                     if kind == 1:      # the kernel reads only the real parts
@@ -240,7 +279,7 @@ def run_pass(state, desc, ctab, ptab_row, eout=None):
             lds = np.zeros((nwg, nth * NR), dtype=regs.dtype)
             lds[:, slot] = regs
         elif not (flags & 1):
-            state[gidx] = regs
+            state[gidx] = regs * pass_sign
     assert pc == d.size
     return state
 
@@ -334,6 +373,9 @@ def build_adjoint_table(ginfo, cpool, params, ptab_size):
             u = c[0] + np.cos(a) * c[1] + np.sin(a) * c[2]
             du = k * (-np.sin(a) * c[1] + np.cos(a) * c[2])
             m = u.conj().T if kind == BK_UDAG else du @ u.conj().T
+            if int(rec[5]) and kind == BK_UDAG:
+                ptab[b, slot: slot + 8] = _shear_params(m.reshape(1, 4), int(rec[5]))[0]
+                continue
             ptab[b, slot: slot + 2 * nn: 2] = m.real.reshape(-1)
             ptab[b, slot + 1: slot + 2 * nn: 2] = m.imag.reshape(-1)
     return ptab
@@ -387,7 +429,8 @@ def run_adjoint_pass(psi, lam, desc, ctab, ptab_row, gout):
                 for j in range(R):
                     if not (mk >> j) & 1:
                         continue
-                    ud = cm(ubase + 8 * j, 2)
+                    shear = (mk >> (20 + j)) & 1
+                    ud = None if shear else cm(ubase + 8 * j, 2)
                     r0 = rid[((rid >> j) & 1) == 0]
                     r1 = r0 | (1 << j)
                     if (kmask >> j) & 1:
@@ -395,6 +438,10 @@ def run_adjoint_pass(psi, lam, desc, ctab, ptab_row, gout):
                         a0, a1 = regs[0][..., r0], regs[0][..., r1]
                         t0, t1 = kk[0, 0] * a0 + kk[0, 1] * a1, kk[1, 0] * a0 + kk[1, 1] * a1
                         gout[int(dsig[q + 5 + j])] += np.sum(np.real(np.conj(regs[1][..., r0]) * t0 + np.conj(regs[1][..., r1]) * t1))
+                    if shear:  # the pulled-out sign is common to psi and lambda and cancels in every gradient
+                        tb8 = tab(ubase + 8 * j, 8)
+                        _apply_shear(regs, r0, r1, tb8[0], tb8[1], (mk >> (8 + 2 * j)) & 3)
+                        continue
                     x0, x1 = regs[..., r0].copy(), regs[..., r1].copy()
                     regs[..., r0] = ud[0, 0] * x0 + ud[0, 1] * x1
                     regs[..., r1] = ud[1, 0] * x0 + ud[1, 1] * x1

@@ -111,6 +111,30 @@ def emit_named(name, args, lines, outs, ins, tmps, clobbers=("scc",)):
     print("}\n")
 
 
+def gen_shear8(name, flavor):
+    """Eight amplitude pairs through a rotation in three-shear form, p = (u, v): x += u y', y' += v x, x += u y'
+    with y' = y (flavor "real") or i y (flavor "rx": y += v (i x)); 3 packed instructions per pair, no temporaries."""
+    f = fma_re if flavor == "real" else (lambda D, A, P, C, hi=False: fma_im(D, A, P, C, hi=hi))
+    seqs = []
+    for p_ in range(8):
+        X, Y = f"%[x{p_}]", f"%[y{p_}]"
+        seqs.append([f(X, Y, "%[p]", X, hi=False), f(Y, X, "%[p]", Y, hi=True), f(X, Y, "%[p]", X, hi=False)])
+    lines = interleave(seqs[:4]) + interleave(seqs[4:])
+    args = ", ".join(f"v2f& x{p_}, v2f& y{p_}" for p_ in range(8)) + ", v2f p"
+    outs = []
+    for p_ in range(8):
+        outs += [f'[x{p_}] "+v"(x{p_})', f'[y{p_}] "+v"(y{p_})']
+    emit_named(name, args, lines, outs, ['[p] "s"(p)'], [], clobbers=())
+
+
+def gen_scale8():
+    """a_k *= p.x (real scalar in an SGPR pair): the sign pulled out of the shear-form gates of a pass."""
+    lines = [mul_re(f"%[a{k}]", f"%[a{k}]", "%[p]") for k in range(8)]
+    args = ", ".join(f"v2f& a{k}" for k in range(8)) + ", v2f p"
+    outs = [f'[a{k}] "+v"(a{k})' for k in range(8)]
+    emit_named("vm2_scale8", args, lines, outs, ['[p] "s"(p)'], [], clobbers=())
+
+
 def gen_cmul8s():
     """a_k *= (c_k + i s_k), coefficient pairs in SGPRs (DIAGC: one table entry per register index)."""
     seqs = []
@@ -291,6 +315,9 @@ if __name__ == "__main__":
     gen_gate8("vm2_gate8_rx", g1_rx, 2)
     gen_gate8("vm2_gate8_real", g1_real, 2)
     gen_gate8("vm2_gate8_gen", g1_gen, 4)
+    gen_shear8("vm2_shear8_real", "real")
+    gen_shear8("vm2_shear8_rx", "rx")
+    gen_scale8()
     gen_cmul8s()
     gen_cmul8v()
     gen_cmul44v()

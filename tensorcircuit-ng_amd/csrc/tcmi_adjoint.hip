@@ -519,6 +519,21 @@ __global__ void build_adjoint_kernel(const int* __restrict__ ginfo, int nrec, co
     dr[i] = kap * (-s * c1[2 * i] + c * c2[2 * i]);
     di[i] = kap * (-s * c1[2 * i + 1] + c * c2[2 * i + 1]);
   }
+  if (kind == TCMI_BK_UDAG && rec[5]) {
+    // three-shear form of U^dagger (see build_kernel in tcmi_vm.hip): U^dagger[0][0] = conj(U[0][0]),
+    // U^dagger[1][0] = conj(U[0][1]); the sign is common to psi and lambda and is not needed
+    double a = ur[0];
+    double cc = (rec[5] == 1) ? ur[1] : -ui[1];
+    const double sg = a < 0 ? -1.0 : 1.0;
+    a *= sg;
+    cc *= sg;
+    const double num = (rec[5] == 1) ? (a - 1.0) : (1.0 - a);
+    out[0] = (F)(fabs(cc) > 1e-30 ? num / cc : 0.0);
+    out[1] = (F)cc;
+    out[2] = (F)sg;
+    for (int i = 3; i < 8; ++i) out[i] = (F)0;
+    return;
+  }
   if (kind == TCMI_BK_UDAG) {
     for (int r = 0; r < dim; ++r)
       for (int q = 0; q < dim; ++q) {

@@ -56,6 +56,13 @@ __device__ __forceinline__ void adj_apply(v2f (&a)[NR], int kf, v2f p0, v2f p1, 
   if (kf & 2) { TCMI_A8(vm2_gate8_real) }
   if (kf & 1) { TCMI_A8(vm2_gate8_gen) }
 #undef TCMI_A8
+#define TCMI_AS8(FN)                                                                                                  \
+  FN(a[r0], a[r0 | B], a[r1], a[r1 | B], a[r2], a[r2 | B], a[r3], a[r3 | B], a[r4], a[r4 | B], a[r5], a[r5 | B], a[r6], \
+     a[r6 | B], a[r7], a[r7 | B], p0);
+  // U^dagger as three shears, p0 = (u, v); its sign is common to psi and lambda and cancels in every gradient
+  if (kf & 32) { TCMI_AS8(vm2_shear8_real) }
+  if (kf & 64) { TCMI_AS8(vm2_shear8_rx) }
+#undef TCMI_AS8
 }
 
 // a[r] *= (e.x + i e.y) for z_J(r) = +1, the conjugate for z_J(r) = -1
@@ -173,8 +180,9 @@ __global__ __launch_bounds__(1 << LT, (1024 >> LT)) void adjoint2_kernel(v2f* __
         qn = q + 5 + R;
 #define TCMI_BW(J)                                                                                           \
   if constexpr (R > J) {                                                                                     \
-    const int kf = aonehot_if((mk >> J) & 1, (mk >> (8 + 2 * J)) & 3);                                       \
-    const int gf = ((kmask >> J) & 1) ? kf : 0;                                                              \
+    const int kd = (mk >> (8 + 2 * J)) & 3;                                                                  \
+    const int gf = ((kmask >> J) & 1) ? aonehot_if((mk >> J) & 1, kd) : 0; /* generator class: never shear */  \
+    const int kf = aonehot_if((mk >> J) & 1, kd + 4 * ((mk >> (20 + J)) & 1));                                \
     if (gf) {                                                                                                \
       float g = adj_grad<NR, J>(a, l, gf, kp[4 * J], kp[4 * J + 1], kp[4 * J + 2], kp[4 * J + 3]);           \
       g = wave_sum_uniform(g);                                                                               \

@@ -408,6 +408,21 @@ __global__ void build_kernel(const int* __restrict__ ginfo, int nrec, const doub
     const double* c0 = cpool + off + 2;
     const double* c1 = c0 + nn;
     const double* c2 = c1 + nn;
+    if (rec[5]) {
+      // three-shear form of a rotation (plan.g1_shear_flavor): sign * M = S(u) L(v) S(u) on (x, y) [flavor 1]
+      // or on (x, i y) [flavor 2]; out = {u, v, sign}
+      double a = c0[0] + c * c1[0] + s * c2[0];
+      double cc = (rec[5] == 1) ? (c0[4] + c * c1[4] + s * c2[4]) : (c0[5] + c * c1[5] + s * c2[5]);
+      const double sg = a < 0 ? -1.0 : 1.0;
+      a *= sg;
+      cc *= sg;
+      const double num = (rec[5] == 1) ? (a - 1.0) : (1.0 - a);
+      out[0] = (F)(fabs(cc) > 1e-30 ? num / cc : 0.0);
+      out[1] = (F)cc;
+      out[2] = (F)sg;
+      for (int i = 3; i < 8; ++i) out[i] = (F)0;
+      return;
+    }
     for (int i = 0; i < nn; ++i) out[i] = (F)(c0[i] + c * c1[i] + s * c2[i]);
   } else if (kind == TCMI_BK_PHASE) {
     // one entry of a DIAGC table: exp(2 pi i sum_t s_t(r) (k_t theta_t + o_t)), s_t = parity of r & mask_t

@@ -76,6 +76,17 @@ __device__ __forceinline__ void vm2_g1(v2f (&a)[NR], int kf, v2f p0, v2f p1, v2f
   if (kf & 2) { TCMI_G8(vm2_gate8_real) }
   if (kf & 1) { TCMI_G8(vm2_gate8_gen) }
 #undef TCMI_G8
+#define TCMI_S8(FN)                                                                                               \
+  _Pragma("unroll") for (int g = 0; g < NR / 2; g += 8) {                                                         \
+    const int r0 = ins0(g, J), r1 = ins0(g + 1, J), r2 = ins0(g + 2, J), r3 = ins0(g + 3, J);                     \
+    const int r4 = ins0(g + 4, J), r5 = ins0(g + 5, J), r6 = ins0(g + 6, J), r7 = ins0(g + 7, J);                 \
+    FN(a[r0], a[r0 | B], a[r1], a[r1 | B], a[r2], a[r2 | B], a[r3], a[r3 | B], a[r4], a[r4 | B], a[r5], a[r5 | B], \
+       a[r6], a[r6 | B], a[r7], a[r7 | B], p0);                                                                   \
+  }
+  // rotations in three-shear form, p0 = (u, v) (plan.g1_shear_flavor; the pulled-out sign is handled by the caller)
+  if (kf & 32) { TCMI_S8(vm2_shear8_real) }
+  if (kf & 64) { TCMI_S8(vm2_shear8_rx) }
+#undef TCMI_S8
 }
 
 template <int NR, int J>
@@ -173,6 +184,7 @@ __global__ __launch_bounds__(1 << LT, (1024 >> LT)) void pass2_kernel(v2f* __res
   }
 
   int pc_cur = pc;
+  uint32_t sgnbits = 0;  // sign pulled out of the shear-form gates of this pass (bit 31)
 #pragma unroll 1
   for (int k = 0;; ++k) {
     pc_cur = pc;
@@ -192,8 +204,13 @@ __global__ __launch_bounds__(1 << LT, (1024 >> LT)) void pass2_kernel(v2f* __res
 #pragma unroll
         for (int i = 0; i < 4 * R; ++i) cf[i] = mp[i];
         // structure class per register bit, one-hot and opaque: 1 general, 2 real, 4 rx-like, 0 = no gate on this bit
-#define TCMI_G1(J) \
-  if constexpr (R > J) vm2_g1<NR, J>(a, onehot_if((mk >> J) & 1, (mk >> (8 + 2 * J)) & 3), cf[4 * J], cf[4 * J + 1], cf[4 * J + 2], cf[4 * J + 3]);
+#define TCMI_G1(J)                                                                                                  \
+  if constexpr (R > J) {                                                                                             \
+    const int sh = (mk >> (20 + J)) & (mk >> J) & 1; /* three-shear form: classes 5 (real) and 6 (rx-like) */          \
+    vm2_g1<NR, J>(a, onehot_if((mk >> J) & 1, ((mk >> (8 + 2 * J)) & 3) + 4 * sh), cf[4 * J], cf[4 * J + 1], cf[4 * J + 2], \
+                  cf[4 * J + 3]);                                                                                    \
+    sgnbits ^= sh ? (__float_as_uint(cf[4 * J + 1].x) & 0x80000000u) : 0u;                                           \
+  }
         TCMI_G1(0) TCMI_G1(1) TCMI_G1(2) TCMI_G1(3) TCMI_G1(4) TCMI_G1(5)
 #undef TCMI_G1
       }
@@ -385,6 +402,13 @@ __global__ __launch_bounds__(1 << LT, (1024 >> LT)) void pass2_kernel(v2f* __res
     }
   }
 
+  if (sgnbits) {  // wave-uniform
+    v2f m1;
+    m1.x = -1.f;
+    m1.y = -1.f;
+#pragma unroll
+    for (int r = 0; r < NR; r += 8) vm2_scale8(a[r], a[r + 1], a[r + 2], a[r + 3], a[r + 4], a[r + 5], a[r + 6], a[r + 7], m1);
+  }
   {  // tile store, layout of the last round (constrained like round 0)
     const KInt rl = desc + pc_cur;
     uint32_t rpm[R];

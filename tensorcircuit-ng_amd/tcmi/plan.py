@@ -554,6 +554,35 @@ def g1_kind(g: GateRec, tol=1e-14) -> int:
     return 0
 
 
+_SHEAR_ANGLES = (0.3, 1.1, 2.9, 4.4, 5.7)
+SHEAR_SHIFT = 20  # bit 20 + j of a G1M mask word: the gate on register bit j is in three-shear form (gen-2 plans)
+
+
+def g1_shear_flavor(g: GateRec, tol=1e-12) -> int:
+    """1 / 2 if the one-qubit gate is, for every parameter value, a rotation of the real class (kind 1:
+    [[c, -s], [s, c]], ry-like) / of the rx-like class (kind 2: [[c, i b], [i b, c]] with c^2 + b^2 = 1), else 0.
+    Such a gate is applied as three in-place shears x += u y', y' += v x, x += u y' (3 instead of 4 packed
+    instructions per amplitude pair, |u| <= 1 after pulling out a global sign); csrc/tcmi_vm2.hip."""
+    if g.select is not None or len(g.qubits) != 1:
+        return 0
+    kind = g1_kind(g)
+    if kind not in (1, 2):
+        return 0
+    mats = [np.asarray(m, dtype=np.complex128) if m is not None else np.zeros((2, 2)) for m in (g.c0, g.c1, g.c2)]
+    angles = _SHEAR_ANGLES if g.param is not None else (0.0,)
+    for a_ in angles:
+        m = mats[0] + np.cos(a_) * mats[1] + np.sin(a_) * mats[2]
+        if kind == 1:
+            a, b, c, d = m[0, 0].real, m[0, 1].real, m[1, 0].real, m[1, 1].real
+            ok = abs(a * d - b * c - 1) < tol and abs(a - d) < tol and abs(b + c) < tol
+        else:
+            a, b, c, d = m[0, 0].real, m[0, 1].imag, m[1, 0].imag, m[1, 1].real
+            ok = abs(a * d + b * c - 1) < tol and abs(a - d) < tol and abs(b - c) < tol
+        if not ok:
+            return 0
+    return kind
+
+
 def _gate_slot(tables: Tables, gi: int, g: GateRec, swap: bool):
     """Table slot holding the dense matrix of gate g (optionally with its two qubits swapped)."""
     key = (gi, swap)
@@ -608,7 +637,7 @@ def g2_kind(g: GateRec, swap: bool, tol=1e-14) -> int:
     return 0
 
 
-def _matrix_record(tables: Tables, slot: int, g: GateRec, kind: int = BK_TRIG, swap: bool = False):
+def _matrix_record(tables: Tables, slot: int, g: GateRec, kind: int = BK_TRIG, swap: bool = False, shear: int = 0):
     """Builder record writing a dense matrix derived from g to ptab[slot ..]: the gate itself
     (BK_TRIG), its adjoint (BK_UDAG) or K = dU U^dagger (BK_KMAT).  Constant gates included, so that
     the matrices of one op can sit contiguously."""
@@ -642,7 +671,8 @@ def _matrix_record(tables: Tables, slot: int, g: GateRec, kind: int = BK_TRIG, s
     for m in mats:
         for z in sw(m).reshape(-1):
             tables.cpool += [float(z.real), float(z.imag)]
-    tables.ginfo.append([kind, slot, pidx, dim, off, 0, 0, 0])
+    # shear != 0: the builder writes {u, v, sign} of the three-shear form of the matrix instead of its entries
+    tables.ginfo.append([kind, slot, pidx, dim, off, shear, 0, 0])
 
 
 def _coef_record(tables: Tables, slot: int, t: DiagTerm):
@@ -735,10 +765,13 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
             for j, gi in pend_g1.items():
                 g = gates[gi]
                 mk |= (1 << j) | (g1_kind(g) << (8 + 2 * j))
+                sh = g1_shear_flavor(g) if cfg.gen >= 2 else 0
+                if sh:
+                    mk |= 1 << (SHEAR_SHIFT + j)
                 if not backward:
-                    _matrix_record(tables, base + 8 * j, g)
+                    _matrix_record(tables, base + 8 * j, g, shear=sh)
                 else:
-                    _matrix_record(tables, base + 8 * j, g, BK_UDAG)
+                    _matrix_record(tables, base + 8 * j, g, BK_UDAG, shear=sh)
                     if g.param is not None:
                         kmask |= 1 << j
                         _matrix_record(tables, kbase + 8 * j, g, BK_KMAT)
