@@ -42,27 +42,24 @@ __device__ __forceinline__ uint32_t ato_vgpr_v(uint32_t v) {
   return r;
 }
 
-// U^dagger on register bit J of one vector; kf = one-hot structure class (1 general, 2 real, 4 rx-like)
+// U^dagger on register bit J of one vector; kf = one-hot structure class (1 general, 2 real, 4 rx-like, 32 / 64 shear forms)
 template <int NR, int J>
 __device__ __forceinline__ void adj_apply(v2f (&a)[NR], int kf, v2f p0, v2f p1, v2f p2, v2f p3) {
   constexpr int B = 1 << J;
-  static_assert(NR == 16, "one asm statement covers the 8 pairs of a 16-amplitude register tile");
-  constexpr int r0 = ains0(0, J), r1 = ains0(1, J), r2 = ains0(2, J), r3 = ains0(3, J);
-  constexpr int r4 = ains0(4, J), r5 = ains0(5, J), r6 = ains0(6, J), r7 = ains0(7, J);
-#define TCMI_A8(FN)                                                                                                  \
-  FN(a[r0], a[r0 | B], a[r1], a[r1 | B], a[r2], a[r2 | B], a[r3], a[r3 | B], a[r4], a[r4 | B], a[r5], a[r5 | B], a[r6], \
-     a[r6 | B], a[r7], a[r7 | B], p0, p1, p2, p3);
-  if (kf & 4) { TCMI_A8(vm2_gate8_rx) }
-  if (kf & 2) { TCMI_A8(vm2_gate8_real) }
-  if (kf & 1) { TCMI_A8(vm2_gate8_gen) }
-#undef TCMI_A8
-#define TCMI_AS8(FN)                                                                                                  \
-  FN(a[r0], a[r0 | B], a[r1], a[r1 | B], a[r2], a[r2 | B], a[r3], a[r3 | B], a[r4], a[r4 | B], a[r5], a[r5 | B], a[r6], \
-     a[r6 | B], a[r7], a[r7 | B], p0);
+#define TCMI_A8(FN, ...)                                                                                              \
+  _Pragma("unroll") for (int g = 0; g < NR / 2; g += 8) {                                                             \
+    const int r0 = ains0(g, J), r1 = ains0(g + 1, J), r2 = ains0(g + 2, J), r3 = ains0(g + 3, J);                     \
+    const int r4 = ains0(g + 4, J), r5 = ains0(g + 5, J), r6 = ains0(g + 6, J), r7 = ains0(g + 7, J);                 \
+    FN(a[r0], a[r0 | B], a[r1], a[r1 | B], a[r2], a[r2 | B], a[r3], a[r3 | B], a[r4], a[r4 | B], a[r5], a[r5 | B],     \
+       a[r6], a[r6 | B], a[r7], a[r7 | B], __VA_ARGS__);                                                              \
+  }
+  if (kf & 4) { TCMI_A8(vm2_gate8_rx, p0, p1, p2, p3) }
+  if (kf & 2) { TCMI_A8(vm2_gate8_real, p0, p1, p2, p3) }
+  if (kf & 1) { TCMI_A8(vm2_gate8_gen, p0, p1, p2, p3) }
   // U^dagger as three shears, p0 = (u, v); its sign is common to psi and lambda and cancels in every gradient
-  if (kf & 32) { TCMI_AS8(vm2_shear8_real) }
-  if (kf & 64) { TCMI_AS8(vm2_shear8_rx) }
-#undef TCMI_AS8
+  if (kf & 32) { TCMI_A8(vm2_shear8_real, p0) }
+  if (kf & 64) { TCMI_A8(vm2_shear8_rx, p0) }
+#undef TCMI_A8
 }
 
 // a[r] *= (e.x + i e.y) for z_J(r) = +1, the conjugate for z_J(r) = -1
@@ -80,15 +77,17 @@ __device__ __forceinline__ void adj_diagb(v2f (&a)[NR], v2f e) {
 template <int NR, int J>
 __device__ __forceinline__ float adj_grad(const v2f (&a)[NR], const v2f (&l)[NR], int kf, v2f k0, v2f k1, v2f k2, v2f k3) {
   constexpr int B = 1 << J;
-  constexpr int r0 = ains0(0, J), r1 = ains0(1, J), r2 = ains0(2, J), r3 = ains0(3, J);
-  constexpr int r4 = ains0(4, J), r5 = ains0(5, J), r6 = ains0(6, J), r7 = ains0(7, J);
   v2f c0 = {0.f, 0.f}, c1 = {0.f, 0.f}, d0 = {0.f, 0.f}, d1 = {0.f, 0.f};
   float g = 0.f;
-#define TCMI_GR(FN, ...)                                                                                          \
-  FN(a[r0], a[r0 | B], a[r1], a[r1 | B], a[r2], a[r2 | B], a[r3], a[r3 | B], l[r0], l[r0 | B], l[r1], l[r1 | B],   \
-     l[r2], l[r2 | B], l[r3], l[r3 | B], ##__VA_ARGS__, c0, c1);                                                  \
-  FN(a[r4], a[r4 | B], a[r5], a[r5 | B], a[r6], a[r6 | B], a[r7], a[r7 | B], l[r4], l[r4 | B], l[r5], l[r5 | B],   \
-     l[r6], l[r6 | B], l[r7], l[r7 | B], ##__VA_ARGS__, d0, d1);
+#define TCMI_GR(FN, ...)                                                                                            \
+  _Pragma("unroll") for (int g8 = 0; g8 < NR / 2; g8 += 8) {                                                        \
+    const int r0 = ains0(g8, J), r1 = ains0(g8 + 1, J), r2 = ains0(g8 + 2, J), r3 = ains0(g8 + 3, J);               \
+    const int r4 = ains0(g8 + 4, J), r5 = ains0(g8 + 5, J), r6 = ains0(g8 + 6, J), r7 = ains0(g8 + 7, J);           \
+    FN(a[r0], a[r0 | B], a[r1], a[r1 | B], a[r2], a[r2 | B], a[r3], a[r3 | B], l[r0], l[r0 | B], l[r1], l[r1 | B],   \
+       l[r2], l[r2 | B], l[r3], l[r3 | B], ##__VA_ARGS__, c0, c1);                                                  \
+    FN(a[r4], a[r4 | B], a[r5], a[r5 | B], a[r6], a[r6 | B], a[r7], a[r7 | B], l[r4], l[r4 | B], l[r5], l[r5 | B],   \
+       l[r6], l[r6 | B], l[r7], l[r7 | B], ##__VA_ARGS__, d0, d1);                                                  \
+  }
   if (kf & 4) {  // K = i kappa X, kappa = Im K01
     TCMI_GR(vm2_grad4_rx)
     g = -k1.y * ((c0.x + c0.y) + (c1.x + c1.y) + (d0.x + d0.y) + (d1.x + d1.y));
@@ -106,7 +105,7 @@ __device__ __forceinline__ float adj_grad(const v2f (&a)[NR], const v2f (&l)[NR]
 }
 
 template <int R, int LT, typename TOFF>
-__global__ __launch_bounds__(1 << LT, (1024 >> LT)) void adjoint2_kernel(v2f* __restrict__ psi, v2f* __restrict__ lam,
+__global__ __launch_bounds__(1 << LT, (R >= 5 ? 512 : 1024) >> LT) void adjoint2_kernel(v2f* __restrict__ psi, v2f* __restrict__ lam,
                                                                        long long state_stride,
                                                                        const int* __restrict__ desc_g,
                                                                        const float* __restrict__ ctab_g,
@@ -192,7 +191,7 @@ __global__ __launch_bounds__(1 << LT, (1024 >> LT)) void adjoint2_kernel(v2f* __
     adj_apply<NR, J>(a, kf, u0, u1, u2, u3);                                                                 \
     adj_apply<NR, J>(l, kf, u0, u1, u2, u3);                                                                 \
   }
-        TCMI_BW(0) TCMI_BW(1) TCMI_BW(2) TCMI_BW(3)
+        TCMI_BW(0) TCMI_BW(1) TCMI_BW(2) TCMI_BW(3) TCMI_BW(4)
 #undef TCMI_BW
       }
       if (f & (1 << TCMI_OP_DIAGF)) {
@@ -272,7 +271,7 @@ __global__ __launch_bounds__(1 << LT, (1024 >> LT)) void adjoint2_kernel(v2f* __
       adj_diagb<NR, J>(l, ev);                                       \
     }                                                                \
   }
-              TCMI_DB(0) TCMI_DB(1) TCMI_DB(2) TCMI_DB(3)
+              TCMI_DB(0) TCMI_DB(1) TCMI_DB(2) TCMI_DB(3) TCMI_DB(4)
 #undef TCMI_DB
             }
           }
@@ -348,20 +347,30 @@ __global__ __launch_bounds__(1 << LT, (1024 >> LT)) void adjoint2_kernel(v2f* __
   }
 }
 
-// complex64 adjoint pass, (R, LT) = (4, 9).  Returns -1 when there is no second-generation variant.
-int run_adjoint2_c64(void* psi, void* lam, long long stride, int batch, int n, int R, int LT, const int* desc,
-                     const void* ctab, const void* ptab, long long ptab_stride, double* gout, long long gout_stride,
-                     int gcopies, long long gcopy_stride, hipStream_t st) {
-  if (!(R == 4 && LT == 9)) return -1;
-  constexpr int T = 13;
+template <int R, int LT>
+static int launch_adjoint2(void* psi, void* lam, long long stride, int batch, int n, const int* desc, const void* ctab,
+                           const void* ptab, long long ptab_stride, double* gout, long long gout_stride, int gcopies,
+                           long long gcopy_stride, hipStream_t st) {
+  constexpr int T = R + LT;
   if (n < T) return -1;
   const size_t lds = sizeof(float) << T;
-  auto kern = n <= 29 ? adjoint2_kernel<4, 9, uint32_t> : adjoint2_kernel<4, 9, unsigned long long>;
-  dim3 grid(1u << (n - T), (unsigned)batch, 1), block(512, 1, 1);
+  auto kern = n <= 29 ? adjoint2_kernel<R, LT, uint32_t> : adjoint2_kernel<R, LT, unsigned long long>;
+  dim3 grid(1u << (n - T), (unsigned)batch, 1), block(1u << LT, 1, 1);
   hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<v2f*>(psi), reinterpret_cast<v2f*>(lam), stride, desc,
                      reinterpret_cast<const float*>(ctab), reinterpret_cast<const float*>(ptab), ptab_stride, gout,
                      gout_stride, gcopies, gcopy_stride);
   return hipGetLastError() == hipSuccess ? TCMI_OK : TCMI_ERR_HIP;
+}
+
+// complex64 adjoint pass, (R, LT) = (4, 9) or (5, 8).  Returns -1 when there is no second-generation variant.
+int run_adjoint2_c64(void* psi, void* lam, long long stride, int batch, int n, int R, int LT, const int* desc,
+                     const void* ctab, const void* ptab, long long ptab_stride, double* gout, long long gout_stride,
+                     int gcopies, long long gcopy_stride, hipStream_t st) {
+  if (R == 4 && LT == 9)
+    return launch_adjoint2<4, 9>(psi, lam, stride, batch, n, desc, ctab, ptab, ptab_stride, gout, gout_stride, gcopies, gcopy_stride, st);
+  if (R == 5 && LT == 8)
+    return launch_adjoint2<5, 8>(psi, lam, stride, batch, n, desc, ctab, ptab, ptab_stride, gout, gout_stride, gcopies, gcopy_stride, st);
+  return -1;
 }
 
 }  // namespace tcmi

@@ -259,6 +259,8 @@ def pick_adjoint_variant(n_exec: int, dtypestr: str, gates) -> P.PlanConfig:
     bits); dense two-qubit gates and small circuits keep the first-generation kernel."""
     dense2 = any((not g.is_diag) and len(g.qubits) > 1 for g in gates)
     if dtypestr == "complex64" and n_exec >= 13 and not dense2 and not os.environ.get("TCMI_VM1"):
+        if os.environ.get("TCMI_ADJ_R5"):   # experiment switch: 32 + 32 amplitude pairs per thread, 2 waves per SIMD
+            return P.PlanConfig(R=5, LT=8, lowbits=5, vec=2, gen=2)
         return P.PlanConfig(R=4, LT=9, lowbits=5, vec=2, gen=2)
     return pick_measure_variant(n_exec, dtypestr)
 
