@@ -71,6 +71,78 @@ def cpu_baseline(n_sample, d, seed, budget_s=25.0):
     }
 
 
+def summarize_events(log):
+    """Per-tag totals of the executor's HIP-event log: {tag: {ms, launches, work, calls}} (call after a sync)."""
+    out = {}
+    for tag, e0, e1, launches, work in log:
+        d = out.setdefault(tag, {"ms": 0.0, "launches": 0, "work": 0.0, "calls": 0})
+        d["ms"] += e0.elapsed_time(e1)
+        d["launches"] += launches
+        d["work"] += work
+        d["calls"] += 1
+    return out
+
+
+def hbm_entry(kernel, ev, steps):
+    """Roofline entry of an HBM-bound kernel family from its event-log totals."""
+    if not ev or ev["launches"] == 0 or ev["ms"] <= 0:
+        return None
+    per_launch = ev["work"] / ev["launches"]
+    avg_us = ev["ms"] * 1e3 / ev["launches"]
+    gbs = per_launch / (avg_us * 1e-6) / 1e9
+    return {"kernel": kernel, "bound": "hbm", "launches_per_step": ev["launches"] / steps, "avg_launch_us": avg_us,
+            "algorithmic_bytes_per_launch": per_launch, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbs / HBM_PEAK_GBS}
+
+
+def traffic_probe(args, kernels, timeout_s=150):
+    """HBM traffic of the headline's dominant kernel from the PMC counters of THIS command: two child runs of a
+    short headline-only bench under rocprofv3 (--pmc FETCH_SIZE, then WRITE_SIZE: the two do not fit one pass;
+    the program itself after `--`), corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950
+    (counter unit KiB; FETCH_SIZE reports half of a wide coalesced streaming read): bytes = (2 FETCH + WRITE) * 1024.
+    Returns {kernel substring: bytes per launch} or {} when the profiler is unavailable."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if shutil.which("rocprofv3") is None:
+        return {}
+    res = {}
+    tmp = tempfile.mkdtemp(prefix="tcmi_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--probe-child", "--steps", "2", "--warmup", "1",
+             "--qubits", str(args.qubits), "--depth", str(args.depth), "--batch", str(args.batch),
+             "--contractor", args.contractor]
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            subprocess.run(["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--"] + child,
+                           cwd="/tmp", env=env, timeout=timeout_s, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                acc = {}
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] != ctr:
+                        continue
+                    for k in kernels:
+                        if k in r["Kernel_Name"]:
+                            a = acc.setdefault(k, [0.0, set()])
+                            a[0] += float(r["Counter_Value"])
+                            a[1].add(r["Dispatch_Id"])
+                for k, (v, ids) in acc.items():
+                    res.setdefault(k, {})[ctr] = v / max(1, len(ids))
+    except Exception:  # noqa: BLE001  (no profiler, timeout ...): traffic stays null
+        res = {}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {}
+    for k, v in res.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            out[k] = (2.0 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024.0
+    return out
+
+
 def vqe_leg(tc, torch, dist, args, rank, world, dev):
     """BASELINE config 3: one VQE step = vectorized value_and_grad of the 2n-1 term TFIM energy
     (reference benchmarks/scripts/vqe_tc.py:75-81,107-141) over a vmap batch of HEA-B circuits,
@@ -125,16 +197,47 @@ def vqe_leg(tc, torch, dist, args, rank, world, dev):
     step()  # staging: plan + adjoint plan + measurement plan compile, first launch
     sync()
     staging = time.perf_counter() - t0
+    from tcmi import executor as X
+
+    step()  # second call: the traced pipeline is validated against the plain path on the first two
+    sync()
+    X.EVENT_LOG = []
     t0 = time.perf_counter()
     for _ in range(args.vqe_steps):
         v, g, esum, gsum = step()
     sync()
     el = time.perf_counter() - t0
+    ev = summarize_events(X.EVENT_LOG)
+    X.EVENT_LOG = None
     if dist is not None:
         tt = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
+    # roofline of the step on the EXECUTED plan: every launch's algorithmic bytes / its HIP-event time
+    S = float(hi - lo) * (2 ** n) * 8          # one pass over this rank's batch of states, bytes
+    nf = ev.get("pass", {}).get("launches", 0) / max(1, args.vqe_steps) / max(1, -(-(hi - lo) // mb))
+    nb_ = ev.get("adjoint", {}).get("launches", 0) / max(1, args.vqe_steps) / max(1, -(-(hi - lo) // mb))
+    exec_bytes = sum(d["work"] for d in ev.values()) / max(1, args.vqe_steps)
+    step_s = el / args.vqe_steps
+    b_fwd = nf * 2.0 * S
+    roof = {
+        "forward_pass": hbm_entry("tcmi::pass2_kernel<5,8> (gate passes)", ev.get("pass"), args.vqe_steps),
+        "adjoint_pass": hbm_entry("tcmi::adjoint2_kernel<4,9> (reverse sweep on psi and lambda)", ev.get("adjoint"),
+                                  args.vqe_steps),
+        "measure_pass": hbm_entry("tcmi::pass_kernel<float,4,8,1> (fused Pauli-sum measurement)", ev.get("measure"),
+                                  args.vqe_steps),
+        "pauli_sum": hbm_entry("tcmi::pauli_sum_kernel (cotangent of the energy)", ev.get("pauli_sum"), args.vqe_steps),
+        "step": {
+            "bound": "hbm", "executed_bytes_per_step": exec_bytes, "achieved": exec_bytes / step_s / 1e9,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": exec_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+            "kernel_ms_per_step": sum(d["ms"] for d in ev.values()) / max(1, args.vqe_steps),
+            "forward_passes": nf, "adjoint_passes": nb_,
+            # the survey's cross-plan convention B_vg = 3 B_fwd + B_exp (reference-equivalent term loop) on this plan
+            "B_vg_convention_bytes": 3.0 * b_fwd + (2 * n - 1) * 2.0 * S,
+        },
+    }
     return {
+        "roofline": roof,
         "workload": f"HEA-B n={n} depth={d} TFIM value_and_grad (55-term style energy), vmap batch {Bg} "
                     f"(SURVEY 8d config 3), complex64",
         "ms_per_step": el / args.vqe_steps * 1e3,
@@ -173,15 +276,25 @@ def mps_leg(tc, torch, args):
     m.position(0)
     torch.cuda.synchronize()
     staging = time.perf_counter() - t0
+    from tcmi import executor as X
+
     times = []
+    X.EVENT_LOG = []
     for _ in range(max(1, args.mps_sweeps)):
         t0 = time.perf_counter()
         sweep()
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
+        log, X.EVENT_LOG = X.EVENT_LOG, None
         m.position(0)                    # back to the sweep's starting gauge: not part of the sweep, so it must
         torch.cuda.synchronize()         # not run into the next timed sweep either
+        X.EVENT_LOG = log
+    ev = summarize_events(X.EVENT_LOG)
+    X.EVENT_LOG = None
     t = sum(times) / len(times)
+    nbonds = (n - 1) * len(times)
+    split = {k.replace("mps_", "") + "_us_per_bond": v["ms"] * 1e3 / nbonds for k, v in ev.items()}
+    split["launches_per_bond"] = sum(v["launches"] for v in ev.values()) / nbonds
     if not all(bool(torch.isfinite(x.abs()).all()) for x in m.get_tensors()):
         raise FloatingPointError("non-finite MPS tensor after the TEBD sweeps")
     return {
@@ -190,6 +303,8 @@ def mps_leg(tc, torch, args):
         "sweeps_per_s": 1.0 / t, "us_per_bond": t / (n - 1) * 1e6, "sweeps": len(times),
         "max_bond": int(max(m.get_bond_dimensions())), "staging_s": round(staging, 3),
         "fidelity_estimate": float(m._fidelity),
+        # neither HBM- nor MFMA-bound: latency of dependent launches; kernel time per bond by kind
+        "roofline": {"bound": "latency", "kernel_us_per_bond": split},
     }
 
 
@@ -227,12 +342,16 @@ def rqc_leg(tc, torch, dist, args, rank, world):
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
+    from tcmi import tn as TN
+
+    TN.COUNTERS = TN.new_counters()
     t0 = time.perf_counter()
     v = dc.value(None, op=lambda x: x)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t = time.perf_counter() - t0
+    cnt, TN.COUNTERS = TN.COUNTERS, None
     tree = dc.tree
     flops = float(tree.total_flops())          # all slices (ContractionTree.total_flops includes nslices)
     steps, dep, _, _ = tree._symbolic_steps()
@@ -245,6 +364,17 @@ def rqc_leg(tc, torch, dist, args, rank, world):
         "contract_s": t, "tflops": flops / t / 1e12, "path_search_s": round(search_s, 2),
         "steps_per_slice": len(steps), "slice_invariant_steps": n_inv,
         "amplitude": [float(v.real), float(v.imag)],
+        # F_alg of the executed (sliced, slice-invariant parts once) steps over the wall time against the f32 MFMA
+        # peak; stand-alone permutes are traffic outside B_alg ("wasted")
+        "roofline": {
+            "bound": "mfma", "achieved": (cnt["gemm_flops"] + cnt["scattered_flops"]) / t / 1e12,
+            "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s",
+            "frac": (cnt["gemm_flops"] + cnt["scattered_flops"]) / t / 1e12 / MFMA_F32_PEAK_TFS,
+            "executed_flops_this_rank": cnt["gemm_flops"] + cnt["scattered_flops"],
+            "algorithmic_bytes": cnt["gemm_bytes"] + cnt["scattered_bytes"],
+            "wasted_traffic": cnt["permute_bytes"],
+            "launches": {k: int(cnt[k + "_launches"]) for k in ("gemm", "scattered", "permute")},
+        },
     }
 
 
@@ -277,6 +407,8 @@ def main():
     ap.add_argument("--rqc-depth", type=int, default=16, help="config 4 leg (32-qubit RQC amplitude): depth; 0 disables")
     ap.add_argument("--rqc-log2-target", type=int, default=27)
     ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph replay measurement")
+    ap.add_argument("--no-traffic-probe", action="store_true", help="skip the rocprofv3 PMC child runs (traffic = null)")
+    ap.add_argument("--probe-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--contractor", default="greedy",
                     help="greedy/auto: cost model picks the contraction order; plain: state-vector plan; cut: cut contraction")
     ap.add_argument("--lowbits", type=int, default=None)
@@ -284,12 +416,23 @@ def main():
     ap.add_argument("--LT", type=int, default=None)
     args = ap.parse_args()
 
-    import numpy as np
-    import torch
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.probe_child:
+        args.no_graph = args.no_cpu_baseline = args.no_traffic_probe = True
+        args.vqe_qubits = args.mps_qubits = args.rqc_depth = 0
+
+    # HBM traffic of the dominant kernel, measured by the PMC counters on this very command (child processes,
+    # started before this process touches the GPU)
+    KERNELS = ("cgemm_mfma_kernel", "pass2_kernel")
+    traffic = {}
+    if rank == 0 and world == 1 and not args.no_traffic_probe:
+        traffic = traffic_probe(args, KERNELS)
+
+    import numpy as np
+    import torch
+
     dist = None
     # TCMI_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL init, barriers, all-reduces) with a
     # world of one rank too (used to validate that path on a one-GPU box under torchrun)
@@ -304,6 +447,8 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
 
     import tcmi as tc
+    from tcmi import executor as X
+    from tcmi.executor import CutCircuit
 
     tc.set_backend("hip")
     tc.set_dtype("complex64")
@@ -313,41 +458,20 @@ def main():
 
     # synthetic parameters: SURVEY 8(d) config-2 generator, one independent row per batch element
     rng = np.random.default_rng(n + 1000 * rank)
-    params_np = rng.uniform(0, 2 * np.pi, [B, 2 * d, n]).astype(np.float32)
-    params = torch.from_numpy(params_np).to(dev)
+    params = torch.from_numpy(rng.uniform(0, 2 * np.pi, [B, 2 * d, n]).astype(np.float32)).to(dev)
 
-    # staging: record the structure once, compile the plan (cached by structure)
+    # the product call, through the reference's public API: K.jit(K.vmap(f)) with f = Circuit(...).wavefunction()
+    def wavefunction(p):
+        return build_circuit(tc, n, d, p).wavefunction()
+
+    fwd = tc.backend.jit(tc.backend.vmap(wavefunction))
     t0 = time.perf_counter()
-    c = build_circuit(tc, n, d, params[0])
-    cc = c._compiled()
+    state = fwd(params)               # staging: records the structure, compiles the plan (cached by structure)
+    torch.cuda.synchronize()
     staging_s = time.perf_counter() - t0
-    # parameter vector layout = recording order; build the [B, P] matrix with the same gather
-    idx = torch.stack(c._params)  # values of batch row 0 in recording order
-    flat0 = params[0].reshape(-1)
-    # map each recorded parameter to its position in the flat [2d*n] row (exact float match is
-    # ambiguous, so recompute the gather order structurally)
-    order = []
-    for j in range(d):
-        order += [(2 * j) * n + i for i in range(n - 1)]
-        order += [(2 * j + 1) * n + i for i in range(n)]
-    gather = torch.tensor(order, device=dev)
-    assert torch.equal(flat0[gather], idx)
-    pmat = params.reshape(B, -1)[:, gather].contiguous()
-
-    from tcmi.executor import CutCircuit
-
+    cc = build_circuit(tc, n, d, params[0])._compiled()
     is_cut = isinstance(cc, CutCircuit)
-    state = torch.empty(B, 2**cc.n_exec, dtype=torch.complex64, device=dev)
     st = cc.stats()
-
-    def step(ev=None):
-        # the product call: CompiledCircuit.state / CutCircuit.state on resident parameters, with HIP
-        # events around the dominant kernel's launches (pass kernels, or the join GEMM of a cut plan)
-        if is_cut:
-            cc.gemm_events = ev
-        else:
-            cc.pass_events = ev
-        cc.state(pmat, out=state)
 
     def sync():
         torch.cuda.synchronize()
@@ -355,22 +479,45 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    for _ in range(max(args.warmup, 2)):   # the first two calls validate the traced pipeline against the plain path
+        state = fwd(params)
     sync()
+    X.EVENT_LOG = []
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(events[k])
+        state = fwd(params)
     sync()
     elapsed = time.perf_counter() - t0
-    cc.gemm_events = cc.pass_events = None
+    ev = summarize_events(X.EVENT_LOG)
+    X.EVENT_LOG = None
+    traced = bool(getattr(fwd, "stats", {}).get("fast", 0) >= args.steps)
+    if args.probe_child:
+        return
+    # sanity: the state is normalised (cheap property check at full size)
+    nrm = float((state[0].abs() ** 2).sum().item())
+
+    # batch-1 latency through the same API (the metric is per batch element)
+    f1 = tc.backend.jit(wavefunction)
+    for _ in range(3):
+        f1(params[0])
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        f1(params[0])
+    torch.cuda.synchronize()
+    lat1 = (time.perf_counter() - t1) / args.steps
+
     # the same step replayed from a hipGraph (launch overhead removed); reported next to the eager figure
     graph_info = None
     if not args.no_graph:
         try:
             from tcmi.executor import GraphedState
 
+            order = []
+            for j in range(d):
+                order += [(2 * j) * n + i for i in range(n - 1)]
+                order += [(2 * j + 1) * n + i for i in range(n)]
+            pmat = params.reshape(B, -1)[:, torch.tensor(order, device=dev)].contiguous()
             gs = GraphedState(cc, B)
             for _ in range(args.warmup):
                 gs(pmat)
@@ -390,10 +537,6 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    kern_ms = sum(a.elapsed_time(b_) for a, b_ in events) / args.steps  # dominant-kernel time per step
-
-    # sanity: the state is normalised (cheap property check at full size)
-    nrm = float((state[0].abs() ** 2).sum().item())
     del state
     torch.cuda.empty_cache()
 
@@ -408,51 +551,45 @@ def main():
     if rank == 0:
         amps = float(world) * B * (2**n) * args.steps
         value = amps / elapsed
+        pass_entry = hbm_entry("tcmi::pass2_kernel<%d,%d> (tile-VM gate passes)" % (cc.cfg.R, cc.cfg.LT), ev.get("pass"),
+                               args.steps)
         if is_cut:
+            g = ev["gemm"]
             M, N, K = 2**cc.spec.n_left, 2 ** (n - cc.spec.n_left), cc.K
-            flops_per_launch = 8.0 * M * N * K * B          # complex MAC = 8 real flops
-            achieved = flops_per_launch / (kern_ms * 1e-3) / 1e12
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01l_traffic.json")
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath))["hbm_bytes_per_output_element"] * B * M * N
+            avg_us = g["ms"] * 1e3 / g["launches"]
+            alg = g["work"] / g["launches"]           # 8 real flops per complex MAC
+            exe = 0.75 * alg                          # the kernel issues Gauss's 3-product form: 6 flops per MAC
+            tr = traffic.get("cgemm_mfma_kernel")
             roof = {
                 "bound": "mfma", "kernel": "tcmi::cgemm_mfma_kernel<true> (cut-contraction join GEMM)",
-                "achieved": achieved, "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s",
-                "frac": achieved / MFMA_F32_PEAK_TFS, "traffic": traffic,
-                "traffic_source": "profiles/r01l_traffic.json (rocprofv3 PMC, scaled by output elements)" if traffic else None,
-                "launches_per_step": 1, "avg_launch_us": kern_ms * 1e3,
-                "algorithmic_flops_per_launch": flops_per_launch,
-                # the kernel uses Gauss's 3-product form: 6 real flops per complex MAC are issued to the MFMA
-                # pipe, so the algorithmic rate (8 per MAC) can touch or pass the f32 peak
-                "executed_flops_per_launch": 0.75 * flops_per_launch,
-                "executed_frac": 0.75 * achieved / MFMA_F32_PEAK_TFS,
+                # frac = EXECUTED flops (what the MFMA pipe does) against the dense f32 MFMA peak
+                "achieved": exe / (avg_us * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s",
+                "frac": exe / (avg_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFS,
+                "algorithmic_achieved": alg / (avg_us * 1e-6) / 1e12,
+                "algorithmic_frac": alg / (avg_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFS,
+                "traffic": tr, "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command, "
+                                                 "(2 FETCH + WRITE) KiB per launch" if tr else None,
+                "launches_per_step": g["launches"] / args.steps, "avg_launch_us": avg_us,
+                "timing": "HIP events on the launch stream around every launch of the timed steps",
+                "executed_flops_per_launch": exe, "algorithmic_flops_per_launch": alg,
                 "algorithmic_bytes_per_launch": 8.0 * B * (K * (M + N) + M * N),
                 "gemm_shape": {"M": M, "N": N, "K": K, "batch": B},
+                "half_circuit_passes": pass_entry,
             }
             plan_info = {"contraction": "cut", "bond": K, "n_left": cc.spec.n_left,
                          "half_circuit_passes": len(cc.left.descs) + len(cc.right.descs),
                          "staging_s": round(staging_s, 4)}
         else:
-            npass = len(cc.descs)
-            bytes_per_launch = 2.0 * B * (2**cc.n_exec) * 8  # read + write the batched state once
-            avg_launch_s = kern_ms * 1e-3 / npass
-            achieved = bytes_per_launch / avg_launch_s / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01b_traffic.json")
-            if os.path.exists(tpath):
-                tj = json.load(open(tpath))
-                traffic = tj["hbm_bytes_per_amplitude_per_launch"] * B * (2**cc.n_exec)
-            roof = {
-                "bound": "hbm", "kernel": "tcmi::pass_kernel<float,%d,%d,0>" % (cc.cfg.R, cc.cfg.LT),
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_source": "profiles/r01b_traffic.json (rocprofv3 PMC, scaled by batch)" if traffic else None,
-                "launches_per_step": npass, "avg_launch_us": avg_launch_s * 1e6,
-                "algorithmic_bytes_per_launch": bytes_per_launch,
-            }
-            plan_info = {"contraction": "state-vector", "passes": npass, "rounds": st["rounds"], "R": cc.cfg.R,
+            roof = dict(pass_entry)
+            tr = traffic.get("pass2_kernel")
+            roof["traffic"] = tr
+            roof["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command, "
+                                      "(2 FETCH + WRITE) KiB per launch") if tr else None
+            roof["timing"] = "HIP events on the launch stream around the pass launches of every timed step"
+            plan_info = {"contraction": "state-vector", "passes": len(cc.descs), "rounds": st["rounds"], "R": cc.cfg.R,
                          "LT": cc.cfg.LT, "lowbits": cc.cfg.lowbits, "staging_s": round(staging_s, 4)}
+            # cross-plan anchor of SURVEY 8d: the canonical gate-by-gate state-vector plan's bytes over this time
+            roof["B_sv_GBps"] = ((d - 1) * (n - 1) + 2) * 2.0 * (2**n) * 8 * B / (elapsed / args.steps) / 1e9
         out = {
             "metric": "amplitudes/sec",
             "value": value,
@@ -468,11 +605,12 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"HEA-B statevector contraction n={n} depth={d} complex64 (SURVEY 8d config 2), "
-                            f"vmap batch {B} per GPU",
+                            f"vmap batch {B} per GPU, timed through backend.jit(backend.vmap(wavefunction))",
                 "qubits": n, "depth": d, "batch_per_gpu": B, "parallelism": f"batch-shard x{world}",
-                "contractor": args.contractor, "plan": plan_info, "state_norm": nrm,
+                "contractor": args.contractor, "plan": plan_info, "state_norm": nrm, "host_side_traced": traced,
             },
             "roofline": roof,
+            "latency_batch1": {"ms_per_state": lat1 * 1e3, "amplitudes_per_s": (2**n) / lat1},
         }
         if graph_info is not None:
             out["hipgraph_replay"] = graph_info

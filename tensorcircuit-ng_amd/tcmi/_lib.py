@@ -5,6 +5,7 @@ There is no fallback: if the shared object is missing or a call fails, the produ
 """
 
 import ctypes
+import threading
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -107,7 +108,19 @@ class TraceAbort(Exception):
     that needs device results during the probe is not a traceable energy and keeps the plain path."""
 
 
-TRACING = [False]
+class _Tracing(threading.local):
+    """Per-thread probe flag (``TRACING[0]``): a probe in one thread must not abort device calls of another."""
+
+    flag = False
+
+    def __getitem__(self, i):
+        return self.flag
+
+    def __setitem__(self, i, v):
+        self.flag = bool(v)
+
+
+TRACING = _Tracing()
 
 
 def lib():

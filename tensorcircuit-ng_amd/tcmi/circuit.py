@@ -282,7 +282,12 @@ class Circuit:
     def wavefunction(self, form: str = "default") -> Tensor:
         """reference circuit.py:701-721."""
         from .expectation import _circuit_full_state
+        from . import _lib
 
+        if _lib.TRACING[0]:   # backend.jit is probing the function (tcmi/jit.py): nothing is evaluated
+            from .jit import TracedState
+
+            return TracedState(self, form)
         full = _circuit_full_state(self)  # cached until the next gate is applied
         psi = full[..., : 2**self._nqubits] if full.shape[-1] != 2**self._nqubits else full
         if form == "ket":

@@ -17,6 +17,31 @@ import numpy as np
 from . import _lib
 from . import plan as P
 
+# bench.py: when a list, every group of kernel launches of the executor is bracketed by HIP events on the launch
+# stream and logged as (tag, start, end, launches, algorithmic bytes or flops) -- the live per-kernel durations the
+# roofline figures are computed from.  None (default): no events are created.
+EVENT_LOG = None
+
+
+class _timed:
+    def __init__(self, tag, launches, work):
+        self.tag, self.launches, self.work = tag, launches, work
+
+    def __enter__(self):
+        if EVENT_LOG is not None:
+            import torch
+
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if EVENT_LOG is not None and exc[0] is None:
+            self.e1.record()
+            EVENT_LOG.append((self.tag, self.e0, self.e1, self.launches, self.work))
+        return False
+
+
 _T_MIN = 8
 ATOMIC_COPIES = 64  # replication of atomically accumulated outputs (spreads same-address atomics)
 
@@ -151,12 +176,9 @@ class CompiledCircuit:
                 ),
                 "tcmi_build_tables",
             )
-        ev = getattr(self, "pass_events", None)  # bench.py: HIP events around the pass launches
-        if ev is not None:
-            ev[0].record()
-        self.run_passes(out, ptab, B, stream)
-        if ev is not None:
-            ev[1].record()
+        item = 8 if self.dtypestr == "complex64" else 16
+        with _timed("pass", len(self.descs), len(self.descs) * 2.0 * B * nel * item):
+            self.run_passes(out, ptab, B, stream)
         if self.n_exec != self.n and not full:
             return out[:, : 2**self.n]
         return out
@@ -231,6 +253,8 @@ class CompiledCircuit:
                 "tcmi_build_adjoint_tables",
             )
             gout = torch.zeros(nb, ATOMIC_COPIES, adj["nslots"], dtype=torch.float64, device=self.device)
+            tm = _timed("adjoint", len(adj["descs"]), len(adj["descs"]) * 4.0 * nb * nel * item)
+            tm.__enter__()
             for d in adj["descs"]:
                 _lib.check(
                     lib.tcmi_run_adjoint_pass(
@@ -239,6 +263,7 @@ class CompiledCircuit:
                         gout.stride(0), ATOMIC_COPIES, gout.stride(1), self.code, stream),
                     "tcmi_run_adjoint_pass",
                 )
+            tm.__exit__(None, None, None)
             out[b0:b1].index_add_(1, adj["gparam"], gout.sum(1) * adj["gfactor"])
         return out[:, : self.nparams].to(self.rdtype)
 
@@ -310,15 +335,17 @@ class CompiledMeasure:
         nl = len(self.light)
         out = torch.zeros(B, ATOMIC_COPIES, 2 * max(nl, 1), dtype=torch.float64, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        for d in self.descs:
-            _lib.check(
-                self._lib.tcmi_run_pass(
-                    state.data_ptr(), state.shape[1], B, self.n_exec, self.cfg.R, self.cfg.LT,
-                    d.data_ptr(), self.dummy.data_ptr(), self.dummy.data_ptr(), 0, out.data_ptr(),
-                    out.stride(0), ATOMIC_COPIES, out.stride(1), self.code, stream,
-                ),
-                "tcmi_run_pass(measure)",
-            )
+        item = 8 if self.dtypestr == "complex64" else 16
+        with _timed("measure", len(self.descs), len(self.descs) * 1.0 * B * state.shape[1] * item):
+            for d in self.descs:
+                _lib.check(
+                    self._lib.tcmi_run_pass(
+                        state.data_ptr(), state.shape[1], B, self.n_exec, self.cfg.R, self.cfg.LT,
+                        d.data_ptr(), self.dummy.data_ptr(), self.dummy.data_ptr(), 0, out.data_ptr(),
+                        out.stride(0), ATOMIC_COPIES, out.stride(1), self.code, stream,
+                    ),
+                    "tcmi_run_pass(measure)",
+                )
         vals_l = torch.view_as_complex(out.sum(1).reshape(B, max(nl, 1), 2))[:, :nl] * self.phase
         if not self.heavy:
             return vals_l
@@ -364,12 +391,14 @@ class CompiledMeasure:
         w = (2.0 * gvals.real.to(torch.float64))[:, self._sum_order].contiguous()
         out = torch.empty_like(state)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        _lib.check(
-            self._lib.tcmi_apply_pauli_sum(
-                state.data_ptr(), out.data_ptr(), state.shape[1], B, self.n_exec,
-                self._sum_terms.data_ptr(), self.nterms, w.data_ptr(), w.stride(0), self.code, stream),
-            "tcmi_apply_pauli_sum",
-        )
+        item = 8 if self.dtypestr == "complex64" else 16
+        with _timed("pauli_sum", 1, 2.0 * B * state.shape[1] * item):
+            _lib.check(
+                self._lib.tcmi_apply_pauli_sum(
+                    state.data_ptr(), out.data_ptr(), state.shape[1], B, self.n_exec,
+                    self._sum_terms.data_ptr(), self.nterms, w.data_ptr(), w.stride(0), self.code, stream),
+                "tcmi_apply_pauli_sum",
+            )
         return out
 
 
@@ -552,16 +581,12 @@ class CutCircuit:
         if out is None:
             out = torch.empty(B, M * N, dtype=self.tdtype, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        ev = getattr(self, "gemm_events", None)
-        if ev is not None:
-            ev[0].record()
-        _lib.check(
-            self._lib.tcmi_cgemm(L.data_ptr(), R.data_ptr(), out.data_ptr(), M, N, K, B, K * M, K * N, M * N,
-                                 1, self.code, stream),
-            "tcmi_cgemm(cut)",
-        )
-        if ev is not None:
-            ev[1].record()
+        with _timed("gemm", 1, 8.0 * M * N * K * B):
+            _lib.check(
+                self._lib.tcmi_cgemm(L.data_ptr(), R.data_ptr(), out.data_ptr(), M, N, K, B, K * M, K * N, M * N,
+                                     1, self.code, stream),
+                "tcmi_cgemm(cut)",
+            )
         return out
 
     def vjp(self, params, psi, g, **kw):

@@ -7,6 +7,7 @@ milliseconds of Python (gate recording, ~100 tensor indexings and their autograd
 of kernels on small circuits.  ``TracedVag`` removes that cost for the standard pattern
 
     f(*args) = real( sum_k w_k <P_k> )   of ONE circuit whose gate angles are elements of tensor arguments
+    f(*args) = that circuit's wavefunction()                      (value-only forms: jit(f), jit(vmap(f)))
 
 It is found by *probing*, not by a tensor subclass: ``f`` is called twice with index-valued arguments
 (element g of the concatenated arguments holds g, then 2 g + 1); an angle that reads back (g, 2 g + 1) is
@@ -30,6 +31,14 @@ from . import gates as G
 
 def _as_tuple(x):
     return (x,) if isinstance(x, int) else tuple(x)
+
+
+class TracedState:
+    """What ``Circuit.wavefunction`` returns while ``backend.jit`` probes a function: the function's output is the
+    state of this circuit (nothing was evaluated)."""
+
+    def __init__(self, circuit, form):
+        self.circuit, self.form = circuit, form
 
 
 class TracedVag:
@@ -97,6 +106,21 @@ class TracedVag:
                 return False
             finally:
                 _lib.TRACING[0] = False
+            if isinstance(out, TracedState):
+                # f(*args) = wavefunction of one circuit: the pipeline is gather -> state plan
+                if not self.value_only or out.circuit.inputs is not None:
+                    return False
+                c = out.circuit
+                pv = []
+                for v in c._params:
+                    if torch.is_tensor(v):
+                        if v.numel() != 1:
+                            return False
+                        pv.append(float(v.detach().reshape(()).to(torch.float64).cpu()))
+                    else:
+                        pv.append(float(np.real(v)))
+                runs.append((c, out.form, None, pv, spans, total))
+                continue
             if not isinstance(out, LazyExpectation) or out._value is not None or not out.is_real:
                 return False
             circuits = {id(t[0]): t[0] for t in out.terms}
@@ -120,6 +144,8 @@ class TracedVag:
                     pv.append(float(np.real(v)))
             runs.append((c, terms, float(np.real(out.const)), pv, spans, total))
             out.terms = []          # drop the pending registration, nothing is evaluated
+        if len(runs) != 2:
+            return False
         (c, terms, const, pa_vals, spans, total), (c2, terms2, const2, pb_vals, _, _) = runs
         if terms != terms2 or const != const2 or len(pa_vals) != len(pb_vals) or len(c._ops) != len(c2._ops):
             return False
@@ -135,6 +161,14 @@ class TracedVag:
         from .executor import get_measure
 
         cc = c._compiled()
+        dev = self.backend.device
+        rdt = torch.float32 if cons.rdtypestr == "float32" else torch.float64
+        if const is None:   # state-valued function (terms holds the requested form)
+            return {
+                "cc": cc, "state_form": terms, "nq": c._nqubits, "spans": spans, "total": total, "rdt": rdt,
+                "index": torch.tensor(index, dtype=torch.int64, device=dev),
+                "consts": torch.tensor(consts, dtype=rdt, device=dev), "checked": False,
+            }
         strings = list(terms.keys())
         if not strings:
             return False
@@ -175,6 +209,16 @@ class TracedVag:
         flats.append(plan["consts"].reshape(1, -1).expand(nb, -1))
         flat = torch.cat(flats, dim=1)
         params = flat.index_select(1, plan["index"]).contiguous()          # [nb, P]
+        if "state_form" in plan:
+            psi = plan["cc"].state(params)                                     # [nb, 2^n]
+            form = plan["state_form"]
+            if not batched:
+                psi = psi[0]
+            if form == "ket":
+                psi = psi.reshape(psi.shape[:-1] + (-1, 1))
+            elif form == "bra":
+                psi = psi.reshape(psi.shape[:-1] + (1, -1))
+            return psi
         cc, cm = plan["cc"], plan["cm"]
         state = cc.state(params, full=True)                                   # [nb, 2^n_exec]
         vals = cm.run(state)                                                  # [nb, T] complex128
@@ -248,7 +292,8 @@ def _close(a, b, tol) -> bool:
     if torch.is_tensor(a) and torch.is_tensor(b):
         if a.shape != b.shape:
             return False
-        a64, b64 = a.detach().to(torch.float64), b.detach().to(torch.float64)
+        cdt = torch.complex128 if (a.is_complex() or b.is_complex()) else torch.float64
+        a64, b64 = a.detach().to(cdt), b.detach().to(cdt)
         scale = max(1.0, float(a64.abs().max()) if a64.numel() else 1.0)
         return bool((a64 - b64).abs().max() <= tol * scale) if a64.numel() else True
     return False

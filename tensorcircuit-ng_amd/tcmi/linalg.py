@@ -59,6 +59,13 @@ def _h(x):
     return x.mH.resolve_conj()
 
 
+def _timed(tag, launches, work):
+    """bench.py's HIP-event log around a launch (no-op unless ``executor.EVENT_LOG`` is a list)."""
+    from .executor import _timed as T
+
+    return T(tag, launches, work)
+
+
 def matmul(a, b):
     """[M,K] @ [K,N] (or batched [B,M,K] @ [B,K,N]) through ``tcmi_cgemm``; differentiable."""
     if _tracked(a, b):
@@ -75,8 +82,9 @@ def _matmul_raw(a, b):
         K2, N = b.shape
         assert K == K2, (a.shape, b.shape)
         c = torch.empty((M, N), dtype=a.dtype, device=a.device)
-        _lib.check(_lib.lib().tcmi_cgemm(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, 1, 0, 0, 0, 0, _code(a),
-                                         _stream(a)), "tcmi_cgemm")
+        with _timed("mps_gemm", 1, 8.0 * M * N * K):
+            _lib.check(_lib.lib().tcmi_cgemm(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, 1, 0, 0, 0, 0, _code(a),
+                                             _stream(a)), "tcmi_cgemm")
         return c
     B, M, K = a.shape
     _, K2, N = b.shape
@@ -106,8 +114,9 @@ def _site_gate_raw(gate, tensor):
     gate = gate.resolve_conj().contiguous()
     l, d, r = tensor.shape
     out = torch.empty_like(tensor)
-    _lib.check(_lib.lib().tcmi_cgemm(gate.data_ptr(), tensor.data_ptr(), out.data_ptr(), d, r, d, l, 0, d * r, d * r,
-                                     0, _code(tensor), _stream(tensor)), "tcmi_cgemm")
+    with _timed("mps_gemm", 1, 8.0 * d * d * r * l):
+        _lib.check(_lib.lib().tcmi_cgemm(gate.data_ptr(), tensor.data_ptr(), out.data_ptr(), d, r, d, l, 0, d * r, d * r,
+                                         0, _code(tensor), _stream(tensor)), "tcmi_cgemm")
     return out
 
 
@@ -127,8 +136,9 @@ def _gate_mix_raw(t, gate, L, R):
     t = t.resolve_conj().contiguous()
     gate = gate.resolve_conj().contiguous()
     out = torch.empty_like(t)
-    _lib.check(_lib.lib().tcmi_mps_gate_mix(t.data_ptr(), gate.data_ptr(), out.data_ptr(), L, R, 1, 0, _code(t),
-                                            _stream(t)), "tcmi_mps_gate_mix")
+    with _timed("mps_mix", 1, 2.0 * t.numel() * t.element_size()):
+        _lib.check(_lib.lib().tcmi_mps_gate_mix(t.data_ptr(), gate.data_ptr(), out.data_ptr(), L, R, 1, 0, _code(t),
+                                                _stream(t)), "tcmi_mps_gate_mix")
     return out
 
 
@@ -150,10 +160,11 @@ def _svd_rows(mat, kmax, max_sv, max_err, relative, absorb):
     vh = torch.empty((kmax, n), dtype=mat.dtype, device=mat.device)
     keep = torch.empty((1,), dtype=torch.int32, device=mat.device)
     tw2 = torch.empty((1,), dtype=rdt, device=mat.device)
-    _lib.check(_lib.lib().tcmi_svd_trunc_batched(
-        mat.data_ptr(), u.data_ptr(), s.data_ptr(), vh.data_ptr(), keep.data_ptr(), tw2.data_ptr(), m, n, kmax, 1,
-        int(max_sv or 0), float(-1.0 if max_err is None else max_err), int(bool(relative)), absorb, 0,
-        work.data_ptr(), work.numel(), code, _stream(mat)), "tcmi_svd_trunc_batched")
+    with _timed("mps_svd", 1, 0.0):
+        _lib.check(_lib.lib().tcmi_svd_trunc_batched(
+            mat.data_ptr(), u.data_ptr(), s.data_ptr(), vh.data_ptr(), keep.data_ptr(), tw2.data_ptr(), m, n, kmax, 1,
+            int(max_sv or 0), float(-1.0 if max_err is None else max_err), int(bool(relative)), absorb, 0,
+            work.data_ptr(), work.numel(), code, _stream(mat)), "tcmi_svd_trunc_batched")
     return u, s, vh, keep, tw2
 
 
@@ -220,8 +231,9 @@ def _qr_raw(mat):
     work = _workspace("qr", nbytes, mat.device)
     q = torch.empty((m, K), dtype=mat.dtype, device=mat.device)
     r = torch.empty((K, n), dtype=mat.dtype, device=mat.device)
-    _lib.check(_lib.lib().tcmi_qr_batched(mat.data_ptr(), q.data_ptr(), r.data_ptr(), m, n, 1, work.data_ptr(),
-                                          work.numel(), code, _stream(mat)), "tcmi_qr_batched")
+    with _timed("mps_qr", 1, 0.0):
+        _lib.check(_lib.lib().tcmi_qr_batched(mat.data_ptr(), q.data_ptr(), r.data_ptr(), m, n, 1, work.data_ptr(),
+                                              work.numel(), code, _stream(mat)), "tcmi_qr_batched")
     return q, r
 
 

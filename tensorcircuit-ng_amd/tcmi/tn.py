@@ -813,6 +813,9 @@ def _permute_raw(t, perm):
         _SRCBIT_CACHE[key] = sb
     t = t.contiguous()
     out = torch.empty_like(t)
+    if COUNTERS is not None:
+        COUNTERS["permute_launches"] += 1
+        COUNTERS["permute_bytes"] += 2.0 * t.numel() * t.element_size()
     stream = torch.cuda.current_stream(t.device).cuda_stream
     _lib.check(_lib.lib().tcmi_permute_bits(t.data_ptr(), out.data_ptr(), rank, sb.data_ptr(), 1, 0, _code(t), stream),
                "tcmi_permute_bits")
@@ -824,6 +827,10 @@ def _gemm_raw(a2, b2, M, N, K):
 
     a2, b2 = a2.contiguous(), b2.contiguous()
     c = torch.empty(M * N, dtype=a2.dtype, device=a2.device)
+    if COUNTERS is not None:
+        COUNTERS["gemm_launches"] += 1
+        COUNTERS["gemm_flops"] += 8.0 * M * N * K
+        COUNTERS["gemm_bytes"] += float(M * K + K * N + M * N) * a2.element_size()
     stream = torch.cuda.current_stream(a2.device).cuda_stream
     _lib.check(_lib.lib().tcmi_cgemm(a2.data_ptr(), b2.data_ptr(), c.data_ptr(), M, N, K, 1, 0, 0, 0, 0, _code(a2), stream),
                "tcmi_cgemm")
@@ -831,6 +838,15 @@ def _gemm_raw(a2, b2, M, N, K):
 
 
 _FN = {}
+
+# bench.py: when a dict (see ``new_counters``), the engine tallies launches, algorithmic flops / bytes of the GEMM
+# and scattered-contraction steps, and the bytes moved by stand-alone permutes (traffic that is not in B_alg).
+COUNTERS = None
+
+
+def new_counters():
+    return {k: 0.0 for k in ("permute_launches", "permute_bytes", "gemm_launches", "gemm_flops", "gemm_bytes",
+                             "scattered_launches", "scattered_flops", "scattered_bytes")}
 
 
 def _fns():
@@ -963,6 +979,10 @@ def _tensordot_scattered(a, b, axes_a, axes_b, fa, fb):
     n = small.numel() >> nk
     out = torch.empty((1 << (rank - nk)) * n, dtype=big.dtype, device=big.device)
     arr = (ctypes.c_int * nk)(*pos)
+    if COUNTERS is not None:
+        COUNTERS["scattered_launches"] += 1
+        COUNTERS["scattered_flops"] += 8.0 * out.numel() * (1 << nk)
+        COUNTERS["scattered_bytes"] += float(big.numel() + small.numel() + out.numel()) * big.element_size()
     stream = torch.cuda.current_stream(big.device).cuda_stream
     _lib.check(_lib.lib().tcmi_contract_scattered(big.data_ptr(), rank, ctypes.cast(arr, ctypes.c_void_p), nk,
                                                   small2.data_ptr(), n, out.data_ptr(), int(big_first), _code(big),

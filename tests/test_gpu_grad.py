@@ -397,8 +397,8 @@ def test_jit_traced_value_and_grad(tcd, n, d):
 
 
 def test_jit_plain_functions(tcd):
-    """jit(f) of a plain energy function is traced (value only); functions that need device results while
-    being probed (states, MPS, arithmetic on expectations) run unchanged."""
+    """jit(f) of a plain energy function or of a state-returning function is traced (value only); functions that
+    need device results while being probed (MPS, arithmetic on expectations) run unchanged."""
     tc = tcd
     n = 9
     rdt = np.float32 if tc.rdtypestr == "float32" else np.float64
@@ -431,7 +431,7 @@ def test_jit_plain_functions(tcd):
         np.testing.assert_allclose(_np(tc, je(p)), _np(tc, energy(p)), atol=tol)
         np.testing.assert_allclose(_np(tc, js(p)), _np(tc, state(p)), atol=tol)
         np.testing.assert_allclose(_np(tc, jq(p)), _np(tc, squared(p)), atol=tol)
-    assert je.stats["fast"] >= 1 and js.stats["fast"] == 0 and jq.stats["fast"] == 0
+    assert je.stats["fast"] >= 1 and js.stats["fast"] >= 1 and jq.stats["fast"] == 0
     jv = tc.backend.jit(tc.backend.vmap(energy))
     pb = tc.backend.convert_to_tensor(rng.normal(size=[4, n]).astype(rdt))
     for _ in range(3):
