@@ -80,7 +80,7 @@ __device__ __forceinline__ void st_sc1(double* p, double v) {
   __hip_atomic_store((gu64*)p, (unsigned long long)__double_as_longlong(v), TCMI_RLX);
 }
 
-// Barrier between the nwg workgroups of one matrix (all resident: the host caps the grid at 256 WGs).
+// Barrier between the nwg workgroups of one matrix (all resident: the host sizes every launch by svd_resident_wgs).
 // Every wave drains its write-through stores, one lane arrives on a monotonic counter and polls it
 // relaxed with s_sleep; the spin is bounded (a timeout sets ctl[1] and ends the kernel).
 __device__ __forceinline__ bool grid_barrier(unsigned* ctl, unsigned nwg, unsigned& epoch, unsigned* s_dead) {
@@ -279,6 +279,24 @@ __device__ __forceinline__ int rotate_pair_reg(typename Cx<F>::type (&x)[E], typ
 // separated only by __syncthreads (round 0 also does the intra-block pairs), then the rows go back to
 // global memory (write-through) and the workgroups of the matrix meet at one grid barrier.  p - 1 pair
 // rounds per sweep as in the flat scheme, but only NB - 1 of them cross the chip.
+// A barrier that timed out (workgroups of the matrix not co-resident: shared or partitioned GPU) must not leave
+// plausible-looking factors behind: every workgroup that notices poisons the outputs callers look at -- the kept rank
+// becomes -1 and every singular value NaN -- before it leaves.
+template <typename F>
+__device__ __forceinline__ void svd_poison(F* s, int p, int* keep_out, F* tw2_out, int bi) {
+  const F nan = __builtin_nanf("");
+  for (int k = threadIdx.x; k < p; k += blockDim.x) s[k] = nan;
+  if (threadIdx.x == 0) {
+    if (keep_out) keep_out[bi] = -1;
+    if (tw2_out) tw2_out[bi] = nan;
+  }
+}
+#define TCMI_SVD_SYNC()                                    \
+  if (!grid_barrier(ctl, nwg, epoch, &s_dead)) {           \
+    svd_poison<F>(s, p, keep_out, tw2_out, b + batch0);    \
+    return;                                                \
+  }
+
 template <typename F, int B>
 __global__ __launch_bounds__(64 * B) void svd_block_kernel(
     const typename Cx<F>::type* __restrict__ a, long long a_stride, typename Cx<F>::type* __restrict__ u, F* s,
@@ -325,7 +343,7 @@ __global__ __launch_bounds__(64 * B) void svd_block_kernel(
       st_sc1(Y + i, v);
     }
   }
-  if (!grid_barrier(ctl, nwg, epoch, &s_dead)) return;
+  TCMI_SVD_SYNC();
 
   const F tol2 = Eps<F>::v * Eps<F>::v * (F)q * (F)(TCMI_SVD_TOL_SCALE * TCMI_SVD_TOL_SCALE);
   const int M = NB - 1;
@@ -393,7 +411,7 @@ __global__ __launch_bounds__(64 * B) void svd_block_kernel(
         row_out<Ct>(Y + gr * P2, src + q, P2, lane);
       }
       if (R == M - 1 && rot > 0 && lane == 0) __hip_atomic_fetch_add((gu32*)&ctl[2 + sweep], 1u, TCMI_RLX);
-      if (!grid_barrier(ctl, nwg, epoch, &s_dead)) return;
+      TCMI_SVD_SYNC();
     }
     if (__hip_atomic_load((gu32*)&ctl[2 + sweep], TCMI_RLX) == 0) break;
   }
@@ -421,7 +439,7 @@ __global__ __launch_bounds__(64 * B) void svd_block_kernel(
       st_sc1(yn + row, 1 / sqrt(accy));
     }
   }
-  if (!grid_barrier(ctl, nwg, epoch, &s_dead)) return;
+  TCMI_SVD_SYNC();
 
   // rank (descending, ties by row index; the zero pad rows sort last), then write s / vh / u sorted
   for (int k = 0; k < 2; ++k) {
@@ -459,7 +477,7 @@ __global__ __launch_bounds__(64 * B) void svd_block_kernel(
       }
     }
   }
-  if (!grid_barrier(ctl, nwg, epoch, &s_dead)) return;
+  TCMI_SVD_SYNC();
 
   if (g == 0 && threadIdx.x == 0) {
     int keep = (max_sv > 0 && max_sv < p) ? max_sv : p;
@@ -932,9 +950,29 @@ static int dispatch_svd(const SvdGeom& gm, int nb, hipStream_t st, const void* a
   return -1;
 }
 
-static int svd_chunk(int wgs, int batch) {
-  int chunk = 256 / wgs;  // co-resident workgroups per launch (one per CU is always resident)
-  if (chunk < 1) chunk = 1;
+// Workgroups of the SVD kernel the device keeps resident at once: the spin barrier needs ALL workgroups of a matrix
+// resident.  Bounded by LDS (160 KiB per CU), by the 32-wave limit of a CU and by the register file (the kernel is
+// built for at most 128 VGPRs: 4 waves per SIMD), times the CU count; one workgroup per CU is taken off as a margin
+// when more than one fits (the occupancy figures can be one high, MI355X_MICROARCH.md "Residency").
+static int svd_resident_wgs(const SvdGeom& gm, bool f64) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1)
+      v = 256;
+    cus = v;
+  }
+  long long per_cu = (160ll * 1024) / (gm.lds_bytes + 16 + 255);
+  const long long by_waves = (f64 ? 12 : 16) / gm.B;   // waves per SIMD by registers (<= 96 / <= 152 VGPRs) x 4 SIMDs
+  if (by_waves < per_cu) per_cu = by_waves;
+  if (per_cu > 1) per_cu -= 1;
+  if (per_cu < 1) per_cu = 1;
+  return (int)(per_cu * cus);
+}
+
+// batch elements per launch so that every workgroup of the launch is resident; 0: one matrix alone does not fit
+static int svd_chunk(const SvdGeom& gm, int batch, bool f64) {
+  int chunk = svd_resident_wgs(gm, f64) / gm.wgs;
   if (chunk > batch) chunk = batch;
   return chunk;
 }
@@ -949,12 +987,12 @@ long long tcmi_svd_work_bytes(int m, int n, int batch, int dtype) {
   if (m < 1 || n < m || batch < 1) return -1;
   if (dtype == TCMI_C64) {
     const tcmi::SvdGeom gm = tcmi::svd_geom<float>(m, n);
-    const int chunk = tcmi::svd_chunk(gm.wgs, batch);
+    const int chunk = tcmi::svd_chunk(gm, batch, false) > 0 ? tcmi::svd_chunk(gm, batch, false) : 1;
     return (long long)chunk * tcmi::SVD_CTL_WORDS * 4 + chunk * gm.work_elems * 8;
   }
   if (dtype == TCMI_C128) {
     const tcmi::SvdGeom gm = tcmi::svd_geom<double>(m, n);
-    const int chunk = tcmi::svd_chunk(gm.wgs, batch);
+    const int chunk = tcmi::svd_chunk(gm, batch, true) > 0 ? tcmi::svd_chunk(gm, batch, true) : 1;
     return (long long)chunk * tcmi::SVD_CTL_WORDS * 4 + chunk * gm.work_elems * 16;
   }
   return -1;
@@ -975,7 +1013,10 @@ int tcmi_svd_trunc_batched(const void* a, void* u, void* s, void* vh, int* keep_
   const tcmi::SvdGeom gm = dtype == TCMI_C64 ? tcmi::svd_geom<float>(m, n) : tcmi::svd_geom<double>(m, n);
   if (gm.lds_bytes > 65536)
     return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_svd_trunc_batched: matrix too wide for the LDS-resident kernel");
-  const int chunk = tcmi::svd_chunk(gm.wgs, batch);
+  const int chunk = tcmi::svd_chunk(gm, batch, dtype == TCMI_C128);
+  if (chunk < 1)
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_svd_trunc_batched: the matrix needs more co-resident workgroups than the "
+                                         "device holds (one-launch Jacobi SVD; split the problem)");
   unsigned* ctl = reinterpret_cast<unsigned*>(work);
   char* wbase = reinterpret_cast<char*>(work) + (long long)chunk * tcmi::SVD_CTL_WORDS * 4;
   for (int b0 = 0; b0 < batch; b0 += chunk) {

@@ -56,6 +56,23 @@ class _Op:
         self.name = name
 
 
+def _constant_value(t, what):
+    """numpy value of a matrix-like gate argument that is baked into the plan as a constant.  A tensor that is being
+    differentiated (requires_grad) or transformed (vmap / grad wrappers) cannot be a constant: the reference would
+    differentiate / batch through it, so this raises instead of silently returning zero gradients."""
+    if _is_tensor(t) and not isinstance(t, np.ndarray):
+        import torch
+
+        if torch.is_tensor(t):
+            if t.requires_grad or torch._C._functorch.is_functorch_wrapped_tensor(t):
+                raise NotImplementedError(
+                    f"Backend 'hip' has not implemented differentiation / vmap through a tensor-valued {what}; "
+                    "pass it as a constant (detach) or use a parametrised gate."
+                )
+        return cons.backend.numpy(t)
+    return t
+
+
 class Circuit:
     """``Circuit`` class: state-vector simulator front end of the hip backend."""
 
@@ -150,9 +167,7 @@ class Circuit:
         if kws.get("mpo") or kws.get("diagonal"):
             raise NotImplementedError("mpo / diagonal gate formats are not supported on the hip backend")
         t = gate.tensor if isinstance(gate, G.Gate) else gate
-        if _is_tensor(t) and not isinstance(t, np.ndarray):
-            t = cons.backend.numpy(t)
-        self._record_const(t, index, name or "")
+        self._record_const(_constant_value(t, "gate matrix"), index, name or "")
 
     apply = apply_general_gate
 
@@ -221,9 +236,7 @@ class Circuit:
             unitary = kw.get("unitary")
             return self.apply_general_gate(unitary, *index, name=kw.get("name", "any"))
         elif name == "su4":
-            theta = kw.get("theta")
-            if _is_tensor(theta) and not isinstance(theta, np.ndarray):
-                theta = cons.backend.numpy(theta)
+            theta = _constant_value(kw.get("theta"), "su4 parameter vector")
             return self._record_const(G.matrix_for_gate(G.su4_gate(theta)), index, "su4")
         elif name == "cu":
             vals = [get("theta"), get("phi"), get("lbd")]
@@ -241,7 +254,7 @@ class Circuit:
             t = t.tensor
         if isinstance(t, np.ndarray) or G.is_concrete(t):
             return np.asarray(t, dtype=np.complex128)
-        return np.asarray(cons.backend.numpy(t), dtype=np.complex128)
+        return np.asarray(_constant_value(t, "gate generator"), dtype=np.complex128)
 
     # ---- lowering -----------------------------------------------------------------------------
     def _gate_records(self) -> List[P.GateRec]:

@@ -10,6 +10,7 @@ Python on every call, ``cons.py:1036,927``).
 
 import hashlib
 import os
+from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -97,6 +98,27 @@ def structure_digest(n: int, dtypestr: str, gates: List[P.GateRec]) -> str:
     return h.hexdigest()
 
 
+def gate_is_unitary(g: P.GateRec, tol: float = 1e-6) -> bool:
+    """Diagonal records are unit-modulus by construction; dense ones are checked (at sample angles when
+    parametrised).  The adjoint sweep un-computes psi with U^dagger, which is only the inverse for unitary gates."""
+    if g.is_diag:
+        return True
+    mats = list(g.select) if g.select is not None else None
+    if mats is None:
+        if g.param is None:
+            mats = [np.asarray(g.c0, dtype=np.complex128)]
+        else:
+            mats = [np.asarray(g.c0, dtype=np.complex128) + np.cos(a) * np.asarray(g.c1) + np.sin(a) * np.asarray(g.c2)
+                    for a in (0.37, 1.9, 4.1)]
+    for m in mats:
+        m = np.asarray(m, dtype=np.complex128)
+        d = int(round(np.sqrt(m.size)))
+        m = m.reshape(d, d)
+        if np.abs(m @ m.conj().T - np.eye(d)).max() > tol:
+            return False
+    return True
+
+
 class CompiledCircuit:
     """A circuit structure lowered to tile-VM passes and resident on one GPU."""
 
@@ -112,6 +134,10 @@ class CompiledCircuit:
         if pad:
             gates = [self._shift(g, pad) for g in gates]
         self._exec_gates = gates
+        self._opts = opts
+        # non-unitary gates (density-matrix channels, `any` with a non-unitary matrix): the reverse sweep cannot
+        # un-compute psi through them; vjp() then works segment by segment from checkpoints
+        self.nonunitary = [i for i, g in enumerate(gates) if not gate_is_unitary(g)]
         self.plan = P.compile_plan(gates, self.n_exec, self.cfg, nparams=nparams)
         self.tdtype = torch.complex64 if dtypestr == "complex64" else torch.complex128
         self.rdtype = torch.float32 if dtypestr == "complex64" else torch.float64
@@ -221,19 +247,27 @@ class CompiledCircuit:
             }
         return self._adj
 
-    def vjp(self, params, psi, g, chunk_bytes=48 << 30):
+    def vjp(self, params, psi, g, chunk_bytes=48 << 30, inputs=None, want_input_grad=False):
         """dL/dparams = Re <g | d psi / d params> for every batch row, by the adjoint sweep.
         params [B, P] real, psi / g [B, 2^n_exec] complex (psi = the forward output).  The sweep
-        works on copies (psi is un-computed in place), processed in batch chunks to bound memory."""
+        works on copies (psi is un-computed in place), processed in batch chunks to bound memory.
+        ``want_input_grad``: also return the cotangent of the input state, U^dagger g = lambda after the whole
+        sweep ([B, 2^n_exec]).  ``inputs``: the forward input state (needed only with non-unitary gates, whose
+        segments restart from recomputed checkpoints)."""
         import torch
 
+        if self.nonunitary:
+            return self._vjp_segmented(params, g, inputs, want_input_grad)
+        lam_out = torch.empty_like(g) if want_input_grad else None
         adj = self._adjoint()
         lib = self._lib
         B = params.shape[0]
         nel = 2**self.n_exec
         out = torch.zeros(B, max(self.nparams, 1), dtype=torch.float64, device=self.device)
-        if adj["nslots"] == 0 or self.nparams == 0:
+        if (adj["nslots"] == 0 or self.nparams == 0) and not want_input_grad:
             return out[:, : self.nparams].to(self.rdtype)
+        if params is None or params.shape[-1] == 0:
+            params = torch.zeros(B, 1, dtype=self.rdtype, device=self.device)
         params = params.to(device=self.device, dtype=self.rdtype).contiguous()
         item = 8 if self.dtypestr == "complex64" else 16
         cb = max(1, int(chunk_bytes // (2 * nel * item)))
@@ -252,7 +286,7 @@ class CompiledCircuit:
                     p.data_ptr(), p.stride(0), ptab.data_ptr(), ptab.stride(0), nb, self.code, stream),
                 "tcmi_build_adjoint_tables",
             )
-            gout = torch.zeros(nb, ATOMIC_COPIES, adj["nslots"], dtype=torch.float64, device=self.device)
+            gout = torch.zeros(nb, ATOMIC_COPIES, max(1, adj["nslots"]), dtype=torch.float64, device=self.device)
             tm = _timed("adjoint", len(adj["descs"]), len(adj["descs"]) * 4.0 * nb * nel * item)
             tm.__enter__()
             for d in adj["descs"]:
@@ -264,8 +298,81 @@ class CompiledCircuit:
                     "tcmi_run_adjoint_pass",
                 )
             tm.__exit__(None, None, None)
-            out[b0:b1].index_add_(1, adj["gparam"], gout.sum(1) * adj["gfactor"])
-        return out[:, : self.nparams].to(self.rdtype)
+            if adj["nslots"]:
+                out[b0:b1].index_add_(1, adj["gparam"], gout.sum(1) * adj["gfactor"])
+            if want_input_grad:
+                lam_out[b0:b1] = lam
+            if getattr(self, "_keep_uncomputed", None) is not None:
+                self._keep_uncomputed.append(a)
+        gp = out[:, : self.nparams].to(self.rdtype)
+        return (gp, lam_out) if want_input_grad else gp
+
+    # ---- reverse mode through non-unitary gates ----------------------------------------------------------
+    def _segments(self):
+        """The gate list cut at every non-unitary gate: [("U", CompiledCircuit of a unitary run) | ("N", forward
+        CompiledCircuit of the gate, CompiledCircuit of its adjoint matrix)]."""
+        if getattr(self, "_segs", None) is None:
+            segs, run = [], []
+            bad = set(self.nonunitary)
+
+            def sub(gs):
+                return CompiledCircuit(self.n_exec, gs, self.nparams, self.dtypestr, self._opts, self.device)
+
+            for i, g in enumerate(self._exec_gates):
+                if i not in bad:
+                    run.append(g)
+                    continue
+                if run:
+                    segs.append(("U", sub(run)))
+                    run = []
+                if g.param is not None or g.select is not None:
+                    raise NotImplementedError(
+                        "Backend 'hip' has not implemented gradients through a parametrised non-unitary gate.")
+                m = np.asarray(g.c0, dtype=np.complex128)
+                d = int(round(np.sqrt(m.size)))
+                gd = P.GateRec(g.qubits, c0=m.reshape(d, d).conj().T.copy(), name=g.name + "^dagger")
+                segs.append(("N", sub([g]), sub([gd])))
+            if run:
+                segs.append(("U", sub(run)))
+            self._segs = segs
+        return self._segs
+
+    def _vjp_segmented(self, params, g, inputs, want_input_grad):
+        """Adjoint sweep with checkpoints: the state entering each non-unitary gate M is recomputed by a forward
+        run and kept; going back, unitary runs are un-computed as usual, at M the cotangent becomes M^dagger lambda
+        and psi restarts from the checkpoint."""
+        import torch
+
+        segs = self._segments()
+        B = g.shape[0]
+        nel = 2**self.n_exec
+        if params is None or self.nparams == 0:
+            params = torch.zeros(B, max(1, self.nparams), dtype=self.rdtype, device=self.device)
+        params = params.to(device=self.device, dtype=self.rdtype).contiguous()
+        if inputs is None:
+            x = torch.zeros(B, nel, dtype=self.tdtype, device=self.device)
+            x[:, 0] = 1
+        else:
+            inp = inputs.reshape(-1, inputs.shape[-1]).to(device=self.device, dtype=self.tdtype)
+            x = torch.zeros(B, nel, dtype=self.tdtype, device=self.device)
+            x[:, : inp.shape[-1]] = inp
+        ends = []   # state after each segment (psi to un-compute from) / before each non-unitary gate (checkpoint)
+        for seg in segs:
+            if seg[0] == "N":
+                ends.append(x)
+            x = seg[1].state(params, inputs=x, full=True).clone()
+            if seg[0] == "U":
+                ends.append(x)
+        lam = g.to(self.tdtype).clone()
+        grad = torch.zeros(B, max(self.nparams, 1), dtype=torch.float64, device=self.device)
+        for seg, x_end in zip(reversed(segs), reversed(ends)):
+            if seg[0] == "U":
+                gp, lam = seg[1].vjp(params, x_end, lam, want_input_grad=True)
+                grad[:, : self.nparams] += gp.to(torch.float64)
+            else:
+                lam = seg[2].state(params, inputs=lam, full=True).clone()
+        gp = grad[:, : self.nparams].to(self.rdtype)
+        return (gp, lam) if want_input_grad else gp
 
 
 def pick_measure_variant(n_exec: int, dtypestr: str) -> P.PlanConfig:
@@ -402,7 +509,7 @@ class CompiledMeasure:
         return out
 
 
-_MCACHE: Dict[Tuple, "CompiledMeasure"] = {}
+_MCACHE: "OrderedDict[Tuple, CompiledMeasure]" = OrderedDict()
 
 
 def get_measure(n, n_exec, strings, dtypestr) -> CompiledMeasure:
@@ -414,6 +521,10 @@ def get_measure(n, n_exec, strings, dtypestr) -> CompiledMeasure:
     if m is None:
         m = CompiledMeasure(n, n_exec, strings, dtypestr)
         _MCACHE[key] = m
+        while len(_MCACHE) > _CACHE_MAX:
+            _MCACHE.popitem(last=False)
+    else:
+        _MCACHE.move_to_end(key)
     return m
 
 
@@ -592,6 +703,10 @@ class CutCircuit:
     def vjp(self, params, psi, g, **kw):
         return self.full.vjp(params, psi, g, **kw)
 
+    @property
+    def nonunitary(self):
+        return self.full.nonunitary
+
     def stats(self):
         item = 8 if self.dtypestr == "complex64" else 16
         M, N = 2**self.spec.n_left, 2 ** (self.n - self.spec.n_left)
@@ -631,7 +746,8 @@ class GraphedState:
         return self.out
 
 
-_CACHE: Dict[Tuple, CompiledCircuit] = {}
+_CACHE: "OrderedDict[Tuple, CompiledCircuit]" = OrderedDict()   # LRU: a training loop over changing constant
+_CACHE_MAX = 64                                                  # matrices must not grow host / device memory unboundedly
 
 
 def get_compiled(n, gates, nparams, dtypestr, opts) -> CompiledCircuit:
@@ -650,6 +766,10 @@ def get_compiled(n, gates, nparams, dtypestr, opts) -> CompiledCircuit:
         cc = CompiledCircuit(n, gates, nparams, dtypestr, opts)
         cc = _maybe_cut(cc, n, gates, nparams, dtypestr, opts)
         _CACHE[key] = cc
+        while len(_CACHE) > _CACHE_MAX:
+            _CACHE.popitem(last=False)
+    else:
+        _CACHE.move_to_end(key)
     return cc
 
 

@@ -47,10 +47,18 @@ def _fns():
             params, cc, inp = inputs
             ctx.cc = cc
             ctx.has_inputs = inp is not None
-            ctx.save_for_backward(params, output)
+            ctx.inp_shape = tuple(inp.shape) if inp is not None else None
+            if inp is not None:
+                ctx.save_for_backward(params, output, inp)
+            else:
+                ctx.save_for_backward(params, output)
 
         @staticmethod
         def backward(ctx, grad_out):
+            if ctx.has_inputs:
+                params, psi, inp = ctx.saved_tensors
+                gp, gin = StateVjpInFn.apply(params, psi, grad_out, ctx.cc, inp)
+                return gp, None, gin
             params, psi = ctx.saved_tensors
             return StateVjpFn.apply(params, psi, grad_out, ctx.cc), None, None
 
@@ -98,6 +106,38 @@ def _fns():
             out = StateVjpFn.apply(p.reshape(-1, p.shape[-1]), s.reshape(-1, s.shape[-1]).contiguous(),
                                    gg.reshape(-1, gg.shape[-1]).contiguous(), cc)
             return out.reshape(*lead, out.shape[-1]), 0
+
+    class StateVjpInFn(torch.autograd.Function):
+        """(params, psi, g, inputs) -> (dL/dparams, dL/dinputs): the cotangent of the input state of
+        ``Circuit(inputs=...)`` is lambda after the whole adjoint sweep (reference circuit.py:90-104 differentiates
+        through the input state)."""
+
+        generate_vmap_rule = False
+
+        @staticmethod
+        def forward(params, psi, g, cc, inp):
+            single = params.dim() == 1 and inp.dim() == 1
+            p2 = params.reshape(-1, params.shape[-1])
+            s2, g2 = psi.reshape(-1, psi.shape[-1]), g.reshape(-1, g.shape[-1])
+            if p2.shape[0] != s2.shape[0]:
+                p2 = p2.expand(s2.shape[0], -1)
+            gp, lam = cc.vjp(p2.contiguous(), s2, g2, inputs=inp, want_input_grad=True)
+            gin = lam[:, : inp.shape[-1]]
+            if inp.dim() == 1:
+                gin = gin.sum(0) if gin.shape[0] > 1 else gin[0]
+            else:
+                gin = gin.reshape(inp.shape)
+            if params.dim() == 1:
+                gp = gp.sum(0) if gp.shape[0] > 1 else gp[0]
+            return gp, gin.to(inp.dtype)
+
+        @staticmethod
+        def setup_context(ctx, inputs, output):
+            pass
+
+        @staticmethod
+        def backward(ctx, *a):
+            raise NotImplementedError("Backend 'hip' has not implemented second-order derivatives.")
 
     class MeasureFn(torch.autograd.Function):
         generate_vmap_rule = False
@@ -162,7 +202,8 @@ def _fns():
             out = MeasureVjpFn.apply(s.reshape(-1, s.shape[-1]).contiguous(), gg.reshape(-1, gg.shape[-1]).contiguous(), cm)
             return out.reshape(*lead, out.shape[-1]), 0
 
-    _FNS.update(StateFn=StateFn, StateVjpFn=StateVjpFn, MeasureFn=MeasureFn, MeasureVjpFn=MeasureVjpFn)
+    _FNS.update(StateFn=StateFn, StateVjpFn=StateVjpFn, StateVjpInFn=StateVjpInFn, MeasureFn=MeasureFn,
+                MeasureVjpFn=MeasureVjpFn)
     return _FNS
 
 
@@ -172,6 +213,11 @@ def circuit_state_full(circuit):
     params = circuit._param_tensor()
     inputs = circuit._input_tensor()
     if params is None:
+        if inputs is not None and _torch().is_tensor(inputs) and (
+                inputs.requires_grad or _torch()._C._functorch.is_functorch_wrapped_tensor(inputs)):
+            # no parametrised gate, but the input state is being differentiated: same primitive, empty parameter row
+            dummy = _torch().zeros(0, dtype=cc.rdtype, device=cc.device)
+            return _fns()["StateFn"].apply(dummy, cc, inputs)
         return cc.state(None, inputs, full=True)[0]
     return _fns()["StateFn"].apply(params, cc, inputs)
 

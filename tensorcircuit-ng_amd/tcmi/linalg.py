@@ -206,6 +206,8 @@ def svd_trunc(mat, max_singular_values: Optional[int] = None, max_truncation_err
     kk = static_keep
     if max_truncation_err is not None:
         kk = int(keep.item())
+        if kk < 0:   # the kernel poisons its outputs when its inter-workgroup barrier times out
+            raise _lib.TcmiError("tcmi_svd_trunc_batched: inter-workgroup barrier timed out (workgroups not co-resident)")
         if kk < static_keep:
             u, vh = u[:, :kk].contiguous(), vh[:kk, :].contiguous()
     return u, s[:kk].to(mat.dtype), vh, s[kk:].to(mat.dtype)

@@ -6,7 +6,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-from oracle import dm as odm, gates as G  # noqa: E402
+from oracle import channels as OC, dm as odm, gates as G  # noqa: E402
 
 
 @pytest.fixture(params=["complex64", "complex128"])
@@ -21,21 +21,20 @@ def tcd(request):
 
 def _build(tc, n, theta, ops=None):
     c = tc.DMCircuit(n)
-    ch = tc.channels
     rec = (lambda *a: ops.append(a)) if ops is not None else (lambda *a: None)
     for i in range(n):
         c.h(i); rec("u", G.H, [i])
     c.cnot(0, 1); rec("u", G.CNOT, [0, 1])
     c.rx(2, theta=theta); rec("u", G.rx(float(theta)), [2])
-    c.depolarizing(1, px=0.1, py=0.05, pz=0.02); rec("k", [k.tensor for k in ch.depolarizingchannel(0.1, 0.05, 0.02)], [1])
+    c.depolarizing(1, px=0.1, py=0.05, pz=0.02); rec("k", OC.depolarizing(0.1, 0.05, 0.02), [1])
     c.rzz(1, 2, theta=0.4); rec("u", G.rzz(0.4), [1, 2])
-    c.amplitudedamping(0, gamma=0.3, p=0.9); rec("k", [k.tensor for k in ch.amplitudedampingchannel(0.3, 0.9)], [0])
+    c.amplitudedamping(0, gamma=0.3, p=0.9); rec("k", OC.amplitudedamping(0.3, 0.9), [0])
     c.toffoli(0, 2, 3); rec("u", G.TOFFOLI, [0, 2, 3])
-    c.phasedamping(3, gamma=0.25); rec("k", [k.tensor for k in ch.phasedampingchannel(0.25)], [3])
+    c.phasedamping(3, gamma=0.25); rec("k", OC.phasedamping(0.25), [3])
     c.ry(3, theta=0.7); rec("u", G.ry(0.7), [3])
     c.reset(4) if n > 4 else None
     if n > 4:
-        rec("k", [k.tensor for k in ch.resetchannel()], [4])
+        rec("k", OC.reset(), [4])
     return c
 
 
@@ -77,3 +76,42 @@ def test_gradient_through_noisy_circuit(tcd):
     np.testing.assert_allclose(float(v), ref(0.37), atol=tol)
     eps = 1e-5
     np.testing.assert_allclose(float(g), (ref(0.37 + eps) - ref(0.37 - eps)) / (2 * eps), atol=2e-4 if tc.dtypestr == "complex64" else 1e-6)
+
+
+def test_gradient_of_a_parameter_before_a_channel(tcd):
+    """A parameter in FRONT of non-unitary super-gates with a non-zero true gradient: the adjoint sweep cannot
+    un-compute psi through a channel (U^dagger is not the inverse), the executor restarts from checkpoints
+    (executor.CompiledCircuit._vjp_segmented).  Finite differences of the dense density-matrix oracle."""
+    tc = tcd
+    n = 3
+
+    def build(t0, t1, ops=None):
+        c = tc.DMCircuit(n)
+        rec = (lambda *a: ops.append(a)) if ops is not None else (lambda *a: None)
+        c.ry(0, theta=t0); rec("u", G.ry(float(t0)), [0])
+        c.h(1); rec("u", G.H, [1])
+        c.cnot(0, 1); rec("u", G.CNOT, [0, 1])
+        c.amplitudedamping(0, gamma=0.35, p=0.8); rec("k", OC.amplitudedamping(0.35, 0.8), [0])
+        c.rx(0, theta=t1); rec("u", G.rx(float(t1)), [0])
+        c.depolarizing(1, px=0.05, py=0.1, pz=0.15); rec("k", OC.depolarizing(0.05, 0.1, 0.15), [1])
+        c.cnot(1, 2); rec("u", G.CNOT, [1, 2])
+        return c
+
+    def f(p):
+        c = build(p[0], p[1])
+        return tc.backend.real(c.expectation((tc.gates.z(), [0])) + 0.5 * c.expectation((tc.gates.x(), [2])))
+
+    def ref(p):
+        o = []
+        build(p[0], p[1], o)
+        rho = odm.run(n, o)
+        return np.real(odm.expectation(rho, n, (G.Z, [0])) + 0.5 * odm.expectation(rho, n, (G.X, [2])))
+
+    rdt = np.float32 if tc.rdtypestr == "float32" else np.float64
+    p0 = np.array([0.7, 1.3])
+    v, g = tc.backend.value_and_grad(f)(tc.backend.convert_to_tensor(p0.astype(rdt)))
+    np.testing.assert_allclose(float(v), ref(p0), atol=2e-5 if tc.dtypestr == "complex64" else 1e-9)
+    eps = 1e-5
+    fd = np.array([(ref(p0 + eps * e) - ref(p0 - eps * e)) / (2 * eps) for e in np.eye(2)])
+    assert np.abs(fd).min() > 0.05   # both true gradients are far from zero
+    np.testing.assert_allclose(tc.backend.numpy(g), fd, atol=3e-4 if tc.dtypestr == "complex64" else 1e-6)

@@ -437,3 +437,86 @@ def test_jit_plain_functions(tcd):
     for _ in range(3):
         np.testing.assert_allclose(_np(tc, jv(pb)), _np(tc, tc.backend.vmap(energy)(pb)), atol=tol)
     assert jv.stats["fast"] >= 1
+
+
+def test_gradient_through_a_non_unitary_gate(tcd):
+    """`any` with a non-unitary matrix between two rotations (round-1 advisor finding): gradients of the parameters in
+    front of it must come from checkpointed segments, not from un-computing psi with M^dagger."""
+    tc = tcd
+    n = 9
+    m = np.array([[1.0, 0.3], [0.1j, 0.8]])
+
+    def f(p):
+        c = tc.Circuit(n)
+        for i in range(n):
+            c.h(i)
+        c.ry(0, theta=p[0])
+        c.cnot(0, 1)
+        c.any(0, unitary=m)
+        c.rx(0, theta=p[1])
+        c.cnot(1, 2)
+        return tc.backend.real(c.expectation_ps(z=[0]) + c.expectation_ps(x=[1]))
+
+    def ref(p):
+        ops = [(G.H, [i]) for i in range(n)] + [(G.ry(p[0]), [0]), (G.CNOT, [0, 1]), (m, [0]), (G.rx(p[1]), [0]),
+                                                 (G.CNOT, [1, 2])]
+        psi = dense.run(n, ops)
+        z0 = 1 - 2 * ((np.arange(2**n) >> (n - 1)) & 1)
+        x1 = np.vdot(psi, psi.reshape(2, 2, -1)[:, ::-1].reshape(-1))
+        return float(np.real(np.vdot(psi, z0 * psi) + x1))
+
+    rdt = np.float32 if tc.rdtypestr == "float32" else np.float64
+    p0 = np.array([0.9, 0.4])
+    v, g = tc.backend.value_and_grad(f)(tc.backend.convert_to_tensor(p0.astype(rdt)))
+    np.testing.assert_allclose(float(v), ref(p0), atol=3e-5 if tc.dtypestr == "complex64" else 1e-9)
+    eps = 1e-5
+    fd = np.array([(ref(p0 + eps * e) - ref(p0 - eps * e)) / (2 * eps) for e in np.eye(2)])
+    np.testing.assert_allclose(tc.backend.numpy(g), fd, atol=5e-4 if tc.dtypestr == "complex64" else 1e-6)
+
+
+def test_gradient_with_respect_to_the_input_state(tcd):
+    """Circuit(inputs=psi): the reference differentiates through the input state (circuit.py:90-104).  Chained
+    circuits: the parameters of the first circuit reach the loss only through the second circuit's inputs."""
+    tc = tcd
+    n = 9
+
+    def f(p):
+        c1 = tc.Circuit(n)
+        for i in range(n):
+            c1.ry(i, theta=p[i])
+        c1.cnot(0, 1)
+        c2 = tc.Circuit(n, inputs=c1.state())
+        c2.h(2)
+        c2.rx(1, theta=p[n])
+        return tc.backend.real(c2.expectation_ps(z=[1]) + c2.expectation_ps(x=[2]))
+
+    def ref(p):
+        ops = [(G.ry(p[i]), [i]) for i in range(n)] + [(G.CNOT, [0, 1]), (G.H, [2]), (G.rx(p[n]), [1])]
+        psi = dense.run(n, ops)
+        z1 = 1 - 2 * ((np.arange(2**n) >> (n - 2)) & 1)
+        x2 = np.vdot(psi, psi.reshape(4, 2, -1)[:, ::-1].reshape(-1))
+        return float(np.real(np.vdot(psi, z1 * psi) + x2))
+
+    rdt = np.float32 if tc.rdtypestr == "float32" else np.float64
+    p0 = np.random.default_rng(3).uniform(0.2, 2.5, n + 1)
+    v, g = tc.backend.value_and_grad(f)(tc.backend.convert_to_tensor(p0.astype(rdt)))
+    np.testing.assert_allclose(float(v), ref(p0), atol=3e-5 if tc.dtypestr == "complex64" else 1e-9)
+    eps = 1e-5
+    fd = np.array([(ref(p0 + eps * e) - ref(p0 - eps * e)) / (2 * eps) for e in np.eye(n + 1)])
+    np.testing.assert_allclose(tc.backend.numpy(g), fd, atol=5e-4 if tc.dtypestr == "complex64" else 1e-6)
+
+
+def test_tensor_valued_gate_matrix_is_not_silently_constant(tcd):
+    """A gate matrix that is being differentiated cannot be baked into the plan as a constant: NotImplementedError
+    with the reference's wording instead of a silent zero gradient."""
+    tc = tcd
+    import torch
+
+    def f(m):
+        c = tc.Circuit(8)
+        c.any(0, unitary=m)
+        return tc.backend.real(c.expectation_ps(z=[0]))
+
+    m = torch.eye(2, dtype=torch.complex64 if tc.dtypestr == "complex64" else torch.complex128, device="cuda")
+    with pytest.raises(NotImplementedError, match="Backend 'hip' has not implemented"):
+        tc.backend.value_and_grad(f)(m)
