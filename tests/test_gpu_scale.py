@@ -1,0 +1,131 @@
+"""Parity at the sizes BASELINE.json quotes: mid-size circuits against the dense oracle with
+central-difference gradients, and the full-size configurations through size-independent properties
+(complex64 against complex128 of the same circuit, norms, canonical forms)."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dense, workloads as W  # noqa: E402
+
+
+def _energy_fn(tc, n, d):
+    def energy(p):
+        c = tc.Circuit(n)
+        W.hea_b(c, n, d, p, zz=tc.gates._zz_matrix)
+        e = 0.0
+        for i in range(n):
+            e += -1.0 * c.expectation((tc.gates.x(), [i]))
+        for i in range(n - 1):
+            e += 1.0 * c.expectation((tc.gates.z(), [i]), (tc.gates.z(), [i + 1]))
+        return tc.backend.real(e)
+
+    return energy
+
+
+@pytest.mark.parametrize("n,d", [(16, 4), (18, 3)])
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+def test_tfim_value_and_gradient_vs_dense_oracle(n, d, dtype):
+    """SURVEY 8d config 3 at n = 16, 18: energy and central-difference gradient components (eps = 1e-6, the
+    reference's own finite-difference step, tests/test_mpscircuit.py:452-457) from the dense complex128 oracle."""
+    import tcmi as tc
+
+    tc.set_backend("hip")
+    tc.set_dtype(dtype)
+    try:
+        params = np.random.default_rng(n).normal(0, 0.5, [2 * d, n])
+        rdt = np.float32 if dtype == "complex64" else np.float64
+        v, g = tc.backend.value_and_grad(_energy_fn(tc, n, d))(tc.backend.convert_to_tensor(params.astype(rdt)))
+        ref = lambda p: W.tfim_energy_dense(dense.run(n, W.hea_b_ops(n, d, p)), n)  # noqa: E731
+        e_ref = ref(params.astype(rdt).astype(np.float64))
+        assert abs(float(v) - e_ref) < (2e-4 if dtype == "complex64" else 1e-9)
+        g = tc.backend.numpy(g)
+        eps = 1e-6
+        comps = [(0, 0), (0, n - 2), (1, 0), (1, n - 1), (2 * d - 2, n // 2), (2 * d - 1, n // 2), (d, 3), (d + 1, n - 4)]
+        base = params.astype(rdt).astype(np.float64)
+        for (a, b) in comps:
+            pp, pm = base.copy(), base.copy()
+            pp[a, b] += eps
+            pm[a, b] -= eps
+            fd = (ref(pp) - ref(pm)) / (2 * eps)
+            assert abs(g[a, b] - fd) < (2e-4 if dtype == "complex64" else 1e-7), (a, b, g[a, b], fd)
+    finally:
+        tc.set_dtype("complex64")
+
+
+def test_config3_full_size_complex64_against_complex128():
+    """SURVEY 8d config 3 at full size (n = 28, depth 12, one sample of the bench's parameter generator): the
+    complex64 energy, state norm and gradient against a complex128 run of the same circuit (the c128 path runs on
+    different kernels: first-generation double-precision tile-VM and adjoint sweep, f64 trigonometry)."""
+    import torch
+    import tcmi as tc
+
+    n, d = 28, 12
+    params = np.random.default_rng(28).normal(0, 0.1, [2 * d, n])
+    tc.set_backend("hip")
+    out = {}
+    try:
+        for dtype in ("complex64", "complex128"):
+            tc.set_dtype(dtype)
+            rdt = np.float32 if dtype == "complex64" else np.float64
+            p = tc.backend.convert_to_tensor(params.astype(np.float32).astype(rdt))
+            v, g = tc.backend.jit(tc.backend.value_and_grad(_energy_fn(tc, n, d)))(p)
+            c = tc.Circuit(n)
+            W.hea_b(c, n, d, p, zz=tc.gates._zz_matrix)
+            psi = c.state()
+            nrm = float((psi.abs().to(torch.float64) ** 2).sum())
+            out[dtype] = (float(v), tc.backend.numpy(g).astype(np.float64), nrm)
+            del psi, c, v, g
+            torch.cuda.empty_cache()
+    finally:
+        tc.set_dtype("complex64")
+    (e64, g64, n64), (e128, g128, n128) = out["complex64"], out["complex128"]
+    assert abs(n128 - 1) < 1e-10 and abs(n64 - 1) < 1e-4, (n64, n128)
+    assert abs(e64 - e128) < 1e-4 * n, (e64, e128)
+    assert np.abs(g64 - g128).max() < 5e-4, np.abs(g64 - g128).max()
+    assert np.abs(g128).max() > 0.1   # the gradient is not trivially small
+
+
+def test_config5_full_size_mps_sweep_properties():
+    """SURVEY 8d config 5 at full size (n = 64, chi = 128, one TEBD sweep of random SU(4) gates): canonical form,
+    unit norm, bond dimensions, and the complex64 fidelity estimate against a complex128 sweep on the same tensors."""
+    import torch
+    from scipy.stats import unitary_group
+    import tcmi as tc
+
+    n, chi = 64, 128
+    rng = np.random.default_rng(64)
+    dims = [min(2 ** i, 2 ** (n - i), chi) for i in range(n + 1)]
+    tensors = [(rng.normal(size=(dims[i], 2, dims[i + 1])) + 1j * rng.normal(size=(dims[i], 2, dims[i + 1])))
+               / np.sqrt(2 * dims[i]) for i in range(n)]
+    gates = [unitary_group.rvs(4, random_state=5000 + i).reshape(2, 2, 2, 2) for i in range(n - 1)]
+    tc.set_backend("hip")
+    fid = {}
+    try:
+        for dtype, cdt in (("complex64", np.complex64), ("complex128", np.complex128)):
+            tc.set_dtype(dtype)
+            m = tc.MPSCircuit(n, tensors=[t.astype(cdt) for t in tensors],
+                              split=tc.cons.split_rules(max_singular_values=chi))
+            m.position(0)
+            nrm0 = float(abs(m.get_norm()))
+            for i in range(n - 1):
+                m.apply(tc.gates.Gate(gates[i].astype(cdt)), i, i + 1)
+            ts = m.get_tensors()
+            assert all(bool(torch.isfinite(t.abs()).all()) for t in ts)
+            assert max(m.get_bond_dimensions()) == chi
+            tol = 2e-3 if dtype == "complex64" else 1e-9
+            # the sweep leaves every site left of the centre left-orthogonal: sum_{l,s} conj(A[l,s,r]) A[l,s,r'] = 1
+            assert m.get_center_position() == n - 2   # the last gate leaves the centre on its first site
+            for site in (0, 7, 31, 61):
+                a = ts[site].to(torch.complex128)
+                gram = torch.einsum("lsr,lsq->rq", a.conj(), a)
+                assert float((gram - torch.eye(gram.shape[0], dtype=gram.dtype, device=gram.device)).abs().max()) < tol
+            fid[dtype] = (float(m._fidelity), nrm0, float(abs(m.get_norm())))
+    finally:
+        tc.set_dtype("complex64")
+    f64, f128 = fid["complex64"], fid["complex128"]
+    assert abs(f64[0] - f128[0]) < 2e-3 * max(f128[0], 1e-3), (f64, f128)
+    assert 0 < f128[0] < 1
+    # truncation only removes weight: the norm after the sweep is the start norm times sqrt of the kept weights
+    assert f128[2] <= f128[1] * (1 + 1e-9)

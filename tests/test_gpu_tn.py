@@ -362,18 +362,34 @@ def test_state_free_measurement_matches_state_route_and_scales_past_the_state(tc
     n = 8
     rng = np.random.default_rng(5)
     c = tc.Circuit(n)
+    ops_ref = []
     for d in range(3):
         for i in range(d % 2, n - 1, 2):
-            c.any(i, i + 1, unitary=G.random_two_qubit_gate(int(rng.integers(1 << 30))))
+            u = G.random_two_qubit_gate(int(rng.integers(1 << 30)))
+            c.any(i, i + 1, unitary=u)
+            ops_ref.append((np.asarray(u).reshape(4, 4), [i, i + 1]))
         for i in range(n):
-            c.rx(i, theta=float(rng.uniform(0, 6)))
+            th = float(rng.uniform(0, 6))
+            c.rx(i, theta=th)
+            ops_ref.append((G.rx(th), [i]))
     tol = 1e-5 if tc.dtypestr == "complex64" else 1e-10
+    from oracle import sampling as OS
+
+    psi_ref = dense.run(n, ops_ref)
     for seed in range(4):
         status = np.random.default_rng(seed).uniform(size=n)
         s1, p1 = c.measure(*range(n), with_prob=True, status=status, state_free=False)
         s2, p2 = c.measure(*range(n), with_prob=True, status=status, state_free=True)
         assert torch.equal(s1.cpu(), s2.cpu())
         np.testing.assert_allclose(float(p1), float(p2), rtol=20 * tol, atol=tol)
+        # the oracle: conditional marginals of the dense state with the reference's comparison rule
+        so, po = OS.measure(psi_ref, n, list(range(n)), status)
+        assert np.array_equal(s1.cpu().numpy().astype(int), so)
+        np.testing.assert_allclose(float(p1), po, rtol=20 * tol, atol=tol)
+    so, po = OS.measure(psi_ref, n, [5, 2], np.array([0.3, 0.9]))
+    s5, p5 = c.measure(5, 2, with_prob=True, status=np.array([0.3, 0.9]), state_free=True)
+    assert np.array_equal(s5.cpu().numpy().astype(int), so)
+    np.testing.assert_allclose(float(p5), po, rtol=20 * tol, atol=tol)
     s3, _ = c.measure(5, 2, status=np.array([0.3, 0.9]), state_free=True)
     s4, _ = c.measure(5, 2, status=np.array([0.3, 0.9]), state_free=False)
     assert torch.equal(s3.cpu(), s4.cpu())
