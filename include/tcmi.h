@@ -118,8 +118,10 @@ int tcmi_contract_scattered(const void* big, int rank, const int* pos, int nk, c
                             void* out, int big_first, int dtype, void* stream);
 
 /* Batched complex GEMM C[M x N] = A[M x K] . B[K x N], row-major interleaved complex, strides in
- * elements between batch members; trans_a != 0: A is stored [K x M] (k-major).  complex64 runs on the f32 MFMA pipe (exact f32 FMA);
- * complex128 on fp64 VALU.  Replaces backend.tensordot's GEMM (numpy/jax/torch BLAS in the reference). */
+ * elements between batch members; trans_a != 0: A is stored [K x M] (k-major).  complex64 runs on the f32 MFMA pipe
+ * (v_mfma_f32_32x32x2_f32, exact f32 FMA), complex128 on the f64 MFMA pipe (v_mfma_f64_16x16x4_f64); both issue
+ * Gauss's three real products per complex multiply.  Replaces backend.tensordot's GEMM (numpy/jax/torch BLAS in
+ * the reference, cons.py:948 -> backend.tensordot). */
 int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch,
                long long strideA, long long strideB, long long strideC, int trans_a, int dtype,
                void* stream);

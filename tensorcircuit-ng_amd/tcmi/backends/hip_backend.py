@@ -139,9 +139,23 @@ class HipBackend:
         n = int(round(np.sqrt(self.sizen(a))))
         return self.reshape(a, [n, n])
 
+    # ---- the ops the reference's contractor calls (cons.py:937-960; template backends/cupy_backend.py:85-99):
+    # complex tensors on the GPU go through libtcmi (tcmi_permute_bits / tcmi_cgemm / tcmi_contract_scattered),
+    # anything else (real dtypes, host tensors) is torch plumbing
+    def _on_hip(self, *ts: Any) -> bool:
+        torch = self._torch
+        return all(torch.is_tensor(t) and t.is_cuda and t.is_complex() for t in ts) and \
+            len({t.dtype for t in ts}) == 1
+
     def transpose(self, a: Tensor, perm: Optional[Sequence[int]] = None) -> Tensor:
         if perm is None:
             perm = tuple(range(a.dim() - 1, -1, -1))
+        perm = tuple(int(p) for p in perm)
+        # a materialised permutation of a [2]*rank tensor is the K2 kernel; small tensors stay views (no copy at all)
+        if self._on_hip(a) and a.dim() >= 2 and a.numel() >= 1024 and all(d == 2 for d in a.shape):
+            from .. import tn
+
+            return tn.permute(a, perm)
         return a.permute(*perm)
 
     def adjoint(self, a: Tensor) -> Tensor:
@@ -235,15 +249,53 @@ class HipBackend:
         return self._torch.kron(a, b)
 
     def matmul(self, a: Tensor, b: Tensor) -> Tensor:
+        if self._on_hip(a, b) and a.dim() == b.dim() and a.dim() in (2, 3) and a.shape[-1] == b.shape[-2] \
+                and (a.dim() == 2 or a.shape[0] == b.shape[0]) and a.numel() > 0 and b.numel() > 0:
+            from .. import linalg as LA
+
+            return LA.matmul(a, b)     # tcmi_cgemm (differentiable: its backward rule is two more tcmi_cgemm calls)
         return self._torch.matmul(a, b)
 
     def tensordot(self, a: Tensor, b: Tensor, axes) -> Tensor:
-        return self._torch.tensordot(a, b, dims=axes)
+        torch = self._torch
+        if not self._on_hip(a, b):
+            return torch.tensordot(a, b, dims=axes)
+        if isinstance(axes, int):
+            ax_a, ax_b = list(range(a.dim() - axes, a.dim())), list(range(axes))
+        else:
+            ax_a, ax_b = [int(x) % a.dim() for x in axes[0]], [int(x) % b.dim() for x in axes[1]]
+        if not ax_a:
+            return torch.tensordot(a, b, dims=0)
+        if all(d == 2 for d in a.shape) and all(d == 2 for d in b.shape):
+            from .. import tn
+
+            return tn.tensordot(a, b, ax_a, ax_b)   # permute_bits + cgemm, or the scattered big x small kernel
+        from .. import linalg as LA
+
+        fa = [i for i in range(a.dim()) if i not in ax_a]
+        fb = [i for i in range(b.dim()) if i not in ax_b]
+        K = int(np.prod([a.shape[i] for i in ax_a])) if ax_a else 1
+        a2 = a.permute(*(fa + ax_a)).reshape(-1, K)
+        b2 = b.permute(*(ax_b + fb)).reshape(K, -1)
+        out = LA.matmul(a2, b2)
+        return out.reshape([a.shape[i] for i in fa] + [b.shape[i] for i in fb])
 
     def outer_product(self, a: Tensor, b: Tensor) -> Tensor:
         return self._torch.tensordot(a, b, dims=0)
 
     def einsum(self, expression: str, *tensors: Tensor, optimize: bool = True) -> Tensor:
+        """Two-operand contractions without repeated or batch indices are a ``tensordot`` + ``transpose`` on the
+        HIP kernels; every other expression is evaluated by torch."""
+        expr = expression.replace(" ", "")
+        if len(tensors) == 2 and "->" in expr and "." not in expr and self._on_hip(*tensors):
+            lhs, out = expr.split("->")
+            ia, ib = lhs.split(",")
+            if len(set(ia)) == len(ia) and len(set(ib)) == len(ib) and len(set(out)) == len(out):
+                shared = [c for c in ia if c in ib]
+                if shared and not any(c in out for c in shared) and set(out) == (set(ia) | set(ib)) - set(shared):
+                    r = self.tensordot(tensors[0], tensors[1], [[ia.index(c) for c in shared], [ib.index(c) for c in shared]])
+                    cur = [c for c in ia if c not in shared] + [c for c in ib if c not in shared]
+                    return self.transpose(r, [cur.index(c) for c in out]) if cur != list(out) else r
         return self._torch.einsum(expression, *tensors)
 
     def trace(self, a: Tensor) -> Tensor:

@@ -56,6 +56,52 @@ class _Op:
         self.name = name
 
 
+def _split_can_truncate(split_conf) -> bool:
+    if not split_conf:
+        return False
+    k = split_conf.get("max_singular_values")
+    err = split_conf.get("max_truncation_err")
+    return (k is not None and int(k) < 4) or (err is not None and float(err) > 0.0)
+
+
+def _split_truncate(m, split_conf):
+    """The reference's two-qubit gate split (basecircuit.py:231-275, simplify.py:88-128): the gate tensor is SVD-split
+    between the two qubits -- legs (out0, in0) | (out1, in1), or the swapped pairing (out0, in1) | (out1, in0) when
+    only ``max_truncation_err`` is given and that pairing keeps fewer values -- and truncated with tensornetwork's
+    rule (keep min(max_singular_values, #{i: sqrt(sum_{j>=i} s_j^2) > max_truncation_err})).  Contracting the two
+    halves again gives this truncated 4x4 matrix, which is what the plan applies; without truncation the split is
+    exact and the gate is left alone."""
+    if not _split_can_truncate(split_conf):
+        return m
+    k = split_conf.get("max_singular_values")
+    err = split_conf.get("max_truncation_err")
+    fixed = split_conf.get("fixed_choice")
+    if k is not None and fixed is None:
+        fixed = 1
+    t = np.asarray(m, dtype=np.complex128).reshape(2, 2, 2, 2)   # [out0, out1, in0, in1]
+
+    def trunc(perm):
+        a = t.transpose(perm).reshape(4, 4)
+        u, sv, vh = np.linalg.svd(a)
+        keep = 4 if k is None else min(int(k), 4)
+        if err is not None:
+            tail = np.sqrt(np.cumsum(sv[::-1] ** 2))[::-1]          # tail[i] = sqrt(sum_{j >= i} s_j^2)
+            keep = min(keep, int(np.count_nonzero(tail > float(err))))
+        rec = (u[:, :keep] * sv[:keep]) @ vh[:keep]
+        inv = np.argsort(perm)
+        return keep, rec.reshape(2, 2, 2, 2).transpose(inv).reshape(4, 4)
+
+    k1, m1 = trunc((0, 2, 1, 3))
+    if fixed == 1:
+        return m1
+    k2, m2 = trunc((0, 3, 1, 2))
+    if fixed == 2:
+        return m2
+    if k1 >= 4 and k2 >= 4:
+        return m
+    return m1 if k1 <= k2 else m2
+
+
 def _constant_value(t, what):
     """numpy value of a matrix-like gate argument that is baked into the plan as a constant.  A tensor that is being
     differentiated (requires_grad) or transformed (vmap / grad wrappers) cannot be a constant: the reference would
@@ -121,8 +167,10 @@ class Circuit:
                 lazy.materialize()
         self._pending.clear()
 
-    def _record_const(self, matrix, index, name):
+    def _record_const(self, matrix, index, name, split_conf=None):
         self._flush_pending()
+        if split_conf is None:
+            split_conf = self.split
         index = self._norm_index(index)
         m = np.asarray(matrix, dtype=np.complex128)
         d = 2 ** len(index)
@@ -131,6 +179,8 @@ class Circuit:
         m = m.reshape(d, d)
         if getattr(self, "_conj", False):   # bra side of a density-matrix circuit (tcmi/densitymatrix.py)
             m = m.conj()
+        if len(index) == 2 and split_conf:
+            m = _split_truncate(m, split_conf)
         if len(index) > 2:
             # dense gates on > 2 qubits (toffoli, fredkin, any(...)): exact plan-time synthesis into
             # <= 2-qubit dense + diagonal gates (tcmi/synth.py); unitary input required
@@ -150,6 +200,10 @@ class Circuit:
     def _record_specs(self, specs, index, name, parameters):
         self._flush_pending()
         index = self._norm_index(index)
+        if len(index) == 2 and _split_can_truncate(self.split):
+            raise NotImplementedError(
+                "Backend 'hip' has not implemented a truncating `split` rule for parametrised two-qubit gates "
+                "(constant gates are truncated at record time).")
         if getattr(self, "_conj", False):
             specs = [G.TrigSpec(np.conj(sp.c0), np.conj(sp.c1), np.conj(sp.c2), sp.theta, sp.scale, sp.offset, sp.name)
                      for sp in specs]
@@ -167,7 +221,7 @@ class Circuit:
         if kws.get("mpo") or kws.get("diagonal"):
             raise NotImplementedError("mpo / diagonal gate formats are not supported on the hip backend")
         t = gate.tensor if isinstance(gate, G.Gate) else gate
-        self._record_const(_constant_value(t, "gate matrix"), index, name or "")
+        self._record_const(_constant_value(t, "gate matrix"), index, name or "", split_conf=kws.get("split"))
 
     apply = apply_general_gate
 
@@ -234,7 +288,7 @@ class Circuit:
                 )
         elif name == "any":
             unitary = kw.get("unitary")
-            return self.apply_general_gate(unitary, *index, name=kw.get("name", "any"))
+            return self.apply_general_gate(unitary, *index, name=kw.get("name", "any"), split=kw.get("split"))
         elif name == "su4":
             theta = _constant_value(kw.get("theta"), "su4 parameter vector")
             return self._record_const(G.matrix_for_gate(G.su4_gate(theta)), index, "su4")

@@ -78,28 +78,51 @@ _KNOWN_CONTRACTORS = (
 def set_contractor(method: Optional[str] = None, optimizer: Any = None, memory_limit: Any = None,
                    opt_conf: Any = None, set_global: bool = True, contraction_info: bool = False,
                    debug_level: int = 0, **kws: Any) -> Callable[..., Any]:
-    """reference cons.py:1123-1261.
+    """reference cons.py:1123-1261.  Returns (and installs as ``tc.contractor``) the callable
 
-    On the hip backend a state-vector contraction always executes as a compiled tile-VM plan
-    (state-vector order with cache/register blocking, see ``tcmi/plan.py``); the result is
-    path-independent up to rounding, so the reference's path-finder names are accepted for API
-    compatibility and select that executor.  Plan tuning knobs may be passed as keywords:
-    ``lowbits`` (coalescing run, default 5), ``R`` / ``LT`` (register / thread bits).
-    ``cotengra-*`` / ``omeco-*`` strings are accepted likewise (reference cons.py:1166-1219)."""
+        contractor(nodes, output_edge_order=None, ignore_edge_order=False) -> Node
+
+    of the reference's contractor plug-in contract (cons.py:377-382, 845-896), executed on the HIP tensordot engine
+    (``tcmi.tn.contract_nodes``).  ``method``:
+
+    * ``"custom"``: ``optimizer`` is the path finder ``f(input_sets, output_set, size_dict, memory_limit)`` or a
+      precomputed list path (cons.py:1037-1040); ``"custom_stateful"``: ``optimizer`` is a class instantiated with
+      ``opt_conf`` for every contraction (cons.py:1062-1081);
+    * the reference's path-finder names (``greedy``, ``branch``, ``optimal``, ``auto``, ``tng``, ``plain``,
+      ``cotengra*``, ``omeco*``) select the built-in search: greedy, or random-greedy + subtree reconfiguration for
+      the names that ask for more than greedy; the result of a contraction does not depend on the path;
+    * ``"tilevm"`` / ``"cut"`` (not in the reference) force the two state-vector execution orders of ``Circuit``.
+
+    ``debug_level`` 1 / 2: contractions return zeros of the right shape without arithmetic (cons.py:928-934);
+    ``contraction_info``: cost of every contraction is printed (cons.py:1084-1120).  Whole-circuit state vectors do not
+    go through this callable: ``Circuit.wavefunction`` runs the compiled tile-VM plan, whose tuning knobs may be
+    passed here as ``lowbits`` / ``R`` / ``LT``."""
     if not method:
         method = "greedy"
     base = method.split("-")[0]
     if method not in _KNOWN_CONTRACTORS and base not in ("cotengra", "omeco"):
         raise ValueError("Unknown contractor type: %s" % method)
-    opts = {k: v for k, v in kws.items() if k in ("lowbits", "R", "LT")}
-    opts["debug_level"] = debug_level
-    opts["contraction_info"] = contraction_info
+    plan_keys = ("lowbits", "R", "LT")
+    # any further keyword travels, as in the reference, into the contractor call where ``_base(**kws)`` ignores it
+    # (cons.py:852, 1229-1258: e.g. the ``max_time`` / ``minimize`` of tests/test_circuit.py:929-937)
+    opts = {k: v for k, v in kws.items() if k in plan_keys}
+    opts["debug_level"] = int(debug_level)
+    opts["contraction_info"] = bool(contraction_info)
+    trials = 0 if method in ("greedy", "plain", "plain-experimental", "tng", "tilevm", "cut") else 16
 
-    def cf(*args: Any, **kwargs: Any) -> Any:
-        raise NotImplementedError(
-            "the hip backend contracts whole circuits through its plan executor; a node-list "
-            "contractor call is only available on the reference's CPU backends"
-        )
+    def cf(nodes: Any, output_edge_order: Any = None, ignore_edge_order: bool = False, **ckws: Any) -> Any:
+        from . import tn
+
+        opt = None
+        if method in ("custom", "custom_stateful") and optimizer is None:
+            raise ValueError("set_contractor(%r) needs an `optimizer`" % method)
+        if method == "custom":
+            opt = optimizer
+        elif method == "custom_stateful":
+            opt = optimizer(**(opt_conf or {}))
+        return tn.contract_nodes(list(nodes), output_edge_order, ignore_edge_order=ignore_edge_order, optimizer=opt,
+                                 memory_limit=memory_limit, debug_level=int(ckws.get("debug_level", debug_level)),
+                                 info=bool(contraction_info), trials=trials)
 
     cf.method = method  # type: ignore
     cf.plan_options = opts  # type: ignore

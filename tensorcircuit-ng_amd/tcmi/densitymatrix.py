@@ -67,7 +67,7 @@ class DMCircuit:
             raise NotImplementedError("Backend 'hip' has not implemented multi-qubit Kraus channels.")
         ket, bra = self._pair(index)
         sup = CH.kraus_to_super_gate(kraus)                       # [ket', bra'; ket, bra]
-        self._c._record_const(sup, (ket[0], bra[0]), "kraus")
+        self._c._record_const(sup, (ket[0], bra[0]), "kraus", split_conf={})
 
     general_kraus = apply_general_kraus
 

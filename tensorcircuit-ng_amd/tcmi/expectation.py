@@ -72,6 +72,13 @@ def _circuit_full_state(circuit):
 
     st = getattr(circuit, "state_tensor", None)
     if st is None:
+        if cons._plan_options.get("debug_level"):
+            # set_contractor(debug_level=1 / 2): no contraction is executed, results are zeros of the right shape
+            # (reference cons.py:928-934; KAT tests/test_circuit.py:922-946)
+            from .executor import pick_variant
+
+            n_exec, _ = pick_variant(circuit._nqubits, cons.dtypestr, cons._plan_options)
+            return cons.backend.zeros([2**n_exec], dtype=cons.dtypestr)
         st = circuit_state_full(circuit)
         circuit.state_tensor = st
     return st

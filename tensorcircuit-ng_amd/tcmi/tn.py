@@ -996,22 +996,67 @@ def contract_between(na: Node, nb: Node) -> Node:
     return Node(t, [e for e in na.edges if e not in shared] + [e for e in nb.edges if e not in shared])
 
 
-def contract_nodes(nodes: Sequence[Node], output_edge_order: Optional[Sequence[int]] = None,
-                   target_size: Optional[int] = None):
-    """The contractor call of the reference (``contractor(nodes, output_edge_order=...)``,
-    cons.py:845-961) on the HIP engine: greedy path, optional slicing, pairwise GEMMs.  Returns a Node."""
+def edge_symbol(i: int) -> str:
+    """opt_einsum.get_symbol: the letters a-zA-Z, then unicode from chr(192) on (the symbols a path finder plugged in
+    through ``set_contractor("custom", optimizer=f)`` receives; reference cons.py:783-800)."""
+    letters = "abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ"
+    return letters[i] if i < 52 else chr(i + 140)
+
+
+def symbolic_info(nodes: Sequence[Node]):
+    """(input_sets, output_set, size_dict) in the form the reference hands to a path finder: one symbol per edge,
+    edges numbered by first appearance (reference cons._get_path_cache_friendly, cons.py:773-800)."""
     inputs, output, size_dict = get_tn_info(nodes)
-    if output_edge_order is None:
-        if len(output) > 1:
-            raise ValueError(
-                "The final node after contraction has more than one remaining edge. "
-                "In this case `output_edge_order` has to be provided."
-            )
+    num: Dict[int, int] = {}
+    for s_ in inputs:
+        for e in s_:
+            num.setdefault(e, len(num))
+    sym = {e: edge_symbol(k) for e, k in num.items()}
+    return ([[sym[e] for e in s_] for s_ in inputs], [sym[e] for e in output], {sym[e]: v for e, v in size_dict.items()})
+
+
+def contract_nodes(nodes: Sequence[Node], output_edge_order: Optional[Sequence[int]] = None,
+                   target_size: Optional[int] = None, ignore_edge_order: bool = False, optimizer: Any = None,
+                   memory_limit: Any = None, debug_level: int = 0, info: bool = False, trials: int = 0):
+    """The contractor call of the reference (``contractor(nodes, output_edge_order=..., ignore_edge_order=...)``,
+    ``_base`` at cons.py:845-961) on the HIP engine: pairwise path -> ``tcmi_cgemm`` / ``tcmi_contract_scattered`` /
+    ``tcmi_permute_bits`` steps, result axes in ``output_edge_order``.  Returns a Node.
+
+    ``optimizer``: the path-finder plug-in of ``set_contractor("custom", optimizer=...)``: a callable
+    ``f(input_sets, output_set, size_dict, memory_limit=None) -> [(i, j), ...]`` in opt_einsum's linear format, or a
+    precomputed list path (cons.py:1037-1040, 949-950); default: the built-in (random-)greedy search.
+    ``debug_level`` 1 / 2: no arithmetic, zeros of the output shape (cons.py:928-934).  Errors as cons.py:877-896."""
+    inputs, output, size_dict = get_tn_info(nodes)
+    if not ignore_edge_order:
+        if output_edge_order is None:
+            if len(output) > 1:
+                raise ValueError(
+                    "The final node after contraction has more than one remaining edge. "
+                    "In this case `output_edge_order` has to be provided."
+                )
+            output_edge_order = output
+        if set(output_edge_order) != set(output):
+            raise ValueError("output edges are not equal to the remaining non-contracted edges of the final node.")
+    else:
         output_edge_order = output
-    if set(output_edge_order) != set(output):
-        raise ValueError("output edges are not equal to the remaining non-contracted edges of the final node.")
-    tree = ContractionTree.from_path(inputs, list(output_edge_order), size_dict)
     arrays = [n.tensor for n in nodes]
+    if debug_level:
+        ref = arrays[0]
+        z = cons.backend.zeros([size_dict[e] for e in output_edge_order], dtype=str(ref.dtype).split(".")[-1])
+        return Node(z, list(output_edge_order))
+    path = None
+    if optimizer is not None:
+        if isinstance(optimizer, (list, tuple)):
+            path = [tuple(int(x) for x in ab) for ab in optimizer]
+        else:
+            sin, sout, ssz = symbolic_info(nodes)
+            path = [tuple(int(x) for x in ab) for ab in optimizer(sin, sout, ssz, memory_limit=memory_limit)]
+        path = [ab for ab in path if len(ab) == 2]   # single-element entries are skipped (cons.py:943-945)
+    tree = ContractionTree.from_path(inputs, list(output_edge_order), size_dict, path=path, trials=trials)
+    if info:
+        print("contraction cost: log2[FLOPs] = %.3f  log2[WRITE] = %.3f  log2[SIZE] = %.1f" % (
+            float(np.log2(max(tree.total_flops(), 1))), float(np.log2(max(tree.total_write(), 1))),
+            float(tree.contraction_width())))
     if target_size is not None:
         tree.slice_to(target_size)
     if not tree.sliced_inds:

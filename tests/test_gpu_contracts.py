@@ -1,0 +1,216 @@
+"""The reference's plug-in contracts on the hip backend: the contractor callable, the custom path
+finder, debug levels, the two-qubit gate split rule, and the backend ops the contractor calls."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dense, gates as G, workloads as W  # noqa: E402
+
+
+@pytest.fixture(params=["complex64", "complex128"])
+def tcd(request):
+    import tcmi as tc
+
+    tc.set_backend("hip")
+    tc.set_dtype(request.param)
+    yield tc
+    tc.set_dtype("complex64")
+    tc.set_contractor("greedy")
+
+
+def _np(tc, x):
+    return tc.backend.numpy(x)
+
+
+def _merge_circuit(tc, n=6, depth=4, ops=None):
+    """reference tests/test_circuit.py:2260-2272 (``_build_merge_circuit``)."""
+    c = tc.Circuit(n)
+    for d in range(depth):
+        for i in range(n):
+            c.h(i); c.rz(i, theta=0.3 * (i + 1)); c.rx(i, theta=0.2 * (d + 1))
+            if ops is not None:
+                ops += [(G.H, [i]), (G.rz(0.3 * (i + 1)), [i]), (G.rx(0.2 * (d + 1)), [i])]
+        for i in range(n - 1):
+            c.cnot(i, i + 1)
+            if ops is not None:
+                ops.append((G.CNOT, [i, i + 1]))
+    return c
+
+
+def test_contractor_equivalence_kat(tcd):
+    """reference tests/test_circuit.py:2274-2292: every contractor gives the same state; here additionally the node-list
+    contractor call on the circuit's own network reproduces it."""
+    tc = tcd
+    ops = []
+    expected = _np(tc, _merge_circuit(tc, ops=ops).state())
+    tol = 1e-5 if tc.dtypestr == "complex64" else 1e-10
+    np.testing.assert_allclose(expected, dense.run(6, ops), atol=tol)
+    for name, kw in (("greedy", {"preprocessing": True}), ("plain-experimental", {"local_steps": 3}), ("branch", {}),
+                     ("optimal", {}), ("auto", {})):
+        with tc.runtime_contractor(name, **kw):
+            np.testing.assert_allclose(_np(tc, _merge_circuit(tc).state()), expected, rtol=1e-5, atol=1e-5)
+    # the contractor callable on the uncontracted amplitude network (basecircuit.py:562-624)
+    c = _merge_circuit(tc)
+    bits = "010110"
+    for name in ("greedy", "branch"):
+        cf = tc.set_contractor(name)
+        amp = cf(c.amplitude_before(bits)).tensor
+        np.testing.assert_allclose(complex(_np(tc, amp)), expected[int(bits, 2)], atol=tol)
+    assert tc.contractor is cf
+
+
+def test_custom_path_finder_plugin(tcd):
+    """set_contractor("custom", optimizer=f): f(input_sets, output_set, size_dict, memory_limit) -> linear path
+    (reference cons.py:800, 1037-1040); a precomputed list path; custom_stateful with a class."""
+    tc = tcd
+    c = _merge_circuit(tc, n=5, depth=2)
+    want = complex(_np(tc, c.state())[0b10110])
+    tol = 1e-5 if tc.dtypestr == "complex64" else 1e-10
+    calls = []
+
+    def naive(input_sets, output_set, size_dict, memory_limit=None):
+        # always contract the two first tensors of the current list: a valid, bad path
+        assert all(isinstance(s, list) and all(isinstance(x, str) and len(x) == 1 for x in s) for s in input_sets)
+        assert set(size_dict.values()) == {2} and output_set == []
+        calls.append((len(input_sets), memory_limit))
+        return [(0, 1)] * (len(input_sets) - 1)
+
+    cf = tc.set_contractor("custom", optimizer=naive, memory_limit=123)
+    amp = cf(c.amplitude_before("10110")).tensor
+    np.testing.assert_allclose(complex(_np(tc, amp)), want, atol=tol)
+    assert calls and calls[0][1] == 123
+    nn = calls[0][0]
+    cf = tc.set_contractor("custom", optimizer=[(0, 1)] * (nn - 1))          # precomputed list path
+    np.testing.assert_allclose(complex(_np(tc, cf(c.amplitude_before("10110")).tensor)), want, atol=tol)
+
+    class Finder:
+        def __init__(self, tag="x"):
+            self.tag = tag
+
+        def __call__(self, input_sets, output_set, size_dict, memory_limit=None):
+            return [(len(input_sets) - 2 - k, len(input_sets) - 1 - k) for k in range(len(input_sets) - 1)]
+
+    cf = tc.set_contractor("custom_stateful", optimizer=Finder, opt_conf={"tag": "y"}, max_time=10, minimize="size")
+    np.testing.assert_allclose(complex(_np(tc, cf(c.amplitude_before("10110")).tensor)), want, atol=tol)
+    with pytest.raises(ValueError, match="needs an `optimizer`"):
+        tc.set_contractor("custom")(c.amplitude_before("10110"))
+
+
+def test_contractor_call_errors_and_edge_order(tcd):
+    """reference cons.py:877-896: more than one dangling edge needs output_edge_order; a wrong order is rejected;
+    the result axes follow output_edge_order."""
+    tc = tcd
+    import torch
+    from tcmi import tn
+
+    cdt = torch.complex64 if tc.dtypestr == "complex64" else torch.complex128
+    rng = np.random.default_rng(0)
+    a = torch.tensor(rng.normal(size=(2, 2, 2)) + 1j * rng.normal(size=(2, 2, 2)), dtype=cdt, device="cuda")
+    b = torch.tensor(rng.normal(size=(2, 2, 2)) + 1j * rng.normal(size=(2, 2, 2)), dtype=cdt, device="cuda")
+    e = [tn.new_edge() for _ in range(5)]
+    mk = lambda: [tn.Node(a, [e[0], e[1], e[2]]), tn.Node(b, [e[2], e[3], e[4]])]  # noqa: E731
+    cf = tc.set_contractor("greedy")
+    with pytest.raises(ValueError, match="more than one remaining edge"):
+        cf(mk())
+    with pytest.raises(ValueError, match="not equal to the remaining"):
+        cf(mk(), output_edge_order=[e[0], e[1]])
+    out = cf(mk(), output_edge_order=[e[4], e[0], e[3], e[1]])
+    ref = np.einsum("abk,kcd->dacb", a.cpu().numpy(), b.cpu().numpy())
+    np.testing.assert_allclose(_np(tc, out.tensor), ref, atol=1e-5)
+    free = cf(mk(), ignore_edge_order=True)
+    assert sorted(free.edges) == sorted([e[0], e[1], e[3], e[4]])
+
+
+def test_debug_level_returns_zeros(tcd):
+    """reference tests/test_circuit.py:922-946: example_block n=10 d=4 with debug_level=2 -> zeros of shape 2^10."""
+    tc = tcd
+    n, d = 10, 4
+
+    @tc.set_function_contractor("greedy", debug_level=2, contraction_info=True)
+    def small_tn():
+        param = tc.backend.ones([2 * d, n])
+        c = tc.Circuit(n)
+        W.hea_b(c, n, d, param, zz=tc.gates._zz_matrix)
+        return c.state()
+
+    out = _np(tc, small_tn())
+    assert out.shape == (2**n,)
+    np.testing.assert_allclose(out, np.zeros([2**n]), atol=1e-5)
+    c = tc.Circuit(4)
+    c.h(0)
+    z = tc.set_contractor("greedy", debug_level=2)(c.amplitude_before("0000"))
+    assert complex(_np(tc, z.tensor)) == 0
+    tc.set_contractor("greedy")
+    assert abs(complex(_np(tc, tc.contractor(c.amplitude_before("0000")).tensor)) - 2 ** -0.5) < 1e-6
+
+
+def test_split_rule_truncates_like_the_reference(tcd):
+    """Circuit(split=...) (reference basecircuit.py:231-275, simplify.py:88-128): a two-qubit gate is replaced by its
+    truncated operator-Schmidt form; no truncation -> unchanged."""
+    tc = tcd
+    n = 8
+    u = np.asarray(G.random_two_qubit_gate(11)).reshape(4, 4)
+
+    def run(split):
+        c = tc.Circuit(n, split=split)
+        for i in range(n):
+            c.h(i)
+        c.any(2, 3, unitary=u)
+        c.cnot(3, 4)
+        c.any(5, 6, unitary=u, split={"max_singular_values": 4})   # per-gate rule that cannot truncate
+        return _np(tc, c.state())
+
+    def oracle(mat):
+        ops = [(G.H, [i]) for i in range(n)] + [(mat, [2, 3]), (G.CNOT, [3, 4]), (u, [5, 6])]
+        return dense.run(n, ops)
+
+    tol = 1e-5 if tc.dtypestr == "complex64" else 1e-10
+    np.testing.assert_allclose(run(None), oracle(u), atol=tol)
+    np.testing.assert_allclose(run({"max_singular_values": 4}), oracle(u), atol=tol)
+    # rank-2 truncation on the (out0, in0) | (out1, in1) split
+    t = u.reshape(2, 2, 2, 2).transpose(0, 2, 1, 3).reshape(4, 4)
+    uu, sv, vh = np.linalg.svd(t)
+    m2 = ((uu[:, :2] * sv[:2]) @ vh[:2]).reshape(2, 2, 2, 2).transpose(0, 2, 1, 3).reshape(4, 4)
+    got = run({"max_singular_values": 2})
+    cn = np.eye(4)[[0, 1, 3, 2]]
+    t2 = cn.reshape(2, 2, 2, 2).transpose(0, 2, 1, 3).reshape(4, 4)
+    u2, s2, v2 = np.linalg.svd(t2)   # CNOT has operator-Schmidt rank 2: unchanged by the rank-2 rule
+    ops = [(G.H, [i]) for i in range(n)] + [(m2, [2, 3]), (G.CNOT, [3, 4]), (u, [5, 6])]
+    np.testing.assert_allclose(got, dense.run(n, ops), atol=tol)
+    with pytest.raises(NotImplementedError, match="Backend 'hip' has not implemented"):
+        c = tc.Circuit(4, split={"max_singular_values": 2})
+        c.rzz(0, 1, theta=0.3)
+        c.rxx(0, 1, theta=0.3)
+
+
+def test_backend_ops_run_on_the_hip_kernels(tcd):
+    """backend.tensordot / transpose / einsum / matmul on complex GPU tensors (template: reference
+    backends/cupy_backend.py:85-99) against numpy."""
+    tc = tcd
+    import torch
+
+    K = tc.backend
+    cdt = torch.complex64 if tc.dtypestr == "complex64" else torch.complex128
+    rng = np.random.default_rng(1)
+    rnd = lambda *s: rng.normal(size=s) + 1j * rng.normal(size=s)  # noqa: E731
+    tol = 1e-4 if tc.dtypestr == "complex64" else 1e-10
+    a, b = rnd(*[2] * 12), rnd(*[2] * 5)
+    ta, tb = torch.tensor(a, dtype=cdt, device="cuda"), torch.tensor(b, dtype=cdt, device="cuda")
+    np.testing.assert_allclose(_np(tc, K.tensordot(ta, tb, [[3, 7], [1, 4]])), np.tensordot(a, b, [[3, 7], [1, 4]]), atol=tol)
+    np.testing.assert_allclose(_np(tc, K.tensordot(ta, tb, 2)), np.tensordot(a, b, 2), atol=tol)
+    perm = list(rng.permutation(12))
+    np.testing.assert_allclose(_np(tc, K.transpose(ta, perm)), a.transpose(perm), atol=tol)
+    m1, m2 = rnd(6, 10), rnd(10, 7)
+    t1, t2 = torch.tensor(m1, dtype=cdt, device="cuda"), torch.tensor(m2, dtype=cdt, device="cuda")
+    np.testing.assert_allclose(_np(tc, K.matmul(t1, t2)), m1 @ m2, atol=tol)
+    g1, g2 = rnd(3, 4, 5), rnd(5, 4, 6)     # general (non-qubit) dimensions
+    np.testing.assert_allclose(_np(tc, K.tensordot(torch.tensor(g1, dtype=cdt, device="cuda"),
+                                                  torch.tensor(g2, dtype=cdt, device="cuda"), [[1, 2], [1, 0]])),
+                               np.tensordot(g1, g2, [[1, 2], [1, 0]]), atol=tol)
+    np.testing.assert_allclose(_np(tc, K.einsum("abcde,xbyd->exayc", tb, torch.tensor(a[0, 0, 0, 0, 0, 0, 0, 0], dtype=cdt, device="cuda"))),
+                               np.einsum("abcde,xbyd->exayc", b, a[0, 0, 0, 0, 0, 0, 0, 0]), atol=tol)
+    # real tensors / odd expressions stay on torch
+    r = torch.tensor(rng.normal(size=(4, 4)), device="cuda")
+    np.testing.assert_allclose(_np(tc, K.einsum("ii->", r)), np.trace(r.cpu().numpy()), atol=1e-6)
