@@ -353,6 +353,29 @@ def rqc_leg(tc, torch, dist, args, rank, world):
     t = time.perf_counter() - t0
     cnt, TN.COUNTERS = TN.COUNTERS, None
     tree = dc.tree
+    # slice-invariant work is repeated on every rank: time one slice and all local slices to split t = t_inv + S t_slice
+    # (what an 8-GPU run can gain: experimental.py:881-890 gives each rank ceil(S / G) slices)
+    split = None
+    if tree.nslices > 1 and len(dc.my_slices) > 1:
+        arrays = dc._arrays(None)
+
+        def run(ids):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for r_ in tree.contract_slices(arrays, ids):
+                pass
+            torch.cuda.synchronize()
+            return time.perf_counter() - t1
+
+        run(dc.my_slices[:1])
+        t_one = min(run(dc.my_slices[:1]) for _ in range(3))
+        t_all = min(run(dc.my_slices) for _ in range(3))
+        S = len(dc.my_slices)
+        t_slice = max(0.0, (t_all - t_one) / (S - 1))
+        t_inv = max(0.0, t_one - t_slice)
+        split = {"slice_invariant_s": t_inv, "per_slice_s": t_slice, "local_slices": S,
+                 "invariant_fraction_of_one_slice_run": t_inv / max(t_one, 1e-12),
+                 "projected_speedup_8_ranks": t_all / (t_inv + t_slice * -(-tree.nslices // 8))}
     flops = float(tree.total_flops())          # all slices (ContractionTree.total_flops includes nslices)
     steps, dep, _, _ = tree._symbolic_steps()
     n_inv = sum(1 for st in steps if not dep[st[4]])   # slice-invariant steps: computed once per rank
@@ -362,7 +385,7 @@ def rqc_leg(tc, torch, dist, args, rank, world):
         "nslices": int(tree.nslices), "slices_per_gpu": int(-(-tree.nslices // world)),
         "contraction_width": float(tree.contraction_width()), "log2_flops_total": float(np.log2(flops)),
         "contract_s": t, "tflops": flops / t / 1e12, "path_search_s": round(search_s, 2),
-        "steps_per_slice": len(steps), "slice_invariant_steps": n_inv,
+        "steps_per_slice": len(steps), "slice_invariant_steps": n_inv, "time_split": split,
         "amplitude": [float(v.real), float(v.imag)],
         # F_alg of the executed (sliced, slice-invariant parts once) steps over the wall time against the f32 MFMA
         # peak; stand-alone permutes are traffic outside B_alg ("wasted")
