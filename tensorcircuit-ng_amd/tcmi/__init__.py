@@ -21,6 +21,7 @@ npdtype = cons.npdtype
 contractor = None
 
 from . import gates  # noqa: E402,F401
+from .gates import array_to_tensor, num_to_tensor  # noqa: E402,F401
 from . import plan  # noqa: E402,F401
 from .circuit import Circuit  # noqa: E402,F401
 from .mpscircuit import MPSCircuit  # noqa: E402,F401
@@ -35,3 +36,9 @@ from .backends import get_backend  # noqa: E402,F401
 
 set_backend("hip")
 set_contractor("greedy")
+
+# ``tc.expectation(*ops, ket=, bra=, ...)`` (reference circuit.py:920-1065).  Bound last: the package attribute takes
+# precedence over the internal submodule of the same name, which stays importable as ``tcmi.expectation`` through
+# ``from .expectation import ...`` (sys.modules).
+from . import expectation as _expectation_module  # noqa: E402,F401  (loaded now: a later first import would rebind the name)
+from .circuit import expectation  # noqa: E402,F401

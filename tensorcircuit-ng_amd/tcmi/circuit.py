@@ -56,6 +56,26 @@ class _Op:
         self.name = name
 
 
+def _host_number(v):
+    if G.is_concrete(v):
+        return complex(v)
+    t = cons.backend.numpy(v)
+    return complex(np.asarray(t).reshape(-1)[0])
+
+
+def _is_complex_angle(v) -> bool:
+    """A gate angle with a non-zero imaginary part (python complex, or a complex 0-d tensor that is a plain value)."""
+    if isinstance(v, (complex, np.complexfloating)):
+        return complex(v).imag != 0.0
+    if _is_tensor(v) and not isinstance(v, np.ndarray):
+        import torch
+
+        if torch.is_tensor(v) and v.is_complex() and v.numel() == 1 and not v.requires_grad \
+                and not torch._C._functorch.is_functorch_wrapped_tensor(v):
+            return complex(v.detach().reshape(-1)[0].cpu().item()).imag != 0.0
+    return False
+
+
 def _split_can_truncate(split_conf) -> bool:
     if not split_conf:
         return False
@@ -300,6 +320,16 @@ class Circuit:
             return self._record_const(G._kron(G._i00, G._i_matrix) + G._kron(G._i11, u), index, "cu")
         else:
             raise NotImplementedError(f"gate {name}")
+        cplx = [sp for sp in specs if _is_complex_angle(sp.theta)]
+        if cplx:
+            # a complex angle (reference tests/test_circuit.py:422-426: ry(theta=0.8 + 0.7j)) gives a constant,
+            # non-unitary matrix: the product of the factors with complex cos / sin, recorded as a constant gate
+            m = None
+            for sp in specs:
+                a = sp.scale * complex(_host_number(sp.theta)) + sp.offset
+                f = sp.c0 + np.cos(a) * sp.c1 + np.sin(a) * sp.c2
+                m = f if m is None else f @ m
+            return self._record_const(m, index, name)
         self._record_specs(specs, index, name, dict(kw))
 
     @staticmethod
@@ -778,3 +808,56 @@ def _install_gate_methods():
 
 
 _install_gate_methods()
+
+
+def expectation(*ops: Tuple[Any, List[int]], ket: Tensor, bra: Optional[Tensor] = None, conj: bool = True,
+                normalization: bool = False, dim: Optional[int] = None) -> Tensor:
+    """reference circuit.py:920-1065 (tensor form): ``<bra| prod ops |ket>`` for states given as tensors; ``bra``
+    defaults to ``ket``, ``conj=True`` conjugates it, ``normalization`` divides by ``|ket| |bra|``.
+
+    On the hip backend: ``ops |ket>`` is one compiled plan on the input state (the operators are recorded as -- not
+    necessarily unitary -- constant gates), the overlap is ``tcmi_vdot`` (float64 accumulation).  Differentiable
+    through ``ket`` / ``bra`` (the state primitive carries the input cotangent; the overlap falls back to torch
+    arithmetic when an operand is on the autograd tape)."""
+    import torch
+
+    from . import _lib
+    from .executor import ATOMIC_COPIES
+    from .linalg import _tracked
+
+    if dim not in (None, 2):
+        raise NotImplementedError("Backend 'hip' has not implemented qudit (dim > 2) expectation.")
+    K = cons.backend
+    ket_t = K.cast(K.convert_to_tensor(ket), cons.dtypestr).reshape(-1)
+    bra_t = ket_t if bra is None else K.cast(K.convert_to_tensor(bra), cons.dtypestr).reshape(-1)
+    n = int(round(np.log2(ket_t.numel())))
+    if 2**n != ket_t.numel() or bra_t.numel() != ket_t.numel():
+        raise ValueError("ket / bra must hold 2^n amplitudes of the same n")
+    c = Circuit(n, inputs=ket_t)
+    occupied = set()
+    for op, index in ops:
+        if isinstance(index, int):
+            index = [index]
+        index = [int(i) % n for i in index]
+        for e in index:
+            if e in occupied:
+                raise ValueError(
+                    f"Cannot measure two operators in one index: qubit {e} is already occupied by a previous "
+                    f"operator in this measurement, index={index}")
+            occupied.add(e)
+        c.apply_general_gate(op, *index, name="op", split={})
+    x = c.wavefunction() if ops else ket_t
+    a = bra_t if conj else torch.conj(bra_t).resolve_conj()
+    if _tracked(x, a) or n < 3:
+        num = (torch.conj(a) * x).sum()
+    else:
+        x, a = x.contiguous(), a.contiguous()
+        code = _lib.TCMI_C64 if cons.dtypestr == "complex64" else _lib.TCMI_C128
+        acc = torch.zeros(1, ATOMIC_COPIES, 2, dtype=torch.float64, device=x.device)
+        _lib.check(_lib.lib().tcmi_vdot(a.data_ptr(), x.data_ptr(), acc.data_ptr(), x.numel(), 1, n, ATOMIC_COPIES,
+                                        acc.stride(0), code, torch.cuda.current_stream(x.device).cuda_stream),
+                   "tcmi_vdot")
+        num = torch.view_as_complex(acc.sum(1))[0].to(x.dtype)
+    if normalization:
+        num = num / (torch.linalg.vector_norm(ket_t) * torch.linalg.vector_norm(bra_t)).to(num.dtype)
+    return num

@@ -340,3 +340,15 @@ def matrix_for_gate(gate):
 # short names of the parameterised gates (reference gates.py:1192-1232: tc.gates.rx, tc.gates.any ...)
 for _n in ("rx", "ry", "rz", "phase", "r", "u", "iswap", "cr", "exp", "exp1", "rzz", "rxx", "ryy", "su4", "any"):
     globals().setdefault(_n, globals()[_n + "_gate"])
+
+
+def num_to_tensor(*num, dtype=None):
+    """reference gates.py:227-262: python numbers -> backend tensors of ``dtype`` (default: the complex dtype)."""
+    from . import cons
+
+    dtype = dtype or cons.dtypestr
+    out = [cons.backend.cast(cons.backend.convert_to_tensor(np.asarray(n)), dtype) for n in num]
+    return out[0] if len(out) == 1 else out
+
+
+array_to_tensor = num_to_tensor

@@ -214,3 +214,62 @@ def test_backend_ops_run_on_the_hip_kernels(tcd):
     # real tensors / odd expressions stay on torch
     r = torch.tensor(rng.normal(size=(4, 4)), device="cuda")
     np.testing.assert_allclose(_np(tc, K.einsum("ii->", r)), np.trace(r.cpu().numpy()), atol=1e-6)
+
+
+def test_expectation_between_two_states_kat(tcd):
+    """reference tests/test_circuit.py:404-445 (module-level ``tc.expectation(*ops, ket=, bra=, normalization=)``):
+    1j, the normalised forms, 1 and 1/sqrt(2)."""
+    tc = tcd
+    zp = np.array([1.0, 0.0])
+    zd = np.array([0.0, 1.0])
+    assert abs(complex(_np(tc, tc.expectation((tc.gates.y(), [0]), ket=zp, bra=zd))) - 1j) < 1e-7
+
+    c = tc.Circuit(3)
+    c.H(0)
+    c.ry(1, theta=tc.num_to_tensor(0.8))
+    c.cnot(1, 2)
+    state = c.wavefunction()
+    x1z2 = [(tc.gates.x(), [0]), (tc.gates.z(), [1])]
+    e1 = c.expectation(*x1z2)
+    e2 = tc.expectation(*x1z2, ket=state, bra=state, normalization=True)
+    np.testing.assert_allclose(_np(tc, e2), _np(tc, e1), atol=1e-6)
+
+    c = tc.Circuit(3)
+    c.H(0)
+    c.ry(1, theta=tc.num_to_tensor(0.8 + 0.7j))       # complex angle: a non-unitary gate, unnormalised state
+    c.cnot(1, 2)
+    state = c.wavefunction()
+    nrm2 = float(np.linalg.norm(_np(tc, state)) ** 2)
+    assert abs(nrm2 - 1) > 0.1
+    # the same state from the dense oracle with the complex-angle matrix
+    a = 0.5 * (0.8 + 0.7j)
+    ry = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
+    ref = dense.run(3, [(G.H, [0]), (ry, [1]), (G.CNOT, [1, 2])])
+    tol = 1e-6 if tc.dtypestr == "complex64" else 1e-12
+    np.testing.assert_allclose(_np(tc, state), ref, atol=tol)
+    e1 = _np(tc, c.expectation(*x1z2)) / nrm2
+    e2 = tc.expectation(*x1z2, ket=state, normalization=True)
+    np.testing.assert_allclose(_np(tc, e2), e1, atol=1e-6)
+    want = np.vdot(ref, dense.run(3, [(G.X, [0]), (G.Z, [1])], inputs=ref)) / np.vdot(ref, ref)
+    np.testing.assert_allclose(complex(_np(tc, e2)), want, atol=1e-6)
+
+    c = tc.Circuit(2); c.X(1); s1 = c.state()
+    c2 = tc.Circuit(2); c2.X(0); s2 = c2.state()
+    c3 = tc.Circuit(2); c3.H(1); s3 = c3.state()
+    x1x2 = [(tc.gates.x(), [0]), (tc.gates.x(), [1])]
+    np.testing.assert_allclose(_np(tc, tc.expectation(*x1x2, ket=s1, bra=s2)), 1.0, atol=1e-6)
+    np.testing.assert_allclose(_np(tc, tc.expectation(*x1x2, ket=s3, bra=s2)), 1.0 / np.sqrt(2), atol=1e-6)
+    with pytest.raises(ValueError, match="Cannot measure two operators in one index"):
+        tc.expectation((tc.gates.x(), [0]), (tc.gates.z(), [0]), ket=s1)
+    # a larger state goes through tcmi_vdot; conj=False uses the bra as given
+    n = 12
+    rng = np.random.default_rng(2)
+    k = rng.normal(size=2**n) + 1j * rng.normal(size=2**n)
+    b = rng.normal(size=2**n) + 1j * rng.normal(size=2**n)
+    op = rng.normal(size=(4, 4)) + 1j * rng.normal(size=(4, 4))      # a non-unitary two-qubit operator
+    ok = dense.run(n, [(op, [3, 7]), (G.Y, [0])], inputs=k)
+    tol = 2e-3 if tc.dtypestr == "complex64" else 1e-8
+    got = complex(_np(tc, tc.expectation((op, [3, 7]), (tc.gates.y(), [0]), ket=k, bra=b)))
+    np.testing.assert_allclose(got, np.vdot(b, ok), rtol=tol)
+    got2 = complex(_np(tc, tc.expectation((op, [3, 7]), (tc.gates.y(), [0]), ket=k, bra=b, conj=False)))
+    np.testing.assert_allclose(got2, np.sum(b * ok), rtol=tol)
