@@ -93,6 +93,8 @@ def set_contractor(method: Optional[str] = None, optimizer: Any = None, memory_l
       the names that ask for more than greedy; the result of a contraction does not depend on the path;
     * ``"tilevm"`` / ``"cut"`` (not in the reference) force the two state-vector execution orders of ``Circuit``.
 
+    ``strip_exponent=True``: the callable returns ``(node, exponent)`` with result = node * 10**exponent, intermediates
+    rescaled on the way (cons.py:736-740, 763-766); networks with ``tn.CopyNode`` hyperedges take the same route.
     ``debug_level`` 1 / 2: contractions return zeros of the right shape without arithmetic (cons.py:928-934);
     ``contraction_info``: cost of every contraction is printed (cons.py:1084-1120).  Whole-circuit state vectors do not
     go through this callable: ``Circuit.wavefunction`` runs the compiled tile-VM plan, whose tuning knobs may be
@@ -122,7 +124,8 @@ def set_contractor(method: Optional[str] = None, optimizer: Any = None, memory_l
             opt = optimizer(**(opt_conf or {}))
         return tn.contract_nodes(list(nodes), output_edge_order, ignore_edge_order=ignore_edge_order, optimizer=opt,
                                  memory_limit=memory_limit, debug_level=int(ckws.get("debug_level", debug_level)),
-                                 info=bool(contraction_info), trials=trials)
+                                 info=bool(contraction_info), trials=trials,
+                                 strip_exponent=bool(ckws.get("strip_exponent", kws.get("strip_exponent", False))))
 
     cf.method = method  # type: ignore
     cf.plan_options = opts  # type: ignore

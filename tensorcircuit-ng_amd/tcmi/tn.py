@@ -41,6 +41,126 @@ class Node:
         return f"Node(name={self.name!r}, edges={self.edges})"
 
 
+class CopyNode(Node):
+    """``tn.CopyNode(rank, dimension)``: the delta tensor that identifies all its legs (a hyperedge).  It carries no
+    array; the contractor merges the labels of its legs into one index that may then occur in more than two tensors
+    and in the output (reference cons.py:499-541)."""
+
+    __slots__ = ("dimension",)
+
+    def __init__(self, rank: int, dimension: int = 2, name: str = "", edges: Optional[Sequence[int]] = None):
+        edges = [new_edge() for _ in range(rank)] if edges is None else list(edges)
+        assert len(edges) == rank
+        super().__init__(None, edges, name)
+        self.dimension = int(dimension)
+
+
+def hyper_info(nodes: Sequence[Node]):
+    """(arrays, input_sets, output_set, size_dict) of a network with CopyNodes: every leg label is replaced by the
+    representative of its hyperedge (union-find over the legs of each CopyNode), dangling labels -- appearing once
+    over all nodes, CopyNodes included -- become the output in order of appearance (reference
+    ``_extract_topology``, cons.py:499-541)."""
+    parent: Dict[int, int] = {}
+
+    def find(x):
+        parent.setdefault(x, x)
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+
+    count: Dict[int, int] = {}
+    order: List[int] = []
+    for nd in nodes:
+        for e in nd.edges:
+            find(e)
+            if e not in count:
+                order.append(e)
+            count[e] = count.get(e, 0) + 1
+    for nd in nodes:
+        if isinstance(nd, CopyNode):
+            for e in nd.edges[1:]:
+                ra, rb = find(nd.edges[0]), find(e)
+                if ra != rb:
+                    parent[rb] = ra
+    regular = [nd for nd in nodes if not isinstance(nd, CopyNode)]
+    inputs = [[find(e) for e in nd.edges] for nd in regular]
+    dangling = [e for e in order if count[e] == 1]
+    output = [find(e) for e in dangling]
+    size_dict: Dict[int, int] = {}
+    for nd in regular:
+        for e, d in zip(nd.edges, nd.tensor.shape):
+            size_dict[find(e)] = int(d)
+    for nd in nodes:
+        if isinstance(nd, CopyNode):
+            size_dict.setdefault(find(nd.edges[0]), nd.dimension)
+    return [nd.tensor for nd in regular], inputs, output, size_dict, dangling
+
+
+def contract_hyper(arrays, inputs, output, size_dict, path=None, strip_exponent: bool = False):
+    """Pairwise contraction of an einsum network whose indices may occur in any number of tensors (the reference's
+    ``_algebraic_base_contraction``, cons.py:706-766).  A pair's shared index is summed only when no other tensor
+    and not the output needs it; otherwise it is a batch index of one batched ``tcmi_cgemm``.  ``strip_exponent``:
+    every intermediate is rescaled to unit maximum and log10 of the factors is accumulated (cotengra's
+    ``tree.contract(strip_exponent=True)``): returns (mantissa, exponent) with result = mantissa * 10**exponent."""
+    import torch
+
+    from . import linalg as LA
+
+    cdt = getattr(torch, cons.dtypestr)
+    tens = [cons.backend.convert_to_tensor(t).to(device=cons.backend.device, dtype=cdt) for t in arrays]
+    edges = [list(s) for s in inputs]
+    for s in edges:
+        if len(set(s)) != len(s):
+            raise NotImplementedError("Backend 'hip' has not implemented a hyperedge joining two legs of one tensor.")
+    if path is None:
+        path = greedy_path(edges, output, size_dict) if len(edges) > 1 else []
+    uses: Dict[int, int] = {}
+    for s in edges:
+        for e in s:
+            uses[e] = uses.get(e, 0) + 1
+    outset = set(output)
+    expo = torch.zeros((), dtype=torch.float64, device=cons.backend.device)
+
+    def strip(t):
+        nonlocal expo
+        if not strip_exponent:
+            return t
+        m = t.abs().max().to(torch.float64)
+        m = torch.where(m > 0, m, torch.ones_like(m))
+        expo = expo + torch.log10(m)
+        return t / m.to(t.real.dtype)
+
+    tens = [strip(t) for t in tens]
+    for a, b in path:
+        ta, tb, ea, eb = tens[a], tens[b], edges[a], edges[b]
+        shared = [e for e in ea if e in eb]
+        summed = [e for e in shared if uses[e] == 2 and e not in outset]
+        batch = [e for e in shared if e not in summed]
+        fa = [e for e in ea if e not in shared]
+        fb = [e for e in eb if e not in shared]
+        dim = lambda es: int(np.prod([size_dict[e] for e in es])) if es else 1  # noqa: E731
+        A = ta.permute(tuple(ea.index(e) for e in batch + fa + summed)).reshape(dim(batch), dim(fa), dim(summed))
+        B = tb.permute(tuple(eb.index(e) for e in batch + summed + fb)).reshape(dim(batch), dim(summed), dim(fb))
+        C = LA.matmul(A.contiguous(), B.contiguous())           # one batched tcmi_cgemm launch
+        ne = batch + fa + fb
+        t = strip(C.reshape([size_dict[e] for e in ne]))
+        for e in summed:
+            uses[e] -= 2
+        for e in batch:
+            uses[e] -= 1
+        tens = [x for k, x in enumerate(tens) if k not in (a, b)] + [t]
+        edges = [x for k, x in enumerate(edges) if k not in (a, b)] + [ne]
+    res, re_ = tens[0], edges[0]
+    extra = [e for e in re_ if e not in outset]
+    if extra:   # an index nobody else needs: summed out (einsum semantics)
+        res = res.sum(dim=[re_.index(e) for e in extra])
+        re_ = [e for e in re_ if e in outset]
+    if list(re_) != list(output):
+        res = res.permute(tuple(re_.index(e) for e in output))
+    return (res, expo) if strip_exponent else res
+
+
 # ---- symbolic part: network info, greedy path, slicing ---------------------------------------------
 def get_tn_info(nodes: Sequence[Node]):
     """``cons.get_tn_info`` (reference cons.py:804): (input_sets, output_set, size_dict) with the
@@ -1017,7 +1137,8 @@ def symbolic_info(nodes: Sequence[Node]):
 
 def contract_nodes(nodes: Sequence[Node], output_edge_order: Optional[Sequence[int]] = None,
                    target_size: Optional[int] = None, ignore_edge_order: bool = False, optimizer: Any = None,
-                   memory_limit: Any = None, debug_level: int = 0, info: bool = False, trials: int = 0):
+                   memory_limit: Any = None, debug_level: int = 0, info: bool = False, trials: int = 0,
+                   strip_exponent: bool = False):
     """The contractor call of the reference (``contractor(nodes, output_edge_order=..., ignore_edge_order=...)``,
     ``_base`` at cons.py:845-961) on the HIP engine: pairwise path -> ``tcmi_cgemm`` / ``tcmi_contract_scattered`` /
     ``tcmi_permute_bits`` steps, result axes in ``output_edge_order``.  Returns a Node.
@@ -1026,6 +1147,46 @@ def contract_nodes(nodes: Sequence[Node], output_edge_order: Optional[Sequence[i
     ``f(input_sets, output_set, size_dict, memory_limit=None) -> [(i, j), ...]`` in opt_einsum's linear format, or a
     precomputed list path (cons.py:1037-1040, 949-950); default: the built-in (random-)greedy search.
     ``debug_level`` 1 / 2: no arithmetic, zeros of the output shape (cons.py:928-934).  Errors as cons.py:877-896."""
+    hyper = strip_exponent or any(isinstance(nd, CopyNode) for nd in nodes)
+    if not hyper:
+        cnt: Dict[int, int] = {}
+        for nd in nodes:
+            for e in nd.edges:
+                cnt[e] = cnt.get(e, 0) + 1
+        hyper = any(v > 2 for v in cnt.values())
+    if hyper:
+        # CopyNodes / indices shared by more than two tensors / strip_exponent: the einsum-style route of the reference
+        # (cons.py:706-766); dangling edges of CopyNodes are valid output edges
+        arrays, inputs, output, size_dict, dangling = hyper_info(nodes)
+        if not ignore_edge_order:
+            if output_edge_order is None:
+                output_edge_order = dangling
+            if set(output_edge_order) != set(dangling):
+                raise ValueError("output edges are not equal to the remaining non-contracted edges of the final node.")
+        else:
+            output_edge_order = dangling
+        rep = dict(zip(dangling, output))
+        want = [rep[e] for e in output_edge_order]
+        path = None
+        if optimizer is not None and len(arrays) > 1:
+            if isinstance(optimizer, (list, tuple)):
+                path = [tuple(int(x) for x in ab) for ab in optimizer]
+            else:
+                num: Dict[int, int] = {}
+                for s_ in inputs:
+                    for e in s_:
+                        num.setdefault(e, len(num))
+                for e in want:
+                    num.setdefault(e, len(num))
+                sym = {e: edge_symbol(k) for e, k in num.items()}
+                path = [tuple(int(x) for x in ab) for ab in optimizer(
+                    [[sym[e] for e in s_] for s_ in inputs], [sym[e] for e in want],
+                    {sym[e]: size_dict[e] for e in num}, memory_limit=memory_limit)]
+            path = [ab for ab in path if len(ab) == 2]
+        r = contract_hyper(arrays, inputs, want, size_dict, path=path, strip_exponent=strip_exponent)
+        if strip_exponent:
+            return Node(r[0], list(output_edge_order)), float(r[1])
+        return Node(r, list(output_edge_order))
     inputs, output, size_dict = get_tn_info(nodes)
     if not ignore_edge_order:
         if output_edge_order is None:

@@ -273,3 +273,64 @@ def test_expectation_between_two_states_kat(tcd):
     np.testing.assert_allclose(got, np.vdot(b, ok), rtol=tol)
     got2 = complex(_np(tc, tc.expectation((op, [3, 7]), (tc.gates.y(), [0]), ket=k, bra=b, conj=False)))
     np.testing.assert_allclose(got2, np.sum(b * ok), rtol=tol)
+
+
+def test_hyperedge_and_strip_exponent_kats(tcd):
+    """reference tests/test_hyperedge.py:73-138, 156-177 (CopyNode networks: 9.0, 17.0, [1, 4], reordered outer
+    product) and tests/test_circuit.py:2178-2257 (strip_exponent: 0.1^400 -> (1.0, -400), ten 10.0 -> (1.0, 10),
+    a 100-qubit expectation network of 2*identity gates -> 200 log10 2)."""
+    tc = tcd
+    from tcmi import tn
+
+    v12 = lambda: tc.gates.num_to_tensor(np.array([1.0, 2.0]))  # noqa: E731
+    cf = tc.set_contractor("greedy")
+    # single hyperedge: sum_i A_i B_i C_i = 1 + 8
+    e = [tn.new_edge() for _ in range(3)]
+    nodes = [tn.Node(v12(), [e[0]]), tn.Node(v12(), [e[1]]), tn.Node(v12(), [e[2]]), tn.CopyNode(3, 2, edges=e)]
+    np.testing.assert_allclose(_np(tc, cf(nodes).tensor), 9.0, atol=1e-5)
+    # chained: A-CN1-B, CN1-CN2, C-CN2-D: sum_i A_i B_i C_i D_i = 17
+    e = [tn.new_edge() for _ in range(5)]
+    nodes = [tn.Node(v12(), [e[0]]), tn.Node(v12(), [e[1]]), tn.Node(v12(), [e[3]]), tn.Node(v12(), [e[4]]),
+             tn.CopyNode(3, 2, edges=[e[0], e[1], e[2]]), tn.CopyNode(3, 2, edges=[e[2], e[3], e[4]])]
+    np.testing.assert_allclose(_np(tc, cf(nodes).tensor), 17.0, atol=1e-5)
+    # dangling hyperedge: C_i = A_i B_i
+    e = [tn.new_edge() for _ in range(3)]
+    res = cf([tn.Node(v12(), [e[0]]), tn.Node(v12(), [e[1]]), tn.CopyNode(3, 2, edges=e)])
+    np.testing.assert_allclose(_np(tc, res.tensor), np.array([1.0, 4.0]), atol=1e-5)
+    # output reordering through two rank-2 CopyNodes
+    a1, a2, b1, b2 = (tn.new_edge() for _ in range(4))
+    nodes = [tn.Node(v12(), [a1]), tn.Node(tc.gates.num_to_tensor(np.array([3.0, 4.0])), [b1]),
+             tn.CopyNode(2, 2, edges=[a1, a2]), tn.CopyNode(2, 2, edges=[b1, b2])]
+    res = cf(nodes, output_edge_order=[b2, a2])
+    np.testing.assert_allclose(_np(tc, res.tensor), np.outer([3.0, 4.0], [1.0, 2.0]), atol=1e-5)
+    assert tuple(res.tensor.shape) == (2, 2)
+    # a custom path finder also sees hyper-indices (one symbol in three inputs)
+    seen = []
+
+    def finder(input_sets, output_set, size_dict, memory_limit=None):
+        seen.append(input_sets)
+        return [(0, 1)] * (len(input_sets) - 1)
+
+    e = [tn.new_edge() for _ in range(3)]
+    nodes = [tn.Node(v12(), [e[0]]), tn.Node(v12(), [e[1]]), tn.Node(v12(), [e[2]]), tn.CopyNode(3, 2, edges=e)]
+    np.testing.assert_allclose(_np(tc, tc.set_contractor("custom", optimizer=finder)(nodes).tensor), 9.0, atol=1e-5)
+    assert seen and seen[0][0] == seen[0][1] == seen[0][2]
+
+    # strip_exponent
+    cf = tc.set_contractor("cotengra", strip_exponent=True)
+    node, ex = cf([tn.Node(tc.backend.convert_to_tensor(0.1, tc.rdtypestr), []) for _ in range(400)])
+    np.testing.assert_allclose(abs(complex(_np(tc, node.tensor))), 1.0, atol=1e-5)
+    np.testing.assert_allclose(ex, -400.0, atol=1e-3 if tc.dtypestr == "complex64" else 1e-8)
+    cf = tc.set_contractor("custom_stateful", optimizer=lambda **kw: (lambda i, o, s, memory_limit=None: [(0, 1)] * (len(i) - 1)),
+                           strip_exponent=True)
+    node, ex = cf([tn.Node(tc.backend.convert_to_tensor(10.0, tc.rdtypestr), []) for _ in range(6)])
+    np.testing.assert_allclose(abs(complex(_np(tc, node.tensor))), 1.0, atol=1e-5)
+    np.testing.assert_allclose(ex, 6.0, atol=1e-4)
+    n = 40
+    c = tc.Circuit(n)
+    for i in range(n):
+        c.any(i, unitary=np.array([[2.0, 0], [0, 2.0]]))
+    cf = tc.set_contractor("cotengra", strip_exponent=True)
+    node, ex = cf(c.expectation_before([tc.gates.z(), [0]], reuse=False))
+    np.testing.assert_allclose(abs(complex(_np(tc, node.tensor))), 1.0, atol=1e-5)
+    np.testing.assert_allclose(ex, 2 * n * np.log10(2.0), atol=1e-3)
