@@ -14,7 +14,7 @@ MAGIC = 0x54434D31
 HDR_WORDS = 24
 RR_WORDS = 50
 OP_G1, OP_G2, OP_DIAG, OP_G1M, OP_EXPECT, OP_DIAGC, OP_DIAGB = 1, 2, 3, 4, 5, 6, 7
-OP_DIAGF, OP_DIAGB2 = 8, 9
+OP_DIAGF, OP_DIAGB2, OP_DIAGCW = 8, 9, 10
 R_MAX = 6
 CONST_FLAG = 1 << 30
 BK_TRIG, BK_COEF, BK_SELECT, BK_PHASE = 1, 2, 5, 6
@@ -242,6 +242,21 @@ def run_pass(state, desc, ctab, ptab_row, eout=None):
                 tb = np.asarray(ptab_row)[int(d[q + 1]): int(d[q + 1]) + 2 * NR]
                 regs = regs * (tb[0::2] + 1j * tb[1::2]).astype(regs.dtype)[None, None, :]
                 q += 2
+            elif op == OP_DIAGCW:
+                # table variant picked per thread (per wave on the device) by the parities of the selector masks
+                slot, nsel = int(d[q + 1]), int(d[q + 2])
+                tidx = (wg_base[:, None] | tphys[None, :]).astype(np.uint64)
+                v = np.zeros(tidx.shape, dtype=np.int64)
+                for k_ in range(nsel):
+                    v += _parity(tidx & np.uint64(int(d[q + 3 + k_]))).astype(np.int64) << k_
+                tb = np.asarray(ptab_row)[slot: slot + 2 * NR * (1 << nsel)]
+                tbc = (tb[0::2] + 1j * tb[1::2]).reshape(1 << nsel, NR)
+                regs = regs * tbc[v].astype(regs.dtype)
+                # the selector bits must be uniform over every wave of 64 threads
+                for k_ in range(nsel):
+                    pk = _parity(tidx & np.uint64(int(d[q + 3 + k_]))).reshape(nwg, -1, min(64, nth))
+                    assert (pk == pk[:, :, :1]).all()
+                q += 6
             elif op == OP_DIAGB2:
                 # factor = table[s1 + 2 s2] for register bit clear, its conjugate for bit set
                 j, m1, m2, slot = int(d[q + 1]), int(d[q + 2]), int(d[q + 3]), int(d[q + 4])
@@ -494,8 +509,9 @@ def run_adjoint_pass(psi, lam, desc, ctab, ptab_row, gout):
                         gout[int(gs[e])] += np.sum(sgn * w)
                 regs = regs * np.exp(-2j * np.pi * phi)[None]
             elif op == OP_DIAGF:
-                cslot, nC, nB, nA = int(dsig[q + 1]), int(d[q + 2]), int(d[q + 3]), int(d[q + 4])
-                q += 5
+                cslot, nC, nB, nA, nsel = int(dsig[q + 1]), int(d[q + 2]), int(d[q + 3]), int(d[q + 4]), int(d[q + 5])
+                sel_masks = [int(d[q + 6 + k_]) for k_ in range(nsel)]
+                q += 9
                 w = np.imag(np.conj(regs[1]) * regs[0])  # [nwg, nth, NR]
                 for e in range(nC):
                     rm, gs = int(d[q]), int(dsig[q + 1])
@@ -504,8 +520,12 @@ def run_adjoint_pass(psi, lam, desc, ctab, ptab_row, gout):
                         z = 1 - 2 * _parity(rid.astype(np.uint64) & np.uint64(rm))
                         gout[gs] += np.sum(w * z[None, None, :])
                 if cslot >= 0:
-                    tb = np.asarray(ptab_row)[cslot: cslot + 2 * NR]
-                    regs = regs * np.conj(tb[0::2] + 1j * tb[1::2])[None, None, None, :]
+                    v = np.zeros(tidx.shape, dtype=np.int64)
+                    for k_, m_ in enumerate(sel_masks):
+                        v += _parity(tidx & np.uint64(m_)).astype(np.int64) << k_
+                    tb = np.asarray(ptab_row)[cslot: cslot + 2 * NR * (1 << nsel)]
+                    tbc = (tb[0::2] + 1j * tb[1::2]).reshape(1 << nsel, NR)
+                    regs = regs * np.conj(tbc[v])[None]
                 for e in range(nB):
                     j, mask, slot, gs = int(d[q]), int(d[q + 1]), int(dsig[q + 2]), int(dsig[q + 3])
                     q += 4

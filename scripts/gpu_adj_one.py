@@ -35,7 +35,7 @@ if "--passes" in sys.argv:
                 elif op == P.OP_G2: q += 6
                 elif op == P.OP_DIAGF:
                     nC, nB, nA = int(w[q + 2]), int(w[q + 3]), int(w[q + 4]); m["DIAG"] += 1; m["terms"] += nC + nB + nA
-                    q += 5 + 2 * nC + 4 * nB + 2 * nA
+                    q += 9 + 2 * nC + 4 * nB + 2 * nA
             pc = q
         return m
     nel = 2**cc.n_exec; stream = torch.cuda.current_stream().cuda_stream

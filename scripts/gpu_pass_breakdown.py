@@ -24,6 +24,7 @@ def mix(desc):
             elif op == P.OP_DIAGC: m["DIAGC"] += 1; q += 2
             elif op == P.OP_DIAGB: m["DIAGB"] += 1; q += 4
             elif op == P.OP_DIAGB2: m["DIAGB"] += 1; q += 5
+            elif op == P.OP_DIAGCW: m["DIAGC"] += 1; q += 6
             elif op == P.OP_G2: m["G2"] += 1; q += 4
         pc = q
     return m

@@ -195,11 +195,18 @@ __global__ __launch_bounds__(1 << LT, (R >= 5 ? 512 : 1024) >> LT) void adjoint2
 #undef TCMI_BW
       }
       if (f & (1 << TCMI_OP_DIAGF)) {
-        // {8, cslot, nC, nB, nA, C: (rmask, gslot)*, B: (j, mask, slot, gslot)*, A: (mask, gslot)*}
-        const int cslot = desc[q + 1], nC = desc[q + 2], nB = desc[q + 3], nA = desc[q + 4];
-        int qq = q + 5;
+        // {8, cslot, nC, nB, nA, nsel, m0, m1, m2, C: (rmask, gslot)*, B: (j, mask, slot, gslot)*, A: (mask, gslot)*}
+        const int cslot = desc[q + 1], nC = desc[q + 2], nB = desc[q + 3], nA = desc[q + 4], nsel = desc[q + 5];
+        int qq = q + 9;
         qn = qq + 2 * nC + 4 * nB + 2 * nA;
         const uint32_t tidx = wg_base | tphys;
+        int tvar = 0;   // wave-selected variant of the register table (OP_DIAGCW semantics)
+        {
+          const uint32_t widx = (uint32_t)__builtin_amdgcn_readfirstlane((int)tidx);
+#pragma unroll
+          for (int k2 = 0; k2 < 3; ++k2)
+            if (k2 < nsel) tvar |= (__popc(widx & (uint32_t)desc[q + 6 + k2]) & 1) << k2;
+        }
         // w[r] = Im(conj(lambda) psi): invariant under the phases applied here, every term's gradient is a signed sum of it
         float w[NR];
 #pragma unroll
@@ -223,7 +230,7 @@ __global__ __launch_bounds__(1 << LT, (R >= 5 ? 512 : 1024) >> LT) void adjoint2
           }
         }
         if (cslot >= 0) {
-          const KV2 tp = (KV2)(ptab + cslot);
+          const KV2 tp = (KV2)(ptab + cslot + 2 * NR * tvar);
           v2f t[NR];
 #pragma unroll
           for (int i = 0; i < NR; ++i) t[i] = tp[i];

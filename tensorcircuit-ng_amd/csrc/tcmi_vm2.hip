@@ -214,9 +214,22 @@ __global__ __launch_bounds__(1 << LT, (1024 >> LT)) void pass2_kernel(v2f* __res
         TCMI_G1(0) TCMI_G1(1) TCMI_G1(2) TCMI_G1(3) TCMI_G1(4) TCMI_G1(5)
 #undef TCMI_G1
       }
-      if (f & (1 << TCMI_OP_DIAGC)) {
-        const KV2 tp = (KV2)(ptab + desc[q + 1]);
+      if (f & ((1 << TCMI_OP_DIAGC) | (1 << TCMI_OP_DIAGCW))) {
+        // register table; OP_DIAGCW: one of 2^nsel variants, picked by sign functions that are uniform over the wave
+        // (register-x-thread phase terms on wave-uniform bits ride on this multiply instead of needing their own)
+        int toff = desc[q + 1];
         qn = q + 2;
+        if (f & (1 << TCMI_OP_DIAGCW)) {
+            const int nsel = desc[q + 2];
+            const uint32_t widx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wg_base | tphys));
+            int v = 0;
+#pragma unroll
+            for (int k2 = 0; k2 < 3; ++k2)
+              if (k2 < nsel) v |= (__popc(widx & (uint32_t)desc[q + 3 + k2]) & 1) << k2;
+            toff += 2 * NR * v;
+            qn = q + 6;
+        }
+        const KV2 tp = (KV2)(ptab + toff);
 #pragma unroll
         for (int h = 0; h < NR; h += 16) {  // 32 scalar registers of table per burst
           v2f t[16];

@@ -81,7 +81,9 @@ def pick_variant(n: int, dtypestr: str, opts: Optional[dict] = None) -> Tuple[in
             low = max(1, min(low, R + LT))
             # complex64 tiles with R >= 4 run on the packed-f32 kernel (csrc/tcmi_vm2.hip), which knows OP_DIAGB2
             gen = 2 if (c64 and R >= 4 and not os.environ.get("TCMI_VM1")) else 1
-            return n_exec, P.PlanConfig(R=R, LT=LT, lowbits=low, vec=2 if c64 else 1, gen=gen)
+            cap = os.environ.get("TCMI_PASS_CAP")
+            return n_exec, P.PlanConfig(R=R, LT=LT, lowbits=low, vec=2 if c64 else 1, gen=gen,
+                                        pass_cap=int(cap) if cap else None)
     raise ValueError("no tile variant fits")
 
 
@@ -564,6 +566,9 @@ def vm_cost_us(plan: "P.CompiledPlan") -> float:
                 elif op == P.OP_DIAGB2:
                     t += VM_COST["g1"]
                     q += 5
+                elif op == P.OP_DIAGCW:
+                    t += VM_COST["g1"]
+                    q += 6
                 else:
                     raise ValueError(op)
             pc = q

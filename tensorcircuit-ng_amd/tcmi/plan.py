@@ -44,6 +44,7 @@ OP_EXPECT = 5
 OP_DIAGB = 7   # one diagonal term on a register bit x thread bits: multiply by exp(+-i phi), sign per thread
 OP_DIAGC = 6   # diagonal terms on register bits only: multiply by a 2^R table of phase factors
 OP_DIAGB2 = 9  # two register-x-thread terms on the same register bit: {9, j, mask1, mask2, slot}, table of 4 factors (gen 2)
+OP_DIAGCW = 10  # DIAGC whose table is picked per wave: {10, slot, nsel, m0, m1, m2}, variant = sum_k parity(wave index & m_k) << k, table of 2^nsel * 2^R factors (gen 2): register-x-thread terms whose thread bits are wave-uniform cost no multiply of their own
 OP_DIAGF = 8   # backward (adjoint sweep) flush of diagonal terms in table form: see encode_pass
 FLAG_NOSTORE = 1
 DIAG_CHUNK = 8
@@ -253,11 +254,12 @@ def _scan(gates, order, qbits_of, res_of, capacity, forced, allowed):
     return S, chosen
 
 
-def _scan_fixed(gates, order, qmask, rmask, S, count_only=False):
+def _scan_fixed(gates, order, qmask, rmask, S, count_only=False, cap=None):
     """Gates of ``order`` (program order) executable with the resource bits ``S`` (bit mask): a dense gate runs if
     its resource bits are in S and no earlier gate on its qubits was left behind; diagonal gates need no resources.
     ``qmask[gi]`` = ordering bits of the gate, ``rmask[gi]`` = resource bits it needs (0 for diagonal gates).
-    ``count_only``: return the weighted number of dense gates only (and stop once every bit of S is blocked)."""
+    ``count_only``: return the weighted number of dense gates only (and stop once every bit of S is blocked).
+    ``cap``: at most this (weighted) number of dense gates; the rest stays pending for later passes."""
     blocked_all = 0
     blocked_dense = 0
     chosen = []
@@ -271,14 +273,13 @@ def _scan_fixed(gates, order, qmask, rmask, S, count_only=False):
             elif not count_only:
                 chosen.append(gi)
             continue
-        if (qs & (blocked_all | blocked_dense)) or (rs & ~S):
+        if (qs & (blocked_all | blocked_dense)) or (rs & ~S) or (cap is not None and cnt >= cap):
             blocked_all |= qs
             if count_only and (S & ~blocked_all) == 0:
                 break
             continue
-        if count_only:
-            cnt += 1 if (rs & (rs - 1)) == 0 else 3
-        else:
+        cnt += 1 if (rs & (rs - 1)) == 0 else 3
+        if not count_only:
             chosen.append(gi)
     return cnt if count_only else chosen
 
@@ -343,6 +344,7 @@ class PlanConfig:
     LT: int = 8         # log2(threads per workgroup)
     lowbits: int = 5    # physical low bits always in the tile (coalescing run = 2^lowbits amps)
     vec: int = 2        # amplitudes per 16-byte global access (2 for complex64, 1 for complex128)
+    pass_cap: Optional[int] = None   # at most this many (weighted) dense gates per pass: a pass costs max(HBM round trip, arithmetic), so more gates than the round trip hides are better left to a later pass
     gen: int = 1        # kernel generation executing the plan: 2 = packed-f32 kernels (tcmi_vm2 / tcmi_adjoint2): extra ops
 
     @property
@@ -381,7 +383,7 @@ def schedule(gates, n: int, cfg: PlanConfig, independent: bool = False) -> List[
             S, chosen = _scan(gates, pending, order_bits, phys_res, T, set(range(L)), all_bits)
         else:
             Sm = _grow(gates, pending, qmask, rmask, T, (1 << L) - 1, (1 << n) - 1)
-            chosen = _scan_fixed(gates, pending, qmask, rmask, Sm)
+            chosen = _scan_fixed(gates, pending, qmask, rmask, Sm, cap=cfg.pass_cap)
             S = {b for b in range(n) if (Sm >> b) & 1}
             if not any(not gates[gi].is_diag for gi in chosen) and any(not gates[gi].is_diag for gi in pending):
                 # nothing dense became executable (should not happen): first-fit fallback
@@ -467,6 +469,27 @@ def _schedule_rounds(gates, n, cfg: PlanConfig, pp: PassPlan, independent: bool 
         if not pending and not independent:
             reg, thr = finish_layout(forced_c, allowed_c)
             rounds.append(Round(reg, thr, []))
+    if cfg.gen >= 2 and not independent and cfg.LT > 6:
+        # thread-bit order: tile bits whose qubits share diagonal terms with this round's register qubits go to the
+        # highest thread positions (>= 6: the same value for a whole wave), where a register-x-thread phase term only
+        # selects a table variant (OP_DIAGCW) instead of costing a multiply of every amplitude (OP_DIAGB)
+        pair = {}
+        for g in gates:
+            if g.is_diag:
+                for t in g.diag:
+                    qs = list(t.qubits)
+                    for a_ in qs:
+                        for b_ in qs:
+                            if a_ != b_:
+                                pair[(a_, b_)] = pair.get((a_, b_), 0) + 1
+        qubit_of_tb = {i: n - 1 - p for i, p in enumerate(pp.tile_bits)}
+        for k, rd in enumerate(rounds):
+            fixed = len(pinned) if (k == 0 or k == len(rounds) - 1) else 0
+            head, tail = rd.thr_tb[:fixed], rd.thr_tb[fixed:]
+            regq = [qubit_of_tb[b] for b in rd.reg_tb]
+            score = lambda b: sum(pair.get((qubit_of_tb[b], rq), 0) for rq in regq)  # noqa: E731
+            tail = sorted(tail, key=lambda b: (score(b), b))
+            rd.thr_tb = head + tail
     pp.rounds = rounds
 
 
@@ -829,21 +852,55 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
                 # d(phase)/d(theta) = scale * s_t(idx); dL/dtheta = -scale * sum s_t Im(conj(lambda) psi)
                 return tables.grad_slot(t.param.index, -t.param.scale) if t.param is not None else -1
 
-            if backward and factorized_bw:
-                # {8, cslot (-1: none), nC, nB, nA, C: (rmask, gslot)*, B: (j, mask, slot (-1: already applied), gslot)*,
-                #  A: (mask, gslot)*}: tables hold the FORWARD phase factors, the kernel applies the conjugate;
-                #  A terms (no register bit: only the final flush has them) contribute gradients only.
-                cslot = -1
-                if C_:
-                    NR = 1 << R
-                    cslot = tables.alloc(2 * NR)
-                    off = phase_terms(C_)
+            # gen-2 kernels: a register-x-thread term whose non-register bits are the same for a whole wave (bits outside
+            # the tile, thread positions >= 6) only picks a variant of the register table; up to 3 such sign functions
+            wsel = []     # [(mask, [(j, term), ...])]
+            if cfg.gen >= 2 and phase_tables and (not backward or factorized_bw):
+                uni = 0
+                for p_ in range(n):
+                    if p_ not in tb_of_phys:
+                        uni |= 1 << p_
+                for pos_, b_ in enumerate(rd.thr_tb):
+                    if pos_ >= 6:
+                        uni |= 1 << pp.tile_bits[b_]
+                for (j, nmask) in list(bgroups):
+                    if nmask and (nmask & ~uni) == 0:
+                        ent = next((w for w in wsel if w[0] == nmask), None)
+                        if ent is None:
+                            if len(wsel) >= 3:
+                                continue
+                            ent = (nmask, [])
+                            wsel.append(ent)
+                        ent[1].extend((j, t) for t in bgroups.pop((j, nmask)))
+
+            def table_variants():
+                """Builder records of the (possibly wave-selected) register table; returns its slot."""
+                NR = 1 << R
+                nv = 1 << len(wsel)
+                slot_ = tables.alloc(2 * NR * nv)
+                terms_ = [(rm, t) for rm, t in C_]
+                for k_, (_m, lst) in enumerate(wsel):
+                    terms_ += [((1 << j) | (1 << (R + k_)), t) for j, t in lst]
+                off_ = phase_terms(terms_)
+                for v_ in range(nv):
                     for r in range(NR):
-                        tables.ginfo.append([BK_PHASE, cslot + 2 * r, 0, len(C_), off, r, 0, 0])
+                        tables.ginfo.append([BK_PHASE, slot_ + 2 * (v_ * NR + r), 0, len(terms_), off_, r | (v_ << R), 0, 0])
+                return slot_
+
+            if backward and factorized_bw:
+                # {8, cslot (-1: none), nC, nB, nA, nsel, m0, m1, m2, C: (rmask, gslot)*,
+                #  B: (j, mask, slot (-1: applied elsewhere), gslot)*, A: (mask, gslot)*}: tables hold the FORWARD phase
+                #  factors (2^nsel wave-selected variants of the register table), the kernel applies the conjugate;
+                #  A terms (no register bit: only the final flush has them) contribute gradients only.
+                cslot = table_variants() if (C_ or wsel) else -1
                 body = []
                 for rm, t in C_:
                     body += [rm, gslot(t)]
                 nB = 0
+                for m_, lst in wsel:          # applied through the table variant: gradient entries only
+                    for j, t in lst:
+                        body += [j, m_, -1, gslot(t)]
+                        nB += 1
                 for (j, nmask), ts in bgroups.items():
                     slot = tables.alloc(2)
                     off = phase_terms([(0, t) for t in ts])
@@ -853,10 +910,10 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
                         nB += 1
                 for nmask, t in A_:
                     body += [nmask, gslot(t)]
-                ops.extend([OP_DIAGF, cslot, len(C_), nB, len(A_)] + body)
+                sel = [m_ for m_, _ in wsel] + [0] * (3 - len(wsel))
+                ops.extend([OP_DIAGF, cslot, len(C_), nB, len(A_), len(wsel)] + sel + body)
                 nops += 1
                 return
-            # gen-2 kernels pair the sign functions that share a register bit (a chain qubit has two neighbours)
             bops = []
             if cfg.gen >= 2:
                 byj = {}
@@ -874,13 +931,12 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
                 # Terms on register bits only -> one table of 2^R factors, the same for all threads
                 # (DIAGC); terms on one register bit and thread bits -> exp(+-i phi) with the sign
                 # z_j(r) * parity(thread & mask) (DIAGB).  4 lane-instructions per amplitude each.
-                if C_:
-                    NR = 1 << R
-                    base = tables.alloc(2 * NR)
-                    off = phase_terms(C_)
-                    for r in range(NR):
-                        tables.ginfo.append([BK_PHASE, base + 2 * r, 0, len(C_), off, r, 0, 0])
-                    ops.extend([OP_DIAGC, base])
+                if wsel:
+                    sel = [m_ for m_, _ in wsel] + [0] * (3 - len(wsel))
+                    ops.extend([OP_DIAGCW, table_variants(), len(wsel)] + sel)
+                    nops += 1
+                elif C_:
+                    ops.extend([OP_DIAGC, table_variants()])
                     nops += 1
                 for it in bops:
                     if len(it) == 2:

@@ -54,7 +54,7 @@ def _op_histogram(pl):
                 if op == P.OP_DIAG:
                     q += 5 + int(w[q + 1]) + 2 * int(w[q + 2]) + int(w[q + 3])
                 else:
-                    q += {P.OP_G2: 4, P.OP_G1M: 3, P.OP_DIAGC: 2, P.OP_DIAGB: 4, P.OP_DIAGB2: 5}[op]
+                    q += {P.OP_G2: 4, P.OP_G1M: 3, P.OP_DIAGC: 2, P.OP_DIAGB: 4, P.OP_DIAGB2: 5, P.OP_DIAGCW: 6}[op]
             assert q == pc + P.RR_WORDS + nw
             pc = q
     return seen
