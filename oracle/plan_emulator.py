@@ -513,12 +513,13 @@ def run_adjoint_pass(psi, lam, desc, ctab, ptab_row, gout):
                 sel_masks = [int(d[q + 6 + k_]) for k_ in range(nsel)]
                 q += 9
                 w = np.imag(np.conj(regs[1]) * regs[0])  # [nwg, nth, NR]
-                for e in range(nC):
-                    rm, gs = int(d[q]), int(dsig[q + 1])
-                    q += 2
+                for rm in range(NR):      # gsC[rm]: gradient slot of the register-only term with mask rm
+                    gs = int(dsig[q + rm])
                     if gs >= 0:
+                        assert nC == 1
                         z = 1 - 2 * _parity(rid.astype(np.uint64) & np.uint64(rm))
                         gout[gs] += np.sum(w * z[None, None, :])
+                q += NR
                 if cslot >= 0:
                     v = np.zeros(tidx.shape, dtype=np.int64)
                     for k_, m_ in enumerate(sel_masks):

@@ -62,6 +62,31 @@ __device__ __forceinline__ void adj_apply(v2f (&a)[NR], int kf, v2f p0, v2f p1, 
 #undef TCMI_A8
 }
 
+// the same on psi and lambda with one test per structure class
+template <int NR, int J>
+__device__ __forceinline__ void adj_apply2(v2f (&a)[NR], v2f (&l)[NR], int kf, KV2 up) {
+  constexpr int B = 1 << J;
+#define TCMI_A8(V, FN, ...)                                                                                           \
+  _Pragma("unroll") for (int g = 0; g < NR / 2; g += 8) {                                                             \
+    const int r0 = ains0(g, J), r1 = ains0(g + 1, J), r2 = ains0(g + 2, J), r3 = ains0(g + 3, J);                     \
+    const int r4 = ains0(g + 4, J), r5 = ains0(g + 5, J), r6 = ains0(g + 6, J), r7 = ains0(g + 7, J);                 \
+    FN(V[r0], V[r0 | B], V[r1], V[r1 | B], V[r2], V[r2 | B], V[r3], V[r3 | B], V[r4], V[r4 | B], V[r5], V[r5 | B],     \
+       V[r6], V[r6 | B], V[r7], V[r7 | B], __VA_ARGS__);                                                              \
+  }
+  if (kf & (32 | 64)) {  // three shears, (u, v) only
+    const v2f p0 = up[4 * J];
+    if (kf & 32) { TCMI_A8(a, vm2_shear8_real, p0) TCMI_A8(l, vm2_shear8_real, p0) }
+    if (kf & 64) { TCMI_A8(a, vm2_shear8_rx, p0) TCMI_A8(l, vm2_shear8_rx, p0) }
+  }
+  if (kf & 7) {
+    const v2f p0 = up[4 * J], p1 = up[4 * J + 1], p2 = up[4 * J + 2], p3 = up[4 * J + 3];
+    if (kf & 4) { TCMI_A8(a, vm2_gate8_rx, p0, p1, p2, p3) TCMI_A8(l, vm2_gate8_rx, p0, p1, p2, p3) }
+    if (kf & 2) { TCMI_A8(a, vm2_gate8_real, p0, p1, p2, p3) TCMI_A8(l, vm2_gate8_real, p0, p1, p2, p3) }
+    if (kf & 1) { TCMI_A8(a, vm2_gate8_gen, p0, p1, p2, p3) TCMI_A8(l, vm2_gate8_gen, p0, p1, p2, p3) }
+  }
+#undef TCMI_A8
+}
+
 // a[r] *= (e.x + i e.y) for z_J(r) = +1, the conjugate for z_J(r) = -1
 template <int NR, int J>
 __device__ __forceinline__ void adj_diagb(v2f (&a)[NR], v2f e) {
@@ -179,35 +204,37 @@ __global__ __launch_bounds__(1 << LT, (R >= 5 ? 512 : 1024) >> LT) void adjoint2
         qn = q + 5 + R;
 #define TCMI_BW(J)                                                                                           \
   if constexpr (R > J) {                                                                                     \
-    const int kd = (mk >> (8 + 2 * J)) & 3;                                                                  \
-    const int gf = ((kmask >> J) & 1) ? aonehot_if((mk >> J) & 1, kd) : 0; /* generator class: never shear */  \
-    const int kf = aonehot_if((mk >> J) & 1, kd + 4 * ((mk >> (20 + J)) & 1));                                \
-    if (gf) {                                                                                                \
-      float g = adj_grad<NR, J>(a, l, gf, kp[4 * J], kp[4 * J + 1], kp[4 * J + 2], kp[4 * J + 3]);           \
-      g = wave_sum_uniform(g);                                                                               \
-      if (lane0) atomicAdd(gout + desc[q + 5 + J], (double)g);                                               \
+    if (aonehot_if((mk >> J) & 1, 0)) { /* register bits without a gate cost two scalar instructions */       \
+      const int kd = (mk >> (8 + 2 * J)) & 3;                                                                \
+      const int gf = aonehot_if((kmask >> J) & 1, kd); /* generator class: never shear */                     \
+      const int kf = aonehot(kd + 4 * ((mk >> (20 + J)) & 1));                                               \
+      if (gf) {                                                                                              \
+        float g = adj_grad<NR, J>(a, l, gf, kp[4 * J], kp[4 * J + 1], kp[4 * J + 2], kp[4 * J + 3]);         \
+        g = wave_sum_uniform(g);                                                                             \
+        if (lane0) atomicAdd(gout + desc[q + 5 + J], (double)g);                                             \
+      }                                                                                                      \
+      adj_apply2<NR, J>(a, l, kf, up);                                                                       \
     }                                                                                                        \
-    const v2f u0 = up[4 * J], u1 = up[4 * J + 1], u2 = up[4 * J + 2], u3 = up[4 * J + 3];                    \
-    adj_apply<NR, J>(a, kf, u0, u1, u2, u3);                                                                 \
-    adj_apply<NR, J>(l, kf, u0, u1, u2, u3);                                                                 \
   }
         TCMI_BW(0) TCMI_BW(1) TCMI_BW(2) TCMI_BW(3) TCMI_BW(4)
 #undef TCMI_BW
       }
       if (f & (1 << TCMI_OP_DIAGF)) {
-        // {8, cslot, nC, nB, nA, nsel, m0, m1, m2, C: (rmask, gslot)*, B: (j, mask, slot, gslot)*, A: (mask, gslot)*}
-        const int cslot = desc[q + 1], nC = desc[q + 2], nB = desc[q + 3], nA = desc[q + 4], nsel = desc[q + 5];
-        int qq = q + 9;
-        qn = qq + 2 * nC + 4 * nB + 2 * nA;
+        // {8, cslot, hasC, nB, nA, nsel, m0, m1, m2, gsC[2^R], B: (j, mask, slot, gslot)*, A: (mask, gslot)*}
+        const int cslot = desc[q + 1], hasC = desc[q + 2], nB = desc[q + 3], nA = desc[q + 4], nsel = desc[q + 5];
+        int qq = q + 9 + NR;
+        qn = qq + 4 * nB + 2 * nA;
         const uint32_t tidx = wg_base | tphys;
         int tvar = 0;   // wave-selected variant of the register table (OP_DIAGCW semantics)
-        {
+        if (nsel > 0) {
           const uint32_t widx = (uint32_t)__builtin_amdgcn_readfirstlane((int)tidx);
 #pragma unroll
           for (int k2 = 0; k2 < 3; ++k2)
             if (k2 < nsel) tvar |= (__popc(widx & (uint32_t)desc[q + 6 + k2]) & 1) << k2;
         }
-        // w[r] = Im(conj(lambda) psi): invariant under the phases applied here, every term's gradient is a signed sum of it
+        // w[r] = Im(conj(lambda) psi): invariant under the phases applied here.  Every term's gradient is a signed sum of
+        // it over the registers: after the Walsh-Hadamard transform below w[k] = sum_r (-1)^{|r & k|} w[r], so the term
+        // with register mask k reads its sum from w[k] (w[0]: register-independent terms, w[1 << j]: one register bit).
         float w[NR];
 #pragma unroll
         for (int h = 0; h < NR; h += 8) {
@@ -217,17 +244,27 @@ __global__ __launch_bounds__(1 << LT, (R >= 5 ? 512 : 1024) >> LT) void adjoint2
 #pragma unroll
           for (int i = 0; i < 8; ++i) w[h + i] = t[i].x - t[i].y;
         }
-#pragma unroll 1
-        for (int e = 0; e < nC; ++e, qq += 2) {
-          const int gs = desc[qq + 1];
-          if (gs >= 0) {  // wave-uniform
-            const uint32_t rmask = (uint32_t)desc[qq];
-            float s = 0.f;
+        if (hasC | nB | nA) {
 #pragma unroll
-            for (int r = 0; r < NR; ++r) s += (__popc((uint32_t)r & rmask) & 1) ? -w[r] : w[r];
-            s = wave_sum_uniform(s);
-            if (lane0) atomicAdd(gout + gs, (double)s);
-          }
+          for (int j = 0; j < R; ++j)
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+              if (!((r >> j) & 1)) {
+                const float lo = w[r], hi = w[r | (1 << j)];
+                w[r] = lo + hi;
+                w[r | (1 << j)] = lo - hi;
+              }
+        }
+        if (hasC) {
+          int gsc[NR];
+#pragma unroll
+          for (int k3 = 0; k3 < NR; ++k3) gsc[k3] = desc[q + 9 + k3];
+#pragma unroll
+          for (int k3 = 1; k3 < NR; ++k3)
+            if (gsc[k3] >= 0) {  // wave-uniform
+              const float sv = wave_sum_uniform(w[k3]);
+              if (lane0) atomicAdd(gout + gsc[k3], (double)sv);
+            }
         }
         if (cslot >= 0) {
           const KV2 tp = (KV2)(ptab + cslot + 2 * NR * tvar);
@@ -243,16 +280,10 @@ __global__ __launch_bounds__(1 << LT, (R >= 5 ? 512 : 1024) >> LT) void adjoint2
           }
         }
         if (nB > 0 || nA > 0) {
-          float w0 = 0.f, wj[R];
+          const float w0 = w[0];
+          float wj[R];
 #pragma unroll
-          for (int r = 0; r < NR; ++r) w0 += w[r];
-#pragma unroll
-          for (int j = 0; j < R; ++j) {
-            float s = 0.f;
-#pragma unroll
-            for (int r = 0; r < NR; ++r) s += ((r >> j) & 1) ? -w[r] : w[r];
-            wj[j] = s;
-          }
+          for (int j = 0; j < R; ++j) wj[j] = w[1 << j];
 #pragma unroll 1
           for (int e = 0; e < nB; ++e, qq += 4) {
             const int jj = desc[qq], slot = desc[qq + 2], gs = desc[qq + 3];

@@ -46,7 +46,7 @@
 #define TCMI_OP_EXPECT 5
 #define TCMI_OP_DIAGB 7 /* {7, j, thread mask, slot}: a[r] *= exp(+-i phi), sign = z_j(r) * parity(thread index & mask); table = {cos, sin} */
 #define TCMI_OP_DIAGC 6 /* {6, slot}: a[r] *= table[r], 2^R complex factors in the per-batch table */
-#define TCMI_OP_DIAGF 8 /* backward flush of diagonal terms in table form (tcmi_adjoint2.hip): {8, cslot (-1: none), nC, nB, nA, nsel, m0, m1, m2, C: (rmask, gslot)*, B: (j, mask, slot (-1: applied elsewhere), gslot)*, A: (mask, gslot)*}; cslot = 2^nsel wave-selected variants (as OP_DIAGCW) of the register table; tables = FORWARD phase factors, the conjugate is applied; A terms: gradient only */
+#define TCMI_OP_DIAGF 8 /* backward flush of diagonal terms in table form (tcmi_adjoint2.hip): {8, cslot (-1: none), hasC, nB, nA, nsel, m0, m1, m2, gsC[2^R] (gradient slot of the register-only term with mask k or -1; hasC = any), B: (j, mask, slot (-1: applied elsewhere), gslot)*, A: (mask, gslot)*}; cslot = 2^nsel wave-selected variants (as OP_DIAGCW) of the register table; tables = FORWARD phase factors, the conjugate is applied; A terms: gradient only */
 #define TCMI_OP_DIAGB2 9 /* {9, j, mask1, mask2, slot}: a[r] *= table[s1 + 2 s2] (conjugate for z_j(r) = -1), s_i = parity(thread index & mask_i); 4 complex factors (second-generation kernels only) */
 #define TCMI_OP_DIAGCW 10 /* {10, slot, nsel, m0, m1, m2}: a[r] *= table[v][r], v = sum_k parity(wave's thread index & m_k) << k (the masks touch wave-uniform bits only), 2^nsel tables of 2^R complex factors (second-generation kernels only) */
 #define TCMI_FLAG_NOSTORE 1

@@ -888,14 +888,23 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
                 return slot_
 
             if backward and factorized_bw:
-                # {8, cslot (-1: none), nC, nB, nA, nsel, m0, m1, m2, C: (rmask, gslot)*,
-                #  B: (j, mask, slot (-1: applied elsewhere), gslot)*, A: (mask, gslot)*}: tables hold the FORWARD phase
+                # {8, cslot (-1: none), hasC, nB, nA, nsel, m0, m1, m2, gsC[2^R] (gradient slot of the register-only term
+                #  with mask k, -1: none), B: (j, mask, slot (-1: applied elsewhere), gslot)*, A: (mask, gslot)*}: tables hold the FORWARD phase
                 #  factors (2^nsel wave-selected variants of the register table), the kernel applies the conjugate;
                 #  A terms (no register bit: only the final flush has them) contribute gradients only.
                 cslot = table_variants() if (C_ or wsel) else -1
-                body = []
+                NR_ = 1 << R
+                gsc = [-1] * NR_          # gradient slot per register mask (the term's Walsh coefficient of w)
+                dup = []                  # further terms with a mask already taken: gradient-only follow-up ops
                 for rm, t in C_:
-                    body += [rm, gslot(t)]
+                    gs_ = gslot(t)
+                    if gs_ < 0:
+                        continue
+                    if gsc[rm] < 0:
+                        gsc[rm] = gs_
+                    else:
+                        dup.append((rm, gs_))
+                body = list(gsc)
                 nB = 0
                 for m_, lst in wsel:          # applied through the table variant: gradient entries only
                     for j, t in lst:
@@ -911,8 +920,18 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
                 for nmask, t in A_:
                     body += [nmask, gslot(t)]
                 sel = [m_ for m_, _ in wsel] + [0] * (3 - len(wsel))
-                ops.extend([OP_DIAGF, cslot, len(C_), nB, len(A_), len(wsel)] + sel + body)
+                ops.extend([OP_DIAGF, cslot, int(any(g_ >= 0 for g_ in gsc)), nB, len(A_), len(wsel)] + sel + body)
                 nops += 1
+                while dup:
+                    gsc2, rest = [-1] * NR_, []
+                    for rm, gs_ in dup:
+                        if gsc2[rm] < 0:
+                            gsc2[rm] = gs_
+                        else:
+                            rest.append((rm, gs_))
+                    ops.extend([OP_DIAGF, -1, 1, 0, 0, 0, 0, 0, 0] + gsc2)
+                    nops += 1
+                    dup = rest
                 return
             bops = []
             if cfg.gen >= 2:
