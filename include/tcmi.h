@@ -91,11 +91,16 @@ int tcmi_build_adjoint_tables(const int* ginfo, int nrec, const double* cpool, c
  * gout[batch][slot] += Re <lambda| K_g |psi> for every parametrised gate g of the pass (float64,
  * caller zeroes it), then psi <- U_g^dagger psi, lambda <- U_g^dagger lambda.  After the last pass
  * psi is the circuit's input state and gout holds dL/dtheta per gate slot (replicated `gcopies`
- * times like eout above; the caller sums the copies). */
+ * times like eout above; the caller sums the copies).
+ * opset: the op set the descriptors were compiled for -- TCMI_OPSET_GENERIC (every backward op of tcmi_vm.h) or
+ * TCMI_OPSET_PACKED (complex64 plans of one-qubit gate ops and table-form diagonal flushes only, run by the
+ * packed-f32 kernel; tiles (R, LT) = (4, 8), (4, 9), (5, 8)). */
+#define TCMI_OPSET_GENERIC 0
+#define TCMI_OPSET_PACKED 1
 int tcmi_run_adjoint_pass(void* psi, void* lam, long long state_stride, int batch, int n, int R, int LT,
                           const int* desc, const void* ctab, const void* ptab, long long ptab_stride,
                           double* gout, long long gout_stride, int gcopies, long long gcopy_stride,
-                          int dtype, void* stream);
+                          int dtype, int opset, void* stream);
 
 /* ---- pairwise contraction engine (closed networks, sliced contraction) -------------------------------
  * tn.contract_between(a, b) -> backend.tensordot(a, b, axes) (tensorcircuit/cons.py:396,413,450,948 via

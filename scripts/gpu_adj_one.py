@@ -34,8 +34,9 @@ if "--passes" in sys.argv:
                     q += 5 + 2 * nA + 3 * nB + 2 * nC
                 elif op == P.OP_G2: q += 6
                 elif op == P.OP_DIAGF:
-                    nC, nB, nA = int(w[q + 2]), int(w[q + 3]), int(w[q + 4]); m["DIAG"] += 1; m["terms"] += nC + nB + nA
-                    q += 9 + 2 * nC + 4 * nB + 2 * nA
+                    nB, nA = int(w[q + 3]), int(w[q + 4]); m["DIAG"] += 1
+                    m["terms"] += int((w[q + 9:q + 9 + 2**cfg.R] >= 0).sum()) + nB + nA
+                    q += 9 + 2**cfg.R + 4 * nB + 2 * nA
             pc = q
         return m
     nel = 2**cc.n_exec; stream = torch.cuda.current_stream().cuda_stream
@@ -46,7 +47,7 @@ if "--passes" in sys.argv:
     tot = 0
     for i, dsc in enumerate(adj["descs"]):
         torch.cuda.synchronize(); e0.record()
-        _lib.check(lib.tcmi_run_adjoint_pass(a.data_ptr(), lam.data_ptr(), nel, B, cc.n_exec, cfg.R, cfg.LT, dsc.data_ptr(), adj["ctab"].data_ptr(), ptab.data_ptr(), ptab.stride(0), gout.data_ptr(), gout.stride(0), ATOMIC_COPIES, gout.stride(1), cc.code, stream), "p")
+        _lib.check(lib.tcmi_run_adjoint_pass(a.data_ptr(), lam.data_ptr(), nel, B, cc.n_exec, cfg.R, cfg.LT, dsc.data_ptr(), adj["ctab"].data_ptr(), ptab.data_ptr(), ptab.stride(0), gout.data_ptr(), gout.stride(0), ATOMIC_COPIES, gout.stride(1), cc.code, int(cfg.gen == 2), stream), "p")
         e1.record(); torch.cuda.synchronize(); ms = e0.elapsed_time(e1); tot += ms
         print(f"pass {i:2d}: {ms*1e3:8.1f} us  {4*B*2**n*8/(ms*1e-3)/1e9:6.0f} GB/s  {mix(adj['plan'].descs[i])}", flush=True)
     print(f"total {tot:.2f} ms")

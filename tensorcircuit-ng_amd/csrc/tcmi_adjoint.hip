@@ -623,19 +623,24 @@ extern "C" {
 int tcmi_run_adjoint_pass(void* psi, void* lam, long long state_stride, int batch, int n, int R, int LT,
                           const int* desc_dev, const void* ctab_dev, const void* ptab_dev,
                           long long ptab_stride, double* gout_dev, long long gout_stride, int gcopies,
-                          long long gcopy_stride, int dtype, void* stream) {
+                          long long gcopy_stride, int dtype, int opset, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (!psi || !lam || !desc_dev || !gout_dev || batch < 1 || n > 32 || gcopies < 1)
+  if (!psi || !lam || !desc_dev || !gout_dev || batch < 1 || n > 32 || gcopies < 1 ||
+      (opset != TCMI_OPSET_GENERIC && opset != TCMI_OPSET_PACKED))
     return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_run_adjoint_pass: bad argument");
-#define TCMI_CASE(FT, RR, LL) \
-  if (R == RR && LT == LL)    \
-    return launch_adjoint<FT, RR, LL>(psi, lam, state_stride, batch, n, desc_dev, ctab_dev, ptab_dev, ptab_stride, gout_dev, gout_stride, gcopies, gcopy_stride, st);
-  if (dtype == TCMI_C64) {
-    // (4, 9): the packed-f32 kernel; its plans hold one-qubit gate ops and phase polynomials only (host-checked)
+  if (opset == TCMI_OPSET_PACKED) {
+    // the packed-f32 kernel; its plans hold one-qubit gate ops and table-form diagonal flushes only (host-checked)
+    if (dtype != TCMI_C64) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_run_adjoint_pass: the packed op set is complex64 only");
     const int rc = tcmi::run_adjoint2_c64(psi, lam, state_stride, batch, n, R, LT, desc_dev, ctab_dev, ptab_dev, ptab_stride,
                                           gout_dev, gout_stride, gcopies, gcopy_stride, st);
     if (rc == TCMI_OK) return rc;
     if (rc != -1) return tcmi_set_error_(TCMI_ERR_HIP, "adjoint2_kernel launch failed");
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_run_adjoint_pass: unsupported packed (R, LT) variant");
+  }
+#define TCMI_CASE(FT, RR, LL) \
+  if (R == RR && LT == LL)    \
+    return launch_adjoint<FT, RR, LL>(psi, lam, state_stride, batch, n, desc_dev, ctab_dev, ptab_dev, ptab_stride, gout_dev, gout_stride, gcopies, gcopy_stride, st);
+  if (dtype == TCMI_C64) {
     TCMI_CASE(float, 4, 8)
     TCMI_CASE(float, 2, 6)
   } else if (dtype == TCMI_C128) {

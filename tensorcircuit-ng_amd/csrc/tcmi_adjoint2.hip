@@ -142,6 +142,34 @@ __global__ __launch_bounds__(1 << LT, (R >= 5 ? 512 : 1024) >> LT) void adjoint2
   constexpr int T = R + LT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* lds = reinterpret_cast<float*>(smem);
+  // gradient contributions of the workgroup's waves meet in LDS (ds_add_f32) and leave as ONE f64 atomic per slot
+  // and workgroup: gacc[i] / gidx[i] = sum and output slot of the i-th gradient event of the pass (events are
+  // numbered in program order, identical in every wave because the op loop is descriptor-driven)
+  constexpr int GACC = 256;
+  float* const gacc = lds + (1 << T);
+  int* const gidx = reinterpret_cast<int*>(gacc + GACC);
+  int gev = 0;
+  for (int i = threadIdx.x; i < GACC; i += (1 << LT)) gacc[i] = 0.f;
+  __syncthreads();
+#define TCMI_GFLUSH()                                                                  \
+  {                                                                                    \
+    __syncthreads();                                                                   \
+    for (int i = threadIdx.x; i < gev; i += (1 << LT)) {                               \
+      atomicAdd(gout + gidx[i], (double)gacc[i]);                                      \
+      gacc[i] = 0.f;                                                                   \
+    }                                                                                  \
+    gev = 0;                                                                           \
+    __syncthreads();                                                                   \
+  }
+#define TCMI_GADD(SLOT, VAL)                             \
+  {                                                      \
+    if (gev == GACC) TCMI_GFLUSH() /* workgroup-uniform */ \
+    if (lane0) {                                         \
+      atomicAdd(gacc + gev, VAL);                        \
+      gidx[gev] = SLOT; /* same value from every wave */ \
+    }                                                    \
+    ++gev;                                               \
+  }
 
   const uint32_t tid = threadIdx.x;
   psi += (long long)blockIdx.y * state_stride;
@@ -211,7 +239,7 @@ __global__ __launch_bounds__(1 << LT, (R >= 5 ? 512 : 1024) >> LT) void adjoint2
       if (gf) {                                                                                              \
         float g = adj_grad<NR, J>(a, l, gf, kp[4 * J], kp[4 * J + 1], kp[4 * J + 2], kp[4 * J + 3]);         \
         g = wave_sum_uniform(g);                                                                             \
-        if (lane0) atomicAdd(gout + desc[q + 5 + J], (double)g);                                             \
+        TCMI_GADD(desc[q + 5 + J], g)                                                                        \
       }                                                                                                      \
       adj_apply2<NR, J>(a, l, kf, up);                                                                       \
     }                                                                                                        \
@@ -263,7 +291,7 @@ __global__ __launch_bounds__(1 << LT, (R >= 5 ? 512 : 1024) >> LT) void adjoint2
           for (int k3 = 1; k3 < NR; ++k3)
             if (gsc[k3] >= 0) {  // wave-uniform
               const float sv = wave_sum_uniform(w[k3]);
-              if (lane0) atomicAdd(gout + gsc[k3], (double)sv);
+              TCMI_GADD(gsc[k3], sv)
             }
         }
         if (cslot >= 0) {
@@ -293,7 +321,7 @@ __global__ __launch_bounds__(1 << LT, (R >= 5 ? 512 : 1024) >> LT) void adjoint2
 #pragma unroll
               for (int j = 1; j < R; ++j) ws = (j == jj) ? wj[j] : ws;
               ws = wave_sum_uniform(neg ? -ws : ws);
-              if (lane0) atomicAdd(gout + gs, (double)ws);
+              TCMI_GADD(gs, ws)
             }
             if (slot >= 0) {
               const KPtr<float> tp = ptab + slot;
@@ -319,7 +347,7 @@ __global__ __launch_bounds__(1 << LT, (R >= 5 ? 512 : 1024) >> LT) void adjoint2
             if (gs >= 0) {
               const bool neg = __popc(tidx & (uint32_t)desc[qq]) & 1;
               const float v = wave_sum_uniform(neg ? -w0 : w0);
-              if (lane0) atomicAdd(gout + gs, (double)v);
+              TCMI_GADD(gs, v)
             }
           }
         }
@@ -363,6 +391,9 @@ __global__ __launch_bounds__(1 << LT, (R >= 5 ? 512 : 1024) >> LT) void adjoint2
     }
   }
 
+  TCMI_GFLUSH()
+#undef TCMI_GADD
+#undef TCMI_GFLUSH
   {
     const KInt rl = desc + pc_cur;
     uint32_t rpm[R];
@@ -391,7 +422,7 @@ static int launch_adjoint2(void* psi, void* lam, long long stride, int batch, in
                            long long gcopy_stride, hipStream_t st) {
   constexpr int T = R + LT;
   if (n < T) return -1;
-  const size_t lds = sizeof(float) << T;
+  const size_t lds = (sizeof(float) << T) + 256 * (sizeof(float) + sizeof(int));
   auto kern = n <= 29 ? adjoint2_kernel<R, LT, uint32_t> : adjoint2_kernel<R, LT, unsigned long long>;
   dim3 grid(1u << (n - T), (unsigned)batch, 1), block(1u << LT, 1, 1);
   hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<v2f*>(psi), reinterpret_cast<v2f*>(lam), stride, desc,
@@ -406,6 +437,8 @@ int run_adjoint2_c64(void* psi, void* lam, long long stride, int batch, int n, i
                      int gcopies, long long gcopy_stride, hipStream_t st) {
   if (R == 4 && LT == 9)
     return launch_adjoint2<4, 9>(psi, lam, stride, batch, n, desc, ctab, ptab, ptab_stride, gout, gout_stride, gcopies, gcopy_stride, st);
+  if (R == 4 && LT == 8)
+    return launch_adjoint2<4, 8>(psi, lam, stride, batch, n, desc, ctab, ptab, ptab_stride, gout, gout_stride, gcopies, gcopy_stride, st);
   if (R == 5 && LT == 8)
     return launch_adjoint2<5, 8>(psi, lam, stride, batch, n, desc, ctab, ptab, ptab_stride, gout, gout_stride, gcopies, gcopy_stride, st);
   return -1;

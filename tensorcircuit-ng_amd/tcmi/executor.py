@@ -296,7 +296,7 @@ class CompiledCircuit:
                     lib.tcmi_run_adjoint_pass(
                         a.data_ptr(), lam.data_ptr(), nel, nb, self.n_exec, cfg.R, cfg.LT, d.data_ptr(),
                         adj["ctab"].data_ptr(), ptab.data_ptr(), ptab.stride(0), gout.data_ptr(),
-                        gout.stride(0), ATOMIC_COPIES, gout.stride(1), self.code, stream),
+                        gout.stride(0), ATOMIC_COPIES, gout.stride(1), self.code, int(cfg.gen == 2), stream),
                     "tcmi_run_adjoint_pass",
                 )
             tm.__exit__(None, None, None)
@@ -389,13 +389,17 @@ def pick_measure_variant(n_exec: int, dtypestr: str) -> P.PlanConfig:
 
 def pick_adjoint_variant(n_exec: int, dtypestr: str, gates) -> P.PlanConfig:
     """Tile of the adjoint sweep (two vectors live in registers).  complex64 circuits of one-qubit gates and
-    diagonals on >= 13 qubits run on the packed-f32 kernel (csrc/tcmi_adjoint2.hip: R = 4, 512 threads, 13 tile
-    bits); dense two-qubit gates and small circuits keep the first-generation kernel."""
+    diagonals on >= 13 qubits run on the packed-f32 kernel (csrc/tcmi_adjoint2.hip: R = 4, 256 threads, 12 tile
+    bits, four workgroups per CU -- one more pass than the 13-bit tile at n = 28, but the load / compute / store
+    phases of four workgroups overlap better than those of two: 44.1 vs 47.6 ms per sample); dense two-qubit
+    gates and small circuits keep the first-generation kernel."""
     dense2 = any((not g.is_diag) and len(g.qubits) > 1 for g in gates)
     if dtypestr == "complex64" and n_exec >= 13 and not dense2 and not os.environ.get("TCMI_VM1"):
         if os.environ.get("TCMI_ADJ_R5"):   # experiment switch: 32 + 32 amplitude pairs per thread, 2 waves per SIMD
             return P.PlanConfig(R=5, LT=8, lowbits=5, vec=2, gen=2)
-        return P.PlanConfig(R=4, LT=9, lowbits=5, vec=2, gen=2)
+        if os.environ.get("TCMI_ADJ_LT9"):  # experiment switch: 512-thread workgroups, two per CU, 13 tile bits
+            return P.PlanConfig(R=4, LT=9, lowbits=5, vec=2, gen=2)
+        return P.PlanConfig(R=4, LT=8, lowbits=5, vec=2, gen=2)
     return pick_measure_variant(n_exec, dtypestr)
 
 
