@@ -21,9 +21,16 @@ def run(n, d, B, reps=3):
     params = tc.backend.convert_to_tensor(np.random.default_rng(n).normal(0, 0.1, [B, 2*d, n]).astype(np.float32))
     fn = tc.backend.vvag(f, argnums=0, vectorized_argnums=0)
     t0 = time.time(); v, g = fn(params); torch.cuda.synchronize(); t_first = time.time() - t0
+    from tcmi import executor as X
+    X.EVENT_LOG = []
     t0 = time.time()
     for _ in range(reps): v, g = fn(params)
     torch.cuda.synchronize(); t = (time.time() - t0) / reps
+    tags = {}
+    for tag, e0, e1, launches, work in X.EVENT_LOG:
+        tt = tags.setdefault(tag, [0.0, 0, 0]); tt[0] += e0.elapsed_time(e1) / reps; tt[1] += launches / reps; tt[2] += 1 / reps
+    X.EVENT_LOG = None
+    print("   per step: " + "  ".join(f"{k} {v_[0]:.1f} ms ({v_[1]:.0f} launches, {v_[2]:.0f} calls)" for k, v_ in tags.items()), flush=True)
     print(f"VQE n={n} d={d} B={B}: first {t_first:.3f}s steady {t*1e3:.1f} ms/step  E0={float(v[0]):.5f} |g|={float(g.norm()):.4f} mem={torch.cuda.max_memory_allocated()/2**30:.1f}GiB", flush=True)
     # decomposition: forward only / measure only
     c = tc.Circuit(n); W.hea_b(c, n, d, params[0], zz=tc.gates._zz_matrix)
