@@ -52,12 +52,18 @@ template <bool TRANS_A>
 __global__ __launch_bounds__(256, 6) void cgemm_mfma_kernel(const float2* __restrict__ A,
                                                           const float2* __restrict__ B,
                                                           float2* __restrict__ C, int M, int N, int K,
-                                                          long long sA, long long sB, long long sC) {
+                                                          long long sA, long long sB, long long sC, int ksplit,
+                                                          int kchunk) {
   __shared__ __attribute__((aligned(16))) float As_re[TCMI_CBK][TCMI_LDP], As_im[TCMI_CBK][TCMI_LDP];
   __shared__ __attribute__((aligned(16))) float Bs_re[TCMI_CBK][TCMI_LDP], Bs_im[TCMI_CBK][TCMI_LDP];
-  A += (long long)blockIdx.z * sA;
-  B += (long long)blockIdx.z * sB;
-  C += (long long)blockIdx.z * sC;
+  // split-K (ksplit > 1): blockIdx.z = batch * ksplit + chunk, every chunk adds its partial product into a
+  // zeroed C with f32 atomics -- few-tile products with a long K (the closing steps of a contraction tree:
+  // 32 x 32 outputs over K = 2^20) would otherwise run on a handful of CUs
+  const int bz = (int)blockIdx.z / ksplit, ks = (int)blockIdx.z - bz * ksplit;
+  const int kbeg = ks * kchunk, kend = (kbeg + kchunk < K) ? kbeg + kchunk : K;
+  A += (long long)bz * sA;
+  B += (long long)bz * sB;
+  C += (long long)bz * sC;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const long long m0 = (long long)blockIdx.y * TCMI_BM, n0 = (long long)blockIdx.x * TCMI_BN;
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(256, 6) void cgemm_mfma_kernel(const float2* __rest
   // 16-byte global loads need even leading dimensions (and 16-byte aligned batch bases)
   const bool vecA = TRANS_A ? ((M & 1) == 0 && (sA & 1) == 0) : ((K & 1) == 0 && (sA & 1) == 0);
   const bool vecB = (N & 1) == 0 && (sB & 1) == 0;
-  for (int k0 = 0; k0 < K; k0 += TCMI_CBK) {
+  for (int k0 = kbeg; k0 < kend; k0 += TCMI_CBK) {
 #pragma unroll
     for (int h = 0; h < TCMI_CBK / 8; ++h) {
       const int ak = ak0 + 8 * h, bk = bk0 + 8 * h;
@@ -78,7 +84,7 @@ __global__ __launch_bounds__(256, 6) void cgemm_mfma_kernel(const float2* __rest
       if constexpr (TRANS_A) {
         const long long r = m0 + ai;
         const int kk = k0 + ak;
-        if (kk < K) {
+        if (kk < kend) {
           if (vecA && r + 1 < M) {
             const float4 t = *reinterpret_cast<const float4*>(A + (long long)kk * M + r);
             v0.x = t.x; v0.y = t.y; v1.x = t.z; v1.y = t.w;
@@ -93,12 +99,12 @@ __global__ __launch_bounds__(256, 6) void cgemm_mfma_kernel(const float2* __rest
         const long long r = m0 + ai;
         const int kk = k0 + ak;
         if (r < M) {
-          if (vecA && kk + 1 < K) {
+          if (vecA && kk + 1 < kend) {
             const float4 t = *reinterpret_cast<const float4*>(A + r * K + kk);
             v0.x = t.x; v0.y = t.y; v1.x = t.z; v1.y = t.w;
           } else {
-            if (kk < K) v0 = A[r * K + kk];
-            if (kk + 1 < K) v1 = A[r * K + kk + 1];
+            if (kk < kend) v0 = A[r * K + kk];
+            if (kk + 1 < kend) v1 = A[r * K + kk + 1];
           }
         }
         As_re[ak][ai] = v0.x;
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(256, 6) void cgemm_mfma_kernel(const float2* __rest
       float2 w0 = {0.f, 0.f}, w1 = {0.f, 0.f};
       const long long c = n0 + bj;
       const int kb = k0 + bk;
-      if (kb < K) {
+      if (kb < kend) {
         if (vecB && c + 1 < N) {
           const float4 t = *reinterpret_cast<const float4*>(B + (long long)kb * N + c);
           w0.x = t.x; w0.y = t.y; w1.x = t.z; w1.y = t.w;
@@ -142,7 +148,12 @@ __global__ __launch_bounds__(256, 6) void cgemm_mfma_kernel(const float2* __rest
       float2 o;
       o.x = p1[reg] - p2[reg];
       o.y = p3[reg] - p1[reg] - p2[reg];
-      C[row * N + col] = o;
+      if (ksplit > 1) {
+        atomicAdd(&C[row * N + col].x, o.x);
+        atomicAdd(&C[row * N + col].y, o.y);
+      } else {
+        C[row * N + col] = o;
+      }
     }
   }
 }
@@ -664,17 +675,33 @@ int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, 
     // 2^27) are issued as row chunks — plain pointer offsets for a row-major A
     const long long mchunk = 65535ll * TCMI_BM / 2;
     if (M > mchunk && trans_a) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm: grid too large (transposed A)");
+    // few output tiles and a long K: split K over blockIdx.z, partial products meet in C through atomics
+    const long long tiles = gx * ((M + TCMI_BM - 1) / TCMI_BM) * batch;
+    int ksplit = 1, kchunk = (int)K;
+    if (tiles < 256 && K >= 4096) {
+      long long want = (1024 + tiles - 1) / tiles;
+      if (want > K / 1024) want = K / 1024;
+      if (want * batch > 65535) want = 65535 / batch;
+      if (want > 1) {
+        kchunk = (int)(((K + want - 1) / want + TCMI_CBK - 1) / TCMI_CBK * TCMI_CBK);
+        ksplit = (int)((K + kchunk - 1) / kchunk);
+        for (int b = 0; b < batch; ++b) {
+          hipError_t me = hipMemsetAsync(reinterpret_cast<float2*>(C) + (size_t)b * strideC, 0, (size_t)(M * N) * sizeof(float2), st);
+          if (me != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(me));
+        }
+      }
+    }
     for (long long m0 = 0; m0 < M; m0 += mchunk) {
       const long long mm = (M - m0 < mchunk) ? (M - m0) : mchunk;
       const float2* Ap = reinterpret_cast<const float2*>(A) + (trans_a ? 0 : m0 * K);
       float2* Cp = reinterpret_cast<float2*>(C) + m0 * N;
-      dim3 grid((unsigned)gx, (unsigned)((mm + TCMI_BM - 1) / TCMI_BM), (unsigned)batch), block(256, 1, 1);
+      dim3 grid((unsigned)gx, (unsigned)((mm + TCMI_BM - 1) / TCMI_BM), (unsigned)(batch * ksplit)), block(256, 1, 1);
       if (trans_a)
         hipLaunchKernelGGL(tcmi::cgemm_mfma_kernel<true>, grid, block, 0, st, Ap, reinterpret_cast<const float2*>(B), Cp,
-                           (int)mm, (int)N, (int)K, strideA, strideB, strideC);
+                           (int)mm, (int)N, (int)K, strideA, strideB, strideC, ksplit, kchunk);
       else
         hipLaunchKernelGGL(tcmi::cgemm_mfma_kernel<false>, grid, block, 0, st, Ap, reinterpret_cast<const float2*>(B), Cp,
-                           (int)mm, (int)N, (int)K, strideA, strideB, strideC);
+                           (int)mm, (int)N, (int)K, strideA, strideB, strideC, ksplit, kchunk);
     }
   } else if (dtype == TCMI_C128 && M * N >= 1024) {
     const long long gx = (N + TCMI_BN - 1) / TCMI_BN;

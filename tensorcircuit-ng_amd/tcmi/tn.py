@@ -344,6 +344,12 @@ def search_path(inputs, output, size_dict, trials: int = 0, seed: int = 0, targe
 
 RECONF_SUBTREE = 10   # intermediates per re-optimised subtree (3^k / 2 splits per dynamic programme)
 RECONF_ALPHA = 0.0     # cost of a step = MACs + alpha * (elements read + written)
+RECONF_COMBO_ALPHAS = (16.0, 32.0, 64.0, 128.0)   # bytes weights tried on the sliced tree (see _reconfigure_sliced)
+# two-roof step model of ContractionTree.model_time (measured on MI355X, profiles/r02*: the MFMA GEMM route with its
+# operand permutes sustains ~100 Tflop/s on 2^27-element steps, the scattered big x small kernel 2.6 - 5 TB/s)
+MODEL_TFLOPS = 100.0
+MODEL_GBS = 4000.0
+MODEL_STEP_S = 8e-6
 
 
 def reconfigure_path(inputs, output, size_dict, path, subtree_size: int = 8, max_size: Optional[int] = None,
@@ -728,9 +734,28 @@ class ContractionTree:
             return self
         return self._slice_repath(target_size, max_slices, max_candidates)
 
+    def model_time(self, itemsize: int = 8) -> float:
+        """Seconds one rank needs for all slices under the two-roof model of a pairwise step on the MI355X engine:
+        max(flops / MODEL_TFLOPS, (|A| + |B| + |C|) itemsize / MODEL_GBS) + MODEL_STEP_S, slice-invariant steps
+        counted once (``contract_slices`` computes them once).  The RQC networks of config 4 sit at the ridge: the
+        flops-optimal tree moves 130 GB for 2.3 Tflop, i.e. it is bound by the bytes of its big x small steps."""
+        steps, dep, _, _ = self._symbolic_steps()
+        t_inv = t_sl = 0.0
+        for (sa, sb, keep), st in zip(self._walk(), steps):
+            fl = 8.0 * self._size(sa | sb)
+            by = float(itemsize) * (self._size(sa) + self._size(sb) + self._size(keep))
+            t = max(fl / (MODEL_TFLOPS * 1e12), by / (MODEL_GBS * 1e9)) + MODEL_STEP_S
+            if dep[st[4]]:
+                t_sl += t
+            else:
+                t_inv += t
+        return t_inv + self.nslices * t_sl
+
     def _reconfigure_sliced(self, target_size: int) -> None:
         """Subtree reconfiguration of the sliced network under the size cap (what cotengra's
-        ``slicing_reconf_opts`` does after choosing the sliced indices)."""
+        ``slicing_reconf_opts`` does after choosing the sliced indices): first for flops, then -- the engine is
+        HBM-bound on big x small steps -- with cotengra's "combo" objective flops + alpha * (elements read +
+        written) for a few alpha; the tree with the smallest ``model_time`` is kept."""
         sl = set(self.sliced_inds)
         inputs = [[e for e in s if e not in sl] for s in self.inputs]
         output = [e for e in self.output if e not in sl]
@@ -740,6 +765,16 @@ class ContractionTree:
                                                        subtree_size=RECONF_SUBTREE, max_size=target_size)]
         if self.total_flops() > before or self.max_size() > target_size:
             self.path = old
+        base = self.path
+        best_path, best_t = base, self.model_time()
+        for alpha in RECONF_COMBO_ALPHAS:
+            self.path = [tuple(x) for x in reconfigure_path(inputs, output, self.size_dict, base, subtree_size=8,
+                                                           max_size=target_size, alpha=alpha)]
+            if self.max_size() <= target_size:
+                t = self.model_time()
+                if t < best_t * (1.0 - 1e-9):
+                    best_path, best_t = self.path, t
+        self.path = best_path
 
     def _slice_repath(self, target_size: int, max_slices: int = 1 << 16, max_candidates: int = 12) -> "ContractionTree":
         """Each step tries the (non-output) indices of the largest intermediates, re-paths the sliced
@@ -836,6 +871,10 @@ class ContractionTree:
         not depend on a sliced index (most of the small early steps of a circuit network: only a few leaves carry
         the sliced indices) are computed once and reused by every slice."""
         steps, dep, last, final_perm = self._symbolic_steps()
+        slice_ids = list(slice_ids)
+        if _graph_ok(arrays, len(steps), slice_ids):
+            yield from self._contract_slices_graph(arrays, slice_ids)
+            return
         shared_t: Dict[int, Any] = {}
         n = len(self.inputs)
         for i in slice_ids:
@@ -858,6 +897,83 @@ class ContractionTree:
             if final_perm is not None:
                 res = permute(res, final_perm)
             yield res
+
+    def _run_steps(self, leaves: Dict[int, Any], shared_t: Dict[int, Any], invariant: bool):
+        """The slice-invariant (``invariant``) or the slice-dependent steps, eagerly, on the given leaf tensors."""
+        steps, dep, last, final_perm = self._symbolic_steps()
+        if invariant:
+            for ia, ib, xa, xb, io in steps:
+                if not dep[io]:
+                    shared_t[io] = tensordot(shared_t[ia], shared_t[ib], xa, xb)
+            return None
+        cur = dict(leaves)
+        for ia, ib, xa, xb, io in steps:
+            if not dep[io]:
+                continue
+            ta = cur.pop(ia) if dep[ia] else shared_t[ia]
+            tb = cur.pop(ib) if dep[ib] else shared_t[ib]
+            cur[io] = tensordot(ta, tb, xa, xb)
+        res = cur[last] if dep[last] else shared_t[last]
+        if final_perm is not None:
+            res = permute(res, final_perm)
+        return res
+
+    def _contract_slices_graph(self, arrays: Sequence[Any], slice_ids: Sequence[int]):
+        """``contract_slices`` as two HIP graphs, captured once per (tree, operand signature) and replayed: the
+        slice-invariant steps (one replay per call) and the slice-dependent steps (one replay per slice), reading
+        static copies of the leaf tensors.  A sliced RQC tree is hundreds of launches of a few microseconds each;
+        issued one by one from Python the launch gaps are 20 % of the wall time (profiles/r02*_rqc_steps.txt)."""
+        import torch
+
+        global COUNTERS
+        steps, dep, last, final_perm = self._symbolic_steps()
+        n = len(self.inputs)
+        first = self.slice_arrays(arrays, slice_ids[0])
+        sig = (tuple(self.path), tuple(self.sliced_inds),
+               tuple((tuple(t.shape), t.dtype, t.device) for t in first))
+        cache = getattr(self, "_graph_cache", None)
+        if cache is None or cache["sig"] != sig:
+            # warm-up: one eager slice (plans, bit-permutation tables and kernels are created outside the capture)
+            warm: Dict[int, Any] = {k: first[k] for k in range(n) if not dep[k]}
+            keep_counters, COUNTERS = COUNTERS, None
+            try:
+                self._run_steps({}, warm, True)
+                self._run_steps({k: first[k] for k in range(n) if dep[k]}, warm, False)
+                torch.cuda.synchronize()
+                del warm
+                static = [first[k].contiguous().clone() for k in range(n)]
+                shared_t: Dict[int, Any] = {k: static[k] for k in range(n) if not dep[k]}
+                COUNTERS = new_counters()
+                g_inv = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_inv):
+                    self._run_steps({}, shared_t, True)
+                cnt_inv, COUNTERS = COUNTERS, new_counters()
+                g_sl = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_sl, pool=g_inv.pool()):
+                    res = self._run_steps({k: static[k] for k in range(n) if dep[k]}, shared_t, False)
+                cnt_sl = COUNTERS
+            finally:
+                COUNTERS = keep_counters
+            cache = {"sig": sig, "static": static, "shared": shared_t, "g_inv": g_inv, "g_sl": g_sl, "res": res,
+                     "cnt_inv": cnt_inv, "cnt_sl": cnt_sl}
+            self._graph_cache = cache
+        static = cache["static"]
+        inv_k = [k for k in range(n) if not dep[k]]
+        dep_k = [k for k in range(n) if dep[k]]
+        torch._foreach_copy_([static[k] for k in inv_k], [first[k] for k in inv_k])
+        cache["g_inv"].replay()
+        if COUNTERS is not None:
+            for key, v in cache["cnt_inv"].items():
+                COUNTERS[key] += v
+        for i in slice_ids:
+            sliced = first if i == slice_ids[0] else self.slice_arrays(arrays, i)
+            for k in dep_k:
+                static[k].copy_(sliced[k])
+            cache["g_sl"].replay()
+            if COUNTERS is not None:
+                for key, v in cache["cnt_sl"].items():
+                    COUNTERS[key] += v
+            yield cache["res"].clone()
 
     def contract_core(self, arrays: Sequence[Any]):
         """Pairwise contraction of (already sliced) arrays along the path; returns the result with
@@ -900,6 +1016,21 @@ class ContractionTree:
 
 # ---- device part: permute / tensordot through the C ABI --------------------------------------------
 _SRCBIT_CACHE: Dict[Tuple, Any] = {}
+GRAPH_MIN_STEPS = 32   # trees with fewer steps are not worth two graph captures
+
+
+def _graph_ok(arrays, nsteps: int, slice_ids) -> bool:
+    """HIP-graph replay of ``contract_slices`` (TCMI_TN_GRAPH=0 disables): plain complex device tensors, nothing on
+    an autograd tape or inside a functorch transform, and enough steps for the launch gaps to matter."""
+    import os
+    import torch
+
+    if os.environ.get("TCMI_TN_GRAPH", "1") == "0" or nsteps < GRAPH_MIN_STEPS or not slice_ids:
+        return False
+    for t in arrays:
+        if not (torch.is_tensor(t) and t.is_cuda and t.is_complex()) or _on_tape(t) or any(d != 2 for d in t.shape):
+            return False
+    return not torch.cuda.is_current_stream_capturing()
 
 
 def _code(t):

@@ -316,6 +316,28 @@ def test_tall_gemm_is_issued_in_row_chunks(dt):
     assert float((c - ref).abs().max()) < tol * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("trans_a", [0, 1])
+@pytest.mark.parametrize("shape", [(32, 32, 1 << 16), (64, 128, (1 << 14) + 40), (96, 32, 5000)])
+def test_few_tile_long_k_gemm_splits_k(shape, trans_a):
+    """Few output tiles and a long K (closing steps of a contraction tree, e.g. 32 x 32 over K = 2^20): the MFMA
+    kernel splits K over the grid and sums the partial products with atomics; same numbers as one pass, with a
+    batch and a ragged last chunk."""
+    import torch
+    from tcmi import _lib
+
+    M, N, K = shape
+    g = torch.Generator(device="cuda").manual_seed(2)
+    batch = 2
+    a = torch.randn(batch, M, K, dtype=torch.complex64, device="cuda", generator=g) / np.sqrt(K)
+    b = torch.randn(batch, K, N, dtype=torch.complex64, device="cuda", generator=g)
+    a_st = a.transpose(1, 2).contiguous() if trans_a else a
+    c = torch.full((batch, M, N), float("nan"), dtype=torch.complex64, device="cuda")
+    _lib.check(_lib.lib().tcmi_cgemm(a_st.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, batch, M * K, K * N, M * N,
+                                     trans_a, _lib.TCMI_C64, torch.cuda.current_stream().cuda_stream), "tcmi_cgemm")
+    ref = (a.to(torch.complex128) @ b.to(torch.complex128))
+    assert float((c - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("dt", ["complex64", "complex128"])
 def test_scattered_contraction_matches_tensordot(dt):
     """tcmi_contract_scattered (big tensor x small tensor over arbitrary axes, no permute of the big one) against
