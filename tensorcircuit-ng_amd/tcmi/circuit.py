@@ -14,6 +14,7 @@ follow the reference.
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
+from collections import OrderedDict
 
 from . import cons
 from . import gates as G
@@ -122,6 +123,10 @@ def _split_truncate(m, split_conf):
     return m1 if k1 <= k2 else m2
 
 
+_CONST_CACHE: "OrderedDict[int, tuple]" = OrderedDict()
+_CONST_CACHE_MAX = 4096
+
+
 def _constant_value(t, what):
     """numpy value of a matrix-like gate argument that is baked into the plan as a constant.  A tensor that is being
     differentiated (requires_grad) or transformed (vmap / grad wrappers) cannot be a constant: the reference would
@@ -135,6 +140,19 @@ def _constant_value(t, what):
                     f"Backend 'hip' has not implemented differentiation / vmap through a tensor-valued {what}; "
                     "pass it as a constant (detach) or use a parametrised gate."
                 )
+            if t.is_cuda:
+                # constant gate tensors that live on the device (e.g. the same Haar-random gates handed to every
+                # call of a DistributedContractor nodes_fn): one device-to-host copy per tensor VERSION, not per use
+                key = id(t)
+                hit = _CONST_CACHE.get(key)
+                if hit is not None and hit[0] is t and hit[1] == t._version:
+                    _CONST_CACHE.move_to_end(key)
+                    return hit[2]
+                val = cons.backend.numpy(t)
+                _CONST_CACHE[key] = (t, t._version, val)   # holds t: its id cannot be reused while cached
+                if len(_CONST_CACHE) > _CONST_CACHE_MAX:
+                    _CONST_CACHE.popitem(last=False)
+                return val
         return cons.backend.numpy(t)
     return t
 
@@ -665,10 +683,20 @@ class Circuit:
             t = self._input_tensor().to(dt).reshape([2] * n)
             front = [tn.new_edge() for _ in range(n)]
             nodes.append(tn.Node(t.conj().resolve_conj() if conj else t, list(front), name="inputs"))
-        for op in self._ops:
+        # constant gates: one upload per gate size (a 32-qubit RQC has hundreds of 4 x 4 constants)
+        const_dev: Dict[int, Any] = {}
+        by_size: Dict[int, List[int]] = {}
+        for i, op in enumerate(self._ops):
+            if op.matrix is not None:
+                by_size.setdefault(int(np.asarray(op.matrix).size), []).append(i)
+        for size, idxs in by_size.items():
+            stack = torch.as_tensor(np.stack([np.asarray(self._ops[i].matrix).reshape(-1) for i in idxs]), device=dev).to(dt)
+            for r, i in enumerate(idxs):
+                const_dev[i] = stack[r]
+        for i, op in enumerate(self._ops):
             k = len(op.qubits)
             if op.matrix is not None:
-                m = torch.as_tensor(op.matrix, dtype=dt, device=dev)
+                m = const_dev[i]
             else:
                 s = op.spec
                 th = self._params[op.pidx]
