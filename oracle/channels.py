@@ -37,3 +37,25 @@ def phasedamping(gamma):
 def reset():
     """channels.py:308-310: |0><0|, |0><1|."""
     return [np.array([[1, 0], [0, 0]], dtype=np.complex128), np.array([[0, 1], [0, 0]], dtype=np.complex128)]
+
+
+def generaldepolarizing(p, num_qubits=1):
+    """reference channels.py:139-230: Kraus operators sqrt(prob_j) P_j, P_j the n-qubit Pauli strings in the order of
+    itertools.product(I, X, Y, Z) with the first factor on the first (most significant) qubit; ``p`` scalar: every
+    non-identity string has probability p, identity 1 - (4^n - 1) p."""
+    import itertools
+
+    m = 4 ** num_qubits - 1
+    probs = [1 - m * p] + [p] * m if np.ndim(p) == 0 else [1 - sum(p)] + list(p)
+    ks = []
+    for pr, fac in zip(probs, itertools.product([_I, _X, _Y, _Z], repeat=num_qubits)):
+        mat = np.array([[1.0 + 0j]])
+        for f in fac:
+            mat = np.kron(mat, f)
+        ks.append(np.sqrt(pr) * mat)
+    return ks
+
+
+def isotropicdepolarizing(p, num_qubits=1):
+    """reference channels.py:103-136."""
+    return generaldepolarizing(p / (4 ** num_qubits - 1), num_qubits)

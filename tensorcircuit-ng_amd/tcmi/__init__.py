@@ -31,7 +31,7 @@ from . import interfaces  # noqa: E402,F401
 from . import channels  # noqa: E402,F401
 from .densitymatrix import DMCircuit, DMCircuit2  # noqa: E402,F401
 from . import backends  # noqa: E402,F401
-from . import tn, experimental, distributed  # noqa: E402,F401
+from . import tn, experimental, distributed, simplify  # noqa: E402,F401
 from .backends import get_backend  # noqa: E402,F401
 
 set_backend("hip")

@@ -25,18 +25,30 @@ def depolarizingchannel(px: float, py: float, pz: float) -> List[Gate]:
 
 
 def isotropicdepolarizingchannel(p: float, num_qubits: int = 1) -> List[Gate]:
-    """reference channels.py:109-136 (one qubit on the hip backend)."""
-    if num_qubits != 1:
-        raise NotImplementedError("Backend 'hip' has not implemented multi-qubit depolarizing channels.")
-    return depolarizingchannel(p / 3, p / 3, p / 3)
+    """reference channels.py:103-136: (1 - p) rho + p / (4^n - 1) sum_j P_j rho P_j."""
+    return generaldepolarizingchannel(float(p) / (4 ** num_qubits - 1), num_qubits)
 
 
 def generaldepolarizingchannel(p, num_qubits: int = 1) -> List[Gate]:
-    """reference channels.py:139-230 (one qubit): p scalar (same for x, y, z) or a list of three."""
-    if num_qubits != 1:
-        raise NotImplementedError("Backend 'hip' has not implemented multi-qubit depolarizing channels.")
-    ps = [p, p, p] if np.ndim(p) == 0 else list(p)
-    return depolarizingchannel(*ps)
+    """reference channels.py:139-230: sqrt(prob_j) P_j over the n-qubit Pauli strings in lexicographic (I, X, Y, Z)
+    order, first factor = first qubit; ``p`` a float (every non-identity string) or the 4^n - 1 probabilities."""
+    m = 4 ** num_qubits - 1
+    if np.ndim(p) == 0:
+        probs = [1 - m * float(p)] + m * [float(p)]
+    else:
+        if len(p) != m:
+            raise ValueError(f"Invalid probability input {p}")
+        probs = [1 - float(sum(p))] + [float(x) for x in p]
+    if not np.all(np.array(probs) >= 0):
+        raise ValueError(f"Invalid probability input {p}")
+    paulis = [_I, _X, _Y, _Z]
+    out = []
+    for j, pr in enumerate(probs):
+        mat = np.ones((1, 1), dtype=np.complex128)
+        for q in range(num_qubits):
+            mat = np.kron(mat, paulis[(j // 4 ** (num_qubits - 1 - q)) % 4])
+        out.append(Gate((np.sqrt(pr) * mat).astype(cons.npdtype).reshape([2] * (2 * num_qubits))))
+    return out
 
 
 def amplitudedampingchannel(gamma: float, p: float) -> List[Gate]:

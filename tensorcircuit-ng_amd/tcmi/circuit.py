@@ -616,9 +616,22 @@ class Circuit:
 
     sexpps = sample_expectation_ps
 
-    def expectation(self, *ops: Tuple[Any, List[int]], reuse: bool = True, **kws: Any) -> Tensor:
-        """reference circuit.py:833-913 (noise-free branch): complex scalar <psi| prod ops |psi>."""
+    def expectation(self, *ops: Tuple[Any, List[int]], reuse: bool = True, enable_lightcone: bool = False,
+                    **kws: Any) -> Tensor:
+        """reference circuit.py:833-913 (noise-free branch): complex scalar <psi| prod ops |psi>.
+        ``enable_lightcone``: the network form with every U / U^dagger pair outside the causal cone of the operators
+        cancelled (reference circuit.py:897-901, simplify.py:198-296), contracted by the contraction engine -- cheap
+        on deep-narrow circuits where the cone is much smaller than the state."""
         from .functional import circuit_expectation
+
+        if kws.get("noise_conf") is not None:
+            raise NotImplementedError("Backend 'hip' has not implemented noise_conf expectation (noise models are out of scope)")
+        if enable_lightcone:
+            from . import tn
+            from .simplify import _full_light_cone_cancel
+
+            nodes = _full_light_cone_cancel(self.expectation_before(*ops, reuse=False))
+            return tn.contract_nodes(nodes, trials=0).tensor.reshape(())
 
         nq = self._nqubits
         occupied = set()
@@ -677,12 +690,13 @@ class Circuit:
             z = torch.tensor([1.0, 0.0], dtype=dt, device=dev)
             for q in range(n):
                 e = tn.new_edge()
-                nodes.append(tn.Node(z, [e], name=f"qb-{q}"))
+                nodes.append(tn.Node(z, [e], name=f"qb-{q}", is_dagger=conj, id=-1 - q))
                 front.append(e)
         else:
             t = self._input_tensor().to(dt).reshape([2] * n)
             front = [tn.new_edge() for _ in range(n)]
-            nodes.append(tn.Node(t.conj().resolve_conj() if conj else t, list(front), name="inputs"))
+            nodes.append(tn.Node(t.conj().resolve_conj() if conj else t, list(front), name="inputs", is_dagger=conj,
+                                 id=-1))
         # constant gates: one upload per gate size (a 32-qubit RQC has hundreds of 4 x 4 constants)
         const_dev: Dict[int, Any] = {}
         by_size: Dict[int, List[int]] = {}
@@ -709,7 +723,15 @@ class Circuit:
             if conj:
                 t = t.conj().resolve_conj()
             out_e = [tn.new_edge() for _ in range(k)]
-            nodes.append(tn.Node(t, out_e + [front[q] for q in op.qubits], name=op.name))
+            # gate identity + side for the light-cone cancellation (tcmi/simplify.py); trigonometric gate families
+            # are unitary by construction, constants are checked
+            if op.matrix is None:
+                uni = True
+            else:
+                mm = np.asarray(op.matrix).reshape(2 ** k, 2 ** k)
+                uni = bool(np.abs(mm @ mm.conj().T - np.eye(2 ** k)).max() < 1e-9)
+            nodes.append(tn.Node(t, out_e + [front[q] for q in op.qubits], name=op.name, is_dagger=conj, id=i,
+                                 is_unitary=uni))
             for j, q in enumerate(op.qubits):
                 front[q] = out_e[j]
         return nodes, front
@@ -730,7 +752,8 @@ class Circuit:
             psi = (full[..., : 2**nq] if full.shape[-1] != 2**nq else full).reshape([2] * nq)
             e1 = [tn.new_edge() for _ in range(nq)]
             e2 = [tn.new_edge() for _ in range(nq)]
-            nodes = [tn.Node(psi, list(e1), "psi"), tn.Node(psi.conj().resolve_conj(), list(e2), "psi*")]
+            nodes = [tn.Node(psi, list(e1), "psi", is_dagger=False, id=-1),
+                     tn.Node(psi.conj().resolve_conj(), list(e2), "psi*", is_dagger=True, id=-1)]
         else:
             n1, e1 = self._tn_nodes()
             n2, e2 = self._tn_nodes(conj=True)
@@ -752,7 +775,8 @@ class Circuit:
                 occupied.add(q)
             k = len(index)
             t = torch.as_tensor(self._np(op), dtype=dt, device=cons.backend.device).reshape([2] * (2 * k))
-            nodes.append(tn.Node(t, [newdang[q + nq] for q in index] + [newdang[q] for q in index], "operator"))
+            nodes.append(tn.Node(t, [newdang[q + nq] for q in index] + [newdang[q] for q in index], "operator",
+                                 is_dagger=False, id=-1000 - len(nodes)))
         for j in range(nq):
             if j not in occupied:
                 rename[newdang[j + nq]] = newdang[j]

@@ -7,8 +7,8 @@ qubit i = ket index i, qubit n + i = bra index i, so
     U rho U^dagger          ->  U on qubit i, conj(U) on qubit n + i          (unitary gates, any arity)
     sum_k K_k rho K_k^dagger ->  the 4 x 4 super-gate sum_k K_k (x) conj(K_k) on the pair (i, n + i)
 
-and every gate runs through the same tile-VM passes (``tcmi_run_pass``) as ``Circuit``.  One-qubit channels
-with concrete parameters are supported (two-qubit channels would need non-unitary 4-qubit gates)."""
+and every gate runs through the same tile-VM passes (``tcmi_run_pass``) as ``Circuit``.  One-qubit channels are one
+non-unitary two-qubit gate of the doubled plan; two-qubit channels are a sum of branches (``apply_general_kraus``)."""
 
 from typing import Any, List, Optional, Sequence, Tuple
 
@@ -63,11 +63,32 @@ class DMCircuit:
     def apply_general_kraus(self, kraus: Sequence[Any], index: Sequence[int], **kws: Any) -> None:
         """reference densitymatrix.py:222-244: rho -> sum_k K_k rho K_k^dagger on the given qubits."""
         index = [index] if isinstance(index, int) else list(index)
-        if len(index) != 1:
-            raise NotImplementedError("Backend 'hip' has not implemented multi-qubit Kraus channels.")
         ket, bra = self._pair(index)
-        sup = CH.kraus_to_super_gate(kraus)                       # [ket', bra'; ket, bra]
-        self._c._record_const(sup, (ket[0], bra[0]), "kraus", split_conf={})
+        if len(index) == 1:
+            sup = CH.kraus_to_super_gate(kraus)                       # [ket', bra'; ket, bra]
+            self._c._record_const(sup, (ket[0], bra[0]), "kraus", split_conf={})
+            return
+        if len(index) > 2:
+            raise NotImplementedError("Backend 'hip' has not implemented Kraus channels on more than two qubits.")
+        # two-qubit channel: the super-gate sum_k K_k (x) conj(K_k) is a non-unitary 4-qubit operator, which the
+        # tile-VM has no dense op for.  It is applied as what it is -- a sum of branches: the vectorised rho so far is
+        # materialised, every branch applies K_k to the ket pair and conj(K_k) to the bra pair (two dense two-qubit
+        # gates, non-unitary allowed) and the branch states are added; the sum is the input state of the plan that
+        # records the rest of the circuit (differentiable through ``Circuit(inputs=...)``).
+        d = 2 ** len(index)
+        from .circuit import _constant_value
+
+        mats = [np.asarray(_constant_value(k.tensor if isinstance(k, G.Gate) else k, "Kraus operator"),
+                           dtype=np.complex128).reshape(d, d) for k in kraus]
+        rho = self._c.wavefunction().reshape(-1)
+        total = None
+        for m in mats:
+            br = Circuit(2 * self._nqubits, inputs=rho)
+            br._record_const(m, ket, "kraus-ket", split_conf={})
+            br._record_const(m.conj(), bra, "kraus-bra", split_conf={})
+            out = br.wavefunction().reshape(-1)
+            total = out if total is None else total + out
+        self._c = Circuit(2 * self._nqubits, inputs=total)
 
     general_kraus = apply_general_kraus
 

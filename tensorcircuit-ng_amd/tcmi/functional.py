@@ -117,8 +117,9 @@ def _fns():
         @staticmethod
         def forward(params, psi, g, cc, inp):
             single = params.dim() == 1 and inp.dim() == 1
-            p2 = params.reshape(-1, params.shape[-1])
             s2, g2 = psi.reshape(-1, psi.shape[-1]), g.reshape(-1, g.shape[-1])
+            # a circuit without parameters (all gates constant, only the input state is differentiated)
+            p2 = params.reshape(-1, params.shape[-1]) if params.shape[-1] else params.new_zeros((s2.shape[0], 0))
             if p2.shape[0] != s2.shape[0]:
                 p2 = p2.expand(s2.shape[0], -1)
             gp, lam = cc.vjp(p2.contiguous(), s2, g2, inputs=inp, want_input_grad=True)

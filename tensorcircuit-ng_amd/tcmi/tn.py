@@ -30,12 +30,18 @@ class Node:
     """A tensor with integer edge labels (a label shared by two nodes is a contracted edge, a label
     appearing once is dangling).  ``node.tensor`` mirrors ``tn.Node.tensor``."""
 
-    __slots__ = ("tensor", "edges", "name")
+    __slots__ = ("tensor", "edges", "name", "is_dagger", "id", "is_unitary")
 
-    def __init__(self, tensor, edges: Sequence[int], name: str = ""):
+    def __init__(self, tensor, edges: Sequence[int], name: str = "", is_dagger: Optional[bool] = None,
+                 id: Optional[int] = None, is_unitary: bool = False):
         self.tensor = tensor
         self.edges = list(edges)
         self.name = name
+        # causal light-cone metadata (reference basecircuit.py:107-147): which side of <psi|O|psi> the node is on
+        # and the identity of the gate it came from; None = untagged
+        self.is_dagger = is_dagger
+        self.id = id
+        self.is_unitary = is_unitary
 
     def __repr__(self):
         return f"Node(name={self.name!r}, edges={self.edges})"
@@ -944,12 +950,14 @@ class ContractionTree:
                 static = [first[k].contiguous().clone() for k in range(n)]
                 shared_t: Dict[int, Any] = {k: static[k] for k in range(n) if not dep[k]}
                 COUNTERS = new_counters()
-                g_inv = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_inv):
-                    self._run_steps({}, shared_t, True)
+                g_inv = None
+                if any(not dep[st[4]] for st in steps):     # (an empty capture is an error on some ROCm versions)
+                    g_inv = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_inv):
+                        self._run_steps({}, shared_t, True)
                 cnt_inv, COUNTERS = COUNTERS, new_counters()
                 g_sl = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_sl, pool=g_inv.pool()):
+                with torch.cuda.graph(g_sl, **({"pool": g_inv.pool()} if g_inv is not None else {})):
                     res = self._run_steps({k: static[k] for k in range(n) if dep[k]}, shared_t, False)
                 cnt_sl = COUNTERS
             finally:
@@ -961,7 +969,8 @@ class ContractionTree:
         inv_k = [k for k in range(n) if not dep[k]]
         dep_k = [k for k in range(n) if dep[k]]
         torch._foreach_copy_([static[k] for k in inv_k], [first[k] for k in inv_k])
-        cache["g_inv"].replay()
+        if cache["g_inv"] is not None:
+            cache["g_inv"].replay()
         if COUNTERS is not None:
             for key, v in cache["cnt_inv"].items():
                 COUNTERS[key] += v

@@ -334,3 +334,54 @@ def test_hyperedge_and_strip_exponent_kats(tcd):
     node, ex = cf(c.expectation_before([tc.gates.z(), [0]], reuse=False))
     np.testing.assert_allclose(abs(complex(_np(tc, node.tensor))), 1.0, atol=1e-5)
     np.testing.assert_allclose(ex, 2 * n * np.log10(2.0), atol=1e-3)
+
+
+def test_lightcone_expectation_kat(tcd):
+    """Reference KAT tests/test_circuit.py:1507-1533 on the device: ``enable_lightcone=True`` gives the same <Z_0>
+    (1e-5), 37 -> 25 nodes on the open chain and 41 -> 41 with the periodic cnot; plus a deep-narrow circuit
+    (n = 12, 3 brickwork layers, <X_5 Z_6>) against the dense oracle -- the cone touches 8 of the 12 qubits."""
+    tc = tcd
+
+    def construct_c(pbc=True):
+        n = 4
+        ns = n if pbc else n - 1
+        c = tc.Circuit(n)
+        for j in range(2):
+            for i in range(n):
+                c.rx(i, theta=0.2, name="rx" + str(j) + "-" + str(i))
+            for i in range(ns):
+                c.cnot(i, (i + 1) % n, name="cnot" + str(j) + "-" + str(i))
+        return c
+
+    for b in [True, False]:
+        c = construct_c(b)
+        m1 = c.expectation_ps(z=[0], enable_lightcone=True)
+        m2 = c.expectation_ps(z=[0])
+        np.testing.assert_allclose(tc.backend.numpy(m1), tc.backend.numpy(m2), atol=1e-5)
+        nodes = c.expectation_before([tc.gates.z(), 0], reuse=False)
+        l1 = len(nodes)
+        nodes = tc.simplify._full_light_cone_cancel(nodes)
+        assert (l1, len(nodes)) == ((37, 25) if b is False else (41, 41))
+
+    n, rng = 12, np.random.default_rng(3)
+    c = tc.Circuit(n)
+    ops = []
+    for layer in range(3):
+        for i in range(n):
+            th = float(rng.uniform(0, 2 * np.pi))
+            c.ry(i, theta=th)
+            ops.append((G.ry(th), [i]))
+        for i in range(layer % 2, n - 1, 2):
+            th = float(rng.uniform(0, 2 * np.pi))
+            c.rzz(i, i + 1, theta=th)
+            c.cnot(i, i + 1)
+            ops += [(G.rzz(th), [i, i + 1]), (G.CNOT, [i, i + 1])]
+    psi = dense.run(n, ops)
+    ps = [0] * n
+    ps[5], ps[6] = 1, 3
+    ref = dense.pauli_string_expectation(psi, n, ps)
+    nodes = c.expectation_before([tc.gates.x(), 5], [tc.gates.z(), 6], reuse=False)
+    assert len(tc.simplify._full_light_cone_cancel(nodes)) < len(nodes) - 20
+    got = c.expectation_ps(x=[5], z=[6], enable_lightcone=True)
+    tol = 2e-5 if tc.dtypestr == "complex64" else 1e-10
+    np.testing.assert_allclose(complex(tc.backend.numpy(got)), ref, atol=tol)

@@ -22,8 +22,19 @@ def test_channels_are_trace_preserving_and_super_gate_matches_oracle():
         want = sum(np.asarray(k.tensor) @ rho @ np.asarray(k.tensor).conj().T for k in ks)
         got = (sup @ rho.reshape(-1)).reshape(2, 2)          # vec index = (ket, bra)
         np.testing.assert_allclose(got, want, atol=1e-6)
-    with pytest.raises(NotImplementedError):
-        ch.generaldepolarizingchannel(0.1, num_qubits=2)
+    # multi-qubit depolarizing channels (reference channels.py:103-230): 4^n Kraus operators, same as the oracle's
+    from oracle import channels as OC
+
+    with pytest.raises(ValueError):
+        ch.generaldepolarizingchannel(0.1, num_qubits=2)        # 1 - 15 * 0.1 < 0, as the reference
+    for got, want in ((ch.generaldepolarizingchannel(0.02, num_qubits=2), OC.generaldepolarizing(0.02, 2)),
+                      (ch.isotropicdepolarizingchannel(0.3, 2), OC.isotropicdepolarizing(0.3, 2)),
+                      (ch.generaldepolarizingchannel([0.004 * k for k in range(1, 16)], 2),
+                       OC.generaldepolarizing([0.004 * k for k in range(1, 16)], 2))):
+        assert len(got) == 16
+        ch.kraus_identity_check(got)
+        for a, b in zip(got, want):
+            np.testing.assert_allclose(np.asarray(a.tensor).reshape(4, 4), b, atol=1e-7)
 
 
 def test_dmcircuit_records_ket_and_conjugated_bra_gates():
@@ -42,7 +53,9 @@ def test_dmcircuit_records_ket_and_conjugated_bra_gates():
     rx_ket, rx_bra = ops[4].spec, ops[5].spec
     np.testing.assert_allclose(rx_bra.c2, np.conj(rx_ket.c2))
     with pytest.raises(NotImplementedError):
-        c.apply_general_kraus(tc.channels.depolarizingchannel(0.1, 0.1, 0.1), [0, 1])
+        c.apply_general_kraus([np.eye(8)], [0, 1, 2])           # channels on more than two qubits
+    with pytest.raises(ValueError):
+        c.apply_general_kraus(tc.channels.depolarizingchannel(0.1, 0.1, 0.1), [0, 1])   # one-qubit operators, two indices
     # the same circuit on the dense oracle: the doubled state vector is vec(rho)
     rho = odm.run(2, [("u", OG.H, [0]), ("u", OG.CNOT, [0, 1])])
     np.testing.assert_allclose(np.trace(rho), 1.0)
@@ -87,3 +100,48 @@ def test_three_qubit_synthesis_of_controlled_gates():
         ops = synth.lower(synth.decompose_dense(u, [2, 0, 1]))
         assert all(len(q) <= 2 for _, q in ops)
         np.testing.assert_allclose(synth.expand(ops, [2, 0, 1]), u, atol=1e-12)
+
+
+def _lightcone_circuit(tc, pbc):
+    n = 4
+    ns = n if pbc else n - 1
+    c = tc.Circuit(n)
+    for j in range(2):
+        for i in range(n):
+            c.rx(i, theta=0.2, name="rx" + str(j) + "-" + str(i))
+        for i in range(ns):
+            c.cnot(i, (i + 1) % n, name="cnot" + str(j) + "-" + str(i))
+    return c
+
+
+def test_lightcone_cancellation_node_counts_and_value():
+    """Reference KAT tests/test_circuit.py:1507-1533: the <Z_0> network of the 2-layer rx + cnot chain has 37 nodes
+    (open chain) of which 12 lie outside the causal cone -> 25; with the periodic cnot nothing cancels (41 -> 41).
+    The simplified network contracts (oracle/tn.py, numpy) to the dense-oracle expectation value."""
+    import tcmi as tc
+    from oracle import dense, gates as OG, tn as OT
+
+    tc.set_backend("hip"); tc.set_dtype("complex128")
+    for pbc, want in ((True, (41, 41)), (False, (37, 25))):
+        c = _lightcone_circuit(tc, pbc)
+        nodes = c.expectation_before([tc.gates.z(), 0], reuse=False)
+        l1 = len(nodes)
+        nodes = tc.simplify._full_light_cone_cancel(nodes)
+        assert (l1, len(nodes)) == want
+        res = OT.contract([OT.Node(np.asarray(nd.tensor.cpu()), nd.edges) for nd in nodes])
+        n = 4
+        ops = []
+        for j in range(2):
+            ops += [(OG.rx(0.2), [i]) for i in range(n)]
+            ops += [(OG.CNOT, [i, (i + 1) % n]) for i in range(n if pbc else n - 1)]
+        psi = dense.run(n, ops)
+        ref = dense.pauli_string_expectation(psi, n, [3, 0, 0, 0])
+        np.testing.assert_allclose(complex(np.asarray(res.tensor)), ref, atol=1e-12)
+    # an untagged node list is returned unchanged; a non-unitary constant keeps its pair in the network
+    from tcmi import tn
+    plain = [tn.Node(None, [1, 2]), tn.Node(None, [1, 2])]
+    assert tc.simplify._full_light_cone_cancel(plain) is plain
+    c = tc.Circuit(2)
+    c.any(1, unitary=np.array([[1.0, 0.0], [0.0, 0.5]]))
+    nodes = c.expectation_before([tc.gates.z(), 0], reuse=False)
+    assert len(tc.simplify._full_light_cone_cancel(nodes)) == len(nodes)
