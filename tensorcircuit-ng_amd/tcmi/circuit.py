@@ -305,7 +305,16 @@ class Circuit:
         elif name == "r":
             specs = G.r_spec(get("theta"), get("alpha"), get("phi"))
         elif name == "cr":
-            specs = G.cr_spec(get("theta"), get("alpha"), get("phi"))
+            al, ph = get("alpha"), get("phi")
+            if not (G.is_concrete(al) and G.is_concrete(ph)):
+                # tensor-valued axis angles: V^dagger on the target, controlled exp(-i theta Z), V on the target
+                ctrl, tgt = index[0], index[1]
+                self._record_specs(G._axis_frame_specs(al, ph, True), (tgt,), "cr", {})
+                self._record_specs([G.TrigSpec(G._kron(G._i00, G._i_matrix), G._kron(G._i11, G._i_matrix),
+                                               -1j * G._kron(G._i11, G._z_matrix), get("theta"), 1.0, name="cr")],
+                                   (ctrl, tgt), "cr", dict(kw))
+                return self._record_specs(G._axis_frame_specs(al, ph, False), (tgt,), "cr", {})
+            specs = G.cr_spec(get("theta"), al, ph)
         elif name == "u":
             specs = G.u_spec(get("theta"), get("phi"), get("lbd"))
         elif name == "exp1":
@@ -333,9 +342,10 @@ class Circuit:
         elif name == "cu":
             vals = [get("theta"), get("phi"), get("lbd")]
             if not all(G.is_concrete(v) for v in vals):
-                raise NotImplementedError("cu gate with tensor parameters is not supported on the hip backend")
-            u = G._concrete(G.u_spec(*vals))
-            return self._record_const(G._kron(G._i00, G._i_matrix) + G._kron(G._i11, u), index, "cu")
+                specs = G.cu_spec(*vals)     # controlled(phase ry phase) = cphase cry cphase, one angle each
+            else:
+                u = G._concrete(G.u_spec(*vals))
+                return self._record_const(G._kron(G._i00, G._i_matrix) + G._kron(G._i11, u), index, "cu")
         else:
             raise NotImplementedError(f"gate {name}")
         cplx = [sp for sp in specs if _is_complex_angle(sp.theta)]

@@ -192,19 +192,37 @@ def _axis(alpha, phi):
     )
 
 
+def _axis_frame_specs(alpha, phi, inverse):
+    """V = rz(phi) ry(alpha) maps the Z axis onto n = (sin a cos p, sin a sin p, cos a): factors of V (or of V^dagger)
+    in application order, each with one angle -- the form tensor-valued ``alpha`` / ``phi`` take on the plan."""
+    ry = lambda a, sc: TrigSpec(_z(2), _i_matrix, -1j * _y_matrix, a, sc, name="ry")
+    rz = lambda a, sc: TrigSpec(_z(2), _i_matrix, -1j * _z_matrix, a, sc, name="rz")
+    return [rz(phi, -0.5), ry(alpha, -0.5)] if inverse else [ry(alpha, 0.5), rz(phi, 0.5)]
+
+
 def r_spec(theta, alpha, phi):
-    """reference gates.py:661-689 (alpha, phi must be concrete numbers)."""
-    if not (is_concrete(alpha) and is_concrete(phi)):
-        raise NotImplementedError("r gate: tensor-valued alpha/phi are not supported on the hip backend")
-    return [TrigSpec(_z(2), _i_matrix, -1j * _axis(float(alpha), float(phi)), theta, 1.0, name="r")]
+    """reference gates.py:661-689: R = cos(theta) I - i sin(theta) n.sigma = exp(-i theta n.sigma).  Concrete
+    ``alpha`` / ``phi``: one factor; tensor-valued: V exp(-i theta Z) V^dagger with V = rz(phi) ry(alpha), five
+    one-angle factors in application order (all differentiable / batchable)."""
+    if is_concrete(alpha) and is_concrete(phi):
+        return [TrigSpec(_z(2), _i_matrix, -1j * _axis(float(alpha), float(phi)), theta, 1.0, name="r")]
+    core = TrigSpec(_z(2), _i_matrix, -1j * _z_matrix, theta, 1.0, name="r")
+    return _axis_frame_specs(alpha, phi, True) + [core] + _axis_frame_specs(alpha, phi, False)
 
 
 def cr_spec(theta, alpha, phi):
-    """reference gates.py:817-849."""
+    """reference gates.py:817-849 (concrete alpha / phi; the tensor-valued form is assembled in
+    ``Circuit._vgate``: frame change on the target, controlled exp(-i theta Z), frame change back)."""
     if not (is_concrete(alpha) and is_concrete(phi)):
-        raise NotImplementedError("cr gate: tensor-valued alpha/phi are not supported on the hip backend")
+        raise NotImplementedError("cr_spec needs concrete alpha / phi; use Circuit.cr for tensor-valued angles")
     ax = _axis(float(alpha), float(phi))
     return [TrigSpec(_kron(_i00, _i_matrix), _kron(_i11, _i_matrix), -1j * _kron(_i11, ax), theta, 1.0, name="cr")]
+
+
+def cu_spec(theta, phi, lbd):
+    """reference gates.py cu = controlled(u): controlled(phase(phi) ry(theta) phase(lbd)) = cphase(phi) cry(theta)
+    cphase(lbd), in application order."""
+    return [cphase_spec(lbd)[0], controlled_rot_spec(_y_matrix, theta, "cry")[0], cphase_spec(phi)[0]]
 
 
 def controlled_rot_spec(pauli, theta, name):

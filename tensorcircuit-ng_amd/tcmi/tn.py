@@ -956,9 +956,11 @@ class ContractionTree:
                     with torch.cuda.graph(g_inv):
                         self._run_steps({}, shared_t, True)
                 cnt_inv, COUNTERS = COUNTERS, new_counters()
-                g_sl = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_sl, **({"pool": g_inv.pool()} if g_inv is not None else {})):
-                    res = self._run_steps({k: static[k] for k in range(n) if dep[k]}, shared_t, False)
+                g_sl, res = None, None
+                if any(dep[st[4]] for st in steps):
+                    g_sl = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_sl, **({"pool": g_inv.pool()} if g_inv is not None else {})):
+                        res = self._run_steps({k: static[k] for k in range(n) if dep[k]}, shared_t, False)
                 cnt_sl = COUNTERS
             finally:
                 COUNTERS = keep_counters
@@ -978,6 +980,9 @@ class ContractionTree:
             sliced = first if i == slice_ids[0] else self.slice_arrays(arrays, i)
             for k in dep_k:
                 static[k].copy_(sliced[k])
+            if cache["g_sl"] is None:      # nothing depends on a sliced index: the invariant graph did all the work
+                yield self._run_steps({}, cache["shared"], False).clone()
+                continue
             cache["g_sl"].replay()
             if COUNTERS is not None:
                 for key, v in cache["cnt_sl"].items():

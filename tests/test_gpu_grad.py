@@ -520,3 +520,37 @@ def test_tensor_valued_gate_matrix_is_not_silently_constant(tcd):
     m = torch.eye(2, dtype=torch.complex64 if tc.dtypestr == "complex64" else torch.complex128, device="cuda")
     with pytest.raises(NotImplementedError, match="Backend 'hip' has not implemented"):
         tc.backend.value_and_grad(f)(m)
+
+
+def test_tensor_valued_axis_angles_of_r_cr_cu(tcd):
+    """r / cr with tensor-valued alpha, phi and cu with tensor parameters (reference gates.py:661-689, 817-849,
+    cu = controlled(u)): value against the dense oracle and the gradient w.r.t. ALL angles by central differences."""
+    tc = tcd
+    n = 5
+    p0 = np.array([0.7, 1.1, -0.4, 0.9, 0.35, 2.1, 0.6, -1.3, 0.8])
+
+    def f(p):
+        c = tc.Circuit(n)
+        for i in range(n):
+            c.h(i)
+        c.r(1, theta=p[0], alpha=p[1], phi=p[2])
+        c.cnot(1, 3)
+        c.cr(0, 2, theta=p[3], alpha=p[4], phi=p[5])
+        c.cu(4, 3, theta=p[6], phi=p[7], lbd=p[8])
+        c.cr(3, 1, theta=0.3, alpha=p[1], phi=0.2)            # mixed concrete / tensor
+        return tc.backend.real(c.expectation_ps(z=[1, 2]) + 0.5 * c.expectation_ps(x=[3]) - 0.25 * c.expectation_ps(y=[2], z=[4]))
+
+    def ref(p):
+        ops = [(G.H, [i]) for i in range(n)]
+        ops += [(G.r(p[0], p[1], p[2]), [1]), (G.CNOT, [1, 3]), (G.cr(p[3], p[4], p[5]), [0, 2]),
+                (G.controlled(G.u(p[6], p[7], p[8])), [4, 3]), (G.cr(0.3, p[1], 0.2), [3, 1])]
+        psi = dense.run(n, ops)
+        pe = lambda ps: dense.pauli_string_expectation(psi, n, ps).real
+        return pe([0, 3, 3, 0, 0]) + 0.5 * pe([0, 0, 0, 1, 0]) - 0.25 * pe([0, 0, 2, 0, 3])
+
+    v, g = tc.backend.value_and_grad(f)(tc.backend.convert_to_tensor(p0, dtype=tc.rdtypestr))
+    eps = 1e-6
+    fd = np.array([(ref(p0 + eps * np.eye(9)[i]) - ref(p0 - eps * np.eye(9)[i])) / (2 * eps) for i in range(9)])
+    tol = 2e-5 if tc.dtypestr == "complex64" else 1e-7
+    np.testing.assert_allclose(float(tc.backend.numpy(v)), ref(p0), atol=tol)
+    np.testing.assert_allclose(tc.backend.numpy(g), fd, atol=10 * tol)
