@@ -122,6 +122,13 @@ int tcmi_permute_bits(const void* in, void* out, int rank, const int* srcbit, in
 int tcmi_contract_scattered(const void* big, int rank, const int* pos, int nk, const void* small_operand, long long n,
                             void* out, int big_first, int dtype, void* stream);
 
+/* tensordot(a, b, axes=(axes_a, axes_b)) of two contiguous [2]^rank complex64 tensors straight from their stored
+ * layouts -- no operand is permuted: c has the axes (free axes of a in order, free axes of b in order), the
+ * contract_between convention of tensornetwork (reference tensorcircuit/cons.py:948 -> backend.tensordot).  MFMA
+ * kernel with bit-deposit operand addressing; splits K over the grid when the output has few tiles.  rank <= 31. */
+int tcmi_tensordot_bits(const void* a, int rank_a, const void* b, int rank_b, const int* axes_a, const int* axes_b,
+                        int nk, void* c, int dtype, void* stream);
+
 /* Batched complex GEMM C[M x N] = A[M x K] . B[K x N], row-major interleaved complex, strides in
  * elements between batch members; trans_a != 0: A is stored [K x M] (k-major).  complex64 runs on the f32 MFMA pipe
  * (v_mfma_f32_32x32x2_f32, exact f32 FMA), complex128 on the f64 MFMA pipe (v_mfma_f64_16x16x4_f64); both issue

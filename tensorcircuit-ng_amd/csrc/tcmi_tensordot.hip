@@ -158,6 +158,147 @@ __global__ __launch_bounds__(256, 6) void cgemm_mfma_kernel(const float2* __rest
   }
 }
 
+// ---- tensordot of two [2]^rank tensors straight from their stored layouts (complex64) --------------------------------
+// C[m][n] = sum_k A[rowA(m) | kA(k)] * B[kB(k) | colB(n)]: every index bit of M, N and K sits at its own address bit of
+// the operand (row bit j of A at pa.free[j], k bit j at pa.k[j] in A and pb.k[j] in B, column bit j of B at
+// pb.free[j]); C is written row-major [M x N], i.e. with the axes (free axes of A in stored order, free axes of B in
+// stored order) -- exactly what tensordot returns, whatever axes are contracted.  The permute + GEMM route moves a
+// big operand three times (read, write permuted, read again); this one reads it once.  Same 64 x 64 tile, planar
+// k-major LDS tiles and 3-product MFMA core as cgemm_mfma_kernel; the loaders gather 8-byte elements.
+//  * which index runs across the lanes of a loader (KFA / KFB: k-fast, else row / column fast) is chosen by the host
+//    from the operand's lowest address bits, so that a wave touches whole 128-byte lines: the 4 lowest address bits
+//    are always among the 6 lowest row bits and the 4 lowest k bits, which one tile iteration covers completely.
+//  * offsets: the tile part of a row / column (6 low bits) and the 4 low k bits are deposited once per thread; the
+//    tile origin and the running k block are wave-uniform and deposited with scalar loops.
+struct BitPos {
+  int free_[32];  // address bit of row (A) / column (B) bit j
+  int k[32];      // address bit of k bit j
+};
+
+__device__ __forceinline__ uint32_t deposit_bits(uint32_t v, const int* pos, int nb, int from) {
+  uint32_t off = 0;
+  for (int j = from; j < nb; ++j) off |= ((v >> j) & 1u) << pos[j];
+  return off;
+}
+
+// Loader of one operand tile (64 rows / columns x 16 k) into the planar k-major LDS tile.  MODE 0: row-fast pairs
+// (address bit 0 = row bit 0: 16-byte loads of two rows), MODE 1: k-fast pairs (address bit 0 = k bit 0), MODE 2:
+// single 8-byte elements, row-fast (address bit 0 is some other k bit).
+template <int MODE>
+struct BitsLoader {
+  uint32_t off[MODE == 2 ? 4 : 2];
+  int r, k;
+  bool pair;
+  __device__ __forceinline__ void init(int tid, uint32_t base, const int* pfree, const int* pk, int lr, int lk) {
+    r = MODE == 1 ? (tid >> 3) : (MODE == 0 ? 2 * (tid & 31) : (tid & 63));
+    k = MODE == 1 ? 2 * (tid & 7) : (MODE == 0 ? (tid >> 5) : (tid >> 6));
+    pair = MODE == 1 ? lk > 0 : lr > 0;
+#pragma unroll
+    for (int h = 0; h < (MODE == 2 ? 4 : 2); ++h)
+      off[h] = base | deposit_bits((uint32_t)row(h), pfree, lr < 6 ? lr : 6, 0) |
+               deposit_bits((uint32_t)kk(h), pk, lk < 4 ? lk : 4, 0);
+  }
+  __device__ __forceinline__ int row(int h) const { return MODE == 1 ? r + 32 * h : r; }
+  __device__ __forceinline__ int kk(int h) const { return MODE == 1 ? k : (MODE == 0 ? k + 8 * h : k + 4 * h); }
+  __device__ __forceinline__ void load(const float2* __restrict__ P, uint32_t kofs, uint32_t r0, uint32_t R,
+                                       uint32_t k0, uint32_t kend, float (*re)[TCMI_LDP], float (*im)[TCMI_LDP]) const {
+#pragma unroll
+    for (int h = 0; h < (MODE == 2 ? 4 : 2); ++h) {
+      const int rr = row(h), kq = kk(h);
+      float2 v0 = {0.f, 0.f}, v1 = {0.f, 0.f};
+      if (r0 + rr < R && k0 + kq < kend) {
+        const float2* src = P + (off[h] | kofs);
+        if (MODE != 2 && pair) {
+          const float4 t = *reinterpret_cast<const float4*>(src);
+          v0.x = t.x; v0.y = t.y; v1.x = t.z; v1.y = t.w;
+        } else {
+          v0 = *src;
+        }
+      }
+      if constexpr (MODE == 1) {
+        re[kq][rr] = v0.x; im[kq][rr] = v0.y; re[kq + 1][rr] = v1.x; im[kq + 1][rr] = v1.y;
+      } else if constexpr (MODE == 0) {
+        *reinterpret_cast<float2*>(&re[kq][rr]) = make_float2(v0.x, v1.x);
+        *reinterpret_cast<float2*>(&im[kq][rr]) = make_float2(v0.y, v1.y);
+      } else {
+        re[kq][rr] = v0.x; im[kq][rr] = v0.y;
+      }
+    }
+  }
+};
+
+template <int MA, int MB>
+__global__ __launch_bounds__(256, 5) void cgemm_bits_kernel(const float2* __restrict__ A, const float2* __restrict__ B,
+                                                            float2* __restrict__ C, int lm, int ln, int lk, BitPos pa,
+                                                            BitPos pb, int ksplit, long long kchunk) {
+  __shared__ __attribute__((aligned(16))) float As_re[TCMI_CBK][TCMI_LDP], As_im[TCMI_CBK][TCMI_LDP];
+  __shared__ __attribute__((aligned(16))) float Bs_re[TCMI_CBK][TCMI_LDP], Bs_im[TCMI_CBK][TCMI_LDP];
+  const uint32_t M = 1u << lm, N = 1u << ln, K = 1u << lk;   // rank <= 31: every extent and element index fits 32 bits
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  // blockIdx.x: column tile, blockIdx.y + 65535 * (blockIdx.z / ksplit): row tile, blockIdx.z % ksplit: k chunk
+  const int zz = (int)blockIdx.z / ksplit, ks = (int)blockIdx.z - zz * ksplit;
+  const unsigned long long m0l = ((unsigned long long)zz * 65535 + blockIdx.y) * TCMI_BM;
+  if (m0l >= M) return;
+  const uint32_t m0 = (uint32_t)m0l, n0 = blockIdx.x * TCMI_BN;
+  const uint32_t kbeg = (uint32_t)ks * (uint32_t)kchunk;
+  const uint32_t kend = ((unsigned long long)kbeg + (unsigned long long)kchunk < K) ? kbeg + (uint32_t)kchunk : K;
+  f32x16 p1 = {0}, p2 = {0}, p3 = {0};
+
+  BitsLoader<MA> la;
+  BitsLoader<MB> lb;
+  la.init(tid, deposit_bits(m0, pa.free_, lm, 6), pa.free_, pa.k, lm, lk);
+  lb.init(tid, deposit_bits(n0, pb.free_, ln, 6), pb.free_, pb.k, ln, lk);
+
+  // offsets of the running k block (wave-uniform): deposited once, then only the bits that toggle when the block
+  // counter advances are flipped (two on average)
+  uint32_t ka = deposit_bits(kbeg, pa.k, lk, 4);
+  uint32_t kb = deposit_bits(kbeg, pb.k, lk, 4);
+  for (uint32_t k0 = kbeg; k0 < kend; k0 += TCMI_CBK) {
+    la.load(A, ka, m0, M, k0, kend, As_re, As_im);
+    lb.load(B, kb, n0, N, k0, kend, Bs_re, Bs_im);
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < TCMI_CBK; kk += 2) {
+      const int kr = kk + (lane >> 5);
+      const float are = As_re[kr][wr * 32 + (lane & 31)], aim = As_im[kr][wr * 32 + (lane & 31)];
+      const float bre = Bs_re[kr][wc * 32 + (lane & 31)], bim = Bs_im[kr][wc * 32 + (lane & 31)];
+      p1 = __builtin_amdgcn_mfma_f32_32x32x2f32(are, bre, p1, 0, 0, 0);
+      p2 = __builtin_amdgcn_mfma_f32_32x32x2f32(aim, bim, p2, 0, 0, 0);
+      p3 = __builtin_amdgcn_mfma_f32_32x32x2f32(are + aim, bre + bim, p3, 0, 0, 0);
+    }
+    __syncthreads();
+    const uint32_t blk = k0 >> 4;
+    uint32_t tog = blk ^ (blk + 1);
+    while (tog) {
+      const int j = __builtin_ctz(tog) + 4;
+      tog &= tog - 1;
+      if (j < lk) {
+        ka ^= 1u << pa.k[j];
+        kb ^= 1u << pb.k[j];
+      }
+    }
+  }
+  const uint32_t col = n0 + wc * 32 + (lane & 31);
+  float2* const Cb = C + ((unsigned long long)(m0 + wr * 32 + 4 * (lane >> 5)) << ln) + col;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const uint32_t dr = (reg & 3) + 8 * (reg >> 2);
+    if (m0 + wr * 32 + 4 * (lane >> 5) + dr < M && col < N) {
+      float2 o;
+      o.x = p1[reg] - p2[reg];
+      o.y = p3[reg] - p1[reg] - p2[reg];
+      float2* dst = Cb + ((unsigned long long)dr << ln);
+      if (ksplit > 1) {
+        atomicAdd(&dst->x, o.x);
+        atomicAdd(&dst->y, o.y);
+      } else {
+        *dst = o;
+      }
+    }
+  }
+}
+
 // complex128 GEMM on the f64 matrix pipe (v_mfma_f64_16x16x4_f64): 64x64 tile per workgroup, 4 waves x
 // (32x32 = 2x2 MFMA tiles), K step 8, the same 3-product (Gauss) form and planar k-major LDS tiles as
 // the complex64 kernel.  Row pitch 66 doubles: 16-byte aligned rows for the vector loaders and
@@ -660,6 +801,79 @@ int tcmi_contract_scattered(const void* big, int rank, const int* pos_host, int 
   }
 #undef TCMI_SC
   return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_contract_scattered: bad dtype");
+}
+
+int tcmi_tensordot_bits(const void* a, int rank_a, const void* b, int rank_b, const int* axes_a, const int* axes_b,
+                        int nk, void* c, int dtype, void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!a || !b || !c || rank_a < 0 || rank_b < 0 || rank_a > 31 || rank_b > 31 || nk < 0 || nk > rank_a ||
+      nk > rank_b || (nk > 0 && (!axes_a || !axes_b)))
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_tensordot_bits: bad argument");
+  if (dtype != TCMI_C64) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_tensordot_bits: complex64 only");
+  // axis i of a [2]^rank tensor is address bit rank - 1 - i
+  tcmi::BitPos pa, pb;
+  unsigned usedA = 0, usedB = 0;
+  for (int j = 0; j < nk; ++j) {
+    if (axes_a[j] < 0 || axes_a[j] >= rank_a || axes_b[j] < 0 || axes_b[j] >= rank_b)
+      return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_tensordot_bits: axis out of range");
+    if ((usedA >> axes_a[j]) & 1u || (usedB >> axes_b[j]) & 1u)
+      return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_tensordot_bits: repeated axis");
+    usedA |= 1u << axes_a[j];
+    usedB |= 1u << axes_b[j];
+  }
+  // k bit j <-> j-th contracted pair, pairs ordered by ascending address bit in the LARGER operand (its k offsets
+  // then grow monotonically with k: consecutive k blocks walk its lines in order)
+  int order[32];
+  for (int j = 0; j < nk; ++j) order[j] = j;
+  const bool a_big = rank_a >= rank_b;
+  for (int i = 1; i < nk; ++i)
+    for (int j = i; j > 0; --j) {
+      const int pj = a_big ? rank_a - 1 - axes_a[order[j]] : rank_b - 1 - axes_b[order[j]];
+      const int pi = a_big ? rank_a - 1 - axes_a[order[j - 1]] : rank_b - 1 - axes_b[order[j - 1]];
+      if (pj < pi) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    }
+  for (int j = 0; j < 32; ++j) pa.k[j] = pb.k[j] = pa.free_[j] = pb.free_[j] = 0;
+  for (int j = 0; j < nk; ++j) {
+    pa.k[j] = rank_a - 1 - axes_a[order[j]];
+    pb.k[j] = rank_b - 1 - axes_b[order[j]];
+  }
+  const int lm = rank_a - nk, ln = rank_b - nk;
+  // free axes in stored order: the LAST free axis is row / column bit 0
+  for (int i = rank_a - 1, j = 0; i >= 0; --i)
+    if (!((usedA >> i) & 1u)) pa.free_[j++] = rank_a - 1 - i;
+  for (int i = rank_b - 1, j = 0; i >= 0; --i)
+    if (!((usedB >> i) & 1u)) pb.free_[j++] = rank_b - 1 - i;
+  // loader mode of each operand by what its address bit 0 is: row / column bit 0 (0), k bit 0 (1), another k bit (2)
+  const int ma = (nk > 0 && pa.k[0] == 0) ? 1 : ((lm > 0 && pa.free_[0] == 0) || rank_a == 0 ? 0 : 2);
+  const int mb = (nk > 0 && pb.k[0] == 0) ? 1 : ((ln > 0 && pb.free_[0] == 0) || rank_b == 0 ? 0 : 2);
+  const long long M = 1ll << lm, N = 1ll << ln, K = 1ll << nk;
+  const long long gx = (N + TCMI_BN - 1) / TCMI_BN, gy_all = (M + TCMI_BM - 1) / TCMI_BM;
+  const long long gy = gy_all < 65535 ? gy_all : 65535, gz = (gy_all + 65534) / 65535;
+  if (gx > 2147483647ll || gz > 65535) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_tensordot_bits: grid too large");
+  int ksplit = 1;
+  long long kchunk = K;
+  const long long tiles = gx * gy_all;
+  if (tiles < 256 && K >= 4096) {
+    long long want = (1024 + tiles - 1) / tiles;
+    if (want > K / 1024) want = K / 1024;
+    if (want * gz > 65535) want = 65535 / gz;
+    if (want > 1) {
+      kchunk = ((K + want - 1) / want + TCMI_CBK - 1) / TCMI_CBK * TCMI_CBK;
+      ksplit = (int)((K + kchunk - 1) / kchunk);
+      hipError_t me = hipMemsetAsync(c, 0, (size_t)(M * N) * sizeof(float2), st);
+      if (me != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(me));
+    }
+  }
+  dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)(gz * ksplit)), block(256, 1, 1);
+#define TCMI_TB(KA, KB)                                                                                               \
+  if (ma == KA && mb == KB)                                                                                           \
+    hipLaunchKernelGGL((tcmi::cgemm_bits_kernel<KA, KB>), grid, block, 0, st, reinterpret_cast<const float2*>(a),       \
+                       reinterpret_cast<const float2*>(b), reinterpret_cast<float2*>(c), lm, ln, nk, pa, pb, ksplit, kchunk);
+  TCMI_TB(0, 0) TCMI_TB(0, 1) TCMI_TB(0, 2) TCMI_TB(1, 0) TCMI_TB(1, 1) TCMI_TB(1, 2) TCMI_TB(2, 0) TCMI_TB(2, 1) TCMI_TB(2, 2)
+#undef TCMI_TB
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));
+  return TCMI_OK;
 }
 
 int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch,

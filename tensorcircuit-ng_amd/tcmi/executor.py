@@ -381,6 +381,11 @@ def pick_measure_variant(n_exec: int, dtypestr: str) -> P.PlanConfig:
     """Measurement passes use a smaller register tile than the gate passes (the EXPECT op keeps
     |a|^2 and cross products live next to the amplitudes)."""
     c64 = dtypestr == "complex64"
+    ov = os.environ.get("TCMI_MEAS_CFG")     # experiment switch: "R,LT,lowbits"
+    if ov and c64:
+        R, LT, lb = (int(x) for x in ov.split(","))
+        if R + LT <= n_exec:
+            return P.PlanConfig(R=R, LT=LT, lowbits=lb, vec=2)
     for R, LT in ([(4, 8), (2, 6)] if c64 else [(3, 8), (2, 6)]):
         if R + LT <= n_exec:
             return P.PlanConfig(R=R, LT=LT, lowbits=min(5, R + LT), vec=2 if c64 else 1)

@@ -9,6 +9,7 @@ of shape ``[2] * rank`` (every circuit network has dimension-2 edges).
 """
 
 import ctypes
+import os
 import heapq
 import itertools
 from dataclasses import dataclass, field
@@ -1202,11 +1203,42 @@ def tensordot(a, b, axes_a: Sequence[int], axes_b: Sequence[int]):
     r = _tensordot_scattered(a, b, axes_a, axes_b, fa, fb)
     if r is not None:
         return r
+    r = _tensordot_bits(a, b, axes_a, axes_b)
+    if r is not None:
+        return r
     a2 = permute(a, fa + axes_a)
     b2 = permute(b, axes_b + fb)
     M, K, N = 2 ** len(fa), 2 ** len(axes_a), 2 ** len(fb)
     c = _fns()["GemmFn"].apply(a2, b2, M, N, K) if _on_tape(a2, b2) else _gemm_raw(a2, b2, M, N, K)
     return c.reshape([2] * (len(fa) + len(fb)))
+
+
+def _tensordot_bits(a, b, axes_a, axes_b):
+    """tensordot of two plain complex64 [2]^rank device tensors straight from their stored layouts
+    (``tcmi_tensordot_bits``: MFMA kernel with bit-deposit addressing, no operand permuted).  None when the step does
+    not qualify (autograd tape / functorch, other dtypes or shapes): the permute + GEMM route handles it."""
+    import torch
+
+    if os.environ.get("TCMI_TN_BITS", "1") == "0":
+        return None
+    if a.dtype != torch.complex64 or not a.is_cuda or not b.is_cuda or _on_tape(a, b):
+        return None
+    if a.dim() > 31 or b.dim() > 31 or any(d != 2 for d in a.shape) or any(d != 2 for d in b.shape):
+        return None
+    a, b = a.contiguous(), b.contiguous()
+    nk = len(axes_a)
+    out = torch.empty([2] * (a.dim() + b.dim() - 2 * nk), dtype=a.dtype, device=a.device)
+    xa = (ctypes.c_int * max(nk, 1))(*axes_a)
+    xb = (ctypes.c_int * max(nk, 1))(*axes_b)
+    if COUNTERS is not None:
+        COUNTERS["gemm_launches"] += 1
+        COUNTERS["gemm_flops"] += 8.0 * (1 << (a.dim() + b.dim() - nk))
+        COUNTERS["gemm_bytes"] += float(a.numel() + b.numel() + out.numel()) * a.element_size()
+    stream = torch.cuda.current_stream(a.device).cuda_stream
+    _lib.check(_lib.lib().tcmi_tensordot_bits(a.data_ptr(), a.dim(), b.data_ptr(), b.dim(),
+                                             ctypes.cast(xa, ctypes.c_void_p), ctypes.cast(xb, ctypes.c_void_p), nk,
+                                             out.data_ptr(), _lib.TCMI_C64, stream), "tcmi_tensordot_bits")
+    return out
 
 
 SCATTERED_MIN_RANK = 16    # big operand: at least 2^16 elements

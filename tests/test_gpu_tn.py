@@ -338,6 +338,44 @@ def test_few_tile_long_k_gemm_splits_k(shape, trans_a):
     assert float((c - ref).abs().max()) < 2e-5 * float(ref.abs().max())
 
 
+def test_tensordot_from_stored_layouts_matches_torch():
+    """tcmi_tensordot_bits (MFMA kernel, bit-deposit addressing, no operand permuted) against torch.tensordot:
+    random contracted axes in random pairing order, ranks 0..20, outer products, outputs narrower than a tile, few-tile
+    outputs with a long K (split-K) and k bits below / above the row bits of either operand."""
+    import ctypes
+    import torch
+    from tcmi import _lib
+
+    rng = np.random.default_rng(7)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    cases = [(12, 10, 4), (18, 9, 7), (9, 18, 5), (6, 6, 6), (14, 14, 12), (20, 20, 17), (8, 3, 0), (0, 5, 0),
+             (5, 5, 5), (16, 7, 1), (19, 15, 13), (7, 17, 2), (13, 13, 0)]
+    for ra, rb, nk in cases:
+        for rep in range(3):
+            xa = [int(x) for x in rng.permutation(ra)[:nk]]
+            xb = [int(x) for x in rng.permutation(rb)[:nk]]
+            if rep == 1 and nk:          # k bits lowest in a, highest in b
+                xa, xb = list(range(ra - nk, ra)), list(range(nk))
+            if rep == 2 and nk:          # k bits highest in a, lowest in b, reversed pairing
+                xa, xb = list(range(nk)), list(range(rb - 1, rb - 1 - nk, -1))
+            a = torch.randn([2] * ra, dtype=torch.complex64, device="cuda", generator=g)
+            b = torch.randn([2] * rb, dtype=torch.complex64, device="cuda", generator=g)
+            c = torch.full([2] * (ra + rb - 2 * nk), float("nan"), dtype=torch.complex64, device="cuda")
+            arr_a, arr_b = (ctypes.c_int * max(nk, 1))(*xa), (ctypes.c_int * max(nk, 1))(*xb)
+            _lib.check(_lib.lib().tcmi_tensordot_bits(
+                a.data_ptr(), ra, b.data_ptr(), rb, ctypes.cast(arr_a, ctypes.c_void_p), ctypes.cast(arr_b, ctypes.c_void_p),
+                nk, c.data_ptr(), _lib.TCMI_C64, torch.cuda.current_stream().cuda_stream), "tcmi_tensordot_bits")
+            ref = np.tensordot(a.cpu().numpy().astype(np.complex128), b.cpu().numpy().astype(np.complex128), axes=(xa, xb))
+            err = float(np.abs(c.cpu().numpy() - ref).max()) / max(float(np.abs(ref).max()), 1e-30)
+            assert err < 3e-5, (ra, rb, nk, xa, xb, err)
+    # argument errors
+    one = torch.zeros(2, 2, dtype=torch.complex64, device="cuda")
+    bad = (ctypes.c_int * 2)(0, 0)
+    rc = _lib.lib().tcmi_tensordot_bits(one.data_ptr(), 2, one.data_ptr(), 2, ctypes.cast(bad, ctypes.c_void_p),
+                                        ctypes.cast(bad, ctypes.c_void_p), 2, one.data_ptr(), _lib.TCMI_C64, 0)
+    assert rc != 0
+
+
 @pytest.mark.parametrize("dt", ["complex64", "complex128"])
 def test_scattered_contraction_matches_tensordot(dt):
     """tcmi_contract_scattered (big tensor x small tensor over arbitrary axes, no permute of the big one) against
