@@ -220,10 +220,13 @@ def vqe_leg(tc, torch, dist, args, rank, world, dev):
     exec_bytes = sum(d["work"] for d in ev.values()) / max(1, args.vqe_steps)
     step_s = el / args.vqe_steps
     b_fwd = nf * 2.0 * S
+    fcfg = X.pick_variant(n, "complex64")[1]
+    acfg = X.pick_adjoint_variant(n, "complex64", [])
     roof = {
-        "forward_pass": hbm_entry("tcmi::pass2_kernel<5,8> (gate passes)", ev.get("pass"), args.vqe_steps),
-        "adjoint_pass": hbm_entry("tcmi::adjoint2_kernel<4,9> (reverse sweep on psi and lambda)", ev.get("adjoint"),
-                                  args.vqe_steps),
+        "forward_pass": hbm_entry(f"tcmi::pass2_kernel<{fcfg.R},{fcfg.LT}> (gate passes)",
+                                  ev.get("pass"), args.vqe_steps),
+        "adjoint_pass": hbm_entry(f"tcmi::adjoint2_kernel<{acfg.R},{acfg.LT}> (reverse sweep on psi and lambda)",
+                                  ev.get("adjoint"), args.vqe_steps),
         "measure_pass": hbm_entry("tcmi::pass_kernel<float,4,8,1> (fused Pauli-sum measurement)", ev.get("measure"),
                                   args.vqe_steps),
         "pauli_sum": hbm_entry("tcmi::pauli_sum_kernel (cotangent of the energy)", ev.get("pauli_sum"), args.vqe_steps),
