@@ -14,7 +14,7 @@ MAGIC = 0x54434D31
 HDR_WORDS = 24
 RR_WORDS = 50
 OP_G1, OP_G2, OP_DIAG, OP_G1M, OP_EXPECT, OP_DIAGC, OP_DIAGB = 1, 2, 3, 4, 5, 6, 7
-OP_DIAGF, OP_DIAGB2, OP_DIAGCW = 8, 9, 10
+OP_DIAGF, OP_DIAGB2, OP_DIAGCW, OP_EXPECT2 = 8, 9, 10, 11
 R_MAX = 6
 CONST_FLAG = 1 << 30
 BK_TRIG, BK_COEF, BK_SELECT, BK_PHASE = 1, 2, 5, 6
@@ -284,6 +284,29 @@ def run_pass(state, desc, ctab, ptab_row, eout=None):
                     st = 1 - 2 * _parity(tidx & np.uint64(zm))
                     eout[oi] += np.sum(np.conj(regs[..., rid ^ xr]) * regs * sr[None, None, :] * st[:, :, None])
                     q += 4
+            elif op == OP_EXPECT2:
+                # {11, nX, gmask, X: (xr, zr, zm, out)*, per set bit k of gmask: count, (zm, out)*}
+                nX, gmask = int(d[q + 1]), int(np.uint32(d[q + 2]))
+                q += 3
+                tidx = (wg_base[:, None] | tphys[None, :]).astype(np.uint64)
+                for _x in range(nX):
+                    xr, zr, zm, oi = (int(v) for v in d[q: q + 4])
+                    assert bin(xr).count("1") in (1, 2)
+                    sr = 1 - 2 * _parity(rid.astype(np.uint64) & np.uint64(zr))
+                    st = 1 - 2 * _parity(tidx & np.uint64(zm))
+                    eout[oi] += np.sum(np.conj(regs[..., rid ^ xr]) * regs * sr[None, None, :] * st[:, :, None])
+                    q += 4
+                for kreg in range(NR):
+                    if not (gmask >> kreg) & 1:
+                        continue
+                    cnt = int(d[q])
+                    q += 1
+                    sr = 1 - 2 * _parity(rid.astype(np.uint64) & np.uint64(kreg))
+                    for _z in range(cnt):
+                        zm, oi = int(d[q]), int(d[q + 1])
+                        st = 1 - 2 * _parity(tidx & np.uint64(zm))
+                        eout[oi] += np.sum((np.abs(regs) ** 2) * sr[None, None, :] * st[:, :, None])
+                        q += 2
             else:
                 raise ValueError(f"bad opcode {op} at word {q}")
         assert q == pc + RR_WORDS + opwords

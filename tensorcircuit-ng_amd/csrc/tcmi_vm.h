@@ -48,6 +48,7 @@
 #define TCMI_OP_DIAGC 6 /* {6, slot}: a[r] *= table[r], 2^R complex factors in the per-batch table */
 #define TCMI_OP_DIAGF 8 /* backward flush of diagonal terms in table form (tcmi_adjoint2.hip): {8, cslot (-1: none), hasC, nB, nA, nsel, m0, m1, m2, gsC[2^R] (gradient slot of the register-only term with mask k or -1; hasC = any), B: (j, mask, slot (-1: applied elsewhere), gslot)*, A: (mask, gslot)*}; cslot = 2^nsel wave-selected variants (as OP_DIAGCW) of the register table; tables = FORWARD phase factors, the conjugate is applied; A terms: gradient only */
 #define TCMI_OP_DIAGB2 9 /* {9, j, mask1, mask2, slot}: a[r] *= table[s1 + 2 s2] (conjugate for z_j(r) = -1), s_i = parity(thread index & mask_i); 4 complex factors (second-generation kernels only) */
+#define TCMI_OP_EXPECT2 11 /* measurement (second-generation kernel tcmi_measure2.hip): {11, nX, gmask, X strings (xr, zr, zm, out)*nX as in EXPECT, then for every set bit k of gmask (ascending): count, (zm, out)*count -- the Z-only strings whose register mask is k */
 #define TCMI_OP_DIAGCW 10 /* {10, slot, nsel, m0, m1, m2}: a[r] *= table[v][r], v = sum_k parity(wave's thread index & m_k) << k (the masks touch wave-uniform bits only), 2^nsel tables of 2^R complex factors (second-generation kernels only) */
 #define TCMI_FLAG_NOSTORE 1
 #define TCMI_CONST_FLAG (1 << 30)

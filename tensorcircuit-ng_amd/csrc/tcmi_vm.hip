@@ -500,6 +500,10 @@ __global__ void zero_state_kernel(typename Cx<F>::type* __restrict__ state, long
   }
 }
 
+// second-generation complex64 measurement pass (tcmi_measure2.hip); -1 = no variant for this (R, LT)
+int run_measure2_c64(const void* state, long long state_stride, int batch, int n, int R, int LT, const int* desc,
+                     double* eout, long long eout_stride, int ecopies, long long ecopy_stride, hipStream_t st);
+
 // second-generation complex64 gate pass (tcmi_vm2.hip); -1 = no variant for this (R, LT)
 int run_pass2_c64(void* state, long long state_stride, int batch, int n, int R, int LT, const int* desc,
                   const void* ctab, const void* ptab, long long ptab_stride, hipStream_t st);
@@ -571,6 +575,14 @@ int tcmi_run_pass(void* state, long long state_stride, int batch, int n, int R, 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!state || !desc_dev || batch < 1) return set_msg(TCMI_ERR_ARG, "tcmi_run_pass: bad argument");
   if (n > 32) return set_msg(TCMI_ERR_ARG, "tcmi_run_pass: n > 32 unsupported");
+  if (dtype == TCMI_C64 && eout_dev && R == 5 && LT == 8 && n >= R + LT) {
+    // measurement passes compiled for the second-generation kernel (TCMI_OP_EXPECT2 descriptors: the host emits them
+    // for exactly this tile, tcmi/plan.py encode_measure_pass)
+    const int rc = tcmi::run_measure2_c64(state, state_stride, batch, n, R, LT, desc_dev, eout_dev, eout_stride, ecopies,
+                                          ecopy_stride, st);
+    if (rc == TCMI_OK) return rc;
+    return set_err("measure2_kernel launch", hipGetLastError());
+  }
   if (dtype == TCMI_C64 && !eout_dev && n >= R + LT) {
     static const bool vm1 = getenv("TCMI_VM1") != nullptr;  // A/B switch: force the first-generation kernel
     if (!vm1) {

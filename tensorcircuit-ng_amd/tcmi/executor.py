@@ -377,19 +377,29 @@ class CompiledCircuit:
         return (gp, lam) if want_input_grad else gp
 
 
-def pick_measure_variant(n_exec: int, dtypestr: str) -> P.PlanConfig:
-    """Measurement passes use a smaller register tile than the gate passes (the EXPECT op keeps
-    |a|^2 and cross products live next to the amplitudes)."""
+def pick_small_tile_variant(n_exec: int, dtypestr: str) -> P.PlanConfig:
+    """Tile of the first-generation measurement / adjoint kernels: a smaller register tile than the gate passes
+    (|a|^2 and cross products, or a second vector, live next to the amplitudes)."""
     c64 = dtypestr == "complex64"
-    ov = os.environ.get("TCMI_MEAS_CFG")     # experiment switch: "R,LT,lowbits"
-    if ov and c64:
-        R, LT, lb = (int(x) for x in ov.split(","))
-        if R + LT <= n_exec:
-            return P.PlanConfig(R=R, LT=LT, lowbits=lb, vec=2)
     for R, LT in ([(4, 8), (2, 6)] if c64 else [(3, 8), (2, 6)]):
         if R + LT <= n_exec:
             return P.PlanConfig(R=R, LT=LT, lowbits=min(5, R + LT), vec=2 if c64 else 1)
-    raise ValueError("no measurement variant fits")
+    raise ValueError("no small-tile variant fits")
+
+
+def pick_measure_variant(n_exec: int, dtypestr: str) -> P.PlanConfig:
+    """Tile of the measurement passes: complex64 states of >= 13 qubits go to the packed kernel
+    (csrc/tcmi_measure2.hip, TCMI_OP_EXPECT2 descriptors), everything else to the first-generation kernel."""
+    c64 = dtypestr == "complex64"
+    ov = os.environ.get("TCMI_MEAS_CFG")     # experiment switch: "R,LT,lowbits" of the first-generation kernel
+    if ov and c64:
+        R, LT, lb = (int(x) for x in ov.split(","))
+        if R + LT <= n_exec and (R, LT) != (5, 8):
+            return P.PlanConfig(R=R, LT=LT, lowbits=lb, vec=2)
+    if c64 and n_exec >= 13 and not os.environ.get("TCMI_VM1"):
+        # packed kernel csrc/tcmi_measure2.hip (TCMI_OP_EXPECT2 descriptors): 32 amplitudes per thread, 13 tile bits
+        return P.PlanConfig(R=5, LT=8, lowbits=int(os.environ.get("TCMI_MEAS_LOWBITS", "5")), vec=2, gen=2)
+    return pick_small_tile_variant(n_exec, dtypestr)
 
 
 def pick_adjoint_variant(n_exec: int, dtypestr: str, gates) -> P.PlanConfig:
@@ -405,7 +415,7 @@ def pick_adjoint_variant(n_exec: int, dtypestr: str, gates) -> P.PlanConfig:
         if os.environ.get("TCMI_ADJ_LT9"):  # experiment switch: 512-thread workgroups, two per CU, 13 tile bits
             return P.PlanConfig(R=4, LT=9, lowbits=5, vec=2, gen=2)
         return P.PlanConfig(R=4, LT=8, lowbits=5, vec=2, gen=2)
-    return pick_measure_variant(n_exec, dtypestr)
+    return pick_small_tile_variant(n_exec, dtypestr)
 
 
 class CompiledMeasure:

@@ -46,6 +46,7 @@ OP_DIAGC = 6   # diagonal terms on register bits only: multiply by a 2^R table o
 OP_DIAGB2 = 9  # two register-x-thread terms on the same register bit: {9, j, mask1, mask2, slot}, table of 4 factors (gen 2)
 OP_DIAGCW = 10  # DIAGC whose table is picked per wave: {10, slot, nsel, m0, m1, m2}, variant = sum_k parity(wave index & m_k) << k, table of 2^nsel * 2^R factors (gen 2): register-x-thread terms whose thread bits are wave-uniform cost no multiply of their own
 OP_DIAGF = 8   # backward (adjoint sweep) flush of diagonal terms in table form: see encode_pass
+OP_EXPECT2 = 11  # measurement, Z-only strings grouped by register mask (gen 2): see encode_measure_pass
 FLAG_NOSTORE = 1
 DIAG_CHUNK = 8
 MAX_DIAGB = 5  # more register-x-thread terms than this in one DIAG op: the per-thread sincos path is cheaper
@@ -1165,7 +1166,20 @@ def encode_measure_pass(terms: List[PauliTerm], n: int, cfg: PlanConfig, pp: Pas
             else:
                 xs += [xr, zr, zm, ti]
         ops = []
-        if zs or xs:
+        if (zs or xs) and cfg.gen >= 2:
+            # {11, nX, gmask, X: (xr, zr, zm, out)*, then for every set bit k of gmask (ascending): count, (zm, out)*}:
+            # the Z-only strings grouped by their register mask k -- the kernel reads the signed sum over the
+            # registers from the Walsh-Hadamard transform of |a|^2 (csrc/tcmi_measure2.hip)
+            groups: Dict[int, List[int]] = {}
+            for i in range(0, len(zs), 3):
+                groups.setdefault(zs[i], []).extend([zs[i + 1], zs[i + 2]])
+            gmask = 0
+            body = []
+            for k in sorted(groups):
+                gmask |= 1 << k
+                body += [len(groups[k]) // 2] + groups[k]
+            ops = [OP_EXPECT2, len(xs) // 4, gmask] + xs + body
+        elif zs or xs:
             ops = [OP_EXPECT, len(zs) // 3, len(xs) // 4] + zs + xs
         rr[0] = 1 if ops else 0
         rr[1] = len(ops)

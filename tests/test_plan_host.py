@@ -212,7 +212,7 @@ def test_small_circuits_are_padded():
 
 
 # ---- measurement and adjoint plans (emulated) -------------------------------------------------------
-@pytest.mark.parametrize("n,R,LT", [(8, 2, 6), (12, 4, 8), (14, 4, 8), (13, 3, 8)])
+@pytest.mark.parametrize("n,R,LT", [(8, 2, 6), (12, 4, 8), (14, 4, 8), (13, 3, 8), (14, 5, 8)])
 def test_measure_plan_emulated(n, R, LT):
     rng = np.random.default_rng(n)
     psi = rng.normal(size=2**n) + 1j * rng.normal(size=2**n)
@@ -229,6 +229,12 @@ def test_measure_plan_emulated(n, R, LT):
     got = E.run_measure_plan(mp, psi)
     ref = np.array([dense.pauli_string_expectation(psi, n, ps) for ps in strings])
     np.testing.assert_allclose(got, ref, atol=1e-12)
+    # the second-generation descriptors (TCMI_OP_EXPECT2: Z-only strings grouped by register mask), both tile widths
+    for lb in (4, 5):
+        mp2 = P.compile_measure_plan(terms, n, P.PlanConfig(R=R, LT=LT, lowbits=min(lb, R + LT), vec=2, gen=2))
+        ops = [int(w) for d in mp2.descs for w in np.asarray(d).view(np.int32)]
+        assert P.OP_EXPECT2 in ops
+        np.testing.assert_allclose(E.run_measure_plan(mp2, psi), ref, atol=1e-12)
     with pytest.raises(NotImplementedError):
         P.compile_measure_plan([P.pauli_term_from_string([1, 1, 1] + [0] * (n - 3))], n, P.PlanConfig(R=R, LT=LT))
 
