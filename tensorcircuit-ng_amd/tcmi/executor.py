@@ -249,7 +249,7 @@ class CompiledCircuit:
             }
         return self._adj
 
-    def vjp(self, params, psi, g, chunk_bytes=48 << 30, inputs=None, want_input_grad=False):
+    def vjp(self, params, psi, g, chunk_bytes=48 << 30, inputs=None, want_input_grad=False, consume=False):
         """dL/dparams = Re <g | d psi / d params> for every batch row, by the adjoint sweep.
         params [B, P] real, psi / g [B, 2^n_exec] complex (psi = the forward output).  The sweep
         works on copies (psi is un-computed in place), processed in batch chunks to bound memory.
@@ -278,8 +278,13 @@ class CompiledCircuit:
         for b0 in range(0, B, cb):
             b1 = min(B, b0 + cb)
             nb = b1 - b0
-            a = psi[b0:b1].to(self.tdtype).clone().contiguous()
-            lam = g[b0:b1].to(self.tdtype).clone().contiguous()
+            if consume and psi.dtype == self.tdtype and g.dtype == self.tdtype and psi.is_contiguous() and g.is_contiguous():
+                # the caller owns psi and g and does not need them afterwards (the traced value_and_grad pipeline):
+                # the sweep un-computes / propagates them in place, two state-sized copies per chunk less
+                a, lam = psi[b0:b1], g[b0:b1]
+            else:
+                a = psi[b0:b1].to(self.tdtype).clone().contiguous()
+                lam = g[b0:b1].to(self.tdtype).clone().contiguous()
             p = params[b0:b1]
             ptab = torch.empty(nb, max(1, adj["plan"].ptab_size), dtype=self.rdtype, device=self.device)
             _lib.check(

@@ -228,7 +228,7 @@ class TracedVag:
             value = value.to(rdt)
             return value if batched else value[0]
         lam = cm.apply_sum(state, w.to(torch.complex128).reshape(1, -1).expand(nb, -1))
-        gp = cc.vjp(params, state, lam).to(torch.float64)                     # [nb, P]
+        gp = cc.vjp(params, state, lam, consume=True).to(torch.float64)       # [nb, P]; state and lam are ours
         gflat = torch.zeros(nb, plan["total"] + plan["consts"].numel(), dtype=torch.float64, device=dev)
         gflat.index_add_(1, plan["index"], gp)
         grads = []
