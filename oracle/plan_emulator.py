@@ -337,10 +337,11 @@ def run_plan(plan, params=None, dtype=np.complex128, batch_index=0):
     return state
 
 
-def lds_conflicts(desc, elem_bytes=8):
+def lds_conflicts(desc, planar=False):
     """Worst-case LDS bank multiplicity of every exchange in a pass: (write_ways, read_ways) per
-    exchange, for 8-byte elements (ds_write_b64: 16-lane groups on 32 banks; ds_read_b64: 32-lane
-    groups on 64 banks)."""
+    exchange.  8-byte elements (first-generation kernels): ds_write_b64, 16-lane groups on 32 banks; ds_read_b64,
+    32-lane groups on 64 banks.  ``planar`` (packed kernels, one 4-byte plane at a time): ds_write_b32 and
+    ds_read_b32, 32-lane groups on 32 four-byte banks."""
     d = np.asarray(desc).view(np.uint32).astype(np.int64)
     n, T, R, LT, nrounds = (int(x) for x in d[1:6])
     pc = HDR_WORDS
@@ -364,7 +365,7 @@ def lds_conflicts(desc, elem_bytes=8):
         return worst
 
     for k in range(nrounds - 1):
-        w = ways(recs[k][40: 40 + LT], recs[k][34: 34 + R], 16, 16)
+        w = ways(recs[k][40: 40 + LT], recs[k][34: 34 + R], 32 if planar else 16, 32 if planar else 16)
         r_ = ways(recs[k + 1][24: 24 + LT], recs[k + 1][18: 18 + R], 32, 32)
         out.append((w, r_))
     return out

@@ -495,12 +495,14 @@ def _schedule_rounds(gates, n, cfg: PlanConfig, pp: PassPlan, independent: bool 
 
 
 # ---- LDS exchange maps -----------------------------------------------------------------
-def exchange_masks(T, wr: Round, rd: Round):
-    """Linear bijection tile-index -> LDS slot for one exchange, chosen so that the 16-lane write
-    groups (ds_write_b64) and the 32-lane read groups (ds_read_b64) are bank-conflict free:
-    slot bits 0..4 <- the tile bits of the reading round's lanes 0..4; tile bits of the writing
-    round's lanes 0..3 that are not among them are XOR-folded into unused low slot bits."""
-    nlw = min(4, len(wr.thr_tb))
+def exchange_masks(T, wr: Round, rd: Round, planar: bool = False):
+    """Linear bijection tile-index -> LDS slot for one exchange, chosen so that the write and the read lane groups
+    are bank-conflict free.  Complex slots (first-generation kernels, 8-byte elements): 16-lane write groups
+    (ds_write_b64), 32-lane read groups (ds_read_b64).  ``planar`` (packed kernels: one 4-byte plane at a time,
+    ds_write_b32 / ds_read_b32, 32-lane groups on 32 four-byte banks): slot bits 0..4 <- the tile bits of the
+    reading round's lanes 0..4; the writing round's lane bits 0..4 that are not among them are XOR-folded into the
+    low slot bits the common ones leave free, so both 5 x 5 low-bit maps are invertible."""
+    nlw = min(5 if planar else 4, len(wr.thr_tb))
     nlr = min(5, len(rd.thr_tb))
     W = list(wr.thr_tb[:nlw])
     Rd = list(rd.thr_tb[:nlr])
@@ -514,7 +516,7 @@ def exchange_masks(T, wr: Round, rd: Round):
             pos[x] = nxt
             nxt += 1
     used_low = {pos[x] for x in both}
-    free_low = [m for m in range(4) if m not in used_low]
+    free_low = [m for m in range(5 if planar else 4) if m not in used_low]
     A = {x: 1 << pos[x] for x in range(T)}
     for x in W:
         if x not in Rd:
@@ -752,7 +754,7 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
         words[8 + i] = p
     tb_of_phys = {p: i for i, p in enumerate(pp.tile_bits)}
     nr = len(pp.rounds)
-    exch = [exchange_masks(T, pp.rounds[k], pp.rounds[k + 1]) for k in range(nr - 1)]
+    exch = [exchange_masks(T, pp.rounds[k], pp.rounds[k + 1], planar=cfg.gen >= 2) for k in range(nr - 1)]
     for k, rd in enumerate(pp.rounds):
         rr = [0] * RR_WORDS
         for j, b in enumerate(rd.reg_tb):
@@ -1128,7 +1130,7 @@ def encode_measure_pass(terms: List[PauliTerm], n: int, cfg: PlanConfig, pp: Pas
     for i, p in enumerate(pp.tile_bits):
         words[8 + i] = p
     nr = len(pp.rounds)
-    exch = [exchange_masks(T, pp.rounds[k], pp.rounds[k + 1]) for k in range(nr - 1)]
+    exch = [exchange_masks(T, pp.rounds[k], pp.rounds[k + 1], planar=cfg.gen >= 2) for k in range(nr - 1)]
     for k, rd in enumerate(pp.rounds):
         rr = [0] * RR_WORDS
         for j, b in enumerate(rd.reg_tb):

@@ -93,10 +93,18 @@ def test_plan_emulated_matches_dense(dtype, n, d):
     pl = P.compile_plan(c._gate_records(), n, cfg, nparams=len(c._params))
     psi = E.run_plan(pl, np.array([float(x) for x in c._params]))
     np.testing.assert_allclose(psi, dense.run(n, ops), atol=1e-12)
-    # every LDS exchange the planner emits is bank-conflict free for 8-byte elements
+    # every LDS exchange the planner emits is bank-conflict free: 8-byte elements for the first-generation kernels,
+    # 4-byte planes (32-lane groups on 32 banks, reads and writes) for the packed ones
     if dtype == "complex64":
         for desc in pl.descs:
-            assert all(w == 1 and r == 1 for w, r in E.lds_conflicts(desc))
+            assert all(w == 1 and r == 1 for w, r in E.lds_conflicts(desc, planar=cfg.gen >= 2))
+    # ... also for the wider tiles of the packed kernels and for adjoint / measurement plans
+    if dtype == "complex64" and n >= 13:
+        for cfg2 in (P.PlanConfig(R=5, LT=8, lowbits=5, vec=2, gen=2), P.PlanConfig(R=4, LT=8, lowbits=5, vec=2, gen=2)):
+            pl2 = P.compile_plan(c._gate_records(), n, cfg2, nparams=len(c._params))
+            np.testing.assert_allclose(E.run_plan(pl2, np.array([float(x) for x in c._params])), dense.run(n, ops), atol=1e-12)
+            for desc in pl2.descs:
+                assert all(w == 1 and r == 1 for w, r in E.lds_conflicts(desc, planar=True))
 
 
 @pytest.mark.parametrize("lowbits,R,LT", [(3, 2, 6), (5, 4, 8), (7, 5, 8), (5, 5, 9), (4, 3, 8)])
