@@ -222,13 +222,15 @@ def vqe_leg(tc, torch, dist, args, rank, world, dev):
     b_fwd = nf * 2.0 * S
     fcfg = X.pick_variant(n, "complex64")[1]
     acfg = X.pick_adjoint_variant(n, "complex64", [])
+    mcfg = X.pick_measure_variant(n, "complex64")
     roof = {
         "forward_pass": hbm_entry(f"tcmi::pass2_kernel<{fcfg.R},{fcfg.LT}> (gate passes)",
                                   ev.get("pass"), args.vqe_steps),
         "adjoint_pass": hbm_entry(f"tcmi::adjoint2_kernel<{acfg.R},{acfg.LT}> (reverse sweep on psi and lambda)",
                                   ev.get("adjoint"), args.vqe_steps),
-        "measure_pass": hbm_entry("tcmi::pass_kernel<float,4,8,1> (fused Pauli-sum measurement)", ev.get("measure"),
-                                  args.vqe_steps),
+        "measure_pass": hbm_entry(f"tcmi::measure2_kernel<{mcfg.R},{mcfg.LT}> (fused Pauli-sum measurement)"
+                                  if mcfg.gen >= 2 else f"tcmi::pass_kernel<float,{mcfg.R},{mcfg.LT},1> (fused Pauli-sum measurement)",
+                                  ev.get("measure"), args.vqe_steps),
         "pauli_sum": hbm_entry("tcmi::pauli_sum_kernel (cotangent of the energy)", ev.get("pauli_sum"), args.vqe_steps),
         "step": {
             "bound": "hbm", "executed_bytes_per_step": exec_bytes, "achieved": exec_bytes / step_s / 1e9,
