@@ -7,7 +7,7 @@ import tcmi as tc
 from tcmi import plan as P, _lib
 from oracle import workloads as W
 n, d = int(sys.argv[1]), int(sys.argv[2]); B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-tc.set_backend("hip"); tc.set_dtype("complex64"); tc.set_contractor("plain")
+tc.set_backend("hip"); tc.set_dtype("complex64"); tc.set_contractor("plain", **({"lowbits": int(os.environ["LOWBITS"])} if os.environ.get("LOWBITS") else {}))
 params = np.random.default_rng(n).uniform(0, 2 * np.pi, [2 * d, n]).astype(np.float32)
 c = tc.Circuit(n); W.hea_b(c, n, d, tc.backend.convert_to_tensor(params), zz=tc.gates._zz_matrix)
 cc = c._compiled(); p = c._param_tensor().reshape(1, -1).repeat(B, 1)

@@ -141,6 +141,17 @@ class CompiledCircuit:
         # un-compute psi through them; vjp() then works segment by segment from checkpoints
         self.nonunitary = [i for i, g in enumerate(gates) if not gate_is_unitary(g)]
         self.plan = P.compile_plan(gates, self.n_exec, self.cfg, nparams=nparams)
+        if self.cfg.gen >= 2 and "lowbits" not in (opts or {}) and self.n_exec >= 20 and len(gates) >= 64:
+            # the greedy tile growth is sensitive to how many low bits are pinned (10 - 11 passes, differently balanced,
+            # at n = 28 d = 12): compile the neighbours too and keep the plan the pass model likes best
+            best = vm_cost_us(self.plan)
+            for lb in (6, 4):
+                cfg2 = P.PlanConfig(R=self.cfg.R, LT=self.cfg.LT, lowbits=lb, vec=self.cfg.vec, gen=self.cfg.gen,
+                                    pass_cap=self.cfg.pass_cap)
+                plan2 = P.compile_plan(gates, self.n_exec, cfg2, nparams=nparams)
+                c2 = vm_cost_us(plan2)
+                if c2 < best * 0.995:
+                    best, self.plan, self.cfg = c2, plan2, cfg2
         self.tdtype = torch.complex64 if dtypestr == "complex64" else torch.complex128
         self.rdtype = torch.float32 if dtypestr == "complex64" else torch.float64
         self.code = _lib.TCMI_C64 if dtypestr == "complex64" else _lib.TCMI_C128
@@ -556,12 +567,44 @@ def get_measure(n, n_exec, strings, dtypestr) -> CompiledMeasure:
 
 # ---- cost model (microseconds per 2^24 amplitudes, fitted on MI355X: profiles/r01b) -------------------
 VM_COST = {"pass": 19.5, "g1": 2.25, "g2": 9.0, "diag": 11.5, "exchange": 10.75}
+# packed complex64 kernel (csrc/tcmi_vm2.hip), fitted to the per-pass times of n = 28, d = 12 (scripts/gpu_pass_breakdown.py):
+# a pass costs max(HBM floor, fixed + gates + phase tables + exchanges), microseconds per 2^24 amplitudes
+VM2_COST = {"floor": 52.0, "fixed": 16.2, "g1": 0.95, "g2": 3.8, "table": 1.1, "diag": 5.0, "exchange": 3.3}
 GEMM_TFLOPS = 140.0  # tcmi_cgemm, batched cut join (3-product kernel, algorithmic flops; profiles/r01h)
 
 
 def vm_cost_us(plan: "P.CompiledPlan") -> float:
     """Estimated time of a tile-VM plan for one state (linear op-count model)."""
     t = 0.0
+    gen2 = getattr(plan.cfg, "gen", 1) >= 2 if hasattr(plan, "cfg") else False
+    if gen2:
+        for desc in plan.descs:
+            d = np.asarray(desc).view(np.uint32).astype(np.int64)
+            pc = P.HDR_WORDS
+            tp = VM2_COST["fixed"] + VM2_COST["exchange"] * (int(d[5]) - 1)
+            for _ in range(int(d[5])):
+                rr = d[pc: pc + P.RR_WORDS]
+                q = pc + P.RR_WORDS
+                for _o in range(int(rr[0])):
+                    op = int(d[q])
+                    if op == P.OP_G1M:
+                        tp += VM2_COST["g1"] * bin(int(d[q + 1]) & 0xFF).count("1")
+                        q += 3
+                    elif op == P.OP_G2:
+                        tp += VM2_COST["g2"] if (int(d[q + 1]) >> 8) == 0 else VM2_COST["g1"]
+                        q += 4
+                    elif op == P.OP_DIAG:
+                        nA, nB, nC = (int(x) for x in d[q + 1: q + 4])
+                        tp += VM2_COST["diag"]
+                        q += 5 + nA + 2 * nB + nC
+                    elif op in (P.OP_DIAGC, P.OP_DIAGB, P.OP_DIAGB2, P.OP_DIAGCW):
+                        tp += VM2_COST["table"]
+                        q += {P.OP_DIAGC: 2, P.OP_DIAGB: 4, P.OP_DIAGB2: 5, P.OP_DIAGCW: 6}[op]
+                    else:
+                        raise ValueError(op)
+                pc = q
+            t += max(VM2_COST["floor"], tp)
+        return t * (2.0 ** plan.n) / 2.0**24
     for pp, desc in zip(plan.passes, plan.descs):
         d = np.asarray(desc).view(np.uint32).astype(np.int64)
         pc = P.HDR_WORDS
