@@ -13,7 +13,7 @@ params = np.random.default_rng(n).normal(0, 0.1, [2 * d, n]).astype(np.float32)
 c = tc.Circuit(n); W.hea_b(c, n, d, tc.backend.convert_to_tensor(params), zz=tc.gates._zz_matrix)
 cc = c._compiled(); cc = getattr(cc, "full", cc); p = c._param_tensor().reshape(1, -1).repeat(B, 1)
 st = cc.state(p, full=True); g = torch.randn_like(st); torch.cuda.synchronize()
-adj = cc._adjoint(); cfg = adj["cfg"]; lib = cc._lib
+adj = cc._adjoint(full=False); cfg = adj["cfg"]; lib = cc._lib
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 cc.vjp(p, st, g); torch.cuda.synchronize()
 e0.record()

@@ -42,7 +42,7 @@ def run(n, d, B, reps=3):
     torch.cuda.synchronize(); t0 = time.time()
     for _ in range(reps): gp = cc.vjp(p, st, g_)
     torch.cuda.synchronize(); tb = (time.time() - t0) / reps
-    adj = cc._adjoint()
+    adj = cc._adjoint(full=False)
     print(f"   forward {tf*1e3:.1f} ms ({len(cc.descs)} passes)  adjoint sweep {tb*1e3:.1f} ms ({len(adj['descs'])} passes, cfg R{adj['cfg'].R})", flush=True)
 
 import sys

@@ -239,16 +239,35 @@ class CompiledCircuit:
         return self.plan.stats(item)
 
     # ---- reverse mode ------------------------------------------------------------------------
-    def _adjoint(self):
-        """Adjoint-sweep plan (compiled lazily, own tile config: two vectors live in registers)."""
+    def _adjoint(self, full: bool = True):
+        """Adjoint-sweep plan (compiled lazily, own tile config: two vectors live in registers).  ``full=False``: the
+        sweep may stop before the constant gates that open the circuit (no gradient slot behind them); the full plan is
+        the one that also returns the input-state cotangent."""
         import torch
 
-        if getattr(self, "_adj", None) is None:
+        key = "_adj" if full else "_adj_short"
+        if getattr(self, key, None) is None:
             gates = self._exec_gates
             cfg = pick_adjoint_variant(self.n_exec, self.dtypestr, gates)
-            ap = P.compile_adjoint_plan(gates, self.n_exec, cfg, factorized=cfg.gen >= 2)
+            if not full and not (gates and not P.gate_has_param(gates[0]) and any(P.gate_has_param(g) for g in gates)):
+                self._adj_short = self._adjoint(True)      # nothing to drop
+                return self._adj_short
+            ap = P.compile_adjoint_plan(gates, self.n_exec, cfg, factorized=cfg.gen >= 2, drop_constant_head=not full)
+            if cfg.gen >= 2 and self.n_exec >= 20 and len(gates) >= 64:
+                # the greedy schedule is sensitive to the pinned low bits and (short sweep) to the dropped gates: compile
+                # the neighbours and keep what the pass model likes best; the short sweep may keep the full gate list
+                best = adj_cost_us(ap)
+                for drop in ((True, False) if not full else (False,)):
+                    for lb in (5, 6, 4):
+                        if best is None or (lb == cfg.lowbits and drop == (not full)):
+                            continue
+                        cfg2 = P.PlanConfig(R=cfg.R, LT=cfg.LT, lowbits=lb, vec=cfg.vec, gen=cfg.gen)
+                        ap2 = P.compile_adjoint_plan(gates, self.n_exec, cfg2, factorized=True, drop_constant_head=drop)
+                        c2 = adj_cost_us(ap2)
+                        if c2 is not None and c2 < best * 0.995:
+                            best, ap, cfg = c2, ap2, cfg2
             dev = self.device
-            self._adj = {
+            setattr(self, key, {
                 "plan": ap, "cfg": cfg,
                 "descs": [_dev(d, dev) for d in ap.descs],
                 "ctab": _dev(ap.ctab, dev, self.rdtype),
@@ -257,8 +276,8 @@ class CompiledCircuit:
                 "gparam": _dev(ap.gslot_param, dev),
                 "gfactor": _dev(ap.gslot_factor, dev),
                 "nslots": len(ap.gslot_param),
-            }
-        return self._adj
+            })
+        return getattr(self, key)
 
     def vjp(self, params, psi, g, chunk_bytes=48 << 30, inputs=None, want_input_grad=False, consume=False):
         """dL/dparams = Re <g | d psi / d params> for every batch row, by the adjoint sweep.
@@ -272,7 +291,7 @@ class CompiledCircuit:
         if self.nonunitary:
             return self._vjp_segmented(params, g, inputs, want_input_grad)
         lam_out = torch.empty_like(g) if want_input_grad else None
-        adj = self._adjoint()
+        adj = self._adjoint(full=want_input_grad)
         lib = self._lib
         B = params.shape[0]
         nel = 2**self.n_exec
@@ -571,6 +590,40 @@ VM_COST = {"pass": 19.5, "g1": 2.25, "g2": 9.0, "diag": 11.5, "exchange": 10.75}
 # a pass costs max(HBM floor, fixed + gates + phase tables + exchanges), microseconds per 2^24 amplitudes
 VM2_COST = {"floor": 52.0, "fixed": 16.2, "g1": 0.95, "g2": 3.8, "table": 1.1, "diag": 5.0, "exchange": 3.3}
 GEMM_TFLOPS = 140.0  # tcmi_cgemm, batched cut join (3-product kernel, algorithmic flops; profiles/r01h)
+
+
+# packed adjoint kernel (csrc/tcmi_adjoint2.hip), fitted to the per-pass times of n = 28, d = 12 (scripts/gpu_adj_one.py
+# --passes): max(HBM floor, gates + diagonal flushes + exchanges), microseconds per 2^24 amplitudes
+ADJ2_COST = {"floor": 106.0, "g1": 4.2, "flush": 8.1, "exchange": 6.3}
+
+
+def adj_cost_us(ap: "P.AdjointPlan") -> float:
+    """Estimated time of a packed (gen 2) adjoint plan for one state; None for other plans."""
+    if ap.cfg.gen < 2:
+        return None
+    R = ap.cfg.R
+    t = 0.0
+    for desc in ap.descs:
+        d = np.asarray(desc).view(np.uint32).astype(np.int64)
+        pc = P.HDR_WORDS
+        tp = ADJ2_COST["exchange"] * (int(d[5]) - 1)
+        for _ in range(int(d[5])):
+            rr = d[pc: pc + P.RR_WORDS]
+            q = pc + P.RR_WORDS
+            end = q + int(rr[1])
+            for _o in range(int(rr[0])):
+                op = int(d[q])
+                if op == P.OP_G1M:
+                    tp += ADJ2_COST["g1"] * bin(int(d[q + 1]) & 0xFF).count("1")
+                    q += 5 + R
+                elif op == P.OP_DIAGF:
+                    tp += ADJ2_COST["flush"]
+                    q += 9 + (1 << R) + 4 * int(d[q + 3]) + 2 * int(d[q + 4])
+                else:
+                    return None
+            pc = end
+        t += max(ADJ2_COST["floor"], tp)
+    return t * (2.0 ** ap.n) / 2.0**24
 
 
 def vm_cost_us(plan: "P.CompiledPlan") -> float:

@@ -1224,12 +1224,23 @@ class AdjointPlan:
     gslot_factor: np.ndarray  # float64 [nslots]
 
 
-def compile_adjoint_plan(gates: List[GateRec], n: int, cfg: PlanConfig, factorized: bool = False) -> AdjointPlan:
+def gate_has_param(g: GateRec) -> bool:
+    return g.param is not None or (g.diag is not None and any(t.param is not None for t in g.diag))
+
+
+def compile_adjoint_plan(gates: List[GateRec], n: int, cfg: PlanConfig, factorized: bool = False,
+                         drop_constant_head: bool = False) -> AdjointPlan:
     """Plan of the reversed circuit: gates in reverse order, each applied as U^dagger to both psi and
     the cotangent lambda, with one gradient slot per parametrised gate / diagonal term.  Valid for
     unitary gates (psi is un-computed, not stored).  ``factorized``: diagonal terms as OP_DIAGF (the
-    packed-f32 kernel csrc/tcmi_adjoint2.hip) instead of the generic OP_DIAG."""
+    packed-f32 kernel csrc/tcmi_adjoint2.hip) instead of the generic OP_DIAG.
+    ``drop_constant_head``: the constant gates BEFORE the first parametrised gate of the circuit (the Hadamard layer
+    of an ansatz) end the reverse sweep and feed no gradient slot -- they are left out; psi and lambda then stop at
+    the state after those gates, so callers that want the input-state cotangent must not set it."""
     rev = list(reversed(gates))
+    if drop_constant_head:
+        last = max((i for i, g in enumerate(rev) if gate_has_param(g)), default=-1)
+        rev = rev[: last + 1]
     passes = schedule(rev, n, cfg)
     tables = Tables()
     tables.ctab += [0.0] * 8
