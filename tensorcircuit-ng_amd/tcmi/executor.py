@@ -142,12 +142,13 @@ class CompiledCircuit:
         self.nonunitary = [i for i, g in enumerate(gates) if not gate_is_unitary(g)]
         self.plan = P.compile_plan(gates, self.n_exec, self.cfg, nparams=nparams)
         if self.cfg.gen >= 2 and "lowbits" not in (opts or {}) and self.n_exec >= 20 and len(gates) >= 64:
-            # the greedy tile growth is sensitive to how many low bits are pinned (10 - 11 passes, differently balanced,
-            # at n = 28 d = 12): compile the neighbours too and keep the plan the pass model likes best
+            # the greedy tile growth is sensitive to how many low bits are pinned and to how equal gains are broken (8 - 11
+            # passes, differently balanced, at n = 28 d = 12): compile the neighbours too and keep the plan the pass model
+            # likes best
             best = vm_cost_us(self.plan)
-            for lb in (6, 4):
+            for lb, tb in ((6, 0), (4, 0), (4, 1), (5, 1), (6, 1)):
                 cfg2 = P.PlanConfig(R=self.cfg.R, LT=self.cfg.LT, lowbits=lb, vec=self.cfg.vec, gen=self.cfg.gen,
-                                    pass_cap=self.cfg.pass_cap)
+                                    pass_cap=self.cfg.pass_cap, tiebreak=tb)
                 plan2 = P.compile_plan(gates, self.n_exec, cfg2, nparams=nparams)
                 c2 = vm_cost_us(plan2)
                 if c2 < best * 0.995:
@@ -258,10 +259,11 @@ class CompiledCircuit:
                 # the neighbours and keep what the pass model likes best; the short sweep may keep the full gate list
                 best = adj_cost_us(ap)
                 for drop in ((True, False) if not full else (False,)):
-                    for lb in (5, 6, 4):
-                        if best is None or (lb == cfg.lowbits and drop == (not full)):
+                    for lb, tb in ((5, 0), (4, 0), (4, 1), (5, 1)):
+                        if best is None or ((lb, tb) == (cfg.lowbits, cfg.tiebreak) and drop == (not full)) \
+                                or (drop is False and not full and (lb, tb) != (4, 1)):
                             continue
-                        cfg2 = P.PlanConfig(R=cfg.R, LT=cfg.LT, lowbits=lb, vec=cfg.vec, gen=cfg.gen)
+                        cfg2 = P.PlanConfig(R=cfg.R, LT=cfg.LT, lowbits=lb, vec=cfg.vec, gen=cfg.gen, tiebreak=tb)
                         ap2 = P.compile_adjoint_plan(gates, self.n_exec, cfg2, factorized=True, drop_constant_head=drop)
                         c2 = adj_cost_us(ap2)
                         if c2 is not None and c2 < best * 0.995:

@@ -285,7 +285,7 @@ def _scan_fixed(gates, order, qmask, rmask, S, count_only=False, cap=None):
     return cnt if count_only else chosen
 
 
-def _grow(gates, order, qmask, rmask, capacity, forced, allowed, window=600):
+def _grow(gates, order, qmask, rmask, capacity, forced, allowed, window=600, tiebreak=0):
     """Choose up to ``capacity`` resource bits (bit mask, superset of ``forced``, subset of ``allowed``) greedily by
     marginal gain: the bit -- or the pair of bits of one pending two-qubit gate -- that makes the most additional
     dense gates executable per bit added.  Returns the mask (possibly with fewer than ``capacity`` bits when nothing
@@ -315,7 +315,7 @@ def _grow(gates, order, qmask, rmask, capacity, forced, allowed, window=600):
             if gain <= 0:
                 continue
             k = bin(c).count("1")
-            key = (gain / k, -k, -c)
+            key = (gain / k, -k, -c if tiebreak == 0 else c)   # equal gains: lowest / highest bits first
             if best_key is None or key > best_key:
                 best, best_key = c, key
         if not best:
@@ -347,6 +347,7 @@ class PlanConfig:
     vec: int = 2        # amplitudes per 16-byte global access (2 for complex64, 1 for complex128)
     pass_cap: Optional[int] = None   # at most this many (weighted) dense gates per pass: a pass costs max(HBM round trip, arithmetic), so more gates than the round trip hides are better left to a later pass
     gen: int = 1        # kernel generation executing the plan: 2 = packed-f32 kernels (tcmi_vm2 / tcmi_adjoint2): extra ops
+    tiebreak: int = 0   # tile growth, equal marginal gains: 0 = lowest physical bits first, 1 = highest first
 
     @property
     def T(self):
@@ -383,7 +384,7 @@ def schedule(gates, n: int, cfg: PlanConfig, independent: bool = False) -> List[
         if independent:
             S, chosen = _scan(gates, pending, order_bits, phys_res, T, set(range(L)), all_bits)
         else:
-            Sm = _grow(gates, pending, qmask, rmask, T, (1 << L) - 1, (1 << n) - 1)
+            Sm = _grow(gates, pending, qmask, rmask, T, (1 << L) - 1, (1 << n) - 1, tiebreak=cfg.tiebreak)
             chosen = _scan_fixed(gates, pending, qmask, rmask, Sm, cap=cfg.pass_cap)
             S = {b for b in range(n) if (Sm >> b) & 1}
             if not any(not gates[gi].is_diag for gi in chosen) and any(not gates[gi].is_diag for gi in pending):
