@@ -445,16 +445,29 @@ __global__ __launch_bounds__(256) void pauli_sum_kernel(const typename Cx<F>::ty
           }
         }
       }
+      // sign = parity((idx ^ xm) & zm), idx = base + tid + 256 k: the thread's part once per term, the rest is
+      // wave-uniform (scalar code); i^ny folded into which component feeds which sum -> two FMAs per element and term
+      // (the per-element popcount / select / swizzle form made this kernel VALU bound: 7.0 -> 5.6 ms per n = 28 state)
+      constexpr uint32_t TM = (uint32_t)TILE - 1u;   // index bits inside the tile
+      const F ct = (__popc((uint32_t)threadIdx.x & zm) & 1) ? -c0 : c0;
+      const uint32_t ubase = (uint32_t)base;
+      const int par0 = __popc(((ubase ^ xm) & ~TM) & zm) + __popc((xm & TM) & zm);
+      if (ny == 0 || ny == 2) {
 #pragma unroll
-      for (int k = 0; k < EPT; ++k) {
-        const uint32_t idx = (uint32_t)(base + threadIdx.x + 256 * k);
-        const F c = (__popc((idx ^ xm) & zm) & 1) ? -c0 : c0;
-        F pr = v[k].x, pi = v[k].y;  // multiply by i^ny
-        if (ny == 1) { pr = -v[k].y; pi = v[k].x; }
-        else if (ny == 2) { pr = -v[k].x; pi = -v[k].y; }
-        else if (ny == 3) { pr = v[k].y; pi = -v[k].x; }
-        re[k] = fma_<F>(c, pr, re[k]);
-        im[k] = fma_<F>(c, pi, im[k]);
+        for (int k = 0; k < EPT; ++k) {
+          const bool neg = ((par0 + __popc(((uint32_t)(256 * k)) & zm)) & 1) != (ny == 2);   // uniform
+          const F c = neg ? -ct : ct;
+          re[k] = fma_<F>(c, v[k].x, re[k]);
+          im[k] = fma_<F>(c, v[k].y, im[k]);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+          const bool neg = ((par0 + __popc(((uint32_t)(256 * k)) & zm)) & 1) != (ny == 3);   // uniform
+          const F c = neg ? -ct : ct;   // i v = (-v.y, v.x)
+          re[k] = fma_<F>(-c, v[k].y, re[k]);
+          im[k] = fma_<F>(c, v[k].x, im[k]);
+        }
       }
     }
 #pragma unroll

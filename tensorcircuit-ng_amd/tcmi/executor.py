@@ -591,7 +591,7 @@ VM_COST = {"pass": 19.5, "g1": 2.25, "g2": 9.0, "diag": 11.5, "exchange": 10.75}
 # packed complex64 kernel (csrc/tcmi_vm2.hip), fitted to the per-pass times of n = 28, d = 12 (scripts/gpu_pass_breakdown.py):
 # a pass costs max(HBM floor, fixed + gates + phase tables + exchanges), microseconds per 2^24 amplitudes
 VM2_COST = {"floor": 52.0, "fixed": 16.2, "g1": 0.95, "g2": 3.8, "table": 1.1, "diag": 5.0, "exchange": 3.3}
-GEMM_TFLOPS = 140.0  # tcmi_cgemm, batched cut join (3-product kernel, algorithmic flops; profiles/r01h)
+GEMM_TFLOPS = 150.0  # tcmi_cgemm, batched cut join (3-product kernel, algorithmic flops: 154 measured, profiles/r02d)
 
 
 # packed adjoint kernel (csrc/tcmi_adjoint2.hip), fitted to the per-pass times of n = 28, d = 12 (scripts/gpu_adj_one.py
@@ -926,7 +926,8 @@ def _maybe_cut(cc, n, gates, nparams, dtypestr, opts):
         return cc
     t_vm = vm_cost_us(cc.plan)
     t_gemm = 8.0 * 2.0**n * best.bond_dim / (GEMM_TFLOPS * 1e6)      # microseconds
-    t_halves = 2 * 40.0 + best.bond_dim * 2.0 ** max(best.n_left, n - best.n_left) / 2.0**24 * 200.0  # two-level
-    if method == "cut" or (t_gemm + t_halves) < 0.7 * t_vm:
+    t_halves = 2 * 15.0 + best.bond_dim * 2.0 ** max(best.n_left, n - best.n_left) / 2.0**24 * 200.0  # two-level
+    # config 2 (n = 24, d = 8, bond 256) measured: cut 286 us per state (model 254), state-vector plan 511 (model 470)
+    if method == "cut" or (t_gemm + t_halves) < 0.85 * t_vm:
         return CutCircuit(n, gates, nparams, dtypestr, opts, best, cc)
     return cc
