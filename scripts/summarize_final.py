@@ -1,0 +1,57 @@
+"""profiles/<tag>_summary.txt from the captures of scripts/gpu_final_profiles.sh: every fraction of the bench line recomputed
+from the committed files.  usage: python scripts/summarize_final.py <tag>"""
+import csv, json, sys
+
+tag = sys.argv[1]
+d = json.loads(open(f"profiles/{tag}_bench_default.json").read().strip().splitlines()[-1])
+ks = {r["Name"]: r for r in csv.DictReader(open(f"profiles/{tag}_bench_default_kernel_stats.csv"))}
+hs = {r["Name"]: r for r in csv.DictReader(open(f"profiles/{tag}_headline_kernel_stats.csv"))}
+
+
+def find(tab, sub):
+    for k, v in tab.items():
+        if sub in k:
+            return v
+
+
+L = [f"Round-2 final captures {tag} (MI355X, one GPU), all from the binary of the last commit that touched csrc/.", "",
+     f"{tag}_bench_default.json                   python3 bench.py   (bench line: HIP-event launch times, PMC traffic probe)",
+     f"{tag}_bench_default_under_rocprof.json     the same command under rocprofv3 --kernel-trace --stats (program directly after --)",
+     f"{tag}_bench_default_kernel_stats.csv       rocprofv3 kernel stats of that run (all legs: launches of different batch sizes share a row)",
+     f"{tag}_headline_kernel_stats.csv            rocprofv3 kernel stats of the timed region of config 2 only (bench.py --probe-child --steps 20",
+     "                                          --warmup 3): every cgemm_mfma_kernel<true> launch is a batch-8 join GEMM",
+     f"{tag}_vqe_n28_d12_pmc.txt                  rocprofv3 --pmc passes (4 separate runs) over scripts/gpu_vqe_timing.py 28,12,1, per-dispatch averages", ""]
+r = d["roofline"]
+L.append(f"Config 2 headline ({d['config']['plan'].get('contraction')} order), dominant kernel {r.get('kernel')}:")
+if r.get("bound") == "mfma":
+    g = find(hs, "cgemm_mfma_kernel<true>")
+    L.append(f"  HIP events (bench line):   {r['avg_launch_us']:.1f} us per launch -> executed flops {r['executed_flops_per_launch']:.4g} / t = {r['achieved']:.1f} TF = {r['frac']:.3f} of 157.3 TF (algorithmic, 8 flops per MAC: {r['algorithmic_frac']:.3f})")
+    if g:
+        tf = r["executed_flops_per_launch"] / float(g["AverageNs"]) * 1e9 / 1e12
+        L.append(f"  rocprofv3 (headline csv):  {float(g['AverageNs'])/1e3:.1f} us average over {g['Calls']} calls (min {float(g['MinNs'])/1e3:.1f}) -> {tf:.1f} TF = {tf/157.3:.3f}")
+    if r.get("traffic"):
+        L.append(f"  PMC traffic (bench line):  {r['traffic']/1e9:.3f} GB per launch ((2 FETCH + WRITE) KiB) vs {r['algorithmic_bytes_per_launch']/1e9:.3f} GB algorithmic")
+L.append(f"  value {d['value']:.4g} amplitudes/s, {d['ms_per_step']:.3f} ms per step; batch 1: {d['latency_batch1']['ms_per_state']:.3f} ms per state")
+v = d["vqe_step"]
+vr = v["roofline"]
+L += ["", f"Config 3 VQE step n=28 d=12 batch 32: {v['ms_per_step']:.1f} ms per step = {v['ms_per_step']/32:.1f} ms per sample"]
+for k in ("forward_pass", "adjoint_pass", "measure_pass", "pauli_sum"):
+    x = vr[k]
+    L.append(f"  {k:13s} {x['kernel']:66s} {x['launches_per_step']:.0f} launches/step, {x['avg_launch_us']/1e3:.2f} ms each, {x['algorithmic_bytes_per_launch']/1e9:.1f} GB algorithmic -> {x['achieved']:.0f} GB/s = {x['frac']:.3f} of 8 TB/s")
+x = vr["step"]
+L.append(f"  step: executed bytes {x['executed_bytes_per_step']/1e12:.2f} TB / wall -> {x['achieved']:.0f} GB/s = {x['frac']:.3f}; kernel time {x['kernel_ms_per_step']:.0f} ms of {v['ms_per_step']:.0f}; {x['forward_passes']:.0f} forward / {x['adjoint_passes']:.0f} adjoint passes")
+for sub, name in (("pass2_kernel<5, 8", "pass2_kernel<5,8>"), ("adjoint2_kernel<4, 8", "adjoint2_kernel<4,8>"),
+                  ("measure2_kernel<5, 8", "measure2_kernel<5,8>"), ("pauli_sum_kernel<float, 4096", "pauli_sum_kernel")):
+    g = find(ks, sub)
+    if g:
+        L.append(f"  rocprofv3 {name:22s} {g['Calls']:>5s} calls, average {float(g['AverageNs'])/1e6:.3f} ms (all batch sizes of the run share the row)")
+q = d["rqc_amplitude"]
+qr = q["roofline"]
+L += ["", f"Config 4 RQC amplitude: {q['contract_s']*1e3:.1f} ms, executed flops {qr['executed_flops_this_rank']:.4g} -> {qr['achieved']:.1f} TF = {qr['frac']:.3f} of 157.3; "
+          f"algorithmic bytes {qr['algorithmic_bytes']/1e9:.1f} GB, stand-alone permute bytes {qr['wasted_traffic']/1e6:.1f} MB; launches {qr['launches']}",
+      f"  amplitude {q['amplitude']}", f"  time split {q['time_split']}"]
+m = d["mps_tebd"]
+L += ["", f"Config 5 MPS sweep: {m['us_per_bond']:.0f} us per bond, kernel us per bond {m['roofline']['kernel_us_per_bond']}", "",
+      f"cpu_baseline: {d['cpu_baseline']}"]
+open(f"profiles/{tag}_summary.txt", "w").write("\n".join(L) + "\n")
+print("\n".join(L))
