@@ -214,6 +214,16 @@ def greedy_path(inputs: Sequence[Sequence[int]], output: Sequence[int], size_dic
                 keep.append(e)
         return frozenset(keep)
 
+    # circuit networks: every index has dimension 2 and two ends (or one end and the output) -- sizes are powers of
+    # two of set lengths and the kept indices are set algebra (same results, a third of the search time)
+    if all(d == 2 for d in size_dict.values()):
+        def sz(s):  # noqa: F811
+            return 1 << len(s)
+    if all(v == 2 or (v == 1 and e in out_set) for e, v in uses.items()):
+        def merged(a, b):  # noqa: F811
+            sa, sb = live[a], live[b]
+            return (sa ^ sb) | ((sa & sb) & out_set)
+
     heap: List[Tuple[int, int, int]] = []
 
     def push(i):
@@ -668,6 +678,56 @@ class ContractionTree:
         ltarget = float(np.log2(target_size)) + 1e-9
         sliced: List[int] = []
         sl: set = set()
+        if all(d == 2 for d in self.size_dict.values()):
+            # every index has dimension 2 (circuit networks): index sets as bit masks, sizes as popcounts -- the set /
+            # generator form below spent half of the whole path search here
+            eid = {e: i for i, e in enumerate(self.size_dict)}
+            um = [sum(1 << eid[e] for e in un) for un, _ in steps]
+            km = [sum(1 << eid[e] for e in keep) for _, keep in steps]
+            outm = sum(1 << eid[e] for e in out)
+            ids = list(self.size_dict)
+            it = int(ltarget)
+            slm = 0
+            nsl = 1
+            while True:
+                live = ~slm
+                mx = max((k & live).bit_count() for k in km)
+                if mx <= it:
+                    flops = sum(2.0 ** (u & live).bit_count() for u in um)
+                    return sliced, 8.0 * flops * nsl
+                score: Dict[int, float] = {}
+                for k in km:
+                    kk = k & live
+                    lk = kk.bit_count()
+                    if lk > it:
+                        w = 2.0 ** lk
+                        kk &= ~outm
+                        while kk:
+                            low = kk & -kk
+                            b = low.bit_length() - 1
+                            score[b] = score.get(b, 0.0) + w
+                            kk ^= low
+                if not score:
+                    return None
+                cands = sorted(score, key=lambda b: (-score[b], ids[b]))[:max_candidates]
+                best = None
+                for b in cands:
+                    lv = live & ~(1 << b)
+                    over = flops = 0.0
+                    for u, k in zip(um, km):
+                        lk = (k & lv).bit_count()
+                        flops += 2.0 ** (u & lv).bit_count()
+                        if lk > it:
+                            over += 2.0 ** lk
+                    key = (over, flops)
+                    if best is None or key < best[0]:
+                        best = (key, b)
+                b = best[1]
+                nsl *= 2
+                if nsl > max_slices:
+                    return None
+                sliced.append(ids[b])
+                slm |= 1 << b
 
         def stats(extra):
             over, flops, mx = 0.0, 0.0, 0.0
