@@ -299,6 +299,66 @@ __global__ __launch_bounds__(256, 5) void cgemm_bits_kernel(const float2* __rest
   }
 }
 
+// tensordot from stored layouts whose result has at most 8 x 8 elements and a long contraction (two big tensors closing
+// to a few numbers: 2^25 x 2^25 -> 8 x 8 over K = 2^22 in a reconfigured RQC tree): one thread per k, MT x NT accumulators
+// in registers, k offsets = the thread's low 8 k bits (deposited once) | the block counter's bits (scalar code), DPP wave
+// sums -> LDS -> one f32 atomic per workgroup and output component into the zeroed C.  The MFMA tile kernel with split-K
+// ran this shape at 0.4 TB/s (an 8 x 8 corner of a 64 x 64 tile, 2 M atomics).
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void tensordot_bits_tiny_kernel(const float2* __restrict__ A, const float2* __restrict__ B,
+                                                                  float2* __restrict__ C, int lm, int ln, int lk, BitPos pa,
+                                                                  BitPos pb) {
+  const int tid = threadIdx.x;
+  const uint32_t K = 1u << lk;
+  uint32_t ra[MT], cb[NT];
+#pragma unroll
+  for (int r = 0; r < MT; ++r) ra[r] = deposit_bits((uint32_t)r, pa.free_, lm, 0);      // wave-uniform
+#pragma unroll
+  for (int c = 0; c < NT; ++c) cb[c] = deposit_bits((uint32_t)c, pb.free_, ln, 0);
+  const uint32_t ka_t = deposit_bits((uint32_t)tid, pa.k, lk < 8 ? lk : 8, 0);
+  const uint32_t kb_t = deposit_bits((uint32_t)tid, pb.k, lk < 8 ? lk : 8, 0);
+  float re[MT][NT], im[MT][NT];
+#pragma unroll
+  for (int r = 0; r < MT; ++r)
+#pragma unroll
+    for (int c = 0; c < NT; ++c) { re[r][c] = 0.f; im[r][c] = 0.f; }
+  const uint32_t nblk = (K + 255u) >> 8;
+  for (uint32_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    if ((blk << 8) + (uint32_t)tid >= K) break;
+    uint32_t ka = ka_t, kb = kb_t;
+    for (int j = 8; j < lk; ++j) {           // the block counter's bits: scalar
+      const uint32_t bit = (blk >> (j - 8)) & 1u;
+      ka |= bit << pa.k[j];
+      kb |= bit << pb.k[j];
+    }
+    float2 a[MT], b[NT];
+#pragma unroll
+    for (int r = 0; r < MT; ++r) a[r] = A[ra[r] | ka];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) b[c] = B[cb[c] | kb];
+#pragma unroll
+    for (int r = 0; r < MT; ++r)
+#pragma unroll
+      for (int c = 0; c < NT; ++c) {
+        re[r][c] = __builtin_fmaf(a[r].x, b[c].x, __builtin_fmaf(-a[r].y, b[c].y, re[r][c]));
+        im[r][c] = __builtin_fmaf(a[r].x, b[c].y, __builtin_fmaf(a[r].y, b[c].x, im[r][c]));
+      }
+  }
+  __shared__ float red[4][2 * MT * NT];
+#pragma unroll
+  for (int r = 0; r < MT; ++r)
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+      const float sr = wave_sum_uniform(re[r][c]), si = wave_sum_uniform(im[r][c]);
+      if ((tid & 63) == 0) {
+        red[tid >> 6][2 * (r * NT + c)] = sr;
+        red[tid >> 6][2 * (r * NT + c) + 1] = si;
+      }
+    }
+  __syncthreads();
+  if (tid < 2 * MT * NT) atomicAdd(reinterpret_cast<float*>(C) + tid, red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+}
+
 // complex128 GEMM on the f64 matrix pipe (v_mfma_f64_16x16x4_f64): 64x64 tile per workgroup, 4 waves x
 // (32x32 = 2x2 MFMA tiles), K step 8, the same 3-product (Gauss) form and planar k-major LDS tiles as
 // the complex64 kernel.  Row pitch 66 doubles: 16-byte aligned rows for the vector loaders and
@@ -847,6 +907,25 @@ int tcmi_tensordot_bits(const void* a, int rank_a, const void* b, int rank_b, co
   const int ma = (nk > 0 && pa.k[0] == 0) ? 1 : ((lm > 0 && pa.free_[0] == 0) || rank_a == 0 ? 0 : 2);
   const int mb = (nk > 0 && pb.k[0] == 0) ? 1 : ((ln > 0 && pb.free_[0] == 0) || rank_b == 0 ? 0 : 2);
   const long long M = 1ll << lm, N = 1ll << ln, K = 1ll << nk;
+  if (lm <= 3 && ln <= 3 && K >= 2048) {
+    // a few numbers out of a long contraction: the register-accumulator kernel
+    hipError_t me = hipMemsetAsync(c, 0, (size_t)(M * N) * sizeof(float2), st);
+    if (me != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(me));
+    long long nb = (K + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    dim3 grid((unsigned)nb, 1, 1), block(256, 1, 1);
+#define TCMI_TT(MV, NV)                                                                                                 \
+  if (lm == MV && ln == NV)                                                                                             \
+    hipLaunchKernelGGL((tcmi::tensordot_bits_tiny_kernel<(1 << MV), (1 << NV)>), grid, block, 0, st,                      \
+                       reinterpret_cast<const float2*>(a), reinterpret_cast<const float2*>(b), reinterpret_cast<float2*>(c), \
+                       lm, ln, nk, pa, pb);
+    TCMI_TT(0, 0) TCMI_TT(0, 1) TCMI_TT(0, 2) TCMI_TT(0, 3) TCMI_TT(1, 0) TCMI_TT(1, 1) TCMI_TT(1, 2) TCMI_TT(1, 3)
+    TCMI_TT(2, 0) TCMI_TT(2, 1) TCMI_TT(2, 2) TCMI_TT(2, 3) TCMI_TT(3, 0) TCMI_TT(3, 1) TCMI_TT(3, 2) TCMI_TT(3, 3)
+#undef TCMI_TT
+    hipError_t te = hipGetLastError();
+    if (te != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(te));
+    return TCMI_OK;
+  }
   const long long gx = (N + TCMI_BN - 1) / TCMI_BN, gy_all = (M + TCMI_BM - 1) / TCMI_BM;
   const long long gy = gy_all < 65535 ? gy_all : 65535, gz = (gy_all + 65534) / 65535;
   if (gx > 2147483647ll || gz > 65535) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_tensordot_bits: grid too large");
