@@ -735,13 +735,9 @@ class Circuit:
             out_e = [tn.new_edge() for _ in range(k)]
             # gate identity + side for the light-cone cancellation (tcmi/simplify.py); trigonometric gate families
             # are unitary by construction, constants are checked
-            if op.matrix is None:
-                uni = True
-            else:
-                mm = np.asarray(op.matrix).reshape(2 ** k, 2 ** k)
-                uni = bool(np.abs(mm @ mm.conj().T - np.eye(2 ** k)).max() < 1e-9)
+            # (unitarity of a constant is checked lazily, by the cancellation itself: tn.node_is_unitary)
             nodes.append(tn.Node(t, out_e + [front[q] for q in op.qubits], name=op.name, is_dagger=conj, id=i,
-                                 is_unitary=uni))
+                                 is_unitary=True if op.matrix is None else op.matrix))
             for j, q in enumerate(op.qubits):
                 front[q] = out_e[j]
         return nodes, front

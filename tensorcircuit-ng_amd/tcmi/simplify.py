@@ -10,6 +10,8 @@ contracted edge, so "joining" two legs is a relabelling.  Unlike the reference t
 unitary (constant non-unitary matrices handed to ``c.any`` stay in the network)."""
 from typing import Any, List, Tuple
 
+from .tn import node_is_unitary
+
 
 def _light_cone_cancel(nodes: List[Any]) -> Tuple[List[Any], bool]:
     """One backward scan: cancel every ket gate whose outputs meet its own conjugate (reference simplify.py:198-270)."""
@@ -27,7 +29,7 @@ def _light_cone_cancel(nodes: List[Any]) -> Tuple[List[Any], bool]:
         return e
 
     for n in reversed(nodes):
-        if id(n) in removed or n.is_dagger is not False or not n.is_unitary:
+        if id(n) in removed or n.is_dagger is not False:
             continue
         noe = len(n.edges)
         if noe % 2 != 0 or noe == 0:
@@ -51,7 +53,7 @@ def _light_cone_cancel(nodes: List[Any]) -> Tuple[List[Any], bool]:
             elif match is not m:
                 ok = False
                 break
-        if not ok or match is None:
+        if not ok or match is None or not node_is_unitary(n):
             continue
         # bypass: the input legs of n and of its conjugate become one edge
         for leg in range(k, noe):

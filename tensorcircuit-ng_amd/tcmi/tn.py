@@ -48,6 +48,19 @@ class Node:
         return f"Node(name={self.name!r}, edges={self.edges})"
 
 
+def node_is_unitary(nd: Node) -> bool:
+    """``is_unitary`` of a node; a constant gate carries its matrix there until somebody asks (the check costs more
+    than recording the gate, and only the light-cone cancellation needs it)."""
+    u = nd.is_unitary
+    if isinstance(u, (bool, np.bool_)):
+        return bool(u)
+    m = np.asarray(u)
+    d = int(round(np.sqrt(m.size)))
+    m = m.reshape(d, d)
+    nd.is_unitary = bool(np.abs(m @ m.conj().T - np.eye(d)).max() < 1e-9)
+    return nd.is_unitary
+
+
 class CopyNode(Node):
     """``tn.CopyNode(rank, dimension)``: the delta tensor that identifies all its legs (a hyperedge).  It carries no
     array; the contractor merges the labels of its legs into one index that may then occur in more than two tensors
