@@ -299,6 +299,33 @@ __global__ __launch_bounds__(256, 5) void cgemm_bits_kernel(const float2* __rest
   }
 }
 
+// tensordot from stored layouts for SMALL tensors (operands and result of at most 4096 elements, at most 8 contracted
+// axes): the gate-absorbs-gate steps at the bottom of a circuit network's tree, hundreds per contraction.  One thread per
+// output element, the k offsets of both operands tabulated in LDS once per workgroup; no tiles, no MFMA -- the 64 x 64
+// tile kernel spends more time depositing its tile origin than these steps have arithmetic.
+__global__ __launch_bounds__(256) void tensordot_bits_small_kernel(const float2* __restrict__ A, const float2* __restrict__ B,
+                                                                   float2* __restrict__ C, int lm, int ln, int lk, BitPos pa,
+                                                                   BitPos pb) {
+  __shared__ uint32_t kA[256], kB[256];
+  const int tid = threadIdx.x;
+  const int K = 1 << lk;
+  if (tid < K) {
+    kA[tid] = deposit_bits((uint32_t)tid, pa.k, lk, 0);
+    kB[tid] = deposit_bits((uint32_t)tid, pb.k, lk, 0);
+  }
+  __syncthreads();
+  const uint32_t o = blockIdx.x * 256u + (uint32_t)tid;
+  if (o >= (1u << (lm + ln))) return;
+  const uint32_t ra = deposit_bits(o >> ln, pa.free_, lm, 0), cb = deposit_bits(o & ((1u << ln) - 1u), pb.free_, ln, 0);
+  float re = 0.f, im = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const float2 a = A[ra | kA[k]], b = B[cb | kB[k]];
+    re = __builtin_fmaf(a.x, b.x, __builtin_fmaf(-a.y, b.y, re));
+    im = __builtin_fmaf(a.x, b.y, __builtin_fmaf(a.y, b.x, im));
+  }
+  C[o] = make_float2(re, im);
+}
+
 // tensordot from stored layouts whose result has at most 8 x 8 elements and a long contraction (two big tensors closing
 // to a few numbers: 2^25 x 2^25 -> 8 x 8 over K = 2^22 in a reconfigured RQC tree): one thread per k, MT x NT accumulators
 // in registers, k offsets = the thread's low 8 k bits (deposited once) | the block counter's bits (scalar code), DPP wave
@@ -907,6 +934,15 @@ int tcmi_tensordot_bits(const void* a, int rank_a, const void* b, int rank_b, co
   const int ma = (nk > 0 && pa.k[0] == 0) ? 1 : ((lm > 0 && pa.free_[0] == 0) || rank_a == 0 ? 0 : 2);
   const int mb = (nk > 0 && pb.k[0] == 0) ? 1 : ((ln > 0 && pb.free_[0] == 0) || rank_b == 0 ? 0 : 2);
   const long long M = 1ll << lm, N = 1ll << ln, K = 1ll << nk;
+  if (rank_a <= 12 && rank_b <= 12 && lm + ln <= 12 && nk <= 8) {
+    // small tensors: one thread per output element
+    dim3 grid((unsigned)(((1ll << (lm + ln)) + 255) / 256), 1, 1), block(256, 1, 1);
+    hipLaunchKernelGGL(tcmi::tensordot_bits_small_kernel, grid, block, 0, st, reinterpret_cast<const float2*>(a),
+                       reinterpret_cast<const float2*>(b), reinterpret_cast<float2*>(c), lm, ln, nk, pa, pb);
+    hipError_t se = hipGetLastError();
+    if (se != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(se));
+    return TCMI_OK;
+  }
   if (lm <= 3 && ln <= 3 && K >= 2048) {
     // a few numbers out of a long contraction: the register-accumulator kernel
     hipError_t me = hipMemsetAsync(c, 0, (size_t)(M * N) * sizeof(float2), st);
