@@ -387,3 +387,38 @@ def test_sample_expectation_ps_and_readout_error(tcd):
         np.testing.assert_allclose(float(c.sample_expectation_ps(**kw)), exact, atol=2e-5)
         est = float(c.sample_expectation_ps(shots=20000, status=rng.uniform(size=20000), **kw))
         assert abs(est - exact) < 0.03
+
+
+@pytest.mark.parametrize("n", [14, 17])
+def test_many_random_pauli_strings_in_one_measurement(tcd, n):
+    """One fused measurement of 60 random strings (0-2 X / Y factors, 0-3 Z factors, weights) against the dense oracle:
+    every path of the measurement kernels -- Z-only strings through the Walsh transform, single-X strings, the general
+    pair loop for Y factors, two X / Y factors and register Z factors -- and each string on its own."""
+    tc = tcd
+    atol = 2e-5 if tc.dtypestr == "complex64" else 1e-10
+    rng = np.random.default_rng(100 + n)
+    d = 2
+    params = rng.normal(0, 0.7, [2 * d, n])
+    c = tc.Circuit(n)
+    W.hea_b(c, n, d, tc.backend.convert_to_tensor(params, dtype=tc.rdtypestr), zz=tc.gates._zz_matrix)
+    psi = dense.run(n, W.hea_b_ops(n, d, params))
+    strings, weights = [], []
+    for k in range(60):
+        ps = [0] * n
+        qs = rng.permutation(n)
+        nx, nz = int(rng.integers(0, 3)), int(rng.integers(0, 4))
+        for q in qs[:nx]:
+            ps[q] = int(rng.integers(1, 3))
+        for q in qs[nx:nx + nz]:
+            ps[q] = 3
+        if not any(ps):
+            ps[int(qs[0])] = 3
+        strings.append(ps)
+        weights.append(float(rng.normal()))
+    e = 0.0
+    for w, ps in zip(weights, strings):
+        e = e + w * c.expectation_ps(ps=ps)
+    want = sum(w * dense.pauli_string_expectation(psi, n, ps) for w, ps in zip(weights, strings))
+    np.testing.assert_allclose(_np(tc, e), want, atol=atol * 10)
+    for ps in strings[:12]:
+        np.testing.assert_allclose(_np(tc, c.expectation_ps(ps=ps)), dense.pauli_string_expectation(psi, n, ps), atol=atol)
