@@ -41,6 +41,34 @@ class TracedState:
         self.circuit, self.form = circuit, form
 
 
+_PROBE_CLS = []
+
+
+def _probe_tensor(t):
+    """A probe argument: a tensor whose VALUES may not steer Python (``bool``, ``float``, ``int``, ``item``, ``tolist``,
+    ``numpy``).  A function that branches on, or concretises, its arguments cannot be replaced by a fixed pipeline -- JAX
+    raises a concretisation error there; here the probe aborts and the function keeps the plain path."""
+    import torch
+    from . import _lib
+
+    if not _PROBE_CLS:
+        class ProbeTensor(torch.Tensor):
+            def _abort(self, *a, **k):
+                raise _lib.TraceAbort("the traced function uses the value of an argument in Python")
+
+            __bool__ = __float__ = __int__ = __index__ = __complex__ = _abort
+            item = tolist = numpy = __array__ = _abort
+
+        _PROBE_CLS.append(ProbeTensor)
+    return t.as_subclass(_PROBE_CLS[0])
+
+
+def _plain(t):
+    import torch
+
+    return t.as_subclass(torch.Tensor) if _PROBE_CLS and isinstance(t, _PROBE_CLS[0]) else t
+
+
 class TracedVag:
     def __init__(self, backend, slow: Callable[..., Any], f: Callable[..., Any], argnums, has_aux: bool,
                  vectorized_argnums=None, value_only: bool = False):
@@ -81,7 +109,7 @@ class TracedVag:
                     shape = shape[1:]
                 nel = int(np.prod(shape)) if shape else 1
                 vals = (torch.arange(off, off + nel, dtype=torch.float64) * mult + add).reshape(shape)
-                out.append(vals)
+                out.append(_probe_tensor(vals))
                 spans.append((i, off, nel, shape))
                 off += nel
             else:
@@ -116,7 +144,7 @@ class TracedVag:
                     if torch.is_tensor(v):
                         if v.numel() != 1:
                             return False
-                        pv.append(float(v.detach().reshape(()).to(torch.float64).cpu()))
+                        pv.append(float(_plain(v).detach().reshape(()).to(torch.float64).cpu()))
                     else:
                         pv.append(float(np.real(v)))
                 runs.append((c, out.form, None, pv, spans, total))
@@ -139,7 +167,7 @@ class TracedVag:
                 if torch.is_tensor(v):
                     if v.numel() != 1:
                         return False
-                    pv.append(float(v.detach().reshape(()).to(torch.float64).cpu()))
+                    pv.append(float(_plain(v).detach().reshape(()).to(torch.float64).cpu()))
                 else:
                     pv.append(float(np.real(v)))
             runs.append((c, terms, float(np.real(out.const)), pv, spans, total))

@@ -554,3 +554,46 @@ def test_tensor_valued_axis_angles_of_r_cr_cu(tcd):
     tol = 2e-5 if tc.dtypestr == "complex64" else 1e-7
     np.testing.assert_allclose(float(tc.backend.numpy(v)), ref(p0), atol=tol)
     np.testing.assert_allclose(tc.backend.numpy(g), fd, atol=10 * tol)
+
+
+def test_jit_does_not_freeze_python_that_depends_on_argument_values(tcd):
+    """``backend.jit`` replaces a traceable function by a fixed pipeline after probing it with index-valued arguments.
+    A function whose Python branches on the VALUE of an argument must not be frozen on the probe's branch: using the
+    value in Python aborts the probe (as a concretisation error would under the reference's JAX jit) and the function
+    keeps the plain path, so every call follows its own branch."""
+    tc = tcd
+    n = 6
+
+    def f(p):
+        c = tc.Circuit(n)
+        for i in range(n):
+            c.rx(i, theta=p[i])
+        if float(p[0]) > 1.0:          # Python control flow on an argument value
+            c.x(0)
+        return tc.backend.real(c.expectation_ps(z=[0]) + 0.5 * c.expectation_ps(z=[1], x=[2]))
+
+    fj = tc.backend.jit(tc.backend.value_and_grad(f))
+    plain = tc.backend.value_and_grad(f)
+    rdt = np.float32 if tc.rdtypestr == "float32" else np.float64
+    for p0 in (0.4, 1.7, 0.9, 2.5):
+        p = np.linspace(0.3, 1.3, n).astype(rdt)
+        p[0] = p0
+        pt = tc.backend.convert_to_tensor(p)
+        for _ in range(2):
+            v, g = fj(pt)
+            vr, gr = plain(pt)
+            np.testing.assert_allclose(float(v), float(vr), atol=1e-6)
+            np.testing.assert_allclose(tc.backend.numpy(g), tc.backend.numpy(gr), atol=1e-6)
+    assert fj.stats["fast"] == 0          # never traced
+    # the same function without the branch is traced
+    def f2(p):
+        c = tc.Circuit(n)
+        for i in range(n):
+            c.rx(i, theta=p[i])
+        return tc.backend.real(c.expectation_ps(z=[0]) + 0.5 * c.expectation_ps(z=[1], x=[2]))
+
+    fj2 = tc.backend.jit(tc.backend.value_and_grad(f2))
+    for _ in range(4):
+        v, g = fj2(pt)
+    assert fj2.stats["fast"] >= 1
+    np.testing.assert_allclose(float(v), float(tc.backend.value_and_grad(f2)(pt)[0]), atol=1e-6)
