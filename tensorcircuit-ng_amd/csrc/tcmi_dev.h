@@ -169,5 +169,57 @@ __device__ __forceinline__ float wave_sum_uniform(float v) {
 }
 __device__ __forceinline__ double wave_sum_uniform(double v) { return wave_sum<double>(v); }
 
+// Two / four wave-wide sums at once.  The first DPP steps fold the values into ONE register (lane % 2 resp. lane % 4
+// selects the quantity), the rest of the butterfly keeps that residue (row_ror 4 / 8, then the gfx950 row swaps
+// v_permlane16_swap / v_permlane32_swap), so four sums cost 21 VALU instructions instead of 4 x 13.
+__device__ __forceinline__ float swap_add16(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap_add32(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float fold2(float a, float b, bool odd) {  // even lanes: a pair sum, odd lanes: b pair sum
+  const float keep = odd ? b : a, give = odd ? a : b;
+  return keep + dpp_get<0xB1>(give);
+}
+__device__ __forceinline__ void wave_sum2_uniform(float& a, float& b, int lane) {
+  float r = fold2(a, b, lane & 1);
+  r = dpp_add_c<0x4E, 0xf>(r);   // quad_perm [2,3,0,1]: keeps the lane parity
+  r = dpp_add_c<0x124, 0xf>(r);  // row_ror 4
+  r = dpp_add_c<0x128, 0xf>(r);  // row_ror 8
+  r = swap_add32(swap_add16(r));
+  a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 0));
+  b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 1));
+}
+__device__ __forceinline__ void wave_sum4_uniform(float& a, float& b, float& c, float& d, int lane) {
+  const float r0 = fold2(a, b, lane & 1), r1 = fold2(c, d, lane & 1);
+  const bool hi = lane & 2;
+  const float keep = hi ? r1 : r0, give = hi ? r0 : r1;
+  float r = keep + dpp_get<0x4E>(give);  // lane % 4: 0 a, 1 b, 2 c, 3 d (sums over the quad)
+  r = dpp_add_c<0x124, 0xf>(r);
+  r = dpp_add_c<0x128, 0xf>(r);
+  r = swap_add32(swap_add16(r));
+  a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 0));
+  b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 1));
+  c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 2));
+  d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 3));
+}
+__device__ __forceinline__ void wave_sum2_uniform(double& a, double& b, int) {
+  a = wave_sum<double>(a);
+  b = wave_sum<double>(b);
+}
+__device__ __forceinline__ void wave_sum4_uniform(double& a, double& b, double& c, double& d, int) {
+  a = wave_sum<double>(a);
+  b = wave_sum<double>(b);
+  c = wave_sum<double>(c);
+  d = wave_sum<double>(d);
+}
+
 }  // namespace tcmi
 #endif

@@ -27,6 +27,11 @@ namespace tcmi {
 #endif
 constexpr int SVD_CTL_WORDS = 64;     // [0] barrier counter, [1] error flag, [2..] rotations per sweep
 constexpr int SVD_MAX_SWEEPS = 60;
+// Stopping rule: every pair whose cosine exceeds the tolerance is rotated, but a sweep only counts as "not converged"
+// when one of its rotations had a cosine above SVD_STOP_SCALE x the tolerance.  A sweep of nothing but smaller
+// rotations leaves second-order cosines behind (quadratic convergence), so the extra sweep that would only confirm
+// "no rotation needed" (1 of 11-12 at 256 x 256) is not run.
+constexpr double SVD_STOP_SCALE = 4.0;
 constexpr unsigned SPIN_LIMIT = 1u << 21;
 
 template <typename F>
@@ -220,7 +225,7 @@ __device__ __forceinline__ int rotate_pair(typename Cx<F>::type* x, typename Cx<
     x[col] = nx;
     y[col] = ny;
   }
-  return 1;
+  return g2 > (F)(SVD_STOP_SCALE * SVD_STOP_SCALE) * tol2 * al * be ? 1 : 0;
 }
 
 // Cross rounds with the wave's own row held in registers (row length ld <= 64 * E): the partner row is
@@ -270,7 +275,145 @@ __device__ __forceinline__ int rotate_pair_reg(typename Cx<F>::type (&x)[E], typ
       yrow[col] = ny;
     }
   }
-  return 1;
+  return g2 > (F)(SVD_STOP_SCALE * SVD_STOP_SCALE) * tol2 * al * be ? 1 : 0;
+}
+
+// The same rounds for rows of exactly 64 * E elements of which the first 64 * EQ are the W part:
+// * no bounds tests, so the E partner loads are all in flight at once (with the tests each ds_read waited for the one
+//   before: 8 serial LDS round trips per round);
+// * the squared row norms are measured once per chip-wide round and then follow the rotations analytically
+//   (|x'|^2 = |x|^2 - t |gamma|, |y'|^2 = |y|^2 + t |gamma|, as LAPACK's xGESVJ does between its refreshes): a round
+//   only measures gamma, two fused wave sums instead of four;
+// the rounds of a workgroup are VALU-issue bound (8 waves x ~230 instructions on 4 SIMDs), so instructions are time.
+template <typename F>
+__device__ __forceinline__ void jacobi_rotation_t(F al, F be, F gr, F gi, F& c, F& sn, F& pr, F& pi, F& tg) {
+  jacobi_rotation<F>(al, be, gr, gi, c, sn, pr, pi);
+  tg = (sn / c) * sqrt(gr * gr + gi * gi);
+}
+template <>
+__device__ __forceinline__ void jacobi_rotation_t<float>(float al, float be, float gr, float gi, float& c, float& sn,
+                                                         float& pr, float& pi, float& tg) {
+  const float g2 = gr * gr + gi * gi;
+  const float ia = __builtin_amdgcn_rsqf(g2);
+  const float zeta = (be - al) * 0.5f * ia;
+  const float az = fabsf(zeta);
+  const float t = __builtin_copysignf(__builtin_amdgcn_rcpf(az + __builtin_amdgcn_sqrtf(1.0f + zeta * zeta)), zeta);
+  c = __builtin_amdgcn_rsqf(1.0f + t * t);
+  sn = c * t;
+  pr = gr * ia;
+  pi = gi * ia;
+  tg = t * g2 * ia;  // t |gamma|
+}
+
+#ifdef TCMI_SVD_TIMING
+#define TCMI_TI(k)                                                 \
+  {                                                                \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+    tin[k] += now_ - tin[7];                                       \
+    tin[7] = now_;                                                 \
+  }
+#define TCMI_TI_ARG , unsigned long long* tin
+#define TCMI_TI_PASS , tin
+#else
+#define TCMI_TI(k)
+#define TCMI_TI_ARG
+#define TCMI_TI_PASS
+#endif
+template <typename F, int E, int EQ>
+__device__ __forceinline__ int rotate_pair_reg_exact(typename Cx<F>::type (&x)[E], typename Cx<F>::type* yrow, F& al,
+                                                     F* be_slot, int lane, F tol2 TCMI_TI_ARG) {
+  using Ct = typename Cx<F>::type;
+  Ct y[E];
+  TCMI_TI(6)
+#pragma unroll
+  for (int e = 0; e < E; ++e) y[e] = yrow[lane + 64 * e];
+  const F be = *be_slot;
+  TCMI_TI(0)
+  F gr = 0, gi = 0;
+#pragma unroll
+  for (int e = 0; e < EQ; ++e) {
+    gr = fma_<F>(x[e].x, y[e].x, fma_<F>(x[e].y, y[e].y, gr));
+    gi = fma_<F>(x[e].y, y[e].x, fma_<F>(-x[e].x, y[e].y, gi));
+  }
+  TCMI_TI(1)
+  wave_sum2_uniform(gr, gi, lane);
+  const F g2 = gr * gr + gi * gi;
+  TCMI_TI(2)
+  if (!(g2 > tol2 * al * be && g2 > Eps<F>::tiny)) return 0;
+  F c, sn, pr, pi, tg;
+  const int big = g2 > (F)(SVD_STOP_SCALE * SVD_STOP_SCALE) * tol2 * al * be ? 1 : 0;
+  jacobi_rotation_t<F>(al, be, gr, gi, c, sn, pr, pi, tg);
+#ifdef TCMI_SVD_TIMING
+  asm volatile("" : "+v"(c), "+v"(sn), "+v"(pr), "+v"(pi));
+#endif
+  TCMI_TI(3)
+  al = al - tg > 0 ? al - tg : 0;
+  if (lane == 0) *be_slot = be + tg > 0 ? be + tg : 0;
+  if constexpr (sizeof(F) == 4) {  // packed f32: (re, im) pairs, 6 v_pk instructions per element instead of 12
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 c2 = {c, c}, s2 = {sn, sn}, pr2 = {pr, pr}, pi2 = {-pi, pi};
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const f2 yv = {y[e].x, y[e].y}, ys = {y[e].y, y[e].x}, xv = {x[e].x, x[e].y};
+      const f2 t = __builtin_elementwise_fma(pr2, yv, pi2 * ys);
+      const f2 nx = __builtin_elementwise_fma(c2, xv, -(s2 * t));
+      const f2 ny = __builtin_elementwise_fma(s2, xv, c2 * t);
+      x[e].x = nx.x;
+      x[e].y = nx.y;
+      Ct o;
+      o.x = ny.x;
+      o.y = ny.y;
+      yrow[lane + 64 * e] = o;
+    }
+    TCMI_TI(4)
+    return big;
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const F tr = pr * y[e].x - pi * y[e].y, ti = pr * y[e].y + pi * y[e].x;
+    Ct nx, ny;
+    nx.x = c * x[e].x - sn * tr;
+    nx.y = c * x[e].y - sn * ti;
+    ny.x = sn * x[e].x + c * tr;
+    ny.y = sn * x[e].y + c * ti;
+    x[e] = nx;
+    yrow[lane + 64 * e] = ny;
+  }
+  return big;
+}
+
+template <typename F, int B, int E, int EQ>
+__device__ __forceinline__ int cross_rounds_exact(typename Cx<F>::type* L, F* nrm, int wave, int lane,
+                                                  F tol2 TCMI_TI_ARG) {
+  using Ct = typename Cx<F>::type;
+  constexpr int ld = 64 * E;
+  Ct* xrow = L + wave * ld;
+  const Ct* prow = L + (B + wave) * ld;
+  Ct xr[E];
+  int rot = 0;
+#pragma unroll
+  for (int e = 0; e < E; ++e) xr[e] = xrow[lane + 64 * e];
+  F al = 0, b0 = 0;  // squared norms of the own row and of partner row `wave`
+#pragma unroll
+  for (int e = 0; e < EQ; ++e) {
+    const Ct pv = prow[lane + 64 * e];
+    al = fma_<F>(xr[e].x, xr[e].x, fma_<F>(xr[e].y, xr[e].y, al));
+    b0 = fma_<F>(pv.x, pv.x, fma_<F>(pv.y, pv.y, b0));
+  }
+  wave_sum2_uniform(al, b0, lane);
+  if (lane == 0) nrm[wave] = b0;
+  __syncthreads();
+  for (int k = 0; k < B; ++k) {
+    const int j = (wave + k) % B;
+    rot += rotate_pair_reg_exact<F, E, EQ>(xr, L + (B + j) * ld, al, nrm + j, lane, tol2 TCMI_TI_PASS);
+    __syncthreads();
+    TCMI_TI(5)
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) xrow[lane + 64 * e] = xr[e];
+  __syncthreads();
+  return rot;
 }
 
 // Blocked one-sided Jacobi.  The P2 (padded) rows are cut into NB = P2 / B blocks of B rows; workgroup g
@@ -291,6 +434,18 @@ __device__ __forceinline__ void svd_poison(F* s, int p, int* keep_out, F* tw2_ou
     if (tw2_out) tw2_out[bi] = nan;
   }
 }
+// Probe builds (-DTCMI_SVD_TIMING, scripts/gpu_svd_phases.py): workgroup 0 accumulates the shader-clock time of each
+// phase of a chip-wide round into control words 48..53 (row_in, intra rounds, cross rounds, row_out, barrier, total).
+#ifdef TCMI_SVD_TIMING
+#define TCMI_T(k)                                                                  \
+  {                                                                                \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                  \
+    tacc[k] += now_ - tlast;                                                       \
+    tlast = now_;                                                                  \
+  }
+#else
+#define TCMI_T(k)
+#endif
 #define TCMI_SVD_SYNC()                                    \
   if (!grid_barrier(ctl, nwg, epoch, &s_dead)) {           \
     svd_poison<F>(s, p, keep_out, tw2_out, b + batch0);    \
@@ -323,6 +478,7 @@ __global__ __launch_bounds__(64 * B) void svd_block_kernel(
   unsigned* ctl = ctl_base + (long long)b * SVD_CTL_WORDS;
   unsigned epoch = 0;
   unsigned& s_dead = *reinterpret_cast<unsigned*>(smem_raw + 2ll * B * ld * (long long)sizeof(Ct));
+  F* nrm = reinterpret_cast<F*>(smem_raw + 2ll * B * ld * (long long)sizeof(Ct) + 16);  // [B] tracked row norms
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
@@ -347,6 +503,11 @@ __global__ __launch_bounds__(64 * B) void svd_block_kernel(
 
   const F tol2 = Eps<F>::v * Eps<F>::v * (F)q * (F)(TCMI_SVD_TOL_SCALE * TCMI_SVD_TOL_SCALE);
   const int M = NB - 1;
+#ifdef TCMI_SVD_TIMING
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+  unsigned long long tin[8] = {0, 0, 0, 0, 0, 0, 0, tlast};  // inside a cross round: load, gram, sum, rotation, apply, barrier
+  const unsigned long long tstart = tlast;
+#endif
   if (max_sweeps > SVD_MAX_SWEEPS) max_sweeps = SVD_MAX_SWEEPS;
   for (int sweep = 0; sweep < max_sweeps; ++sweep) {
     int rot = 0;
@@ -363,6 +524,7 @@ __global__ __launch_bounds__(64 * B) void svd_block_kernel(
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
+      TCMI_T(0)
       if (R == 0 && B > 1) {  // intra-block pairs, both blocks at once (B/2 waves each)
         constexpr int H = B > 1 ? B / 2 : 1;
         const int blk = wave / H, idx = wave % H, Mb = B - 1;
@@ -373,7 +535,12 @@ __global__ __launch_bounds__(64 * B) void svd_block_kernel(
           __syncthreads();
         }
       }
-      if (ld <= 512) {  // own row in registers for the B cross rounds
+      TCMI_T(1)
+      if (q == P2 && (q == 256 || q == 128 || q == 64)) {  // square, rows of whole 64-element chunks
+        if (q == 256) rot += cross_rounds_exact<F, B, 8, 4>(L, nrm, wave, lane, tol2 TCMI_TI_PASS);
+        else if (q == 128) rot += cross_rounds_exact<F, B, 4, 2>(L, nrm, wave, lane, tol2 TCMI_TI_PASS);
+        else rot += cross_rounds_exact<F, B, 2, 1>(L, nrm, wave, lane, tol2 TCMI_TI_PASS);
+      } else if (ld <= 512) {  // own row in registers for the B cross rounds
         constexpr int E = 8;
         Ct* xrow = L + (long long)wave * ld;
         Ct xr[E];
@@ -403,6 +570,7 @@ __global__ __launch_bounds__(64 * B) void svd_block_kernel(
           __syncthreads();
         }
       }
+      TCMI_T(2)
       for (int h = 0; h < 2; ++h) {
         const int lr = h * B + wave;
         const long long gr = (long long)(h == 0 ? bA : bB) * B + wave;
@@ -411,11 +579,20 @@ __global__ __launch_bounds__(64 * B) void svd_block_kernel(
         row_out<Ct>(Y + gr * P2, src + q, P2, lane);
       }
       if (R == M - 1 && rot > 0 && lane == 0) __hip_atomic_fetch_add((gu32*)&ctl[2 + sweep], 1u, TCMI_RLX);
+      TCMI_T(3)
       TCMI_SVD_SYNC();
+      TCMI_T(4)
     }
     if (__hip_atomic_load((gu32*)&ctl[2 + sweep], TCMI_RLX) == 0) break;
   }
 
+#ifdef TCMI_SVD_TIMING
+  if (g == 0 && threadIdx.x == 0) {
+    tacc[5] = __builtin_amdgcn_s_memtime() - tstart;
+    for (int k = 0; k < 6; ++k) ctl[48 + k] = (unsigned)(tacc[k] >> 4);
+    for (int k = 0; k < 7; ++k) ctl[54 + k] = (unsigned)(tin[k] >> 4);
+  }
+#endif
   const int gw = g * B + wave;  // P2 / 2 waves in total, two rows each
   // squared row norms of W and Y: sigma_i = |W_i| / |Y_i| (W = Y a holds to rounding whatever the
   // accumulated non-unitarity of the rotations; dividing it out removes the common drift)
@@ -924,7 +1101,7 @@ static void launch_svd(const SvdGeom& gm, int nb, hipStream_t st, const void* a,
                        void* vh, int* keep, void* tw2, int p, int q, int kmax, void* work, unsigned* ctl,
                        int max_sweeps, int max_sv, double max_err, int relative, int absorb, int batch0) {
   using Ct = typename Cx<F>::type;
-  hipLaunchKernelGGL((svd_block_kernel<F, B>), dim3(gm.wgs, nb, 1), dim3(64 * B), (size_t)gm.lds_bytes + 16, st,
+  hipLaunchKernelGGL((svd_block_kernel<F, B>), dim3(gm.wgs, nb, 1), dim3(64 * B), (size_t)gm.lds_bytes + 16 + 128, st,
                      reinterpret_cast<const Ct*>(a), a_stride, reinterpret_cast<Ct*>(u), reinterpret_cast<F*>(s),
                      reinterpret_cast<Ct*>(vh), keep, reinterpret_cast<F*>(tw2), p, q, kmax, gm.P2,
                      reinterpret_cast<Ct*>(work), gm.work_elems, ctl, max_sweeps, max_sv, (F)max_err, relative,
