@@ -293,16 +293,19 @@ __device__ __forceinline__ void jacobi_rotation_t(F al, F be, F gr, F gi, F& c, 
 template <>
 __device__ __forceinline__ void jacobi_rotation_t<float>(float al, float be, float gr, float gi, float& c, float& sn,
                                                          float& pr, float& pi, float& tg) {
+  // half-angle form: two dependent transcendentals on the critical path (rsq, rsq) instead of four (rsq, sqrt, rcp, rsq)
   const float g2 = gr * gr + gi * gi;
   const float ia = __builtin_amdgcn_rsqf(g2);
-  const float zeta = (be - al) * 0.5f * ia;
-  const float az = fabsf(zeta);
-  const float t = __builtin_copysignf(__builtin_amdgcn_rcpf(az + __builtin_amdgcn_sqrtf(1.0f + zeta * zeta)), zeta);
-  c = __builtin_amdgcn_rsqf(1.0f + t * t);
-  sn = c * t;
+  const float d = 0.5f * (be - al), ad = fabsf(d);
+  const float h2 = fmaf(d, d, g2);                 // h^2 = d^2 + |gamma|^2
+  const float ih = __builtin_amdgcn_rsqf(h2);
+  const float u = fmaf(0.5f * ad, ih, 0.5f);       // c^2 = (h + |d|) / 2h
+  const float ic = __builtin_amdgcn_rsqf(u);
+  c = u * ic;
+  sn = __builtin_copysignf(0.5f * (g2 * ia) * ih * ic, d);
   pr = gr * ia;
   pi = gi * ia;
-  tg = t * g2 * ia;  // t |gamma|
+  tg = __builtin_copysignf(g2 * __builtin_amdgcn_rcpf(ad + h2 * ih), d);  // t |gamma| = |gamma|^2 / (|d| + h)
 }
 
 #ifdef TCMI_SVD_TIMING
