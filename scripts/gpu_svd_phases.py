@@ -32,3 +32,5 @@ nround = sweeps * (m // 8 - 1) * 8
 print("inside a cross round (wave 0, cycles per round; the probes add s_waitcnt + s_memtime each):")
 for k, v in zip(["load", "gram", "wave sums", "rotation", "apply+store", "barrier", "other"], inner):
     print(f"  {k:12s} {v / max(nround, 1):8.1f}")
+hw = w[40:48].astype(np.int64)
+print("HW_ID of the 8 waves of workgroup 0: " + ", ".join(f"wave {k}: simd {int(v >> 4) & 3} cu {int(v >> 8) & 15} se {int(v >> 13) & 7}" for k, v in enumerate(hw)))

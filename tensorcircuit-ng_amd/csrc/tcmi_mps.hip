@@ -590,6 +590,7 @@ __global__ __launch_bounds__(64 * B) void svd_block_kernel(
   }
 
 #ifdef TCMI_SVD_TIMING
+  if (g == 0 && lane == 0 && wave < 8) ctl[40 + wave] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
   if (g == 0 && threadIdx.x == 0) {
     tacc[5] = __builtin_amdgcn_s_memtime() - tstart;
     for (int k = 0; k < 6; ++k) ctl[48 + k] = (unsigned)(tacc[k] >> 4);
