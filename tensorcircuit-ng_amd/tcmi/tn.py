@@ -1395,6 +1395,7 @@ def _tensordot_bits(a, b, axes_a, axes_b):
 
 SCATTERED_MIN_RANK = 16    # big operand: at least 2^16 elements
 SCATTERED_MAX_SMALL = 4096  # small operand: at most this many elements (it lives in LDS)
+SCATTERED_MAX_NK = int(os.environ.get("TCMI_TN_SCAT_MAXK", "8"))   # more contracted axes: the MFMA bits kernel
 
 
 def _tensordot_scattered(a, b, axes_a, axes_b, fa, fb):
@@ -1404,7 +1405,7 @@ def _tensordot_scattered(a, b, axes_a, axes_b, fa, fb):
     import torch
 
     nk = len(axes_a)
-    if nk < 1 or nk > 8:
+    if nk < 1 or nk > SCATTERED_MAX_NK:
         return None
     big_first = a.numel() >= b.numel()
     big, small = (a, b) if big_first else (b, a)
