@@ -129,3 +129,53 @@ def test_config5_full_size_mps_sweep_properties():
     assert 0 < f128[0] < 1
     # truncation only removes weight: the norm after the sweep is the start norm times sqrt of the kept weights
     assert f128[2] <= f128[1] * (1 + 1e-9)
+
+
+def test_config4_full_size_amplitude_against_statevector():
+    """SURVEY 8d config 4 at full size (the bench workload: 32 qubits on a 4x8 grid, depth 16, 448 Haar-random
+    two-qubit gates, complex64): the amplitude <0^32|C|0^32> from DistributedContractor (tree search, slicing to 2^27
+    elements, 8 slices summed) equals element 0 of the state vector that the plan executor computes for the same
+    circuit (34 GB of state, an independent algorithm: tile passes instead of a sliced contraction tree), and the
+    state is normalised.  The dense oracle cannot reach n = 32; both routes are pinned to it at n <= 20
+    (test_gpu_tn.py::test_config4_grid_rqc_amplitude_sliced, test_gpu_state.py)."""
+    import torch
+    import tcmi as tc
+
+    tc.set_backend("hip"); tc.set_dtype("complex64")
+    rows, cols, depth = 4, 8, 16
+    n = rows * cols
+    gates = [tc.gates.random_two_qubit_gate(7000 + i).tensor for i in range(depth * rows * cols)]
+    q = lambda r, c: r * cols + c
+
+    def build():
+        c = tc.Circuit(n)
+        k = 0
+        for d in range(depth):
+            pat = d % 4
+            if pat in (0, 1):
+                pairs = [(q(r, cc), q(r, cc + 1)) for r in range(rows) for cc in range(pat, cols - 1, 2)]
+            else:
+                pairs = [(q(r, cc), q(r + 1, cc)) for r in range(pat - 2, rows - 1, 2) for cc in range(cols)]
+            for a, b in pairs:
+                c.any(a, b, unitary=gates[k])
+                k += 1
+        return c
+
+    dc = tc.experimental.DistributedContractor(lambda _: build().amplitude_before("0" * n), None,
+                                               cotengra_options={"slicing_opts": {"target_size": 2**27}, "max_repeats": 128})
+    assert dc.tree.nslices >= 2 and dc.tree.max_size() <= 2**27
+    v = complex(dc.value(None, op=lambda x: x))
+    del dc
+    torch.cuda.empty_cache()
+    psi = build().wavefunction()
+    assert psi.numel() == 2**n
+    a0 = complex(psi[0])
+    # norm in float64 chunks (a float32 sum of 2^32 terms would lose the digits being checked)
+    nrm = 0.0
+    for ch in psi.reshape(64, -1):
+        nrm += float((ch.real.double() ** 2 + ch.imag.double() ** 2).sum())
+    del psi
+    torch.cuda.empty_cache()
+    assert abs(nrm - 1.0) < 2e-4, nrm
+    assert abs(v) > 1e-6                                     # a typical amplitude is 2^-16
+    assert abs(v - a0) < 2e-4 * abs(a0), (v, a0)
