@@ -302,6 +302,39 @@ def mps_leg(tc, torch, args):
     split["launches_per_bond"] = sum(v["launches"] for v in ev.values()) / nbonds
     if not all(bool(torch.isfinite(x.abs()).all()) for x in m.get_tensors()):
         raise FloatingPointError("non-finite MPS tensor after the TEBD sweeps")
+    # Independent chains from the Python layer: backend.vmap over C chains that start from the same saturated MPS and
+    # apply their own random SU(4) gates.  GEMMs, QRs and SVDs of the C chains go out as one batched launch each (the
+    # batch argument of the ABI: 16 workgroups per 256 x 256 SVD, so 16 chains fill the chip).
+    chains = None
+    C = int(args.mps_chains)
+    if C > 1:
+        start = [x.clone() for x in m.get_tensors()]
+        gs = torch.stack([torch.stack([torch.as_tensor(
+            unitary_group.rvs(4, random_state=9000 + 100 * c + i).reshape(2, 2, 2, 2).astype(np.complex64))
+            for i in range(n - 1)]) for c in range(C)]).cuda()
+
+        def chain(g):
+            mc = tc.MPSCircuit(n, tensors=start, center_position=0, split=tc.cons.split_rules(max_singular_values=chi))
+            for i in range(n - 1):
+                mc.apply(tc.gates.Gate(g[i]), i, i + 1)
+            last = mc.get_tensors()[-1]
+            return tc.backend.real(tc.backend.sum(last * tc.backend.conj(last)))
+
+        vchain = tc.backend.vmap(chain)
+        nrm = vchain(gs)                      # staging run
+        torch.cuda.synchronize()
+        tt = []
+        for _ in range(max(1, args.mps_sweeps)):
+            t0 = time.perf_counter()
+            nrm = vchain(gs)
+            torch.cuda.synchronize()
+            tt.append(time.perf_counter() - t0)
+        tb = sum(tt) / len(tt)
+        if not bool(torch.isfinite(nrm).all()):
+            raise FloatingPointError("non-finite norm after the batched TEBD sweeps")
+        chains = {"chains": C, "api": "backend.vmap over chains (one batched GEMM / QR / SVD launch per bond)",
+                  "chain_sweeps_per_s": C / tb, "us_per_bond_per_chain": tb / (n - 1) / C * 1e6,
+                  "us_per_bond_all_chains": tb / (n - 1) * 1e6, "last_tensor_norm2": [float(x) for x in nrm[:4]]}
     return {
         "workload": f"MPSCircuit n={n} chi={chi} TEBD sweep of {n - 1} adjacent random SU(4) gates, complex64 "
                     f"(SURVEY 8d config 5)",
@@ -310,6 +343,7 @@ def mps_leg(tc, torch, args):
         "fidelity_estimate": float(m._fidelity),
         # neither HBM- nor MFMA-bound: latency of dependent launches; kernel time per bond by kind
         "roofline": {"bound": "latency", "kernel_us_per_bond": split},
+        "batched_chains": chains,
     }
 
 
@@ -432,6 +466,7 @@ def main():
     ap.add_argument("--mps-qubits", type=int, default=64, help="MPS TEBD leg (config 5): qubits; 0 disables the leg")
     ap.add_argument("--mps-chi", type=int, default=128)
     ap.add_argument("--mps-sweeps", type=int, default=2)
+    ap.add_argument("--mps-chains", type=int, default=16, help="config 5: independent chains through backend.vmap (0/1 disables)")
     ap.add_argument("--rqc-depth", type=int, default=16, help="config 4 leg (32-qubit RQC amplitude): depth; 0 disables")
     ap.add_argument("--rqc-log2-target", type=int, default=27)
     ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph replay measurement")

@@ -143,26 +143,29 @@ def _gate_mix_raw(t, gate, L, R):
 
 
 def _svd_rows(mat, kmax, max_sv, max_err, relative, absorb):
-    """SVD of a [m, n] matrix with m <= n.  Returns u [m,kmax], s [m], vh [kmax,n], keep (device int32
-    [1]), tw2 (device real [1])."""
+    """SVD of a [m, n] matrix with m <= n, or of a stack [B, m, n] of them in ONE call (the ``batch`` argument of the
+    ABI: the matrices of a launch run side by side, 16 workgroups each at 256 x 256, so up to 16 chains cost the time
+    of one).  Returns u [.., m,kmax], s [.., m], vh [.., kmax,n], keep (device int32 [B]), tw2 (device real [B])."""
     import torch
 
     mat = mat.resolve_conj().contiguous()
-    m, n = mat.shape
+    lead = tuple(mat.shape[:-2])
+    B = int(lead[0]) if lead else 1
+    m, n = mat.shape[-2:]
     rdt = torch.float32 if mat.dtype == torch.complex64 else torch.float64
     code = _code(mat)
-    nbytes = _lib.lib().tcmi_svd_work_bytes(m, n, 1, code)
+    nbytes = _lib.lib().tcmi_svd_work_bytes(m, n, B, code)
     if nbytes < 0:
         raise _lib.TcmiError("tcmi_svd_work_bytes: bad arguments")
     work = _workspace("svd", nbytes, mat.device)
-    u = torch.empty((m, kmax), dtype=mat.dtype, device=mat.device)
-    s = torch.empty((m,), dtype=rdt, device=mat.device)
-    vh = torch.empty((kmax, n), dtype=mat.dtype, device=mat.device)
-    keep = torch.empty((1,), dtype=torch.int32, device=mat.device)
-    tw2 = torch.empty((1,), dtype=rdt, device=mat.device)
+    u = torch.empty(lead + (m, kmax), dtype=mat.dtype, device=mat.device)
+    s = torch.empty(lead + (m,), dtype=rdt, device=mat.device)
+    vh = torch.empty(lead + (kmax, n), dtype=mat.dtype, device=mat.device)
+    keep = torch.empty((B,), dtype=torch.int32, device=mat.device)
+    tw2 = torch.empty((B,), dtype=rdt, device=mat.device)
     with _timed("mps_svd", 1, 0.0):
         _lib.check(_lib.lib().tcmi_svd_trunc_batched(
-            mat.data_ptr(), u.data_ptr(), s.data_ptr(), vh.data_ptr(), keep.data_ptr(), tw2.data_ptr(), m, n, kmax, 1,
+            mat.data_ptr(), u.data_ptr(), s.data_ptr(), vh.data_ptr(), keep.data_ptr(), tw2.data_ptr(), m, n, kmax, B,
             int(max_sv or 0), float(-1.0 if max_err is None else max_err), int(bool(relative)), absorb, 0,
             work.data_ptr(), work.numel(), code, _stream(mat)), "tcmi_svd_trunc_batched")
     return u, s, vh, keep, tw2
@@ -226,15 +229,17 @@ def _qr_raw(mat):
     import torch
 
     mat = mat.resolve_conj().contiguous()
-    m, n = mat.shape
+    lead = tuple(mat.shape[:-2])                       # [B] for a stack of matrices: one batched launch
+    B = int(lead[0]) if lead else 1
+    m, n = mat.shape[-2:]
     K = min(m, n)
     code = _code(mat)
-    nbytes = _lib.lib().tcmi_qr_work_bytes(m, n, 1, code)
+    nbytes = _lib.lib().tcmi_qr_work_bytes(m, n, B, code)
     work = _workspace("qr", nbytes, mat.device)
-    q = torch.empty((m, K), dtype=mat.dtype, device=mat.device)
-    r = torch.empty((K, n), dtype=mat.dtype, device=mat.device)
+    q = torch.empty(lead + (m, K), dtype=mat.dtype, device=mat.device)
+    r = torch.empty(lead + (K, n), dtype=mat.dtype, device=mat.device)
     with _timed("mps_qr", 1, 0.0):
-        _lib.check(_lib.lib().tcmi_qr_batched(mat.data_ptr(), q.data_ptr(), r.data_ptr(), m, n, 1, work.data_ptr(),
+        _lib.check(_lib.lib().tcmi_qr_batched(mat.data_ptr(), q.data_ptr(), r.data_ptr(), m, n, B, work.data_ptr(),
                                               work.numel(), code, _stream(mat)), "tcmi_qr_batched")
     return q, r
 
@@ -257,12 +262,13 @@ _QR_EPS = 1e-8
 
 
 def _svd_full_raw(mat):
-    m, n = mat.shape
+    """thin SVD of [m, n] or of a stack [B, m, n] (one batched launch)"""
+    m, n = mat.shape[-2:]
     if m <= n:
         u, s, vh, _, _ = _svd_rows(mat, m, None, None, False, 0)
         return u, s, vh
-    u2, s, vh2, _, _ = _svd_rows(mat.t(), n, None, None, False, 0)
-    return vh2.t().contiguous(), s, u2.t().contiguous()
+    u2, s, vh2, _, _ = _svd_rows(mat.transpose(-1, -2), n, None, None, False, 0)
+    return vh2.transpose(-1, -2).contiguous(), s, u2.transpose(-1, -2).contiguous()
 
 
 def _svd_backward(u, s, vh, gu, gs, gvh):
@@ -270,25 +276,25 @@ def _svd_backward(u, s, vh, gu, gs, gvh):
     the diagonal, as in ``jax_ops.py:33-75``."""
     import torch
 
-    m, k = u.shape
-    n = vh.shape[1]
+    m, k = u.shape[-2:]                                # leading batch dimension allowed (stacked chains)
+    n = vh.shape[-1]
     cdt = u.dtype
     v, gv, uh = _h(vh), _h(gvh), _h(u)
     s2 = s * s
-    E = s2[None, :] - s2[:, None]                      # E_ij = s_j^2 - s_i^2, zero on the diagonal
+    E = s2[..., None, :] - s2[..., :, None]            # E_ij = s_j^2 - s_i^2, zero on the diagonal
     F = (E / (E * E + _SVD_EPS)).to(cdt)
     sinv = (s / (s * s + _SVD_EPS)).to(cdt)
     sc = s.to(cdt)
     GU = matmul(uh, gu)
     GV = matmul(vh, gv)
-    core = ((GU - _h(GU)) * F) * sc[None, :] + sc[:, None] * ((GV - _h(GV)) * F)
-    dg = gs.to(cdt) + 1j * (torch.diagonal(GU).imag.to(cdt) * sinv)
+    core = ((GU - _h(GU)) * F) * sc[..., None, :] + sc[..., :, None] * ((GV - _h(GV)) * F)
+    dg = gs.to(cdt) + 1j * (torch.diagonal(GU, dim1=-2, dim2=-1).imag.to(cdt) * sinv)
     core = core + torch.diag_embed(dg)
     ga = matmul(matmul(u, core), vh)
     if m > k:
-        ga = ga + matmul((gu - matmul(u, GU)) * sinv[None, :], vh)
+        ga = ga + matmul((gu - matmul(u, GU)) * sinv[..., None, :], vh)
     if n > k:
-        ga = ga + matmul(u * sinv[None, :], _h(gv - matmul(v, GV)))
+        ga = ga + matmul(u * sinv[..., None, :], _h(gv - matmul(v, GV)))
     return ga
 
 
@@ -371,8 +377,8 @@ def _ad():
     import torch
 
     def vmap_loop(fn, info, in_dims, *args):
-        """vmap rule shared by the three primitives: one call per batch element (the products of one element are
-        already GPU-sized in the MPS path; 2-D GEMMs use the batched launch instead)."""
+        """fallback vmap rule of the three primitives: one call per batch element (nested vmap; 2-D GEMMs and the
+        decompositions of 2-D matrices use their batched launches instead)."""
         outs = []
         for i in range(info.batch_size):
             outs.append(fn(*[a.select(d, i) if d is not None else a for a, d in zip(args, in_dims)]))
@@ -417,6 +423,8 @@ def _ad():
 
         @staticmethod
         def vmap(info, in_dims, mat):
+            if mat.dim() == 3:   # a batch of 2-D matrices (vmapped chains): ONE launch, the matrices side by side
+                return Svd.apply(mat.movedim(in_dims[0], 0)), (0, 0, 0)
             return vmap_loop(Svd.apply, info, in_dims, mat)
 
         @staticmethod
@@ -434,14 +442,16 @@ def _ad():
         @staticmethod
         def forward(mat):
             q, r = _qr_raw(mat)
-            d = torch.diagonal(r)
+            d = torch.diagonal(r, dim1=-2, dim2=-1)
             a = d.abs()
             ph = torch.where(a > 0, d / a.clamp_min(1e-300 if d.dtype == torch.complex128 else 1e-30),
                              torch.ones_like(d))
-            return q * ph[None, :], ph.conj()[:, None] * r
+            return q * ph[..., None, :], ph.conj()[..., :, None] * r
 
         @staticmethod
         def vmap(info, in_dims, mat):
+            if mat.dim() == 3:   # batched launch, as Svd
+                return Qr.apply(mat.movedim(in_dims[0], 0)), (0, 0)
             return vmap_loop(Qr.apply, info, in_dims, mat)
 
         @staticmethod
@@ -451,6 +461,8 @@ def _ad():
         @staticmethod
         def backward(ctx, gq, gr):
             q, r = ctx.saved_tensors
+            if q.dim() == 3:     # stacked chains: the rule is written for one matrix
+                return torch.stack([_qr_backward(q[i], r[i], gq[i], gr[i]) for i in range(q.shape[0])])
             return _qr_backward(q, r, gq, gr)
 
     # the decompositions' saved tensors are their own outputs: under torch.func they arrive wrapped, and

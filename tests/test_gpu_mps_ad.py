@@ -177,8 +177,10 @@ def test_vqe_like_energy_grad_complex64():
 
 
 def test_vmap_and_vvag_over_mps_circuits(c128):
-    """backend.vmap / vvag of an MPSCircuit energy through the real kernels (batched GEMM launch, per-element
-    SVD / QR)."""
+    """backend.vmap / vvag of an MPSCircuit energy through the real kernels: 2-D GEMMs, SVDs and QRs of the vmapped
+    chains each go out as ONE batched launch (the ``batch`` argument of the C ABI), so four chains issue as many SVD /
+    QR launches as one; value_and_grad of a sum over vmapped chains (grad outside vmap) takes the batched backward
+    rules."""
     def expec(params):
         mps = tc.MPSCircuit(N, split=dict(max_singular_values=D))
         mps.rx(0, theta=params[0])
@@ -191,8 +193,32 @@ def test_vmap_and_vvag_over_mps_circuits(c128):
     g0 = torch.Generator().manual_seed(0)
     ps = (torch.rand(4, 3, generator=g0, dtype=torch.float64) * 2.0 + 0.2).cuda()
     want = torch.stack([expec(p) for p in ps])
-    got = tc.backend.vmap(expec)(ps)
+    from tcmi import executor as EX
+
+    def launches(fn):
+        EX.EVENT_LOG = []
+        try:
+            out = fn()
+            torch.cuda.synchronize()
+            cnt = {}
+            for tag, *_ in EX.EVENT_LOG:
+                cnt[tag] = cnt.get(tag, 0) + 1
+        finally:
+            EX.EVENT_LOG = None
+        return out, cnt
+
+    got, n4 = launches(lambda: tc.backend.vmap(expec)(ps))
     np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), atol=1e-11)
+    _, n1 = launches(lambda: tc.backend.vmap(expec)(ps[:1]))
+    assert n4.get("mps_svd", 0) > 0 and n4.get("mps_svd") == n1.get("mps_svd"), (n4, n1)
+    assert n4.get("mps_qr", 0) == n1.get("mps_qr", 0), (n4, n1)
+    # grad outside vmap: the decompositions record stacked matrices, their backward rules take the batch dimension
+    tot = lambda q: tc.backend.sum(tc.backend.vmap(expec)(q))
+    vt, gt = tc.backend.value_and_grad(tot)(ps)
+    np.testing.assert_allclose(float(vt), float(want.sum()), atol=1e-10)
+    for i in range(ps.shape[0]):
+        _, gi = tc.backend.value_and_grad(expec)(ps[i])
+        np.testing.assert_allclose(gt[i].cpu().numpy(), gi.cpu().numpy(), atol=1e-8)
     vs, gs = tc.backend.vvag(expec, argnums=0, vectorized_argnums=0)(ps)
     np.testing.assert_allclose(vs.cpu().numpy(), want.cpu().numpy(), atol=1e-11)
     vag = tc.backend.value_and_grad(expec)
