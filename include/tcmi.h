@@ -49,6 +49,17 @@ int tcmi_build_tables(const int* ginfo, int nrec, const double* cpool, const voi
                       long long params_stride, void* ptab, long long ptab_stride, int batch,
                       int dtype, void* stream);
 
+/* Weights of the cut contraction (tcmi/cut.py): a shallow circuit is cut between two qubit groups, every gate across
+ * the cut is written as a sum of products (left factor x right factor x coefficient), and the wavefunction is
+ * sum_k w[k] L_k (x) R_k with  w[b][k] = prod_j coef_j(digit_j(k), theta_b).  `tab_i` = int32[nb*rmax] entries
+ * kind | (param_index << 2) (kind 0 constant, 1 cos, 2 sin); `tab_f` = float64[nb*rmax][4] {scale, offset, const_re,
+ * const_im}; `digits` = uint8[K][nb]; params float (C64) / double (C128) [batch][params_stride]; `w` = complex
+ * [batch][K] of the state's precision.  One launch for what is otherwise a dozen elementwise launches per step.
+ * Replaces: the coefficient arithmetic of the cross-cut gates inside the contraction that Circuit.wavefunction
+ * executes (tensorcircuit/circuit.py:701-721, gate factories tensorcircuit/gates.py:692-743). */
+int tcmi_cut_weights(const void* params, long long params_stride, int batch, const int* tab_i, const double* tab_f,
+                     const unsigned char* digits, int K, int nb, int rmax, void* w, int dtype, void* stream);
+
 /* One pass of a compiled plan over the (batched) state, in place: every workgroup loads a tile of
  * 2^(R+LT) amplitudes, applies the pass program `desc` (int32 words, layout in
  * tensorcircuit-ng_amd/csrc/tcmi_vm.h) and stores the tile back.  `ctab` = shared constant table,

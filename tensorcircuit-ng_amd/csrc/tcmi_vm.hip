@@ -500,6 +500,37 @@ __global__ void zero_state_kernel(typename Cx<F>::type* __restrict__ state, long
   }
 }
 
+// Weights of the cut contraction: w[b][k] = prod_j coef_j(digit_j(k), theta_b), one thread per (b, k).  An entry is a
+// constant or cos / sin of (scale * theta[param] + offset); the product runs in float64 whatever the state's precision.
+template <typename F>
+__global__ void cut_weights_kernel(const F* __restrict__ params, long long pstride, const int* __restrict__ tab_i,
+                                   const double* __restrict__ tab_f, const unsigned char* __restrict__ digits, int K,
+                                   int nb, int rmax, typename Cx<F>::type* __restrict__ w) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (k >= K) return;
+  double ar = 1.0, ai = 0.0;
+  for (int j = 0; j < nb; ++j) {
+    const int e = j * rmax + digits[k * nb + j];
+    const int kind = tab_i[e] & 3;
+    double vr, vi = 0.0;
+    if (kind == 0) {
+      vr = tab_f[4 * e + 2];
+      vi = tab_f[4 * e + 3];
+    } else {
+      const double a = (double)params[(long long)b * pstride + (tab_i[e] >> 2)] * tab_f[4 * e] + tab_f[4 * e + 1];
+      vr = kind == 1 ? cos(a) : sin(a);
+    }
+    const double nr = ar * vr - ai * vi;
+    ai = ar * vi + ai * vr;
+    ar = nr;
+  }
+  typename Cx<F>::type o;
+  o.x = (F)ar;
+  o.y = (F)ai;
+  w[(long long)b * K + k] = o;
+}
+
 // second-generation complex64 measurement pass (tcmi_measure2.hip); -1 = no variant for this (R, LT)
 int run_measure2_c64(const void* state, long long state_stride, int batch, int n, int R, int LT, const int* desc,
                      double* eout, long long eout_stride, int ecopies, long long ecopy_stride, hipStream_t st);
@@ -629,6 +660,26 @@ int tcmi_build_tables(const int* ginfo_dev, int nrec, const double* cpool_dev, c
     return set_msg(TCMI_ERR_ARG, "tcmi_build_tables: bad dtype");
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_err("build_kernel launch", e);
+  return TCMI_OK;
+}
+
+int tcmi_cut_weights(const void* params_dev, long long params_stride, int batch, const int* tab_i_dev,
+                     const double* tab_f_dev, const unsigned char* digits_dev, int K, int nb, int rmax, void* w_dev,
+                     int dtype, void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!params_dev || !tab_i_dev || !tab_f_dev || !digits_dev || !w_dev || batch < 1 || K < 1 || nb < 0 || rmax < 1)
+    return set_msg(TCMI_ERR_ARG, "tcmi_cut_weights: bad argument");
+  dim3 block(128, 1, 1), grid((K + 127) / 128, batch, 1);
+  if (dtype == TCMI_C64)
+    hipLaunchKernelGGL(tcmi::cut_weights_kernel<float>, grid, block, 0, st, reinterpret_cast<const float*>(params_dev),
+                       params_stride, tab_i_dev, tab_f_dev, digits_dev, K, nb, rmax, reinterpret_cast<float2*>(w_dev));
+  else if (dtype == TCMI_C128)
+    hipLaunchKernelGGL(tcmi::cut_weights_kernel<double>, grid, block, 0, st, reinterpret_cast<const double*>(params_dev),
+                       params_stride, tab_i_dev, tab_f_dev, digits_dev, K, nb, rmax, reinterpret_cast<double2*>(w_dev));
+  else
+    return set_msg(TCMI_ERR_ARG, "tcmi_cut_weights: bad dtype");
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_err("cut_weights_kernel launch", e);
   return TCMI_OK;
 }
 

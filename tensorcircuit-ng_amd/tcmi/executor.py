@@ -174,9 +174,10 @@ class CompiledCircuit:
         return P.GateRec(tuple(q + pad for q in g.qubits), g.c0, g.c1, g.c2, g.param, diag, g.name)
 
     # ------------------------------------------------------------------------------------
-    def state(self, params=None, inputs=None, out=None, full=False):
+    def state(self, params=None, inputs=None, out=None, full=False, consume_inputs=False):
         """Run the plan.  ``params``: real tensor [B, P] (or [P]) on the device, or None when the
-        circuit has no parameters.  Returns a complex tensor [B, 2^n]."""
+        circuit has no parameters.  Returns a complex tensor [B, 2^n].  ``consume_inputs``: the passes may run in
+        place on ``inputs`` (a scratch batch the caller gives up) instead of on a copy."""
         import torch
 
         lib = self._lib
@@ -196,14 +197,19 @@ class CompiledCircuit:
         nel = 2**self.n_exec
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if out is None:
-            out = torch.empty(B, nel, dtype=self.tdtype, device=self.device)
+            if (consume_inputs and inputs is not None and self.n_exec == self.n and inp.is_contiguous()
+                    and inp.shape[0] == B and not inp.requires_grad):
+                out = inp
+            else:
+                out = torch.empty(B, nel, dtype=self.tdtype, device=self.device)
         if inputs is None:
             _lib.check(
                 lib.tcmi_init_zero_state(out.data_ptr(), nel, B, self.n_exec, self.code, stream),
                 "tcmi_init_zero_state",
             )
         elif self.n_exec == self.n:
-            out.copy_(inp)
+            if out is not inp:
+                out.copy_(inp)
         else:
             out.zero_()
             out[:, : 2**self.n] = inp
@@ -729,15 +735,23 @@ class _HalfBatch:
             self.suffix = CompiledCircuit(nq, gates[cut:], nparams + nb, dtypestr, opts)
             self.descs = list(self.prefix.descs) + list(self.suffix.descs)
 
-    def states(self, pfull, B):
-        """pfull [B*K, nparams + nb] (digits in the last nb columns) -> [B*K, 2^nq]."""
+    def states(self, pfull, B, scale=None):
+        """pfull [B*K, nparams + nb] (digits in the last nb columns) -> [B*K, 2^nq]; ``scale`` [B, K]: every state
+        multiplied by its weight (applied where the prefix states are replicated over the suffix digits: the
+        replication writes the batch anyway, and the suffix passes then run in place on it)."""
         if self.s == 0:
-            return self.single.state(pfull)
+            out = self.single.state(pfull)
+            if scale is not None:
+                out *= scale.reshape(-1, 1)
+            return out
         K, Ks = self.K, self.Ks
         ppre = pfull.reshape(B, Ks, K // Ks, -1)[:, :, 0, :].reshape(B * Ks, -1).contiguous()
         pre = self.prefix.state(ppre)                                            # [B*Ks, 2^nq]
-        rep = pre.reshape(B, Ks, 1, -1).expand(B, Ks, K // Ks, pre.shape[-1]).reshape(B * K, -1)
-        return self.suffix.state(pfull, inputs=rep)
+        if scale is None:
+            rep = pre.reshape(B, Ks, 1, -1).expand(B, Ks, K // Ks, pre.shape[-1]).reshape(B * K, -1)
+        else:
+            rep = (pre.reshape(B, Ks, 1, -1) * scale.reshape(B, Ks, K // Ks, 1)).reshape(B * K, -1)
+        return self.suffix.state(pfull, inputs=rep, consume_inputs=True)
 
 
 class CutCircuit:
@@ -793,12 +807,27 @@ class CutCircuit:
                         pidx=_dev(pidx.reshape(-1), self.device), scale=_dev(scale, self.device),
                         offs=_dev(offs, self.device), dig=dig.t().contiguous().unsqueeze(0), nb=nb, rmax=rmax)
             self._wtabs = tabs
+            # the same tables for the one-launch kernel (tcmi_cut_weights)
+            kind = (cmask + 2 * smask).astype(np.int64)
+            tab_i = (kind | (pidx << 2)).astype(np.int32).reshape(-1)
+            tab_f = np.stack([scale, offs, const.real, const.imag], axis=-1).astype(np.float64).reshape(-1)
+            tabs["tab_i"] = torch.as_tensor(tab_i).to(self.device)
+            tabs["tab_f"] = torch.as_tensor(tab_f).to(self.device)
+            tabs["dig8"] = self.digits.to(torch.uint8).contiguous()              # [K, nb]
         B = params.shape[0]
         nb, rmax = tabs["nb"], tabs["rmax"]
-        a = params[:, tabs["pidx"]].to(torch.float64).reshape(B, nb, rmax) * tabs["scale"] + tabs["offs"]
-        v = tabs["const"] + tabs["cmask"] * torch.cos(a) + tabs["smask"] * torch.sin(a)   # [B, nb, rmax] complex128
-        sel = torch.gather(v, 2, tabs["dig"].expand(B, nb, -1))                 # [B, nb, K]
-        return sel.prod(dim=1).to(self.tdtype)
+        if os.environ.get("TCMI_CUT_WEIGHTS_TORCH", "0") == "1":                 # the elementwise formulation (12 launches)
+            a = params[:, tabs["pidx"]].to(torch.float64).reshape(B, nb, rmax) * tabs["scale"] + tabs["offs"]
+            v = tabs["const"] + tabs["cmask"] * torch.cos(a) + tabs["smask"] * torch.sin(a)   # [B, nb, rmax] complex128
+            sel = torch.gather(v, 2, tabs["dig"].expand(B, nb, -1))             # [B, nb, K]
+            return sel.prod(dim=1).to(self.tdtype)
+        p = params.contiguous()
+        w = torch.empty(B, self.K, dtype=self.tdtype, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.tcmi_cut_weights(p.data_ptr(), p.stride(0), B, tabs["tab_i"].data_ptr(),
+                                              tabs["tab_f"].data_ptr(), tabs["dig8"].data_ptr(), self.K, nb, rmax,
+                                              w.data_ptr(), self.code, stream), "tcmi_cut_weights")
+        return w
 
     def state(self, params=None, inputs=None, out=None, full=False):
         import torch
@@ -813,8 +842,7 @@ class CutCircuit:
         pfull = torch.cat([p[:, : self.nparams].unsqueeze(1).expand(B, K, self.nparams),
                            self.digits.unsqueeze(0).expand(B, K, -1)], dim=2).reshape(B * K, -1).contiguous()
         L = self.left.states(pfull, B)                                  # [B*K, M]
-        R = self.right.states(pfull, B)                                 # [B*K, N]
-        R = R * self._weights(p).reshape(B * K, 1)
+        R = self.right.states(pfull, B, scale=self._weights(p))         # [B*K, N], each state times its weight
         M, N = 2**self.spec.n_left, 2 ** (self.n - self.spec.n_left)
         if out is None:
             out = torch.empty(B, M * N, dtype=self.tdtype, device=self.device)

@@ -247,6 +247,40 @@ def test_cut_contraction_matches_oracle_and_statevector(n, d):
     assert np.abs(outs["cut"] - outs["plain"]).max() < 1e-5
 
 
+@pytest.mark.parametrize("dt", ["complex64"])      # the cut order is a complex64 plan (executor._maybe_cut)
+def test_cut_weights_kernel_matches_the_elementwise_formulation(dt, monkeypatch):
+    """``tcmi_cut_weights`` (one launch: w[b][k] = prod_j coef_j(digit_j(k), theta_b) in float64) against the same
+    product written with torch elementwise ops / gather / prod, for a batch of parameter vectors; the cut circuit has
+    constant (cnot, dense gate) and parametrised (rzz) gates across the cut."""
+    import torch
+    import tcmi as tc
+    from tcmi.executor import CutCircuit
+
+    n, d = 16, 3
+    tc.set_backend("hip"); tc.set_dtype(dt)
+    try:
+        tc.set_contractor("cut")
+        rdt = "float32" if dt == "complex64" else "float64"
+        params = np.random.default_rng(5).uniform(0, 2 * np.pi, [2 * d, n])
+        c = tc.Circuit(n)
+        W.hea_b(c, n, d, tc.backend.convert_to_tensor(params, dtype=rdt), zz=tc.gates._zz_matrix)
+        c.cnot(n // 2 - 1, n // 2)
+        c.any(n // 2, n // 2 - 2, unitary=G.random_two_qubit_gate(3))
+        cc = c._compiled()
+        assert isinstance(cc, CutCircuit)
+        g = torch.Generator().manual_seed(1)
+        p = (torch.rand(5, max(1, cc.nparams), generator=g, dtype=torch.float64) * 6.0).to(cc.rdtype).cuda()
+        w_kernel = cc._weights(p)
+        monkeypatch.setenv("TCMI_CUT_WEIGHTS_TORCH", "1")
+        w_torch = cc._weights(p)
+        assert w_kernel.shape == (5, cc.K) and w_kernel.dtype == w_torch.dtype
+        np.testing.assert_allclose(w_kernel.cpu().numpy(), w_torch.cpu().numpy(), atol=3e-7 if dt == "complex64" else 1e-14)
+        assert float(w_kernel.abs().max()) > 1e-3
+    finally:
+        tc.set_contractor("greedy")
+        tc.set_dtype("complex64")
+
+
 def test_cut_contraction_full_size_batch_and_grad():
     """Config 2 at full size through the cut order (auto-selected by the cost model): parity with the
     oracle's TN contraction, vmap batching, and value_and_grad (forward = cut, backward = adjoint
