@@ -61,7 +61,14 @@ def _t(x):
         x = x.tensor
     if torch.is_tensor(x):
         return x.to(device=_device(), dtype=_dtype())
-    return torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=cons.npdtype))).to(_device())
+    t = torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=cons.npdtype)))
+    dev = _device()
+    if dev.type == "cuda":
+        # a pageable host-to-device copy blocks the host until the stream has drained: inside a TEBD sweep that is one
+        # full wait per gate (the host could not enqueue ahead of the 2.5 ms SVD launches).  Staged through pinned
+        # memory the upload is asynchronous (torch's caching host allocator keeps the staging block alive).
+        return t.pin_memory().to(dev, non_blocking=True)
+    return t.to(dev)
 
 
 def split_tensor(tensor: Tensor, center_left: bool = True, split: Optional[Dict[str, Any]] = None):
