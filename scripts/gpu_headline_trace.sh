@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/htrace
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python3 bench.py --probe-child --steps 3 --warmup 1 > /dev/null 2> $OUT/err.txt
+rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python3 bench.py --probe-child --steps 3 --warmup 1 ${BATCH:+--batch $BATCH} > /dev/null 2> $OUT/err.txt
 python3 - <<PY
 import csv, glob
 f = glob.glob("$OUT/**/*kernel_trace.csv", recursive=True)[0]

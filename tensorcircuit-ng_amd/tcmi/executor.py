@@ -841,8 +841,25 @@ class CutCircuit:
         B, K = p.shape[0], self.K
         pfull = torch.cat([p[:, : self.nparams].unsqueeze(1).expand(B, K, self.nparams),
                            self.digits.unsqueeze(0).expand(B, K, -1)], dim=2).reshape(B * K, -1).contiguous()
-        L = self.left.states(pfull, B)                                  # [B*K, M]
-        R = self.right.states(pfull, B, scale=self._weights(p))         # [B*K, N], each state times its weight
+        # The two half-circuit batches are independent and neither fills the chip (one workgroup per state: B*Ks
+        # workgroups in the prefix passes), so the right half runs on a second HIP stream beside the left one.
+        cur = torch.cuda.current_stream(self.device)
+        two = os.environ.get("TCMI_CUT_STREAMS", "1") != "0" and not torch.cuda.is_current_stream_capturing()
+        if two:
+            side = getattr(self, "_side", None)
+            if side is None:
+                side = self._side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                R = self.right.states(pfull, B, scale=self._weights(p))     # [B*K, N], each state times its weight
+            pfull.record_stream(side)
+            p.record_stream(side)
+            L = self.left.states(pfull, B)                              # [B*K, M]
+            cur.wait_stream(side)
+            R.record_stream(cur)
+        else:
+            L = self.left.states(pfull, B)
+            R = self.right.states(pfull, B, scale=self._weights(p))
         M, N = 2**self.spec.n_left, 2 ** (self.n - self.spec.n_left)
         if out is None:
             out = torch.empty(B, M * N, dtype=self.tdtype, device=self.device)
