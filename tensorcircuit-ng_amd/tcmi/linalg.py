@@ -198,11 +198,11 @@ def svd_trunc(mat, max_singular_values: Optional[int] = None, max_truncation_err
     if _tracked(mat):
         return _svd_trunc_ad(mat, static_keep, max_truncation_err, relative, absorb)
     if m <= n:
-        u, s, vh, keep, _ = _svd_rows(mat, static_keep, max_singular_values, max_truncation_err, relative, absorb)
+        u, s, vh, keep, tw2 = _svd_rows(mat, static_keep, max_singular_values, max_truncation_err, relative, absorb)
     else:
         # mat^T = U' S V'h  ->  mat = V'h^T S U'^T
         sw = {0: 0, 1: 2, 2: 1}[absorb]
-        u2, s, vh2, keep, _ = _svd_rows(mat.t(), static_keep, max_singular_values, max_truncation_err, relative, sw)
+        u2, s, vh2, keep, tw2 = _svd_rows(mat.t(), static_keep, max_singular_values, max_truncation_err, relative, sw)
         u, vh = vh2.t().contiguous(), u2.t().contiguous()
     if _CHECK_SVD and last_svd_status(mat.device) != 0:
         raise _lib.TcmiError("tcmi_svd_trunc_batched: inter-workgroup barrier timed out")
@@ -213,7 +213,9 @@ def svd_trunc(mat, max_singular_values: Optional[int] = None, max_truncation_err
             raise _lib.TcmiError("tcmi_svd_trunc_batched: inter-workgroup barrier timed out (workgroups not co-resident)")
         if kk < static_keep:
             u, vh = u[:, :kk].contiguous(), vh[:kk, :].contiguous()
-    return u, s[:kk].to(mat.dtype), vh, s[kk:].to(mat.dtype)
+    rest = s[kk:].to(mat.dtype)
+    rest._tcmi_tw2 = tw2          # sum of the squared discarded values, already reduced inside the kernel
+    return u, s[:kk].to(mat.dtype), vh, rest
 
 
 def qr(mat):

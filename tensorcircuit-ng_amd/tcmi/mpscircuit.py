@@ -341,7 +341,8 @@ class MPSCircuit:
                 self.position(index2)
         err = self._mps.apply_two_site_gate(_t(gate).reshape(2, 2, 2, 2), index1, index2,
                                             center_position=center_position, **split)
-        self._fidelity = self._fidelity * (1 - (err.real ** 2 + err.imag ** 2).sum())
+        tw2 = getattr(err, "_tcmi_tw2", None)      # the SVD kernel's own sum of squared discarded values
+        self._fidelity = self._fidelity * (1 - (tw2[0] if tw2 is not None else (err.real ** 2 + err.imag ** 2).sum()))
 
     def consecutive_swap(self, index_from: int, index_to: int, split: Optional[Dict[str, Any]] = None) -> None:
         if split is None:
