@@ -614,7 +614,11 @@ def main():
     if rank == 0:
         amps = float(world) * B * (2**n) * args.steps
         value = amps / elapsed
-        pass_entry = hbm_entry("tcmi::pass2_kernel<%d,%d> (tile-VM gate passes)" % (cc.cfg.R, cc.cfg.LT), ev.get("pass"),
+        pcfg = cc.cfg
+        if is_cut:                       # the half-circuit batches have their own (small-tile) plan configuration
+            half = cc.left.single if cc.left.s == 0 else cc.left.prefix
+            pcfg = half.cfg
+        pass_entry = hbm_entry("tcmi::pass2_kernel<%d,%d> (tile-VM gate passes)" % (pcfg.R, pcfg.LT), ev.get("pass"),
                                args.steps)
         if is_cut:
             g = ev["gemm"]
