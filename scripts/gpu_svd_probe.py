@@ -4,6 +4,8 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tensorcircuit-ng_amd")); sys.path.insert(0, ROOT)
 import numpy as np, torch
+import tcmi._lib as L
+if os.environ.get("TCMI_LIB"): L.LIB_PATH = os.environ["TCMI_LIB"]
 import tcmi as tc
 from tcmi import linalg as LA
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 256
@@ -27,4 +29,8 @@ for name, a in cases.items():
     sweeps = int((w[2:62] != 0).sum()) + 1
     sref = np.linalg.svd(a, compute_uv=False)
     err = float(np.abs(np.concatenate([s.cpu().numpy().real, rest.cpu().numpy().real]) - sref).max() / sref[0])
-    print(f"{name:12s} {m}x{n} {dt}: {t*1e3:.2f} ms, sweeps {sweeps}, rotations/sweep {w[2:2+sweeps].tolist()}, sigma err {err:.1e}")
+    uf, sf, vf, _ = LA.svd_trunc(A)                      # full thin SVD: orthogonality and reconstruction
+    eye = torch.eye(min(m, n), dtype=tdt, device="cuda")
+    ou = float((uf.mH @ uf - eye).abs().max()); ov = float((vf @ vf.mH - eye).abs().max())
+    rec = float(((uf * sf[None, :]) @ vf - A).abs().max() / sref[0])
+    print(f"{name:12s} {m}x{n} {dt}: {t*1e3:.2f} ms, sweeps {sweeps}, rotations/sweep {w[2:2+sweeps].tolist()}, sigma err {err:.1e}, |U^H U - 1| {ou:.1e}, |V V^H - 1| {ov:.1e}, recon {rec:.1e}")

@@ -31,7 +31,10 @@ constexpr int SVD_MAX_SWEEPS = 60;
 // when one of its rotations had a cosine above SVD_STOP_SCALE x the tolerance.  A sweep of nothing but smaller
 // rotations leaves second-order cosines behind (quadratic convergence), so the extra sweep that would only confirm
 // "no rotation needed" (1 of 11-12 at 256 x 256) is not run.
-constexpr double SVD_STOP_SCALE = 4.0;
+#ifndef TCMI_SVD_STOP_SCALE
+#define TCMI_SVD_STOP_SCALE 4.0
+#endif
+constexpr double SVD_STOP_SCALE = TCMI_SVD_STOP_SCALE;
 constexpr unsigned SPIN_LIMIT = 1u << 21;
 
 template <typename F>
@@ -39,7 +42,10 @@ struct Eps;
 template <>
 struct Eps<float> {
   static constexpr float v = 5.9604645e-8f;
-  static constexpr float tiny = 1e-30f;  // |<x,y>|^2 below this is zero (keeps rsq / rcp away from denormals)
+  // |<x,y>|^2 below this is zero (keeps rsq / rcp away from denormals).  Just above the smallest normal number: with
+  // 1e-30 here, rows with sigma < 3e-5 sigma_max (|x|^2 |y|^2 tol^2 < 1e-30) were never rotated against each other and
+  // the vh rows of a spectrum graded over six decades came out orthogonal only to 7e-4 (now 1e-6, like the others).
+  static constexpr float tiny = 1e-36f;
 };
 template <>
 struct Eps<double> {

@@ -79,6 +79,26 @@ def test_svd_tiny_rows_stay_finite(dt):
     assert LA.last_svd_status() == 0
 
 
+@pytest.mark.parametrize("n", [128, 256])
+def test_svd_factors_stay_orthonormal_for_a_spectrum_graded_over_six_decades(n):
+    """complex64, singular values from 1 down to 1e-6 (TEBD-like decay): u and vh are isometries to a few 1e-6 -- also
+    the rows that belong to the smallest singular values, which an absolute cut-off in the rotation test used to leave
+    orthogonal only to 7e-4 -- and the values match LAPACK to float accuracy relative to the largest."""
+    rng = np.random.default_rng(21)
+    q1, _ = np.linalg.qr(rng.normal(size=(n, n)) + 1j * rng.normal(size=(n, n)))
+    q2, _ = np.linalg.qr(rng.normal(size=(n, n)) + 1j * rng.normal(size=(n, n)))
+    sv = np.logspace(0, -6, n)
+    a = ((q1 * sv) @ q2).astype(np.complex64)
+    u, s, vh, _ = LA.svd_trunc(torch.from_numpy(a).cuda())
+    u, s, vh = u.cpu().numpy(), s.cpu().numpy().real, vh.cpu().numpy()
+    eye = np.eye(n)
+    assert np.abs(u.conj().T @ u - eye).max() < 2e-5
+    assert np.abs(vh @ vh.conj().T - eye).max() < 2e-5
+    np.testing.assert_allclose(s, np.linalg.svd(a.astype(np.complex128), compute_uv=False), atol=5e-6)
+    np.testing.assert_allclose((u * s) @ vh, a, atol=5e-6)
+    assert LA.last_svd_status() == 0
+
+
 def test_svd_rank_deficient_and_zero():
     rng = np.random.default_rng(9)
     a = _rand(rng, 32, 32, "complex128", rank=5)
