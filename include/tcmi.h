@@ -39,6 +39,17 @@ int tcmi_device_count(void);
  * tensorcircuit/basecircuit.py:51-66). */
 int tcmi_init_zero_state(void* state, long long state_stride, int batch, int n, int dtype, void* stream);
 
+/* Host-side planner helper (no GPU work): exact dynamic programme over the subsets of the k <= 16 frontier tensors of a
+ * contraction subtree.  `masks` = k index sets as W 64-bit words each; `lw` = log2 of the index dimensions by bit
+ * (NULL: all dimensions 2); intermediates with more than `cap` (log2 elements) are not allowed; cost of a step =
+ * 2^|union| + alpha (elements read + written).  Writes split[S] (the larger half A of the best bipartition of subset S,
+ * 0 if none) for all 2^k subsets and the cost of the full set.  Bit-identical to the Python loop of
+ * tcmi/tn.py::reconfigure_path it accelerates.
+ * Replaces: cotengra's subtree reconfiguration behind tensorcircuit/cons.py:1168-1190 (`optimizer_reconf`) and
+ * experimental.py `slicing_reconf_opts`. */
+int tcmi_subtree_dp(int k, int W, const unsigned long long* masks, const double* lw, double cap, double alpha,
+                    int* split, double* best_full);
+
 /* Gate-table builder: per batch element, turn the flat real parameter vector into the dense gate
  * matrices  M = C0 + cos(k*theta+o) C1 + sin(k*theta+o) C2  and the diagonal phase coefficients the
  * pass programs reference.  `ginfo` = int32[nrec][8] records {kind, out_slot, param_index, dim,

@@ -384,6 +384,21 @@ MODEL_GBS = 4000.0
 MODEL_STEP_S = 8e-6
 
 
+_NATIVE_DP: List[Any] = []
+
+
+def _native_subtree_dp():
+    """``tcmi_subtree_dp`` of libtcmi (host code), or None: the planner then runs its Python loop (same results)."""
+    if os.environ.get("TCMI_TN_NATIVE_DP", "1") == "0":
+        return None
+    if not _NATIVE_DP:
+        try:
+            _NATIVE_DP.append(_lib.lib().tcmi_subtree_dp)
+        except Exception:  # noqa: BLE001  (library not built, or a jit probe is running)
+            return None
+    return _NATIVE_DP[0]
+
+
 def reconfigure_path(inputs, output, size_dict, path, subtree_size: int = 8, max_size: Optional[int] = None,
                      max_passes: int = 4, max_evals: int = 4000, alpha: Optional[float] = None):
     """Subtree reconfiguration of a contraction path (the refinement cotengra applies to its trees,
@@ -450,6 +465,14 @@ def reconfigure_path(inputs, output, size_dict, path, subtree_size: int = 8, max
     if root is None:          # disconnected leftovers: leave such paths alone
         return list(path)
 
+    native = _native_subtree_dp() if subtree_size <= 16 else None
+    nwords = (len(eid) + 63) // 64
+    lw_c = None
+    if native is not None and not uniform:
+        lw_c = (ctypes.c_double * (64 * nwords))(*(lw + [0.0] * (64 * nwords - len(lw))))
+    if nwords > 64:
+        native = None
+
     def step_cost(a: int, b: int) -> float:
         c = 2.0 ** lsize(idx[a] | idx[b])
         if alpha:
@@ -475,6 +498,42 @@ def reconfigure_path(inputs, output, size_dict, path, subtree_size: int = 8, max
         old = sum(step_cost(*kids[v]) for v in inner)
         masks = [idx[f] for f in front]
         full = (1 << k) - 1
+        if native is not None:
+            # the same dynamic programme in libtcmi (tcmi_subtree_dp, bit-identical costs and tie-breaking)
+            split_c = (ctypes.c_int * (full + 1))()
+            bf = ctypes.c_double()
+            buf = b"".join(m.to_bytes(8 * nwords, "little") for m in masks)
+            if native(k, nwords, buf, lw_c, cap, float(alpha), split_c, ctypes.byref(bf)) != 0:
+                raise RuntimeError("tcmi_subtree_dp failed")
+            if not bf.value < old * (1.0 - 1e-9):
+                return False
+            for v in inner:
+                del kids[v]
+                if v != x:
+                    del idx[v]
+
+            def build_c(S: int, top: bool) -> int:
+                nonlocal nxt
+                if S & (S - 1) == 0:
+                    return front[S.bit_length() - 1]
+                A = split_c[S]
+                l, r = build_c(A, False), build_c(S ^ A, False)
+                if top:
+                    v = x
+                else:
+                    v = nxt
+                    nxt += 1
+                    m, T = 0, S
+                    while T:
+                        low = T & -T
+                        m ^= masks[low.bit_length() - 1]
+                        T ^= low
+                    idx[v] = m
+                kids[v] = (l, r)
+                return v
+
+            build_c(full, True)
+            return True
         sidx = [0] * (full + 1)
         ssz = [0.0] * (full + 1)
         best = [float("inf")] * (full + 1)

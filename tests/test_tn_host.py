@@ -184,6 +184,27 @@ def test_reconfigure_path_is_valid_and_not_worse(nt, seed):
     assert m2 <= m0 and f2 <= f0
 
 
+@pytest.mark.parametrize("nt,seed", [(30, 1), (60, 2), (90, 3)])
+def test_native_subtree_programme_gives_the_python_loops_paths(nt, seed, monkeypatch):
+    """``tcmi_subtree_dp`` (host code of libtcmi) replaces the Python loop over the 3^k bipartitions of a subtree's
+    frontier: same costs, same tie-breaking, hence the identical path -- with and without a size cap, with the bytes
+    weight of the sliced search, with dimensions other than 2 (weighted index sizes), at subtree sizes 6, 8 and 10."""
+    from tcmi import tn
+
+    assert tn._native_subtree_dp() is not None            # the library is built: this is the path the product takes
+    inputs, output, sd = _rand_net(nt, 3, seed)
+    sd3 = {k: (3 if k % 5 == 0 else 2) for k in sd}
+    p0 = tn.greedy_path(inputs, output, sd)
+    m0, _ = tn._path_stats(inputs, output, sd, p0)
+    for dims, kw in ((sd, dict(subtree_size=8)), (sd, dict(subtree_size=10, max_size=m0)),
+                     (sd, dict(subtree_size=6, alpha=32.0)), (sd3, dict(subtree_size=8, alpha=16.0))):
+        monkeypatch.setenv("TCMI_TN_NATIVE_DP", "1")
+        fast = tn.reconfigure_path(inputs, output, dims, p0, **kw)
+        monkeypatch.setenv("TCMI_TN_NATIVE_DP", "0")
+        slow = tn.reconfigure_path(inputs, output, dims, p0, **kw)
+        assert fast == slow
+
+
 def test_reconfigure_improves_a_poor_path():
     from tcmi import tn
 
