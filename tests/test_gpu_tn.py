@@ -281,6 +281,43 @@ def test_cut_weights_kernel_matches_the_elementwise_formulation(dt, monkeypatch)
         tc.set_dtype("complex64")
 
 
+def test_cut_contraction_two_streams_equal_one_stream(monkeypatch):
+    """The right half-circuit batch runs on a second HIP stream and joins before the GEMM: bit-identical to the
+    one-stream order (``TCMI_CUT_STREAMS=0``) for several batches in a row, with allocator churn between the calls."""
+    import torch
+    import tcmi as tc
+    from tcmi.executor import CutCircuit
+
+    n, d = 20, 5
+    tc.set_backend("hip"); tc.set_dtype("complex64")
+    try:
+        tc.set_contractor("cut")
+
+        def f(p):
+            c = tc.Circuit(n)
+            W.hea_b(c, n, d, p, zz=tc.gates._zz_matrix)
+            return c.wavefunction()
+
+        fv = tc.backend.vmap(f)
+        g = torch.Generator().manual_seed(3)
+        for B in (4, 1):
+            for _ in range(6):
+                p = (torch.rand(B, 2 * d, n, generator=g) * 6.28).cuda()
+                monkeypatch.setenv("TCMI_CUT_STREAMS", "1")
+                a = fv(p)
+                junk = torch.randn(1 << 20, device="cuda")
+                monkeypatch.setenv("TCMI_CUT_STREAMS", "0")
+                b = fv(p)
+                del junk
+                assert torch.equal(a, b)
+                assert abs(float((a.abs() ** 2).sum(-1).max()) - 1.0) < 1e-4
+        c = tc.Circuit(n)
+        W.hea_b(c, n, d, tc.backend.convert_to_tensor(np.zeros([2 * d, n]), dtype="float32"), zz=tc.gates._zz_matrix)
+        assert isinstance(c._compiled(), CutCircuit)
+    finally:
+        tc.set_contractor("greedy")
+
+
 def test_cut_contraction_full_size_batch_and_grad():
     """Config 2 at full size through the cut order (auto-selected by the cost model): parity with the
     oracle's TN contraction, vmap batching, and value_and_grad (forward = cut, backward = adjoint
