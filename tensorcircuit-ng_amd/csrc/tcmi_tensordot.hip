@@ -839,6 +839,23 @@ static int launch_scattered_stream(const void* big, const void* small_, void* ou
   return TCMI_OK;
 }
 
+// Zero fill as an ordinary kernel launch.  The split-K paths clear their output before accumulating with atomics; as a
+// hipMemsetAsync that clear becomes a memset NODE when the call is captured into a HIP graph, and two graphs replayed
+// side by side then produced garbage sums (scripts/experiments/README.md); a kernel node is ordered like its
+// neighbours.
+__global__ void zero_fill_kernel(unsigned long long* __restrict__ p, size_t n8) {
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += step) p[i] = 0ull;
+}
+static hipError_t zero_async(void* p, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return hipSuccess;
+  if ((bytes & 7) || (reinterpret_cast<size_t>(p) & 7)) return hipMemsetAsync(p, 0, bytes, st);
+  const size_t n8 = bytes / 8;
+  unsigned gx = (unsigned)((n8 + 255) / 256 > 1024 ? 1024 : (n8 + 255) / 256);
+  hipLaunchKernelGGL(zero_fill_kernel, dim3(gx), dim3(256), 0, st, reinterpret_cast<unsigned long long*>(p), n8);
+  return hipGetLastError();
+}
+
 }  // namespace tcmi
 
 
@@ -945,7 +962,7 @@ int tcmi_tensordot_bits(const void* a, int rank_a, const void* b, int rank_b, co
   }
   if (lm <= 3 && ln <= 3 && K >= 2048) {
     // a few numbers out of a long contraction: the register-accumulator kernel
-    hipError_t me = hipMemsetAsync(c, 0, (size_t)(M * N) * sizeof(float2), st);
+    hipError_t me = tcmi::zero_async(c, (size_t)(M * N) * sizeof(float2), st);
     if (me != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(me));
     long long nb = (K + 255) / 256;
     if (nb > 2048) nb = 2048;
@@ -975,7 +992,7 @@ int tcmi_tensordot_bits(const void* a, int rank_a, const void* b, int rank_b, co
     if (want > 1) {
       kchunk = ((K + want - 1) / want + TCMI_CBK - 1) / TCMI_CBK * TCMI_CBK;
       ksplit = (int)((K + kchunk - 1) / kchunk);
-      hipError_t me = hipMemsetAsync(c, 0, (size_t)(M * N) * sizeof(float2), st);
+      hipError_t me = tcmi::zero_async(c, (size_t)(M * N) * sizeof(float2), st);
       if (me != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(me));
     }
   }
@@ -1015,7 +1032,7 @@ int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, 
         kchunk = (int)(((K + want - 1) / want + TCMI_CBK - 1) / TCMI_CBK * TCMI_CBK);
         ksplit = (int)((K + kchunk - 1) / kchunk);
         for (int b = 0; b < batch; ++b) {
-          hipError_t me = hipMemsetAsync(reinterpret_cast<float2*>(C) + (size_t)b * strideC, 0, (size_t)(M * N) * sizeof(float2), st);
+          hipError_t me = tcmi::zero_async(reinterpret_cast<float2*>(C) + (size_t)b * strideC, (size_t)(M * N) * sizeof(float2), st);
           if (me != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(me));
         }
       }
@@ -1058,7 +1075,7 @@ int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, 
     const long long chunks = (K + kchunk - 1) / kchunk;
     const size_t esz = dtype == TCMI_C64 ? 8 : 16;
     for (int b = 0; b < batch; ++b) {
-      hipError_t me = hipMemsetAsync(reinterpret_cast<char*>(C) + (size_t)b * strideC * esz, 0, (size_t)total * esz, st);
+      hipError_t me = tcmi::zero_async(reinterpret_cast<char*>(C) + (size_t)b * strideC * esz, (size_t)total * esz, st);
       if (me != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(me));
     }
     const bool pow2 = (M & (M - 1)) == 0 && (N & (N - 1)) == 0;

@@ -1174,10 +1174,21 @@ class ContractionTree:
                     with torch.cuda.graph(g_sl, **({"pool": g_inv.pool()} if g_inv is not None else {})):
                         res = self._run_steps({k: static[k] for k in range(n) if dep[k]}, shared_t, False)
                 cnt_sl = COUNTERS
+                # a second instance of the per-slice graph (own leaf copies, own memory pool) for a second stream: the
+                # slice-dependent part is a chain of launches, many of them far too small to fill the chip, so two slices
+                # side by side overlap each other's small steps
+                g_sl2, res2, static2 = None, None, None
+                if g_sl is not None and TN_STREAMS >= 2 and len(slice_ids) >= 2:
+                    COUNTERS = None
+                    static2 = {k: static[k].clone() for k in range(n) if dep[k]}
+                    g_sl2 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_sl2):
+                        res2 = self._run_steps(dict(static2), shared_t, False)
             finally:
                 COUNTERS = keep_counters
             cache = {"sig": sig, "static": static, "shared": shared_t, "g_inv": g_inv, "g_sl": g_sl, "res": res,
-                     "cnt_inv": cnt_inv, "cnt_sl": cnt_sl}
+                     "cnt_inv": cnt_inv, "cnt_sl": cnt_sl, "g_sl2": g_sl2, "res2": res2, "static2": static2,
+                     "side": torch.cuda.Stream(device=first[0].device) if g_sl2 is not None else None}
             self._graph_cache = cache
         static = cache["static"]
         inv_k = [k for k in range(n) if not dep[k]]
@@ -1188,18 +1199,43 @@ class ContractionTree:
         if COUNTERS is not None:
             for key, v in cache["cnt_inv"].items():
                 COUNTERS[key] += v
-        for i in slice_ids:
-            sliced = first if i == slice_ids[0] else self.slice_arrays(arrays, i)
+        ids = list(slice_ids)
+        two = cache.get("g_sl2") is not None
+        cur_s = torch.cuda.current_stream(first[0].device) if two else None
+        j = 0
+        while j < len(ids):
+            i = ids[j]
+            i2 = ids[j + 1] if two and j + 1 < len(ids) else None
+            if i2 is not None:           # the partner slice goes out first, on the second stream
+                side = cache["side"]
+                side.wait_stream(cur_s)  # invariant tensors, the leaves, and the clone of the previous partner result
+                with torch.cuda.stream(side):
+                    sl2 = self.slice_arrays(arrays, i2)
+                    for k in dep_k:
+                        cache["static2"][k].copy_(sl2[k])
+                    cache["g_sl2"].replay()
+                    del sl2
+            sliced = first if i == ids[0] else self.slice_arrays(arrays, i)
             for k in dep_k:
                 static[k].copy_(sliced[k])
             if cache["g_sl"] is None:      # nothing depends on a sliced index: the invariant graph did all the work
                 yield self._run_steps({}, cache["shared"], False).clone()
+                j += 1
                 continue
             cache["g_sl"].replay()
+            n_done = 1 if i2 is None else 2
             if COUNTERS is not None:
                 for key, v in cache["cnt_sl"].items():
-                    COUNTERS[key] += v
-            yield cache["res"].clone()
+                    COUNTERS[key] += v * n_done
+            r1 = cache["res"].clone()
+            r2 = None
+            if i2 is not None:
+                cur_s.wait_stream(cache["side"])
+                r2 = cache["res2"].clone()
+            yield r1
+            if r2 is not None:
+                yield r2
+            j += n_done
 
     def contract_core(self, arrays: Sequence[Any]):
         """Pairwise contraction of (already sliced) arrays along the path; returns the result with
@@ -1452,6 +1488,7 @@ def _tensordot_bits(a, b, axes_a, axes_b):
     return out
 
 
+TN_STREAMS = int(os.environ.get("TCMI_TN_STREAMS", "2"))   # two slices of a sliced contraction side by side (1: one stream)
 SCATTERED_MIN_RANK = 16    # big operand: at least 2^16 elements
 SCATTERED_MAX_SMALL = 4096  # small operand: at most this many elements (it lives in LDS)
 SCATTERED_MAX_NK = int(os.environ.get("TCMI_TN_SCAT_MAXK", "8"))   # more contracted axes: the MFMA bits kernel
