@@ -844,7 +844,7 @@ class CutCircuit:
         # The two half-circuit batches are independent and neither fills the chip (one workgroup per state: B*Ks
         # workgroups in the prefix passes), so the right half runs on a second HIP stream beside the left one.
         cur = torch.cuda.current_stream(self.device)
-        two = os.environ.get("TCMI_CUT_STREAMS", "1") != "0" and not torch.cuda.is_current_stream_capturing()
+        two = os.environ.get("TCMI_CUT_STREAMS", "1") != "0"      # also under hipGraph capture (fork / join in the graph)
         if two:
             side = getattr(self, "_side", None)
             if side is None:
