@@ -8,6 +8,7 @@ resident in HBM.  One process per GPU; ranks run independent batches (vmap-batch
 data-path collective), timing is max-over-ranks between barriers.  Rank 0 prints ONE JSON line.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8 --steps 20 --warmup 3        (starts its own 8 rank processes, see self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
 """
@@ -418,7 +419,9 @@ def rqc_leg(tc, torch, dist, args, rank, world):
                  "one_slice_run_s": t_one, "invariant_fraction_of_one_slice_run": t_inv / max(t_one, 1e-12),
                  # slices go out in pairs on two streams, so per_slice_s is the paired rate; the 8-rank figure is the
                  # measured time of the slices ONE rank would hold (invariant part included), not a model
-                 "projected_speedup_8_ranks": t_all / t_rank}
+                 "projected_speedup_8_ranks": t_all / t_rank,
+                 "projection_basis": "ONE-rank measurement: time of all local slices / time of the slices one rank of "
+                                     "an 8-rank run would hold (with the invariant work that rank executes); no 8-GPU run"}
     flops = float(tree.total_flops())          # all slices (ContractionTree.total_flops includes nslices)
     steps, dep, _, _ = tree._symbolic_steps()
     n_inv = sum(1 for st in steps if not dep[st[4]])   # slice-invariant steps: computed once per rank
@@ -427,7 +430,10 @@ def rqc_leg(tc, torch, dist, args, rank, world):
                     f"2^{args.rqc_log2_target} elements (SURVEY 8d config 4)",
         "nslices": int(tree.nslices), "slices_per_gpu": int(-(-tree.nslices // world)),
         "contraction_width": float(tree.contraction_width()), "log2_flops_total": float(np.log2(flops)),
-        "contract_s": t, "tflops": flops / t / 1e12, "path_search_s": round(search_s, 2),
+        # primary rate = the flops the engine EXECUTED (slice-invariant steps once per call); the sliced tree's own
+        # count (every step x nslices) is kept as algorithmic_tflops_sliced_tree
+        "contract_s": t, "tflops": (cnt["gemm_flops"] + cnt["scattered_flops"]) / t / 1e12,
+        "algorithmic_tflops_sliced_tree": flops / t / 1e12, "path_search_s": round(search_s, 2),
         "steps_per_slice": len(steps), "slice_invariant_steps": n_inv, "time_split": split,
         "amplitude": [float(v.real), float(v.imag)],
         # F_alg of the executed (sliced, slice-invariant parts once) steps over the wall time against the f32 MFMA
@@ -450,6 +456,55 @@ def _guard(name, fn, *a):
         return fn(*a)
     except Exception as e:  # noqa: BLE001
         return {"error": f"{name}: {type(e).__name__}: {e}"[:300]}
+
+
+def self_launch(n):
+    """``python bench.py --gpus N`` without a launcher: start N fresh rank processes of this very command (the
+    reference drives all devices from one command, examples/slicing_auto_pmap_vqa.py:8-10,60-66), one per GPU, with
+    the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT) and the nccl
+    (= RCCL) backend.  The parent makes no GPU call before or after the spawn -- a process that has initialised the
+    GPU must not start other programs on this pool -- it only waits; rank 0 prints the JSON line on the inherited
+    stdout.  Returns the worst exit code; if a rank dies the others are terminated (by PID)."""
+    import socket
+    import subprocess
+
+    import torch   # device_count() does not initialise the GPU
+
+    have = torch.cuda.device_count()
+    share = have < n and have >= 1 and os.environ.get("TCMI_BENCH_OVERSUBSCRIBE") == "1"
+    if have < n and not share:
+        print(f"bench.py: --gpus {n} but only {have} device(s) visible "
+              f"(TCMI_BENCH_OVERSUBSCRIBE=1 runs the ranks round-robin on the visible devices over gloo: a test of the "
+              f"launch path, not a measurement)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if share:
+            env.update(LOCAL_RANK=str(r % have), TCMI_BENCH_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while procs:
+            for p_ in list(procs):
+                code = p_.poll()
+                if code is None:
+                    continue
+                procs.remove(p_)
+                if code != 0:
+                    rc = rc or code
+                    for q_ in procs:      # a dead rank would leave the others in a collective forever
+                        q_.terminate()
+            time.sleep(0.2)
+    finally:
+        for p_ in procs:
+            p_.kill()
+    return rc
 
 
 def main():
@@ -483,6 +538,9 @@ def main():
     ap.add_argument("--LT", type=int, default=None)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.probe_child:
+        sys.exit(self_launch(args.gpus))   # one fresh process per GPU; this parent never touches the GPU
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -508,7 +566,10 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("TCMI_BENCH_BACKEND", "nccl") == "gloo":   # ranks sharing a device (launch-path test only)
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -666,6 +727,8 @@ def main():
             "value": value,
             "unit": "amplitudes/s",
             "n_gpus": world,
+            **({"oversubscribed": "ranks share the visible device(s), gloo: launch-path test, not a measurement"}
+               if os.environ.get("TCMI_BENCH_BACKEND") == "gloo" else {}),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,

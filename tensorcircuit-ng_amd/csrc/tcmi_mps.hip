@@ -684,6 +684,12 @@ __global__ __launch_bounds__(64 * B) void svd_block_kernel(
       const F sk = ld_sc1(s + k);
       tw2 += sk * sk;
     }
+    // a workgroup that timed out at an EARLIER barrier has poisoned s / keep / tw2 and left; this workgroup may still
+    // have seen the last barrier complete -- do not overwrite the poison with valid-looking numbers
+    if (nwg > 1 && __hip_atomic_load((gu32*)ctl + 1, TCMI_RLX)) {
+      keep = -1;
+      tw2 = __builtin_nanf("");
+    }
     if (keep_out) keep_out[b + batch0] = keep;
     if (tw2_out) tw2_out[b + batch0] = tw2;
   }

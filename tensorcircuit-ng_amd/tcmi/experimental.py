@@ -42,16 +42,55 @@ class DistributedContractor:
         self.my_slices = [int(s) for s in self.slice_table[self.rank] if s >= 0]
 
     # ---- path search / persistence (reference experimental.py:923-991) --------------------------
+    # cotengra options this backend understands (reference experimental.py:934-946 hands the dictionary to
+    # ``ctg.ReusableHyperOptimizer(**opts)``); anything else raises instead of being dropped
+    _SLICING_KEYS = ("target_size", "target_slices")
+
+    @staticmethod
+    def _parse_options(cotengra_options: Optional[Dict[str, Any]]) -> Dict[str, Any]:
+        opts = dict(cotengra_options or {})
+        out: Dict[str, Any] = {"target_size": None, "target_slices": None, "minimize": None}
+        out["max_repeats"] = int(opts.pop("max_repeats", 128))      # reference default (experimental.py:936-942)
+        out["seed"] = int(opts.pop("seed", 0))
+        for key in ("slicing_opts", "slicing_reconf_opts"):
+            sub = dict(opts.pop(key, None) or {})
+            for k in DistributedContractor._SLICING_KEYS:
+                if k in sub:
+                    out[k] = int(sub.pop(k))
+            sub.pop("max_repeats", None)         # repeats of the reconfiguration: the beam of tn._reconfigure_sliced
+            if sub:
+                raise NotImplementedError(f"Backend 'hip' has not implemented cotengra {key} keys {sorted(sub)} "
+                                          f"(understood: {DistributedContractor._SLICING_KEYS})")
+        if "minimize" in opts:
+            m = opts.pop("minimize")
+            if not isinstance(m, str) or not (m in ("flops", "write", "size", "max") or m.startswith("combo")):
+                raise NotImplementedError(f"Backend 'hip' has not implemented minimize={m!r}")
+            out["minimize"] = m
+        methods = opts.pop("methods", None)
+        if methods is not None:
+            methods = [methods] if isinstance(methods, str) else list(methods)
+            bad = [m for m in methods if m not in ("greedy", "random-greedy")]
+            if bad:
+                raise NotImplementedError(f"Backend 'hip' has not implemented the path-search methods {bad}: the search is "
+                                          f"random-greedy + subtree reconfiguration (methods=['greedy'])")
+        # execution hints without an effect on the result: every rank derives the same tree in-process (deterministic
+        # search, native subtree programme), so there is nothing to parallelise over and nothing to show
+        for k in ("parallel", "progbar"):
+            opts.pop(k, None)
+        if opts:
+            raise NotImplementedError(f"Backend 'hip' has not implemented the cotengra options {sorted(opts)}")
+        if out["target_size"] is None and out["target_slices"] is None:
+            out["target_size"] = 2**28           # reference default slicing_reconf_opts (experimental.py:936-942)
+        return out
+
     @staticmethod
     def _target_size(cotengra_options: Optional[Dict[str, Any]]) -> int:
-        opts = cotengra_options or {}
-        for key in ("slicing_reconf_opts", "slicing_opts"):
-            if key in opts and "target_size" in opts[key]:
-                return int(opts[key]["target_size"])
-        return 2**28  # reference default (experimental.py:936-942)
+        ts = DistributedContractor._parse_options(cotengra_options)["target_size"]
+        return 2**28 if ts is None else ts
 
     @staticmethod
     def _get_tree_data(nodes_fn, params, cotengra_options) -> Dict[str, Any]:
+        o = DistributedContractor._parse_options(cotengra_options)
         nodes = nodes_fn(params)
         inputs, output, size_dict = tn.get_tn_info(nodes)
         # edge labels are renumbered 0..E-1 in first-appearance order: valid for every re-trace
@@ -62,11 +101,12 @@ class DistributedContractor:
         inputs = [[ren[e] for e in s] for s in inputs]
         output = [ren[e] for e in output]
         size_dict = {ren[e]: d for e, d in size_dict.items()}
-        # reference default max_repeats = 128 (experimental.py:936-942): trials of the random-greedy search
-        opts = cotengra_options or {}
-        tree = tn.ContractionTree.from_path(inputs, output, size_dict, trials=int(opts.get("max_repeats", 128)),
-                                            seed=int(opts.get("seed", 0)))
-        tree.slice_to(DistributedContractor._target_size(cotengra_options))
+        tree = tn.ContractionTree.from_path(inputs, output, size_dict, trials=o["max_repeats"], seed=o["seed"])
+        tree.minimize = o["minimize"]
+        if o["target_size"] is not None:
+            tree.slice_to(o["target_size"])
+        if o["target_slices"] is not None:
+            tree.slice_to_slices(o["target_slices"])
         return tree.to_data()
 
     @staticmethod
@@ -137,13 +177,25 @@ class DistributedContractor:
         p = K.tree_unflatten(spec, leaves)
         fop = op if op is not None else (lambda x: x.sum().real)
         arrays = self._arrays(p)
-        value = None
-        for r in self.tree.contract_slices(arrays, self.my_slices):
-            r = fop(r)
-            value = r if value is None else value + r
-        if value is None:
-            value = sum((x.sum() * 0 for x in leaves)).real
-        grads = torch.autograd.grad(value, leaves, allow_unused=True)
+        if self._fast_vjp(arrays):
+            # reverse sweep over the step list on the untaped kernels (tn.contract_slices_vjp); the small gate tensors
+            # stay on torch's tape, so their cotangents reach ``params`` through one autograd call
+            value, agrads = self.tree.contract_slices_vjp(arrays, self.my_slices, fop)
+            if value is None:
+                value = sum((x.sum() * 0 for x in leaves)).real.detach()
+            pairs = [(a, g) for a, g in zip(arrays, agrads) if g is not None and a.requires_grad]
+            if pairs:
+                grads = torch.autograd.grad([a for a, _ in pairs], leaves, [g for _, g in pairs], allow_unused=True)
+            else:
+                grads = [None] * len(leaves)
+        else:
+            value = None
+            for r in self.tree.contract_slices(arrays, self.my_slices):
+                r = fop(r)
+                value = r if value is None else value + r
+            if value is None:
+                value = sum((x.sum() * 0 for x in leaves)).real
+            grads = torch.autograd.grad(value, leaves, allow_unused=True)
         grads = [g if g is not None else torch.zeros_like(x) for g, x in zip(grads, leaves)]
         packed = D.allreduce_sum_packed([value.detach().reshape(1).real.to(torch.float64)] + [g.to(torch.float64) if not g.is_complex() else g.real.to(torch.float64) for g in grads])
         v = packed[0].reshape(())
@@ -153,6 +205,17 @@ class DistributedContractor:
         else:
             v = v.to(getattr(torch, cons.rdtypestr))
         return v, K.tree_unflatten(spec, gs)
+
+    @staticmethod
+    def _fast_vjp(arrays) -> bool:
+        """The hand-written reverse sweep needs plain complex [2]^rank device tensors (TCMI_TN_VJP=0: torch's tape)."""
+        import os
+        import torch
+
+        if os.environ.get("TCMI_TN_VJP", "1") == "0":
+            return False
+        return all(torch.is_tensor(t) and t.is_cuda and t.is_complex() and all(d == 2 for d in t.shape)
+                   and not torch._C._functorch.is_functorch_wrapped_tensor(t) for t in arrays)
 
     def grad(self, params: Any, op: Optional[Callable[[Tensor], Tensor]] = None, output_dtype: Optional[str] = None) -> Any:
         return self.value_and_grad(params, op, output_dtype)[1]

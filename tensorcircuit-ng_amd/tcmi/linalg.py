@@ -30,10 +30,20 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+def _devkey(device):
+    """Canonical dictionary key of a device: ``cuda`` without an index means the current device."""
+    import torch
+
+    if device is None:
+        return ("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    return (device.type, device.index if device.index is not None else (torch.cuda.current_device() if device.type == "cuda" else 0))
+
+
 def _workspace(kind, nbytes, device):
     import torch
 
-    key = (kind, device)
+    key = (kind, _devkey(device))
     w = _WORK.get(key)
     if w is None or w.numel() < nbytes:
         w = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=device)
@@ -177,12 +187,28 @@ def last_svd_status(device=None) -> int:
     every ``svd_trunc`` call check it and raise)."""
     import torch
 
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device())
-    w = _WORK.get(("svd", device))
+    w = _WORK.get(("svd", _devkey(device)))
     if w is None:
         return 0
     return int(w[4:8].view(torch.int32).item())
+
+
+_SVD_PENDING: Dict[Any, bool] = {}    # device -> SVD launches since the last status read-back
+
+
+def svd_health_check(device=None) -> None:
+    """Raise if an SVD launched since the last check ended on a timed-out inter-workgroup barrier (its factors are
+    poisoned: s = NaN, kept rank -1, discarded weight NaN).  ``svd_trunc`` with only ``max_singular_values`` never
+    reads anything back, so the MPS front end calls this where it hands results to the user (one 4-byte read,
+    only when SVDs ran since the previous check)."""
+    import torch
+
+    if not _SVD_PENDING.get(_devkey(device)):
+        return
+    _SVD_PENDING[_devkey(device)] = False
+    if last_svd_status(device) != 0:
+        raise _lib.TcmiError("tcmi_svd_trunc_batched: inter-workgroup barrier timed out (workgroups not co-resident); "
+                             "the factors of that decomposition are invalid")
 
 
 def svd_trunc(mat, max_singular_values: Optional[int] = None, max_truncation_err: Optional[float] = None,
@@ -197,6 +223,7 @@ def svd_trunc(mat, max_singular_values: Optional[int] = None, max_truncation_err
     static_keep = k if max_singular_values is None else min(int(max_singular_values), k)
     if _tracked(mat):
         return _svd_trunc_ad(mat, static_keep, max_truncation_err, relative, absorb)
+    _SVD_PENDING[_devkey(mat.device)] = True
     if m <= n:
         u, s, vh, keep, tw2 = _svd_rows(mat, static_keep, max_singular_values, max_truncation_err, relative, absorb)
     else:

@@ -554,6 +554,7 @@ class MPSCircuit:
 
     def wavefunction(self, form: str = "default") -> Tensor:
         torch = _torch()
+        LA.svd_health_check(_device())
         result = torch.ones((1, 1), dtype=_dtype(), device=_device())
         for t in self._mps.tensors:
             j, b, k = t.shape
@@ -591,6 +592,7 @@ class MPSCircuit:
 
     def amplitude(self, l: str) -> Tensor:
         assert len(l) == self._nqubits
+        LA.svd_health_check(_device())
         mats = [self._mps.tensors[i][:, int(ch), :] for i, ch in enumerate(l)]
         return reduce(LA.matmul, mats)[0, 0]
 
@@ -626,6 +628,7 @@ class MPSCircuit:
                     **kws: Any) -> Tensor:
         if split is None:
             split = {}
+        LA.svd_health_check(_device())    # no result is handed out from factors of a timed-out decomposition
         ops2 = [[op[0], [op[1]] if isinstance(op[1], int) else list(op[1])] for op in ops]
         all_sites = np.concatenate([op[1] for op in ops2])
         if other is None:

@@ -878,10 +878,10 @@ class ContractionTree:
                 # of the reconfiguration beam; the better one (model time) gets the rest (the 32-qubit RQC: 25.2 ms for
                 # the fixed-tree slicing, 19.3 ms for the interleaved one)
                 self._reconfigure_sliced(target_size, rounds=1)
-                a = (self.model_time(), self.path, self.sliced_inds)
+                a = (self.objective(), self.path, self.sliced_inds)
                 if self._slice_interleaved(start_path, target_size, max_slices, max_candidates):
                     self._reconfigure_sliced(target_size, rounds=1)
-                    if self.model_time() >= a[0]:
+                    if self.objective() >= a[0]:
                         self.path, self.sliced_inds = a[1], a[2]
                 else:
                     self.path, self.sliced_inds = a[1], a[2]
@@ -947,6 +947,57 @@ class ContractionTree:
                 t_inv += t
         return t_inv + self.nslices * t_sl
 
+    def objective(self) -> Any:
+        """What the tree search minimises (cotengra's ``minimize``, reference experimental.py:934-946): ``None`` = the
+        engine's own two-roof ``model_time``; "flops", "write", "size" (largest intermediate, then flops), "combo" /
+        "combo-<f>" = scalar operations + f x elements written (cotengra's default f = 64)."""
+        m = getattr(self, "minimize", None)
+        if m is None:
+            return self.model_time()
+        if m == "flops":
+            return float(self.total_flops())
+        if m == "write":
+            return float(self.total_write())
+        if m == "size":
+            return (self.max_size(), float(self.total_flops()))
+        if m == "max":
+            return (self.max_size(), float(self.total_write()))
+        if m.startswith("combo"):
+            f = float(m.split("-", 1)[1]) if "-" in m else 64.0
+            return self.total_flops() / 8.0 + f * self.total_write()
+        raise NotImplementedError(f"Backend 'hip' has not implemented minimize={m!r} "
+                                  f"(flops / write / size / max / combo / combo-<factor>)")
+
+    def slice_to_slices(self, target_slices: int, max_candidates: int = 12) -> "ContractionTree":
+        """cotengra's ``slicing_opts={"target_slices": S}`` (reference examples/slicing_auto_pmap_vqa.py:86-94): slice
+        until there are at least S slices -- one per device -- whatever the size of the intermediates.  Greedy on the
+        current tree: of the indices of the largest intermediates take the one that leaves the smallest objective."""
+        out = set(self.output)
+        while self.nslices < int(target_slices):
+            score: Dict[int, int] = {}
+            for _, _, k in self._walk():
+                sz = self._size(k)
+                for e in k:
+                    if e not in out:
+                        score[e] = score.get(e, 0) + sz
+            for sa, sb, _ in self._walk():          # contracted indices never appear in an output set
+                for e in sa & sb:
+                    if e not in out:
+                        score.setdefault(e, self._size(sa | sb))
+            if not score:
+                break
+            base = list(self.sliced_inds)
+            best = None
+            for e in sorted(score, key=lambda e: (-score[e], e))[:max_candidates]:
+                self.sliced_inds = base + [e]
+                key = (self.objective(), e)
+                if best is None or key < best:
+                    best = key
+            self.sliced_inds = base + [best[1]]
+        if getattr(self, "trials", 0) > 0 and self.sliced_inds:
+            self._reconfigure_sliced(self.max_size())
+        return self
+
     def _reconfigure_sliced(self, target_size: int, rounds: Optional[int] = None, flops_pass: bool = True) -> None:
         """Subtree reconfiguration of the sliced network under the size cap (what cotengra's
         ``slicing_reconf_opts`` does after choosing the sliced indices): first for flops, then -- the engine is
@@ -967,7 +1018,10 @@ class ContractionTree:
         # later rounds with the full subtree size from the two best trees so far
         def tried(path):
             self.path = path
-            return self.model_time() if self.max_size() <= target_size else float("inf")
+            if self.max_size() > target_size:
+                return float("inf")
+            o = self.objective()
+            return o if not isinstance(o, tuple) else float(o[0]) * 1e30 + o[1]
 
         start = self.path
         beam = [(tried(start), start)]
@@ -1115,6 +1169,100 @@ class ContractionTree:
             if final_perm is not None:
                 res = permute(res, final_perm)
             yield res
+
+    def contract_slices_vjp(self, arrays: Sequence[Any], slice_ids: Sequence[int], fop, need=None):
+        """``sum_i fop(contract_core(slice_arrays(arrays, i)))`` and its gradient with respect to every array, by a
+        reverse sweep over the step list instead of a framework tape (reference ``experimental.py:1182-1211``:
+        ``value_and_grad`` of ``contract_core`` per slice, summed).  Every forward AND backward step is one launch of
+        the untaped engine (``tcmi_tensordot_bits`` / ``tcmi_contract_scattered`` / ``tcmi_cgemm``): the VJP of a
+        tensordot is two tensordots (``tensordot_vjp``).  Intermediates live for one slice only; the slice-invariant
+        subtrees are contracted once, their cotangents accumulate over the slices and are pulled back once at the end.
+
+        ``fop`` maps a slice result to a real scalar (linear in the result, as in the reference);
+        ``need[k]`` = whether array k wants a gradient (default: ``requires_grad``).  Returns (value, grads) with
+        ``grads[k]`` shaped like ``arrays[k]`` (or None)."""
+        import torch
+
+        steps, dep, last, final_perm = self._symbolic_steps()
+        n = len(self.inputs)
+        slice_ids = list(slice_ids)
+        raw = [a.detach() for a in arrays]
+        if need is None:
+            need = [bool(a.requires_grad) for a in arrays]
+        needs = {k: bool(need[k]) for k in range(n)}
+        for ia, ib, xa, xb, io in steps:
+            needs[io] = needs[ia] or needs[ib]
+        total = None
+        grads: List[Any] = [None] * n
+        ginv: Dict[int, Any] = {}
+        inv_perm = None
+        if final_perm is not None:
+            inv_perm = [0] * len(final_perm)
+            for i, p in enumerate(final_perm):
+                inv_perm[p] = i
+
+        def acc(store, k, g):
+            store[k] = g if store.get(k) is None else store[k] + g
+
+        with torch.no_grad():
+            shared_t: Dict[int, Any] = {k: raw[k].contiguous() for k in range(n) if not dep[k]}
+            for ia, ib, xa, xb, io in steps:
+                if not dep[io]:
+                    shared_t[io] = _tensordot_raw(shared_t[ia], shared_t[ib], xa, xb)
+            for i in slice_ids:
+                vals = self.slice_index_values(i)
+                idx = [tuple(vals[e] if e in vals else slice(None) for e in edges) for edges in self.inputs]
+                cur: Dict[int, Any] = {k: raw[k][idx[k]].contiguous() for k in range(n) if dep[k]}
+                for ia, ib, xa, xb, io in steps:
+                    if dep[io]:
+                        cur[io] = _tensordot_raw(cur[ia] if dep[ia] else shared_t[ia], cur[ib] if dep[ib] else shared_t[ib], xa, xb)
+                res = cur[last] if dep[last] else shared_t[last]
+                if final_perm is not None:
+                    res = _permute_raw(res, final_perm)
+                with torch.enable_grad():
+                    r_ = res.detach().requires_grad_(True)
+                    v = fop(r_)
+                    (g,) = torch.autograd.grad(v, r_)
+                total = v.detach() if total is None else total + v.detach()
+                if not needs[last]:
+                    continue
+                g = g.contiguous()
+                if inv_perm is not None:
+                    g = _permute_raw(g, inv_perm)
+                gbar: Dict[int, Any] = {}
+                acc(gbar if dep[last] else ginv, last, g)
+                for ia, ib, xa, xb, io in reversed(steps):
+                    if not dep[io] or io not in gbar:
+                        continue
+                    gio = gbar.pop(io)
+                    ta = cur[ia] if dep[ia] else shared_t[ia]
+                    tb = cur[ib] if dep[ib] else shared_t[ib]
+                    ga, gb = tensordot_vjp(ta, tb, xa, xb, gio, needs[ia], needs[ib])
+                    del cur[io]
+                    if ga is not None:
+                        acc(gbar if dep[ia] else ginv, ia, ga)
+                    if gb is not None:
+                        acc(gbar if dep[ib] else ginv, ib, gb)
+                for k in range(n):
+                    if dep[k] and k in gbar:
+                        if grads[k] is None:
+                            grads[k] = torch.zeros_like(raw[k])
+                        grads[k][idx[k]] += gbar[k]
+                del cur, gbar
+            # pull the accumulated cotangents of the slice-invariant intermediates back to their leaves
+            for ia, ib, xa, xb, io in reversed(steps):
+                if dep[io] or io not in ginv:
+                    continue
+                gio = ginv.pop(io)
+                ga, gb = tensordot_vjp(shared_t[ia], shared_t[ib], xa, xb, gio, needs[ia], needs[ib])
+                if ga is not None:
+                    acc(ginv, ia, ga)
+                if gb is not None:
+                    acc(ginv, ib, gb)
+            for k in range(n):
+                if not dep[k] and k in ginv and need[k]:
+                    grads[k] = ginv[k].reshape(raw[k].shape)
+        return total, [g if need[k] else None for k, g in enumerate(grads)]
 
     def _run_steps(self, leaves: Dict[int, Any], shared_t: Dict[int, Any], invariant: bool):
         """The slice-invariant (``invariant``) or the slice-dependent steps, eagerly, on the given leaf tensors."""
@@ -1362,49 +1510,108 @@ def new_counters():
                              "scattered_launches", "scattered_flops", "scattered_bytes")}
 
 
+def _vjp_axes(rank_a, rank_b, axes_a, axes_b):
+    """Index bookkeeping of the two VJPs of ``c = tensordot(a, b, [axes_a, axes_b])`` (c axes = free(a), free(b)):
+    gA = transpose(tensordot(g, conj b, [g's b-part], [free(b)]), perm_a), gB likewise -- each again ONE tensordot of
+    the engine plus a bit permutation into the operand's own axis order."""
+    fa = [i for i in range(rank_a) if i not in axes_a]
+    fb = [i for i in range(rank_b) if i not in axes_b]
+    sb, sa = sorted(axes_b), sorted(axes_a)
+    # gA_raw axes: fa in order, then b's contracted axes in b's own order
+    perm_a = [fa.index(i) if i in fa else len(fa) + sb.index(axes_b[axes_a.index(i)]) for i in range(rank_a)]
+    # gB_raw axes: a's contracted axes in a's own order, then fb in order
+    perm_b = [len(sa) + fb.index(j) if j in fb else sa.index(axes_a[axes_b.index(j)]) for j in range(rank_b)]
+    return fa, fb, perm_a, perm_b
+
+
+def _conj(t):
+    return t.conj().resolve_conj()
+
+
+def tensordot_vjp(a, b, axes_a, axes_b, g, need_a=True, need_b=True):
+    """(gA, gB) of ``tensordot(a, b, [axes_a, axes_b])`` for the cotangent ``g`` (torch's convention for complex
+    tensors: gA = g . b^H), computed by the same kernels as the forward step -- the rule the reference gets from
+    JAX's transpose of ``dot_general`` (``experimental.py:1182-1211`` differentiates ``contract_core``)."""
+    fa, fb, perm_a, perm_b = _vjp_axes(a.dim(), b.dim(), axes_a, axes_b)
+    ga = gb = None
+    if need_a:
+        ga = _tensordot_raw(g, _conj(b), list(range(len(fa), len(fa) + len(fb))), fb)
+        ga = _permute_raw(ga, perm_a) if perm_a != list(range(a.dim())) else ga
+    if need_b:
+        gb = _tensordot_raw(_conj(a), g, fa, list(range(len(fa))))
+        gb = _permute_raw(gb, perm_b) if perm_b != list(range(b.dim())) else gb
+    return ga, gb
+
+
 def _fns():
     if _FN:
         return _FN
     import torch
 
+    def vmap_loop(fn, info, in_dims, *args):
+        outs = []
+        for i in range(info.batch_size):
+            outs.append(fn(*[a.select(d, i) if d is not None else a for a, d in zip(args, in_dims)]))
+        return torch.stack(outs), 0
+
+    # new-style Functions (setup_context + vmap rule): usable under torch.func.grad / vmap, which is how
+    # backend.value_and_grad / vmap / vvag reach K.tensordot / K.transpose / K.einsum
     class PermuteFn(torch.autograd.Function):
+        generate_vmap_rule = False
+
         @staticmethod
-        def forward(ctx, t, perm):
-            ctx.perm = tuple(perm)
-            return _permute_raw(t, perm)
+        def forward(t, perm):
+            return _permute_raw(t.contiguous(), perm)
+
+        @staticmethod
+        def setup_context(ctx, inputs, output):
+            ctx.perm = tuple(inputs[1])
+
+        @staticmethod
+        def vmap(info, in_dims, t, perm):
+            return vmap_loop(lambda x: PermuteFn.apply(x, perm), info, in_dims[:1], t)
 
         @staticmethod
         def backward(ctx, g):
             inv = [0] * len(ctx.perm)
             for i, p in enumerate(ctx.perm):
                 inv[p] = i
-            return PermuteFn.apply(g.contiguous(), tuple(inv)), None
+            return permute(g.contiguous(), tuple(inv)), None
 
-    class GemmFn(torch.autograd.Function):
-        """C[M,N] = A[M,K] B[K,N] on flat [2]*r tensors already in GEMM layout."""
+    class TensordotFn(torch.autograd.Function):
+        """``tensordot`` of two [2]^rank tensors with the fast kernels in BOTH directions: forward = the untaped route
+        (scattered / bit-deposit MFMA / permute + GEMM), backward = two more tensordots of the same engine."""
+        generate_vmap_rule = False
 
         @staticmethod
-        def forward(ctx, a, b, M, N, K):
+        def forward(a, b, axes_a, axes_b):
+            return _tensordot_raw(a, b, list(axes_a), list(axes_b))
+
+        @staticmethod
+        def setup_context(ctx, inputs, output):
+            a, b, axes_a, axes_b = inputs
             ctx.save_for_backward(a, b)
-            ctx.dims = (M, N, K)
-            return _gemm_raw(a, b, M, N, K)
+            ctx.axes = (tuple(axes_a), tuple(axes_b))
+
+        @staticmethod
+        def vmap(info, in_dims, a, b, axes_a, axes_b):
+            return vmap_loop(lambda x, y: TensordotFn.apply(x, y, axes_a, axes_b), info, in_dims[:2], a, b)
 
         @staticmethod
         def backward(ctx, g):
             a, b = ctx.saved_tensors
-            M, N, K = ctx.dims
-            ga = gb = None
+            xa, xb = list(ctx.axes[0]), list(ctx.axes[1])
             g = g.contiguous()
-            if ctx.needs_input_grad[0]:
-                # gA = g . B^H : (M x N)(N x K); B^H = conj(transpose(B)) via the bit-permute kernel
-                bh = _transpose2(b.conj().resolve_conj(), K, N)
-                ga = _gemm_raw(g, bh, M, K, N).reshape(a.shape)
-            if ctx.needs_input_grad[1]:
-                ah = _transpose2(a.conj().resolve_conj(), M, K)
-                gb = _gemm_raw(ah, g, K, N, M).reshape(b.shape)
-            return ga, gb, None, None, None
+            if _on_tape(a, b, g):      # double backward / nested transforms: stay differentiable
+                fa, fb, perm_a, perm_b = _vjp_axes(a.dim(), b.dim(), xa, xb)
+                ga = permute(tensordot(g, _conj(b), list(range(len(fa), len(fa) + len(fb))), fb), perm_a) \
+                    if ctx.needs_input_grad[0] else None
+                gb = permute(tensordot(_conj(a), g, fa, list(range(len(fa)))), perm_b) if ctx.needs_input_grad[1] else None
+                return ga, gb, None, None
+            ga, gb = tensordot_vjp(a, b, xa, xb, g, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+            return ga, gb, None, None
 
-    _FN.update(PermuteFn=PermuteFn, GemmFn=GemmFn)
+    _FN.update(PermuteFn=PermuteFn, TensordotFn=TensordotFn)
     return _FN
 
 
@@ -1419,7 +1626,9 @@ def _transpose2(t, rows, cols):
 
 def permute(t, perm):
     """Differentiable axis permutation on the device (K2)."""
-    perm = tuple(int(p) for p in perm)
+    perm = tuple(int(p) % max(1, t.dim()) for p in perm)
+    if sorted(perm) != list(range(t.dim())):
+        raise ValueError(f"permute: {perm} is not a permutation of the {t.dim()} axes")
     if perm == tuple(range(t.dim())):
         return t
     if not _on_tape(t):
@@ -1438,13 +1647,21 @@ def _on_tape(*ts) -> bool:
 
 def tensordot(a, b, axes_a: Sequence[int], axes_b: Sequence[int]):
     """``backend.tensordot(a, b, [axes_a, axes_b])`` on the HIP engine (K1b): result axes = a's free
-    axes in order, then b's (the ``contract_between`` convention)."""
+    axes in order, then b's (the ``contract_between`` convention).  Operands on an autograd tape (or inside a
+    ``torch.func`` transform) go through ``TensordotFn``: the same kernels forward, and backward."""
     import torch
 
     if a.dtype != b.dtype:
         dt = torch.promote_types(a.dtype, b.dtype)
         a, b = a.to(dt), b.to(dt)
     axes_a, axes_b = [int(x) for x in axes_a], [int(x) for x in axes_b]
+    if _on_tape(a, b):
+        return _fns()["TensordotFn"].apply(a, b, tuple(axes_a), tuple(axes_b))
+    return _tensordot_raw(a, b, axes_a, axes_b)
+
+
+def _tensordot_raw(a, b, axes_a, axes_b):
+    """The untaped step: scattered big x small kernel, else the bit-deposit MFMA kernel, else permute + GEMM."""
     fa = [i for i in range(a.dim()) if i not in axes_a]
     fb = [i for i in range(b.dim()) if i not in axes_b]
     r = _tensordot_scattered(a, b, axes_a, axes_b, fa, fb)
@@ -1453,10 +1670,10 @@ def tensordot(a, b, axes_a: Sequence[int], axes_b: Sequence[int]):
     r = _tensordot_bits(a, b, axes_a, axes_b)
     if r is not None:
         return r
-    a2 = permute(a, fa + axes_a)
-    b2 = permute(b, axes_b + fb)
+    a2 = _permute_raw(a.contiguous(), fa + axes_a)
+    b2 = _permute_raw(b.contiguous(), axes_b + fb)
     M, K, N = 2 ** len(fa), 2 ** len(axes_a), 2 ** len(fb)
-    c = _fns()["GemmFn"].apply(a2, b2, M, N, K) if _on_tape(a2, b2) else _gemm_raw(a2, b2, M, N, K)
+    c = _gemm_raw(a2, b2, M, N, K)
     return c.reshape([2] * (len(fa) + len(fb)))
 
 
@@ -1468,7 +1685,7 @@ def _tensordot_bits(a, b, axes_a, axes_b):
 
     if os.environ.get("TCMI_TN_BITS", "1") == "0":
         return None
-    if a.dtype != torch.complex64 or not a.is_cuda or not b.is_cuda or _on_tape(a, b):
+    if a.dtype != torch.complex64 or not a.is_cuda or not b.is_cuda:
         return None
     if a.dim() > 31 or b.dim() > 31 or any(d != 2 for d in a.shape) or any(d != 2 for d in b.shape):
         return None
@@ -1509,16 +1726,12 @@ def _tensordot_scattered(a, b, axes_a, axes_b, fa, fb):
         return None
     if nk > 5 and (small.numel() >> nk) > 16:
         return None
-    if torch.is_grad_enabled() and (a.requires_grad or b.requires_grad):
-        return None
-    if torch._C._functorch.is_functorch_wrapped_tensor(a) or torch._C._functorch.is_functorch_wrapped_tensor(b):
-        return None
     if any(d != 2 for d in big.shape) or any(d != 2 for d in small.shape):
         return None
     ax_big, ax_small = (axes_a, axes_b) if big_first else (axes_b, axes_a)
     f_small = fb if big_first else fa
     pairs = sorted(zip(ax_big, ax_small))                      # ascending big axis = descending bit position
-    small2 = permute(small, [p[1] for p in pairs] + list(f_small)).contiguous()
+    small2 = _permute_raw(small.contiguous(), [p[1] for p in pairs] + list(f_small)).contiguous()
     big = big.contiguous()
     rank = big.dim()
     pos = sorted(rank - 1 - p[0] for p in pairs)

@@ -15,10 +15,11 @@ def pytest_configure(config):
 
 
 MULTIRANK_OUT = os.path.join(ROOT, ".pytest_cache", "multirank_slices.json")
+MULTIRANK4_OUT = os.path.join(ROOT, ".pytest_cache", "multirank_slices_w4.json")
 
 
 def pytest_sessionstart(session):
-    """The two-rank DistributedContractor run of tests/test_gpu_multirank.py is started here, BEFORE this process
+    """The two-rank and four-rank DistributedContractor runs of tests/test_gpu_multirank.py are started here, BEFORE this process
     makes any HIP call: its ranks are fresh child processes with their own GPU contexts (a process that has
     initialised the GPU must not be the one that starts them on this pool).  Counting devices does not initialise."""
     expr = session.config.getoption("-m", default="") or ""
@@ -32,10 +33,11 @@ def pytest_sessionstart(session):
         if torch.cuda.device_count() < 1:
             return
         os.makedirs(os.path.dirname(MULTIRANK_OUT), exist_ok=True)
-        if os.path.exists(MULTIRANK_OUT):
-            os.remove(MULTIRANK_OUT)
-        subprocess.run([sys.executable, os.path.join(ROOT, "tests", "multirank_slices.py"), "2", MULTIRANK_OUT],
-                       timeout=900, check=False)
+        for world, out in ((2, MULTIRANK_OUT), (4, MULTIRANK4_OUT)):
+            if os.path.exists(out):
+                os.remove(out)
+            subprocess.run([sys.executable, os.path.join(ROOT, "tests", "multirank_slices.py"), str(world), out],
+                           timeout=900, check=False)
     except Exception as e:  # noqa: BLE001  (the test reports the missing file)
         print("multirank launcher failed:", e)
 

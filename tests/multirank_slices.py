@@ -91,6 +91,30 @@ def worker(rank, world, port, out):
         val = complex(dc.value(None, op=lambda x: x))
         res[tag] = {"nslices": int(dc.tree.nslices), "mine": dc.my_slices, "table": dc.slice_table.tolist(),
                     "value": [val.real, val.imag]}
+    # ---- the north-star workload (examples/slicing_auto_pmap_vqa.py:20-41,86-94): rzz / rx ladder, <Z_0>, sliced to
+    # one-or-more slices per rank with ``target_slices``; value_and_grad through the hand-written reverse sweep ----
+    nq, dq = 16, 4
+    pv = np.random.default_rng(5).uniform(0.2, 1.2, [nq, dq, 2])
+
+    def vqa_nodes(params):
+        c = tc.Circuit(nq)
+        for i in range(dq):
+            for j in range(nq - 1):
+                c.rzz(j, j + 1, theta=params[j, i, 0])
+            for j in range(nq):
+                c.rx(j, theta=params[j, i, 1])
+        return c.expectation_before([tc.gates.z(), [0]], reuse=False)
+
+    for dt in ("complex64", "complex128"):
+        tc.set_dtype(dt)
+        pt = tc.backend.convert_to_tensor(pv.astype(np.float32 if dt == "complex64" else np.float64))
+        dc = tc.experimental.DistributedContractor(
+            vqa_nodes, pt, {"slicing_opts": {"target_slices": 8}, "max_repeats": 16, "minimize": "combo", "parallel": True})
+        v, g = dc.value_and_grad(pt)
+        res["vqa_" + dt] = {"nslices": int(dc.tree.nslices), "mine": dc.my_slices, "value": float(v),
+                            "grad": tc.backend.numpy(g).astype(np.float64).tolist(),
+                            "value_only": float(dc.value(pt).real)}
+    tc.set_dtype("complex128")
     allres = [None] * world
     dist.all_gather_object(allres, res)
     if rank == 0:

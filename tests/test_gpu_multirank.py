@@ -9,7 +9,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-from conftest import MULTIRANK_OUT  # noqa: E402
+from conftest import MULTIRANK_OUT, MULTIRANK4_OUT  # noqa: E402
 from oracle import dense, gates as OG  # noqa: E402
 
 
@@ -74,5 +74,52 @@ def test_two_rank_slice_shard_equals_single_process():
         # one slice on two ranks: rank 1 holds only -1 padding and contributes zero (experimental.py:881-890)
         assert r0["rqc_padding"]["nslices"] == 1 and r0["rqc_padding"]["table"] == [[0], [-1]]
         assert r0["rqc_padding"]["mine"] == [0] and r1["rqc_padding"]["mine"] == []
+    finally:
+        tc.set_dtype("complex64")
+
+
+def test_four_rank_sliced_value_and_grad_equals_the_adjoint_path():
+    """World 4 (gloo on the one visible device, nccl when four are): the rzz / rx ladder of
+    examples/slicing_auto_pmap_vqa.py at 16 qubits, sliced with ``slicing_opts={"target_slices": 8}`` -- every rank
+    holds at least two slices -- and differentiated by the reverse sweep of ``tn.contract_slices_vjp`` (forward and
+    backward on tcmi_tensordot_bits / tcmi_contract_scattered / tcmi_cgemm) against ``backend.value_and_grad`` of the
+    same energy on the state-vector adjoint path of ONE process.  Tolerances: BASELINE.json (1e-5 / 1e-10)."""
+    assert os.path.exists(MULTIRANK4_OUT), "the four-rank run did not produce its result file (see the session log)"
+    ranks = json.load(open(MULTIRANK4_OUT))
+    assert len(ranks) == 4 and all(r["world"] == 4 for r in ranks)
+
+    import tcmi as tc
+
+    tc.set_backend("hip")
+    nq, dq = 16, 4
+    pv = np.random.default_rng(5).uniform(0.2, 1.2, [nq, dq, 2])
+
+    def energy(params):
+        c = tc.Circuit(nq)
+        for i in range(dq):
+            for j in range(nq - 1):
+                c.rzz(j, j + 1, theta=params[j, i, 0])
+            for j in range(nq):
+                c.rx(j, theta=params[j, i, 1])
+        return tc.backend.real(c.expectation_ps(z=[0]))
+
+    try:
+        for dt, tol in (("complex64", 1e-5), ("complex128", 1e-10)):
+            tc.set_dtype(dt)
+            pt = tc.backend.convert_to_tensor(pv.astype(np.float32 if dt == "complex64" else np.float64))
+            v, g = tc.backend.value_and_grad(energy)(pt)
+            v, g = float(v), tc.backend.numpy(g).astype(np.float64)
+            key = "vqa_" + dt
+            assert ranks[0][key]["nslices"] >= 8
+            held = sorted(sum((r[key]["mine"] for r in ranks), []))
+            assert held == list(range(ranks[0][key]["nslices"])) and all(len(r[key]["mine"]) >= 2 for r in ranks)
+            errs = []
+            for r in ranks:          # the packed all-reduce leaves value and gradient on every rank
+                assert abs(r[key]["value"] - v) < tol, (dt, r[key]["value"], v)
+                assert abs(r[key]["value_only"] - v) < tol
+                errs.append(np.abs(np.asarray(r[key]["grad"]) - g).max())
+            print(f"sliced vqa {dt}: value {v:.8f}, max |grad - adjoint| over ranks {max(errs):.2e}")
+            assert max(errs) < tol
+            assert np.abs(g).max() > 1e-3      # a gradient that is really there
     finally:
         tc.set_dtype("complex64")

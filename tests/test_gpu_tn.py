@@ -590,3 +590,47 @@ def test_graph_replay_follows_new_leaf_values_and_random_bitstrings():
         vals.append(v)
     assert getattr(dc.tree, "_graph_cache", None) is not None
     assert abs(vals[0] - vals[3]) < 1e-7
+
+
+@pytest.mark.parametrize("dt,tol", [("complex64", 1e-5), ("complex128", 1e-10)])
+def test_sliced_value_and_grad_on_the_fast_kernels_matches_the_adjoint_path(dt, tol, monkeypatch):
+    """Really sliced network (rzz / rx ladder of examples/slicing_auto_pmap_vqa.py, 18 qubits, >= 8 slices):
+    ``DistributedContractor.value_and_grad`` through the hand-written reverse sweep (``tn.contract_slices_vjp``: every
+    forward and backward step on the untaped kernels) against (a) ``backend.value_and_grad`` on the state-vector
+    adjoint path and (b) torch's tape over the same tree (TCMI_TN_VJP=0: ``TensordotFn``, same kernels step by step).
+    Reference: experimental.py:1182-1211."""
+    import tcmi as tc
+
+    tc.set_backend("hip")
+    tc.set_dtype(dt)
+    try:
+        nq, dq = 18, 4
+        pv = np.random.default_rng(11).uniform(0.2, 1.2, [nq, dq, 2]).astype(np.float32 if dt == "complex64" else np.float64)
+        pt = tc.backend.convert_to_tensor(pv)
+
+        def circuit(params):
+            c = tc.Circuit(nq)
+            for i in range(dq):
+                for j in range(nq - 1):
+                    c.rzz(j, j + 1, theta=params[j, i, 0])
+                for j in range(nq):
+                    c.rx(j, theta=params[j, i, 1])
+            return c
+
+        dc = tc.experimental.DistributedContractor(
+            lambda p: circuit(p).expectation_before([tc.gates.z(), [0]], reuse=False), pt,
+            {"slicing_opts": {"target_slices": 8}, "max_repeats": 16, "minimize": "combo"})
+        assert dc.tree.nslices >= 8
+        v, g = dc.value_and_grad(pt)
+        v0, g0 = tc.backend.value_and_grad(lambda p: tc.backend.real(circuit(p).expectation_ps(z=[0])))(pt)
+        monkeypatch.setenv("TCMI_TN_VJP", "0")
+        v1, g1 = dc.value_and_grad(pt)
+        e_adj = float((g - g0).abs().max())
+        e_tape = float((g - g1).abs().max())
+        print(f"sliced value_and_grad {dt}: {dc.tree.nslices} slices, |v - adjoint| {abs(float(v) - float(v0)):.2e}, "
+              f"max |g - adjoint| {e_adj:.2e}, max |g - tape| {e_tape:.2e}")
+        assert abs(float(v) - float(v0)) < tol and abs(float(v) - float(v1)) < tol
+        assert e_adj < tol and e_tape < tol
+        assert float(g0.abs().max()) > 1e-3
+    finally:
+        tc.set_dtype("complex64")

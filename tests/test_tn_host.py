@@ -284,3 +284,109 @@ def test_path_search_is_identical_across_processes():
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1]
+
+
+@pytest.mark.parametrize("dangling", [0, 2])
+def test_hand_written_reverse_sweep_equals_the_framework_tape(monkeypatch, dangling):
+    """``contract_slices_vjp`` (the sliced value_and_grad route of DistributedContractor, reference
+    experimental.py:1182-1211) against torch autograd through the same tree: torch stand-ins replace the two raw
+    device launches, so this checks the axis bookkeeping of ``tensordot_vjp``, the per-slice scatter of the leaf
+    cotangents and the once-only pull-back through the slice-invariant subtrees."""
+    import torch
+    from tcmi import tn
+
+    inputs, output, sd = _rand_net(36, 3, 5, dangling=dangling)
+    tree = tn.ContractionTree.from_path(inputs, output, sd, trials=4, seed=0)
+    tree.slice_to(max(4, tree.max_size() // 8))
+    assert tree.nslices >= 4
+    rng = np.random.default_rng(9)
+    arrays = [torch.from_numpy(rng.normal(size=[2] * len(s)) + 1j * rng.normal(size=[2] * len(s))).requires_grad_(k % 3 != 1)
+              for k, s in enumerate(inputs)]
+    monkeypatch.setattr(tn, "_tensordot_raw", lambda a, b, xa, xb: torch.tensordot(a, b, (list(xa), list(xb))))
+    monkeypatch.setattr(tn, "_permute_raw", lambda t, perm: t.permute(*perm).contiguous())
+    wts = torch.from_numpy(np.asarray(rng.normal(size=[2] * len(tree.output)) + 1j * rng.normal(size=[2] * len(tree.output))))
+    fop = lambda x: (x * wts).sum().real
+    ids = list(range(tree.nslices))
+    total, grads = tree.contract_slices_vjp(arrays, ids, fop)
+    # reference: the framework tape through contract_core, slice by slice
+    monkeypatch.setattr(tn, "tensordot", lambda a, b, xa, xb: torch.tensordot(a, b, (list(xa), list(xb))))
+    monkeypatch.setattr(tn, "permute", lambda t, perm: t.permute(*perm).contiguous())
+    want = sum(fop(tree.contract_core(tree.slice_arrays(arrays, i))) for i in ids)
+    wg = torch.autograd.grad(want, [a for a in arrays if a.requires_grad])
+    np.testing.assert_allclose(float(total), float(want), rtol=1e-12)
+    it = iter(wg)
+    for a, g in zip(arrays, grads):
+        if not a.requires_grad:
+            assert g is None
+            continue
+        np.testing.assert_allclose(g.numpy(), next(it).numpy(), atol=1e-10)
+    # a subset of the slices (what one rank of a slice shard holds)
+    t2, g2 = tree.contract_slices_vjp(arrays, ids[1:3], fop)
+    w2 = sum(fop(tree.contract_core(tree.slice_arrays(arrays, i))) for i in ids[1:3])
+    np.testing.assert_allclose(float(t2), float(w2), rtol=1e-12)
+
+
+def test_engine_ops_work_under_torch_func_transforms(monkeypatch):
+    """``tn.tensordot`` / ``tn.permute`` on operands inside ``torch.func.grad`` / ``vmap`` (how backend.value_and_grad,
+    vmap and vvag reach ``K.tensordot`` / ``K.transpose`` / ``K.einsum``): the two autograd Functions carry
+    ``setup_context`` and a vmap rule.  Raw launches replaced by torch stand-ins."""
+    import torch
+    from tcmi import tn
+
+    monkeypatch.setattr(tn, "_tensordot_raw", lambda a, b, xa, xb: torch.tensordot(a, b, (list(xa), list(xb))))
+    monkeypatch.setattr(tn, "_permute_raw", lambda t, perm: t.permute(*perm).contiguous())
+    rng = np.random.default_rng(0)
+    a = torch.from_numpy(rng.normal(size=[2] * 5) + 1j * rng.normal(size=[2] * 5))
+    b = torch.from_numpy(rng.normal(size=[2] * 4) + 1j * rng.normal(size=[2] * 4))
+
+    def f_engine(x, y):
+        return (tn.permute(tn.tensordot(x, y, [1, 3], [2, 0]), (-1, 0, 3, 1, 2)).abs() ** 2).sum()
+
+    def f_torch(x, y):
+        return (torch.tensordot(x, y, ([1, 3], [2, 0])).permute(4, 0, 3, 1, 2).abs() ** 2).sum()
+
+    (ga, gb), v = torch.func.grad_and_value(f_engine, argnums=(0, 1))(a, b)
+    (wa, wb), w = torch.func.grad_and_value(f_torch, argnums=(0, 1))(a, b)
+    np.testing.assert_allclose(float(v), float(w), rtol=1e-12)
+    np.testing.assert_allclose(ga.numpy(), wa.numpy(), atol=1e-10)
+    np.testing.assert_allclose(gb.numpy(), wb.numpy(), atol=1e-10)
+    ab = torch.stack([a, 2 * a, a.conj()])
+    got = torch.func.vmap(lambda x: f_engine(x, b))(ab)
+    want = torch.stack([f_torch(x, b) for x in ab])
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-12)
+    gv = torch.func.vmap(torch.func.grad(f_engine), in_dims=(0, None))(ab, b)
+    wv = torch.stack([torch.func.grad(f_torch)(x, b) for x in ab])
+    np.testing.assert_allclose(gv.numpy(), wv.numpy(), atol=1e-10)
+    with pytest.raises(ValueError):
+        tn.permute(a, (0, 0, 1, 2, 3))
+
+
+def test_cotengra_options_are_honoured_or_refused():
+    """reference experimental.py:934-946 passes ``cotengra_options`` to ``ctg.ReusableHyperOptimizer``; the
+    north-star example sets ``slicing_opts={"target_slices": num_device}``, ``minimize="combo"``
+    (examples/slicing_auto_pmap_vqa.py:86-94).  Here: understood keys act, everything else raises."""
+    from tcmi import tn
+    from tcmi.experimental import DistributedContractor as DC
+
+    o = DC._parse_options({"slicing_opts": {"target_slices": 8}, "max_repeats": 16, "progbar": True,
+                           "minimize": "combo", "parallel": True})
+    assert o["target_slices"] == 8 and o["target_size"] is None and o["minimize"] == "combo" and o["max_repeats"] == 16
+    assert DC._parse_options(None)["target_size"] == 2**28
+    for bad in ({"optlib": "optuna"}, {"slicing_opts": {"target_overhead": 2}}, {"minimize": "foo"},
+                {"methods": ["kahypar"]}, {"max_time": 3}):
+        with pytest.raises(NotImplementedError):
+            DC._parse_options(bad)
+    inputs, output, sd = _rand_net(30, 3, 4, dangling=0)
+    base = tn.ContractionTree.from_path(inputs, output, sd, trials=4, seed=0)
+    for minimize in (None, "flops", "write", "combo", "size"):
+        t = tn.ContractionTree.from_path(inputs, output, sd, trials=4, seed=0)
+        t.minimize = minimize
+        t.slice_to_slices(8)
+        assert t.nslices >= 8 and t.nslices <= 16, (minimize, t.nslices)
+        assert t.max_size() <= base.max_size()
+    # both limits at once: the size cap first, then at least that many slices
+    t = tn.ContractionTree.from_path(inputs, output, sd, trials=4, seed=0)
+    t.slice_to(max(4, base.max_size() // 4))
+    cap = t.max_size()
+    t.slice_to_slices(16)
+    assert t.nslices >= 16 and t.max_size() <= cap
