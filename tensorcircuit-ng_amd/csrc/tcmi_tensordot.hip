@@ -158,6 +158,119 @@ __global__ __launch_bounds__(256, 6) void cgemm_mfma_kernel(const float2* __rest
   }
 }
 
+// ---- the same product for a k-major A ([K][M], the cut join's L^T), software-pipelined with LDS-DMA -------------------
+// cgemm_mfma_kernel stages its operand tiles through VGPRs and waits for every load (single buffer, two barriers per
+// K step): a workgroup's MFMA phase (24 x 64 cycles per wave and K step) never overlaps its own loads, and the other
+// resident workgroups fill in only partly -- 0.71-0.74 of the f32 MFMA peak on the join GEMM (profiles/r02o_*).  Here
+// the tiles go global -> LDS directly (global_load_lds_dwordx4: 1 KiB per wave instruction, no staging registers, no
+// ds_write pass) into a ring of DMA_STAGES buffers; the loads of K step i + DMA_STAGES - 1 are issued before the MFMAs
+// of step i, there is ONE raw s_barrier per K step and the only wait on the memory counter is a counted vmcnt that
+// leaves the younger stages in flight across the barrier.
+//   * LDS tile = the global layout: [16 k][64 m] interleaved (re, im), 512 B per k row; an MFMA operand fragment is ONE
+//     ds_read_b64 per lane (lanes 0-31: 256 contiguous bytes of row k, lanes 32-63: row k + 1 -- conflict-free).
+//   * Gauss's 3-product form as in cgemm_mfma_kernel (P1 = Ar Br, P2 = Ai Bi, P3 = (Ar + Ai)(Br + Bi)).
+//   * blockIdx -> tile mapping is XCD-aware: consecutive workgroups go to the 8 XCDs round-robin, so workgroup id L
+//     belongs to XCD L % 8 and is that XCD's (L / 8)-th tile; every XCD walks its own 16-column strip of C row by
+//     row, i.e. its L2 holds one A row-tile and 16 B column-tiles (2.1 MB of 4 MB) instead of the whole operands.
+// Requirements (host checks): M, N multiples of 64, K a multiple of 16, 16-byte aligned batch bases.
+#define TCMI_DMA_BK 16
+#define TCMI_DMA_STAGE_BYTES (2 * TCMI_DMA_BK * 64 * 8)
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int STAGES>
+__global__ __launch_bounds__(256, 3) void cgemm_dma_kernel(const float2* __restrict__ A, const float2* __restrict__ B,
+                                                        float2* __restrict__ C, int M, int N, int K, long long sA,
+                                                        long long sB, long long sC, int tiles_x, int tiles_y) {
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  // XCD-aware tile walk (see above); falls back to the plain order when the grid does not split into 8 strips
+  int tx, ty;
+  {
+    const unsigned L = blockIdx.x, ntile = (unsigned)tiles_x * (unsigned)tiles_y;
+    if ((tiles_x & 7) == 0 && (ntile & 7) == 0) {
+      const unsigned xcd = L & 7u, j = L >> 3, sw = (unsigned)tiles_x >> 3;   // strip width in tiles
+      tx = (int)(xcd * sw + j % sw);
+      ty = (int)(j / sw);
+    } else {
+      tx = (int)(L % (unsigned)tiles_x);
+      ty = (int)(L / (unsigned)tiles_x);
+    }
+  }
+  const long long m0 = (long long)ty * 64, n0 = (long long)tx * 64;
+  A += (long long)blockIdx.y * sA + m0;
+  B += (long long)blockIdx.y * sB + n0;
+  C += (long long)blockIdx.y * sC;
+  // DMA source of this lane: k row (4 wave + 2 h + lane / 32) of the stage, 16 bytes = two complex at column 2 (lane % 32)
+  const float2* ag = A + (long long)(4 * wave + (lane >> 5)) * M + 2 * (lane & 31);
+  const float2* bg = B + (long long)(4 * wave + (lane >> 5)) * N + 2 * (lane & 31);
+  const long long a2 = 2ll * M, b2 = 2ll * N, a16 = 16ll * M, b16 = 16ll * N;
+  const int nk = K / TCMI_DMA_BK;
+#define TCMI_DMA_ISSUE(KT, ST)                                                                                         \
+  {                                                                                                                    \
+    char* sb_ = dsm + (ST) * TCMI_DMA_STAGE_BYTES + wave * 2048;                                                       \
+    const float2* ap_ = ag + (long long)(KT) * a16;                                                                    \
+    const float2* bp_ = bg + (long long)(KT) * b16;                                                                    \
+    __builtin_amdgcn_global_load_lds((gptr_t)ap_, (lptr_t)sb_, 16, 0, 0);                                              \
+    __builtin_amdgcn_global_load_lds((gptr_t)(ap_ + a2), (lptr_t)(sb_ + 1024), 16, 0, 0);                             \
+    __builtin_amdgcn_global_load_lds((gptr_t)bp_, (lptr_t)(sb_ + 8192), 16, 0, 0);                                    \
+    __builtin_amdgcn_global_load_lds((gptr_t)(bp_ + b2), (lptr_t)(sb_ + 8192 + 1024), 16, 0, 0);                      \
+  }
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < nk) TCMI_DMA_ISSUE(s, s)
+  f32x16 p1 = {0}, p2 = {0}, p3 = {0};
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)dsm;
+  // fragment addresses inside a stage: row (lane / 32) of the k pair, element wr * 32 + lane % 32 (A) / wc * 32 + ... (B)
+  const int fa = (lane >> 5) * 512 + (wr * 32 + (lane & 31)) * 8;
+  const int fb = 8192 + (lane >> 5) * 512 + (wc * 32 + (lane & 31)) * 8;
+  int st = 0;
+  for (int i = 0; i < nk; ++i) {
+    // this wave's DMA pieces of stage i have landed (younger stages stay in flight), then everybody's have
+    if (i + STAGES - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (STAGES - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // the buffer of stage i - 1 is free now (every wave finished its MFMAs on it before the barrier): refill it
+    if (i + STAGES - 1 < nk) {
+      const int sn = (st == 0) ? STAGES - 1 : st - 1;
+      TCMI_DMA_ISSUE(i + STAGES - 1, sn)
+    }
+    // operand fragments of the whole K step: 16 ds_read_b64 issued together from inline asm (the compiler would put a
+    // vmcnt(0) in front of any LDS read it can see while an LDS-DMA is outstanding -- that wait would drain the
+    // prefetch just issued), then an uninterrupted MFMA stream (anything issued between the MFMAs of a wave costs
+    // matrix-pipe time: reads interleaved with the MFMAs measured 7 % slower)
+    const uint32_t sa_ = lds0 + (uint32_t)(st * TCMI_DMA_STAGE_BYTES) + (uint32_t)fa;
+    const uint32_t sb_ = lds0 + (uint32_t)(st * TCMI_DMA_STAGE_BYTES) + (uint32_t)fb;
+    v2f fa_[TCMI_DMA_BK / 2], fb_[TCMI_DMA_BK / 2];
+#pragma unroll
+    for (int q = 0; q < TCMI_DMA_BK / 2; ++q) {
+      asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fa_[q]) : "v"(sa_), "n"(q * 1024));
+      asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fb_[q]) : "v"(sb_), "n"(q * 1024));
+    }
+#pragma unroll
+    for (int q = 0; q < TCMI_DMA_BK / 2; ++q) {
+      asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(fa_[q]), "+v"(fb_[q]) : "n"(TCMI_DMA_BK - 2 - 2 * q));
+      p1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[q].x, fb_[q].x, p1, 0, 0, 0);
+      p2 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[q].y, fb_[q].y, p2, 0, 0, 0);
+      p3 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[q].x + fa_[q].y, fb_[q].x + fb_[q].y, p3, 0, 0, 0);
+    }
+    st = (st + 1 == STAGES) ? 0 : st + 1;
+  }
+#undef TCMI_DMA_ISSUE
+  const long long col = n0 + wc * 32 + (lane & 31);
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const long long row = m0 + wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    float2 o;
+    o.x = p1[reg] - p2[reg];
+    o.y = p3[reg] - p1[reg] - p2[reg];
+    C[row * N + col] = o;
+  }
+}
+
 // ---- tensordot of two [2]^rank tensors straight from their stored layouts (complex64) --------------------------------
 // C[m][n] = sum_k A[rowA(m) | kA(k)] * B[kB(k) | colB(n)]: every index bit of M, N and K sits at its own address bit of
 // the operand (row bit j of A at pa.free[j], k bit j at pa.k[j] in A and pb.k[j] in B, column bit j of B at
@@ -1036,6 +1149,31 @@ int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, 
           if (me != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(me));
         }
       }
+    }
+    // k-major A, whole tiles, no split-K (the cut join): the LDS-DMA pipelined kernel
+    static const bool dma_off = getenv("TCMI_GEMM_DMA") && getenv("TCMI_GEMM_DMA")[0] == '0';
+    if (trans_a && !dma_off && ksplit == 1 && (M % 64) == 0 && (N % 64) == 0 && (K % TCMI_DMA_BK) == 0 &&
+        (M / 64) * (N / 64) < (1ll << 31) && (strideA & 1) == 0 && (strideB & 1) == 0 &&
+        (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0) {
+      const int txn = (int)(N / 64), tyn = (int)(M / 64);
+      static const int stages = getenv("TCMI_GEMM_STAGES") ? atoi(getenv("TCMI_GEMM_STAGES")) : 3;
+      dim3 grid((unsigned)((long long)txn * tyn), (unsigned)batch, 1), block(256, 1, 1);
+#define TCMI_DMA_LAUNCH(S)                                                                                           \
+  {                                                                                                                  \
+    if ((S) * TCMI_DMA_STAGE_BYTES > 48 * 1024)                                                                      \
+      hipFuncSetAttribute(reinterpret_cast<const void*>(tcmi::cgemm_dma_kernel<S>),                                 \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (S) * TCMI_DMA_STAGE_BYTES);                  \
+    hipLaunchKernelGGL(tcmi::cgemm_dma_kernel<S>, grid, block, (S) * TCMI_DMA_STAGE_BYTES, st,                      \
+                       reinterpret_cast<const float2*>(A), reinterpret_cast<const float2*>(B),                      \
+                       reinterpret_cast<float2*>(C), (int)M, (int)N, (int)K, strideA, strideB, strideC, txn, tyn);  \
+  }
+      if (stages == 2) TCMI_DMA_LAUNCH(2)
+      else if (stages == 4) TCMI_DMA_LAUNCH(4)
+      else TCMI_DMA_LAUNCH(3)
+#undef TCMI_DMA_LAUNCH
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));
+      return TCMI_OK;
     }
     for (long long m0 = 0; m0 < M; m0 += mchunk) {
       const long long mm = (M - m0 < mchunk) ? (M - m0) : mchunk;

@@ -65,16 +65,17 @@ def _host_number(v):
 
 
 def _is_complex_angle(v) -> bool:
-    """A gate angle with a non-zero imaginary part: a python / numpy complex scalar or a complex 0-d tensor that
-    already lives on the host.  A DEVICE tensor is never inspected (reference-style code casts every parameter to
-    the complex dtype; reading one back per gate would block the host behind the stream): its real part is the
-    angle, as for tensors on the autograd tape."""
+    """A gate angle with a non-zero imaginary part: a python / numpy complex scalar, or a STANDALONE complex 0-d tensor
+    (``tc.num_to_tensor(0.8 + 0.7j)``, reference tests/test_circuit.py:404-445).  Elements / views of a parameter array
+    are never inspected -- reference-style code casts every parameter to the complex dtype, and reading one value back
+    per gate would block the host behind the stream; their real part is the angle, as for tensors on the autograd
+    tape.  A standalone device scalar costs one read-back."""
     if isinstance(v, (complex, np.complexfloating)):
         return complex(v).imag != 0.0
     if _is_tensor(v) and not isinstance(v, np.ndarray):
         import torch
 
-        if torch.is_tensor(v) and v.is_complex() and v.numel() == 1 and not v.is_cuda and not v.requires_grad \
+        if torch.is_tensor(v) and v.is_complex() and v.numel() == 1 and not v.requires_grad and v._base is None \
                 and not torch._C._functorch.is_functorch_wrapped_tensor(v):
             return complex(v.detach().reshape(-1)[0].item()).imag != 0.0
     return False

@@ -634,3 +634,37 @@ def test_sliced_value_and_grad_on_the_fast_kernels_matches_the_adjoint_path(dt, 
         assert float(g0.abs().max()) > 1e-3
     finally:
         tc.set_dtype("complex64")
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 16), (64, 64, 32), (128, 192, 48), (512, 320, 256), (4096, 4096, 256),
+                                   (64, 4096, 1024)])
+def test_dma_pipelined_join_gemm_matches_complex128_and_the_plain_kernel(shape, monkeypatch):
+    """k-major A with whole 64 x 64 tiles and K a multiple of 16 (the cut-contraction join, cut.py) runs on
+    ``cgemm_dma_kernel``: LDS-DMA ring of 3 stages, one barrier per K step, XCD-aware tile walk.  Same numbers as a
+    complex128 product (f32 accumulation bound) and, per element, close to the register-staged kernel
+    (TCMI_GEMM_DMA is read once per process, so that comparison uses a shape the DMA kernel does not take)."""
+    import torch
+    from tcmi import _lib
+
+    M, N, K = shape
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    batch = 3 if M * N <= 1 << 20 else 2
+    a = torch.randn(batch, K, M, dtype=torch.complex64, device="cuda", generator=g) / np.sqrt(K)   # [K][M]: k-major
+    b = torch.randn(batch, K, N, dtype=torch.complex64, device="cuda", generator=g)
+    c = torch.full((batch, M, N), float("nan"), dtype=torch.complex64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):   # repeated launches: a ring-buffer race would show up as run-to-run differences
+        c.fill_(float("nan"))
+        _lib.check(_lib.lib().tcmi_cgemm(a.data_ptr(), b.data_ptr(), c.data_ptr(), M, N, K, batch, M * K, K * N, M * N,
+                                         1, _lib.TCMI_C64, st), "tcmi_cgemm")
+        ref = a.transpose(1, 2).to(torch.complex128) @ b.to(torch.complex128)
+        err = float((c - ref).abs().max()) / float(ref.abs().max())
+        assert err < 2e-5, (shape, err)
+    # ragged neighbour shape -> the register-staged kernel; its leading 64-aligned block must agree with the DMA result
+    if M >= 128:
+        M2 = M - 8
+        a2 = a[:, :, :M2].contiguous()
+        c2 = torch.empty(batch, M2, N, dtype=torch.complex64, device="cuda")
+        _lib.check(_lib.lib().tcmi_cgemm(a2.data_ptr(), b.data_ptr(), c2.data_ptr(), M2, N, K, batch, M2 * K, K * N,
+                                         M2 * N, 1, _lib.TCMI_C64, st), "tcmi_cgemm")
+        assert float((c2 - c[:, :M2]).abs().max()) < 1e-5 * float(ref.abs().max())
