@@ -271,6 +271,134 @@ __global__ __launch_bounds__(256, 3) void cgemm_dma_kernel(const float2* __restr
   }
 }
 
+// ---- 128 x 128 workgroup tile, 64 x 64 per wave (2 x 2 MFMA tiles, three Gauss products each: 12 accumulators) --------
+// scripts/ubench/mfma_gemm_steps.hip: the f32 matrix pipe issues a bare MFMA chain at 65 cycles per v_mfma_f32_32x32x2,
+// but every other instruction of the issuing wave costs it 4-6 cycles -- the 64 x 64 tile's K step (24 MFMAs, 16 LDS
+// reads, 16 adds, 4 DMA pieces, a barrier) runs at 72-77 cycles per MFMA in isolation and 80 in the kernel.  The
+// register tile here needs ONE ds_read_b128 per operand and k pair for 12 MFMAs (a lane's 16 bytes hold two
+// neighbouring rows / columns of the same k, which become the two A / B fragments), 4 adds and 2/3 of a DMA piece:
+// 0.6 instead of 1.5 other instructions per MFMA.  Stage = A [16 k][128 m] + B [16 k][128 n] interleaved complex =
+// 32 KiB, two stages, two workgroups per CU (accumulators in AGPRs: 192 + 48 fragment registers per lane).
+#define TCMI_T128_STAGE_BYTES (2 * TCMI_DMA_BK * 128 * 8)
+typedef float v4f_ __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256, 2) void cgemm_dma128_kernel(const float2* __restrict__ A, const float2* __restrict__ B,
+                                                              float2* __restrict__ C, int M, int N, int K, long long sA,
+                                                              long long sB, long long sC, int tiles_x, int tiles_y) {
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  int tx, ty;
+  {
+    const unsigned L = blockIdx.x, ntile = (unsigned)tiles_x * (unsigned)tiles_y;
+    if ((tiles_x & 7) == 0 && (ntile & 7) == 0) {
+      const unsigned xcd = L & 7u, j = L >> 3, sw = (unsigned)tiles_x >> 3;
+      tx = (int)(xcd * sw + j % sw);
+      ty = (int)(j / sw);
+    } else {
+      tx = (int)(L % (unsigned)tiles_x);
+      ty = (int)(L / (unsigned)tiles_x);
+    }
+  }
+  const long long m0 = (long long)ty * 128, n0 = (long long)tx * 128;
+  A += (long long)blockIdx.y * sA + m0;
+  B += (long long)blockIdx.y * sB + n0;
+  C += (long long)blockIdx.y * sC;
+  // DMA: piece = one k row of a tile (128 complex = 1 KiB = 64 lanes x 16 bytes); wave w moves rows 4w .. 4w + 3 of A and B
+  const float2* ag = A + (long long)(4 * wave) * M + 2 * lane;
+  const float2* bg = B + (long long)(4 * wave) * N + 2 * lane;
+  const int nk = K / TCMI_DMA_BK;
+#define TCMI_DMA_ISSUE(KT, ST)                                                                                   \
+  {                                                                                                              \
+    char* sb_ = dsm + (ST) * TCMI_T128_STAGE_BYTES + wave * 4096;                                                \
+    const float2* ap_ = ag + (long long)(KT) * 16 * M;                                                           \
+    const float2* bp_ = bg + (long long)(KT) * 16 * N;                                                           \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                              \
+      __builtin_amdgcn_global_load_lds((gptr_t)(ap_ + (long long)r * M), (lptr_t)(sb_ + r * 1024), 16, 0, 0);    \
+      __builtin_amdgcn_global_load_lds((gptr_t)(bp_ + (long long)r * N), (lptr_t)(sb_ + 16384 + r * 1024), 16, 0, 0); \
+    }                                                                                                            \
+  }
+  TCMI_DMA_ISSUE(0, 0)
+  f32x16 acc[2][2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][t][e] = 0.f;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)dsm;
+  // fragment address: k row (lane / 32) of the pair, 16 bytes = elements 2 (lane % 32), + 1 of the wave's 64 rows / columns
+  const uint32_t fa = lds0 + (uint32_t)((lane >> 5) * 1024 + (wr * 64 + 2 * (lane & 31)) * 8);
+  const uint32_t fb = lds0 + (uint32_t)(16384 + (lane >> 5) * 1024 + (wc * 64 + 2 * (lane & 31)) * 8);
+  int st = 0;
+  for (int i = 0; i < nk; ++i) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of stage i have landed ...
+    __builtin_amdgcn_s_barrier();                          // ... everybody's have, and the other buffer is free
+    if (i + 1 < nk) TCMI_DMA_ISSUE(i + 1, st ^ 1)
+    const uint32_t sa_ = fa + (uint32_t)(st * TCMI_T128_STAGE_BYTES), sb_ = fb + (uint32_t)(st * TCMI_T128_STAGE_BYTES);
+    // fragments of two k pairs at a time, double-buffered: the reads of quarter t + 1 are issued before the 24 MFMAs of
+    // quarter t, so only the first quarter's LDS latency of a K step is exposed
+    v4f_ xa[2][2], xb[2][2];
+#define TCMI_QREAD(BUF, QT)                                                                                          \
+  _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                                    \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xa[BUF][q]) : "v"(sa_), "n"(((QT) * 2 + q) * 2048));         \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xb[BUF][q]) : "v"(sb_), "n"(((QT) * 2 + q) * 2048));         \
+  }
+#define TCMI_QWAIT(BUF) \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xa[BUF][0]), "+v"(xa[BUF][1]), "+v"(xb[BUF][0]), "+v"(xb[BUF][1]));
+    TCMI_QREAD(0, 0)
+    TCMI_QWAIT(0)
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      if (qt < 3) {
+        if (qt & 1) { TCMI_QREAD(0, qt + 1) } else { TCMI_QREAD(1, qt + 1) }
+      }
+      __builtin_amdgcn_sched_barrier(0);     // the MFMAs below stay between the reads above and the wait below
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const v4f_ va = xa[qt & 1][q], vb = xb[qt & 1][q];
+        // va = (re, im) of rows 2j and 2j + 1; vb likewise for two columns
+        const float ar[2] = {va.x, va.z}, ai[2] = {va.y, va.w};
+        const float br[2] = {vb.x, vb.z}, bi[2] = {vb.y, vb.w};
+        const float as[2] = {ar[0] + ai[0], ar[1] + ai[1]}, bs[2] = {br[0] + bi[0], br[1] + bi[1]};
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int v = 0; v < 2; ++v) {
+            acc[u][v][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[u], br[v], acc[u][v][0], 0, 0, 0);
+            acc[u][v][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[u], bi[v], acc[u][v][1], 0, 0, 0);
+            acc[u][v][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(as[u], bs[v], acc[u][v][2], 0, 0, 0);
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (qt < 3) {
+        if (qt & 1) { TCMI_QWAIT(0) } else { TCMI_QWAIT(1) }
+      }
+    }
+#undef TCMI_QREAD
+#undef TCMI_QWAIT
+    st ^= 1;
+  }
+#undef TCMI_DMA_ISSUE
+  // MFMA result element (row i = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), column j = lane & 31) of the (u, v) product
+  // is C[wr 64 + 2 i + u][wc 64 + 2 j + v]: the two v of a lane are neighbours -> one 16-byte store per (u, reg)
+  const long long colb = n0 + wc * 64 + 2 * (lane & 31);
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const long long row = m0 + wr * 64 + 2 * ((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)) + u;
+      v4f_ o;
+      o.x = acc[u][0][0][reg] - acc[u][0][1][reg];
+      o.y = acc[u][0][2][reg] - acc[u][0][0][reg] - acc[u][0][1][reg];
+      o.z = acc[u][1][0][reg] - acc[u][1][1][reg];
+      o.w = acc[u][1][2][reg] - acc[u][1][0][reg] - acc[u][1][1][reg];
+      *reinterpret_cast<v4f_*>(C + row * N + colb) = o;
+    }
+}
+
 // ---- tensordot of two [2]^rank tensors straight from their stored layouts (complex64) --------------------------------
 // C[m][n] = sum_k A[rowA(m) | kA(k)] * B[kB(k) | colB(n)]: every index bit of M, N and K sits at its own address bit of
 // the operand (row bit j of A at pa.free[j], k bit j at pa.k[j] in A and pb.k[j] in B, column bit j of B at
@@ -1155,6 +1283,24 @@ int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, 
     if (trans_a && !dma_off && ksplit == 1 && (M % 64) == 0 && (N % 64) == 0 && (K % TCMI_DMA_BK) == 0 &&
         (M / 64) * (N / 64) < (1ll << 31) && (strideA & 1) == 0 && (strideB & 1) == 0 &&
         (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0) {
+      static const bool t128_off = getenv("TCMI_GEMM_T128") && getenv("TCMI_GEMM_T128")[0] == '0';
+      if (!t128_off && (M % 128) == 0 && (N % 128) == 0 && (strideC & 1) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) {
+        const int txn = (int)(N / 128), tyn = (int)(M / 128);
+        dim3 grid((unsigned)((long long)txn * tyn), (unsigned)batch, 1), block(256, 1, 1);
+        static bool attr_set = false;
+        if (!attr_set) {
+          if (hipFuncSetAttribute(reinterpret_cast<const void*>(tcmi::cgemm_dma128_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TCMI_T128_STAGE_BYTES) != hipSuccess)
+            return tcmi_set_error_(TCMI_ERR_HIP, "tcmi_cgemm: cannot raise the dynamic LDS limit");
+          attr_set = true;
+        }
+        hipLaunchKernelGGL(tcmi::cgemm_dma128_kernel, grid, block, 2 * TCMI_T128_STAGE_BYTES, st,
+                           reinterpret_cast<const float2*>(A), reinterpret_cast<const float2*>(B),
+                           reinterpret_cast<float2*>(C), (int)M, (int)N, (int)K, strideA, strideB, strideC, txn, tyn);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));
+        return TCMI_OK;
+      }
       const int txn = (int)(N / 64), tyn = (int)(M / 64);
       static const int stages = getenv("TCMI_GEMM_STAGES") ? atoi(getenv("TCMI_GEMM_STAGES")) : 3;
       dim3 grid((unsigned)((long long)txn * tyn), (unsigned)batch, 1), block(256, 1, 1);

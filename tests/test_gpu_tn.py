@@ -637,10 +637,11 @@ def test_sliced_value_and_grad_on_the_fast_kernels_matches_the_adjoint_path(dt, 
 
 
 @pytest.mark.parametrize("shape", [(64, 64, 16), (64, 64, 32), (128, 192, 48), (512, 320, 256), (4096, 4096, 256),
-                                   (64, 4096, 1024)])
+                                   (64, 4096, 1024), (128, 128, 16), (256, 384, 80), (1024, 128, 512)])
 def test_dma_pipelined_join_gemm_matches_complex128_and_the_plain_kernel(shape, monkeypatch):
-    """k-major A with whole 64 x 64 tiles and K a multiple of 16 (the cut-contraction join, cut.py) runs on
-    ``cgemm_dma_kernel``: LDS-DMA ring of 3 stages, one barrier per K step, XCD-aware tile walk.  Same numbers as a
+    """k-major A with whole tiles and K a multiple of 16 (the cut-contraction join, cut.py) runs on the LDS-DMA
+    pipelined kernels: ``cgemm_dma128_kernel`` (128 x 128 tile, 64 x 64 per wave, two stages) when M and N are
+    multiples of 128, else ``cgemm_dma_kernel`` (64 x 64 tile, ring of 3 stages); XCD-aware tile walk.  Same numbers as a
     complex128 product (f32 accumulation bound) and, per element, close to the register-staged kernel
     (TCMI_GEMM_DMA is read once per process, so that comparison uses a shape the DMA kernel does not take)."""
     import torch
