@@ -103,6 +103,22 @@ int tcmi_apply_pauli_sum(const void* in, void* out, long long state_stride, int 
                          const int* terms, int nterms, const double* weights, long long weights_stride,
                          int dtype, void* stream);
 
+/* The same product as tile passes (csrc/tcmi_hsum.hip): ONE pass over tiles spanned by `tilepos` (T =
+ * tcmi_pauli_sum_tile_bits(dtype) ascending physical index bits, tilepos[0] must be 0) that applies every given term --
+ * all X masks must lie inside the tile bits.  terms = int32[nterms][4] {X mask in tile-index space (bit j = tile bit j),
+ * Z/Y sign mask over physical bits, number of Y | emask << 8, parity(popcount(X & Z)) with X the physical mask}; emask =
+ * the sign mask restricted to the element bits of a thread: bit 0 = tile bit 0, bit 1 + b = tile bit 9 + b.  The first
+ * ndiag rows are the Z-only strings sorted by emask, the others are sorted by X mask; w = float64[batch][nterms] in row
+ * order.  accumulate != 0: out += ..., else out = ....  eout (may be NULL): float64[batch][ecopies], zeroed by the
+ * caller; receives Re <in | this pass's part of out> spread over the copies -- summed over the passes of a Hermitian sum
+ * that is sum_t w_t <P_t>, the energy whose cotangent `out` is (reference circuit.py:833-913 for the value, :899-902
+ * under value_and_grad for the cotangent; n <= 32). */
+int tcmi_pauli_sum_tile_bits(int dtype);
+int tcmi_apply_pauli_sum_tiled(const void* in, void* out, long long state_stride, int batch, int n, const int* tilepos,
+                               const int* terms, int nterms, int ndiag, const double* weights, long long weights_stride,
+                               int accumulate, double* eout, long long eout_stride, int ecopies, int dtype,
+                               void* stream);
+
 /* Adjoint-sweep tables: U^dagger and K = (dU/dtheta) U^dagger per gate (records as in
  * tcmi_build_tables with kinds TCMI_BK_UDAG / TCMI_BK_KMAT / TCMI_BK_COEF). */
 int tcmi_build_adjoint_tables(const int* ginfo, int nrec, const double* cpool, const void* params,

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(1 << LT, (R >= 5 ? 512 : 1024) >> LT) void adjoint2
   // and workgroup: gacc[i] / gidx[i] = sum and output slot of the i-th gradient event of the pass (events are
   // numbered in program order, identical in every wave because the op loop is descriptor-driven)
   constexpr int GACC = 256;
-  float* const gacc = lds + (1 << T);
+  float* const gacc = lds + (2 << T);
   int* const gidx = reinterpret_cast<int*>(gacc + GACC);
   int gev = 0;
   for (int i = threadIdx.x; i < GACC; i += (1 << LT)) gacc[i] = 0.f;
@@ -357,16 +357,19 @@ __global__ __launch_bounds__(1 << LT, (R >= 5 ? 512 : 1024) >> LT) void adjoint2
     pc += TCMI_RR_WORDS + rr[1];
     if (k == nrounds - 1) break;
 
-    // ---- planar LDS exchange of the four real planes (psi.re, psi.im, lambda.re, lambda.im), one 2^T-float buffer ----
+    // ---- LDS exchange, one VECTOR at a time as 8-byte (re, im) values through one 2^T x 8-byte buffer (32 KiB at
+    // T = 12: still four workgroups per CU).  Against the four real planes of the first version: half the LDS
+    // instructions, address walks and barriers (ds_write_b64 6 / ds_read_b64 2 LDS cycles per 8 bytes instead of
+    // 2 x 4 / 2 x 2); the slot permutation is conflict-free for 8-byte accesses exactly when it is for 4-byte ones ----
     {
       const KInt rn = desc + pc;
       tphys = xor_masks<LT>(tid, rn + 8);
-      const uint32_t wslot = xor_masks<LT>(tid, rr + 40) << 2, rslot = xor_masks<LT>(tid, rn + 24) << 2;
+      const uint32_t wslot = xor_masks<LT>(tid, rr + 40) << 3, rslot = xor_masks<LT>(tid, rn + 24) << 3;
       char* const lb = reinterpret_cast<char*>(lds);
       uint32_t ad;
       uint32_t mv[R];
 #define TCMI_MASKS(SRC, OFF) \
-  _Pragma("unroll") for (int j = 0; j < R; ++j) mv[j] = ato_vgpr_v((uint32_t)SRC[OFF + j] << 2);
+  _Pragma("unroll") for (int j = 0; j < R; ++j) mv[j] = ato_vgpr_v((uint32_t)SRC[OFF + j] << 3);
 #define TCMI_WALK(BASE, STMT)                      \
   ad = BASE;                                       \
   _Pragma("unroll") for (int g = 0; g < NR; ++g) { \
@@ -374,18 +377,16 @@ __global__ __launch_bounds__(1 << LT, (R >= 5 ? 512 : 1024) >> LT) void adjoint2
     const int r = g ^ (g >> 1);                    \
     STMT;                                          \
   }
-#define TCMI_PLANE(V, C)                                                      \
+#define TCMI_VECTOR(V)                                                        \
   TCMI_MASKS(rr, 34)                                                          \
-  TCMI_WALK(wslot, *reinterpret_cast<float*>(lb + ad) = V[r].C)               \
+  TCMI_WALK(wslot, *reinterpret_cast<v2f*>(lb + ad) = V[r])                   \
   __syncthreads();                                                            \
   TCMI_MASKS(rn, 18)                                                          \
-  TCMI_WALK(rslot, V[r].C = *reinterpret_cast<const float*>(lb + ad))         \
+  TCMI_WALK(rslot, V[r] = *reinterpret_cast<const v2f*>(lb + ad))             \
   __syncthreads();
-      TCMI_PLANE(a, x)
-      TCMI_PLANE(a, y)
-      TCMI_PLANE(l, x)
-      TCMI_PLANE(l, y)
-#undef TCMI_PLANE
+      TCMI_VECTOR(a)
+      TCMI_VECTOR(l)
+#undef TCMI_VECTOR
 #undef TCMI_MASKS
 #undef TCMI_WALK
     }
@@ -422,8 +423,11 @@ static int launch_adjoint2(void* psi, void* lam, long long stride, int batch, in
                            long long gcopy_stride, hipStream_t st) {
   constexpr int T = R + LT;
   if (n < T) return -1;
-  const size_t lds = (sizeof(float) << T) + 256 * (sizeof(float) + sizeof(int));
+  const size_t lds = (2 * sizeof(float) << T) + 256 * (sizeof(float) + sizeof(int));
   auto kern = n <= 29 ? adjoint2_kernel<R, LT, uint32_t> : adjoint2_kernel<R, LT, unsigned long long>;
+  if (lds > 48 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return TCMI_ERR_HIP;
   dim3 grid(1u << (n - T), (unsigned)batch, 1), block(1u << LT, 1, 1);
   hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<v2f*>(psi), reinterpret_cast<v2f*>(lam), stride, desc,
                      reinterpret_cast<const float*>(ctab), reinterpret_cast<const float*>(ptab), ptab_stride, gout,

@@ -538,11 +538,58 @@ class CompiledMeasure:
             vals[:, k] = torch.view_as_complex(acc.sum(1))
         return vals
 
-    def apply_sum(self, state, gvals):
-        """Cotangent of the state for L = f(<psi|P_t|psi>): 2 * sum_t Re(g_t) P_t |psi>
-        (``tcmi_apply_pauli_sum``).  state [B, 2^n_exec], gvals [B, nterms] complex."""
+    def _tiled_plan(self):
+        """Passes of ``tcmi_apply_pauli_sum_tiled`` for this term list (``plan_pauli_passes``), or None when the flat
+        gather kernel is the better (or the only) choice."""
+        if not hasattr(self, "_tiled"):
+            self._tiled = None
+            if os.environ.get("TCMI_PAULI_TILED", "1") != "0" and self.n_exec <= 32:
+                n = self.n_exec
+                rows = []
+                for k, t in enumerate(self.all_terms):
+                    xm = sum(1 << (n - 1 - q) for q in t.x)
+                    zm = sum(1 << (n - 1 - q) for q in t.z)
+                    rows.append((xm, zm, t.ny, k))
+                T = int(self._lib.tcmi_pauli_sum_tile_bits(self.code))
+                passes = plan_pauli_passes(n, rows, T) if n >= T else None
+                if passes is not None:
+                    self._tiled = [
+                        dict(tilepos=_dev(np.asarray(ps["tilepos"], dtype=np.int32), self.device),
+                             terms=_dev(np.asarray(ps["rows"], dtype=np.int64).astype(np.uint32).view(np.int32).reshape(-1, 4),
+                                        self.device),
+                             order=_dev(np.asarray(ps["order"], dtype=np.int64), self.device), n=len(ps["order"]),
+                             ndiag=int(ps["ndiag"]))
+                        for ps in passes]
+        return self._tiled
+
+    def apply_sum(self, state, gvals, want_dot=False):
+        """Cotangent of the state for L = f(<psi|P_t|psi>): 2 * sum_t Re(g_t) P_t |psi>.  state [B, 2^n_exec], gvals
+        [B, nterms] complex.  Tile passes (``tcmi_apply_pauli_sum_tiled``) when every X mask fits a tile, else the flat
+        gather kernel (``tcmi_apply_pauli_sum``).  ``want_dot``: also return Re <psi|lambda> per batch element
+        (float64 [B]) -- for g_t = w_t that is 2 sum_t w_t <P_t>, i.e. the energy comes with its cotangent and the
+        measurement passes are not needed."""
         import torch
 
+        tiled = self._tiled_plan()
+        if tiled is not None:
+            B = state.shape[0]
+            wall = 2.0 * gvals.real.to(torch.float64)
+            out = torch.empty_like(state)
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            item = 8 if self.dtypestr == "complex64" else 16
+            dots = torch.zeros(B, ATOMIC_COPIES, dtype=torch.float64, device=self.device) if want_dot else None
+            nbytes = sum((2.0 if i == 0 else 3.0) for i in range(len(tiled))) * B * state.shape[1] * item
+            with _timed("pauli_sum", len(tiled), nbytes):
+                for i, ps in enumerate(tiled):
+                    w = wall[:, ps["order"]].contiguous()
+                    _lib.check(
+                        self._lib.tcmi_apply_pauli_sum_tiled(
+                            state.data_ptr(), out.data_ptr(), state.shape[1], B, self.n_exec, ps["tilepos"].data_ptr(),
+                            ps["terms"].data_ptr(), ps["n"], ps["ndiag"], w.data_ptr(), w.stride(0), int(i > 0),
+                            dots.data_ptr() if want_dot else None, dots.stride(0) if want_dot else 0, ATOMIC_COPIES,
+                            self.code, stream),
+                        "tcmi_apply_pauli_sum_tiled")
+            return (out, dots.sum(1)) if want_dot else out
         if getattr(self, "_sum_terms", None) is None:
             n = self.n_exec
             rows = []
@@ -570,7 +617,91 @@ class CompiledMeasure:
                     self._sum_terms.data_ptr(), self.nterms, w.data_ptr(), w.stride(0), self.code, stream),
                 "tcmi_apply_pauli_sum",
             )
+        if want_dot:
+            acc = torch.zeros(B, ATOMIC_COPIES, 2, dtype=torch.float64, device=self.device)
+            _lib.check(self._lib.tcmi_vdot(state.data_ptr(), out.data_ptr(), acc.data_ptr(), state.shape[1], B, self.n_exec,
+                                           ATOMIC_COPIES, acc.stride(0), self.code, stream), "tcmi_vdot")
+            return out, acc.sum(1)[:, 0]
         return out
+
+
+def plan_pauli_passes(n: int, rows, T: int, lowbits: int = 4, max_passes: int = 6):
+    """Tile passes for ``(sum_t w_t P_t)|psi>``: every pass owns tiles over the ``lowbits`` lowest index bits (whole
+    128-byte segments) plus ``T - lowbits`` further bits, and applies the terms whose X mask lies inside its tile bits;
+    every term is applied in exactly one pass, the diagonal ones in the first.  ``rows`` = (xmask, zmask, nY, term
+    index) over physical bits.  Greedy cover: a pass is seeded with the remaining mask that reaches lowest and takes
+    every other mask that still fits, fewest new bits first.  Returns a list of {tilepos, rows (xmask in tile-index
+    space, zmask, nY | emask << 8, parity(x & z); the Z-only rows first, sorted by emask), ndiag, order} or None when a mask does not fit a tile, more than ``max_passes`` passes
+    are needed, or the flat gather kernel moves fewer bytes (1 read per distinct mask outside its 2^T-element window
+    + 1 read + 1 write, against 2 transfers for the first pass and 3 for each further one)."""
+    free = T - lowbits
+    lowmask = (1 << lowbits) - 1
+    masks = sorted({r[0] for r in rows})
+    high = {m: m & ~lowmask for m in masks}
+    if any(bin(h).count("1") > free for h in high.values()):
+        return None
+    todo = [m for m in masks if high[m]]
+    groups = []
+    while todo:
+        g = 0
+        todo.sort(key=lambda m: ((high[m] & -high[m]), m))
+        picked = []
+        rest = list(todo)
+        while rest:
+            best = None
+            for m in rest:
+                new = bin(high[m] & ~g).count("1")
+                if bin(g | high[m]).count("1") <= free and (best is None or (new, m) < best[0]):
+                    best = ((new, m), m)
+            if best is None:
+                break
+            g |= high[best[1]]
+            picked.append(best[1])
+            rest.remove(best[1])
+        groups.append((g, picked))
+        todo = [m for m in todo if m not in picked]
+        if len(groups) > max_passes:
+            return None
+    if not groups:
+        groups = [(0, [])]
+    local = [m for m in masks if not high[m]]          # inside the low bits: first pass
+    groups[0] = (groups[0][0], local + groups[0][1])
+    flat_window = (1 << min(n, 12)) - 1
+    flat_cost = 2 + sum(1 for m in masks if m & ~flat_window)
+    if 2 + 3 * (len(groups) - 1) >= flat_cost and flat_cost <= 6:
+        return None
+    passes = []
+    for g, picked in groups:
+        bits = [b for b in range(lowbits)] + [b for b in range(lowbits, n) if (g >> b) & 1]
+        fill = [b for b in range(lowbits, n) if not (g >> b) & 1]
+        while len(bits) < T:                             # unused tile bits: the next free index bits
+            bits.append(fill.pop(0))
+        bits.sort()
+        pos = {b: j for j, b in enumerate(bits)}
+        ebits = [bits[0]] + bits[9:]                     # element bits of a thread: pair member, pair counter
+
+        def emask(zm):
+            return sum(((zm >> b) & 1) << j for j, b in enumerate(ebits))
+
+        sel = [r for r in rows if r[0] in picked]
+        diag = sorted((r for r in sel if r[0] == 0), key=lambda r: (emask(r[1]), r[3]))
+        offd = sorted((r for r in sel if r[0] != 0), key=lambda r: (_to_local(r[0], pos), r[3]))
+        passes.append({
+            "tilepos": bits, "ndiag": len(diag),
+            "rows": [(_to_local(r[0], pos), r[1], r[2] | (emask(r[1]) << 8), bin(r[0] & r[1]).count("1") & 1)
+                     for r in diag + offd],
+            "order": [r[3] for r in diag + offd],
+        })
+    return passes
+
+
+def _to_local(xm: int, pos) -> int:
+    out, b = 0, 0
+    while xm >> b:
+        if (xm >> b) & 1:
+            out |= 1 << pos[b]
+        b += 1
+    return out
 
 
 _MCACHE: "OrderedDict[Tuple, CompiledMeasure]" = OrderedDict()

@@ -249,13 +249,15 @@ class TracedVag:
             return psi
         cc, cm = plan["cc"], plan["cm"]
         state = cc.state(params, full=True)                                   # [nb, 2^n_exec]
-        vals = cm.run(state)                                                  # [nb, T] complex128
         w = plan["weights"]
-        value = (vals.real * w).sum(-1) + plan["const"]
         if self.value_only:
-            value = value.to(rdt)
+            vals = cm.run(state)                                              # [nb, T] complex128
+            value = ((vals.real * w).sum(-1) + plan["const"]).to(rdt)
             return value if batched else value[0]
-        lam = cm.apply_sum(state, w.to(torch.complex128).reshape(1, -1).expand(nb, -1))
+        # lambda = 2 sum_t w_t P_t |psi> and, from the same launches, Re <psi|lambda> = 2 sum_t w_t <P_t>: the energy comes
+        # with its cotangent, no measurement passes (executor.CompiledMeasure.apply_sum)
+        lam, dot = cm.apply_sum(state, w.to(torch.complex128).reshape(1, -1).expand(nb, -1), want_dot=True)
+        value = 0.5 * dot + plan["const"]
         gp = cc.vjp(params, state, lam, consume=True).to(torch.float64)       # [nb, P]; state and lam are ours
         gflat = torch.zeros(nb, plan["total"] + plan["consts"].numel(), dtype=torch.float64, device=dev)
         gflat.index_add_(1, plan["index"], gp)

@@ -363,3 +363,48 @@ def test_dense_three_qubit_gates_are_synthesised_exactly():
     plan = P.compile_plan(recs, n, cfg, nparams=len(c._params))
     out = E.run_plan(plan, np.array([float(p) for p in c._params]))
     np.testing.assert_allclose(out, dense.run(n, ops), atol=1e-12)
+
+
+def test_pauli_sum_tile_passes_cover_every_term_once():
+    """Host planner of the tiled (sum_t w_t P_t)|psi> (executor.plan_pauli_passes): every term lands in exactly one
+    pass, its X mask inside that pass's tile bits; the low bits are in every tile; the TFIM of BASELINE config 3 needs
+    three passes; masks that cannot share a tile, or sums the flat kernel handles with less traffic, return None."""
+    from tcmi.executor import plan_pauli_passes
+
+    n, T = 28, 12
+    rows = [(1 << (n - 1 - q), 0, 0, q) for q in range(n)]
+    rows += [(0, (1 << (n - 1 - q)) | (1 << (n - 2 - q)), 0, n + q) for q in range(n - 1)]
+    passes = plan_pauli_passes(n, rows, T)
+    assert passes is not None and len(passes) == 3
+    seen = []
+    for ps in passes:
+        tp = ps["tilepos"]
+        assert len(tp) == T and tp == sorted(tp) and tp[:4] == [0, 1, 2, 3]
+        for (xl, zm, ny, xpar), k in zip(ps["rows"], ps["order"]):
+            xm, zm0, ny0, _ = rows[k]
+            back = sum(1 << tp[j] for j in range(T) if (xl >> j) & 1)
+            assert back == xm and zm == zm0 and (ny & 3) == ny0 and xpar == (bin(xm & zm).count("1") & 1)
+            ebits = [tp[0]] + tp[9:]
+            assert (ny >> 8) == sum(((zm >> b) & 1) << j for j, b in enumerate(ebits))
+            seen.append(k)
+        nd = ps["ndiag"]
+        assert all(r[0] == 0 for r in ps["rows"][:nd]) and all(r[0] != 0 for r in ps["rows"][nd:])
+        assert [r[2] >> 8 for r in ps["rows"][:nd]] == sorted(r[2] >> 8 for r in ps["rows"][:nd])
+        assert [r[0] for r in ps["rows"][nd:]] == sorted(r[0] for r in ps["rows"][nd:])   # sorted by X mask
+    assert sorted(seen) == list(range(len(rows)))
+    assert all(k in passes[0]["order"] for k in range(n, 2 * n - 1))              # diagonal terms: first pass
+    # random few-body strings on 20 qubits
+    rng = np.random.default_rng(3)
+    rows = []
+    for k in range(40):
+        qs = rng.choice(20, size=int(rng.integers(1, 4)), replace=False)
+        xm = sum(1 << int(q) for q in qs[: int(rng.integers(0, len(qs) + 1))])
+        zm = sum(1 << int(q) for q in qs)
+        rows.append((xm, zm, int(rng.integers(0, 3)), k))
+    passes = plan_pauli_passes(20, rows, 12)
+    if passes is not None:
+        assert sorted(k for ps in passes for k in ps["order"]) == list(range(40))
+    # a mask with more high bits than a tile has free bits cannot be tiled
+    assert plan_pauli_passes(28, [(sum(1 << b for b in range(8, 20)), 0, 0, 0)], 12) is None
+    # small state: the flat kernel's window already holds nearly everything
+    assert plan_pauli_passes(14, [(1 << (13 - q), 0, 0, q) for q in range(14)], 12) is None
