@@ -415,11 +415,32 @@ def rqc_leg(tc, torch, dist, args, rank, world):
         t_inv = max(0.0, t_one - t_slice)
         per_rank = min(S, -(-tree.nslices // 8))      # slices a rank of an 8-GPU run holds
         t_rank = t_one if per_rank == 1 else min(run(dc.my_slices[:per_rank]) for _ in range(3))
+
+        # the same with the slice-invariant subtrees split over 8 ranks (ContractionTree.invariant_shards; what
+        # DistributedContractor does when it runs on more than one rank): this rank computes the subtrees of rank 0 --
+        # the most loaded one -- and the other ranks' roots are already in place (the all-gather itself, a few MB over
+        # xGMI, is not in this one-rank figure)
+        def run_sharded(ids):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for r_ in tree.contract_slices(arrays, ids, shard=(0, 8, "emulate")):
+                pass
+            torch.cuda.synchronize()
+            return time.perf_counter() - t1
+
+        run_sharded(dc.my_slices[:per_rank])
+        t_rank_sh = min(run_sharded(dc.my_slices[:per_rank]) for _ in range(3))
+        loads = tree.invariant_shards(8)[2]
+        for r_ in tree.contract_slices(arrays, dc.my_slices):     # back to the unsharded graphs for later callers
+            pass
         split = {"slice_invariant_s": t_inv, "per_slice_s": t_slice, "local_slices": S,
                  "one_slice_run_s": t_one, "invariant_fraction_of_one_slice_run": t_inv / max(t_one, 1e-12),
-                 # slices go out in pairs on two streams, so per_slice_s is the paired rate; the 8-rank figure is the
-                 # measured time of the slices ONE rank would hold (invariant part included), not a model
-                 "projected_speedup_8_ranks": t_all / t_rank,
+                 # slices go out in pairs on two streams, so per_slice_s is the paired rate; the 8-rank figures are
+                 # measured times of the slices ONE rank would hold, not a model
+                 "one_rank_of_8_replicated_invariants_s": t_rank, "one_rank_of_8_sharded_invariants_s": t_rank_sh,
+                 "projected_speedup_8_ranks_replicated_invariants": t_all / t_rank,
+                 "projected_speedup_8_ranks": t_all / t_rank_sh,
+                 "invariant_shard_model_us": [round(x * 1e6) for x in loads],
                  "projection_basis": "ONE-rank measurement: time of all local slices / time of the slices one rank of "
                                      "an 8-rank run would hold (with the invariant work that rank executes); no 8-GPU run"}
     flops = float(tree.total_flops())          # all slices (ContractionTree.total_flops includes nslices)

@@ -140,10 +140,19 @@ class DistributedContractor:
         nodes = self.nodes_fn(params)
         return [n.tensor for n in nodes]
 
+    def _shard(self):
+        """(rank, world, group) for the split of the slice-invariant subtrees (TCMI_TN_SHARD_INV=0: every rank computes
+        all of them, as the reference's pmap replicas do)."""
+        import os
+
+        if self.num_devices > 1 and os.environ.get("TCMI_TN_SHARD_INV", "1") != "0":
+            return (self.rank, self.num_devices, None)
+        return None
+
     def _local_sum(self, params, op):
         total = None
         arrays = self._arrays(params)
-        for r in self.tree.contract_slices(arrays, self.my_slices):
+        for r in self.tree.contract_slices(arrays, self.my_slices, shard=self._shard()):
             total = r if total is None else total + r
         if total is None:  # this rank only holds padding
             import torch

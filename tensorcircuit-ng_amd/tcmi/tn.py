@@ -1138,12 +1138,22 @@ class ContractionTree:
         self._steps_cache = (key, plan)
         return plan
 
-    def contract_slices(self, arrays: Sequence[Any], slice_ids: Sequence[int]):
+    def contract_slices(self, arrays: Sequence[Any], slice_ids: Sequence[int], shard=None):
         """Yield ``contract_core(slice_arrays(arrays, i))`` for every i in ``slice_ids``.  Intermediates that do
         not depend on a sliced index (most of the small early steps of a circuit network: only a few leaves carry
-        the sliced indices) are computed once and reused by every slice."""
+        the sliced indices) are computed once and reused by every slice.
+
+        ``shard = (rank, world, group)``: the slice-invariant subtrees are split over the ranks of a slice shard
+        (``invariant_shards``) and their roots exchanged with ONE all-gather, instead of every rank recomputing all of
+        them (232 of 271 steps of the 32-qubit RQC: 1.7 of the 4.0 ms a rank spends on one slice).  Collective: every
+        rank of the group must make the call, also ranks that hold only padding (empty ``slice_ids``).  ``group`` =
+        "emulate": no collective, the other ranks' roots are computed locally once (bench.py's one-rank estimate)."""
         steps, dep, last, final_perm = self._symbolic_steps()
         slice_ids = list(slice_ids)
+        if shard is not None and shard[1] > 1 and _graph_ok(arrays, len(steps), slice_ids or [0]) \
+                and any(dep[st[4]] for st in steps):
+            yield from self._contract_slices_graph(arrays, slice_ids, shard)
+            return
         if _graph_ok(arrays, len(steps), slice_ids):
             yield from self._contract_slices_graph(arrays, slice_ids)
             return
@@ -1264,12 +1274,55 @@ class ContractionTree:
                     grads[k] = ginv[k].reshape(raw[k].shape)
         return total, [g if need[k] else None for k, g in enumerate(grads)]
 
-    def _run_steps(self, leaves: Dict[int, Any], shared_t: Dict[int, Any], invariant: bool):
-        """The slice-invariant (``invariant``) or the slice-dependent steps, eagerly, on the given leaf tensors."""
+    def invariant_shards(self, world: int):
+        """Split of the slice-invariant steps over ``world`` ranks: the invariant part of the tree is a forest (roots =
+        invariant intermediates consumed by slice-dependent steps); whole subtrees go to the least loaded rank, largest
+        first, under the step model of ``model_time`` (deterministic: every rank derives the same split).  Returns
+        (steps_of[r]: set of produced tensor ids, roots_of[r]: [(root id, log2 size)], model seconds per rank)."""
+        steps, dep, last, _ = self._symbolic_steps()
+        n = len(self.inputs)
+        prod = {st[4]: st for st in steps}
+        sl = set(self.sliced_inds)
+        rank_of = {i: len([e for e in s if e not in sl]) for i, s in enumerate(self.inputs)}
+        for ia, ib, xa, xb, io in steps:
+            rank_of[io] = rank_of[ia] + rank_of[ib] - 2 * len(xa)
+        roots: List[int] = []
+        for ia, ib, xa, xb, io in steps:
+            if dep[io]:
+                for t in (ia, ib):
+                    if not dep[t] and t >= n and t not in roots:
+                        roots.append(t)
+        trees = []
+        for r in roots:
+            sub, stack, cost = [], [r], 0.0
+            while stack:
+                t = stack.pop()
+                st = prod.get(t)
+                if st is not None and not dep[t]:
+                    sub.append(t)
+                    stack += [st[0], st[1]]
+                    fl = 8.0 * 2.0 ** (rank_of[st[0]] + rank_of[st[1]] - len(st[2]))
+                    by = 8.0 * (2.0 ** rank_of[st[0]] + 2.0 ** rank_of[st[1]] + 2.0 ** rank_of[t])
+                    cost += max(fl / (MODEL_TFLOPS * 1e12), by / (MODEL_GBS * 1e9)) + MODEL_STEP_S
+            trees.append((cost, r, sub))
+        trees.sort(key=lambda c: (-c[0], c[1]))
+        loads = [0.0] * world
+        steps_of = [set() for _ in range(world)]
+        roots_of: List[List[Tuple[int, int]]] = [[] for _ in range(world)]
+        for cost, r, sub in trees:
+            k = min(range(world), key=lambda j: (loads[j], j))
+            loads[k] += cost
+            steps_of[k].update(sub)
+            roots_of[k].append((r, rank_of[r]))
+        return steps_of, roots_of, loads
+
+    def _run_steps(self, leaves: Dict[int, Any], shared_t: Dict[int, Any], invariant: bool, only=None):
+        """The slice-invariant (``invariant``; ``only``: just the steps producing these tensors) or the slice-dependent
+        steps, eagerly, on the given leaf tensors."""
         steps, dep, last, final_perm = self._symbolic_steps()
         if invariant:
             for ia, ib, xa, xb, io in steps:
-                if not dep[io]:
+                if not dep[io] and (only is None or io in only):
                     shared_t[io] = tensordot(shared_t[ia], shared_t[ib], xa, xb)
             return None
         cur = dict(leaves)
@@ -1284,7 +1337,7 @@ class ContractionTree:
             res = permute(res, final_perm)
         return res
 
-    def _contract_slices_graph(self, arrays: Sequence[Any], slice_ids: Sequence[int]):
+    def _contract_slices_graph(self, arrays: Sequence[Any], slice_ids: Sequence[int], shard=None):
         """``contract_slices`` as two HIP graphs, captured once per (tree, operand signature) and replayed: the
         slice-invariant steps (one replay per call) and the slice-dependent steps (one replay per slice), reading
         static copies of the leaf tensors.  A sliced RQC tree is hundreds of launches of a few microseconds each;
@@ -1294,9 +1347,10 @@ class ContractionTree:
         global COUNTERS
         steps, dep, last, final_perm = self._symbolic_steps()
         n = len(self.inputs)
-        first = self.slice_arrays(arrays, slice_ids[0])
+        first = self.slice_arrays(arrays, slice_ids[0] if slice_ids else 0)
+        srank, sworld, sgroup = shard if shard is not None else (0, 1, None)
         sig = (tuple(self.path), tuple(self.sliced_inds),
-               tuple((tuple(t.shape), t.dtype, t.device) for t in first))
+               tuple((tuple(t.shape), t.dtype, t.device) for t in first), srank, sworld, sgroup == "emulate")
         cache = getattr(self, "_graph_cache", None)
         if cache is None or cache["sig"] != sig:
             # warm-up: one eager slice (plans, bit-permutation tables and kernels are created outside the capture)
@@ -1306,15 +1360,40 @@ class ContractionTree:
                 self._run_steps({}, warm, True)
                 self._run_steps({k: first[k] for k in range(n) if dep[k]}, warm, False)
                 torch.cuda.synchronize()
-                del warm
                 static = [first[k].contiguous().clone() for k in range(n)]
                 shared_t: Dict[int, Any] = {k: static[k] for k in range(n) if not dep[k]}
                 COUNTERS = new_counters()
                 g_inv = None
-                if any(not dep[st[4]] for st in steps):     # (an empty capture is an error on some ROCm versions)
+                big = mine_steps = None
+                if sworld > 1:
+                    # invariant subtrees split over the ranks: this rank's graph computes its own subtrees and packs
+                    # their roots into row `srank` of `big`; after the all-gather every root is a view of `big`
+                    steps_of, roots_of, _ = self.invariant_shards(sworld)
+                    cap = max(1, max(sum(1 << lg for _, lg in rs) for rs in roots_of))
+                    big = torch.zeros(sworld, cap, dtype=first[0].dtype, device=first[0].device)
+                    mine_steps = steps_of[srank]
+                    views = {}
+                    for r_, rs in enumerate(roots_of):
+                        off = 0
+                        for root, lg in rs:
+                            views[root] = big[r_, off: off + (1 << lg)].view([2] * lg)
+                            if sgroup == "emulate":      # the other ranks' roots, computed here once
+                                views[root].copy_(warm[root])
+                            off += 1 << lg
+                    if mine_steps:
+                        g_inv = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g_inv):
+                            self._run_steps({}, shared_t, True, only=mine_steps)
+                            for root, lg in roots_of[srank]:
+                                views[root].copy_(shared_t[root])
+                    shared_t.update(views)
+                elif any(not dep[st[4]] for st in steps):     # (an empty capture is an error on some ROCm versions)
                     g_inv = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g_inv):
                         self._run_steps({}, shared_t, True)
+                del warm
+                if sworld > 1 and sgroup != "emulate":
+                    self._gather_invariants(big, srank, sworld, sgroup)   # the captures below replay on real values
                 cnt_inv, COUNTERS = COUNTERS, new_counters()
                 g_sl, res = None, None
                 if any(dep[st[4]] for st in steps):
@@ -1334,16 +1413,29 @@ class ContractionTree:
                         res2 = self._run_steps(dict(static2), shared_t, False)
             finally:
                 COUNTERS = keep_counters
-            cache = {"sig": sig, "static": static, "shared": shared_t, "g_inv": g_inv, "g_sl": g_sl, "res": res,
+            cache = {"sig": sig, "big": big, "static": static, "shared": shared_t, "g_inv": g_inv, "g_sl": g_sl, "res": res,
                      "cnt_inv": cnt_inv, "cnt_sl": cnt_sl, "g_sl2": g_sl2, "res2": res2, "static2": static2,
                      "side": torch.cuda.Stream(device=first[0].device) if g_sl2 is not None else None}
             self._graph_cache = cache
         static = cache["static"]
-        inv_k = [k for k in range(n) if not dep[k]]
+        inv_k = cache.get("inv_leaves")
+        if inv_k is None:
+            inv_k = [k for k in range(n) if not dep[k]]
+            if sworld > 1:     # only the leaves this rank's subtrees read, and those the slice-dependent steps read directly
+                mine = self.invariant_shards(sworld)[0][srank]
+                used = set()
+                for ia, ib, xa, xb, io in steps:
+                    if io in mine or dep[io]:
+                        used.update(t for t in (ia, ib) if t < n and not dep[t])
+                inv_k = [k for k in inv_k if k in used]
+            cache["inv_leaves"] = inv_k
         dep_k = [k for k in range(n) if dep[k]]
-        torch._foreach_copy_([static[k] for k in inv_k], [first[k] for k in inv_k])
+        if inv_k:
+            torch._foreach_copy_([static[k] for k in inv_k], [first[k] for k in inv_k])
         if cache["g_inv"] is not None:
             cache["g_inv"].replay()
+        if sworld > 1 and sgroup != "emulate":
+            self._gather_invariants(cache["big"], srank, sworld, sgroup)
         if COUNTERS is not None:
             for key, v in cache["cnt_inv"].items():
                 COUNTERS[key] += v
@@ -1384,6 +1476,23 @@ class ContractionTree:
             if r2 is not None:
                 yield r2
             j += n_done
+
+    @staticmethod
+    def _gather_invariants(big, rank: int, world: int, group) -> None:
+        """Row r of ``big`` [world, cap] <- rank r's packed invariant roots: the one collective of the sharded
+        invariant part (RCCL all-gather of at most a few MB; gloo in the one-device tests)."""
+        import torch
+        import torch.distributed as dist
+
+        mine = big[rank].clone()
+        if dist.get_backend(group) == "nccl":
+            dist.all_gather_into_tensor(big.view(-1), mine, group=group)
+        else:
+            re = torch.view_as_real(mine).contiguous()
+            outs = [torch.empty_like(re) for _ in range(world)]
+            dist.all_gather(outs, re, group=group)
+            for r in range(world):
+                torch.view_as_real(big[r]).copy_(outs[r])
 
     def contract_core(self, arrays: Sequence[Any]):
         """Pairwise contraction of (already sliced) arrays along the path; returns the result with

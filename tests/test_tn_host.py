@@ -390,3 +390,37 @@ def test_cotengra_options_are_honoured_or_refused():
     cap = t.max_size()
     t.slice_to_slices(16)
     assert t.nslices >= 16 and t.max_size() <= cap
+
+
+def test_invariant_subtrees_are_split_over_the_ranks_once_each():
+    """``ContractionTree.invariant_shards``: every slice-invariant step belongs to exactly one rank, whole subtrees stay
+    together, every invariant tensor a slice-dependent step consumes is some rank's root, and the split is the same
+    whoever computes it (the ranks of a slice shard derive it independently)."""
+    from tcmi import tn
+
+    inputs, output, sd = _rand_net(60, 3, 21, dangling=0)
+    tree = tn.ContractionTree.from_path(inputs, output, sd, trials=4, seed=0)
+    tree.slice_to(max(4, tree.max_size() // 16))
+    steps, dep, last, _ = tree._symbolic_steps()
+    n = len(tree.inputs)
+    inv = {st[4] for st in steps if not dep[st[4]]}
+    assert inv, "this network should have slice-invariant steps"
+    prod = {st[4]: st for st in steps}
+    for world in (2, 4, 8):
+        steps_of, roots_of, loads = tree.invariant_shards(world)
+        again = tree.invariant_shards(world)
+        assert [sorted(x) for x in steps_of] == [sorted(x) for x in again[0]] and roots_of == again[1]
+        allsteps = [t for sset in steps_of for t in sset]
+        assert len(allsteps) == len(set(allsteps))
+        needed = set()
+        for ia, ib, xa, xb, io in steps:
+            if dep[io]:
+                needed |= {t for t in (ia, ib) if not dep[t] and t >= n}
+        assert {r for rs in roots_of for r, _ in rs} == needed
+        for k in range(world):
+            for t in steps_of[k]:                      # a step's invariant operands were produced by the same rank
+                for src in prod[t][:2]:
+                    assert src < n or src in steps_of[k]
+            for r, lg in roots_of[k]:
+                assert r in steps_of[k]
+        assert max(loads) <= sum(loads)
