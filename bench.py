@@ -471,6 +471,99 @@ def rqc_leg(tc, torch, dist, args, rank, world):
     }
 
 
+def sliced_vqa_leg(tc, torch, dist, args, rank, world):
+    """The reference's sliced-VQA workload scaled up (examples/slicing_auto_pmap_vqa.py:20-41,86-94): rzz / rx ladder,
+    <Z> of the middle qubit, contraction tree sliced with ``slicing_opts={"target_slices": S}``, one
+    ``DistributedContractor.value_and_grad`` per step (reference experimental.py:1182-1211): forward and backward sweep of
+    every slice on the untaped kernels, replayed from HIP graphs (tn.contract_slices_vjp), slices sharded over the ranks,
+    one packed all-reduce of [value || gradient]."""
+    import numpy as np
+    from tcmi.experimental import DistributedContractor
+
+    n, d, S = args.svqa_qubits, args.svqa_depth, args.svqa_slices
+    pv = np.random.default_rng(5).uniform(0.2, 1.2, [n, d, 2]).astype(np.float32)
+    pt = tc.backend.convert_to_tensor(pv)
+
+    def nodes_fn(params):
+        c = tc.Circuit(n)
+        for i in range(d):
+            for j in range(n - 1):
+                c.rzz(j, j + 1, theta=params[j, i, 0])
+            for j in range(n):
+                c.rx(j, theta=params[j, i, 1])
+        return c.expectation_before([tc.gates.z(), [n // 2]], reuse=False)
+
+    t0 = time.perf_counter()
+    dc = DistributedContractor(nodes_fn, pt, cotengra_options={"slicing_opts": {"target_slices": S}, "max_repeats": 32,
+                                                               "minimize": "combo"})
+    search_s = time.perf_counter() - t0
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t0 = time.perf_counter()
+    v, g = dc.value_and_grad(pt)          # staging: kernels, bit tables, the four graph captures
+    sync()
+    staging = time.perf_counter() - t0
+    v, g = dc.value_and_grad(pt)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.svqa_steps):
+        v, g = dc.value_and_grad(pt)
+    sync()
+    el = (time.perf_counter() - t0) / args.svqa_steps
+    if dist is not None:
+        tt = torch.tensor([el], device=pt.device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    tree = dc.tree
+    steps, dep, _, _ = tree._symbolic_steps()
+    out = {
+        "workload": f"rzz/rx ladder n={n} depth={d}, <Z_{n // 2}>, value_and_grad of {2 * n * d} parameters through "
+                    f"DistributedContractor, tree sliced to {tree.nslices} slices (target_slices={S}), complex64",
+        "ms_per_value_and_grad": el * 1e3, "nslices": int(tree.nslices), "slices_per_gpu": len(dc.my_slices),
+        "steps_per_slice": len(steps), "slice_invariant_steps": sum(1 for st in steps if not dep[st[4]]),
+        "contraction_width": float(tree.contraction_width()), "log10_flops_forward": dc.tree_info["log10_flops"],
+        "path_search_s": round(search_s, 2), "staging_s": round(staging, 2),
+        "value": float(v), "grad_norm": float(g.norm()),
+    }
+    # device time of the four graphs (HIP events around one replay each): what is left is host time of the user's
+    # node function, the op on the result and torch's backward through the gate matrices
+    c = getattr(tree, "_vjp_graph_cache", None)
+    if c is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        gt = {}
+        for name, key in (("invariant_forward", "g_a"), ("slice_forward", "g_b"), ("slice_backward", "g_c"),
+                          ("invariant_backward", "g_d")):
+            if c[key] is None:
+                continue
+            torch.cuda.synchronize()
+            e0.record()
+            c[key].replay()
+            e1.record()
+            torch.cuda.synchronize()
+            gt[name + "_ms"] = e0.elapsed_time(e1)
+        ns = len(dc.my_slices)
+        dev_ms = gt.get("invariant_forward_ms", 0) + gt.get("invariant_backward_ms", 0) + \
+            ns * (gt.get("slice_forward_ms", 0) + gt.get("slice_backward_ms", 0))
+        per8 = -(-tree.nslices // 8)
+        dev8 = gt.get("invariant_forward_ms", 0) + gt.get("invariant_backward_ms", 0) + \
+            per8 * (gt.get("slice_forward_ms", 0) + gt.get("slice_backward_ms", 0))
+        # F_alg of forward + backward (the VJP of a tensordot is two tensordots: 3 x the forward flops) over device time
+        fl = 3.0 * 10.0 ** dc.tree_info["log10_flops"]
+        out["graphs"] = gt
+        out["roofline"] = {"bound": "latency", "device_ms_per_step": dev_ms, "host_bound": bool(el * 1e3 > 1.2 * dev_ms),
+                           "achieved": fl / (dev_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s",
+                           "frac": fl / (dev_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFS,
+                           "note": "thousands of rank <= 21 steps of a few microseconds each: launch-latency bound"}
+        out["one_rank_of_8_device_ms"] = dev8
+        out["projected_speedup_8_ranks_device_time"] = dev_ms / dev8 if dev8 > 0 else None
+    return out
+
+
 def _guard(name, fn, *a):
     """Secondary legs must never take the headline line down with them."""
     try:
@@ -549,6 +642,10 @@ def main():
     ap.add_argument("--mps-chains", type=int, default=16, help="config 5: independent chains through backend.vmap (0/1 disables)")
     ap.add_argument("--rqc-depth", type=int, default=16, help="config 4 leg (32-qubit RQC amplitude): depth; 0 disables")
     ap.add_argument("--rqc-log2-target", type=int, default=27)
+    ap.add_argument("--svqa-qubits", type=int, default=30, help="sliced-VQA leg (value_and_grad of a sliced network): qubits; 0 disables")
+    ap.add_argument("--svqa-depth", type=int, default=8)
+    ap.add_argument("--svqa-slices", type=int, default=8)
+    ap.add_argument("--svqa-steps", type=int, default=3)
     ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph replay measurement")
     ap.add_argument("--no-traffic-probe", action="store_true", help="skip the rocprofv3 PMC child runs (traffic = null)")
     ap.add_argument("--probe-child", action="store_true", help=argparse.SUPPRESS)
@@ -567,7 +664,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.probe_child:
         args.no_graph = args.no_cpu_baseline = args.no_traffic_probe = True
-        args.vqe_qubits = args.mps_qubits = args.rqc_depth = 0
+        args.vqe_qubits = args.mps_qubits = args.rqc_depth = args.svqa_qubits = 0
 
     # HBM traffic of the dominant kernel, measured by the PMC counters on this very command (child processes,
     # started before this process touches the GPU)
@@ -697,6 +794,11 @@ def main():
         torch.cuda.empty_cache()
         rqc = _guard("rqc_amplitude", rqc_leg, tc, torch, dist, args, rank, world)
 
+    svqa = None
+    if args.svqa_qubits:
+        torch.cuda.empty_cache()
+        svqa = _guard("sliced_vqa", sliced_vqa_leg, tc, torch, dist, args, rank, world)
+
     if rank == 0:
         amps = float(world) * B * (2**n) * args.steps
         value = amps / elapsed
@@ -773,6 +875,8 @@ def main():
             out["vqe_step"] = vqe
         if rqc is not None:
             out["rqc_amplitude"] = rqc
+        if svqa is not None:
+            out["sliced_vqa"] = svqa
         if args.mps_qubits > 0 and world == 1:
             out["mps_tebd"] = _guard("mps_tebd", mps_leg, tc, torch, args)
         if not args.no_cpu_baseline and world == 1:

@@ -686,12 +686,52 @@ class Circuit:
         return self.expectation(*ops, reuse=reuse, **kws)
 
     # ---- tensor-network form (closed networks, sliced / distributed contraction) ------------------
-    def _tn_nodes(self, conj: bool = False):
+    def _gate_stacks(self):
+        """[(op indices, stack [G, size])]: one flat device tensor per recorded gate (row of a stack), built with a handful of batched torch ops (differentiable):
+        constants are uploaded in one stack per gate size; the parametrised families ``C0 + cos(a) C1 + sin(a) C2``
+        (``gates.TrigSpec``) of one size are ONE stack of angles -> one cos / sin -> one broadcast expression, and the
+        gates are rows of the result.  (One small expression per gate made a 30-qubit, depth-8 ladder spend 120 ms
+        building 944 tensors and as long again in their backward, scripts/gpu_sliced_vqa_prof.py.)"""
+        import torch
+
+        K = cons.backend
+        dt = getattr(torch, cons.dtypestr)
+        rdt = getattr(torch, cons.rdtypestr)
+        dev = K.device
+        out: List[Tuple[List[int], Any]] = []
+        by_size: Dict[int, List[int]] = {}
+        par_size: Dict[int, List[int]] = {}
+        for i, op in enumerate(self._ops):
+            if op.matrix is not None:
+                by_size.setdefault(int(np.asarray(op.matrix).size), []).append(i)
+            else:
+                par_size.setdefault(int(np.asarray(op.spec.c0).size), []).append(i)
+        for size, idxs in by_size.items():
+            stack = torch.as_tensor(np.stack([np.asarray(self._ops[i].matrix).reshape(-1) for i in idxs]), device=dev).to(dt)
+            out.append((idxs, stack))
+        for size, idxs in par_size.items():
+            specs = [self._ops[i].spec for i in idxs]
+            cst = np.stack([np.stack([np.asarray(s_.c0).reshape(-1), np.asarray(s_.c1).reshape(-1),
+                                      np.asarray(s_.c2).reshape(-1)]) for s_ in specs])          # [G, 3, size]
+            cdev = torch.as_tensor(cst, device=dev).to(dt)
+            aff = torch.as_tensor(np.array([[s_.scale, s_.offset] for s_ in specs], dtype=np.float64), device=dev).to(rdt)
+            ths = []
+            for i in idxs:
+                th = self._params[self._ops[i].pidx]
+                th = K.convert_to_tensor(th) if not torch.is_tensor(th) else th
+                th = th.real if th.is_complex() else th
+                ths.append(th.to(device=dev, dtype=rdt).reshape(()))
+            a = torch.stack(ths) * aff[:, 0] + aff[:, 1]
+            m = cdev[:, 0] + torch.cos(a)[:, None] * cdev[:, 1] + torch.sin(a)[:, None] * cdev[:, 2]    # [G, size]
+            out.append((idxs, m))
+        return out
+
+    def _tn_nodes(self, conj: bool = False, stacks=None):
         """The circuit as a node list (reference ``BaseCircuit._copy``, basecircuit.py:150-181):
         n rank-1 |0> nodes (or one input node) followed by one node per gate, wired
         ``gate[i+k] ^ front[q_i]; front[q_i] = gate[i]`` (basecircuit.py:288-290).  Returns
         (nodes, front edges).  Gate tensors are built on the device from the current parameters
-        (differentiable)."""
+        (differentiable, ``_gate_stacks``; ``stacks``: an already built set, shared by the ket and the bra)."""
         import torch
         from . import tn
 
@@ -711,31 +751,17 @@ class Circuit:
             front = [tn.new_edge() for _ in range(n)]
             nodes.append(tn.Node(t.conj().resolve_conj() if conj else t, list(front), name="inputs", is_dagger=conj,
                                  id=-1))
-        # constant gates: one upload per gate size (a 32-qubit RQC has hundreds of 4 x 4 constants)
-        const_dev: Dict[int, Any] = {}
-        by_size: Dict[int, List[int]] = {}
-        for i, op in enumerate(self._ops):
-            if op.matrix is not None:
-                by_size.setdefault(int(np.asarray(op.matrix).size), []).append(i)
-        for size, idxs in by_size.items():
-            stack = torch.as_tensor(np.stack([np.asarray(self._ops[i].matrix).reshape(-1) for i in idxs]), device=dev).to(dt)
+        if stacks is None:
+            stacks = self._gate_stacks()
+        tensors: Dict[int, Any] = {}
+        for idxs, st in stacks:
+            st = st.conj().resolve_conj() if conj else st        # one conjugation per stack, not per gate
             for r, i in enumerate(idxs):
-                const_dev[i] = stack[r]
+                tensors[i] = st[r]
         for i, op in enumerate(self._ops):
             k = len(op.qubits)
-            if op.matrix is not None:
-                m = const_dev[i]
-            else:
-                s = op.spec
-                th = self._params[op.pidx]
-                th = K.convert_to_tensor(th) if not torch.is_tensor(th) else th
-                th = th.real if th.is_complex() else th
-                a = th.to(getattr(torch, cons.rdtypestr)) * s.scale + s.offset
-                c0, c1, c2 = (torch.as_tensor(x, dtype=dt, device=dev) for x in (s.c0, s.c1, s.c2))
-                m = c0 + torch.cos(a) * c1 + torch.sin(a) * c2
+            m = tensors[i]
             t = m.reshape([2] * (2 * k))
-            if conj:
-                t = t.conj().resolve_conj()
             out_e = [tn.new_edge() for _ in range(k)]
             # gate identity + side for the light-cone cancellation (tcmi/simplify.py); trigonometric gate families
             # are unitary by construction, constants are checked
@@ -765,8 +791,9 @@ class Circuit:
             nodes = [tn.Node(psi, list(e1), "psi", is_dagger=False, id=-1),
                      tn.Node(psi.conj().resolve_conj(), list(e2), "psi*", is_dagger=True, id=-1)]
         else:
-            n1, e1 = self._tn_nodes()
-            n2, e2 = self._tn_nodes(conj=True)
+            gt = self._gate_stacks()
+            n1, e1 = self._tn_nodes(stacks=gt)
+            n2, e2 = self._tn_nodes(conj=True, stacks=gt)
             nodes = n1 + n2
         newdang = list(e1) + list(e2)
         occupied = set()

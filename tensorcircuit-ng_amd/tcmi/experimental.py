@@ -194,7 +194,25 @@ class DistributedContractor:
                 value = sum((x.sum() * 0 for x in leaves)).real.detach()
             pairs = [(a, g) for a, g in zip(arrays, agrads) if g is not None and a.requires_grad]
             if pairs:
-                grads = torch.autograd.grad([a for a, _ in pairs], leaves, [g for _, g in pairs], allow_unused=True)
+                # gate tensors are rows of a few stacks (Circuit._gate_stacks): hand autograd one cotangent per STACK --
+                # a thousand row selections would each run their own backward node
+                outs, gouts, groups = [], [], {}
+                for a, g in pairs:
+                    b = a._base
+                    if b is not None and b.dim() == 2 and b.requires_grad and a.is_contiguous() and a.numel() == b.shape[1] \
+                            and a.storage_offset() % b.shape[1] == 0:
+                        groups.setdefault(id(b), (b, [], []))
+                        groups[id(b)][1].append(a.storage_offset() // b.shape[1])
+                        groups[id(b)][2].append(g.reshape(-1))
+                    else:
+                        outs.append(a)
+                        gouts.append(g)
+                for b, rows, gs in groups.values():
+                    gb = torch.zeros_like(b)
+                    gb.index_add_(0, torch.tensor(rows, device=b.device), torch.stack(gs))
+                    outs.append(b)
+                    gouts.append(gb)
+                grads = torch.autograd.grad(outs, leaves, gouts, allow_unused=True)
             else:
                 grads = [None] * len(leaves)
         else:

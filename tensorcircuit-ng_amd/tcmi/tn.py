@@ -1202,6 +1202,8 @@ class ContractionTree:
         needs = {k: bool(need[k]) for k in range(n)}
         for ia, ib, xa, xb, io in steps:
             needs[io] = needs[ia] or needs[ib]
+        if slice_ids and needs[last] and _graph_ok(raw, len(steps), slice_ids):
+            return self._contract_slices_vjp_graph(raw, slice_ids, fop, need, needs)
         total = None
         grads: List[Any] = [None] * n
         ginv: Dict[int, Any] = {}
@@ -1272,6 +1274,168 @@ class ContractionTree:
             for k in range(n):
                 if not dep[k] and k in ginv and need[k]:
                     grads[k] = ginv[k].reshape(raw[k].shape)
+        return total, [g if need[k] else None for k, g in enumerate(grads)]
+
+    def _contract_slices_vjp_graph(self, raw, slice_ids, fop, need, needs):
+        """``contract_slices_vjp`` replayed from four HIP graphs (captured once per tree and operand signature): the
+        slice-invariant forward steps, one slice forward, one slice backward, the invariant backward.  Between the
+        slice graphs only ``fop`` and its derivative run eagerly, on the small result.  A 30-qubit depth-8 ladder is
+        ~1000 forward and ~2000 backward steps of a few microseconds: issued one by one from Python they are host
+        bound (0.2 s per call, scripts/gpu_sliced_vqa_prof.py)."""
+        import torch
+
+        global COUNTERS
+        steps, dep, last, final_perm = self._symbolic_steps()
+        n = len(self.inputs)
+        vals0 = self.slice_index_values(slice_ids[0])
+        idx0 = [tuple(vals0[e] if e in vals0 else slice(None) for e in edges) for edges in self.inputs]
+        sig = (tuple(self.path), tuple(self.sliced_inds), tuple(bool(x) for x in need),
+               tuple((tuple(t.shape), t.dtype, t.device) for t in raw))
+        cache = getattr(self, "_vjp_graph_cache", None)
+        inv_perm = None
+        if final_perm is not None:
+            inv_perm = [0] * len(final_perm)
+            for i, p in enumerate(final_perm):
+                inv_perm[p] = i
+        if cache is None or cache["sig"] != sig:
+            keep_counters, COUNTERS = COUNTERS, None
+            try:
+                with torch.no_grad():
+                    st_inv = {k: raw[k].contiguous().clone() for k in range(n) if not dep[k]}
+                    st_dep = {k: raw[k][idx0[k]].contiguous().clone() for k in range(n) if dep[k]}
+
+                    def fwd_inv(shared):
+                        for ia, ib, xa, xb, io in steps:
+                            if not dep[io]:
+                                shared[io] = _tensordot_raw(shared[ia], shared[ib], xa, xb)
+
+                    def fwd_slice(shared, cur):
+                        for ia, ib, xa, xb, io in steps:
+                            if dep[io]:
+                                cur[io] = _tensordot_raw(cur[ia] if dep[ia] else shared[ia],
+                                                         cur[ib] if dep[ib] else shared[ib], xa, xb)
+                        res = cur[last] if dep[last] else shared[last]
+                        return _permute_raw(res, final_perm) if final_perm is not None else res
+
+                    def bwd_slice(shared, cur, g_in, gacc):
+                        g0 = _permute_raw(g_in, inv_perm) if inv_perm is not None else g_in
+                        gbar = {}
+                        if dep[last]:
+                            gbar[last] = g0
+                        else:
+                            gacc[last].add_(g0.reshape(gacc[last].shape))
+                        gleaf = {}
+                        for ia, ib, xa, xb, io in reversed(steps):
+                            if not dep[io] or io not in gbar:
+                                continue
+                            gio = gbar.pop(io)
+                            ta = cur[ia] if dep[ia] else shared[ia]
+                            tb = cur[ib] if dep[ib] else shared[ib]
+                            ga, gb = tensordot_vjp(ta, tb, xa, xb, gio, needs[ia], needs[ib])
+                            for t_, g_ in ((ia, ga), (ib, gb)):
+                                if g_ is None:
+                                    continue
+                                if dep[t_]:
+                                    gbar[t_] = g_
+                                else:
+                                    gacc[t_].add_(g_.reshape(gacc[t_].shape))
+                        for k in range(n):
+                            if dep[k] and k in gbar:
+                                gleaf[k] = gbar[k]
+                        return gleaf
+
+                    def bwd_inv(shared, gacc):
+                        gt = dict(gacc)
+                        out = {}
+                        for ia, ib, xa, xb, io in reversed(steps):
+                            if dep[io] or io not in gt:
+                                continue
+                            gio = gt.pop(io)
+                            ga, gb = tensordot_vjp(shared[ia], shared[ib], xa, xb, gio, needs[ia], needs[ib])
+                            if ga is not None:
+                                gt[ia] = ga
+                            if gb is not None:
+                                gt[ib] = gb
+                        for k in range(n):
+                            if not dep[k] and k in gt and need[k]:
+                                out[k] = gt[k]
+                        return out
+
+                    # invariant tensors that receive cotangents from the slice sweeps: static accumulators
+                    targets = set()
+                    for ia, ib, xa, xb, io in steps:
+                        if dep[io]:
+                            targets |= {t for t in (ia, ib) if not dep[t] and needs[t]}
+                    if not dep[last]:
+                        targets.add(last)
+                    # warm-up (kernels, bit tables), then the captures; every intermediate stays referenced so that the
+                    # backward graphs read the memory the forward graphs wrote
+                    shared = dict(st_inv)
+                    fwd_inv(shared)
+                    cur = dict(st_dep)
+                    res = fwd_slice(shared, cur)
+                    g_in = torch.zeros_like(res)
+                    gacc = {t: torch.zeros_like(shared[t]) for t in targets}
+                    bwd_slice(shared, cur, g_in, gacc)
+                    bwd_inv(shared, gacc)
+                    torch.cuda.synchronize()
+                    shared = dict(st_inv)
+                    g_a = None
+                    if any(not dep[st[4]] for st in steps):
+                        g_a = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g_a):
+                            fwd_inv(shared)
+                    pool = g_a.pool() if g_a is not None else None
+                    gacc = {t: torch.zeros_like(shared[t]) for t in targets}
+                    cur = dict(st_dep)
+                    g_b = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_b, **({"pool": pool} if pool is not None else {})):
+                        res = fwd_slice(shared, cur)
+                    pool = g_b.pool()
+                    g_in = torch.zeros_like(res)
+                    g_c = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_c, pool=pool):
+                        gleaf = bwd_slice(shared, cur, g_in, gacc)
+                    g_d = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_d, pool=pool):
+                        ginv_leaf = bwd_inv(shared, gacc)
+            finally:
+                COUNTERS = keep_counters
+            cache = {"sig": sig, "st_inv": st_inv, "st_dep": st_dep, "shared": shared, "cur": cur, "res": res,
+                     "g_in": g_in, "gacc": gacc, "gleaf": gleaf, "ginv_leaf": ginv_leaf, "g_a": g_a, "g_b": g_b,
+                     "g_c": g_c, "g_d": g_d}
+            self._vjp_graph_cache = cache
+        with torch.no_grad():
+            inv_k = list(cache["st_inv"])
+            if inv_k:
+                torch._foreach_copy_([cache["st_inv"][k] for k in inv_k], [raw[k] for k in inv_k])
+            if cache["gacc"]:
+                torch._foreach_zero_(list(cache["gacc"].values()))
+            if cache["g_a"] is not None:
+                cache["g_a"].replay()
+            grads: List[Any] = [None] * n
+            total = None
+            for i in slice_ids:
+                vals = self.slice_index_values(i)
+                idx = [tuple(vals[e] if e in vals else slice(None) for e in edges) for edges in self.inputs]
+                for k, buf in cache["st_dep"].items():
+                    buf.copy_(raw[k][idx[k]])
+                cache["g_b"].replay()
+                with torch.enable_grad():
+                    r_ = cache["res"].detach().clone().requires_grad_(True)
+                    v = fop(r_)
+                    (g,) = torch.autograd.grad(v, r_)
+                total = v.detach() if total is None else total + v.detach()
+                cache["g_in"].copy_(g)
+                cache["g_c"].replay()
+                for k, gl in cache["gleaf"].items():
+                    if need[k]:
+                        if grads[k] is None:
+                            grads[k] = torch.zeros_like(raw[k])
+                        grads[k][idx[k]] += gl
+            cache["g_d"].replay()
+            for k, gl in cache["ginv_leaf"].items():
+                grads[k] = gl.reshape(raw[k].shape).clone()
         return total, [g if need[k] else None for k, g in enumerate(grads)]
 
     def invariant_shards(self, world: int):
