@@ -258,14 +258,121 @@ class Circuit:
         self.state_tensor = None
 
     def apply_general_gate(self, gate, *index: int, name: Optional[str] = None, **kws: Any) -> None:
-        """Apply an arbitrary gate given as ``Gate`` / matrix / tensor (reference
-        basecircuit.py:183-371; mpo / diagonal / split forms are outside the hot path)."""
-        if kws.get("mpo") or kws.get("diagonal"):
-            raise NotImplementedError("mpo / diagonal gate formats are not supported on the hip backend")
+        """Apply an arbitrary gate (reference basecircuit.py:183-371): a ``Gate`` / matrix / tensor, or -- ``mpo=True``
+        -- a gate in MPO form (``gates.multicontrol_gate``, any ``gates.Operator``; basecircuit.py:295-316), or --
+        ``diagonal=True`` -- the coefficient tensor / MPS of a diagonal gate (basecircuit.py:318-369).  The reference
+        wires MPO nodes and CopyNode hyperedges into its network; the tile-VM executes the same unitaries natively:
+        a diagonal becomes phase-polynomial terms (no pass of its own), a multi-controlled U becomes
+        V^dagger . diag . V on the targets (U = V D V^dagger), any other MPO is evaluated to its matrix."""
+        if kws.get("mpo"):
+            return self._apply_mpo(gate, index, name or "mpo")
+        if kws.get("diagonal"):
+            if isinstance(gate, G.Operator):
+                vec = gate.kind[1] if gate.kind and gate.kind[0] == "diagonal" else gate.eval_matrix()
+            else:
+                t = gate.tensor if isinstance(gate, G.Gate) else gate
+                vec = _constant_value(t, "diagonal gate")
+            return self._record_diagonal(np.asarray(vec, dtype=np.complex128).reshape(-1), index, name or "diagonal")
         t = gate.tensor if isinstance(gate, G.Gate) else gate
         self._record_const(_constant_value(t, "gate matrix"), index, name or "", split_conf=kws.get("split"))
 
     apply = apply_general_gate
+
+    MAX_DIAGONAL_QUBITS = 10    # a diagonal on k qubits becomes up to 2^k phase-polynomial terms
+
+    def _record_diagonal(self, vec, index, name):
+        """A diagonal gate given by its 2^k entries (index bits = ``index`` in listed order, first = most significant)."""
+        self._flush_pending()
+        index = self._norm_index(index)
+        k = len(index)
+        if vec.size != 2 ** k:
+            raise ValueError(f"diagonal of {vec.size} entries does not act on {k} qubits")
+        if getattr(self, "_conj", False):
+            vec = vec.conj()
+        if k <= 2:
+            return self._record_const(np.diag(vec), index, name)
+        if np.abs(np.abs(vec) - 1).max() > 1e-6:
+            raise NotImplementedError("Backend 'hip' has not implemented non-unitary diagonal gates on more than 2 qubits")
+        vec = vec / np.abs(vec)          # entries that went through a complex64 Gate are unit to 1e-7 only
+        if k > self.MAX_DIAGONAL_QUBITS:
+            raise NotImplementedError(f"Backend 'hip' has not implemented diagonal gates on more than "
+                                      f"{self.MAX_DIAGONAL_QUBITS} qubits")
+        self._ops.append(_Op(index, matrix=np.diag(vec), name=name))
+        self._qir.append({"gate": None, "index": index, "name": name, "parameters": {"diag": vec}, "diagonal": True})
+        self.state_tensor = None
+
+    def _apply_mpo(self, op, index, name):
+        if not isinstance(op, G.Operator):
+            raise TypeError("mpo gates are gates.Operator objects (gates.multicontrol_gate, gates.mpo_gate)")
+        index = self._norm_index(index)
+        if op.kind and op.kind[0] == "multicontrol":
+            u, ctrl = op.kind[1], op.kind[2]
+            nc, nt = len(ctrl), int(round(np.log2(u.shape[0])))
+            if len(index) != nc + nt:
+                raise ValueError(f"multicontrol gate on {nc} + {nt} qubits applied to {len(index)} indices")
+            if np.abs(u @ u.conj().T - np.eye(u.shape[0])).max() > 1e-9:
+                return self._record_const(op.eval_matrix(), index, name)
+            # U = V D V^dagger (Schur form of a unitary is diagonal): controlled-U = (1 x V) . controlled-D . (1 x V^dagger),
+            # and controlled-D is a diagonal gate on all the qubits
+            import scipy.linalg
+
+            t, v = scipy.linalg.schur(u, output="complex")
+            dvals = np.diag(t) / np.abs(np.diag(t))
+            tq = index[nc:]
+            self._record_const(v.conj().T, tq, name)
+            full = np.ones(2 ** (nc + nt), dtype=np.complex128)
+            cval = int("".join(str(c) for c in ctrl), 2)
+            full[cval * 2 ** nt:(cval + 1) * 2 ** nt] = dvals
+            self._record_diagonal(full, index, name)
+            self._record_const(v, tq, name)
+            return None
+        return self._record_const(op.eval_matrix(), index, name)
+
+    def mpo(self, *index, mpo=None, **kw):
+        """reference abstractcircuit.py:310-339: apply a gate given in MPO form."""
+        self.apply_general_gate(mpo if mpo is not None else kw.get("gate"), *index, name="mpo", mpo=True)
+
+    MPO = mpo
+
+    def multicontrol(self, *index, ctrl=None, unitary=None, **kw):
+        """reference abstractcircuit.py:310-339 / gates.py:981: ``index`` = control qubits then target qubits."""
+        self.apply_general_gate(G.multicontrol_gate(unitary, ctrl if ctrl is not None else 1), *index,
+                                name="multicontrol", mpo=True)
+
+    MULTICONTROL = multicontrol
+
+    def diagonal(self, *index, diag=None, **kw):
+        """reference abstractcircuit.py:340-369 / gates.py:1058: a diagonal gate given by its 2^k entries."""
+        vec = _constant_value(diag.tensor if isinstance(diag, G.Gate) else diag, "diagonal gate")   # full precision
+        self._record_diagonal(np.asarray(vec, dtype=np.complex128).reshape(-1), index, "diagonal")
+
+    DIAGONAL = diagonal
+
+    def cmz(self, *index, **kw):
+        """reference gates.py:1134: multi-controlled Z on the listed qubits."""
+        vec = np.ones(2 ** len(self._norm_index(index)), dtype=np.complex128)
+        vec[-1] = -1.0
+        self._record_diagonal(vec, index, "cmz")
+
+    CMZ = cmz
+
+    def rzm(self, *index, theta=0.0, **kw):
+        """reference gates.py:1078: exp(-i theta/2 Z x ... x Z) on the listed qubits; the angle may be a tensor."""
+        index = self._norm_index(index)
+        k = len(index)
+        if k < 2:
+            raise ValueError("Gate requires at least 2 qubits.")
+        if k > self.MAX_DIAGONAL_QUBITS:
+            raise NotImplementedError(f"Backend 'hip' has not implemented diagonal gates on more than "
+                                      f"{self.MAX_DIAGONAL_QUBITS} qubits")
+        zs = np.array([1.0])
+        for _ in range(k):
+            zs = np.kron(zs, np.array([1.0, -1.0]))
+        d = 2 ** k
+        self._record_specs([G.TrigSpec(np.zeros((d, d), dtype=np.complex128), np.eye(d, dtype=np.complex128),
+                                       np.diag(-1j * zs), theta, 0.5, name="rzm")], index, "rzm", {"theta": theta})
+
+    RZM = rzm
 
     @staticmethod
     def _bcast(index):

@@ -451,7 +451,10 @@ def pick_adjoint_variant(n_exec: int, dtypestr: str, gates) -> P.PlanConfig:
     bits, four workgroups per CU -- one more pass than the 13-bit tile at n = 28, but the load / compute / store
     phases of four workgroups overlap better than those of two: 44.1 vs 47.6 ms per sample); dense two-qubit
     gates and small circuits keep the first-generation kernel."""
-    dense2 = any((not g.is_diag) and len(g.qubits) > 1 for g in gates)
+    # dense two-qubit gates, and diagonal terms of three or more qubits (their emission may need CNOT register moves,
+    # plan.emit_diag): both are G2 ops, which only the first-generation sweep executes
+    dense2 = any(((not g.is_diag) and len(g.qubits) > 1) or (g.is_diag and any(len(t.qubits) > 2 for t in g.diag))
+                 for g in gates)
     if dtypestr == "complex64" and n_exec >= 13 and not dense2 and not os.environ.get("TCMI_VM1"):
         if os.environ.get("TCMI_ADJ_R5"):   # experiment switch: 32 + 32 amplitude pairs per thread, 2 waves per SIMD
             return P.PlanConfig(R=5, LT=8, lowbits=5, vec=2, gen=2)

@@ -355,8 +355,147 @@ def matrix_for_gate(gate):
     return t.reshape(d, d)
 
 
+# ---- gates in MPO / diagonal (hyperedge) form: reference gates.py:981-1190 ----------------------------------------------
+class Operator:
+    """What the reference's MPO-format gate factories return (``QuOperator`` / ``QuVector``, quantum.py): a small tensor
+    network -- ``nodes`` = [(tensor, edge labels)], dangling ``out_edges`` then ``in_edges`` -- that a circuit applies
+    with ``c.mpo(*index, mpo=op)`` or, for the diagonal forms, ``c.diagonal(...)``.  Here it is a host-side description:
+    ``eval_matrix()`` contracts it with numpy; the circuit lowers it to the tile-VM's native operations
+    (``Circuit.apply_general_gate``)."""
+
+    def __init__(self, nodes, out_edges, in_edges=(), kind=None):
+        self.nodes = [(np.asarray(t), list(e)) for t, e in nodes]
+        self.out_edges, self.in_edges = list(out_edges), list(in_edges)
+        self.kind = kind        # ("multicontrol", unitary, ctrl) | ("diagonal", vector) | None
+
+    def copy(self):
+        return Operator(self.nodes, self.out_edges, self.in_edges, self.kind)
+
+    def adjoint(self):
+        return Operator([(np.conj(t), e) for t, e in self.nodes], self.in_edges or self.out_edges,
+                        self.out_edges if self.in_edges else (), None)
+
+    def eval(self):
+        """The contracted tensor with axes (out_edges..., in_edges...)."""
+        labels = {}
+        for _, es in self.nodes:
+            for e in es:
+                labels.setdefault(e, len(labels))
+        import string
+
+        sym = (string.ascii_letters * 4)
+        expr = ",".join("".join(sym[labels[e]] for e in es) for _, es in self.nodes)
+        outs = "".join(sym[labels[e]] for e in self.out_edges + self.in_edges)
+        return np.einsum(expr + "->" + outs, *[t for t, _ in self.nodes])
+
+    def eval_matrix(self):
+        t = self.eval()
+        d = 2 ** len(self.out_edges)
+        return t.reshape(d, -1) if self.in_edges else t.reshape(-1)
+
+
+def multicontrol_gate(unitary, ctrl=1):
+    """reference gates.py:981-1055: U on the target qubits iff the control qubits read ``ctrl``; an MPO of bond
+    dimension 2 (the same node tensors as the reference's)."""
+    if isinstance(unitary, Gate):
+        unitary = unitary.tensor
+    if _is_device_tensor(unitary):
+        unitary = unitary.detach().cpu().numpy()
+    u = np.asarray(unitary, dtype=np.complex128)
+    d = int(round(np.sqrt(u.size)))
+    u = u.reshape(d, d)
+    l = int(round(np.log2(d)))
+    ctrl = [int(ctrl)] if isinstance(ctrl, (int, np.integer)) else [int(round(float(np.real(c)))) for c in ctrl]
+    rend = np.stack([u, np.eye(d)]).reshape([2] + [2] * (2 * l))
+    nodes = []
+    left = np.zeros([2, 2, 2])
+    if ctrl[0] == 1:
+        left[1, 1, 0] = 1
+        left[0, 0, 1] = 1
+    else:
+        left[0, 0, 0] = 1
+        left[1, 1, 1] = 1
+    eid = iter(range(10 ** 6))
+    bond = next(eid)
+    outs, ins = [next(eid)], [next(eid)]
+    nodes.append((left, [outs[0], ins[0], bond]))
+    for c in ctrl[1:]:
+        mid = np.zeros([2, 2, 2, 2])
+        if c == 1:
+            mid[0, 1, 1, 0] = mid[1, 0, 0, 1] = mid[1, 1, 1, 1] = mid[0, 0, 0, 1] = 1
+        else:
+            mid[0, 0, 0, 0] = mid[1, 1, 1, 1] = mid[1, 0, 0, 1] = mid[0, 1, 1, 1] = 1
+        o, i_, nb = next(eid), next(eid), next(eid)
+        nodes.append((mid, [bond, o, i_, nb]))
+        outs.append(o)
+        ins.append(i_)
+        bond = nb
+    to, ti = [next(eid) for _ in range(l)], [next(eid) for _ in range(l)]
+    nodes.append((rend, [bond] + to + ti))
+    return Operator(nodes, outs + to, ins + ti, kind=("multicontrol", u, list(ctrl)))
+
+
+def diagonal_gate(diag, dim=2, name="diagonal"):
+    """reference gates.py:1058-1075: the coefficient tensor [2]^k of a diagonal gate (applied through hyperedges)."""
+    if dim != 2:
+        raise NotImplementedError("Backend 'hip' has not implemented qudit gates")
+    if _is_device_tensor(diag):
+        k = int(round(np.log2(diag.numel())))
+        return Gate(diag.reshape([2] * k), name=name)
+    d = np.asarray(diag).astype(_npdtype())
+    k = int(round(np.log2(d.size)))
+    return Gate(d.reshape([2] * k), name=name)
+
+
+def rzm_gate(theta, n, dim=2, name="rzm"):
+    """reference gates.py:1078-1131: exp(-i theta/2 Z...Z) on n qubits as an MPS of diagonal coefficients (chi = 2)."""
+    if n < 2:
+        raise ValueError("Gate requires at least 2 qubits.")
+    if dim != 2:
+        raise ValueError("rzm gate only supports dim=2 at the moment.")
+    th = float(np.real(theta if is_concrete(theta) else np.asarray(theta.detach().cpu())))
+    c, s_ = np.cos(th / 2), np.sin(th / 2)
+    m1 = np.array([c, -1j * s_, c, 1j * s_]).reshape(2, 2)
+    mk = np.zeros((2, 2, 2), dtype=np.complex128)
+    mk[0, 0, 0] = mk[0, 1, 0] = mk[1, 0, 1] = 1.0
+    mk[1, 1, 1] = -1.0
+    mn = np.array([[1.0, 1.0], [1.0, -1.0]], dtype=np.complex128)
+    return _diag_mps([m1] + [mk] * (n - 2) + [mn], name, None)
+
+
+def cmz_gate(n, dim=2, name="cmz"):
+    """reference gates.py:1134-1185: the multi-controlled Z on n qubits as an MPS of diagonal coefficients (chi = 2)."""
+    if n < 2:
+        raise ValueError("Gate requires at least 2 qubits.")
+    if dim != 2:
+        raise ValueError("cmz gate only supports dim=2 at the moment.")
+    m1 = np.array([[1.0, 0.0], [1.0, -2.0]], dtype=np.complex128)
+    mk = np.zeros((2, 2, 2), dtype=np.complex128)
+    mk[0, 0, 0] = mk[0, 1, 0] = mk[1, 1, 1] = 1.0
+    mn = np.array([[1.0, 1.0], [0.0, 1.0]], dtype=np.complex128)
+    return _diag_mps([m1] + [mk] * (n - 2) + [mn], name, None)
+
+
+def _diag_mps(tensors, name, kind):
+    n = len(tensors)
+    outs = list(range(n))
+    bonds = [n + i for i in range(n - 1)]
+    nodes = [(tensors[0], [outs[0], bonds[0]])]
+    for i in range(1, n - 1):
+        nodes.append((tensors[i], [bonds[i - 1], outs[i], bonds[i]]))
+    nodes.append((tensors[-1], [bonds[-1], outs[-1]]))
+    op = Operator(nodes, outs, (), kind)
+    op.kind = ("diagonal", op.eval_matrix())
+    return op
+
+
+def mpo_gate(mpo, name="mpo"):
+    return mpo
+
+
 # short names of the parameterised gates (reference gates.py:1192-1232: tc.gates.rx, tc.gates.any ...)
-for _n in ("rx", "ry", "rz", "phase", "r", "u", "iswap", "cr", "exp", "exp1", "rzz", "rxx", "ryy", "su4", "any"):
+for _n in ("rx", "ry", "rz", "phase", "r", "u", "iswap", "cr", "exp", "exp1", "rzz", "rxx", "ryy", "su4", "any",
+           "multicontrol", "mpo", "diagonal", "rzm", "cmz"):
     globals().setdefault(_n, globals()[_n + "_gate"])
 
 

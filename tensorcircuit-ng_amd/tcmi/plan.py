@@ -116,18 +116,29 @@ class GateRec:
 # ---- diagonal analysis -----------------------------------------------------------------
 def walsh_terms(phases: np.ndarray, qubits: Sequence[int]):
     """phases[x] (x = bits of ``qubits`` in listed order, first = MSB) -> list of
-    (qubit subset, coefficient) with phase(x) = sum coef * (-1)^{parity(x & subset)}."""
+    (qubit subset, coefficient) with phase(x) = sum coef * (-1)^{parity(x & subset)}: the Walsh-Hadamard transform of
+    the phases (butterflies over the k index bits, O(k 2^k))."""
     k = len(qubits)
+    c = np.asarray(phases, dtype=np.float64).reshape([2] * k) if k else np.asarray(phases, dtype=np.float64)
+    for ax in range(k):
+        lo, hi = np.take(c, 0, axis=ax), np.take(c, 1, axis=ax)
+        c = np.stack([lo + hi, lo - hi], axis=ax)
+    c = np.asarray(c).reshape(-1) / 2**k
     out = []
     for s in range(2**k):
-        c = 0.0
-        for x in range(2**k):
-            c += phases[x] * (-1) ** bin(x & s).count("1")
-        c /= 2**k
-        if abs(c) > 1e-15:
+        if abs(c[s]) > 1e-15:
             sub = tuple(qubits[i] for i in range(k) if (s >> (k - 1 - i)) & 1)
-            out.append((sub, c))
+            out.append((sub, float(c[s])))
     return out
+
+
+def diag_terms_vector(d: np.ndarray, qubits: Sequence[int], tol=1e-12):
+    """Unit-modulus diagonal given by its 2^k entries (index bits = ``qubits`` in listed order, first = MSB) -> DiagTerm
+    list, else None."""
+    d = np.asarray(d, dtype=np.complex128).reshape(-1)
+    if d.size != 2 ** len(qubits) or np.abs(np.abs(d) - 1).max() > tol:
+        return None
+    return [DiagTerm(sub, const=c) for sub, c in walsh_terms(np.angle(d), qubits)]
 
 
 def diag_terms_const(matrix: np.ndarray, qubits: Sequence[int], tol=1e-12):
@@ -821,8 +832,45 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
                                      float(t.param.index), float(rm)]
             return off
 
+        def emit_cnot(jc, jt):
+            """CNOT between register bits (control jc, target jt): a register move of the kernels' G2 op."""
+            nonlocal nops
+            ja, jb, kind = (jc, jt, 1) if jc < jt else (jt, jc, 2)
+            if not backward:
+                ops.extend([OP_G2, ja | (kind << 8), jb, 0])
+            else:
+                ops.extend([OP_G2, ja | (kind << 8), jb, 0, -1, 0])
+            nops += 1
+
         def emit_diag(terms):
-            """Emit the diagonal terms ``terms`` (DiagTerm list) at the current point of this round."""
+            """Emit the diagonal terms ``terms`` (DiagTerm list) at the current point of this round.  The kernels' phase
+            ops know three sign patterns: thread bits only, ONE register bit x thread bits, register bits only.  A term of
+            three or more qubits (multi-controlled phases, the diagonal factors of synthesised dense gates, ``rzm``) can
+            have two or more register bits AND thread bits: its register parity is first folded into one register bit by
+            CNOTs between register bits (register moves), the term is applied as a one-register-bit term, and the CNOTs
+            are undone -- P^dagger D_t P has the sign (-1)^{(P x)_t} = the parity of the folded bits."""
+            if not terms:
+                return
+            plain, mixed = [], {}
+            for t in terms:
+                pb = [n - 1 - q for q in t.qubits]
+                rb = sorted(regphys[p] for p in pb if p in regphys)
+                if len(rb) >= 2 and any(p not in regphys for p in pb):
+                    mixed.setdefault(tuple(rb), []).append(t)
+                else:
+                    plain.append(t)
+            emit_diag_core(plain)
+            phys_of_reg = {j: p for p, j in regphys.items()}
+            for rb, ts in mixed.items():
+                tgt = rb[0]
+                drop = {n - 1 - phys_of_reg[j] for j in rb[1:]}       # qubits folded into the target bit
+                for jc in rb[1:]:
+                    emit_cnot(jc, tgt)
+                emit_diag_core([DiagTerm(tuple(q for q in t.qubits if q not in drop), t.const, t.param) for t in ts])
+                for jc in reversed(rb[1:]):
+                    emit_cnot(jc, tgt)
+
+        def emit_diag_core(terms):
             nonlocal nops
             if not terms:
                 return

@@ -385,3 +385,127 @@ def test_lightcone_expectation_kat(tcd):
     got = c.expectation_ps(x=[5], z=[6], enable_lightcone=True)
     tol = 2e-5 if tc.dtypestr == "complex64" else 1e-10
     np.testing.assert_allclose(complex(tc.backend.numpy(got)), ref, atol=tol)
+
+
+def test_mpo_and_diagonal_gate_format_kats(tcd):
+    """``apply_general_gate(mpo=True)`` / ``(diagonal=True)`` (reference basecircuit.py:295-369) through the HIP
+    executor with the reference's own known answers: ``test_apply_mpo_gate`` / ``test_apply_multicontrol_gate``
+    (tests/test_circuit.py:998-1040), ``test_circuit_diagonal_gate`` / ``_rzm_gate`` / ``_cmz_gate``
+    (tests/test_hyperedge.py:532-640: the hyperedge form equals the dense diagonal matrix)."""
+    tc = tcd
+    tol = 1e-5 if tc.dtypestr == "complex64" else 1e-10
+    ex = lambda c, q: float(_np(tc, tc.backend.real(c.expectation([tc.gates.z(), [q]]))))  # noqa: E731
+    gate = tc.gates.multicontrol_gate(tc.gates._x_matrix, ctrl=[1, 0])
+    c = tc.Circuit(3)
+    c.X(0)
+    c.mpo(0, 1, 2, mpo=gate.copy())
+    assert abs(ex(c, 2) + 1) < tol
+    c = tc.Circuit(3)
+    c.X(1)
+    c.mpo(0, 1, 2, mpo=gate.copy())
+    assert abs(ex(c, 2) - 1) < tol
+    c = tc.Circuit(3)
+    c.X(2)
+    c.multicontrol(0, 2, 1, ctrl=[0, 1], unitary=tc.gates._x_matrix)
+    assert abs(ex(c, 1) + 1) < tol
+    c = tc.Circuit(3)
+    c.X(0)
+    c.multicontrol(0, 2, 1, ctrl=[0, 1], unitary=tc.gates._x_matrix)
+    assert abs(ex(c, 1) - 1) < tol
+    c = tc.Circuit(4)
+    c.X(0)
+    c.X(2)
+    c.multicontrol(0, 1, 2, 3, ctrl=[1, 0], unitary=tc.gates.swap())
+    assert abs(ex(c, 3) + 1) < tol
+
+    # diagonal: hyperedge form == dense diagonal matrix (state and a two-operator expectation)
+    n = 3
+    diag = np.array([1, -1, 1j, -1j, 1, 1, -1, -1])
+    c1, c2 = tc.Circuit(n), tc.Circuit(n)
+    for i in range(n):
+        c1.h(i)
+        c2.h(i)
+    c1.any(*range(n), unitary=np.diag(diag))
+    c2.diagonal(*range(n), diag=tc.backend.convert_to_tensor(diag))
+    for i in range(n):
+        c1.rx(i, theta=0.2)
+        c2.rx(i, theta=0.2)
+    np.testing.assert_allclose(_np(tc, c1.state()), _np(tc, c2.state()), atol=tol)
+    e1 = c1.expectation([tc.gates.z(), [0]], [tc.gates.y(), [1]])
+    e2 = c2.expectation([tc.gates.z(), [0]], [tc.gates.y(), [1]])
+    np.testing.assert_allclose(_np(tc, e1), _np(tc, e2), atol=tol)
+
+    # rzm / cmz on a 14-qubit register (packed kernels, terms of up to six qubits across register and thread bits)
+    # against the dense oracle
+    n = 14
+    c = tc.Circuit(n)
+    ops = []
+    for i in range(n):
+        c.h(i)
+        ops.append((G.H, [i]))
+    theta = 1.2
+    qs = [0, 5, 9, 13, 2]
+    c.rzm(*qs, theta=theta)
+    zs = np.array([1.0])
+    for _ in qs:
+        zs = np.kron(zs, [1.0, -1.0])
+    ops.append((np.diag(np.exp(-0.5j * theta * zs)), qs))
+    qs2 = [3, 1, 12, 7, 10, 6]
+    c.cmz(*qs2)
+    z6 = np.ones(64, dtype=np.complex128)
+    z6[-1] = -1
+    ops.append((np.diag(z6), qs2))
+    u1 = G.rx(0.7) @ G.rz(0.3)
+    c.multicontrol(4, 11, 8, 0, ctrl=[1, 1, 0], unitary=u1)
+    mc = np.eye(16, dtype=np.complex128)
+    mc[12:14, 12:14] = u1
+    ops.append((mc, [4, 11, 8, 0]))
+    for i in range(n):
+        c.rx(i, theta=0.3 + 0.05 * i)
+        ops.append((G.rx(0.3 + 0.05 * i), [i]))
+    np.testing.assert_allclose(_np(tc, c.state()), dense.run(n, ops), atol=tol)
+
+
+def test_gradient_through_a_multi_qubit_z_rotation(tcd):
+    """d/d theta of an energy through ``rzm`` (a five-qubit parity phase whose qubits fall on register AND thread bits:
+    CNOT register moves around the folded term, plan.emit_diag) and the surrounding rotations, against central
+    differences of the dense oracle."""
+    tc = tcd
+    n = 14
+    qs = [0, 5, 9, 13, 2]
+
+    def energy(p):
+        c = tc.Circuit(n)
+        for i in range(n):
+            c.h(i)
+            c.rx(i, theta=p[i])
+        c.rzm(*qs, theta=p[n])
+        for i in range(n):
+            c.ry(i, theta=p[n + 1 + i])
+        return tc.backend.real(c.expectation((tc.gates.x(), [5])) + c.expectation((tc.gates.z(), [0]), (tc.gates.z(), [9])))
+
+    def ref(p):
+        ops = []
+        for i in range(n):
+            ops += [(G.H, [i]), (G.rx(p[i]), [i])]
+        zs = np.array([1.0])
+        for _ in qs:
+            zs = np.kron(zs, [1.0, -1.0])
+        ops.append((np.diag(np.exp(-0.5j * p[n] * zs)), qs))
+        for i in range(n):
+            ops.append((G.ry(p[n + 1 + i]), [i]))
+        psi = dense.run(n, ops)
+        return (dense.expectation(psi, n, (G.X, [5])) + dense.expectation(psi, n, (G.Z, [0]), (G.Z, [9]))).real
+
+    p0 = np.random.default_rng(2).uniform(0.2, 1.4, 2 * n + 1)
+    rdt = np.float32 if tc.dtypestr == "complex64" else np.float64
+    v, g = tc.backend.value_and_grad(energy)(tc.backend.convert_to_tensor(p0.astype(rdt)))
+    g = _np(tc, g).astype(np.float64)
+    pb = p0.astype(rdt).astype(np.float64)
+    assert abs(float(v) - ref(pb)) < (2e-5 if rdt == np.float32 else 1e-10)
+    for i in (n, 3, n + 4, 2 * n):
+        pp, pm = pb.copy(), pb.copy()
+        pp[i] += 1e-6
+        pm[i] -= 1e-6
+        fd = (ref(pp) - ref(pm)) / 2e-6
+        assert abs(g[i] - fd) < (2e-4 if rdt == np.float32 else 1e-7), (i, g[i], fd)
