@@ -190,6 +190,9 @@ class CompiledCircuit:
             B = params2.shape[0]
             if params2.shape[1] < self.nparams:
                 raise ValueError("parameter vector shorter than the plan's parameter count")
+            if params2.numel() == 0:     # an empty parameter row (constant gates on a differentiated input state)
+                params2 = torch.zeros(max(B, 1), 1, dtype=self.rdtype, device=self.device)
+                B = params2.shape[0]
         if inputs is not None:
             inp = inputs.reshape(-1, 2**self.n).to(device=self.device, dtype=self.tdtype)
             if params is None:

@@ -246,3 +246,83 @@ class DistributedContractor:
 
     def grad(self, params: Any, op: Optional[Callable[[Tensor], Tensor]] = None, output_dtype: Optional[str] = None) -> Any:
         return self.value_and_grad(params, op, output_dtype)[1]
+
+
+# ---- output-wavefunction slicing (reference examples/slicing_wavefunction_vqa.py:20-36,76-103) -------------------------
+def sliced_state(c, cut: List[int], mask) -> Tensor:
+    """The output state of circuit ``c`` projected on ``|mask>`` of the qubits ``cut``: 2^(n - len(cut)) amplitudes with
+    the remaining qubits in circuit order, contracted as a tensor network with the projected legs capped -- the whole
+    2^n state never exists (reference ``sliced_state``: one-hot ends on ``front[cut]``, ``tc.contractor(nodes + ends,
+    output_edge_order=...)``).  Differentiable in the gate parameters (``tn.TensordotFn``)."""
+    import torch
+
+    from . import tn as _tn
+
+    n = c._nqubits
+    cut = [int(q) % n for q in cut]
+    if len(set(cut)) != len(cut):
+        raise ValueError("cut qubits must be distinct")
+    mask = [int(round(float(m))) for m in (cons.backend.numpy(mask).reshape(-1) if not isinstance(mask, (list, tuple)) else mask)]
+    if len(mask) != len(cut):
+        raise ValueError("one mask bit per cut qubit")
+    dt = getattr(torch, cons.dtypestr)
+    nodes, front = c._tn_nodes()
+    for q, b in zip(cut, mask):
+        v = torch.zeros(2, dtype=dt, device=cons.backend.device)
+        v[b] = 1.0
+        nodes.append(_tn.Node(v, [front[q]], "slice-end"))
+    oeo = [front[i] for i in range(n) if i not in cut]
+    res = _tn.contract_nodes(nodes, output_edge_order=oeo)
+    return res.tensor.reshape(-1)
+
+
+def sliced_expectation_ps(circuit_fn: Callable[[], Any], ps, cut: List[int], masks=None) -> Tensor:
+    """<psi| P |psi> of the Pauli string ``ps`` (0/1/2/3 per qubit) as a sum over the 2^k projections of the ``cut``
+    qubits, each term built from two sliced states of 2^(n-k) amplitudes (reference ``sliced_core`` /
+    ``sliced_expectation_and_grad``): P on the cut qubits maps |m> to phase(m) |m ^ x_cut>, the rest of the string is
+    applied to the sliced ket (module-level ``expectation(ket=, bra=)``).  The 2^k terms are independent: with an
+    initialised process group they are dealt to the ranks in contiguous blocks (``distributed.shard_range``) and the
+    partial sums meet in one all-reduce -- the multi-GPU route for a state that does not fit one HBM.  ``masks``
+    restricts the sum (testing).  Returns the real part (``ps`` is Hermitian)."""
+    import itertools
+
+    import torch
+    import torch.distributed as dist
+
+    from . import gates as _G
+    from .circuit import expectation as state_expectation
+
+    c = circuit_fn()
+    n = c._nqubits
+    ps = [int(p) for p in ps]
+    cut = [int(q) % n for q in cut]
+    rest = [i for i in range(n) if i not in cut]
+    pos = {q: j for j, q in enumerate(rest)}
+    ops_rest = [(getattr(_G, "ixyz"[ps[q]])(), [pos[q]]) for q in rest if ps[q] != 0]
+    allm = list(itertools.product((0, 1), repeat=len(cut))) if masks is None else [tuple(m) for m in masks]
+    rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    lo, hi = D.shard_range(len(allm), rank, world)
+    total = None
+    for m1 in allm[lo:hi]:
+        # P_cut |m1> = phase |m2>: X, Y flip the bit; Y contributes i (-1)^b, Z contributes (-1)^b
+        phase, m2 = 1.0 + 0.0j, list(m1)
+        for j, q in enumerate(cut):
+            b = m1[j]
+            if ps[q] == 1:
+                m2[j] = 1 - b
+            elif ps[q] == 2:
+                m2[j] = 1 - b
+                phase *= 1j * (1 - 2 * b)
+            elif ps[q] == 3:
+                phase *= (1 - 2 * b)
+        ket = sliced_state(circuit_fn(), cut, m1)
+        bra = ket if tuple(m2) == tuple(m1) else sliced_state(circuit_fn(), cut, m2)
+        term = phase * state_expectation(*ops_rest, ket=ket, bra=bra)
+        total = term if total is None else total + term
+    if total is None:
+        total = torch.zeros((), dtype=getattr(torch, cons.dtypestr), device=cons.backend.device)
+    if world > 1:
+        re, im = D.allreduce_sum_packed([total.real.reshape(1), total.imag.reshape(1)])
+        return re.reshape(())
+    return total.real

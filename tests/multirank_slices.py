@@ -114,7 +114,21 @@ def worker(rank, world, port, out):
         res["vqa_" + dt] = {"nslices": int(dc.tree.nslices), "mine": dc.my_slices, "value": float(v),
                             "grad": tc.backend.numpy(g).astype(np.float64).tolist(),
                             "value_only": float(dc.value(pt).real)}
+    # ---- output-wavefunction slicing (examples/slicing_wavefunction_vqa.py): the 2^3 projections of three cut qubits
+    # dealt to the ranks, one all-reduce ----
     tc.set_dtype("complex128")
+    from tcmi.experimental import sliced_expectation_ps
+    from oracle import workloads as OW
+
+    nw, dw = 12, 3
+    pw = tc.backend.convert_to_tensor(np.random.default_rng(4).uniform(0, 2 * np.pi, [2 * dw, nw]))
+
+    def wcirc():
+        c = tc.Circuit(nw)
+        OW.hea_b(c, nw, dw, pw, zz=tc.gates._zz_matrix)
+        return c
+
+    res["wfslice"] = float(sliced_expectation_ps(wcirc, [0, 1, 0, 0, 3, 2, 0, 0, 0, 3, 1, 0], [1, 5, 9]))
     allres = [None] * world
     dist.all_gather_object(allres, res)
     if rank == 0:

@@ -74,6 +74,17 @@ def test_two_rank_slice_shard_equals_single_process():
         # one slice on two ranks: rank 1 holds only -1 padding and contributes zero (experimental.py:881-890)
         assert r0["rqc_padding"]["nslices"] == 1 and r0["rqc_padding"]["table"] == [[0], [-1]]
         assert r0["rqc_padding"]["mine"] == [0] and r1["rqc_padding"]["mine"] == []
+
+        # ---- output-wavefunction slicing: the mask sum sharded over the two ranks equals expectation_ps ----
+        from oracle import workloads as OW
+
+        nw, dw = 12, 3
+        pw = tc.backend.convert_to_tensor(np.random.default_rng(4).uniform(0, 2 * np.pi, [2 * dw, nw]))
+        cw = tc.Circuit(nw)
+        OW.hea_b(cw, nw, dw, pw, zz=tc.gates._zz_matrix)
+        want = float(tc.backend.numpy(tc.backend.real(cw.expectation_ps(x=[1, 10], y=[5], z=[4, 9]))))
+        for r in ranks:
+            assert abs(r["wfslice"] - want) < 1e-10, (r["wfslice"], want)
     finally:
         tc.set_dtype("complex64")
 

@@ -669,3 +669,45 @@ def test_dma_pipelined_join_gemm_matches_complex128_and_the_plain_kernel(shape, 
         _lib.check(_lib.lib().tcmi_cgemm(a2.data_ptr(), b.data_ptr(), c2.data_ptr(), M2, N, K, batch, M2 * K, K * N,
                                          M2 * N, 1, _lib.TCMI_C64, st), "tcmi_cgemm")
         assert float((c2 - c[:, :M2]).abs().max()) < 1e-5 * float(ref.abs().max())
+
+
+def test_output_wavefunction_slicing_matches_the_full_state(tcd):
+    """``experimental.sliced_state`` / ``sliced_expectation_ps`` (reference examples/slicing_wavefunction_vqa.py): the
+    state projected on every mask of three cut qubits equals the corresponding amplitudes of the full state; the Pauli
+    string expectation summed over the 2^3 mask pairs equals ``expectation_ps`` (X, Y and Z on cut and kept qubits);
+    its gradient through the sliced route equals the adjoint sweep's."""
+    import itertools
+    tc = tcd
+    from tcmi.experimental import sliced_expectation_ps, sliced_state
+
+    n, d = 12, 3
+    rng = np.random.default_rng(4)
+    rdt = np.float32 if tc.dtypestr == "complex64" else np.float64
+    pv = rng.uniform(0, 2 * np.pi, [2 * d, n]).astype(rdt)
+    tol = 2e-5 if tc.dtypestr == "complex64" else 1e-10
+
+    def circ(p):
+        c = tc.Circuit(n)
+        W.hea_b(c, n, d, p, zz=tc.gates._zz_matrix)
+        return c
+
+    pt = tc.backend.convert_to_tensor(pv)
+    full = tc.backend.numpy(circ(pt).state()).reshape([2] * n)
+    cut = [1, 5, 9]
+    for mask in itertools.product((0, 1), repeat=3):
+        got = tc.backend.numpy(sliced_state(circ(pt), cut, list(mask)))
+        idx = [slice(None)] * n
+        for q, b in zip(cut, mask):
+            idx[q] = b
+        np.testing.assert_allclose(got, full[tuple(idx)].reshape(-1), atol=tol)
+    for ps in ([0, 1, 0, 0, 3, 2, 0, 0, 0, 3, 1, 0], [3, 3] + [0] * 10, [0, 2, 2, 0, 0, 1, 0, 1, 0, 0, 0, 3]):
+        want = float(tc.backend.numpy(tc.backend.real(circ(pt).expectation_ps(
+            x=[i for i, p in enumerate(ps) if p == 1], y=[i for i, p in enumerate(ps) if p == 2],
+            z=[i for i, p in enumerate(ps) if p == 3]))))
+        got = float(sliced_expectation_ps(lambda: circ(pt), ps, cut))
+        assert abs(got - want) < tol, (ps, got, want)
+    ps = [0, 1, 0, 0, 3, 2, 0, 0, 0, 3, 1, 0]
+    v1, g1 = tc.backend.value_and_grad(lambda p: sliced_expectation_ps(lambda: circ(p), ps, cut))(pt)
+    v2, g2 = tc.backend.value_and_grad(lambda p: tc.backend.real(circ(p).expectation_ps(x=[1, 10], y=[5], z=[4, 9])))(pt)
+    assert abs(float(v1) - float(v2)) < tol
+    assert float((g1 - g2).abs().max()) < (2e-4 if tc.dtypestr == "complex64" else 1e-8)
