@@ -376,8 +376,10 @@ def rqc_leg(tc, torch, dist, args, rank, world):
 
     t0 = time.perf_counter()
     dc = DistributedContractor(nodes_fn, None, cotengra_options={
-        "slicing_opts": {"target_size": 2 ** args.rqc_log2_target}, "max_repeats": 128})
+        "slicing_opts": {"target_size": 2 ** args.rqc_log2_target}, "max_repeats": 128,
+        "seed": list(range(args.rqc_seeds))})
     search_s = time.perf_counter() - t0
+    seeds = list(DistributedContractor.last_search)
     v = dc.value(None, op=lambda x: x)          # staging run
     torch.cuda.synchronize()
     if dist is not None:
@@ -456,6 +458,11 @@ def rqc_leg(tc, torch, dist, args, rank, world):
         "contract_s": t, "tflops": (cnt["gemm_flops"] + cnt["scattered_flops"]) / t / 1e12,
         "algorithmic_tflops_sliced_tree": flops / t / 1e12, "path_search_s": round(search_s, 2),
         "steps_per_slice": len(steps), "slice_invariant_steps": n_inv, "time_split": split,
+        # the search is a small hyper-search over seeds (whole pipeline per seed, best tree by the engine's time model)
+        "path_search": {"seeds": len(seeds), "best_model_ms": min(x["model_time_s"] for x in seeds) * 1e3,
+                        "median_model_ms": float(np.median([x["model_time_s"] for x in seeds])) * 1e3,
+                        "per_seed_model_ms": [round(x["model_time_s"] * 1e3, 1) for x in seeds],
+                        "per_seed_search_s": [x["search_s"] for x in seeds]} if seeds else None,
         "amplitude": [float(v.real), float(v.imag)],
         # F_alg of the executed (sliced, slice-invariant parts once) steps over the wall time against the f32 MFMA
         # peak; stand-alone permutes are traffic outside B_alg ("wasted")
@@ -642,6 +649,7 @@ def main():
     ap.add_argument("--mps-chains", type=int, default=16, help="config 5: independent chains through backend.vmap (0/1 disables)")
     ap.add_argument("--rqc-depth", type=int, default=16, help="config 4 leg (32-qubit RQC amplitude): depth; 0 disables")
     ap.add_argument("--rqc-log2-target", type=int, default=27)
+    ap.add_argument("--rqc-seeds", type=int, default=8, help="config 4: seeds of the path hyper-search")
     ap.add_argument("--svqa-qubits", type=int, default=30, help="sliced-VQA leg (value_and_grad of a sliced network): qubits; 0 disables")
     ap.add_argument("--svqa-depth", type=int, default=8)
     ap.add_argument("--svqa-slices", type=int, default=8)

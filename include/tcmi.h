@@ -50,6 +50,16 @@ int tcmi_init_zero_state(void* state, long long state_stride, int batch, int n, 
 int tcmi_subtree_dp(int k, int W, const unsigned long long* masks, const double* lw, double cap, double alpha,
                     int* split, double* best_full);
 
+/* Host code, no device work: the random-greedy pairwise path of a circuit network (every index has dimension 2 and at most
+ * two ends; one end = an output index) -- opt_einsum's RandomGreedy, which the reference reaches through cotengra's
+ * "greedy" method (tensorcircuit/cons.py:1168-1190).  masks: ntensors x W 64-bit words (bit e = index e), outmask: the
+ * output indices; alpha: the size-difference weight; temperature > 0: Boltzmann choice among the nbranch best candidates,
+ * one pre-drawn uniform number per step (`uniforms`).  ssa[2 * step + {0, 1}] = the contracted pair in SSA numbering.
+ * Returns the number of steps (ntensors - 1 for a connected network) or a negative error. */
+int tcmi_greedy_path(int ntensors, int W, const unsigned long long* masks, const unsigned long long* outmask,
+                     double alpha, double temperature, int nbranch, const double* uniforms, int nuniforms, int* ssa);
+
+
 /* Gate-table builder: per batch element, turn the flat real parameter vector into the dense gate
  * matrices  M = C0 + cos(k*theta+o) C1 + sin(k*theta+o) C2  and the diagonal phase coefficients the
  * pass programs reference.  `ginfo` = int32[nrec][8] records {kind, out_slot, param_index, dim,

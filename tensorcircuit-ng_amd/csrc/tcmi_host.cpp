@@ -83,3 +83,221 @@ extern "C" int tcmi_subtree_dp(int k, int W, const unsigned long long* masks, co
   *best_full = best[full];
   return TCMI_OK;
 }
+
+// ---- random-greedy pairwise path of a circuit network (tcmi/tn.py::greedy_path, opt_einsum's RandomGreedy; the reference
+// reaches it through cotengra's "greedy" method, tensorcircuit/cons.py:1168-1190) ----------------------------------------
+// Two thirds of a path search were this loop in Python (257 calls of 60 ms for the 32-qubit RQC).  Same algorithm, same
+// arithmetic and tie-breaking: candidates (cost, a, b) ordered lexicographically, cost = 2^|out| - alpha (2^|a| + 2^|b|)
+// with exact integer sizes converted once; stale heap entries re-costed on pop; with temperature > 0 the next pair is
+// drawn from the nbranch best candidates with Boltzmann weights by inverse CDF of ONE pre-drawn uniform number per
+// step (`uniforms`, drawn by the caller's numpy generator: the choice is reproducible on every rank).
+// Networks: every index has dimension 2 and at most two ends (one end: an output index).  inputs as bit masks of W
+// 64-bit words per tensor.  ssa[2 * step] receives the (a, b) tensor ids in SSA numbering; returns the step count.
+#include <algorithm>
+#include <queue>
+
+namespace {
+struct Cand {
+  double cost;
+  int a, b;
+  bool operator>(const Cand& o) const {
+    if (cost != o.cost) return cost > o.cost;
+    if (a != o.a) return a > o.a;
+    return b > o.b;
+  }
+};
+}  // namespace
+
+extern "C" int tcmi_greedy_path(int ntensors, int W, const unsigned long long* masks, const unsigned long long* outmask,
+                                double alpha, double temperature, int nbranch, const double* uniforms, int nuniforms,
+                                int* ssa) {
+  if (ntensors < 1 || W < 1 || W > 256 || !masks || !outmask || !ssa || nbranch < 1 || nbranch > 64) return -1;
+  const int cap = 2 * ntensors;
+  std::vector<uint64_t> live((size_t)cap * W, 0);
+  std::vector<char> alive(cap, 0);
+  std::vector<int> len(cap, 0);
+  for (int i = 0; i < ntensors; ++i) {
+    int c = 0;
+    for (int w = 0; w < W; ++w) {
+      live[(size_t)i * W + w] = masks[(size_t)i * W + w];
+      c += __builtin_popcountll(masks[(size_t)i * W + w]);
+    }
+    len[i] = c;
+    alive[i] = 1;
+  }
+  // owners of every index (at most two live tensors)
+  const int nbits = 64 * W;
+  std::vector<int> own((size_t)nbits * 2, -1);
+  auto add_owner = [&](int e, int t) {
+    if (own[2 * e] < 0) own[2 * e] = t;
+    else own[2 * e + 1] = t;
+  };
+  auto del_owner = [&](int e, int t) {
+    if (own[2 * e] == t) own[2 * e] = own[2 * e + 1], own[2 * e + 1] = -1;
+    else if (own[2 * e + 1] == t) own[2 * e + 1] = -1;
+  };
+  for (int i = 0; i < ntensors; ++i)
+    for (int w = 0; w < W; ++w) {
+      uint64_t x = live[(size_t)i * W + w];
+      while (x) {
+        add_owner(64 * w + __builtin_ctzll(x), i);
+        x &= x - 1;
+      }
+    }
+  auto pow2 = [](int l) -> double { return std::ldexp(1.0, l); };
+  auto size_sum = [&](int la, int lb) -> double {
+    // Python: alpha * (2^la + 2^lb) with an exact integer sum rounded once to double
+    if (la < 63 && lb < 63) return (double)((1ull << la) + (1ull << lb));
+    const int hi = la > lb ? la : lb, lo = la > lb ? lb : la;
+    if (hi - lo > 53) return std::ldexp(1.0, hi);
+    return std::ldexp(1.0, hi) + std::ldexp(1.0, lo);
+  };
+  std::vector<uint64_t> tmp(W);
+  auto merged_len = [&](int a, int b) -> int {
+    int c = 0;
+    const uint64_t *sa = &live[(size_t)a * W], *sb = &live[(size_t)b * W];
+    for (int w = 0; w < W; ++w) c += __builtin_popcountll((sa[w] ^ sb[w]) | (sa[w] & sb[w] & outmask[w]));
+    return c;
+  };
+  auto cost_of = [&](int a, int b) -> double { return pow2(merged_len(a, b)) - alpha * size_sum(len[a], len[b]); };
+  std::priority_queue<Cand, std::vector<Cand>, std::greater<Cand>> heap;
+  std::vector<int> seen_stamp(cap, -1);
+  int stamp = 0;
+  auto push = [&](int i) {
+    ++stamp;
+    for (int w = 0; w < W; ++w) {
+      uint64_t x = live[(size_t)i * W + w];
+      while (x) {
+        const int e = 64 * w + __builtin_ctzll(x);
+        x &= x - 1;
+        for (int s = 0; s < 2; ++s) {
+          const int j = own[2 * e + s];
+          if (j < 0 || j == i || !alive[j] || seen_stamp[j] == stamp) continue;
+          seen_stamp[j] = stamp;
+          const int a = i < j ? i : j, b = i < j ? j : i;
+          heap.push(Cand{cost_of(a, b), a, b});
+        }
+      }
+    }
+  };
+  for (int i = 0; i < ntensors; ++i) push(i);
+  auto pop_valid = [&](Cand& out) -> bool {
+    while (!heap.empty()) {
+      Cand c = heap.top();
+      heap.pop();
+      if (!alive[c.a] || !alive[c.b]) continue;
+      const double real = cost_of(c.a, c.b);
+      if (real != c.cost) {
+        c.cost = real;
+        heap.push(c);
+        continue;
+      }
+      out = c;
+      return true;
+    }
+    return false;
+  };
+  int nxt = ntensors, nstep = 0, ustep = 0;
+  std::vector<Cand> cands;
+  std::vector<double> wts;
+  while (!heap.empty()) {
+    Cand first;
+    if (!pop_valid(first)) break;
+    if (temperature > 0 && uniforms) {
+      cands.clear();
+      cands.push_back(first);
+      while ((int)cands.size() < nbranch) {
+        Cand c;
+        if (!pop_valid(c)) break;
+        bool dup = false;
+        for (const Cand& o : cands) dup = dup || (o.a == c.a && o.b == c.b);
+        if (dup) continue;
+        cands.push_back(c);
+      }
+      const double c0 = cands[0].cost;
+      const double scale = temperature * std::max(1.0, std::fabs(c0));
+      wts.assign(cands.size(), 0.0);
+      double tot = 0.0;
+      for (size_t q = 0; q < cands.size(); ++q) {
+        wts[q] = std::exp(-(cands[q].cost - c0) / scale);
+        tot += wts[q];
+      }
+      // numpy's Generator.choice(n, p = w / sum w): cdf = cumsum(p), cdf /= cdf[-1], first index with u < cdf
+      const double u = ustep < nuniforms ? uniforms[ustep] : 0.5;
+      ++ustep;
+      double acc = 0.0;
+      for (size_t q = 0; q < cands.size(); ++q) {
+        acc += wts[q] / tot;
+        wts[q] = acc;
+      }
+      size_t k = cands.size() - 1;
+      for (size_t q = 0; q < cands.size(); ++q)
+        if (u < wts[q] / acc) {
+          k = q;
+          break;
+        }
+      for (size_t q = 0; q < cands.size(); ++q)
+        if (q != k) heap.push(cands[q]);
+      first = cands[k];
+    }
+    const int a = first.a, b = first.b;
+    if (nxt >= cap) return -2;
+    uint64_t* m = &live[(size_t)nxt * W];
+    const uint64_t *sa = &live[(size_t)a * W], *sb = &live[(size_t)b * W];
+    int c = 0;
+    for (int w = 0; w < W; ++w) {
+      m[w] = (sa[w] ^ sb[w]) | (sa[w] & sb[w] & outmask[w]);
+      c += __builtin_popcountll(m[w]);
+    }
+    for (int t : {a, b}) {
+      for (int w = 0; w < W; ++w) {
+        uint64_t x = live[(size_t)t * W + w];
+        while (x) {
+          del_owner(64 * w + __builtin_ctzll(x), t);
+          x &= x - 1;
+        }
+      }
+      alive[t] = 0;
+    }
+    len[nxt] = c;
+    alive[nxt] = 1;
+    for (int w = 0; w < W; ++w) {
+      uint64_t x = m[w];
+      while (x) {
+        add_owner(64 * w + __builtin_ctzll(x), nxt);
+        x &= x - 1;
+      }
+    }
+    ssa[2 * nstep] = a;
+    ssa[2 * nstep + 1] = b;
+    ++nstep;
+    push(nxt);
+    ++nxt;
+  }
+  // leftovers (disconnected components): outer products, smallest first (ties: lowest id, as Python's stable sort)
+  std::vector<int> rest;
+  for (int i = 0; i < nxt; ++i)
+    if (alive[i]) rest.push_back(i);
+  auto by_size = [&](int x, int y) { return len[x] != len[y] ? len[x] < len[y] : false; };
+  std::stable_sort(rest.begin(), rest.end(), by_size);
+  while (rest.size() > 1) {
+    const int a = rest[0], b = rest[1];
+    if (nxt >= cap) return -2;
+    int c = 0;
+    for (int w = 0; w < W; ++w) {
+      live[(size_t)nxt * W + w] = live[(size_t)a * W + w] | live[(size_t)b * W + w];
+      c += __builtin_popcountll(live[(size_t)nxt * W + w]);
+    }
+    len[nxt] = c;
+    ssa[2 * nstep] = a;
+    ssa[2 * nstep + 1] = b;
+    ++nstep;
+    std::vector<int> nr;
+    nr.push_back(nxt);
+    for (size_t q = 2; q < rest.size(); ++q) nr.push_back(rest[q]);
+    std::stable_sort(nr.begin(), nr.end(), by_size);
+    rest.swap(nr);
+    ++nxt;
+  }
+  return nstep;
+}

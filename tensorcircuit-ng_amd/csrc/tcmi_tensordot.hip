@@ -1307,7 +1307,7 @@ int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, 
 #define TCMI_DMA_LAUNCH(S)                                                                                           \
   {                                                                                                                  \
     if ((S) * TCMI_DMA_STAGE_BYTES > 48 * 1024)                                                                      \
-      hipFuncSetAttribute(reinterpret_cast<const void*>(tcmi::cgemm_dma_kernel<S>),                                 \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tcmi::cgemm_dma_kernel<S>),                               \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (S) * TCMI_DMA_STAGE_BYTES);                  \
     hipLaunchKernelGGL(tcmi::cgemm_dma_kernel<S>, grid, block, (S) * TCMI_DMA_STAGE_BYTES, st,                      \
                        reinterpret_cast<const float2*>(A), reinterpret_cast<const float2*>(B),                      \

@@ -34,6 +34,11 @@ _SIGNATURES = {
         [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong,
          ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_void_p],
     ),
+    "tcmi_greedy_path": (
+        ctypes.c_int,
+        [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_int,
+         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p],
+    ),
     "tcmi_subtree_dp": (
         ctypes.c_int,
         [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_double,

@@ -11,6 +11,7 @@ of shape ``[2] * rank`` (every circuit network has dimension-2 edges).
 import ctypes
 import os
 import heapq
+import math
 import itertools
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional, Sequence, Tuple
@@ -211,6 +212,17 @@ def greedy_path(inputs: Sequence[Sequence[int]], output: Sequence[int], size_dic
         for e in s:
             uses[e] = uses.get(e, 0) + 1
             owners.setdefault(e, set()).add(i)
+    # one uniform number per step, drawn up front: the Boltzmann choice is an inverse-CDF look-up, the same in this
+    # loop and in the library's (tcmi_greedy_path)
+    # (numpy's Generator.choice(n, p=...) is exactly this: one uniform number, a look-up in the normalised cumulative
+    # sum -- so the trees are those of the rng.choice formulation this replaces)
+    uniforms = rng.random(max(1, len(inputs) - 1)) if (temperature > 0 and rng is not None) else None
+    circuit_net = all(d == 2 for d in size_dict.values()) and \
+        all(v == 2 or (v == 1 and e in out_set) for e, v in uses.items())
+    if circuit_net and memory_limit is None:
+        ssa_n = _native_greedy(inputs, out_set, alpha, temperature, nbranch, uniforms)
+        if ssa_n is not None:
+            return _ssa_to_linear(ssa_n, len(inputs))
 
     def sz(s):
         r = 1
@@ -281,8 +293,20 @@ def greedy_path(inputs: Sequence[Sequence[int]], output: Sequence[int], size_dic
                 cands.append(c)
             c0 = cands[0][0]
             scale = temperature * max(1.0, abs(c0))
-            w = np.array([np.exp(-(c[0] - c0) / scale) for c in cands])
-            k = int(rng.choice(len(cands), p=w / w.sum()))
+            w = [math.exp(-(c[0] - c0) / scale) for c in cands]
+            tot = 0.0
+            for x in w:
+                tot += x
+            cdf, acc = [], 0.0
+            for x in w:
+                acc += x / tot
+                cdf.append(acc)
+            u = float(uniforms[len(ssa)]) if len(ssa) < len(uniforms) else 0.5
+            k = len(cands) - 1
+            for i, x in enumerate(cdf):
+                if u < x / cdf[-1]:
+                    k = i
+                    break
             for i, c in enumerate(cands):
                 if i != k:
                     heapq.heappush(heap, (c[0], c[1], c[2]))
@@ -307,9 +331,13 @@ def greedy_path(inputs: Sequence[Sequence[int]], output: Sequence[int], size_dic
         ssa.append((a, b))
         rest = sorted([nxt] + rest[2:], key=lambda i: sz(live[i]))
         nxt += 1
-    ids = list(range(len(inputs)))
+    return _ssa_to_linear(ssa, len(inputs))
+
+
+def _ssa_to_linear(ssa, n: int) -> List[Tuple[int, int]]:
+    ids = list(range(n))
     path = []
-    k = len(inputs)
+    k = n
     for a, b in ssa:
         ia, ib = ids.index(a), ids.index(b)
         path.append((min(ia, ib), max(ia, ib)))
@@ -318,6 +346,48 @@ def greedy_path(inputs: Sequence[Sequence[int]], output: Sequence[int], size_dic
         ids.append(k)
         k += 1
     return path
+
+
+_NATIVE_GREEDY: List[Any] = []
+
+
+def _native_greedy(inputs, out_set, alpha, temperature, nbranch, uniforms):
+    """``tcmi_greedy_path`` of libtcmi (host code) on a circuit network, or None (library not built / switched off with
+    TCMI_TN_NATIVE_GREEDY=0): the Python loop then runs, with the same choices."""
+    if os.environ.get("TCMI_TN_NATIVE_GREEDY", "1") == "0":
+        return None
+    if not _NATIVE_GREEDY:
+        try:
+            _NATIVE_GREEDY.append(_lib.lib().tcmi_greedy_path)
+        except Exception:  # noqa: BLE001
+            _NATIVE_GREEDY.append(None)
+    fn = _NATIVE_GREEDY[0]
+    if fn is None:
+        return None
+    labels: Dict[int, int] = {}
+    for s in inputs:
+        for e in s:
+            labels.setdefault(e, len(labels))
+    for e in out_set:
+        labels.setdefault(e, len(labels))
+    W = max(1, (len(labels) + 63) // 64)
+    nt = len(inputs)
+    masks = np.zeros((nt, W), dtype=np.uint64)
+    for i, s in enumerate(inputs):
+        for e in s:
+            b = labels[e]
+            masks[i, b >> 6] |= np.uint64(1) << np.uint64(b & 63)
+    outm = np.zeros(W, dtype=np.uint64)
+    for e in out_set:
+        b = labels[e]
+        outm[b >> 6] |= np.uint64(1) << np.uint64(b & 63)
+    ssa = np.zeros(2 * max(1, nt), dtype=np.int32)
+    un = np.ascontiguousarray(uniforms, dtype=np.float64) if uniforms is not None else None
+    r = fn(nt, W, masks.ctypes.data, outm.ctypes.data, float(alpha), float(temperature if un is not None else 0.0),
+           int(nbranch), un.ctypes.data if un is not None else None, len(un) if un is not None else 0, ssa.ctypes.data)
+    if r < 0:
+        return None
+    return [(int(ssa[2 * k]), int(ssa[2 * k + 1])) for k in range(r)]
 
 
 def _path_stats(inputs, output, size_dict, path):

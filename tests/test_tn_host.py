@@ -371,6 +371,7 @@ def test_cotengra_options_are_honoured_or_refused():
     o = DC._parse_options({"slicing_opts": {"target_slices": 8}, "max_repeats": 16, "progbar": True,
                            "minimize": "combo", "parallel": True})
     assert o["target_slices"] == 8 and o["target_size"] is None and o["minimize"] == "combo" and o["max_repeats"] == 16
+    assert o["seeds"] == [0] and DC._parse_options({"seed": [3, 5]})["seeds"] == [3, 5]
     assert DC._parse_options(None)["target_size"] == 2**28
     for bad in ({"optlib": "optuna"}, {"slicing_opts": {"target_overhead": 2}}, {"minimize": "foo"},
                 {"methods": ["kahypar"]}, {"max_time": 3}):
@@ -424,3 +425,26 @@ def test_invariant_subtrees_are_split_over_the_ranks_once_each():
             for r, lg in roots_of[k]:
                 assert r in steps_of[k]
         assert max(loads) <= sum(loads)
+
+
+def test_native_greedy_path_equals_the_python_loop(monkeypatch):
+    """``tcmi_greedy_path`` (host code of libtcmi) against the Python random-greedy loop on circuit networks: the same
+    pairs in the same order for the deterministic search and for random-greedy draws (temperature / alpha / seed), with
+    output indices and a disconnected component."""
+    from tcmi import tn
+
+    rng0 = np.random.default_rng(0)
+    for case in range(6):
+        nt = int(rng0.integers(20, 90))
+        inputs, output, sd = _rand_net(nt, 3, 100 + case, dangling=case % 3)
+        if case == 4:                       # a second, disconnected component
+            base = max(sd) + 1
+            inputs += [[base, base + 1], [base + 1, base + 2], [base + 2, base]]
+            sd.update({base + k: 2 for k in range(3)})
+        for temp, alpha in ((0.0, 1.0), (0.2, 1.0), (0.01, 0.5), (1.0, 1.5)):
+            monkeypatch.setenv("TCMI_TN_NATIVE_GREEDY", "1")
+            a = tn.greedy_path(inputs, output, sd, temperature=temp, alpha=alpha, rng=np.random.default_rng(case))
+            monkeypatch.setenv("TCMI_TN_NATIVE_GREEDY", "0")
+            b = tn.greedy_path(inputs, output, sd, temperature=temp, alpha=alpha, rng=np.random.default_rng(case))
+            assert a == b, (case, temp, alpha)
+            assert len(a) == len(inputs) - 1
