@@ -232,7 +232,10 @@ def vqe_leg(tc, torch, dist, args, rank, world, dev):
         "measure_pass": hbm_entry(f"tcmi::measure2_kernel<{mcfg.R},{mcfg.LT}> (fused Pauli-sum measurement)"
                                   if mcfg.gen >= 2 else f"tcmi::pass_kernel<float,{mcfg.R},{mcfg.LT},1> (fused Pauli-sum measurement)",
                                   ev.get("measure"), args.vqe_steps),
-        "pauli_sum": hbm_entry("tcmi::pauli_sum_kernel (cotangent of the energy)", ev.get("pauli_sum"), args.vqe_steps),
+        # tile passes (3 launches per micro-batch for the TFIM: 2 + 3 + 3 state transfers) that also return the energy:
+        # the traced step runs no measurement pass (measure_pass is null then)
+        "pauli_sum": hbm_entry("tcmi::pauli_tile_kernel (cotangent of the energy as tile passes, returns the energy too)",
+                               ev.get("pauli_sum"), args.vqe_steps),
         "step": {
             "bound": "hbm", "executed_bytes_per_step": exec_bytes, "achieved": exec_bytes / step_s / 1e9,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": exec_bytes / step_s / 1e9 / HBM_PEAK_GBS,
@@ -242,6 +245,21 @@ def vqe_leg(tc, torch, dist, args, rank, world, dev):
             "B_vg_convention_bytes": 3.0 * b_fwd + (2 * n - 1) * 2.0 * S,
         },
     }
+    # The gate passes are bound by VALU issue, not by HBM (PMC: profiles/r03*_vqe_n28_d12_pmc.txt): next to the byte rates,
+    # the FP32 rate of the GATE ARITHMETIC ALONE (one-qubit gates in three-shear form: 3 packed FMAs = 12 flops per
+    # amplitude pair; the reverse sweep applies U^dagger to psi and lambda and forms the generator's expectation: 32 flops
+    # per pair) against the 157.3 TFLOP/s vector peak -- phase tables, Walsh transforms and exchanges come on top
+    ngates = n * (d + 1)
+    def _valu(ev_key, flops_per_pair):
+        e = ev.get(ev_key)
+        if not e or e["ms"] <= 0:
+            return None
+        per_step_s = e["ms"] * 1e-3 / max(1, args.vqe_steps)
+        fl = float(hi - lo) * ngates * (2.0 ** (n - 1)) * flops_per_pair
+        return {"bound": "valu", "gate_arithmetic_flops_per_step": fl, "achieved": fl / per_step_s / 1e12,
+                "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s", "frac": fl / per_step_s / 1e12 / MFMA_F32_PEAK_TFS}
+    roof["forward_pass_valu"] = _valu("pass", 12.0)
+    roof["adjoint_pass_valu"] = _valu("adjoint", 32.0)
     return {
         "roofline": roof,
         "workload": f"HEA-B n={n} depth={d} TFIM value_and_grad (55-term style energy), vmap batch {Bg} "
@@ -676,7 +694,7 @@ def main():
 
     # HBM traffic of the dominant kernel, measured by the PMC counters on this very command (child processes,
     # started before this process touches the GPU)
-    KERNELS = ("cgemm_mfma_kernel", "pass2_kernel")
+    KERNELS = ("cgemm_dma128_kernel", "cgemm_dma_kernel", "cgemm_mfma_kernel", "pass2_kernel")
     traffic = {}
     if rank == 0 and world == 1 and not args.no_traffic_probe:
         traffic = traffic_probe(args, KERNELS)
@@ -822,9 +840,13 @@ def main():
             avg_us = g["ms"] * 1e3 / g["launches"]
             alg = g["work"] / g["launches"]           # 8 real flops per complex MAC
             exe = 0.75 * alg                          # the kernel issues Gauss's 3-product form: 6 flops per MAC
-            tr = traffic.get("cgemm_mfma_kernel")
+            # the join runs on cgemm_dma128_kernel when M and N are multiples of 128 (every n >= 14 cut), else on the
+            # 64-tile DMA kernel / the register-staged kernel
+            gk = "cgemm_dma128_kernel" if (M % 128 == 0 and N % 128 == 0 and K % 16 == 0) else \
+                ("cgemm_dma_kernel" if (M % 64 == 0 and N % 64 == 0 and K % 16 == 0) else "cgemm_mfma_kernel<true>")
+            tr = traffic.get(gk.split("<")[0])
             roof = {
-                "bound": "mfma", "kernel": "tcmi::cgemm_mfma_kernel<true> (cut-contraction join GEMM)",
+                "bound": "mfma", "kernel": f"tcmi::{gk} (cut-contraction join GEMM)",
                 # frac = EXECUTED flops (what the MFMA pipe does) against the dense f32 MFMA peak
                 "achieved": exe / (avg_us * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s",
                 "frac": exe / (avg_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFS,

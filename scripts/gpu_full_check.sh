@@ -11,7 +11,7 @@ v=d.get("vqe_step")
 if v and "error" not in v:
     print("vqe ms/step",v["ms_per_step"],"E",v["mean_energy"],"gn",v["grad_norm"])
     for k,e in v["roofline"].items():
-        if e: print(" ",k, {kk:(round(vv,3) if isinstance(vv,float) else vv) for kk,vv in e.items() if kk in ("avg_launch_us","achieved","frac","launches_per_step","kernel_ms_per_step")})
+        if e: print(" ",k, {kk:(round(vv,3) if isinstance(vv,float) else vv) for kk,vv in e.items() if kk in ("avg_launch_us","achieved","frac","launches_per_step","kernel_ms_per_step","bound")})
 else: print("vqe", v)
 r=d.get("rqc_amplitude"); print("rqc", {k:r[k] for k in r if k in ("contract_s","tflops","time_split","error","path_search_s")} if r else None)
 m=d.get("mps_tebd"); print("mps",{k:m[k] for k in m if k!="roofline"} if m else None)

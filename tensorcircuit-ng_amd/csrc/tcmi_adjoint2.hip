@@ -395,7 +395,9 @@ __global__ __launch_bounds__(1 << LT, (R >= 5 ? 512 : 1024) >> LT) void adjoint2
   TCMI_GFLUSH()
 #undef TCMI_GADD
 #undef TCMI_GFLUSH
-  {
+  // TCMI_FLAG_NOSTORE on the LAST pass of a sweep whose un-computed psi and propagated lambda nobody reads (a
+  // value_and_grad step without the input-state cotangent): only the gradient sums leave the tile
+  if (!(desc[6] & TCMI_FLAG_NOSTORE)) {
     const KInt rl = desc + pc_cur;
     uint32_t rpm[R];
 #pragma unroll

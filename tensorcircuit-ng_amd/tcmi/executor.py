@@ -335,9 +335,19 @@ class CompiledCircuit:
                 "tcmi_build_adjoint_tables",
             )
             gout = torch.zeros(nb, ATOMIC_COPIES, max(1, adj["nslots"]), dtype=torch.float64, device=self.device)
-            tm = _timed("adjoint", len(adj["descs"]), len(adj["descs"]) * 4.0 * nb * nel * item)
+            descs = adj["descs"]
+            # nobody reads psi / lambda after the sweep (no input-state cotangent): the last pass of the packed kernel
+            # keeps its tile to itself (FLAG_NOSTORE: two of its four state transfers less)
+            nostore = cfg.gen == 2 and not want_input_grad and getattr(self, "_keep_uncomputed", None) is None and descs
+            if nostore:
+                if adj.get("last_nostore") is None:
+                    w = descs[-1].clone()
+                    w[6] = w[6] | P.FLAG_NOSTORE
+                    adj["last_nostore"] = w
+                descs = list(descs[:-1]) + [adj["last_nostore"]]
+            tm = _timed("adjoint", len(descs), (len(descs) * 4.0 - (2.0 if nostore else 0.0)) * nb * nel * item)
             tm.__enter__()
-            for d in adj["descs"]:
+            for d in descs:
                 _lib.check(
                     lib.tcmi_run_adjoint_pass(
                         a.data_ptr(), lam.data_ptr(), nel, nb, self.n_exec, cfg.R, cfg.LT, d.data_ptr(),
