@@ -14,17 +14,17 @@ def find(tab, sub):
             return v
 
 
-L = [f"Round-2 final captures {tag} (MI355X, one GPU), all from the binary of the last commit that touched csrc/.", "",
+L = [f"Final captures {tag} (MI355X, one GPU), all from the binary of the last commit that touched csrc/.", "",
      f"{tag}_bench_default.json                   python3 bench.py   (bench line: HIP-event launch times, PMC traffic probe)",
      f"{tag}_bench_default_under_rocprof.json     the same command under rocprofv3 --kernel-trace --stats (program directly after --)",
      f"{tag}_bench_default_kernel_stats.csv       rocprofv3 kernel stats of that run (all legs: launches of different batch sizes share a row)",
      f"{tag}_headline_kernel_stats.csv            rocprofv3 kernel stats of the timed region of config 2 only (bench.py --probe-child --steps 20",
-     "                                          --warmup 3): every cgemm_mfma_kernel<true> launch is a batch-8 join GEMM",
+     "                                          --warmup 3): every join-GEMM launch (cgemm_dma128_kernel) is a batch-8 join",
      f"{tag}_vqe_n28_d12_pmc.txt                  rocprofv3 --pmc passes (4 separate runs) over scripts/gpu_vqe_timing.py 28,12,1, per-dispatch averages", ""]
 r = d["roofline"]
 L.append(f"Config 2 headline ({d['config']['plan'].get('contraction')} order), dominant kernel {r.get('kernel')}:")
 if r.get("bound") == "mfma":
-    g = find(hs, "cgemm_mfma_kernel<true>")
+    g = find(hs, "cgemm_dma128_kernel") or find(hs, "cgemm_dma_kernel") or find(hs, "cgemm_mfma_kernel<true>")
     L.append(f"  HIP events (bench line):   {r['avg_launch_us']:.1f} us per launch -> executed flops {r['executed_flops_per_launch']:.4g} / t = {r['achieved']:.1f} TF = {r['frac']:.3f} of 157.3 TF (algorithmic, 8 flops per MAC: {r['algorithmic_frac']:.3f})")
     if g:
         tf = r["executed_flops_per_launch"] / float(g["AverageNs"]) * 1e9 / 1e12
@@ -36,12 +36,20 @@ v = d["vqe_step"]
 vr = v["roofline"]
 L += ["", f"Config 3 VQE step n=28 d=12 batch 32: {v['ms_per_step']:.1f} ms per step = {v['ms_per_step']/32:.1f} ms per sample"]
 for k in ("forward_pass", "adjoint_pass", "measure_pass", "pauli_sum"):
-    x = vr[k]
+    x = vr.get(k)
+    if not x:
+        L.append(f"  {k:13s} (no launch in the timed steps: the traced step takes the energy from the cotangent passes)")
+        continue
     L.append(f"  {k:13s} {x['kernel']:66s} {x['launches_per_step']:.0f} launches/step, {x['avg_launch_us']/1e3:.2f} ms each, {x['algorithmic_bytes_per_launch']/1e9:.1f} GB algorithmic -> {x['achieved']:.0f} GB/s = {x['frac']:.3f} of 8 TB/s")
 x = vr["step"]
+for k in ("forward_pass_valu", "adjoint_pass_valu"):
+    x = vr.get(k)
+    if x:
+        L.append(f"  {k:18s} gate arithmetic alone {x['gate_arithmetic_flops_per_step']/1e12:.1f} Tflop per step -> {x['achieved']:.1f} TF = {x['frac']:.3f} of the 157.3 TF FP32 vector peak")
 L.append(f"  step: executed bytes {x['executed_bytes_per_step']/1e12:.2f} TB / wall -> {x['achieved']:.0f} GB/s = {x['frac']:.3f}; kernel time {x['kernel_ms_per_step']:.0f} ms of {v['ms_per_step']:.0f}; {x['forward_passes']:.0f} forward / {x['adjoint_passes']:.0f} adjoint passes")
 for sub, name in (("pass2_kernel<5, 8", "pass2_kernel<5,8>"), ("adjoint2_kernel<4, 8", "adjoint2_kernel<4,8>"),
-                  ("measure2_kernel<5, 8", "measure2_kernel<5,8>"), ("pauli_sum_kernel<float, 4096", "pauli_sum_kernel")):
+                  ("measure2_kernel<5, 8", "measure2_kernel<5,8>"), ("pauli_tile_kernel<float", "pauli_tile_kernel"),
+                  ("pauli_sum_kernel<float, 4096", "pauli_sum_kernel")):
     g = find(ks, sub)
     if g:
         L.append(f"  rocprofv3 {name:22s} {g['Calls']:>5s} calls, average {float(g['AverageNs'])/1e6:.3f} ms (all batch sizes of the run share the row)")
@@ -49,7 +57,11 @@ q = d["rqc_amplitude"]
 qr = q["roofline"]
 L += ["", f"Config 4 RQC amplitude: {q['contract_s']*1e3:.1f} ms, executed flops {qr['executed_flops_this_rank']:.4g} -> {qr['achieved']:.1f} TF = {qr['frac']:.3f} of 157.3; "
           f"algorithmic bytes {qr['algorithmic_bytes']/1e9:.1f} GB, stand-alone permute bytes {qr['wasted_traffic']/1e6:.1f} MB; launches {qr['launches']}",
-      f"  amplitude {q['amplitude']}", f"  time split {q['time_split']}"]
+      f"  amplitude {q['amplitude']}", f"  time split {q['time_split']}", f"  path search {q.get('path_search')}"]
+sv = d.get("sliced_vqa")
+if sv and "error" not in sv:
+    L += ["", f"Sliced value_and_grad (n={sv['workload'].split('n=')[1].split(' ')[0]}): {sv['ms_per_value_and_grad']:.1f} ms per call, graphs {sv.get('graphs')}",
+          f"  roofline {sv.get('roofline')}"]
 m = d["mps_tebd"]
 L += ["", f"Config 5 MPS sweep: {m['us_per_bond']:.0f} us per bond, kernel us per bond {m['roofline']['kernel_us_per_bond']}", "",
       f"cpu_baseline: {d['cpu_baseline']}"]

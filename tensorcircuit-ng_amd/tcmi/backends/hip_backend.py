@@ -464,7 +464,12 @@ class HipBackend:
         """Device plans are compiled and cached per circuit structure by the executor.  For the variational
         idiom ``jit(value_and_grad(f))`` / ``jit(vvag(f))`` the host side is traced too (``tcmi/jit.py``):
         after the first calls the Python function is no longer executed per step.  Any other function
-        is returned unchanged (reference pytorch_backend.py:830-842 also returns ``f``)."""
+        is returned unchanged (reference pytorch_backend.py:830-842 also returns ``f``).
+
+        As under the reference's ``jax.jit``, a traced function is a function of its ARGUMENTS only: the trace is
+        validated against the plain path on the first two calls, after that global state the Python body reads
+        (module variables, closures that change between calls) is frozen at its traced value; Python that branches on
+        an argument's value is detected while probing and keeps the plain path."""
         from ..jit import TracedVag
 
         if static_argnums:
