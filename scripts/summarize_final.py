@@ -41,11 +41,11 @@ for k in ("forward_pass", "adjoint_pass", "measure_pass", "pauli_sum"):
         L.append(f"  {k:13s} (no launch in the timed steps: the traced step takes the energy from the cotangent passes)")
         continue
     L.append(f"  {k:13s} {x['kernel']:66s} {x['launches_per_step']:.0f} launches/step, {x['avg_launch_us']/1e3:.2f} ms each, {x['algorithmic_bytes_per_launch']/1e9:.1f} GB algorithmic -> {x['achieved']:.0f} GB/s = {x['frac']:.3f} of 8 TB/s")
-x = vr["step"]
 for k in ("forward_pass_valu", "adjoint_pass_valu"):
     x = vr.get(k)
     if x:
         L.append(f"  {k:18s} gate arithmetic alone {x['gate_arithmetic_flops_per_step']/1e12:.1f} Tflop per step -> {x['achieved']:.1f} TF = {x['frac']:.3f} of the 157.3 TF FP32 vector peak")
+x = vr["step"]
 L.append(f"  step: executed bytes {x['executed_bytes_per_step']/1e12:.2f} TB / wall -> {x['achieved']:.0f} GB/s = {x['frac']:.3f}; kernel time {x['kernel_ms_per_step']:.0f} ms of {v['ms_per_step']:.0f}; {x['forward_passes']:.0f} forward / {x['adjoint_passes']:.0f} adjoint passes")
 for sub, name in (("pass2_kernel<5, 8", "pass2_kernel<5,8>"), ("adjoint2_kernel<4, 8", "adjoint2_kernel<4,8>"),
                   ("measure2_kernel<5, 8", "measure2_kernel<5,8>"), ("pauli_tile_kernel<float", "pauli_tile_kernel"),

@@ -243,9 +243,19 @@ class Circuit:
         self._flush_pending()
         index = self._norm_index(index)
         if len(index) == 2 and _split_can_truncate(self.split):
+            # reference basecircuit.py:231-275 splits the gate TENSOR at application time.  With concrete angles the
+            # gate is a constant here too: evaluate it and truncate it like any constant gate.  Angles that live on the
+            # device / the autograd tape would make the truncation data-dependent inside a cached plan: refused.
+            if all(G.is_concrete(sp.theta) for sp in specs):
+                m = None
+                for sp in specs:
+                    a = sp.scale * float(np.real(sp.theta)) + sp.offset
+                    f = sp.c0 + np.cos(a) * sp.c1 + np.sin(a) * sp.c2
+                    m = f if m is None else f @ m
+                return self._record_const(m, index, name)
             raise NotImplementedError(
-                "Backend 'hip' has not implemented a truncating `split` rule for parametrised two-qubit gates "
-                "(constant gates are truncated at record time).")
+                "Backend 'hip' has not implemented a truncating `split` rule for two-qubit gates with tensor-valued "
+                "parameters (constant gates and concrete angles are truncated at record time).")
         if getattr(self, "_conj", False):
             specs = [G.TrigSpec(np.conj(sp.c0), np.conj(sp.c1), np.conj(sp.c2), sp.theta, sp.scale, sp.offset, sp.name)
                      for sp in specs]

@@ -179,10 +179,31 @@ def test_split_rule_truncates_like_the_reference(tcd):
     u2, s2, v2 = np.linalg.svd(t2)   # CNOT has operator-Schmidt rank 2: unchanged by the rank-2 rule
     ops = [(G.H, [i]) for i in range(n)] + [(m2, [2, 3]), (G.CNOT, [3, 4]), (u, [5, 6])]
     np.testing.assert_allclose(got, dense.run(n, ops), atol=tol)
+    # parametrised two-qubit gates with concrete angles are truncated like constants (rank-1 rule: the largest
+    # operator-Schmidt component of rzz and of iswap survives); tensor-valued angles are refused
+    c = tc.Circuit(4, split={"max_singular_values": 1})
+    for i in range(4):
+        c.h(i)
+        c.rz(i, theta=0.4 * (i + 1))
+    c.rzz(0, 1, theta=0.3)
+    c.iswap(1, 2, theta=0.7)
+
+    def rank1(m):
+        t = np.asarray(m, dtype=np.complex128).reshape(2, 2, 2, 2).transpose(0, 2, 1, 3).reshape(4, 4)
+        uu, sv, vh = np.linalg.svd(t)
+        assert sv[0] - sv[1] > 1e-2
+        return ((uu[:, :1] * sv[:1]) @ vh[:1]).reshape(2, 2, 2, 2).transpose(0, 2, 1, 3).reshape(4, 4)
+
+    zz = np.diag(np.exp(-0.5j * 0.3 * np.array([1, -1, -1, 1])))
+    isw = np.asarray(tc.gates.iswap_gate(0.7).tensor, dtype=np.complex128).reshape(4, 4)
+    ops = []
+    for i in range(4):
+        ops += [(G.H, [i]), (G.rz(0.4 * (i + 1)), [i])]
+    ops += [(rank1(zz), [0, 1]), (rank1(isw), [1, 2])]
+    np.testing.assert_allclose(_np(tc, c.state()), dense.run(4, ops), atol=tol)
     with pytest.raises(NotImplementedError, match="Backend 'hip' has not implemented"):
         c = tc.Circuit(4, split={"max_singular_values": 2})
-        c.rzz(0, 1, theta=0.3)
-        c.rxx(0, 1, theta=0.3)
+        c.rzz(0, 1, theta=tc.backend.convert_to_tensor(np.float32(0.3)))
 
 
 def test_backend_ops_run_on_the_hip_kernels(tcd):
