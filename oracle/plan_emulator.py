@@ -18,6 +18,29 @@ OP_DIAGF, OP_DIAGB2, OP_DIAGCW, OP_EXPECT2 = 8, 9, 10, 11
 R_MAX = 6
 CONST_FLAG = 1 << 30
 BK_TRIG, BK_COEF, BK_SELECT, BK_PHASE = 1, 2, 5, 6
+SHEAR2_CMIN = 0.5      # plan.SHEAR2_CMIN / TCMI_SHEAR2_CMIN
+SCALE_TERM = 1 << 16   # plan.SCALE_TERM
+
+
+def _phase_entry(cpool, off, nterms, r, params, invert=False):
+    """One BK_PHASE table entry [B] (complex): exp(2 pi i sum_t s_t(r) (k_t theta + o_t)) times the real scale terms
+    c^(+-1), c = cos(k theta + o) -- 1 where |c| < SHEAR2_CMIN (the gate then ran in three-shear form).
+    ``invert``: reciprocal scale (the lambda table of the adjoint sweep)."""
+    B = params.shape[0]
+    phi = np.zeros(B)
+    mag = np.ones(B)
+    for t in range(nterms):
+        kt, ot, pt, rm = cpool[off + 4 * t: off + 4 * t + 4]
+        rm = int(rm)
+        odd = bin(r & rm & (SCALE_TERM - 1)).count("1") & 1
+        if rm & SCALE_TERM:
+            c = np.cos(kt * params[:, int(pt)] + ot)
+            ok = np.abs(c) >= SHEAR2_CMIN
+            f = np.where(ok, c, 1.0)
+            mag *= (1.0 / f) if (odd != invert) else f
+            continue
+        phi += (-1.0 if odd else 1.0) * (kt * params[:, int(pt)] + ot)
+    return mag * np.exp(2j * np.pi * phi)
 
 
 def build_table(ginfo, cpool, params, ptab_size):
@@ -30,14 +53,9 @@ def build_table(ginfo, cpool, params, ptab_size):
         k, o = cpool[off], cpool[off + 1]
         th = params[:, pidx]
         if kind == BK_PHASE:
-            r = int(rec[5])
-            phi = np.zeros(B)
-            for t in range(dim):
-                kt, ot, pt, rm = cpool[off + 4 * t: off + 4 * t + 4]
-                sgn = -1.0 if bin(r & int(rm)).count("1") & 1 else 1.0
-                phi += sgn * (kt * params[:, int(pt)] + ot)
-            ptab[:, slot] = np.cos(2 * np.pi * phi)
-            ptab[:, slot + 1] = np.sin(2 * np.pi * phi)
+            e = _phase_entry(cpool, off, dim, int(rec[5]), params)
+            ptab[:, slot] = e.real
+            ptab[:, slot + 1] = e.imag
         elif kind == BK_TRIG:
             a = k * th + o
             nn = dim * dim
@@ -48,7 +66,7 @@ def build_table(ginfo, cpool, params, ptab_size):
             c = [x[:, 0] + 1j * x[:, 1] for x in c]
             m = c[0][None, :] + np.cos(a)[:, None] * c[1][None, :] + np.sin(a)[:, None] * c[2][None, :]
             if int(rec[5]):
-                ptab[:, slot: slot + 8] = _shear_params(m, int(rec[5]))
+                ptab[:, slot: slot + 8] = _shear_params(m, int(rec[5]), two=bool(rec[6]))
                 continue
             ptab[:, slot: slot + 2 * nn: 2] = m.real
             ptab[:, slot + 1: slot + 2 * nn: 2] = m.imag
@@ -65,30 +83,40 @@ def build_table(ginfo, cpool, params, ptab_size):
     return ptab
 
 
-def _shear_params(m, flavor):
-    """{u, v, sign, 0...} of the three-shear form of the rotation matrices m [B, 4] (row-major 2x2), as the builder
-    kernels write them: sign * m = S(u) L(v) S(u) on (x, y) (flavor 1) or on (x, i y) (flavor 2)."""
+def _shear_params(m, flavor, two=False):
+    """{u, v, sign, flag, 0...} of the shear form of the rotation matrices m [B, 4] (row-major 2x2), as the builder
+    kernels write them: sign * m = S(u) L(v) S(u) on (x, y) (flavor 1) or on (x, i y) (flavor 2), flag = 0; with
+    ``two`` and |m00| >= SHEAR2_CMIN the two-shear form m = diag(m00, 1 / m00) L(v) S(u), sign = 1, flag = 2."""
     m = np.asarray(m).reshape(-1, 4)
     out = np.zeros((m.shape[0], 8))
     a = m[:, 0].real
     c = m[:, 2].real if flavor == 1 else m[:, 2].imag
     sg = np.where(a < 0, -1.0, 1.0)
-    a, c = a * sg, c * sg
-    safe = np.abs(c) > 1e-30
-    num = (a - 1.0) if flavor == 1 else (1.0 - a)
-    out[:, 0] = np.where(safe, num / np.where(safe, c, 1.0), 0.0)
-    out[:, 1] = c
+    a3, c3 = a * sg, c * sg
+    safe = np.abs(c3) > 1e-30
+    num = (a3 - 1.0) if flavor == 1 else (1.0 - a3)
+    out[:, 0] = np.where(safe, num / np.where(safe, c3, 1.0), 0.0)
+    out[:, 1] = c3
     out[:, 2] = sg
+    if two:
+        ok = np.abs(a) >= SHEAR2_CMIN
+        asafe = np.where(ok, a, 1.0)
+        out[:, 0] = np.where(ok, (-c if flavor == 1 else c) / asafe, out[:, 0])
+        out[:, 1] = np.where(ok, c * a, out[:, 1])
+        out[:, 2] = np.where(ok, 1.0, out[:, 2])
+        out[:, 3] = np.where(ok, 2.0, 0.0)
     return out
 
 
-def _apply_shear(regs, r0, r1, u, v, flavor):
-    """x += u y', y' += v x, x += u y' with y' = y (flavor 1) or i y (flavor 2: y += v (i x))."""
+def _apply_shear(regs, r0, r1, u, v, flavor, two=False):
+    """x += u y', y' += v x, x += u y' with y' = y (flavor 1) or i y (flavor 2: y += v (i x)); ``two``: without the
+    third step (the real factor diag(c, 1/c) that completes the rotation is a pending scale term)."""
     f = 1.0 if flavor == 1 else 1j
     x, y = regs[..., r0].copy(), regs[..., r1].copy()
     x = x + u * f * y
     y = y + v * f * x
-    x = x + u * f * y
+    if not two:
+        x = x + u * f * y
     regs[..., r0] = x
     regs[..., r1] = y
 
@@ -176,7 +204,7 @@ def run_pass(state, desc, ctab, ptab_row, eout=None):
                         tb8 = tab(slot, 8)
                         bit = (rid >> j) & 1
                         r0 = rid[bit == 0]
-                        _apply_shear(regs, r0, r0 | (1 << j), tb8[0], tb8[1], kind)
+                        _apply_shear(regs, r0, r0 | (1 << j), tb8[0], tb8[1], kind, two=tb8[3] != 0)
                         pass_sign *= tb8[2]
                         continue
                     m = tab(slot, 8)
@@ -392,14 +420,9 @@ def build_adjoint_table(ginfo, cpool, params, ptab_size):
         kind, slot, pidx, dim, off = (int(x) for x in rec[:5])
         k, o = cpool[off], cpool[off + 1]
         if kind == BK_PHASE:
-            r = int(rec[5])
-            phi = np.zeros(B)
-            for t in range(dim):
-                kt, ot, pt, rm = cpool[off + 4 * t: off + 4 * t + 4]
-                sgn = -1.0 if bin(r & int(rm)).count("1") & 1 else 1.0
-                phi += sgn * (kt * params[:, int(pt)] + ot)
-            ptab[:, slot] = np.cos(2 * np.pi * phi)
-            ptab[:, slot + 1] = np.sin(2 * np.pi * phi)
+            e = _phase_entry(cpool, off, dim, int(rec[5]), params, invert=bool(rec[6]))
+            ptab[:, slot] = e.real
+            ptab[:, slot + 1] = e.imag
             continue
         for b in range(B):
             a = k * params[b, pidx] + o
@@ -413,7 +436,7 @@ def build_adjoint_table(ginfo, cpool, params, ptab_size):
             du = k * (-np.sin(a) * c[1] + np.cos(a) * c[2])
             m = u.conj().T if kind == BK_UDAG else du @ u.conj().T
             if int(rec[5]) and kind == BK_UDAG:
-                ptab[b, slot: slot + 8] = _shear_params(m.reshape(1, 4), int(rec[5]))[0]
+                ptab[b, slot: slot + 8] = _shear_params(m.reshape(1, 4), int(rec[5]), two=bool(rec[6]))[0]
                 continue
             ptab[b, slot: slot + 2 * nn: 2] = m.real.reshape(-1)
             ptab[b, slot + 1: slot + 2 * nn: 2] = m.imag.reshape(-1)
@@ -448,6 +471,7 @@ def run_adjoint_pass(psi, lam, desc, ctab, ptab_row, gout):
     pc = HDR_WORDS
     regs = None  # [2, nwg, nth, NR]: psi, lambda
     lds = None
+    pass_sign = 1.0
     for k in range(nrounds):
         rr = d[pc: pc + RR_WORDS]
         nops, opwords = int(rr[0]), int(rr[1])
@@ -477,9 +501,24 @@ def run_adjoint_pass(psi, lam, desc, ctab, ptab_row, gout):
                         a0, a1 = regs[0][..., r0], regs[0][..., r1]
                         t0, t1 = kk[0, 0] * a0 + kk[0, 1] * a1, kk[1, 0] * a0 + kk[1, 1] * a1
                         gout[int(dsig[q + 5 + j])] += np.sum(np.real(np.conj(regs[1][..., r0]) * t0 + np.conj(regs[1][..., r1]) * t1))
-                    if shear:  # the pulled-out sign is common to psi and lambda and cancels in every gradient
+                    if shear:  # the pulled-out sign is common to psi and lambda: no gradient sees it, the store applies it
                         tb8 = tab(ubase + 8 * j, 8)
-                        _apply_shear(regs, r0, r1, tb8[0], tb8[1], (mk >> (8 + 2 * j)) & 3)
+                        pass_sign *= tb8[2]
+                        flv = (mk >> (8 + 2 * j)) & 3
+                        if tb8[3] != 0:
+                            # two-shear form: psi <- L(v) S(u) psi, pending factor diag(c, 1/c); lambda takes the other
+                            # order, lambda <- S(b) L(g) lambda with pending diag(1/c, c): (g, b) = (-u, -v) for the
+                            # real class, (u, v) for the rx-like class
+                            _apply_shear(regs[0], r0, r1, tb8[0], tb8[1], flv, two=True)
+                            f = 1.0 if flv == 1 else 1j
+                            g_, b_ = (-tb8[0], -tb8[1]) if flv == 1 else (tb8[0], tb8[1])
+                            x, y = regs[1][..., r0].copy(), regs[1][..., r1].copy()
+                            y = y + g_ * f * x
+                            x = x + b_ * f * y
+                            regs[1][..., r0] = x
+                            regs[1][..., r1] = y
+                            continue
+                        _apply_shear(regs, r0, r1, tb8[0], tb8[1], flv)
                         continue
                     x0, x1 = regs[..., r0].copy(), regs[..., r1].copy()
                     regs[..., r0] = ud[0, 0] * x0 + ud[0, 1] * x1
@@ -540,7 +579,7 @@ def run_adjoint_pass(psi, lam, desc, ctab, ptab_row, gout):
                 for rm in range(NR):      # gsC[rm]: gradient slot of the register-only term with mask rm
                     gs = int(dsig[q + rm])
                     if gs >= 0:
-                        assert nC == 1
+                        assert nC & 1
                         z = 1 - 2 * _parity(rid.astype(np.uint64) & np.uint64(rm))
                         gout[gs] += np.sum(w * z[None, None, :])
                 q += NR
@@ -548,9 +587,10 @@ def run_adjoint_pass(psi, lam, desc, ctab, ptab_row, gout):
                     v = np.zeros(tidx.shape, dtype=np.int64)
                     for k_, m_ in enumerate(sel_masks):
                         v += _parity(tidx & np.uint64(m_)).astype(np.int64) << k_
-                    tb = np.asarray(ptab_row)[cslot: cslot + 2 * NR * (1 << nsel)]
-                    tbc = (tb[0::2] + 1j * tb[1::2]).reshape(1 << nsel, NR)
-                    regs = regs * np.conj(tbc[v])[None]
+                    ntab = 2 if nC & 2 else 1       # bit 1: lambda's table (reciprocal real factors) follows psi's
+                    tb = np.asarray(ptab_row)[cslot: cslot + 2 * NR * (1 << nsel) * ntab]
+                    tbc = (tb[0::2] + 1j * tb[1::2]).reshape(ntab, 1 << nsel, NR)
+                    regs = np.stack([regs[0] * np.conj(tbc[0][v]), regs[1] * np.conj(tbc[-1][v])])
                 for e in range(nB):
                     j, mask, slot, gs = int(d[q]), int(d[q + 1]), int(dsig[q + 2]), int(dsig[q + 3])
                     q += 4
@@ -575,12 +615,12 @@ def run_adjoint_pass(psi, lam, desc, ctab, ptab_row, gout):
             lds = np.zeros((2, nwg, nth * NR), dtype=regs.dtype)
             lds[:, :, slot] = regs
         else:
-            psi[gidx] = regs[0]
-            lam[gidx] = regs[1]
+            psi[gidx] = regs[0] * pass_sign
+            lam[gidx] = regs[1] * pass_sign
     assert pc == d.size
 
 
-def run_adjoint_plan(aplan, params, psi, lam, nparams):
+def run_adjoint_plan(aplan, params, psi, lam, nparams, return_lambda=False):
     """Returns (dL/dparams, psi_in): Re<lam | d psi / d params> by the adjoint sweep (float64)."""
     psi = np.array(psi, dtype=np.complex128)
     lam = np.array(lam, dtype=np.complex128)
@@ -591,4 +631,6 @@ def run_adjoint_plan(aplan, params, psi, lam, nparams):
         run_adjoint_pass(psi, lam, desc, aplan.ctab, ptab, gout)
     g = np.zeros(max(nparams, 1))
     np.add.at(g, aplan.gslot_param, gout * aplan.gslot_factor)
+    if return_lambda:
+        return g[:nparams], psi, lam
     return g[:nparams], psi

@@ -111,14 +111,25 @@ def emit_named(name, args, lines, outs, ins, tmps, clobbers=("scc",)):
     print("}\n")
 
 
-def gen_shear8(name, flavor):
+def gen_shear8(name, flavor, steps=3):
     """Eight amplitude pairs through a rotation in three-shear form, p = (u, v): x += u y', y' += v x, x += u y'
-    with y' = y (flavor "real") or i y (flavor "rx": y += v (i x)); 3 packed instructions per pair, no temporaries."""
+    with y' = y (flavor "real") or i y (flavor "rx": y += v (i x)); 3 packed instructions per pair, no temporaries.
+    steps = 2: the two-shear form (no third step; the real factor diag(c, 1/c) is a pending scale term of the plan);
+    steps = "third": the third step alone (the forward kernel runs the three-shear form as the two-shear body + this:
+    fewer instructions of kernel text -- past a certain size of the op loop hipcc drains every tile load before
+    the loop instead of waiting at first use, 6 % of the pass time); steps = "lambda": see below."""
     f = fma_re if flavor == "real" else (lambda D, A, P, C, hi=False: fma_im(D, A, P, C, hi=hi))
     seqs = []
     for p_ in range(8):
         X, Y = f"%[x{p_}]", f"%[y{p_}]"
-        seqs.append([f(X, Y, "%[p]", X, hi=False), f(Y, X, "%[p]", Y, hi=True), f(X, Y, "%[p]", X, hi=False)])
+        if steps == "lambda":
+            # the cotangent's side of a two-shear U^dagger (adjoint sweep): lower shear first, lambda carries the
+            # reciprocal factor diag(1/c, c).  y' += g x, x += b y' with (g, b) = (-u, -v) [real] or (u, v) [rx-like]
+            neg = " neg_lo:[0,1,0] neg_hi:[0,1,0]" if flavor == "real" else ""
+            seqs.append([f(Y, X, "%[p]", Y, hi=False) + neg, f(X, Y, "%[p]", X, hi=True) + neg])
+            continue
+        full = [f(X, Y, "%[p]", X, hi=False), f(Y, X, "%[p]", Y, hi=True), f(X, Y, "%[p]", X, hi=False)]
+        seqs.append(full[2:] if steps == "third" else full[:steps])
     lines = interleave(seqs[:4]) + interleave(seqs[4:])
     args = ", ".join(f"v2f& x{p_}, v2f& y{p_}" for p_ in range(8)) + ", v2f p"
     outs = []
@@ -317,6 +328,9 @@ if __name__ == "__main__":
     gen_gate8("vm2_gate8_gen", g1_gen, 4)
     gen_shear8("vm2_shear8_real", "real")
     gen_shear8("vm2_shear8_rx", "rx")
+    gen_shear8("vm2_shear2_8_rx", "rx", steps=2)
+    gen_shear8("vm2_shear3rd_8_rx", "rx", steps="third")
+    gen_shear8("vm2_shear2l_8_rx", "rx", steps="lambda")
     gen_scale8()
     gen_cmul8s()
     gen_cmul8v()

@@ -495,7 +495,7 @@ __global__ void build_adjoint_kernel(const int* __restrict__ ginfo, int nrec, co
   const int kind = rec[0], slot = rec[1], pidx = rec[2], dim = rec[3], off = rec[4];
   const double theta = (double)params[(long long)b * pstride + pidx];
   const double kap = cpool[off];
-  const double ang = kap * theta + cpool[off + 1];
+  const double ang = fma(kap, theta, cpool[off + 1]);
   F* out = ptab + (long long)b * tstride + slot;
   if (kind == TCMI_BK_COEF) {
     out[0] = (F)(ang - rint(ang));
@@ -503,19 +503,7 @@ __global__ void build_adjoint_kernel(const int* __restrict__ ginfo, int nrec, co
   }
   if (kind == TCMI_BK_PHASE) {
     // one entry of a phase table of OP_DIAGF (same record as the forward builder, tcmi_vm.hip)
-    const int r = rec[5];
-    const double* tp = cpool + off;
-    double phi = 0.0;
-    for (int t = 0; t < dim; ++t) {
-      const double th = (double)params[(long long)b * pstride + (int)tp[4 * t + 2]];
-      const double v = tp[4 * t] * th + tp[4 * t + 1];
-      phi += (__popc((unsigned)r & (unsigned)tp[4 * t + 3]) & 1) ? -v : v;
-    }
-    phi -= rint(phi);
-    double ps, pc;
-    sincospi(2.0 * phi, &ps, &pc);
-    out[0] = (F)pc;
-    out[1] = (F)ps;
+    phase_entry<F>(cpool + off, dim, rec[5], params + (long long)b * pstride, rec[6] != 0, out);
     return;
   }
   double s, c;
@@ -537,6 +525,16 @@ __global__ void build_adjoint_kernel(const int* __restrict__ ginfo, int nrec, co
     // U^dagger[1][0] = conj(U[0][1]); the sign is common to psi and lambda and is not needed
     double a = ur[0];
     double cc = (rec[5] == 1) ? ur[1] : -ui[1];
+    for (int i = 3; i < 8; ++i) out[i] = (F)0;
+    if (rec[6] && fabs(a) >= TCMI_SHEAR2_CMIN) {
+      // two-shear form U^dagger = diag(a, 1 / a) L(v) S(u), as in build_kernel; the kernel shears lambda in the
+      // other order and the plan's scale term carries diag(a, 1 / a) for psi, its reciprocal for lambda
+      out[0] = (F)((rec[5] == 1 ? -cc : cc) / a);
+      out[1] = (F)(cc * a);
+      out[2] = (F)1;
+      out[3] = (F)2;
+      return;
+    }
     const double sg = a < 0 ? -1.0 : 1.0;
     a *= sg;
     cc *= sg;
@@ -544,7 +542,6 @@ __global__ void build_adjoint_kernel(const int* __restrict__ ginfo, int nrec, co
     out[0] = (F)(fabs(cc) > 1e-30 ? num / cc : 0.0);
     out[1] = (F)cc;
     out[2] = (F)sg;
-    for (int i = 3; i < 8; ++i) out[i] = (F)0;
     return;
   }
   if (kind == TCMI_BK_UDAG) {

@@ -62,9 +62,9 @@ __device__ __forceinline__ void adj_apply(v2f (&a)[NR], int kf, v2f p0, v2f p1, 
 #undef TCMI_A8
 }
 
-// the same on psi and lambda with one test per structure class
+// the same on psi and lambda with one test per structure class; (p0 .. p3) = the record of the gate (shear forms: p0)
 template <int NR, int J>
-__device__ __forceinline__ void adj_apply2(v2f (&a)[NR], v2f (&l)[NR], int kf, KV2 up) {
+__device__ __forceinline__ void adj_apply2(v2f (&a)[NR], v2f (&l)[NR], int kf, v2f p0, v2f p1, v2f p2, v2f p3) {
   constexpr int B = 1 << J;
 #define TCMI_A8(V, FN, ...)                                                                                           \
   _Pragma("unroll") for (int g = 0; g < NR / 2; g += 8) {                                                             \
@@ -73,13 +73,17 @@ __device__ __forceinline__ void adj_apply2(v2f (&a)[NR], v2f (&l)[NR], int kf, K
     FN(V[r0], V[r0 | B], V[r1], V[r1 | B], V[r2], V[r2 | B], V[r3], V[r3 | B], V[r4], V[r4 | B], V[r5], V[r5 | B],     \
        V[r6], V[r6 | B], V[r7], V[r7 | B], __VA_ARGS__);                                                              \
   }
-  if (kf & (32 | 64)) {  // three shears, (u, v) only
-    const v2f p0 = up[4 * J];
-    if (kf & 32) { TCMI_A8(a, vm2_shear8_real, p0) TCMI_A8(l, vm2_shear8_real, p0) }
+  // two groups of tests: every skipped body is a taken branch (see vm2_g1 in tcmi_vm2.hip)
+  if (kf & (16 | 32 | 64)) {
+    // three shears, (u, v) only
     if (kf & 64) { TCMI_A8(a, vm2_shear8_rx, p0) TCMI_A8(l, vm2_shear8_rx, p0) }
+    // two-shear form (plan.shear2_gates, rx-like class only): psi is left with the pending factor diag(c, 1/c), lambda
+    // -- sheared in the other order -- with its reciprocal, so Im(conj(lambda) psi) and every gradient bilinear stay
+    // what they are
+    if (kf & 16) { TCMI_A8(a, vm2_shear2_8_rx, p0) TCMI_A8(l, vm2_shear2l_8_rx, p0) }
+    if (kf & 32) { TCMI_A8(a, vm2_shear8_real, p0) TCMI_A8(l, vm2_shear8_real, p0) }
   }
   if (kf & 7) {
-    const v2f p0 = up[4 * J], p1 = up[4 * J + 1], p2 = up[4 * J + 2], p3 = up[4 * J + 3];
     if (kf & 4) { TCMI_A8(a, vm2_gate8_rx, p0, p1, p2, p3) TCMI_A8(l, vm2_gate8_rx, p0, p1, p2, p3) }
     if (kf & 2) { TCMI_A8(a, vm2_gate8_real, p0, p1, p2, p3) TCMI_A8(l, vm2_gate8_real, p0, p1, p2, p3) }
     if (kf & 1) { TCMI_A8(a, vm2_gate8_gen, p0, p1, p2, p3) TCMI_A8(l, vm2_gate8_gen, p0, p1, p2, p3) }
@@ -214,6 +218,7 @@ __global__ __launch_bounds__(1 << LT, (R >= 5 ? 512 : 1024) >> LT) void adjoint2
   }
 
   int pc_cur = pc;
+  uint32_t sgnbits = 0;  // sign pulled out of the three-shear gates of this pass (bit 31): psi and lambda both carry it
 #pragma unroll 1
   for (int k = 0;; ++k) {
     pc_cur = pc;
@@ -230,18 +235,30 @@ __global__ __launch_bounds__(1 << LT, (R >= 5 ? 512 : 1024) >> LT) void adjoint2
         const KV2 up = (KV2)(ptab + desc[q + 2]);
         const KV2 kp = (KV2)(ptab + desc[q + 4]);
         qn = q + 5 + R;
+        // every record of the op in ONE burst of scalar loads: U^dagger (8 floats per register bit; the shear forms use
+        // the first four: u, v, sign, form flag) and K.  One exposed load latency per op instead of three per gate --
+        // the waves of this kernel spend more time waiting for dependent scalar loads than issuing VALU work.
+        v2f uf[4 * R], kf_[4 * R];
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) uf[i] = up[i];
+#pragma unroll
+        for (int i = 0; i < 4 * R; ++i) kf_[i] = kp[i];
 #define TCMI_BW(J)                                                                                           \
   if constexpr (R > J) {                                                                                     \
     if (aonehot_if((mk >> J) & 1, 0)) { /* register bits without a gate cost two scalar instructions */       \
       const int kd = (mk >> (8 + 2 * J)) & 3;                                                                \
       const int gf = aonehot_if((kmask >> J) & 1, kd); /* generator class: never shear */                     \
-      const int kf = aonehot(kd + 4 * ((mk >> (20 + J)) & 1));                                               \
+      const int sh = (mk >> (20 + J)) & 1;                                                                   \
+      const v2f sf = uf[4 * J + 1]; /* shear records: {sign, form flag} */                                     \
+      const int two = sh & (int)(__float_as_uint(sf.y) >> 30);                                               \
+      sgnbits ^= sh ? (__float_as_uint(sf.x) & 0x80000000u) : 0u;                                            \
+      const int kf = aonehot(kd + 4 * sh - 2 * two);                                                         \
       if (gf) {                                                                                              \
-        float g = adj_grad<NR, J>(a, l, gf, kp[4 * J], kp[4 * J + 1], kp[4 * J + 2], kp[4 * J + 3]);         \
+        float g = adj_grad<NR, J>(a, l, gf, kf_[4 * J], kf_[4 * J + 1], kf_[4 * J + 2], kf_[4 * J + 3]);     \
         g = wave_sum_uniform(g);                                                                             \
         TCMI_GADD(desc[q + 5 + J], g)                                                                        \
       }                                                                                                      \
-      adj_apply2<NR, J>(a, l, kf, up);                                                                       \
+      adj_apply2<NR, J>(a, l, kf, uf[4 * J], uf[4 * J + 1], uf[4 * J + 2], uf[4 * J + 3]);                   \
     }                                                                                                        \
   }
         TCMI_BW(0) TCMI_BW(1) TCMI_BW(2) TCMI_BW(3) TCMI_BW(4)
@@ -272,7 +289,7 @@ __global__ __launch_bounds__(1 << LT, (R >= 5 ? 512 : 1024) >> LT) void adjoint2
 #pragma unroll
           for (int i = 0; i < 8; ++i) w[h + i] = t[i].x - t[i].y;
         }
-        if (hasC | nB | nA) {
+        if ((hasC & 1) | nB | nA) {
 #pragma unroll
           for (int j = 0; j < R; ++j)
 #pragma unroll
@@ -283,7 +300,7 @@ __global__ __launch_bounds__(1 << LT, (R >= 5 ? 512 : 1024) >> LT) void adjoint2
                 w[r | (1 << j)] = lo - hi;
               }
         }
-        if (hasC) {
+        if (hasC & 1) {
           int gsc[NR];
 #pragma unroll
           for (int k3 = 0; k3 < NR; ++k3) gsc[k3] = desc[q + 9 + k3];
@@ -294,7 +311,10 @@ __global__ __launch_bounds__(1 << LT, (R >= 5 ? 512 : 1024) >> LT) void adjoint2
               TCMI_GADD(gsc[k3], sv)
             }
         }
-        if (cslot >= 0) {
+        // one of two table multiplies, picked by independent skip tests on an opaque one-hot flag (a nested if / else
+        // would merge two modified copies of the amplitude arrays: 40 more live registers)
+        const int tf = aonehot_if(cslot >= 0 ? 1 : 0, (hasC >> 1) & 1);
+        if (tf & 1) {
           const KV2 tp = (KV2)(ptab + cslot + 2 * NR * tvar);
           v2f t[NR];
 #pragma unroll
@@ -305,6 +325,31 @@ __global__ __launch_bounds__(1 << LT, (R >= 5 ? 512 : 1024) >> LT) void adjoint2
                             t[h + 2], t[h + 3], t[h + 4], t[h + 5], t[h + 6], t[h + 7]);
             vm2_cmul8s_conj(l[h], l[h + 1], l[h + 2], l[h + 3], l[h + 4], l[h + 5], l[h + 6], l[h + 7], t[h], t[h + 1],
                             t[h + 2], t[h + 3], t[h + 4], t[h + 5], t[h + 6], t[h + 7]);
+          }
+        }
+        if (tf & 2) {
+          // real scale terms in the table (two-shear rotations): lambda's copy, with the reciprocal factors, follows
+          // the 2^nsel variants of psi's
+          const KV2 tp = (KV2)(ptab + cslot + 2 * NR * tvar);
+          const KV2 tl = tp + (NR << nsel);
+          constexpr int CH = NR < 16 ? NR : 16;  // both tables of a chunk in one burst of scalar loads (64 SGPRs)
+#pragma unroll
+          for (int h0 = 0; h0 < NR; h0 += CH) {
+            v2f t[CH], u[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+              t[i] = tp[h0 + i];
+              u[i] = tl[h0 + i];
+            }
+#pragma unroll
+            for (int h = 0; h < CH; h += 8) {
+              vm2_cmul8s_conj(a[h0 + h], a[h0 + h + 1], a[h0 + h + 2], a[h0 + h + 3], a[h0 + h + 4], a[h0 + h + 5],
+                              a[h0 + h + 6], a[h0 + h + 7], t[h], t[h + 1], t[h + 2], t[h + 3], t[h + 4], t[h + 5], t[h + 6],
+                              t[h + 7]);
+              vm2_cmul8s_conj(l[h0 + h], l[h0 + h + 1], l[h0 + h + 2], l[h0 + h + 3], l[h0 + h + 4], l[h0 + h + 5],
+                              l[h0 + h + 6], l[h0 + h + 7], u[h], u[h + 1], u[h + 2], u[h + 3], u[h + 4], u[h + 5], u[h + 6],
+                              u[h + 7]);
+            }
           }
         }
         if (nB > 0 || nA > 0) {
@@ -398,6 +443,16 @@ __global__ __launch_bounds__(1 << LT, (R >= 5 ? 512 : 1024) >> LT) void adjoint2
   // TCMI_FLAG_NOSTORE on the LAST pass of a sweep whose un-computed psi and propagated lambda nobody reads (a
   // value_and_grad step without the input-state cotangent): only the gradient sums leave the tile
   if (!(desc[6] & TCMI_FLAG_NOSTORE)) {
+    if (sgnbits) {  // wave-uniform; no gradient sees it, the stored psi and the input-state cotangent do
+      v2f m1;
+      m1.x = -1.f;
+      m1.y = -1.f;
+#pragma unroll
+      for (int h = 0; h < NR; h += 8) {
+        vm2_scale8(a[h], a[h + 1], a[h + 2], a[h + 3], a[h + 4], a[h + 5], a[h + 6], a[h + 7], m1);
+        vm2_scale8(l[h], l[h + 1], l[h + 2], l[h + 3], l[h + 4], l[h + 5], l[h + 6], l[h + 7], m1);
+      }
+    }
     const KInt rl = desc + pc_cur;
     uint32_t rpm[R];
 #pragma unroll

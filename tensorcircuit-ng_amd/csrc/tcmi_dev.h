@@ -27,6 +27,33 @@ template <> __device__ __forceinline__ void sincos_turns<double>(double x, doubl
   sincospi(2.0 * x, s, c);
 }
 
+// One BK_PHASE table entry (both builder kernels): exp(2 pi i sum_t s_t(r) (k_t theta_t + o_t)) times the real scale
+// terms c^(+-1) of rotations applied in two-shear form (TCMI_SCALE_TERM; the same sincos and threshold as the gate
+// record, so the two always agree on the form).
+template <typename F>
+__device__ inline void phase_entry(const double* __restrict__ tp, int nterms, int r, const F* __restrict__ prow,
+                                   bool invert, F* __restrict__ out) {
+  double phi = 0.0, mag = 1.0;
+  for (int t = 0; t < nterms; ++t) {
+    const double th = (double)prow[(int)tp[4 * t + 2]];
+    const double v = fma(tp[4 * t], th, tp[4 * t + 1]);  // explicit: the gate records form the angle the same way
+    const unsigned rm = (unsigned)tp[4 * t + 3];
+    const bool odd = __popc((unsigned)r & rm & (TCMI_SCALE_TERM - 1)) & 1;
+    if (rm & TCMI_SCALE_TERM) {
+      double s, c;
+      sincos(v, &s, &c);
+      if (fabs(c) >= TCMI_SHEAR2_CMIN) mag *= (odd != invert) ? 1.0 / c : c;
+      continue;
+    }
+    phi += odd ? -v : v;
+  }
+  phi -= rint(phi);
+  double s, c;
+  sincospi(2.0 * phi, &s, &c);
+  out[0] = (F)(c * mag);
+  out[1] = (F)(s * mag);
+}
+
 // Tables and descriptors are read-only for the whole launch and every access is wave-uniform:
 // read them through the constant address space so they become s_load (SGPR) operands.
 #define TCMI_K __attribute__((address_space(4)))

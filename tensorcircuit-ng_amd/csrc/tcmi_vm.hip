@@ -432,7 +432,7 @@ __global__ void build_kernel(const int* __restrict__ ginfo, int nrec, const doub
   const int* rec = ginfo + 8 * g;
   const int kind = rec[0], slot = rec[1], pidx = rec[2], dim = rec[3], off = rec[4];
   const double theta = (double)params[(long long)b * pstride + pidx];
-  const double ang = cpool[off] * theta + cpool[off + 1];
+  const double ang = fma(cpool[off], theta, cpool[off + 1]);
   F* out = ptab + (long long)b * tstride + slot;
   if (kind == TCMI_BK_TRIG) {
     double s, c;
@@ -446,6 +446,15 @@ __global__ void build_kernel(const int* __restrict__ ginfo, int nrec, const doub
       // or on (x, i y) [flavor 2]; out = {u, v, sign}
       double a = c0[0] + c * c1[0] + s * c2[0];
       double cc = (rec[5] == 1) ? (c0[4] + c * c1[4] + s * c2[4]) : (c0[5] + c * c1[5] + s * c2[5]);
+      for (int i = 3; i < 8; ++i) out[i] = (F)0;
+      if (rec[6] && fabs(a) >= TCMI_SHEAR2_CMIN) {
+        // two-shear form M = diag(a, 1 / a) L(v) S(u) (the diagonal factor is a pending scale term of the plan)
+        out[0] = (F)((rec[5] == 1 ? -cc : cc) / a);
+        out[1] = (F)(cc * a);
+        out[2] = (F)1;
+        out[3] = (F)2;  // bit 30 of the float: the kernels' form flag
+        return;
+      }
       const double sg = a < 0 ? -1.0 : 1.0;
       a *= sg;
       cc *= sg;
@@ -453,25 +462,12 @@ __global__ void build_kernel(const int* __restrict__ ginfo, int nrec, const doub
       out[0] = (F)(fabs(cc) > 1e-30 ? num / cc : 0.0);
       out[1] = (F)cc;
       out[2] = (F)sg;
-      for (int i = 3; i < 8; ++i) out[i] = (F)0;
       return;
     }
     for (int i = 0; i < nn; ++i) out[i] = (F)(c0[i] + c * c1[i] + s * c2[i]);
   } else if (kind == TCMI_BK_PHASE) {
     // one entry of a DIAGC table: exp(2 pi i sum_t s_t(r) (k_t theta_t + o_t)), s_t = parity of r & mask_t
-    const int r = rec[5];
-    const double* tp = cpool + off;
-    double phi = 0.0;
-    for (int t = 0; t < dim; ++t) {
-      const double th = (double)params[(long long)b * pstride + (int)tp[4 * t + 2]];
-      const double v = tp[4 * t] * th + tp[4 * t + 1];
-      phi += (__popc((unsigned)r & (unsigned)tp[4 * t + 3]) & 1) ? -v : v;
-    }
-    phi -= rint(phi);
-    double s, c;
-    sincospi(2.0 * phi, &s, &c);
-    out[0] = (F)c;
-    out[1] = (F)s;
+    phase_entry<F>(cpool + off, dim, rec[5], params + (long long)b * pstride, false, out);
   } else if (kind == TCMI_BK_COEF) {
     out[0] = (F)(ang - rint(ang));  // phase coefficient in turns, reduced to [-0.5, 0.5]
   } else if (kind == TCMI_BK_SELECT) {

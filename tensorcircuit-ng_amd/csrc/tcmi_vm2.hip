@@ -72,9 +72,13 @@ __device__ __forceinline__ void vm2_g1(v2f (&a)[NR], int kf, v2f p0, v2f p1, v2f
     FN(a[r0], a[r0 | B], a[r1], a[r1 | B], a[r2], a[r2 | B], a[r3], a[r3 | B], a[r4], a[r4 | B], a[r5], a[r5 | B], \
        a[r6], a[r6 | B], a[r7], a[r7 | B], p0, p1, p2, p3);                                                       \
   }
-  if (kf & 4) { TCMI_G8(vm2_gate8_rx) }
-  if (kf & 2) { TCMI_G8(vm2_gate8_real) }
-  if (kf & 1) { TCMI_G8(vm2_gate8_gen) }
+  // Every skipped body is a TAKEN branch, and taken branches are what this dispatch costs (one more test per register
+  // bit was 5 % of the pass time): two groups, so a gate passes at most four tests and an empty bit one (the caller's).
+  if (kf & 7) {
+    if (kf & 4) { TCMI_G8(vm2_gate8_rx) }
+    if (kf & 2) { TCMI_G8(vm2_gate8_real) }
+    if (kf & 1) { TCMI_G8(vm2_gate8_gen) }
+  }
 #undef TCMI_G8
 #define TCMI_S8(FN)                                                                                               \
   _Pragma("unroll") for (int g = 0; g < NR / 2; g += 8) {                                                         \
@@ -83,9 +87,14 @@ __device__ __forceinline__ void vm2_g1(v2f (&a)[NR], int kf, v2f p0, v2f p1, v2f
     FN(a[r0], a[r0 | B], a[r1], a[r1 | B], a[r2], a[r2 | B], a[r3], a[r3 | B], a[r4], a[r4 | B], a[r5], a[r5 | B], \
        a[r6], a[r6 | B], a[r7], a[r7 | B], p0);                                                                   \
   }
-  // rotations in three-shear form, p0 = (u, v) (plan.g1_shear_flavor; the pulled-out sign is handled by the caller)
-  if (kf & 32) { TCMI_S8(vm2_shear8_real) }
-  if (kf & 64) { TCMI_S8(vm2_shear8_rx) }
+  // rotations in three-shear form, p0 = (u, v) (plan.g1_shear_flavor; the pulled-out sign is handled by the caller);
+  // the rx-like class also in TWO-shear form (class 4: the builder's choice per batch element, plan.shear2_gates): the
+  // first two shears, then the third for class 6 only
+  if (kf & (16 | 32 | 64)) {
+    if (kf & (16 | 64)) { TCMI_S8(vm2_shear2_8_rx) }
+    if (kf & 64) { TCMI_S8(vm2_shear3rd_8_rx) }
+    if (kf & 32) { TCMI_S8(vm2_shear8_real) }
+  }
 #undef TCMI_S8
 }
 
@@ -136,6 +145,8 @@ __device__ __forceinline__ void vm2_g2(v2f (&a)[NR], int kflag, KV2 m) {
   }
 }
 
+#define TCMI_DIAGB_OPS ((1 << TCMI_OP_DIAGB) | (1 << TCMI_OP_DIAGB2) | (1 << TCMI_OP_DIAG))
+#define TCMI_DIAG_OPS (TCMI_DIAGB_OPS | (1 << TCMI_OP_DIAGC) | (1 << TCMI_OP_DIAGCW))
 // TOFF: type of the per-thread byte offset (uint32_t while every tile bit is below bit 29, i.e. n <= 29)
 template <int R, int LT, typename TOFF>
 __global__ __launch_bounds__(1 << LT, (1024 >> LT)) void pass2_kernel(v2f* __restrict__ state, long long state_stride,
@@ -207,152 +218,158 @@ __global__ __launch_bounds__(1 << LT, (1024 >> LT)) void pass2_kernel(v2f* __res
 #define TCMI_G1(J)                                                                                                  \
   if constexpr (R > J) {                                                                                             \
     const int sh = (mk >> (20 + J)) & (mk >> J) & 1; /* three-shear form: classes 5 (real) and 6 (rx-like) */          \
-    vm2_g1<NR, J>(a, onehot_if((mk >> J) & 1, ((mk >> (8 + 2 * J)) & 3) + 4 * sh), cf[4 * J], cf[4 * J + 1], cf[4 * J + 2], \
-                  cf[4 * J + 3]);                                                                                    \
+    const int two = sh & (int)(__float_as_uint(cf[4 * J + 1].y) >> 30); /* two-shear form: class 4 (rx-like only) */      \
+    const int kf = onehot_if((mk >> J) & 1, ((mk >> (8 + 2 * J)) & 3) + 4 * sh - 2 * two);                           \
+    if (kf) vm2_g1<NR, J>(a, kf, cf[4 * J], cf[4 * J + 1], cf[4 * J + 2], cf[4 * J + 3]);                            \
     sgnbits ^= sh ? (__float_as_uint(cf[4 * J + 1].x) & 0x80000000u) : 0u;                                           \
   }
         TCMI_G1(0) TCMI_G1(1) TCMI_G1(2) TCMI_G1(3) TCMI_G1(4) TCMI_G1(5)
 #undef TCMI_G1
       }
-      if (f & ((1 << TCMI_OP_DIAGC) | (1 << TCMI_OP_DIAGCW))) {
-        // register table; OP_DIAGCW: one of 2^nsel variants, picked by sign functions that are uniform over the wave
-        // (register-x-thread phase terms on wave-uniform bits ride on this multiply instead of needing their own)
-        int toff = desc[q + 1];
-        qn = q + 2;
-        if (f & (1 << TCMI_OP_DIAGCW)) {
-            const int nsel = desc[q + 2];
-            const uint32_t widx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wg_base | tphys));
-            int v = 0;
-#pragma unroll
-            for (int k2 = 0; k2 < 3; ++k2)
-              if (k2 < nsel) v |= (__popc(widx & (uint32_t)desc[q + 3 + k2]) & 1) << k2;
-            toff += 2 * NR * v;
-            qn = q + 6;
-        }
-        const KV2 tp = (KV2)(ptab + toff);
-#pragma unroll
-        for (int h = 0; h < NR; h += 16) {  // 32 scalar registers of table per burst
-          v2f t[16];
-#pragma unroll
-          for (int i = 0; i < 16; ++i) t[i] = tp[h + i];
-#pragma unroll
-          for (int r = 0; r < 16; r += 8)
-            vm2_cmul8s(a[h + r], a[h + r + 1], a[h + r + 2], a[h + r + 3], a[h + r + 4], a[h + r + 5], a[h + r + 6],
-                       a[h + r + 7], t[r], t[r + 1], t[r + 2], t[r + 3], t[r + 4], t[r + 5], t[r + 6], t[r + 7]);
-        }
-      }
-      if (f & (1 << TCMI_OP_DIAGB)) {
-        const int fj = onehot(desc[q + 1]);
-        const uint32_t m = (uint32_t)desc[q + 2];
-        const KPtr<float> tp = ptab + desc[q + 3];
-        qn = q + 4;
-        v2f e;
-        e.x = tp[0];
-        const float sn = tp[1];
-        e.y = (__popc((wg_base | tphys) & m) & 1) ? -sn : sn;
-#define TCMI_DB(J) \
-  if constexpr (R > J) { if (fj & (1 << J)) vm2_diagb<NR, J>(a, e); }
-        TCMI_DB(0) TCMI_DB(1) TCMI_DB(2) TCMI_DB(3) TCMI_DB(4) TCMI_DB(5)
-#undef TCMI_DB
-      }
-      if (f & (1 << TCMI_OP_DIAGB2)) {
-        // two sign functions on one register bit: factor = table[s1 + 2 s2] (4 builder-evaluated entries)
-        const int fj = onehot(desc[q + 1]);
-        const uint32_t m1 = (uint32_t)desc[q + 2], m2 = (uint32_t)desc[q + 3];
-        const KV2 tp = (KV2)(ptab + desc[q + 4]);
-        qn = q + 5;
-        const v2f t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
-        const uint32_t tidx = wg_base | tphys;
-        const bool s1 = __popc(tidx & m1) & 1, s2 = __popc(tidx & m2) & 1;
-        v2f e;
-        e.x = s2 ? (s1 ? t3.x : t2.x) : (s1 ? t1.x : t0.x);
-        e.y = s2 ? (s1 ? t3.y : t2.y) : (s1 ? t1.y : t0.y);
-#define TCMI_DB(J) \
-  if constexpr (R > J) { if (fj & (1 << J)) vm2_diagb<NR, J>(a, e); }
-        TCMI_DB(0) TCMI_DB(1) TCMI_DB(2) TCMI_DB(3) TCMI_DB(4) TCMI_DB(5)
-#undef TCMI_DB
-      }
-      if (f & (1 << TCMI_OP_DIAG)) {
-        // general phase polynomial (many thread x register terms): per-thread phases in turns, hardware sin / cos
-        const int nA = desc[q + 1], nB = desc[q + 2], nC = desc[q + 3];
-        const KPtr<float> cf = ptab + desc[q + 4];
-        int qq = q + 5;
-        const uint32_t tidx = wg_base | tphys;
-        double phi = 0.0;
-#pragma unroll 1
-        for (int e = 0; e < nA; e += TCMI_DIAG_CHUNK) {
-          uint32_t mk[TCMI_DIAG_CHUNK];
-          float cc[TCMI_DIAG_CHUNK];
-#pragma unroll
-          for (int i = 0; i < TCMI_DIAG_CHUNK; ++i) {
-            mk[i] = (uint32_t)desc[qq + e + i];
-            cc[i] = cf[e + i];
+      // diagonal ops in two nested groups (skipped tests are taken branches, see vm2_g1)
+      if (f & TCMI_DIAG_OPS) {
+        if (f & ((1 << TCMI_OP_DIAGC) | (1 << TCMI_OP_DIAGCW))) {
+          // register table; OP_DIAGCW: one of 2^nsel variants, picked by sign functions that are uniform over the wave
+          // (register-x-thread phase terms on wave-uniform bits ride on this multiply instead of needing their own)
+          int toff = desc[q + 1];
+          qn = q + 2;
+          if (f & (1 << TCMI_OP_DIAGCW)) {
+              const int nsel = desc[q + 2];
+              const uint32_t widx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wg_base | tphys));
+              int v = 0;
+  #pragma unroll
+              for (int k2 = 0; k2 < 3; ++k2)
+                if (k2 < nsel) v |= (__popc(widx & (uint32_t)desc[q + 3 + k2]) & 1) << k2;
+              toff += 2 * NR * v;
+              qn = q + 6;
           }
-#pragma unroll
-          for (int i = 0; i < TCMI_DIAG_CHUNK; ++i) {
-            const double c = (double)cc[i];
-            phi += (__popc(tidx & mk[i]) & 1) ? -c : c;
+          const KV2 tp = (KV2)(ptab + toff);
+  #pragma unroll
+          for (int h = 0; h < NR; h += 16) {  // 32 scalar registers of table per burst
+            v2f t[16];
+  #pragma unroll
+            for (int i = 0; i < 16; ++i) t[i] = tp[h + i];
+  #pragma unroll
+            for (int r = 0; r < 16; r += 8)
+              vm2_cmul8s(a[h + r], a[h + r + 1], a[h + r + 2], a[h + r + 3], a[h + r + 4], a[h + r + 5], a[h + r + 6],
+                         a[h + r + 7], t[r], t[r + 1], t[r + 2], t[r + 3], t[r + 4], t[r + 5], t[r + 6], t[r + 7]);
           }
         }
-        qq += nA;
-        double cj[R];
-#pragma unroll
-        for (int j = 0; j < R; ++j) cj[j] = 0.0;
-#pragma unroll 1
-        for (int e = 0; e < nB; e += TCMI_DIAG_CHUNK) {
-          uint32_t mk[TCMI_DIAG_CHUNK];
-          int jj[TCMI_DIAG_CHUNK];
-          float cc[TCMI_DIAG_CHUNK];
-#pragma unroll
-          for (int i = 0; i < TCMI_DIAG_CHUNK; ++i) {
-            mk[i] = (uint32_t)desc[qq + e + i];
-            jj[i] = desc[qq + nB + e + i];
-            cc[i] = cf[nA + e + i];
+        if (f & TCMI_DIAGB_OPS) {
+          if (f & (1 << TCMI_OP_DIAGB)) {
+            const int fj = onehot(desc[q + 1]);
+            const uint32_t m = (uint32_t)desc[q + 2];
+            const KPtr<float> tp = ptab + desc[q + 3];
+            qn = q + 4;
+            v2f e;
+            e.x = tp[0];
+            const float sn = tp[1];
+            e.y = (__popc((wg_base | tphys) & m) & 1) ? -sn : sn;
+    #define TCMI_DB(J) \
+      if constexpr (R > J) { if (fj & (1 << J)) vm2_diagb<NR, J>(a, e); }
+            TCMI_DB(0) TCMI_DB(1) TCMI_DB(2) TCMI_DB(3) TCMI_DB(4) TCMI_DB(5)
+    #undef TCMI_DB
           }
-#pragma unroll
-          for (int i = 0; i < TCMI_DIAG_CHUNK; ++i) {
-            const double c = (double)cc[i];
-            const double sgn = (__popc(tidx & mk[i]) & 1) ? -c : c;
-#pragma unroll
-            for (int j = 0; j < R; ++j) cj[j] += (j == jj[i]) ? sgn : 0.0;
+          if (f & (1 << TCMI_OP_DIAGB2)) {
+            // two sign functions on one register bit: factor = table[s1 + 2 s2] (4 builder-evaluated entries)
+            const int fj = onehot(desc[q + 1]);
+            const uint32_t m1 = (uint32_t)desc[q + 2], m2 = (uint32_t)desc[q + 3];
+            const KV2 tp = (KV2)(ptab + desc[q + 4]);
+            qn = q + 5;
+            const v2f t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3];
+            const uint32_t tidx = wg_base | tphys;
+            const bool s1 = __popc(tidx & m1) & 1, s2 = __popc(tidx & m2) & 1;
+            v2f e;
+            e.x = s2 ? (s1 ? t3.x : t2.x) : (s1 ? t1.x : t0.x);
+            e.y = s2 ? (s1 ? t3.y : t2.y) : (s1 ? t1.y : t0.y);
+    #define TCMI_DB(J) \
+      if constexpr (R > J) { if (fj & (1 << J)) vm2_diagb<NR, J>(a, e); }
+            TCMI_DB(0) TCMI_DB(1) TCMI_DB(2) TCMI_DB(3) TCMI_DB(4) TCMI_DB(5)
+    #undef TCMI_DB
           }
-        }
-        qq += 2 * nB;
-        // phases of eight register indices at a time (the full 2^R table would cost 32 more live registers)
-        const float ph0 = (float)(phi - rint(phi));
-        float cjf[R];
-#pragma unroll
-        for (int j = 0; j < R; ++j) cjf[j] = (float)(cj[j] - rint(cj[j]));
-        const KInt mC = desc + qq;
-        const KPtr<float> cC = cf + nA + nB;
-        qn = qq + nC;
-#pragma unroll
-        for (int h = 0; h < NR; h += 8) {
-          float ph[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            float v = ph0;
-#pragma unroll
-            for (int j = 0; j < R; ++j) v += (((h + i) >> j) & 1) ? -cjf[j] : cjf[j];
-            ph[i] = v;
+          if (f & (1 << TCMI_OP_DIAG)) {
+            // general phase polynomial (many thread x register terms): per-thread phases in turns, hardware sin / cos
+            const int nA = desc[q + 1], nB = desc[q + 2], nC = desc[q + 3];
+            const KPtr<float> cf = ptab + desc[q + 4];
+            int qq = q + 5;
+            const uint32_t tidx = wg_base | tphys;
+            double phi = 0.0;
+    #pragma unroll 1
+            for (int e = 0; e < nA; e += TCMI_DIAG_CHUNK) {
+              uint32_t mk[TCMI_DIAG_CHUNK];
+              float cc[TCMI_DIAG_CHUNK];
+    #pragma unroll
+              for (int i = 0; i < TCMI_DIAG_CHUNK; ++i) {
+                mk[i] = (uint32_t)desc[qq + e + i];
+                cc[i] = cf[e + i];
+              }
+    #pragma unroll
+              for (int i = 0; i < TCMI_DIAG_CHUNK; ++i) {
+                const double c = (double)cc[i];
+                phi += (__popc(tidx & mk[i]) & 1) ? -c : c;
+              }
+            }
+            qq += nA;
+            double cj[R];
+    #pragma unroll
+            for (int j = 0; j < R; ++j) cj[j] = 0.0;
+    #pragma unroll 1
+            for (int e = 0; e < nB; e += TCMI_DIAG_CHUNK) {
+              uint32_t mk[TCMI_DIAG_CHUNK];
+              int jj[TCMI_DIAG_CHUNK];
+              float cc[TCMI_DIAG_CHUNK];
+    #pragma unroll
+              for (int i = 0; i < TCMI_DIAG_CHUNK; ++i) {
+                mk[i] = (uint32_t)desc[qq + e + i];
+                jj[i] = desc[qq + nB + e + i];
+                cc[i] = cf[nA + e + i];
+              }
+    #pragma unroll
+              for (int i = 0; i < TCMI_DIAG_CHUNK; ++i) {
+                const double c = (double)cc[i];
+                const double sgn = (__popc(tidx & mk[i]) & 1) ? -c : c;
+    #pragma unroll
+                for (int j = 0; j < R; ++j) cj[j] += (j == jj[i]) ? sgn : 0.0;
+              }
+            }
+            qq += 2 * nB;
+            // phases of eight register indices at a time (the full 2^R table would cost 32 more live registers)
+            const float ph0 = (float)(phi - rint(phi));
+            float cjf[R];
+    #pragma unroll
+            for (int j = 0; j < R; ++j) cjf[j] = (float)(cj[j] - rint(cj[j]));
+            const KInt mC = desc + qq;
+            const KPtr<float> cC = cf + nA + nB;
+            qn = qq + nC;
+    #pragma unroll
+            for (int h = 0; h < NR; h += 8) {
+              float ph[8];
+    #pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                float v = ph0;
+    #pragma unroll
+                for (int j = 0; j < R; ++j) v += (((h + i) >> j) & 1) ? -cjf[j] : cjf[j];
+                ph[i] = v;
+              }
+    #pragma unroll 1
+              for (int e = 0; e < nC; ++e) {
+                const uint32_t rmask = (uint32_t)mC[e];
+                const float c = cC[e];
+    #pragma unroll
+                for (int i = 0; i < 8; ++i) ph[i] += (__popc((uint32_t)(h + i) & rmask) & 1) ? -c : c;
+              }
+              v2f e8[8];
+    #pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                float sn, cs;
+                sincos_turns<float>(ph[i], &sn, &cs);
+                e8[i].x = cs;
+                e8[i].y = sn;
+              }
+              vm2_cmul8v(a[h], a[h + 1], a[h + 2], a[h + 3], a[h + 4], a[h + 5], a[h + 6], a[h + 7], e8[0], e8[1], e8[2],
+                         e8[3], e8[4], e8[5], e8[6], e8[7]);
+            }
           }
-#pragma unroll 1
-          for (int e = 0; e < nC; ++e) {
-            const uint32_t rmask = (uint32_t)mC[e];
-            const float c = cC[e];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) ph[i] += (__popc((uint32_t)(h + i) & rmask) & 1) ? -c : c;
-          }
-          v2f e8[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            float sn, cs;
-            sincos_turns<float>(ph[i], &sn, &cs);
-            e8[i].x = cs;
-            e8[i].y = sn;
-          }
-          vm2_cmul8v(a[h], a[h + 1], a[h + 2], a[h + 3], a[h + 4], a[h + 5], a[h + 6], a[h + 7], e8[0], e8[1], e8[2],
-                     e8[3], e8[4], e8[5], e8[6], e8[7]);
         }
       }
       if (f & (1 << TCMI_OP_G2)) {

@@ -8,6 +8,7 @@ without it the reference re-runs ``tn.copy``, ``_merge_single_gates`` and the gr
 Python on every call, ``cons.py:1036,927``).
 """
 
+import dataclasses
 import hashlib
 import os
 from collections import OrderedDict
@@ -83,7 +84,8 @@ def pick_variant(n: int, dtypestr: str, opts: Optional[dict] = None) -> Tuple[in
             gen = 2 if (c64 and R >= 4 and not os.environ.get("TCMI_VM1")) else 1
             cap = os.environ.get("TCMI_PASS_CAP")
             return n_exec, P.PlanConfig(R=R, LT=LT, lowbits=low, vec=2 if c64 else 1, gen=gen,
-                                        pass_cap=int(cap) if cap else None)
+                                        pass_cap=int(cap) if cap else None,
+                                        shear2=os.environ.get("TCMI_SHEAR2", "1") != "0")
     raise ValueError("no tile variant fits")
 
 
@@ -147,8 +149,7 @@ class CompiledCircuit:
             # likes best
             best = vm_cost_us(self.plan)
             for lb, tb in ((6, 0), (4, 0), (4, 1), (5, 1), (6, 1)):
-                cfg2 = P.PlanConfig(R=self.cfg.R, LT=self.cfg.LT, lowbits=lb, vec=self.cfg.vec, gen=self.cfg.gen,
-                                    pass_cap=self.cfg.pass_cap, tiebreak=tb)
+                cfg2 = dataclasses.replace(self.cfg, lowbits=lb, tiebreak=tb)
                 plan2 = P.compile_plan(gates, self.n_exec, cfg2, nparams=nparams)
                 c2 = vm_cost_us(plan2)
                 if c2 < best * 0.995:
@@ -272,7 +273,7 @@ class CompiledCircuit:
                         if best is None or ((lb, tb) == (cfg.lowbits, cfg.tiebreak) and drop == (not full)) \
                                 or (drop is False and not full and (lb, tb) != (4, 1)):
                             continue
-                        cfg2 = P.PlanConfig(R=cfg.R, LT=cfg.LT, lowbits=lb, vec=cfg.vec, gen=cfg.gen, tiebreak=tb)
+                        cfg2 = dataclasses.replace(cfg, lowbits=lb, tiebreak=tb, pass_cap=None)
                         ap2 = P.compile_adjoint_plan(gates, self.n_exec, cfg2, factorized=True, drop_constant_head=drop)
                         c2 = adj_cost_us(ap2)
                         if c2 is not None and c2 < best * 0.995:
@@ -469,11 +470,15 @@ def pick_adjoint_variant(n_exec: int, dtypestr: str, gates) -> P.PlanConfig:
     dense2 = any(((not g.is_diag) and len(g.qubits) > 1) or (g.is_diag and any(len(t.qubits) > 2 for t in g.diag))
                  for g in gates)
     if dtypestr == "complex64" and n_exec >= 13 and not dense2 and not os.environ.get("TCMI_VM1"):
+        # two-shear rotations in the reverse sweep: implemented and tested (TCMI_SHEAR2_BW=1), off by default -- the sweep
+        # needs a second phase table for lambda (reciprocal real factors), whose scalar loads cost what the dropped
+        # shears save (n = 28 d = 12: 28.8 vs 28.7 ms per pass)
+        sh2 = os.environ.get("TCMI_SHEAR2_BW", "0") == "1"
         if os.environ.get("TCMI_ADJ_R5"):   # experiment switch: 32 + 32 amplitude pairs per thread, 2 waves per SIMD
-            return P.PlanConfig(R=5, LT=8, lowbits=5, vec=2, gen=2)
+            return P.PlanConfig(R=5, LT=8, lowbits=5, vec=2, gen=2, shear2=sh2)
         if os.environ.get("TCMI_ADJ_LT9"):  # experiment switch: 512-thread workgroups, two per CU, 13 tile bits
-            return P.PlanConfig(R=4, LT=9, lowbits=5, vec=2, gen=2)
-        return P.PlanConfig(R=4, LT=8, lowbits=5, vec=2, gen=2)
+            return P.PlanConfig(R=4, LT=9, lowbits=5, vec=2, gen=2, shear2=sh2)
+        return P.PlanConfig(R=4, LT=8, lowbits=5, vec=2, gen=2, shear2=sh2)
     return pick_small_tile_variant(n_exec, dtypestr)
 
 

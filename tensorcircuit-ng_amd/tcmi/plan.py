@@ -79,6 +79,10 @@ class DiagTerm:
     qubits: Tuple[int, ...]
     const: float = 0.0
     param: Optional[ParamRef] = None
+    # scale=True: not a phase but the real factor diag(c, 1/c) on the one listed qubit, c = cos(param.scale * theta +
+    # param.offset): what a rotation applied as two shears leaves behind (encode_pass, two-shear form); planner-internal
+    scale: bool = False
+    gate: int = -1   # scale terms: index of the rotation they belong to
 
 
 @dataclass
@@ -359,6 +363,7 @@ class PlanConfig:
     pass_cap: Optional[int] = None   # at most this many (weighted) dense gates per pass: a pass costs max(HBM round trip, arithmetic), so more gates than the round trip hides are better left to a later pass
     gen: int = 1        # kernel generation executing the plan: 2 = packed-f32 kernels (tcmi_vm2 / tcmi_adjoint2): extra ops
     tiebreak: int = 0   # tile growth, equal marginal gains: 0 = lowest physical bits first, 1 = highest first
+    shear2: bool = True  # gen-2 plans: rotations in two-shear form where the real factor rides on a phase table (shear2_gates)
 
     @property
     def T(self):
@@ -547,6 +552,8 @@ class Tables:
     cpool: List[float] = field(default_factory=list)       # builder constants (float64)
     _slot_cache: dict = field(default_factory=dict)
     pending: list = field(default_factory=list)               # diagonal terms not emitted yet (lazy flush)
+    shear2: set = field(default_factory=set)                  # gate ids applied in two-shear form (shear2_gates)
+    scale_only: set = field(default_factory=set)              # ... whose factor needed a table of its own (no phase term to ride on)
     gslot_param: List[int] = field(default_factory=list)     # adjoint: parameter index per slot
     gslot_factor: List[float] = field(default_factory=list)  # adjoint: d(theta)/d(slot value)
 
@@ -621,6 +628,42 @@ def g1_shear_flavor(g: GateRec, tol=1e-12) -> int:
     return kind
 
 
+SHEAR2_CMIN = 0.5      # two-shear form only while |cos| >= this (per batch element, decided by the builder kernel)
+SCALE_TERM = 1 << 16   # flag in the register-mask field of a BK_PHASE term: real scale term (DiagTerm.scale)
+
+
+def shear2_gates(gates: List[GateRec], order: Sequence[int], cfg: PlanConfig) -> set:
+    """Gates of the schedule ``order`` that may run in TWO-shear form.  An rx-like rotation U = [[c, i b], [i b, c]]
+    is diag(c, 1/c) L(i b c) S(i b / c): two in-place shears and a REAL diagonal factor (the same holds for the real
+    class [[c, -s], [s, c]], but the kernels carry a two-shear body for the rx-like class only, see csrc/tcmi_vm2.hip).
+    The factor is left pending like a diagonal gate (it commutes with everything that does not act on the qubit) and
+    is folded into the phase table of the flush that precedes the next dense gate on the qubit -- 2 instead of 3
+    packed instructions per amplitude pair when that flush multiplies by a table anyway.  Eligible: parametrised
+    rotations with U[0, 0] = cos(angle) exactly, whose next gate on the qubit is diagonal (so a table flush is due)
+    and which are not the last dense gate on the qubit (the factor must be gone when the plan ends).  At run time
+    the builder kernel falls back to the three-shear form for batch elements with |cos| < SHEAR2_CMIN."""
+    if cfg.gen < 2:
+        return set()
+    out = set()
+    nxt_diag = {}     # qubit -> True if the following gate on it (in schedule order) is diagonal
+    later_dense = set()
+    for gi in reversed(list(order)):
+        g = gates[gi]
+        if g.is_diag:
+            for q in g.qubits:
+                nxt_diag[q] = True
+            continue
+        if (len(g.qubits) == 1 and g.param is not None and g.select is None and g1_shear_flavor(g) == 2
+                and nxt_diag.get(g.qubits[0], False) and g.qubits[0] in later_dense):
+            c0, c1, c2 = (np.asarray(m, dtype=np.complex128) for m in (g.c0, g.c1, g.c2))
+            if abs(c0[0, 0]) < 1e-15 and abs(c1[0, 0] - 1) < 1e-15 and abs(c2[0, 0]) < 1e-15:
+                out.add(gi)
+        for q in g.qubits:
+            nxt_diag[q] = False
+            later_dense.add(q)
+    return out
+
+
 def _gate_slot(tables: Tables, gi: int, g: GateRec, swap: bool):
     """Table slot holding the dense matrix of gate g (optionally with its two qubits swapped)."""
     key = (gi, swap)
@@ -675,7 +718,8 @@ def g2_kind(g: GateRec, swap: bool, tol=1e-14) -> int:
     return 0
 
 
-def _matrix_record(tables: Tables, slot: int, g: GateRec, kind: int = BK_TRIG, swap: bool = False, shear: int = 0):
+def _matrix_record(tables: Tables, slot: int, g: GateRec, kind: int = BK_TRIG, swap: bool = False, shear: int = 0,
+                   two: bool = False):
     """Builder record writing a dense matrix derived from g to ptab[slot ..]: the gate itself
     (BK_TRIG), its adjoint (BK_UDAG) or K = dU U^dagger (BK_KMAT).  Constant gates included, so that
     the matrices of one op can sit contiguously."""
@@ -709,8 +753,9 @@ def _matrix_record(tables: Tables, slot: int, g: GateRec, kind: int = BK_TRIG, s
     for m in mats:
         for z in sw(m).reshape(-1):
             tables.cpool += [float(z.real), float(z.imag)]
-    # shear != 0: the builder writes {u, v, sign} of the three-shear form of the matrix instead of its entries
-    tables.ginfo.append([kind, slot, pidx, dim, off, shear, 0, 0])
+    # shear != 0: the builder writes {u, v, sign, flag} of the three-shear form of the matrix instead of its entries;
+    # two: it may choose the two-shear form (flag = 2.0, sign = 1, the factor diag(c, 1/c) is a pending scale term)
+    tables.ginfo.append([kind, slot, pidx, dim, off, shear, int(two), 0])
 
 
 def _coef_record(tables: Tables, slot: int, t: DiagTerm):
@@ -807,9 +852,9 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
                 if sh:
                     mk |= 1 << (SHEAR_SHIFT + j)
                 if not backward:
-                    _matrix_record(tables, base + 8 * j, g, shear=sh)
+                    _matrix_record(tables, base + 8 * j, g, shear=sh, two=gi in tables.shear2)
                 else:
-                    _matrix_record(tables, base + 8 * j, g, BK_UDAG, shear=sh)
+                    _matrix_record(tables, base + 8 * j, g, BK_UDAG, shear=sh, two=gi in tables.shear2)
                     if g.param is not None:
                         kmask |= 1 << j
                         _matrix_record(tables, kbase + 8 * j, g, BK_KMAT)
@@ -825,6 +870,9 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
             """Builder constants of one table entry: {k, o, param index, register mask} per term (in turns)."""
             off = len(tables.cpool)
             for rm, t in ts:
+                if t.scale:   # real factor c^(+-1), c = cos(k theta + o) in RADIANS (same arithmetic as the gate record)
+                    tables.cpool += [t.param.scale, t.param.offset, float(t.param.index), float(rm | SCALE_TERM)]
+                    continue
                 if t.param is None:
                     tables.cpool += [0.0, t.const / TWO_PI, 0.0, float(rm)]
                 else:
@@ -878,6 +926,10 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
             for t in terms:
                 pbits = [n - 1 - q for q in t.qubits]
                 rbits = [regphys[p] for p in pbits if p in regphys]
+                if t.scale:   # flushed right before a dense gate on its qubit: always a register bit, always the table
+                    assert len(rbits) == 1 and len(pbits) == 1, "scale term off the register bits"
+                    C_.append((1 << rbits[0], t))
+                    continue
                 nmask = 0
                 for p in pbits:
                     if p not in regphys:
@@ -902,6 +954,8 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
 
             def gslot(t):
                 # d(phase)/d(theta) = scale * s_t(idx); dL/dtheta = -scale * sum s_t Im(conj(lambda) psi)
+                if t.scale:
+                    return -1   # part of its rotation gate, whose gradient is taken there
                 return tables.grad_slot(t.param.index, -t.param.scale) if t.param is not None else -1
 
             # gen-2 kernels: a register-x-thread term whose non-register bits are the same for a whole wave (bits outside
@@ -925,18 +979,24 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
                             wsel.append(ent)
                         ent[1].extend((j, t) for t in bgroups.pop((j, nmask)))
 
-            def table_variants():
-                """Builder records of the (possibly wave-selected) register table; returns its slot."""
+            def table_variants(twin=False):
+                """Builder records of the (possibly wave-selected) register table; returns its slot.  ``twin`` (adjoint
+                sweep, scale terms present): a second table with the reciprocal real factors follows it -- psi carries
+                diag(c, 1/c), lambda its inverse, so that every gradient bilinear <lambda| . |psi> is unchanged."""
                 NR = 1 << R
                 nv = 1 << len(wsel)
-                slot_ = tables.alloc(2 * NR * nv)
+                slot_ = tables.alloc(2 * NR * nv * (2 if twin else 1))
                 terms_ = [(rm, t) for rm, t in C_]
+                if not wsel and all(t.scale for _, t in C_):
+                    tables.scale_only.update(t.gate for _, t in C_)
                 for k_, (_m, lst) in enumerate(wsel):
                     terms_ += [((1 << j) | (1 << (R + k_)), t) for j, t in lst]
                 off_ = phase_terms(terms_)
-                for v_ in range(nv):
-                    for r in range(NR):
-                        tables.ginfo.append([BK_PHASE, slot_ + 2 * (v_ * NR + r), 0, len(terms_), off_, r | (v_ << R), 0, 0])
+                for inv_ in range(2 if twin else 1):
+                    for v_ in range(nv):
+                        for r in range(NR):
+                            tables.ginfo.append([BK_PHASE, slot_ + 2 * ((inv_ * nv + v_) * NR + r), 0, len(terms_), off_,
+                                                 r | (v_ << R), inv_, 0])
                 return slot_
 
             if backward and factorized_bw:
@@ -944,7 +1004,8 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
                 #  with mask k, -1: none), B: (j, mask, slot (-1: applied elsewhere), gslot)*, A: (mask, gslot)*}: tables hold the FORWARD phase
                 #  factors (2^nsel wave-selected variants of the register table), the kernel applies the conjugate;
                 #  A terms (no register bit: only the final flush has them) contribute gradients only.
-                cslot = table_variants() if (C_ or wsel) else -1
+                twin = any(t.scale for _, t in C_)
+                cslot = table_variants(twin) if (C_ or wsel) else -1
                 NR_ = 1 << R
                 gsc = [-1] * NR_          # gradient slot per register mask (the term's Walsh coefficient of w)
                 dup = []                  # further terms with a mask already taken: gradient-only follow-up ops
@@ -972,7 +1033,9 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
                 for nmask, t in A_:
                     body += [nmask, gslot(t)]
                 sel = [m_ for m_, _ in wsel] + [0] * (3 - len(wsel))
-                ops.extend([OP_DIAGF, cslot, int(any(g_ >= 0 for g_ in gsc)), nB, len(A_), len(wsel)] + sel + body)
+                # hasC: bit 0 = some register-only term has a gradient slot, bit 1 = lambda has its own table (after psi's)
+                ops.extend([OP_DIAGF, cslot, int(any(g_ >= 0 for g_ in gsc)) | (2 if twin else 0), nB, len(A_), len(wsel)]
+                           + sel + body)
                 nops += 1
                 while dup:
                     gsc2, rest = [-1] * NR_, []
@@ -1029,6 +1092,15 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
                 return
             # generic form: coefficients live contiguously in the per-batch table (bulk scalar loads), padded
             # to a multiple of DIAG_CHUNK with zero terms
+            sc_ = [(rm, t) for rm, t in C_ if t.scale]
+            if sc_:   # scale terms are not phases: their own table multiply first
+                assert not backward
+                C_keep, C_[:] = [x for x in C_ if not x[1].scale], sc_
+                wsel_keep, wsel[:] = list(wsel), []
+                ops.extend([OP_DIAGC, table_variants()])
+                nops += 1
+                C_[:] = C_keep
+                wsel[:] = wsel_keep
             padA = (-len(A_)) % DIAG_CHUNK
             padB = (-len(B_)) % DIAG_CHUNK
             nA, nB, nC = len(A_) + padA, len(B_) + padB, len(C_)
@@ -1076,6 +1148,9 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
                     flush_group()
                 pend_flush.extend(due)
                 pend_g1[js[0]] = gi
+                if gi in tables.shear2:   # its factor diag(c, 1/c) follows the gate: pending from here on
+                    tables.pending.append(DiagTerm(g.qubits, 0.0, ParamRef(g.param.index, g.param.scale, g.param.offset),
+                                                   scale=True, gate=gi))
             elif len(js) == 2:
                 flush_group()
                 emit_diag(take_pending(g.qubits))
@@ -1132,9 +1207,17 @@ class CompiledPlan:
 
 def compile_plan(gates: List[GateRec], n: int, cfg: PlanConfig, nparams: int = 0) -> CompiledPlan:
     passes = schedule(gates, n, cfg)
-    tables = Tables()
-    tables.ctab += [0.0] * 8  # dummy matrix for the unused slots of G1M ops
-    descs = [encode_pass(gates, n, cfg, pp, tables, final=(i == len(passes) - 1)) for i, pp in enumerate(passes)]
+    sh2 = shear2_gates(gates, [gi for pp in passes for rd in pp.rounds for gi in rd.gates], cfg) if cfg.shear2 else set()
+    while True:
+        tables = Tables()
+        tables.ctab += [0.0] * 8
+        tables.shear2 = set(sh2)
+        descs = [encode_pass(gates, n, cfg, pp, tables, final=(i == len(passes) - 1)) for i, pp in enumerate(passes)]
+        if not tables.scale_only:
+            break
+        # a real factor that found no phase table to ride on costs a table multiply of its own -- more than the
+        # third shear it saves: those rotations go back to the three-shear form
+        sh2 -= tables.scale_only
     ginfo = np.array(tables.ginfo, dtype=np.int32).reshape(-1, 8)
     return CompiledPlan(
         n=n, cfg=cfg, passes=passes, descs=descs,
@@ -1291,10 +1374,18 @@ def compile_adjoint_plan(gates: List[GateRec], n: int, cfg: PlanConfig, factoriz
         last = max((i for i, g in enumerate(rev) if gate_has_param(g)), default=-1)
         rev = rev[: last + 1]
     passes = schedule(rev, n, cfg)
-    tables = Tables()
-    tables.ctab += [0.0] * 8
-    descs = [encode_pass(rev, n, cfg, pp, tables, backward=True, final=(i == len(passes) - 1), factorized_bw=factorized)
-             for i, pp in enumerate(passes)]
+    sh2 = set()
+    if cfg.shear2 and factorized:
+        sh2 = shear2_gates(rev, [gi for pp in passes for rd in pp.rounds for gi in rd.gates], cfg)
+    while True:
+        tables = Tables()
+        tables.ctab += [0.0] * 8
+        tables.shear2 = set(sh2)
+        descs = [encode_pass(rev, n, cfg, pp, tables, backward=True, final=(i == len(passes) - 1), factorized_bw=factorized)
+                 for i, pp in enumerate(passes)]
+        if not tables.scale_only:
+            break
+        sh2 -= tables.scale_only   # as in compile_plan
     return AdjointPlan(
         n=n, cfg=cfg, passes=passes, descs=descs, ctab=np.array(tables.ctab, dtype=np.float64),
         ptab_size=tables.ptab_size, ginfo=np.array(tables.ginfo, dtype=np.int32).reshape(-1, 8),

@@ -506,6 +506,88 @@ def test_gradient_with_respect_to_the_input_state(tcd):
     np.testing.assert_allclose(tc.backend.numpy(g), fd, atol=5e-4 if tc.dtypestr == "complex64" else 1e-6)
 
 
+def test_two_shear_reverse_sweep_on_the_gpu(monkeypatch):
+    """TCMI_SHEAR2_BW=1: the reverse sweep with rotations in two-shear form (lambda sheared in the other order, second
+    phase table with the reciprocal factors) gives the gradient of the default three-shear sweep and of the float64
+    kernels; angles on both sides of the builder's |cos| threshold."""
+    import tcmi as tc
+
+    tc.set_backend("hip")
+    n, d = 15, 3
+    rng = np.random.default_rng(15)
+    params = np.where(rng.random([2 * d, n]) < 0.7, rng.normal(0, 0.3, [2 * d, n]), rng.uniform(2.2, 4.0, [2 * d, n]))
+
+    def grad(dt, extra):
+        tc.set_dtype(dt)
+
+        def f(p):
+            c = tc.Circuit(n)
+            W.hea_b(c, n, d, p, zz=tc.gates._zz_matrix)
+            c.rx(extra, theta=0.25)      # a structure no other test compiles: the plan is built under the switch
+            return _tfim(tc, c, n)
+
+        v, g = tc.backend.value_and_grad(f)(tc.backend.convert_to_tensor(params, dtype=tc.rdtypestr))
+        return float(tc.backend.numpy(v)), tc.backend.numpy(g).astype(np.float64)
+
+    try:
+        monkeypatch.setenv("TCMI_SHEAR2_BW", "1")
+        v2, g2 = grad("complex64", 0)
+        from tcmi import executor as X
+        cc = next(reversed(X._CACHE.values()))
+        cc = getattr(cc, "full", cc)
+        recs = np.asarray(cc._adjoint(full=False)["plan"].ginfo).reshape(-1, 8)
+        assert ((recs[:, 0] == 3) & (recs[:, 6] != 0)).sum() >= 10     # BK_UDAG records allowed the two-shear form
+        monkeypatch.setenv("TCMI_SHEAR2_BW", "0")
+        v64, g64 = grad("complex128", 0)
+    finally:
+        tc.set_dtype("complex64")
+    assert abs(v2 - v64) < 1e-4
+    assert np.abs(g2 - g64).max() < 5e-4
+
+
+def test_input_state_cotangent_through_wide_angle_rotations(tcd):
+    """The packed reverse sweep pulls a sign out of rotations with cos < 0 (three-shear form) and leaves real factors
+    pending after two-shear ones; neither may reach the input-state cotangent.  Chained circuits on a packed-kernel
+    tile (n = 13), second circuit with rotation angles on both sides of pi; gradient of the FIRST circuit's angles
+    against central differences of the dense oracle."""
+    tc = tcd
+    n = 13
+    wide = [4.0, 0.5, 3.6, 5.9, 0.9, 2.4]
+
+    def f(p):
+        c1 = tc.Circuit(n)
+        for i in range(n):
+            c1.ry(i, theta=p[i])
+        c1.cnot(0, 1)
+        c2 = tc.Circuit(n, inputs=c1.state())
+        for k, a in enumerate(wide):
+            c2.rx(k, theta=p[n] * a)
+        for k in range(len(wide) - 1):
+            c2.rzz(k, k + 1, theta=0.3 + 0.1 * k)
+        for k, a in enumerate(wide):
+            c2.rx(k, theta=a)
+        c2.ry(3, theta=4.4)
+        return tc.backend.real(c2.expectation_ps(z=[1]) + c2.expectation_ps(x=[2]))
+
+    def ref(p):
+        ops = [(G.ry(p[i]), [i]) for i in range(n)] + [(G.CNOT, [0, 1])]
+        ops += [(G.rx(p[n] * a), [k]) for k, a in enumerate(wide)]
+        ops += [(G.rzz(0.3 + 0.1 * k), [k, k + 1]) for k in range(len(wide) - 1)]
+        ops += [(G.rx(a), [k]) for k, a in enumerate(wide)] + [(G.ry(4.4), [3])]
+        psi = dense.run(n, ops)
+        z1 = 1 - 2 * ((np.arange(2**n) >> (n - 2)) & 1)
+        x2 = np.vdot(psi, psi.reshape(4, 2, -1)[:, ::-1].reshape(-1))
+        return float(np.real(np.vdot(psi, z1 * psi) + x2))
+
+    rdt = np.float32 if tc.rdtypestr == "float32" else np.float64
+    p0 = np.concatenate([np.random.default_rng(5).uniform(0.2, 2.5, n), [1.0]])
+    v, g = tc.backend.value_and_grad(f)(tc.backend.convert_to_tensor(p0.astype(rdt)))
+    np.testing.assert_allclose(float(v), ref(p0), atol=3e-5 if tc.dtypestr == "complex64" else 1e-9)
+    eps = 1e-5
+    fd = np.array([(ref(p0 + eps * e) - ref(p0 - eps * e)) / (2 * eps) for e in np.eye(n + 1)])
+    np.testing.assert_allclose(tc.backend.numpy(g), fd, atol=5e-4 if tc.dtypestr == "complex64" else 1e-6)
+
+
 def test_tensor_valued_gate_matrix_is_not_silently_constant(tcd):
     """A gate matrix that is being differentiated cannot be baked into the plan as a constant: NotImplementedError
     with the reference's wording instead of a silent zero gradient."""

@@ -132,6 +132,84 @@ def test_plan_variants(lowbits, R, LT):
         assert pp.rounds[0].reg_tb[0] == 0 and pp.rounds[-1].reg_tb[0] == 0          # 16-byte accesses
 
 
+@pytest.mark.parametrize("scale", [0.3, 3.0])
+def test_two_shear_rotations_leave_a_pending_real_factor(scale):
+    """gen-2 plans apply a rotation that a diagonal gate follows as two shears; its factor diag(c, 1/c) rides on the
+    phase table of the next flush (plan.shear2_gates).  Small angles: every eligible gate takes the form; large
+    angles: the builder falls back to three shears wherever |cos| < SHEAR2_CMIN.  Both match the dense oracle."""
+    n, d = 14, 3
+    rng = np.random.default_rng(5)
+    pb = rng.normal(0, scale, [2 * d, n])
+    c = tc.Circuit(n)
+    W.hea_b(c, n, d, pb, zz=tc.gates._zz_matrix)
+    c.ry(3, theta=0.4)
+    c.rzz(3, 9, theta=0.2)
+    c.ry(3, theta=-0.7)
+    c.rx(9, theta=2.9)
+    ops = W.hea_b_ops(n, d, pb) + [(G.ry(0.4), [3]), (G.rzz(0.2), [3, 9]), (G.ry(-0.7), [3]), (G.rx(2.9), [9])]
+    th = np.array([float(x) for x in c._params])
+    ref = dense.run(n, ops)
+    for R in (4, 5):
+        cfg = P.PlanConfig(R=R, LT=8, lowbits=5, vec=2, gen=2)
+        pl = P.compile_plan(c._gate_records(), n, cfg, nparams=len(c._params))
+        recs = np.asarray(pl.ginfo).reshape(-1, 8)
+        allowed = recs[(recs[:, 0] == P.BK_TRIG) & (recs[:, 5] != 0) & (recs[:, 6] != 0)]
+        assert len(allowed) >= (d - 1) * n // 2   # the rx layers but the last (minus those whose factor found no table), the ry before the rzz
+        ptab = E.build_table(pl.ginfo, pl.cpool, th[None], pl.ptab_size)[0]
+        taken = sum(ptab[int(r[1]) + 3] != 0 for r in allowed)
+        assert (taken == len(allowed)) if scale < 1 else (0 < taken < len(allowed))
+        np.testing.assert_allclose(E.run_plan(pl, th), ref, atol=1e-12)
+        off = P.compile_plan(c._gate_records(), n, P.PlanConfig(R=R, LT=8, lowbits=5, vec=2, gen=2, shear2=False), nparams=len(c._params))
+        assert not np.asarray(off.ginfo).reshape(-1, 8)[:, 6].any()
+    # first-generation plans (complex128 kernels) never use it
+    pl1 = P.compile_plan(c._gate_records(), n, P.PlanConfig(R=4, LT=8, lowbits=5, vec=1), nparams=len(c._params))
+    assert not np.asarray(pl1.ginfo).reshape(-1, 8)[:, 6].any()
+
+
+@pytest.mark.parametrize("scale", [0.3, 3.0])
+def test_two_shear_adjoint_sweep(scale):
+    """The reverse sweep of the packed kernels with rotations in two-shear form: psi carries the pending factor
+    diag(c, 1/c), lambda its reciprocal (other shear order, second table in OP_DIAGF), so gradients are untouched.
+    Checked against central differences of the forward plan; the un-computed psi and the input-state cotangent
+    U^dagger g come back with the right sign (the sign pulled out of three-shear gates is applied at the store)."""
+    n, d = 13, 3
+    rng = np.random.default_rng(3)
+    pb = rng.normal(0, scale, [2 * d, n])
+    c = tc.Circuit(n)
+    W.hea_b(c, n, d, pb, zz=tc.gates._zz_matrix)
+    c.ry(3, theta=0.4); c.rzz(3, 9, theta=0.2); c.ry(3, theta=-0.7); c.rx(9, theta=2.9)
+    ops = W.hea_b_ops(n, d, pb) + [(G.ry(0.4), [3]), (G.rzz(0.2), [3, 9]), (G.ry(-0.7), [3]), (G.rx(2.9), [9])]
+    recs = c._gate_records()
+    vals = np.array([float(x) for x in c._params])
+    g = rng.normal(size=2 ** n) + 1j * rng.normal(size=2 ** n)
+    lam_ref = g
+    for m, qs in reversed(ops):
+        lam_ref = dense.apply_gate(lam_ref, n, np.asarray(m).conj().T, qs)
+    e0 = np.zeros(2 ** n)
+    e0[0] = 1
+    for R in (4, 5):
+        cfg = P.PlanConfig(R=R, LT=8, lowbits=5, vec=2, gen=2)
+        pl = P.compile_plan(recs, n, cfg, nparams=len(vals))
+        psi = E.run_plan(pl, vals)
+        for drop in (False, True):
+            ap = P.compile_adjoint_plan(recs, n, cfg, factorized=True, drop_constant_head=drop)
+            ra = np.asarray(ap.ginfo).reshape(-1, 8)
+            assert ((ra[:, 0] == E.BK_UDAG) & (ra[:, 6] != 0)).sum() >= 10      # two-shear candidates
+            assert ((ra[:, 0] == P.BK_PHASE) & (ra[:, 6] != 0)).any()            # lambda tables
+            grad, psi_in, lam_in = E.run_adjoint_plan(ap, vals, psi, g, len(vals), return_lambda=True)
+            if not drop:
+                np.testing.assert_allclose(psi_in, e0, atol=1e-12)
+                np.testing.assert_allclose(lam_in, lam_ref, atol=1e-11)
+            for i in rng.choice(len(vals), 5, replace=False):
+                vp, vm = vals.copy(), vals.copy()
+                vp[i] += 1e-6
+                vm[i] -= 1e-6
+                fd = (np.real(np.vdot(g, E.run_plan(pl, vp))) - np.real(np.vdot(g, E.run_plan(pl, vm)))) / 2e-6
+                assert abs(grad[i] - fd) < 2e-8, (R, drop, i, grad[i], fd)
+        ap0 = P.compile_adjoint_plan(recs, n, P.PlanConfig(R=R, LT=8, lowbits=5, vec=2, gen=2, shear2=False), factorized=True)
+        assert not np.asarray(ap0.ginfo).reshape(-1, 8)[:, 6].any()
+
+
 def test_batched_table_builder():
     n, d = 10, 2
     rng = np.random.default_rng(2)
