@@ -70,7 +70,7 @@ def main():
     out["svd_%dx%d_ms" % (2 * chi, 2 * chi)] = timeit(lambda: LA.svd_trunc(a, max_singular_values=chi, absorb=1)) * 1e3
     LA.svd_trunc(a, max_singular_values=chi, absorb=1)
     torch.cuda.synchronize()
-    ctl = LA._WORK[("svd", a.device)][:256].view(torch.int32).cpu().numpy()
+    ctl = LA._WORK[("svd", LA._devkey(a.device))][:256].view(torch.int32).cpu().numpy()
     out["svd_sweeps"] = int((ctl[2:62] > 0).sum()) + 1
     out["svd_barriers"] = int(ctl[0])
     b = a[:, :chi].contiguous()

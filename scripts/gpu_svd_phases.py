@@ -19,7 +19,7 @@ for rep in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     u, s, vh, rest = LA.svd_trunc(A, max_singular_values=min(m, n) // 2, absorb=2)
     torch.cuda.synchronize(); t = time.perf_counter() - t0
-w = LA._WORK[("svd", A.device)][:256].view(torch.int32).cpu().numpy()
+w = LA._WORK[("svd", LA._devkey(A.device))][:256].view(torch.int32).cpu().numpy()
 sweeps = int((w[2:42] != 0).sum()) + 1
 ph = w[48:54].astype(np.int64) * 16
 names = ["row_in", "intra", "cross", "row_out", "barrier", "total(sweeps)"]

@@ -25,7 +25,7 @@ for name, a in cases.items():
         torch.cuda.synchronize(); t0 = time.perf_counter()
         u, s, vh, rest = LA.svd_trunc(A, max_singular_values=min(m, n) // 2, absorb=2)
         torch.cuda.synchronize(); t = time.perf_counter() - t0
-    w = LA._WORK[("svd", A.device)][:256].view(torch.int32).cpu().numpy()
+    w = LA._WORK[("svd", LA._devkey(A.device))][:256].view(torch.int32).cpu().numpy()
     sweeps = int((w[2:62] != 0).sum()) + 1
     sref = np.linalg.svd(a, compute_uv=False)
     err = float(np.abs(np.concatenate([s.cpu().numpy().real, rest.cpu().numpy().real]) - sref).max() / sref[0])

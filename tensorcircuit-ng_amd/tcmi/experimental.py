@@ -17,6 +17,7 @@ from typing import Any, Callable, Dict, List, Optional
 import numpy as np
 
 from . import cons
+from .circuit import upload_cached
 from . import distributed as D
 from . import tn
 
@@ -228,7 +229,7 @@ class DistributedContractor:
                         gouts.append(g)
                 for b, rows, gs in groups.values():
                     gb = torch.zeros_like(b)
-                    gb.index_add_(0, torch.tensor(rows, device=b.device), torch.stack(gs))
+                    gb.index_add_(0, upload_cached(np.asarray(rows, dtype=np.int64), None, b.device), torch.stack(gs))
                     outs.append(b)
                     gouts.append(gb)
                 grads = torch.autograd.grad(outs, leaves, gouts, allow_unused=True)
