@@ -866,9 +866,18 @@ class Circuit:
             for i in idxs:
                 th = self._params[self._ops[i].pidx]
                 th = K.convert_to_tensor(th) if not torch.is_tensor(th) else th
-                th = th.real if th.is_complex() else th
-                ths.append(th.to(device=dev, dtype=rdt).reshape(()))
-            a = torch.stack(ths) * aff[:, 0] + aff[:, 1]
+                ths.append(th)
+            base = ths[0]._base if torch.is_tensor(ths[0]) else None
+            if (base is not None and base.is_contiguous() and base.device == torch.device(dev) and base.dtype == rdt
+                    and not torch._C._functorch.is_functorch_wrapped_tensor(base)
+                    and all(t._base is base and t.dim() == 0 for t in ths)):
+                # the usual case -- every angle is an element ``params[j, i, k]`` of ONE tensor: a single gather (and a
+                # single index_add in the backward) instead of a stack of hundreds of views with a node each
+                offs = np.array([t.storage_offset() - base.storage_offset() for t in ths], dtype=np.int64)
+                angles = base.reshape(-1)[upload_cached(offs, None, dev)]
+            else:
+                angles = torch.stack([(t.real if t.is_complex() else t).to(device=dev, dtype=rdt).reshape(()) for t in ths])
+            a = angles * aff[:, 0] + aff[:, 1]
             m = cdev[:, 0] + torch.cos(a)[:, None] * cdev[:, 1] + torch.sin(a)[:, None] * cdev[:, 2]    # [G, size]
             out.append((idxs, m))
         return out

@@ -209,7 +209,7 @@ class DistributedContractor:
         if self._fast_vjp(arrays):
             # reverse sweep over the step list on the untaped kernels (tn.contract_slices_vjp); the small gate tensors
             # stay on torch's tape, so their cotangents reach ``params`` through one autograd call
-            value, agrads = self.tree.contract_slices_vjp(arrays, self.my_slices, fop)
+            value, agrads = self.tree.contract_slices_vjp(arrays, self.my_slices, fop, alias_ok=True)
             if value is None:
                 value = sum((x.sum() * 0 for x in leaves)).real.detach()
             pairs = [(a, g) for a, g in zip(arrays, agrads) if g is not None and a.requires_grad]

@@ -1250,7 +1250,7 @@ class ContractionTree:
                 res = permute(res, final_perm)
             yield res
 
-    def contract_slices_vjp(self, arrays: Sequence[Any], slice_ids: Sequence[int], fop, need=None):
+    def contract_slices_vjp(self, arrays: Sequence[Any], slice_ids: Sequence[int], fop, need=None, alias_ok=False):
         """``sum_i fop(contract_core(slice_arrays(arrays, i)))`` and its gradient with respect to every array, by a
         reverse sweep over the step list instead of a framework tape (reference ``experimental.py:1182-1211``:
         ``value_and_grad`` of ``contract_core`` per slice, summed).  Every forward AND backward step is one launch of
@@ -1260,7 +1260,9 @@ class ContractionTree:
 
         ``fop`` maps a slice result to a real scalar (linear in the result, as in the reference);
         ``need[k]`` = whether array k wants a gradient (default: ``requires_grad``).  Returns (value, grads) with
-        ``grads[k]`` shaped like ``arrays[k]`` (or None)."""
+        ``grads[k]`` shaped like ``arrays[k]`` (or None).  ``alias_ok``: the gradients of the slice-invariant leaves
+        may be views of the replayed graphs' static memory (valid until the next call on this tree) instead of clones
+        -- a caller that consumes them at once (``DistributedContractor.value_and_grad``) saves a thousand tiny copies."""
         import torch
 
         steps, dep, last, final_perm = self._symbolic_steps()
@@ -1273,7 +1275,7 @@ class ContractionTree:
         for ia, ib, xa, xb, io in steps:
             needs[io] = needs[ia] or needs[ib]
         if slice_ids and needs[last] and _graph_ok(raw, len(steps), slice_ids):
-            return self._contract_slices_vjp_graph(raw, slice_ids, fop, need, needs)
+            return self._contract_slices_vjp_graph(raw, slice_ids, fop, need, needs, alias_ok)
         total = None
         grads: List[Any] = [None] * n
         ginv: Dict[int, Any] = {}
@@ -1346,7 +1348,7 @@ class ContractionTree:
                     grads[k] = ginv[k].reshape(raw[k].shape)
         return total, [g if need[k] else None for k, g in enumerate(grads)]
 
-    def _contract_slices_vjp_graph(self, raw, slice_ids, fop, need, needs):
+    def _contract_slices_vjp_graph(self, raw, slice_ids, fop, need, needs, alias_ok=False):
         """``contract_slices_vjp`` replayed from four HIP graphs (captured once per tree and operand signature): the
         slice-invariant forward steps, one slice forward, one slice backward, the invariant backward.  Between the
         slice graphs only ``fop`` and its derivative run eagerly, on the small result.  A 30-qubit depth-8 ladder is
@@ -1485,9 +1487,10 @@ class ContractionTree:
                 cache["g_a"].replay()
             grads: List[Any] = [None] * n
             total = None
+            touched = sorted(set(cache["st_dep"]) | set(cache["gleaf"]))   # the leaves that carry a sliced index
             for i in slice_ids:
                 vals = self.slice_index_values(i)
-                idx = [tuple(vals[e] if e in vals else slice(None) for e in edges) for edges in self.inputs]
+                idx = {k: tuple(vals[e] if e in vals else slice(None) for e in self.inputs[k]) for k in touched}
                 for k, buf in cache["st_dep"].items():
                     buf.copy_(raw[k][idx[k]])
                 cache["g_b"].replay()
@@ -1505,7 +1508,7 @@ class ContractionTree:
                         grads[k][idx[k]] += gl
             cache["g_d"].replay()
             for k, gl in cache["ginv_leaf"].items():
-                grads[k] = gl.reshape(raw[k].shape).clone()
+                grads[k] = gl.reshape(raw[k].shape) if alias_ok else gl.reshape(raw[k].shape).clone()
         return total, [g if need[k] else None for k, g in enumerate(grads)]
 
     def invariant_shards(self, world: int):
