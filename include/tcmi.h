@@ -177,6 +177,17 @@ int tcmi_contract_scattered(const void* big, int rank, const int* pos, int nk, c
 int tcmi_tensordot_bits(const void* a, int rank_a, const void* b, int rank_b, const int* axes_a, const int* axes_b,
                         int nk, void* c, int dtype, void* stream);
 
+/* The same with the elementwise and index work of a reverse-mode step fused in: flags bit 0 / 1 = use conj(a) /
+ * conj(b); out_axes (NULL: natural order) = the result is stored as permute(natural, out_axes), natural = (free axes of
+ * a, free axes of b).  The two VJPs of c = tensordot(a, b) -- gA = tensordot(g, conj b) moved to a's axis order, gB
+ * likewise (JAX's transpose rule of dot_general, which the reference gets through value_and_grad of contract_core,
+ * tensorcircuit/experimental.py:1182-1211) -- are then ONE launch each instead of three.  Only for the shapes
+ * tcmi_tensordot_bits_small_ok() accepts (both ranks <= 12, result rank <= 12, nk <= 8: the thousands of gate-sized
+ * steps of a circuit network); other shapes return TCMI_ERR_ARG and the caller keeps the three-launch form. */
+int tcmi_tensordot_bits_ex(const void* a, int rank_a, const void* b, int rank_b, const int* axes_a, const int* axes_b,
+                           int nk, const int* out_axes, int flags, void* c, int dtype, void* stream);
+int tcmi_tensordot_bits_small_ok(int rank_a, int rank_b, int nk);
+
 /* Batched complex GEMM C[M x N] = A[M x K] . B[K x N], row-major interleaved complex, strides in
  * elements between batch members; trans_a != 0: A is stored [K x M] (k-major).  complex64 runs on the f32 MFMA pipe
  * (v_mfma_f32_32x32x2_f32, exact f32 FMA), complex128 on the f64 MFMA pipe (v_mfma_f64_16x16x4_f64); both issue

@@ -544,9 +544,17 @@ __global__ __launch_bounds__(256, 5) void cgemm_bits_kernel(const float2* __rest
 // axes): the gate-absorbs-gate steps at the bottom of a circuit network's tree, hundreds per contraction.  One thread per
 // output element, the k offsets of both operands tabulated in LDS once per workgroup; no tiles, no MFMA -- the 64 x 64
 // tile kernel spends more time depositing its tile origin than these steps have arithmetic.
+struct OutPos {
+  int pos[32];  // address bit (in C) of bit j of the natural output index (row bits above column bits); identity: j
+};
+
+// flags: 1 = conjugate A's elements, 2 = conjugate B's; po: the result is stored with its axes permuted (the two VJPs
+// of a tensordot are tensordot(g, conj b) and tensordot(conj a, g) followed by a transposition into the operand's own
+// axis order: fused here they are one launch instead of three, and the reverse sweep of a circuit network is
+// thousands of such steps of a few microseconds each).
 __global__ __launch_bounds__(256) void tensordot_bits_small_kernel(const float2* __restrict__ A, const float2* __restrict__ B,
                                                                    float2* __restrict__ C, int lm, int ln, int lk, BitPos pa,
-                                                                   BitPos pb) {
+                                                                   BitPos pb, OutPos po, int flags) {
   __shared__ uint32_t kA[256], kB[256];
   const int tid = threadIdx.x;
   const int K = 1 << lk;
@@ -558,13 +566,16 @@ __global__ __launch_bounds__(256) void tensordot_bits_small_kernel(const float2*
   const uint32_t o = blockIdx.x * 256u + (uint32_t)tid;
   if (o >= (1u << (lm + ln))) return;
   const uint32_t ra = deposit_bits(o >> ln, pa.free_, lm, 0), cb = deposit_bits(o & ((1u << ln) - 1u), pb.free_, ln, 0);
+  const float sa = (flags & 1) ? -1.f : 1.f, sb = (flags & 2) ? -1.f : 1.f;
   float re = 0.f, im = 0.f;
   for (int k = 0; k < K; ++k) {
-    const float2 a = A[ra | kA[k]], b = B[cb | kB[k]];
+    float2 a = A[ra | kA[k]], b = B[cb | kB[k]];
+    a.y *= sa;
+    b.y *= sb;
     re = __builtin_fmaf(a.x, b.x, __builtin_fmaf(-a.y, b.y, re));
     im = __builtin_fmaf(a.x, b.y, __builtin_fmaf(a.y, b.x, im));
   }
-  C[o] = make_float2(re, im);
+  C[deposit_bits(o, po.pos, lm + ln, 0)] = make_float2(re, im);
 }
 
 // tensordot from stored layouts whose result has at most 8 x 8 elements and a long contraction (two big tensors closing
@@ -1148,9 +1159,21 @@ int tcmi_contract_scattered(const void* big, int rank, const int* pos_host, int 
   return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_contract_scattered: bad dtype");
 }
 
+int tcmi_tensordot_bits_small_ok(int rank_a, int rank_b, int nk) {
+  const int lm = rank_a - nk, ln = rank_b - nk;
+  return rank_a <= 12 && rank_b <= 12 && lm + ln <= 12 && nk <= 8 && nk >= 0 && lm >= 0 && ln >= 0;
+}
+
 int tcmi_tensordot_bits(const void* a, int rank_a, const void* b, int rank_b, const int* axes_a, const int* axes_b,
                         int nk, void* c, int dtype, void* stream) {
+  return tcmi_tensordot_bits_ex(a, rank_a, b, rank_b, axes_a, axes_b, nk, nullptr, 0, c, dtype, stream);
+}
+
+int tcmi_tensordot_bits_ex(const void* a, int rank_a, const void* b, int rank_b, const int* axes_a, const int* axes_b,
+                           int nk, const int* out_axes, int flags, void* c, int dtype, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if ((out_axes || flags) && !tcmi_tensordot_bits_small_ok(rank_a, rank_b, nk))
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_tensordot_bits_ex: conjugation / output permutation only for the small-tensor kernel (tcmi_tensordot_bits_small_ok)");
   if (!a || !b || !c || rank_a < 0 || rank_b < 0 || rank_a > 31 || rank_b > 31 || nk < 0 || nk > rank_a ||
       nk > rank_b || (nk > 0 && (!axes_a || !axes_b)))
     return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_tensordot_bits: bad argument");
@@ -1194,9 +1217,23 @@ int tcmi_tensordot_bits(const void* a, int rank_a, const void* b, int rank_b, co
   const long long M = 1ll << lm, N = 1ll << ln, K = 1ll << nk;
   if (rank_a <= 12 && rank_b <= 12 && lm + ln <= 12 && nk <= 8) {
     // small tensors: one thread per output element
+    // stored axis i of the result = natural axis out_axes[i] (natural order: free(a), free(b)); natural axis j is
+    // bit rc - 1 - j of the natural output index
+    const int rc = lm + ln;
+    tcmi::OutPos po;
+    for (int j = 0; j < 32; ++j) po.pos[j] = j;
+    if (out_axes) {
+      unsigned seen = 0;
+      for (int i = 0; i < rc; ++i) {
+        if (out_axes[i] < 0 || out_axes[i] >= rc || ((seen >> out_axes[i]) & 1u))
+          return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_tensordot_bits_ex: out_axes is not a permutation");
+        seen |= 1u << out_axes[i];
+        po.pos[rc - 1 - out_axes[i]] = rc - 1 - i;
+      }
+    }
     dim3 grid((unsigned)(((1ll << (lm + ln)) + 255) / 256), 1, 1), block(256, 1, 1);
     hipLaunchKernelGGL(tcmi::tensordot_bits_small_kernel, grid, block, 0, st, reinterpret_cast<const float2*>(a),
-                       reinterpret_cast<const float2*>(b), reinterpret_cast<float2*>(c), lm, ln, nk, pa, pb);
+                       reinterpret_cast<const float2*>(b), reinterpret_cast<float2*>(c), lm, ln, nk, pa, pb, po, flags);
     hipError_t se = hipGetLastError();
     if (se != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(se));
     return TCMI_OK;
@@ -1226,9 +1263,19 @@ int tcmi_tensordot_bits(const void* a, int rank_a, const void* b, int rank_b, co
   int ksplit = 1;
   long long kchunk = K;
   const long long tiles = gx * gy_all;
-  if (tiles < 256 && K >= 4096) {
+  // few output tiles, long contraction (the closing steps of a sliced network and most steps of its reverse sweep: a
+  // rank-20 x rank-18 step over 11 axes is 16 tiles): split K until about a thousand workgroups stream the operands,
+  // chunks of at least TCMI_BITS_KMIN k values (default 128 = 8 K steps; the first policy -- K >= 4096, chunks >= 1024 --
+  // left such steps on 8 ... 64 workgroups, 100 ... 470 us each)
+  static long long kmin = 0;
+  if (kmin == 0) {
+    const char* e = getenv("TCMI_BITS_KMIN");
+    kmin = e ? atoll(e) : 128;
+    if (kmin < TCMI_CBK) kmin = TCMI_CBK;
+  }
+  if (tiles < 512 && K >= 2 * kmin) {
     long long want = (1024 + tiles - 1) / tiles;
-    if (want > K / 1024) want = K / 1024;
+    if (want > K / kmin) want = K / kmin;
     if (want * gz > 65535) want = 65535 / gz;
     if (want > 1) {
       kchunk = ((K + want - 1) / want + TCMI_CBK - 1) / TCMI_CBK * TCMI_CBK;

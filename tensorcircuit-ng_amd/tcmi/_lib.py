@@ -89,6 +89,12 @@ _SIGNATURES = {
         [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
          ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p],
     ),
+    "tcmi_tensordot_bits_ex": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p],
+    ),
+    "tcmi_tensordot_bits_small_ok": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "tcmi_permute_bits": (
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong,

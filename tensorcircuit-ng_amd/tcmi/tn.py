@@ -1881,12 +1881,49 @@ def tensordot_vjp(a, b, axes_a, axes_b, g, need_a=True, need_b=True):
     fa, fb, perm_a, perm_b = _vjp_axes(a.dim(), b.dim(), axes_a, axes_b)
     ga = gb = None
     if need_a:
-        ga = _tensordot_raw(g, _conj(b), list(range(len(fa), len(fa) + len(fb))), fb)
-        ga = _permute_raw(ga, perm_a) if perm_a != list(range(a.dim())) else ga
+        ga = _tensordot_fused(g, b, list(range(len(fa), len(fa) + len(fb))), fb, perm_a, 2)
+        if ga is None:
+            ga = _tensordot_raw(g, _conj(b), list(range(len(fa), len(fa) + len(fb))), fb)
+            ga = _permute_raw(ga, perm_a) if perm_a != list(range(a.dim())) else ga
     if need_b:
-        gb = _tensordot_raw(_conj(a), g, fa, list(range(len(fa))))
-        gb = _permute_raw(gb, perm_b) if perm_b != list(range(b.dim())) else gb
+        gb = _tensordot_fused(a, g, fa, list(range(len(fa))), perm_b, 1)
+        if gb is None:
+            gb = _tensordot_raw(_conj(a), g, fa, list(range(len(fa))))
+            gb = _permute_raw(gb, perm_b) if perm_b != list(range(b.dim())) else gb
     return ga, gb
+
+
+def _tensordot_fused(a, b, axes_a, axes_b, out_perm, flags):
+    """``permute(tensordot(conj?(a), conj?(b)), out_perm)`` in ONE launch (``tcmi_tensordot_bits_ex``; flags 1 / 2:
+    conjugate a / b) for the gate-sized steps the small-tensor kernel takes; None for every other shape."""
+    import torch
+
+    if os.environ.get("TCMI_TN_FUSED_VJP", "1") == "0" or os.environ.get("TCMI_TN_BITS", "1") == "0":
+        return None
+    nk = len(axes_a)
+    if a.dtype != torch.complex64 or b.dtype != torch.complex64 or not a.is_cuda or not b.is_cuda:
+        return None
+    if any(d != 2 for d in a.shape) or any(d != 2 for d in b.shape):
+        return None
+    L = _lib.lib()
+    if not L.tcmi_tensordot_bits_small_ok(a.dim(), b.dim(), nk):
+        return None
+    a, b = a.contiguous(), b.contiguous()
+    rc = a.dim() + b.dim() - 2 * nk
+    out = torch.empty([2] * rc, dtype=a.dtype, device=a.device)
+    xa = (ctypes.c_int * max(nk, 1))(*axes_a)
+    xb = (ctypes.c_int * max(nk, 1))(*axes_b)
+    op = (ctypes.c_int * max(rc, 1))(*out_perm) if rc else None
+    if COUNTERS is not None:
+        COUNTERS["gemm_launches"] += 1
+        COUNTERS["gemm_flops"] += 8.0 * (1 << (a.dim() + b.dim() - nk))
+        COUNTERS["gemm_bytes"] += float(a.numel() + b.numel() + out.numel()) * a.element_size()
+    stream = torch.cuda.current_stream(a.device).cuda_stream
+    _lib.check(L.tcmi_tensordot_bits_ex(a.data_ptr(), a.dim(), b.data_ptr(), b.dim(), ctypes.cast(xa, ctypes.c_void_p),
+                                        ctypes.cast(xb, ctypes.c_void_p), nk,
+                                        ctypes.cast(op, ctypes.c_void_p) if op is not None else None, int(flags),
+                                        out.data_ptr(), _lib.TCMI_C64, stream), "tcmi_tensordot_bits_ex")
+    return out
 
 
 def _fns():
@@ -2055,6 +2092,8 @@ TN_STREAMS = int(os.environ.get("TCMI_TN_STREAMS", "2"))   # two slices of a sli
 SCATTERED_MIN_RANK = 16    # big operand: at least 2^16 elements
 SCATTERED_MAX_SMALL = 4096  # small operand: at most this many elements (it lives in LDS)
 SCATTERED_MAX_NK = int(os.environ.get("TCMI_TN_SCAT_MAXK", "8"))   # more contracted axes: the MFMA bits kernel
+SCATTERED_MIN_FREE = int(os.environ.get("TCMI_TN_SCAT_MINFREE", "14"))   # at least 2^14 threads (free indices of the big operand)
+SCATTERED_MAX_OUT = int(os.environ.get("TCMI_TN_SCAT_MAXOUT", "32"))     # at most this many outputs per thread
 
 
 def _tensordot_scattered(a, b, axes_a, axes_b, fa, fb):
@@ -2071,6 +2110,11 @@ def _tensordot_scattered(a, b, axes_a, axes_b, fa, fb):
     if big.dim() < SCATTERED_MIN_RANK or small.numel() > SCATTERED_MAX_SMALL or small.numel() < (1 << nk):
         return None
     if nk > 5 and (small.numel() >> nk) > 16:
+        return None
+    # one thread per free index of the big operand, n outputs each: it needs many threads with little to do each.
+    # (The reverse sweep of a sliced network has steps like rank 16 x rank 12 over 8 axes -- 256 threads -- or rank 17
+    # x rank 12 over 5 -- 128 outputs per thread: 100 us here, 20 us on the split-K tile kernel.)
+    if big.dim() - nk < SCATTERED_MIN_FREE or (small.numel() >> nk) > SCATTERED_MAX_OUT:
         return None
     if any(d != 2 for d in big.shape) or any(d != 2 for d in small.shape):
         return None

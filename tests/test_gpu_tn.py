@@ -447,6 +447,42 @@ def test_tensordot_from_stored_layouts_matches_torch():
     assert rc != 0
 
 
+def test_fused_reverse_mode_steps_match_torch_autograd(monkeypatch):
+    """tcmi_tensordot_bits_ex (conjugated operand + result stored in the operand's axis order, one launch): the two
+    VJPs of a tensordot against torch's autograd of torch.tensordot and against the three-launch form; a shape the
+    small-tensor kernel does not take falls back by itself; the entry point refuses such shapes."""
+    import ctypes
+    import torch
+    from tcmi import _lib, tn
+
+    rng = np.random.default_rng(11)
+    g_ = torch.Generator(device="cuda").manual_seed(5)
+    for ra, rb, nk in [(4, 4, 2), (6, 2, 1), (2, 6, 2), (8, 7, 3), (12, 4, 4), (5, 5, 5), (3, 3, 0), (10, 10, 8), (14, 4, 2)]:
+        xa = [int(x) for x in rng.permutation(ra)[:nk]]
+        xb = [int(x) for x in rng.permutation(rb)[:nk]]
+        a = torch.randn([2] * ra, dtype=torch.complex64, device="cuda", generator=g_)
+        b = torch.randn([2] * rb, dtype=torch.complex64, device="cuda", generator=g_)
+        cot = torch.randn([2] * (ra + rb - 2 * nk), dtype=torch.complex64, device="cuda", generator=g_)
+        a64, b64 = a.to(torch.complex128).requires_grad_(True), b.to(torch.complex128).requires_grad_(True)
+        ra_, rb_ = torch.autograd.grad(torch.tensordot(a64, b64, dims=(xa, xb)), (a64, b64), cot.to(torch.complex128))
+        monkeypatch.setenv("TCMI_TN_FUSED_VJP", "1")
+        ga, gb = tn.tensordot_vjp(a, b, xa, xb, cot)
+        monkeypatch.setenv("TCMI_TN_FUSED_VJP", "0")
+        ga0, gb0 = tn.tensordot_vjp(a, b, xa, xb, cot)
+        for got, plain, ref in ((ga, ga0, ra_), (gb, gb0, rb_)):
+            scale = max(float(ref.abs().max()), 1e-30)
+            assert tuple(got.shape) == tuple(ref.shape)
+            assert float((got.to(torch.complex128) - ref).abs().max()) / scale < 3e-5, (ra, rb, nk)
+            assert float((got - plain).abs().max()) / scale < 3e-5
+    monkeypatch.setenv("TCMI_TN_FUSED_VJP", "1")
+    assert _lib.lib().tcmi_tensordot_bits_small_ok(12, 4, 4) == 1 and _lib.lib().tcmi_tensordot_bits_small_ok(14, 4, 2) == 0
+    big = torch.zeros([2] * 14, dtype=torch.complex64, device="cuda")
+    ax = (ctypes.c_int * 2)(0, 1)
+    rc = _lib.lib().tcmi_tensordot_bits_ex(big.data_ptr(), 14, big.data_ptr(), 14, ctypes.cast(ax, ctypes.c_void_p),
+                                           ctypes.cast(ax, ctypes.c_void_p), 2, None, 1, big.data_ptr(), _lib.TCMI_C64, 0)
+    assert rc != 0
+
+
 @pytest.mark.parametrize("dt", ["complex64", "complex128"])
 def test_scattered_contraction_matches_tensordot(dt):
     """tcmi_contract_scattered (big tensor x small tensor over arbitrary axes, no permute of the big one) against
@@ -457,7 +493,7 @@ def test_scattered_contraction_matches_tensordot(dt):
     tdt = torch.complex64 if dt == "complex64" else torch.complex128
     rng = np.random.default_rng(0)
     g = torch.Generator(device="cuda").manual_seed(1)
-    rank = 18
+    rank = 22     # 2^14 free indices of the big operand are left after 8 contracted axes (tn.SCATTERED_MIN_FREE)
     big = torch.randn([2] * rank, dtype=tdt, device="cuda", generator=g)
     cases = 0
     for nk in (1, 2, 3, 4, 5, 6, 7, 8):
