@@ -188,6 +188,17 @@ int tcmi_tensordot_bits_ex(const void* a, int rank_a, const void* b, int rank_b,
                            int nk, const int* out_axes, int flags, void* c, int dtype, void* stream);
 int tcmi_tensordot_bits_small_ok(int rank_a, int rank_b, int nk);
 
+/* The same gate-sized steps, MANY per launch: tcmi_tensordot_small_desc() writes the 64-word job descriptor of one
+ * tcmi_tensordot_bits_ex() call (host memory; the addresses a, b, c are baked in), tcmi_tensordot_small_batch() runs
+ * `count` consecutive descriptors that live in DEVICE memory in one launch (jobs of one launch must not depend on each
+ * other; max_log2_out = the largest log2(result elements) among them).  The steps of one level of a contraction tree
+ * are independent: a circuit network's slice-invariant part and its reverse sweep become one launch per level instead
+ * of one per contract_between (reference tensorcircuit/cons.py:948, called ~1000 times per contraction of a 30-qubit
+ * ladder). */
+int tcmi_tensordot_small_desc(const void* a, int rank_a, const void* b, int rank_b, const int* axes_a, const int* axes_b,
+                              int nk, const int* out_axes, int flags, void* c, int* desc);
+int tcmi_tensordot_small_batch(const int* desc_dev, int count, int max_log2_out, void* stream);
+
 /* Batched complex GEMM C[M x N] = A[M x K] . B[K x N], row-major interleaved complex, strides in
  * elements between batch members; trans_a != 0: A is stored [K x M] (k-major).  complex64 runs on the f32 MFMA pipe
  * (v_mfma_f32_32x32x2_f32, exact f32 FMA), complex128 on the f64 MFMA pipe (v_mfma_f64_16x16x4_f64); both issue

@@ -578,6 +578,48 @@ __global__ __launch_bounds__(256) void tensordot_bits_small_kernel(const float2*
   C[deposit_bits(o, po.pos, lm + ln, 0)] = make_float2(re, im);
 }
 
+// MANY gate-sized tensordots in one launch: blockIdx.y = job, each job a TCMI_SMALL_DESC_WORDS-word descriptor in device
+// memory {a, b, c (64-bit addresses, lo / hi), lm, ln, lk, flags, row bits of a [12], k bits of a [8], column bits of b
+// [12], k bits of b [8], output bits [12]}.  The steps of one LEVEL of a contraction tree are independent of each other;
+// a 30-qubit depth-8 ladder has ~950 slice-invariant steps in ~40 levels, and its reverse sweep twice as many: one
+// launch per level instead of one per step (tn.SmallBatch).
+__global__ __launch_bounds__(256) void tensordot_small_batch_kernel(const int* __restrict__ desc_all) {
+  __shared__ uint32_t kA[256], kB[256];
+  __shared__ int d[TCMI_SMALL_DESC_WORDS];
+  const int tid = threadIdx.x;
+  if (tid < TCMI_SMALL_DESC_WORDS) d[tid] = desc_all[(long long)blockIdx.y * TCMI_SMALL_DESC_WORDS + tid];
+  __syncthreads();
+  const int lm = d[6], ln = d[7], lk = d[8], flags = d[9];
+  if (blockIdx.x * 256u >= (1u << (lm + ln))) return;   // workgroup-uniform
+  const float2* A = reinterpret_cast<const float2*>(((unsigned long long)(unsigned)d[1] << 32) | (unsigned)d[0]);
+  const float2* B = reinterpret_cast<const float2*>(((unsigned long long)(unsigned)d[3] << 32) | (unsigned)d[2]);
+  float2* C = reinterpret_cast<float2*>(((unsigned long long)(unsigned)d[5] << 32) | (unsigned)d[4]);
+  const int* pfa = d + 10;
+  const int* pka = d + 22;
+  const int* pfb = d + 30;
+  const int* pkb = d + 42;
+  const int* pc = d + 50;
+  const int K = 1 << lk;
+  if (tid < K) {
+    kA[tid] = deposit_bits((uint32_t)tid, pka, lk, 0);
+    kB[tid] = deposit_bits((uint32_t)tid, pkb, lk, 0);
+  }
+  __syncthreads();
+  const uint32_t o = blockIdx.x * 256u + (uint32_t)tid;
+  if (o >= (1u << (lm + ln))) return;
+  const uint32_t ra = deposit_bits(o >> ln, pfa, lm, 0), cb = deposit_bits(o & ((1u << ln) - 1u), pfb, ln, 0);
+  const float sa = (flags & 1) ? -1.f : 1.f, sb = (flags & 2) ? -1.f : 1.f;
+  float re = 0.f, im = 0.f;
+  for (int k = 0; k < K; ++k) {
+    float2 a = A[ra | kA[k]], b = B[cb | kB[k]];
+    a.y *= sa;
+    b.y *= sb;
+    re = __builtin_fmaf(a.x, b.x, __builtin_fmaf(-a.y, b.y, re));
+    im = __builtin_fmaf(a.x, b.y, __builtin_fmaf(a.y, b.x, im));
+  }
+  C[deposit_bits(o, pc, lm + ln, 0)] = make_float2(re, im);
+}
+
 // tensordot from stored layouts whose result has at most 8 x 8 elements and a long contraction (two big tensors closing
 // to a few numbers: 2^25 x 2^25 -> 8 x 8 over K = 2^22 in a reconfigured RQC tree): one thread per k, MT x NT accumulators
 // in registers, k offsets = the thread's low 8 k bits (deposited once) | the block counter's bits (scalar code), DPP wave
@@ -1159,27 +1201,13 @@ int tcmi_contract_scattered(const void* big, int rank, const int* pos_host, int 
   return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_contract_scattered: bad dtype");
 }
 
-int tcmi_tensordot_bits_small_ok(int rank_a, int rank_b, int nk) {
-  const int lm = rank_a - nk, ln = rank_b - nk;
-  return rank_a <= 12 && rank_b <= 12 && lm + ln <= 12 && nk <= 8 && nk >= 0 && lm >= 0 && ln >= 0;
-}
-
-int tcmi_tensordot_bits(const void* a, int rank_a, const void* b, int rank_b, const int* axes_a, const int* axes_b,
-                        int nk, void* c, int dtype, void* stream) {
-  return tcmi_tensordot_bits_ex(a, rank_a, b, rank_b, axes_a, axes_b, nk, nullptr, 0, c, dtype, stream);
-}
-
-int tcmi_tensordot_bits_ex(const void* a, int rank_a, const void* b, int rank_b, const int* axes_a, const int* axes_b,
-                           int nk, const int* out_axes, int flags, void* c, int dtype, void* stream) {
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if ((out_axes || flags) && !tcmi_tensordot_bits_small_ok(rank_a, rank_b, nk))
-    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_tensordot_bits_ex: conjugation / output permutation only for the small-tensor kernel (tcmi_tensordot_bits_small_ok)");
-  if (!a || !b || !c || rank_a < 0 || rank_b < 0 || rank_a > 31 || rank_b > 31 || nk < 0 || nk > rank_a ||
-      nk > rank_b || (nk > 0 && (!axes_a || !axes_b)))
+// Bit geometry of tensordot(a, b, axes): address bits of the k / row / column bits of both operands, and of the bits
+// of the natural output index when the result is stored permuted (out_axes; NULL: natural).  0 or an error code.
+static int bits_geometry(int rank_a, int rank_b, const int* axes_a, const int* axes_b, int nk, const int* out_axes,
+                         tcmi::BitPos& pa, tcmi::BitPos& pb, tcmi::OutPos& po) {
+  if (rank_a < 0 || rank_b < 0 || rank_a > 31 || rank_b > 31 || nk < 0 || nk > rank_a || nk > rank_b ||
+      (nk > 0 && (!axes_a || !axes_b)))
     return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_tensordot_bits: bad argument");
-  if (dtype != TCMI_C64) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_tensordot_bits: complex64 only");
-  // axis i of a [2]^rank tensor is address bit rank - 1 - i
-  tcmi::BitPos pa, pb;
   unsigned usedA = 0, usedB = 0;
   for (int j = 0; j < nk; ++j) {
     if (axes_a[j] < 0 || axes_a[j] >= rank_a || axes_b[j] < 0 || axes_b[j] >= rank_b)
@@ -1205,32 +1233,99 @@ int tcmi_tensordot_bits_ex(const void* a, int rank_a, const void* b, int rank_b,
     pa.k[j] = rank_a - 1 - axes_a[order[j]];
     pb.k[j] = rank_b - 1 - axes_b[order[j]];
   }
-  const int lm = rank_a - nk, ln = rank_b - nk;
   // free axes in stored order: the LAST free axis is row / column bit 0
   for (int i = rank_a - 1, j = 0; i >= 0; --i)
     if (!((usedA >> i) & 1u)) pa.free_[j++] = rank_a - 1 - i;
   for (int i = rank_b - 1, j = 0; i >= 0; --i)
     if (!((usedB >> i) & 1u)) pb.free_[j++] = rank_b - 1 - i;
+  // stored axis i of the result = natural axis out_axes[i] (natural order: free(a), free(b)); natural axis j is
+  // bit rc - 1 - j of the natural output index
+  const int rc = rank_a + rank_b - 2 * nk;
+  for (int j = 0; j < 32; ++j) po.pos[j] = j;
+  if (out_axes) {
+    if (rc > 31) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_tensordot_bits_ex: result rank above 31");
+    unsigned seen = 0;
+    for (int i = 0; i < rc; ++i) {
+      if (out_axes[i] < 0 || out_axes[i] >= rc || ((seen >> out_axes[i]) & 1u))
+        return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_tensordot_bits_ex: out_axes is not a permutation");
+      seen |= 1u << out_axes[i];
+      po.pos[rc - 1 - out_axes[i]] = rc - 1 - i;
+    }
+  }
+  return TCMI_OK;
+}
+
+int tcmi_tensordot_small_desc(const void* a, int rank_a, const void* b, int rank_b, const int* axes_a, const int* axes_b,
+                              int nk, const int* out_axes, int flags, void* c, int* desc) {
+  if (!desc || !a || !b || !c) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_tensordot_small_desc: null argument");
+  if (!tcmi_tensordot_bits_small_ok(rank_a, rank_b, nk))
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_tensordot_small_desc: not a small-kernel shape (tcmi_tensordot_bits_small_ok)");
+  tcmi::BitPos pa, pb;
+  tcmi::OutPos po;
+  const int e = bits_geometry(rank_a, rank_b, axes_a, axes_b, nk, out_axes, pa, pb, po);
+  if (e != TCMI_OK) return e;
+  const unsigned long long pv[3] = {(unsigned long long)a, (unsigned long long)b, (unsigned long long)c};
+  for (int i = 0; i < 3; ++i) {
+    desc[2 * i] = (int)(unsigned)(pv[i] & 0xffffffffull);
+    desc[2 * i + 1] = (int)(unsigned)(pv[i] >> 32);
+  }
+  desc[6] = rank_a - nk;
+  desc[7] = rank_b - nk;
+  desc[8] = nk;
+  desc[9] = flags;
+  for (int j = 0; j < 12; ++j) desc[10 + j] = pa.free_[j];
+  for (int j = 0; j < 8; ++j) desc[22 + j] = pa.k[j];
+  for (int j = 0; j < 12; ++j) desc[30 + j] = pb.free_[j];
+  for (int j = 0; j < 8; ++j) desc[42 + j] = pb.k[j];
+  for (int j = 0; j < 12; ++j) desc[50 + j] = po.pos[j];
+  desc[62] = desc[63] = 0;
+  return TCMI_OK;
+}
+
+int tcmi_tensordot_small_batch(const int* desc_dev, int count, int max_log2_out, void* stream) {
+  if (!desc_dev || count < 0 || max_log2_out < 0 || max_log2_out > 12)
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_tensordot_small_batch: bad argument");
+  if (count == 0) return TCMI_OK;
+  if (count > 65535) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_tensordot_small_batch: more than 65535 jobs");
+  const unsigned gx = (unsigned)(((1u << max_log2_out) + 255u) / 256u);
+  hipLaunchKernelGGL(tcmi::tensordot_small_batch_kernel, dim3(gx, (unsigned)count, 1), dim3(256, 1, 1), 0,
+                     reinterpret_cast<hipStream_t>(stream), desc_dev);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));
+  return TCMI_OK;
+}
+
+int tcmi_tensordot_bits_small_ok(int rank_a, int rank_b, int nk) {
+  const int lm = rank_a - nk, ln = rank_b - nk;
+  return rank_a <= 12 && rank_b <= 12 && lm + ln <= 12 && nk <= 8 && nk >= 0 && lm >= 0 && ln >= 0;
+}
+
+int tcmi_tensordot_bits(const void* a, int rank_a, const void* b, int rank_b, const int* axes_a, const int* axes_b,
+                        int nk, void* c, int dtype, void* stream) {
+  return tcmi_tensordot_bits_ex(a, rank_a, b, rank_b, axes_a, axes_b, nk, nullptr, 0, c, dtype, stream);
+}
+
+int tcmi_tensordot_bits_ex(const void* a, int rank_a, const void* b, int rank_b, const int* axes_a, const int* axes_b,
+                           int nk, const int* out_axes, int flags, void* c, int dtype, void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if ((out_axes || flags) && !tcmi_tensordot_bits_small_ok(rank_a, rank_b, nk))
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_tensordot_bits_ex: conjugation / output permutation only for the small-tensor kernel (tcmi_tensordot_bits_small_ok)");
+  if (!a || !b || !c) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_tensordot_bits: bad argument");
+  if (dtype != TCMI_C64) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_tensordot_bits: complex64 only");
+  // axis i of a [2]^rank tensor is address bit rank - 1 - i
+  tcmi::BitPos pa, pb;
+  tcmi::OutPos po;
+  {
+    const int ge = bits_geometry(rank_a, rank_b, axes_a, axes_b, nk, out_axes, pa, pb, po);
+    if (ge != TCMI_OK) return ge;
+  }
+  const int lm = rank_a - nk, ln = rank_b - nk;
   // loader mode of each operand by what its address bit 0 is: row / column bit 0 (0), k bit 0 (1), another k bit (2)
   const int ma = (nk > 0 && pa.k[0] == 0) ? 1 : ((lm > 0 && pa.free_[0] == 0) || rank_a == 0 ? 0 : 2);
   const int mb = (nk > 0 && pb.k[0] == 0) ? 1 : ((ln > 0 && pb.free_[0] == 0) || rank_b == 0 ? 0 : 2);
   const long long M = 1ll << lm, N = 1ll << ln, K = 1ll << nk;
   if (rank_a <= 12 && rank_b <= 12 && lm + ln <= 12 && nk <= 8) {
     // small tensors: one thread per output element
-    // stored axis i of the result = natural axis out_axes[i] (natural order: free(a), free(b)); natural axis j is
-    // bit rc - 1 - j of the natural output index
-    const int rc = lm + ln;
-    tcmi::OutPos po;
-    for (int j = 0; j < 32; ++j) po.pos[j] = j;
-    if (out_axes) {
-      unsigned seen = 0;
-      for (int i = 0; i < rc; ++i) {
-        if (out_axes[i] < 0 || out_axes[i] >= rc || ((seen >> out_axes[i]) & 1u))
-          return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_tensordot_bits_ex: out_axes is not a permutation");
-        seen |= 1u << out_axes[i];
-        po.pos[rc - 1 - out_axes[i]] = rc - 1 - i;
-      }
-    }
     dim3 grid((unsigned)(((1ll << (lm + ln)) + 255) / 256), 1, 1), block(256, 1, 1);
     hipLaunchKernelGGL(tcmi::tensordot_bits_small_kernel, grid, block, 0, st, reinterpret_cast<const float2*>(a),
                        reinterpret_cast<const float2*>(b), reinterpret_cast<float2*>(c), lm, ln, nk, pa, pb, po, flags);

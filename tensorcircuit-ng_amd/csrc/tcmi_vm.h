@@ -59,6 +59,7 @@
 #define TCMI_BK_PHASE 6 /* exp(2 pi i sum_t +-(k_t theta_t + o_t)) for one register index: rec = {6, slot, 0, nterms, off, r}, cpool = {k, o, param index, register mask} per term */
 #define TCMI_SCALE_TERM (1 << 16) /* BK_PHASE term flag (register-mask field): real factor c^(+-1), c = cos(k theta + o) in radians: what a rotation applied in two-shear form leaves behind (plan.shear2_gates); rec[6] = 1: reciprocal (lambda tables of the adjoint sweep) */
 #define TCMI_SHEAR2_CMIN 0.5      /* two-shear form only while |cos| >= this, else the three-shear form and factor 1 */
+#define TCMI_SMALL_DESC_WORDS 64 /* words of one job of tcmi_tensordot_small_batch (tcmi_tensordot.hip) */
 #define TCMI_BK_SELECT 5 /* M = table[round(theta)]: cpool = {count, 0, matrices...} */
 
 #endif

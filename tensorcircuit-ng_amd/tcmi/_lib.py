@@ -95,6 +95,12 @@ _SIGNATURES = {
          ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p],
     ),
     "tcmi_tensordot_bits_small_ok": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "tcmi_tensordot_small_desc": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+         ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p],
+    ),
+    "tcmi_tensordot_small_batch": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "tcmi_permute_bits": (
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong,

@@ -1376,62 +1376,100 @@ class ContractionTree:
                     st_inv = {k: raw[k].contiguous().clone() for k in range(n) if not dep[k]}
                     st_dep = {k: raw[k][idx0[k]].contiguous().clone() for k in range(n) if dep[k]}
 
-                    def fwd_inv(shared):
-                        for ia, ib, xa, xb, io in steps:
-                            if not dep[io]:
-                                shared[io] = _tensordot_raw(shared[ia], shared[ib], xa, xb)
+                    # Steps by LEVEL (1 + the deepest operand; for the slice-dependent steps invariant operands count
+                    # as leaves): the steps of a level are independent of each other, so under capture the gate-sized
+                    # ones of a level go out as ONE launch (SmallBatch) -- forward and, level by level downwards, both
+                    # halves of their VJPs.  The eager warm-up keeps the step-by-step form (B is None).
+                    lvl_inv: Dict[int, int] = {}
+                    lvl_dep: Dict[int, int] = {}
+                    inv_levels: Dict[int, list] = {}
+                    dep_levels: Dict[int, list] = {}
+                    for st in steps:
+                        ia, ib, xa, xb, io = st
+                        if dep[io]:
+                            lv = 1 + max(lvl_dep.get(ia, 0), lvl_dep.get(ib, 0))
+                            lvl_dep[io] = lv
+                            dep_levels.setdefault(lv, []).append(st)
+                        else:
+                            lv = 1 + max(lvl_inv.get(ia, 0), lvl_inv.get(ib, 0))
+                            lvl_inv[io] = lv
+                            inv_levels.setdefault(lv, []).append(st)
+                    inv_order = [inv_levels[k] for k in sorted(inv_levels)]
+                    dep_order = [dep_levels[k] for k in sorted(dep_levels)]
 
-                    def fwd_slice(shared, cur):
-                        for ia, ib, xa, xb, io in steps:
-                            if dep[io]:
-                                cur[io] = _tensordot_raw(cur[ia] if dep[ia] else shared[ia],
-                                                         cur[ib] if dep[ib] else shared[ib], xa, xb)
+                    def forward_level(level, src, dst, B):
+                        later = []
+                        for st in level:
+                            ia, ib, xa, xb, io = st
+                            ta, tb = src(ia), src(ib)
+                            if B is not None and B.ok(ta, tb, len(xa)):
+                                dst[io] = B.add(ta, tb, xa, xb, None, 0)
+                            else:
+                                later.append((io, ta, tb, xa, xb))
+                        if B is not None:
+                            B.flush()
+                        for io, ta, tb, xa, xb in later:
+                            dst[io] = _tensordot_raw(ta, tb, xa, xb)
+
+                    def backward_level(level, src, gsrc, route, B):
+                        """VJP halves of the steps of one level: ``gsrc`` pops the cotangent of a step's result (None:
+                        not needed), ``route(t, g)`` receives the cotangent of operand t."""
+                        later, done = [], []
+                        for ia, ib, xa, xb, io in level:
+                            gio = gsrc(io)
+                            if gio is None:
+                                continue
+                            for which, x, y, ax, ay, perm, fl in _vjp_halves(src(ia), src(ib), xa, xb, gio, needs[ia], needs[ib]):
+                                t_ = ib if which else ia
+                                if B is not None and B.ok(x, y, len(ax)):
+                                    done.append((t_, B.add(x, y, ax, ay, perm, fl)))
+                                else:
+                                    later.append((t_, x, y, ax, ay, perm, fl))
+                        if B is not None:
+                            B.flush()
+                        for t_, x, y, ax, ay, perm, fl in later:
+                            done.append((t_, _vjp_half_run(x, y, ax, ay, perm, fl)))
+                        for t_, g_ in done:
+                            route(t_, g_)
+
+                    def fwd_inv(shared, B=None):
+                        for level in inv_order:
+                            forward_level(level, lambda t: shared[t], shared, B)
+
+                    def fwd_slice(shared, cur, B=None):
+                        for level in dep_order:
+                            forward_level(level, lambda t: cur[t] if dep[t] else shared[t], cur, B)
                         res = cur[last] if dep[last] else shared[last]
                         return _permute_raw(res, final_perm) if final_perm is not None else res
 
-                    def bwd_slice(shared, cur, g_in, gacc):
+                    def bwd_slice(shared, cur, g_in, gacc, B=None):
                         g0 = _permute_raw(g_in, inv_perm) if inv_perm is not None else g_in
                         gbar = {}
                         if dep[last]:
                             gbar[last] = g0
                         else:
                             gacc[last].add_(g0.reshape(gacc[last].shape))
-                        gleaf = {}
-                        for ia, ib, xa, xb, io in reversed(steps):
-                            if not dep[io] or io not in gbar:
-                                continue
-                            gio = gbar.pop(io)
-                            ta = cur[ia] if dep[ia] else shared[ia]
-                            tb = cur[ib] if dep[ib] else shared[ib]
-                            ga, gb = tensordot_vjp(ta, tb, xa, xb, gio, needs[ia], needs[ib])
-                            for t_, g_ in ((ia, ga), (ib, gb)):
-                                if g_ is None:
-                                    continue
-                                if dep[t_]:
-                                    gbar[t_] = g_
-                                else:
-                                    gacc[t_].add_(g_.reshape(gacc[t_].shape))
-                        for k in range(n):
-                            if dep[k] and k in gbar:
-                                gleaf[k] = gbar[k]
-                        return gleaf
 
-                    def bwd_inv(shared, gacc):
+                        def route(t_, g_):
+                            if dep[t_]:
+                                gbar[t_] = g_
+                            else:
+                                gacc[t_].add_(g_.reshape(gacc[t_].shape))
+
+                        for level in reversed(dep_order):
+                            backward_level(level, lambda t: cur[t] if dep[t] else shared[t],
+                                           lambda io: gbar.pop(io, None), route, B)
+                        return {k: gbar[k] for k in range(n) if dep[k] and k in gbar}
+
+                    def bwd_inv(shared, gacc, B=None):
                         gt = dict(gacc)
-                        out = {}
-                        for ia, ib, xa, xb, io in reversed(steps):
-                            if dep[io] or io not in gt:
-                                continue
-                            gio = gt.pop(io)
-                            ga, gb = tensordot_vjp(shared[ia], shared[ib], xa, xb, gio, needs[ia], needs[ib])
-                            if ga is not None:
-                                gt[ia] = ga
-                            if gb is not None:
-                                gt[ib] = gb
-                        for k in range(n):
-                            if not dep[k] and k in gt and need[k]:
-                                out[k] = gt[k]
-                        return out
+
+                        def route(t_, g_):
+                            gt[t_] = g_
+
+                        for level in reversed(inv_order):
+                            backward_level(level, lambda t: shared[t], lambda io: gt.pop(io, None), route, B)
+                        return {k: gt[k] for k in range(n) if not dep[k] and k in gt and need[k]}
 
                     # invariant tensors that receive cotangents from the slice sweeps: static accumulators
                     targets = set()
@@ -1452,30 +1490,35 @@ class ContractionTree:
                     bwd_inv(shared, gacc)
                     torch.cuda.synchronize()
                     shared = dict(st_inv)
+                    B = None
+                    if os.environ.get("TCMI_TN_BATCH", "1") != "0" and all(t.dtype == torch.complex64 for t in raw):
+                        B = SmallBatch(raw[0].device, 3 * len(steps) + 16)
                     g_a = None
                     if any(not dep[st[4]] for st in steps):
                         g_a = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(g_a):
-                            fwd_inv(shared)
+                            fwd_inv(shared, B)
                     pool = g_a.pool() if g_a is not None else None
                     gacc = {t: torch.zeros_like(shared[t]) for t in targets}
                     cur = dict(st_dep)
                     g_b = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g_b, **({"pool": pool} if pool is not None else {})):
-                        res = fwd_slice(shared, cur)
+                        res = fwd_slice(shared, cur, B)
                     pool = g_b.pool()
                     g_in = torch.zeros_like(res)
                     g_c = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g_c, pool=pool):
-                        gleaf = bwd_slice(shared, cur, g_in, gacc)
+                        gleaf = bwd_slice(shared, cur, g_in, gacc, B)
                     g_d = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g_d, pool=pool):
-                        ginv_leaf = bwd_inv(shared, gacc)
+                        ginv_leaf = bwd_inv(shared, gacc, B)
+                    if B is not None:
+                        B.finish()     # the descriptor table the captured launches read: uploaded before any replay
             finally:
                 COUNTERS = keep_counters
             cache = {"sig": sig, "st_inv": st_inv, "st_dep": st_dep, "shared": shared, "cur": cur, "res": res,
                      "g_in": g_in, "gacc": gacc, "gleaf": gleaf, "ginv_leaf": ginv_leaf, "g_a": g_a, "g_b": g_b,
-                     "g_c": g_c, "g_d": g_d}
+                     "g_c": g_c, "g_d": g_d, "batch": B}
             self._vjp_graph_cache = cache
         with torch.no_grad():
             inv_k = list(cache["st_inv"])
@@ -1553,10 +1596,53 @@ class ContractionTree:
             roots_of[k].append((r, rank_of[r]))
         return steps_of, roots_of, loads
 
-    def _run_steps(self, leaves: Dict[int, Any], shared_t: Dict[int, Any], invariant: bool, only=None):
+    def _run_steps(self, leaves: Dict[int, Any], shared_t: Dict[int, Any], invariant: bool, only=None, batch=None):
         """The slice-invariant (``invariant``; ``only``: just the steps producing these tensors) or the slice-dependent
-        steps, eagerly, on the given leaf tensors."""
+        steps, eagerly, on the given leaf tensors.  ``batch`` (a SmallBatch, under graph capture only): the steps run
+        level by level and the gate-sized ones of a level share one launch."""
         steps, dep, last, final_perm = self._symbolic_steps()
+        if batch is not None:
+            # Phase 1: the steps whose whole subtree (within this part) is gate-sized -- the bottom of a circuit network's
+            # tree, most of its steps -- level by level, one launch per level.  Phase 2: everything else in the tree's
+            # own order (which bounds the live intermediates), consumed operands released as before.
+            want = (lambda io: not dep[io] and (only is None or io in only)) if invariant else (lambda io: dep[io])
+            cur = shared_t if invariant else dict(leaves)
+            src = (lambda t: shared_t[t]) if invariant else (lambda t: cur[t] if dep[t] else shared_t[t])
+            produced = {st[4] for st in steps if want(st[4])}
+            rank: Dict[int, int] = {}
+            small: Dict[int, bool] = {}
+            lvl: Dict[int, int] = {}
+            levels: Dict[int, list] = {}
+            ok_fn = _lib.lib().tcmi_tensordot_bits_small_ok
+            for st in steps:
+                ia, ib, xa, xb, io = st
+                if not want(io):
+                    continue
+                ra = rank[ia] if ia in produced else src(ia).dim()
+                rb = rank[ib] if ib in produced else src(ib).dim()
+                rank[io] = ra + rb - 2 * len(xa)
+                small[io] = bool(ok_fn(ra, rb, len(xa))) and all(t not in produced or small[t] for t in (ia, ib))
+                if small[io]:
+                    lv = 1 + max(lvl.get(ia, 0), lvl.get(ib, 0))
+                    lvl[io] = lv
+                    levels.setdefault(lv, []).append(st)
+            for lv in sorted(levels):
+                for ia, ib, xa, xb, io in levels[lv]:
+                    cur[io] = batch.add(src(ia), src(ib), xa, xb, None, 0)
+                batch.flush()
+            for ia, ib, xa, xb, io in steps:
+                if not want(io) or small[io]:
+                    continue
+                if invariant:
+                    cur[io] = tensordot(cur[ia], cur[ib], xa, xb)
+                else:
+                    ta = cur.pop(ia) if dep[ia] else shared_t[ia]
+                    tb = cur.pop(ib) if dep[ib] else shared_t[ib]
+                    cur[io] = tensordot(ta, tb, xa, xb)
+            if invariant:
+                return None
+            res = cur[last] if dep[last] else shared_t[last]
+            return permute(res, final_perm) if final_perm is not None else res
         if invariant:
             for ia, ib, xa, xb, io in steps:
                 if not dep[io] and (only is None or io in only):
@@ -1602,6 +1688,9 @@ class ContractionTree:
                 COUNTERS = new_counters()
                 g_inv = None
                 big = mine_steps = None
+                B = None
+                if os.environ.get("TCMI_TN_BATCH", "1") != "0" and all(t.dtype == torch.complex64 and t.is_cuda for t in first):
+                    B = SmallBatch(first[0].device, 2 * len(steps) + 16)
                 if sworld > 1:
                     # invariant subtrees split over the ranks: this rank's graph computes its own subtrees and packs
                     # their roots into row `srank` of `big`; after the all-gather every root is a view of `big`
@@ -1620,14 +1709,14 @@ class ContractionTree:
                     if mine_steps:
                         g_inv = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(g_inv):
-                            self._run_steps({}, shared_t, True, only=mine_steps)
+                            self._run_steps({}, shared_t, True, only=mine_steps, batch=B)
                             for root, lg in roots_of[srank]:
                                 views[root].copy_(shared_t[root])
                     shared_t.update(views)
                 elif any(not dep[st[4]] for st in steps):     # (an empty capture is an error on some ROCm versions)
                     g_inv = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g_inv):
-                        self._run_steps({}, shared_t, True)
+                        self._run_steps({}, shared_t, True, batch=B)
                 del warm
                 if sworld > 1 and sgroup != "emulate":
                     self._gather_invariants(big, srank, sworld, sgroup)   # the captures below replay on real values
@@ -1636,7 +1725,7 @@ class ContractionTree:
                 if any(dep[st[4]] for st in steps):
                     g_sl = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g_sl, **({"pool": g_inv.pool()} if g_inv is not None else {})):
-                        res = self._run_steps({k: static[k] for k in range(n) if dep[k]}, shared_t, False)
+                        res = self._run_steps({k: static[k] for k in range(n) if dep[k]}, shared_t, False, batch=B)
                 cnt_sl = COUNTERS
                 # a second instance of the per-slice graph (own leaf copies, own memory pool) for a second stream: the
                 # slice-dependent part is a chain of launches, many of them far too small to fill the chip, so two slices
@@ -1647,11 +1736,13 @@ class ContractionTree:
                     static2 = {k: static[k].clone() for k in range(n) if dep[k]}
                     g_sl2 = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g_sl2):
-                        res2 = self._run_steps(dict(static2), shared_t, False)
+                        res2 = self._run_steps(dict(static2), shared_t, False, batch=B)
+                if B is not None:
+                    B.finish()     # descriptor table of the batched launches: uploaded before any replay
             finally:
                 COUNTERS = keep_counters
             cache = {"sig": sig, "big": big, "static": static, "shared": shared_t, "g_inv": g_inv, "g_sl": g_sl, "res": res,
-                     "cnt_inv": cnt_inv, "cnt_sl": cnt_sl, "g_sl2": g_sl2, "res2": res2, "static2": static2,
+                     "cnt_inv": cnt_inv, "cnt_sl": cnt_sl, "g_sl2": g_sl2, "res2": res2, "static2": static2, "batch": B,
                      "side": torch.cuda.Stream(device=first[0].device) if g_sl2 is not None else None}
             self._graph_cache = cache
         static = cache["static"]
@@ -1874,23 +1965,116 @@ def _conj(t):
     return t.conj().resolve_conj()
 
 
+def _vjp_halves(a, b, axes_a, axes_b, g, need_a=True, need_b=True):
+    """The VJPs of ``tensordot(a, b)`` as jobs ``(which, x, y, axes_x, axes_y, out_perm, flags)``: which = 0 / 1 for gA /
+    gB, the job = permute(tensordot(conj?(x), conj?(y)), out_perm) with flags 1 / 2 = conjugate x / y."""
+    fa, fb, perm_a, perm_b = _vjp_axes(a.dim(), b.dim(), axes_a, axes_b)
+    jobs = []
+    if need_a:
+        jobs.append((0, g, b, list(range(len(fa), len(fa) + len(fb))), fb, perm_a, 2))
+    if need_b:
+        jobs.append((1, a, g, fa, list(range(len(fa))), perm_b, 1))
+    return jobs
+
+
+def _vjp_half_run(x, y, ax, ay, perm, flags):
+    """One such job on its own: the fused launch for gate-sized operands, else conjugate + tensordot + permute."""
+    r = _tensordot_fused(x, y, ax, ay, perm, flags)
+    if r is None:
+        r = _tensordot_raw(_conj(x) if flags & 1 else x, _conj(y) if flags & 2 else y, ax, ay)
+        r = _permute_raw(r, perm) if list(perm) != list(range(r.dim())) else r
+    return r
+
+
+SMALL_DESC_WORDS = 64
+
+
+class SmallBatch:
+    """Gate-sized tensordots of one tree LEVEL in one launch (``tcmi_tensordot_small_batch``).  Used while the HIP
+    graphs of a sliced contraction are captured: ``add`` allocates the result (graph-pool memory, fixed address), writes
+    the job's descriptor into a host table and returns the result tensor; ``flush`` launches the jobs added since the
+    last flush -- they must be independent of each other -- reading their descriptors from a static device table;
+    ``finish`` (after the captures, before the first replay) uploads the table.  Every tensor a descriptor points to is
+    kept alive here."""
+
+    def __init__(self, device, capacity: int):
+        import torch
+
+        self.host = np.zeros((max(1, capacity), SMALL_DESC_WORDS), dtype=np.int32)
+        self.dev = torch.zeros(max(1, capacity) * SMALL_DESC_WORDS, dtype=torch.int32, device=device)
+        self.n = 0
+        self.start = 0
+        self.maxlog = 0
+        self.keep: List[Any] = []
+        self.launches = 0
+
+    @staticmethod
+    def ok(a, b, nk: int) -> bool:
+        import torch
+
+        if os.environ.get("TCMI_TN_BITS", "1") == "0":
+            return False
+        if a.dtype != torch.complex64 or b.dtype != torch.complex64 or not a.is_cuda or not b.is_cuda:
+            return False
+        if any(d != 2 for d in a.shape) or any(d != 2 for d in b.shape):
+            return False
+        return bool(_lib.lib().tcmi_tensordot_bits_small_ok(a.dim(), b.dim(), nk))
+
+    def add(self, a, b, axes_a, axes_b, out_perm=None, flags: int = 0):
+        import torch
+
+        if self.n >= self.host.shape[0]:
+            raise RuntimeError("SmallBatch: descriptor table full")
+        a, b = a.contiguous(), b.contiguous()
+        nk = len(axes_a)
+        rc = a.dim() + b.dim() - 2 * nk
+        out = torch.empty([2] * rc, dtype=a.dtype, device=a.device)
+        xa = (ctypes.c_int * max(nk, 1))(*axes_a)
+        xb = (ctypes.c_int * max(nk, 1))(*axes_b)
+        op = (ctypes.c_int * max(rc, 1))(*out_perm) if (out_perm is not None and rc) else None
+        _lib.check(_lib.lib().tcmi_tensordot_small_desc(
+            a.data_ptr(), a.dim(), b.data_ptr(), b.dim(), ctypes.cast(xa, ctypes.c_void_p), ctypes.cast(xb, ctypes.c_void_p),
+            nk, ctypes.cast(op, ctypes.c_void_p) if op is not None else None, int(flags), out.data_ptr(),
+            self.host[self.n].ctypes.data), "tcmi_tensordot_small_desc")
+        self.n += 1
+        self.maxlog = max(self.maxlog, rc)
+        self.keep += [a, b, out]
+        if COUNTERS is not None:
+            COUNTERS["gemm_flops"] += 8.0 * (1 << (a.dim() + b.dim() - nk))
+            COUNTERS["gemm_bytes"] += float(a.numel() + b.numel() + out.numel()) * a.element_size()
+        return out
+
+    def flush(self):
+        import torch
+
+        while self.start < self.n:
+            cnt = min(self.n - self.start, 65535)
+            stream = torch.cuda.current_stream(self.dev.device).cuda_stream
+            _lib.check(_lib.lib().tcmi_tensordot_small_batch(self.dev.data_ptr() + 4 * SMALL_DESC_WORDS * self.start, cnt,
+                                                             self.maxlog, stream), "tcmi_tensordot_small_batch")
+            self.start += cnt
+            self.launches += 1
+            if COUNTERS is not None:
+                COUNTERS["gemm_launches"] += 1
+        self.maxlog = 0
+
+    def finish(self):
+        import torch
+
+        assert self.start == self.n, "SmallBatch: jobs added after the last flush"
+        if self.n:
+            self.dev[: self.n * SMALL_DESC_WORDS].copy_(torch.from_numpy(self.host[: self.n].reshape(-1)))
+            torch.cuda.synchronize(self.dev.device)
+
+
 def tensordot_vjp(a, b, axes_a, axes_b, g, need_a=True, need_b=True):
     """(gA, gB) of ``tensordot(a, b, [axes_a, axes_b])`` for the cotangent ``g`` (torch's convention for complex
     tensors: gA = g . b^H), computed by the same kernels as the forward step -- the rule the reference gets from
     JAX's transpose of ``dot_general`` (``experimental.py:1182-1211`` differentiates ``contract_core``)."""
-    fa, fb, perm_a, perm_b = _vjp_axes(a.dim(), b.dim(), axes_a, axes_b)
-    ga = gb = None
-    if need_a:
-        ga = _tensordot_fused(g, b, list(range(len(fa), len(fa) + len(fb))), fb, perm_a, 2)
-        if ga is None:
-            ga = _tensordot_raw(g, _conj(b), list(range(len(fa), len(fa) + len(fb))), fb)
-            ga = _permute_raw(ga, perm_a) if perm_a != list(range(a.dim())) else ga
-    if need_b:
-        gb = _tensordot_fused(a, g, fa, list(range(len(fa))), perm_b, 1)
-        if gb is None:
-            gb = _tensordot_raw(_conj(a), g, fa, list(range(len(fa))))
-            gb = _permute_raw(gb, perm_b) if perm_b != list(range(b.dim())) else gb
-    return ga, gb
+    out = [None, None]
+    for which, x, y, ax, ay, perm, fl in _vjp_halves(a, b, axes_a, axes_b, g, need_a, need_b):
+        out[which] = _vjp_half_run(x, y, ax, ay, perm, fl)
+    return out[0], out[1]
 
 
 def _tensordot_fused(a, b, axes_a, axes_b, out_perm, flags):
