@@ -483,6 +483,54 @@ def test_fused_reverse_mode_steps_match_torch_autograd(monkeypatch):
     assert rc != 0
 
 
+def test_many_gate_sized_tensordots_in_one_launch():
+    """tcmi_tensordot_small_desc + tcmi_tensordot_small_batch: 40 independent jobs of different shapes (conjugated
+    operands, permuted results, scalars, outer products, 4096-element results) in ONE launch against numpy; the
+    descriptor builder refuses shapes the small kernel does not take."""
+    import ctypes
+    import torch
+    from tcmi import _lib, tn
+
+    L = _lib.lib()
+    rng = np.random.default_rng(21)
+    g_ = torch.Generator(device="cuda").manual_seed(9)
+    shapes = [(4, 4, 2), (6, 2, 1), (2, 6, 2), (8, 7, 3), (12, 4, 4), (5, 5, 5), (3, 3, 0), (10, 10, 8), (0, 4, 0), (7, 7, 1)]
+    jobs, host = [], np.zeros((40, tn.SMALL_DESC_WORDS), dtype=np.int32)
+    for j in range(40):
+        ra, rb, nk = shapes[j % len(shapes)]
+        xa = [int(x) for x in rng.permutation(ra)[:nk]]
+        xb = [int(x) for x in rng.permutation(rb)[:nk]]
+        rc = ra + rb - 2 * nk
+        perm = [int(x) for x in rng.permutation(rc)] if j % 3 else None
+        flags = j % 4
+        a = torch.randn([2] * ra, dtype=torch.complex64, device="cuda", generator=g_)
+        b = torch.randn([2] * rb, dtype=torch.complex64, device="cuda", generator=g_)
+        c = torch.full([2] * rc, float("nan"), dtype=torch.complex64, device="cuda")
+        arr_a, arr_b = (ctypes.c_int * max(nk, 1))(*xa), (ctypes.c_int * max(nk, 1))(*xb)
+        arr_p = (ctypes.c_int * max(rc, 1))(*perm) if perm is not None and rc else None
+        _lib.check(L.tcmi_tensordot_small_desc(
+            a.data_ptr(), ra, b.data_ptr(), rb, ctypes.cast(arr_a, ctypes.c_void_p), ctypes.cast(arr_b, ctypes.c_void_p), nk,
+            ctypes.cast(arr_p, ctypes.c_void_p) if arr_p is not None else None, flags, c.data_ptr(), host[j].ctypes.data),
+            "tcmi_tensordot_small_desc")
+        jobs.append((a, b, c, xa, xb, perm, flags))
+    dev = torch.from_numpy(host.reshape(-1)).cuda()
+    _lib.check(L.tcmi_tensordot_small_batch(dev.data_ptr(), 40, 12, torch.cuda.current_stream().cuda_stream),
+               "tcmi_tensordot_small_batch")
+    torch.cuda.synchronize()
+    for a, b, c, xa, xb, perm, flags in jobs:
+        an, bn = a.cpu().numpy().astype(np.complex128), b.cpu().numpy().astype(np.complex128)
+        ref = np.tensordot(an.conj() if flags & 1 else an, bn.conj() if flags & 2 else bn, axes=(xa, xb))
+        if perm is not None and ref.ndim:
+            ref = ref.transpose(perm)
+        err = float(np.abs(c.cpu().numpy() - ref).max()) / max(float(np.abs(ref).max()), 1e-30)
+        assert err < 3e-5, (a.dim(), b.dim(), xa, xb, perm, flags, err)
+    big = torch.zeros([2] * 14, dtype=torch.complex64, device="cuda")
+    ax = (ctypes.c_int * 2)(0, 1)
+    assert L.tcmi_tensordot_small_desc(big.data_ptr(), 14, big.data_ptr(), 14, ctypes.cast(ax, ctypes.c_void_p),
+                                       ctypes.cast(ax, ctypes.c_void_p), 2, None, 0, big.data_ptr(), host[0].ctypes.data) != 0
+    assert L.tcmi_tensordot_small_batch(dev.data_ptr(), 70000, 12, 0) != 0
+
+
 @pytest.mark.parametrize("dt", ["complex64", "complex128"])
 def test_scattered_contraction_matches_tensordot(dt):
     """tcmi_contract_scattered (big tensor x small tensor over arbitrary axes, no permute of the big one) against
@@ -659,6 +707,18 @@ def test_sliced_value_and_grad_on_the_fast_kernels_matches_the_adjoint_path(dt, 
         assert dc.tree.nslices >= 8
         v, g = dc.value_and_grad(pt)
         v0, g0 = tc.backend.value_and_grad(lambda p: tc.backend.real(circuit(p).expectation_ps(z=[0])))(pt)
+        # replays follow the parameters: a second point through the same graphs (static descriptor tables of the
+        # batched levels, static leaf copies), then the first one again
+        pt2 = pt * 0.7 + 0.1
+        vb, gb = dc.value_and_grad(pt2)
+        v0b, g0b = tc.backend.value_and_grad(lambda p: tc.backend.real(circuit(p).expectation_ps(z=[0])))(pt2)
+        assert abs(float(vb) - float(v0b)) < tol and float((gb - g0b).abs().max()) < tol
+        assert float((gb - g).abs().max()) > 1e-3
+        vc, gc = dc.value_and_grad(pt)
+        assert abs(float(vc) - float(v)) < 1e-6 and float((gc - g).abs().max()) < 1e-6
+        cache = dc.tree._vjp_graph_cache
+        if dt == "complex64":
+            assert cache["batch"] is not None and cache["batch"].n > 100 and cache["batch"].launches < cache["batch"].n / 4
         monkeypatch.setenv("TCMI_TN_VJP", "0")
         v1, g1 = dc.value_and_grad(pt)
         e_adj = float((g - g0).abs().max())
