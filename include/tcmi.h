@@ -181,9 +181,11 @@ int tcmi_tensordot_bits(const void* a, int rank_a, const void* b, int rank_b, co
  * conj(b); out_axes (NULL: natural order) = the result is stored as permute(natural, out_axes), natural = (free axes of
  * a, free axes of b).  The two VJPs of c = tensordot(a, b) -- gA = tensordot(g, conj b) moved to a's axis order, gB
  * likewise (JAX's transpose rule of dot_general, which the reference gets through value_and_grad of contract_core,
- * tensorcircuit/experimental.py:1182-1211) -- are then ONE launch each instead of three.  Only for the shapes
+ * tensorcircuit/experimental.py:1182-1211) -- are then ONE launch each instead of three.  out_axes works for every
+ * shape (the tile kernels store through the bit permutation); the conjugation flags only for the shapes
  * tcmi_tensordot_bits_small_ok() accepts (both ranks <= 12, result rank <= 12, nk <= 8: the thousands of gate-sized
- * steps of a circuit network); other shapes return TCMI_ERR_ARG and the caller keeps the three-launch form. */
+ * steps of a circuit network) -- other shapes return TCMI_ERR_ARG for flags != 0 (a reverse sweep that carries the
+ * CONJUGATED cotangent needs no conjugation at all: conj(gA) = tensordot(conj g, b)). */
 int tcmi_tensordot_bits_ex(const void* a, int rank_a, const void* b, int rank_b, const int* axes_a, const int* axes_b,
                            int nk, const int* out_axes, int flags, void* c, int dtype, void* stream);
 int tcmi_tensordot_bits_small_ok(int rank_a, int rank_b, int nk);

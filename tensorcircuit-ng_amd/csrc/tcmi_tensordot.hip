@@ -416,6 +416,10 @@ struct BitPos {
   int k[32];      // address bit of k bit j
 };
 
+struct OutPos {
+  int pos[32];  // address bit (in C) of bit j of the natural output index (row bits above column bits); identity: j
+};
+
 __device__ __forceinline__ uint32_t deposit_bits(uint32_t v, const int* pos, int nb, int from) {
   uint32_t off = 0;
   for (int j = from; j < nb; ++j) off |= ((v >> j) & 1u) << pos[j];
@@ -471,7 +475,8 @@ struct BitsLoader {
 template <int MA, int MB>
 __global__ __launch_bounds__(256, 5) void cgemm_bits_kernel(const float2* __restrict__ A, const float2* __restrict__ B,
                                                             float2* __restrict__ C, int lm, int ln, int lk, BitPos pa,
-                                                            BitPos pb, int ksplit, long long kchunk) {
+                                                            BitPos pb, int ksplit, long long kchunk, OutPos po,
+                                                            int permuted) {
   __shared__ __attribute__((aligned(16))) float As_re[TCMI_CBK][TCMI_LDP], As_im[TCMI_CBK][TCMI_LDP];
   __shared__ __attribute__((aligned(16))) float Bs_re[TCMI_CBK][TCMI_LDP], Bs_im[TCMI_CBK][TCMI_LDP];
   const uint32_t M = 1u << lm, N = 1u << ln, K = 1u << lk;   // rank <= 31: every extent and element index fits 32 bits
@@ -521,15 +526,27 @@ __global__ __launch_bounds__(256, 5) void cgemm_bits_kernel(const float2* __rest
     }
   }
   const uint32_t col = n0 + wc * 32 + (lane & 31);
-  float2* const Cb = C + ((unsigned long long)(m0 + wr * 32 + 4 * (lane >> 5)) << ln) + col;
+  const uint32_t rbase = m0 + wr * 32 + 4 * (lane >> 5);
+  float2* Cb = C + ((unsigned long long)rbase << ln) + col;
+  // result stored with permuted axes (tcmi_tensordot_bits_ex): bit j of the natural index (row << ln | col) goes to
+  // address bit po.pos[j].  The 16 rows of a lane differ in row bits 0, 1, 3, 4 only (rbase has them clear), so the
+  // address is the deposit of (rbase, col) OR'ed with the deposits of those four bits.
+  uint32_t d0 = 1u << ln, d1 = 2u << ln, d3 = 8u << ln, d4 = 16u << ln;
+  if (permuted) {
+    Cb = C + (deposit_bits(col, po.pos, ln, 0) | deposit_bits(rbase, po.pos + ln, lm, 0));
+    d0 = lm > 0 ? 1u << po.pos[ln] : 0u;
+    d1 = lm > 1 ? 1u << po.pos[ln + 1] : 0u;
+    d3 = lm > 3 ? 1u << po.pos[ln + 3] : 0u;
+    d4 = lm > 4 ? 1u << po.pos[ln + 4] : 0u;
+  }
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) {
     const uint32_t dr = (reg & 3) + 8 * (reg >> 2);
-    if (m0 + wr * 32 + 4 * (lane >> 5) + dr < M && col < N) {
+    if (rbase + dr < M && col < N) {
       float2 o;
       o.x = p1[reg] - p2[reg];
       o.y = p3[reg] - p1[reg] - p2[reg];
-      float2* dst = Cb + ((unsigned long long)dr << ln);
+      float2* dst = Cb + (((reg & 1) ? d0 : 0u) | ((reg & 2) ? d1 : 0u) | ((reg & 4) ? d3 : 0u) | ((reg & 8) ? d4 : 0u));
       if (ksplit > 1) {
         atomicAdd(&dst->x, o.x);
         atomicAdd(&dst->y, o.y);
@@ -544,10 +561,6 @@ __global__ __launch_bounds__(256, 5) void cgemm_bits_kernel(const float2* __rest
 // axes): the gate-absorbs-gate steps at the bottom of a circuit network's tree, hundreds per contraction.  One thread per
 // output element, the k offsets of both operands tabulated in LDS once per workgroup; no tiles, no MFMA -- the 64 x 64
 // tile kernel spends more time depositing its tile origin than these steps have arithmetic.
-struct OutPos {
-  int pos[32];  // address bit (in C) of bit j of the natural output index (row bits above column bits); identity: j
-};
-
 // flags: 1 = conjugate A's elements, 2 = conjugate B's; po: the result is stored with its axes permuted (the two VJPs
 // of a tensordot are tensordot(g, conj b) and tensordot(conj a, g) followed by a transposition into the operand's own
 // axis order: fused here they are one launch instead of three, and the reverse sweep of a circuit network is
@@ -628,7 +641,7 @@ __global__ __launch_bounds__(256) void tensordot_small_batch_kernel(const int* _
 template <int MT, int NT>
 __global__ __launch_bounds__(256) void tensordot_bits_tiny_kernel(const float2* __restrict__ A, const float2* __restrict__ B,
                                                                   float2* __restrict__ C, int lm, int ln, int lk, BitPos pa,
-                                                                  BitPos pb) {
+                                                                  BitPos pb, OutPos po) {
   const int tid = threadIdx.x;
   const uint32_t K = 1u << lk;
   uint32_t ra[MT], cb[NT];
@@ -677,7 +690,9 @@ __global__ __launch_bounds__(256) void tensordot_bits_tiny_kernel(const float2* 
       }
     }
   __syncthreads();
-  if (tid < 2 * MT * NT) atomicAdd(reinterpret_cast<float*>(C) + tid, red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+  if (tid < 2 * MT * NT)   // (po: identity unless the result is stored with permuted axes)
+    atomicAdd(reinterpret_cast<float*>(C) + 2 * deposit_bits((uint32_t)tid >> 1, po.pos, lm + ln, 0) + (tid & 1),
+              red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
 }
 
 // complex128 GEMM on the f64 matrix pipe (v_mfma_f64_16x16x4_f64): 64x64 tile per workgroup, 4 waves x
@@ -1308,8 +1323,8 @@ int tcmi_tensordot_bits(const void* a, int rank_a, const void* b, int rank_b, co
 int tcmi_tensordot_bits_ex(const void* a, int rank_a, const void* b, int rank_b, const int* axes_a, const int* axes_b,
                            int nk, const int* out_axes, int flags, void* c, int dtype, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if ((out_axes || flags) && !tcmi_tensordot_bits_small_ok(rank_a, rank_b, nk))
-    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_tensordot_bits_ex: conjugation / output permutation only for the small-tensor kernel (tcmi_tensordot_bits_small_ok)");
+  if (flags && !tcmi_tensordot_bits_small_ok(rank_a, rank_b, nk))
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_tensordot_bits_ex: conjugation only for the small-tensor kernel (tcmi_tensordot_bits_small_ok)");
   if (!a || !b || !c) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_tensordot_bits: bad argument");
   if (dtype != TCMI_C64) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_tensordot_bits: complex64 only");
   // axis i of a [2]^rank tensor is address bit rank - 1 - i
@@ -1344,7 +1359,7 @@ int tcmi_tensordot_bits_ex(const void* a, int rank_a, const void* b, int rank_b,
   if (lm == MV && ln == NV)                                                                                             \
     hipLaunchKernelGGL((tcmi::tensordot_bits_tiny_kernel<(1 << MV), (1 << NV)>), grid, block, 0, st,                      \
                        reinterpret_cast<const float2*>(a), reinterpret_cast<const float2*>(b), reinterpret_cast<float2*>(c), \
-                       lm, ln, nk, pa, pb);
+                       lm, ln, nk, pa, pb, po);
     TCMI_TT(0, 0) TCMI_TT(0, 1) TCMI_TT(0, 2) TCMI_TT(0, 3) TCMI_TT(1, 0) TCMI_TT(1, 1) TCMI_TT(1, 2) TCMI_TT(1, 3)
     TCMI_TT(2, 0) TCMI_TT(2, 1) TCMI_TT(2, 2) TCMI_TT(2, 3) TCMI_TT(3, 0) TCMI_TT(3, 1) TCMI_TT(3, 2) TCMI_TT(3, 3)
 #undef TCMI_TT
@@ -1383,7 +1398,8 @@ int tcmi_tensordot_bits_ex(const void* a, int rank_a, const void* b, int rank_b,
 #define TCMI_TB(KA, KB)                                                                                               \
   if (ma == KA && mb == KB)                                                                                           \
     hipLaunchKernelGGL((tcmi::cgemm_bits_kernel<KA, KB>), grid, block, 0, st, reinterpret_cast<const float2*>(a),       \
-                       reinterpret_cast<const float2*>(b), reinterpret_cast<float2*>(c), lm, ln, nk, pa, pb, ksplit, kchunk);
+                       reinterpret_cast<const float2*>(b), reinterpret_cast<float2*>(c), lm, ln, nk, pa, pb, ksplit, kchunk, \
+                       po, out_axes ? 1 : 0);
   TCMI_TB(0, 0) TCMI_TB(0, 1) TCMI_TB(0, 2) TCMI_TB(1, 0) TCMI_TB(1, 1) TCMI_TB(1, 2) TCMI_TB(2, 0) TCMI_TB(2, 1) TCMI_TB(2, 2)
 #undef TCMI_TB
   hipError_t e = hipGetLastError();

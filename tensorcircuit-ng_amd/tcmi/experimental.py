@@ -209,7 +209,8 @@ class DistributedContractor:
         if self._fast_vjp(arrays):
             # reverse sweep over the step list on the untaped kernels (tn.contract_slices_vjp); the small gate tensors
             # stay on torch's tape, so their cotangents reach ``params`` through one autograd call
-            value, agrads = self.tree.contract_slices_vjp(arrays, self.my_slices, fop, alias_ok=True)
+            value, agrads = self.tree.contract_slices_vjp(arrays, self.my_slices, fop, alias_ok=True, hat_ok=True)
+            hat = bool(getattr(self.tree, "last_vjp_conjugated", False))   # the sweep handed over conj(g): undone per stack
             if value is None:
                 value = sum((x.sum() * 0 for x in leaves)).real.detach()
             pairs = [(a, g) for a, g in zip(arrays, agrads) if g is not None and a.requires_grad]
@@ -226,10 +227,12 @@ class DistributedContractor:
                         groups[id(b)][2].append(g.reshape(-1))
                     else:
                         outs.append(a)
-                        gouts.append(g)
+                        gouts.append(g.conj().resolve_conj() if hat else g)
                 for b, rows, gs in groups.values():
                     gb = torch.zeros_like(b)
-                    gb.index_add_(0, upload_cached(np.asarray(rows, dtype=np.int64), None, b.device), torch.stack(gs))
+                    st = torch.stack(gs)
+                    gb.index_add_(0, upload_cached(np.asarray(rows, dtype=np.int64), None, b.device),
+                                  st.conj().resolve_conj() if hat else st)
                     outs.append(b)
                     gouts.append(gb)
                 grads = torch.autograd.grad(outs, leaves, gouts, allow_unused=True)

@@ -1250,7 +1250,8 @@ class ContractionTree:
                 res = permute(res, final_perm)
             yield res
 
-    def contract_slices_vjp(self, arrays: Sequence[Any], slice_ids: Sequence[int], fop, need=None, alias_ok=False):
+    def contract_slices_vjp(self, arrays: Sequence[Any], slice_ids: Sequence[int], fop, need=None, alias_ok=False,
+                            hat_ok=False):
         """``sum_i fop(contract_core(slice_arrays(arrays, i)))`` and its gradient with respect to every array, by a
         reverse sweep over the step list instead of a framework tape (reference ``experimental.py:1182-1211``:
         ``value_and_grad`` of ``contract_core`` per slice, summed).  Every forward AND backward step is one launch of
@@ -1262,7 +1263,9 @@ class ContractionTree:
         ``need[k]`` = whether array k wants a gradient (default: ``requires_grad``).  Returns (value, grads) with
         ``grads[k]`` shaped like ``arrays[k]`` (or None).  ``alias_ok``: the gradients of the slice-invariant leaves
         may be views of the replayed graphs' static memory (valid until the next call on this tree) instead of clones
-        -- a caller that consumes them at once (``DistributedContractor.value_and_grad``) saves a thousand tiny copies."""
+        -- a caller that consumes them at once (``DistributedContractor.value_and_grad``) saves a thousand tiny copies.
+        ``hat_ok``: the graph path may return the CONJUGATES of the gradients (it sweeps conj(g), see ``_vjp_halves``) and
+        says so in ``self.last_vjp_conjugated``; the caller conjugates once, after stacking them."""
         import torch
 
         steps, dep, last, final_perm = self._symbolic_steps()
@@ -1274,8 +1277,9 @@ class ContractionTree:
         needs = {k: bool(need[k]) for k in range(n)}
         for ia, ib, xa, xb, io in steps:
             needs[io] = needs[ia] or needs[ib]
+        self.last_vjp_conjugated = False
         if slice_ids and needs[last] and _graph_ok(raw, len(steps), slice_ids):
-            return self._contract_slices_vjp_graph(raw, slice_ids, fop, need, needs, alias_ok)
+            return self._contract_slices_vjp_graph(raw, slice_ids, fop, need, needs, alias_ok, hat_ok)
         total = None
         grads: List[Any] = [None] * n
         ginv: Dict[int, Any] = {}
@@ -1348,7 +1352,7 @@ class ContractionTree:
                     grads[k] = ginv[k].reshape(raw[k].shape)
         return total, [g if need[k] else None for k, g in enumerate(grads)]
 
-    def _contract_slices_vjp_graph(self, raw, slice_ids, fop, need, needs, alias_ok=False):
+    def _contract_slices_vjp_graph(self, raw, slice_ids, fop, need, needs, alias_ok=False, hat_ok=False):
         """``contract_slices_vjp`` replayed from four HIP graphs (captured once per tree and operand signature): the
         slice-invariant forward steps, one slice forward, one slice backward, the invariant backward.  Between the
         slice graphs only ``fop`` and its derivative run eagerly, on the small result.  A 30-qubit depth-8 ladder is
@@ -1413,13 +1417,15 @@ class ContractionTree:
 
                     def backward_level(level, src, gsrc, route, B):
                         """VJP halves of the steps of one level: ``gsrc`` pops the cotangent of a step's result (None:
-                        not needed), ``route(t, g)`` receives the cotangent of operand t."""
+                        not needed), ``route(t, g)`` receives the cotangent of operand t.  All cotangents of the graphs
+                        are CONJUGATED (``_vjp_halves(hat=True)``): no step conjugates an operand."""
                         later, done = [], []
                         for ia, ib, xa, xb, io in level:
                             gio = gsrc(io)
                             if gio is None:
                                 continue
-                            for which, x, y, ax, ay, perm, fl in _vjp_halves(src(ia), src(ib), xa, xb, gio, needs[ia], needs[ib]):
+                            for which, x, y, ax, ay, perm, fl in _vjp_halves(src(ia), src(ib), xa, xb, gio, needs[ia],
+                                                                             needs[ib], hat=True):
                                 t_ = ib if which else ia
                                 if B is not None and B.ok(x, y, len(ax)):
                                     done.append((t_, B.add(x, y, ax, ay, perm, fl)))
@@ -1443,22 +1449,27 @@ class ContractionTree:
                         return _permute_raw(res, final_perm) if final_perm is not None else res
 
                     def bwd_slice(shared, cur, g_in, gacc, B=None):
-                        g0 = _permute_raw(g_in, inv_perm) if inv_perm is not None else g_in
+                        g0 = _conj(_permute_raw(g_in, inv_perm) if inv_perm is not None else g_in)   # the sweep carries conj(g)
                         gbar = {}
                         if dep[last]:
                             gbar[last] = g0
                         else:
                             gacc[last].add_(g0.reshape(gacc[last].shape))
 
+                        acc_to, acc_from = [], []
+
                         def route(t_, g_):
                             if dep[t_]:
                                 gbar[t_] = g_
-                            else:
-                                gacc[t_].add_(g_.reshape(gacc[t_].shape))
+                            else:       # every invariant tensor is consumed by ONE step: one contribution per slice
+                                acc_to.append(gacc[t_])
+                                acc_from.append(g_.reshape(gacc[t_].shape))
 
                         for level in reversed(dep_order):
                             backward_level(level, lambda t: cur[t] if dep[t] else shared[t],
                                            lambda io: gbar.pop(io, None), route, B)
+                        if acc_to:      # one multi-tensor add instead of ~50 launches per slice
+                            torch._foreach_add_(acc_to, acc_from)
                         return {k: gbar[k] for k in range(n) if dep[k] and k in gbar}
 
                     def bwd_inv(shared, gacc, B=None):
@@ -1552,6 +1563,11 @@ class ContractionTree:
             cache["g_d"].replay()
             for k, gl in cache["ginv_leaf"].items():
                 grads[k] = gl.reshape(raw[k].shape) if alias_ok else gl.reshape(raw[k].shape).clone()
+            # the graphs deliver conj(g)
+            if hat_ok:
+                self.last_vjp_conjugated = True
+            else:
+                grads = [g_.conj().resolve_conj() if g_ is not None else None for g_ in grads]
         return total, [g if need[k] else None for k, g in enumerate(grads)]
 
     def invariant_shards(self, world: int):
@@ -1965,20 +1981,24 @@ def _conj(t):
     return t.conj().resolve_conj()
 
 
-def _vjp_halves(a, b, axes_a, axes_b, g, need_a=True, need_b=True):
+def _vjp_halves(a, b, axes_a, axes_b, g, need_a=True, need_b=True, hat=False):
     """The VJPs of ``tensordot(a, b)`` as jobs ``(which, x, y, axes_x, axes_y, out_perm, flags)``: which = 0 / 1 for gA /
-    gB, the job = permute(tensordot(conj?(x), conj?(y)), out_perm) with flags 1 / 2 = conjugate x / y."""
+    gB, the job = permute(tensordot(conj?(x), conj?(y)), out_perm) with flags 1 / 2 = conjugate x / y.
+    ``hat``: ``g`` is the CONJUGATED cotangent and so are the results -- conj(gA) = conj(g) . b and conj(gB) = a . conj(g)
+    are plain tensordots, so a sweep that carries conj(g) from the result down to the leaves conjugates nothing on the
+    way (flags 0; the caller conjugates once at either end)."""
     fa, fb, perm_a, perm_b = _vjp_axes(a.dim(), b.dim(), axes_a, axes_b)
     jobs = []
     if need_a:
-        jobs.append((0, g, b, list(range(len(fa), len(fa) + len(fb))), fb, perm_a, 2))
+        jobs.append((0, g, b, list(range(len(fa), len(fa) + len(fb))), fb, perm_a, 0 if hat else 2))
     if need_b:
-        jobs.append((1, a, g, fa, list(range(len(fa))), perm_b, 1))
+        jobs.append((1, a, g, fa, list(range(len(fa))), perm_b, 0 if hat else 1))
     return jobs
 
 
 def _vjp_half_run(x, y, ax, ay, perm, flags):
-    """One such job on its own: the fused launch for gate-sized operands, else conjugate + tensordot + permute."""
+    """One such job on its own: the fused launch (gate-sized operands: conjugation and transposition; tile kernel:
+    transposition, for flags == 0), else conjugate + tensordot (scattered big x small kernel included) + permute."""
     r = _tensordot_fused(x, y, ax, ay, perm, flags)
     if r is None:
         r = _tensordot_raw(_conj(x) if flags & 1 else x, _conj(y) if flags & 2 else y, ax, ay)
@@ -2091,7 +2111,20 @@ def _tensordot_fused(a, b, axes_a, axes_b, out_perm, flags):
         return None
     L = _lib.lib()
     if not L.tcmi_tensordot_bits_small_ok(a.dim(), b.dim(), nk):
-        return None
+        # bigger operands: the tile kernel stores through the permutation but does not conjugate, and the streaming
+        # big x small kernel keeps the steps it is good at (their transposition stays a launch of its own)
+        rc_ = a.dim() + b.dim() - 2 * nk
+        if flags or a.dim() > 31 or b.dim() > 31 or list(out_perm) == list(range(rc_)):
+            return None
+        # a transposed store is 8-byte scattered unless the three fastest axes stay in place (64-byte runs): worth it
+        # while the launch it saves costs more than the store (2.15 vs 1.70 ms per slice backward when rank-19..21
+        # results were stored that way)
+        if rc_ > FUSED_PERM_MAX_RANK and list(out_perm[-3:]) != list(range(rc_ - 3, rc_)):
+            return None
+        fa_ = [i for i in range(a.dim()) if i not in axes_a]
+        fb_ = [i for i in range(b.dim()) if i not in axes_b]
+        if _scattered_ok(a, b, nk, fa_, fb_):
+            return None
     a, b = a.contiguous(), b.contiguous()
     rc = a.dim() + b.dim() - 2 * nk
     out = torch.empty([2] * rc, dtype=a.dtype, device=a.device)
@@ -2276,8 +2309,29 @@ TN_STREAMS = int(os.environ.get("TCMI_TN_STREAMS", "2"))   # two slices of a sli
 SCATTERED_MIN_RANK = 16    # big operand: at least 2^16 elements
 SCATTERED_MAX_SMALL = 4096  # small operand: at most this many elements (it lives in LDS)
 SCATTERED_MAX_NK = int(os.environ.get("TCMI_TN_SCAT_MAXK", "8"))   # more contracted axes: the MFMA bits kernel
+FUSED_PERM_MAX_RANK = int(os.environ.get("TCMI_TN_FUSED_PERM_RANK", "0"))   # tile kernel: transposed stores up to this result rank (measured: no gain over the permute launch, 1.71-1.75 vs 1.70 ms per slice backward at 12-14; worse above)
 SCATTERED_MIN_FREE = int(os.environ.get("TCMI_TN_SCAT_MINFREE", "14"))   # at least 2^14 threads (free indices of the big operand)
 SCATTERED_MAX_OUT = int(os.environ.get("TCMI_TN_SCAT_MAXOUT", "32"))     # at most this many outputs per thread
+
+
+def _scattered_ok(a, b, nk, fa, fb) -> bool:
+    """Whether ``_tensordot_scattered`` takes the step."""
+    if nk < 1 or nk > SCATTERED_MAX_NK:
+        return False
+    big_first = a.numel() >= b.numel()
+    big, small = (a, b) if big_first else (b, a)
+    if big.dim() < SCATTERED_MIN_RANK or small.numel() > SCATTERED_MAX_SMALL or small.numel() < (1 << nk):
+        return False
+    if nk > 5 and (small.numel() >> nk) > 16:
+        return False
+    # one thread per free index of the big operand, n outputs each: it needs many threads with little to do each.
+    # (The reverse sweep of a sliced network has steps like rank 16 x rank 12 over 8 axes -- 256 threads -- or rank 17
+    # x rank 12 over 5 -- 128 outputs per thread: 100 us here, 20 us on the split-K tile kernel.)
+    if big.dim() - nk < SCATTERED_MIN_FREE or (small.numel() >> nk) > SCATTERED_MAX_OUT:
+        return False
+    if any(d != 2 for d in big.shape) or any(d != 2 for d in small.shape):
+        return False
+    return True
 
 
 def _tensordot_scattered(a, b, axes_a, axes_b, fa, fb):
@@ -2287,21 +2341,10 @@ def _tensordot_scattered(a, b, axes_a, axes_b, fa, fb):
     import torch
 
     nk = len(axes_a)
-    if nk < 1 or nk > SCATTERED_MAX_NK:
+    if not _scattered_ok(a, b, nk, fa, fb):
         return None
     big_first = a.numel() >= b.numel()
     big, small = (a, b) if big_first else (b, a)
-    if big.dim() < SCATTERED_MIN_RANK or small.numel() > SCATTERED_MAX_SMALL or small.numel() < (1 << nk):
-        return None
-    if nk > 5 and (small.numel() >> nk) > 16:
-        return None
-    # one thread per free index of the big operand, n outputs each: it needs many threads with little to do each.
-    # (The reverse sweep of a sliced network has steps like rank 16 x rank 12 over 8 axes -- 256 threads -- or rank 17
-    # x rank 12 over 5 -- 128 outputs per thread: 100 us here, 20 us on the split-K tile kernel.)
-    if big.dim() - nk < SCATTERED_MIN_FREE or (small.numel() >> nk) > SCATTERED_MAX_OUT:
-        return None
-    if any(d != 2 for d in big.shape) or any(d != 2 for d in small.shape):
-        return None
     ax_big, ax_small = (axes_a, axes_b) if big_first else (axes_b, axes_a)
     f_small = fb if big_first else fa
     pairs = sorted(zip(ax_big, ax_small))                      # ascending big axis = descending bit position

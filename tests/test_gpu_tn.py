@@ -475,6 +475,21 @@ def test_fused_reverse_mode_steps_match_torch_autograd(monkeypatch):
             assert float((got.to(torch.complex128) - ref).abs().max()) / scale < 3e-5, (ra, rb, nk)
             assert float((got - plain).abs().max()) / scale < 3e-5
     monkeypatch.setenv("TCMI_TN_FUSED_VJP", "1")
+    # the tile kernels store through the permutation too (no conjugation there): plain tiles, split-K with atomics,
+    # the register-accumulator kernel for <= 8 x 8 results, rows / columns narrower than a tile
+    for ra, rb, nk in [(14, 6, 3), (16, 16, 12), (13, 13, 11), (15, 5, 2), (10, 15, 4), (17, 14, 13)]:
+        xa = [int(x) for x in rng.permutation(ra)[:nk]]
+        xb = [int(x) for x in rng.permutation(rb)[:nk]]
+        rc = ra + rb - 2 * nk
+        perm = [int(x) for x in rng.permutation(rc)]
+        a = torch.randn([2] * ra, dtype=torch.complex64, device="cuda", generator=g_)
+        b = torch.randn([2] * rb, dtype=torch.complex64, device="cuda", generator=g_)
+        monkeypatch.setattr(tn, "FUSED_PERM_MAX_RANK", 31)
+        got = tn._tensordot_fused(a, b, xa, xb, perm, 0)
+        assert got is not None
+        ref = np.tensordot(a.cpu().numpy().astype(np.complex128), b.cpu().numpy().astype(np.complex128),
+                           axes=(xa, xb)).transpose(perm)
+        assert float(np.abs(got.cpu().numpy() - ref).max()) / float(np.abs(ref).max()) < 3e-5, (ra, rb, nk)
     assert _lib.lib().tcmi_tensordot_bits_small_ok(12, 4, 4) == 1 and _lib.lib().tcmi_tensordot_bits_small_ok(14, 4, 2) == 0
     big = torch.zeros([2] * 14, dtype=torch.complex64, device="cuda")
     ax = (ctypes.c_int * 2)(0, 1)
