@@ -354,6 +354,39 @@ def mps_leg(tc, torch, args):
         chains = {"chains": C, "api": "backend.vmap over chains (one batched GEMM / QR / SVD launch per bond)",
                   "chain_sweeps_per_s": C / tb, "us_per_bond_per_chain": tb / (n - 1) / C * 1e6,
                   "us_per_bond_all_chains": tb / (n - 1) * 1e6, "last_tensor_norm2": [float(x) for x in nrm[:4]]}
+    # Graded spectra: the bond matrices of random circuits are flat, those of ground-state searches are not.  One
+    # (2 chi) x (2 chi) matrix with singular values spread over six decades through the plain one-sided Jacobi and
+    # through the QR-preconditioned path (linalg.SVD_PRECONDITION): sweeps and milliseconds by HIP events.
+    graded = None
+    try:
+        from tcmi import linalg as LA
+
+        def haar(k, seed):
+            z = np.random.default_rng(seed).normal(size=(k, k, 2)) @ np.array([1.0, 1j])
+            qh, rh = np.linalg.qr(z)
+            return qh * (np.diag(rh) / np.abs(np.diag(rh)))
+
+        md = 2 * chi
+        ag = torch.from_numpy(((haar(md, 1) * np.logspace(0, -6, md)) @ haar(md, 2)).astype(np.complex64)).cuda()
+        graded = {"matrix": f"{md} x {md} complex64, singular values 1 .. 1e-6 (log-spaced)"}
+        keep_flag = LA.SVD_PRECONDITION
+        for name, pre in (("plain", False), ("qr_preconditioned", True)):
+            LA.SVD_PRECONDITION = pre
+            LA.svd_trunc(ag, max_singular_values=chi, absorb=1)
+            torch.cuda.synchronize()
+            ev = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                ug, sg, vg, _rest = LA.svd_trunc(ag, max_singular_values=chi, absorb=1)
+                e1.record()
+                torch.cuda.synchronize()
+                ev.append(e0.elapsed_time(e1))
+            graded[name] = {"ms": float(np.median(ev)), "sweeps": int(LA.last_svd_sweeps(ag.device)),
+                            "sigma_max": float(sg.real.max())}
+        LA.SVD_PRECONDITION = keep_flag
+    except Exception as e:  # noqa: BLE001 - an auxiliary figure must not take the leg down
+        graded = {"error": repr(e)}
     return {
         "workload": f"MPSCircuit n={n} chi={chi} TEBD sweep of {n - 1} adjacent random SU(4) gates, complex64 "
                     f"(SURVEY 8d config 5)",
@@ -363,6 +396,7 @@ def mps_leg(tc, torch, args):
         # neither HBM- nor MFMA-bound: latency of dependent launches; kernel time per bond by kind
         "roofline": {"bound": "latency", "kernel_us_per_bond": split},
         "batched_chains": chains,
+        "graded": graded,
     }
 
 

@@ -6,6 +6,7 @@ C-ABI entry points ``tcmi_cgemm``, ``tcmi_svd_trunc_batched``, ``tcmi_qr_batched
 ``torch.linalg`` — without ``libtcmi.so`` every function raises ``TcmiError``.
 """
 
+import os
 from typing import Any, Dict, Optional, Tuple
 
 from . import _lib
@@ -211,6 +212,69 @@ def svd_health_check(device=None) -> None:
                              "the factors of that decomposition are invalid")
 
 
+# QR-preconditioned Jacobi (Drmac / Veselic): ``SVD_PRECONDITION = True`` (or TCMI_SVD_PRECOND=1) sends every
+# ``svd_trunc`` of an untaped complex matrix through ``A^H = Q R`` first.  Plain one-sided Jacobi needs more sweeps the
+# more the spectrum is graded (256 x 256 complex64: 11 / 13 / 19 / 27 sweeps of 0.275 ms for spectra graded over 1 / 2 /
+# 4 / 6 decades); on the triangular factor it needs 10 whatever the grading.  The QR (two register-resident panels +
+# GEMMs) costs ~2 ms, so the switch pays from about 3.5 decades on and is off by default: the bond matrices of random
+# circuits have flat spectra (scripts/gpu_svd_precond.py, bench ``mps_tebd.graded``).
+SVD_PRECONDITION = os.environ.get("TCMI_SVD_PRECOND", "0") == "1"
+
+
+def last_svd_sweeps(device=None) -> int:
+    """Sweeps the most recent SVD launch on ``device`` needed (synchronises; tests and the bench's graded leg)."""
+    import torch
+
+    w = _WORK.get(("svd", _devkey(device)))
+    if w is None:
+        return 0
+    ctl = w[:256].view(torch.int32).cpu().numpy()
+    return int((ctl[2:62] > 0).sum()) + 1
+
+
+def qr_two_panels(mat):
+    """QR of a tall or square [m, n] matrix with 128 < n <= 256 <= ... as two panels the register-resident kernel takes
+    (n <= 128 each): block Gram-Schmidt with one re-orthogonalisation of the second panel against the first ("twice is
+    enough").  Returns (q [m, n], r [n, n]) with q^H q = 1 to working precision."""
+    import torch
+
+    m, n = mat.shape
+    h = n // 2
+    a1, a2 = mat[:, :h].contiguous(), mat[:, h:].contiguous()
+    q1, r11 = _qr_raw(a1)
+    q1h = q1.conj().t().contiguous()
+    r12 = _matmul_raw(q1h, a2)
+    w = a2 - _matmul_raw(q1, r12)
+    c = _matmul_raw(q1h, w)
+    w = w - _matmul_raw(q1, c)
+    r12 = r12 + c
+    q2, r22 = _qr_raw(w.contiguous())
+    # columns of w below the working precision are completed to an isometry arbitrarily -- not orthogonally to q1
+    # (|q1^H q2| = 4e-5 for a spectrum graded over six decades): project once more and move the component into r12
+    # (q2 stays orthonormal to the square of that number)
+    c2 = _matmul_raw(q1h, q2)
+    q2 = q2 - _matmul_raw(q1, c2)
+    r12 = r12 + _matmul_raw(c2, r22)
+    q = torch.cat([q1, q2], dim=1)
+    r = torch.zeros(n, n, dtype=mat.dtype, device=mat.device)
+    r[:h, :h] = r11
+    r[:h, h:] = r12
+    r[h:, h:] = r22
+    return q, r
+
+
+def _svd_preconditioned(mat, static_keep, max_singular_values, max_truncation_err, relative, absorb):
+    """m <= n: ``mat^H = Q R`` (Q [n, m], R [m, m]), Jacobi on R = U_R S V_R^h, then mat = R^H Q^H = V_R S (Q U_R)^H."""
+    m, n = mat.shape
+    ah = mat.conj().t().contiguous()
+    q, r = qr_two_panels(ah) if m > 128 else _qr_raw(ah)
+    sw = {0: 0, 1: 2, 2: 1}[absorb]          # U_A S = (S V_R^h)^H, S Vh_A = (Q U_R S)^H
+    ur, s, vhr, keep, tw2 = _svd_rows(r, static_keep, max_singular_values, max_truncation_err, relative, sw)
+    u = vhr.conj().t().contiguous()
+    vh = _matmul_raw(q, ur).conj().t().contiguous()
+    return u, s, vh, keep, tw2
+
+
 def svd_trunc(mat, max_singular_values: Optional[int] = None, max_truncation_err: Optional[float] = None,
               relative: bool = False, absorb: int = 0) -> Tuple[Any, Any, Any, Any]:
     """``backend.svd(mat, pivot_axis=1, ...)`` with the reference truncation rule.  Returns
@@ -224,7 +288,14 @@ def svd_trunc(mat, max_singular_values: Optional[int] = None, max_truncation_err
     if _tracked(mat):
         return _svd_trunc_ad(mat, static_keep, max_truncation_err, relative, absorb)
     _SVD_PENDING[_devkey(mat.device)] = True
-    if m <= n:
+    if SVD_PRECONDITION and mat.dim() == 2 and str(mat.dtype) == "torch.complex64" and 16 <= min(m, n) and max(m, n) <= 256:
+        if m <= n:
+            u, s, vh, keep, tw2 = _svd_preconditioned(mat, static_keep, max_singular_values, max_truncation_err, relative, absorb)
+        else:
+            sw = {0: 0, 1: 2, 2: 1}[absorb]
+            u2, s, vh2, keep, tw2 = _svd_preconditioned(mat.t(), static_keep, max_singular_values, max_truncation_err, relative, sw)
+            u, vh = vh2.t().contiguous(), u2.t().contiguous()
+    elif m <= n:
         u, s, vh, keep, tw2 = _svd_rows(mat, static_keep, max_singular_values, max_truncation_err, relative, absorb)
     else:
         # mat^T = U' S V'h  ->  mat = V'h^T S U'^T

@@ -364,3 +364,56 @@ def test_svd_qr_fuzz_shapes_scales_and_ranks():
         np.testing.assert_allclose(qn @ rn, a, atol=tol, err_msg=f"qr {m}x{n} {dt}")
         k = min(m, n)
         np.testing.assert_allclose(qn.conj().T @ qn, np.eye(k), atol=5e-5 if dt == "complex64" else 1e-11)
+
+
+def test_qr_preconditioned_jacobi_needs_ten_sweeps_whatever_the_grading(monkeypatch):
+    """linalg.SVD_PRECONDITION: A^H = Q R (two register-resident panels, block Gram-Schmidt with re-orthogonalisation),
+    Jacobi on R, factors mapped back.  On a 256 x 256 complex64 matrix with a spectrum graded over six decades the plain
+    kernel needs > 20 sweeps, the preconditioned one <= 12; both reconstruct the matrix, give orthonormal factors and
+    the singular values of LAPACK; the truncated / absorbed forms agree with the plain path."""
+    import torch
+    import tcmi as tc
+    from tcmi import linalg as LA
+
+    tc.set_backend("hip")
+    tc.set_dtype("complex64")
+    rng = np.random.default_rng(3)
+
+    def haar(k):
+        z = rng.normal(size=(k, k)) + 1j * rng.normal(size=(k, k))
+        q, r = np.linalg.qr(z)
+        return q * (np.diag(r) / abs(np.diag(r)))
+
+    m = 256
+    a_np = ((haar(m) * np.logspace(0, -6, m)) @ haar(m)).astype(np.complex64)
+    a = torch.from_numpy(a_np).cuda()
+    ref = np.linalg.svd(a_np.astype(np.complex128), compute_uv=False)
+    eye = torch.eye(m, device="cuda")
+    sweeps = {}
+    for pre in (False, True):
+        monkeypatch.setattr(LA, "SVD_PRECONDITION", pre)
+        u, s, vh, _ = LA.svd_trunc(a, max_singular_values=m)
+        sweeps[pre] = LA.last_svd_sweeps(a.device)
+        sr = s.real.cpu().numpy()
+        assert float(((u * s.reshape(1, -1)) @ vh - a).abs().max()) < 2e-5
+        assert float((u.conj().t() @ u - eye).abs().max()) < 2e-5 and float((vh @ vh.conj().t() - eye).abs().max()) < 2e-5
+        assert np.abs(sr - ref).max() < 1e-5 * ref[0]
+        if pre:      # the small singular values keep their RELATIVE accuracy down to eps * sigma_max
+            big = ref > 1e-4
+            assert np.abs(sr[big] / ref[big] - 1).max() < 1e-3
+    assert sweeps[False] > 20 and sweeps[True] <= 12, sweeps
+    # truncation + absorption (what one TEBD bond update asks for), rectangular both ways
+    for shape, absorb in (((256, 256), 1), ((128, 256), 2), ((256, 128), 1), ((64, 200), 0)):
+        b = torch.from_numpy((rng.normal(size=shape) + 1j * rng.normal(size=shape)).astype(np.complex64)).cuda()
+        k = min(shape) // 2
+        monkeypatch.setattr(LA, "SVD_PRECONDITION", False)
+        u0, s0, vh0, r0 = LA.svd_trunc(b, max_singular_values=k, absorb=absorb)
+        monkeypatch.setattr(LA, "SVD_PRECONDITION", True)
+        u1, s1, vh1, r1 = LA.svd_trunc(b, max_singular_values=k, absorb=absorb)
+        assert u1.shape == u0.shape and vh1.shape == vh0.shape and s1.shape == s0.shape
+        assert float((s1 - s0).abs().max()) < 1e-4 * float(s0.abs().max())
+        p0 = u0 @ vh0 if absorb else (u0 * s0.reshape(1, -1)) @ vh0
+        p1 = u1 @ vh1 if absorb else (u1 * s1.reshape(1, -1)) @ vh1
+        assert float((p1 - p0).abs().max()) < 1e-4 * float(p0.abs().max())
+        assert abs(float(r1._tcmi_tw2[0]) - float(r0._tcmi_tw2[0])) < 1e-4 * max(1.0, float(r0._tcmi_tw2[0]))
+
