@@ -1503,7 +1503,7 @@ class ContractionTree:
                     shared = dict(st_inv)
                     B = None
                     if os.environ.get("TCMI_TN_BATCH", "1") != "0" and all(t.dtype == torch.complex64 for t in raw):
-                        B = SmallBatch(raw[0].device, 3 * len(steps) + 16)
+                        B = SmallBatch(raw[0].device, 6 * len(steps) + 16)
                     g_a = None
                     if any(not dep[st[4]] for st in steps):
                         g_a = torch.cuda.CUDAGraph()
@@ -1523,13 +1523,31 @@ class ContractionTree:
                     g_d = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g_d, pool=pool):
                         ginv_leaf = bwd_inv(shared, gacc, B)
+                    # a second instance of the two per-slice graphs (own leaf copies, intermediates, cotangent
+                    # accumulators and memory pool) for a second stream: a slice's sweep is a chain of launches most of
+                    # which cannot fill the chip (41 tile-kernel steps of ~30 us per slice backward), two slices side by
+                    # side overlap them -- as contract_slices does for the forward-only replay
+                    two = None
+                    if TN_STREAMS >= 2 and len(slice_ids) >= 2:
+                        st_dep2 = {k: v.clone() for k, v in st_dep.items()}
+                        cur2 = dict(st_dep2)
+                        gacc2 = {t: torch.zeros_like(v) for t, v in gacc.items()}
+                        g_b2 = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g_b2):
+                            res2 = fwd_slice(shared, cur2, B)
+                        g_in2 = torch.zeros_like(res2)
+                        g_c2 = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g_c2, pool=g_b2.pool()):
+                            gleaf2 = bwd_slice(shared, cur2, g_in2, gacc2, B)
+                        two = {"st_dep": st_dep2, "cur": cur2, "gacc": gacc2, "g_b": g_b2, "res": res2, "g_in": g_in2,
+                               "g_c": g_c2, "gleaf": gleaf2, "side": torch.cuda.Stream(device=raw[0].device)}
                     if B is not None:
                         B.finish()     # the descriptor table the captured launches read: uploaded before any replay
             finally:
                 COUNTERS = keep_counters
             cache = {"sig": sig, "st_inv": st_inv, "st_dep": st_dep, "shared": shared, "cur": cur, "res": res,
                      "g_in": g_in, "gacc": gacc, "gleaf": gleaf, "ginv_leaf": ginv_leaf, "g_a": g_a, "g_b": g_b,
-                     "g_c": g_c, "g_d": g_d, "batch": B}
+                     "g_c": g_c, "g_d": g_d, "batch": B, "two": two}
             self._vjp_graph_cache = cache
         with torch.no_grad():
             inv_k = list(cache["st_inv"])
@@ -1542,24 +1560,50 @@ class ContractionTree:
             grads: List[Any] = [None] * n
             total = None
             touched = sorted(set(cache["st_dep"]) | set(cache["gleaf"]))   # the leaves that carry a sliced index
-            for i in slice_ids:
+            for k in cache["gleaf"]:
+                if need[k]:
+                    grads[k] = torch.zeros_like(raw[k])
+            two = cache.get("two")
+            if two is not None and two["gacc"]:
+                torch._foreach_zero_(list(two["gacc"].values()))
+
+            def one_slice(i, inst):
+                """Forward, op and its derivative, backward of slice i on the graphs of ``inst``; returns op's value.
+                (Different slices write different blocks of a sliced leaf's gradient: no two streams meet there.)"""
                 vals = self.slice_index_values(i)
                 idx = {k: tuple(vals[e] if e in vals else slice(None) for e in self.inputs[k]) for k in touched}
-                for k, buf in cache["st_dep"].items():
+                for k, buf in inst["st_dep"].items():
                     buf.copy_(raw[k][idx[k]])
-                cache["g_b"].replay()
+                inst["g_b"].replay()
                 with torch.enable_grad():
-                    r_ = cache["res"].detach().clone().requires_grad_(True)
+                    r_ = inst["res"].detach().clone().requires_grad_(True)
                     v = fop(r_)
                     (g,) = torch.autograd.grad(v, r_)
-                total = v.detach() if total is None else total + v.detach()
-                cache["g_in"].copy_(g)
-                cache["g_c"].replay()
-                for k, gl in cache["gleaf"].items():
+                inst["g_in"].copy_(g)
+                inst["g_c"].replay()
+                for k, gl in inst["gleaf"].items():
                     if need[k]:
-                        if grads[k] is None:
-                            grads[k] = torch.zeros_like(raw[k])
                         grads[k][idx[k]] += gl
+                return v.detach()
+
+            ids = list(slice_ids)
+            cur_s = torch.cuda.current_stream(raw[0].device) if two is not None else None
+            j = 0
+            while j < len(ids):
+                v2 = None
+                if two is not None and j + 1 < len(ids):      # the partner slice goes out first, on the second stream
+                    two["side"].wait_stream(cur_s)
+                    with torch.cuda.stream(two["side"]):
+                        v2 = one_slice(ids[j + 1], two)
+                v = one_slice(ids[j], cache)
+                total = v if total is None else total + v
+                if v2 is not None:
+                    cur_s.wait_stream(two["side"])
+                    total = total + v2
+                j += 1 if v2 is None else 2
+            if two is not None and two["gacc"]:
+                keys = list(cache["gacc"])
+                torch._foreach_add_([cache["gacc"][t] for t in keys], [two["gacc"][t] for t in keys])
             cache["g_d"].replay()
             for k, gl in cache["ginv_leaf"].items():
                 grads[k] = gl.reshape(raw[k].shape) if alias_ok else gl.reshape(raw[k].shape).clone()
