@@ -130,6 +130,19 @@ def _split_truncate(m, split_conf):
 _CONST_CACHE: "OrderedDict[int, tuple]" = OrderedDict()
 _CONST_CACHE_MAX = 4096
 
+class NodeTrace:
+    """What ``Circuit._gate_stacks`` / ``_tn_nodes`` did while a node function ran, recorded so that the same gate
+    tensors can be recomputed from new parameter values without running the Python function again
+    (``experimental.DistributedContractor``: the reference jits its node function, this is the host-side counterpart).
+    ``stacks[sid]`` = ("const", tensor) | ("trig", constants [G, 3, size], affine [G, 2], gather offsets, base tensor)
+    | ("opaque",); every node tensor cut out of a stack carries ``_tcmi_src = (sid, row, conjugated)``."""
+
+    def __init__(self):
+        self.stacks: List[tuple] = []
+
+
+NODE_TRACE: Optional[NodeTrace] = None     # set by DistributedContractor around the node function
+
 _UPLOAD_CACHE: "OrderedDict[tuple, Any]" = OrderedDict()
 _UPLOAD_CACHE_MAX = 256
 
@@ -159,6 +172,14 @@ def upload_cached(arr, dtype=None, device=None):
     if len(_UPLOAD_CACHE) > _UPLOAD_CACHE_MAX:
         _UPLOAD_CACHE.popitem(last=False)
     return t
+
+
+def trig_stack(cdev, aff, angles):
+    """[G, size] gate tensors ``C0 + cos(a) C1 + sin(a) C2`` of one parametrised family, a = scale * angle + offset."""
+    import torch
+
+    a = angles * aff[:, 0] + aff[:, 1]
+    return cdev[:, 0] + torch.cos(a)[:, None] * cdev[:, 1] + torch.sin(a)[:, None] * cdev[:, 2]
 
 
 def _constant_value(t, what):
@@ -855,6 +876,10 @@ class Circuit:
                 par_size.setdefault(int(np.asarray(op.spec.c0).size), []).append(i)
         for size, idxs in by_size.items():
             stack = upload_cached(np.stack([np.asarray(self._ops[i].matrix).reshape(-1) for i in idxs]), dt, dev)
+            if NODE_TRACE is not None:
+                NODE_TRACE.stacks.append(("const", stack))
+                out.append((idxs, stack, len(NODE_TRACE.stacks) - 1))
+                continue
             out.append((idxs, stack))
         for size, idxs in par_size.items():
             specs = [self._ops[i].spec for i in idxs]
@@ -874,15 +899,21 @@ class Circuit:
                 # the usual case -- every angle is an element ``params[j, i, k]`` of ONE tensor: a single gather (and a
                 # single index_add in the backward) instead of a stack of hundreds of views with a node each
                 offs = np.array([t.storage_offset() - base.storage_offset() for t in ths], dtype=np.int64)
-                angles = base.reshape(-1)[upload_cached(offs, None, dev)]
+                offs_dev = upload_cached(offs, None, dev)
+                angles = base.reshape(-1)[offs_dev]
+                rec = ("trig", cdev, aff, offs_dev, base)
             else:
                 angles = torch.stack([(t.real if t.is_complex() else t).to(device=dev, dtype=rdt).reshape(()) for t in ths])
-            a = angles * aff[:, 0] + aff[:, 1]
-            m = cdev[:, 0] + torch.cos(a)[:, None] * cdev[:, 1] + torch.sin(a)[:, None] * cdev[:, 2]    # [G, size]
+                rec = ("opaque",)
+            m = trig_stack(cdev, aff, angles)
+            if NODE_TRACE is not None:
+                NODE_TRACE.stacks.append(rec)
+                out.append((idxs, m, len(NODE_TRACE.stacks) - 1))
+                continue
             out.append((idxs, m))
         return out
 
-    def _tn_nodes(self, conj: bool = False, stacks=None):
+    def _tn_nodes(self, conj: bool = False, stacks=None):  # noqa: C901
         """The circuit as a node list (reference ``BaseCircuit._copy``, basecircuit.py:150-181):
         n rank-1 |0> nodes (or one input node) followed by one node per gate, wired
         ``gate[i+k] ^ front[q_i]; front[q_i] = gate[i]`` (basecircuit.py:288-290).  Returns
@@ -910,14 +941,20 @@ class Circuit:
         if stacks is None:
             stacks = self._gate_stacks()
         tensors: Dict[int, Any] = {}
-        for idxs, st in stacks:
+        srcs: Dict[int, tuple] = {}
+        for ent in stacks:
+            idxs, st = ent[0], ent[1]
             st = st.conj().resolve_conj() if conj else st        # one conjugation per stack, not per gate
             for r, i in enumerate(idxs):
                 tensors[i] = st[r]
+                if len(ent) > 2:
+                    srcs[i] = (ent[2], r, conj)
         for i, op in enumerate(self._ops):
             k = len(op.qubits)
             m = tensors[i]
             t = m.reshape([2] * (2 * k))
+            if i in srcs:
+                t._tcmi_src = srcs[i]
             out_e = [tn.new_edge() for _ in range(k)]
             # gate identity + side for the light-cone cancellation (tcmi/simplify.py); trigonometric gate families
             # are unitary by construction, constants are checked

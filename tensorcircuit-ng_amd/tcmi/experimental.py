@@ -157,8 +157,104 @@ class DistributedContractor:
 
     # ---- evaluation -----------------------------------------------------------------------------------
     def _arrays(self, params):
-        nodes = self.nodes_fn(params)
-        return [n.tensor for n in nodes]
+        """The leaf tensors of the network for ``params``.  The node function is TRACED (the reference jits it,
+        experimental.py:1182-1211): the first call records how every gate tensor came out of the batched stacks of
+        ``Circuit._gate_stacks`` (constants, or ``C0 + cos C1 + sin C2`` of angles gathered from one parameter tensor), the
+        second call checks that the recorded recipe reproduces the function's tensors bit for bit, and from then on only
+        the recipe runs -- a handful of batched torch ops instead of one Python gate call per gate (20 -> 3 ms per call
+        at 944 gates).  Anything the recipe cannot express (a gate tensor that is on the tape but did not come out of a
+        stack, angles that are not elements of one parameter tensor) keeps the function.  TCMI_TN_TRACE=0 disables."""
+        import os
+
+        import torch
+
+        from . import circuit as _circ
+
+        st = getattr(self, "_trace_state", None)
+        if st is None:
+            st = self._trace_state = {"mode": "off" if os.environ.get("TCMI_TN_TRACE", "1") == "0" else "record", "recipe": None}
+        leaves = [x for x in cons.backend.tree_flatten(params)[0]] if params is not None else []
+        if st["mode"] == "replay":
+            out = self._replay_recipe(st["recipe"], leaves)
+            if out is not None:
+                return out
+            st["mode"] = "off"
+        if st["mode"] == "off":
+            return [n.tensor for n in self.nodes_fn(params)]
+        rec = _circ.NodeTrace()
+        keep, _circ.NODE_TRACE = _circ.NODE_TRACE, rec
+        try:
+            nodes = self.nodes_fn(params)
+        finally:
+            _circ.NODE_TRACE = keep
+        arrays = [n.tensor for n in nodes]
+        recipe = self._build_recipe(rec, arrays, leaves)
+        if recipe is None:
+            st["mode"] = "off"
+        elif st["recipe"] is None:
+            st["recipe"] = recipe            # first call: remember, check against the function on the next one
+        else:
+            again = self._replay_recipe(st["recipe"], leaves)
+            same = again is not None and len(again) == len(arrays) and all(
+                a.shape == b.shape and a.dtype == b.dtype and torch.equal(a.detach(), b.detach()) for a, b in zip(again, arrays))
+            st["mode"] = "replay" if same else "off"
+        return arrays
+
+    @staticmethod
+    def _build_recipe(rec, arrays, leaves):
+        import torch
+
+        stacks = []
+        for ent in rec.stacks:
+            if ent[0] == "const":
+                stacks.append(("const", ent[1]))
+            elif ent[0] == "trig":
+                li = next((i for i, x in enumerate(leaves) if x is ent[4]), None)
+                if li is None:
+                    return None
+                stacks.append(("trig", ent[1], ent[2], ent[3], li, tuple(ent[4].shape), ent[4].dtype))
+            else:
+                return None
+        items = []
+        for t in arrays:
+            src = getattr(t, "_tcmi_src", None)
+            if src is not None:
+                items.append((src[0], src[1], src[2], tuple(t.shape)))
+            elif torch.is_tensor(t) and not t.requires_grad and not torch._C._functorch.is_functorch_wrapped_tensor(t):
+                items.append(t)                 # a constant of the network (|0>, the measured operator)
+            else:
+                return None
+        return {"stacks": stacks, "items": items}
+
+    @staticmethod
+    def _replay_recipe(recipe, leaves):
+        import torch
+
+        from .circuit import trig_stack
+
+        plain, conj = [], {}
+        for ent in recipe["stacks"]:
+            if ent[0] == "const":
+                plain.append(ent[1])
+                continue
+            _, cdev, aff, offs, li, shape, dtype = ent
+            if li >= len(leaves) or not torch.is_tensor(leaves[li]) or tuple(leaves[li].shape) != shape or \
+                    leaves[li].dtype != dtype or leaves[li].device != cdev.device or not leaves[li].is_contiguous():
+                return None
+            plain.append(trig_stack(cdev, aff, leaves[li].reshape(-1)[offs]))
+        out = []
+        for it in recipe["items"]:
+            if torch.is_tensor(it):
+                out.append(it)
+                continue
+            sid, row, cj, shape = it
+            stk = plain[sid]
+            if cj:
+                if sid not in conj:
+                    conj[sid] = stk.conj().resolve_conj()
+                stk = conj[sid]
+            out.append(stk[row].reshape(shape))
+        return out
 
     def _shard(self):
         """(rank, world, group) for the split of the slice-invariant subtrees (TCMI_TN_SHARD_INV=0: every rank computes
