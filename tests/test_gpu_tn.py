@@ -747,6 +747,66 @@ def test_sliced_value_and_grad_on_the_fast_kernels_matches_the_adjoint_path(dt, 
         tc.set_dtype("complex64")
 
 
+def test_node_function_is_traced_validated_and_given_up_when_it_must_be(tcd):
+    """DistributedContractor._arrays: recipe recorded on the first call, compared bit for bit with the function on the
+    second, replayed from the third on; angles that are not elements of the parameter tensor, or a function whose
+    second call does something else, keep the function."""
+    tc = tcd
+    if tc.dtypestr != "complex64":
+        pytest.skip("one dtype is enough")
+    nq, dq = 10, 2
+    rng = np.random.default_rng(2)
+    pts = [tc.backend.convert_to_tensor(rng.uniform(0.2, 1.2, [nq, dq, 2]).astype(np.float32)) for _ in range(4)]
+    calls = {"n": 0}
+
+    def circuit(params, scale=1.0):
+        c = tc.Circuit(nq)
+        for i in range(dq):
+            for j in range(nq - 1):
+                c.rzz(j, j + 1, theta=params[j, i, 0])
+            for j in range(nq):
+                c.rx(j, theta=params[j, i, 1] if scale == 1.0 else params[j, i, 1] * scale)
+        return c
+
+    def ref(p, scale=1.0):
+        return tc.backend.value_and_grad(lambda q: tc.backend.real(circuit(q, scale).expectation_ps(z=[0])))(p)
+
+    def plain(p):
+        calls["n"] += 1
+        return circuit(p).expectation_before([tc.gates.z(), [0]], reuse=False)
+
+    dc = tc.experimental.DistributedContractor(plain, pts[0], {"slicing_opts": {"target_slices": 2}, "max_repeats": 4})
+    for k, p in enumerate(pts):
+        v, g = dc.value_and_grad(p)
+        v0, g0 = ref(p)
+        assert abs(float(v) - float(v0)) < 2e-5 and float((g - g0).abs().max()) < 2e-4, k
+        assert dc._trace_state["mode"] == ("record" if k == 0 else "replay")
+    assert calls["n"] == 3        # the constructor, the recording call and the validating call
+
+    def computed(p):              # angles are results of arithmetic, not elements of the parameter tensor
+        return circuit(p, 0.5).expectation_before([tc.gates.z(), [0]], reuse=False)
+
+    dc2 = tc.experimental.DistributedContractor(computed, pts[0], {"slicing_opts": {"target_slices": 2}, "max_repeats": 4})
+    for p in pts[:3]:
+        v, g = dc2.value_and_grad(p)
+        v0, g0 = ref(p, 0.5)
+        assert abs(float(v) - float(v0)) < 2e-5 and float((g - g0).abs().max()) < 2e-4
+    assert dc2._trace_state["mode"] == "off"
+
+    flip = {"n": 0}
+
+    def moody(p):                 # the same network, but the second call reads the parameters differently
+        flip["n"] += 1
+        return circuit(p if flip["n"] != 3 else p.flip(0).contiguous()).expectation_before([tc.gates.z(), [0]], reuse=False)
+
+    dc3 = tc.experimental.DistributedContractor(moody, pts[0], {"slicing_opts": {"target_slices": 2}, "max_repeats": 4})
+    dc3.value_and_grad(pts[0])
+    v, g = dc3.value_and_grad(pts[1])            # call 3 of the function: the recipe of call 2 does not reproduce it
+    v0, g0 = ref(pts[1].flip(0).contiguous())
+    assert dc3._trace_state["mode"] == "off"
+    assert abs(float(v) - float(v0)) < 2e-5 and float((g.flip(0) - g0).abs().max()) < 2e-4
+
+
 @pytest.mark.parametrize("shape", [(64, 64, 16), (64, 64, 32), (128, 192, 48), (512, 320, 256), (4096, 4096, 256),
                                    (64, 4096, 1024), (128, 128, 16), (256, 384, 80), (1024, 128, 512)])
 def test_dma_pipelined_join_gemm_matches_complex128_and_the_plain_kernel(shape, monkeypatch):
