@@ -433,6 +433,7 @@ def rqc_leg(tc, torch, dist, args, rank, world):
     search_s = time.perf_counter() - t0
     seeds = list(DistributedContractor.last_search)
     v = dc.value(None, op=lambda x: x)          # staging run
+    v = dc.value(None, op=lambda x: x)          # (the second call validates the traced node function)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
