@@ -17,4 +17,4 @@ for dec in (0,1,2,3,4,5,6):
         e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
         e0.record(); LA.svd_trunc(a, max_singular_values=m); e1.record(); torch.cuda.synchronize(); ts.append(round(e0.elapsed_time(e1),2))
     ctl = LA._WORK[("svd", LA._devkey(a.device))][:256].view(torch.int32).cpu().numpy()
-    print(dec, ts, "sweeps", int((ctl[2:62] > 2).sum()) + 1, "rot/sweep", ctl[2:30].tolist(), flush=True)
+    print(dec, ts, "sweeps", int((ctl[2:62] > 0).sum()) + 1, "rot/sweep", ctl[2:30].tolist(), flush=True)
