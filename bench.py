@@ -615,10 +615,13 @@ def sliced_vqa_leg(tc, torch, dist, args, rank, world):
         # F_alg of forward + backward (the VJP of a tensordot is two tensordots: 3 x the forward flops) over device time
         fl = 3.0 * 10.0 ** dc.tree_info["log10_flops"]
         out["graphs"] = gt
+        # achieved = F_alg over the measured step (the per-slice graphs run in pairs on two streams, so the step can be
+        # shorter than the sum of its graphs' stand-alone times, which `device_ms_per_step` keeps for comparison)
         out["roofline"] = {"bound": "latency", "device_ms_per_step": dev_ms, "host_bound": bool(el * 1e3 > 1.2 * dev_ms),
-                           "achieved": fl / (dev_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s",
-                           "frac": fl / (dev_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFS,
-                           "note": "thousands of rank <= 21 steps of a few microseconds each: launch-latency bound"}
+                           "achieved": fl / el / 1e12, "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s",
+                           "frac": fl / el / 1e12 / MFMA_F32_PEAK_TFS,
+                           "note": "thousands of rank <= 21 steps of a few microseconds each: launch-latency bound; "
+                                   "device_ms_per_step = sum of the graphs' stand-alone times (one stream)"}
         out["one_rank_of_8_device_ms"] = dev8
         out["projected_speedup_8_ranks_device_time"] = dev_ms / dev8 if dev8 > 0 else None
     return out
