@@ -157,6 +157,45 @@ def test_config2_full_size_state_against_the_dense_oracle():
         tc.set_dtype("complex64")
 
 
+def test_sliced_value_and_grad_replays_under_stress():
+    """Reduced form of scripts/gpu_vjp_stress.py: the graphs of the sliced reverse sweep (one launch per tree level from a
+    static descriptor table, slices in pairs on two streams, traced node function) visited 30 times over three
+    parameter points in random order, with allocator churn in between: every result equals the first one of its point."""
+    import torch
+    import tcmi as tc
+
+    tc.set_backend("hip")
+    tc.set_dtype("complex64")
+    nq, dq = 16, 3
+    rng = np.random.default_rng(1)
+    pts = [tc.backend.convert_to_tensor(rng.uniform(0.2, 1.2, [nq, dq, 2]).astype(np.float32)) for _ in range(3)]
+
+    def nodes(params):
+        c = tc.Circuit(nq)
+        for i in range(dq):
+            for j in range(nq - 1):
+                c.rzz(j, j + 1, theta=params[j, i, 0])
+            for j in range(nq):
+                c.rx(j, theta=params[j, i, 1])
+        return c.expectation_before([tc.gates.z(), [nq // 2]], reuse=False)
+
+    dc = tc.experimental.DistributedContractor(nodes, pts[0], {"slicing_opts": {"target_slices": 8}, "max_repeats": 8,
+                                                               "minimize": "combo"})
+    ref, junk = {}, []
+    for it, k in enumerate(rng.integers(0, 3, 30)):
+        v, g = dc.value_and_grad(pts[int(k)])
+        junk.append(torch.empty(int(rng.integers(1, 1 << 20)), device="cuda"))
+        if it % 5 == 0:
+            junk.clear()
+            torch.cuda.synchronize()
+        if int(k) not in ref:
+            ref[int(k)] = (v.clone(), g.clone())
+        else:
+            assert abs(float(v) - float(ref[int(k)][0])) < 1e-6 and float((g - ref[int(k)][1]).abs().max()) < 1e-6, it
+    assert dc._trace_state["mode"] == "replay" and dc.tree._vjp_graph_cache["two"] is not None
+    assert float((ref[0][1] - ref[1][1]).abs().max()) > 1e-3
+
+
 def test_graph_replay_and_two_stream_paths_under_stress():
     """Reduced forms of scripts/gpu_graph_stress.py and scripts/gpu_cut_streams_stress.py (round 2 found real ordering
     bugs on these paths: memset nodes mis-ordered between two replaying graphs): (a) 30 replays of the sliced 32-qubit
