@@ -249,6 +249,26 @@ int tcmi_qr_batched(const void* a, void* q, void* r, int m, int n, int batch, vo
 int tcmi_mps_gate_mix(const void* t, const void* gate, void* out, int L, int R, int batch, long long gate_stride,
                       int dtype, void* stream);
 
+/* ---- plan-specialised pass kernels ---------------------------------------------------------------------
+ * A pass descriptor can be compiled ahead of its first hot use into a straight-line gfx950 kernel (generator:
+ * tensorcircuit-ng_amd/tcmi/specialize.py; same tables, same arithmetic bodies as the interpreting kernels behind
+ * tcmi_run_pass / tcmi_run_adjoint_pass, which remain the fallback).  The library loads such a code object and
+ * launches it; it does not compile.
+ * Replaces: the compiled executable behind backend.jit (jax.jit of the circuit function,
+ * tensorcircuit/backends/jax_backend.py `jit`; benchmarks/scripts/vqe_tc.py:136-141 jits the VQE step): compiled once
+ * per circuit structure, replayed for every parameter value.
+ * tcmi_spec_load: `path_host` = code-object file, `kernel_name_host` = its kernel, `lds_bytes` = dynamic LDS per
+ * workgroup; the handle comes back through `handle_out_host` and belongs to the current device.
+ * tcmi_spec_run_pass / _adjoint_pass: arguments as tcmi_run_pass / tcmi_run_adjoint_pass without the descriptor;
+ * T = tile bits, LT = log2(threads per workgroup) of the plan the kernel was generated from. */
+int tcmi_spec_load(const char* path_host, const char* kernel_name_host, int lds_bytes, void** handle_out_host);
+int tcmi_spec_unload(void* handle);
+int tcmi_spec_run_pass(void* handle, void* state, long long state_stride, int batch, int n, int T, int LT,
+                       const void* ctab, const void* ptab, long long ptab_stride, void* stream);
+int tcmi_spec_run_adjoint_pass(void* handle, void* psi, void* lam, long long state_stride, int batch, int n, int T,
+                               int LT, const void* ctab, const void* ptab, long long ptab_stride, double* gout,
+                               long long gout_stride, int gcopies, long long gcopy_stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

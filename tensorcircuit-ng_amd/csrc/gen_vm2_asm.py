@@ -320,6 +320,38 @@ def gen_cmul8v_conj():
     emit_named("vm2_cmul8v_conj", args, lines, outs, ins, ["t0", "t1"], clobbers=())
 
 
+# ---- bodies with an internal wave-uniform skip (plan-specialised kernels, tcmi/specialize.py) -------------------
+# A C-level `if` around an asm body splits the kernel into basic blocks, and hipcc's register allocator then spills
+# scalar operands at the block boundaries (240 v_writelane / v_readlane pairs in a 9-round pass).  With the skip inside
+# the asm statement the whole pass stays ONE basic block.
+def gen_shear23(name="vm2_shear23_8_rx"):
+    """Eight amplitude pairs through an rx-like rotation whose form the table builder chose per batch element:
+    two shears always, the third unless bit 30 of `f` is set (flag word 2.0f = two-shear form, plan.shear2_gates)."""
+    fm = lambda D, A, P, C, hi=False: fma_im(D, A, P, C, hi=hi)  # noqa: E731
+    first, third = [], []
+    for p_ in range(8):
+        X, Y = f"%[x{p_}]", f"%[y{p_}]"
+        first.append([fm(X, Y, "%[p]", X, hi=False), fm(Y, X, "%[p]", Y, hi=True)])
+        third.append([fm(X, Y, "%[p]", X, hi=False)])
+    lines = ["s_bitcmp1_b32 %[f], 30"] + interleave(first[:4]) + interleave(first[4:]) + ["s_cbranch_scc1 1f"]
+    lines += interleave(third) + ["1:"]
+    args = ", ".join(f"v2f& x{p_}, v2f& y{p_}" for p_ in range(8)) + ", v2f p, uint32_t f"
+    outs = []
+    for p_ in range(8):
+        outs += [f'[x{p_}] "+v"(x{p_})', f'[y{p_}] "+v"(y{p_})']
+    emit_named(name, args, lines, outs, ['[p] "s"(p)', '[f] "s"(f)'], [], clobbers=("scc",))
+
+
+def gen_negate16_if():
+    """a_k = -a_k for sixteen amplitudes when `f` is non-zero (the sign pulled out of the shear-form gates of a pass)."""
+    lines = ["s_cmp_eq_u32 %[f], 0", "s_cbranch_scc1 1f"]
+    lines += [f"v_pk_mul_f32 %[a{k}], %[a{k}], -1.0 op_sel_hi:[1,0]" for k in range(16)]
+    lines += ["1:"]
+    args = ", ".join(f"v2f& a{k}" for k in range(16)) + ", uint32_t f"
+    outs = [f'[a{k}] "+v"(a{k})' for k in range(16)]
+    emit_named("vm2_negate16_if", args, lines, outs, ['[f] "s"(f)'], [], clobbers=("scc",))
+
+
 if __name__ == "__main__":
     print("// GENERATED by gen_vm2_asm.py -- do not edit; see that file for the conventions.")
     print("#ifndef TCMI_VM2_ASM_INC\n#define TCMI_VM2_ASM_INC\n")
@@ -343,4 +375,6 @@ if __name__ == "__main__":
     gen_cross8()
     gen_cmul8v_conj()
     gen_cmul8s_conj()
+    gen_shear23()
+    gen_negate16_if()
     print("#endif")

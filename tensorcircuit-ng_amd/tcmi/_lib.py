@@ -130,6 +130,19 @@ _SIGNATURES = {
         [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
          ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p],
     ),
+    "tcmi_spec_load": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p]),
+    "tcmi_spec_unload": (ctypes.c_int, [ctypes.c_void_p]),
+    "tcmi_spec_run_pass": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p],
+    ),
+    "tcmi_spec_run_adjoint_pass": (
+        ctypes.c_int,
+        [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+         ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_longlong,
+         ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p],
+    ),
     "tcmi_mps_gate_mix": (
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -18,6 +18,7 @@ import numpy as np
 
 from . import _lib
 from . import plan as P
+from . import specialize as S
 
 # bench.py: when a list, every group of kernel launches of the executor is bracketed by HIP events on the launch
 # stream and logged as (tag, start, end, launches, algorithmic bytes or flops) -- the live per-kernel durations the
@@ -123,6 +124,59 @@ def gate_is_unitary(g: P.GateRec, tol: float = 1e-6) -> bool:
     return True
 
 
+def _shift_gate(g: P.GateRec, pad: int) -> P.GateRec:
+    diag = None
+    if g.diag is not None:
+        diag = [P.DiagTerm(tuple(q + pad for q in t.qubits), t.const, t.param) for t in g.diag]
+    return P.GateRec(tuple(q + pad for q in g.qubits), g.c0, g.c1, g.c2, g.param, diag, g.name)
+
+
+def choose_plan(n: int, gates: List[P.GateRec], nparams: int, dtypestr: str, opts: Optional[dict] = None):
+    """(n_exec, cfg, plan, executed gate list) of a circuit: host work only (no device), deterministic -- also used to
+    pre-compile the plan-specialised kernels of a known workload (tcmi/specialize.py, __graft_entry__.build)."""
+    n_exec, cfg = pick_variant(n, dtypestr, opts)
+    pad = n_exec - n
+    if pad:
+        gates = [_shift_gate(g, pad) for g in gates]
+    plan = P.compile_plan(gates, n_exec, cfg, nparams=nparams)
+    if cfg.gen >= 2 and "lowbits" not in (opts or {}) and n_exec >= 20 and len(gates) >= 64:
+        # the greedy tile growth is sensitive to how many low bits are pinned and to how equal gains are broken (8 - 11
+        # passes, differently balanced, at n = 28 d = 12): compile the neighbours too and keep the plan the pass model
+        # likes best
+        best = vm_cost_us(plan)
+        for lb, tb in ((6, 0), (4, 0), (4, 1), (5, 1), (6, 1)):
+            cfg2 = dataclasses.replace(cfg, lowbits=lb, tiebreak=tb)
+            plan2 = P.compile_plan(gates, n_exec, cfg2, nparams=nparams)
+            c2 = vm_cost_us(plan2)
+            if c2 < best * 0.995:
+                best, plan, cfg = c2, plan2, cfg2
+    return n_exec, cfg, plan, gates
+
+
+def choose_adjoint_plan(gates: List[P.GateRec], n_exec: int, dtypestr: str, full: bool):
+    """(cfg, adjoint plan) of the executed gate list, or None when the short sweep has nothing to drop (use the full
+    one).  Host work only, deterministic (see choose_plan)."""
+    cfg = pick_adjoint_variant(n_exec, dtypestr, gates)
+    if not full and not (gates and not P.gate_has_param(gates[0]) and any(P.gate_has_param(g) for g in gates)):
+        return None
+    ap = P.compile_adjoint_plan(gates, n_exec, cfg, factorized=cfg.gen >= 2, drop_constant_head=not full)
+    if cfg.gen >= 2 and n_exec >= 20 and len(gates) >= 64:
+        # the greedy schedule is sensitive to the pinned low bits and (short sweep) to the dropped gates: compile
+        # the neighbours and keep what the pass model likes best; the short sweep may keep the full gate list
+        best = adj_cost_us(ap)
+        for drop in ((True, False) if not full else (False,)):
+            for lb, tb in ((5, 0), (4, 0), (4, 1), (5, 1)):
+                if best is None or ((lb, tb) == (cfg.lowbits, cfg.tiebreak) and drop == (not full)) \
+                        or (drop is False and not full and (lb, tb) != (4, 1)):
+                    continue
+                cfg2 = dataclasses.replace(cfg, lowbits=lb, tiebreak=tb, pass_cap=None)
+                ap2 = P.compile_adjoint_plan(gates, n_exec, cfg2, factorized=True, drop_constant_head=drop)
+                c2 = adj_cost_us(ap2)
+                if c2 is not None and c2 < best * 0.995:
+                    best, ap, cfg = c2, ap2, cfg2
+    return cfg, ap
+
+
 class CompiledCircuit:
     """A circuit structure lowered to tile-VM passes and resident on one GPU."""
 
@@ -133,27 +187,12 @@ class CompiledCircuit:
         self.n = n
         self.dtypestr = dtypestr
         self.nparams = nparams
-        self.n_exec, self.cfg = pick_variant(n, dtypestr, opts)
-        pad = self.n_exec - n
-        if pad:
-            gates = [self._shift(g, pad) for g in gates]
+        self.n_exec, self.cfg, self.plan, gates = choose_plan(n, gates, nparams, dtypestr, opts)
         self._exec_gates = gates
         self._opts = opts
         # non-unitary gates (density-matrix channels, `any` with a non-unitary matrix): the reverse sweep cannot
         # un-compute psi through them; vjp() then works segment by segment from checkpoints
         self.nonunitary = [i for i, g in enumerate(gates) if not gate_is_unitary(g)]
-        self.plan = P.compile_plan(gates, self.n_exec, self.cfg, nparams=nparams)
-        if self.cfg.gen >= 2 and "lowbits" not in (opts or {}) and self.n_exec >= 20 and len(gates) >= 64:
-            # the greedy tile growth is sensitive to how many low bits are pinned and to how equal gains are broken (8 - 11
-            # passes, differently balanced, at n = 28 d = 12): compile the neighbours too and keep the plan the pass model
-            # likes best
-            best = vm_cost_us(self.plan)
-            for lb, tb in ((6, 0), (4, 0), (4, 1), (5, 1), (6, 1)):
-                cfg2 = dataclasses.replace(self.cfg, lowbits=lb, tiebreak=tb)
-                plan2 = P.compile_plan(gates, self.n_exec, cfg2, nparams=nparams)
-                c2 = vm_cost_us(plan2)
-                if c2 < best * 0.995:
-                    best, self.plan, self.cfg = c2, plan2, cfg2
         self.tdtype = torch.complex64 if dtypestr == "complex64" else torch.complex128
         self.rdtype = torch.float32 if dtypestr == "complex64" else torch.float64
         self.code = _lib.TCMI_C64 if dtypestr == "complex64" else _lib.TCMI_C128
@@ -167,12 +206,7 @@ class CompiledCircuit:
         self.nrec = int(self.plan.ginfo.shape[0])
         self.ptab_size = max(1, self.plan.ptab_size)
 
-    @staticmethod
-    def _shift(g: P.GateRec, pad: int) -> P.GateRec:
-        diag = None
-        if g.diag is not None:
-            diag = [P.DiagTerm(tuple(q + pad for q in t.qubits), t.const, t.param) for t in g.diag]
-        return P.GateRec(tuple(q + pad for q in g.qubits), g.c0, g.c1, g.c2, g.param, diag, g.name)
+    _shift = staticmethod(_shift_gate)
 
     # ------------------------------------------------------------------------------------
     def state(self, params=None, inputs=None, out=None, full=False, consume_inputs=False):
@@ -236,7 +270,20 @@ class CompiledCircuit:
     def run_passes(self, state, ptab, B, stream, first=0, last=None):
         lib = self._lib
         nel = 2**self.n_exec
-        for d in self.descs[first:last]:
+        spec = [None] * len(self.descs)
+        if self.cfg.gen >= 2 and self.dtypestr == "complex64":
+            # plan-specialised straight-line kernels where they exist (tcmi/specialize.py); the interpreter otherwise
+            if getattr(self, "_spec_fwd", None) is None:
+                self._spec_fwd = S.PassSet("forward", self.plan.descs, self.n_exec)
+            spec = self._spec_fwd.get()
+        for d, k in list(zip(self.descs, spec))[first:last]:
+            if k is not None:
+                _lib.check(
+                    lib.tcmi_spec_run_pass(k.handle, state.data_ptr(), nel, B, self.n_exec, self.cfg.T, self.cfg.LT,
+                                           self.ctab.data_ptr(), ptab.data_ptr(), ptab.stride(0), stream),
+                    "tcmi_spec_run_pass",
+                )
+                continue
             _lib.check(
                 lib.tcmi_run_pass(
                     state.data_ptr(), nel, B, self.n_exec, self.cfg.R, self.cfg.LT, d.data_ptr(),
@@ -258,26 +305,11 @@ class CompiledCircuit:
 
         key = "_adj" if full else "_adj_short"
         if getattr(self, key, None) is None:
-            gates = self._exec_gates
-            cfg = pick_adjoint_variant(self.n_exec, self.dtypestr, gates)
-            if not full and not (gates and not P.gate_has_param(gates[0]) and any(P.gate_has_param(g) for g in gates)):
+            res = choose_adjoint_plan(self._exec_gates, self.n_exec, self.dtypestr, full)
+            if res is None:
                 self._adj_short = self._adjoint(True)      # nothing to drop
                 return self._adj_short
-            ap = P.compile_adjoint_plan(gates, self.n_exec, cfg, factorized=cfg.gen >= 2, drop_constant_head=not full)
-            if cfg.gen >= 2 and self.n_exec >= 20 and len(gates) >= 64:
-                # the greedy schedule is sensitive to the pinned low bits and (short sweep) to the dropped gates: compile
-                # the neighbours and keep what the pass model likes best; the short sweep may keep the full gate list
-                best = adj_cost_us(ap)
-                for drop in ((True, False) if not full else (False,)):
-                    for lb, tb in ((5, 0), (4, 0), (4, 1), (5, 1)):
-                        if best is None or ((lb, tb) == (cfg.lowbits, cfg.tiebreak) and drop == (not full)) \
-                                or (drop is False and not full and (lb, tb) != (4, 1)):
-                            continue
-                        cfg2 = dataclasses.replace(cfg, lowbits=lb, tiebreak=tb, pass_cap=None)
-                        ap2 = P.compile_adjoint_plan(gates, self.n_exec, cfg2, factorized=True, drop_constant_head=drop)
-                        c2 = adj_cost_us(ap2)
-                        if c2 is not None and c2 < best * 0.995:
-                            best, ap, cfg = c2, ap2, cfg2
+            cfg, ap = res
             dev = self.device
             setattr(self, key, {
                 "plan": ap, "cfg": cfg,

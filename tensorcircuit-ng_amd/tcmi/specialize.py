@@ -1,0 +1,761 @@
+"""Plan-specialised pass kernels: a pass descriptor lowered to straight-line gfx950 code.
+
+The tile-VM kernels (csrc/tcmi_vm2.hip, csrc/tcmi_adjoint2.hip) INTERPRET a pass descriptor: per op they
+fetch descriptor words, build one-hot dispatch flags, branch over the bodies they do not need, walk LDS
+addresses from mask words held in SGPRs.  The PMC counters of the n = 28 passes (profiles/r03d_*_pmc.txt)
+show what that costs: 41 % of the issued VALU instructions and 0.84e9 scalar instructions per dispatch of
+the reverse sweep are neither gate arithmetic nor data movement.  This module removes the interpreter for
+plans that are worth it: the SAME descriptor (written by tcmi/plan.py, same tables, same arithmetic
+bodies from csrc/tcmi_vm2_asm.inc) is translated once into HIP source in which
+
+  * every op is emitted in program order with its register indices, table offsets and masks as literals
+    (no dispatch, no descriptor loads, no taken branches around unused bodies);
+  * the LDS exchange addresses are `thread part + literal offset` wherever the register bits own their slot
+    bits (the literal goes into the DS instruction's offset field: no address arithmetic at all);
+  * all scalar table loads of the pass sit in one basic block, so the compiler hoists them far ahead of use.
+
+The source is compiled with hipcc to a code object (one kernel per pass), cached on disk by a digest of the
+descriptor, and launched through `tcmi_spec_launch_*` (hipModuleLaunchKernel; include/tcmi.h).  This is the
+role `jax.jit` plays for the reference (tensorcircuit/backends/jax_backend.py `jit`; the reference harness
+jits the VQE step, benchmarks/scripts/vqe_tc.py:136-141): compile once per circuit structure, reuse for every
+parameter value.  Passes with ops the emitter does not know keep the interpreter; so does everything when
+hipcc is unavailable (TCMI_SPECIALIZE=0 switches the whole mechanism off).
+"""
+
+import hashlib
+import os
+import shutil
+import subprocess
+import threading
+from concurrent.futures import ThreadPoolExecutor
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import plan as P
+
+GEN_VERSION = 1           # bump when the emitted code changes (part of the cache key)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
+CACHE_DIR = os.environ.get("TCMI_SPEC_CACHE") or os.path.join(CSRC, "plancache")
+HIPCC = os.environ.get("HIPCC") or "/opt/rocm/bin/hipcc"
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-munsafe-fp-atomics",
+               "-mllvm", "-simplifycfg-sink-common=false", "-mllvm", "-disable-promote-alloca-to-vector",
+               "--genco", "-I", CSRC]
+
+
+class Unsupported(Exception):
+    """The pass contains an op (or a shape) the emitter has no straight-line form for: it stays interpreted."""
+
+
+def _ins0(k: int, j: int) -> int:
+    return ((k >> j) << (j + 1)) | (k & ((1 << j) - 1))
+
+
+def _u32(x) -> int:
+    return int(x) & 0xFFFFFFFF
+
+
+def _i32(x) -> int:
+    x = int(x) & 0xFFFFFFFF
+    return x - (1 << 32) if x & 0x80000000 else x
+
+
+def _runs(pairs: Sequence[Tuple[int, int]]):
+    """[(source bit, destination bit)] sorted by source -> maximal runs (src0, dst0, length) of consecutive bits."""
+    out = []
+    for s, d in pairs:
+        if out and out[-1][0] + out[-1][2] == s and out[-1][1] + out[-1][2] == d:
+            out[-1][2] += 1
+        else:
+            out.append([s, d, 1])
+    return [tuple(x) for x in out]
+
+
+def _deposit_expr(var: str, pairs: Sequence[Tuple[int, int]], ctype: str = "uint32_t") -> str:
+    """C expression moving bit s of ``var`` to bit d for every (s, d)."""
+    terms = []
+    for s, d, ln in _runs(sorted(pairs)):
+        m = ((1 << ln) - 1) << s
+        t = f"(({ctype}){var} & {m:#x}u)"
+        if d > s:
+            t = f"({t} << {d - s})"
+        elif d < s:
+            t = f"({t} >> {s - d})"
+        terms.append(t)
+    return " | ".join(terms) if terms else "0u"
+
+
+def _xor_const(masks: Sequence[int], r: int) -> int:
+    out = 0
+    for j, m in enumerate(masks):
+        if (r >> j) & 1:
+            out ^= m
+    return out
+
+
+class _Round:
+    def __init__(self, w, pc, R, LT):
+        self.pc = pc
+        self.nops = int(w[pc])
+        self.nwords = int(w[pc + 1])
+        self.reg_phys = [_u32(w[pc + 2 + j]) for j in range(R)]
+        self.thr_phys = [_u32(w[pc + 8 + i]) for i in range(LT)]
+        self.reg_rd = [_u32(w[pc + 18 + j]) for j in range(R)]
+        self.thr_rd = [_u32(w[pc + 24 + i]) for i in range(LT)]
+        self.reg_wr = [_u32(w[pc + 34 + j]) for j in range(R)]
+        self.thr_wr = [_u32(w[pc + 40 + i]) for i in range(LT)]
+        self.ops_at = pc + P.RR_WORDS
+
+
+class Seg:
+    """One schedulable unit of a pass: wave-uniform operand loads + body pieces.  The linearisation (``_Emitter.linear``)
+    issues the loads of segment i + 1 right after the FIRST piece of segment i, i.e. after the wait that piece needs for
+    its own operands and a whole body ahead of their use; scheduling barriers pin that order.  (All scalar loads of a
+    wave share one out-of-order counter, so a wait for any of them waits for all that were issued before it.)"""
+
+    def __init__(self, tag: str = ""):
+        self.tag = tag
+        self.loads: List[str] = []
+        self.parts: List[List[str]] = [[]]
+
+    def new_part(self) -> List[str]:
+        if self.parts[-1]:
+            self.parts.append([])
+        return self.parts[-1]
+
+
+class _Emitter:
+    """Common parts of the forward and the reverse-sweep emitters: header decode, index arithmetic, tile load /
+    store, LDS exchange, linearisation."""
+
+    SB = "  __builtin_amdgcn_sched_barrier(0);"
+
+    def __init__(self, words, vectors: Sequence[str], opts: Optional[dict] = None):
+        w = np.asarray(words).view(np.int32).astype(np.int64)
+        if int(w[0]) != P.MAGIC:
+            raise Unsupported("not a pass descriptor")
+        self.w = w
+        self.opts = dict(opts or {})
+        self.n, self.T, self.R, self.LT = int(w[1]), int(w[2]), int(w[3]), int(w[4])
+        self.nrounds, self.flags = int(w[5]), int(w[6])
+        self.NR = 1 << self.R
+        if self.n > 32:
+            raise Unsupported("n > 32")
+        self.tile_bits = [int(w[8 + i]) for i in range(self.T)]
+        self.vectors = list(vectors)
+        self.rounds: List[_Round] = []
+        pc = P.HDR_WORDS
+        for _ in range(self.nrounds):
+            rd = _Round(w, pc, self.R, self.LT)
+            self.rounds.append(rd)
+            pc = rd.ops_at + rd.nwords
+        self.segs: List[Seg] = []
+        self.uid = 0
+        # logical register index -> variable index (CNOT / SWAP between register bits are renamings here)
+        self.reg = list(range(self.NR))
+
+    # ---- small helpers -------------------------------------------------------------------------------
+    def seg(self, tag: str = "") -> Seg:
+        s = Seg(tag)
+        self.segs.append(s)
+        return s
+
+    def fresh(self, stem: str) -> str:
+        self.uid += 1
+        return f"{stem}{self.uid}"
+
+    def A(self, r: int, vec: str = "a") -> str:
+        return f"{vec}{self.reg[r]}"
+
+    def toff_type(self) -> str:
+        return "uint32_t" if self.n <= 29 else "unsigned long long"
+
+    def linear(self) -> List[str]:
+        out: List[str] = []
+        segs = [s for s in self.segs if s.loads or any(s.parts)]
+        if segs:
+            out += segs[0].loads
+        for i, s in enumerate(segs):
+            parts = [p for p in s.parts if p] or [[]]
+            out.append(f"  // -- {s.tag}")
+            out += parts[0]
+            out.append(self.SB)
+            if i + 1 < len(segs) and segs[i + 1].loads:
+                out += segs[i + 1].loads
+                out.append(self.SB)
+            for p in parts[1:]:
+                out += p
+                out.append(self.SB)
+        return out
+
+    # ---- prologue ------------------------------------------------------------------------------------
+    def index_lines(self) -> List[str]:
+        free = [p for p in range(self.n) if p not in self.tile_bits]
+        pairs = [(i, p) for i, p in enumerate(free)]
+        return ["  const uint32_t tid = threadIdx.x;", "  const uint32_t bx = blockIdx.x;",
+                f"  const uint32_t wg_base = {_deposit_expr('bx', pairs)};"]
+
+    def thread_xor(self, out: List[str], name: str, masks: Sequence[int], shift: int = 0):
+        """uint32_t name = XOR of masks[i] << shift over the set bits of tid."""
+        pairs = [(i, m.bit_length() - 1 + shift) for i, m in enumerate(masks) if m and (m & (m - 1)) == 0]
+        multi = [(i, m) for i, m in enumerate(masks) if m and (m & (m - 1)) != 0]
+        if not multi:
+            out.append(f"  const uint32_t {name} = {_deposit_expr('tid', pairs)};")
+            return
+        out.append(f"  uint32_t {name} = {_deposit_expr('tid', pairs)};")
+        for i, m in multi:
+            out.append(f"  {name} ^= (0u - ((tid >> {i}) & 1u)) & {(m << shift):#x}u;")
+
+    def tile_io(self, out: List[str], rd: _Round, store: bool, ptrs: Dict[str, str], tphys: str):
+        """16-byte accesses, two amplitudes each (register bit 0 = the lowest physical bit of the tile)."""
+        tt = self.toff_type()
+        if rd.reg_phys[0] != 1 or self.tile_bits[0] != 0:
+            raise Unsupported("register bit 0 is not physical bit 0 in the load / store layout")
+        toff = self.fresh("toff")
+        out.append(f"  const {tt} {toff} = ({tt}){tphys} * 8u;")
+        for vec in self.vectors:
+            base = self.fresh("gb")
+            cq = "" if store else "const "
+            out.append(f"  {cq}char* __restrict__ {base} = reinterpret_cast<{cq}char*>({ptrs[vec]} + wg_base);")
+            for r in range(0, self.NR, 2):
+                c = _xor_const(rd.reg_phys, r) * 8
+                addr = f"{base} + {c:#x}ull + {toff}"
+                if store:
+                    v = self.fresh("sv")
+                    out.append(f"  {{ v4f {v}; {v}.xy = {self.A(r, vec)}; {v}.zw = {self.A(r + 1, vec)}; "
+                               f"*reinterpret_cast<v4f*>({addr}) = {v}; }}")
+                else:
+                    v = self.fresh("lv")
+                    out.append(f"  const v4f {v} = *reinterpret_cast<const v4f*>({addr});")
+                    out.append(f"  {self.A(r, vec)} = {v}.xy; {self.A(r + 1, vec)} = {v}.zw;")
+
+    # ---- LDS exchange --------------------------------------------------------------------------------
+    def exchange_plan(self, reg_masks: Sequence[int], thr_masks: Sequence[int]):
+        """Split the slot of register index r into (dirty, clean): clean bits are touched by no thread mask, so
+        `thread part ^ dirty` + clean is the address and `clean` rides in the instruction's offset field."""
+        U = 0
+        for m in thr_masks:
+            U |= m
+        out = []
+        for r in range(self.NR):
+            c = _xor_const(reg_masks, r)
+            out.append((c & U, c & ~U))
+        return out
+
+    def exchange(self, k: int, planes: Sequence[Tuple[str, str]], elem_bytes: int) -> Seg:
+        """Exchange from the layout of round k into round k + 1.  ``planes``: (vector, component suffix) moved one
+        after the other through the one LDS buffer ('' = the whole 8-byte value).  Returns the segment; the name of
+        the new thread-part of the physical index is left in ``self.tphys``."""
+        wr, rdn = self.rounds[k], self.rounds[k + 1]
+        sh = {4: 2, 8: 3}[elem_bytes]
+        sg = self.seg(f"exchange {k} -> {k + 1}")
+        out = sg.parts[0]
+        ws, rs, tpn = self.fresh("ws"), self.fresh("rs"), self.fresh("tph")
+        self.thread_xor(out, ws, wr.thr_wr, sh)
+        self.thread_xor(out, rs, rdn.thr_rd, sh)
+        self.thread_xor(out, tpn, rdn.thr_phys)
+        wplan = self.exchange_plan(wr.reg_wr, wr.thr_wr)
+        rplan = self.exchange_plan(rdn.reg_rd, rdn.thr_rd)
+        ctype = "float" if elem_bytes == 4 else "v2f"
+        # volatile reads: the load / store optimiser would pair two 4-byte reads into one ds_read2, whose two results
+        # land in ONE register pair -- but the two values are the same component of two different amplitudes, so every
+        # such read costs two v_mov afterwards (428 of them in a 9-round pass)
+        vq = "volatile " if (elem_bytes == 4 and self.opts.get("single_reads", True)) else ""
+
+        def walk(out, stem, var, plan, stmt):
+            """One address variant (thread part ^ dirty bits) at a time, defined right before its accesses (short live
+            ranges: the variants never sit next to each other in registers); clean bits ride in the offset field."""
+            order = sorted(range(self.NR), key=lambda r: (plan[r][0], plan[r][1]))
+            cur, nm = None, var
+            for r in order:
+                d, c = plan[r]
+                if d != cur:
+                    cur = d
+                    if d == 0:
+                        nm = var
+                    else:
+                        nm = self.fresh(stem)
+                        out.append(f"  const uint32_t {nm} = {var} ^ {(d << sh):#x}u;")
+                out.append("  " + stmt(r, f"lb + {nm} + {c << sh}"))
+
+        first = True
+        for vec, comp in planes:
+            sfx = f".{comp}" if comp else ""
+            walk(out, "wsd", ws, wplan, lambda r, ad: f"*({ctype} LDS_AS*)({ad}) = {self.A(r, vec)}{sfx};")
+            out.append("  __syncthreads();")
+            if first:
+                out = sg.new_part()
+                first = False
+            walk(out, "rsd", rs, rplan,
+                 lambda r, ad: f"{self.A(r, vec)}{sfx} = *(const {vq}{ctype} LDS_AS*)({ad});")
+            out.append("  __syncthreads();")
+        self.tphys = tpn
+        return sg
+
+    # ---- shared op pieces ----------------------------------------------------------------------------
+    def pairs_of(self, J: int):
+        B = 1 << J
+        return [(_ins0(g, J), _ins0(g, J) | B) for g in range(self.NR // 2)]
+
+    def calls8(self, fn: str, J: int, vec: str, tail: str) -> List[str]:
+        """fn(x0, y0, ..., x7, y7, tail) over all amplitude pairs of register bit J, eight pairs per call."""
+        pr = self.pairs_of(J)
+        if len(pr) % 8:
+            raise Unsupported("fewer than 8 amplitude pairs per thread")
+        out = []
+        for g in range(0, len(pr), 8):
+            args = ", ".join(f"{self.A(x, vec)}, {self.A(y, vec)}" for x, y in pr[g:g + 8])
+            out.append(f"  {fn}({args}, {tail});")
+        return out
+
+    def load_v2(self, out: List[str], name: str, off, count: int, tab: str = "ptab"):
+        """const v2f name_i = ((KV2)(tab + off))[i], i < count"""
+        p = self.fresh("tp")
+        out.append(f"  const KV2 {p} = (KV2)({tab} + {off});")
+        for i in range(count):
+            out.append(f"  const v2f {name}_{i} = {p}[{i}];")
+
+    def slot_ptr(self, slot: int) -> Tuple[str, int]:
+        slot = _u32(slot)
+        if slot & P.CONST_FLAG:
+            return "ctab", slot & ~P.CONST_FLAG
+        return "ptab", slot
+
+    def rename_perm(self, ja: int, jb: int, kind: int):
+        """CNOT (kind 1: control ja, 2: control jb) / SWAP (3) between register bits: swap the variable names."""
+        A, B = 1 << ja, 1 << jb
+        for g in range(self.NR // 4):
+            r0 = _ins0(_ins0(g, ja), jb)
+            if kind == 1:
+                x, y = r0 | A, r0 | A | B
+            elif kind == 2:
+                x, y = r0 | B, r0 | A | B
+            else:
+                x, y = r0 | B, r0 | A
+            self.reg[x], self.reg[y] = self.reg[y], self.reg[x]
+
+    def header(self, kname: str, params: str) -> List[str]:
+        return [
+            "// GENERATED by tcmi/specialize.py -- one pass of one plan, straight-line (see that file).",
+            "#include <hip/hip_runtime.h>",
+            "#include <stdint.h>",
+            '#include "tcmi_dev.h"',
+            "using namespace tcmi;",
+            "typedef float v2f __attribute__((ext_vector_type(2)));",
+            "typedef float v4f __attribute__((ext_vector_type(4)));",
+            "typedef const v2f TCMI_K* KV2;",
+            "typedef const float TCMI_K* KF;",
+            "#define LDS_AS __attribute__((address_space(3)))",
+            '#include "tcmi_vm2_asm.inc"',
+            "",
+            f'extern "C" __global__ __launch_bounds__({1 << self.LT}, {self.waves_per_eu()}) void {kname}({params}) {{',
+        ]
+
+    def waves_per_eu(self) -> int:
+        return 1024 >> self.LT
+
+
+# ======================================================================================================
+#  forward gate pass  (mirror of pass2_kernel, csrc/tcmi_vm2.hip)
+# ======================================================================================================
+class _Forward(_Emitter):
+    def __init__(self, words, opts=None):
+        super().__init__(words, ["a"], opts)
+        if self.R < 4:
+            raise Unsupported("R < 4")
+
+    def g1m(self, q: int) -> int:
+        w = self.w
+        mk, base = int(w[q + 1]), int(w[q + 2])
+        for J in range(self.R):
+            if not (mk >> J) & 1:
+                continue
+            kind = (mk >> (8 + 2 * J)) & 3
+            sh = (mk >> (P.SHEAR_SHIFT + J)) & 1
+            c = self.fresh("c")
+            off = base + 8 * J
+            sg = self.seg(f"gate on register bit {J}")
+            if sh:
+                self.load_v2(sg.loads, c, off, 2)
+                sg.loads.append(f"  sgn ^= __float_as_uint({c}_1.x) & 0x80000000u;")
+                if kind == 2:
+                    # two shears + the third unless the builder chose the two-shear form for this batch element (the
+                    # skip is inside the asm body: the pass stays one basic block)
+                    calls = self.calls8("vm2_shear23_8_rx", J, "a", f"{c}_0, __float_as_uint({c}_1.y)")
+                    sg.parts[0] += calls[:1]
+                    sg.new_part().extend(calls[1:])
+                elif kind == 1:
+                    calls = self.calls8("vm2_shear8_real", J, "a", f"{c}_0")
+                    sg.parts[0] += calls[:1]
+                    sg.new_part().extend(calls[1:])
+                else:
+                    raise Unsupported("shear form of a general gate")
+            else:
+                self.load_v2(sg.loads, c, off, 4)
+                fn = {0: "vm2_gate8_gen", 1: "vm2_gate8_real", 2: "vm2_gate8_rx"}.get(kind)
+                if fn is None:
+                    raise Unsupported("gate class 3")
+                calls = self.calls8(fn, J, "a", f"{c}_0, {c}_1, {c}_2, {c}_3")
+                sg.parts[0] += calls[:1]
+                sg.new_part().extend(calls[1:])
+        return q + 3
+
+    def wave_variant(self, out: List[str], q0: int, nsel: int) -> str:
+        """v = sum_k parity(wave's thread index & m_k) << k   (wave-uniform)"""
+        v = self.fresh("tv")
+        out.append(f"  const uint32_t {v}w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wg_base | {self.tphys}));")
+        terms = [f"((__builtin_popcount({v}w & {_u32(self.w[q0 + k2]):#x}u) & 1u) << {k2})" for k2 in range(nsel)]
+        out.append(f"  const uint32_t {v} = {' | '.join(terms) if terms else '0u'};")
+        return v
+
+    def table_mul(self, pre: List[str], tabexpr: str, fn: str = "vm2_cmul8s", vecs: Sequence[str] = ("a",)):
+        """a[r] *= table[r]: two segments of 16 entries (32 scalar registers each)."""
+        p = self.fresh("tp")
+        CH = min(16, self.NR)
+        for h0 in range(0, self.NR, CH):
+            sg = self.seg(f"table entries {h0}..{h0 + CH - 1}")
+            if h0 == 0:
+                sg.loads += pre
+                sg.loads.append(f"  const KV2 {p} = (KV2)({tabexpr});")
+            t = self.fresh("t")
+            for i in range(CH):
+                sg.loads.append(f"  const v2f {t}_{i} = {p}[{h0 + i}];")
+            first = True
+            for h in range(0, CH, 8):
+                for vec in vecs:
+                    amps = ", ".join(self.A(h0 + h + i, vec) for i in range(8))
+                    tabs = ", ".join(f"{t}_{h + i}" for i in range(8))
+                    (sg.parts[0] if first else sg.new_part()).append(f"  {fn}({amps}, {tabs});")
+                    first = False
+
+    def diagb_apply(self, sg: Seg, J: int, e: str, vecs: Sequence[str] = ("a",)):
+        pr = self.pairs_of(J)
+        for vec in vecs:
+            for g in range(0, len(pr), 4):
+                lo = ", ".join(self.A(x, vec) for x, _ in pr[g:g + 4])
+                hi = ", ".join(self.A(y, vec) for _, y in pr[g:g + 4])
+                sg.parts[-1].append(f"  vm2_cmul44v({lo}, {hi}, {e});")
+                if g == 0 and vec == vecs[0]:
+                    sg.new_part()
+
+    def op(self, q: int) -> int:
+        w = self.w
+        op = int(w[q])
+        NR = self.NR
+        if op == P.OP_G1M:
+            return self.g1m(q)
+        if op == P.OP_DIAGC:
+            self.table_mul([], f"ptab + {int(w[q + 1])}")
+            return q + 2
+        if op == P.OP_DIAGCW:
+            nsel = int(w[q + 2])
+            pre: List[str] = []
+            v = self.wave_variant(pre, q + 3, nsel)
+            self.table_mul(pre, f"ptab + {int(w[q + 1])} + {2 * NR} * {v}")
+            return q + 6
+        if op == P.OP_DIAGB:
+            J, m, slot = int(w[q + 1]), _u32(w[q + 2]), int(w[q + 3])
+            sg = self.seg(f"DIAGB bit {J}")
+            e, t = self.fresh("e"), self.fresh("b")
+            sg.loads.append(f"  const float {t}c = ptab[{slot}], {t}s = ptab[{slot + 1}];")
+            sg.parts[0].append(f"  v2f {e}; {e}.x = {t}c; {e}.y = (__builtin_popcount((wg_base | {self.tphys}) & {m:#x}u) & 1) "
+                               f"? -{t}s : {t}s;")
+            self.diagb_apply(sg, J, e)
+            return q + 4
+        if op == P.OP_DIAGB2:
+            J, m1, m2, slot = int(w[q + 1]), _u32(w[q + 2]), _u32(w[q + 3]), int(w[q + 4])
+            sg = self.seg(f"DIAGB2 bit {J}")
+            t = self.fresh("b")
+            self.load_v2(sg.loads, t, slot, 4)
+            e = self.fresh("e")
+            p = sg.parts[0]
+            p.append(f"  v2f {e};")
+            p.append(f"  {{ const uint32_t ti = wg_base | {self.tphys}; const bool s1 = __builtin_popcount(ti & {m1:#x}u) & 1, "
+                     f"s2 = __builtin_popcount(ti & {m2:#x}u) & 1;")
+            p.append(f"    {e}.x = s2 ? (s1 ? {t}_3.x : {t}_2.x) : (s1 ? {t}_1.x : {t}_0.x);")
+            p.append(f"    {e}.y = s2 ? (s1 ? {t}_3.y : {t}_2.y) : (s1 ? {t}_1.y : {t}_0.y); }}")
+            self.diagb_apply(sg, J, e)
+            return q + 5
+        if op == P.OP_G2:
+            jak, jb, slot = int(w[q + 1]), int(w[q + 2]), int(w[q + 3])
+            ja, kind = jak & 0xFF, jak >> 8
+            if kind:
+                self.rename_perm(ja, jb, kind)
+                return q + 4
+            tab, off = self.slot_ptr(slot)
+            sg = self.seg(f"G2 bits {ja},{jb}")
+            m = self.fresh("m")
+            self.load_v2(sg.loads, m, off, 16, tab)
+            A, B = 1 << ja, 1 << jb
+            ms = ", ".join(f"{m}_{i}" for i in range(16))
+            for g in range(0, NR // 4, 2):
+                r0, r1 = _ins0(_ins0(g, ja), jb), _ins0(_ins0(g + 1, ja), jb)
+                quad = lambda r: f"{self.A(r)}, {self.A(r | B)}, {self.A(r | A)}, {self.A(r | A | B)}"  # noqa: E731
+                (sg.parts[0] if g == 0 else sg.new_part()).append(f"  vm2_g2x2({quad(r0)}, {quad(r1)}, {ms});")
+            return q + 4
+        raise Unsupported(f"forward op {op}")
+
+    def source(self, kname: str) -> str:
+        NR = self.NR
+        params = ("v2f* __restrict__ state, long long state_stride, const float* __restrict__ ctab_g, "
+                  "const float* __restrict__ ptab_g, long long ptab_stride")
+        pro = ["  extern __shared__ __attribute__((aligned(16))) char lb_[];",
+               "  char LDS_AS* const lb = (char LDS_AS*)lb_;",
+               "  state += (long long)blockIdx.y * state_stride;",
+               "  const KF ctab = (KF)ctab_g; (void)ctab;",
+               "  const KF ptab = (KF)(ptab_g + (long long)blockIdx.y * ptab_stride);"]
+        pro += self.index_lines()
+        pro.append("  v2f " + ", ".join(f"a{r}" for r in range(NR)) + ";")
+        pro.append("  uint32_t sgn = 0u;")
+        rd0 = self.rounds[0]
+        sg = self.seg("tile load")
+        self.tphys = self.fresh("tph")
+        self.thread_xor(sg.parts[0], self.tphys, rd0.thr_phys)
+        self.tile_io(sg.parts[0], rd0, False, {"a": "state"}, self.tphys)
+        for k, rd in enumerate(self.rounds):
+            q = rd.ops_at
+            for _ in range(rd.nops):
+                q = self.op(q)
+            if q != rd.ops_at + rd.nwords:
+                raise Unsupported("descriptor length mismatch")
+            if k == self.nrounds - 1:
+                break
+            self.exchange(k, [("a", "x"), ("a", "y")], 4)
+        last = self.rounds[-1]
+        sg = self.seg("sign + tile store")
+        p = sg.parts[0]
+        for r in range(0, NR, 16):
+            p.append("  vm2_negate16_if(" + ", ".join(self.A(r + i) for i in range(16)) + ", sgn);")
+        self.tile_io(p, last, True, {"a": "state"}, self.tphys)
+        return "\n".join(self.header(kname, params) + pro + self.linear() + ["}"]) + "\n"
+
+    def lds_bytes(self) -> int:
+        return 4 << self.T
+
+
+def forward_source(words, kname: str = "tcmi_spec_pass", opts=None) -> Tuple[str, dict]:
+    """HIP source of the straight-line kernel of one forward gate pass + its launch geometry."""
+    e = _Forward(words, opts)
+    src = e.source(kname)
+    return src, {"kind": "forward", "n": e.n, "T": e.T, "LT": e.LT, "lds": e.lds_bytes()}
+
+
+# ======================================================================================================
+#  cache, compiler driver, loader
+# ======================================================================================================
+_SRC_DIGEST = None
+_LOCK = threading.Lock()
+_LOADED: Dict[str, "SpecKernel"] = {}
+STATS = {"compiled": 0, "cache_hits": 0, "unsupported": 0, "compile_s": 0.0}
+
+
+def mode() -> str:
+    """TCMI_SPECIALIZE: '0' = never, '1' = compile at the first use of a plan, 'auto' (default) = use cached kernels at once,
+    compile missing ones when a plan turns out to be hot (TCMI_SPEC_HOT calls, default 3) and big enough to pay."""
+    return os.environ.get("TCMI_SPECIALIZE", "auto")
+
+
+def _support_digest() -> bytes:
+    global _SRC_DIGEST
+    if _SRC_DIGEST is None:
+        h = hashlib.blake2b(digest_size=16)
+        for f in ("tcmi_vm2_asm.inc", "tcmi_dev.h", "tcmi_vm.h"):
+            with open(os.path.join(CSRC, f), "rb") as fh:
+                h.update(fh.read())
+        h.update(" ".join(HIPCC_FLAGS[:-1]).encode())   # not the include path
+        _SRC_DIGEST = h.digest()
+    return _SRC_DIGEST
+
+
+def pass_digest(kind: str, words, opts: Optional[dict] = None) -> str:
+    h = hashlib.blake2b(digest_size=16)
+    h.update(f"{GEN_VERSION}|{kind}|{sorted((opts or {}).items())!r}|".encode())
+    h.update(_support_digest())
+    h.update(np.ascontiguousarray(np.asarray(words).view(np.int32)).tobytes())
+    return h.hexdigest()
+
+
+class SpecKernel:
+    """A loaded plan-specialised kernel: ``handle`` for tcmi_spec_run_*; geometry in ``meta``."""
+
+    def __init__(self, handle, meta, path):
+        self.handle, self.meta, self.path = handle, meta, path
+
+
+_EMITTERS = {}
+
+
+def _source(kind: str, words, opts) -> Tuple[str, dict]:
+    return _EMITTERS[kind](words, "tcmi_spec_pass", opts)
+
+
+def have_compiler() -> bool:
+    return os.path.exists(HIPCC) or shutil.which("hipcc") is not None
+
+
+def _compile(src: str, out_path: str, keep_source: bool):
+    os.makedirs(os.path.dirname(out_path), exist_ok=True)
+    tmp_base = f"{out_path}.{os.getpid()}.{threading.get_ident()}"
+    hip = tmp_base + ".hip"
+    with open(hip, "w") as fh:
+        fh.write(src)
+    tmp_out = tmp_base + ".hsaco"
+    cc = HIPCC if os.path.exists(HIPCC) else shutil.which("hipcc")
+    try:
+        r = subprocess.run([cc] + HIPCC_FLAGS + [hip, "-o", tmp_out], capture_output=True, text=True)
+        if r.returncode != 0 or not os.path.exists(tmp_out):
+            raise RuntimeError(f"hipcc failed on a plan-specialised kernel:\n{r.stderr[-2000:]}")
+        os.replace(tmp_out, out_path)     # atomic: ranks of one job may compile the same pass side by side
+        if keep_source:
+            os.replace(hip, out_path[:-6] + ".hip")
+    finally:
+        for f in (hip, tmp_out):
+            if os.path.exists(f):
+                os.remove(f)
+
+
+def _cache_dirs() -> List[str]:
+    """In-tree cache first (it travels with the built library), a per-user directory when the tree is read-only."""
+    return [CACHE_DIR, os.path.join(os.environ.get("TMPDIR", "/tmp"), f"tcmi_plancache_{os.getuid()}")]
+
+
+def _find(dg: str) -> Optional[str]:
+    for d in _cache_dirs():
+        p = os.path.join(d, dg + ".hsaco")
+        if os.path.exists(p):
+            return p
+    return None
+
+
+def _writable_dir() -> str:
+    for d in _cache_dirs():
+        try:
+            os.makedirs(d, exist_ok=True)
+            if os.access(d, os.W_OK):
+                return d
+        except OSError:
+            continue
+    raise RuntimeError("no writable directory for plan-specialised kernels")
+
+
+def prepare(kind: str, descs: Sequence, opts: Optional[dict] = None, compile_missing: bool = True,
+            workers: Optional[int] = None) -> List[Optional[Tuple[str, dict]]]:
+    """(code-object path, meta) per descriptor, None where the pass is not specialisable (or not compiled yet and
+    ``compile_missing`` is off).  Needs no GPU: __graft_entry__.build() pre-compiles the bench plans with it."""
+    import time
+
+    out: List[Optional[Tuple[str, dict]]] = [None] * len(descs)
+    jobs = []
+    for i, d in enumerate(descs):
+        try:
+            src, meta = _source(kind, d, opts)
+        except Unsupported:
+            STATS["unsupported"] += 1
+            continue
+        dg = pass_digest(kind, d, opts)
+        p = _find(dg)
+        if p is not None:
+            STATS["cache_hits"] += 1
+            out[i] = (p, meta)
+        elif compile_missing and have_compiler():
+            jobs.append((i, src, meta, os.path.join(_writable_dir(), dg + ".hsaco")))
+    if jobs:
+        t0 = time.perf_counter()
+        keep = bool(os.environ.get("TCMI_SPEC_KEEP"))
+        nw = workers or min(len(jobs), max(1, (os.cpu_count() or 2) - 1), 32)
+        with ThreadPoolExecutor(max_workers=nw) as ex:
+            futs = [ex.submit(_compile, src, path, keep) for _, src, _, path in jobs]
+            for f in futs:
+                f.result()
+        for i, _src, meta, path in jobs:
+            out[i] = (path, meta)
+        STATS["compiled"] += len(jobs)
+        STATS["compile_s"] += time.perf_counter() - t0
+    return out
+
+
+def load(path: str, meta: dict) -> SpecKernel:
+    import ctypes
+
+    from . import _lib
+
+    with _LOCK:
+        k = _LOADED.get(path)
+        if k is None:
+            h = ctypes.c_void_p()
+            _lib.check(_lib.lib().tcmi_spec_load(path.encode(), b"tcmi_spec_pass", int(meta["lds"]), ctypes.byref(h)),
+                       "tcmi_spec_load")
+            k = SpecKernel(h, meta, path)
+            _LOADED[path] = k
+        return k
+
+
+class PassSet:
+    """The specialised kernels of one list of pass descriptors (a forward plan or a reverse sweep), resolved lazily:
+    cached code objects are loaded at the first call, missing ones are compiled once the plan is hot."""
+
+    def __init__(self, kind: str, descs: Sequence, n_exec: int, opts: Optional[dict] = None):
+        self.kind, self.descs, self.n_exec, self.opts = kind, [np.asarray(d) for d in descs], n_exec, opts
+        self.kernels: List[Optional[SpecKernel]] = [None] * len(self.descs)
+        self.calls = 0
+        self.state = "new"       # new -> cached (hits loaded, misses pending) -> done
+        self.hot = int(os.environ.get("TCMI_SPEC_HOT", "3"))
+        self.min_n = int(os.environ.get("TCMI_SPEC_MIN_N", "22"))
+
+    def get(self) -> List[Optional[SpecKernel]]:
+        m = mode()
+        if m == "0" or self.state == "done":
+            return self.kernels if m != "0" else [None] * len(self.descs)
+        self.calls += 1
+        if self.state == "new":
+            for i, r in enumerate(prepare(self.kind, self.descs, self.opts, compile_missing=False)):
+                if r is not None:
+                    self.kernels[i] = load(*r)
+            self.state = "cached"
+            if all(k is not None for k in self.kernels):
+                self.state = "done"
+                return self.kernels
+        want = m == "1" or (self.calls >= self.hot and self.n_exec >= self.min_n)
+        if want:
+            for i, r in enumerate(prepare(self.kind, self.descs, self.opts, compile_missing=True)):
+                if r is not None and self.kernels[i] is None:
+                    self.kernels[i] = load(*r)
+            self.state = "done"
+        return self.kernels
+
+
+_EMITTERS["forward"] = forward_source
+
+
+def precompile_circuit(c, adjoint: bool = True, forward: bool = True) -> dict:
+    """Compile (into the cache) the specialised kernels of the plans the executor will choose for circuit ``c``: the
+    forward passes and, with ``adjoint``, the reverse sweep that a traced value_and_grad runs (short sweep, last pass
+    without write-back).  Host work only -- no GPU needed (hipcc cross-compiles)."""
+    from . import cons
+    from . import executor as X
+
+    gates, nparams = c._gate_records(), len(c._params)
+    n_exec, cfg, plan, eg = X.choose_plan(c._nqubits, gates, nparams, cons.dtypestr, cons._plan_options)
+    res = {"n_exec": n_exec, "forward": None, "adjoint": None}
+    if cfg.gen < 2 or cons.dtypestr != "complex64":
+        return res
+    if forward:
+        res["forward"] = [r is not None for r in prepare("forward", plan.descs)]
+    if adjoint and "adjoint" in _EMITTERS:
+        for full in (False, True):
+            r = X.choose_adjoint_plan(eg, n_exec, cons.dtypestr, full)
+            if r is None:
+                continue
+            acfg, ap = r
+            if acfg.gen < 2:
+                continue
+            descs = [np.asarray(d) for d in ap.descs]
+            out = [x is not None for x in prepare("adjoint", descs)]
+            if not full and descs:
+                last = descs[-1].copy()
+                last[6] = last[6] | P.FLAG_NOSTORE
+                out.append(prepare("adjoint", [last])[0] is not None)
+            res["adjoint" if not full else "adjoint_full"] = out
+    return res
