@@ -378,9 +378,29 @@ class CompiledCircuit:
                     w[6] = w[6] | P.FLAG_NOSTORE
                     adj["last_nostore"] = w
                 descs = list(descs[:-1]) + [adj["last_nostore"]]
+            spec = [None] * len(descs)
+            if cfg.gen == 2 and self.dtypestr == "complex64":
+                # plan-specialised straight-line kernels where they exist (tcmi/specialize.py); the interpreter otherwise
+                skey = "spec_nostore" if nostore else "spec"
+                if adj.get(skey) is None:
+                    nd = [np.asarray(d) for d in adj["plan"].descs]
+                    if nostore:
+                        nd[-1] = nd[-1].copy()
+                        nd[-1][6] |= P.FLAG_NOSTORE
+                    adj[skey] = S.PassSet("adjoint", nd, self.n_exec, S.adjoint_opts(cfg))
+                spec = adj[skey].get()
             tm = _timed("adjoint", len(descs), (len(descs) * 4.0 - (2.0 if nostore else 0.0)) * nb * nel * item)
             tm.__enter__()
-            for d in descs:
+            for d, k in zip(descs, spec):
+                if k is not None:
+                    _lib.check(
+                        lib.tcmi_spec_run_adjoint_pass(
+                            k.handle, a.data_ptr(), lam.data_ptr(), nel, nb, self.n_exec, cfg.T, cfg.LT,
+                            adj["ctab"].data_ptr(), ptab.data_ptr(), ptab.stride(0), gout.data_ptr(), gout.stride(0),
+                            ATOMIC_COPIES, gout.stride(1), stream),
+                        "tcmi_spec_run_adjoint_pass",
+                    )
+                    continue
                 _lib.check(
                     lib.tcmi_run_adjoint_pass(
                         a.data_ptr(), lam.data_ptr(), nel, nb, self.n_exec, cfg.R, cfg.LT, d.data_ptr(),

@@ -34,8 +34,6 @@ import numpy as np
 
 from . import plan as P
 
-GEN_VERSION = 1           # bump when the emitted code changes (part of the cache key)
-
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 CACHE_DIR = os.environ.get("TCMI_SPEC_CACHE") or os.path.join(CSRC, "plancache")
@@ -197,16 +195,24 @@ class _Emitter:
         return ["  const uint32_t tid = threadIdx.x;", "  const uint32_t bx = blockIdx.x;",
                 f"  const uint32_t wg_base = {_deposit_expr('bx', pairs)};"]
 
-    def thread_xor(self, out: List[str], name: str, masks: Sequence[int], shift: int = 0):
+    def local_tid(self, out: List[str]) -> str:
+        """A copy of the thread index the optimiser cannot see through: index arithmetic derived from it is computed
+        where it is written instead of being merged with the other exchanges' and kept alive from the top of the kernel
+        (20 spilled VGPRs in a 9-round pass)."""
+        t = self.fresh("tid")
+        out.append(f'  uint32_t {t} = tid; asm volatile("" : "+v"({t}));')
+        return t
+
+    def thread_xor(self, out: List[str], name: str, masks: Sequence[int], shift: int = 0, tid: str = "tid"):
         """uint32_t name = XOR of masks[i] << shift over the set bits of tid."""
         pairs = [(i, m.bit_length() - 1 + shift) for i, m in enumerate(masks) if m and (m & (m - 1)) == 0]
         multi = [(i, m) for i, m in enumerate(masks) if m and (m & (m - 1)) != 0]
         if not multi:
-            out.append(f"  const uint32_t {name} = {_deposit_expr('tid', pairs)};")
+            out.append(f"  const uint32_t {name} = {_deposit_expr(tid, pairs)};")
             return
-        out.append(f"  uint32_t {name} = {_deposit_expr('tid', pairs)};")
+        out.append(f"  uint32_t {name} = {_deposit_expr(tid, pairs)};")
         for i, m in multi:
-            out.append(f"  {name} ^= (0u - ((tid >> {i}) & 1u)) & {(m << shift):#x}u;")
+            out.append(f"  {name} ^= (0u - (({tid} >> {i}) & 1u)) & {(m << shift):#x}u;")
 
     def tile_io(self, out: List[str], rd: _Round, store: bool, ptrs: Dict[str, str], tphys: str):
         """16-byte accesses, two amplitudes each (register bit 0 = the lowest physical bit of the tile)."""
@@ -214,6 +220,10 @@ class _Emitter:
         if rd.reg_phys[0] != 1 or self.tile_bits[0] != 0:
             raise Unsupported("register bit 0 is not physical bit 0 in the load / store layout")
         toff = self.fresh("toff")
+        if store:
+            tp2 = self.fresh("tps")
+            out.append(f'  uint32_t {tp2} = {tphys}; asm volatile("" : "+v"({tp2}));')
+            tphys = tp2
         out.append(f"  const {tt} {toff} = ({tt}){tphys} * 8u;")
         for vec in self.vectors:
             base = self.fresh("gb")
@@ -253,9 +263,10 @@ class _Emitter:
         sg = self.seg(f"exchange {k} -> {k + 1}")
         out = sg.parts[0]
         ws, rs, tpn = self.fresh("ws"), self.fresh("rs"), self.fresh("tph")
-        self.thread_xor(out, ws, wr.thr_wr, sh)
-        self.thread_xor(out, rs, rdn.thr_rd, sh)
-        self.thread_xor(out, tpn, rdn.thr_phys)
+        lt = self.local_tid(out)
+        self.thread_xor(out, ws, wr.thr_wr, sh, lt)
+        self.thread_xor(out, rs, rdn.thr_rd, sh, lt)
+        self.thread_xor(out, tpn, rdn.thr_phys, 0, lt)
         wplan = self.exchange_plan(wr.reg_wr, wr.thr_wr)
         rplan = self.exchange_plan(rdn.reg_rd, rdn.thr_rd)
         ctype = "float" if elem_bytes == 4 else "v2f"
@@ -295,6 +306,13 @@ class _Emitter:
         return sg
 
     # ---- shared op pieces ----------------------------------------------------------------------------
+    def sign_update(self, sg: "Seg", expr: str):
+        """sgn ^= sign bit of a shear record.  The asm fence keeps the update where it is written: left alone, the compiler
+        defers the whole xor chain to the end of the pass and keeps every record alive until then (250 spilled SGPRs)."""
+        if getattr(self, "nostore", False):
+            return          # nobody reads psi / lambda after this pass: the sign is never applied
+        sg.parts[0].append(f'  sgn ^= __float_as_uint({expr}) & 0x80000000u; asm volatile("" : "+s"(sgn));')
+
     def pairs_of(self, J: int):
         B = 1 << J
         return [(_ins0(g, J), _ins0(g, J) | B) for g in range(self.NR // 2)]
@@ -379,7 +397,7 @@ class _Forward(_Emitter):
             sg = self.seg(f"gate on register bit {J}")
             if sh:
                 self.load_v2(sg.loads, c, off, 2)
-                sg.loads.append(f"  sgn ^= __float_as_uint({c}_1.x) & 0x80000000u;")
+                self.sign_update(sg, f"{c}_1.x")
                 if kind == 2:
                     # two shears + the third unless the builder chose the two-shear form for this batch element (the
                     # skip is inside the asm body: the pass stays one basic block)
@@ -569,11 +587,11 @@ def _support_digest() -> bytes:
     return _SRC_DIGEST
 
 
-def pass_digest(kind: str, words, opts: Optional[dict] = None) -> str:
+def pass_digest(src: str) -> str:
+    """Cache key of a generated kernel: its source text + the included bodies + the compiler flags."""
     h = hashlib.blake2b(digest_size=16)
-    h.update(f"{GEN_VERSION}|{kind}|{sorted((opts or {}).items())!r}|".encode())
     h.update(_support_digest())
-    h.update(np.ascontiguousarray(np.asarray(words).view(np.int32)).tobytes())
+    h.update(src.encode())
     return h.hexdigest()
 
 
@@ -654,7 +672,7 @@ def prepare(kind: str, descs: Sequence, opts: Optional[dict] = None, compile_mis
         except Unsupported:
             STATS["unsupported"] += 1
             continue
-        dg = pass_digest(kind, d, opts)
+        dg = pass_digest(src)
         p = _find(dg)
         if p is not None:
             STATS["cache_hits"] += 1
@@ -729,6 +747,11 @@ class PassSet:
 _EMITTERS["forward"] = forward_source
 
 
+def adjoint_opts(cfg) -> dict:
+    """Emitter options of a reverse-sweep plan (part of the cache key)."""
+    return {"shear2": bool(cfg.shear2)}
+
+
 def precompile_circuit(c, adjoint: bool = True, forward: bool = True) -> dict:
     """Compile (into the cache) the specialised kernels of the plans the executor will choose for circuit ``c``: the
     forward passes and, with ``adjoint``, the reverse sweep that a traced value_and_grad runs (short sweep, last pass
@@ -752,10 +775,279 @@ def precompile_circuit(c, adjoint: bool = True, forward: bool = True) -> dict:
             if acfg.gen < 2:
                 continue
             descs = [np.asarray(d) for d in ap.descs]
-            out = [x is not None for x in prepare("adjoint", descs)]
+            out = [x is not None for x in prepare("adjoint", descs, adjoint_opts(acfg))]
             if not full and descs:
                 last = descs[-1].copy()
                 last[6] = last[6] | P.FLAG_NOSTORE
-                out.append(prepare("adjoint", [last])[0] is not None)
+                out.append(prepare("adjoint", [last], adjoint_opts(acfg))[0] is not None)
             res["adjoint" if not full else "adjoint_full"] = out
     return res
+
+
+# ======================================================================================================
+#  reverse-sweep pass  (mirror of adjoint2_kernel, csrc/tcmi_adjoint2.hip)
+# ======================================================================================================
+class _Adjoint(_Forward):
+    """psi (a*) is un-computed and lambda (l*) propagated through U^dagger gate by gate; every parametrised gate and
+    diagonal term leaves one gradient EVENT = a per-lane partial sum.  Events are static here, so
+      * they are reduced over the wave four at a time (wave_sum4_uniform) and parked in lanes of accumulator registers
+        (v_writelane) -- no LDS atomics, no slot bookkeeping at run time;
+      * the Walsh-Hadamard transform of w = Im(conj(lambda) psi) is written as plain float code: only the outputs some
+        event reads are live, the compiler drops the rest of the butterfly;
+      * the accumulators of the workgroup's waves meet in LDS once, at the end of the pass: one f64 atomic per event."""
+
+    def __init__(self, words, opts=None):
+        _Emitter.__init__(self, words, ["a", "l"], opts)
+        if self.R < 4:
+            raise Unsupported("R < 4")
+        if self.opts.get("shear2"):
+            raise Unsupported("two-shear rotations in the reverse sweep")
+        self.events: List[int] = []          # gradient slot of event e
+        self.pending: List[Tuple[str, int]] = []   # (per-lane float expression, slot) not reduced yet
+        self.nostore = bool(self.flags & P.FLAG_NOSTORE)
+
+    # ---- gradient events ---------------------------------------------------------------------------------
+    def event(self, sg: Seg, expr: str, slot: int):
+        v = self.fresh("gv")
+        sg.parts[-1].append(f"  const float {v} = {expr};")
+        self.pending.append((v, slot))
+        if len(self.pending) == 4:
+            self.reduce_pending(sg.parts[-1])
+
+    def reduce_pending(self, out: List[str]):
+        if not self.pending:
+            return
+        names = []
+        for v, _ in self.pending:
+            m = self.fresh("gs")
+            out.append(f"  float {m} = {v};")
+            names.append(m)
+        while len(names) < 4:
+            z = self.fresh("gz")
+            out.append(f"  float {z} = 0.f;")
+            names.append(z)
+        if len(self.pending) == 1:
+            out.append(f"  {names[0]} = wave_sum_uniform({names[0]});")
+        elif len(self.pending) == 2:
+            out.append(f"  wave_sum2_uniform({names[0]}, {names[1]}, (int)lane);")
+        else:
+            out.append(f"  wave_sum4_uniform({names[0]}, {names[1]}, {names[2]}, {names[3]}, (int)lane);")
+        for (v, slot), m in zip(self.pending, names):
+            e = len(self.events)
+            self.events.append(slot)
+            acc = f"gacc{e // 64}"
+            out.append(f'  asm("v_writelane_b32 %0, %1, {e % 64}" : "+v"({acc}) : "s"(__float_as_int({m})));')
+        self.pending = []
+
+    # ---- ops ---------------------------------------------------------------------------------------------
+    def g1m(self, q: int) -> int:
+        w, R = self.w, self.R
+        mk, ubase, kmask, kbase = int(w[q + 1]), int(w[q + 2]), int(w[q + 3]), int(w[q + 4])
+        for J in range(R):
+            if not (mk >> J) & 1:
+                continue
+            kd = (mk >> (8 + 2 * J)) & 3
+            sh = (mk >> (P.SHEAR_SHIFT + J)) & 1
+            sg = self.seg(f"U^dagger on register bit {J}")
+            u = self.fresh("u")
+            pr = self.pairs_of(J)
+            if (kmask >> J) & 1:
+                k = self.fresh("k")
+                self.load_v2(sg.loads, k, kbase + 8 * J, 4)
+                fn = {2: "vm2_grad4_rx", 1: "vm2_grad4_real", 0: "vm2_grad4_gen"}.get(kd)
+                if fn is None:
+                    raise Unsupported("generator class 3")
+                accs = []
+                p = sg.parts[-1]
+                for g in range(0, len(pr), 4):
+                    c0, c1 = self.fresh("gc"), self.fresh("gc")
+                    accs += [c0, c1]
+                    p.append(f"  v2f {c0} = {{0.f, 0.f}}, {c1} = {{0.f, 0.f}};")
+                    av = ", ".join(f"{self.A(x, 'a')}, {self.A(y, 'a')}" for x, y in pr[g:g + 4])
+                    lv = ", ".join(f"{self.A(x, 'l')}, {self.A(y, 'l')}" for x, y in pr[g:g + 4])
+                    kk = f", {k}_0, {k}_1, {k}_2, {k}_3" if kd == 0 else ""
+                    p.append(f"  {fn}({av}, {lv}{kk}, {c0}, {c1});")
+                s0 = " + ".join(f"({c}.x + {c}.y)" for c in accs[0::2])
+                s1 = " + ".join(f"({c}.x + {c}.y)" for c in accs[1::2])
+                if kd == 2:      # K = i kappa X, kappa = Im K01
+                    expr = f"-{k}_1.y * (({s0}) + ({s1}))"
+                elif kd == 1:    # real antisymmetric K
+                    expr = f"{k}_1.x * ({s0}) + {k}_2.x * ({s1})"
+                else:
+                    expr = f"({s0}) + ({s1})"
+                self.event(sg, expr, int(w[q + 5 + J]))
+                sg.new_part()
+            if sh:
+                self.load_v2(sg.loads, u, ubase + 8 * J, 2)
+                self.sign_update(sg, f"{u}_1.x")
+                fn = {2: "vm2_shear8_rx", 1: "vm2_shear8_real"}.get(kd)
+                if fn is None:
+                    raise Unsupported("shear form of a general gate")
+                tail = f"{u}_0"
+            else:
+                self.load_v2(sg.loads, u, ubase + 8 * J, 4)
+                fn = {0: "vm2_gate8_gen", 1: "vm2_gate8_real", 2: "vm2_gate8_rx"}.get(kd)
+                if fn is None:
+                    raise Unsupported("gate class 3")
+                tail = f"{u}_0, {u}_1, {u}_2, {u}_3"
+            for vec in ("a", "l"):
+                for cl in self.calls8(fn, J, vec, tail):
+                    sg.new_part().append(cl)
+        return q + 5 + R
+
+    def diagf(self, q: int) -> int:
+        w, R, NR = self.w, self.R, self.NR
+        cslot, hasC, nB, nA, nsel = (_i32(w[q + 1]), int(w[q + 2]), int(w[q + 3]), int(w[q + 4]), int(w[q + 5]))
+        gsc = [_i32(w[q + 9 + k]) for k in range(NR)]
+        qq = q + 9 + NR
+        Bs = [(int(w[qq + 4 * e]), _u32(w[qq + 4 * e + 1]), _i32(w[qq + 4 * e + 2]), _i32(w[qq + 4 * e + 3])) for e in range(nB)]
+        qq += 4 * nB
+        As = [(_u32(w[qq + 2 * e]), _i32(w[qq + 2 * e + 1])) for e in range(nA)]
+        qn = qq + 2 * nA
+        need_w = ((hasC & 1) and any(g >= 0 for g in gsc[1:])) or any(b[3] >= 0 for b in Bs) or any(a_[1] >= 0 for a_ in As)
+        sg = self.seg("diagonal flush: gradients")
+        p = sg.parts[-1]
+        wn = None
+        if need_w:
+            # w[r] = Im(conj(lambda[r]) psi[r]); its Walsh-Hadamard transform holds every term's signed sum.  Plain float
+            # code: the outputs nobody reads (and the butterflies that only feed them) are dropped by the compiler.
+            wn = self.fresh("w")
+            for h in range(0, NR, 8):
+                ts = [f"{wn}t{h + i}" for i in range(8)]
+                p.append("  v2f " + ", ".join(ts) + ";")
+                p.append("  vm2_cross8(" + ", ".join(self.A(h + i, "a") for i in range(8)) + ", "
+                         + ", ".join(self.A(h + i, "l") for i in range(8)) + ", " + ", ".join(ts) + ");")
+            cur = [f"({wn}t{r}.x - {wn}t{r}.y)" for r in range(NR)]
+            for j in range(R):
+                nxt = list(cur)
+                for r in range(NR):
+                    if not (r >> j) & 1:
+                        lo, hi = cur[r], cur[r | (1 << j)]
+                        a_, b_ = f"{wn}_{j}_{r}", f"{wn}_{j}_{r | (1 << j)}"
+                        p.append(f"  const float {a_} = {lo} + {hi}, {b_} = {lo} - {hi};")
+                        nxt[r], nxt[r | (1 << j)] = a_, b_
+                cur = nxt
+            W = cur
+            if hasC & 1:
+                for k3 in range(1, NR):
+                    if gsc[k3] >= 0:
+                        self.event(sg, W[k3], gsc[k3])
+            tix = self.fresh("ti")
+            if Bs or As:
+                p = sg.parts[-1]
+                p.append(f"  const uint32_t {tix} = wg_base | {self.tphys};")
+            for (jj, mask, slot, gs) in Bs:
+                if gs >= 0:
+                    self.event(sg, f"(__builtin_popcount({tix} & {mask:#x}u) & 1) ? -{W[1 << jj]} : {W[1 << jj]}", gs)
+            for (mask, gs) in As:
+                if gs >= 0:
+                    self.event(sg, f"(__builtin_popcount({tix} & {mask:#x}u) & 1) ? -{W[0]} : {W[0]}", gs)
+        # conjugate table multiply of both vectors
+        if cslot >= 0:
+            pre: List[str] = []
+            v = self.wave_variant(pre, q + 6, nsel) if nsel > 0 else "0u"
+            twin = (hasC >> 1) & 1
+            base = f"ptab + {cslot} + {2 * NR} * {v}"
+            if not twin:
+                self.table_mul(pre, base, "vm2_cmul8s_conj", ("a", "l"))
+            else:
+                self.table_mul(pre, base, "vm2_cmul8s_conj", ("a",))
+                self.table_mul([], f"{base} + {2 * (NR << nsel)}", "vm2_cmul8s_conj", ("l",))
+        # register-x-thread terms with their own factor: the inverse phase (cs - i ys on z = +1) on both vectors
+        for (jj, mask, slot, gs) in Bs:
+            if slot < 0:
+                continue
+            sg2 = self.seg(f"DIAGF B term bit {jj}")
+            e, t = self.fresh("e"), self.fresh("b")
+            sg2.loads.append(f"  const float {t}c = ptab[{slot}], {t}s = ptab[{slot + 1}];")
+            sg2.parts[0].append(f"  v2f {e}; {e}.x = {t}c; {e}.y = (__builtin_popcount((wg_base | {self.tphys}) & {mask:#x}u) & 1) "
+                                f"? {t}s : -{t}s;")
+            self.diagb_apply(sg2, jj, e, ("a", "l"))
+        return qn
+
+    def op(self, q: int) -> int:
+        op = int(self.w[q])
+        if op == P.OP_G1M:
+            return self.g1m(q)
+        if op == P.OP_DIAGF:
+            return self.diagf(q)
+        raise Unsupported(f"backward op {op}")
+
+    def lds_bytes(self) -> int:
+        return max(8 << self.T, 4 * 64 * (1 << (self.LT - 6)) * max(1, (len(self.events) + 63) // 64))
+
+    def source(self, kname: str) -> str:
+        NR = self.NR
+        params = ("v2f* __restrict__ psi, v2f* __restrict__ lam, long long state_stride, const float* __restrict__ ctab_g, "
+                  "const float* __restrict__ ptab_g, long long ptab_stride, double* __restrict__ gout, "
+                  "long long gout_stride, int gcopies, int pad_, long long gcopy_stride")
+        pro = ["  extern __shared__ __attribute__((aligned(16))) char lb_[];",
+               "  char LDS_AS* const lb = (char LDS_AS*)lb_;",
+               "  psi += (long long)blockIdx.y * state_stride;",
+               "  lam += (long long)blockIdx.y * state_stride;",
+               "  gout += (long long)blockIdx.y * gout_stride + (long long)(blockIdx.x % (unsigned)gcopies) * gcopy_stride;",
+               "  const KF ctab = (KF)ctab_g; (void)ctab; (void)pad_;",
+               "  const KF ptab = (KF)(ptab_g + (long long)blockIdx.y * ptab_stride);"]
+        pro += self.index_lines()
+        pro.append("  const uint32_t lane = tid & 63u;")
+        pro.append("  v2f " + ", ".join(f"a{r}" for r in range(NR)) + ";")
+        pro.append("  v2f " + ", ".join(f"l{r}" for r in range(NR)) + ";")
+        pro.append("  uint32_t sgn = 0u;")
+        rd0 = self.rounds[0]
+        sg = self.seg("tile load")
+        self.tphys = self.fresh("tph")
+        self.thread_xor(sg.parts[0], self.tphys, rd0.thr_phys)
+        self.tile_io(sg.parts[0], rd0, False, {"a": "psi", "l": "lam"}, self.tphys)
+        for k, rd in enumerate(self.rounds):
+            q = rd.ops_at
+            for _ in range(rd.nops):
+                q = self.op(q)
+            if q != rd.ops_at + rd.nwords:
+                raise Unsupported("descriptor length mismatch")
+            if k == self.nrounds - 1:
+                break
+            self.exchange(k, [("a", ""), ("l", "")], 8)
+        sg = self.seg("gradient sums")
+        p = sg.parts[0]
+        self.reduce_pending(p)
+        nev = len(self.events)
+        nacc = (nev + 63) // 64
+        NW = 1 << (self.LT - 6)
+        if nev:
+            # the waves' accumulators meet in LDS (the exchange buffer is free now): one f64 atomic per event
+            p.append("  __syncthreads();")
+            p.append("  { float LDS_AS* const gl = (float LDS_AS*)lb;")
+            for k in range(nacc):
+                p.append(f"    gl[({k * NW}u + (tid >> 6)) * 64u + lane] = __int_as_float(gacc{k});")
+            p.append("    __syncthreads();")
+            p.append(f"    for (uint32_t e = tid; e < {nev}u; e += {1 << self.LT}u) {{")
+            p.append("      float s = 0.f;")
+            p.append(f"      for (uint32_t w_ = 0; w_ < {NW}u; ++w_) s += gl[((e >> 6) * {NW}u + w_) * 64u + (e & 63u)];")
+            p.append("      atomicAdd(gout + tcmi_spec_slots[e], (double)s);")
+            p.append("    }")
+            p.append("  }")
+        if not self.nostore:
+            sg = self.seg("sign + tile store")
+            p = sg.parts[0]
+            for vec in ("a", "l"):
+                for r in range(0, NR, 16):
+                    p.append("  vm2_negate16_if(" + ", ".join(self.A(r + i, vec) for i in range(16)) + ", sgn);")
+            self.tile_io(p, self.rounds[-1], True, {"a": "psi", "l": "lam"}, self.tphys)
+        body = self.linear()
+        pro += [f"  int gacc{k} = 0;" for k in range(nacc)]
+        head = self.header(kname, params)
+        if nev:
+            # before the kernel: the events' gradient slots
+            i = head.index("")
+            head[i:i] = [f"__constant__ int tcmi_spec_slots[{nev}] = {{{', '.join(str(s) for s in self.events)}}};"]
+        return "\n".join(head + pro + body + ["}"]) + "\n"
+
+
+def adjoint_source(words, kname: str = "tcmi_spec_pass", opts=None) -> Tuple[str, dict]:
+    """HIP source of the straight-line kernel of one reverse-sweep pass + its launch geometry."""
+    e = _Adjoint(words, opts)
+    src = e.source(kname)
+    return src, {"kind": "adjoint", "n": e.n, "T": e.T, "LT": e.LT, "lds": e.lds_bytes(), "events": len(e.events)}
+
+
+_EMITTERS["adjoint"] = adjoint_source
