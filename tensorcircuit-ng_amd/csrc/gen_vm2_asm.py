@@ -245,6 +245,30 @@ def gen_swap4():
 
 
 # ---- adjoint sweep (tcmi_adjoint2.hip): gradient inner products and conjugate phases ----------------------------
+def gen_grad4_init(name, kind):
+    """As gen_grad4, but the accumulators START here (first pair by v_pk_mul instead of a zeroed register + fma): the
+    plan-specialised sweep opens every gradient sum with this body and continues with the accumulating one."""
+    lines = []
+    for p in range(4):
+        if kind == "rx":
+            m3, m2 = "op_sel:[0,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]", "op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]"
+        else:
+            m3, m2 = "op_sel:[0,0,0] op_sel_hi:[1,1,1]", "op_sel:[0,0] op_sel_hi:[1,1]"
+        if p == 0:
+            lines.append(f"v_pk_mul_f32 %[c0], %[lx{p}], %[ay{p}] {m2}")
+            lines.append(f"v_pk_mul_f32 %[c1], %[ly{p}], %[ax{p}] {m2}")
+        else:
+            lines.append(f"v_pk_fma_f32 %[c0], %[lx{p}], %[ay{p}], %[c0] {m3}")
+            lines.append(f"v_pk_fma_f32 %[c1], %[ly{p}], %[ax{p}], %[c1] {m3}")
+    args = (", ".join(f"v2f ax{p}, v2f ay{p}" for p in range(4)) + ", " + ", ".join(f"v2f lx{p}, v2f ly{p}" for p in range(4))
+            + ", v2f& c0, v2f& c1")
+    outs = ['[c0] "=&v"(c0)', '[c1] "=&v"(c1)']
+    ins = []
+    for p in range(4):
+        ins += [f'[ax{p}] "v"(ax{p})', f'[ay{p}] "v"(ay{p})', f'[lx{p}] "v"(lx{p})', f'[ly{p}] "v"(ly{p})']
+    emit_named(name, args, lines, outs, ins, [], clobbers=())
+
+
 def gen_grad4(name, kind):
     """Accumulate the gradient inner product of one gate over four amplitude pairs (x = index with the gate's bit
     clear, y = set) of psi (ax, ay) and lambda (lx, ly); nothing is modified but the two accumulators.
@@ -342,6 +366,25 @@ def gen_shear23(name="vm2_shear23_8_rx"):
     emit_named(name, args, lines, outs, ['[p] "s"(p)', '[f] "s"(f)'], [], clobbers=("scc",))
 
 
+def gen_shear23l(name="vm2_shear23l_8_rx"):
+    """The cotangent's side of gen_shear23 (reverse sweep): the three-shear form of U^dagger unless bit 30 of `f` is set,
+    else the two shears in the other order (lower first; lambda carries the reciprocal factor diag(1/c, c), see
+    gen_shear8 steps="lambda")."""
+    fm = lambda D, A, P, C, hi=False: fma_im(D, A, P, C, hi=hi)  # noqa: E731
+    three, two = [], []
+    for p_ in range(8):
+        X, Y = f"%[x{p_}]", f"%[y{p_}]"
+        three.append([fm(X, Y, "%[p]", X, hi=False), fm(Y, X, "%[p]", Y, hi=True), fm(X, Y, "%[p]", X, hi=False)])
+        two.append([fm(Y, X, "%[p]", Y, hi=False), fm(X, Y, "%[p]", X, hi=True)])
+    lines = ["s_bitcmp1_b32 %[f], 30", "s_cbranch_scc1 2f"] + interleave(three[:4]) + interleave(three[4:])
+    lines += ["s_branch 3f", "2:"] + interleave(two[:4]) + interleave(two[4:]) + ["3:"]
+    args = ", ".join(f"v2f& x{p_}, v2f& y{p_}" for p_ in range(8)) + ", v2f p, uint32_t f"
+    outs = []
+    for p_ in range(8):
+        outs += [f'[x{p_}] "+v"(x{p_})', f'[y{p_}] "+v"(y{p_})']
+    emit_named(name, args, lines, outs, ['[p] "s"(p)', '[f] "s"(f)'], [], clobbers=("scc",))
+
+
 def gen_negate16_if():
     """a_k = -a_k for sixteen amplitudes when `f` is non-zero (the sign pulled out of the shear-form gates of a pass)."""
     lines = ["s_cmp_eq_u32 %[f], 0", "s_cbranch_scc1 1f"]
@@ -376,5 +419,8 @@ if __name__ == "__main__":
     gen_cmul8v_conj()
     gen_cmul8s_conj()
     gen_shear23()
+    gen_shear23l()
     gen_negate16_if()
+    gen_grad4_init("vm2_grad4i_rx", "rx")
+    gen_grad4_init("vm2_grad4i_real", "real")
     print("#endif")

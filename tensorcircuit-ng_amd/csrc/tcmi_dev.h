@@ -237,6 +237,33 @@ __device__ __forceinline__ void wave_sum4_uniform(float& a, float& b, float& c, 
   c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 2));
   d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r), 3));
 }
+// Eight wave-wide sums at once, NOT made uniform: afterwards every lane with lane % 8 == k holds the sum of v_k over the
+// whole wave.  Three folding steps (strides 1, 2, 4; 3 instructions each per pair of quantities), then the rest of the
+// butterfly on the one folded register: 29 VALU instructions for eight sums, no v_readlane / v_writelane.  The
+// plan-specialised reverse sweep (tcmi/specialize.py) parks the result in the lanes of an accumulator register
+// (park8) -- its gradient events are static, so lane e % 64 of accumulator e / 64 IS event e.
+__device__ __forceinline__ float fold_q2(float a, float b, bool hi) {  // lane bit 1 clear: a, set: b (partner = lane ^ 2)
+  const float keep = hi ? b : a, give = hi ? a : b;
+  return keep + dpp_get<0x4E>(give);
+}
+__device__ __forceinline__ float fold_r4(float a, float b, bool hi) {  // lane bit 2 clear: a, set: b (partner: row_ror 4)
+  const float keep = hi ? b : a, give = hi ? a : b;
+  return keep + dpp_get<0x124>(give);
+}
+__device__ __forceinline__ float wave_fold8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7,
+                                            int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+  const float r01 = fold2(v0, v1, b0), r23 = fold2(v2, v3, b0), r45 = fold2(v4, v5, b0), r67 = fold2(v6, v7, b0);
+  const float q0 = fold_q2(r01, r23, b1), q1 = fold_q2(r45, r67, b1);
+  float r = fold_r4(q0, q1, b2);   // lane % 8 = k: partial sum of v_k over the lanes {l, l ^ 1, l ^ 2, l ^ 3, ...} it met
+  r = dpp_add_c<0x128, 0xf>(r);    // row_ror 8: the other half of the row
+  return swap_add32(swap_add16(r));
+}
+// acc[lane] = r[lane] for the lanes of group G (lane >> 3 == G), unchanged elsewhere: one DPP move
+template <int G>
+__device__ __forceinline__ int park8(int acc, float r) {
+  return __builtin_amdgcn_update_dpp(acc, __float_as_int(r), 0xE4, 1 << (G >> 1), 3 << (2 * (G & 1)), false);
+}
 __device__ __forceinline__ void wave_sum2_uniform(double& a, double& b, int) {
   a = wave_sum<double>(a);
   b = wave_sum<double>(b);

@@ -24,6 +24,9 @@ from . import specialize as S
 # stream and logged as (tag, start, end, launches, algorithmic bytes or flops) -- the live per-kernel durations the
 # roofline figures are computed from.  None (default): no events are created.
 EVENT_LOG = None
+# scripts/gpu_spec_*.py: when a list, every pass launch of the reverse sweep is bracketed by its own pair of HIP events:
+# (pass index, start, end)
+PASS_EVENTS = None
 
 
 class _timed:
@@ -77,6 +80,8 @@ def pick_variant(n: int, dtypestr: str, opts: Optional[dict] = None) -> Tuple[in
         variants = [(4, 8), (3, 8), (2, 6)]
     if "R" in opts and "LT" in opts:
         variants = [(int(opts["R"]), int(opts["LT"]))] + variants
+    elif os.environ.get("TCMI_FWD_TILE"):       # experiment switch: "R,LT" of the gate passes
+        variants = [tuple(int(x) for x in os.environ["TCMI_FWD_TILE"].split(","))] + variants
     for R, LT in variants:
         if R + LT <= n_exec:
             low = int(opts.get("lowbits", 5))
@@ -391,7 +396,13 @@ class CompiledCircuit:
                 spec = adj[skey].get()
             tm = _timed("adjoint", len(descs), (len(descs) * 4.0 - (2.0 if nostore else 0.0)) * nb * nel * item)
             tm.__enter__()
-            for d, k in zip(descs, spec):
+            for ip, (d, k) in enumerate(zip(descs, spec)):
+                if PASS_EVENTS is not None:
+                    pe = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    if ip:
+                        PASS_EVENTS[-1][2].record()
+                    pe[0].record()
+                    PASS_EVENTS.append((ip, pe[0], pe[1]))
                 if k is not None:
                     _lib.check(
                         lib.tcmi_spec_run_adjoint_pass(
@@ -408,6 +419,8 @@ class CompiledCircuit:
                         gout.stride(0), ATOMIC_COPIES, gout.stride(1), self.code, int(cfg.gen == 2), stream),
                     "tcmi_run_adjoint_pass",
                 )
+            if PASS_EVENTS is not None and descs:
+                PASS_EVENTS[-1][2].record()
             tm.__exit__(None, None, None)
             if adj["nslots"]:
                 out[b0:b1].index_add_(1, adj["gparam"], gout.sum(1) * adj["gfactor"])
@@ -525,7 +538,9 @@ def pick_adjoint_variant(n_exec: int, dtypestr: str, gates) -> P.PlanConfig:
         # two-shear rotations in the reverse sweep: implemented and tested (TCMI_SHEAR2_BW=1), off by default -- the sweep
         # needs a second phase table for lambda (reciprocal real factors), whose scalar loads cost what the dropped
         # shears save (n = 28 d = 12: 28.8 vs 28.7 ms per pass)
-        sh2 = os.environ.get("TCMI_SHEAR2_BW", "0") == "1"
+        # ... in the INTERPRETING kernel.  The plan-specialised sweep prefetches its tables a segment ahead, so there the
+        # dropped shears are pure gain (16 of 64 packed instructions per eligible gate): on whenever specialisation is
+        sh2 = os.environ.get("TCMI_SHEAR2_BW", "1" if (S.mode() != "0" and n_exec >= S.MIN_N) else "0") == "1"
         if os.environ.get("TCMI_ADJ_R5"):   # experiment switch: 32 + 32 amplitude pairs per thread, 2 waves per SIMD
             return P.PlanConfig(R=5, LT=8, lowbits=5, vec=2, gen=2, shear2=sh2)
         if os.environ.get("TCMI_ADJ_LT9"):  # experiment switch: 512-thread workgroups, two per CU, 13 tile bits

@@ -173,27 +173,42 @@ class _Emitter:
     def linear(self) -> List[str]:
         out: List[str] = []
         segs = [s for s in self.segs if s.loads or any(s.parts)]
-        if segs:
-            out += segs[0].loads
+        pf = 1     # prefetch distance in segments (operand loads may name values defined by the segment right before)
+        sb = [] if self.opts.get("nosb") else [self.SB]
+        for s in segs[:pf]:
+            out += s.loads
         for i, s in enumerate(segs):
             parts = [p for p in s.parts if p] or [[]]
             out.append(f"  // -- {s.tag}")
             out += parts[0]
-            out.append(self.SB)
-            if i + 1 < len(segs) and segs[i + 1].loads:
-                out += segs[i + 1].loads
-                out.append(self.SB)
+            out += sb
+            if i + pf < len(segs) and segs[i + pf].loads:
+                out += segs[i + pf].loads
+                out += sb
             for p in parts[1:]:
                 out += p
-                out.append(self.SB)
+                out += sb
         return out
 
     # ---- prologue ------------------------------------------------------------------------------------
     def index_lines(self) -> List[str]:
         free = [p for p in range(self.n) if p not in self.tile_bits]
         pairs = [(i, p) for i, p in enumerate(free)]
-        return ["  const uint32_t tid = threadIdx.x;", "  const uint32_t bx = blockIdx.x;",
-                f"  const uint32_t wg_base = {_deposit_expr('bx', pairs)};"]
+        out = ["  const uint32_t tid = threadIdx.x;", "  const uint32_t bx = blockIdx.x;",
+               f"  const uint32_t wg_base = {_deposit_expr('bx', pairs)};"]
+        k = int(self.opts.get("stagger", 0))
+        if k > 0:
+            # Every workgroup of a pass does the same work, so the workgroups that share a CU run in lock step: all load,
+            # then all compute, then all store, and HBM time adds to VALU time instead of hiding behind it.  The first
+            # generation (the workgroups that find the chip empty) is therefore started out of phase, by wave slot; later
+            # workgroups inherit the offset of the one whose slot they take over.
+            slots = (1024 >> self.LT) * 256 * 4 >> 2       # workgroups of the first generation: all wave slots of the chip
+            out += [f"  if (blockIdx.y == 0 && bx < {slots}u) {{",
+                    "    uint32_t hw;",
+                    '    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));',
+                    f"    for (uint32_t i = (hw & 3u) * {k}u; i > 0; --i) __builtin_amdgcn_s_sleep(127);",
+                    "  }"]
+        return out
 
     def local_tid(self, out: List[str]) -> str:
         """A copy of the thread index the optimiser cannot see through: index arithmetic derived from it is computed
@@ -232,6 +247,13 @@ class _Emitter:
             for r in range(0, self.NR, 2):
                 c = _xor_const(rd.reg_phys, r) * 8
                 addr = f"{base} + {c:#x}ull + {toff}"
+                if self.opts.get("nomem"):     # timing experiment only (wrong results): the pass without its HBM traffic
+                    if not store:
+                        out.append(f'  asm volatile("v_mov_b32 %0, 0" : "=v"({self.A(r, vec)}.x)); {self.A(r, vec)}.y = 1.f; '
+                                   f'{self.A(r + 1, vec)} = {self.A(r, vec)};')
+                    elif r == 0:
+                        out.append(f"  if ({self.A(r, vec)}.x == 123.456f) *reinterpret_cast<v2f*>({addr}) = {self.A(r, vec)};")
+                    continue
                 if store:
                     v = self.fresh("sv")
                     out.append(f"  {{ v4f {v}; {v}.xy = {self.A(r, vec)}; {v}.zw = {self.A(r + 1, vec)}; "
@@ -292,6 +314,8 @@ class _Emitter:
                 out.append("  " + stmt(r, f"lb + {nm} + {c << sh}"))
 
         first = True
+        if self.opts.get("noexch"):      # timing experiment only (wrong results): what do the exchanges cost?
+            planes = []
         for vec, comp in planes:
             sfx = f".{comp}" if comp else ""
             walk(out, "wsd", ws, wplan, lambda r, ad: f"*({ctype} LDS_AS*)({ad}) = {self.A(r, vec)}{sfx};")
@@ -372,7 +396,7 @@ class _Emitter:
         ]
 
     def waves_per_eu(self) -> int:
-        return 1024 >> self.LT
+        return int(self.opts.get("waves", 1024 >> self.LT))
 
 
 # ======================================================================================================
@@ -513,7 +537,58 @@ class _Forward(_Emitter):
                 quad = lambda r: f"{self.A(r)}, {self.A(r | B)}, {self.A(r | A)}, {self.A(r | A | B)}"  # noqa: E731
                 (sg.parts[0] if g == 0 else sg.new_part()).append(f"  vm2_g2x2({quad(r0)}, {quad(r1)}, {ms});")
             return q + 4
+        if op == P.OP_DIAG:
+            return self.diag_generic(q)
         raise Unsupported(f"forward op {op}")
+
+    def diag_generic(self, q: int) -> int:
+        """General phase polynomial (thread-only terms, many register-x-thread terms: the final flush of a plan): per-thread
+        phases in turns, hardware sin / cos.  Same arithmetic, term by term, as the interpreting kernel (pass2_kernel,
+        OP_DIAG): double sums over the terms in descriptor order, float phases per register index."""
+        w, R, NR = self.w, self.R, self.NR
+        nA, nB, nC, base = int(w[q + 1]), int(w[q + 2]), int(w[q + 3]), int(w[q + 4])
+        qq = q + 5
+        mA = [_u32(w[qq + e]) for e in range(nA)]
+        qq += nA
+        mB = [_u32(w[qq + e]) for e in range(nB)]
+        jB = [int(w[qq + nB + e]) for e in range(nB)]
+        qq += 2 * nB
+        mC = [_u32(w[qq + e]) for e in range(nC)]
+        sg = self.seg("generic phase polynomial")
+        p = sg.parts[0]
+        t = self.fresh("dg")
+        p.append(f"  const uint32_t {t}i = wg_base | {self.tphys};")
+        p.append(f"  double {t}phi = 0.0;")
+        for e in range(nA):
+            p.append(f"  {{ const double c = (double)ptab[{base + e}]; {t}phi += (__builtin_popcount({t}i & {mA[e]:#x}u) & 1) ? -c : c; }}")
+        for j in range(R):
+            p.append(f"  double {t}c{j} = 0.0;")
+        for e in range(nB):
+            p.append(f"  {{ const double c = (double)ptab[{base + nA + e}]; "
+                     f"{t}c{jB[e]} += (__builtin_popcount({t}i & {mB[e]:#x}u) & 1) ? -c : c; }}")
+        p.append(f"  const float {t}p0 = (float)({t}phi - rint({t}phi));")
+        for j in range(R):
+            p.append(f"  const float {t}f{j} = (float)({t}c{j} - rint({t}c{j}));")
+        for e in range(nC):
+            p.append(f"  const float {t}k{e} = ptab[{base + nA + nB + e}];")
+        for h in range(0, NR, 8):
+            part = sg.new_part()
+            es = []
+            for i in range(8):
+                r = h + i
+                terms = [f"{t}p0"] + [("-" if (r >> j) & 1 else "+") + f" {t}f{j}" for j in range(R)]
+                # the interpreter adds the C terms one after the other to the running float phase
+                expr = "(" * (R + nC) + terms[0]
+                for x in terms[1:]:
+                    expr += f" {x})"
+                for e in range(nC):
+                    sgn = "-" if bin(r & mC[e]).count("1") & 1 else "+"
+                    expr += f" {sgn} {t}k{e})"
+                ev = f"{t}e{r}"
+                part.append(f"  v2f {ev}; {{ float sn, cs; sincos_turns<float>({expr}, &sn, &cs); {ev}.x = cs; {ev}.y = sn; }}")
+                es.append(ev)
+            part.append("  vm2_cmul8v(" + ", ".join(self.A(h + i) for i in range(8)) + ", " + ", ".join(es) + ");")
+        return qq + nC
 
     def source(self, kname: str) -> str:
         NR = self.NR
@@ -530,8 +605,15 @@ class _Forward(_Emitter):
         rd0 = self.rounds[0]
         sg = self.seg("tile load")
         self.tphys = self.fresh("tph")
+        trace = bool(self.opts.get("trace"))     # timing experiment: (start, tile arrived, compute done) per workgroup
+        if trace:
+            sg.parts[0].append("  unsigned long long* const trc = (unsigned long long*)ctab_g + 32ull * (bx + (unsigned long long)gridDim.x * blockIdx.y);")
+            sg.parts[0].append("  if (tid == 0) { trc[0] = wall_clock64(); unsigned hw; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\" : \"=s\"(hw)); trc[3] = hw; }")
         self.thread_xor(sg.parts[0], self.tphys, rd0.thr_phys)
         self.tile_io(sg.parts[0], rd0, False, {"a": "state"}, self.tphys)
+        if trace:
+            sg.parts[0].append('  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");')
+            sg.parts[0].append("  if (tid == 0) trc[1] = wall_clock64();")
         for k, rd in enumerate(self.rounds):
             q = rd.ops_at
             for _ in range(rd.nops):
@@ -540,10 +622,16 @@ class _Forward(_Emitter):
                 raise Unsupported("descriptor length mismatch")
             if k == self.nrounds - 1:
                 break
+            if trace and 4 + 2 * k < 30:
+                self.seg("trace").parts[0].append(f"  if (tid == 0) trc[{4 + 2 * k}] = wall_clock64();")
             self.exchange(k, [("a", "x"), ("a", "y")], 4)
+            if trace and 5 + 2 * k < 30:
+                self.seg("trace").parts[0].append(f"  if (tid == 0) trc[{5 + 2 * k}] = wall_clock64();")
         last = self.rounds[-1]
         sg = self.seg("sign + tile store")
         p = sg.parts[0]
+        if trace:
+            p.append("  if (tid == 0) trc[2] = wall_clock64();")
         for r in range(0, NR, 16):
             p.append("  vm2_negate16_if(" + ", ".join(self.A(r + i) for i in range(16)) + ", sgn);")
         self.tile_io(p, last, True, {"a": "state"}, self.tphys)
@@ -567,6 +655,9 @@ _SRC_DIGEST = None
 _LOCK = threading.Lock()
 _LOADED: Dict[str, "SpecKernel"] = {}
 STATS = {"compiled": 0, "cache_hits": 0, "unsupported": 0, "compile_s": 0.0}
+
+
+MIN_N = int(os.environ.get("TCMI_SPEC_MIN_N", "22"))   # 'auto': plans below this size are never compiled (cached ones still load)
 
 
 def mode() -> str:
@@ -606,7 +697,15 @@ _EMITTERS = {}
 
 
 def _source(kind: str, words, opts) -> Tuple[str, dict]:
-    return _EMITTERS[kind](words, "tcmi_spec_pass", opts)
+    opts = dict(opts or {})
+    if os.environ.get("TCMI_SPEC_STAGGER"):
+        opts["stagger"] = int(os.environ["TCMI_SPEC_STAGGER"])
+    for kv in filter(None, os.environ.get("TCMI_SPEC_EXP", "").split(",")):     # experiment knobs: "pf=2,noexch,waves=5"
+        k, _, v = kv.partition("=")
+        opts[k] = int(v) if v else 1
+    src, meta = _EMITTERS[kind](words, f"tcmi_spec_{kind}", opts)
+    meta["kernel"] = f"tcmi_spec_{kind}"
+    return src, meta
 
 
 def have_compiler() -> bool:
@@ -703,7 +802,7 @@ def load(path: str, meta: dict) -> SpecKernel:
         k = _LOADED.get(path)
         if k is None:
             h = ctypes.c_void_p()
-            _lib.check(_lib.lib().tcmi_spec_load(path.encode(), b"tcmi_spec_pass", int(meta["lds"]), ctypes.byref(h)),
+            _lib.check(_lib.lib().tcmi_spec_load(path.encode(), meta["kernel"].encode(), int(meta["lds"]), ctypes.byref(h)),
                        "tcmi_spec_load")
             k = SpecKernel(h, meta, path)
             _LOADED[path] = k
@@ -720,12 +819,20 @@ class PassSet:
         self.calls = 0
         self.state = "new"       # new -> cached (hits loaded, misses pending) -> done
         self.hot = int(os.environ.get("TCMI_SPEC_HOT", "3"))
-        self.min_n = int(os.environ.get("TCMI_SPEC_MIN_N", "22"))
 
     def get(self) -> List[Optional[SpecKernel]]:
         m = mode()
-        if m == "0" or self.state == "done":
-            return self.kernels if m != "0" else [None] * len(self.descs)
+        if m == "0":
+            return [None] * len(self.descs)
+        if self.state == "done":
+            return self.kernels
+        try:
+            import torch
+
+            if torch.cuda.is_current_stream_capturing():   # no module loads / compiler runs inside a hipGraph capture
+                return self.kernels
+        except Exception:  # noqa: BLE001
+            pass
         self.calls += 1
         if self.state == "new":
             for i, r in enumerate(prepare(self.kind, self.descs, self.opts, compile_missing=False)):
@@ -735,7 +842,7 @@ class PassSet:
             if all(k is not None for k in self.kernels):
                 self.state = "done"
                 return self.kernels
-        want = m == "1" or (self.calls >= self.hot and self.n_exec >= self.min_n)
+        want = m == "1" or (self.calls >= self.hot and self.n_exec >= MIN_N)
         if want:
             for i, r in enumerate(prepare(self.kind, self.descs, self.opts, compile_missing=True)):
                 if r is not None and self.kernels[i] is None:
@@ -800,43 +907,37 @@ class _Adjoint(_Forward):
         _Emitter.__init__(self, words, ["a", "l"], opts)
         if self.R < 4:
             raise Unsupported("R < 4")
-        if self.opts.get("shear2"):
-            raise Unsupported("two-shear rotations in the reverse sweep")
         self.events: List[int] = []          # gradient slot of event e
         self.pending: List[Tuple[str, int]] = []   # (per-lane float expression, slot) not reduced yet
         self.nostore = bool(self.flags & P.FLAG_NOSTORE)
 
     # ---- gradient events ---------------------------------------------------------------------------------
+    EVB = 8     # events reduced together (wave_fold8)
+
     def event(self, sg: Seg, expr: str, slot: int):
+        if self.opts.get("noevents"):    # timing experiment only (wrong results)
+            return
         v = self.fresh("gv")
         sg.parts[-1].append(f"  const float {v} = {expr};")
         self.pending.append((v, slot))
-        if len(self.pending) == 4:
+        if len(self.pending) == self.EVB:
             self.reduce_pending(sg.parts[-1])
 
     def reduce_pending(self, out: List[str]):
+        """Eight pending per-lane sums -> one folded register -> parked in lane group (batch % 8) of an accumulator:
+        lane e % 64 of gacc[e / 64] is event e (tcmi_dev.h wave_fold8 / park8)."""
         if not self.pending:
             return
-        names = []
-        for v, _ in self.pending:
-            m = self.fresh("gs")
-            out.append(f"  float {m} = {v};")
-            names.append(m)
-        while len(names) < 4:
-            z = self.fresh("gz")
-            out.append(f"  float {z} = 0.f;")
-            names.append(z)
-        if len(self.pending) == 1:
-            out.append(f"  {names[0]} = wave_sum_uniform({names[0]});")
-        elif len(self.pending) == 2:
-            out.append(f"  wave_sum2_uniform({names[0]}, {names[1]}, (int)lane);")
-        else:
-            out.append(f"  wave_sum4_uniform({names[0]}, {names[1]}, {names[2]}, {names[3]}, (int)lane);")
-        for (v, slot), m in zip(self.pending, names):
-            e = len(self.events)
+        names = [v for v, _ in self.pending] + ["0.f"] * (self.EVB - len(self.pending))
+        e0 = len(self.events)
+        assert e0 % self.EVB == 0
+        r = self.fresh("gr")
+        out.append(f"  const float {r} = wave_fold8({', '.join(names)}, (int)lane);")
+        out.append(f"  gacc{e0 // 64} = park8<{(e0 // 8) % 8}>(gacc{e0 // 64}, {r});")
+        for _v, slot in self.pending:
             self.events.append(slot)
-            acc = f"gacc{e // 64}"
-            out.append(f'  asm("v_writelane_b32 %0, %1, {e % 64}" : "+v"({acc}) : "s"(__float_as_int({m})));')
+        while len(self.events) % self.EVB:
+            self.events.append(-1)        # padding lane: nothing to add
         self.pending = []
 
     # ---- ops ---------------------------------------------------------------------------------------------
@@ -857,18 +958,18 @@ class _Adjoint(_Forward):
                 fn = {2: "vm2_grad4_rx", 1: "vm2_grad4_real", 0: "vm2_grad4_gen"}.get(kd)
                 if fn is None:
                     raise Unsupported("generator class 3")
-                accs = []
                 p = sg.parts[-1]
+                c0, c1 = self.fresh("gc"), self.fresh("gc")
+                p.append(f"  v2f {c0}, {c1};")
                 for g in range(0, len(pr), 4):
-                    c0, c1 = self.fresh("gc"), self.fresh("gc")
-                    accs += [c0, c1]
-                    p.append(f"  v2f {c0} = {{0.f, 0.f}}, {c1} = {{0.f, 0.f}};")
                     av = ", ".join(f"{self.A(x, 'a')}, {self.A(y, 'a')}" for x, y in pr[g:g + 4])
                     lv = ", ".join(f"{self.A(x, 'l')}, {self.A(y, 'l')}" for x, y in pr[g:g + 4])
                     kk = f", {k}_0, {k}_1, {k}_2, {k}_3" if kd == 0 else ""
-                    p.append(f"  {fn}({av}, {lv}{kk}, {c0}, {c1});")
-                s0 = " + ".join(f"({c}.x + {c}.y)" for c in accs[0::2])
-                s1 = " + ".join(f"({c}.x + {c}.y)" for c in accs[1::2])
+                    if g == 0 and kd == 0:
+                        p.append(f"  {c0} = v2f{{0.f, 0.f}}; {c1} = v2f{{0.f, 0.f}};")
+                    # the first group starts the two accumulators (v_pk_mul), the others add to them
+                    p.append(f"  {fn if (g or kd == 0) else fn.replace('grad4_', 'grad4i_')}({av}, {lv}{kk}, {c0}, {c1});")
+                s0, s1 = f"({c0}.x + {c0}.y)", f"({c1}.x + {c1}.y)"
                 if kd == 2:      # K = i kappa X, kappa = Im K01
                     expr = f"-{k}_1.y * (({s0}) + ({s1}))"
                 elif kd == 1:    # real antisymmetric K
@@ -891,7 +992,13 @@ class _Adjoint(_Forward):
                     raise Unsupported("gate class 3")
                 tail = f"{u}_0, {u}_1, {u}_2, {u}_3"
             for vec in ("a", "l"):
-                for cl in self.calls8(fn, J, vec, tail):
+                f2, t2 = fn, tail
+                if sh and kd == 2 and self.opts.get("shear2"):
+                    # the builder may have chosen the two-shear form for this batch element (flag word of the record):
+                    # psi gets two shears, lambda the two in the other order; the skip is inside the asm bodies
+                    f2 = "vm2_shear23_8_rx" if vec == "a" else "vm2_shear23l_8_rx"
+                    t2 = f"{u}_0, __float_as_uint({u}_1.y)"
+                for cl in self.calls8(f2, J, vec, t2):
                     sg.new_part().append(cl)
         return q + 5 + R
 
@@ -917,16 +1024,19 @@ class _Adjoint(_Forward):
                 p.append("  v2f " + ", ".join(ts) + ";")
                 p.append("  vm2_cross8(" + ", ".join(self.A(h + i, "a") for i in range(8)) + ", "
                          + ", ".join(self.A(h + i, "l") for i in range(8)) + ", " + ", ".join(ts) + ");")
-            cur = [f"({wn}t{r}.x - {wn}t{r}.y)" for r in range(NR)]
+            # the transform runs on the (re, im) PAIRS (packed adds: two transforms for the price of one), the difference
+            # t.x - t.y is taken only of the outputs that are read
+            cur = [f"{wn}t{r}" for r in range(NR)]
             for j in range(R):
                 nxt = list(cur)
                 for r in range(NR):
                     if not (r >> j) & 1:
                         lo, hi = cur[r], cur[r | (1 << j)]
                         a_, b_ = f"{wn}_{j}_{r}", f"{wn}_{j}_{r | (1 << j)}"
-                        p.append(f"  const float {a_} = {lo} + {hi}, {b_} = {lo} - {hi};")
+                        p.append(f"  const v2f {a_} = {lo} + {hi}, {b_} = {lo} - {hi};")
                         nxt[r], nxt[r | (1 << j)] = a_, b_
                 cur = nxt
+            cur = [f"({c}.x - {c}.y)" for c in cur]
             W = cur
             if hasC & 1:
                 for k3 in range(1, NR):
@@ -1023,7 +1133,8 @@ class _Adjoint(_Forward):
             p.append(f"    for (uint32_t e = tid; e < {nev}u; e += {1 << self.LT}u) {{")
             p.append("      float s = 0.f;")
             p.append(f"      for (uint32_t w_ = 0; w_ < {NW}u; ++w_) s += gl[((e >> 6) * {NW}u + w_) * 64u + (e & 63u)];")
-            p.append("      atomicAdd(gout + tcmi_spec_slots[e], (double)s);")
+            p.append("      const int sl = tcmi_spec_slots[e];")
+            p.append("      if (sl >= 0) atomicAdd(gout + sl, (double)s);")
             p.append("    }")
             p.append("  }")
         if not self.nostore:

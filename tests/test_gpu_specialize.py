@@ -1,0 +1,167 @@
+"""Plan-specialised pass kernels on the GPU (tcmi/specialize.py): every generated kernel is compared with the
+interpreting kernel it replaces (same descriptor, same tables: the states must agree to the last bit, gradients to
+summation order) and with the dense oracle."""
+
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dense, gates as G, workloads as W  # noqa: E402
+
+
+@pytest.fixture
+def tc64():
+    import tcmi as tc
+
+    tc.set_backend("hip")
+    tc.set_dtype("complex64")
+    old = os.environ.get("TCMI_SPECIALIZE")
+    yield tc
+    if old is None:
+        os.environ.pop("TCMI_SPECIALIZE", None)
+    else:
+        os.environ["TCMI_SPECIALIZE"] = old
+
+
+def _mixed(tc, n, seed):
+    rng = np.random.default_rng(seed)
+    c = tc.Circuit(n)
+    ops = []
+    for i in range(n):
+        c.h(i)
+        ops.append((G.H, [i]))
+    for layer in range(3):
+        for i in range(n - 1):
+            th = float(rng.uniform(0, 6))
+            c.rzz(i, i + 1, theta=th)
+            ops.append((G.rzz(th), [i, i + 1]))
+        for i in range(n):
+            th = float(rng.uniform(0, 6))
+            c.rx(i, theta=th)
+            ops.append((G.rx(th), [i]))
+        for i in range(layer, n, 3):
+            th = float(rng.uniform(0, 6))
+            c.ry(i, theta=th)
+            ops.append((G.ry(th), [i]))
+        a, b = int(rng.integers(0, n)), int(rng.integers(0, n - 1))
+        b = b if b < a else b + 1
+        c.cnot(a, b)
+        ops.append((G.CNOT, [a, b]))
+        c.swap(1, n - 2)
+        ops.append((G.SWAP, [1, n - 2]))
+        u = G.random_two_qubit_gate(5 + layer + seed)
+        c.any(3, 4 + layer, unitary=u)
+        ops.append((u, [3, 4 + layer]))
+        c.cz(2 + layer, 5)
+        ops.append((G.CZ, [2 + layer, 5]))
+    return c, ops
+
+
+def _state(tc, build, flag):
+    os.environ["TCMI_SPECIALIZE"] = flag
+    c = build()
+    cc = c._compiled()
+    for k in ("_spec_fwd",):
+        if hasattr(cc, k):
+            setattr(cc, k, None)
+    return tc.backend.numpy(c.wavefunction())
+
+
+@pytest.mark.parametrize("n,seed", [(13, 0), (14, 1), (16, 2), (18, 3)])
+def test_specialised_forward_passes_equal_the_interpreter_bit_for_bit(tc64, n, seed):
+    tc = tc64
+    from tcmi import specialize as S
+
+    tc.set_contractor("plain")      # the state-vector plan (the cut order has its own half-circuit plans)
+    try:
+        ref_ops = _mixed(tc, n, seed)[1]
+        a = _state(tc, lambda: _mixed(tc, n, seed)[0], "0")
+        before = S.STATS["compiled"] + S.STATS["cache_hits"]
+        b = _state(tc, lambda: _mixed(tc, n, seed)[0], "1")
+        assert S.STATS["compiled"] + S.STATS["cache_hits"] > before, "no specialised kernel was used"
+        assert np.array_equal(a, b), np.abs(a - b).max()
+        if n <= 16:
+            ref = dense.run(n, ref_ops)
+            assert np.abs(b - ref).max() < 1e-5
+    finally:
+        tc.set_contractor("greedy")
+
+
+@pytest.mark.parametrize("n,d", [(13, 2), (16, 3), (20, 4)])
+def test_specialised_reverse_sweep_matches_the_interpreter_and_the_oracle(tc64, n, d):
+    """HEA-B + TFIM value_and_grad: specialised sweep (forced) against the interpreting sweep; one gradient component
+    against a central difference of the dense oracle at n <= 16."""
+    tc = tc64
+    rng = np.random.default_rng(n)
+    params = rng.uniform(0, 2 * np.pi, [2 * d, n])
+
+    def energy(p):
+        c = tc.Circuit(n)
+        W.hea_b(c, n, d, p, zz=tc.gates._zz_matrix)
+        e = 0.0
+        for i in range(n):
+            e += -1.0 * c.expectation((tc.gates.x(), [i]))
+        for i in range(n - 1):
+            e += 1.0 * c.expectation((tc.gates.z(), [i]), (tc.gates.z(), [i + 1]))
+        return tc.backend.real(e)
+
+    res = {}
+    for flag in ("0", "1"):
+        os.environ["TCMI_SPECIALIZE"] = flag
+        from tcmi import executor as X
+
+        X._CACHE.clear()
+        pt = tc.backend.convert_to_tensor(params, dtype=tc.rdtypestr)
+        v, g = tc.backend.value_and_grad(energy)(pt)
+        res[flag] = (float(v), tc.backend.numpy(g))
+    assert abs(res["0"][0] - res["1"][0]) < 1e-5
+    assert np.abs(res["0"][1] - res["1"][1]).max() < 5e-6
+    if n <= 16:
+        eps = 1e-5
+        pp, pm = params.copy(), params.copy()
+        pp[1, 3] += eps
+        pm[1, 3] -= eps
+        fd = (W.tfim_energy_dense(dense.run(n, W.hea_b_ops(n, d, pp)), n)
+              - W.tfim_energy_dense(dense.run(n, W.hea_b_ops(n, d, pm)), n)) / (2 * eps)
+        assert abs(res["1"][1][1, 3] - fd) < 5e-4
+
+
+def test_specialised_kernels_under_vmap_and_jit(tc64):
+    """The bench's call shape, small: jit(vvag(energy)) over a batch; specialised against interpreted."""
+    tc = tc64
+    import torch
+
+    n, d, B = 14, 3, 4
+    params = torch.from_numpy(np.random.default_rng(5).normal(0, 0.5, [B, 2 * d, n]).astype(np.float32)).cuda()
+
+    def energy(p):
+        c = tc.Circuit(n)
+        for i in range(n):
+            c.h(i)
+        for j in range(d):
+            for i in range(n - 1):
+                c.exp1(i, i + 1, unitary=tc.gates._zz_matrix, theta=p[2 * j, i])
+            for i in range(n):
+                c.rx(i, theta=p[2 * j + 1, i])
+        e = 0.0
+        for i in range(n):
+            e += -1.0 * c.expectation((tc.gates.x(), [i]))
+        for i in range(n - 1):
+            e += 1.0 * c.expectation((tc.gates.z(), [i]), (tc.gates.z(), [i + 1]))
+        return tc.backend.real(e)
+
+    out = {}
+    for flag in ("0", "1"):
+        os.environ["TCMI_SPECIALIZE"] = flag
+        from tcmi import executor as X
+
+        X._CACHE.clear()
+        f = tc.backend.jit(tc.backend.vvag(energy, argnums=0, vectorized_argnums=0))
+        for _ in range(3):
+            v, g = f(params)
+        out[flag] = (v.cpu().numpy(), g.cpu().numpy())
+    assert np.abs(out["0"][0] - out["1"][0]).max() < 1e-5
+    assert np.abs(out["0"][1] - out["1"][1]).max() < 5e-6
