@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the tcmi hot path (BASELINE.json metric: amplitudes/sec).
 
-A "step" = one full ``Circuit.wavefunction`` contraction of a batch of HEA-B circuits (reference
+A "step" = the full ``Circuit.wavefunction`` contraction of a fixed GLOBAL batch of HEA-B circuits (reference
 ``templates/blocks.py:146-185`` ansatz, seeded random parameters, SURVEY.md section 8(d) config 2:
-24 qubits, depth 8, complex64) through the compiled tile-VM plan, with parameters and states
-resident in HBM.  One process per GPU; ranks run independent batches (vmap-batch sharding, no
-data-path collective), timing is max-over-ranks between barriers.  Rank 0 prints ONE JSON line.
+24 qubits, depth 8, complex64; 64 circuits per step, 8 per vmap call) through the compiled plan, with
+parameters and states resident in HBM.  One process per GPU; the global batch is sharded over the ranks in
+contiguous blocks (vmap-batch sharding, no data-path collective; "scaling": "strong" -- the total work does not
+grow with the number of GPUs), timing is max-over-ranks between barriers.  Rank 0 prints ONE JSON line.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python bench.py --gpus 8 --steps 20 --warmup 3        (starts its own 8 rank processes, see self_launch)
@@ -691,7 +692,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--qubits", type=int, default=24)
     ap.add_argument("--depth", type=int, default=8)
-    ap.add_argument("--batch", type=int, default=8, help="circuits per GPU per step (vmap batch)")
+    ap.add_argument("--batch", type=int, default=8, help="circuits per vmap call (micro-batch of the headline step)")
+    ap.add_argument("--global-batch", type=int, default=64,
+                    help="headline step = this many circuits contracted, whatever the number of GPUs (strong scaling): "
+                         "sharded over the ranks in contiguous blocks, each rank works through its block --batch at a time")
     ap.add_argument("--cpu-qubits", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--vqe-qubits", type=int, default=28, help="VQE leg (config 3): qubits; 0 disables the leg")
@@ -766,9 +770,20 @@ def main():
     tc.set_contractor(args.contractor, **opts)
     n, d, B = args.qubits, args.depth, args.batch
 
-    # synthetic parameters: SURVEY 8(d) config-2 generator, one independent row per batch element
-    rng = np.random.default_rng(n + 1000 * rank)
-    params = torch.from_numpy(rng.uniform(0, 2 * np.pi, [B, 2 * d, n]).astype(np.float32)).to(dev)
+    if os.environ.get("TCMI_BENCH_KILL_RANK") == str(rank) and world > 1:
+        os._exit(3)        # tests/test_gpu_bench_multirank.py: a rank that dies must take the whole job down
+
+    # synthetic parameters: SURVEY 8(d) config-2 generator, one independent row per circuit of the GLOBAL batch (the
+    # same rows whatever the number of ranks); this rank contracts its contiguous block of them, B per vmap call
+    from tcmi import distributed as D_
+
+    Bg = max(args.global_batch, B)
+    lo, hi = D_.shard_range(Bg, rank, world)
+    rng = np.random.default_rng(n)
+    params_all = rng.uniform(0, 2 * np.pi, [Bg, 2 * d, n]).astype(np.float32)
+    params_loc = torch.from_numpy(params_all[lo:hi]).to(dev)
+    chunks = [params_loc[b0: b0 + B] for b0 in range(0, hi - lo, B)]
+    params = chunks[0] if chunks else torch.from_numpy(params_all[:B]).to(dev)
 
     # the product call, through the reference's public API: K.jit(K.vmap(f)) with f = Circuit(...).wavefunction()
     def wavefunction(p):
@@ -792,15 +807,29 @@ def main():
     for _ in range(max(args.warmup, 2)):   # the first two calls validate the traced pipeline against the plain path
         state = fwd(params)
     sync()
+    for ch in chunks[-1:]:                 # a ragged last chunk has its own batch size: stage it outside the timed region
+        if ch.shape[0] != B:
+            for _ in range(3):
+                fwd(ch)
+    sync()
     X.EVENT_LOG = []
     t0 = time.perf_counter()
     for k in range(args.steps):
-        state = fwd(params)
+        for ch in chunks:                  # one step = the whole global batch: this rank's block, B circuits per call
+            state = fwd(ch)
     sync()
     elapsed = time.perf_counter() - t0
     ev = summarize_events(X.EVENT_LOG)
     X.EVENT_LOG = None
     traced = bool(getattr(fwd, "stats", {}).get("fast", 0) >= args.steps)
+    # a checksum of the step's result that every world size must reproduce: sum over the global batch of <psi|Z_0|psi>
+    chk = torch.zeros(1, device=dev, dtype=torch.float64)
+    for ch in chunks:
+        pr = (fwd(ch).abs() ** 2).to(torch.float64)
+        chk += (pr[:, : 2 ** (n - 1)].sum() - pr[:, 2 ** (n - 1):].sum())
+    if dist is not None:
+        dist.all_reduce(chk)
+    checksum = float(chk.item())
     if args.probe_child:
         return
     # sanity: the state is normalised (cheap property check at full size)
@@ -864,7 +893,7 @@ def main():
         svqa = _guard("sliced_vqa", sliced_vqa_leg, tc, torch, dist, args, rank, world)
 
     if rank == 0:
-        amps = float(world) * B * (2**n) * args.steps
+        amps = float(Bg) * (2**n) * args.steps
         value = amps / elapsed
         pcfg = cc.cfg
         if is_cut:                       # the half-circuit batches have their own (small-tile) plan configuration
@@ -924,14 +953,16 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "c64 (f32 arithmetic)",
             "data": "synthetic",
             "config": {
-                "workload": f"HEA-B statevector contraction n={n} depth={d} complex64 (SURVEY 8d config 2), "
-                            f"vmap batch {B} per GPU, timed through backend.jit(backend.vmap(wavefunction))",
-                "qubits": n, "depth": d, "batch_per_gpu": B, "parallelism": f"batch-shard x{world}",
+                "workload": f"HEA-B statevector contraction n={n} depth={d} complex64 (SURVEY 8d config 2): one step = "
+                            f"{Bg} circuits (fixed for every number of GPUs, sharded in contiguous blocks), {B} per vmap call, "
+                            f"timed through backend.jit(backend.vmap(wavefunction))",
+                "qubits": n, "depth": d, "global_batch": Bg, "batch_per_call": B, "calls_per_step_per_gpu": len(chunks),
+                "parallelism": f"batch-shard x{world}", "z0_checksum": checksum,
                 "contractor": args.contractor, "plan": plan_info, "state_norm": nrm, "host_side_traced": traced,
             },
             "roofline": roof,

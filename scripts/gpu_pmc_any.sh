@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$1
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --pmc $2 --output-format csv -d $OUT -o bench -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --vqe-qubits 0 --mps-qubits 0 --rqc-depth 0 --svqa-qubits 0 --no-graph ${@:3} > $OUT/run.log 2>&1
+rocprofv3 --pmc $2 --output-format csv -d $OUT -o bench -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --vqe-qubits 0 --mps-qubits 0 --rqc-depth 0 --svqa-qubits 0 --no-graph --no-traffic-probe ${@:3} > $OUT/run.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob("$OUT/**/*counter_collection.csv", recursive=True)[0]

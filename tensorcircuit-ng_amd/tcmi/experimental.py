@@ -202,8 +202,47 @@ class DistributedContractor:
                 for a, b in zip(again, arrays):
                     by_dt.setdefault(a.dtype, []).append((a.detach().reshape(-1), b.detach().reshape(-1)))
                 same = all(torch.equal(torch.cat([x for x, _ in prs]), torch.cat([y for _, y in prs])) for prs in by_dt.values())
+            if same and leaves:
+                same = self._constants_ignore_the_arguments(params, arrays, st["recipe"])
             st["mode"] = "replay" if same else "off"
         return arrays
+
+    def _constants_ignore_the_arguments(self, params, arrays, recipe) -> bool:
+        """The recipe freezes every node tensor that did not come out of a gate stack as a CONSTANT of the network.  That
+        is only right if those tensors do not depend on the arguments -- the one-hot caps of
+        ``amplitude_before(params["bitstring"])``, ``Circuit(inputs=f(params))`` or a matrix baked from an argument's
+        value do, and a replay would keep returning the first call's network (the reference jits nodes_fn: every argument
+        stays live there).  Checked once, on the validating call: the node function is run on PERTURBED arguments (every
+        element of every leaf changed) and the would-be constants must come out unchanged; a function that cannot even
+        run on them (a bitstring that is no longer one) is not traced either."""
+        import torch
+
+        K = cons.backend
+        try:
+            leaves, spec = K.tree_flatten(params)
+            moved = []
+            for x in leaves:
+                if not torch.is_tensor(x):
+                    x = K.convert_to_tensor(x)
+                x = x.detach()
+                if x.is_floating_point() or x.is_complex():
+                    moved.append(x + 0.7311)
+                elif x.dtype == torch.bool:
+                    moved.append(~x)
+                else:
+                    moved.append(torch.where((x == 0) | (x == 1), 1 - x, x + 1))
+            with torch.no_grad():
+                other = [n.tensor for n in self.nodes_fn(K.tree_unflatten(spec, moved))]
+            if len(other) != len(arrays):
+                return False
+            for a, b, it in zip(arrays, other, recipe["items"]):
+                if not torch.is_tensor(it):
+                    continue
+                if a.shape != b.shape or a.dtype != b.dtype or not torch.equal(a.detach(), b.detach()):
+                    return False
+            return True
+        except Exception:  # noqa: BLE001
+            return False
 
     @staticmethod
     def _build_recipe(rec, arrays, leaves):
@@ -310,7 +349,8 @@ class DistributedContractor:
         if self._fast_vjp(arrays):
             # reverse sweep over the step list on the untaped kernels (tn.contract_slices_vjp); the small gate tensors
             # stay on torch's tape, so their cotangents reach ``params`` through one autograd call
-            value, agrads = self.tree.contract_slices_vjp(arrays, self.my_slices, fop, alias_ok=True, hat_ok=True)
+            value, agrads = self.tree.contract_slices_vjp(arrays, self.my_slices, fop, alias_ok=True, hat_ok=True,
+                                                          shard=self._shard())
             hat = bool(getattr(self.tree, "last_vjp_conjugated", False))   # the sweep handed over conj(g): undone per stack
             if value is None:
                 value = sum((x.sum() * 0 for x in leaves)).real.detach()
@@ -321,8 +361,8 @@ class DistributedContractor:
                 outs, gouts, groups = [], [], {}
                 for a, g in pairs:
                     b = a._base
-                    if b is not None and b.dim() == 2 and b.requires_grad and a.is_contiguous() and a.numel() == b.shape[1] \
-                            and a.storage_offset() % b.shape[1] == 0:
+                    if b is not None and b.dim() == 2 and b.requires_grad and b.is_contiguous() and b.storage_offset() == 0 \
+                            and a.is_contiguous() and a.numel() == b.shape[1] and a.storage_offset() % b.shape[1] == 0:
                         groups.setdefault(id(b), (b, [], []))
                         groups[id(b)][1].append(a.storage_offset() // b.shape[1])
                         groups[id(b)][2].append(g.reshape(-1))

@@ -1091,7 +1091,12 @@ class ContractionTree:
             if self.max_size() > target_size:
                 return float("inf")
             o = self.objective()
-            return o if not isinstance(o, tuple) else float(o[0]) * 1e30 + o[1]
+            if not isinstance(o, tuple):
+                return o
+            # (primary, secondary), e.g. minimize="size": (largest intermediate, flops).  The primary term is an element
+            # count (an integer), so a secondary term squeezed into [0, 1) keeps the lexicographic order in one float;
+            # log2 keeps a 10 % difference of the secondary term far above the ulp of the sum (o[0] * 1e30 + o[1] lost it)
+            return float(o[0]) + math.log2(1.0 + float(o[1])) / 1024.0
 
         start = self.path
         beam = [(tried(start), start)]
@@ -1251,7 +1256,7 @@ class ContractionTree:
             yield res
 
     def contract_slices_vjp(self, arrays: Sequence[Any], slice_ids: Sequence[int], fop, need=None, alias_ok=False,
-                            hat_ok=False):
+                            hat_ok=False, shard=None):
         """``sum_i fop(contract_core(slice_arrays(arrays, i)))`` and its gradient with respect to every array, by a
         reverse sweep over the step list instead of a framework tape (reference ``experimental.py:1182-1211``:
         ``value_and_grad`` of ``contract_core`` per slice, summed).  Every forward AND backward step is one launch of
@@ -1265,7 +1270,12 @@ class ContractionTree:
         may be views of the replayed graphs' static memory (valid until the next call on this tree) instead of clones
         -- a caller that consumes them at once (``DistributedContractor.value_and_grad``) saves a thousand tiny copies.
         ``hat_ok``: the graph path may return the CONJUGATES of the gradients (it sweeps conj(g), see ``_vjp_halves``) and
-        says so in ``self.last_vjp_conjugated``; the caller conjugates once, after stacking them."""
+        says so in ``self.last_vjp_conjugated``; the caller conjugates once, after stacking them.
+        ``shard = (rank, world, group)`` (graph path): the slice-invariant subtrees are split over the ranks in BOTH
+        directions -- forward as in ``contract_slices`` (own subtrees, one all-gather of the roots), backward by one
+        all-reduce of the roots' accumulated cotangents, after which every rank pulls back through its own subtrees only
+        (reference experimental.py:1028-1063: a rank holds only its slices' work).  The returned gradients are then
+        PARTIAL: their sum over the ranks (which the caller's gradient all-reduce forms anyway) is the gradient."""
         import torch
 
         steps, dep, last, final_perm = self._symbolic_steps()
@@ -1279,7 +1289,7 @@ class ContractionTree:
             needs[io] = needs[ia] or needs[ib]
         self.last_vjp_conjugated = False
         if slice_ids and needs[last] and _graph_ok(raw, len(steps), slice_ids):
-            return self._contract_slices_vjp_graph(raw, slice_ids, fop, need, needs, alias_ok, hat_ok)
+            return self._contract_slices_vjp_graph(raw, slice_ids, fop, need, needs, alias_ok, hat_ok, shard)
         total = None
         grads: List[Any] = [None] * n
         ginv: Dict[int, Any] = {}
@@ -1352,7 +1362,7 @@ class ContractionTree:
                     grads[k] = ginv[k].reshape(raw[k].shape)
         return total, [g if need[k] else None for k, g in enumerate(grads)]
 
-    def _contract_slices_vjp_graph(self, raw, slice_ids, fop, need, needs, alias_ok=False, hat_ok=False):
+    def _contract_slices_vjp_graph(self, raw, slice_ids, fop, need, needs, alias_ok=False, hat_ok=False, shard=None):
         """``contract_slices_vjp`` replayed from four HIP graphs (captured once per tree and operand signature): the
         slice-invariant forward steps, one slice forward, one slice backward, the invariant backward.  Between the
         slice graphs only ``fop`` and its derivative run eagerly, on the small result.  A 30-qubit depth-8 ladder is
@@ -1365,8 +1375,11 @@ class ContractionTree:
         n = len(self.inputs)
         vals0 = self.slice_index_values(slice_ids[0])
         idx0 = [tuple(vals0[e] if e in vals0 else slice(None) for e in edges) for edges in self.inputs]
+        srank, sworld, sgroup = shard if shard is not None else (0, 1, None)
+        if sworld <= 1:
+            srank, sworld, sgroup = 0, 1, None
         sig = (tuple(self.path), tuple(self.sliced_inds), tuple(bool(x) for x in need),
-               tuple((tuple(t.shape), t.dtype, t.device) for t in raw))
+               tuple((tuple(t.shape), t.dtype, t.device) for t in raw), srank, sworld, sgroup == "emulate")
         cache = getattr(self, "_vjp_graph_cache", None)
         inv_perm = None
         if final_perm is not None:
@@ -1438,8 +1451,17 @@ class ContractionTree:
                         for t_, g_ in done:
                             route(t_, g_)
 
-                    def fwd_inv(shared, B=None):
-                        for level in inv_order:
+                    # invariant subtrees of THIS rank (sharded run): the forward computes and the backward pulls back
+                    # through these only; `mine` = None: everything
+                    mine = roots_of = None
+                    if sworld > 1:
+                        steps_of, roots_of, _ = self.invariant_shards(sworld)
+                        mine = steps_of[srank]
+                    inv_mine = inv_order if mine is None else \
+                        [lv for lv in ([st for st in level if st[4] in mine] for level in inv_order) if lv]
+
+                    def fwd_inv(shared, B=None, only_mine=True):
+                        for level in (inv_mine if only_mine else inv_order):
                             forward_level(level, lambda t: shared[t], shared, B)
 
                     def fwd_slice(shared, cur, B=None):
@@ -1478,7 +1500,7 @@ class ContractionTree:
                         def route(t_, g_):
                             gt[t_] = g_
 
-                        for level in reversed(inv_order):
+                        for level in reversed(inv_mine):
                             backward_level(level, lambda t: shared[t], lambda io: gt.pop(io, None), route, B)
                         return {k: gt[k] for k in range(n) if not dep[k] and k in gt and need[k]}
 
@@ -1492,7 +1514,7 @@ class ContractionTree:
                     # warm-up (kernels, bit tables), then the captures; every intermediate stays referenced so that the
                     # backward graphs read the memory the forward graphs wrote
                     shared = dict(st_inv)
-                    fwd_inv(shared)
+                    fwd_inv(shared, only_mine=False)       # warm-up on the whole invariant part (also the other ranks' roots)
                     cur = dict(st_dep)
                     res = fwd_slice(shared, cur)
                     g_in = torch.zeros_like(res)
@@ -1500,17 +1522,54 @@ class ContractionTree:
                     bwd_slice(shared, cur, g_in, gacc)
                     bwd_inv(shared, gacc)
                     torch.cuda.synchronize()
+                    warm_roots = shared
                     shared = dict(st_inv)
                     B = None
                     if os.environ.get("TCMI_TN_BATCH", "1") != "0" and all(t.dtype == torch.complex64 for t in raw):
                         B = SmallBatch(raw[0].device, 6 * len(steps) + 16)
                     g_a = None
-                    if any(not dep[st[4]] for st in steps):
+                    big = gbig = None
+                    views: Dict[int, Any] = {}
+                    if sworld > 1:
+                        # every root of the invariant forest is a view of `big` [world, cap]: this rank's graph fills its
+                        # row, one all-gather fills the others (as in _contract_slices_graph)
+                        cap = max(1, max(sum(1 << lg for _, lg in rs) for rs in roots_of))
+                        big = torch.zeros(sworld, cap, dtype=raw[0].dtype, device=raw[0].device)
+                        for r_, rs in enumerate(roots_of):
+                            off = 0
+                            for root, lg in rs:
+                                views[root] = big[r_, off: off + (1 << lg)].view([2] * lg)
+                                if sgroup == "emulate":          # the other ranks' roots, computed here once
+                                    views[root].copy_(warm_roots[root])
+                                off += 1 << lg
+                    del warm_roots
+                    if inv_mine:
                         g_a = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(g_a):
                             fwd_inv(shared, B)
+                            if sworld > 1:
+                                for root, lg in roots_of[srank]:
+                                    views[root].copy_(shared[root])
+                    if sworld > 1:
+                        shared.update(views)
+                        if sgroup != "emulate":
+                            self._gather_invariants(big, srank, sworld, sgroup)   # the captures below replay on real values
                     pool = g_a.pool() if g_a is not None else None
-                    gacc = {t: torch.zeros_like(shared[t]) for t in targets}
+                    if sworld > 1:
+                        # the cotangents of the roots accumulate in views of ONE buffer: one all-reduce sums them over the
+                        # ranks' slices before the invariant backward (leaf targets are summed with the gradients)
+                        inner = sorted(t for t in targets if t >= n)
+                        gbig = torch.zeros(max(1, sum(shared[t].numel() for t in inner)), dtype=raw[0].dtype,
+                                           device=raw[0].device)
+                        gacc, off = {}, 0
+                        for t in inner:
+                            gacc[t] = gbig[off: off + shared[t].numel()].view(shared[t].shape)
+                            off += shared[t].numel()
+                        for t in targets:
+                            if t < n:
+                                gacc[t] = torch.zeros_like(shared[t])
+                    else:
+                        gacc = {t: torch.zeros_like(shared[t]) for t in targets}
                     cur = dict(st_dep)
                     g_b = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g_b, **({"pool": pool} if pool is not None else {})):
@@ -1520,9 +1579,13 @@ class ContractionTree:
                     g_c = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g_c, pool=pool):
                         gleaf = bwd_slice(shared, cur, g_in, gacc, B)
-                    g_d = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g_d, pool=pool):
-                        ginv_leaf = bwd_inv(shared, gacc, B)
+                    g_d = None
+                    if inv_mine:
+                        g_d = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g_d, pool=pool):
+                            ginv_leaf = bwd_inv(shared, gacc, B)
+                    else:       # nothing to pull back through on this rank (an empty capture is an error on some ROCm versions)
+                        ginv_leaf = {k: gacc[k] for k in range(n) if not dep[k] and k in gacc and need[k]}
                     # a second instance of the two per-slice graphs (own leaf copies, intermediates, cotangent
                     # accumulators and memory pool) for a second stream: a slice's sweep is a chain of launches most of
                     # which cannot fill the chip (41 tile-kernel steps of ~30 us per slice backward), two slices side by
@@ -1547,7 +1610,7 @@ class ContractionTree:
                 COUNTERS = keep_counters
             cache = {"sig": sig, "st_inv": st_inv, "st_dep": st_dep, "shared": shared, "cur": cur, "res": res,
                      "g_in": g_in, "gacc": gacc, "gleaf": gleaf, "ginv_leaf": ginv_leaf, "g_a": g_a, "g_b": g_b,
-                     "g_c": g_c, "g_d": g_d, "batch": B, "two": two}
+                     "g_c": g_c, "g_d": g_d, "batch": B, "two": two, "big": big, "gbig": gbig}
             self._vjp_graph_cache = cache
         with torch.no_grad():
             inv_k = list(cache["st_inv"])
@@ -1557,6 +1620,8 @@ class ContractionTree:
                 torch._foreach_zero_(list(cache["gacc"].values()))
             if cache["g_a"] is not None:
                 cache["g_a"].replay()
+            if sworld > 1 and sgroup != "emulate":
+                self._gather_invariants(cache["big"], srank, sworld, sgroup)
             grads: List[Any] = [None] * n
             total = None
             touched = sorted(set(cache["st_dep"]) | set(cache["gleaf"]))   # the leaves that carry a sliced index
@@ -1568,8 +1633,10 @@ class ContractionTree:
                 torch._foreach_zero_(list(two["gacc"].values()))
 
             def one_slice(i, inst):
-                """Forward, op and its derivative, backward of slice i on the graphs of ``inst``; returns op's value.
-                (Different slices write different blocks of a sliced leaf's gradient: no two streams meet there.)"""
+                """Forward, op and its derivative, backward of slice i on the graphs of ``inst``; returns op's value and
+                the slice's index tuples.  The sliced leaves' gradient blocks are NOT added here: two slices of a pair
+                differ in the last sliced index only, so a leaf that carries just the earlier ones receives the SAME
+                block from both -- the additions of both instances are issued on the main stream, after the join."""
                 vals = self.slice_index_values(i)
                 idx = {k: tuple(vals[e] if e in vals else slice(None) for e in self.inputs[k]) for k in touched}
                 for k, buf in inst["st_dep"].items():
@@ -1581,10 +1648,12 @@ class ContractionTree:
                     (g,) = torch.autograd.grad(v, r_)
                 inst["g_in"].copy_(g)
                 inst["g_c"].replay()
+                return v.detach(), idx
+
+            def add_leaf_grads(inst, idx):
                 for k, gl in inst["gleaf"].items():
                     if need[k]:
                         grads[k][idx[k]] += gl
-                return v.detach()
 
             ids = list(slice_ids)
             cur_s = torch.cuda.current_stream(raw[0].device) if two is not None else None
@@ -1594,17 +1663,22 @@ class ContractionTree:
                 if two is not None and j + 1 < len(ids):      # the partner slice goes out first, on the second stream
                     two["side"].wait_stream(cur_s)
                     with torch.cuda.stream(two["side"]):
-                        v2 = one_slice(ids[j + 1], two)
-                v = one_slice(ids[j], cache)
+                        v2, idx2 = one_slice(ids[j + 1], two)
+                v, idx1 = one_slice(ids[j], cache)
+                add_leaf_grads(cache, idx1)
                 total = v if total is None else total + v
                 if v2 is not None:
                     cur_s.wait_stream(two["side"])
+                    add_leaf_grads(two, idx2)       # on the main stream: ordered after the main instance's additions
                     total = total + v2
                 j += 1 if v2 is None else 2
             if two is not None and two["gacc"]:
                 keys = list(cache["gacc"])
                 torch._foreach_add_([cache["gacc"][t] for t in keys], [two["gacc"][t] for t in keys])
-            cache["g_d"].replay()
+            if sworld > 1 and sgroup != "emulate" and cache["gbig"] is not None:
+                self._allreduce_complex(cache["gbig"], sgroup)     # the roots' cotangents, summed over every rank's slices
+            if cache["g_d"] is not None:
+                cache["g_d"].replay()
             for k, gl in cache["ginv_leaf"].items():
                 grads[k] = gl.reshape(raw[k].shape) if alias_ok else gl.reshape(raw[k].shape).clone()
             # the graphs deliver conj(g)
@@ -1864,6 +1938,14 @@ class ContractionTree:
             if r2 is not None:
                 yield r2
             j += n_done
+
+    @staticmethod
+    def _allreduce_complex(buf, group) -> None:
+        """Sum of a complex buffer over the ranks (RCCL all-reduce; through the real view, which every backend takes)."""
+        import torch
+        import torch.distributed as dist
+
+        dist.all_reduce(torch.view_as_real(buf), group=group)
 
     @staticmethod
     def _gather_invariants(big, rank: int, world: int, group) -> None:

@@ -14,6 +14,39 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+BENCH_SMALL = ["--steps", "2", "--warmup", "1", "--qubits", "16", "--depth", "4", "--batch", "2", "--global-batch", "4",
+               "--vqe-qubits", "16", "--vqe-depth", "3", "--vqe-batch", "4", "--vqe-microbatch", "2", "--vqe-steps", "1",
+               "--rqc-depth", "8", "--rqc-log2-target", "20", "--rqc-seeds", "1", "--svqa-qubits", "12", "--svqa-depth", "2",
+               "--svqa-slices", "4", "--svqa-steps", "1", "--mps-qubits", "0", "--no-cpu-baseline", "--no-traffic-probe",
+               "--no-graph"]
+BENCH_OUT = {k: os.path.join(ROOT, ".pytest_cache", f"bench_{k}.json") for k in ("w1", "w2", "dead")}
+
+
+def _run_bench(tag, gpus, extra_env, timeout):
+    """`python bench.py --gpus N` exactly as the driver starts it, at toy sizes; {rc, seconds, line} -> BENCH_OUT[tag]."""
+    import json
+    import subprocess
+    import time
+
+    env = dict(os.environ, **extra_env)
+    t0 = time.time()
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus)] + BENCH_SMALL,
+                           env=env, capture_output=True, text=True, timeout=timeout)
+        rc, out, err = r.returncode, r.stdout, r.stderr
+    except subprocess.TimeoutExpired as e:
+        rc, out, err = -999, (e.stdout or b"").decode() if isinstance(e.stdout, bytes) else (e.stdout or ""), "timeout"
+    line = None
+    for ln in out.splitlines():
+        if ln.startswith("{"):
+            try:
+                line = json.loads(ln)
+            except ValueError:
+                pass
+    with open(BENCH_OUT[tag], "w") as fh:
+        json.dump({"rc": rc, "seconds": time.time() - t0, "line": line, "stderr": err[-2000:]}, fh)
+
+
 MULTIRANK_OUT = os.path.join(ROOT, ".pytest_cache", "multirank_slices.json")
 MULTIRANK4_OUT = os.path.join(ROOT, ".pytest_cache", "multirank_slices_w4.json")
 
@@ -38,6 +71,15 @@ def pytest_sessionstart(session):
                 os.remove(out)
             subprocess.run([sys.executable, os.path.join(ROOT, "tests", "multirank_slices.py"), str(world), out],
                            timeout=900, check=False)
+        # the driver's multi-GPU command (tests/test_gpu_bench_multirank.py): one rank, two ranks sharing this box's
+        # device over gloo (TCMI_BENCH_OVERSUBSCRIBE: the launch path, the sharding and the collectives, not a
+        # measurement), and two ranks one of which dies
+        for f in BENCH_OUT.values():
+            if os.path.exists(f):
+                os.remove(f)
+        _run_bench("w1", 1, {}, 900)
+        _run_bench("w2", 2, {"TCMI_BENCH_OVERSUBSCRIBE": "1"}, 900)
+        _run_bench("dead", 2, {"TCMI_BENCH_OVERSUBSCRIBE": "1", "TCMI_BENCH_KILL_RANK": "1"}, 300)
     except Exception as e:  # noqa: BLE001  (the test reports the missing file)
         print("multirank launcher failed:", e)
 

@@ -1,0 +1,53 @@
+"""`python bench.py --gpus N` -- the one command the driver runs on a multi-GPU node -- executed for real before an
+8-GPU node ever sees it: N = 1 and N = 2 at toy sizes (the two ranks share this box's device, gloo instead of RCCL:
+TCMI_BENCH_OVERSUBSCRIBE=1), started from tests/conftest.py::pytest_sessionstart before this process touches the GPU.
+What must hold (reference behaviour: tensorcircuit/experimental.py:881-894 slice blocks, 1125-1152 summed value and
+gradients; examples/slicing_auto_pmap_vqa.py:60-72): the job exits 0, reports the world size, and every sharded leg
+returns what one rank returns; a rank that dies takes the job down instead of leaving the others in a collective."""
+
+import json
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from conftest import BENCH_OUT  # noqa: E402
+
+
+def _load(tag):
+    if not os.path.exists(BENCH_OUT[tag]):
+        pytest.skip("bench runs were not started (no GPU at session start)")
+    return json.load(open(BENCH_OUT[tag]))
+
+
+def test_two_rank_bench_equals_the_one_rank_bench():
+    a, b = _load("w1"), _load("w2")
+    assert a["rc"] == 0 and a["line"] is not None, a["stderr"]
+    assert b["rc"] == 0 and b["line"] is not None, b["stderr"]
+    la, lb = a["line"], b["line"]
+    assert la["n_gpus"] == 1 and lb["n_gpus"] == 2
+    assert la["scaling"] == lb["scaling"] == "strong"
+    # headline: the same global batch, sharded -- same checksum of the states, same amount of work per step
+    assert la["config"]["global_batch"] == lb["config"]["global_batch"] == 4
+    assert abs(la["config"]["z0_checksum"] - lb["config"]["z0_checksum"]) < 1e-5
+    assert lb["config"]["calls_per_step_per_gpu"] * 2 == la["config"]["calls_per_step_per_gpu"]
+    for leg in ("vqe_step", "rqc_amplitude", "sliced_vqa"):
+        assert "error" not in la[leg], la[leg]
+        assert "error" not in lb[leg], lb[leg]
+    va, vb = la["vqe_step"], lb["vqe_step"]
+    assert vb["batch_per_gpu"] * 2 == va["batch_per_gpu"] == 4
+    assert abs(va["mean_energy"] - vb["mean_energy"]) < 1e-5 * max(1.0, abs(va["mean_energy"]))
+    assert abs(va["grad_norm"] - vb["grad_norm"]) < 1e-4 * max(1.0, abs(va["grad_norm"]))
+    ra, rb = la["rqc_amplitude"]["amplitude"], lb["rqc_amplitude"]["amplitude"]
+    scale = max(abs(complex(*ra)), 1e-30)
+    assert abs(complex(*ra) - complex(*rb)) < 1e-4 * scale
+    sa, sb = la["sliced_vqa"], lb["sliced_vqa"]
+    assert abs(sa["value"] - sb["value"]) < 1e-5 and abs(sa["grad_norm"] - sb["grad_norm"]) < 1e-4
+
+
+def test_a_dead_rank_terminates_the_job():
+    d = _load("dead")
+    assert d["rc"] not in (0, -999), d       # non-zero exit, and not by the test's own timeout
+    assert d["line"] is None
+    assert d["seconds"] < 240

@@ -781,7 +781,7 @@ def test_node_function_is_traced_validated_and_given_up_when_it_must_be(tcd):
         v0, g0 = ref(p)
         assert abs(float(v) - float(v0)) < 2e-5 and float((g - g0).abs().max()) < 2e-4, k
         assert dc._trace_state["mode"] == ("record" if k == 0 else "replay")
-    assert calls["n"] == 3        # the constructor, the recording call and the validating call
+    assert calls["n"] == 4        # the constructor, the recording call, the validating call and its perturbed re-run
 
     def computed(p):              # angles are results of arithmetic, not elements of the parameter tensor
         return circuit(p, 0.5).expectation_before([tc.gates.z(), [0]], reuse=False)
@@ -805,6 +805,47 @@ def test_node_function_is_traced_validated_and_given_up_when_it_must_be(tcd):
     v0, g0 = ref(pts[1].flip(0).contiguous())
     assert dc3._trace_state["mode"] == "off"
     assert abs(float(v) - float(v0)) < 2e-5 and float((g.flip(0) - g0).abs().max()) < 2e-4
+
+
+def test_arguments_that_shape_the_networks_constants_are_never_frozen_by_the_trace(tcd):
+    """`value(p0), value(p0), value(p1)` with a different amplitude bitstring in p1.  The one-hot
+    caps of `amplitude_before(params["bits"])` are constants of the network built from an ARGUMENT; two identical warm-up
+    calls must not freeze them (the reference jits nodes_fn, every argument stays live:
+    examples/distributed_interface_amplitude.py pattern)."""
+    tc = tcd
+    if tc.dtypestr != "complex64":
+        pytest.skip("one dtype is enough")
+    import torch
+
+    nq = 8
+    rng = np.random.default_rng(4)
+    th = tc.backend.convert_to_tensor(rng.uniform(0.2, 1.2, [nq, 2]).astype(np.float32))
+
+    def circ(angles):
+        c = tc.Circuit(nq)
+        for j in range(nq):
+            c.rx(j, theta=angles[j, 0])
+        for j in range(nq - 1):
+            c.cnot(j, j + 1)
+        for j in range(nq):
+            c.ry(j, theta=angles[j, 1])
+        return c
+
+    def nodes_fn(params):
+        return circ(params["angles"]).amplitude_before(params["bits"])
+
+    b0 = torch.tensor([0, 1, 0, 0, 1, 1, 0, 1], device="cuda")
+    b1 = torch.tensor([1, 1, 0, 1, 0, 0, 0, 1], device="cuda")
+    dc = tc.experimental.DistributedContractor(nodes_fn, {"angles": th, "bits": b0}, {"max_repeats": 4})
+    psi = tc.backend.numpy(circ(th).wavefunction())
+
+    def amp(bits):
+        return psi[int("".join(str(int(x)) for x in bits.tolist()), 2)]
+
+    for bits in (b0, b0, b1, b0, b1):
+        v = dc.value({"angles": th, "bits": bits}, op=lambda x: x)
+        assert abs(complex(tc.backend.numpy(v).reshape(-1)[0]) - amp(bits)) < 1e-5, bits
+    assert dc._trace_state["mode"] == "off"
 
 
 @pytest.mark.parametrize("shape", [(64, 64, 16), (64, 64, 32), (128, 192, 48), (512, 320, 256), (4096, 4096, 256),
