@@ -29,15 +29,8 @@ MFMA_F32_PEAK_TFS = 157.3  # dense FP32 (f32-input) MFMA peak, same table
 
 
 def build_circuit(tc, n, d, params_row):
-    c = tc.Circuit(n)
-    for i in range(n):
-        c.h(i)
-    for j in range(d):
-        for i in range(n - 1):
-            c.exp1(i, i + 1, unitary=tc.gates._zz_matrix, theta=params_row[2 * j, i])
-        for i in range(n):
-            c.rx(i, theta=params_row[2 * j + 1, i])
-    return c
+    """HEA-B: the reference's own ansatz template (templates/blocks.py:146-185), through the product's mirror of it."""
+    return tc.templates.blocks.example_block(tc.Circuit(n), params_row, nlayers=d)
 
 
 def cpu_baseline(n_sample, d, seed, budget_s=25.0):
@@ -159,14 +152,7 @@ def vqe_leg(tc, torch, dist, args, rank, world, dev):
     params = torch.from_numpy(params_np[lo:hi]).to(dev)
 
     def energy(p):
-        c = tc.Circuit(n)
-        for i in range(n):
-            c.h(i)
-        for j in range(d):
-            for i in range(n - 1):
-                c.exp1(i, i + 1, unitary=tc.gates._zz_matrix, theta=p[2 * j, i])
-            for i in range(n):
-                c.rx(i, theta=p[2 * j + 1, i])
+        c = tc.templates.blocks.example_block(tc.Circuit(n), p, nlayers=d)
         e = 0.0
         for i in range(n):
             e += -1.0 * c.expectation((tc.gates.x(), [i]))

@@ -31,11 +31,39 @@ def apply_gate(psi, n, matrix, qubits):
     return np.ascontiguousarray(t).reshape(-1)
 
 
-def run(n, ops, dtype=np.complex128, inputs=None):
-    """``ops`` = iterable of ``(matrix, qubits)``."""
+def apply_gate_inplace(psi, n, matrix, qubits):
+    """The same product as ``apply_gate`` for one-qubit gates and for diagonal gates, updating ``psi`` in place through
+    strided views (no transposed copies of the state): what makes the n = 28 fixtures of tests/golden/make_golden_full.py
+    affordable (a 4 GiB state; ``apply_gate`` moves it three times per gate).  Anything else falls back to ``apply_gate``.
+    Returns the updated vector."""
+    k = len(qubits)
+    qubits = [q if q >= 0 else n + q for q in qubits]
+    u = np.asarray(matrix, dtype=psi.dtype).reshape(2**k, 2**k)
+    if k == 1:
+        q = qubits[0]
+        v = psi.reshape(2**q, 2, 2 ** (n - 1 - q))
+        x0 = v[:, 0, :].copy()
+        v[:, 0, :] *= u[0, 0]
+        v[:, 0, :] += u[0, 1] * v[:, 1, :]
+        v[:, 1, :] *= u[1, 1]
+        v[:, 1, :] += u[1, 0] * x0
+        return psi
+    if np.abs(u - np.diag(np.diag(u))).max() == 0.0 and len(set(qubits)) == k:
+        t = psi.reshape([2] * n)
+        for idx in range(2**k):
+            sel = [slice(None)] * n
+            for j, q in enumerate(qubits):
+                sel[q] = (idx >> (k - 1 - j)) & 1
+            t[tuple(sel)] *= u[idx, idx]
+        return psi
+    return apply_gate(psi, n, matrix, qubits)
+
+
+def run(n, ops, dtype=np.complex128, inputs=None, inplace=False):
+    """``ops`` = iterable of ``(matrix, qubits)``.  ``inplace``: use ``apply_gate_inplace`` (large n)."""
     psi = zero_state(n, dtype) if inputs is None else np.asarray(inputs, dtype=dtype).copy()
     for m, qs in ops:
-        psi = apply_gate(psi, n, m, list(qs))
+        psi = apply_gate_inplace(psi, n, m, list(qs)) if inplace else apply_gate(psi, n, m, list(qs))
     return psi
 
 

@@ -585,6 +585,9 @@ class Circuit:
             from .jit import TracedState
 
             return TracedState(self, form)
+        if self._extra_input_legs():
+            psi = self._state_of_matrix_inputs()
+            return psi.reshape(-1, 1) if form == "ket" else (psi.reshape(1, -1) if form == "bra" else psi)
         full = _circuit_full_state(self)  # cached until the next gate is applied
         psi = full[..., : 2**self._nqubits] if full.shape[-1] != 2**self._nqubits else full
         if form == "ket":
@@ -599,6 +602,73 @@ class Circuit:
         if self.inputs is None:
             return None
         return cons.backend.cast(cons.backend.convert_to_tensor(self.inputs), cons.dtypestr).reshape(-1)
+
+    def _extra_input_legs(self) -> int:
+        """``inputs`` with MORE than 2^n elements (reference circuit.py:44-131: the tensor is reshaped to [2] * N and its
+        first n legs are the circuit's qubits, the other N - n stay open): e.g. ``Circuit(2, inputs=np.eye(4))``, whose
+        wavefunction is the circuit's unitary (reference tests/test_circuit.py:539-547).  Returns N - n."""
+        if self.inputs is None:
+            return 0
+        size = int(np.prod(np.shape(self.inputs))) if not hasattr(self.inputs, "numel") else int(self.inputs.numel())
+        extra = size.bit_length() - 1 - self._nqubits
+        if size != 1 << (self._nqubits + max(extra, 0)) or extra < 0:
+            raise ValueError(f"inputs of {size} elements do not fit a circuit of {self._nqubits} qubits")
+        return extra
+
+    def _state_of_matrix_inputs(self):
+        """The open legs of ``inputs`` are a batch: every column [2^n] of inputs.reshape(2^n, 2^m) goes through the
+        compiled plan as one batch element; result legs = (circuit outputs, open legs), as in the reference.  Values only
+        (no tape through this route)."""
+        import torch
+
+        K = cons.backend
+        nq, m = self._nqubits, self._extra_input_legs()
+        cols = K.cast(K.convert_to_tensor(self.inputs), cons.dtypestr).detach().reshape(2**nq, 2**m).T.contiguous()
+        cc = self._compiled()
+        while hasattr(cc, "full"):      # cut contraction: inputs other than |0> run on the state-vector plan
+            cc = cc.full
+        p = self._param_tensor()
+        if p is not None:
+            p = p.detach().reshape(1, -1).expand(2**m, -1).contiguous()
+        with torch.no_grad():
+            out = cc.state(p, inputs=cols)
+        return out.T.reshape(-1)
+
+    def matrix(self) -> Tensor:
+        """reference circuit.py:744-769: the unitary of the whole circuit as a dense [2^n, 2^n] matrix, whatever its
+        input state (the circuit applied to every basis state at once: inputs = identity)."""
+        nq = self._nqubits
+        if nq > 14:
+            raise NotImplementedError("Backend 'hip' has not implemented Circuit.matrix beyond 14 qubits (a 2^28-element matrix)")
+        c = Circuit(nq, inputs=np.eye(2**nq))
+        c._ops, c._params = list(self._ops), list(self._params)
+        return c.wavefunction().reshape(2**nq, 2**nq)
+
+    def get_quoperator(self):
+        """reference circuit.py:723-737: the circuit as an operator object (here: dense, ``quantum.QuOperator``)."""
+        from .quantum import QuOperator
+
+        return QuOperator.from_matrix(self.matrix(), self._nqubits)
+
+    quoperator = get_quoperator
+    get_circuit_as_quoperator = get_quoperator
+
+    def mid_measurement(self, index: int, keep: int = 0) -> Tensor:
+        """reference circuit.py:196-235: post-selection of qubit ``index`` on outcome ``keep`` in the z basis -- the
+        projector |keep><keep| as a (non-unitary) one-qubit gate; the state is NOT renormalised; like the reference this
+        leaves no record in the circuit's QIR.  Returns ``keep`` as an int32 tensor."""
+        if keep not in (0, 1):
+            raise ValueError("keep must be 0 or 1")
+        proj = np.zeros((2, 2), dtype=np.complex128)
+        proj[keep, keep] = 1.0
+        self._record_const(proj, (index,), "post-select")
+        self._qir.pop()
+        K = cons.backend
+        return K.cast(K.convert_to_tensor(keep), "int32")
+
+    mid_measure = mid_measurement
+    post_select = mid_measurement
+    post_selection = mid_measurement
 
     def amplitude(self, l) -> Tensor:
         """reference basecircuit.py:562-624: <l|psi>."""

@@ -158,3 +158,42 @@ def reduced_density_matrix(state: Tensor, cut: Any, p: Optional[Tensor] = None) 
     if p is not None:
         m = m * cons.backend.cast(cons.backend.convert_to_tensor(p), cons.dtypestr).sqrt().reshape(1, -1)
     return LA.matmul(m, m.conj().t().resolve_conj())
+
+
+class QuOperator:
+    """The part of the reference's ``QuOperator`` (tensorcircuit/quantum.py) the hot path's callers use: an operator on n
+    qubits given either as ONE local tensor on some sites (``from_local_tensor``, the MPO of
+    templates.measurements.mpo_expectation's known-answer test, reference tests/test_templates.py:191-211) or as a dense
+    matrix (``Circuit.get_quoperator``).  There is no tensor-network algebra here: ``eval_matrix`` is the dense matrix."""
+
+    def __init__(self, n: int, local: Optional[Any] = None, loc: Optional[Sequence[int]] = None, dense: Optional[Any] = None):
+        self.n, self.local, self.loc, self.dense = int(n), local, (list(loc) if loc is not None else None), dense
+
+    @classmethod
+    def from_local_tensor(cls, tensor: Any, space: Sequence[int], loc: Sequence[int], out_axes=None, in_axes=None):
+        """reference quantum.py ``QuOperator.from_local_tensor``: ``tensor`` acts on the sites ``loc`` of a register with
+        local dimensions ``space`` (qubits only here); identity elsewhere."""
+        if any(int(d) != 2 for d in space):
+            raise NotImplementedError("Backend 'hip' has not implemented QuOperator on local dimensions other than 2")
+        k = len(loc)
+        t = cons.backend.reshape(cons.backend.cast(cons.backend.convert_to_tensor(tensor), cons.dtypestr), [2**k, 2**k])
+        return cls(len(space), local=t, loc=loc)
+
+    @classmethod
+    def from_matrix(cls, matrix: Any, n: int):
+        return cls(n, dense=matrix)
+
+    def eval_matrix(self) -> Tensor:
+        K = cons.backend
+        if self.dense is not None:
+            return self.dense
+        if self.n > 12:
+            raise NotImplementedError("Backend 'hip' has not implemented dense QuOperator matrices beyond 12 qubits")
+        k = len(self.loc)
+        rest = [q for q in range(self.n) if q not in self.loc]
+        full = K.reshape(K.kron(self.local, K.eye(2 ** len(rest), dtype=cons.dtypestr)), [2] * (2 * self.n))
+        order = list(self.loc) + rest                       # axis j of `full` (both halves) is qubit order[j]
+        perm = [order.index(q) for q in range(self.n)]
+        return K.reshape(K.transpose(full, perm + [self.n + x for x in perm]), [2**self.n, 2**self.n])
+
+    eval = eval_matrix

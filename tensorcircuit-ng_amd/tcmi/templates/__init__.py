@@ -1,1 +1,1 @@
-from . import measurements  # noqa: F401
+from . import blocks, measurements  # noqa: F401

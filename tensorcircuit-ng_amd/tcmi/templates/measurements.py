@@ -3,7 +3,7 @@
 from typing import Any
 
 from .. import cons
-from ..quantum import PauliSum
+from ..quantum import PauliSum, QuOperator
 
 Tensor = Any
 
@@ -27,10 +27,27 @@ def sparse_expectation(c: Any, hamiltonian: PauliSum) -> Tensor:
     return cons.backend.real(e)
 
 
+def mpo_expectation(c: Any, mpo: QuOperator) -> Tensor:
+    """reference measurements.py:194-208: real <psi| O |psi> for an operator in ``QuOperator`` form.  A local-tensor
+    operator is measured as what it is -- ``c.expectation((tensor, sites))``, i.e. the fused Pauli-sum measurement and
+    its cotangent kernel in reverse mode; a dense one through the state."""
+    if not isinstance(mpo, QuOperator):
+        raise TypeError("mpo_expectation expects a tc.quantum.QuOperator")
+    if mpo.n != c._nqubits:
+        raise ValueError("operator and circuit act on different numbers of qubits")
+    b = cons.backend
+    if mpo.local is not None:
+        return b.real(c.expectation((mpo.local, list(mpo.loc))))
+    w = c.state(form="ket")
+    return b.real((b.adjoint(w) @ b.cast(mpo.dense, cons.dtypestr) @ w)[0, 0])
+
+
 def operator_expectation(c: Any, hamiltonian: Any) -> Tensor:
-    """reference measurements.py:156-172: dense matrix or sparse (here: PauliSum) Hamiltonian."""
+    """reference measurements.py:156-172: dense matrix, sparse (here: PauliSum) or MPO (QuOperator) Hamiltonian."""
     if isinstance(hamiltonian, PauliSum):
         return sparse_expectation(c, hamiltonian)
+    if isinstance(hamiltonian, QuOperator):
+        return mpo_expectation(c, hamiltonian)
     b = cons.backend
     w = c.state(form="ket")
     h = b.cast(b.convert_to_tensor(hamiltonian), cons.dtypestr)

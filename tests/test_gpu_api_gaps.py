@@ -1,0 +1,133 @@
+"""Small API rows of the reference's circuit front end closed in round 4, each with the reference's own known answer:
+post-selection (tests/test_circuit.py:528-536), matrix-shaped inputs and Circuit.matrix (tests/test_circuit.py:539-547,
+circuit.py:744-769), mpo_expectation (tests/test_templates.py:191-211), templates.blocks.example_block
+(templates/blocks.py:146-185)."""
+
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dense, gates as G, workloads as W  # noqa: E402
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "hea_golden.npz"))
+
+
+@pytest.fixture(params=["complex64", "complex128"])
+def tcd(request):
+    import tcmi as tc
+
+    tc.set_backend("hip")
+    tc.set_dtype(request.param)
+    yield tc
+    tc.set_dtype("complex64")
+
+
+def test_postselection_kat(tcd):
+    """reference tests/test_circuit.py:528-536: s[3].real == 0.5 (the state is not renormalised)."""
+    tc = tcd
+    c = tc.Circuit(3)
+    c.H(1)
+    c.H(2)
+    r = c.mid_measurement(1, 1)
+    c.mid_measurement(2, 1)
+    s = tc.backend.numpy(c.wavefunction())
+    np.testing.assert_allclose(s[3].real, 0.5, atol=1e-6)
+    np.testing.assert_allclose(np.abs(s).sum(), 0.5, atol=1e-6)       # every other amplitude is projected out
+    assert int(tc.backend.numpy(r)) == 1
+    assert len(c.to_qir()) == 2                                        # like the reference: not recorded in the QIR
+    # post-selection inside a longer circuit, against the dense oracle (projector as a gate)
+    n = 12
+    rng = np.random.default_rng(3)
+    c2, ops = tc.Circuit(n), []
+    for i in range(n):
+        c2.h(i); ops.append((G.H, [i]))
+    for i in range(n - 1):
+        th = float(rng.uniform(0, 6)); c2.rzz(i, i + 1, theta=th); ops.append((G.rzz(th), [i, i + 1]))
+    c2.post_select(4, keep=1); ops.append((np.diag([0.0, 1.0]), [4]))
+    for i in range(n):
+        th = float(rng.uniform(0, 6)); c2.rx(i, theta=th); ops.append((G.rx(th), [i]))
+    c2.mid_measure(9, keep=0); ops.append((np.diag([1.0, 0.0]), [9]))
+    ref = dense.run(n, ops)
+    tol = 1e-5 if tc.dtypestr == "complex64" else 1e-10
+    assert np.abs(tc.backend.numpy(c2.wavefunction()) - ref).max() < tol
+
+
+def test_matrix_inputs_and_circuit_matrix_kat(tcd):
+    """reference tests/test_circuit.py:539-547: Circuit(2, inputs=eye(4)); X(0); Y(1): wavefunction.reshape(4, 4) = X (x) Y."""
+    tc = tcd
+    c = tc.Circuit(2, inputs=np.eye(4))
+    c.X(0)
+    c.Y(1)
+    answer = np.kron(G.X, G.Y)
+    np.testing.assert_allclose(tc.backend.numpy(c.wavefunction()).reshape(4, 4), answer, atol=1e-4)
+    # Circuit.matrix / get_quoperator: the unitary of a parametrised circuit against the dense oracle, column by column
+    n = 8
+    rng = np.random.default_rng(1)
+    pr = rng.uniform(0, 6, [4, n])
+    c3 = tc.Circuit(n)
+    W.hea_b(c3, n, 2, tc.backend.convert_to_tensor(pr, dtype=tc.rdtypestr), zz=tc.gates._zz_matrix)
+    u = tc.backend.numpy(c3.matrix())
+    ops = W.hea_b_ops(n, 2, pr)
+    tol = 1e-5 if tc.dtypestr == "complex64" else 1e-10
+    for col in (0, 5, 77, 255):
+        e = np.zeros(2**n, dtype=np.complex128)
+        e[col] = 1.0
+        assert np.abs(u[:, col] - dense.run(n, ops, inputs=e)).max() < tol
+    assert np.abs(u.conj().T @ u - np.eye(2**n)).max() < 50 * tol
+    np.testing.assert_allclose(tc.backend.numpy(c3.get_quoperator().eval_matrix()), u)
+    # open input legs that are not a square matrix: 3 circuit qubits, 1 open leg
+    inp = (rng.normal(size=16) + 1j * rng.normal(size=16))
+    c4 = tc.Circuit(3, inputs=inp)
+    c4.h(0); c4.cnot(0, 2); c4.rx(1, theta=0.3)
+    got = tc.backend.numpy(c4.wavefunction()).reshape(8, 2)
+    for j in range(2):
+        want = dense.run(3, [(G.H, [0]), (G.CNOT, [0, 2]), (G.rx(0.3), [1])], inputs=inp.reshape(8, 2)[:, j])
+        assert np.abs(got[:, j] - want).max() < tol * 10
+
+
+def test_mpo_expectation_kat(tcd):
+    """reference tests/test_templates.py:191-211 (the MPO branch): value 0.84147, gradient 0.54032 (atol 1e-4)."""
+    tc = tcd
+    mpo = tc.quantum.QuOperator.from_local_tensor(tc.gates._x_matrix, [2, 2], [0])
+
+    def f(theta):
+        c = tc.Circuit(2)
+        c.ry(0, theta=theta)
+        c.H(1)
+        return tc.templates.measurements.operator_expectation(c, mpo)
+
+    v, g = tc.backend.jit(tc.backend.value_and_grad(f))(tc.backend.ones([], dtype=tc.rdtypestr))
+    np.testing.assert_allclose(tc.backend.numpy(v), 0.84147, atol=1e-4)
+    np.testing.assert_allclose(tc.backend.numpy(g), 0.54032, atol=1e-4)
+    # a two-site local tensor on non-adjacent sites, value against the dense oracle and the operator's matrix
+    n = 5
+    rng = np.random.default_rng(2)
+    h = rng.normal(size=(4, 4)) + 1j * rng.normal(size=(4, 4))
+    h = h + h.conj().T
+    op = tc.quantum.QuOperator.from_local_tensor(h, [2] * n, [3, 1])
+    pr = rng.uniform(0, 6, [4, n])
+    c = tc.Circuit(n)
+    W.hea_b(c, n, 2, tc.backend.convert_to_tensor(pr, dtype=tc.rdtypestr), zz=tc.gates._zz_matrix)
+    psi = dense.run(n, W.hea_b_ops(n, 2, pr))
+    want = dense.expectation(psi, n, (h, [3, 1])).real
+    got = float(tc.backend.numpy(tc.templates.measurements.mpo_expectation(c, op)))
+    assert abs(got - want) < (1e-4 if tc.dtypestr == "complex64" else 1e-9)
+    m = tc.backend.numpy(op.eval_matrix())
+    assert abs(np.vdot(psi, m @ psi).real - want) < 1e-4
+
+
+def test_example_block_is_the_hea_b_ansatz(tcd):
+    """templates.blocks.example_block (reference blocks.py:146-185) reproduces the golden HEA-B states; with
+    is_split=True (max_singular_values 2 keeps the ZZ gate exactly) too."""
+    tc = tcd
+    for n, d in ((8, 3), (10, 4)):
+        params = GOLD[f"hea_b_{n}_{d}_params"]
+        ref = GOLD[f"hea_b_{n}_{d}_state"]
+        tol = 1e-5 if tc.dtypestr == "complex64" else 1e-10
+        for split in (False, True):
+            c = tc.templates.blocks.example_block(tc.Circuit(n), tc.backend.convert_to_tensor(params.reshape(-1), dtype=tc.rdtypestr),
+                                                  nlayers=d, is_split=split)
+            assert np.abs(tc.backend.numpy(c.wavefunction()) - ref).max() < tol, (n, d, split)

@@ -2,6 +2,8 @@
 central-difference gradients, and the full-size configurations through size-independent properties
 (complex64 against complex128 of the same circuit, norms, canonical forms)."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -54,6 +56,13 @@ def test_tfim_value_and_gradient_vs_dense_oracle(n, d, dtype):
         tc.set_dtype("complex64")
 
 
+def _full_golden():
+    f = os.path.join(os.path.dirname(__file__), "golden", "full_size_golden.npz")
+    if not os.path.exists(f):
+        pytest.fail("tests/golden/full_size_golden.npz is missing (python tests/golden/make_golden_full.py ...)")
+    return np.load(f)
+
+
 def test_config3_full_size_complex64_against_complex128():
     """SURVEY 8d config 3 at full size (n = 28, depth 12, one sample of the bench's parameter generator), complex64
     against a complex128 run of the same circuit (the c128 path runs on different kernels: first-generation
@@ -90,6 +99,16 @@ def test_config3_full_size_complex64_against_complex128():
           f"|E| difference {de:.2e}, max gradient difference {dg:.2e}, norms {n64:.8f} / {n128:.12f}")
     assert abs(n128 - 1) < 1e-10 and abs(n64 - 1) < 1e-4, (n64, n128)
     assert dterm < 1e-5, dterm
+    # ... and against the ORACLE: the 55 terms and the energy of this very circuit from oracle.dense (complex128, gate by
+    # gate on the 4 GiB state; tests/golden/make_golden_full.py config3), committed as a fixture
+    full = _full_golden()
+    assert np.array_equal(full["config3_params"].astype(np.float32), params.astype(np.float32))
+    tor = np.concatenate([full["config3_x"], full["config3_zz"]])
+    print(f"config 3 full size vs oracle.dense fixture: max |<P_t>| error complex64 {np.abs(t64 - tor).max():.2e}, "
+          f"complex128 {np.abs(t128 - tor).max():.2e}; energy error {abs(e64 - float(full['config3_energy'])):.2e} / "
+          f"{abs(e128 - float(full['config3_energy'])):.2e}")
+    assert np.abs(t128 - tor).max() < 1e-10 and abs(e128 - float(full["config3_energy"])) < 1e-9
+    assert np.abs(t64 - tor).max() < 1e-5 and abs(e64 - float(full["config3_energy"])) < 55e-5
     assert abs(e128 - (t128[n:].sum() - t128[:n].sum())) < 1e-9      # the energy is the sum of its terms
     assert de < 55e-5, (e64, e128)
     assert dg < 1e-4, dg
@@ -280,7 +299,7 @@ def test_config5_full_size_mps_sweep_properties():
                / np.sqrt(2 * dims[i]) for i in range(n)]
     gates = [unitary_group.rvs(4, random_state=5000 + i).reshape(2, 2, 2, 2) for i in range(n - 1)]
     tc.set_backend("hip")
-    fid = {}
+    fid, spec = {}, {}
     try:
         for dtype, cdt in (("complex64", np.complex64), ("complex128", np.complex128)):
             tc.set_dtype(dtype)
@@ -301,10 +320,26 @@ def test_config5_full_size_mps_sweep_properties():
                 gram = torch.einsum("lsr,lsq->rq", a.conj(), a)
                 assert float((gram - torch.eye(gram.shape[0], dtype=gram.dtype, device=gram.device)).abs().max()) < tol
             fid[dtype] = (float(m._fidelity), nrm0, float(abs(m.get_norm())))
+            bd = m.get_bond_dimensions()
+            m.position(n // 2)
+            a = m.get_tensors()[n // 2].to(torch.complex128).cpu()
+            spec[dtype] = (torch.linalg.svdvals(a.reshape(a.shape[0], -1)).numpy(), bd)
     finally:
         tc.set_dtype("complex64")
     f64, f128 = fid["complex64"], fid["complex128"]
     assert abs(f64[0] - f128[0]) < 2e-3 * max(f128[0], 1e-3), (f64, f128)
+    # against the ORACLE (oracle.mps: numpy + LAPACK SVD on the same tensors and gates; make_golden_full.py config5):
+    # fidelity estimate, norms before / after the sweep, bond dimensions, Schmidt spectrum of the middle bond
+    full = _full_golden()
+    fo, n0, n1 = float(full["config5_fidelity"]), float(full["config5_norm0"]), float(full["config5_norm1"])
+    print(f"config 5 full size vs oracle.mps fixture: fidelity {fo:.9f}; complex128 {f128[0]:.9f}, complex64 {f64[0]:.6f}; "
+          f"norm after the sweep {n1:.9f} / {f128[2]:.9f} / {f64[2]:.6f}")
+    assert abs(f128[0] - fo) < 1e-8 and abs(f128[1] - n0) < 1e-9 and abs(f128[2] - n1) < 1e-8
+    assert abs(f64[0] - fo) < 2e-3 * fo and abs(f64[2] - n1) < 2e-3
+    for dtype in ("complex64", "complex128"):
+        assert list(spec[dtype][1]) == [int(x) for x in full["config5_bond_dims"]]
+        err = np.abs(spec[dtype][0] - full["config5_mid_spectrum"]).max()
+        assert err < (2e-4 if dtype == "complex64" else 1e-8), (dtype, err)
     assert 0 < f128[0] < 1
     # truncation only removes weight: the norm after the sweep is the start norm times sqrt of the kept weights
     assert f128[2] <= f128[1] * (1 + 1e-9)
@@ -358,3 +393,10 @@ def test_config4_full_size_amplitude_against_statevector():
     assert abs(nrm - 1.0) < 2e-4, nrm
     assert abs(v) > 1e-6                                     # a typical amplitude is 2^-16
     assert abs(v - a0) < 2e-4 * abs(a0), (v, a0)
+    # ... and both against the ORACLE: the same amplitude from a numpy complex128 tensordot chain over a sliced pairwise
+    # path (tests/golden/make_golden_full.py config4; the chain is checked there against oracle.tn's own greedy
+    # contraction at 20 qubits)
+    ao = complex(*_full_golden()["config4_amplitude"])
+    print(f"config 4 full size vs the numpy oracle fixture: |DistributedContractor - oracle| / |oracle| = {abs(v - ao) / abs(ao):.2e}, "
+          f"|state vector[0] - oracle| / |oracle| = {abs(a0 - ao) / abs(ao):.2e}")
+    assert abs(v - ao) < 5e-4 * abs(ao) and abs(a0 - ao) < 5e-4 * abs(ao), (v, a0, ao)
