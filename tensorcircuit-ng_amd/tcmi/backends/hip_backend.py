@@ -469,7 +469,16 @@ class HipBackend:
         As under the reference's ``jax.jit``, a traced function is a function of its ARGUMENTS only: the trace is
         validated against the plain path on the first two calls, after that global state the Python body reads
         (module variables, closures that change between calls) is frozen at its traced value; Python that branches on
-        an argument's value is detected while probing and keeps the plain path."""
+        an argument's value is detected while probing and keeps the plain path.
+
+        What a trace is keyed on -- a change of any of these traces (and validates) again, exactly the properties
+        ``jax.jit`` re-traces on (``tcmi/jit.py::TracedVag._signature``; ``test_gpu_grad.py::test_what_invalidates_a_jit_trace``):
+          * shape and dtype of every tensor / numpy positional argument;
+          * the VALUE of every python scalar positional argument (int, float, complex, str, bool, None): they are
+            static, as under ``static_argnums``;
+          * the global dtype (``tc.set_dtype``) and contractor (``tc.set_contractor``).
+        Calls with keyword arguments, or with positional arguments of any other type, are never traced (plain path).
+        NOT part of the key: values of tensor arguments (that is the point), closures, module globals."""
         from ..jit import TracedVag
 
         if static_argnums:

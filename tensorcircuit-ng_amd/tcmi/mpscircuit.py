@@ -345,16 +345,18 @@ class MPSCircuit:
         self._fidelity = self._fidelity * (1 - (tw2[0] if tw2 is not None else (err.real ** 2 + err.imag ** 2).sum()))
 
     def consecutive_swap(self, index_from: int, index_to: int, split: Optional[Dict[str, Any]] = None) -> None:
+        """Carry the site at ``index_from`` to ``index_to`` through its neighbours (reference :329-351).  A SWAP of two
+        adjacent sites needs no gate arithmetic: the two-site block is formed, its physical legs are exchanged by
+        relabelling, and the block is split again (``_block`` / ``_split_block``) -- the centre travels with the site."""
         if split is None:
             split = self.split
         self.position(index_from)
-        swap = G.swap()
-        if index_from < index_to:
-            for i in range(index_from, index_to):
-                self.apply_adjacent_double_gate(swap, i, i + 1, center_position=i + 1, split=split)
-        elif index_from > index_to:
-            for i in range(index_from, index_to, -1):
-                self.apply_adjacent_double_gate(swap, i - 1, i, center_position=i - 1, split=split)
+        step = 1 if index_to > index_from else -1
+        for i in range(index_from, index_to, step):
+            lo = min(i, i + step)
+            theta = self._block(lo, lo + 1)                                   # [cl, 2, 2, cr]
+            theta = theta.permute(0, 2, 1, 3).contiguous()
+            self._split_block(theta, lo, lo + 1, center_left=(step == -1), split=split, track=True)
         assert self._mps.center_position == index_to
 
     def apply_double_gate(self, gate: Any, index1: int, index2: int,
@@ -378,118 +380,212 @@ class MPSCircuit:
             self.apply_adjacent_double_gate(gate, index1, index1 + 1, center_position=index1 + 1, split=split)
             self.consecutive_swap(index1 + 1, index2, split=split)
 
-    # ---- MPO route for n >= 3 qubit gates (reference :386-668)
+    # ---- gates on three or more sites: BLOCK UPDATE (reference :386-668 reaches the same states through an MPO) -------
+    # The reference turns an n-qubit gate into an MPO by a chain of SVDs, multiplies it into the MPS site by site (one QR
+    # per site on a bond of chi x D) and then compresses bond by bond.  Here the unit of work is the GPU's: the w sites the
+    # gate spans are contracted into ONE block [chi_l, 2^w, chi_r] (w - 1 GEMMs, tcmi_cgemm), the gate is ONE GEMM on the
+    # block's physical legs, and the block is split back by w - 1 (truncated) factorisations that peel one site at a time
+    # off the far end -- the same cuts, truncated in the same order, as the reference's compression sweep, so the states
+    # agree; no MPO, no intermediate bond of chi x D.  Spans too wide for one block are first gathered with
+    # ``consecutive_swap``.  ``gate_to_MPO`` / ``apply_MPO`` / ``reduce_dimension`` stay as public entry points on top of
+    # the same two primitives.
+    BLOCK_MAX_ELEMENTS = 1 << 26          # chi_l * 2^w * chi_r of one block (512 MiB of complex64)
+    BLOCK_MAX_SITES = 12                  # ... and 4^w elements of the operator on its physical legs
+
+    def _block(self, left: int, right: int) -> Tensor:
+        """Sites left..right contracted into [chi_l, 2, ..., 2, chi_r] (the centre must sit inside)."""
+        ts = self._mps.tensors
+        theta = ts[left]
+        cl = int(theta.shape[0])
+        for s_ in range(left + 1, right + 1):
+            t = ts[s_]
+            theta = LA.matmul(theta.reshape(-1, t.shape[0]), t.reshape(t.shape[0], -1))
+        w = right - left + 1
+        return theta.reshape((cl,) + (2,) * w + (int(ts[right].shape[-1]),))
+
+    def _cut(self, rem: Tensor, center_left: bool, split: Optional[Dict[str, Any]], track: bool):
+        """One cut of a block: (left factor, right factor) with the weights on the centre's side.  ``track``: the
+        discarded weight of a truncating cut enters the fidelity estimate (as the reference's two-site updates do)."""
+        if not (track and split):
+            return split_tensor(rem, center_left=center_left, split=split)
+        u, _, vh, rest = LA.svd_trunc(rem, absorb=1 if center_left else 2, **split)
+        tw2 = getattr(rest, "_tcmi_tw2", None)
+        self._fidelity = self._fidelity * (1 - (tw2[0] if tw2 is not None else (rest.real ** 2 + rest.imag ** 2).sum()))
+        return u, vh
+
+    def _split_block(self, theta: Tensor, left: int, right: int, center_left: bool,
+                     split: Optional[Dict[str, Any]] = None, track: bool = False) -> None:
+        """Write the block back as sites left..right.  ``center_left``: sites are peeled off the RIGHT end (each an
+        isometry from the right, the remainder keeps the weights) and the centre ends on ``left``; otherwise mirrored.
+        With truncation rules every cut is a truncated SVD of the exact remainder, else QR / RQ (``split_tensor``)."""
+        ts = self._mps.tensors
+        cl, cr = int(theta.shape[0]), int(theta.shape[-1])
+        if center_left:
+            rem = theta.reshape(-1, 2 * cr)
+            for site in range(right, left, -1):
+                keep_l, iso_r = self._cut(rem, True, split, track)
+                k = int(iso_r.shape[0])
+                ts[site] = iso_r.reshape(k, 2, -1)
+                rem = keep_l.reshape(-1, 2 * k)
+            ts[left] = rem.reshape(cl, 2, -1).contiguous()
+            self._mps.center_position = left
+        else:
+            rem = theta.reshape(cl * 2, -1)
+            for site in range(left, right):
+                iso_l, keep_r = self._cut(rem, False, split, track)
+                k = int(iso_l.shape[1])
+                ts[site] = iso_l.reshape(-1, 2, k)
+                rem = keep_r.reshape(k * 2, -1)
+            ts[right] = rem.reshape(-1, 2, cr).contiguous()
+            self._mps.center_position = right
+        self._mps._svd_hint = None
+
+    def _block_fits(self, left: int, right: int, extra_bond: int = 1) -> bool:
+        w = right - left + 1
+        ts = self._mps.tensors
+        return w <= self.BLOCK_MAX_SITES and int(ts[left].shape[0]) * int(ts[right].shape[-1]) * (1 << w) * extra_bond \
+            <= self.BLOCK_MAX_ELEMENTS
+
+    def _block_update(self, op: Tensor, sites: Sequence[int], left: int, right: int, center_left: bool,
+                      split: Optional[Dict[str, Any]] = None) -> None:
+        """``op`` [2^k, 2^k] (rows = outputs) acts on the sorted ``sites`` inside the block left..right."""
+        torch = _torch()
+        self.position(left if center_left else right)
+        theta = self._block(left, right)
+        w, k = right - left + 1, len(sites)
+        legs = [1 + (q - left) for q in sites]
+        rest = [a for a in range(w + 2) if a not in legs]
+        perm = legs + rest
+        moved = theta.permute(perm).contiguous()
+        shp = moved.shape
+        moved = LA.matmul(_t(op).reshape(2**k, 2**k), moved.reshape(2**k, -1)).reshape(shp)
+        inv = [0] * len(perm)
+        for i_, a in enumerate(perm):
+            inv[a] = i_
+        theta = moved.permute(inv).contiguous()
+        del moved
+        # end1 = where the reference's sweep starts: its compression runs back towards it, the centre ends there
+        self._split_block(theta, left, right, center_left=center_left, split=split)
+
     @classmethod
     def gate_to_MPO(cls, gate: Any, *index: int) -> Tuple[List[Tensor], int]:
+        """An exact MPO of the gate on the strictly increasing sites ``index`` (identity tensors on the sites in between):
+        tensors [D_l, 2 (out), 2 (in), D_r] and the leftmost site.  No decomposition is computed: the sites left of the
+        middle one hand their (out, in) leg pairs to the right through the bond, the sites right of it to the left, and
+        the middle site holds the gate -- bonds 4, 16, ... , 4^floor(k/2), the worst case of an SVD-built MPO."""
         torch = _torch()
         if len(index) == 0:
             raise ValueError("`index` must contain at least one site.")
         if not all(index[i] < index[i + 1] for i in range(len(index) - 1)):
             raise ValueError("`index` must be strictly increasing.")
-        index_left = int(np.min(index))
-        nindex = len(index)
-        dim = 2
-        gate = _t(gate).reshape((dim,) * (2 * nindex))
-        order = tuple(np.arange(2 * nindex).reshape(2, nindex).T.flatten().tolist())
-        gate = gate.permute(order).contiguous().reshape((dim * dim,) * nindex)
-        main_tensors = cls.wavefunction_to_tensors(gate, dim_phys=dim * dim, norm=False)
+        k = len(index)
+        g = _t(gate).reshape((2,) * (2 * k))
+        m = k // 2                                # the site that holds the gate
+        # legs (o_1..o_k, i_1..i_k) -> (pairs left of m | o_m, i_m | pairs right of m)
+        order = []
+        for j in list(range(m)) + [m] + list(range(m + 1, k)):
+            order += [j, k + j]
+        g = g.permute(order).contiguous()
+        eye4 = torch.eye(4, dtype=g.dtype, device=g.device)
+        mains: List[Tensor] = []
+        for j in range(k):
+            if j < m:      # [4^j, o, i, 4^(j+1)]: appends its (o, i) pair to the bond
+                dl = 4**j
+                t = torch.einsum("ab,cd->acbd", torch.eye(dl, dtype=g.dtype, device=g.device), eye4)     # [dl, 4, dl, 4]
+                mains.append(t.reshape(dl, 2, 2, dl * 4))
+            elif j == m:
+                mains.append(g.reshape(4**m, 2, 2, 4 ** (k - 1 - m)))
+            else:          # [4^(k-j), o, i, 4^(k-1-j)]: takes the first (o, i) pair off the bond
+                dr = 4 ** (k - 1 - j)
+                t = torch.einsum("cd,ab->cadb", eye4, torch.eye(dr, dtype=g.dtype, device=g.device))     # [4, dr, 4, dr]
+                mains.append(t.reshape(4 * dr, 2, 2, dr))
         tensors: List[Tensor] = []
-        previous_i = None
-        for i, main in zip(np.array(index, dtype=int) - index_left, main_tensors):
-            if previous_i is not None:
-                for _ in range(int(previous_i) + 1, int(i)):
-                    bond = int(tensors[-1].shape[-1])
-                    eye = torch.eye(bond * dim, dtype=tensors[-1].dtype, device=tensors[-1].device)
-                    tensors.append(eye.reshape(bond, dim, bond, dim).permute(0, 1, 3, 2).contiguous())
-            nleft, _, nright = main.shape
-            tensors.append(main.reshape(nleft, dim, dim, nright))
-            previous_i = int(i)
-        return tensors, index_left
+        for j, site in enumerate(index):
+            if j > 0:
+                bond = int(tensors[-1].shape[-1])
+                for _ in range(index[j - 1] + 1, site):
+                    fill = torch.einsum("ab,cd->acdb", torch.eye(bond, dtype=g.dtype, device=g.device),
+                                        torch.eye(2, dtype=g.dtype, device=g.device))
+                    tensors.append(fill.contiguous())
+            tensors.append(mains[j].contiguous())
+        return tensors, int(index[0])
+
+    @classmethod
+    def MPO_to_gate(cls, tensors: Sequence[Tensor]) -> Any:
+        """reference :464-486: the MPO contracted back into a gate tensor with legs (out_1..out_w, in_1..in_w)."""
+        op = cls._mpo_operator([_t(t) for t in tensors])
+        w = len(tensors)
+        return G.Gate(op.reshape((2,) * (2 * w)))
+
+    @staticmethod
+    def _mpo_operator(tensors: Sequence[Tensor]) -> Tensor:
+        """[2^w, 2^w] matrix (rows = outputs) of an MPO whose outer bonds have dimension 1."""
+        acc = tensors[0]
+        if int(acc.shape[0]) != 1 or int(tensors[-1].shape[-1]) != 1:
+            raise ValueError("MPO with open outer bonds")
+        acc = acc.reshape(2, 2, -1)                               # [O, I, bond]
+        for t in tensors[1:]:
+            dl, _, _, dr = t.shape
+            nxt = LA.matmul(acc.reshape(-1, dl), t.reshape(dl, -1))                  # [O I, o i dr]
+            o_, i_ = int(acc.shape[0]), int(acc.shape[1])
+            acc = nxt.reshape(o_, i_, 2, 2, dr).permute(0, 2, 1, 3, 4).contiguous().reshape(o_ * 2, i_ * 2, dr)
+        return acc.reshape(acc.shape[0], acc.shape[1])
 
     @classmethod
     def reduce_tensor_dimension(cls, tensor_left: Tensor, tensor_right: Tensor, center_left: bool = True,
                                 split: Optional[Dict[str, Any]] = None) -> Tuple[Tensor, Tensor]:
-        split = split or {}
-        ni, di = tensor_left.shape[0], tensor_right.shape[1]
-        nk, dk = tensor_right.shape[-1], tensor_right.shape[-2]
-        nj = tensor_left.shape[-1]
-        t = LA.matmul(tensor_left.reshape(-1, nj), tensor_right.reshape(nj, -1)).reshape(ni * di, nk * dk)
-        nl, nr = split_tensor(t, center_left=center_left, split=split)
-        return nl.reshape(ni, di, -1), nr.reshape(-1, dk, nk)
+        """Two neighbouring site tensors re-split across their bond under the truncation rules (reference :488-520)."""
+        a, b = _t(tensor_left), _t(tensor_right)
+        pair = LA.matmul(a.reshape(-1, a.shape[-1]), b.reshape(b.shape[0], -1))      # [cl * 2, 2 * cr]
+        lft, rgt = split_tensor(pair, center_left=center_left, split=split or {})
+        return lft.reshape(a.shape[0], a.shape[1], -1), rgt.reshape(-1, b.shape[1], b.shape[2])
 
     def reduce_dimension(self, index_left: int, center_left: bool = True,
                          split: Optional[Dict[str, Any]] = None) -> None:
+        """Compress the bond (index_left, index_left + 1); the centre must sit on one of the two sites (reference :522-550)."""
         if split is None:
             split = self.split
-        index_right = index_left + 1
-        assert self._mps.center_position in [index_left, index_right]
-        nl, nr = self.reduce_tensor_dimension(self._mps.tensors[index_left], self._mps.tensors[index_right],
-                                              center_left=center_left, split=split)
-        self._mps.tensors[index_left] = nl
-        self._mps.tensors[index_right] = nr
-        self._mps.center_position = index_left if center_left else index_right
+        if self._mps.center_position not in (index_left, index_left + 1):
+            raise ValueError("reduce_dimension: the centre must be on one of the two sites")
+        self._split_block(self._block(index_left, index_left + 1), index_left, index_left + 1,
+                          center_left=center_left, split=split)
 
     def apply_MPO(self, tensors: Sequence[Tensor], index_left: int, center_left: bool = True,
                   split: Optional[Dict[str, Any]] = None) -> None:
+        """An MPO on the sites index_left .. index_left + len(tensors) - 1 (reference :552-634); ``center_left``: the
+        sweep starts -- and the centre ends -- on the left end.  The MPO is contracted into its operator on the block's
+        physical legs and applied as one block update."""
         if split is None:
             split = self.split
         tensors = [_t(t) for t in tensors]
-        nindex = len(tensors)
-        index_right = index_left + nindex - 1
-        if center_left:
-            end1, end2, step = index_left, index_right, 1
-        else:
-            end1, end2, step = index_right, index_left, -1
-        n_list = np.arange(nindex)[::step]
-        idx_list = np.arange(index_left, index_right + 1)[::step]
-        self.position(end1)
-        residue = None
-        for i, idx in zip(n_list, idx_list):
-            idx = int(idx)
-            o = tensors[int(i)]
-            t = self._mps.tensors[idx]
-            ni, d_out, _, nj = o.shape
-            nk, _, nl = t.shape
-            ot = LA.einsum2("iabj,kbl->ikajl", o, t).reshape(ni * nk, d_out, nj * nl)
-            if residue is not None:
-                if step == 1:
-                    ot = LA.matmul(residue, ot.reshape(ni * nk, -1)).reshape(-1, d_out, nj * nl)
-                else:
-                    ot = LA.matmul(ot.reshape(-1, nj * nl), residue).reshape(ni * nk, d_out, -1)
-            s0, s1, s2 = ot.shape
-            if idx != end2:
-                if step == 1:
-                    q, r = LA.qr(ot.reshape(s0 * s1, -1))
-                    self._mps.tensors[idx] = q.reshape(s0, s1, -1)
-                    residue = r
-                    self._mps.center_position = idx + 1
-                else:
-                    q_t, r_t = LA.qr(ot.permute(2, 1, 0).contiguous().reshape(s2 * s1, -1))
-                    self._mps.tensors[idx] = q_t.reshape(s2, s1, -1).permute(2, 1, 0).contiguous()
-                    residue = r_t.t().contiguous()
-                    self._mps.center_position = idx - 1
-            else:
-                self._mps.tensors[idx] = ot.contiguous()
-                self._mps.center_position = end2
-        for i in idx_list[::-1][:-1]:
-            i = int(i)
-            self.reduce_dimension(min(i, i - step), center_left=center_left, split=split)
+        w = len(tensors)
+        right = index_left + w - 1
+        if not self._block_fits(index_left, right):
+            raise NotImplementedError(f"Backend 'hip' has not implemented apply_MPO over {w} sites at these bond dimensions "
+                                      f"(one block of more than {self.BLOCK_MAX_ELEMENTS} elements)")
+        self._block_update(self._mpo_operator(tensors), list(range(index_left, right + 1)), index_left, right,
+                           center_left=center_left, split=split)
 
     def apply_nqubit_gate(self, gate: Any, *index: int, split: Optional[Dict[str, Any]] = None) -> None:
-        gate = _t(gate)
-        if not np.all(np.diff(index) > 0):
-            order = np.argsort(index)
-            order_all = order.tolist() + (order + len(index)).tolist()
-            gate = gate.reshape((2,) * (2 * len(index))).permute(order_all).contiguous()
-            self.apply_nqubit_gate(gate, *np.sort(index).tolist(), split=split)
-            return
+        """A gate on three or more sites (reference :636-668), by one block update over the sites it spans; a span too
+        wide for one block is gathered next to its first site with ``consecutive_swap`` and scattered again afterwards."""
         if split is None:
             split = self.split
-        mpo, index_left = self.gate_to_MPO(gate, *index)
-        index_right = index_left + len(mpo) - 1
-        diff_left = abs(index_left - self._mps.center_position)
-        diff_right = abs(index_right - self._mps.center_position)
-        self.apply_MPO(mpo, index_left, center_left=diff_left < diff_right, split=split)
+        k = len(index)
+        order = sorted(range(k), key=lambda j: index[j])
+        sites = [int(index[j]) for j in order]
+        op = _t(gate).reshape((2,) * (2 * k)).permute(order + [k + j for j in order]).contiguous().reshape(2**k, 2**k)
+        left, right = sites[0], sites[-1]
+        if self._block_fits(left, right):
+            near_left = abs(left - self._mps.center_position) < abs(right - self._mps.center_position)
+            self._block_update(op, sites, left, right, center_left=near_left, split=split)
+            return
+        home = list(sites)
+        for j in range(1, k):                       # gather: site j of the gate next to site j - 1
+            self.consecutive_swap(sites[j], left + j, split=split)
+        self._block_update(op, [left + j for j in range(k)], left, left + k - 1, center_left=True, split=split)
+        for j in range(k - 1, 0, -1):               # scatter, last moved first
+            self.consecutive_swap(left + j, home[j], split=split)
 
     def apply_general_gate(self, gate: Any, *index: int, name: Optional[str] = None,
                            split: Optional[Dict[str, Any]] = None, mpo: bool = False,

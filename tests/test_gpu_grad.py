@@ -743,3 +743,69 @@ def test_tiled_pauli_sum_equals_the_flat_kernel_and_gives_the_energy(dt):
         v = psi[b].cpu().numpy().astype(np.complex128)
         want = sum(float(w[b, k]) * dense.pauli_string_expectation(v, n, strings[k]).real for k in range(len(rows)))
         assert abs(e[b] - want) < (2e-5 if dt == "complex64" else 1e-11), (b, e[b], want)
+
+
+def test_what_invalidates_a_jit_trace():
+    """HipBackend.jit's contract: the host-side trace is keyed on tensor shapes / dtypes, on the
+    VALUES of python scalar arguments, on the global dtype and contractor -- each of them re-traces -- and on nothing
+    else: tensor values replay, a closure that changes after tracing is frozen (as under jax.jit)."""
+    import tcmi as tc
+
+    tc.set_backend("hip")
+    tc.set_dtype("complex64")
+    K = tc.backend
+    scale = {"v": 1.0}
+
+    def energy(p, k):
+        n = p.shape[-1]
+        c = tc.Circuit(n)
+        for i in range(n):
+            c.h(i)
+        for i in range(n - 1):
+            c.rzz(i, i + 1, theta=p[0, i])
+        for i in range(n):
+            c.rx(i, theta=p[1, i])
+        return K.real(scale["v"] * k * c.expectation_ps(z=[0, 1]) + c.expectation_ps(x=[n - 1]))
+
+    def ref(p, k):
+        return K.value_and_grad(energy)(p, k)
+
+    f = K.jit(K.value_and_grad(energy))
+    rng = np.random.default_rng(0)
+    p6 = [K.convert_to_tensor(rng.uniform(0, 3, [2, 6]).astype(np.float32)) for _ in range(4)]
+    try:
+        for p in p6:                      # calls 1-2 trace + validate, 3-4 replay
+            v, g = f(p, 2)
+            v0, g0 = ref(p, 2)
+            assert abs(float(v) - float(v0)) < 1e-5 and float((g - g0).abs().max()) < 1e-5
+        assert f.stats["fast"] == 2 and len(f.plans) == 1
+        # a python scalar argument is static: another value is another trace, with the right result
+        v, g = f(p6[0], 3)
+        v0, g0 = ref(p6[0], 3)
+        assert abs(float(v) - float(v0)) < 1e-5 and len(f.plans) == 2
+        # another shape: another trace
+        p8 = K.convert_to_tensor(rng.uniform(0, 3, [2, 8]).astype(np.float32))
+        for _ in range(3):
+            v, g = f(p8, 2)
+        v0, g0 = ref(p8, 2)
+        assert abs(float(v) - float(v0)) < 1e-5 and float((g - g0).abs().max()) < 1e-5 and len(f.plans) == 3
+        # the global dtype is part of the key
+        tc.set_dtype("complex128")
+        p6d = K.convert_to_tensor(rng.uniform(0, 3, [2, 6]))
+        v, g = f(p6d, 2)
+        v0, g0 = ref(p6d, 2)
+        assert abs(float(v) - float(v0)) < 1e-10 and len(f.plans) == 4
+        tc.set_dtype("complex64")
+        # keyword arguments: never traced
+        slow = f.stats["slow"]
+        f(p6[0], k=2)
+        assert f.stats["slow"] == slow + 1 and len(f.plans) == 4
+        # NOT part of the key: a closure that changes after the trace is frozen at its traced value (jax.jit's contract)
+        fast = f.stats["fast"]
+        v_before, _ = f(p6[1], 2)
+        scale["v"] = 5.0
+        v_after, _ = f(p6[1], 2)
+        assert f.stats["fast"] == fast + 2 and abs(float(v_before) - float(v_after)) < 1e-7
+        scale["v"] = 1.0
+    finally:
+        tc.set_dtype("complex64")

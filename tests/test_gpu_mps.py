@@ -417,3 +417,139 @@ def test_qr_preconditioned_jacobi_needs_ten_sweeps_whatever_the_grading(monkeypa
         assert float((p1 - p0).abs().max()) < 1e-4 * float(p0.abs().max())
         assert abs(float(r1._tcmi_tw2[0]) - float(r0._tcmi_tw2[0])) < 1e-4 * max(1.0, float(r0._tcmi_tw2[0]))
 
+
+
+# ---- gates on three or more sites: the block update (tcmi/mpscircuit.py) against the oracle's MPO route -----------------
+def _haar(k, seed):
+    from scipy.stats import unitary_group
+
+    return unitary_group.rvs(2**k, random_state=seed).reshape((2,) * (2 * k))
+
+
+def _prepared(tcm, n, seed, split=None):
+    """The same entangling prelude on a product MPSCircuit and on the oracle's: nearest-neighbour Haar gates, two layers."""
+    ops = []
+    k = 0
+    for layer in range(2):
+        for i in range(layer % 2, n - 1, 2):
+            g = _haar(2, seed + k)
+            k += 1
+            ops.append((g, (i, i + 1)))
+    return ops
+
+
+@pytest.mark.parametrize("dt", ["complex64", "complex128"])
+def test_three_and_four_qubit_gates_on_non_adjacent_sites_match_the_oracle(dt):
+    """3- and 4-qubit gates on scattered, unsorted sites: without truncation the state equals oracle.mps (which follows the
+    reference's MPO route, mpscircuit.py:386-668) and the dense oracle; with max_singular_values the block update cuts the
+    same bonds in the same order as the reference's compression sweep, so the truncated states agree too."""
+    from oracle import dense
+
+    tc.set_backend("hip")
+    tc.set_dtype(dt)
+    try:
+        n = 9
+        cdt = np.complex64 if dt == "complex64" else np.complex128
+        big = [(_haar(3, 11), (1, 3, 4)), (_haar(3, 12), (6, 2, 4)), (_haar(4, 13), (0, 2, 5, 8)), (_haar(3, 14), (7, 8, 5))]
+        for split, tol in ((None, 3e-5 if dt == "complex64" else 1e-10),
+                           (dict(max_singular_values=6), 2e-4 if dt == "complex64" else 1e-8)):
+            m = tc.MPSCircuit(n, split=tc.cons.split_rules(**split) if split else None)
+            o = omps.MPSCircuit(n, split=omps.split_rules(**split) if split else None)
+            ops = _prepared(None, n, 100) + big + _prepared(None, n, 200)
+            for g, idx in ops:
+                m.apply(tc.gates.Gate(g.astype(cdt)), *idx)
+                o.apply(g.astype(np.complex128), *idx)
+            got = m.wavefunction().reshape(-1).cpu().numpy()
+            want = np.asarray(o.wavefunction()).reshape(-1)
+            assert np.abs(got - want).max() < tol, (dt, split, np.abs(got - want).max())
+            assert m.is_valid()
+            if split is None:
+                ref = dense.run(n, [(g.reshape(2 ** len(idx), -1), list(idx)) for g, idx in ops])
+                assert np.abs(got - ref).max() < tol
+            else:
+                assert max(m.get_bond_dimensions()) <= 6
+                assert list(m.get_bond_dimensions()) == list(o.get_bond_dimensions())
+            # canonical form around the centre
+            ts = m.get_tensors()
+            c = m.get_center_position()
+            for site in range(n):
+                a = ts[site].to(torch.complex128)
+                if site < c:
+                    gram = torch.einsum("lsr,lsq->rq", a.conj(), a)
+                elif site > c:
+                    gram = torch.einsum("lsr,ksr->lk", a.conj(), a)
+                else:
+                    continue
+                eye = torch.eye(gram.shape[0], dtype=gram.dtype, device=gram.device)
+                assert float((gram - eye).abs().max()) < (2e-4 if dt == "complex64" else 1e-10), site
+    finally:
+        tc.set_dtype("complex64")
+
+
+def test_mpo_conversion_and_explicit_mpo_sweeps_like_the_reference_tests():
+    """reference tests/test_mpscircuit.py:275-291 (MPO_to_gate(gate_to_MPO(g)) = g, identity tensors on skipped sites)
+    and :343-372 (apply_MPO in both directions: canonical afterwards, state = the circuit's)."""
+    tc.set_backend("hip")
+    tc.set_dtype("complex128")
+    try:
+        o3 = _haar(3, 21)
+        mpo3, left = tc.MPSCircuit.gate_to_MPO(tc.gates.Gate(o3), 2, 3, 4)
+        assert left == 2 and len(mpo3) == 3
+        np.testing.assert_allclose(tc.MPSCircuit.MPO_to_gate(mpo3).tensor.cpu().numpy(), o3, atol=1e-12)
+        mpo4, left = tc.MPSCircuit.gate_to_MPO(tc.gates.Gate(o3), 1, 3, 4)
+        assert left == 1 and len(mpo4) == 4
+        want = np.einsum("ijkabc,pq->ipjkaqbc", o3, np.eye(2))
+        np.testing.assert_allclose(tc.MPSCircuit.MPO_to_gate(mpo4).tensor.cpu().numpy(), want, atol=1e-12)
+        o5 = _haar(5, 22)
+        mpo5, _ = tc.MPSCircuit.gate_to_MPO(tc.gates.Gate(o5), 0, 1, 2, 3, 4)
+        np.testing.assert_allclose(tc.MPSCircuit.MPO_to_gate(mpo5).tensor.cpu().numpy(), o5, atol=1e-12)
+        with pytest.raises(ValueError):
+            tc.MPSCircuit.gate_to_MPO(tc.gates.Gate(o3), 3, 2, 4)
+        # explicit MPO, both sweep directions
+        u1 = _haar(1, 23)
+        u_mpo = [torch.from_numpy(u1[None, :, :, None]).cuda()] * 4
+        m = tc.MPSCircuit(4)
+        m.position(0)
+        m.apply_MPO(u_mpo, 0, center_left=True)
+        assert m.get_center_position() == 0
+        m.position(3)
+        m.apply_MPO(u_mpo, 0, center_left=False)
+        assert m.get_center_position() == 3
+        c = tc.Circuit(4)
+        for _ in range(2):
+            for i in range(4):
+                c.any(i, unitary=u1)
+        np.testing.assert_allclose(m.wavefunction().reshape(-1).cpu().numpy(), c.wavefunction().cpu().numpy(), atol=1e-12)
+        # reduce_dimension on one bond: the reference's entry point, here a two-site block re-split
+        m2 = tc.MPSCircuit(6)
+        for g, idx in _prepared(None, 6, 300):
+            m2.apply(tc.gates.Gate(g), *idx)
+        before = m2.wavefunction().reshape(-1).cpu().numpy()
+        m2.position(2)
+        m2.reduce_dimension(2, center_left=False)
+        assert m2.get_center_position() == 3
+        np.testing.assert_allclose(m2.wavefunction().reshape(-1).cpu().numpy(), before, atol=1e-12)
+    finally:
+        tc.set_dtype("complex64")
+
+
+def test_spans_too_wide_for_one_block_are_gathered_by_swaps(monkeypatch):
+    """With the block budget forced down, a 3-qubit gate on sites (0, 4, 7) takes the gather / scatter route
+    (consecutive_swap = two-site blocks with relabelled legs): same state as the dense oracle."""
+    from oracle import dense
+    from tcmi.mpscircuit import MPSCircuit
+
+    tc.set_backend("hip")
+    tc.set_dtype("complex128")
+    try:
+        monkeypatch.setattr(MPSCircuit, "BLOCK_MAX_SITES", 4)
+        n = 8
+        ops = _prepared(None, n, 400) + [(_haar(3, 31), (7, 0, 4))] + _prepared(None, n, 500) + [(_haar(4, 32), (1, 6, 3, 5))]
+        m = tc.MPSCircuit(n)
+        for g, idx in ops:
+            m.apply(tc.gates.Gate(g), *idx)
+        ref = dense.run(n, [(g.reshape(2 ** len(idx), -1), list(idx)) for g, idx in ops])
+        assert np.abs(m.wavefunction().reshape(-1).cpu().numpy() - ref).max() < 1e-10
+        assert abs(float(m._fidelity) - 1.0) < 1e-12
+    finally:
+        tc.set_dtype("complex64")
