@@ -614,6 +614,59 @@ def sliced_vqa_leg(tc, torch, dist, args, rank, world):
     return out
 
 
+def hea_a_leg(tc, torch, args, dev):
+    """SURVEY 8(d) config 2, secondary workload: HEA-A (reference benchmarks/scripts_v2/benchmark_core.py:6-14: H layer, then
+    per layer rx on every qubit and a CNOT ladder), same size and call as the headline -- backend.jit(backend.vmap(
+    wavefunction)), batch --batch, this rank only (it is a per-GPU figure next to the headline, not a second headline)."""
+    import numpy as np
+    from tcmi import executor as X
+
+    n, d, B = args.qubits, args.depth, args.batch
+    params = torch.from_numpy(np.random.default_rng(n + 7).uniform(0, 2 * np.pi, [B, d, n]).astype(np.float32)).to(dev)
+
+    def wavefunction(p):
+        c = tc.Circuit(n)
+        for i in range(n):
+            c.h(i)
+        for j in range(d):
+            for i in range(n):
+                c.rx(i, theta=p[j, i])
+            for i in range(n - 1):
+                c.cx(i, i + 1)
+        return c.wavefunction()
+
+    fwd = tc.backend.jit(tc.backend.vmap(wavefunction))
+    for _ in range(3):
+        st = fwd(params)
+    torch.cuda.synchronize()
+    X.EVENT_LOG = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = fwd(params)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / args.steps
+    ev = summarize_events(X.EVENT_LOG)
+    X.EVENT_LOG = None
+    nrm = float((st[0].abs() ** 2).sum().item())
+    from tcmi.executor import CutCircuit
+
+    c0 = tc.Circuit(n)
+    for i in range(n):
+        c0.h(i)
+    for j in range(d):
+        for i in range(n):
+            c0.rx(i, theta=params[0, j, i])
+        for i in range(n - 1):
+            c0.cx(i, i + 1)
+    cc = c0._compiled()
+    return {"workload": f"HEA-A statevector contraction n={n} depth={d} complex64, vmap batch {B}, through "
+                        f"backend.jit(backend.vmap(wavefunction))",
+            "amplitudes_per_s_per_gpu": B * (2**n) / el, "ms_per_call": el * 1e3, "state_norm": nrm,
+            "contraction": "cut" if isinstance(cc, CutCircuit) else "state-vector",
+            "passes": hbm_entry("tile-VM gate passes", ev.get("pass"), args.steps),
+            "kernel_ms_per_call": {k: v["ms"] / args.steps for k, v in ev.items()}}
+
+
 def _guard(name, fn, *a):
     """Secondary legs must never take the headline line down with them."""
     try:
@@ -701,6 +754,7 @@ def main():
     ap.add_argument("--svqa-slices", type=int, default=8)
     ap.add_argument("--svqa-steps", type=int, default=3)
     ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph replay measurement")
+    ap.add_argument("--no-hea-a", action="store_true", help="skip the HEA-A secondary workload of config 2")
     ap.add_argument("--no-traffic-probe", action="store_true", help="skip the rocprofv3 PMC child runs (traffic = null)")
     ap.add_argument("--probe-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--contractor", default="greedy",
@@ -865,6 +919,10 @@ def main():
     del state
     torch.cuda.empty_cache()
 
+    hea_a = None
+    if rank == 0 and not args.probe_child and not args.no_hea_a:
+        hea_a = _guard("hea_a", hea_a_leg, tc, torch, args, dev)
+        torch.cuda.empty_cache()
     vqe = None
     if args.vqe_qubits:
         vqe = _guard("vqe_step", vqe_leg, tc, torch, dist, args, rank, world, dev)
@@ -956,6 +1014,8 @@ def main():
         }
         if graph_info is not None:
             out["hipgraph_replay"] = graph_info
+        if hea_a is not None:
+            out["hea_a"] = hea_a
         if vqe is not None:
             out["vqe_step"] = vqe
         if rqc is not None:

@@ -929,8 +929,9 @@ class _HalfBatch:
     per K_s = prod_{k<s} r_k digit prefixes, its states are replicated K / K_s times, and the suffix
     runs on the replicas — K_s |prefix| + K |suffix| gate applications instead of K (|prefix| + |suffix|)."""
 
-    def __init__(self, nq, gates, nparams, nb, radices, dtypestr, opts):
-        self.nq, self.radices = nq, list(radices)
+    @staticmethod
+    def split_point(gates, nparams, nb, radices):
+        """(s, position of the (s+1)-th selector gate) of the two-level split, s = 0: one level.  Host work only."""
         K = int(np.prod(radices)) if radices else 1
         sel_pos = [i for i, g in enumerate(gates) if g.select is not None]
         ordered = [gates[i].param.index - nparams for i in sel_pos] == list(range(len(sel_pos)))
@@ -942,13 +943,16 @@ class _HalfBatch:
                 cost = ks * cut + K * (len(gates) - cut) + 0.02 * K * len(gates)  # + extra launches / copy
                 if cost < best[0]:
                     best = (cost, s_)
-        self.s = best[1]
+        return best[1], (sel_pos[best[1]] if best[1] else None), K
+
+    def __init__(self, nq, gates, nparams, nb, radices, dtypestr, opts):
+        self.nq, self.radices = nq, list(radices)
+        self.s, cut, K = self.split_point(gates, nparams, nb, radices)
         self.K = K
         if self.s == 0:
             self.single = CompiledCircuit(nq, gates, nparams + nb, dtypestr, opts)
             self.descs = list(self.single.descs)
         else:
-            cut = sel_pos[self.s]
             self.Ks = int(np.prod(radices[: self.s]))
             self.prefix = CompiledCircuit(nq, gates[:cut], nparams + nb, dtypestr, opts)
             self.suffix = CompiledCircuit(nq, gates[cut:], nparams + nb, dtypestr, opts)
@@ -1167,12 +1171,19 @@ def get_compiled(n, gates, nparams, dtypestr, opts) -> CompiledCircuit:
 def _maybe_cut(cc, n, gates, nparams, dtypestr, opts):
     """Pick the cheaper contraction order for ``wavefunction``: state-vector plan or cut contraction.
     ``set_contractor("plain")`` / ``"tilevm"`` forces the former, ``"cut"`` the latter."""
+    best = choose_cut(n, gates, nparams, dtypestr, cc.plan)
+    return cc if best is None else CutCircuit(n, gates, nparams, dtypestr, opts, best, cc)
+
+
+def choose_cut(n, gates, nparams, dtypestr, plan):
+    """The cut (``cut.CutSpec``) the executor would contract this circuit's wavefunction with, or None for the
+    state-vector plan.  Host work only (also used to pre-compile the half-circuits' specialised kernels)."""
     from . import cons
     from . import cut as C
 
     method = getattr(cons, "_contractor_name", "greedy")
     if method in ("plain", "plain-experimental", "tilevm") or n < 16 or dtypestr != "complex64":
-        return cc
+        return None
     best, best_key = None, None
     for nl in sorted({n // 2, (n + 1) // 2, n // 2 - 1, n // 2 + 1}):
         if nl < 8 or n - nl < 8:
@@ -1187,11 +1198,11 @@ def _maybe_cut(cc, n, gates, nparams, dtypestr, opts):
     if best is None:
         if method == "cut":
             raise ValueError("set_contractor('cut'): this circuit cannot be cut (see tcmi/cut.py)")
-        return cc
-    t_vm = vm_cost_us(cc.plan)
+        return None
+    t_vm = vm_cost_us(plan)
     t_gemm = 8.0 * 2.0**n * best.bond_dim / (GEMM_TFLOPS * 1e6)      # microseconds
     t_halves = 2 * 15.0 + best.bond_dim * 2.0 ** max(best.n_left, n - best.n_left) / 2.0**24 * 200.0  # two-level
     # config 2 (n = 24, d = 8, bond 256) measured: cut 286 us per state (model 254), state-vector plan 511 (model 470)
     if method == "cut" or (t_gemm + t_halves) < 0.85 * t_vm:
-        return CutCircuit(n, gates, nparams, dtypestr, opts, best, cc)
-    return cc
+        return best
+    return None

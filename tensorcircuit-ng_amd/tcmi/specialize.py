@@ -873,6 +873,18 @@ def precompile_circuit(c, adjoint: bool = True, forward: bool = True) -> dict:
         return res
     if forward:
         res["forward"] = [r is not None for r in prepare("forward", plan.descs)]
+        # wavefunction by cut contraction: the two half-circuit batches have plans of their own (prefix / suffix)
+        spec = X.choose_cut(c._nqubits, gates, nparams, cons.dtypestr, plan)
+        if spec is not None:
+            nb = len(spec.bonds)
+            radices = [len(b.terms) for b in spec.bonds]
+            res["cut_halves"] = []
+            for nq, hg in ((spec.n_left, spec.left), (c._nqubits - spec.n_left, spec.right)):
+                s_, cut, _K = X._HalfBatch.split_point(hg, nparams, nb, radices)
+                for sub in ([hg] if s_ == 0 else [hg[:cut], hg[cut:]]):
+                    _, hcfg, hplan, _ = X.choose_plan(nq, sub, nparams + nb, cons.dtypestr, cons._plan_options)
+                    if hcfg.gen >= 2:
+                        res["cut_halves"] += [r is not None for r in prepare("forward", hplan.descs)]
     if adjoint and "adjoint" in _EMITTERS:
         for full in (False, True):
             r = X.choose_adjoint_plan(eg, n_exec, cons.dtypestr, full)
