@@ -305,6 +305,9 @@ class DistributedContractor:
         all of them, as the reference's pmap replicas do)."""
         import os
 
+        emu = getattr(self, "_emulate_rank", None)
+        if emu is not None:       # bench.py: ONE process executes what rank emu[0] of emu[1] would (no collectives; the
+            return (emu[0], emu[1], "emulate")   # other ranks' invariant roots are computed here once, outside the timing)
         if self.num_devices > 1 and os.environ.get("TCMI_TN_SHARD_INV", "1") != "0":
             return (self.rank, self.num_devices, None)
         return None

@@ -774,11 +774,11 @@ def test_what_invalidates_a_jit_trace():
     rng = np.random.default_rng(0)
     p6 = [K.convert_to_tensor(rng.uniform(0, 3, [2, 6]).astype(np.float32)) for _ in range(4)]
     try:
-        for p in p6:                      # calls 1-2 trace + validate, 3-4 replay
+        for p in p6:                      # call 1 traces and validates against the plain path, calls 2-4 replay
             v, g = f(p, 2)
             v0, g0 = ref(p, 2)
             assert abs(float(v) - float(v0)) < 1e-5 and float((g - g0).abs().max()) < 1e-5
-        assert f.stats["fast"] == 2 and len(f.plans) == 1
+        assert f.stats["fast"] == 3 and len(f.plans) == 1
         # a python scalar argument is static: another value is another trace, with the right result
         v, g = f(p6[0], 3)
         v0, g0 = ref(p6[0], 3)
