@@ -14,7 +14,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kh -o head -- pytho
 cp $(find $OUT/kh -name "*kernel_stats.csv" | head -1) $OUT/${TAG}_headline_kernel_stats.csv
 find $OUT -name "*kernel_trace.csv" -delete
 # 4. PMC passes over one VQE step at n=28 d=12 (forward, measurement, cotangent, adjoint kernels)
-for G in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_THREAD_CYCLES_VALU"; do
+for G in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_WAVE_CYCLES" "SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_VMEM" "SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_THREAD_CYCLES_VALU"; do
   i=$((i+1))
   rocprofv3 --pmc $G --output-format csv -d $OUT/pmc$i -o run -- python3 scripts/gpu_vqe_timing.py 28,12,1 > $OUT/pmc_run$i.log 2>&1
 done

@@ -47,7 +47,8 @@ for k in ("forward_pass_valu", "adjoint_pass_valu"):
         L.append(f"  {k:18s} gate arithmetic alone {x['gate_arithmetic_flops_per_step']/1e12:.1f} Tflop per step -> {x['achieved']:.1f} TF = {x['frac']:.3f} of the 157.3 TF FP32 vector peak")
 x = vr["step"]
 L.append(f"  step: executed bytes {x['executed_bytes_per_step']/1e12:.2f} TB / wall -> {x['achieved']:.0f} GB/s = {x['frac']:.3f}; kernel time {x['kernel_ms_per_step']:.0f} ms of {v['ms_per_step']:.0f}; {x['forward_passes']:.0f} forward / {x['adjoint_passes']:.0f} adjoint passes")
-for sub, name in (("pass2_kernel<5, 8", "pass2_kernel<5,8>"), ("adjoint2_kernel<4, 8", "adjoint2_kernel<4,8>"),
+for sub, name in (("tcmi_spec_forward", "tcmi_spec_forward"), ("tcmi_spec_adjoint", "tcmi_spec_adjoint"),
+                  ("pass2_kernel<5, 8", "pass2_kernel<5,8>"), ("adjoint2_kernel<4, 8", "adjoint2_kernel<4,8>"),
                   ("measure2_kernel<5, 8", "measure2_kernel<5,8>"), ("pauli_tile_kernel<float", "pauli_tile_kernel"),
                   ("pauli_sum_kernel<float, 4096", "pauli_sum_kernel")):
     g = find(ks, sub)
@@ -59,9 +60,13 @@ L += ["", f"Config 4 RQC amplitude: {q['contract_s']*1e3:.1f} ms, executed flops
           f"algorithmic bytes {qr['algorithmic_bytes']/1e9:.1f} GB, stand-alone permute bytes {qr['wasted_traffic']/1e6:.1f} MB; launches {qr['launches']}",
       f"  amplitude {q['amplitude']}", f"  time split {q['time_split']}", f"  path search {q.get('path_search')}"]
 sv = d.get("sliced_vqa")
+ha = d.get("hea_a")
+if ha and "error" not in ha:
+    L += ["", f"Config 2 secondary workload HEA-A: {ha['amplitudes_per_s_per_gpu']:.4g} amplitudes/s per GPU, {ha['ms_per_call']:.3f} ms per call "
+              f"({ha['contraction']} order), kernel ms per call {ha['kernel_ms_per_call']}"]
 if sv and "error" not in sv:
     L += ["", f"Sliced value_and_grad (n={sv['workload'].split('n=')[1].split(' ')[0]}): {sv['ms_per_value_and_grad']:.1f} ms per call, graphs {sv.get('graphs')}",
-          f"  roofline {sv.get('roofline')}"]
+          f"  roofline {sv.get('roofline')}", f"  one rank of 8, invariants sharded forward and backward: {sv.get('one_rank_of_8_sharded')}"]
 m = d["mps_tebd"]
 L += ["", f"Config 5 MPS sweep: {m['us_per_bond']:.0f} us per bond, kernel us per bond {m['roofline']['kernel_us_per_bond']}", "",
       f"cpu_baseline: {d['cpu_baseline']}"]

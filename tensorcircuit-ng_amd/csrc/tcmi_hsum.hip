@@ -120,28 +120,43 @@ __global__ __launch_bounds__(256) void pauli_tile_kernel(const typename Cx<F>::t
     const int w2 = tm[4 * t + 2], ny = w2 & 3, em = (w2 >> 8) & (EPT - 1), xpar = tm[4 * t + 3] & 1;
     const F c0 = (F)wk[t];
     const F ct = ((__popc(tlo & zm) + __popc(blo & zm) + xpar) & 1) ? -c0 : c0;
-    if (em == 0 && ny == 0) {   // no sign inside the thread (every pure-X string): two FMAs per element
-#pragma unroll
-      for (int e = 0; e < EPT; ++e) {
-        const C v = tile[(2 * tid + 512 * (e >> 1) + (e & 1)) ^ xm];
-        re[e] = fma_<F>(ct, v.x, re[e]);
-        im[e] = fma_<F>(ct, v.y, im[e]);
-      }
-      continue;
-    }
+    // Partner values: both members of a pair sit side by side in LDS (index bit 0), so complex64 partners are fetched
+    // as ONE 16-byte read per pair -- lanes 16 bytes apart, conflict free -- and swapped in registers when the X mask
+    // flips the member bit.  (Two 8-byte reads per pair, with lanes 16 bytes apart, hit every bank twice: the PMC run of
+    // round 3 counted more bank-conflict cycles than active LDS cycles in this kernel.)
+    const uint32_t xh = xm & ~1u;
+    const bool sw = (xm & 1u) != 0;                    // wave-uniform
+    const bool plain = (em == 0 && ny == 0);           // no sign inside the thread (every pure-X string): two FMAs per element
     const bool flip = (ny == 2) || (ny == 3);          // i^2 = -1, i^3 = -i
     const bool rot = (ny & 1) != 0;                    // odd number of Y: multiply by i
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-      const C v = tile[(2 * tid + 512 * (e >> 1) + (e & 1)) ^ xm];
-      const bool neg = ((__popc((uint32_t)(e & em)) & 1) != 0) != flip;   // uniform
-      const F c = neg ? -ct : ct;
-      if (rot) {   // i v = (-v.y, v.x)
-        re[e] = fma_<F>(-c, v.y, re[e]);
-        im[e] = fma_<F>(c, v.x, im[e]);
+    for (int k = 0; k < EPT / 2; ++k) {
+      C v0, v1;
+      if constexpr (sizeof(F) == 4) {
+        const float4 q = *reinterpret_cast<const float4*>(&tile[(2 * tid + 512 * k) ^ xh]);
+        v0.x = sw ? q.z : q.x; v0.y = sw ? q.w : q.y; v1.x = sw ? q.x : q.z; v1.y = sw ? q.y : q.w;
       } else {
-        re[e] = fma_<F>(c, v.x, re[e]);
-        im[e] = fma_<F>(c, v.y, im[e]);
+        v0 = tile[(2 * tid + 512 * k) ^ xm];
+        v1 = tile[(2 * tid + 512 * k + 1) ^ xm];
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int e = 2 * k + h;
+        const C v = h ? v1 : v0;
+        if (plain) {
+          re[e] = fma_<F>(ct, v.x, re[e]);
+          im[e] = fma_<F>(ct, v.y, im[e]);
+        } else {
+          const bool neg = ((__popc((uint32_t)(e & em)) & 1) != 0) != flip;   // uniform
+          const F c = neg ? -ct : ct;
+          if (rot) {   // i v = (-v.y, v.x)
+            re[e] = fma_<F>(-c, v.y, re[e]);
+            im[e] = fma_<F>(c, v.x, im[e]);
+          } else {
+            re[e] = fma_<F>(c, v.x, re[e]);
+            im[e] = fma_<F>(c, v.y, im[e]);
+          }
+        }
       }
     }
   }
