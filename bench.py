@@ -211,11 +211,11 @@ def vqe_leg(tc, torch, dist, args, rank, world, dev):
     fcfg = X.pick_variant(n, "complex64")[1]
     acfg = X.pick_adjoint_variant(n, "complex64", [])
     mcfg = X.pick_measure_variant(n, "complex64")
-    from tcmi import specialize as S
+    from tcmi import specialize as SP
 
     # the passes run as plan-specialised straight-line kernels when the plan's code objects are there (tcmi/specialize.py;
     # kernel names tcmi_spec_forward / tcmi_spec_adjoint in a rocprofv3 trace), else on the interpreting kernels
-    nspec = {k: sum(1 for v in S._LOADED.values() if v.meta.get("kind") == k) for k in ("forward", "adjoint")}
+    nspec = {k: sum(1 for v in SP._LOADED.values() if v.meta.get("kind") == k) for k in ("forward", "adjoint")}
     fname = (f"tcmi_spec_forward (plan-specialised gate passes, {nspec['forward']} code objects; programs of pass2_kernel<{fcfg.R},{fcfg.LT}>)"
              if nspec["forward"] else f"tcmi::pass2_kernel<{fcfg.R},{fcfg.LT}> (gate passes)")
     aname = (f"tcmi_spec_adjoint (plan-specialised reverse sweep on psi and lambda, {nspec['adjoint']} code objects; programs of "
@@ -267,8 +267,8 @@ def vqe_leg(tc, torch, dist, args, rank, world, dev):
         "mean_energy": float(esum.item()) / Bg,
         "grad_norm": float(gsum.norm().item()),
         "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 1),
-        "specialised_kernels": {**nspec, "mode": S.mode(), "compiled_in_this_process": S.STATS["compiled"],
-                                "compile_s": round(S.STATS["compile_s"], 2), "cache_hits": S.STATS["cache_hits"]},
+        "specialised_kernels": {**nspec, "mode": SP.mode(), "compiled_in_this_process": SP.STATS["compiled"],
+                                "compile_s": round(SP.STATS["compile_s"], 2), "cache_hits": SP.STATS["cache_hits"]},
     }
 
 

@@ -7,6 +7,12 @@
  * library with ctypes from a new backend class; every entry point below names
  * the reference interface it replaces.
  *
+ * Multi-GPU: this ABI runs ONE rank.  The path's exchange steps (one packed all-reduce of [value || gradients] per step,
+ * one all-gather of the slice-invariant roots and one all-reduce of their cotangents in a sliced contraction) belong to
+ * the host framework's process group (torch.distributed, backend nccl = RCCL); there is deliberately no
+ * tcmi_allreduce_sum here (SURVEY.md 8(b) lists one; see INTEGRATION.md section 3 for the ncclAllReduce call a non-torch
+ * host would issue on the stream it passes to these entry points).
+ *
  * Conventions: all pointers are DEVICE pointers unless the name ends in _host; the caller owns every
  * buffer; `stream` is a hipStream_t passed as void* (NULL = default stream); every function returns
  * 0 (TCMI_OK) or a negative error code and never throws; tcmi_last_error() gives the message of the

@@ -23,7 +23,8 @@ extern "C" int tcmi_set_error_(int code, const char* msg);
 namespace tcmi {
 
 // T tile bits, 256 threads, EPT = 2^T / 256 elements per thread, held as EPT / 2 neighbouring pairs (tile bit 0 is
-// physical bit 0: one 16-byte access per pair).  LDS index e = pair member | thread << 1 | k << 9.
+// physical bit 0: one 16-byte global access per pair).  Host-side LDS index e = pair member | thread << 1 | k << 9; the
+// kernel stores member-planar (see the staging loop).
 // terms: int32 [nterms][4] = {X mask in LDS-index space, Z/Y sign mask (physical bits), number of Y | emask << 8,
 // parity(X & Z)}; the first ndiag rows are the Z-only strings, sorted by emask, the rest is sorted by X mask.
 template <typename F, int T>
@@ -70,11 +71,19 @@ __global__ __launch_bounds__(256) void pauli_tile_kernel(const typename Cx<F>::t
 #pragma unroll
   for (int k = 0; k < EPT / 2; ++k) {
     const C* src = in + (wg_base | tphys | kphys[k]);
+    // LDS layout: the two members of a pair live in two PLANES (index = thread | k << 8 | member << (T - 1)): the lanes of
+    // a wave are then 8 (16) bytes apart in every partner read below.  With the members side by side the lanes sat 16
+    // (32) bytes apart and every 8-byte read hit each bank twice -- the round-3 PMC run counted more bank-conflict cycles
+    // than active LDS cycles in this kernel.
     if constexpr (sizeof(F) == 4) {
-      *reinterpret_cast<float4*>(&tile[2 * tid + 512 * k]) = *reinterpret_cast<const float4*>(src);
+      const float4 q = *reinterpret_cast<const float4*>(src);
+      C a0, a1;
+      a0.x = q.x; a0.y = q.y; a1.x = q.z; a1.y = q.w;
+      tile[tid + 256 * k] = a0;
+      tile[tid + 256 * k + NE / 2] = a1;
     } else {
-      tile[2 * tid + 512 * k] = src[0];
-      tile[2 * tid + 512 * k + 1] = src[1];
+      tile[tid + 256 * k] = src[0];
+      tile[tid + 256 * k + NE / 2] = src[1];
     }
   }
   __syncthreads();
@@ -116,47 +125,33 @@ __global__ __launch_bounds__(256) void pauli_tile_kernel(const typename Cx<F>::t
   // ---- strings with X / Y factors, sorted by X mask: partner values from LDS
 #pragma unroll 1
   for (; t < nterms; ++t) {
-    const uint32_t xm = (uint32_t)tm[4 * t], zm = (uint32_t)tm[4 * t + 1];
+    const uint32_t xm0 = (uint32_t)tm[4 * t], zm = (uint32_t)tm[4 * t + 1];
+    const uint32_t xm = ((xm0 & 1u) << (T - 1)) | (xm0 >> 1);     // the host's mask (member bit lowest) in plane layout
     const int w2 = tm[4 * t + 2], ny = w2 & 3, em = (w2 >> 8) & (EPT - 1), xpar = tm[4 * t + 3] & 1;
     const F c0 = (F)wk[t];
     const F ct = ((__popc(tlo & zm) + __popc(blo & zm) + xpar) & 1) ? -c0 : c0;
-    // Partner values: both members of a pair sit side by side in LDS (index bit 0), so complex64 partners are fetched
-    // as ONE 16-byte read per pair -- lanes 16 bytes apart, conflict free -- and swapped in registers when the X mask
-    // flips the member bit.  (Two 8-byte reads per pair, with lanes 16 bytes apart, hit every bank twice: the PMC run of
-    // round 3 counted more bank-conflict cycles than active LDS cycles in this kernel.)
-    const uint32_t xh = xm & ~1u;
-    const bool sw = (xm & 1u) != 0;                    // wave-uniform
-    const bool plain = (em == 0 && ny == 0);           // no sign inside the thread (every pure-X string): two FMAs per element
+    if (em == 0 && ny == 0) {   // no sign inside the thread (every pure-X string): two FMAs per element
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const C v = tile[(tid + 256 * (e >> 1) + (e & 1) * (NE / 2)) ^ xm];
+        re[e] = fma_<F>(ct, v.x, re[e]);
+        im[e] = fma_<F>(ct, v.y, im[e]);
+      }
+      continue;
+    }
     const bool flip = (ny == 2) || (ny == 3);          // i^2 = -1, i^3 = -i
     const bool rot = (ny & 1) != 0;                    // odd number of Y: multiply by i
 #pragma unroll
-    for (int k = 0; k < EPT / 2; ++k) {
-      C v0, v1;
-      if constexpr (sizeof(F) == 4) {
-        const float4 q = *reinterpret_cast<const float4*>(&tile[(2 * tid + 512 * k) ^ xh]);
-        v0.x = sw ? q.z : q.x; v0.y = sw ? q.w : q.y; v1.x = sw ? q.x : q.z; v1.y = sw ? q.y : q.w;
+    for (int e = 0; e < EPT; ++e) {
+      const C v = tile[(tid + 256 * (e >> 1) + (e & 1) * (NE / 2)) ^ xm];
+      const bool neg = ((__popc((uint32_t)(e & em)) & 1) != 0) != flip;   // uniform
+      const F c = neg ? -ct : ct;
+      if (rot) {   // i v = (-v.y, v.x)
+        re[e] = fma_<F>(-c, v.y, re[e]);
+        im[e] = fma_<F>(c, v.x, im[e]);
       } else {
-        v0 = tile[(2 * tid + 512 * k) ^ xm];
-        v1 = tile[(2 * tid + 512 * k + 1) ^ xm];
-      }
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int e = 2 * k + h;
-        const C v = h ? v1 : v0;
-        if (plain) {
-          re[e] = fma_<F>(ct, v.x, re[e]);
-          im[e] = fma_<F>(ct, v.y, im[e]);
-        } else {
-          const bool neg = ((__popc((uint32_t)(e & em)) & 1) != 0) != flip;   // uniform
-          const F c = neg ? -ct : ct;
-          if (rot) {   // i v = (-v.y, v.x)
-            re[e] = fma_<F>(-c, v.y, re[e]);
-            im[e] = fma_<F>(c, v.x, im[e]);
-          } else {
-            re[e] = fma_<F>(c, v.x, re[e]);
-            im[e] = fma_<F>(c, v.y, im[e]);
-          }
-        }
+        re[e] = fma_<F>(c, v.x, re[e]);
+        im[e] = fma_<F>(c, v.y, im[e]);
       }
     }
   }
@@ -165,13 +160,8 @@ __global__ __launch_bounds__(256) void pauli_tile_kernel(const typename Cx<F>::t
 #pragma unroll
   for (int k = 0; k < EPT / 2; ++k) {
     C o0, o1;
-    if constexpr (sizeof(F) == 4) {
-      const float4 q = *reinterpret_cast<const float4*>(&tile[2 * tid + 512 * k]);
-      o0.x = q.x; o0.y = q.y; o1.x = q.z; o1.y = q.w;
-    } else {
-      o0 = tile[2 * tid + 512 * k];
-      o1 = tile[2 * tid + 512 * k + 1];
-    }
+    o0 = tile[tid + 256 * k];
+    o1 = tile[tid + 256 * k + NE / 2];
     re[2 * k] = fma_<F>(dg[2 * k], o0.x, re[2 * k]);
     im[2 * k] = fma_<F>(dg[2 * k], o0.y, im[2 * k]);
     re[2 * k + 1] = fma_<F>(dg[2 * k + 1], o1.x, re[2 * k + 1]);
