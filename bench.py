@@ -967,7 +967,7 @@ def main():
                 gs(pmat)
             sync()
             tg = time.perf_counter() - tg0
-            same = bool(torch.allclose(gs.out, state, atol=1e-6, rtol=0))
+            same = bool(torch.allclose(gs.out, fwd(params), atol=1e-6, rtol=0))     # the eager result of the same chunk
             graph_info = {"ms_per_step": tg / args.steps * 1e3, "amplitudes_per_s_per_gpu": B * (2**n) * args.steps / tg,
                           "matches_eager": same}
             del gs
@@ -1010,6 +1010,7 @@ def main():
             g = ev["gemm"]
             M, N, K = 2**cc.spec.n_left, 2 ** (n - cc.spec.n_left), cc.K
             avg_us = g["ms"] * 1e3 / g["launches"]
+            gl_call = g["launches"] / float(args.steps * max(1, len(chunks)))
             alg = g["work"] / g["launches"]           # 8 real flops per complex MAC
             exe = 0.75 * alg                          # the kernel issues Gauss's 3-product form: 6 flops per MAC
             # the join runs on cgemm_dma128_kernel when M and N are multiples of 128 (every n >= 14 cut), else on the
@@ -1029,8 +1030,9 @@ def main():
                 "launches_per_step": g["launches"] / args.steps, "avg_launch_us": avg_us,
                 "timing": "HIP events on the launch stream around every launch of the timed steps",
                 "executed_flops_per_launch": exe, "algorithmic_flops_per_launch": alg,
-                "algorithmic_bytes_per_launch": 8.0 * B * (K * (M + N) + M * N),
-                "gemm_shape": {"M": M, "N": N, "K": K, "batch": B},
+                # a vmap call of B circuits is joined in sub-batches (CutCircuit._state_pipelined): batch per launch
+                "algorithmic_bytes_per_launch": 8.0 * (B / gl_call) * (K * (M + N) + M * N),
+                "gemm_shape": {"M": M, "N": N, "K": K, "batch": B / gl_call, "launches_per_vmap_call": gl_call},
                 "half_circuit_passes": pass_entry,
             }
             plan_info = {"contraction": "cut", "bond": K, "n_left": cc.spec.n_left,

@@ -1068,6 +1068,12 @@ class CutCircuit:
         # workgroups in the prefix passes), so the right half runs on a second HIP stream beside the left one.
         cur = torch.cuda.current_stream(self.device)
         two = os.environ.get("TCMI_CUT_STREAMS", "1") != "0"      # also under hipGraph capture (fork / join in the graph)
+        # experiment switch (scripts/experiments/README.md, round 4): sub-batches on their own streams so that the passes of
+        # one hide under the join of another -- measured SLOWER (7.4e10 -> 6.9e10 / 6.4e10 amplitudes/s at 2 / 4 sub-batches:
+        # the join GEMM loses more on smaller batches than the passes cost), so off
+        nsplit = min(int(os.environ.get("TCMI_CUT_SPLIT", "1")), B) if two else 1
+        if nsplit >= 2:
+            return self._state_pipelined(p, pfull, B, nsplit, out)
         if two:
             side = getattr(self, "_side", None)
             if side is None:
@@ -1093,6 +1099,50 @@ class CutCircuit:
                                      1, self.code, stream),
                 "tcmi_cgemm(cut)",
             )
+        return out
+
+    def _state_pipelined(self, p, pfull, B, nsplit, out):
+        """The batch in ``nsplit`` sub-batches, each on its own HIP stream: the half-circuit passes of a sub-batch are a
+        chain of small launches (one workgroup per 12-qubit state) that cannot fill the chip, the join GEMM fills it.
+        With every chain on its own stream and the joins in order on the caller's stream, the first join starts after
+        the SHORTEST chain (a quarter of the batch) and the other chains finish underneath it: the passes leave the
+        critical path (they were 14 % of the headline step).  Fork and join become part of a hipGraph under capture."""
+        import torch
+
+        K = self.K
+        M, N = 2**self.spec.n_left, 2 ** (self.n - self.spec.n_left)
+        if out is None:
+            out = torch.empty(B, M * N, dtype=self.tdtype, device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        sides = getattr(self, "_sides", None)
+        if sides is None or len(sides) < nsplit:
+            sides = self._sides = [torch.cuda.Stream(device=self.device) for _ in range(nsplit)]
+        w = self._weights(p)                                    # [B, K], one launch for the whole batch
+        bounds = [(i * B) // nsplit for i in range(nsplit + 1)]
+        parts = []
+        for i in range(nsplit):
+            b0, b1 = bounds[i], bounds[i + 1]
+            st = sides[i]
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                pf = pfull[b0 * K: b1 * K]
+                R = self.right.states(pf, b1 - b0, scale=w[b0:b1])     # [(b1-b0)*K, N], each state times its weight
+                L = self.left.states(pf, b1 - b0)                      # [(b1-b0)*K, M]
+            parts.append((b0, b1, L, R, st))
+        for t_ in (pfull, p, w):
+            for st in sides[:nsplit]:
+                t_.record_stream(st)
+        stream = cur.cuda_stream
+        for b0, b1, L, R, st in parts:
+            cur.wait_stream(st)
+            L.record_stream(cur)
+            R.record_stream(cur)
+            with _timed("gemm", 1, 8.0 * M * N * K * (b1 - b0)):
+                _lib.check(
+                    self._lib.tcmi_cgemm(L.data_ptr(), R.data_ptr(), out[b0:b1].data_ptr(), M, N, K, b1 - b0, K * M, K * N,
+                                         M * N, 1, self.code, stream),
+                    "tcmi_cgemm(cut)",
+                )
         return out
 
     def vjp(self, params, psi, g, **kw):
