@@ -164,12 +164,31 @@ def vqe_leg(tc, torch, dist, args, rank, world, dev):
     vvag = tc.backend.jit(tc.backend.vvag(energy, argnums=0, vectorized_argnums=0))
     mb = max(1, args.vqe_microbatch)
 
+    nstreams = max(1, int(os.environ.get("TCMI_BENCH_VQE_STREAMS", str(args.vqe_streams))))
+    side = [torch.cuda.Stream(device=dev) for _ in range(nstreams)] if nstreams > 1 else []
+
     def step():
         vals, grads = [], []
-        for b0 in range(0, hi - lo, mb):
-            v, g = vvag(params[b0: b0 + mb])
-            vals.append(v)
-            grads.append(g)
+        if side:
+            # micro-batches are independent: alternate them over HIP streams, so that the VALU-bound passes of one overlap
+            # the HBM-bound passes of another (every allocation of the traced pipeline is per call and stream-ordered)
+            cur = torch.cuda.current_stream(dev)
+            for k, b0 in enumerate(range(0, hi - lo, mb)):
+                st = side[k % len(side)]
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    v, g = vvag(params[b0: b0 + mb])
+                vals.append(v)
+                grads.append(g)
+            for st in side:
+                cur.wait_stream(st)
+            for t_ in vals + grads:
+                t_.record_stream(cur)
+        else:
+            for b0 in range(0, hi - lo, mb):
+                v, g = vvag(params[b0: b0 + mb])
+                vals.append(v)
+                grads.append(g)
         v = torch.cat(vals) if vals else torch.zeros(0, device=dev)
         g = torch.cat(grads) if grads else torch.zeros(0, 2 * d, n, device=dev)
         esum, gsum = D.allreduce_sum_packed([v.sum().reshape(1), g.sum(0)])
@@ -803,6 +822,7 @@ def main():
     ap.add_argument("--vqe-batch", type=int, default=32, help="VQE leg: global vmap batch (sharded over ranks)")
     ap.add_argument("--vqe-steps", type=int, default=2)
     ap.add_argument("--vqe-microbatch", type=int, default=8, help="samples per vvag call (bounds HBM use)")
+    ap.add_argument("--vqe-streams", type=int, default=1, help="micro-batches of the VQE step alternate over this many HIP streams")
     ap.add_argument("--mps-qubits", type=int, default=64, help="MPS TEBD leg (config 5): qubits; 0 disables the leg")
     ap.add_argument("--mps-chi", type=int, default=128)
     ap.add_argument("--mps-sweeps", type=int, default=2)
