@@ -269,6 +269,9 @@ int tcmi_mps_gate_mix(const void* t, const void* gate, void* out, int L, int R, 
  * T = tile bits, LT = log2(threads per workgroup) of the plan the kernel was generated from. */
 int tcmi_spec_load(const char* path_host, const char* kernel_name_host, int lds_bytes, void** handle_out_host);
 int tcmi_spec_unload(void* handle);
+/* Persistent kernels (one workgroup loops over many tiles): launch at most `max_workgroups` workgroups (grid.x * batch);
+ * 0 (the default after tcmi_spec_load) = one workgroup per tile.  Must match how the kernel was generated. */
+int tcmi_spec_set_grid(void* handle, int max_workgroups);
 int tcmi_spec_run_pass(void* handle, void* state, long long state_stride, int batch, int n, int T, int LT,
                        const void* ctab, const void* ptab, long long ptab_stride, void* stream);
 int tcmi_spec_run_adjoint_pass(void* handle, void* psi, void* lam, long long state_stride, int batch, int n, int T,

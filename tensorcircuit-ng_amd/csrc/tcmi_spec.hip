@@ -19,7 +19,15 @@ struct SpecKernel {
   hipModule_t mod;
   hipFunction_t fn;
   int lds_bytes;
+  int max_workgroups;   // > 0: persistent kernel, grid.x * batch capped at this many workgroups (it loops over its tiles)
 };
+unsigned grid_x(const SpecKernel* k, int n, int T, int batch) {
+  const unsigned tiles = 1u << (n - T);
+  if (k->max_workgroups <= 0) return tiles;
+  unsigned g = (unsigned)k->max_workgroups / (unsigned)batch;
+  if (g < 1u) g = 1u;
+  return g < tiles ? g : tiles;
+}
 int hip_fail(const char* what, hipError_t e) {
   char buf[256];
   snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
@@ -33,7 +41,7 @@ int tcmi_spec_load(const char* path_host, const char* kernel_name_host, int lds_
   if (!path_host || !kernel_name_host || !handle_out_host || lds_bytes < 0)
     return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_spec_load: bad argument");
   *handle_out_host = nullptr;
-  SpecKernel* k = new SpecKernel{nullptr, nullptr, lds_bytes};
+  SpecKernel* k = new SpecKernel{nullptr, nullptr, lds_bytes, 0};
   hipError_t e = hipModuleLoad(&k->mod, path_host);
   if (e != hipSuccess) {
     delete k;
@@ -50,6 +58,12 @@ int tcmi_spec_load(const char* path_host, const char* kernel_name_host, int lds_
     if (e != hipSuccess) (void)hipGetLastError();  // module functions take the size from the launch on ROCm
   }
   *handle_out_host = k;
+  return TCMI_OK;
+}
+
+int tcmi_spec_set_grid(void* handle, int max_workgroups) {
+  if (!handle || max_workgroups < 0) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_spec_set_grid: bad argument");
+  reinterpret_cast<SpecKernel*>(handle)->max_workgroups = max_workgroups;
   return TCMI_OK;
 }
 
@@ -75,7 +89,7 @@ int tcmi_spec_run_pass(void* handle, void* state, long long state_stride, int ba
   } args = {state, state_stride, ctab, ptab, ptab_stride};
   size_t sz = sizeof(args);
   void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  hipError_t e = hipModuleLaunchKernel(k->fn, 1u << (n - T), (unsigned)batch, 1, 1u << LT, 1, 1, (unsigned)k->lds_bytes,
+  hipError_t e = hipModuleLaunchKernel(k->fn, grid_x(k, n, T, batch), (unsigned)batch, 1, 1u << LT, 1, 1, (unsigned)k->lds_bytes,
                                        reinterpret_cast<hipStream_t>(stream), nullptr, cfg);
   return e == hipSuccess ? TCMI_OK : hip_fail("tcmi_spec_run_pass", e);
 }
@@ -101,7 +115,7 @@ int tcmi_spec_run_adjoint_pass(void* handle, void* psi, void* lam, long long sta
   } args = {psi, lam, state_stride, ctab, ptab, ptab_stride, gout, gout_stride, gcopies, 0, gcopy_stride};
   size_t sz = sizeof(args);
   void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  hipError_t e = hipModuleLaunchKernel(k->fn, 1u << (n - T), (unsigned)batch, 1, 1u << LT, 1, 1, (unsigned)k->lds_bytes,
+  hipError_t e = hipModuleLaunchKernel(k->fn, grid_x(k, n, T, batch), (unsigned)batch, 1, 1u << LT, 1, 1, (unsigned)k->lds_bytes,
                                        reinterpret_cast<hipStream_t>(stream), nullptr, cfg);
   return e == hipSuccess ? TCMI_OK : hip_fail("tcmi_spec_run_adjoint_pass", e);
 }

@@ -191,24 +191,35 @@ class _Emitter:
         return out
 
     # ---- prologue ------------------------------------------------------------------------------------
-    def index_lines(self) -> List[str]:
+    def persistent(self) -> bool:
+        """Experiment switch (TCMI_SPEC_EXP=persist; off): one workgroup loops over many tiles (grid = the workgroups the chip
+        holds at once, tcmi_spec_set_grid) instead of one workgroup per tile -- no dispatch gap between two tiles on a wave
+        slot, gradient sums leave the kernel once per workgroup.  Measured SLOWER (forward 8.9 -> 10.5 ms, sweep 27.3 ->
+        31 ms per sample, with or without an initial stagger): on gfx9-family hardware vmcnt counts stores too, so the wait
+        for the next tile's loads also waits for the previous tile's write acknowledgements, which a fresh workgroup on
+        the same slot never sees."""
+        return bool(self.opts.get("persist", False))
+
+    def index_lines(self) -> Tuple[List[str], List[str]]:
+        """(lines before the tile loop, lines that open it)."""
         free = [p for p in range(self.n) if p not in self.tile_bits]
         pairs = [(i, p) for i, p in enumerate(free)]
-        out = ["  const uint32_t tid = threadIdx.x;", "  const uint32_t bx = blockIdx.x;",
-               f"  const uint32_t wg_base = {_deposit_expr('bx', pairs)};"]
+        pre = ["  const uint32_t tid = threadIdx.x;"]
         k = int(self.opts.get("stagger", 0))
-        if k > 0:
-            # Every workgroup of a pass does the same work, so the workgroups that share a CU run in lock step: all load,
-            # then all compute, then all store, and HBM time adds to VALU time instead of hiding behind it.  The first
-            # generation (the workgroups that find the chip empty) is therefore started out of phase, by wave slot; later
-            # workgroups inherit the offset of the one whose slot they take over.
-            slots = (1024 >> self.LT) * 256 * 4 >> 2       # workgroups of the first generation: all wave slots of the chip
-            out += [f"  if (blockIdx.y == 0 && bx < {slots}u) {{",
+        if k > 0:     # experiment (scripts/experiments/README.md, round 4: no effect): first generation started out of phase
+            slots = (1024 >> self.LT) * 256 * 4 >> 2
+            cond = "true" if self.persistent() else f"blockIdx.y == 0 && blockIdx.x < {slots}u"
+            pre += [f"  if ({cond}) {{",
                     "    uint32_t hw;",
                     '    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));',
                     f"    for (uint32_t i = (hw & 3u) * {k}u; i > 0; --i) __builtin_amdgcn_s_sleep(127);",
                     "  }"]
-        return out
+        if self.persistent():
+            loop = [f"  for (uint32_t bx = blockIdx.x; bx < {1 << (self.n - self.T)}u; bx += gridDim.x) {{"]
+        else:
+            loop = ["  { const uint32_t bx = blockIdx.x;"]
+        loop.append(f"  const uint32_t wg_base = {_deposit_expr('bx', pairs)};")
+        return pre, loop
 
     def local_tid(self, out: List[str]) -> str:
         """A copy of the thread index the optimiser cannot see through: index arithmetic derived from it is computed
@@ -599,7 +610,8 @@ class _Forward(_Emitter):
                "  state += (long long)blockIdx.y * state_stride;",
                "  const KF ctab = (KF)ctab_g; (void)ctab;",
                "  const KF ptab = (KF)(ptab_g + (long long)blockIdx.y * ptab_stride);"]
-        pro += self.index_lines()
+        pre, loop = self.index_lines()
+        pro += pre + loop
         pro.append("  v2f " + ", ".join(f"a{r}" for r in range(NR)) + ";")
         pro.append("  uint32_t sgn = 0u;")
         rd0 = self.rounds[0]
@@ -635,7 +647,7 @@ class _Forward(_Emitter):
         for r in range(0, NR, 16):
             p.append("  vm2_negate16_if(" + ", ".join(self.A(r + i) for i in range(16)) + ", sgn);")
         self.tile_io(p, last, True, {"a": "state"}, self.tphys)
-        return "\n".join(self.header(kname, params) + pro + self.linear() + ["}"]) + "\n"
+        return "\n".join(self.header(kname, params) + pro + self.linear() + ["  }", "}"]) + "\n"
 
     def lds_bytes(self) -> int:
         return 4 << self.T
@@ -645,7 +657,7 @@ def forward_source(words, kname: str = "tcmi_spec_pass", opts=None) -> Tuple[str
     """HIP source of the straight-line kernel of one forward gate pass + its launch geometry."""
     e = _Forward(words, opts)
     src = e.source(kname)
-    return src, {"kind": "forward", "n": e.n, "T": e.T, "LT": e.LT, "lds": e.lds_bytes()}
+    return src, {"kind": "forward", "n": e.n, "T": e.T, "LT": e.LT, "lds": e.lds_bytes(), "persistent": e.persistent()}
 
 
 # ======================================================================================================
@@ -804,6 +816,13 @@ def load(path: str, meta: dict) -> SpecKernel:
             h = ctypes.c_void_p()
             _lib.check(_lib.lib().tcmi_spec_load(path.encode(), meta["kernel"].encode(), int(meta["lds"]), ctypes.byref(h)),
                        "tcmi_spec_load")
+            if meta.get("persistent"):
+                # a persistent kernel loops over its tiles: launch as many workgroups as the chip holds at once
+                import torch
+
+                cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+                wg_per_cu = max(1, min((1024 >> int(meta["LT"])), (160 * 1024) // max(1, int(meta["lds"]))))
+                _lib.check(_lib.lib().tcmi_spec_set_grid(h, int(cus * wg_per_cu)), "tcmi_spec_set_grid")
             k = SpecKernel(h, meta, path)
             _LOADED[path] = k
         return k
@@ -945,7 +964,9 @@ class _Adjoint(_Forward):
         assert e0 % self.EVB == 0
         r = self.fresh("gr")
         out.append(f"  const float {r} = wave_fold8({', '.join(names)}, (int)lane);")
-        out.append(f"  gacc{e0 // 64} = park8<{(e0 // 8) % 8}>(gacc{e0 // 64}, {r});")
+        g_ = (e0 // 8) % 8       # lane group of this batch of eight: row g_ >> 1, banks 2 (g_ & 1) and 2 (g_ & 1) + 1
+        out.append(f'  asm("v_add_f32_dpp %0, %1, %0 quad_perm:[0,1,2,3] row_mask:{1 << (g_ >> 1):#x} bank_mask:{3 << (2 * (g_ & 1)):#x}" '
+                   f': "+v"(gacc{e0 // 64}) : "v"({r}));')
         for _v, slot in self.pending:
             self.events.append(slot)
         while len(self.events) % self.EVB:
@@ -1110,8 +1131,11 @@ class _Adjoint(_Forward):
                "  gout += (long long)blockIdx.y * gout_stride + (long long)(blockIdx.x % (unsigned)gcopies) * gcopy_stride;",
                "  const KF ctab = (KF)ctab_g; (void)ctab; (void)pad_;",
                "  const KF ptab = (KF)(ptab_g + (long long)blockIdx.y * ptab_stride);"]
-        pro += self.index_lines()
+        pre, loop = self.index_lines()
+        pro += pre
         pro.append("  const uint32_t lane = tid & 63u;")
+        pro.append("  //GACC")
+        pro += loop
         pro.append("  v2f " + ", ".join(f"a{r}" for r in range(NR)) + ";")
         pro.append("  v2f " + ", ".join(f"l{r}" for r in range(NR)) + ";")
         pro.append("  uint32_t sgn = 0u;")
@@ -1130,17 +1154,17 @@ class _Adjoint(_Forward):
                 break
             self.exchange(k, [("a", ""), ("l", "")], 8)
         sg = self.seg("gradient sums")
-        p = sg.parts[0]
-        self.reduce_pending(p)
+        self.reduce_pending(sg.parts[0])
         nev = len(self.events)
         nacc = (nev + 63) // 64
         NW = 1 << (self.LT - 6)
+        p = post = []       # after the tile loop: the accumulators hold the sums over all of this workgroup's tiles
         if nev:
             # the waves' accumulators meet in LDS (the exchange buffer is free now): one f64 atomic per event
             p.append("  __syncthreads();")
             p.append("  { float LDS_AS* const gl = (float LDS_AS*)lb;")
             for k in range(nacc):
-                p.append(f"    gl[({k * NW}u + (tid >> 6)) * 64u + lane] = __int_as_float(gacc{k});")
+                p.append(f"    gl[({k * NW}u + (tid >> 6)) * 64u + lane] = gacc{k};")
             p.append("    __syncthreads();")
             p.append(f"    for (uint32_t e = tid; e < {nev}u; e += {1 << self.LT}u) {{")
             p.append("      float s = 0.f;")
@@ -1157,7 +1181,9 @@ class _Adjoint(_Forward):
                     p.append("  vm2_negate16_if(" + ", ".join(self.A(r + i, vec) for i in range(16)) + ", sgn);")
             self.tile_io(p, self.rounds[-1], True, {"a": "psi", "l": "lam"}, self.tphys)
         body = self.linear()
-        pro += [f"  int gacc{k} = 0;" for k in range(nacc)]
+        i = pro.index("  //GACC")
+        pro[i:i + 1] = [f"  float gacc{k} = 0.f;" for k in range(nacc)]
+        body = body + ["  }"] + post
         head = self.header(kname, params)
         if nev:
             # before the kernel: the events' gradient slots
@@ -1170,7 +1196,8 @@ def adjoint_source(words, kname: str = "tcmi_spec_pass", opts=None) -> Tuple[str
     """HIP source of the straight-line kernel of one reverse-sweep pass + its launch geometry."""
     e = _Adjoint(words, opts)
     src = e.source(kname)
-    return src, {"kind": "adjoint", "n": e.n, "T": e.T, "LT": e.LT, "lds": e.lds_bytes(), "events": len(e.events)}
+    return src, {"kind": "adjoint", "n": e.n, "T": e.T, "LT": e.LT, "lds": e.lds_bytes(), "events": len(e.events),
+                 "persistent": e.persistent()}
 
 
 _EMITTERS["adjoint"] = adjoint_source
