@@ -1007,15 +1007,16 @@ def main():
     vqe = None
     if args.vqe_qubits:
         vqe = _guard("vqe_step", vqe_leg, tc, torch, dist, args, rank, world, dev)
-    rqc = None
-    if args.rqc_depth:
-        torch.cuda.empty_cache()
-        rqc = _guard("rqc_amplitude", rqc_leg, tc, torch, dist, args, rank, world)
-
+    # the host-bound leg first: it is the one that feels what earlier legs leave behind (graph memory pools, cached plans)
     svqa = None
     if args.svqa_qubits:
         torch.cuda.empty_cache()
         svqa = _guard("sliced_vqa", sliced_vqa_leg, tc, torch, dist, args, rank, world)
+
+    rqc = None
+    if args.rqc_depth:
+        torch.cuda.empty_cache()
+        rqc = _guard("rqc_amplitude", rqc_leg, tc, torch, dist, args, rank, world)
 
     if rank == 0:
         amps = float(Bg) * (2**n) * args.steps

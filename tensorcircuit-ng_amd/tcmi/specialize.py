@@ -853,21 +853,37 @@ class PassSet:
         except Exception:  # noqa: BLE001
             pass
         self.calls += 1
-        if self.state == "new":
-            for i, r in enumerate(prepare(self.kind, self.descs, self.opts, compile_missing=False)):
-                if r is not None:
-                    self.kernels[i] = load(*r)
-            self.state = "cached"
-            if all(k is not None for k in self.kernels):
+        try:
+            if self.state == "new":
+                self._resolve(compile_missing=False)
+                self.state = "cached"
+                if all(k is not None for k in self.kernels):
+                    self.state = "done"
+                    return self.kernels
+            if m == "1" or (self.calls >= self.hot and self.n_exec >= MIN_N):
+                self._resolve(compile_missing=True)
                 self.state = "done"
-                return self.kernels
-        want = m == "1" or (self.calls >= self.hot and self.n_exec >= MIN_N)
-        if want:
-            for i, r in enumerate(prepare(self.kind, self.descs, self.opts, compile_missing=True)):
-                if r is not None and self.kernels[i] is None:
-                    self.kernels[i] = load(*r)
+        except Exception as e:  # noqa: BLE001
+            # specialisation is an optimisation: a compiler that fails, a cache that cannot be written or a code object
+            # that does not load must never take the computation down -- the interpreting kernels run instead
+            import warnings
+
+            warnings.warn(f"tcmi: plan-specialised {self.kind} kernels unavailable ({type(e).__name__}: {str(e)[:200]}); "
+                          f"using the interpreting kernels", RuntimeWarning)
             self.state = "done"
         return self.kernels
+
+    def _resolve(self, compile_missing: bool) -> None:
+        for i, r in enumerate(prepare(self.kind, self.descs, self.opts, compile_missing=compile_missing)):
+            if r is not None and self.kernels[i] is None:
+                try:
+                    self.kernels[i] = load(*r)
+                except Exception:  # noqa: BLE001   (a truncated / foreign file in the cache): drop it, keep the interpreter
+                    try:
+                        os.remove(r[0])
+                    except OSError:
+                        pass
+                    raise
 
 
 _EMITTERS["forward"] = forward_source

@@ -189,3 +189,24 @@ def test_switch_off(monkeypatch):
     monkeypatch.setenv("TCMI_SPECIALIZE", "0")
     ps = S.PassSet("forward", [np.zeros(64, dtype=np.int32)], 28)
     assert ps.get() == [None]
+
+
+def test_a_failing_compiler_degrades_to_the_interpreter(monkeypatch, tmp_path):
+    """hipcc missing / failing, or a cache nobody can write to: `PassSet.get` warns once and hands back no kernels (the
+    executor then launches the interpreting kernel); it never raises into the user's computation."""
+    monkeypatch.setenv("TCMI_SPECIALIZE", "1")
+    monkeypatch.setattr(S, "CACHE_DIR", str(tmp_path / "plancache"))
+    monkeypatch.setattr(S, "HIPCC", "/bin/false")
+    monkeypatch.setattr(S.shutil, "which", lambda *_a, **_k: None)
+    n = 14
+    c = tc.Circuit(n)
+    for i in range(n):
+        c.h(i)
+        c.rx(i, theta=0.1 * i)
+    gates, nparams = _records(c)
+    _, _, plan, _ = X.choose_plan(n, gates, nparams, "complex64", None)
+    ps = S.PassSet("forward", plan.descs, n)
+    with pytest.warns(RuntimeWarning):
+        ks = ps.get()
+    assert ks == [None] * len(plan.descs) and ps.state == "done"
+    assert ps.get() == [None] * len(plan.descs)          # and stays quiet afterwards
