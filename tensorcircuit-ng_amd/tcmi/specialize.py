@@ -293,15 +293,32 @@ class _Emitter:
         the new thread-part of the physical index is left in ``self.tphys``."""
         wr, rdn = self.rounds[k], self.rounds[k + 1]
         sh = {4: 2, 8: 3}[elem_bytes]
+        reg_wr, thr_wr, reg_rd, thr_rd = wr.reg_wr, wr.thr_wr, rdn.reg_rd, rdn.thr_rd
+        if elem_bytes == 8 and self.opts.get("own_slots", True):
+            # The slot map is private to the kernel.  The descriptor's masks are laid out for 4-byte planes (32-lane
+            # groups on 32 banks); an 8-byte exchange through them conflicts (PMC, reverse sweep: 0.57 conflict cycles per
+            # active LDS cycle).  The planner's rule for 8-byte elements -- 16-lane write groups, 32-lane read groups --
+            # is applied here instead (plan.exchange_masks(planar=False)).
+            tb = {1 << p: i for i, p in enumerate(self.tile_bits)}
+
+            class _R:          # the two rounds in the planner's terms: tile-bit index of every register / thread bit
+                pass
+
+            a_, b_ = _R(), _R()
+            a_.reg_tb, a_.thr_tb = [tb[m] for m in wr.reg_phys], [tb[m] for m in wr.thr_phys]
+            b_.reg_tb, b_.thr_tb = [tb[m] for m in rdn.reg_phys], [tb[m] for m in rdn.thr_phys]
+            A = P.exchange_masks(self.T, a_, b_, planar=False)
+            reg_wr, thr_wr = [A[x] for x in a_.reg_tb], [A[x] for x in a_.thr_tb]
+            reg_rd, thr_rd = [A[x] for x in b_.reg_tb], [A[x] for x in b_.thr_tb]
         sg = self.seg(f"exchange {k} -> {k + 1}")
         out = sg.parts[0]
         ws, rs, tpn = self.fresh("ws"), self.fresh("rs"), self.fresh("tph")
         lt = self.local_tid(out)
-        self.thread_xor(out, ws, wr.thr_wr, sh, lt)
-        self.thread_xor(out, rs, rdn.thr_rd, sh, lt)
+        self.thread_xor(out, ws, thr_wr, sh, lt)
+        self.thread_xor(out, rs, thr_rd, sh, lt)
         self.thread_xor(out, tpn, rdn.thr_phys, 0, lt)
-        wplan = self.exchange_plan(wr.reg_wr, wr.thr_wr)
-        rplan = self.exchange_plan(rdn.reg_rd, rdn.thr_rd)
+        wplan = self.exchange_plan(reg_wr, thr_wr)
+        rplan = self.exchange_plan(reg_rd, thr_rd)
         ctype = "float" if elem_bytes == 4 else "v2f"
         # volatile reads: the load / store optimiser would pair two 4-byte reads into one ds_read2, whose two results
         # land in ONE register pair -- but the two values are the same component of two different amplitudes, so every
@@ -665,7 +682,7 @@ def forward_source(words, kname: str = "tcmi_spec_pass", opts=None) -> Tuple[str
 # ======================================================================================================
 _SRC_DIGEST = None
 _LOCK = threading.Lock()
-_LOADED: Dict[str, "SpecKernel"] = {}
+_LOADED: Dict[tuple, "SpecKernel"] = {}
 STATS = {"compiled": 0, "cache_hits": 0, "unsupported": 0, "compile_s": 0.0}
 
 
@@ -810,21 +827,22 @@ def load(path: str, meta: dict) -> SpecKernel:
 
     from . import _lib
 
+    import torch
+
+    key = (path, torch.cuda.current_device())      # a module belongs to the device it was loaded on
     with _LOCK:
-        k = _LOADED.get(path)
+        k = _LOADED.get(key)
         if k is None:
             h = ctypes.c_void_p()
             _lib.check(_lib.lib().tcmi_spec_load(path.encode(), meta["kernel"].encode(), int(meta["lds"]), ctypes.byref(h)),
                        "tcmi_spec_load")
             if meta.get("persistent"):
                 # a persistent kernel loops over its tiles: launch as many workgroups as the chip holds at once
-                import torch
-
                 cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
                 wg_per_cu = max(1, min((1024 >> int(meta["LT"])), (160 * 1024) // max(1, int(meta["lds"]))))
                 _lib.check(_lib.lib().tcmi_spec_set_grid(h, int(cus * wg_per_cu)), "tcmi_spec_set_grid")
             k = SpecKernel(h, meta, path)
-            _LOADED[path] = k
+            _LOADED[key] = k
         return k
 
 

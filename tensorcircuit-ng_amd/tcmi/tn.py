@@ -1956,7 +1956,8 @@ class ContractionTree:
 
         mine = big[rank].clone()
         if dist.get_backend(group) == "nccl":
-            dist.all_gather_into_tensor(big.view(-1), mine, group=group)
+            # through the real views: every backend version takes float32 / float64, not every one takes complex
+            dist.all_gather_into_tensor(torch.view_as_real(big).reshape(-1), torch.view_as_real(mine).reshape(-1), group=group)
         else:
             re = torch.view_as_real(mine).contiguous()
             outs = [torch.empty_like(re) for _ in range(world)]
