@@ -47,14 +47,89 @@ def _is_tensor(v):
 
 
 class _Op:
-    __slots__ = ("qubits", "matrix", "spec", "pidx", "name")
+    __slots__ = ("qubits", "matrix", "spec", "pidx", "name", "diag", "chain")
 
-    def __init__(self, qubits, matrix=None, spec=None, pidx=None, name=""):
+    def __init__(self, qubits, matrix=None, spec=None, pidx=None, name="", diag=None):
         self.qubits = qubits
         self.matrix = matrix
         self.spec = spec
         self.pidx = pidx
         self.name = name
+        self.diag = diag          # the 2^k entries of a diagonal gate on k > 2 qubits
+        self.chain = None         # its chain form (``_diag_chain``), built when a network first asks
+
+
+DIAG_CHAIN_MIN = 4    # diagonal gates on at least this many qubits enter tensor networks as a chain of site tensors
+
+
+def _diag_chain(vec, k: int, tol: float = 1e-13):
+    """The 2^k entries of a diagonal gate as a chain: cores ``A_j [L_j, 2, R_j]`` with
+    ``vec[b_1 .. b_k] = A_1[0, b_1, :] . A_2[:, b_2, :] ... A_k[:, b_k, 0]`` (left-to-right SVD sweep, ranks cut at
+    ``tol`` relative and then padded with zeros to powers of two so that every bond is a bundle of dimension-2 legs,
+    the only kind the contraction engine's bit-index kernels address).  The reference wires such gates as MPO nodes /
+    CopyNode hyperedges (basecircuit.py:295-369, gates.py:981-1057: a multi-controlled gate has bond dimension 2);
+    this is the same network form, derived from the entries instead of being written per gate family."""
+    rest = np.asarray(vec, dtype=np.complex128).reshape(1, -1)
+    cores = []
+    for j in range(k - 1):
+        L = rest.shape[0]
+        u, s, vh = np.linalg.svd(rest.reshape(L * 2, -1), full_matrices=False)
+        r = max(1, int(np.count_nonzero(s > tol * s[0])))
+        R = 1 << (r - 1).bit_length()
+        a = np.zeros((L * 2, R), dtype=np.complex128)
+        a[:, :r] = u[:, :r]
+        cores.append(a.reshape(L, 2, R))
+        rest = np.zeros((R, vh.shape[1]), dtype=np.complex128)
+        rest[:r] = s[:r, None] * vh[:r]
+    cores.append(rest.reshape(rest.shape[0], 2, 1))
+    return cores
+
+
+class _DiagPlaceholder:
+    """Stands for a big diagonal gate while the light-cone cancellation runs (a chain of site tensors has no single
+    U / U^dagger pair to cancel); ``_expand_chains`` replaces the survivors."""
+
+    __slots__ = ("op", "conj")
+
+    def __init__(self, op, conj):
+        self.op = op
+        self.conj = conj
+
+
+def _chain_nodes(op, conj, outs, ins, tag, is_dagger, dt, dev):
+    """Site nodes of a diagonal gate: node j carries [left bond legs..., out_j, in_j, right bond legs...] and is
+    ``A_j[l, b, r]`` on out = in = b."""
+    from . import tn
+
+    k = len(op.qubits)
+    if op.chain is None:
+        op.chain = _diag_chain(op.diag, k)
+    nodes = []
+    left = []
+    for j, a in enumerate(op.chain):
+        L, _, R = a.shape
+        t = np.zeros((L, 2, 2, R), dtype=np.complex128)
+        t[:, 0, 0, :] = a[:, 0, :]
+        t[:, 1, 1, :] = a[:, 1, :]
+        if conj:
+            t = t.conj()
+        nl, nr = L.bit_length() - 1, R.bit_length() - 1
+        right = [tn.new_edge() for _ in range(nr)]
+        nodes.append(tn.Node(upload_cached(t, dt, dev).reshape([2] * (nl + 2 + nr)), left + [outs[j], ins[j]] + right,
+                             name=f"{op.name}-{j}", is_dagger=is_dagger, id=(tag, j), is_unitary=False))
+        left = right
+    return nodes
+
+
+def _expand_chains(nodes, dt, dev):
+    out = []
+    for nd in nodes:
+        if isinstance(nd.tensor, _DiagPlaceholder):
+            k = len(nd.edges) // 2
+            out.extend(_chain_nodes(nd.tensor.op, nd.tensor.conj, nd.edges[:k], nd.edges[k:], nd.id, nd.is_dagger, dt, dev))
+        else:
+            out.append(nd)
+    return out
 
 
 def _host_number(v):
@@ -358,7 +433,7 @@ class Circuit:
         if k > self.MAX_DIAGONAL_QUBITS:
             raise NotImplementedError(f"Backend 'hip' has not implemented diagonal gates on more than "
                                       f"{self.MAX_DIAGONAL_QUBITS} qubits")
-        self._ops.append(_Op(index, matrix=np.diag(vec), name=name))
+        self._ops.append(_Op(index, matrix=np.diag(vec), name=name, diag=vec))
         self._qir.append({"gate": None, "index": index, "name": name, "parameters": {"diag": vec}, "diagonal": True})
         self.state_tensor = None
 
@@ -882,7 +957,10 @@ class Circuit:
             from . import tn
             from .simplify import _full_light_cone_cancel
 
-            nodes = _full_light_cone_cancel(self.expectation_before(*ops, reuse=False))
+            import torch
+
+            nodes = _full_light_cone_cancel(self.expectation_before(*ops, reuse=False, _chains=False))
+            nodes = _expand_chains(nodes, getattr(torch, cons.dtypestr), cons.backend.device)
             return tn.contract_nodes(nodes, trials=0).tensor.reshape(())
 
         nq = self._nqubits
@@ -940,6 +1018,8 @@ class Circuit:
         by_size: Dict[int, List[int]] = {}
         par_size: Dict[int, List[int]] = {}
         for i, op in enumerate(self._ops):
+            if op.diag is not None and len(op.qubits) >= DIAG_CHAIN_MIN:
+                continue                                         # enters the network as a chain (_chain_nodes)
             if op.matrix is not None:
                 by_size.setdefault(int(np.asarray(op.matrix).size), []).append(i)
             else:
@@ -983,12 +1063,15 @@ class Circuit:
             out.append((idxs, m))
         return out
 
-    def _tn_nodes(self, conj: bool = False, stacks=None):  # noqa: C901
+    def _tn_nodes(self, conj: bool = False, stacks=None, chains: bool = True):  # noqa: C901
         """The circuit as a node list (reference ``BaseCircuit._copy``, basecircuit.py:150-181):
         n rank-1 |0> nodes (or one input node) followed by one node per gate, wired
         ``gate[i+k] ^ front[q_i]; front[q_i] = gate[i]`` (basecircuit.py:288-290).  Returns
         (nodes, front edges).  Gate tensors are built on the device from the current parameters
-        (differentiable, ``_gate_stacks``; ``stacks``: an already built set, shared by the ket and the bra)."""
+        (differentiable, ``_gate_stacks``; ``stacks``: an already built set, shared by the ket and the bra).
+        A diagonal gate on ``DIAG_CHAIN_MIN`` or more qubits (``diagonal``, ``cmz``, the controlled-D of a
+        ``multicontrol``) is a chain of k site nodes, never its 4^k-entry matrix (``_chain_nodes``; ``chains=False``
+        leaves one placeholder node per such gate for the light-cone cancellation, ``_expand_chains`` afterwards)."""
         import torch
         from . import tn
 
@@ -1021,6 +1104,17 @@ class Circuit:
                     srcs[i] = (ent[2], r, conj)
         for i, op in enumerate(self._ops):
             k = len(op.qubits)
+            if i not in tensors:
+                out_e = [tn.new_edge() for _ in range(k)]
+                ins = [front[q] for q in op.qubits]
+                if chains:
+                    nodes.extend(_chain_nodes(op, conj, out_e, ins, i, conj, dt, dev))
+                else:
+                    nodes.append(tn.Node(_DiagPlaceholder(op, conj), out_e + ins, name=op.name, is_dagger=conj, id=i,
+                                         is_unitary=True))
+                for j, q in enumerate(op.qubits):
+                    front[q] = out_e[j]
+                continue
             m = tensors[i]
             t = m.reshape([2] * (2 * k))
             if i in srcs:
@@ -1055,8 +1149,9 @@ class Circuit:
                      tn.Node(psi.conj().resolve_conj(), list(e2), "psi*", is_dagger=True, id=-1)]
         else:
             gt = self._gate_stacks()
-            n1, e1 = self._tn_nodes(stacks=gt)
-            n2, e2 = self._tn_nodes(conj=True, stacks=gt)
+            chains = kws.get("_chains", True)
+            n1, e1 = self._tn_nodes(stacks=gt, chains=chains)
+            n2, e2 = self._tn_nodes(conj=True, stacks=gt, chains=chains)
             nodes = n1 + n2
         newdang = list(e1) + list(e2)
         occupied = set()

@@ -131,3 +131,60 @@ def test_example_block_is_the_hea_b_ansatz(tcd):
             c = tc.templates.blocks.example_block(tc.Circuit(n), tc.backend.convert_to_tensor(params.reshape(-1), dtype=tc.rdtypestr),
                                                   nlayers=d, is_split=split)
             assert np.abs(tc.backend.numpy(c.wavefunction()) - ref).max() < tol, (n, d, split)
+
+
+def test_big_diagonals_in_the_network_route(tcd):
+    """Reference basecircuit.py:295-369 (mpo= / diagonal= gates as MPO nodes): cmz on 10 qubits, a 5-control
+    multicontrol and a 7-qubit diagonal in the contraction engine -- amplitude, light-cone expectation and the sliced
+    DistributedContractor value_and_grad -- against the state-vector route; no network node exceeds 2^10 entries
+    (the gates' matrices would be 2^20 / 2^12 / 2^14)."""
+    import torch
+
+    tc = tcd
+    from tcmi import tn
+
+    n = 12
+    rng = np.random.default_rng(11)
+    dv = np.exp(1j * rng.uniform(0, 6, 128))
+    u = G.rx(0.9) @ G.rz(0.4)
+
+    def build(p):
+        c = tc.Circuit(n)
+        for i in range(n):
+            c.h(i)
+        for i in range(n):
+            c.rx(i, theta=p[0, i])
+        c.cmz(0, 1, 2, 3, 4, 6, 7, 8, 10, 11)
+        c.multicontrol(9, 5, 3, 1, 0, 7, ctrl=[1, 1, 0, 1, 1], unitary=u)
+        for i in range(n):
+            c.ry(i, theta=p[1, i])
+        c.diagonal(2, 4, 5, 6, 8, 9, 11, diag=dv)
+        for i in range(n):
+            c.rx(i, theta=p[2, i])
+        return c
+
+    p = tc.backend.convert_to_tensor(rng.uniform(0, 6, [3, n]), dtype=tc.rdtypestr)
+    tol = 2e-5 if tc.dtypestr == "complex64" else 1e-10
+    c = build(p)
+    psi = tc.backend.numpy(c.wavefunction())
+    bits = "101100101101"
+    nodes = c.amplitude_before(bits)
+    assert max(nd.tensor.numel() for nd in nodes) <= 2 ** 10
+    a = tn.contract_nodes(nodes).tensor
+    assert abs(complex(tc.backend.numpy(a)) - psi[int(bits, 2)]) < tol
+    ref = float(tc.backend.numpy(tc.backend.real(c.expectation_ps(z=[5], x=[8]))))
+    e = c.expectation((tc.gates.z(), [5]), (tc.gates.x(), [8]), enable_lightcone=True)
+    assert abs(float(tc.backend.numpy(tc.backend.real(e))) - ref) < tol * 4
+
+    def nodes_fn(q):
+        return build(q).expectation_before((tc.gates.z(), [5]), (tc.gates.x(), [8]), reuse=False)
+
+    dc = tc.experimental.DistributedContractor(nodes_fn, p, {"slicing_reconf_opts": {"target_size": 2 ** 9}, "max_repeats": 4})
+    v, g = dc.value_and_grad(p)
+    assert abs(float(tc.backend.numpy(v)) - ref) < tol * 4
+
+    def f(q):
+        return tc.backend.real(build(q).expectation_ps(z=[5], x=[8]))
+
+    _, g2 = tc.backend.value_and_grad(f)(p)
+    assert np.abs(tc.backend.numpy(g) - tc.backend.numpy(g2)).max() < tol * 20

@@ -145,3 +145,76 @@ def test_lightcone_cancellation_node_counts_and_value():
     c.any(1, unitary=np.array([[1.0, 0.0], [0.0, 0.5]]))
     nodes = c.expectation_before([tc.gates.z(), 0], reuse=False)
     assert len(tc.simplify._full_light_cone_cancel(nodes)) == len(nodes)
+
+
+def _diag_circuit(tc):
+    """h layer, cmz on 6 qubits, a 4-control multicontrol, a 5-qubit diagonal, rx layer; + the oracle's op list."""
+    from oracle import gates as OG
+
+    n = 8
+    rng = np.random.default_rng(5)
+    c, ops = tc.Circuit(n), []
+    for i in range(n):
+        c.h(i); ops.append((OG.H, [i]))
+    c.cmz(0, 2, 3, 5, 6, 7)
+    d = np.ones(64, dtype=complex); d[-1] = -1
+    ops.append((np.diag(d), [0, 2, 3, 5, 6, 7]))
+    u = OG.rx(0.7)
+    c.multicontrol(1, 4, 6, 0, 3, ctrl=[1, 0, 1, 1], unitary=u)
+    m = np.eye(32, dtype=complex)
+    cv = 0b1011
+    m[2 * cv:2 * cv + 2, 2 * cv:2 * cv + 2] = u
+    ops.append((m, [1, 4, 6, 0, 3]))
+    dv = np.exp(1j * rng.uniform(0, 6, 32))
+    c.diagonal(7, 1, 2, 4, 5, diag=dv); ops.append((np.diag(dv), [7, 1, 2, 4, 5]))
+    for i in range(n):
+        th = float(rng.uniform(0, 6)); c.rx(i, theta=th); ops.append((OG.rx(th), [i]))
+    return c, ops, n
+
+
+def test_big_diagonal_gates_enter_networks_as_chains():
+    """Reference basecircuit.py:295-369 wires mpo= / diagonal= gates as MPO nodes and CopyNode hyperedges; here a
+    diagonal on >= 4 qubits is a chain of site nodes with dimension-2 bond bundles (circuit._diag_chain): no node of
+    the network is the gate's 4^k-entry matrix, and the network contracts (oracle/tn.py) to the dense-oracle values.
+    Under the light-cone cancellation the gate is one placeholder until the cancellation is done."""
+    import tcmi as tc
+    from tcmi import circuit as C
+    from oracle import dense, tn as OT
+
+    tc.set_backend("hip"); tc.set_dtype("complex128")
+    c, ops, n = _diag_circuit(tc)
+    psi = dense.run(n, ops)
+    # amplitude network
+    bits = "10110010"
+    nodes = c.amplitude_before(bits)
+    assert max(nd.tensor.numel() for nd in nodes) <= 2 ** 8, max(nd.tensor.numel() for nd in nodes)
+    assert sum(1 for nd in nodes if "-" in nd.name and not nd.name.startswith("qb")) == 6 + 5 + 5
+    res = OT.contract([OT.Node(np.asarray(nd.tensor.cpu()), nd.edges) for nd in nodes])
+    np.testing.assert_allclose(complex(np.asarray(res.tensor)), psi[int(bits, 2)], atol=1e-12)
+    # expectation network (ket + bra chains, conjugated cores on the bra side)
+    nodes = c.expectation_before([tc.gates.z(), 2], [tc.gates.x(), 5], reuse=False)
+    assert max(nd.tensor.numel() for nd in nodes) <= 2 ** 8
+    res = OT.contract([OT.Node(np.asarray(nd.tensor.cpu()), nd.edges) for nd in nodes])
+    ref = dense.pauli_string_expectation(psi, n, [0, 0, 3, 0, 0, 1, 0, 0])
+    np.testing.assert_allclose(complex(np.asarray(res.tensor)), ref, atol=1e-12)
+    # light cone: a trailing cmz on qubits the operator does not touch cancels as ONE gate, then the rest expands
+    import torch
+    c2, ops2, _ = _diag_circuit(tc)
+    c2.cmz(0, 1, 3, 4)
+    nodes = c2.expectation_before([tc.gates.z(), 6], reuse=False, _chains=False)
+    l0 = len(nodes)
+    nodes = tc.simplify._full_light_cone_cancel(nodes)
+    assert l0 - len(nodes) >= 2 + 2 * 7         # the trailing cmz pair and the 7 rx pairs off qubit 6
+    nodes = C._expand_chains(nodes, torch.complex128, tc.backend.device)
+    assert not any(isinstance(nd.tensor, C._DiagPlaceholder) for nd in nodes)
+    res = OT.contract([OT.Node(np.asarray(nd.tensor.cpu()), nd.edges) for nd in nodes])
+    ref = dense.pauli_string_expectation(psi, n, [0, 0, 0, 0, 0, 0, 3, 0])
+    np.testing.assert_allclose(complex(np.asarray(res.tensor)), ref, atol=1e-12)
+    # the chain itself: cores reproduce the entries; a multi-controlled phase has bond dimension 2
+    v = np.ones(2 ** 9, dtype=complex); v[-1] = -1
+    cores = C._diag_chain(v, 9)
+    assert max(a.shape[2] for a in cores) == 2
+    r = cores[0][0]
+    for a in cores[1:]:
+        r = np.tensordot(r, a, axes=([-1], [0]))
+    np.testing.assert_allclose(r.reshape(-1), v, atol=1e-13)
