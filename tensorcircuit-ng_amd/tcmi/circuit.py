@@ -202,6 +202,32 @@ def _split_truncate(m, split_conf):
     return m1 if k1 <= k2 else m2
 
 
+def _family_split_is_exact(specs, split_conf) -> bool:
+    """Whether the split of a parametrised two-qubit gate keeps it exactly at EVERY angle: only ``max_singular_values``
+    caps the split (a ``max_truncation_err`` threshold is angle-dependent by nature) and the operator-Schmidt rank of
+    the family across the pairing the reference would use (``fixed_choice``, default 1 = (out0, in0) | (out1, in1))
+    fits under it.  The rank of ``c0 + cos(a) c1 + sin(a) c2`` is the same at every generic angle (its minors are
+    trigonometric polynomials), so three irrational angles decide: rzz / rxx / ryy / exp1 of a Pauli pair / the
+    controlled rotations have rank 2, which is what the reference's own ``max_singular_values: 2`` configurations
+    (examples, templates/blocks.py:146-185) rely on."""
+    k = split_conf.get("max_singular_values")
+    err = split_conf.get("max_truncation_err")
+    if k is None or (err is not None and float(err) > 0.0):
+        return False
+    perm = (0, 3, 1, 2) if split_conf.get("fixed_choice") == 2 else (0, 2, 1, 3)
+    rank = 0
+    for a0 in (0.7390851332151607, 2.0943951023931953 + 0.1234567, 4.1887902047863905 + 0.7654321):
+        m = None
+        for j, sp in enumerate(specs):
+            a = sp.scale * (a0 + 0.917 * j) + sp.offset
+            f = sp.c0 + np.cos(a) * sp.c1 + np.sin(a) * sp.c2
+            m = f if m is None else f @ m
+        sv = np.linalg.svd(np.asarray(m, dtype=np.complex128).reshape(2, 2, 2, 2).transpose(perm).reshape(4, 4),
+                           compute_uv=False)
+        rank = max(rank, int(np.count_nonzero(sv > 1e-10 * sv[0])))
+    return rank <= int(k)
+
+
 _CONST_CACHE: "OrderedDict[int, tuple]" = OrderedDict()
 _CONST_CACHE_MAX = 4096
 
@@ -379,9 +405,11 @@ class Circuit:
                     f = sp.c0 + np.cos(a) * sp.c1 + np.sin(a) * sp.c2
                     m = f if m is None else f @ m
                 return self._record_const(m, index, name)
-            raise NotImplementedError(
-                "Backend 'hip' has not implemented a truncating `split` rule for two-qubit gates with tensor-valued "
-                "parameters (constant gates and concrete angles are truncated at record time).")
+            if not _family_split_is_exact(specs, self.split):
+                raise NotImplementedError(
+                    "Backend 'hip' has not implemented a truncating `split` rule for two-qubit gates with tensor-valued "
+                    "parameters whose truncation depends on the angle (constant gates and concrete angles are truncated "
+                    "at record time; families whose operator-Schmidt rank fits max_singular_values are exact).")
         if getattr(self, "_conj", False):
             specs = [G.TrigSpec(np.conj(sp.c0), np.conj(sp.c1), np.conj(sp.c2), sp.theta, sp.scale, sp.offset, sp.name)
                      for sp in specs]

@@ -201,9 +201,25 @@ def test_split_rule_truncates_like_the_reference(tcd):
         ops += [(G.H, [i]), (G.rz(0.4 * (i + 1)), [i])]
     ops += [(rank1(zz), [0, 1]), (rank1(isw), [1, 2])]
     np.testing.assert_allclose(_np(tc, c.state()), dense.run(4, ops), atol=tol)
-    with pytest.raises(NotImplementedError, match="Backend 'hip' has not implemented"):
-        c = tc.Circuit(4, split={"max_singular_values": 2})
-        c.rzz(0, 1, theta=tc.backend.convert_to_tensor(np.float32(0.3)))
+    # tensor-valued angles: a family whose operator-Schmidt rank fits the cap at every angle is exact (rzz has rank 2,
+    # the reference's own max_singular_values = 2 configurations); a truncation that depends on the angle is refused
+    th = tc.backend.convert_to_tensor(np.asarray(0.3, dtype=tc.rdtypestr))
+    c = tc.Circuit(4, split={"max_singular_values": 2, "fixed_choice": 1})
+    for i in range(4):
+        c.h(i)
+        c.rz(i, theta=0.4 * (i + 1))
+    c.rzz(0, 1, theta=th)
+    c.cphase(2, 3, theta=th)
+    ops = []
+    for i in range(4):
+        ops += [(G.H, [i]), (G.rz(0.4 * (i + 1)), [i])]
+    ops += [(zz, [0, 1]), (np.diag([1, 1, 1, np.exp(0.3j)]), [2, 3])]
+    np.testing.assert_allclose(_np(tc, c.state()), dense.run(4, ops), atol=tol)
+    for conf, gate in (({"max_singular_values": 1}, "rzz"), ({"max_singular_values": 2}, "iswap"),
+                       ({"max_truncation_err": 0.1}, "rzz")):
+        with pytest.raises(NotImplementedError, match="Backend 'hip' has not implemented"):
+            c = tc.Circuit(4, split=conf)
+            getattr(c, gate)(0, 1, theta=th)
 
 
 def test_backend_ops_run_on_the_hip_kernels(tcd):
