@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md chip table (spec; 6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFS = 157.3  # dense FP32 (f32-input) MFMA peak, same table
+MFMA_BF16_PEAK_TFS = 2516.6  # dense bf16 MFMA peak (256 CUs x 4 SIMDs x 32768 flop / 32 cycles x 2.4 GHz), same table
 
 
 def build_circuit(tc, n, d, params_row):
@@ -857,7 +858,7 @@ def main():
 
     # HBM traffic of the dominant kernel, measured by the PMC counters on this very command (child processes,
     # started before this process touches the GPU)
-    KERNELS = ("cgemm_dma128_kernel", "cgemm_dma_kernel", "cgemm_mfma_kernel", "pass2_kernel")
+    KERNELS = ("cgemm_split_kernel", "cgemm_dma128_kernel", "cgemm_dma_kernel", "cgemm_mfma_kernel", "pass2_kernel")
     traffic = {}
     if rank == 0 and world == 1 and not args.no_traffic_probe:
         traffic = traffic_probe(args, KERNELS)
@@ -943,6 +944,28 @@ def main():
     ev = summarize_events(X.EVENT_LOG)
     X.EVENT_LOG = None
     traced = bool(getattr(fwd, "stats", {}).get("fast", 0) >= args.steps)
+    # the same step with every join on the exact-f32 MFMA kernel (tcmi_cgemm), and how far the two results differ
+    join_f32 = None
+    if is_cut and X.JOIN_GEMM != "f32" and not args.probe_child:
+        split_state = fwd(chunks[0]).clone() if chunks else None
+        X.JOIN_GEMM = "f32"
+        try:
+            for _ in range(2):
+                state = fwd(params)
+            sync()
+            tf0 = time.perf_counter()
+            for k in range(args.steps):
+                for ch in chunks:
+                    state = fwd(ch)
+            sync()
+            tf = time.perf_counter() - tf0
+            diff = float((fwd(chunks[0]) - split_state).abs().max().item()) if chunks else None
+            join_f32 = {"ms_per_step": tf / args.steps * 1e3, "amplitudes_per_s": float(Bg) * (2**n) * args.steps / tf,
+                        "max_abs_difference_of_the_two_states": diff,
+                        "largest_amplitude": float(split_state.abs().max().item()) if chunks else None}
+        finally:
+            X.JOIN_GEMM = "split"
+        del split_state
     # a checksum of the step's result that every world size must reproduce: sum over the global batch of <psi|Z_0|psi>
     chk = torch.zeros(1, device=dev, dtype=torch.float64)
     for ch in chunks:
@@ -1038,12 +1061,20 @@ def main():
             # 64-tile DMA kernel / the register-staged kernel
             gk = "cgemm_dma128_kernel" if (M % 128 == 0 and N % 128 == 0 and K % 16 == 0) else \
                 ("cgemm_dma_kernel" if (M % 64 == 0 and N % 64 == 0 and K % 16 == 0) else "cgemm_mfma_kernel<true>")
+            peak = MFMA_F32_PEAK_TFS
+            split = X.JOIN_GEMM != "f32" and M % 128 == 0 and N % 128 == 0 and K % 32 == 0
+            if split:
+                # tcmi_cgemm_split: 3 real products x 6 bf16 piece products per complex MAC = 36 flops on the bf16 pipe
+                gk, exe, peak = "cgemm_split_kernel<0>", 4.5 * alg, MFMA_BF16_PEAK_TFS
             tr = traffic.get(gk.split("<")[0])
             roof = {
                 "bound": "mfma", "kernel": f"tcmi::{gk} (cut-contraction join GEMM)",
-                # frac = EXECUTED flops (what the MFMA pipe does) against the dense f32 MFMA peak
-                "achieved": exe / (avg_us * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s",
-                "frac": exe / (avg_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFS,
+                # frac = EXECUTED flops (what the MFMA pipe does) against the dense MFMA peak of the pipe it runs on
+                "achieved": exe / (avg_us * 1e-6) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                "frac": exe / (avg_us * 1e-6) / 1e12 / peak,
+                **({"pipe": "bf16 MFMA, f32 operands cut into three bf16 pieces, six piece products per real product "
+                            "(f32 accuracy: error against float64 equal to the f32 MFMA kernel's, "
+                            "tests/test_gpu_gemm_split.py)"} if split else {}),
                 "algorithmic_achieved": alg / (avg_us * 1e-6) / 1e12,
                 "algorithmic_frac": alg / (avg_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFS,
                 "traffic": tr, "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command, "
@@ -1083,7 +1114,8 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "c64 (f32 arithmetic)",
+            "dtype": "c64 (f32 arithmetic)" if join_f32 is None else
+                     "c64 (f32 arithmetic; join GEMM at f32 accuracy on the bf16 MFMA pipe, see roofline.pipe and join_on_f32_mfma)",
             "data": "synthetic",
             "config": {
                 "workload": f"HEA-B statevector contraction n={n} depth={d} complex64 (SURVEY 8d config 2): one step = "
@@ -1096,6 +1128,8 @@ def main():
             "roofline": roof,
             "latency_batch1": {"ms_per_state": lat1 * 1e3, "amplitudes_per_s": (2**n) / lat1},
         }
+        if join_f32 is not None:
+            out["join_on_f32_mfma"] = join_f32
         if graph_info is not None:
             out["hipgraph_replay"] = graph_info
         if hea_a is not None:

@@ -216,6 +216,15 @@ int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, 
                long long strideA, long long strideB, long long strideC, int trans_a, int dtype,
                void* stream);
 
+/* The same product for complex64 with a k-major A (trans_a form: A [K x M], B [K x N]; M, N multiples of 128, K of 32,
+ * 16-byte aligned operands, even strides) on the bf16 matrix pipe at f32 accuracy: every f32 operand value is cut exactly
+ * into three bf16 pieces and a real product is the six piece products of order <= 2^-16 accumulated in f32
+ * (v_mfma_f32_32x32x16_bf16); the dropped pieces are below one f32 rounding of the product (tcmi_gemm_split.hip; error
+ * against a float64 product measured equal to tcmi_cgemm's).  2.7 x the MFMA rate of the exact-f32 pipe that tcmi_cgemm
+ * uses.  The join of the cut contraction (reference circuit.py:701-721 -> cons.py:948). */
+int tcmi_cgemm_split(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch,
+                     long long strideA, long long strideB, long long strideC, void* stream);
+
 /* <a|b> = sum conj(a_i) b_i per batch element (states [batch][2^n], stride elements apart), accumulated in
  * float64 into `copies` replicated {re, im} pairs: out[b * out_batch_stride + 2 * copy + {0,1}] += ...; the
  * caller zeroes `out` and sums the copies.  Used for <psi|P|psi> of Pauli strings with more than two X/Y

@@ -817,6 +817,7 @@ VM_COST = {"pass": 19.5, "g1": 2.25, "g2": 9.0, "diag": 11.5, "exchange": 10.75}
 # a pass costs max(HBM floor, fixed + gates + phase tables + exchanges), microseconds per 2^24 amplitudes
 VM2_COST = {"floor": 52.0, "fixed": 16.2, "g1": 0.95, "g2": 3.8, "table": 1.1, "diag": 5.0, "exchange": 3.3}
 GEMM_TFLOPS = 150.0  # tcmi_cgemm, batched cut join (3-product kernel, algorithmic flops: 154 measured, profiles/r02d)
+JOIN_GEMM = os.environ.get("TCMI_JOIN_GEMM", "split")   # "f32": joins on the exact-f32 MFMA kernel (tcmi_cgemm) only
 
 
 # packed adjoint kernel (csrc/tcmi_adjoint2.hip), fitted to the per-pass times of n = 28, d = 12 (scripts/gpu_adj_one.py
@@ -1094,12 +1095,19 @@ class CutCircuit:
             out = torch.empty(B, M * N, dtype=self.tdtype, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         with _timed("gemm", 1, 8.0 * M * N * K * B):
-            _lib.check(
-                self._lib.tcmi_cgemm(L.data_ptr(), R.data_ptr(), out.data_ptr(), M, N, K, B, K * M, K * N, M * N,
-                                     1, self.code, stream),
-                "tcmi_cgemm(cut)",
-            )
+            self._join(L, R, out, M, N, K, B, stream)
         return out
+
+    def _join(self, L, R, out, M, N, K, B, stream):
+        """psi[b] = L[b]^T . R[b] (k-major halves).  complex64 joins whose shape the kernel takes run on the bf16
+        matrix pipe with three-piece operands (``tcmi_cgemm_split``: f32 accuracy, measured against float64 next to the
+        f32 MFMA kernel in tests/test_gpu_gemm_split.py); ``TCMI_JOIN_GEMM=f32`` keeps every join on ``tcmi_cgemm``."""
+        if self.code == _lib.TCMI_C64 and JOIN_GEMM != "f32" and M % 128 == 0 and N % 128 == 0 and K % 32 == 0:
+            _lib.check(self._lib.tcmi_cgemm_split(L.data_ptr(), R.data_ptr(), out.data_ptr(), M, N, K, B, K * M, K * N,
+                                                  M * N, stream), "tcmi_cgemm_split(cut)")
+            return
+        _lib.check(self._lib.tcmi_cgemm(L.data_ptr(), R.data_ptr(), out.data_ptr(), M, N, K, B, K * M, K * N, M * N,
+                                        1, self.code, stream), "tcmi_cgemm(cut)")
 
     def _state_pipelined(self, p, pfull, B, nsplit, out):
         """The batch in ``nsplit`` sub-batches, each on its own HIP stream: the half-circuit passes of a sub-batch are a
@@ -1138,11 +1146,7 @@ class CutCircuit:
             L.record_stream(cur)
             R.record_stream(cur)
             with _timed("gemm", 1, 8.0 * M * N * K * (b1 - b0)):
-                _lib.check(
-                    self._lib.tcmi_cgemm(L.data_ptr(), R.data_ptr(), out[b0:b1].data_ptr(), M, N, K, b1 - b0, K * M, K * N,
-                                         M * N, 1, self.code, stream),
-                    "tcmi_cgemm(cut)",
-                )
+                self._join(L, R, out[b0:b1], M, N, K, b1 - b0, stream)
         return out
 
     def vjp(self, params, psi, g, **kw):
