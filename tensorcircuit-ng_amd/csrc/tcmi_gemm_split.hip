@@ -320,9 +320,13 @@ int tcmi_cgemm_split(const void* A, const void* B, void* C, long long M, long lo
   }
 #define TCMI_SPLIT_LAUNCH(MODE)                                                                                        \
   {                                                                                                                    \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(tcmi::cgemm_split_kernel<MODE>),                             \
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * tcmi::SPLIT_STAGE_BYTES) != hipSuccess)    \
-      return tcmi_set_error_(TCMI_ERR_HIP, "tcmi_cgemm_split: cannot raise the dynamic LDS limit");                    \
+    static bool attr_set_ = false;                                                                                     \
+    if (!attr_set_) {                                                                                                  \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(tcmi::cgemm_split_kernel<MODE>),                           \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * tcmi::SPLIT_STAGE_BYTES) != hipSuccess)  \
+        return tcmi_set_error_(TCMI_ERR_HIP, "tcmi_cgemm_split: cannot raise the dynamic LDS limit");                  \
+      attr_set_ = true;                                                                                                \
+    }                                                                                                                  \
     hipLaunchKernelGGL(tcmi::cgemm_split_kernel<MODE>, dim3((unsigned)(nwork < ncu ? nwork : ncu), 1, 1), dim3(256),   \
                        2 * tcmi::SPLIT_STAGE_BYTES, st, reinterpret_cast<const float2*>(A),                            \
                        reinterpret_cast<const float2*>(B), reinterpret_cast<float2*>(C), (int)M, (int)N, (int)K, strideA, \
