@@ -1048,7 +1048,11 @@ def main():
         if is_cut:                       # the half-circuit batches have their own (small-tile) plan configuration
             half = cc.left.single if cc.left.s == 0 else cc.left.prefix
             pcfg = half.cfg
-        pass_entry = hbm_entry("tcmi::pass2_kernel<%d,%d> (tile-VM gate passes)" % (pcfg.R, pcfg.LT), ev.get("pass"),
+        from tcmi import specialize as SP_
+
+        nspec_fwd = sum(1 for v in SP_._LOADED.values() if v.meta.get("kind") == "forward")
+        pass_entry = hbm_entry(("tcmi_spec_forward (plan-specialised gate passes; programs of pass2_kernel<%d,%d>)" if nspec_fwd
+                                else "tcmi::pass2_kernel<%d,%d> (tile-VM gate passes)") % (pcfg.R, pcfg.LT), ev.get("pass"),
                                args.steps)
         if is_cut:
             g = ev["gemm"]
