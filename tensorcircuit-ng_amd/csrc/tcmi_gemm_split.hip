@@ -17,7 +17,7 @@
 // wave (2 x 2 MFMA tiles x 3 products = 12 f32x16 accumulators in AGPRs), k in steps of 16 (one MFMA).  Operands are
 // read as f32: every thread loads 16 elements of the block after next straight into registers (8 x 16 bytes: two
 // neighbouring rows of eight k), cuts the block that arrived a step earlier into its nine planes ({re, im, re + im} x
-// three pieces) with ~300 VALU instructions placed four behind each of the 72 MFMAs of the step
+// three pieces) with ~300 VALU instructions placed five behind each MFMA of the step
 // (sched_group_barrier), and writes them to the idle plane stage (18 ds_write_b128, conflict-free).  The MFMA
 // fragments are 36 ds_read_b128 per wave and step (64 lanes read 1 KiB contiguous: conflict-free).  The stage layout
 // is [operand][product t][piece s][k half][row position][8 k]; rows and columns of a tile sit in it interleaved
@@ -58,7 +58,7 @@ constexpr int SPLIT_BLOCK_BYTES = 128 * SPLIT_BK * 2;      // one (product, piec
 constexpr int SPLIT_STAGE_BYTES = 18 * SPLIT_BLOCK_BYTES;  // A: 9 blocks, B: 9 blocks
 
 #ifndef TCMI_S2_VPM
-#define TCMI_S2_VPM 4
+#define TCMI_S2_VPM 5
 #endif
 typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
 typedef float f32x2_ __attribute__((ext_vector_type(2)));
