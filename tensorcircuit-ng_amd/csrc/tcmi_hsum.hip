@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void pauli_tile_kernel(const typename Cx<F>::t
                                                          const int* __restrict__ tilepos_g, const int* __restrict__ terms,
                                                          int nterms, int ndiag, const double* __restrict__ w,
                                                          long long wstride, int accumulate, double* __restrict__ eout, long long estride,
-                                                         int ecopies) {
+                                                         int ecopies, int nt) {
   using C = typename Cx<F>::type;
   constexpr int NE = 1 << T, EPT = NE / 256, KB = T - 9;   // KB = index bits carried by the pair counter k
   static_assert(EPT >= 2 && (EPT & 1) == 0, "at least one pair per thread");
@@ -76,7 +76,10 @@ __global__ __launch_bounds__(256) void pauli_tile_kernel(const typename Cx<F>::t
     // (32) bytes apart and every 8-byte read hit each bank twice -- the round-3 PMC run counted more bank-conflict cycles
     // than active LDS cycles in this kernel.
     if constexpr (sizeof(F) == 4) {
-      const float4 q = *reinterpret_cast<const float4*>(src);
+      // states that no cache holds until the next pass (nt: 2^26 amplitudes and up) are streamed with the nontemporal hint
+      typedef float v4f_nt __attribute__((ext_vector_type(4)));
+      const v4f_nt q = nt ? __builtin_nontemporal_load(reinterpret_cast<const v4f_nt*>(src))
+                          : *reinterpret_cast<const v4f_nt*>(src);
       C a0, a1;
       a0.x = q.x; a0.y = q.y; a1.x = q.z; a1.y = q.w;
       tile[tid + 256 * k] = a0;
@@ -181,7 +184,10 @@ __global__ __launch_bounds__(256) void pauli_tile_kernel(const typename Cx<F>::t
         const float4 old = *reinterpret_cast<const float4*>(dst);
         o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
       }
-      *reinterpret_cast<float4*>(dst) = o;
+      typedef float v4f_nt __attribute__((ext_vector_type(4)));
+      const v4f_nt ov = {o.x, o.y, o.z, o.w};
+      if (nt) __builtin_nontemporal_store(ov, reinterpret_cast<v4f_nt*>(dst));
+      else *reinterpret_cast<v4f_nt*>(dst) = ov;
     } else {
       C o0, o1;
       o0.x = re[2 * k]; o0.y = im[2 * k]; o1.x = re[2 * k + 1]; o1.y = im[2 * k + 1];
@@ -216,11 +222,11 @@ int tcmi_apply_pauli_sum_tiled(const void* in, void* out, long long state_stride
   if (dtype == TCMI_C64)
     hipLaunchKernelGGL((tcmi::pauli_tile_kernel<float, 12>), grid, block, sizeof(float2) << 12, st,
                        reinterpret_cast<const float2*>(in), reinterpret_cast<float2*>(out), state_stride, tilepos, terms,
-                       nterms, ndiag, weights, weights_stride, accumulate, eout, eout_stride, ecopies);
+                       nterms, ndiag, weights, weights_stride, accumulate, eout, eout_stride, ecopies, n >= 26 ? 1 : 0);
   else
     hipLaunchKernelGGL((tcmi::pauli_tile_kernel<double, 11>), grid, block, sizeof(double2) << 11, st,
                        reinterpret_cast<const double2*>(in), reinterpret_cast<double2*>(out), state_stride, tilepos,
-                       terms, nterms, ndiag, weights, weights_stride, accumulate, eout, eout_stride, ecopies);
+                       terms, nterms, ndiag, weights, weights_stride, accumulate, eout, eout_stride, ecopies, 0);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));
   return TCMI_OK;

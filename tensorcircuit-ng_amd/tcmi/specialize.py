@@ -43,6 +43,9 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize
                "--genco", "-I", CSRC]
 
 
+NT_MIN_N = 26
+
+
 class Unsupported(Exception):
     """The pass contains an op (or a shape) the emitter has no straight-line form for: it stays interpreted."""
 
@@ -137,6 +140,11 @@ class _Emitter:
         self.w = w
         self.opts = dict(opts or {})
         self.n, self.T, self.R, self.LT = int(w[1]), int(w[2]), int(w[3]), int(w[4])
+        # tile loads / stores of states that no cache holds until the next pass (2^26 amplitudes = 512 MiB per state and
+        # up) carry the nontemporal hint: forward 8.96 -> 8.85 ms per state, sweep 27.3 -> 27.1 ms per sample at n = 28
+        # (TCMI_SPEC_EXP=ntl=0,nts=0 to compare); smaller states are re-read from L2 / MALL by the next pass or the join
+        self.opts.setdefault("ntl", int(self.n >= NT_MIN_N))
+        self.opts.setdefault("nts", int(self.n >= NT_MIN_N))
         self.nrounds, self.flags = int(w[5]), int(w[6])
         self.NR = 1 << self.R
         if self.n > 32:
@@ -267,11 +275,14 @@ class _Emitter:
                     continue
                 if store:
                     v = self.fresh("sv")
-                    out.append(f"  {{ v4f {v}; {v}.xy = {self.A(r, vec)}; {v}.zw = {self.A(r + 1, vec)}; "
-                               f"*reinterpret_cast<v4f*>({addr}) = {v}; }}")
+                    st = (f"__builtin_nontemporal_store({v}, reinterpret_cast<v4f*>({addr}))" if self.opts.get("nts")
+                          else f"*reinterpret_cast<v4f*>({addr}) = {v}")
+                    out.append(f"  {{ v4f {v}; {v}.xy = {self.A(r, vec)}; {v}.zw = {self.A(r + 1, vec)}; {st}; }}")
                 else:
                     v = self.fresh("lv")
-                    out.append(f"  const v4f {v} = *reinterpret_cast<const v4f*>({addr});")
+                    ld = (f"__builtin_nontemporal_load(reinterpret_cast<const v4f*>({addr}))" if self.opts.get("ntl")
+                          else f"*reinterpret_cast<const v4f*>({addr})")
+                    out.append(f"  const v4f {v} = {ld};")
                     out.append(f"  {self.A(r, vec)} = {v}.xy; {self.A(r + 1, vec)} = {v}.zw;")
 
     # ---- LDS exchange --------------------------------------------------------------------------------
