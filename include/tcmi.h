@@ -281,11 +281,17 @@ int tcmi_spec_unload(void* handle);
 /* Persistent kernels (one workgroup loops over many tiles): launch at most `max_workgroups` workgroups (grid.x * batch);
  * 0 (the default after tcmi_spec_load) = one workgroup per tile.  Must match how the kernel was generated. */
 int tcmi_spec_set_grid(void* handle, int max_workgroups);
+/* `live_mask` (over the n - T bits of the tile index; 0xffffffff = every tile): only the tiles whose index is zero outside
+ * the mask get a workgroup.  A circuit started from |0...0> leaves every amplitude whose index has a 1 on a qubit no pass
+ * has had in its tile yet exactly zero, and a pass acts inside its tiles: those tiles are zero before and after it, so
+ * the first passes of a state (and the last passes of the reverse sweep, where psi is back to that shape and a zero psi
+ * tile contributes to no gradient) run on the few tiles that can be non-zero (tcmi/executor.py live_masks). */
 int tcmi_spec_run_pass(void* handle, void* state, long long state_stride, int batch, int n, int T, int LT,
-                       const void* ctab, const void* ptab, long long ptab_stride, void* stream);
+                       const void* ctab, const void* ptab, long long ptab_stride, unsigned live_mask, void* stream);
 int tcmi_spec_run_adjoint_pass(void* handle, void* psi, void* lam, long long state_stride, int batch, int n, int T,
                                int LT, const void* ctab, const void* ptab, long long ptab_stride, double* gout,
-                               long long gout_stride, int gcopies, long long gcopy_stride, void* stream);
+                               long long gout_stride, int gcopies, long long gcopy_stride, unsigned live_mask,
+                               void* stream);
 
 #ifdef __cplusplus
 }

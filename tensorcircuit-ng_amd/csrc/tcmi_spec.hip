@@ -21,8 +21,11 @@ struct SpecKernel {
   int lds_bytes;
   int max_workgroups;   // > 0: persistent kernel, grid.x * batch capped at this many workgroups (it loops over its tiles)
 };
-unsigned grid_x(const SpecKernel* k, int n, int T, int batch) {
-  const unsigned tiles = 1u << (n - T);
+// live_mask (over the n - T bits of the tile index): 0xffffffff = one workgroup per tile; else one workgroup per tile whose
+// index is zero outside the mask (the kernel spreads blockIdx.x over the mask's bits)
+unsigned grid_x(const SpecKernel* k, int n, int T, int batch, unsigned live_mask) {
+  unsigned tiles = 1u << (n - T);
+  if (live_mask != 0xffffffffu) tiles = 1u << __builtin_popcount(live_mask & (tiles - 1u));
   if (k->max_workgroups <= 0) return tiles;
   unsigned g = (unsigned)k->max_workgroups / (unsigned)batch;
   if (g < 1u) g = 1u;
@@ -76,7 +79,7 @@ int tcmi_spec_unload(void* handle) {
 }
 
 int tcmi_spec_run_pass(void* handle, void* state, long long state_stride, int batch, int n, int T, int LT,
-                       const void* ctab, const void* ptab, long long ptab_stride, void* stream) {
+                       const void* ctab, const void* ptab, long long ptab_stride, unsigned live_mask, void* stream) {
   if (!handle || !state || batch < 1 || n < T || T <= LT || LT < 6 || LT > 10)
     return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_spec_run_pass: bad argument");
   SpecKernel* k = reinterpret_cast<SpecKernel*>(handle);
@@ -86,17 +89,20 @@ int tcmi_spec_run_pass(void* handle, void* state, long long state_stride, int ba
     const void* ctab;
     const void* ptab;
     long long ptab_stride;
-  } args = {state, state_stride, ctab, ptab, ptab_stride};
+    unsigned live_mask;
+    unsigned pad_;
+  } args = {state, state_stride, ctab, ptab, ptab_stride, live_mask, 0u};
   size_t sz = sizeof(args);
   void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  hipError_t e = hipModuleLaunchKernel(k->fn, grid_x(k, n, T, batch), (unsigned)batch, 1, 1u << LT, 1, 1, (unsigned)k->lds_bytes,
+  hipError_t e = hipModuleLaunchKernel(k->fn, grid_x(k, n, T, batch, live_mask), (unsigned)batch, 1, 1u << LT, 1, 1, (unsigned)k->lds_bytes,
                                        reinterpret_cast<hipStream_t>(stream), nullptr, cfg);
   return e == hipSuccess ? TCMI_OK : hip_fail("tcmi_spec_run_pass", e);
 }
 
 int tcmi_spec_run_adjoint_pass(void* handle, void* psi, void* lam, long long state_stride, int batch, int n, int T, int LT,
                                const void* ctab, const void* ptab, long long ptab_stride, double* gout,
-                               long long gout_stride, int gcopies, long long gcopy_stride, void* stream) {
+                               long long gout_stride, int gcopies, long long gcopy_stride, unsigned live_mask,
+                               void* stream) {
   if (!handle || !psi || !lam || !gout || batch < 1 || n < T || T <= LT || LT < 6 || LT > 10 || gcopies < 1)
     return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_spec_run_adjoint_pass: bad argument");
   SpecKernel* k = reinterpret_cast<SpecKernel*>(handle);
@@ -110,12 +116,12 @@ int tcmi_spec_run_adjoint_pass(void* handle, void* psi, void* lam, long long sta
     double* gout;
     long long gout_stride;
     int gcopies;
-    int pad_;
+    unsigned live_mask;
     long long gcopy_stride;
-  } args = {psi, lam, state_stride, ctab, ptab, ptab_stride, gout, gout_stride, gcopies, 0, gcopy_stride};
+  } args = {psi, lam, state_stride, ctab, ptab, ptab_stride, gout, gout_stride, gcopies, live_mask, gcopy_stride};
   size_t sz = sizeof(args);
   void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  hipError_t e = hipModuleLaunchKernel(k->fn, grid_x(k, n, T, batch), (unsigned)batch, 1, 1u << LT, 1, 1, (unsigned)k->lds_bytes,
+  hipError_t e = hipModuleLaunchKernel(k->fn, grid_x(k, n, T, batch, live_mask), (unsigned)batch, 1, 1u << LT, 1, 1, (unsigned)k->lds_bytes,
                                        reinterpret_cast<hipStream_t>(stream), nullptr, cfg);
   return e == hipSuccess ? TCMI_OK : hip_fail("tcmi_spec_run_adjoint_pass", e);
 }

@@ -158,6 +158,46 @@ def choose_plan(n: int, gates: List[P.GateRec], nparams: int, dtypestr: str, opt
     return n_exec, cfg, plan, gates
 
 
+LIVE_FULL = 0xFFFFFFFF
+SPARSE_START = os.environ.get("TCMI_SPARSE_START", "1") != "0"
+
+
+def live_masks(descs, n: int, start_bits: int = 0, reverse: bool = False):
+    """Which tiles of every pass can hold a non-zero amplitude when the circuit starts from |0...0>.
+
+    An amplitude whose index has a 1 on a physical bit that no pass has had in its tile yet (and that no gate outside the
+    plan touched: ``start_bits``) is exactly zero, and a pass acts inside its tiles (bits outside a tile only enter
+    phases): a tile whose index is non-zero on such a bit is zero before and after the pass.  Per pass: a mask over the
+    COMPACT tile index (bit i = the i-th physical bit outside the tile, ascending) of the bits that may vary,
+    ``LIVE_FULL`` when every tile is live -- the ``live_mask`` of ``tcmi_spec_run_pass / _adjoint_pass``.
+    ``reverse``: the passes are those of a reverse sweep (pass 0 un-does the END of the circuit): the psi entering sweep
+    pass j carries the gates of passes j, j + 1, ... only, and a zero psi tile adds to no gradient slot whatever lambda
+    holds there.  Returns (masks, fractions of live tiles)."""
+    tiles = []
+    for d in descs:
+        w = np.asarray(d).view(np.uint32).astype(np.int64)
+        tiles.append(sum(1 << int(w[8 + i]) for i in range(int(w[2]))))
+    touched_before = []
+    t = start_bits
+    for tb in (reversed(tiles) if reverse else tiles):
+        if reverse:
+            t |= tb                       # psi entering this sweep pass already carries the pass's own gates
+            touched_before.append(t)
+        else:
+            touched_before.append(t)
+            t |= tb
+    if reverse:
+        touched_before.reverse()
+    masks, fracs = [], []
+    for tb, tch in zip(tiles, touched_before):
+        free = [p_ for p_ in range(n) if not (tb >> p_) & 1]
+        m = sum(1 << i for i, p_ in enumerate(free) if (tch >> p_) & 1)
+        full = (1 << len(free)) - 1
+        masks.append(LIVE_FULL if m == full else m)
+        fracs.append(2.0 ** (bin(m).count("1") - len(free)))
+    return masks, fracs
+
+
 def choose_adjoint_plan(gates: List[P.GateRec], n_exec: int, dtypestr: str, full: bool):
     """(cfg, adjoint plan) of the executed gate list, or None when the short sweep has nothing to drop (use the full
     one).  Host work only, deterministic (see choose_plan)."""
@@ -266,26 +306,47 @@ class CompiledCircuit:
                 "tcmi_build_tables",
             )
         item = 8 if self.dtypestr == "complex64" else 16
-        with _timed("pass", len(self.descs), len(self.descs) * 2.0 * B * nel * item):
-            self.run_passes(out, ptab, B, stream)
+        live, units = None, float(len(self.descs))
+        if inputs is None and SPARSE_START and self.cfg.gen >= 2 and self.dtypestr == "complex64":
+            # |0...0> start: the first passes only have a few tiles that can be non-zero (live_masks); the algorithmic
+            # bytes of a pass are those of its live tiles (specialised kernels; an interpreted pass moves every tile)
+            masks, fracs = self.zero_start()
+            if any(m != LIVE_FULL for m in masks):
+                live = masks
+                units = float(sum(f if k is not None else 1.0 for f, k in zip(fracs, self._specialised())))
+        with _timed("pass", len(self.descs), units * 2.0 * B * nel * item):
+            self.run_passes(out, ptab, B, stream, live=live)
         if self.n_exec != self.n and not full:
             return out[:, : 2**self.n]
         return out
 
-    def run_passes(self, state, ptab, B, stream, first=0, last=None):
-        lib = self._lib
-        nel = 2**self.n_exec
+    def _specialised(self):
         spec = [None] * len(self.descs)
         if self.cfg.gen >= 2 and self.dtypestr == "complex64":
             # plan-specialised straight-line kernels where they exist (tcmi/specialize.py); the interpreter otherwise
             if getattr(self, "_spec_fwd", None) is None:
                 self._spec_fwd = S.PassSet("forward", self.plan.descs, self.n_exec)
             spec = self._spec_fwd.get()
-        for d, k in list(zip(self.descs, spec))[first:last]:
+        return spec
+
+    def zero_start(self):
+        """(live masks, live fractions) of the passes for a state that starts from |0...0> (``live_masks``)."""
+        if getattr(self, "_zero_start", None) is None:
+            self._zero_start = live_masks(self.plan.descs, self.n_exec)
+        return self._zero_start
+
+    def run_passes(self, state, ptab, B, stream, first=0, last=None, live=None):
+        """``live``: per-pass live-tile masks (the state is |0...0> before pass 0); the specialised kernels then run on
+        the live tiles only, an interpreted pass runs on all of them (zero tiles stay zero)."""
+        lib = self._lib
+        nel = 2**self.n_exec
+        spec = self._specialised()
+        for i, (d, k) in list(enumerate(zip(self.descs, spec)))[first:last]:
             if k is not None:
                 _lib.check(
                     lib.tcmi_spec_run_pass(k.handle, state.data_ptr(), nel, B, self.n_exec, self.cfg.T, self.cfg.LT,
-                                           self.ctab.data_ptr(), ptab.data_ptr(), ptab.stride(0), stream),
+                                           self.ctab.data_ptr(), ptab.data_ptr(), ptab.stride(0),
+                                           LIVE_FULL if live is None else live[i], stream),
                     "tcmi_spec_run_pass",
                 )
                 continue
@@ -328,19 +389,57 @@ class CompiledCircuit:
             })
         return getattr(self, key)
 
-    def vjp(self, params, psi, g, chunk_bytes=48 << 30, inputs=None, want_input_grad=False, consume=False):
+    def _adjoint_from_zero(self):
+        """The sweep plan for a psi that came from |0...0>, with its live-tile masks: psi is back to a few non-zero tiles
+        in the last sweep passes (``live_masks``), so those run on a handful of workgroups.  The short sweep stops at the
+        state behind the circuit's constant head -- non-zero wherever those gates acted, every pass dense for an ansatz
+        that opens with a Hadamard layer -- so the full gate list is usually the cheaper sweep now; the pass model
+        decides.  Returns (plan record, masks, fractions)."""
+        if getattr(self, "_adj_zero", None) is None:
+            best = None
+            for full in (False, True):
+                adj = self._adjoint(full)
+                if best is not None and adj is best[0]:
+                    continue
+                ngates = sum(1 for _ in self._exec_gates)
+                start = 0
+                if not full:
+                    # qubits touched by the constant head a short plan may leave out (never un-computed; assumed left
+                    # out even where choose_adjoint_plan kept the whole gate list for the short sweep: conservative)
+                    first = next((i for i, g_ in enumerate(self._exec_gates) if P.gate_has_param(g_)), ngates)
+                    for g_ in self._exec_gates[:first]:
+                        for q in g_.qubits:
+                            start |= 1 << (self.n_exec - 1 - q)
+                masks, fracs = live_masks(adj["plan"].descs, self.n_exec, start_bits=start, reverse=True)
+                cost = adj_cost_us(adj["plan"], fracs)
+                if cost is None:
+                    cost = float(sum(fracs))
+                if best is None or cost < best[3]:
+                    best = (adj, masks, fracs, cost)
+            self._adj_zero = best[:3]
+        return self._adj_zero
+
+    def vjp(self, params, psi, g, chunk_bytes=48 << 30, inputs=None, want_input_grad=False, consume=False,
+            from_zero=False):
         """dL/dparams = Re <g | d psi / d params> for every batch row, by the adjoint sweep.
         params [B, P] real, psi / g [B, 2^n_exec] complex (psi = the forward output).  The sweep
         works on copies (psi is un-computed in place), processed in batch chunks to bound memory.
         ``want_input_grad``: also return the cotangent of the input state, U^dagger g = lambda after the whole
         sweep ([B, 2^n_exec]).  ``inputs``: the forward input state (needed only with non-unitary gates, whose
-        segments restart from recomputed checkpoints)."""
+        segments restart from recomputed checkpoints).  ``from_zero``: psi is the state of this plan run from |0...0>
+        (enables the live-tile sweep, ``_adjoint_from_zero``)."""
         import torch
 
         if self.nonunitary:
             return self._vjp_segmented(params, g, inputs, want_input_grad)
         lam_out = torch.empty_like(g) if want_input_grad else None
         adj = self._adjoint(full=want_input_grad)
+        live, lfracs = None, None
+        if (from_zero and SPARSE_START and not want_input_grad and self.dtypestr == "complex64"
+                and getattr(self, "_keep_uncomputed", None) is None):
+            adj0, masks, fracs = self._adjoint_from_zero()
+            if adj0["cfg"].gen == 2 and any(m != LIVE_FULL for m in masks):
+                adj, live, lfracs = adj0, masks, fracs
         lib = self._lib
         B = params.shape[0]
         nel = 2**self.n_exec
@@ -394,7 +493,11 @@ class CompiledCircuit:
                         nd[-1][6] |= P.FLAG_NOSTORE
                     adj[skey] = S.PassSet("adjoint", nd, self.n_exec, S.adjoint_opts(cfg))
                 spec = adj[skey].get()
-            tm = _timed("adjoint", len(descs), (len(descs) * 4.0 - (2.0 if nostore else 0.0)) * nb * nel * item)
+            units = len(descs) * 4.0 - (2.0 if nostore else 0.0)
+            if live is not None:       # algorithmic bytes of the live tiles only (interpreted passes move every tile)
+                units = sum((4.0 if (i < len(descs) - 1 or not nostore) else 2.0) * (lfracs[i] if k is not None else 1.0)
+                            for i, k in enumerate(spec))
+            tm = _timed("adjoint", len(descs), units * nb * nel * item)
             tm.__enter__()
             for ip, (d, k) in enumerate(zip(descs, spec)):
                 if PASS_EVENTS is not None:
@@ -408,7 +511,7 @@ class CompiledCircuit:
                         lib.tcmi_spec_run_adjoint_pass(
                             k.handle, a.data_ptr(), lam.data_ptr(), nel, nb, self.n_exec, cfg.T, cfg.LT,
                             adj["ctab"].data_ptr(), ptab.data_ptr(), ptab.stride(0), gout.data_ptr(), gout.stride(0),
-                            ATOMIC_COPIES, gout.stride(1), stream),
+                            ATOMIC_COPIES, gout.stride(1), LIVE_FULL if live is None else live[ip], stream),
                         "tcmi_spec_run_adjoint_pass",
                     )
                     continue
@@ -825,13 +928,16 @@ JOIN_GEMM = os.environ.get("TCMI_JOIN_GEMM", "split")   # "f32": joins on the ex
 ADJ2_COST = {"floor": 106.0, "g1": 4.2, "flush": 8.1, "exchange": 6.3}
 
 
-def adj_cost_us(ap: "P.AdjointPlan") -> float:
-    """Estimated time of a packed (gen 2) adjoint plan for one state; None for other plans."""
+def adj_cost_us(ap: "P.AdjointPlan", fracs=None) -> float:
+    """Estimated time of a packed (gen 2) adjoint plan for one state; None for other plans.  ``fracs``: fraction of live
+    tiles per pass (``live_masks``)."""
     if ap.cfg.gen < 2:
         return None
     R = ap.cfg.R
     t = 0.0
+    ipass = -1
     for desc in ap.descs:
+        ipass += 1
         d = np.asarray(desc).view(np.uint32).astype(np.int64)
         pc = P.HDR_WORDS
         tp = ADJ2_COST["exchange"] * (int(d[5]) - 1)
@@ -850,7 +956,7 @@ def adj_cost_us(ap: "P.AdjointPlan") -> float:
                 else:
                     return None
             pc = end
-        t += max(ADJ2_COST["floor"], tp)
+        t += max(ADJ2_COST["floor"], tp) * (1.0 if fracs is None else fracs[ipass])
     return t * (2.0 ** ap.n) / 2.0**24
 
 

@@ -81,7 +81,7 @@ def _fns():
         def forward(params, psi, g, cc):
             single = params.dim() == 1
             gp = cc.vjp(params.reshape(-1, params.shape[-1]), psi.reshape(-1, psi.shape[-1]),
-                        g.reshape(-1, g.shape[-1]))
+                        g.reshape(-1, g.shape[-1]), from_zero=True)       # StateFn without inputs: psi came from |0...0>
             return gp[0] if single else gp
 
         @staticmethod

@@ -258,7 +258,7 @@ class TracedVag:
         # with its cotangent, no measurement passes (executor.CompiledMeasure.apply_sum)
         lam, dot = cm.apply_sum(state, w.to(torch.complex128).reshape(1, -1).expand(nb, -1), want_dot=True)
         value = 0.5 * dot + plan["const"]
-        gp = cc.vjp(params, state, lam, consume=True).to(torch.float64)       # [nb, P]; state and lam are ours
+        gp = cc.vjp(params, state, lam, consume=True, from_zero=True).to(torch.float64)   # [nb, P]; state and lam are ours
         gflat = torch.zeros(nb, plan["total"] + plan["consts"].numel(), dtype=torch.float64, device=dev)
         gflat.index_add_(1, plan["index"], gp)
         grads = []

@@ -225,7 +225,15 @@ class _Emitter:
         if self.persistent():
             loop = [f"  for (uint32_t bx = blockIdx.x; bx < {1 << (self.n - self.T)}u; bx += gridDim.x) {{"]
         else:
-            loop = ["  { const uint32_t bx = blockIdx.x;"]
+            # live_mask (kernel argument, over the bits of the tile index): 0xffffffff = every tile has its workgroup; else
+            # the grid holds one workgroup per tile whose index is zero outside the mask -- the tiles that can be non-zero
+            # while some qubits of a circuit started from |0...0> have not been touched yet (executor.live_masks)
+            loop = ["  { uint32_t bx = blockIdx.x;",
+                    "  if (live_mask != 0xffffffffu) {",
+                    "    uint32_t b_ = 0, s_ = bx;",
+                    "    for (uint32_t m_ = live_mask; m_; m_ &= m_ - 1u) { if (s_ & 1u) b_ |= m_ & (0u - m_); s_ >>= 1; }",
+                    "    bx = b_;",
+                    "  }"]
         loop.append(f"  const uint32_t wg_base = {_deposit_expr('bx', pairs)};")
         return pre, loop
 
@@ -632,7 +640,7 @@ class _Forward(_Emitter):
     def source(self, kname: str) -> str:
         NR = self.NR
         params = ("v2f* __restrict__ state, long long state_stride, const float* __restrict__ ctab_g, "
-                  "const float* __restrict__ ptab_g, long long ptab_stride")
+                  "const float* __restrict__ ptab_g, long long ptab_stride, uint32_t live_mask")
         pro = ["  extern __shared__ __attribute__((aligned(16))) char lb_[];",
                "  char LDS_AS* const lb = (char LDS_AS*)lb_;",
                "  state += (long long)blockIdx.y * state_stride;",
@@ -925,8 +933,8 @@ def adjoint_opts(cfg) -> dict:
 
 def precompile_circuit(c, adjoint: bool = True, forward: bool = True) -> dict:
     """Compile (into the cache) the specialised kernels of the plans the executor will choose for circuit ``c``: the
-    forward passes and, with ``adjoint``, the reverse sweep that a traced value_and_grad runs (short sweep, last pass
-    without write-back).  Host work only -- no GPU needed (hipcc cross-compiles)."""
+    forward passes and, with ``adjoint``, the reverse sweeps a value_and_grad may run (short and full gate list, last pass
+    with and without write-back).  Host work only -- no GPU needed (hipcc cross-compiles)."""
     from . import cons
     from . import executor as X
 
@@ -959,7 +967,8 @@ def precompile_circuit(c, adjoint: bool = True, forward: bool = True) -> dict:
                 continue
             descs = [np.asarray(d) for d in ap.descs]
             out = [x is not None for x in prepare("adjoint", descs, adjoint_opts(acfg))]
-            if not full and descs:
+            if descs:      # the sweep of a traced value_and_grad keeps its last tile to itself (either plan: the full one
+                # is the cheaper sweep for a psi that came from |0...0>, executor._adjoint_from_zero)
                 last = descs[-1].copy()
                 last[6] = last[6] | P.FLAG_NOSTORE
                 out.append(prepare("adjoint", [last], adjoint_opts(acfg))[0] is not None)
@@ -1168,13 +1177,13 @@ class _Adjoint(_Forward):
         NR = self.NR
         params = ("v2f* __restrict__ psi, v2f* __restrict__ lam, long long state_stride, const float* __restrict__ ctab_g, "
                   "const float* __restrict__ ptab_g, long long ptab_stride, double* __restrict__ gout, "
-                  "long long gout_stride, int gcopies, int pad_, long long gcopy_stride")
+                  "long long gout_stride, int gcopies, uint32_t live_mask, long long gcopy_stride")
         pro = ["  extern __shared__ __attribute__((aligned(16))) char lb_[];",
                "  char LDS_AS* const lb = (char LDS_AS*)lb_;",
                "  psi += (long long)blockIdx.y * state_stride;",
                "  lam += (long long)blockIdx.y * state_stride;",
                "  gout += (long long)blockIdx.y * gout_stride + (long long)(blockIdx.x % (unsigned)gcopies) * gcopy_stride;",
-               "  const KF ctab = (KF)ctab_g; (void)ctab; (void)pad_;",
+               "  const KF ctab = (KF)ctab_g; (void)ctab; (void)live_mask;",
                "  const KF ptab = (KF)(ptab_g + (long long)blockIdx.y * ptab_stride);"]
         pre, loop = self.index_lines()
         pro += pre
