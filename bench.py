@@ -217,7 +217,31 @@ def vqe_leg(tc, torch, dist, args, rank, world, dev):
     el = time.perf_counter() - t0
     ev = summarize_events(X.EVENT_LOG)
     X.EVENT_LOG = None
+    # the same kernels with every tile live (TCMI_SPARSE_START=0: the dense plan, every pass moves the whole state): what
+    # the pass kernels reach on full passes, next to the step that skips the tiles that are still zero
+    dense = None
+    if X.SPARSE_START and dist is None:      # one rank only: step() holds a collective
+        X.SPARSE_START = False
+        try:
+            vd, gd, _, _ = step()
+            sync()
+            X.EVENT_LOG = []
+            td0 = time.perf_counter()
+            vd, gd, _, _ = step()
+            torch.cuda.synchronize()
+            td = time.perf_counter() - td0
+            evd = summarize_events(X.EVENT_LOG)
+            X.EVENT_LOG = None
+            dense = {"ms_per_step": td * 1e3, "steps": 1,
+                     "forward_pass": hbm_entry("the forward pass kernels, every tile live", evd.get("pass"), 1),
+                     "adjoint_pass": hbm_entry("the reverse-sweep pass kernels, every tile live", evd.get("adjoint"), 1),
+                     "max_abs_energy_difference": float((vd - v).abs().max().item()),
+                     "max_abs_gradient_difference": float((gd - g).abs().max().item())}
+        finally:
+            X.EVENT_LOG = None
+            X.SPARSE_START = True
     if dist is not None:
+        sync()
         tt = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
@@ -273,6 +297,19 @@ def vqe_leg(tc, torch, dist, args, rank, world, dev):
         fl = float(hi - lo) * ngates * (2.0 ** (n - 1)) * flops_per_pair
         return {"bound": "valu", "gate_arithmetic_flops_per_step": fl, "achieved": fl / per_step_s / 1e12,
                 "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s", "frac": fl / per_step_s / 1e12 / MFMA_F32_PEAK_TFS}
+    # live-tile passes (executor.live_masks): a state that starts from |0...0> has few tiles that can be non-zero during its
+    # first passes (and psi is back to that shape in the last passes of the reverse sweep); `frac` above is on the bytes of
+    # the live tiles -- what the sparse-start algorithm has to move -- and `frac_on_dense_plan_bytes` prices the same time
+    # against the bytes of the dense plan (every pass moving the whole state: the round-3 / SURVEY 8d figure)
+    for key, evk, dense_units in (("forward_pass", "pass", 2.0 * nf), ("adjoint_pass", "adjoint", 4.0 * nb_ - 2.0)):
+        ent, e_ = roof.get(key), ev.get(evk)
+        if ent and e_ and e_["launches"]:
+            dense = dense_units * S * max(1, args.vqe_steps) / e_["launches"]
+            ent["dense_plan_bytes_per_launch"] = dense
+            ent["frac_on_dense_plan_bytes"] = dense / (ent["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            ent["live_tile_passes"] = bool(X.SPARSE_START and abs(dense - ent["algorithmic_bytes_per_launch"]) > 1e-6 * dense)
+    if dense is not None:
+        roof["dense_plan"] = dense
     roof["forward_pass_valu"] = _valu("pass", 12.0)
     roof["adjoint_pass_valu"] = _valu("adjoint", 32.0)
     return {

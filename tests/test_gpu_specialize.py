@@ -165,3 +165,51 @@ def test_specialised_kernels_under_vmap_and_jit(tc64):
         out[flag] = (v.cpu().numpy(), g.cpu().numpy())
     assert np.abs(out["0"][0] - out["1"][0]).max() < 1e-5
     assert np.abs(out["0"][1] - out["1"][1]).max() < 5e-6
+
+
+def test_live_tile_passes_equal_the_dense_passes(tc64):
+    """executor.live_masks: a state started from |0...0> runs its first passes -- and the reverse sweep its last ones -- on
+    the tiles that can be non-zero only.  Same kernels with every tile live (TCMI_SPARSE_START=0 semantics): the state is
+    bit-identical, energy and gradient agree to rounding (a zero psi tile that is skipped was zero to 1e-7 only)."""
+    tc = tc64
+    from tcmi import executor as X
+
+    n, d = 20, 4
+    params = np.random.default_rng(n).uniform(0, 2 * np.pi, [2 * d, n])
+
+    def energy(p):
+        c = tc.Circuit(n)
+        W.hea_b(c, n, d, p, zz=tc.gates._zz_matrix)
+        e = 0.0
+        for i in range(n):
+            e += -1.0 * c.expectation((tc.gates.x(), [i]))
+        for i in range(n - 1):
+            e += 1.0 * c.expectation((tc.gates.z(), [i]), (tc.gates.z(), [i + 1]))
+        return tc.backend.real(e)
+
+    os.environ["TCMI_SPECIALIZE"] = "1"
+    tc.set_contractor("plain")
+    old = X.SPARSE_START
+    res = {}
+    try:
+        for flag in (True, False):
+            X.SPARSE_START = flag
+            X._CACHE.clear()
+            pt = tc.backend.convert_to_tensor(params, dtype=tc.rdtypestr)
+            c = tc.Circuit(n)
+            W.hea_b(c, n, d, pt, zz=tc.gates._zz_matrix)
+            cc = c._compiled()
+            if flag:
+                masks, fracs = cc.zero_start()
+                assert any(m != X.LIVE_FULL for m in masks) and min(fracs) < 1e-2
+                _, rmasks, rfracs = cc._adjoint_from_zero()
+                assert any(m != X.LIVE_FULL for m in rmasks) and min(rfracs) < 1e-2
+            psi = tc.backend.numpy(c.wavefunction())
+            v, g = tc.backend.value_and_grad(energy)(pt)
+            res[flag] = (psi, float(v), tc.backend.numpy(g))
+    finally:
+        X.SPARSE_START = old
+        tc.set_contractor("greedy")
+    assert np.array_equal(res[True][0], res[False][0])
+    assert abs(res[True][1] - res[False][1]) < 1e-5
+    assert np.abs(res[True][2] - res[False][2]).max() < 5e-6

@@ -575,3 +575,95 @@ def test_mpo_and_diagonal_gate_formats_through_the_plan_emulator():
         tc.Circuit(12).cmz(*range(11))
     with pytest.raises(NotImplementedError):
         tc.Circuit(4).diagonal(0, 1, 2, diag=np.array([1, 2, 1, 1, 1, 1, 1, 1.0]))
+
+
+def _expand_live(mask, tile_bits, n):
+    """Physical-bit mask of the positions where an amplitude's index may be non-zero: the pass's tile bits plus the bits
+    of the compact tile index that ``mask`` lets vary."""
+    from tcmi import executor as X
+
+    tb = 0
+    for p in tile_bits:
+        tb |= 1 << int(p)
+    if mask == X.LIVE_FULL:
+        return (1 << n) - 1
+    free = [p for p in range(n) if not (tb >> p) & 1]
+    out = tb
+    for i, p in enumerate(free):
+        if (mask >> i) & 1:
+            out |= 1 << p
+    return out
+
+
+def test_live_tile_masks_cover_every_nonzero_amplitude():
+    """executor.live_masks against the pass emulator (oracle/plan_emulator.py): before pass k of a state started from
+    |0...0> every non-zero amplitude sits in a live tile, and in the reverse sweep the psi entering pass j (un-computed
+    pass by pass) is zero outside the live tiles to rounding, so skipping the other tiles drops nothing."""
+    import tcmi as tc
+    from tcmi import executor as X, plan as P
+    from oracle import plan_emulator as E
+
+    tc.set_backend("hip"); tc.set_dtype("complex64")
+    import torch
+
+    n, d = 17, 3
+    rng = np.random.default_rng(2)
+    prm = rng.uniform(0, 2 * np.pi, 2 * d * n)
+    c = tc.templates.blocks.example_block(tc.Circuit(n), torch.tensor(prm), nlayers=d)
+    gates, nparams = c._gate_records(), len(c._params)
+    n_exec, cfg, plan, eg = X.choose_plan(n, gates, nparams, "complex64", None)
+    assert cfg.gen >= 2 and len(plan.descs) >= 2
+    masks, fracs = X.live_masks(plan.descs, n_exec)
+    assert masks[0] == 0 and fracs[0] == 2.0 ** -(n_exec - cfg.T) and masks[-1] == X.LIVE_FULL
+    state = np.zeros(2 ** n_exec, dtype=np.complex128)
+    state[0] = 1.0
+    ptab = E.build_table(plan.ginfo, plan.cpool, prm, plan.ptab_size)[0] if plan.ptab_size else np.zeros(0)
+    idx = np.arange(2 ** n_exec)
+    sparse_seen = 0
+    for k, desc in enumerate(plan.descs):
+        allowed = _expand_live(masks[k], plan.passes[k].tile_bits, n_exec)
+        outside = (idx & ~allowed) != 0
+        assert not np.any(state[outside] != 0), k              # exactly zero: nothing ever touched these amplitudes
+        sparse_seen += int(masks[k] != X.LIVE_FULL)
+        # the pass restricted to its live tiles gives the same state as the pass on all tiles
+        full = state.copy()
+        E.run_pass(full, desc, plan.ctab, ptab)
+        live_only = state.copy()
+        E.run_pass(live_only, desc, plan.ctab, ptab)
+        live_only[outside] = 0.0
+        np.testing.assert_array_equal(full, live_only)
+        state = full
+    assert sparse_seen >= 1
+    # reverse sweep of the whole gate list: psi un-computed pass by pass
+    cfg_a, ap = X.choose_adjoint_plan(eg, n_exec, "complex64", True)
+    rmasks, rfr = X.live_masks(ap.descs, n_exec, reverse=True)
+    assert rmasks[0] == X.LIVE_FULL and rfr[-1] < 1.0
+    for a, b in zip(rfr, rfr[1:]):
+        assert b <= a                                           # the live sets shrink along the sweep
+    psi = state.copy()
+    lam = (rng.normal(size=psi.shape) + 1j * rng.normal(size=psi.shape))
+    ptab_a = E.build_adjoint_table(ap.ginfo, ap.cpool, prm, ap.ptab_size)[0] if ap.ptab_size else np.zeros(0)
+    gout = np.zeros(max(1, len(ap.gslot_param)))
+    gout_live = np.zeros_like(gout)
+    psi2, lam2 = psi.copy(), lam.copy()
+    for j, desc in enumerate(ap.descs):
+        allowed = _expand_live(rmasks[j], ap.passes[j].tile_bits, n_exec)
+        outside = (idx & ~allowed) != 0
+        assert np.abs(psi[outside]).max(initial=0.0) < 1e-12, j    # un-computed to rounding
+        E.run_adjoint_pass(psi, lam, desc, ap.ctab, ptab_a, gout)
+        # the live-tile sweep: tiles outside never enter (psi there counts as zero, lambda there is never needed again)
+        psi2[outside] = 0.0
+        lam2[outside] = 0.0
+        E.run_adjoint_pass(psi2, lam2, desc, ap.ctab, ptab_a, gout_live)
+    np.testing.assert_allclose(gout_live, gout, atol=1e-10)
+    # a short sweep that leaves the constant head out ends on a dense state: its start bits switch the masks off
+    first = next(i for i, g_ in enumerate(eg) if P.gate_has_param(g_))
+    start = 0
+    for g_ in eg[:first]:
+        for q in g_.qubits:
+            start |= 1 << (n_exec - 1 - q)
+    if start == (1 << n_exec) - 1:
+        r = X.choose_adjoint_plan(eg, n_exec, "complex64", False)
+        if r is not None:
+            m2, _ = X.live_masks(r[1].descs, n_exec, start_bits=start, reverse=True)
+            assert all(m == X.LIVE_FULL for m in m2)
