@@ -304,10 +304,10 @@ def vqe_leg(tc, torch, dist, args, rank, world, dev):
     for key, evk, dense_units in (("forward_pass", "pass", 2.0 * nf), ("adjoint_pass", "adjoint", 4.0 * nb_ - 2.0)):
         ent, e_ = roof.get(key), ev.get(evk)
         if ent and e_ and e_["launches"]:
-            dense = dense_units * S * max(1, args.vqe_steps) / e_["launches"]
-            ent["dense_plan_bytes_per_launch"] = dense
-            ent["frac_on_dense_plan_bytes"] = dense / (ent["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
-            ent["live_tile_passes"] = bool(X.SPARSE_START and abs(dense - ent["algorithmic_bytes_per_launch"]) > 1e-6 * dense)
+            dbytes = dense_units * S * max(1, args.vqe_steps) / e_["launches"]
+            ent["dense_plan_bytes_per_launch"] = dbytes
+            ent["frac_on_dense_plan_bytes"] = dbytes / (ent["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            ent["live_tile_passes"] = bool(X.SPARSE_START and abs(dbytes - ent["algorithmic_bytes_per_launch"]) > 1e-6 * dbytes)
     if dense is not None:
         roof["dense_plan"] = dense
     roof["forward_pass_valu"] = _valu("pass", 12.0)
