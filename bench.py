@@ -299,14 +299,13 @@ def vqe_leg(tc, torch, dist, args, rank, world, dev):
                 "peak": MFMA_F32_PEAK_TFS, "unit": "TFLOP/s", "frac": fl / per_step_s / 1e12 / MFMA_F32_PEAK_TFS}
     # live-tile passes (executor.live_masks): a state that starts from |0...0> has few tiles that can be non-zero during its
     # first passes (and psi is back to that shape in the last passes of the reverse sweep); `frac` above is on the bytes of
-    # the live tiles -- what the sparse-start algorithm has to move -- and `frac_on_dense_plan_bytes` prices the same time
-    # against the bytes of the dense plan (every pass moving the whole state: the round-3 / SURVEY 8d figure)
+    # the live tiles -- what the sparse-start algorithm has to move; `dense_plan_bytes_per_launch` = what the same passes
+    # move with every tile live (measured in the `dense_plan` block below)
     for key, evk, dense_units in (("forward_pass", "pass", 2.0 * nf), ("adjoint_pass", "adjoint", 4.0 * nb_ - 2.0)):
         ent, e_ = roof.get(key), ev.get(evk)
         if ent and e_ and e_["launches"]:
             dbytes = dense_units * S * max(1, args.vqe_steps) / e_["launches"]
             ent["dense_plan_bytes_per_launch"] = dbytes
-            ent["frac_on_dense_plan_bytes"] = dbytes / (ent["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
             ent["live_tile_passes"] = bool(X.SPARSE_START and abs(dbytes - ent["algorithmic_bytes_per_launch"]) > 1e-6 * dbytes)
     if dense is not None:
         roof["dense_plan"] = dense

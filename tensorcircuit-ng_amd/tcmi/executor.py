@@ -136,6 +136,11 @@ def _shift_gate(g: P.GateRec, pad: int) -> P.GateRec:
     return P.GateRec(tuple(q + pad for q in g.qubits), g.c0, g.c1, g.c2, g.param, diag, g.name)
 
 
+LIVE_FULL = 0xFFFFFFFF
+SPARSE_START = os.environ.get("TCMI_SPARSE_START", "1") != "0"
+LIVE_PLAN = SPARSE_START and os.environ.get("TCMI_LIVE_PLAN", "1") != "0"    # plans chosen by the cost of their live tiles
+
+
 def choose_plan(n: int, gates: List[P.GateRec], nparams: int, dtypestr: str, opts: Optional[dict] = None):
     """(n_exec, cfg, plan, executed gate list) of a circuit: host work only (no device), deterministic -- also used to
     pre-compile the plan-specialised kernels of a known workload (tcmi/specialize.py, __graft_entry__.build)."""
@@ -147,19 +152,21 @@ def choose_plan(n: int, gates: List[P.GateRec], nparams: int, dtypestr: str, opt
     if cfg.gen >= 2 and "lowbits" not in (opts or {}) and n_exec >= 20 and len(gates) >= 64:
         # the greedy tile growth is sensitive to how many low bits are pinned and to how equal gains are broken (8 - 11
         # passes, differently balanced, at n = 28 d = 12): compile the neighbours too and keep the plan the pass model
-        # likes best
-        best = vm_cost_us(plan)
+        # likes best.  The model prices a pass on its live tiles (live_masks: the plan is for a state that starts from
+        # |0...0>, the case that matters; with an input state every tile is live and the pick is a few per cent off)
+        def cost(pl):
+            return vm_cost_us(pl, live_masks(pl.descs, n_exec)[1] if LIVE_PLAN else None)
+
+        best = cost(plan)
         for lb, tb in ((6, 0), (4, 0), (4, 1), (5, 1), (6, 1)):
             cfg2 = dataclasses.replace(cfg, lowbits=lb, tiebreak=tb)
             plan2 = P.compile_plan(gates, n_exec, cfg2, nparams=nparams)
-            c2 = vm_cost_us(plan2)
+            c2 = cost(plan2)
             if c2 < best * 0.995:
                 best, plan, cfg = c2, plan2, cfg2
     return n_exec, cfg, plan, gates
 
 
-LIVE_FULL = 0xFFFFFFFF
-SPARSE_START = os.environ.get("TCMI_SPARSE_START", "1") != "0"
 
 
 def live_masks(descs, n: int, start_bits: int = 0, reverse: bool = False):
@@ -198,9 +205,11 @@ def live_masks(descs, n: int, start_bits: int = 0, reverse: bool = False):
     return masks, fracs
 
 
-def choose_adjoint_plan(gates: List[P.GateRec], n_exec: int, dtypestr: str, full: bool):
+def choose_adjoint_plan(gates: List[P.GateRec], n_exec: int, dtypestr: str, full: bool, zero_start: bool = False):
     """(cfg, adjoint plan) of the executed gate list, or None when the short sweep has nothing to drop (use the full
-    one).  Host work only, deterministic (see choose_plan)."""
+    one).  Host work only, deterministic (see choose_plan).  ``zero_start`` (with ``full``): the sweep un-computes a psi
+    that came from |0...0> -- candidates are priced on their live tiles (live_masks), and tiles of 8-amplitude runs are
+    candidates too (the passes that stay dense are bound by VALU issue, not by how HBM likes its bursts)."""
     cfg = pick_adjoint_variant(n_exec, dtypestr, gates)
     if not full and not (gates and not P.gate_has_param(gates[0]) and any(P.gate_has_param(g) for g in gates)):
         return None
@@ -208,15 +217,20 @@ def choose_adjoint_plan(gates: List[P.GateRec], n_exec: int, dtypestr: str, full
     if cfg.gen >= 2 and n_exec >= 20 and len(gates) >= 64:
         # the greedy schedule is sensitive to the pinned low bits and (short sweep) to the dropped gates: compile
         # the neighbours and keep what the pass model likes best; the short sweep may keep the full gate list
-        best = adj_cost_us(ap)
+        live = zero_start and full and LIVE_PLAN
+
+        def adj_cost(a):
+            return adj_cost_us(a, live_masks(a.descs, n_exec, reverse=True)[1] if live else None)
+
+        best = adj_cost(ap)
         for drop in ((True, False) if not full else (False,)):
-            for lb, tb in ((5, 0), (4, 0), (4, 1), (5, 1)):
+            for lb, tb in ((5, 0), (4, 0), (4, 1), (5, 1)) + (((3, 0), (3, 1)) if live else ()):
                 if best is None or ((lb, tb) == (cfg.lowbits, cfg.tiebreak) and drop == (not full)) \
                         or (drop is False and not full and (lb, tb) != (4, 1)):
                     continue
                 cfg2 = dataclasses.replace(cfg, lowbits=lb, tiebreak=tb, pass_cap=None)
                 ap2 = P.compile_adjoint_plan(gates, n_exec, cfg2, factorized=True, drop_constant_head=drop)
-                c2 = adj_cost_us(ap2)
+                c2 = adj_cost(ap2)
                 if c2 is not None and c2 < best * 0.995:
                     best, ap, cfg = c2, ap2, cfg2
     return cfg, ap
@@ -363,15 +377,16 @@ class CompiledCircuit:
         return self.plan.stats(item)
 
     # ---- reverse mode ------------------------------------------------------------------------
-    def _adjoint(self, full: bool = True):
+    def _adjoint(self, full: bool = True, zero_start: bool = False):
         """Adjoint-sweep plan (compiled lazily, own tile config: two vectors live in registers).  ``full=False``: the
         sweep may stop before the constant gates that open the circuit (no gradient slot behind them); the full plan is
-        the one that also returns the input-state cotangent."""
+        the one that also returns the input-state cotangent.  ``zero_start``: the full gate list, chosen for a psi that
+        came from |0...0> (choose_adjoint_plan)."""
         import torch
 
-        key = "_adj" if full else "_adj_short"
+        key = "_adj_zero_plan" if zero_start else ("_adj" if full else "_adj_short")
         if getattr(self, key, None) is None:
-            res = choose_adjoint_plan(self._exec_gates, self.n_exec, self.dtypestr, full)
+            res = choose_adjoint_plan(self._exec_gates, self.n_exec, self.dtypestr, full or zero_start, zero_start)
             if res is None:
                 self._adj_short = self._adjoint(True)      # nothing to drop
                 return self._adj_short
@@ -398,7 +413,7 @@ class CompiledCircuit:
         if getattr(self, "_adj_zero", None) is None:
             best = None
             for full in (False, True):
-                adj = self._adjoint(full)
+                adj = self._adjoint(full, zero_start=full)
                 if best is not None and adj is best[0]:
                     continue
                 ngates = sum(1 for _ in self._exec_gates)
@@ -960,12 +975,13 @@ def adj_cost_us(ap: "P.AdjointPlan", fracs=None) -> float:
     return t * (2.0 ** ap.n) / 2.0**24
 
 
-def vm_cost_us(plan: "P.CompiledPlan") -> float:
-    """Estimated time of a tile-VM plan for one state (linear op-count model)."""
+def vm_cost_us(plan: "P.CompiledPlan", fracs=None) -> float:
+    """Estimated time of a tile-VM plan for one state (linear op-count model).  ``fracs``: fraction of live tiles per pass
+    (``live_masks``; packed plans only)."""
     t = 0.0
     gen2 = getattr(plan.cfg, "gen", 1) >= 2 if hasattr(plan, "cfg") else False
     if gen2:
-        for desc in plan.descs:
+        for ipass, desc in enumerate(plan.descs):
             d = np.asarray(desc).view(np.uint32).astype(np.int64)
             pc = P.HDR_WORDS
             tp = VM2_COST["fixed"] + VM2_COST["exchange"] * (int(d[5]) - 1)
@@ -990,7 +1006,7 @@ def vm_cost_us(plan: "P.CompiledPlan") -> float:
                     else:
                         raise ValueError(op)
                 pc = q
-            t += max(VM2_COST["floor"], tp)
+            t += max(VM2_COST["floor"], tp) * (1.0 if fracs is None else fracs[ipass])
         return t * (2.0 ** plan.n) / 2.0**24
     for pp, desc in zip(plan.passes, plan.descs):
         d = np.asarray(desc).view(np.uint32).astype(np.int64)

@@ -958,8 +958,8 @@ def precompile_circuit(c, adjoint: bool = True, forward: bool = True) -> dict:
                     if hcfg.gen >= 2:
                         res["cut_halves"] += [r is not None for r in prepare("forward", hplan.descs)]
     if adjoint and "adjoint" in _EMITTERS:
-        for full in (False, True):
-            r = X.choose_adjoint_plan(eg, n_exec, cons.dtypestr, full)
+        for full, zero in ((False, False), (True, False), (True, True)):
+            r = X.choose_adjoint_plan(eg, n_exec, cons.dtypestr, full, zero)    # zero: the sweep of a psi from |0...0>
             if r is None:
                 continue
             acfg, ap = r
@@ -972,7 +972,7 @@ def precompile_circuit(c, adjoint: bool = True, forward: bool = True) -> dict:
                 last = descs[-1].copy()
                 last[6] = last[6] | P.FLAG_NOSTORE
                 out.append(prepare("adjoint", [last], adjoint_opts(acfg))[0] is not None)
-            res["adjoint" if not full else "adjoint_full"] = out
+            res["adjoint" if not full else ("adjoint_zero_start" if zero else "adjoint_full")] = out
     return res
 
 
