@@ -309,8 +309,10 @@ def vqe_leg(tc, torch, dist, args, rank, world, dev):
             ent["live_tile_passes"] = bool(X.SPARSE_START and abs(dbytes - ent["algorithmic_bytes_per_launch"]) > 1e-6 * dbytes)
     if dense is not None:
         roof["dense_plan"] = dense
-    roof["forward_pass_valu"] = _valu("pass", 12.0)
-    roof["adjoint_pass_valu"] = _valu("adjoint", 32.0)
+    # (the count assumes every gate acts on the whole state: only meaningful when every tile is live)
+    live_on = bool(roof.get("forward_pass") and roof["forward_pass"].get("live_tile_passes"))
+    roof["forward_pass_valu"] = None if live_on else _valu("pass", 12.0)
+    roof["adjoint_pass_valu"] = None if live_on else _valu("adjoint", 32.0)
     return {
         "roofline": roof,
         "workload": f"HEA-B n={n} depth={d} TFIM value_and_grad (55-term style energy), vmap batch {Bg} "

@@ -19,16 +19,23 @@ L = [f"Final captures {tag} (MI355X, one GPU), all from the binary of the last c
      f"{tag}_bench_default_under_rocprof.json     the same command under rocprofv3 --kernel-trace --stats (program directly after --)",
      f"{tag}_bench_default_kernel_stats.csv       rocprofv3 kernel stats of that run (all legs: launches of different batch sizes share a row)",
      f"{tag}_headline_kernel_stats.csv            rocprofv3 kernel stats of the timed region of config 2 only (bench.py --probe-child --steps 20",
-     "                                          --warmup 3): every join-GEMM launch (cgemm_dma128_kernel) is a batch-8 join",
+     "                                          --warmup 3): every join-GEMM launch (cgemm_split_kernel / cgemm_dma128_kernel) is a batch-8 join",
      f"{tag}_vqe_n28_d12_pmc.txt                  rocprofv3 --pmc passes (4 separate runs) over scripts/gpu_vqe_timing.py 28,12,1, per-dispatch averages", ""]
 r = d["roofline"]
 L.append(f"Config 2 headline ({d['config']['plan'].get('contraction')} order), dominant kernel {r.get('kernel')}:")
 if r.get("bound") == "mfma":
-    g = find(hs, "cgemm_dma128_kernel") or find(hs, "cgemm_dma_kernel") or find(hs, "cgemm_mfma_kernel<true>")
-    L.append(f"  HIP events (bench line):   {r['avg_launch_us']:.1f} us per launch -> executed flops {r['executed_flops_per_launch']:.4g} / t = {r['achieved']:.1f} TF = {r['frac']:.3f} of 157.3 TF (algorithmic, 8 flops per MAC: {r['algorithmic_frac']:.3f})")
+    g = find(hs, "cgemm_split_kernel") or find(hs, "cgemm_dma128_kernel") or find(hs, "cgemm_dma_kernel") or find(hs, "cgemm_mfma_kernel<true>")
+    pk = r["peak"]
+    pipe = "bf16 MFMA peak, 36 executed flops per complex MAC" if pk > 1000 else "f32 MFMA peak, 6 executed flops per complex MAC"
+    L.append(f"  HIP events (bench line):   {r['avg_launch_us']:.1f} us per launch -> executed flops {r['executed_flops_per_launch']:.4g} / t = {r['achieved']:.1f} TF = {r['frac']:.3f} of {pk:.1f} TF ({pipe}); "
+             f"on 8 flops per MAC: {r['algorithmic_achieved']:.1f} TF = {r['algorithmic_frac']:.3f} of the 157.3 TF f32 MFMA peak")
     if g:
         tf = r["executed_flops_per_launch"] / float(g["AverageNs"]) * 1e9 / 1e12
-        L.append(f"  rocprofv3 (headline csv):  {float(g['AverageNs'])/1e3:.1f} us average over {g['Calls']} calls (min {float(g['MinNs'])/1e3:.1f}) -> {tf:.1f} TF = {tf/157.3:.3f}")
+        L.append(f"  rocprofv3 (headline csv):  {float(g['AverageNs'])/1e3:.1f} us average over {g['Calls']} calls (min {float(g['MinNs'])/1e3:.1f}) -> {tf:.1f} TF = {tf/pk:.3f}")
+    j = d.get("join_on_f32_mfma")
+    if j:
+        L.append(f"  the same step with the join on the exact-f32 MFMA kernel: {j['amplitudes_per_s']:.4g} amplitudes/s, {j['ms_per_step']:.3f} ms per step; "
+                 f"largest difference of the two states {j['max_abs_difference_of_the_two_states']:.2e} at amplitudes up to {j['largest_amplitude']:.2e}")
     if r.get("traffic"):
         L.append(f"  PMC traffic (bench line):  {r['traffic']/1e9:.3f} GB per launch ((2 FETCH + WRITE) KiB) vs {r['algorithmic_bytes_per_launch']/1e9:.3f} GB algorithmic")
 L.append(f"  value {d['value']:.4g} amplitudes/s, {d['ms_per_step']:.3f} ms per step; batch 1: {d['latency_batch1']['ms_per_state']:.3f} ms per state")
@@ -43,8 +50,14 @@ for k in ("forward_pass", "adjoint_pass", "measure_pass", "pauli_sum"):
     L.append(f"  {k:13s} {x['kernel']:66s} {x['launches_per_step']:.0f} launches/step, {x['avg_launch_us']/1e3:.2f} ms each, {x['algorithmic_bytes_per_launch']/1e9:.1f} GB algorithmic -> {x['achieved']:.0f} GB/s = {x['frac']:.3f} of 8 TB/s")
 for k in ("forward_pass_valu", "adjoint_pass_valu"):
     x = vr.get(k)
-    if x:
+    if x and not vr.get("dense_plan"):     # the count assumes every gate acts on the whole state: meaningless with live-tile passes
         L.append(f"  {k:18s} gate arithmetic alone {x['gate_arithmetic_flops_per_step']/1e12:.1f} Tflop per step -> {x['achieved']:.1f} TF = {x['frac']:.3f} of the 157.3 TF FP32 vector peak")
+dp = vr.get("dense_plan")
+if dp:
+    L.append(f"  live-tile passes are on (bytes above = bytes of the live tiles).  The same kernels with every tile live (one step, TCMI_SPARSE_START=0 semantics): "
+             f"{dp['ms_per_step']:.0f} ms per step; forward {dp['forward_pass']['avg_launch_us']/1e3:.2f} ms per launch = {dp['forward_pass']['frac']:.3f} of 8 TB/s, "
+             f"sweep {dp['adjoint_pass']['avg_launch_us']/1e3:.2f} ms per launch = {dp['adjoint_pass']['frac']:.3f}; "
+             f"energy difference {dp['max_abs_energy_difference']:.1e}, largest gradient difference {dp['max_abs_gradient_difference']:.1e}")
 x = vr["step"]
 L.append(f"  step: executed bytes {x['executed_bytes_per_step']/1e12:.2f} TB / wall -> {x['achieved']:.0f} GB/s = {x['frac']:.3f}; kernel time {x['kernel_ms_per_step']:.0f} ms of {v['ms_per_step']:.0f}; {x['forward_passes']:.0f} forward / {x['adjoint_passes']:.0f} adjoint passes")
 for sub, name in (("tcmi_spec_forward", "tcmi_spec_forward"), ("tcmi_spec_adjoint", "tcmi_spec_adjoint"),
