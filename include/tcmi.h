@@ -285,9 +285,13 @@ int tcmi_spec_set_grid(void* handle, int max_workgroups);
  * the mask get a workgroup.  A circuit started from |0...0> leaves every amplitude whose index has a 1 on a qubit no pass
  * has had in its tile yet exactly zero, and a pass acts inside its tiles: those tiles are zero before and after it, so
  * the first passes of a state (and the last passes of the reverse sweep, where psi is back to that shape and a zero psi
- * tile contributes to no gradient) run on the few tiles that can be non-zero (tcmi/executor.py live_masks). */
+ * tile contributes to no gradient) run on the few tiles that can be non-zero (tcmi/executor.py live_masks).
+ * `zero_bits` (forward pass; physical index bits inside the tile, 0 = none): amplitudes whose index has one of these bits
+ * set are zero for the same reason and are not read -- they need not even have been written: a state whose passes are
+ * all launched this way needs no zero fill, only its amplitude 0 set to 1 (CompiledCircuit.zero_start). */
 int tcmi_spec_run_pass(void* handle, void* state, long long state_stride, int batch, int n, int T, int LT,
-                       const void* ctab, const void* ptab, long long ptab_stride, unsigned live_mask, void* stream);
+                       const void* ctab, const void* ptab, long long ptab_stride, unsigned live_mask, unsigned zero_bits,
+                       void* stream);
 int tcmi_spec_run_adjoint_pass(void* handle, void* psi, void* lam, long long state_stride, int batch, int n, int T,
                                int LT, const void* ctab, const void* ptab, long long ptab_stride, double* gout,
                                long long gout_stride, int gcopies, long long gcopy_stride, unsigned live_mask,

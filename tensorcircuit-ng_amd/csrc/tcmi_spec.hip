@@ -79,7 +79,8 @@ int tcmi_spec_unload(void* handle) {
 }
 
 int tcmi_spec_run_pass(void* handle, void* state, long long state_stride, int batch, int n, int T, int LT,
-                       const void* ctab, const void* ptab, long long ptab_stride, unsigned live_mask, void* stream) {
+                       const void* ctab, const void* ptab, long long ptab_stride, unsigned live_mask, unsigned zero_bits,
+                       void* stream) {
   if (!handle || !state || batch < 1 || n < T || T <= LT || LT < 6 || LT > 10)
     return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_spec_run_pass: bad argument");
   SpecKernel* k = reinterpret_cast<SpecKernel*>(handle);
@@ -90,8 +91,8 @@ int tcmi_spec_run_pass(void* handle, void* state, long long state_stride, int ba
     const void* ptab;
     long long ptab_stride;
     unsigned live_mask;
-    unsigned pad_;
-  } args = {state, state_stride, ctab, ptab, ptab_stride, live_mask, 0u};
+    unsigned zero_bits;
+  } args = {state, state_stride, ctab, ptab, ptab_stride, live_mask, zero_bits};
   size_t sz = sizeof(args);
   void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   hipError_t e = hipModuleLaunchKernel(k->fn, grid_x(k, n, T, batch, live_mask), (unsigned)batch, 1, 1u << LT, 1, 1, (unsigned)k->lds_bytes,

@@ -141,7 +141,7 @@ _SIGNATURES = {
     "tcmi_spec_run_pass": (
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_uint, ctypes.c_void_p],
+         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p],
     ),
     "tcmi_spec_run_adjoint_pass": (
         ctypes.c_int,

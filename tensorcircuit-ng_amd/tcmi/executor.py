@@ -139,6 +139,7 @@ def _shift_gate(g: P.GateRec, pad: int) -> P.GateRec:
 LIVE_FULL = 0xFFFFFFFF
 SPARSE_START = os.environ.get("TCMI_SPARSE_START", "1") != "0"
 LIVE_PLAN = SPARSE_START and os.environ.get("TCMI_LIVE_PLAN", "1") != "0"    # plans chosen by the cost of their live tiles
+NO_ZERO_FILL = os.environ.get("TCMI_NO_ZERO_FILL", "1") != "0"   # |0...0> start without the zero fill (CompiledCircuit.zero_bits)
 
 
 def choose_plan(n: int, gates: List[P.GateRec], nparams: int, dtypestr: str, opts: Optional[dict] = None):
@@ -299,7 +300,15 @@ class CompiledCircuit:
                 out = inp
             else:
                 out = torch.empty(B, nel, dtype=self.tdtype, device=self.device)
-        if inputs is None:
+        sparse = inputs is None and SPARSE_START and self.cfg.gen >= 2 and self.dtypestr == "complex64"
+        zbits = rfr = None
+        if sparse and NO_ZERO_FILL and all(k is not None for k in self._specialised()):
+            zb, rf, covered = self.zero_bits()
+            if covered:
+                zbits, rfr = zb, rf
+        if inputs is None and zbits is not None:
+            out[:, 0] = 1.0           # everything else the passes read, earlier passes have written (zero_bits())
+        elif inputs is None:
             _lib.check(
                 lib.tcmi_init_zero_state(out.data_ptr(), nel, B, self.n_exec, self.code, stream),
                 "tcmi_init_zero_state",
@@ -320,16 +329,18 @@ class CompiledCircuit:
                 "tcmi_build_tables",
             )
         item = 8 if self.dtypestr == "complex64" else 16
-        live, units = None, float(len(self.descs))
-        if inputs is None and SPARSE_START and self.cfg.gen >= 2 and self.dtypestr == "complex64":
+        live, units = None, 2.0 * len(self.descs)
+        if sparse:
             # |0...0> start: the first passes only have a few tiles that can be non-zero (live_masks); the algorithmic
-            # bytes of a pass are those of its live tiles (specialised kernels; an interpreted pass moves every tile)
+            # bytes of a pass are those of its live tiles (specialised kernels; an interpreted pass moves every tile),
+            # written whole and read as far as they can be non-zero (zero_bits)
             masks, fracs = self.zero_start()
-            if any(m != LIVE_FULL for m in masks):
+            if any(m != LIVE_FULL for m in masks) or zbits is not None:
                 live = masks
-                units = float(sum(f if k is not None else 1.0 for f, k in zip(fracs, self._specialised())))
-        with _timed("pass", len(self.descs), units * 2.0 * B * nel * item):
-            self.run_passes(out, ptab, B, stream, live=live)
+                units = float(sum((f * (1.0 + (rfr[i] if rfr is not None else 1.0))) if k is not None else 2.0
+                                  for i, (f, k) in enumerate(zip(fracs, self._specialised()))))
+        with _timed("pass", len(self.descs), units * B * nel * item):
+            self.run_passes(out, ptab, B, stream, live=live, zbits=zbits)
         if self.n_exec != self.n and not full:
             return out[:, : 2**self.n]
         return out
@@ -349,9 +360,29 @@ class CompiledCircuit:
             self._zero_start = live_masks(self.plan.descs, self.n_exec)
         return self._zero_start
 
-    def run_passes(self, state, ptab, B, stream, first=0, last=None, live=None):
+    def zero_bits(self):
+        """(per-pass ``zero_bits`` of tcmi_spec_run_pass, fraction of a live tile that is read, every bit covered?):
+        the physical bits INSIDE pass k's tile that no earlier pass had in its tile -- amplitudes with one of them set are
+        still zero when pass k loads its tile, so they are not read.  Pass k's live tiles are written whole, and they are
+        exactly the amplitudes pass k + 1 reads: a state whose passes all run this way never reads an amplitude that was
+        not written, i.e. it needs no zero fill -- provided the tiles cover every bit (else amplitudes nobody ever wrote
+        would be left in the result)."""
+        if getattr(self, "_zero_bits", None) is None:
+            touched, zb, rf = 0, [], []
+            for d in self.plan.descs:
+                w = np.asarray(d).view(np.uint32).astype(np.int64)
+                tb = sum(1 << int(w[8 + i]) for i in range(int(w[2])))
+                u = tb & ~touched
+                zb.append(u)
+                rf.append(2.0 ** -bin(u).count("1"))
+                touched |= tb
+            self._zero_bits = (zb, rf, touched == (1 << self.n_exec) - 1)
+        return self._zero_bits
+
+    def run_passes(self, state, ptab, B, stream, first=0, last=None, live=None, zbits=None):
         """``live``: per-pass live-tile masks (the state is |0...0> before pass 0); the specialised kernels then run on
-        the live tiles only, an interpreted pass runs on all of them (zero tiles stay zero)."""
+        the live tiles only, an interpreted pass runs on all of them (zero tiles stay zero).  ``zbits``: per-pass
+        ``zero_bits`` (amplitudes that are not read, see zero_bits())."""
         lib = self._lib
         nel = 2**self.n_exec
         spec = self._specialised()
@@ -360,7 +391,8 @@ class CompiledCircuit:
                 _lib.check(
                     lib.tcmi_spec_run_pass(k.handle, state.data_ptr(), nel, B, self.n_exec, self.cfg.T, self.cfg.LT,
                                            self.ctab.data_ptr(), ptab.data_ptr(), ptab.stride(0),
-                                           LIVE_FULL if live is None else live[i], stream),
+                                           LIVE_FULL if live is None else live[i], 0 if zbits is None else zbits[i],
+                                           stream),
                     "tcmi_spec_run_pass",
                 )
                 continue

@@ -290,7 +290,14 @@ class _Emitter:
                     v = self.fresh("lv")
                     ld = (f"__builtin_nontemporal_load(reinterpret_cast<const v4f*>({addr}))" if self.opts.get("ntl")
                           else f"*reinterpret_cast<const v4f*>({addr})")
-                    out.append(f"  const v4f {v} = {ld};")
+                    if self.opts.get("umask_arg"):
+                        # umask (kernel argument, physical bits inside the tile): amplitudes whose index has one of these
+                        # bits set are known to be zero (no pass has touched the qubit yet, executor.zero_start) and may
+                        # never have been written: they are not read
+                        out.append(f"  v4f {v} = {{0.f, 0.f, 0.f, 0.f}};")
+                        out.append(f"  if (((({c >> 3:#x}u | {tphys}) & umask) == 0u)) {{ {v} = {ld}; if (umask & 1u) {{ {v}.z = 0.f; {v}.w = 0.f; }} }}")
+                    else:
+                        out.append(f"  const v4f {v} = {ld};")
                     out.append(f"  {self.A(r, vec)} = {v}.xy; {self.A(r + 1, vec)} = {v}.zw;")
 
     # ---- LDS exchange --------------------------------------------------------------------------------
@@ -640,7 +647,8 @@ class _Forward(_Emitter):
     def source(self, kname: str) -> str:
         NR = self.NR
         params = ("v2f* __restrict__ state, long long state_stride, const float* __restrict__ ctab_g, "
-                  "const float* __restrict__ ptab_g, long long ptab_stride, uint32_t live_mask")
+                  "const float* __restrict__ ptab_g, long long ptab_stride, uint32_t live_mask, uint32_t umask")
+        self.opts["umask_arg"] = 1
         pro = ["  extern __shared__ __attribute__((aligned(16))) char lb_[];",
                "  char LDS_AS* const lb = (char LDS_AS*)lb_;",
                "  state += (long long)blockIdx.y * state_stride;",

@@ -634,6 +634,25 @@ def test_live_tile_masks_cover_every_nonzero_amplitude():
         np.testing.assert_array_equal(full, live_only)
         state = full
     assert sparse_seen >= 1
+    # no zero fill (CompiledCircuit.zero_bits): memory starts as garbage with amplitude 0 = 1; a pass reads the
+    # amplitudes of its live tiles that have no not-yet-touched bit set and writes its live tiles whole -- it never reads
+    # garbage and the final state is complete
+    touched, mem = 0, np.full(2 ** n_exec, np.nan + 0j)
+    mem[0] = 1.0
+    for k, desc in enumerate(plan.descs):
+        tb = 0
+        for p_ in plan.passes[k].tile_bits:
+            tb |= 1 << int(p_)
+        zb = tb & ~touched
+        live = (idx & ~_expand_live(masks[k], plan.passes[k].tile_bits, n_exec)) == 0
+        read = live & ((idx & zb) == 0)
+        assert not np.isnan(mem[read]).any(), k
+        work = np.where(read, mem, 0.0)
+        E.run_pass(work, desc, plan.ctab, ptab)
+        mem = np.where(live, work, mem)
+        touched |= tb
+    assert touched == (1 << n_exec) - 1
+    np.testing.assert_array_equal(mem, state)
     # reverse sweep of the whole gate list: psi un-computed pass by pass
     cfg_a, ap = X.choose_adjoint_plan(eg, n_exec, "complex64", True)
     rmasks, rfr = X.live_masks(ap.descs, n_exec, reverse=True)
