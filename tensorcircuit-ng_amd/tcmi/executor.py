@@ -967,6 +967,7 @@ VM_COST = {"pass": 19.5, "g1": 2.25, "g2": 9.0, "diag": 11.5, "exchange": 10.75}
 # a pass costs max(HBM floor, fixed + gates + phase tables + exchanges), microseconds per 2^24 amplitudes
 VM2_COST = {"floor": 52.0, "fixed": 16.2, "g1": 0.95, "g2": 3.8, "table": 1.1, "diag": 5.0, "exchange": 3.3}
 GEMM_TFLOPS = 150.0  # tcmi_cgemm, batched cut join (3-product kernel, algorithmic flops: 154 measured, profiles/r02d)
+GEMM_SPLIT_TFLOPS = 260.0   # tcmi_cgemm_split on the same shape (8 flops per complex MAC / measured time, profiles/r04f)
 JOIN_GEMM = os.environ.get("TCMI_JOIN_GEMM", "split")   # "f32": joins on the exact-f32 MFMA kernel (tcmi_cgemm) only
 
 
@@ -1407,10 +1408,15 @@ def choose_cut(n, gates, nparams, dtypestr, plan):
         if method == "cut":
             raise ValueError("set_contractor('cut'): this circuit cannot be cut (see tcmi/cut.py)")
         return None
-    t_vm = vm_cost_us(plan)
-    t_gemm = 8.0 * 2.0**n * best.bond_dim / (GEMM_TFLOPS * 1e6)      # microseconds
+    # the state-vector plan is priced on its live tiles (the circuit starts from |0...0>: live_masks), the join on the
+    # kernel it will run on (tcmi_cgemm_split for complex64 joins of whole 128 x 128 tiles with K a multiple of 32)
+    t_vm = vm_cost_us(plan, live_masks(plan.descs, plan.n)[1] if (LIVE_PLAN and getattr(plan.cfg, "gen", 1) >= 2) else None)
+    M, N = 2 ** best.n_left, 2 ** (n - best.n_left)
+    split = JOIN_GEMM != "f32" and M % 128 == 0 and N % 128 == 0 and best.bond_dim % 32 == 0
+    t_gemm = 8.0 * 2.0**n * best.bond_dim / ((GEMM_SPLIT_TFLOPS if split else GEMM_TFLOPS) * 1e6)      # microseconds
     t_halves = 2 * 15.0 + best.bond_dim * 2.0 ** max(best.n_left, n - best.n_left) / 2.0**24 * 200.0  # two-level
-    # config 2 (n = 24, d = 8, bond 256) measured: cut 286 us per state (model 254), state-vector plan 511 (model 470)
-    if method == "cut" or (t_gemm + t_halves) < 0.85 * t_vm:
+    # config 2 (n = 24, d = 8, bond 256), per state at batch 8, round 4: cut 161 us measured (model 174), state-vector plan
+    # on its live tiles 181 us (model 181); near-ties go to the cut (its join has measured better than its model so far)
+    if method == "cut" or (t_gemm + t_halves) < 1.05 * t_vm:
         return best
     return None
