@@ -10,6 +10,8 @@ if len(sys.argv) == 1:
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tensorcircuit-ng_amd"))
 import torch
 from tcmi import _lib
+# the mode switch exists in the probe build only (make -C tensorcircuit-ng_amd/csrc libtcmi_probe.so)
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tensorcircuit-ng_amd", "csrc", "libtcmi_probe.so")
 L = _lib.lib()
 M = N = 4096; B = 8
 st = torch.cuda.current_stream().cuda_stream

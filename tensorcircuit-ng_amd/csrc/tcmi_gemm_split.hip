@@ -299,9 +299,12 @@ extern "C" {
 int tcmi_cgemm_split(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch,
                      long long strideA, long long strideB, long long strideC, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  // probe builds of the kernel (scripts/gpu_gemm_split_modes.py): 1 no conversion, 2 no MFMA, 3 no result stores,
-  // 4 cycle / wall-clock stamps into C[0], 5 conversion without plane writes, 6 plane writes without conversion
+#ifdef TCMI_SPLIT_PROBE
+  // probe builds of the kernel (libtcmi_probe.so only, scripts/gpu_gemm_split_modes.py): 1 no conversion, 2 no MFMA,
+  // 3 no result stores, 4 cycle / wall-clock stamps into C[0], 5 conversion without plane writes, 6 plane writes without
+  // conversion.  The production library has no such switch: it instantiates cgemm_split_kernel<0> alone.
   static const int mode = getenv("TCMI_SPLIT_MODE") ? atoi(getenv("TCMI_SPLIT_MODE")) : 0;
+#endif
   if (!A || !B || !C || M < 1 || N < 1 || K < 1 || batch < 1 || (M % 128) || (N % 128) || (K % 32) || batch > 65535 ||
       M > (1ll << 30) || N > (1ll << 30) || ((strideA | strideB | strideC) & 1) ||
       ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C)) & 15))
@@ -332,13 +335,16 @@ int tcmi_cgemm_split(const void* A, const void* B, void* C, long long M, long lo
                        reinterpret_cast<const float2*>(B), reinterpret_cast<float2*>(C), (int)M, (int)N, (int)K, strideA, \
                        strideB, strideC, txn, tyn, batch);                                                             \
   }
+#ifdef TCMI_SPLIT_PROBE
   if (mode == 1) TCMI_SPLIT_LAUNCH(1)
   else if (mode == 2) TCMI_SPLIT_LAUNCH(2)
   else if (mode == 3) TCMI_SPLIT_LAUNCH(3)
   else if (mode == 4) TCMI_SPLIT_LAUNCH(4)
   else if (mode == 5) TCMI_SPLIT_LAUNCH(5)
   else if (mode == 6) TCMI_SPLIT_LAUNCH(6)
-  else TCMI_SPLIT_LAUNCH(0)
+  else
+#endif
+  TCMI_SPLIT_LAUNCH(0)
 #undef TCMI_SPLIT_LAUNCH
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));

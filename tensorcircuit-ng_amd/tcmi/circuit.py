@@ -720,17 +720,38 @@ class Circuit:
 
     def _state_of_matrix_inputs(self):
         """The open legs of ``inputs`` are a batch: every column [2^n] of inputs.reshape(2^n, 2^m) goes through the
-        compiled plan as one batch element; result legs = (circuit outputs, open legs), as in the reference.  Values only
-        (no tape through this route)."""
+        compiled plan as one batch element; result legs = (circuit outputs, open legs), as in the reference, where
+        ``matrix()`` / ``wavefunction()`` with matrix inputs are ordinary differentiable contractions
+        (circuit.py:744-769).  Parameters or inputs that are being differentiated go through the same ``StateFn``
+        primitive as every other state (reverse sweep per column, the parameter cotangents summed over the columns by
+        the broadcast's own backward); plain values skip the tape."""
         import torch
 
         K = cons.backend
         nq, m = self._nqubits, self._extra_input_legs()
-        cols = K.cast(K.convert_to_tensor(self.inputs), cons.dtypestr).detach().reshape(2**nq, 2**m).T.contiguous()
+        inp = K.cast(K.convert_to_tensor(self.inputs), cons.dtypestr)
         cc = self._compiled()
         while hasattr(cc, "full"):      # cut contraction: inputs other than |0> run on the state-vector plan
             cc = cc.full
         p = self._param_tensor()
+        F = torch._C._functorch
+
+        def taped(t):
+            return t is not None and torch.is_tensor(t) and (t.requires_grad or F.is_functorch_wrapped_tensor(t))
+
+        if taped(p) or taped(inp):
+            if F.is_batchedtensor(inp) or (p is not None and F.is_batchedtensor(p)):
+                raise NotImplementedError("Backend 'hip' has not implemented vmap over a circuit with matrix-shaped inputs.")
+            from .functional import _fns
+
+            cols = inp.reshape(2**nq, 2**m).T.contiguous()
+            pp = (p.reshape(1, -1).expand(2**m, -1) if p is not None
+                  else torch.zeros(2**m, 0, dtype=cc.rdtype, device=cc.device))
+            out = _fns()["StateFn"].apply(pp, cc, cols)
+            if out.shape[-1] != 2**nq:
+                out = out[..., : 2**nq]
+            return out.T.reshape(-1)
+        cols = inp.detach().reshape(2**nq, 2**m).T.contiguous()
         if p is not None:
             p = p.detach().reshape(1, -1).expand(2**m, -1).contiguous()
         with torch.no_grad():

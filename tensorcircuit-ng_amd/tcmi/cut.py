@@ -118,42 +118,3 @@ def make_cut(gates: List[P.GateRec], n: int, n_left: int, nparams: int, max_bond
         if bond > max_bond:
             return None
     return CutSpec(n, n_left, left, right, bonds, nparams)
-
-
-def reference_state(spec: CutSpec, params: np.ndarray) -> np.ndarray:
-    """Dense numpy evaluation of the cut formula (used by the CPU tests to validate make_cut)."""
-    nl, nr = spec.n_left, spec.n - spec.n_left
-    K = spec.bond_dim
-    radices = [len(b.terms) for b in spec.bonds]
-    psi = np.zeros((2**nl, 2**nr), dtype=np.complex128)
-
-    def run(gl, n, pvec):
-        st = np.zeros(2**n, dtype=np.complex128)
-        st[0] = 1
-        for g in gl:
-            m = g.matrix(pvec)
-            k = len(g.qubits)
-            t = st.reshape([2] * n)
-            t = np.moveaxis(t, list(g.qubits), range(k))
-            shp = t.shape
-            t = (m.reshape(2**k, 2**k) @ t.reshape(2**k, -1)).reshape(shp)
-            st = np.ascontiguousarray(np.moveaxis(t, range(k), list(g.qubits))).reshape(-1)
-        return st
-
-    for b in range(K):
-        digits, x = [], b
-        for r in reversed(radices):
-            digits.append(x % r)
-            x //= r
-        digits = digits[::-1]
-        w = 1.0 + 0j
-        for bond, dgt in zip(spec.bonds, digits):
-            kind, ref = bond.terms[dgt][2]
-            if kind == "const":
-                w *= ref
-            else:
-                a = ref.scale * params[ref.index] + ref.offset
-                w *= np.cos(a) if kind == "cos" else np.sin(a)
-        pvec = np.concatenate([np.asarray(params, dtype=np.float64), np.array(digits, dtype=np.float64)])
-        psi += w * np.outer(run(spec.left, nl, pvec), run(spec.right, nr, pvec))
-    return psi.reshape(-1)

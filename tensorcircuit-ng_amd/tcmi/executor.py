@@ -302,7 +302,10 @@ class CompiledCircuit:
                 out = torch.empty(B, nel, dtype=self.tdtype, device=self.device)
         sparse = inputs is None and SPARSE_START and self.cfg.gen >= 2 and self.dtypestr == "complex64"
         zbits = rfr = None
-        if sparse and NO_ZERO_FILL and all(k is not None for k in self._specialised()):
+        # resolved ONCE per call: the kernel set the zero-fill decision and the byte accounting look at is the one
+        # run_passes launches, and a call counts once towards the plan's hotness (specialize.PassSet.get)
+        spec = self._specialised()
+        if sparse and NO_ZERO_FILL and all(k is not None for k in spec):
             zb, rf, covered = self.zero_bits()
             if covered:
                 zbits, rfr = zb, rf
@@ -338,9 +341,9 @@ class CompiledCircuit:
             if any(m != LIVE_FULL for m in masks) or zbits is not None:
                 live = masks
                 units = float(sum((f * (1.0 + (rfr[i] if rfr is not None else 1.0))) if k is not None else 2.0
-                                  for i, (f, k) in enumerate(zip(fracs, self._specialised()))))
+                                  for i, (f, k) in enumerate(zip(fracs, spec))))
         with _timed("pass", len(self.descs), units * B * nel * item):
-            self.run_passes(out, ptab, B, stream, live=live, zbits=zbits)
+            self.run_passes(out, ptab, B, stream, live=live, zbits=zbits, spec=spec)
         if self.n_exec != self.n and not full:
             return out[:, : 2**self.n]
         return out
@@ -379,13 +382,14 @@ class CompiledCircuit:
             self._zero_bits = (zb, rf, touched == (1 << self.n_exec) - 1)
         return self._zero_bits
 
-    def run_passes(self, state, ptab, B, stream, first=0, last=None, live=None, zbits=None):
+    def run_passes(self, state, ptab, B, stream, first=0, last=None, live=None, zbits=None, spec=None):
         """``live``: per-pass live-tile masks (the state is |0...0> before pass 0); the specialised kernels then run on
         the live tiles only, an interpreted pass runs on all of them (zero tiles stay zero).  ``zbits``: per-pass
         ``zero_bits`` (amplitudes that are not read, see zero_bits())."""
         lib = self._lib
         nel = 2**self.n_exec
-        spec = self._specialised()
+        if spec is None:
+            spec = self._specialised()
         for i, (d, k) in list(enumerate(zip(self.descs, spec)))[first:last]:
             if k is not None:
                 _lib.check(

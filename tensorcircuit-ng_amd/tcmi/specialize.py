@@ -350,6 +350,15 @@ class _Emitter:
         # land in ONE register pair -- but the two values are the same component of two different amplitudes, so every
         # such read costs two v_mov afterwards (428 of them in a 9-round pass)
         vq = "volatile " if (elem_bytes == 4 and self.opts.get("single_reads", True)) else ""
+        # 8-byte elements (reverse sweep): left alone, the load / store optimiser pairs EVERY access into ds_read2_b64 /
+        # ds_read2st64_b64 / ds_write2_b64 (scripts/isa_lds_mix.py).  A ds_read2_b64 is served as two accesses of four
+        # contiguous 16-lane groups on 32 banks -- 8 LDS cycles per 1 KiB where two ds_read_b64 (32-lane groups on 64
+        # banks, the groups the slot map is laid out for) take 4 -- so the paired form runs at half the read rate AND
+        # conflicts on a conflict-free map (PMC round 4: 0.45 conflict cycles per active LDS cycle in the sweep, 0 in the
+        # forward kernel).  Volatile accesses keep the single-element forms.
+        vq8 = "volatile " if (elem_bytes == 8 and self.opts.get("single8", True)) else ""
+        vqw = vq8
+        vq = vq or vq8
 
         def walk(out, stem, var, plan, stmt):
             """One address variant (thread part ^ dirty bits) at a time, defined right before its accesses (short live
@@ -372,7 +381,7 @@ class _Emitter:
             planes = []
         for vec, comp in planes:
             sfx = f".{comp}" if comp else ""
-            walk(out, "wsd", ws, wplan, lambda r, ad: f"*({ctype} LDS_AS*)({ad}) = {self.A(r, vec)}{sfx};")
+            walk(out, "wsd", ws, wplan, lambda r, ad: f"*({vqw}{ctype} LDS_AS*)({ad}) = {self.A(r, vec)}{sfx};")
             out.append("  __syncthreads();")
             if first:
                 out = sg.new_part()
@@ -752,15 +761,25 @@ class SpecKernel:
 _EMITTERS = {}
 
 
-def _source(kind: str, words, opts) -> Tuple[str, dict]:
+_SHORT = {"forward": "fwd", "adjoint": "adj"}
+
+
+def _source(kind: str, words, opts, index: int = 0) -> Tuple[str, dict]:
+    """Source + meta of pass ``index`` of a plan.  The kernel is NAMED after its pass and its text --
+    ``tcmi_spec_fwd_p<k>_<digest8>`` / ``tcmi_spec_adj_p<k>_<digest8>`` -- so that a rocprofv3 kernel trace separates the
+    passes of a plan (and the plans of one process) instead of one row for every generated kernel."""
     opts = dict(opts or {})
     if os.environ.get("TCMI_SPEC_STAGGER"):
         opts["stagger"] = int(os.environ["TCMI_SPEC_STAGGER"])
     for kv in filter(None, os.environ.get("TCMI_SPEC_EXP", "").split(",")):     # experiment knobs: "pf=2,noexch,waves=5"
         k, _, v = kv.partition("=")
         opts[k] = int(v) if v else 1
-    src, meta = _EMITTERS[kind](words, f"tcmi_spec_{kind}", opts)
-    meta["kernel"] = f"tcmi_spec_{kind}"
+    generic = f"tcmi_spec_{kind}"
+    src, meta = _EMITTERS[kind](words, generic, opts)
+    name = f"tcmi_spec_{_SHORT.get(kind, kind)}_p{int(index)}_{pass_digest(src)[:8]}"
+    src = src.replace(generic, name)
+    meta["kernel"] = name
+    meta["pass_index"] = int(index)
     return src, meta
 
 
@@ -789,9 +808,26 @@ def _compile(src: str, out_path: str, keep_source: bool):
                 os.remove(f)
 
 
+def _user_cache_dir() -> Optional[str]:
+    """Per-user cache (``$XDG_CACHE_HOME/tcmi/plancache``, default ``~/.cache``) for trees that are read-only.  Code
+    objects found here are loaded and LAUNCHED, so the directory is only used when it belongs to this user and nobody
+    else can write to it (created 0700; a directory somebody else prepared is ignored)."""
+    base = os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache")
+    d = os.path.join(base, "tcmi", "plancache")
+    try:
+        os.makedirs(d, mode=0o700, exist_ok=True)
+        st = os.stat(d)
+    except OSError:
+        return None
+    if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+        return None
+    return d
+
+
 def _cache_dirs() -> List[str]:
-    """In-tree cache first (it travels with the built library), a per-user directory when the tree is read-only."""
-    return [CACHE_DIR, os.path.join(os.environ.get("TMPDIR", "/tmp"), f"tcmi_plancache_{os.getuid()}")]
+    """In-tree cache first (it travels with the built library), the per-user directory when the tree is read-only."""
+    u = _user_cache_dir()
+    return [CACHE_DIR] + ([u] if u else [])
 
 
 def _find(dg: str) -> Optional[str]:
@@ -823,7 +859,7 @@ def prepare(kind: str, descs: Sequence, opts: Optional[dict] = None, compile_mis
     jobs = []
     for i, d in enumerate(descs):
         try:
-            src, meta = _source(kind, d, opts)
+            src, meta = _source(kind, d, opts, i)
         except Unsupported:
             STATS["unsupported"] += 1
             continue
@@ -923,11 +959,17 @@ class PassSet:
             if r is not None and self.kernels[i] is None:
                 try:
                     self.kernels[i] = load(*r)
-                except Exception:  # noqa: BLE001   (a truncated / foreign file in the cache): drop it, keep the interpreter
-                    try:
-                        os.remove(r[0])
-                    except OSError:
-                        pass
+                except Exception as e:  # noqa: BLE001
+                    # a truncated file in the per-user cache is dropped (recompiled next time); never on a transient error
+                    # (out of memory ...) and never from the in-tree cache build() shipped
+                    u = _user_cache_dir()
+                    if u and os.path.dirname(os.path.abspath(r[0])) == os.path.abspath(u) and any(
+                            t in str(e).lower() for t in ("invalid image", "invalid kernel file", "invalid device function",
+                                                          "no kernel image", "not found")):
+                        try:
+                            os.remove(r[0])
+                        except OSError:
+                            pass
                     raise
 
 

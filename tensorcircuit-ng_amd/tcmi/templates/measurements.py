@@ -39,7 +39,9 @@ def mpo_expectation(c: Any, mpo: QuOperator) -> Tensor:
     if mpo.local is not None:
         return b.real(c.expectation((mpo.local, list(mpo.loc))))
     w = c.state(form="ket")
-    return b.real((b.adjoint(w) @ b.cast(mpo.dense, cons.dtypestr) @ w)[0, 0])
+    # H|psi> and <psi|H psi> on tcmi_cgemm (backend.matmul), not torch's ``@`` (rocBLAS)
+    hw = b.matmul(b.cast(mpo.dense, cons.dtypestr), w)
+    return b.real(b.matmul(b.adjoint(w), hw)[0, 0])
 
 
 def operator_expectation(c: Any, hamiltonian: Any) -> Tensor:
@@ -51,5 +53,5 @@ def operator_expectation(c: Any, hamiltonian: Any) -> Tensor:
     b = cons.backend
     w = c.state(form="ket")
     h = b.cast(b.convert_to_tensor(hamiltonian), cons.dtypestr)
-    e = (b.adjoint(w) @ h @ w)[0, 0]
+    e = b.matmul(b.adjoint(w), b.matmul(h, w))[0, 0]      # tcmi_cgemm, differentiable through its own backward rule
     return b.real(e)

@@ -1288,7 +1288,14 @@ class ContractionTree:
         for ia, ib, xa, xb, io in steps:
             needs[io] = needs[ia] or needs[ib]
         self.last_vjp_conjugated = False
-        if slice_ids and needs[last] and _graph_ok(raw, len(steps), slice_ids):
+        # A sharded run issues collectives inside the graph path (all-gather of the invariant roots, all-reduce of their
+        # cotangents): the choice graph / no graph must then be the SAME on every rank, also on ranks that hold only
+        # padding (slice_table fills rows first: 4 or 9 slices on 8 ranks leave ranks without any) -- those enter the
+        # graph path with zero slices and still run their share of the invariant forest and both collectives.
+        if shard is not None and not dep[last]:
+            shard = None          # nothing is sliced: there is no invariant forest to split (decided alike on every rank)
+        sharded = shard is not None and shard[1] > 1 and shard[2] != "emulate"
+        if needs[last] and (slice_ids or sharded) and _graph_ok(raw, len(steps), slice_ids or [0]):
             return self._contract_slices_vjp_graph(raw, slice_ids, fop, need, needs, alias_ok, hat_ok, shard)
         total = None
         grads: List[Any] = [None] * n
@@ -1373,7 +1380,7 @@ class ContractionTree:
         global COUNTERS
         steps, dep, last, final_perm = self._symbolic_steps()
         n = len(self.inputs)
-        vals0 = self.slice_index_values(slice_ids[0])
+        vals0 = self.slice_index_values(slice_ids[0] if slice_ids else 0)    # a padding-only rank captures on slice 0
         idx0 = [tuple(vals0[e] if e in vals0 else slice(None) for e in edges) for edges in self.inputs]
         srank, sworld, sgroup = shard if shard is not None else (0, 1, None)
         if sworld <= 1:

@@ -114,6 +114,16 @@ def worker(rank, world, port, out):
         res["vqa_" + dt] = {"nslices": int(dc.tree.nslices), "mine": dc.my_slices, "value": float(v),
                             "grad": tc.backend.numpy(g).astype(np.float64).tolist(),
                             "value_only": float(dc.value(pt).real)}
+    # ---- fewer slices than ranks (slice_table fills rows first: with world 4 ranks 2 and 3 hold only padding): the
+    # padding ranks must still make the sharded sweep's collectives (all-gather of the invariant roots, all-reduce of
+    # their cotangents) or the job hangs ----
+    dc = tc.experimental.DistributedContractor(
+        vqa_nodes, pt, {"slicing_opts": {"target_slices": 2}, "max_repeats": 16, "minimize": "combo", "parallel": True})
+    v, g = dc.value_and_grad(pt)
+    v2, g2 = dc.value_and_grad(pt)      # replay of the captured graphs
+    res["vqa_fewslices"] = {"nslices": int(dc.tree.nslices), "mine": dc.my_slices, "value": float(v), "value2": float(v2),
+                            "grad": tc.backend.numpy(g).astype(np.float64).tolist(),
+                            "grad2": tc.backend.numpy(g2).astype(np.float64).tolist()}
     # ---- output-wavefunction slicing (examples/slicing_wavefunction_vqa.py): the 2^3 projections of three cut qubits
     # dealt to the ranks, one all-reduce ----
     tc.set_dtype("complex128")

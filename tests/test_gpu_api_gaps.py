@@ -88,6 +88,38 @@ def test_matrix_inputs_and_circuit_matrix_kat(tcd):
         assert np.abs(got[:, j] - want).max() < tol * 10
 
 
+def test_circuit_matrix_is_differentiable(tcd):
+    """reference circuit.py:744-769: ``matrix()`` is an ordinary differentiable contraction.  d/dtheta of
+    Re(U[0, 0] + 2 U[5, 3]) for U = the unitary of an rx / cnot / rzz circuit, against central differences of the dense
+    oracle's columns -- the route through matrix-shaped inputs must not cut the tape."""
+    tc = tcd
+    n = 3
+    th0 = np.array([0.4, 1.1, -0.7])
+
+    def ops_of(th):
+        return [(G.rx(th[0]), [0]), (G.CNOT, [0, 1]), (G.rx(th[1]), [2]), (G.rzz(th[2]), [1, 2]), (G.H, [1])]
+
+    def oracle_f(th):
+        u = np.stack([dense.run(n, ops_of(th), inputs=np.eye(2**n)[:, j]) for j in range(2**n)], axis=1)
+        return float((u[0, 0] + 2 * u[5, 3]).real)
+
+    def f(th):
+        c = tc.Circuit(n)
+        c.rx(0, theta=th[0]); c.cnot(0, 1); c.rx(2, theta=th[1]); c.rzz(1, 2, theta=th[2]); c.h(1)
+        u = c.matrix()
+        return tc.backend.real(u[0, 0] + 2 * u[5, 3])
+
+    v, g = tc.backend.value_and_grad(f)(tc.backend.convert_to_tensor(th0, dtype=tc.rdtypestr))
+    tol = 2e-4 if tc.dtypestr == "complex64" else 1e-7
+    assert abs(float(v) - oracle_f(th0)) < tol
+    eps = 1e-6
+    for k in range(3):
+        d = np.zeros(3); d[k] = eps
+        fd = (oracle_f(th0 + d) - oracle_f(th0 - d)) / (2 * eps)
+        assert abs(float(g[k]) - fd) < tol, (k, float(g[k]), fd)
+    assert np.abs(tc.backend.numpy(g)).max() > 1e-2
+
+
 def test_mpo_expectation_kat(tcd):
     """reference tests/test_templates.py:191-211 (the MPO branch): value 0.84147, gradient 0.54032 (atol 1e-4)."""
     tc = tcd

@@ -132,5 +132,13 @@ def test_four_rank_sliced_value_and_grad_equals_the_adjoint_path():
             print(f"sliced vqa {dt}: value {v:.8f}, max |grad - adjoint| over ranks {max(errs):.2e}")
             assert max(errs) < tol
             assert np.abs(g).max() > 1e-3      # a gradient that is really there
+        # fewer slices than ranks: two ranks hold only -1 padding and still make the sharded sweep's collectives
+        # (complex128 is the dtype the loop above ends on)
+        few = [r["vqa_fewslices"] for r in ranks]
+        assert few[0]["nslices"] == 2 and [len(f["mine"]) for f in few] == [1, 1, 0, 0], [f["mine"] for f in few]
+        for f in few:
+            assert abs(f["value"] - v) < 1e-10 and abs(f["value2"] - v) < 1e-10
+            assert np.abs(np.asarray(f["grad"]) - g).max() < 1e-10
+            assert np.abs(np.asarray(f["grad2"]) - g).max() < 1e-10
     finally:
         tc.set_dtype("complex64")

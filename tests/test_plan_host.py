@@ -7,7 +7,7 @@ import pytest
 import tcmi as tc
 from tcmi import plan as P
 from tcmi.executor import pick_variant, structure_digest
-from oracle import dense, gates as G, plan_emulator as E, workloads as W
+from oracle import cut as oracle_cut, dense, gates as G, plan_emulator as E, workloads as W
 
 
 def _mixed(n, d, seed):
@@ -385,7 +385,7 @@ def test_cut_spec_and_selector_gates():
     spec = cut.make_cut(recs, n, 5, len(pv))
     assert [len(b.terms) for b in spec.bonds] == [2, 2, 2, 2, 4, 2] and spec.bond_dim == 128
     ops = W.hea_b_ops(n, d, params) + [(G.CNOT, [4, 5]), (G.CZ, [5, 4]), (G.random_two_qubit_gate(1), [4, 5]), (G.rzz(0.7), [5, 4])]
-    np.testing.assert_allclose(cut.reference_state(spec, pv), dense.run(n, ops), atol=1e-12)
+    np.testing.assert_allclose(oracle_cut.reference_state(spec, pv), dense.run(n, ops), atol=1e-12)
     # one bond configuration of the left half through the plan compiler + emulator
     nb = len(spec.bonds)
     digits = np.array([1, 0, 1, 1, 3, 0], dtype=np.float64)
