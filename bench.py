@@ -210,13 +210,16 @@ def vqe_leg(tc, torch, dist, args, rank, world, dev):
     step()  # second call: the traced pipeline is validated against the plain path on the first two
     sync()
     X.EVENT_LOG = []
+    X.VALU_LOG = {}
     t0 = time.perf_counter()
     for _ in range(args.vqe_steps):
         v, g, esum, gsum = step()
     sync()
     el = time.perf_counter() - t0
     ev = summarize_events(X.EVENT_LOG)
+    valu_log = X.VALU_LOG
     X.EVENT_LOG = None
+    X.VALU_LOG = None
     # the same kernels with every tile live (TCMI_SPARSE_START=0: the dense plan, every pass moves the whole state): what
     # the pass kernels reach on full passes, next to the step that skips the tiles that are still zero
     dense = None
@@ -309,10 +312,30 @@ def vqe_leg(tc, torch, dist, args, rank, world, dev):
             ent["live_tile_passes"] = bool(X.SPARSE_START and abs(dbytes - ent["algorithmic_bytes_per_launch"]) > 1e-6 * dbytes)
     if dense is not None:
         roof["dense_plan"] = dense
-    # (the count assumes every gate acts on the whole state: only meaningful when every tile is live)
+    # VALU roofline on the EXECUTED plan (the fraction of whichever roof bounds the kernel): flops and packed
+    # instructions counted from the generated source of every specialised pass (specialize.pass_arithmetic: the asm bodies
+    # it calls in their two-shear form, the pruned Walsh butterflies, the wave folds), x the waves of the LIVE tiles x batch,
+    # against the FP32 vector peak (a packed FMA = 256 flops holds a SIMD's issue port for 4 clocks: 1024 SIMDs x 64 flops
+    # x 2.4 GHz = 157.3 TFLOP/s).  ``issue_frac`` = the time the VALU needs to issue those instructions / the measured time.
+    def _valu_exec(tag):
+        e, vl = ev.get(tag), valu_log.get(tag)
+        if not e or e["ms"] <= 0 or not vl or vl[0] <= 0:
+            return None
+        per_step_s = e["ms"] * 1e-3 / max(1, args.vqe_steps)
+        fl, ins = vl[0] / max(1, args.vqe_steps), vl[1] / max(1, args.vqe_steps)
+        issue_s = ins * 4.0 / (1024 * 2.4e9)
+        return {"bound": "valu", "flops_per_step": fl, "achieved": fl / per_step_s / 1e12, "peak": MFMA_F32_PEAK_TFS,
+                "unit": "TFLOP/s", "frac": fl / per_step_s / 1e12 / MFMA_F32_PEAK_TFS,
+                "valu_instructions_x_waves_per_step": ins, "issue_time_ms_per_step": issue_s * 1e3,
+                "issue_frac": issue_s / per_step_s, "interpreted_passes_not_counted": int(vl[2] / max(1, args.vqe_steps)),
+                "counted_from": "generated source of the executed passes (tcmi/specialize.py::pass_arithmetic), live tiles only"}
+    roof["forward_pass_valu"] = _valu_exec("pass")
+    roof["adjoint_pass_valu"] = _valu_exec("adjoint")
+    # the older convention (gate arithmetic alone on full passes), kept for the dense plan's comparison with round 3
     live_on = bool(roof.get("forward_pass") and roof["forward_pass"].get("live_tile_passes"))
-    roof["forward_pass_valu"] = None if live_on else _valu("pass", 12.0)
-    roof["adjoint_pass_valu"] = None if live_on else _valu("adjoint", 32.0)
+    roof["forward_pass_gate_flops_only"] = None if live_on else _valu("pass", 12.0)
+    roof["adjoint_pass_gate_flops_only"] = None if live_on else _valu("adjoint", 32.0)
+    interp = sum(int(v_[2]) for v_ in valu_log.values()) // max(1, args.vqe_steps)
     return {
         "roofline": roof,
         "workload": f"HEA-B n={n} depth={d} TFIM value_and_grad (55-term style energy), vmap batch {Bg} "
@@ -325,7 +348,8 @@ def vqe_leg(tc, torch, dist, args, rank, world, dev):
         "mean_energy": float(esum.item()) / Bg,
         "grad_norm": float(gsum.norm().item()),
         "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 1),
-        "specialised_kernels": {**nspec, "mode": SP.mode(), "compiled_in_this_process": SP.STATS["compiled"],
+        "specialised_kernels": {**nspec, "mode": SP.mode(), "interpreted_passes_per_step": interp,
+                                "compiled_in_this_process": SP.STATS["compiled"],
                                 "compile_s": round(SP.STATS["compile_s"], 2), "cache_hits": SP.STATS["cache_hits"]},
     }
 

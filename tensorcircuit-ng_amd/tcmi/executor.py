@@ -29,6 +29,27 @@ EVENT_LOG = None
 PASS_EVENTS = None
 
 
+VALU_LOG = None    # bench.py: {tag: [flops, VALU instructions x waves]} of the plan-specialised launches logged in EVENT_LOG
+
+
+def _log_valu(tag, spec, fracs, n_exec, batch):
+    """Arithmetic of the specialised kernels of one call, as executed: per pass ``specialize.pass_arithmetic`` (per wave) x
+    waves of the live tiles x batch.  Interpreted passes are not counted (their arithmetic is not straight-line)."""
+    if VALU_LOG is None:
+        return
+    ent = VALU_LOG.setdefault(tag, [0.0, 0.0, 0])
+    for i, k in enumerate(spec):
+        if k is None:
+            ent[2] += 1
+            continue
+        ar = k.meta.get("arith")
+        if not ar:
+            continue
+        waves = (2.0 ** (n_exec - int(k.meta["T"]))) * (1 << (int(k.meta["LT"]) - 6)) * (1.0 if fracs is None else fracs[i]) * batch
+        ent[0] += ar["flops"] * waves
+        ent[1] += ar["valu_instructions"] * waves
+
+
 class _timed:
     def __init__(self, tag, launches, work):
         self.tag, self.launches, self.work = tag, launches, work
@@ -224,6 +245,11 @@ def choose_adjoint_plan(gates: List[P.GateRec], n_exec: int, dtypestr: str, full
             return adj_cost_us(a, live_masks(a.descs, n_exec, reverse=True)[1] if live else None)
 
         best = adj_cost(ap)
+        force = os.environ.get("TCMI_ADJ_FORCE")      # experiment switch "lowbits,tiebreak[,pass cap]": that candidate, whatever the model says
+        if force and full:
+            lb, tb, *cap_ = (int(x) for x in force.split(","))
+            cfg = dataclasses.replace(cfg, lowbits=lb, tiebreak=tb, pass_cap=cap_[0] if cap_ else None)
+            return cfg, P.compile_adjoint_plan(gates, n_exec, cfg, factorized=True, drop_constant_head=False)
         for drop in ((True, False) if not full else (False,)):
             for lb, tb in ((5, 0), (4, 0), (4, 1), (5, 1)) + (((3, 0), (3, 1)) if live else ()):
                 if best is None or ((lb, tb) == (cfg.lowbits, cfg.tiebreak) and drop == (not full)) \
@@ -342,6 +368,7 @@ class CompiledCircuit:
                 live = masks
                 units = float(sum((f * (1.0 + (rfr[i] if rfr is not None else 1.0))) if k is not None else 2.0
                                   for i, (f, k) in enumerate(zip(fracs, spec))))
+        _log_valu("pass", spec, self.zero_start()[1] if live is not None else None, self.n_exec, B)
         with _timed("pass", len(self.descs), units * B * nel * item):
             self.run_passes(out, ptab, B, stream, live=live, zbits=zbits, spec=spec)
         if self.n_exec != self.n and not full:
@@ -548,6 +575,7 @@ class CompiledCircuit:
             if live is not None:       # algorithmic bytes of the live tiles only (interpreted passes move every tile)
                 units = sum((4.0 if (i < len(descs) - 1 or not nostore) else 2.0) * (lfracs[i] if k is not None else 1.0)
                             for i, k in enumerate(spec))
+            _log_valu("adjoint", spec, lfracs if live is not None else None, self.n_exec, nb)
             tm = _timed("adjoint", len(descs), units * nb * nel * item)
             tm.__enter__()
             for ip, (d, k) in enumerate(zip(descs, spec)):
@@ -697,6 +725,9 @@ def pick_adjoint_variant(n_exec: int, dtypestr: str, gates) -> P.PlanConfig:
         sh2 = os.environ.get("TCMI_SHEAR2_BW", "1" if (S.mode() != "0" and n_exec >= S.MIN_N) else "0") == "1"
         if os.environ.get("TCMI_ADJ_R5"):   # experiment switch: 32 + 32 amplitude pairs per thread, 2 waves per SIMD
             return P.PlanConfig(R=5, LT=8, lowbits=5, vec=2, gen=2, shear2=sh2)
+        if os.environ.get("TCMI_ADJ_TILE"):   # experiment switch "R,LT": 2^R amplitudes of psi and of lambda per thread,
+            r_, lt_ = (int(x) for x in os.environ["TCMI_ADJ_TILE"].split(","))    # workgroups of 2^LT threads (6: one wave, no barriers)
+            return P.PlanConfig(R=r_, LT=lt_, lowbits=5, vec=2, gen=2, shear2=sh2)
         if os.environ.get("TCMI_ADJ_LT9"):  # experiment switch: 512-thread workgroups, two per CU, 13 tile bits
             return P.PlanConfig(R=4, LT=9, lowbits=5, vec=2, gen=2, shear2=sh2)
         return P.PlanConfig(R=4, LT=8, lowbits=5, vec=2, gen=2, shear2=sh2)

@@ -143,6 +143,10 @@ class _Emitter:
         # tile loads / stores of states that no cache holds until the next pass (2^26 amplitudes = 512 MiB per state and
         # up) carry the nontemporal hint: forward 8.96 -> 8.85 ms per state, sweep 27.3 -> 27.1 ms per sample at n = 28
         # (TCMI_SPEC_EXP=ntl=0,nts=0 to compare); smaller states are re-read from L2 / MALL by the next pass or the join
+        # a young workgroup issues its tile loads at raised priority (s_setprio 3 until they are out): its index arithmetic
+        # no longer queues behind the older workgroups' gate bodies (forward dense passes -3 %, sweep -2 %; raising the
+        # exchanges as well (prio=2) gained nothing)
+        self.opts.setdefault("prio", 1)
         self.opts.setdefault("ntl", int(self.n >= NT_MIN_N))
         self.opts.setdefault("nts", int(self.n >= NT_MIN_N))
         self.nrounds, self.flags = int(w[5]), int(w[6])
@@ -150,6 +154,13 @@ class _Emitter:
         if self.n > 32:
             raise Unsupported("n > 32")
         self.tile_bits = [int(w[8 + i]) for i in range(self.T)]
+        # contiguous run of a tile in memory: 8 bytes x 2^(tile bits 0, 1, 2 ... without a gap).  Runs shorter than an L2
+        # line (128 bytes) get the XCD-aware tile order (index_lines); measured on the n = 28 VQE step: the sweep (64-byte
+        # runs) 111 -> 98 ms per 8 samples, the forward passes (128-byte runs) 2.5 % SLOWER with it, so not there
+        run = 0
+        while run < self.T and self.tile_bits[run] == run:
+            run += 1
+        self.opts.setdefault("xcd", int((8 << run) < 128))
         self.vectors = list(vectors)
         self.rounds: List[_Round] = []
         pc = P.HDR_WORDS
@@ -228,8 +239,16 @@ class _Emitter:
             # live_mask (kernel argument, over the bits of the tile index): 0xffffffff = every tile has its workgroup; else
             # the grid holds one workgroup per tile whose index is zero outside the mask -- the tiles that can be non-zero
             # while some qubits of a circuit started from |0...0> have not been touched yet (executor.live_masks)
-            loop = ["  { uint32_t bx = blockIdx.x;",
-                    "  if (live_mask != 0xffffffffu) {",
+            loop = ["  { uint32_t bx = blockIdx.x;"]
+            if self.opts.get("xcd", 1):
+                # XCD-aware tile order.  Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md, workgroup dispatch), every XCD
+                # has its own L2 (128-byte lines), and tile index t and t + 1 differ in the LOWEST physical bit outside the
+                # tile: with tiles of 64-byte runs (pinned low bits 0..2) they are the two halves of the same L2 lines.
+                # Dealt round-robin, the two halves go to two XCDs and each L2 fetches (and writes back) whole lines for
+                # half their bytes; here XCD x walks the contiguous range [x N/8, (x + 1) N/8) of tile indices instead, so
+                # neighbours in the tile order are neighbours in time on ONE L2.
+                loop += ["  if (gridDim.x >= 16u) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);"]
+            loop += ["  if (live_mask != 0xffffffffu) {",
                     "    uint32_t b_ = 0, s_ = bx;",
                     "    for (uint32_t m_ = live_mask; m_; m_ &= m_ - 1u) { if (s_ & 1u) b_ |= m_ & (0u - m_); s_ >>= 1; }",
                     "    bx = b_;",
@@ -338,6 +357,9 @@ class _Emitter:
             reg_rd, thr_rd = [A[x] for x in b_.reg_tb], [A[x] for x in b_.thr_tb]
         sg = self.seg(f"exchange {k} -> {k + 1}")
         out = sg.parts[0]
+        prio = int(self.opts.get("prio", 0))
+        if prio & 2:       # the barrier / LDS chain of an exchange is latency-bound: let it overtake the other workgroups' arithmetic
+            out.append("  __builtin_amdgcn_s_setprio(2);")
         ws, rs, tpn = self.fresh("ws"), self.fresh("rs"), self.fresh("tph")
         lt = self.local_tid(out)
         self.thread_xor(out, ws, thr_wr, sh, lt)
@@ -389,6 +411,8 @@ class _Emitter:
             walk(out, "rsd", rs, rplan,
                  lambda r, ad: f"{self.A(r, vec)}{sfx} = *(const {vq}{ctype} LDS_AS*)({ad});")
             out.append("  __syncthreads();")
+        if prio & 2:
+            out.append("  __builtin_amdgcn_s_setprio(0);")
         self.tphys = tpn
         return sg
 
@@ -459,7 +483,9 @@ class _Emitter:
         ]
 
     def waves_per_eu(self) -> int:
-        return int(self.opts.get("waves", 1024 >> self.LT))
+        # waves per SIMD the register budget is sized for: 4 (128 VGPRs) with up to 16 amplitudes per vector and thread,
+        # 2 (256) beyond that
+        return int(self.opts.get("waves", min(4 if self.R * len(self.vectors) <= 5 else 2, 1024 >> self.LT)))
 
 
 # ======================================================================================================
@@ -674,8 +700,12 @@ class _Forward(_Emitter):
         if trace:
             sg.parts[0].append("  unsigned long long* const trc = (unsigned long long*)ctab_g + 32ull * (bx + (unsigned long long)gridDim.x * blockIdx.y);")
             sg.parts[0].append("  if (tid == 0) { trc[0] = wall_clock64(); unsigned hw; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\" : \"=s\"(hw)); trc[3] = hw; }")
+        if int(self.opts.get("prio", 0)) & 1:      # a young workgroup's loads go out ahead of the older ones' arithmetic
+            sg.parts[0].append("  __builtin_amdgcn_s_setprio(3);")
         self.thread_xor(sg.parts[0], self.tphys, rd0.thr_phys)
         self.tile_io(sg.parts[0], rd0, False, {"a": "state"}, self.tphys)
+        if int(self.opts.get("prio", 0)) & 1:
+            sg.parts[0].append("  __builtin_amdgcn_s_setprio(0);")
         if trace:
             sg.parts[0].append('  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");')
             sg.parts[0].append("  if (tid == 0) trc[1] = wall_clock64();")
@@ -780,7 +810,55 @@ def _source(kind: str, words, opts, index: int = 0) -> Tuple[str, dict]:
     src = src.replace(generic, name)
     meta["kernel"] = name
     meta["pass_index"] = int(index)
+    meta["arith"] = pass_arithmetic(src)
     return src, meta
+
+
+_BODY_OPS: Optional[Dict[str, Dict[str, float]]] = None
+
+
+def _body_ops() -> Dict[str, Dict[str, float]]:
+    """Packed-f32 instruction counts of the hand-written bodies (csrc/tcmi_vm2_asm.inc), by mnemonic, as EXECUTED: the
+    two-or-three-shear bodies skip part of their text at run time (the builder's flag bit), counted here in the two-shear
+    form the plans of this package ask for (``shear2``) -- the lower bound of the arithmetic."""
+    global _BODY_OPS
+    if _BODY_OPS is None:
+        import re
+
+        text = open(os.path.join(CSRC, "tcmi_vm2_asm.inc")).read()
+        out: Dict[str, Dict[str, float]] = {}
+        for m in re.finditer(r"void (vm2_\w+)\(.*?\n\}\n", text, re.S):
+            body = m.group(0)
+            ops = {k: float(len(re.findall(r'"' + k + r" ", body))) for k in ("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32")}
+            out[m.group(1)] = ops
+        # executed, not written: shear23 = 16 of its 24 FMAs in the two-shear form, shear23l = 16 of the 40 it holds
+        for name in ("vm2_shear23_8_rx", "vm2_shear23l_8_rx"):
+            if name in out:
+                out[name] = {"v_pk_fma_f32": 16.0, "v_pk_mul_f32": 0.0, "v_pk_add_f32": 0.0}
+        _BODY_OPS = out
+    return _BODY_OPS
+
+
+def pass_arithmetic(src: str) -> dict:
+    """Arithmetic of one generated pass per WAVE, counted from its source: packed-f32 instructions of the asm bodies it
+    calls (two-shear forms), the packed adds of the Walsh transforms written as plain code, and the wave folds of the
+    gradient events (29 VALU instructions each, tcmi_dev.h wave_fold8).  ``flops`` per wave = 64 lanes x (4 per packed
+    FMA, 2 per packed multiply / add); ``valu_instructions`` = what the VALU must issue at least (a packed op holds the
+    issue port for 4 clocks; exchange addressing, selects and moves come on top)."""
+    import re
+
+    ops = _body_ops()
+    tot = {"v_pk_fma_f32": 0.0, "v_pk_mul_f32": 0.0, "v_pk_add_f32": 0.0}
+    for name, cnt in re.findall(r"\b(vm2_\w+)\(", src) and [(n_, src.count(n_ + "(")) for n_ in set(re.findall(r"\b(vm2_\w+)\(", src))]:
+        for k, v in ops.get(name, {}).items():
+            tot[k] += v * cnt
+    # Walsh transform lines: "const v2f a = lo + hi;" / "... = lo - hi;" = one packed add each
+    tot["v_pk_add_f32"] += float(len(re.findall(r"const v2f \w+ = \w+ [+-] \w+;", src)))
+    folds = src.count("wave_fold8(")
+    pk = tot["v_pk_fma_f32"] + tot["v_pk_mul_f32"] + tot["v_pk_add_f32"]
+    flops = 64.0 * (4.0 * tot["v_pk_fma_f32"] + 2.0 * tot["v_pk_mul_f32"] + 2.0 * tot["v_pk_add_f32"])
+    return {"pk_fma": tot["v_pk_fma_f32"], "pk_mul": tot["v_pk_mul_f32"], "pk_add": tot["v_pk_add_f32"],
+            "wave_folds": folds, "valu_instructions": pk + 29.0 * folds, "flops": flops}
 
 
 def have_compiler() -> bool:
@@ -1162,16 +1240,27 @@ class _Adjoint(_Forward):
                 p.append("  vm2_cross8(" + ", ".join(self.A(h + i, "a") for i in range(8)) + ", "
                          + ", ".join(self.A(h + i, "l") for i in range(8)) + ", " + ", ".join(ts) + ");")
             # the transform runs on the (re, im) PAIRS (packed adds: two transforms for the price of one), the difference
-            # t.x - t.y is taken only of the outputs that are read
+            # t.x - t.y is taken only of the outputs that are read.  Only the butterflies that feed an output some event
+            # reads are written (the source is what executes: pass_arithmetic counts it).
+            wanted = set()
+            if hasC & 1:
+                wanted |= {k3 for k3 in range(1, NR) if gsc[k3] >= 0}
+            wanted |= {1 << b[0] for b in Bs if b[3] >= 0}
+            if any(a_[1] >= 0 for a_ in As):
+                wanted.add(0)
+            need = [set() for _ in range(R + 1)]      # need[j]: indices whose value after stage j - 1 is read
+            need[R] = set(wanted)
+            for j in reversed(range(R)):
+                for r in need[j + 1]:
+                    need[j] |= {r & ~(1 << j), r | (1 << j)}
             cur = [f"{wn}t{r}" for r in range(NR)]
             for j in range(R):
                 nxt = list(cur)
-                for r in range(NR):
-                    if not (r >> j) & 1:
-                        lo, hi = cur[r], cur[r | (1 << j)]
-                        a_, b_ = f"{wn}_{j}_{r}", f"{wn}_{j}_{r | (1 << j)}"
-                        p.append(f"  const v2f {a_} = {lo} + {hi}, {b_} = {lo} - {hi};")
-                        nxt[r], nxt[r | (1 << j)] = a_, b_
+                for r in sorted(need[j + 1]):
+                    lo, hi = cur[r & ~(1 << j)], cur[r | (1 << j)]
+                    nm = f"{wn}_{j}_{r}"
+                    p.append(f"  const v2f {nm} = {lo} {'-' if (r >> j) & 1 else '+'} {hi};")
+                    nxt[r] = nm
                 cur = nxt
             cur = [f"({c}.x - {c}.y)" for c in cur]
             W = cur
@@ -1246,8 +1335,12 @@ class _Adjoint(_Forward):
         rd0 = self.rounds[0]
         sg = self.seg("tile load")
         self.tphys = self.fresh("tph")
+        if int(self.opts.get("prio", 0)) & 1:
+            sg.parts[0].append("  __builtin_amdgcn_s_setprio(3);")
         self.thread_xor(sg.parts[0], self.tphys, rd0.thr_phys)
         self.tile_io(sg.parts[0], rd0, False, {"a": "psi", "l": "lam"}, self.tphys)
+        if int(self.opts.get("prio", 0)) & 1:
+            sg.parts[0].append("  __builtin_amdgcn_s_setprio(0);")
         for k, rd in enumerate(self.rounds):
             q = rd.ops_at
             for _ in range(rd.nops):

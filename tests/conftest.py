@@ -19,7 +19,7 @@ BENCH_SMALL = ["--steps", "2", "--warmup", "1", "--qubits", "16", "--depth", "4"
                "--rqc-depth", "8", "--rqc-log2-target", "20", "--rqc-seeds", "1", "--svqa-qubits", "12", "--svqa-depth", "2",
                "--svqa-slices", "4", "--svqa-steps", "1", "--mps-qubits", "0", "--no-cpu-baseline", "--no-traffic-probe",
                "--no-graph"]
-BENCH_OUT = {k: os.path.join(ROOT, ".pytest_cache", f"bench_{k}.json") for k in ("w1", "w2", "dead")}
+BENCH_OUT = {k: os.path.join(ROOT, ".pytest_cache", f"bench_{k}.json") for k in ("w1", "w2", "dead", "nccl1")}
 
 
 def _run_bench(tag, gpus, extra_env, timeout):
@@ -80,6 +80,16 @@ def pytest_sessionstart(session):
         _run_bench("w1", 1, {}, 900)
         _run_bench("w2", 2, {"TCMI_BENCH_OVERSUBSCRIBE": "1"}, 900)
         _run_bench("dead", 2, {"TCMI_BENCH_OVERSUBSCRIBE": "1", "TCMI_BENCH_KILL_RANK": "1"}, 300)
+        # RCCL itself on this box's one GPU: the multi-rank code path of bench.py (init_process_group("nccl"), barriers,
+        # the packed all-reduces, the sharded legs' collectives) with a world of ONE rank, torchrun-style environment
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        _run_bench("nccl1", 1, {"TCMI_BENCH_FORCE_DIST": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1",
+                                "LOCAL_WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                                "HSA_ENABLE_IPC_MODE_LEGACY": "0"}, 900)
     except Exception as e:  # noqa: BLE001  (the test reports the missing file)
         print("multirank launcher failed:", e)
 

@@ -17,7 +17,13 @@ tests/golden/full_size_golden.npz:
             estimate, the norm before / after and the Schmidt spectrum of the middle bond, from oracle.mps (numpy, LAPACK
             SVD).
 
-    python tests/golden/make_golden_full.py config3 | config4 | config5 | merge
+  config3grad   four components of the gradient of that energy with respect to the parameters of row 0, by central
+            differences of oracle.dense's energy (the reference's own convention for checking gradients,
+            tests/test_mpscircuit.py:452-457), step h = 1e-4 in float64: truncation ~ h^2 |E(3)| / 6 ~ 1e-8, rounding
+            ~ 1e-13 / 2h ~ 5e-10 -- below the complex128 tolerance (1e-7) the GPU test asserts.  Components: one ZZ angle
+            of the first layer, one rx angle of the first layer, one rx angle in the middle, one ZZ angle of the last layer.
+
+    python tests/golden/make_golden_full.py config3 | config3grad | config4 | config5 | merge
 """
 import os
 import sys
@@ -56,6 +62,51 @@ def config3():
     np.savez(_part("config3"), config3_params=params, config3_x=np.array(xs), config3_zz=np.array(zz),
              config3_energy=np.array(energy))
     print("config3", energy, time.time() - t0, "s")
+
+
+GRAD_COMPONENTS = [(0, 3), (1, 0), (13, 14), (22, 26)]     # (row of the [2d, n] parameter block, qubit)
+GRAD_STEP = 1e-4
+
+
+def _tfim_terms(psi, n):
+    """(<X_i>, <Z_i Z_i+1>) of a flat state through strided views (no index arrays: 4 GiB states)."""
+    xs, zz = [], []
+    for i in range(n):                       # <X_i> = 2 Re sum conj(a[..0..]) a[..1..]
+        v = psi.reshape(2**i, 2, 2 ** (n - 1 - i))
+        xs.append(2.0 * float(np.real(np.vdot(v[:, 0, :], v[:, 1, :]))))
+    prob = (psi.real**2 + psi.imag**2)
+    for i in range(n - 1):                   # <Z_i Z_i+1> = sum |a|^2 z_i z_i+1
+        v = prob.reshape(2**i, 2, 2, 2 ** (n - 2 - i))
+        zz.append(float(v[:, 0, 0, :].sum() + v[:, 1, 1, :].sum() - v[:, 0, 1, :].sum() - v[:, 1, 0, :].sum()))
+    return xs, zz
+
+
+def _config3_fd(args):
+    k, sign = args
+    n, d = 28, 12
+    params = np.random.default_rng(28).normal(0, 0.1, [32, 2 * d, n]).astype(np.float32)[0].astype(np.float64)
+    r, q = GRAD_COMPONENTS[k]
+    params[r, q] += sign * GRAD_STEP
+    t0 = time.time()
+    psi = dense.run(n, W.hea_b_ops(n, d, params), inplace=True)
+    xs, zz = _tfim_terms(psi, n)
+    e = float(np.sum(zz) - np.sum(xs))
+    print("  component", k, "sign", sign, "energy", e, time.time() - t0, "s", flush=True)
+    return k, sign, e
+
+
+def config3grad():
+    import multiprocessing as mp
+
+    t0 = time.time()
+    jobs = [(k, s_) for k in range(len(GRAD_COMPONENTS)) for s_ in (+1, -1)]
+    with mp.get_context("spawn").Pool(int(os.environ.get("GOLDEN_WORKERS", "4"))) as pool:
+        res = pool.map(_config3_fd, jobs, chunksize=1)
+    e = {(k, s_): v for k, s_, v in res}
+    fd = np.array([(e[(k, 1)] - e[(k, -1)]) / (2 * GRAD_STEP) for k in range(len(GRAD_COMPONENTS))])
+    np.savez(_part("config3grad"), config3_grad_components=np.array(GRAD_COMPONENTS), config3_grad_fd=fd,
+             config3_grad_step=np.array(GRAD_STEP))
+    print("config3grad", fd, time.time() - t0, "s")
 
 
 def _rqc_network(rows, cols, depth, dtype=np.complex128):
@@ -204,7 +255,10 @@ def config5():
 
 def merge():
     out = {}
-    for name in ("config3", "config4", "config5"):
+    if os.path.exists(OUT):           # parts that are not regenerated keep their committed values
+        with np.load(OUT) as z:
+            out.update({k: z[k] for k in z.files})
+    for name in ("config3", "config3grad", "config4", "config5"):
         if os.path.exists(_part(name)):
             with np.load(_part(name)) as z:
                 out.update({k: z[k] for k in z.files})
@@ -213,4 +267,4 @@ def merge():
 
 
 if __name__ == "__main__":
-    {"config3": config3, "config4": config4, "config5": config5, "merge": merge}[sys.argv[1]]()
+    {"config3": config3, "config3grad": config3grad, "config4": config4, "config5": config5, "merge": merge}[sys.argv[1]]()

@@ -46,6 +46,28 @@ def test_two_rank_bench_equals_the_one_rank_bench():
     assert abs(sa["value"] - sb["value"]) < 1e-5 and abs(sa["grad_norm"] - sb["grad_norm"]) < 1e-4
 
 
+def test_rccl_world_of_one_equals_the_plain_one_rank_bench():
+    """RCCL on real hardware: ``TCMI_BENCH_FORCE_DIST=1 python bench.py --gpus 1`` initialises the ``nccl`` process group
+    (= RCCL on ROCm) with a world of one rank and takes the multi-rank code path -- barrier + synchronize around the timed
+    region, the MAX-over-ranks all-reduce of the time, the packed [value || gradient] all-reduces of the VQE and sliced
+    legs (reference tensorcircuit/experimental.py:1145-1152) -- on the GPU.  It must exit 0 and report what the plain
+    one-rank run reports."""
+    a, b = _load("w1"), _load("nccl1")
+    assert a["rc"] == 0 and a["line"] is not None, a["stderr"]
+    assert b["rc"] == 0 and b["line"] is not None, b["stderr"]
+    la, lb = a["line"], b["line"]
+    assert lb["n_gpus"] == 1 and "oversubscribed" not in lb
+    assert abs(la["config"]["z0_checksum"] - lb["config"]["z0_checksum"]) < 1e-6
+    assert la["config"]["calls_per_step_per_gpu"] == lb["config"]["calls_per_step_per_gpu"]
+    for leg in ("vqe_step", "rqc_amplitude", "sliced_vqa"):
+        assert "error" not in lb[leg], lb[leg]
+    assert abs(la["vqe_step"]["mean_energy"] - lb["vqe_step"]["mean_energy"]) < 1e-6 * max(1.0, abs(la["vqe_step"]["mean_energy"]))
+    assert abs(la["vqe_step"]["grad_norm"] - lb["vqe_step"]["grad_norm"]) < 1e-5 * max(1.0, abs(la["vqe_step"]["grad_norm"]))
+    ra, rb = complex(*la["rqc_amplitude"]["amplitude"]), complex(*lb["rqc_amplitude"]["amplitude"])
+    assert abs(ra - rb) < 1e-5 * max(abs(ra), 1e-30)
+    assert abs(la["sliced_vqa"]["value"] - lb["sliced_vqa"]["value"]) < 1e-6
+
+
 def test_a_dead_rank_terminates_the_job():
     d = _load("dead")
     assert d["rc"] not in (0, -999), d       # non-zero exit, and not by the test's own timeout
