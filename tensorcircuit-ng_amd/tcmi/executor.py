@@ -295,10 +295,34 @@ class CompiledCircuit:
     _shift = staticmethod(_shift_gate)
 
     # ------------------------------------------------------------------------------------
-    def state(self, params=None, inputs=None, out=None, full=False, consume_inputs=False):
+    def build_ptab(self, params):
+        """The per-batch table of ``state`` (gate records and phase tables from the parameter rows), built on the current
+        stream: a caller that knows the parameters before it has the input states (the suffix of a cut half-circuit) builds
+        it on a side stream, under the passes that produce those states, and hands it to ``state(..., ptab=...)``."""
+        import torch
+
+        params2 = params.reshape(-1, params.shape[-1]) if params.dim() > 1 else params.reshape(1, -1)
+        params2 = params2.to(device=self.device, dtype=self.rdtype)
+        if params2.stride(-1) != 1 or params2.stride(0) < params2.shape[1]:
+            params2 = params2.contiguous()
+        B = params2.shape[0]
+        ptab = torch.empty(B, max(1, self.ptab_size), dtype=self.rdtype, device=self.device)
+        if self.nrec:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(
+                self._lib.tcmi_build_tables(
+                    self.ginfo.data_ptr(), self.nrec, self.cpool.data_ptr(), params2.data_ptr(),
+                    params2.stride(0), ptab.data_ptr(), ptab.stride(0), B, self.code, stream,
+                ),
+                "tcmi_build_tables",
+            )
+        return ptab
+
+    def state(self, params=None, inputs=None, out=None, full=False, consume_inputs=False, ptab=None):
         """Run the plan.  ``params``: real tensor [B, P] (or [P]) on the device, or None when the
         circuit has no parameters.  Returns a complex tensor [B, 2^n].  ``consume_inputs``: the passes may run in
-        place on ``inputs`` (a scratch batch the caller gives up) instead of on a copy."""
+        place on ``inputs`` (a scratch batch the caller gives up) instead of on a copy.  ``ptab``: the table of
+        ``build_ptab(params)``, already built."""
         import torch
 
         lib = self._lib
@@ -307,7 +331,9 @@ class CompiledCircuit:
             params2 = torch.zeros(1, 1, dtype=self.rdtype, device=self.device)
         else:
             params2 = params.reshape(-1, params.shape[-1]) if params.dim() > 1 else params.reshape(1, -1)
-            params2 = params2.to(device=self.device, dtype=self.rdtype).contiguous()
+            params2 = params2.to(device=self.device, dtype=self.rdtype)
+            if params2.stride(-1) != 1 or params2.stride(0) < params2.shape[1]:
+                params2 = params2.contiguous()      # the builder takes a row stride, rows themselves must be dense
             B = params2.shape[0]
             if params2.shape[1] < self.nparams:
                 raise ValueError("parameter vector shorter than the plan's parameter count")
@@ -348,15 +374,16 @@ class CompiledCircuit:
         else:
             out.zero_()
             out[:, : 2**self.n] = inp
-        ptab = torch.empty(B, self.ptab_size, dtype=self.rdtype, device=self.device)
-        if self.nrec:
-            _lib.check(
-                lib.tcmi_build_tables(
-                    self.ginfo.data_ptr(), self.nrec, self.cpool.data_ptr(), params2.data_ptr(),
-                    params2.stride(0), ptab.data_ptr(), ptab.stride(0), B, self.code, stream,
-                ),
-                "tcmi_build_tables",
-            )
+        if ptab is None:
+            ptab = torch.empty(B, self.ptab_size, dtype=self.rdtype, device=self.device)
+            if self.nrec:
+                _lib.check(
+                    lib.tcmi_build_tables(
+                        self.ginfo.data_ptr(), self.nrec, self.cpool.data_ptr(), params2.data_ptr(),
+                        params2.stride(0), ptab.data_ptr(), ptab.stride(0), B, self.code, stream,
+                    ),
+                    "tcmi_build_tables",
+                )
         item = 8 if self.dtypestr == "complex64" else 16
         live, units = None, 2.0 * len(self.descs)
         if sparse:
@@ -1158,14 +1185,35 @@ class _HalfBatch:
             if scale is not None:
                 out *= scale.reshape(-1, 1)
             return out
+        import torch
+
         K, Ks = self.K, self.Ks
-        ppre = pfull.reshape(B, Ks, K // Ks, -1)[:, :, 0, :].reshape(B * Ks, -1).contiguous()
+        # experiment switch (TCMI_CUT_BUILD_AHEAD=1; off): the suffix's tables depend on the parameters alone, so they can
+        # be built on a side stream under the prefix passes and the replication (25-35 us of every half-circuit chain in the
+        # kernel trace).  Measured on the headline: 1.001e11 / 1.010e11 with, 1.017e11 / 1.007e11 without -- the chains of
+        # the two halves already overlap each other and the host is the one issuing them; not under a hipGraph capture (a
+        # fork off an already forked stream ends the capture in a crash on this ROCm)
+        ptab_suf = None
+        if os.environ.get("TCMI_CUT_BUILD_AHEAD", "0") == "1" and not torch.cuda.is_current_stream_capturing():
+            cur = torch.cuda.current_stream(self.suffix.device)
+            aux = getattr(self, "_aux", None)
+            if aux is None:
+                aux = self._aux = torch.cuda.Stream(device=self.suffix.device)
+            aux.wait_stream(cur)
+            with torch.cuda.stream(aux):
+                ptab_suf = self.suffix.build_ptab(pfull)
+            pfull.record_stream(aux)
+        # the prefix parameter rows are every (K / Ks)-th row of pfull: a strided view, no gather
+        ppre = pfull.reshape(B * Ks, (K // Ks) * pfull.shape[-1])[:, : pfull.shape[-1]]
         pre = self.prefix.state(ppre)                                            # [B*Ks, 2^nq]
         if scale is None:
             rep = pre.reshape(B, Ks, 1, -1).expand(B, Ks, K // Ks, pre.shape[-1]).reshape(B * K, -1)
         else:
             rep = (pre.reshape(B, Ks, 1, -1) * scale.reshape(B, Ks, K // Ks, 1)).reshape(B * K, -1)
-        return self.suffix.state(pfull, inputs=rep, consume_inputs=True)
+        if ptab_suf is not None:
+            cur.wait_stream(aux)
+            ptab_suf.record_stream(cur)
+        return self.suffix.state(pfull, inputs=rep, consume_inputs=True, ptab=ptab_suf)
 
 
 class CutCircuit:

@@ -286,18 +286,26 @@ class DistributedContractor:
                     leaves[li].dtype != dtype or leaves[li].device != cdev.device or not leaves[li].is_contiguous():
                 return None
             plain.append(trig_stack(cdev, aff, leaves[li].reshape(-1)[offs]))
+        # the gate tensors of one stack that share a shape come out of ONE unbind of the stack viewed as [rows, *shape]
+        # (a thousand ``stk[row].reshape(shape)`` calls were 2 ms of host time per call of a 30-qubit depth-8 ladder);
+        # every view's _base is still the 2-D stack, which is what value_and_grad groups the cotangents by
+        rows_of: Dict[Any, Any] = {}
         out = []
         for it in recipe["items"]:
             if torch.is_tensor(it):
                 out.append(it)
                 continue
             sid, row, cj, shape = it
-            stk = plain[sid]
-            if cj:
-                if sid not in conj:
-                    conj[sid] = stk.conj().resolve_conj()
-                stk = conj[sid]
-            out.append(stk[row].reshape(shape))
+            key = (sid, cj, shape)
+            views = rows_of.get(key)
+            if views is None:
+                stk = plain[sid]
+                if cj:
+                    if sid not in conj:
+                        conj[sid] = stk.conj().resolve_conj()
+                    stk = conj[sid]
+                views = rows_of[key] = stk.reshape((stk.shape[0],) + tuple(shape)).unbind(0)
+            out.append(views[row])
         return out
 
     def _shard(self):
@@ -349,16 +357,42 @@ class DistributedContractor:
         p = K.tree_unflatten(spec, leaves)
         fop = op if op is not None else (lambda x: x.sum().real)
         arrays = self._arrays(p)
-        if self._fast_vjp(arrays):
+        # A traced node function replays ONE recipe: the arrays of every call have the same count, shapes, dtypes and tape
+        # membership, so what was established about them once (the hand-written sweep takes them, the graphs fit them, which
+        # rows of which stack they are) is not re-derived array by array on every call -- with a thousand gate tensors those
+        # loops were most of the host time of a step (scripts/gpu_svqa_host.py).
+        st_ = getattr(self, "_trace_state", None)
+        fast_key = None
+        if st_ is not None and st_["mode"] == "replay":
+            fast_key = (id(st_["recipe"]), tuple((tuple(x.shape), x.dtype) for x in leaves), cons.dtypestr)
+        fk = getattr(self, "_fast_vjp_ok", None)
+        if fast_key is not None and fk == fast_key:
+            fast = True
+        else:
+            fast = self._fast_vjp(arrays)
+            self._fast_vjp_ok = fast_key if fast else None
+        if fast:
             # reverse sweep over the step list on the untaped kernels (tn.contract_slices_vjp); the small gate tensors
             # stay on torch's tape, so their cotangents reach ``params`` through one autograd call
             value, agrads = self.tree.contract_slices_vjp(arrays, self.my_slices, fop, alias_ok=True, hat_ok=True,
-                                                          shard=self._shard())
+                                                          shard=self._shard(), fast_key=fast_key)
             hat = bool(getattr(self.tree, "last_vjp_conjugated", False))   # the sweep handed over conj(g): undone per stack
             if value is None:
                 value = sum((x.sum() * 0 for x in leaves)).real.detach()
-            pairs = [(a, g) for a, g in zip(arrays, agrads) if g is not None and a.requires_grad]
-            if pairs:
+            # (which arrays receive a cotangent depends on the slices and the invariant subtrees this rank holds)
+            sh_ = self._shard()
+            gkey = None if fast_key is None else (fast_key, tuple(self.my_slices),
+                                                  None if sh_ is None else (sh_[0], sh_[1], sh_[2] == "emulate"))
+            grouped = self._grouped_cotangents(gkey, arrays, agrads, hat) if gkey is not None else None
+            if grouped is not None:
+                outs, gouts = grouped
+                grads = torch.autograd.grad(outs, leaves, gouts, allow_unused=True) if outs else [None] * len(leaves)
+                pairs = None
+            else:
+                pairs = [(a, g) for a, g in zip(arrays, agrads) if g is not None and a.requires_grad]
+            if grouped is not None:
+                pass
+            elif pairs:
                 # gate tensors are rows of a few stacks (Circuit._gate_stacks): hand autograd one cotangent per STACK --
                 # a thousand row selections would each run their own backward node
                 outs, gouts, groups = [], [], {}
@@ -399,6 +433,42 @@ class DistributedContractor:
         else:
             v = v.to(getattr(torch, cons.rdtypestr))
         return v, K.tree_unflatten(spec, gs)
+
+    def _grouped_cotangents(self, fast_key, arrays, agrads, hat):
+        """(stack tensors, their cotangents) for ``torch.autograd.grad``: the rows-of-stacks grouping of value_and_grad with
+        its structure (which array is which row of which stack) cached per recipe.  None: no cached structure applies (the
+        caller groups array by array and, if every array on the tape is a stack row, the structure is remembered)."""
+        import torch
+
+        gc = getattr(self, "_group_cache", None)
+        if gc is None or gc["key"] != fast_key:
+            groups, order = {}, []
+            for k, (a, g) in enumerate(zip(arrays, agrads)):
+                if g is None or not a.requires_grad:
+                    continue
+                b = a._base
+                if not (b is not None and b.dim() == 2 and b.requires_grad and b.is_contiguous() and b.storage_offset() == 0
+                        and a.is_contiguous() and a.numel() == b.shape[1] and a.storage_offset() % b.shape[1] == 0):
+                    return None             # an array on the tape that is not a stack row: the general route
+                if id(b) not in groups:
+                    groups[id(b)] = {"k0": k, "rows": [], "ks": []}
+                    order.append(id(b))
+                groups[id(b)]["rows"].append(a.storage_offset() // b.shape[1])
+                groups[id(b)]["ks"].append(k)
+            gl = []
+            for bid in order:
+                gr = groups[bid]
+                gl.append((gr["k0"], upload_cached(np.asarray(gr["rows"], dtype=np.int64), None, arrays[gr["k0"]].device), gr["ks"]))
+            gc = self._group_cache = {"key": fast_key, "groups": gl}
+        outs, gouts = [], []
+        for k0, rows, ks in gc["groups"]:
+            b = arrays[k0]._base
+            st = torch.stack([agrads[k].reshape(-1) for k in ks])
+            gb = torch.zeros_like(b)
+            gb.index_add_(0, rows, st.conj().resolve_conj() if hat else st)
+            outs.append(b)
+            gouts.append(gb)
+        return outs, gouts
 
     @staticmethod
     def _fast_vjp(arrays) -> bool:

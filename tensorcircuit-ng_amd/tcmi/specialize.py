@@ -140,15 +140,10 @@ class _Emitter:
         self.w = w
         self.opts = dict(opts or {})
         self.n, self.T, self.R, self.LT = int(w[1]), int(w[2]), int(w[3]), int(w[4])
-        # tile loads / stores of states that no cache holds until the next pass (2^26 amplitudes = 512 MiB per state and
-        # up) carry the nontemporal hint: forward 8.96 -> 8.85 ms per state, sweep 27.3 -> 27.1 ms per sample at n = 28
-        # (TCMI_SPEC_EXP=ntl=0,nts=0 to compare); smaller states are re-read from L2 / MALL by the next pass or the join
         # a young workgroup issues its tile loads at raised priority (s_setprio 3 until they are out): its index arithmetic
         # no longer queues behind the older workgroups' gate bodies (forward dense passes -3 %, sweep -2 %; raising the
         # exchanges as well (prio=2) gained nothing)
         self.opts.setdefault("prio", 1)
-        self.opts.setdefault("ntl", int(self.n >= NT_MIN_N))
-        self.opts.setdefault("nts", int(self.n >= NT_MIN_N))
         self.nrounds, self.flags = int(w[5]), int(w[6])
         self.NR = 1 << self.R
         if self.n > 32:
@@ -161,6 +156,15 @@ class _Emitter:
         while run < self.T and self.tile_bits[run] == run:
             run += 1
         self.opts.setdefault("xcd", int((8 << run) < 128))
+        # ... and no nontemporal hint: the other half of every 128-byte L2 line belongs to the neighbouring tile, which the
+        # XCD-aware order runs on the same L2 a moment later -- a line marked streaming is gone by then (PMC, sweep pass 1 of
+        # n = 28: 88 GB moved for 69 GB algorithmic with the hint; passes on 64-byte runs 5-27 % faster without it).  Tiles of
+        # whole lines keep it for states that no cache holds until the next pass (2^26 amplitudes = 512 MiB and up: forward
+        # 8.96 -> 8.85 ms per state at n = 28; TCMI_SPEC_EXP=ntl=0,nts=0 to compare); smaller states are re-read from L2 /
+        # MALL by the next pass or the join.
+        nt = int(self.n >= NT_MIN_N and (8 << run) >= 128)
+        self.opts.setdefault("ntl", nt)
+        self.opts.setdefault("nts", nt)
         self.vectors = list(vectors)
         self.rounds: List[_Round] = []
         pc = P.HDR_WORDS

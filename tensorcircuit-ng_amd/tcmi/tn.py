@@ -1256,7 +1256,7 @@ class ContractionTree:
             yield res
 
     def contract_slices_vjp(self, arrays: Sequence[Any], slice_ids: Sequence[int], fop, need=None, alias_ok=False,
-                            hat_ok=False, shard=None):
+                            hat_ok=False, shard=None, fast_key=None):
         """``sum_i fop(contract_core(slice_arrays(arrays, i)))`` and its gradient with respect to every array, by a
         reverse sweep over the step list instead of a framework tape (reference ``experimental.py:1182-1211``:
         ``value_and_grad`` of ``contract_core`` per slice, summed).  Every forward AND backward step is one launch of
@@ -1278,6 +1278,18 @@ class ContractionTree:
         PARTIAL: their sum over the ranks (which the caller's gradient all-reduce forms anyway) is the gradient."""
         import torch
 
+        # ``fast_key``: the caller vouches that arrays with this key have the structure (count, shapes, dtypes, device,
+        # which of them are on the tape) of the call the graphs were captured on -- a traced node function replaying the
+        # same recipe (DistributedContractor).  The per-array checks below (a thousand arrays: 2-3 ms of host time per
+        # call) are then skipped and the captured graphs are replayed at once.
+        cache = getattr(self, "_vjp_graph_cache", None)
+        if fast_key is not None:
+            fast_key = (fast_key, tuple(slice_ids), alias_ok, hat_ok,
+                        None if shard is None else (shard[0], shard[1], shard[2] == "emulate"))
+        if fast_key is not None and cache is not None and cache.get("fast_key") == fast_key \
+                and not torch.cuda.is_current_stream_capturing() and os.environ.get("TCMI_TN_GRAPH", "1") != "0":
+            self.last_vjp_conjugated = False
+            return self._vjp_graph_replay(cache, arrays, list(slice_ids), fop, cache["need"], alias_ok, hat_ok, cache["shard3"])
         steps, dep, last, final_perm = self._symbolic_steps()
         n = len(self.inputs)
         slice_ids = list(slice_ids)
@@ -1296,7 +1308,10 @@ class ContractionTree:
             shard = None          # nothing is sliced: there is no invariant forest to split (decided alike on every rank)
         sharded = shard is not None and shard[1] > 1 and shard[2] != "emulate"
         if needs[last] and (slice_ids or sharded) and _graph_ok(raw, len(steps), slice_ids or [0]):
-            return self._contract_slices_vjp_graph(raw, slice_ids, fop, need, needs, alias_ok, hat_ok, shard)
+            out = self._contract_slices_vjp_graph(raw, slice_ids, fop, need, needs, alias_ok, hat_ok, shard)
+            if fast_key is not None:
+                self._vjp_graph_cache["fast_key"] = fast_key
+            return out
         total = None
         grads: List[Any] = [None] * n
         ginv: Dict[int, Any] = {}
@@ -1618,7 +1633,19 @@ class ContractionTree:
             cache = {"sig": sig, "st_inv": st_inv, "st_dep": st_dep, "shared": shared, "cur": cur, "res": res,
                      "g_in": g_in, "gacc": gacc, "gleaf": gleaf, "ginv_leaf": ginv_leaf, "g_a": g_a, "g_b": g_b,
                      "g_c": g_c, "g_d": g_d, "batch": B, "two": two, "big": big, "gbig": gbig}
+            cache["need"] = list(need)
+            cache["shard3"] = (srank, sworld, sgroup)
             self._vjp_graph_cache = cache
+        return self._vjp_graph_replay(cache, raw, slice_ids, fop, need, alias_ok, hat_ok, (srank, sworld, sgroup))
+
+    def _vjp_graph_replay(self, cache, raw, slice_ids, fop, need, alias_ok, hat_ok, shard3):
+        """One evaluation on the captured graphs of ``_contract_slices_vjp_graph``: leaf values into the static buffers,
+        invariant forward, [all-gather], per slice {sliced leaves in, forward, op and its derivative, backward}, [all-reduce
+        of the roots' cotangents], invariant backward."""
+        import torch
+
+        srank, sworld, sgroup = shard3
+        n = len(self.inputs)
         with torch.no_grad():
             inv_k = list(cache["st_inv"])
             if inv_k:
@@ -1686,8 +1713,15 @@ class ContractionTree:
                 self._allreduce_complex(cache["gbig"], sgroup)     # the roots' cotangents, summed over every rank's slices
             if cache["g_d"] is not None:
                 cache["g_d"].replay()
-            for k, gl in cache["ginv_leaf"].items():
-                grads[k] = gl.reshape(raw[k].shape) if alias_ok else gl.reshape(raw[k].shape).clone()
+            if alias_ok:      # views of the graphs' static memory: the same objects on every call
+                al = cache.get("ginv_alias")
+                if al is None:
+                    al = cache["ginv_alias"] = {k: gl.reshape(raw[k].shape) for k, gl in cache["ginv_leaf"].items()}
+                for k, gl in al.items():
+                    grads[k] = gl
+            else:
+                for k, gl in cache["ginv_leaf"].items():
+                    grads[k] = gl.reshape(raw[k].shape).clone()
             # the graphs deliver conj(g)
             if hat_ok:
                 self.last_vjp_conjugated = True

@@ -93,3 +93,49 @@ def test_cut_join_runs_on_the_split_kernel_and_matches_the_f32_join():
         tc.set_contractor("greedy")
     assert np.abs(s_split - ref).max() < 1e-5 and np.abs(s_f32 - ref).max() < 1e-5
     assert np.abs(s_split - ref).max() < 2 * np.abs(s_f32 - ref).max() + 1e-8
+
+
+def test_split_gemm_on_sums_that_cancel_down_to_the_dropped_terms():
+    """Adversarial operands: every k-pair is (x, -1) . (y, z) with x = 1 + 2^-9 + 2^-18 (bf16 pieces 1, 2^-9, 2^-18), y of
+    the same form and z = the sum of the SIX piece products the kernel keeps, which is exact in f32.  The exact value of
+    x y - z is then precisely what the kernel drops (x1 y2 + x2 y1 + x2 y2 = 2^-26 + 2^-36 per pair): the split kernel
+    returns 0 where float64 returns K/2 * 2^-26 -- a 100 % RELATIVE error on a fully cancelled sum.  The bound the kernel
+    meets, and this test asserts, is the absolute one of an f32 GEMM that rounds every product once:
+    |c - exact| <= 2^-23 sum_k |a_k||b_k| (here the error is 2^-27 of that scale).  An exact-f32 FMA chain can do better on
+    this input only by luck of its accumulation order (fl(x y) alone already loses the 2^-26); nothing in the path --
+    reference tensorcircuit contracts complex64 with an f32 GEMM (circuit.py:701-721, backend.tensordot) -- relies on more."""
+    import torch
+    from tcmi import _lib
+
+    L = _lib.lib()
+    M = N = 128
+    K, B = 64, 1
+    x = 1.0 + 2.0 ** -9 + 2.0 ** -18
+    kept = 1.0 + 2.0 ** -8 + 3.0 * 2.0 ** -18              # x0 y0 + x0 y1 + x1 y0 + x0 y2 + x2 y0 + x1 y1, exact in f32
+    assert float(np.float32(kept)) == kept and float(np.float32(x)) == x
+    a = torch.zeros(B, K, M, 2, dtype=torch.float32, device="cuda")
+    b = torch.zeros(B, K, N, 2, dtype=torch.float32, device="cuda")
+    a[:, 0::2, :, 0] = x
+    a[:, 1::2, :, 0] = -1.0
+    b[:, 0::2, :, 0] = x
+    b[:, 1::2, :, 0] = kept
+    # exact phases i^k on the rows of a and (-i)^k on b: the complex arithmetic (Gauss's three products) is exercised and
+    # the sum stays the same
+    ph = torch.tensor([[1.0, 0.0], [0.0, 1.0], [-1.0, 0.0], [0.0, -1.0]], device="cuda")
+    for k in range(K):
+        p, q = ph[(k // 2) % 4], ph[(-(k // 2)) % 4]
+        ar, br = a[:, k, :, 0].clone(), b[:, k, :, 0].clone()
+        a[:, k, :, 0], a[:, k, :, 1] = ar * p[0], ar * p[1]
+        b[:, k, :, 0], b[:, k, :, 1] = br * q[0], br * q[1]
+    A, Bm = torch.view_as_complex(a), torch.view_as_complex(b)
+    c = torch.full((B, M, N), float("nan"), dtype=torch.complex64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(L.tcmi_cgemm_split(A.data_ptr(), Bm.data_ptr(), c.data_ptr(), M, N, K, B, K * M, K * N, M * N, st), "split")
+    ref = torch.einsum("bkm,bkn->bmn", A.to(torch.complex128), Bm.to(torch.complex128))
+    want = (K // 2) * (2.0 ** -26 + 2.0 ** -36)
+    assert abs(complex(ref[0, 0, 0]) - want) < 1e-15             # float64 sees exactly the dropped terms
+    scale = float(torch.einsum("bkm,bkn->bmn", A.abs().double(), Bm.abs().double())[0, 0, 0])
+    err = float((c.to(torch.complex128) - ref).abs().max())
+    assert np.isfinite(err)
+    assert err <= 2.0 ** -23 * scale, (err, scale)               # the f32-GEMM bound (one rounding per product)
+    assert err <= 1.01 * want                                    # and nothing beyond the dropped terms is lost

@@ -213,3 +213,103 @@ def test_live_tile_passes_equal_the_dense_passes(tc64):
     assert np.array_equal(res[True][0], res[False][0])
     assert abs(res[True][1] - res[False][1]) < 1e-5
     assert np.abs(res[True][2] - res[False][2]).max() < 5e-6
+
+
+def test_live_tile_kernels_against_the_dense_oracle_directly(tc64):
+    """The executed fast path of the VQE leg -- plan-specialised kernels, live-tile passes, no zero fill, live-tile reverse
+    sweep, XCD-aware tile order -- against ``oracle.dense`` itself (not against the product's own dense passes) at n = 21:
+    the state (complex64 tolerance of BASELINE.json, 1e-5), the TFIM energy, and three gradient components against
+    central differences of the oracle's energy (the reference's convention, tests/test_mpscircuit.py:452-457)."""
+    tc = tc64
+    from tcmi import executor as X
+
+    n, d = 21, 4
+    params = np.random.default_rng(2100).uniform(0, 2 * np.pi, [2 * d, n])
+
+    def energy(p):
+        c = tc.Circuit(n)
+        W.hea_b(c, n, d, p, zz=tc.gates._zz_matrix)
+        e = 0.0
+        for i in range(n):
+            e += -1.0 * c.expectation((tc.gates.x(), [i]))
+        for i in range(n - 1):
+            e += 1.0 * c.expectation((tc.gates.z(), [i]), (tc.gates.z(), [i + 1]))
+        return tc.backend.real(e)
+
+    os.environ["TCMI_SPECIALIZE"] = "1"
+    tc.set_contractor("plain")
+    try:
+        X._CACHE.clear()
+        pt = tc.backend.convert_to_tensor(params, dtype=tc.rdtypestr)
+        c = tc.Circuit(n)
+        W.hea_b(c, n, d, pt, zz=tc.gates._zz_matrix)
+        cc = c._compiled()
+        masks, fracs = cc.zero_start()
+        assert X.SPARSE_START and any(m != X.LIVE_FULL for m in masks)      # the live-tile path is what runs
+        psi = tc.backend.numpy(c.wavefunction())
+        assert all(k is not None for k in cc._specialised())                # every pass on a generated kernel
+        v, g = tc.backend.value_and_grad(energy)(pt)
+        g = tc.backend.numpy(g)
+    finally:
+        tc.set_contractor("greedy")
+    ref = dense.run(n, W.hea_b_ops(n, d, params))
+    assert np.abs(psi - ref).max() < 1e-5
+    e_ref = W.tfim_energy_dense(ref, n)
+    assert abs(float(v) - e_ref) < 1e-5 * n
+    eps = 1e-5
+    for (r, q) in ((0, 5), (3, 11), (7, 20)):
+        pp, pm = params.copy(), params.copy()
+        pp[r, q] += eps
+        pm[r, q] -= eps
+        fd = (W.tfim_energy_dense(dense.run(n, W.hea_b_ops(n, d, pp)), n)
+              - W.tfim_energy_dense(dense.run(n, W.hea_b_ops(n, d, pm)), n)) / (2 * eps)
+        assert abs(g[r, q] - fd) < 2e-4, ((r, q), g[r, q], fd)
+
+
+def test_generated_kernel_options_do_not_change_results(tc64):
+    """Round-5 code-generation choices -- XCD-aware tile order, raised load priority, single 8-byte LDS accesses -- only move
+    work in time and space: with each of them off (TCMI_SPEC_EXP) the state is bit-identical and the gradient agrees to
+    summation order."""
+    tc = tc64
+    from tcmi import executor as X
+
+    n, d = 18, 3
+    params = np.random.default_rng(18).uniform(0, 2 * np.pi, [2 * d, n])
+
+    def energy(p):
+        c = tc.Circuit(n)
+        W.hea_b(c, n, d, p, zz=tc.gates._zz_matrix)
+        e = 0.0
+        for i in range(n):
+            e += -1.0 * c.expectation((tc.gates.x(), [i]))
+        for i in range(n - 1):
+            e += 1.0 * c.expectation((tc.gates.z(), [i]), (tc.gates.z(), [i + 1]))
+        return tc.backend.real(e)
+
+    os.environ["TCMI_SPECIALIZE"] = "1"
+    tc.set_contractor("plain")
+    old = os.environ.get("TCMI_SPEC_EXP")
+    res = {}
+    try:
+        for exp in ("", "xcd=0,prio=0,single8=0", "xcd=1"):
+            os.environ["TCMI_SPEC_EXP"] = exp
+            X._CACHE.clear()
+            pt = tc.backend.convert_to_tensor(params, dtype=tc.rdtypestr)
+            c = tc.Circuit(n)
+            W.hea_b(c, n, d, pt, zz=tc.gates._zz_matrix)
+            psi = tc.backend.numpy(c.wavefunction())
+            v, g = tc.backend.value_and_grad(energy)(pt)
+            res[exp] = (psi, float(v), tc.backend.numpy(g))
+    finally:
+        if old is None:
+            os.environ.pop("TCMI_SPEC_EXP", None)
+        else:
+            os.environ["TCMI_SPEC_EXP"] = old
+        tc.set_contractor("greedy")
+        X._CACHE.clear()
+    for exp in ("xcd=0,prio=0,single8=0", "xcd=1"):
+        assert np.array_equal(res[""][0], res[exp][0])
+        assert abs(res[""][1] - res[exp][1]) < 1e-5
+        assert np.abs(res[""][2] - res[exp][2]).max() < 5e-6
+    ref = dense.run(n, W.hea_b_ops(n, d, params))
+    assert np.abs(res["xcd=1"][0] - ref).max() < 1e-5
