@@ -323,14 +323,18 @@ class Circuit:
     gate_aliases = gate_aliases
 
     def __init__(self, nqubits: int, inputs: Optional[Tensor] = None,
-                 mps_inputs: Optional[Any] = None, split: Optional[Dict[str, Any]] = None,
-                 dim: Optional[int] = None):
+                 mps_inputs: Optional[Any] = None, tensors: Optional[Sequence[Any]] = None,
+                 split: Optional[Dict[str, Any]] = None, dim: Optional[int] = None):
         if dim not in (None, 2):
             raise NotImplementedError("the hip backend supports qubits (dim=2) only")
-        if mps_inputs is not None:
-            raise NotImplementedError("mps_inputs is not supported on the hip backend")
         self._nqubits = int(nqubits)
         self._d = 2
+        self.mps_inputs = mps_inputs
+        if inputs is None and (mps_inputs is not None or tensors is not None):
+            # reference circuit.py:44-131 wires an MPS-shaped initial state (``mps_inputs``: a QuVector; ``tensors``: site
+            # tensors [bond-left, physical, bond-right], basecircuit.py:72-102) into the network as it is; here the chain
+            # is contracted once into the dense state the plan executor starts from (tcmi_cgemm per site, on the tape)
+            inputs = self._dense_of_mps(mps_inputs if mps_inputs is not None else tensors)
         self.inputs = inputs
         self.split = split
         self._ops: List[_Op] = []
@@ -338,7 +342,45 @@ class Circuit:
         self._qir: List[Dict[str, Any]] = []
         self.state_tensor = None
         self._pending = {}  # id -> weakref of unevaluated LazyExpectation objects referring to this circuit
-        self.circuit_param = {"nqubits": nqubits, "inputs": inputs, "mps_inputs": None, "split": split}
+        self.circuit_param = {"nqubits": nqubits, "inputs": inputs, "mps_inputs": mps_inputs, "tensors": tensors,
+                              "split": split}
+
+    def _dense_of_mps(self, mps) -> Tensor:
+        from .quantum import QuVector
+
+        if isinstance(mps, QuVector):
+            qv = mps
+        elif hasattr(mps, "get_tensors"):            # an MPSCircuit
+            qv = QuVector(tensors=mps.get_tensors())
+        elif hasattr(mps, "tensors") and getattr(mps, "tensors") is not None:
+            qv = QuVector(tensors=mps.tensors)
+        else:
+            qv = QuVector(tensors=list(mps))
+        if qv.n != self._nqubits:
+            raise ValueError(f"the MPS input has {qv.n} sites, the circuit {self._nqubits} qubits")
+        return qv.eval()
+
+    def quvector(self):
+        """reference basecircuit.py ``quvector``: the circuit's state as a ``QuVector`` (dense here)."""
+        from .quantum import QuVector
+
+        return QuVector(dense=self.wavefunction())
+
+    get_quvector = quvector
+
+    def replace_inputs(self, inputs: Tensor) -> None:
+        """reference circuit.py ``replace_inputs``: another input state under the same gates (the compiled plan depends on
+        the gate structure only, so nothing is recompiled)."""
+        self._flush_pending()
+        self.inputs = inputs
+        self.state_tensor = None
+        self.circuit_param["inputs"] = inputs
+
+    def replace_mps_inputs(self, mps_inputs: Any) -> None:
+        """reference circuit.py:133-160: another MPS-shaped input state under the same gates."""
+        self._flush_pending()
+        self.mps_inputs = mps_inputs
+        self.replace_inputs(self._dense_of_mps(mps_inputs))
 
     # ---- recording (reference basecircuit.py:183-371) ---------------------------------------
     def _norm_index(self, index: Sequence[int]) -> Tuple[int, ...]:
@@ -378,8 +420,11 @@ class Circuit:
         if len(index) > 2:
             # dense gates on > 2 qubits (toffoli, fredkin, any(...)): exact plan-time synthesis into
             # <= 2-qubit dense + diagonal gates (tcmi/synth.py); unitary input required
-            if len(index) > 5:
-                raise NotImplementedError("dense gates on more than 5 qubits are not supported on the hip backend")
+            # (the reference takes an ``any`` gate of every size, gates.py:866-890; the decomposition is exact for every k
+            # -- 697 / 3177 / 13673 / 57001 native ops for k = 5 / 6 / 7 / 8, 0.1 / 0.2 / 0.5 / 18 s of host time once per
+            # gate matrix -- and beyond 8 qubits a dense 2^k x 2^k matrix is no longer a gate but a state-sized operator)
+            if len(index) > 8:
+                raise NotImplementedError("dense gates on more than 8 qubits are not supported on the hip backend")
             if np.abs(m @ m.conj().T - np.eye(d)).max() > 1e-9:
                 raise NotImplementedError("non-unitary gates on more than 2 qubits are not supported on the hip backend")
             from .synth import decompose_dense, lower

@@ -160,6 +160,50 @@ def reduced_density_matrix(state: Tensor, cut: Any, p: Optional[Tensor] = None) 
     return LA.matmul(m, m.conj().t().resolve_conj())
 
 
+class QuVector:
+    """The part of the reference's ``QuVector`` (tensorcircuit/quantum.py) the circuit constructors use: a state given as
+    an MPS -- site tensors ``[bond-left, physical, bond-right]``, the layout of ``Circuit(n, tensors=...)``
+    (reference basecircuit.py:72-102) and of ``MPSCircuit.get_tensors`` -- or as a dense vector (``Circuit.quvector()``,
+    reference basecircuit.py ``quvector``).  ``eval`` is the dense state: the chain is contracted left to right, one
+    ``tcmi_cgemm`` per site (``backend.matmul``: differentiable through its own backward rule)."""
+
+    def __init__(self, tensors: Optional[Sequence[Any]] = None, dense: Optional[Any] = None):
+        if (tensors is None) == (dense is None):
+            raise ValueError("QuVector takes either MPS tensors or a dense state")
+        self.tensors = list(tensors) if tensors is not None else None
+        self.dense = dense
+
+    @classmethod
+    def from_tensors(cls, tensors: Sequence[Any]) -> "QuVector":
+        return cls(tensors=tensors)
+
+    @property
+    def n(self) -> int:
+        if self.tensors is not None:
+            return len(self.tensors)
+        return int(self.dense.numel() if hasattr(self.dense, "numel") else np.size(self.dense)).bit_length() - 1
+
+    def eval(self) -> Tensor:
+        K = cons.backend
+        if self.dense is not None:
+            return K.reshape(K.cast(K.convert_to_tensor(self.dense), cons.dtypestr), [-1])
+        ts = [K.cast(K.convert_to_tensor(t), cons.dtypestr) for t in self.tensors]
+        for j, t in enumerate(ts):
+            if len(t.shape) != 3 or int(t.shape[1]) != 2:
+                raise ValueError(f"MPS tensor {j} has shape {tuple(t.shape)}; expected (bond-left, 2, bond-right)")
+        if int(ts[0].shape[0]) != 1 or int(ts[-1].shape[2]) != 1:
+            raise ValueError("an MPS state needs boundary bonds of dimension 1")
+        acc = K.reshape(ts[0], [2, int(ts[0].shape[2])])               # [2^j, D_j]
+        for t in ts[1:]:
+            dl, dr = int(t.shape[0]), int(t.shape[2])
+            if dl != int(acc.shape[1]):
+                raise ValueError("MPS bond dimensions do not match")
+            acc = K.reshape(K.matmul(acc, K.reshape(t, [dl, 2 * dr])), [-1, dr])
+        return K.reshape(acc, [-1])
+
+    eval_matrix = eval
+
+
 class QuOperator:
     """The part of the reference's ``QuOperator`` (tensorcircuit/quantum.py) the hot path's callers use: an operator on n
     qubits given either as ONE local tensor on some sites (``from_local_tensor``, the MPO of

@@ -220,3 +220,99 @@ def test_big_diagonals_in_the_network_route(tcd):
 
     _, g2 = tc.backend.value_and_grad(f)(p)
     assert np.abs(tc.backend.numpy(g) - tc.backend.numpy(g2)).max() < tol * 20
+
+
+def test_mps_shaped_input_states_kats(tcd):
+    """reference tests/test_circuit.py:470-495 (``Circuit(n, tensors=[t1, t2, t3])``: GHZ site tensors -> GHZ state) and
+    :693-704 (``Circuit(2, mps_inputs=c.quvector())`` and ``replace_mps_inputs``: X X|00> = |00>); an MPSCircuit's own
+    tensors as the input of a Circuit give the state of the same gates applied to the dense state (oracle.dense); the
+    gradient with respect to a site tensor flows through the chain contraction (tcmi_cgemm's backward rule)."""
+    tc = tcd
+    tol = 1e-5 if tc.dtypestr == "complex64" else 1e-10
+    n = 3
+    t1 = np.zeros([1, 2, 2], dtype=np.complex64); t1[0, 0, 0] = 1; t1[0, 1, 1] = 1
+    t2 = np.zeros([2, 2, 2], dtype=np.complex64); t2[0, 0, 0] = 1; t2[1, 1, 1] = 1
+    t3 = np.zeros([2, 2, 1], dtype=np.complex64); t3[0, 0, 0] = 1 / np.sqrt(2); t3[1, 1, 0] = 1 / np.sqrt(2)
+    c = tc.Circuit(n, tensors=[t1, t2, t3])
+    ghz = np.zeros(8); ghz[0] = ghz[7] = 1 / np.sqrt(2)
+    np.testing.assert_allclose(tc.backend.numpy(c.wavefunction()), ghz, atol=1e-5)
+    # reference test_circuit_add_demo
+    c = tc.Circuit(2); c.x(0)
+    c2 = tc.Circuit(2, mps_inputs=c.quvector()); c2.X(0)
+    np.testing.assert_allclose(tc.backend.numpy(c2.wavefunction()), np.array([1.0, 0, 0, 0]), atol=1e-4)
+    c3 = tc.Circuit(2); c3.X(0)
+    c3.replace_mps_inputs(c.quvector())
+    np.testing.assert_allclose(tc.backend.numpy(c3.wavefunction()), np.array([1.0, 0, 0, 0]), atol=1e-4)
+    # a random MPS (bond dimension 4) under gates, against the dense oracle on the contracted chain
+    n = 8
+    rng = np.random.default_rng(8)
+    dims = [1, 2, 4, 4, 4, 4, 4, 2, 1]
+    ts = [rng.normal(size=(dims[i], 2, dims[i + 1])) + 1j * rng.normal(size=(dims[i], 2, dims[i + 1])) for i in range(n)]
+    dense_in = ts[0].reshape(2, -1)
+    for t in ts[1:]:
+        dense_in = (dense_in @ t.reshape(t.shape[0], -1)).reshape(-1, t.shape[2])
+    dense_in = dense_in.reshape(-1)
+    nrm = np.linalg.norm(dense_in)
+    ts[0] = ts[0] / nrm
+    dense_in = dense_in / nrm
+    cm = tc.Circuit(n, tensors=ts)
+    cm.h(0); cm.cnot(0, 5); cm.rx(3, theta=0.7); cm.rzz(2, 6, theta=-0.4)
+    want = dense.run(n, [(G.H, [0]), (G.CNOT, [0, 5]), (G.rx(0.7), [3]), (G.rzz(-0.4), [2, 6])], inputs=dense_in)
+    assert np.abs(tc.backend.numpy(cm.wavefunction()) - want).max() < 10 * tol
+    with pytest.raises(ValueError):
+        tc.Circuit(5, tensors=ts)
+    # differentiable: d/ds of <Z_3> for the input MPS with site 2 scaled by (1 + s A) -- against central differences of
+    # the oracle
+    A = rng.normal(size=ts[2].shape) + 1j * rng.normal(size=ts[2].shape)
+
+    def z3_oracle(s):
+        tt = list(ts); tt[2] = ts[2] + s * A
+        v = tt[0].reshape(2, -1)
+        for t in tt[1:]:
+            v = (v @ t.reshape(t.shape[0], -1)).reshape(-1, t.shape[2])
+        psi = dense.run(n, [(G.rx(0.7), [3])], inputs=v.reshape(-1))
+        return float(np.real(dense.expectation(psi, n, (G.Z, [3]))))
+
+    def z3(s):
+        import torch
+
+        cdt = getattr(torch, tc.dtypestr)
+        tt = [torch.as_tensor(t).to(device=s.device, dtype=cdt) for t in ts]
+        tt[2] = tt[2] + tc.backend.cast(s, tc.dtypestr) * torch.as_tensor(A).to(device=s.device, dtype=cdt)
+        cc = tc.Circuit(n, tensors=tt)
+        cc.rx(3, theta=0.7)
+        return tc.backend.real(cc.expectation((tc.gates.z(), [3])))
+
+    import torch
+
+    s0 = torch.zeros((), dtype=getattr(torch, tc.rdtypestr), device="cuda")
+    v, g = tc.backend.value_and_grad(z3)(s0)
+    eps = 1e-5
+    fd = (z3_oracle(eps) - z3_oracle(-eps)) / (2 * eps)
+    gt = 2e-3 if tc.dtypestr == "complex64" else 1e-7
+    assert abs(float(v) - z3_oracle(0.0)) < 10 * tol and abs(float(g) - fd) < gt, (float(g), fd)
+
+
+def test_dense_any_gates_on_six_and_seven_qubits(tcd):
+    """reference gates.py:866-890 (``any`` takes a unitary of any size): Haar-random 6- and 7-qubit gates on scattered
+    qubits, between ordinary gates, against the dense oracle; nine qubits raise (a 2^18-element matrix is a state-sized
+    operator, not a gate)."""
+    from scipy.stats import unitary_group
+
+    tc = tcd
+    tol = 2e-5 if tc.dtypestr == "complex64" else 1e-10
+    n = 14
+    for k, qs in ((6, [1, 3, 4, 8, 12, 13]), (7, [0, 2, 5, 6, 9, 10, 11])):
+        u = unitary_group.rvs(2**k, random_state=40 + k)
+        c = tc.Circuit(n)
+        for i in range(n):
+            c.h(i)
+        c.rx(3, theta=0.3)
+        c.any(*qs, unitary=u)
+        c.cnot(qs[0], (qs[0] + 7) % n if (qs[0] + 7) % n not in (qs[0],) else 1)
+        ops = [(G.H, [i]) for i in range(n)] + [(G.rx(0.3), [3]), (u, qs), (G.CNOT, [qs[0], (qs[0] + 7) % n])]
+        want = dense.run(n, ops)
+        got = tc.backend.numpy(c.wavefunction())
+        assert np.abs(got - want).max() < tol, (k, np.abs(got - want).max())
+    with pytest.raises(NotImplementedError):
+        tc.Circuit(10).any(*range(9), unitary=np.eye(2**9))

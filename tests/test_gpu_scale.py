@@ -110,6 +110,17 @@ def test_config3_full_size_complex64_against_complex128():
     assert np.abs(t128 - tor).max() < 1e-10 and abs(e128 - float(full["config3_energy"])) < 1e-9
     assert np.abs(t64 - tor).max() < 1e-5 and abs(e64 - float(full["config3_energy"])) < 55e-5
     assert abs(e128 - (t128[n:].sum() - t128[:n].sum())) < 1e-9      # the energy is the sum of its terms
+    # ... and the GRADIENT against the oracle: four components by central differences of oracle.dense's energy (step 1e-4,
+    # float64: accurate to ~1e-8; the reference's convention, tests/test_mpscircuit.py:452-457), fixture config3grad
+    assert "config3_grad_fd" in full.files, "full_size_golden.npz has no config3grad part (make_golden_full.py config3grad; merge)"
+    comps, fd = full["config3_grad_components"], full["config3_grad_fd"]
+    e64g = max(abs(g64[int(r), int(q)] - f) for (r, q), f in zip(comps, fd))
+    e128g = max(abs(g128[int(r), int(q)] - f) for (r, q), f in zip(comps, fd))
+    print(f"config 3 full size gradient vs oracle.dense central differences ({len(fd)} components, |g| up to "
+          f"{np.abs(fd).max():.3f}): max error complex64 {e64g:.2e}, complex128 {e128g:.2e}")
+    assert e128g < 1e-7, e128g
+    assert e64g < 2e-4, e64g
+    assert np.abs(fd).max() > 1e-2
     assert de < 55e-5, (e64, e128)
     assert dg < 1e-4, dg
     assert np.abs(g128).max() > 0.1   # the gradient is not trivially small
