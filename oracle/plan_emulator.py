@@ -14,7 +14,7 @@ MAGIC = 0x54434D31
 HDR_WORDS = 24
 RR_WORDS = 50
 OP_G1, OP_G2, OP_DIAG, OP_G1M, OP_EXPECT, OP_DIAGC, OP_DIAGB = 1, 2, 3, 4, 5, 6, 7
-OP_DIAGF, OP_DIAGB2, OP_DIAGCW, OP_EXPECT2 = 8, 9, 10, 11
+OP_DIAGF, OP_DIAGB2, OP_DIAGCW, OP_EXPECT2, OP_XFOLD, OP_DFOLD = 8, 9, 10, 11, 12, 13
 R_MAX = 6
 CONST_FLAG = 1 << 30
 BK_TRIG, BK_COEF, BK_SELECT, BK_PHASE = 1, 2, 5, 6
@@ -479,7 +479,8 @@ def run_adjoint_pass(psi, lam, desc, ctab, ptab_row, gout):
         rphys = _xor_masks(rid, rr[2: 2 + R])
         gidx = (wg_base[:, None, None] | tphys[None, :, None] | rphys[None, None, :]).astype(np.int64)
         if k == 0:
-            regs = np.stack([psi[gidx], lam[gidx]])
+            # FLAG_LAMBDA_ZERO (header word 6, bit 1): lambda is born in this pass, nothing is loaded
+            regs = np.stack([psi[gidx], np.zeros_like(lam[gidx]) if (int(d[6]) & 2) else lam[gidx]])
         else:
             slot = (_xor_masks(tid, rr[24: 24 + LT])[:, None] ^ _xor_masks(rid, rr[18: 18 + R])[None, :]).astype(np.int64)
             regs = lds[:, :, slot]
@@ -524,6 +525,28 @@ def run_adjoint_pass(psi, lam, desc, ctab, ptab_row, gout):
                     regs[..., r0] = ud[0, 0] * x0 + ud[0, 1] * x1
                     regs[..., r1] = ud[1, 0] * x0 + ud[1, 1] * x1
                 q += 5 + R
+            elif op == OP_DFOLD:
+                # {13, nterms, gslot, (thread-side Z mask, register mask, cslot) * nterms}: lambda += D psi, D = sum_t c_t sign_t
+                nt_, gs_ = int(d[q + 1]), int(dsig[q + 2])
+                D = np.zeros((nwg, nth, NR))
+                for t_ in range(nt_):
+                    zm_, rm_, c_ = int(d[q + 3 + 3 * t_]), int(d[q + 4 + 3 * t_]), float(tab(d[q + 5 + 3 * t_], 1)[0])
+                    st_ = 1 - 2 * _parity(tidx & np.uint64(zm_))
+                    sr_ = 1 - 2 * _parity(rid & np.uint32(rm_)).astype(np.int64)
+                    D += c_ * st_[:, :, None] * sr_[None, None, :]
+                gout[gs_] += 0.5 * np.sum(D * np.abs(regs[0]) ** 2)
+                regs[1] = regs[1] + D * regs[0]
+                q += 3 + 3 * nt_
+            elif op == OP_XFOLD:
+                # {12, j, cslot, gslot}: lambda += c X_j psi on register bit j, energy slot += c sum_pairs Re(conj(psi_x) psi_y)
+                j, c_, gs_ = int(d[q + 1]), float(tab(d[q + 2], 1)[0]), int(dsig[q + 3])
+                r0 = rid[((rid >> j) & 1) == 0]
+                r1 = r0 | (1 << j)
+                a0, a1 = regs[0][..., r0].copy(), regs[0][..., r1].copy()
+                regs[1][..., r0] += c_ * a1
+                regs[1][..., r1] += c_ * a0
+                gout[gs_] += c_ * np.sum(np.real(np.conj(a0) * a1))
+                q += 4
             elif op == OP_G2:
                 ja, kind, jb = int(d[q + 1]) & 0xFF, int(d[q + 1]) >> 8, int(d[q + 2])
                 uslot, kslot, gslot = int(dsig[q + 3]), int(dsig[q + 4]), int(dsig[q + 5])

@@ -263,6 +263,64 @@ def choose_adjoint_plan(gates: List[P.GateRec], n_exec: int, dtypestr: str, full
     return cfg, ap
 
 
+def pick_adjoint_from_zero(exec_gates, n_exec: int, get_plan):
+    """Host part of CompiledCircuit._adjoint_from_zero: of the short sweep (``get_plan(False)``) and the full gate list
+    chosen for a psi from |0...0> (``get_plan(True)``) the one whose live tiles cost less under the pass model.
+    ``get_plan(full)`` returns a record with "plan" (AdjointPlan).  Returns (record, masks, fractions)."""
+    best = None
+    for full in (False, True):
+        adj = get_plan(full)
+        if best is not None and adj is best[0]:
+            continue
+        ngates = sum(1 for _ in exec_gates)
+        start = 0
+        if not full:
+            # qubits touched by the constant head a short plan may leave out (never un-computed; assumed left
+            # out even where choose_adjoint_plan kept the whole gate list for the short sweep: conservative)
+            first = next((i for i, g_ in enumerate(exec_gates) if P.gate_has_param(g_)), ngates)
+            for g_ in exec_gates[:first]:
+                for q in g_.qubits:
+                    start |= 1 << (n_exec - 1 - q)
+        masks, fracs = live_masks(adj["plan"].descs, n_exec, start_bits=start, reverse=True)
+        cost = adj_cost_us(adj["plan"], fracs)
+        if cost is None:
+            cost = float(sum(fracs))
+        if best is None or cost < best[3]:
+            best = (adj, masks, fracs, cost)
+    return best[:3]
+
+
+def fold_plan_host(exec_gates, n_exec: int, adj0: dict, nparams: int, xw, dw=(), nterms: int = 0):
+    """Host part of CompiledCircuit.fold_setup (also run by specialize.precompile_circuit, without a GPU): the sweep plan
+    of ``adj0`` (record of _adjoint_from_zero: its tile configuration and gate list) recompiled with terms of the Pauli-sum
+    cotangent born in registers -- ``xw`` = [(term index, physical bit, weight)]: single-X terms, each folded into the first
+    pass whose tile holds its bit; ``dw`` = [(term index, Z mask over physical bits, weight)]: Z-only strings, folded at
+    the start of the sweep.  ``nterms`` = number of terms of the whole sum: when every one of them is folded the first pass
+    does not load lambda at all (FLAG_LAMBDA_ZERO).  Returns (AdjointPlan, indices of the folded terms, lam_zero) or None
+    when fewer than four X terms qualify or the schedule moved."""
+    ap0 = adj0["plan"]
+    seen, xs = set(), []
+    for k, bit, w in xw:
+        if bit not in seen and float(w) != 0.0:
+            seen.add(bit)
+            xs.append((k, bit, 2.0 * float(w)))
+    ds = [(k, int(zm), 2.0 * float(w)) for k, zm, w in dw if float(w) != 0.0]
+    if len(xs) < 4:
+        return None
+    kw = dict(factorized=True, drop_constant_head=bool(getattr(ap0, "drop_constant_head", False)),
+              fold=[(bit, c) for _, bit, c in xs], fold_param=nparams, dfold=[(zm, c) for _, zm, c in ds] or None)
+    ap = P.compile_adjoint_plan(exec_gates, n_exec, adj0["cfg"], **kw)
+    if [pp.tile_bits for pp in ap.passes] != [pp.tile_bits for pp in ap0.passes] or len(ap.folded) < 4:
+        return None
+    done = sorted([xs[i][0] for i in ap.folded] + [k for k, _, _ in ds])
+    lam_zero = bool(nterms) and len(done) == nterms
+    if lam_zero:
+        ap2 = P.compile_adjoint_plan(exec_gates, n_exec, adj0["cfg"], lam_zero=True, **kw)
+        assert ap2.folded == ap.folded
+        ap = ap2
+    return ap, done, lam_zero
+
+
 class CompiledCircuit:
     """A circuit structure lowered to tile-VM passes and resident on one GPU."""
 
@@ -501,31 +559,65 @@ class CompiledCircuit:
         that opens with a Hadamard layer -- so the full gate list is usually the cheaper sweep now; the pass model
         decides.  Returns (plan record, masks, fractions)."""
         if getattr(self, "_adj_zero", None) is None:
-            best = None
-            for full in (False, True):
-                adj = self._adjoint(full, zero_start=full)
-                if best is not None and adj is best[0]:
-                    continue
-                ngates = sum(1 for _ in self._exec_gates)
-                start = 0
-                if not full:
-                    # qubits touched by the constant head a short plan may leave out (never un-computed; assumed left
-                    # out even where choose_adjoint_plan kept the whole gate list for the short sweep: conservative)
-                    first = next((i for i, g_ in enumerate(self._exec_gates) if P.gate_has_param(g_)), ngates)
-                    for g_ in self._exec_gates[:first]:
-                        for q in g_.qubits:
-                            start |= 1 << (self.n_exec - 1 - q)
-                masks, fracs = live_masks(adj["plan"].descs, self.n_exec, start_bits=start, reverse=True)
-                cost = adj_cost_us(adj["plan"], fracs)
-                if cost is None:
-                    cost = float(sum(fracs))
-                if best is None or cost < best[3]:
-                    best = (adj, masks, fracs, cost)
-            self._adj_zero = best[:3]
+            self._adj_zero = pick_adjoint_from_zero(self._exec_gates, self.n_exec,
+                                                    lambda full: self._adjoint(full, zero_start=full))
         return self._adj_zero
 
+    def fold_setup(self, cm, weights):
+        """Can part of the Pauli-sum cotangent of ``cm`` (weights: one float per term) be BORN in the reverse sweep instead of
+        arriving through memory?  lambda = 2 sum_t w_t P_t |psi> costs 2 + 3 + 3 state transfers of tcmi_apply_pauli_sum_tiled
+        for the n = 28 TFIM (one pass per 8-12 index bits that carry an X), and the sweep's first pass then reads it back.
+        The single-X terms on the qubits of that first pass's TILE are added to lambda in registers there (plan.fold_rounds,
+        OP_XFOLD: 24 packed instructions per term and thread), their energies arrive as gradient events, and the tile passes
+        only cover the remaining terms.  The same holds for every later pass whose tile brings new qubits, and the Z-only
+        strings need no neighbours at all: for the TFIM EVERY term is born in the sweep, no tile pass runs and the first pass
+        does not even load lambda (8 + 1 state transfers less per sample).  Returns None (nothing to fold, or
+        the plan-specialised kernels of the folded sweep are not there yet: only they execute OP_XFOLD) or a record
+        {"skip": term indices left out of the tile passes, "adj": the sweep plan record, masks, fracs}."""
+        if (os.environ.get("TCMI_PAULI_FOLD", "1") == "0" or not SPARSE_START or self.dtypestr != "complex64"
+                or self.nonunitary or self.cfg.gen < 2 or S.mode() == "0"):
+            return None
+        key = (id(cm), tuple(float(w) for w in weights))
+        cache = self.__dict__.setdefault("_fold_cache", {})
+        if key not in cache:
+            cache[key] = None
+            adj0, masks, fracs = self._adjoint_from_zero()
+            if adj0["cfg"].gen >= 2 and adj0["plan"].descs and any(m != LIVE_FULL for m in masks):
+                n = self.n_exec
+                xw = [(k, n - 1 - t.x[0], float(weights[k])) for k, t in enumerate(cm.all_terms) if len(t.x) == 1 and not t.z]
+                dw = [(k, sum(1 << (n - 1 - q) for q in t.z), float(weights[k])) for k, t in enumerate(cm.all_terms)
+                      if not t.x and t.z]
+                res = fold_plan_host(self._exec_gates, n, adj0, self.nparams, xw, dw, len(cm.all_terms))
+                if res is not None:
+                    ap, done, lam_zero = res
+                    skip = frozenset(done)
+                    # what is left (strings with two or more X / Y factors ...) still goes through the tile passes
+                    if lam_zero or (cm._tiled_plan(skip) is not None and cm._tiled_plan() is not None
+                                    and len(cm._tiled_plan(skip)) < len(cm._tiled_plan())):
+                        dev = self.device
+                        cache[key] = {"skip": skip, "lam_zero": lam_zero, "masks": masks, "fracs": fracs, "adj": {
+                            "plan": ap, "cfg": adj0["cfg"], "descs": [_dev(d, dev) for d in ap.descs],
+                            "ctab": _dev(ap.ctab, dev, self.rdtype), "ginfo": _dev(ap.ginfo, dev),
+                            "cpool": _dev(ap.cpool if ap.cpool.size else np.zeros(1), dev),
+                            "gparam": _dev(ap.gslot_param, dev), "gfactor": _dev(ap.gslot_factor, dev),
+                            "nslots": len(ap.gslot_param)}}
+        rec = cache[key]
+        if rec is None:
+            return None
+        # only the generated kernels know OP_XFOLD: the sweep the traced pipeline runs (last pass without write-back) must be
+        # loaded -- PassSet.get() also counts this call towards the plan's hotness, so a missing kernel gets compiled
+        adj = rec["adj"]
+        if adj.get("spec_nostore") is None:
+            nd = [np.asarray(d) for d in adj["plan"].descs]
+            nd[-1] = nd[-1].copy()
+            nd[-1][6] |= P.FLAG_NOSTORE
+            adj["spec_nostore"] = S.PassSet("adjoint", nd, self.n_exec, S.adjoint_opts(adj["cfg"]))
+        if any(k is None for k in adj["spec_nostore"].get()):
+            return None
+        return rec
+
     def vjp(self, params, psi, g, chunk_bytes=48 << 30, inputs=None, want_input_grad=False, consume=False,
-            from_zero=False):
+            from_zero=False, fold=None):
         """dL/dparams = Re <g | d psi / d params> for every batch row, by the adjoint sweep.
         params [B, P] real, psi / g [B, 2^n_exec] complex (psi = the forward output).  The sweep
         works on copies (psi is un-computed in place), processed in batch chunks to bound memory.
@@ -540,7 +632,12 @@ class CompiledCircuit:
         lam_out = torch.empty_like(g) if want_input_grad else None
         adj = self._adjoint(full=want_input_grad)
         live, lfracs = None, None
-        if (from_zero and SPARSE_START and not want_input_grad and self.dtypestr == "complex64"
+        if fold is not None:
+            # ``fold`` (a record of fold_setup): g lacks the folded terms of the cotangent, the sweep's first pass adds them;
+            # returns (dL/dparams, energy of the folded terms [B])
+            assert from_zero and not want_input_grad and getattr(self, "_keep_uncomputed", None) is None
+            adj, live, lfracs = fold["adj"], fold["masks"], fold["fracs"]
+        elif (from_zero and SPARSE_START and not want_input_grad and self.dtypestr == "complex64"
                 and getattr(self, "_keep_uncomputed", None) is None):
             adj0, masks, fracs = self._adjoint_from_zero()
             if adj0["cfg"].gen == 2 and any(m != LIVE_FULL for m in masks):
@@ -548,8 +645,8 @@ class CompiledCircuit:
         lib = self._lib
         B = params.shape[0]
         nel = 2**self.n_exec
-        out = torch.zeros(B, max(self.nparams, 1), dtype=torch.float64, device=self.device)
-        if (adj["nslots"] == 0 or self.nparams == 0) and not want_input_grad:
+        out = torch.zeros(B, max(self.nparams, 1) + (1 if fold is not None else 0), dtype=torch.float64, device=self.device)
+        if (adj["nslots"] == 0 or self.nparams == 0) and not want_input_grad and fold is None:
             return out[:, : self.nparams].to(self.rdtype)
         if params is None or params.shape[-1] == 0:
             params = torch.zeros(B, 1, dtype=self.rdtype, device=self.device)
@@ -598,10 +695,14 @@ class CompiledCircuit:
                         nd[-1][6] |= P.FLAG_NOSTORE
                     adj[skey] = S.PassSet("adjoint", nd, self.n_exec, S.adjoint_opts(cfg))
                 spec = adj[skey].get()
+            if fold is not None and any(k is None for k in spec):
+                raise RuntimeError("the folded reverse sweep needs its plan-specialised kernels (fold_setup checks this)")
             units = len(descs) * 4.0 - (2.0 if nostore else 0.0)
             if live is not None:       # algorithmic bytes of the live tiles only (interpreted passes move every tile)
                 units = sum((4.0 if (i < len(descs) - 1 or not nostore) else 2.0) * (lfracs[i] if k is not None else 1.0)
                             for i, k in enumerate(spec))
+                if fold is not None and fold.get("lam_zero"):
+                    units -= lfracs[0]          # the first pass does not read lambda
             _log_valu("adjoint", spec, lfracs if live is not None else None, self.n_exec, nb)
             tm = _timed("adjoint", len(descs), units * nb * nel * item)
             tm.__enter__()
@@ -638,6 +739,8 @@ class CompiledCircuit:
             if getattr(self, "_keep_uncomputed", None) is not None:
                 self._keep_uncomputed.append(a)
         gp = out[:, : self.nparams].to(self.rdtype)
+        if fold is not None:
+            return gp, out[:, self.nparams]
         return (gp, lam_out) if want_input_grad else gp
 
     # ---- reverse mode through non-unitary gates ----------------------------------------------------------
@@ -838,31 +941,35 @@ class CompiledMeasure:
             vals[:, k] = torch.view_as_complex(acc.sum(1))
         return vals
 
-    def _tiled_plan(self):
+    def _tiled_plan(self, skip=frozenset()):
         """Passes of ``tcmi_apply_pauli_sum_tiled`` for this term list (``plan_pauli_passes``), or None when the flat
-        gather kernel is the better (or the only) choice."""
-        if not hasattr(self, "_tiled"):
-            self._tiled = None
+        gather kernel is the better (or the only) choice.  ``skip``: indices of terms that are left out (they reach the
+        cotangent another way: CompiledCircuit.fold_setup)."""
+        cache = self.__dict__.setdefault("_tiled_cache", {})
+        if skip not in cache:
+            cache[skip] = None
             if os.environ.get("TCMI_PAULI_TILED", "1") != "0" and self.n_exec <= 32:
                 n = self.n_exec
                 rows = []
                 for k, t in enumerate(self.all_terms):
+                    if k in skip:
+                        continue
                     xm = sum(1 << (n - 1 - q) for q in t.x)
                     zm = sum(1 << (n - 1 - q) for q in t.z)
                     rows.append((xm, zm, t.ny, k))
                 T = int(self._lib.tcmi_pauli_sum_tile_bits(self.code))
-                passes = plan_pauli_passes(n, rows, T) if n >= T else None
+                passes = plan_pauli_passes(n, rows, T) if (n >= T and rows) else None
                 if passes is not None:
-                    self._tiled = [
+                    cache[skip] = [
                         dict(tilepos=_dev(np.asarray(ps["tilepos"], dtype=np.int32), self.device),
                              terms=_dev(np.asarray(ps["rows"], dtype=np.int64).astype(np.uint32).view(np.int32).reshape(-1, 4),
                                         self.device),
                              order=_dev(np.asarray(ps["order"], dtype=np.int64), self.device), n=len(ps["order"]),
                              ndiag=int(ps["ndiag"]))
                         for ps in passes]
-        return self._tiled
+        return cache[skip]
 
-    def apply_sum(self, state, gvals, want_dot=False):
+    def apply_sum(self, state, gvals, want_dot=False, skip=frozenset()):
         """Cotangent of the state for L = f(<psi|P_t|psi>): 2 * sum_t Re(g_t) P_t |psi>.  state [B, 2^n_exec], gvals
         [B, nterms] complex.  Tile passes (``tcmi_apply_pauli_sum_tiled``) when every X mask fits a tile, else the flat
         gather kernel (``tcmi_apply_pauli_sum``).  ``want_dot``: also return Re <psi|lambda> per batch element
@@ -870,7 +977,9 @@ class CompiledMeasure:
         measurement passes are not needed."""
         import torch
 
-        tiled = self._tiled_plan()
+        tiled = self._tiled_plan(skip)
+        if skip and tiled is None:
+            raise RuntimeError("apply_sum(skip=...) needs the tile passes (fold_setup checks _tiled_plan(skip) first)")
         if tiled is not None:
             B = state.shape[0]
             wall = 2.0 * gvals.real.to(torch.float64)

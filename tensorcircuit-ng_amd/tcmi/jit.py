@@ -208,6 +208,7 @@ class TracedVag:
             "index": torch.tensor(index, dtype=torch.int64, device=dev),
             "consts": torch.tensor(consts, dtype=rdt, device=dev),
             "weights": torch.tensor([terms[s] for s in strings], dtype=torch.float64, device=dev),
+            "weights_host": [float(terms[s]) for s in strings],
             "checked": False,
         }
 
@@ -256,9 +257,22 @@ class TracedVag:
             return value if batched else value[0]
         # lambda = 2 sum_t w_t P_t |psi> and, from the same launches, Re <psi|lambda> = 2 sum_t w_t <P_t>: the energy comes
         # with its cotangent, no measurement passes (executor.CompiledMeasure.apply_sum)
-        lam, dot = cm.apply_sum(state, w.to(torch.complex128).reshape(1, -1).expand(nb, -1), want_dot=True)
-        value = 0.5 * dot + plan["const"]
-        gp = cc.vjp(params, state, lam, consume=True, from_zero=True).to(torch.float64)   # [nb, P]; state and lam are ours
+        # ... and the single-X terms on the qubits of the sweep's first tile are not sent through memory at all: that pass
+        # adds them to lambda in registers and returns their energies (executor.fold_setup; None: nothing to fold)
+        fold = cc.fold_setup(cm, plan["weights_host"]) if hasattr(cc, "fold_setup") else None
+        if fold is not None:
+            if fold["lam_zero"]:     # every term is born in the sweep: no tile pass, lambda is a buffer nobody initialises
+                lam, dot = torch.empty_like(state), 0.0
+            else:
+                lam, dot = cm.apply_sum(state, w.to(torch.complex128).reshape(1, -1).expand(nb, -1), want_dot=True,
+                                        skip=fold["skip"])
+            gp, efold = cc.vjp(params, state, lam, consume=True, from_zero=True, fold=fold)
+            value = 0.5 * dot + efold + plan["const"]
+            gp = gp.to(torch.float64)
+        else:
+            lam, dot = cm.apply_sum(state, w.to(torch.complex128).reshape(1, -1).expand(nb, -1), want_dot=True)
+            value = 0.5 * dot + plan["const"]
+            gp = cc.vjp(params, state, lam, consume=True, from_zero=True).to(torch.float64)   # [nb, P]; state and lam are ours
         gflat = torch.zeros(nb, plan["total"] + plan["consts"].numel(), dtype=torch.float64, device=dev)
         gflat.index_add_(1, plan["index"], gp)
         grads = []

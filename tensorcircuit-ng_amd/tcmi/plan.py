@@ -46,8 +46,11 @@ OP_DIAGC = 6   # diagonal terms on register bits only: multiply by a 2^R table o
 OP_DIAGB2 = 9  # two register-x-thread terms on the same register bit: {9, j, mask1, mask2, slot}, table of 4 factors (gen 2)
 OP_DIAGCW = 10  # DIAGC whose table is picked per wave: {10, slot, nsel, m0, m1, m2}, variant = sum_k parity(wave index & m_k) << k, table of 2^nsel * 2^R factors (gen 2): register-x-thread terms whose thread bits are wave-uniform cost no multiply of their own
 OP_DIAGF = 8   # backward (adjoint sweep) flush of diagonal terms in table form: see encode_pass
+OP_XFOLD = 12   # reverse sweep, plan-specialised kernels only: {12, j, cslot, gslot}: lambda[r] += c psi[r ^ (1 << j)] (c = ctab[cslot], real) and gradient slot gslot += c sum_pairs Re(conj(psi_x) psi_y): the term c/2 X_q of a Pauli-sum cotangent born in registers (compile_adjoint_plan ``fold``)
+OP_DFOLD = 13   # reverse sweep, plan-specialised kernels only: {13, nterms, gslot, (thread-side Z mask over physical bits, register mask, cslot) * nterms}: lambda[r] += D psi[r] with D = sum_t c_t (-1)^{parity(index & zmask_t)} (the Z-only strings of a Pauli-sum cotangent, register part of every mask split off for the round's layout) and gradient slot gslot += 1/2 sum_r D |psi[r]|^2
 OP_EXPECT2 = 11  # measurement, Z-only strings grouped by register mask (gen 2): see encode_measure_pass
 FLAG_NOSTORE = 1
+FLAG_LAMBDA_ZERO = 2   # reverse sweep: lambda is not loaded, it starts as zero and is BORN in this pass (OP_XFOLD / OP_DFOLD)
 DIAG_CHUNK = 8
 MAX_DIAGB = 5  # more register-x-thread terms than this in one DIAG op: the per-thread sincos path is cheaper
 # G2 kinds: 0 general, 1 = CNOT(control ja, target jb), 2 = CNOT(control jb, target ja), 3 = SWAP
@@ -345,6 +348,8 @@ class Round:
     reg_tb: List[int]  # tile-bit index of each register bit
     thr_tb: List[int]  # tile-bit index of each thread bit
     gates: List[int]   # gate ids executed in this round (program order)
+    fold: List[Tuple[int, float, int]] = field(default_factory=list)   # (register bit, coefficient, fold index): OP_XFOLD ops at the start of the round
+    dfold: List[Tuple[int, float]] = field(default_factory=list)       # (Z mask over physical bits, coefficient): one OP_DFOLD at the start of the round
 
 
 @dataclass
@@ -554,6 +559,7 @@ class Tables:
     pending: list = field(default_factory=list)               # diagonal terms not emitted yet (lazy flush)
     shear2: set = field(default_factory=set)                  # gate ids applied in two-shear form (shear2_gates)
     scale_only: set = field(default_factory=set)              # ... whose factor needed a table of its own (no phase term to ride on)
+    fold_slots: dict = field(default_factory=dict)            # adjoint: gradient slot of folded Pauli term i (compile_adjoint_plan ``fold``)
     gslot_param: List[int] = field(default_factory=list)     # adjoint: parameter index per slot
     gslot_factor: List[float] = field(default_factory=list)  # adjoint: d(theta)/d(slot value)
 
@@ -1131,6 +1137,23 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
                 tables.pending = [t for t in tables.pending if not (qs & set(t.qubits))]
             return hit
 
+        if getattr(rd, "dfold", None):
+            assert backward
+            regmask_phys = 0
+            for j_, b_ in enumerate(rd.reg_tb):
+                regmask_phys |= 1 << pp.tile_bits[b_]
+            ops.extend([OP_DFOLD, len(rd.dfold), tables.fold_slots["diag"]])
+            for zm_, cf_ in rd.dfold:
+                rm_ = 0
+                for j_, b_ in enumerate(rd.reg_tb):
+                    if (zm_ >> pp.tile_bits[b_]) & 1:
+                        rm_ |= 1 << j_
+                ops.extend([zm_ & ~regmask_phys, rm_, tables.const_real(cf_)])
+            nops += 1
+        for (jf, cf_, fi_) in getattr(rd, "fold", []):
+            assert backward
+            ops.extend([OP_XFOLD, jf, tables.const_real(cf_), tables.fold_slots[fi_]])
+            nops += 1
         for gi in rd.gates:
             g = gates[gi]
             if g.is_diag:
@@ -1360,8 +1383,41 @@ def gate_has_param(g: GateRec) -> bool:
     return g.param is not None or (g.diag is not None and any(t.param is not None for t in g.diag))
 
 
+def fold_rounds(pp: PassPlan, cfg: PlanConfig, xterms: Sequence[Tuple[int, float, int]],
+                dterms: Optional[Sequence[Tuple[int, float]]] = None) -> None:
+    """Prepend to one pass of a reverse sweep the rounds in which terms of a Pauli-sum cotangent are BORN in registers:
+    ``xterms`` = [(physical bit inside the pass's tile, coefficient c, fold index)] stands for lambda += c X_bit psi (and the
+    energy c / 2 <X_bit>), ``dterms`` = [(Z mask over physical bits, coefficient)] for lambda += c Z...Z psi.  The tile's
+    bits that carry an X term are cycled through the register bits by rounds of their own BEFORE any gate of the pass runs,
+    starting in the load layout of the pass's first round (which also takes the diagonal terms: they need no particular
+    layout); the pass then continues with its own rounds.  Costs ceil(#bits / R) exchanges and 24 packed instructions per X
+    term and thread; saves the Pauli-sum passes (tcmi_apply_pauli_sum_tiled) that would have produced those terms."""
+    tb_of_phys = {p: i for i, p in enumerate(pp.tile_bits)}
+    todo = {tb_of_phys[p]: (i, float(c)) for (p, c, i) in xterms}
+    if not (todo or dterms) or not pp.rounds:
+        return
+    T, R = cfg.T, cfg.R
+    first = pp.rounds[0]
+    r0 = Round(list(first.reg_tb), list(first.thr_tb), [])
+    r0.fold = [(j, todo[b][1], todo[b][0]) for j, b in enumerate(r0.reg_tb) if b in todo]
+    r0.dfold = [(int(zm), float(c)) for zm, c in (dterms or [])]
+    pre = [r0]
+    rest = [b for b in sorted(todo) if b not in set(r0.reg_tb)]
+    while rest:
+        grp, rest = rest[:R], rest[R:]
+        fill = [b for b in range(T - 1, -1, -1) if b not in grp]
+        reg = sorted(grp + fill[: R - len(grp)])
+        thr = [b for b in range(T) if b not in reg]
+        rd = Round(reg, thr, [])
+        rd.fold = [(j, todo[b][1], todo[b][0]) for j, b in enumerate(reg) if b in grp]
+        pre.append(rd)
+    pp.rounds = pre + pp.rounds
+
+
 def compile_adjoint_plan(gates: List[GateRec], n: int, cfg: PlanConfig, factorized: bool = False,
-                         drop_constant_head: bool = False) -> AdjointPlan:
+                         drop_constant_head: bool = False, fold: Optional[Sequence[Tuple[int, float]]] = None,
+                         fold_param: int = 0, dfold: Optional[Sequence[Tuple[int, float]]] = None,
+                         lam_zero: bool = False) -> AdjointPlan:
     """Plan of the reversed circuit: gates in reverse order, each applied as U^dagger to both psi and
     the cotangent lambda, with one gradient slot per parametrised gate / diagonal term.  Valid for
     unitary gates (psi is un-computed, not stored).  ``factorized``: diagonal terms as OP_DIAGF (the
@@ -1374,6 +1430,29 @@ def compile_adjoint_plan(gates: List[GateRec], n: int, cfg: PlanConfig, factoriz
         last = max((i for i, g in enumerate(rev) if gate_has_param(g)), default=-1)
         rev = rev[: last + 1]
     passes = schedule(rev, n, cfg)
+    folded: List[int] = []
+    if fold or dfold:
+        # ``fold``: single-X terms c_i X_i of the cotangent lambda = (sum_i c_i X_i + sum_t d_t Z..Z) psi, ``dfold`` its
+        # Z-only strings: born in registers instead of arriving through memory (fold_rounds).  An X term is added by the
+        # FIRST pass whose tile holds its bit -- nothing that ran before touches that qubit (a gate needs its qubit in
+        # the tile, a diagonal term waits for the gates before it), so everything applied so far commutes with X_i, and so
+        # do the generators of the gradient events taken so far: lambda_k + c_i X_i psi_k IS the propagated full cotangent
+        # where it matters.  The diagonal strings are added at the very start of the sweep.  Energies c_i / 2 <X_i> and
+        # 1/2 sum_t d_t <Z..Z> arrive in gradient slots mapped to "parameter" ``fold_param``.  ``lam_zero``: every term of
+        # the cotangent is folded, lambda is never loaded by the first pass (FLAG_LAMBDA_ZERO).
+        assert factorized and cfg.gen >= 2
+        seen_bits, touched = set(), set()
+        for k, pp in enumerate(passes):
+            new_bits = [b for b in pp.tile_bits if b not in seen_bits]
+            xs = [(b, float(c), i) for i, (b, c) in enumerate(fold or [])
+                  if b in new_bits and (n - 1 - b) not in touched and i not in folded]
+            ds = list(dfold) if (dfold and k == 0) else None
+            if xs or ds:
+                fold_rounds(pp, cfg, xs, ds)
+                folded += [i for _, _, i in xs]
+            seen_bits |= set(pp.tile_bits)
+            for gi in pp.gate_ids:
+                touched |= set(rev[gi].qubits)
     sh2 = set()
     if cfg.shear2 and factorized:
         sh2 = shear2_gates(rev, [gi for pp in passes for rd in pp.rounds for gi in rd.gates], cfg)
@@ -1381,15 +1460,37 @@ def compile_adjoint_plan(gates: List[GateRec], n: int, cfg: PlanConfig, factoriz
         tables = Tables()
         tables.ctab += [0.0] * 8
         tables.shear2 = set(sh2)
-        descs = [encode_pass(rev, n, cfg, pp, tables, backward=True, final=(i == len(passes) - 1), factorized_bw=factorized)
-                 for i, pp in enumerate(passes)]
+        tables.fold_slots = {i: tables.grad_slot(int(fold_param), 1.0) for i in folded}
+        if dfold:
+            tables.fold_slots["diag"] = tables.grad_slot(int(fold_param), 1.0)
+        descs, crossing = [], set()
+        for i, pp in enumerate(passes):
+            if i > 0 and any(getattr(rd, "fold", None) for rd in pp.rounds):
+                # A two-shear rotation leaves a REAL factor diag(c, 1/c) pending on psi (its reciprocal on lambda) until the
+                # next phase table carries it.  Across the start of a pass that folds terms into lambda that would be wrong:
+                # the fold adds c X psi_memory to lambda_memory, and the two differ from the true vectors by that factor and
+                # its inverse.  Gates whose factor is still pending here take the three-shear form instead.
+                crossing |= {t.gate for t in tables.pending if t.scale}
+            descs.append(encode_pass(rev, n, cfg, pp, tables, backward=True, final=(i == len(passes) - 1),
+                                     factorized_bw=factorized))
+        if crossing:
+            sh2 -= crossing
+            continue
         if not tables.scale_only:
             break
         sh2 -= tables.scale_only   # as in compile_plan
-    return AdjointPlan(
+    ap = AdjointPlan(
         n=n, cfg=cfg, passes=passes, descs=descs, ctab=np.array(tables.ctab, dtype=np.float64),
         ptab_size=tables.ptab_size, ginfo=np.array(tables.ginfo, dtype=np.int32).reshape(-1, 8),
         cpool=np.array(tables.cpool, dtype=np.float64),
         gslot_param=np.array(tables.gslot_param, dtype=np.int64),
         gslot_factor=np.array(tables.gslot_factor, dtype=np.float64),
     )
+    if lam_zero:
+        assert folded or dfold
+        descs[0] = descs[0].copy()
+        descs[0][6] = descs[0][6] | FLAG_LAMBDA_ZERO
+        ap.descs = descs
+    ap.folded = sorted(folded)
+    ap.drop_constant_head = bool(drop_constant_head)
+    return ap

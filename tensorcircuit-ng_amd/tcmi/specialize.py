@@ -279,7 +279,7 @@ class _Emitter:
         for i, m in multi:
             out.append(f"  {name} ^= (0u - (({tid} >> {i}) & 1u)) & {(m << shift):#x}u;")
 
-    def tile_io(self, out: List[str], rd: _Round, store: bool, ptrs: Dict[str, str], tphys: str):
+    def tile_io(self, out: List[str], rd: _Round, store: bool, ptrs: Dict[str, str], tphys: str, vecs=None):
         """16-byte accesses, two amplitudes each (register bit 0 = the lowest physical bit of the tile)."""
         tt = self.toff_type()
         if rd.reg_phys[0] != 1 or self.tile_bits[0] != 0:
@@ -290,7 +290,7 @@ class _Emitter:
             out.append(f'  uint32_t {tp2} = {tphys}; asm volatile("" : "+v"({tp2}));')
             tphys = tp2
         out.append(f"  const {tt} {toff} = ({tt}){tphys} * 8u;")
-        for vec in self.vectors:
+        for vec in (self.vectors if vecs is None else vecs):
             base = self.fresh("gb")
             cq = "" if store else "const "
             out.append(f"  {cq}char* __restrict__ {base} = reinterpret_cast<{cq}char*>({ptrs[vec]} + wg_base);")
@@ -858,6 +858,7 @@ def pass_arithmetic(src: str) -> dict:
             tot[k] += v * cnt
     # Walsh transform lines: "const v2f a = lo + hi;" / "... = lo - hi;" = one packed add each
     tot["v_pk_add_f32"] += float(len(re.findall(r"const v2f \w+ = \w+ [+-] \w+;", src)))
+    tot["v_pk_fma_f32"] += float(src.count("__builtin_elementwise_fma("))      # Pauli-sum terms folded into a sweep pass
     folds = src.count("wave_fold8(")
     pk = tot["v_pk_fma_f32"] + tot["v_pk_mul_f32"] + tot["v_pk_add_f32"]
     flops = 64.0 * (4.0 * tot["v_pk_fma_f32"] + 2.0 * tot["v_pk_mul_f32"] + 2.0 * tot["v_pk_add_f32"])
@@ -1063,10 +1064,12 @@ def adjoint_opts(cfg) -> dict:
     return {"shear2": bool(cfg.shear2)}
 
 
-def precompile_circuit(c, adjoint: bool = True, forward: bool = True) -> dict:
+def precompile_circuit(c, adjoint: bool = True, forward: bool = True, fold_x=None, fold_z=None, nterms: int = 0) -> dict:
     """Compile (into the cache) the specialised kernels of the plans the executor will choose for circuit ``c``: the
     forward passes and, with ``adjoint``, the reverse sweeps a value_and_grad may run (short and full gate list, last pass
-    with and without write-back).  Host work only -- no GPU needed (hipcc cross-compiles)."""
+    with and without write-back).  ``fold_x`` = [(qubit, weight)] / ``fold_z`` = [(qubits, weight)] / ``nterms``: also the
+    sweep in which those single-X terms and Z-only strings of a Pauli-sum energy of ``nterms`` terms are born (executor.
+    fold_setup).  Host work only -- no GPU needed (hipcc cross-compiles)."""
     from . import cons
     from . import executor as X
 
@@ -1105,6 +1108,28 @@ def precompile_circuit(c, adjoint: bool = True, forward: bool = True) -> dict:
                 last[6] = last[6] | P.FLAG_NOSTORE
                 out.append(prepare("adjoint", [last], adjoint_opts(acfg))[0] is not None)
             res["adjoint" if not full else ("adjoint_zero_start" if zero else "adjoint_full")] = out
+        if fold_x:
+            plans = {}
+
+            def get_plan(full):
+                if full not in plans:
+                    r_ = X.choose_adjoint_plan(eg, n_exec, cons.dtypestr, full, full)
+                    if r_ is None:
+                        r_ = X.choose_adjoint_plan(eg, n_exec, cons.dtypestr, True, False)
+                    plans[full] = {"plan": r_[1], "cfg": r_[0]}
+                return plans[full]
+
+            adj0, _m, _f = X.pick_adjoint_from_zero(eg, n_exec, get_plan)
+            pad = n_exec - c._nqubits
+            xw = [(k, n_exec - 1 - (int(q) + pad), float(w)) for k, (q, w) in enumerate(fold_x)]
+            dw = [(len(xw) + k, sum(1 << (n_exec - 1 - (int(q) + pad)) for q in qs), float(w))
+                  for k, (qs, w) in enumerate(fold_z or [])]
+            fr = X.fold_plan_host(eg, n_exec, adj0, nparams, xw, dw, nterms) if adj0["cfg"].gen >= 2 else None
+            if fr is not None:
+                descs = [np.asarray(d) for d in fr[0].descs]
+                descs[-1] = descs[-1].copy()
+                descs[-1][6] = descs[-1][6] | P.FLAG_NOSTORE
+                res["adjoint_fold"] = [x is not None for x in prepare("adjoint", descs, adjoint_opts(adj0["cfg"]))]
     return res
 
 
@@ -1305,12 +1330,75 @@ class _Adjoint(_Forward):
             self.diagb_apply(sg2, jj, e, ("a", "l"))
         return qn
 
+    def xfold(self, q: int) -> int:
+        """{OP_XFOLD, j, cslot, gslot}: lambda[r] += c psi[r ^ (1 << j)] -- the term (c / 2) X_q of a Pauli-sum cotangent
+        2 sum_t w_t P_t |psi>, born in registers instead of arriving from a pass of tcmi_apply_pauli_sum_tiled (plan.py
+        fold_rounds) -- and its energy (c / 2) <X_q> = c sum_pairs Re(conj(psi_x) psi_y) as one gradient event."""
+        w = self.w
+        J, cslot, gslot = int(w[q + 1]), int(w[q + 2]), _i32(w[q + 3])
+        tab, off = self.slot_ptr(cslot)
+        sg = self.seg(f"X fold on register bit {J}")
+        c, e = self.fresh("xc"), self.fresh("xe")
+        sg.loads.append(f"  const float {c} = {tab}[{off}];")
+        p = sg.parts[0]
+        pr = self.pairs_of(J)
+        p.append(f"  v2f {e} = {self.A(pr[0][0], 'a')} * {self.A(pr[0][1], 'a')};")
+        for x, y in pr[1:]:
+            p.append(f"  {e} = __builtin_elementwise_fma({self.A(x, 'a')}, {self.A(y, 'a')}, {e});")
+        p = sg.new_part()
+        for x, y in pr:
+            p.append(f"  {self.A(x, 'l')} = __builtin_elementwise_fma(v2f{{{c}, {c}}}, {self.A(y, 'a')}, {self.A(x, 'l')}); "
+                     f"{self.A(y, 'l')} = __builtin_elementwise_fma(v2f{{{c}, {c}}}, {self.A(x, 'a')}, {self.A(y, 'l')});")
+        self.event(sg, f"{c} * ({e}.x + {e}.y)", gslot)
+        return q + 4
+
+    def dfold(self, q: int) -> int:
+        """{OP_DFOLD, nterms, gslot, (thread-side Z mask, register mask, cslot) * nterms}: lambda[r] += D[r] psi[r] with
+        D = sum_t c_t (-1)^{parity(index & zmask_t)} -- the Z-only strings of the cotangent 2 sum_t w_t P_t |psi> (c_t = 2 w_t),
+        born in registers -- and their energy 1/2 sum_r D[r] |psi[r]|^2 as one gradient event.  Per thread: one signed
+        coefficient per term, summed per register mask; D[r] = sum over the masks in use of +-that sum (plain float code)."""
+        w, NR = self.w, self.NR
+        nt, gslot = int(w[q + 1]), _i32(w[q + 2])
+        sg = self.seg("diagonal strings of the cotangent")
+        p = sg.parts[0]
+        t = self.fresh("df")
+        p.append(f"  const uint32_t {t}i = wg_base | {self.tphys};")
+        by_mask: Dict[int, List[str]] = {}
+        for e in range(nt):
+            zm, rm, cslot = _u32(w[q + 3 + 3 * e]), int(w[q + 4 + 3 * e]), int(w[q + 5 + 3 * e])
+            tab, off = self.slot_ptr(cslot)
+            c = f"{t}c{e}"
+            sg.loads.append(f"  const float {c} = {tab}[{off}];")
+            if zm:
+                p.append(f"  const float {t}s{e} = (__builtin_popcount({t}i & {zm:#x}u) & 1) ? -{c} : {c};")
+                by_mask.setdefault(rm, []).append(f"{t}s{e}")
+            else:
+                by_mask.setdefault(rm, []).append(c)
+        for rm, names in by_mask.items():
+            p.append(f"  const float {t}m{rm} = " + " + ".join(names) + ";")
+        p = sg.new_part()
+        acc = f"{t}e"
+        p.append(f"  v2f {acc} = v2f{{0.f, 0.f}};")
+        for r in range(NR):
+            terms = [("-" if bin(r & rm).count("1") & 1 else "+") + f" {t}m{rm}" for rm in by_mask]
+            expr = " ".join(terms)
+            expr = expr[2:] if expr.startswith("+ ") else expr
+            p.append(f"  {{ const float d_ = {expr}; const v2f dd_ = v2f{{d_, d_}}; "
+                     f"{acc} = __builtin_elementwise_fma(dd_, {self.A(r, 'a')} * {self.A(r, 'a')}, {acc}); "
+                     f"{self.A(r, 'l')} = __builtin_elementwise_fma(dd_, {self.A(r, 'a')}, {self.A(r, 'l')}); }}")
+        self.event(sg, f"0.5f * ({acc}.x + {acc}.y)", gslot)
+        return q + 3 + 3 * nt
+
     def op(self, q: int) -> int:
         op = int(self.w[q])
         if op == P.OP_G1M:
             return self.g1m(q)
         if op == P.OP_DIAGF:
             return self.diagf(q)
+        if op == P.OP_XFOLD:
+            return self.xfold(q)
+        if op == P.OP_DFOLD:
+            return self.dfold(q)
         raise Unsupported(f"backward op {op}")
 
     def lds_bytes(self) -> int:
@@ -1342,7 +1430,13 @@ class _Adjoint(_Forward):
         if int(self.opts.get("prio", 0)) & 1:
             sg.parts[0].append("  __builtin_amdgcn_s_setprio(3);")
         self.thread_xor(sg.parts[0], self.tphys, rd0.thr_phys)
-        self.tile_io(sg.parts[0], rd0, False, {"a": "psi", "l": "lam"}, self.tphys)
+        if self.flags & P.FLAG_LAMBDA_ZERO:
+            # every term of the cotangent is born in this pass (OP_XFOLD / OP_DFOLD): lambda is not read
+            self.tile_io(sg.parts[0], rd0, False, {"a": "psi"}, self.tphys, vecs=["a"])
+            for r in range(NR):
+                sg.parts[0].append(f"  {self.A(r, 'l')} = v2f{{0.f, 0.f}};")
+        else:
+            self.tile_io(sg.parts[0], rd0, False, {"a": "psi", "l": "lam"}, self.tphys)
         if int(self.opts.get("prio", 0)) & 1:
             sg.parts[0].append("  __builtin_amdgcn_s_setprio(0);")
         for k, rd in enumerate(self.rounds):

@@ -313,3 +313,66 @@ def test_generated_kernel_options_do_not_change_results(tc64):
         assert np.abs(res[""][2] - res[exp][2]).max() < 5e-6
     ref = dense.run(n, W.hea_b_ops(n, d, params))
     assert np.abs(res["xcd=1"][0] - ref).max() < 1e-5
+
+
+def test_pauli_terms_folded_into_the_sweep_match_the_plain_route_and_the_oracle(tc64):
+    """executor.fold_setup: in the traced value_and_grad (jit) the single-X terms of the TFIM on the qubits of the sweep's
+    first tile are added to lambda inside that pass (OP_XFOLD, generated kernels) and the Pauli-sum tile passes shrink.
+    With the fold on (default) and off (TCMI_PAULI_FOLD=0): same energy, same gradient; and both against oracle.dense
+    (energy, two central-difference gradient components)."""
+    tc = tc64
+    import torch
+    from tcmi import executor as X
+
+    n, d, B = 20, 3, 2
+    rng = np.random.default_rng(2020)
+    params_np = rng.uniform(0, 2 * np.pi, [B, 2 * d, n])
+
+    def energy(p):
+        c = tc.Circuit(n)
+        W.hea_b(c, n, d, p, zz=tc.gates._zz_matrix)
+        e = 0.0
+        for i in range(n):
+            e += -1.0 * c.expectation((tc.gates.x(), [i]))
+        for i in range(n - 1):
+            e += 1.0 * c.expectation((tc.gates.z(), [i]), (tc.gates.z(), [i + 1]))
+        return tc.backend.real(e)
+
+    os.environ["TCMI_SPECIALIZE"] = "1"
+    old = os.environ.get("TCMI_PAULI_FOLD")
+    res = {}
+    try:
+        for flag in ("1", "0"):
+            os.environ["TCMI_PAULI_FOLD"] = flag
+            X._CACHE.clear()
+            f = tc.backend.jit(tc.backend.vvag(energy, argnums=0, vectorized_argnums=0))
+            p = torch.from_numpy(params_np.astype(np.float32)).cuda()
+            for _ in range(3):
+                v, g = f(p)
+            torch.cuda.synchronize()
+            X.EVENT_LOG = []                      # the fourth call runs the traced pipeline: its launches alone
+            v, g = f(p)
+            torch.cuda.synchronize()
+            launches = sum(e[3] for e in X.EVENT_LOG if e[0] == "pauli_sum")
+            X.EVENT_LOG = None
+            res[flag] = (v.cpu().numpy().astype(np.float64), g.cpu().numpy().astype(np.float64), launches)
+    finally:
+        X.EVENT_LOG = None
+        if old is None:
+            os.environ.pop("TCMI_PAULI_FOLD", None)
+        else:
+            os.environ["TCMI_PAULI_FOLD"] = old
+        X._CACHE.clear()
+    assert res["1"][2] == 0 and res["0"][2] >= 2, (res["1"][2], res["0"][2])   # the fold really ran: NO Pauli-sum pass at all
+    assert np.abs(res["1"][0] - res["0"][0]).max() < 2e-5
+    assert np.abs(res["1"][1] - res["0"][1]).max() < 2e-5
+    p64 = params_np.astype(np.float32).astype(np.float64)
+    ref = lambda q: W.tfim_energy_dense(dense.run(n, W.hea_b_ops(n, d, q)), n)  # noqa: E731
+    assert abs(res["1"][0][0] - ref(p64[0])) < 2e-4
+    eps = 1e-5
+    for (r, q) in ((1, 2), (4, 17)):
+        pp, pm = p64[0].copy(), p64[0].copy()
+        pp[r, q] += eps
+        pm[r, q] -= eps
+        fd = (ref(pp) - ref(pm)) / (2 * eps)
+        assert abs(res["1"][1][0, r, q] - fd) < 2e-4, ((r, q), res["1"][1][0, r, q], fd)

@@ -274,15 +274,18 @@ def test_structure_cache_key():
 
 
 def test_unsupported_gates_raise():
-    """Dense gates on 3-5 qubits are synthesised (tcmi/synth.py); what stays unsupported fails loudly."""
+    """Dense gates on 3-8 qubits are synthesised (tcmi/synth.py); what stays unsupported fails loudly."""
     c = tc.Circuit(14)
     c.toffoli(0, 1, 2)
     _, cfg = pick_variant(14, "complex64")
     P.compile_plan(c._gate_records(), 14, cfg)
     with pytest.raises(NotImplementedError):
         c.any(0, 1, 2, unitary=np.arange(64).reshape((2,) * 6))          # non-unitary 3-qubit tensor
+    c6 = tc.Circuit(14)
+    c6.any(0, 1, 2, 3, 4, 5, unitary=np.eye(64)[::-1].reshape((2,) * 12))     # dense on 6 qubits: exact synthesis
+    P.compile_plan(c6._gate_records(), 14, cfg)
     with pytest.raises(NotImplementedError):
-        c.any(0, 1, 2, 3, 4, 5, unitary=np.eye(64)[::-1].reshape((2,) * 12))  # dense on 6 qubits
+        c.any(*range(9), unitary=np.eye(512))                                  # dense on 9 qubits
     raw = P.GateRec((0, 1, 2), c0=np.eye(8)[::-1].copy(), name="raw3")
     with pytest.raises(NotImplementedError):
         P.compile_plan([raw], 14, cfg)
@@ -686,3 +689,94 @@ def test_live_tile_masks_cover_every_nonzero_amplitude():
         if r is not None:
             m2, _ = X.live_masks(r[1].descs, n_exec, start_bits=start, reverse=True)
             assert all(m == X.LIVE_FULL for m in m2)
+
+
+def test_pauli_terms_folded_into_the_first_sweep_pass():
+    """plan.fold_rounds / OP_XFOLD: the single-X terms of the TFIM cotangent lambda = 2 sum_t w_t P_t |psi> on the qubits of
+    the sweep's first tile are added to lambda in registers by that pass.  On the CPU emulator: the gradient of the folded
+    sweep started from the PARTIAL cotangent equals the gradient of the plain sweep started from the full one, and the
+    folded terms' energy arrives in the extra gradient slot."""
+    n, d = 14, 3
+    rng = np.random.default_rng(3)
+    params = rng.uniform(0, 2 * np.pi, [2 * d, n])
+    c = tc.Circuit(n)
+    W.hea_b(c, n, d, params, zz=tc.gates._zz_matrix)
+    recs = c._gate_records()
+    vals = np.array([float(x) for x in c._params])
+    cfg = P.PlanConfig(R=4, LT=8, lowbits=3, vec=2, gen=2, shear2=True)
+    psi = dense.run(n, W.hea_b_ops(n, d, params))
+    h, J = -1.0, 1.0
+
+    def X(q, v):
+        return v.reshape(2**q, 2, -1)[:, ::-1, :].reshape(-1)
+
+    idx = np.arange(2**n)
+    lam = np.zeros_like(psi)
+    for q in range(n):
+        lam += 2 * h * X(q, psi)
+    for q in range(n - 1):
+        lam += 2 * J * (1 - 2 * ((idx >> (n - 1 - q)) & 1)) * (1 - 2 * ((idx >> (n - 2 - q)) & 1)) * psi
+    ap0 = P.compile_adjoint_plan(recs, n, cfg, factorized=True)
+    g0, _ = E.run_adjoint_plan(ap0, vals, psi, lam, len(vals))
+    fold = [(n - 1 - q, 2 * h) for q in range(n)]
+    ap1 = P.compile_adjoint_plan(recs, n, cfg, factorized=True, fold=fold, fold_param=len(vals))
+    tile0 = set(ap0.passes[0].tile_bits)
+    assert {fold[i][0] for i in ap1.folded} >= tile0 and len(tile0) == cfg.T       # (later passes fold the bits they bring)
+    assert [pp.tile_bits for pp in ap1.passes] == [pp.tile_bits for pp in ap0.passes]       # same passes, same live tiles
+    part = lam.copy()
+    for i in ap1.folded:
+        part -= 2 * h * X(n - 1 - fold[i][0], psi)
+    g1, _ = E.run_adjoint_plan(ap1, vals, psi, part, len(vals) + 1)
+    assert np.abs(g1[: len(vals)] - g0).max() < 1e-12 and np.abs(g0).max() > 0.1
+    want = sum(h * np.real(np.vdot(psi, X(n - 1 - fold[i][0], psi))) for i in ap1.folded)
+    assert abs(g1[len(vals)] - want) < 1e-12
+    # the generated kernel of the folded pass: emitted, OP_XFOLD in its source
+    from tcmi import specialize as S
+
+    src, meta = S._source("adjoint", np.asarray(ap1.descs[0]), S.adjoint_opts(cfg), 0)
+    assert src.count("X fold on register bit") == cfg.T          # the first pass folds the twelve bits of its tile
+
+
+def test_whole_pauli_sum_cotangent_born_in_the_sweep():
+    """Every term of the TFIM cotangent folded (compile_adjoint_plan fold= / dfold= / lam_zero): X terms by the first pass
+    whose tile holds their qubit (two-shear rotations whose real factor would still be pending across such a pass boundary
+    fall back to three shears), ZZ strings at the start, lambda never loaded (FLAG_LAMBDA_ZERO: the emulator is handed
+    noise for it).  Gradient = the plain sweep's on the full cotangent; the extra slot = the energy."""
+    n, d = 16, 3
+    rng = np.random.default_rng(3)
+    params = rng.uniform(0, 2 * np.pi, [2 * d, n])
+    c = tc.Circuit(n)
+    W.hea_b(c, n, d, params, zz=tc.gates._zz_matrix)
+    recs = c._gate_records()
+    vals = np.array([float(x) for x in c._params])
+    cfg = P.PlanConfig(R=4, LT=8, lowbits=3, vec=2, gen=2, shear2=True)
+    psi = dense.run(n, W.hea_b_ops(n, d, params))
+    h, J = -1.0, 1.0
+
+    def X(q, v):
+        return v.reshape(2**q, 2, -1)[:, ::-1, :].reshape(-1)
+
+    idx = np.arange(2**n)
+    zz = np.zeros(2**n)
+    for q in range(n - 1):
+        zz += J * (1 - 2 * ((idx >> (n - 1 - q)) & 1)) * (1 - 2 * ((idx >> (n - 2 - q)) & 1))
+    lam = 2 * zz * psi
+    for q in range(n):
+        lam = lam + 2 * h * X(q, psi)
+    ap0 = P.compile_adjoint_plan(recs, n, cfg, factorized=True)
+    assert len(ap0.passes) >= 2                       # X terms are folded in more than one pass
+    g0, _ = E.run_adjoint_plan(ap0, vals, psi, lam, len(vals))
+    fold = [(n - 1 - q, 2 * h) for q in range(n)]
+    dfold = [((1 << (n - 1 - q)) | (1 << (n - 2 - q)), 2 * J) for q in range(n - 1)]
+    ap1 = P.compile_adjoint_plan(recs, n, cfg, factorized=True, fold=fold, fold_param=len(vals), dfold=dfold, lam_zero=True)
+    assert ap1.folded == list(range(n))
+    assert int(np.asarray(ap1.descs[0]).view(np.int32)[6]) & P.FLAG_LAMBDA_ZERO
+    noise = rng.normal(size=2**n) + 1j * rng.normal(size=2**n)
+    g1, _ = E.run_adjoint_plan(ap1, vals, psi, noise, len(vals) + 1)
+    assert np.abs(g1[: len(vals)] - g0).max() < 1e-12 and np.abs(g0).max() > 0.1
+    energy = sum(h * np.real(np.vdot(psi, X(q, psi))) for q in range(n)) + float(np.sum(zz * np.abs(psi) ** 2))
+    assert abs(g1[len(vals)] - energy) < 1e-12
+    from tcmi import specialize as S
+
+    src, _ = S._source("adjoint", np.asarray(ap1.descs[0]), S.adjoint_opts(cfg), 0)
+    assert "diagonal strings of the cotangent" in src and "lam + wg_base" not in src.split("// -- ")[1]
