@@ -539,13 +539,14 @@ def run_adjoint_pass(psi, lam, desc, ctab, ptab_row, gout):
                 q += 3 + 3 * nt_
             elif op == OP_XFOLD:
                 # {12, j, cslot, gslot}: lambda += c X_j psi on register bit j, energy slot += c sum_pairs Re(conj(psi_x) psi_y)
-                j, c_, gs_ = int(d[q + 1]), float(tab(d[q + 2], 1)[0]), int(dsig[q + 3])
+                j, kd_, c_, gs_ = int(d[q + 1]) & 0xFF, int(d[q + 1]) >> 8, float(tab(d[q + 2], 1)[0]), int(dsig[q + 3])
                 r0 = rid[((rid >> j) & 1) == 0]
                 r1 = r0 | (1 << j)
                 a0, a1 = regs[0][..., r0].copy(), regs[0][..., r1].copy()
-                regs[1][..., r0] += c_ * a1
-                regs[1][..., r1] += c_ * a0
-                gout[gs_] += c_ * np.sum(np.real(np.conj(a0) * a1))
+                f01, f10 = (1.0, 1.0) if kd_ == 0 else (-1j, 1j)        # P[0, 1], P[1, 0] of X / Y
+                regs[1][..., r0] += c_ * f01 * a1
+                regs[1][..., r1] += c_ * f10 * a0
+                gout[gs_] += c_ * np.sum(np.real(np.conj(a0) * f01 * a1))
                 q += 4
             elif op == OP_G2:
                 ja, kind, jb = int(d[q + 1]) & 0xFF, int(d[q + 1]) >> 8, int(d[q + 2])

@@ -293,22 +293,25 @@ def pick_adjoint_from_zero(exec_gates, n_exec: int, get_plan):
 def fold_plan_host(exec_gates, n_exec: int, adj0: dict, nparams: int, xw, dw=(), nterms: int = 0):
     """Host part of CompiledCircuit.fold_setup (also run by specialize.precompile_circuit, without a GPU): the sweep plan
     of ``adj0`` (record of _adjoint_from_zero: its tile configuration and gate list) recompiled with terms of the Pauli-sum
-    cotangent born in registers -- ``xw`` = [(term index, physical bit, weight)]: single-X terms, each folded into the first
+    cotangent born in registers -- ``xw`` = [(term index, physical bit, weight[, kind])]: single-X (kind 0) / single-Y (kind 1) terms, each folded into the first
     pass whose tile holds its bit; ``dw`` = [(term index, Z mask over physical bits, weight)]: Z-only strings, folded at
     the start of the sweep.  ``nterms`` = number of terms of the whole sum: when every one of them is folded the first pass
     does not load lambda at all (FLAG_LAMBDA_ZERO).  Returns (AdjointPlan, indices of the folded terms, lam_zero) or None
     when fewer than four X terms qualify or the schedule moved."""
     ap0 = adj0["plan"]
     seen, xs = set(), []
-    for k, bit, w in xw:
-        if bit not in seen and float(w) != 0.0:
+    for item in xw:
+        k, bit, w = item[:3]
+        kind = int(item[3]) if len(item) > 3 else 0      # 0: X, 1: Y
+        if bit not in seen and float(w) != 0.0:          # (one folded term per qubit: a second one takes the tile passes)
             seen.add(bit)
-            xs.append((k, bit, 2.0 * float(w)))
+            xs.append((k, bit, 2.0 * float(w), kind))
     ds = [(k, int(zm), 2.0 * float(w)) for k, zm, w in dw if float(w) != 0.0]
     if len(xs) < 4:
         return None
     kw = dict(factorized=True, drop_constant_head=bool(getattr(ap0, "drop_constant_head", False)),
-              fold=[(bit, c) for _, bit, c in xs], fold_param=nparams, dfold=[(zm, c) for _, zm, c in ds] or None)
+              fold=[(bit, c, kind) for _, bit, c, kind in xs], fold_param=nparams,
+              dfold=[(zm, c) for _, zm, c in ds] or None)
     ap = P.compile_adjoint_plan(exec_gates, n_exec, adj0["cfg"], **kw)
     if [pp.tile_bits for pp in ap.passes] != [pp.tile_bits for pp in ap0.passes] or len(ap.folded) < 4:
         return None
@@ -577,14 +580,17 @@ class CompiledCircuit:
         if (os.environ.get("TCMI_PAULI_FOLD", "1") == "0" or not SPARSE_START or self.dtypestr != "complex64"
                 or self.nonunitary or self.cfg.gen < 2 or S.mode() == "0"):
             return None
-        key = (id(cm), tuple(float(w) for w in weights))
+        # keyed by the terms themselves (an id() could be reused by another measurement object after this one is evicted)
+        key = (tuple((tuple(t.x), tuple(t.z)) for t in cm.all_terms), tuple(float(w) for w in weights))
         cache = self.__dict__.setdefault("_fold_cache", {})
         if key not in cache:
             cache[key] = None
             adj0, masks, fracs = self._adjoint_from_zero()
             if adj0["cfg"].gen >= 2 and adj0["plan"].descs and any(m != LIVE_FULL for m in masks):
                 n = self.n_exec
-                xw = [(k, n - 1 - t.x[0], float(weights[k])) for k, t in enumerate(cm.all_terms) if len(t.x) == 1 and not t.z]
+                # single X (x = (q,), z = ()) and single Y (x = z = (q,)) strings; Z-only strings; everything else stays
+                xw = [(k, n - 1 - t.x[0], float(weights[k]), 0 if not t.z else 1) for k, t in enumerate(cm.all_terms)
+                      if len(t.x) == 1 and (not t.z or tuple(t.z) == tuple(t.x))]
                 dw = [(k, sum(1 << (n - 1 - q) for q in t.z), float(weights[k])) for k, t in enumerate(cm.all_terms)
                       if not t.x and t.z]
                 res = fold_plan_host(self._exec_gates, n, adj0, self.nparams, xw, dw, len(cm.all_terms))

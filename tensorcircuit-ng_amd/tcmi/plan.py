@@ -46,7 +46,7 @@ OP_DIAGC = 6   # diagonal terms on register bits only: multiply by a 2^R table o
 OP_DIAGB2 = 9  # two register-x-thread terms on the same register bit: {9, j, mask1, mask2, slot}, table of 4 factors (gen 2)
 OP_DIAGCW = 10  # DIAGC whose table is picked per wave: {10, slot, nsel, m0, m1, m2}, variant = sum_k parity(wave index & m_k) << k, table of 2^nsel * 2^R factors (gen 2): register-x-thread terms whose thread bits are wave-uniform cost no multiply of their own
 OP_DIAGF = 8   # backward (adjoint sweep) flush of diagonal terms in table form: see encode_pass
-OP_XFOLD = 12   # reverse sweep, plan-specialised kernels only: {12, j, cslot, gslot}: lambda[r] += c psi[r ^ (1 << j)] (c = ctab[cslot], real) and gradient slot gslot += c sum_pairs Re(conj(psi_x) psi_y): the term c/2 X_q of a Pauli-sum cotangent born in registers (compile_adjoint_plan ``fold``)
+OP_XFOLD = 12   # reverse sweep, plan-specialised kernels only: {12, j | kind << 8, cslot, gslot}: lambda += c P psi with P = X (kind 0) or Y (kind 1) on register bit j (c = ctab[cslot], real) and gradient slot gslot += c/2 <psi|P|psi> of the tile: the term c/2 P_q of a Pauli-sum cotangent born in registers (compile_adjoint_plan ``fold``)
 OP_DFOLD = 13   # reverse sweep, plan-specialised kernels only: {13, nterms, gslot, (thread-side Z mask over physical bits, register mask, cslot) * nterms}: lambda[r] += D psi[r] with D = sum_t c_t (-1)^{parity(index & zmask_t)} (the Z-only strings of a Pauli-sum cotangent, register part of every mask split off for the round's layout) and gradient slot gslot += 1/2 sum_r D |psi[r]|^2
 OP_EXPECT2 = 11  # measurement, Z-only strings grouped by register mask (gen 2): see encode_measure_pass
 FLAG_NOSTORE = 1
@@ -348,7 +348,7 @@ class Round:
     reg_tb: List[int]  # tile-bit index of each register bit
     thr_tb: List[int]  # tile-bit index of each thread bit
     gates: List[int]   # gate ids executed in this round (program order)
-    fold: List[Tuple[int, float, int]] = field(default_factory=list)   # (register bit, coefficient, fold index): OP_XFOLD ops at the start of the round
+    fold: List[Tuple[int, float, int, int]] = field(default_factory=list)   # (register bit, coefficient, fold index, kind 0 = X / 1 = Y): OP_XFOLD ops at the start of the round
     dfold: List[Tuple[int, float]] = field(default_factory=list)       # (Z mask over physical bits, coefficient): one OP_DFOLD at the start of the round
 
 
@@ -1150,9 +1150,9 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
                         rm_ |= 1 << j_
                 ops.extend([zm_ & ~regmask_phys, rm_, tables.const_real(cf_)])
             nops += 1
-        for (jf, cf_, fi_) in getattr(rd, "fold", []):
+        for (jf, cf_, fi_, kd_) in getattr(rd, "fold", []):
             assert backward
-            ops.extend([OP_XFOLD, jf, tables.const_real(cf_), tables.fold_slots[fi_]])
+            ops.extend([OP_XFOLD, jf | (int(kd_) << 8), tables.const_real(cf_), tables.fold_slots[fi_]])
             nops += 1
         for gi in rd.gates:
             g = gates[gi]
@@ -1386,20 +1386,20 @@ def gate_has_param(g: GateRec) -> bool:
 def fold_rounds(pp: PassPlan, cfg: PlanConfig, xterms: Sequence[Tuple[int, float, int]],
                 dterms: Optional[Sequence[Tuple[int, float]]] = None) -> None:
     """Prepend to one pass of a reverse sweep the rounds in which terms of a Pauli-sum cotangent are BORN in registers:
-    ``xterms`` = [(physical bit inside the pass's tile, coefficient c, fold index)] stands for lambda += c X_bit psi (and the
-    energy c / 2 <X_bit>), ``dterms`` = [(Z mask over physical bits, coefficient)] for lambda += c Z...Z psi.  The tile's
+    ``xterms`` = [(physical bit inside the pass's tile, coefficient c, fold index, kind)] stands for lambda += c P_bit psi
+    (P = X for kind 0, Y for kind 1; and the energy c / 2 <P_bit>), ``dterms`` = [(Z mask over physical bits, coefficient)] for lambda += c Z...Z psi.  The tile's
     bits that carry an X term are cycled through the register bits by rounds of their own BEFORE any gate of the pass runs,
     starting in the load layout of the pass's first round (which also takes the diagonal terms: they need no particular
     layout); the pass then continues with its own rounds.  Costs ceil(#bits / R) exchanges and 24 packed instructions per X
     term and thread; saves the Pauli-sum passes (tcmi_apply_pauli_sum_tiled) that would have produced those terms."""
     tb_of_phys = {p: i for i, p in enumerate(pp.tile_bits)}
-    todo = {tb_of_phys[p]: (i, float(c)) for (p, c, i) in xterms}
+    todo = {tb_of_phys[p]: (i, float(c), int(kd)) for (p, c, i, kd) in xterms}
     if not (todo or dterms) or not pp.rounds:
         return
     T, R = cfg.T, cfg.R
     first = pp.rounds[0]
     r0 = Round(list(first.reg_tb), list(first.thr_tb), [])
-    r0.fold = [(j, todo[b][1], todo[b][0]) for j, b in enumerate(r0.reg_tb) if b in todo]
+    r0.fold = [(j, todo[b][1], todo[b][0], todo[b][2]) for j, b in enumerate(r0.reg_tb) if b in todo]
     r0.dfold = [(int(zm), float(c)) for zm, c in (dterms or [])]
     pre = [r0]
     rest = [b for b in sorted(todo) if b not in set(r0.reg_tb)]
@@ -1409,7 +1409,7 @@ def fold_rounds(pp: PassPlan, cfg: PlanConfig, xterms: Sequence[Tuple[int, float
         reg = sorted(grp + fill[: R - len(grp)])
         thr = [b for b in range(T) if b not in reg]
         rd = Round(reg, thr, [])
-        rd.fold = [(j, todo[b][1], todo[b][0]) for j, b in enumerate(reg) if b in grp]
+        rd.fold = [(j, todo[b][1], todo[b][0], todo[b][2]) for j, b in enumerate(reg) if b in grp]
         pre.append(rd)
     pp.rounds = pre + pp.rounds
 
@@ -1444,12 +1444,12 @@ def compile_adjoint_plan(gates: List[GateRec], n: int, cfg: PlanConfig, factoriz
         seen_bits, touched = set(), set()
         for k, pp in enumerate(passes):
             new_bits = [b for b in pp.tile_bits if b not in seen_bits]
-            xs = [(b, float(c), i) for i, (b, c) in enumerate(fold or [])
-                  if b in new_bits and (n - 1 - b) not in touched and i not in folded]
+            xs = [(f_[0], float(f_[1]), i, int(f_[2]) if len(f_) > 2 else 0) for i, f_ in enumerate(fold or [])
+                  if f_[0] in new_bits and (n - 1 - f_[0]) not in touched and i not in folded]
             ds = list(dfold) if (dfold and k == 0) else None
             if xs or ds:
                 fold_rounds(pp, cfg, xs, ds)
-                folded += [i for _, _, i in xs]
+                folded += [i for _, _, i, _ in xs]
             seen_bits |= set(pp.tile_bits)
             for gi in pp.gate_ids:
                 touched |= set(rev[gi].qubits)

@@ -1335,21 +1335,33 @@ class _Adjoint(_Forward):
         2 sum_t w_t P_t |psi>, born in registers instead of arriving from a pass of tcmi_apply_pauli_sum_tiled (plan.py
         fold_rounds) -- and its energy (c / 2) <X_q> = c sum_pairs Re(conj(psi_x) psi_y) as one gradient event."""
         w = self.w
-        J, cslot, gslot = int(w[q + 1]), int(w[q + 2]), _i32(w[q + 3])
+        J, kind, cslot, gslot = int(w[q + 1]) & 0xFF, int(w[q + 1]) >> 8, int(w[q + 2]), _i32(w[q + 3])
         tab, off = self.slot_ptr(cslot)
-        sg = self.seg(f"X fold on register bit {J}")
+        sg = self.seg(f"{'XY'[kind]} fold on register bit {J}")
         c, e = self.fresh("xc"), self.fresh("xe")
         sg.loads.append(f"  const float {c} = {tab}[{off}];")
         p = sg.parts[0]
         pr = self.pairs_of(J)
-        p.append(f"  v2f {e} = {self.A(pr[0][0], 'a')} * {self.A(pr[0][1], 'a')};")
-        for x, y in pr[1:]:
-            p.append(f"  {e} = __builtin_elementwise_fma({self.A(x, 'a')}, {self.A(y, 'a')}, {e});")
-        p = sg.new_part()
-        for x, y in pr:
-            p.append(f"  {self.A(x, 'l')} = __builtin_elementwise_fma(v2f{{{c}, {c}}}, {self.A(y, 'a')}, {self.A(x, 'l')}); "
-                     f"{self.A(y, 'l')} = __builtin_elementwise_fma(v2f{{{c}, {c}}}, {self.A(x, 'a')}, {self.A(y, 'l')});")
-        self.event(sg, f"{c} * ({e}.x + {e}.y)", gslot)
+        if kind == 0:
+            # energy: c sum_pairs Re(conj(a_x) a_y) = c sum (x.x y.x + x.y y.y)
+            p.append(f"  v2f {e} = {self.A(pr[0][0], 'a')} * {self.A(pr[0][1], 'a')};")
+            for x, y in pr[1:]:
+                p.append(f"  {e} = __builtin_elementwise_fma({self.A(x, 'a')}, {self.A(y, 'a')}, {e});")
+            p = sg.new_part()
+            for x, y in pr:
+                p.append(f"  {self.A(x, 'l')} = __builtin_elementwise_fma(v2f{{{c}, {c}}}, {self.A(y, 'a')}, {self.A(x, 'l')}); "
+                         f"{self.A(y, 'l')} = __builtin_elementwise_fma(v2f{{{c}, {c}}}, {self.A(x, 'a')}, {self.A(y, 'l')});")
+            self.event(sg, f"{c} * ({e}.x + {e}.y)", gslot)
+        else:
+            # Y: (Y a)_x = -i a_y, (Y a)_y = +i a_x; energy: c sum_pairs Re(conj(a_x) (-i a_y)) = c sum (x.x y.y - x.y y.x)
+            p.append(f"  v2f {e} = {self.A(pr[0][0], 'a')} * {self.A(pr[0][1], 'a')}.yx;")
+            for x, y in pr[1:]:
+                p.append(f"  {e} = __builtin_elementwise_fma({self.A(x, 'a')}, {self.A(y, 'a')}.yx, {e});")
+            p = sg.new_part()
+            for x, y in pr:
+                p.append(f"  {self.A(x, 'l')} = __builtin_elementwise_fma(v2f{{{c}, -{c}}}, {self.A(y, 'a')}.yx, {self.A(x, 'l')}); "
+                         f"{self.A(y, 'l')} = __builtin_elementwise_fma(v2f{{-{c}, {c}}}, {self.A(x, 'a')}.yx, {self.A(y, 'l')});")
+            self.event(sg, f"{c} * ({e}.x - {e}.y)", gslot)
         return q + 4
 
     def dfold(self, q: int) -> int:

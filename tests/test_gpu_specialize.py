@@ -376,3 +376,67 @@ def test_pauli_terms_folded_into_the_sweep_match_the_plain_route_and_the_oracle(
         pm[r, q] -= eps
         fd = (ref(pp) - ref(pm)) / (2 * eps)
         assert abs(res["1"][1][0, r, q] - fd) < 2e-4, ((r, q), res["1"][1][0, r, q], fd)
+
+
+def test_partial_fold_with_y_fields_and_strings_that_stay_in_the_tile_passes(tc64):
+    """A Hamiltonian of which only a part folds: alternating X / Y fields (OP_XFOLD kinds 0 / 1), a Z field and the ZZ chain
+    (OP_DFOLD) are born in the sweep, two XX strings and one XYZ string are not -- they keep going through
+    tcmi_apply_pauli_sum_tiled, and lambda IS loaded by the first pass (no FLAG_LAMBDA_ZERO).  Fold on / off agree; the
+    energy equals the dense oracle's."""
+    tc = tc64
+    import torch
+    from tcmi import executor as X
+
+    n, d = 20, 3
+    rng = np.random.default_rng(77)
+    params_np = rng.uniform(0, 2 * np.pi, [2 * d, n])
+    wf, wz = rng.normal(size=n), rng.normal(size=n)
+
+    def energy(p):
+        c = tc.Circuit(n)
+        W.hea_b(c, n, d, p, zz=tc.gates._zz_matrix)
+        e = 0.0
+        for i in range(n):
+            e += float(wf[i]) * (c.expectation_ps(y=[i]) if i % 2 else c.expectation_ps(x=[i]))
+            e += float(wz[i]) * c.expectation_ps(z=[i])
+        for i in range(n - 1):
+            e += 0.7 * c.expectation_ps(z=[i, i + 1])
+        e += 0.31 * c.expectation_ps(x=[3, 4]) - 0.22 * c.expectation_ps(x=[11, 17]) + 0.5 * c.expectation_ps(x=[6], y=[7], z=[9])
+        return tc.backend.real(e)
+
+    os.environ["TCMI_SPECIALIZE"] = "1"
+    old = os.environ.get("TCMI_PAULI_FOLD")
+    res = {}
+    try:
+        for flag in ("1", "0"):
+            os.environ["TCMI_PAULI_FOLD"] = flag
+            X._CACHE.clear()
+            f = tc.backend.jit(tc.backend.value_and_grad(energy))
+            p = torch.from_numpy(params_np.astype(np.float32)).cuda()
+            for _ in range(3):
+                v, g = f(p)
+            torch.cuda.synchronize()
+            X.EVENT_LOG = []
+            v, g = f(p)
+            torch.cuda.synchronize()
+            launches = sum(e[3] for e in X.EVENT_LOG if e[0] == "pauli_sum")
+            X.EVENT_LOG = None
+            res[flag] = (float(v), g.cpu().numpy().astype(np.float64), launches)
+    finally:
+        X.EVENT_LOG = None
+        if old is None:
+            os.environ.pop("TCMI_PAULI_FOLD", None)
+        else:
+            os.environ["TCMI_PAULI_FOLD"] = old
+        X._CACHE.clear()
+    assert 0 < res["1"][2] < res["0"][2], (res["1"][2], res["0"][2])      # fewer tile passes, but not none
+    assert abs(res["1"][0] - res["0"][0]) < 3e-5 and np.abs(res["1"][1] - res["0"][1]).max() < 3e-5
+    psi = dense.run(n, W.hea_b_ops(n, d, params_np.astype(np.float32).astype(np.float64)))
+    ref = 0.0
+    for i in range(n):
+        ref += wf[i] * dense.expectation(psi, n, (G.Y if i % 2 else G.X, [i])).real + wz[i] * dense.expectation(psi, n, (G.Z, [i])).real
+    for i in range(n - 1):
+        ref += 0.7 * dense.expectation(psi, n, (G.Z, [i]), (G.Z, [i + 1])).real
+    ref += 0.31 * dense.expectation(psi, n, (G.X, [3]), (G.X, [4])).real - 0.22 * dense.expectation(psi, n, (G.X, [11]), (G.X, [17])).real
+    ref += 0.5 * dense.expectation(psi, n, (G.X, [6]), (G.Y, [7]), (G.Z, [9])).real
+    assert abs(res["1"][0] - ref) < 2e-4, (res["1"][0], ref)

@@ -780,3 +780,44 @@ def test_whole_pauli_sum_cotangent_born_in_the_sweep():
 
     src, _ = S._source("adjoint", np.asarray(ap1.descs[0]), S.adjoint_opts(cfg), 0)
     assert "diagonal strings of the cotangent" in src and "lam + wg_base" not in src.split("// -- ")[1]
+
+
+def test_single_y_and_z_field_terms_fold_too():
+    """OP_XFOLD kind 1 (single Y) and Z-only strings of one factor: alternating X / Y fields with random weights plus a Z
+    field, every term born in the sweep; against the plain sweep on the full cotangent (emulator)."""
+    n, d = 14, 3
+    rng = np.random.default_rng(4)
+    params = rng.uniform(0, 2 * np.pi, [2 * d, n])
+    c = tc.Circuit(n)
+    W.hea_b(c, n, d, params, zz=tc.gates._zz_matrix)
+    recs = c._gate_records()
+    vals = np.array([float(x) for x in c._params])
+    cfg = P.PlanConfig(R=4, LT=8, lowbits=3, vec=2, gen=2, shear2=True)
+    psi = dense.run(n, W.hea_b_ops(n, d, params))
+
+    def Xq(q, v):
+        return v.reshape(2**q, 2, -1)[:, ::-1, :].reshape(-1)
+
+    def Yq(q, v):
+        t = v.reshape(2**q, 2, -1)
+        o = np.empty_like(t)
+        o[:, 0, :], o[:, 1, :] = -1j * t[:, 1, :], 1j * t[:, 0, :]
+        return o.reshape(-1)
+
+    idx = np.arange(2**n)
+    wy, wz = rng.normal(size=n), rng.normal(size=n)
+    lam, energy = np.zeros_like(psi), 0.0
+    for q in range(n):
+        pq = (Yq if q % 2 else Xq)(q, psi)
+        lam += 2 * wy[q] * pq
+        energy += wy[q] * np.real(np.vdot(psi, pq))
+        z = 1 - 2 * ((idx >> (n - 1 - q)) & 1)
+        lam += 2 * wz[q] * z * psi
+        energy += wz[q] * float(np.sum(z * np.abs(psi) ** 2))
+    g0, _ = E.run_adjoint_plan(P.compile_adjoint_plan(recs, n, cfg, factorized=True), vals, psi, lam, len(vals))
+    fold = [(n - 1 - q, 2 * wy[q], q % 2) for q in range(n)]
+    dfold = [(1 << (n - 1 - q), 2 * wz[q]) for q in range(n)]
+    ap1 = P.compile_adjoint_plan(recs, n, cfg, factorized=True, fold=fold, fold_param=len(vals), dfold=dfold, lam_zero=True)
+    assert ap1.folded == list(range(n))
+    g1, _ = E.run_adjoint_plan(ap1, vals, psi, rng.normal(size=2**n) + 0j, len(vals) + 1)
+    assert np.abs(g1[: len(vals)] - g0).max() < 1e-12 and abs(g1[len(vals)] - energy) < 1e-12
