@@ -292,6 +292,15 @@ int tcmi_spec_set_grid(void* handle, int max_workgroups);
 int tcmi_spec_run_pass(void* handle, void* state, long long state_stride, int batch, int n, int T, int LT,
                        const void* ctab, const void* ptab, long long ptab_stride, unsigned live_mask, unsigned zero_bits,
                        void* stream);
+/* The first pass of a plan whose input states are read from ANOTHER batch: state[b] <- pass(scale[b] * src[b >> src_shift])
+ * (`scale` complex, one per output state, or NULL).  Replaces: the replication of the shared prefix states over the bond
+ * digits of a cut contraction and their multiplication by the bond weights (reference circuit.py:701-721 contracts the two
+ * halves of the network and joins them; here the K variants of a half share prefixes, tcmi/executor.py _HalfBatch) --
+ * formerly an elementwise launch of its own that wrote the whole batch before this pass read it again.  The handle must
+ * come from a kernel generated with the "src" option (tcmi/specialize.py). */
+int tcmi_spec_run_pass_from(void* handle, void* state, long long state_stride, int batch, int n, int T, int LT,
+                            const void* ctab, const void* ptab, long long ptab_stride, const void* src,
+                            long long src_stride, int src_shift, const void* scale, void* stream);
 int tcmi_spec_run_adjoint_pass(void* handle, void* psi, void* lam, long long state_stride, int batch, int n, int T,
                                int LT, const void* ctab, const void* ptab, long long ptab_stride, double* gout,
                                long long gout_stride, int gcopies, long long gcopy_stride, unsigned live_mask,

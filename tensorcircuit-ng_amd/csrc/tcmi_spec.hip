@@ -100,6 +100,34 @@ int tcmi_spec_run_pass(void* handle, void* state, long long state_stride, int ba
   return e == hipSuccess ? TCMI_OK : hip_fail("tcmi_spec_run_pass", e);
 }
 
+int tcmi_spec_run_pass_from(void* handle, void* state, long long state_stride, int batch, int n, int T, int LT,
+                            const void* ctab, const void* ptab, long long ptab_stride, const void* src,
+                            long long src_stride, int src_shift, const void* scale, void* stream) {
+  if (!handle || !state || !src || batch < 1 || n < T || T <= LT || LT < 6 || LT > 10 || src_shift < 0 || src_shift > 30)
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_spec_run_pass_from: bad argument");
+  SpecKernel* k = reinterpret_cast<SpecKernel*>(handle);
+  struct {
+    void* state;
+    long long state_stride;
+    const void* ctab;
+    const void* ptab;
+    long long ptab_stride;
+    unsigned live_mask;
+    unsigned zero_bits;
+    const void* src;
+    long long src_stride;
+    unsigned src_shift;
+    unsigned has_scale;
+    const void* scale;
+  } args = {state, state_stride, ctab, ptab, ptab_stride, 0xffffffffu, 0u, src, src_stride, (unsigned)src_shift,
+            scale ? 1u : 0u, scale ? scale : src};
+  size_t sz = sizeof(args);
+  void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  hipError_t e = hipModuleLaunchKernel(k->fn, grid_x(k, n, T, batch, 0xffffffffu), (unsigned)batch, 1, 1u << LT, 1, 1,
+                                       (unsigned)k->lds_bytes, reinterpret_cast<hipStream_t>(stream), nullptr, cfg);
+  return e == hipSuccess ? TCMI_OK : hip_fail("tcmi_spec_run_pass_from", e);
+}
+
 int tcmi_spec_run_adjoint_pass(void* handle, void* psi, void* lam, long long state_stride, int batch, int n, int T, int LT,
                                const void* ctab, const void* ptab, long long ptab_stride, double* gout,
                                long long gout_stride, int gcopies, long long gcopy_stride, unsigned live_mask,

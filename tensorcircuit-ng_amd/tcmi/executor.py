@@ -379,12 +379,34 @@ class CompiledCircuit:
             )
         return ptab
 
-    def state(self, params=None, inputs=None, out=None, full=False, consume_inputs=False, ptab=None):
+    def _specialised_src(self):
+        """The generated kernel of the FIRST pass in its "src" variant (tcmi_spec_run_pass_from), or None."""
+        if self.cfg.gen < 2 or self.dtypestr != "complex64" or self.n_exec != self.n or not self.plan.descs:
+            return None
+        if getattr(self, "_spec_src", None) is None:
+            self._spec_src = S.PassSet("forward", self.plan.descs[:1], self.n_exec, {"src": 1})
+        return self._spec_src.get()[0]
+
+    def state(self, params=None, inputs=None, out=None, full=False, consume_inputs=False, ptab=None, src=None):
         """Run the plan.  ``params``: real tensor [B, P] (or [P]) on the device, or None when the
         circuit has no parameters.  Returns a complex tensor [B, 2^n].  ``consume_inputs``: the passes may run in
         place on ``inputs`` (a scratch batch the caller gives up) instead of on a copy.  ``ptab``: the table of
-        ``build_ptab(params)``, already built."""
+        ``build_ptab(params)``, already built.  ``src`` = (states [Bs, 2^n], shift, scale [B] or None): input state b is
+        ``scale[b] * states[b >> shift]``, read by the first pass itself when its "src" kernel is there
+        (tcmi_spec_run_pass_from), else materialised."""
         import torch
+
+        ksrc = None
+        if src is not None:
+            assert inputs is None
+            st_, sh_, sc_ = src
+            ksrc = self._specialised_src() if (st_.dtype == self.tdtype and st_.is_contiguous()) else None
+            if ksrc is None:      # no generated kernel for it: the replicated, weighted batch as an ordinary input
+                Bs = st_.shape[0]
+                rep_ = st_.reshape(Bs, 1, -1).expand(Bs, 1 << sh_, st_.shape[-1])
+                if sc_ is not None:
+                    rep_ = rep_ * sc_.reshape(Bs, 1 << sh_, 1)
+                inputs, consume_inputs = rep_.reshape(Bs << sh_, -1), True      # (the caller gives ``states`` up)
 
         lib = self._lib
         if params is None:
@@ -413,7 +435,7 @@ class CompiledCircuit:
                 out = inp
             else:
                 out = torch.empty(B, nel, dtype=self.tdtype, device=self.device)
-        sparse = inputs is None and SPARSE_START and self.cfg.gen >= 2 and self.dtypestr == "complex64"
+        sparse = inputs is None and ksrc is None and SPARSE_START and self.cfg.gen >= 2 and self.dtypestr == "complex64"
         zbits = rfr = None
         # resolved ONCE per call: the kernel set the zero-fill decision and the byte accounting look at is the one
         # run_passes launches, and a call counts once towards the plan's hotness (specialize.PassSet.get)
@@ -422,7 +444,9 @@ class CompiledCircuit:
             zb, rf, covered = self.zero_bits()
             if covered:
                 zbits, rfr = zb, rf
-        if inputs is None and zbits is not None:
+        if ksrc is not None:
+            pass                      # the first pass reads its tiles from src and writes every tile of out
+        elif inputs is None and zbits is not None:
             out[:, 0] = 1.0           # everything else the passes read, earlier passes have written (zero_bits())
         elif inputs is None:
             _lib.check(
@@ -458,7 +482,21 @@ class CompiledCircuit:
                                   for i, (f, k) in enumerate(zip(fracs, spec))))
         _log_valu("pass", spec, self.zero_start()[1] if live is not None else None, self.n_exec, B)
         with _timed("pass", len(self.descs), units * B * nel * item):
-            self.run_passes(out, ptab, B, stream, live=live, zbits=zbits, spec=spec)
+            first = 0
+            if ksrc is not None:
+                st_, sh_, sc_ = src
+                if sc_ is not None:
+                    sc_ = sc_.reshape(-1).to(self.tdtype).contiguous()
+                    assert sc_.numel() == B
+                assert (st_.shape[0] << sh_) == B and st_.shape[1] == nel
+                _lib.check(
+                    lib.tcmi_spec_run_pass_from(ksrc.handle, out.data_ptr(), nel, B, self.n_exec, self.cfg.T, self.cfg.LT,
+                                                self.ctab.data_ptr(), ptab.data_ptr(), ptab.stride(0), st_.data_ptr(),
+                                                st_.stride(0), int(sh_), sc_.data_ptr() if sc_ is not None else None,
+                                                stream),
+                    "tcmi_spec_run_pass_from")
+                first = 1
+            self.run_passes(out, ptab, B, stream, first=first, live=live, zbits=zbits, spec=spec)
         if self.n_exec != self.n and not full:
             return out[:, : 2**self.n]
         return out
@@ -1321,13 +1359,18 @@ class _HalfBatch:
         # the prefix parameter rows are every (K / Ks)-th row of pfull: a strided view, no gather
         ppre = pfull.reshape(B * Ks, (K // Ks) * pfull.shape[-1])[:, : pfull.shape[-1]]
         pre = self.prefix.state(ppre)                                            # [B*Ks, 2^nq]
+        if ptab_suf is not None:
+            cur.wait_stream(aux)
+            ptab_suf.record_stream(cur)
+        rep_n = K // Ks
+        if rep_n & (rep_n - 1) == 0 and os.environ.get("TCMI_CUT_FUSED_REP", "1") != "0":
+            # state b*K + j of the suffix batch = weight[b, j] * prefix state (b*K + j) >> log2(K / Ks): read by the suffix's
+            # first pass itself (tcmi_spec_run_pass_from; materialised inside state() when that kernel is not there)
+            return self.suffix.state(pfull, ptab=ptab_suf, src=(pre, rep_n.bit_length() - 1, scale))
         if scale is None:
             rep = pre.reshape(B, Ks, 1, -1).expand(B, Ks, K // Ks, pre.shape[-1]).reshape(B * K, -1)
         else:
             rep = (pre.reshape(B, Ks, 1, -1) * scale.reshape(B, Ks, K // Ks, 1)).reshape(B * K, -1)
-        if ptab_suf is not None:
-            cur.wait_stream(aux)
-            ptab_suf.record_stream(cur)
         return self.suffix.state(pfull, inputs=rep, consume_inputs=True, ptab=ptab_suf)
 
 

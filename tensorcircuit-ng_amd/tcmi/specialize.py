@@ -687,7 +687,15 @@ class _Forward(_Emitter):
         NR = self.NR
         params = ("v2f* __restrict__ state, long long state_stride, const float* __restrict__ ctab_g, "
                   "const float* __restrict__ ptab_g, long long ptab_stride, uint32_t live_mask, uint32_t umask")
-        self.opts["umask_arg"] = 1
+        from_src = bool(self.opts.get("src"))
+        if from_src:
+            # "src" variant (tcmi_spec_run_pass_from): the tile is read from ANOTHER batch -- state b of this pass starts as
+            # scale[b] * src[b >> src_shift] -- and written to ``state``: the replicate-and-weight step of a cut
+            # half-circuit (executor._HalfBatch) without a launch and a round trip of its own
+            params += (", const v2f* __restrict__ src, long long src_stride, uint32_t src_shift, uint32_t has_scale, "
+                       "const v2f* __restrict__ scale")
+        else:
+            self.opts["umask_arg"] = 1
         pro = ["  extern __shared__ __attribute__((aligned(16))) char lb_[];",
                "  char LDS_AS* const lb = (char LDS_AS*)lb_;",
                "  state += (long long)blockIdx.y * state_stride;",
@@ -707,9 +715,20 @@ class _Forward(_Emitter):
         if int(self.opts.get("prio", 0)) & 1:      # a young workgroup's loads go out ahead of the older ones' arithmetic
             sg.parts[0].append("  __builtin_amdgcn_s_setprio(3);")
         self.thread_xor(sg.parts[0], self.tphys, rd0.thr_phys)
-        self.tile_io(sg.parts[0], rd0, False, {"a": "state"}, self.tphys)
+        if from_src:
+            sg.parts[0].append("  const v2f* __restrict__ src_b = src + (long long)(blockIdx.y >> src_shift) * src_stride;")
+            self.tile_io(sg.parts[0], rd0, False, {"a": "src_b"}, self.tphys)
+        else:
+            self.tile_io(sg.parts[0], rd0, False, {"a": "state"}, self.tphys)
         if int(self.opts.get("prio", 0)) & 1:
             sg.parts[0].append("  __builtin_amdgcn_s_setprio(0);")
+        if from_src:
+            sc = self.fresh("sc")
+            p_ = sg.new_part()
+            p_.append(f"  v2f {sc} = v2f{{1.f, 0.f}};")
+            p_.append(f"  if (has_scale) {sc} = ((KV2)scale)[blockIdx.y];")
+            for h in range(0, NR, 8):
+                p_.append("  vm2_cmul8s(" + ", ".join(self.A(h + i) for i in range(8)) + ", " + ", ".join([sc] * 8) + ");")
         if trace:
             sg.parts[0].append('  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");')
             sg.parts[0].append("  if (tid == 0) trc[1] = wall_clock64();")
@@ -744,7 +763,8 @@ def forward_source(words, kname: str = "tcmi_spec_pass", opts=None) -> Tuple[str
     """HIP source of the straight-line kernel of one forward gate pass + its launch geometry."""
     e = _Forward(words, opts)
     src = e.source(kname)
-    return src, {"kind": "forward", "n": e.n, "T": e.T, "LT": e.LT, "lds": e.lds_bytes(), "persistent": e.persistent()}
+    return src, {"kind": "forward", "n": e.n, "T": e.T, "LT": e.LT, "lds": e.lds_bytes(), "persistent": e.persistent(),
+                 "src": bool(e.opts.get("src"))}
 
 
 # ======================================================================================================
@@ -1088,10 +1108,12 @@ def precompile_circuit(c, adjoint: bool = True, forward: bool = True, fold_x=Non
             res["cut_halves"] = []
             for nq, hg in ((spec.n_left, spec.left), (c._nqubits - spec.n_left, spec.right)):
                 s_, cut, _K = X._HalfBatch.split_point(hg, nparams, nb, radices)
-                for sub in ([hg] if s_ == 0 else [hg[:cut], hg[cut:]]):
+                for isub, sub in enumerate([hg] if s_ == 0 else [hg[:cut], hg[cut:]]):
                     _, hcfg, hplan, _ = X.choose_plan(nq, sub, nparams + nb, cons.dtypestr, cons._plan_options)
                     if hcfg.gen >= 2:
                         res["cut_halves"] += [r is not None for r in prepare("forward", hplan.descs)]
+                        if isub == 1:      # the suffix reads its input states from the prefix batch (tcmi_spec_run_pass_from)
+                            res["cut_halves"] += [r is not None for r in prepare("forward", hplan.descs[:1], {"src": 1})]
     if adjoint and "adjoint" in _EMITTERS:
         for full, zero in ((False, False), (True, False), (True, True)):
             r = X.choose_adjoint_plan(eg, n_exec, cons.dtypestr, full, zero)    # zero: the sweep of a psi from |0...0>

@@ -440,3 +440,49 @@ def test_partial_fold_with_y_fields_and_strings_that_stay_in_the_tile_passes(tc6
     ref += 0.31 * dense.expectation(psi, n, (G.X, [3]), (G.X, [4])).real - 0.22 * dense.expectation(psi, n, (G.X, [11]), (G.X, [17])).real
     ref += 0.5 * dense.expectation(psi, n, (G.X, [6]), (G.Y, [7]), (G.Z, [9])).real
     assert abs(res["1"][0] - ref) < 2e-4, (res["1"][0], ref)
+
+
+def test_cut_suffix_reads_its_inputs_from_the_prefix_batch(tc64):
+    """tcmi_spec_run_pass_from: the first pass of a cut half-circuit's suffix reads state b as weight[b] * prefix[b >> shift]
+    instead of a replicated, weighted copy written by an elementwise launch.  Same state with the fused load on / off
+    (TCMI_CUT_FUSED_REP), batched over two parameter rows, and against the dense oracle."""
+    tc = tc64
+    import torch
+    from tcmi import executor as X
+
+    n, d, B = 24, 3, 2          # halves of 12 qubits: the smallest tile the packed kernels (and their generated forms) run on
+    params = np.random.default_rng(16).uniform(0, 2 * np.pi, [B, 2 * d, n])
+    os.environ["TCMI_SPECIALIZE"] = "1"
+    old = os.environ.get("TCMI_CUT_FUSED_REP")
+    tc.set_contractor("cut")
+    res = {}
+    try:
+        for flag in ("1", "0"):
+            os.environ["TCMI_CUT_FUSED_REP"] = flag
+            X._CACHE.clear()
+
+            def wf(p):
+                c = tc.Circuit(n)
+                W.hea_b(c, n, d, p, zz=tc.gates._zz_matrix)
+                return c.wavefunction()
+
+            pt = torch.from_numpy(params.astype(np.float32)).cuda()
+            c0 = tc.Circuit(n)
+            W.hea_b(c0, n, d, pt[0], zz=tc.gates._zz_matrix)
+            cc = c0._compiled()
+            if not isinstance(cc, X.CutCircuit) or cc.right.s == 0:
+                pytest.skip("the planner did not cut this circuit into prefix / suffix batches")
+            st = tc.backend.vmap(wf)(pt)
+            if flag == "1":       # the generated "src" kernels of both suffixes are what ran
+                assert cc.left.suffix._specialised_src() is not None and cc.right.suffix._specialised_src() is not None
+            res[flag] = st.cpu().numpy()
+    finally:
+        if old is None:
+            os.environ.pop("TCMI_CUT_FUSED_REP", None)
+        else:
+            os.environ["TCMI_CUT_FUSED_REP"] = old
+        tc.set_contractor("greedy")
+        X._CACHE.clear()
+    assert np.abs(res["1"] - res["0"]).max() < 1e-7
+    ref = dense.run(n, W.hea_b_ops(n, d, params[1].astype(np.float32).astype(np.float64)), inplace=True)
+    assert np.abs(res["1"][1] - ref).max() < 1e-5
