@@ -1329,13 +1329,17 @@ class _HalfBatch:
             self.suffix = CompiledCircuit(nq, gates[cut:], nparams + nb, dtypestr, opts)
             self.descs = list(self.prefix.descs) + list(self.suffix.descs)
 
-    def states(self, pfull, B, scale=None):
+    def states(self, pfull, B, scale=None, scale_ready=None):
         """pfull [B*K, nparams + nb] (digits in the last nb columns) -> [B*K, 2^nq]; ``scale`` [B, K]: every state
         multiplied by its weight (applied where the prefix states are replicated over the suffix digits: the
-        replication writes the batch anyway, and the suffix passes then run in place on it)."""
+        replication writes the batch anyway, and the suffix passes then run in place on it).  ``scale_ready``: an event
+        after which ``scale`` may be read (it is produced on another stream, under this half's prefix)."""
         if self.s == 0:
             out = self.single.state(pfull)
             if scale is not None:
+                if scale_ready is not None:
+                    torch_ = __import__("torch")
+                    torch_.cuda.current_stream(self.single.device).wait_event(scale_ready)
                 out *= scale.reshape(-1, 1)
             return out
         import torch
@@ -1362,6 +1366,8 @@ class _HalfBatch:
         if ptab_suf is not None:
             cur.wait_stream(aux)
             ptab_suf.record_stream(cur)
+        if scale is not None and scale_ready is not None:
+            torch.cuda.current_stream(self.suffix.device).wait_event(scale_ready)
         rep_n = K // Ks
         if rep_n & (rep_n - 1) == 0 and os.environ.get("TCMI_CUT_FUSED_REP", "1") != "0":
             # state b*K + j of the suffix batch = weight[b, j] * prefix state (b*K + j) >> log2(K / Ks): read by the suffix's
@@ -1476,10 +1482,20 @@ class CutCircuit:
             if side is None:
                 side = self._side = torch.cuda.Stream(device=self.device)
             side.wait_stream(cur)
+            # the bond weights are only read by the right half's SUFFIX: computed on this stream, at the head of the left
+            # half's (shorter) chain, instead of at the head of the right half's (the longer one)
+            if os.environ.get("TCMI_CUT_WEIGHTS_LATE", "1") != "0":
+                w = self._weights(p)
+                w_ready = torch.cuda.Event()
+                w_ready.record(cur)
+            else:                       # (the weights at the head of the right half's chain, as before)
+                with torch.cuda.stream(side):
+                    w, w_ready = self._weights(p), None
             with torch.cuda.stream(side):
-                R = self.right.states(pfull, B, scale=self._weights(p))     # [B*K, N], each state times its weight
+                R = self.right.states(pfull, B, scale=w, scale_ready=w_ready)     # [B*K, N], each state times its weight
             pfull.record_stream(side)
             p.record_stream(side)
+            w.record_stream(side)
             L = self.left.states(pfull, B)                              # [B*K, M]
             cur.wait_stream(side)
             R.record_stream(cur)
