@@ -1482,9 +1482,11 @@ class CutCircuit:
             if side is None:
                 side = self._side = torch.cuda.Stream(device=self.device)
             side.wait_stream(cur)
-            # the bond weights are only read by the right half's SUFFIX: computed on this stream, at the head of the left
-            # half's (shorter) chain, instead of at the head of the right half's (the longer one)
-            if os.environ.get("TCMI_CUT_WEIGHTS_LATE", "1") != "0":
+            # experiment switch (TCMI_CUT_WEIGHTS_LATE=1; off): the bond weights are only read by the right half's SUFFIX, so
+            # they can be computed on this stream at the head of the left half's (shorter) chain instead of at the head of
+            # the right half's.  Measured: eager 1.033e11 vs 1.025e11 (noise), hipGraph replay 0.95e11 vs 0.99e11 (the extra
+            # event edge costs more than the 11 us it moves)
+            if os.environ.get("TCMI_CUT_WEIGHTS_LATE", "0") == "1":
                 w = self._weights(p)
                 w_ready = torch.cuda.Event()
                 w_ready.record(cur)
