@@ -87,6 +87,17 @@ int tcmi_build_tables(const int* ginfo, int nrec, const double* cpool, const voi
 int tcmi_cut_weights(const void* params, long long params_stride, int batch, const int* tab_i, const double* tab_f,
                      const unsigned char* digits, int K, int nb, int rmax, void* w, int dtype, void* stream);
 
+/* The 4 x 4 epilogue of a cut contraction whose LAST crossing gate is applied after the join (tcmi/cut.py, `Epilogue`):
+ * X[b] = prod_g (c0_g + cos(a_g) c1_g + sin(a_g) c2_g), later factors on the left, a_g = scale_g * theta_b[param_g] +
+ * offset_g, every factor a 4 x 4 over (last qubit of the left half, first qubit of the right half).  `tab_i` =
+ * int32[nfac] parameter indices (-1: constant factor); `tab_f` = float64[nfac][98] {scale, offset, c0[16], c1[16],
+ * c2[16]} (complex entries as re, im; row-major [out][in]); params float (TCMI_C64) / double (TCMI_C128)
+ * [batch][params_stride]; `x` = complex64 [batch][16], the operand of tcmi_cgemm_split_epi.  Replaces: the gate
+ * matrices of those gates inside the contraction Circuit.wavefunction executes (tensorcircuit/circuit.py:701-721,
+ * gate factories tensorcircuit/gates.py:692-743). */
+int tcmi_cut_epilogue(const void* params, long long params_stride, int batch, const int* tab_i, const double* tab_f,
+                      int nfac, void* x, int dtype, void* stream);
+
 /* One pass of a compiled plan over the (batched) state, in place: every workgroup loads a tile of
  * 2^(R+LT) amplitudes, applies the pass program `desc` (int32 words, layout in
  * tensorcircuit-ng_amd/csrc/tcmi_vm.h) and stores the tile back.  `ctab` = shared constant table,
@@ -224,6 +235,17 @@ int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, 
  * uses.  The join of the cut contraction (reference circuit.py:701-721 -> cons.py:948). */
 int tcmi_cgemm_split(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch,
                      long long strideA, long long strideB, long long strideC, void* stream);
+
+/* tcmi_cgemm_split with a 4 x 4 gate applied to the product before it is stored: with P[b] = A[b]^T B[b] (M x N), u the
+ * lowest bit of the row index and v the lowest bit of P's column index,
+ *     C[b][(m, u')][col(c, v')] = sum_{u, v} X[b][2 u' + v'][2 u + v] P[b][(m, u)][(c, v)],   col(c, v) = c + v N / 2:
+ * P's column index is C's column index rotated left by one bit (B's columns come from a half-circuit whose first qubit
+ * is labelled last, so that the gate's right-hand qubit is bit 0).  `X` = complex64 [batch][16] (tcmi_cut_epilogue).  The
+ * four (u, v) results sit in one thread of the MFMA result layout: 16 complex multiply-adds in registers.  Same
+ * argument rules as tcmi_cgemm_split.  The join of a cut contraction whose last crossing gate is deferred: half the
+ * bond dimension for ZZ / CNOT / CZ crossings (reference circuit.py:701-721 -> cons.py:948). */
+int tcmi_cgemm_split_epi(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch,
+                         long long strideA, long long strideB, long long strideC, const void* X, void* stream);
 
 /* <a|b> = sum conj(a_i) b_i per batch element (states [batch][2^n], stride elements apart), accumulated in
  * float64 into `copies` replicated {re, im} pairs: out[b * out_batch_stride + 2 * copy + {0,1}] += ...; the

@@ -42,4 +42,23 @@ def reference_state(spec, params: np.ndarray) -> np.ndarray:
                 w *= np.cos(a) if kind == "cos" else np.sin(a)
         pvec = np.concatenate([np.asarray(params, dtype=np.float64), np.array(digits, dtype=np.float64)])
         psi += w * np.outer(run(spec.left, nl, pvec), run(spec.right, nr, pvec))
+    if getattr(spec, "right_rot", False):
+        # the right half's qubits are labelled rotated by one (global qubit n_left is its LAST local qubit): back to the
+        # natural column order, then the deferred gate and its one-qubit tail as an ordinary two-qubit gate
+        t = psi.reshape([2**nl] + [2] * nr)
+        psi = np.moveaxis(t, nr, 1).reshape(2**nl, 2**nr)
+    if getattr(spec, "epilogue", None) is not None:
+        e = spec.epilogue
+        x = np.eye(4, dtype=np.complex128)
+        for c0, c1, c2, ref in e.factors:
+            m = np.array(c0, dtype=np.complex128)
+            if ref is not None:
+                a = ref.scale * params[ref.index] + ref.offset
+                m = m + np.cos(a) * c1 + np.sin(a) * c2
+            x = m @ x
+        t = psi.reshape([2] * spec.n)
+        t = np.moveaxis(t, [e.ql, e.qr], [0, 1])
+        shp = t.shape
+        t = (x @ t.reshape(4, -1)).reshape(shp)
+        psi = np.ascontiguousarray(np.moveaxis(t, [0, 1], [e.ql, e.qr]))
     return psi.reshape(-1)

@@ -36,6 +36,15 @@
 //     independent VALU instruction beside an MFMA costs 1.1, a dependent one 2.5, scripts/ubench/mfma_valu_shadow.hip),
 //     the plane writes 0.11.
 //   Result 1.13 ms against 1.74 ms of cgemm_dma128_kernel on the same random operands (1.54x).
+//
+// EPI = 1 (tcmi_cgemm_split_epi): a 4 x 4 complex matrix X[b] per batch member is applied to the product before it is
+// stored -- the deferred last crossing gate of the cut contraction (tcmi/cut.py), acting on the lowest row bit u and
+// the lowest column bit v of the product.  The MFMA result layout puts the four (u, v) elements of every (row pair,
+// column pair) into ONE thread (the 2 x 2 MFMA tiles of a wave interleave rows and columns), so the epilogue is 16
+// complex multiply-adds per four results in registers (32 v_pk_fma_f32) and no data moves.  The product's column index
+// is the caller's column index rotated left by one bit (B's columns come from a half-circuit whose first qubit was
+// labelled last): column c of the product is stored at (c >> 1) | ((c & 1) * N / 2), as 8-byte stores that are 256
+// bytes contiguous per row over 32 lanes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -67,10 +76,11 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
   const f32x2_ v = {lo, hi};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_));
 }
-template <int MODE>
+template <int MODE, int EPI>
 __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __restrict__ A, const float2* __restrict__ B,
                                                               float2* __restrict__ C, int M, int N, int K, long long sA,
-                                                              long long sB, long long sC, int tiles_x, int tiles_y, int batch) {
+                                                              long long sB, long long sC, int tiles_x, int tiles_y, int batch,
+                                                              const float2* __restrict__ X) {
   extern __shared__ __attribute__((aligned(16))) char dsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
@@ -247,7 +257,49 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
     // the last step cut block 0 of the next tile into stage 0 and blocks 0, 1 of it are (being) loaded: only the
     // results stand between the tiles.  MFMA result element (i = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), j = lane & 31)
     // of tile (u, v) is C[wr 64 + 2 i + u][wc 64 + 2 j + v]
-    {
+    if (EPI) {
+      // y[2 u' + v'] = sum_{u, v} X[b][2 u' + v'][2 u + v] c[u][v]; column 2 j + v of the product is column j + v N / 2 of C
+      float2* Cb = C + (long long)bi * sC;
+      const float2* Xb = X + (long long)__builtin_amdgcn_readfirstlane(bi) * 16;
+      f32x2_ xr[16], xi[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float2 x = Xb[e];
+        xr[e] = f32x2_{x.x, x.x};
+        xi[e] = f32x2_{x.y, x.y};
+      }
+      const long long colh = (n0 >> 1) + wc * 32 + (lane & 31);
+      const long long half = (long long)N >> 1;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const long long row0 = m0 + wr * 64 + 2 * ((reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5));
+        f32x2_ c[4], cs[4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int v = 0; v < 2; ++v) {
+            const float re = acc[u][v][0][reg] - acc[u][v][1][reg];
+            const float im = acc[u][v][2][reg] - acc[u][v][0][reg] - acc[u][v][1][reg];
+            c[2 * u + v] = f32x2_{re, im};
+            cs[2 * u + v] = f32x2_{-im, re};
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc[u][v][t][reg] = 0.f;
+          }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          f32x2_ y = {0.f, 0.f};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            y = __builtin_elementwise_fma(xr[4 * o + i], c[i], y);
+            y = __builtin_elementwise_fma(xi[4 * o + i], cs[i], y);
+          }
+          float2 w;
+          w.x = y.x;
+          w.y = y.y;
+          Cb[(row0 + (o >> 1)) * N + colh + (o & 1) * half] = w;
+        }
+      }
+    } else {
       float2* Cb = C + (long long)bi * sC;
       const long long colb = n0 + wc * 64 + 2 * (lane & 31);
 #pragma unroll
@@ -294,22 +346,24 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
 
 }  // namespace tcmi
 
-extern "C" {
+namespace {
 
-int tcmi_cgemm_split(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch,
-                     long long strideA, long long strideB, long long strideC, void* stream) {
+int split_launch(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch, long long strideA,
+                 long long strideB, long long strideC, const void* X, void* stream, const char* who) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #ifdef TCMI_SPLIT_PROBE
   // probe builds of the kernel (libtcmi_probe.so only, scripts/gpu_gemm_split_modes.py): 1 no conversion, 2 no MFMA,
   // 3 no result stores, 4 cycle / wall-clock stamps into C[0], 5 conversion without plane writes, 6 plane writes without
-  // conversion.  The production library has no such switch: it instantiates cgemm_split_kernel<0> alone.
+  // conversion.  The production library has no such switch: it instantiates cgemm_split_kernel<0, *> alone.
   static const int mode = getenv("TCMI_SPLIT_MODE") ? atoi(getenv("TCMI_SPLIT_MODE")) : 0;
 #endif
   if (!A || !B || !C || M < 1 || N < 1 || K < 1 || batch < 1 || (M % 128) || (N % 128) || (K % 32) || batch > 65535 ||
       M > (1ll << 30) || N > (1ll << 30) || ((strideA | strideB | strideC) & 1) ||
-      ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C)) & 15))
+      ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C)) & 15) ||
+      (reinterpret_cast<uintptr_t>(X) & 7))
     return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm_split: bad argument (k-major A, M and N multiples of 128, K of 32, "
                                          "16-byte aligned operands)");
+  (void)who;
   const int txn = (int)(N / 128), tyn = (int)(M / 128);
   const long long nwork = (long long)txn * tyn * batch;
   if (nwork >= (1ll << 31)) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm_split: too many tiles");
@@ -321,34 +375,53 @@ int tcmi_cgemm_split(const void* A, const void* B, void* C, long long M, long lo
       return tcmi_set_error_(TCMI_ERR_HIP, "tcmi_cgemm_split: cannot query the device");
     ncu = prop.multiProcessorCount;
   }
-#define TCMI_SPLIT_LAUNCH(MODE)                                                                                        \
+#define TCMI_SPLIT_LAUNCH(MODE, EPI)                                                                                   \
   {                                                                                                                    \
     static bool attr_set_ = false;                                                                                     \
     if (!attr_set_) {                                                                                                  \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(tcmi::cgemm_split_kernel<MODE>),                           \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(tcmi::cgemm_split_kernel<MODE, EPI>),                      \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * tcmi::SPLIT_STAGE_BYTES) != hipSuccess)  \
         return tcmi_set_error_(TCMI_ERR_HIP, "tcmi_cgemm_split: cannot raise the dynamic LDS limit");                  \
       attr_set_ = true;                                                                                                \
     }                                                                                                                  \
-    hipLaunchKernelGGL(tcmi::cgemm_split_kernel<MODE>, dim3((unsigned)(nwork < ncu ? nwork : ncu), 1, 1), dim3(256),   \
-                       2 * tcmi::SPLIT_STAGE_BYTES, st, reinterpret_cast<const float2*>(A),                            \
+    hipLaunchKernelGGL((tcmi::cgemm_split_kernel<MODE, EPI>), dim3((unsigned)(nwork < ncu ? nwork : ncu), 1, 1),       \
+                       dim3(256), 2 * tcmi::SPLIT_STAGE_BYTES, st, reinterpret_cast<const float2*>(A),                 \
                        reinterpret_cast<const float2*>(B), reinterpret_cast<float2*>(C), (int)M, (int)N, (int)K, strideA, \
-                       strideB, strideC, txn, tyn, batch);                                                             \
+                       strideB, strideC, txn, tyn, batch, reinterpret_cast<const float2*>(X));                         \
   }
+  if (X) {
+    TCMI_SPLIT_LAUNCH(0, 1)
+  } else {
 #ifdef TCMI_SPLIT_PROBE
-  if (mode == 1) TCMI_SPLIT_LAUNCH(1)
-  else if (mode == 2) TCMI_SPLIT_LAUNCH(2)
-  else if (mode == 3) TCMI_SPLIT_LAUNCH(3)
-  else if (mode == 4) TCMI_SPLIT_LAUNCH(4)
-  else if (mode == 5) TCMI_SPLIT_LAUNCH(5)
-  else if (mode == 6) TCMI_SPLIT_LAUNCH(6)
-  else
+    if (mode == 1) TCMI_SPLIT_LAUNCH(1, 0)
+    else if (mode == 2) TCMI_SPLIT_LAUNCH(2, 0)
+    else if (mode == 3) TCMI_SPLIT_LAUNCH(3, 0)
+    else if (mode == 4) TCMI_SPLIT_LAUNCH(4, 0)
+    else if (mode == 5) TCMI_SPLIT_LAUNCH(5, 0)
+    else if (mode == 6) TCMI_SPLIT_LAUNCH(6, 0)
+    else
 #endif
-  TCMI_SPLIT_LAUNCH(0)
+    TCMI_SPLIT_LAUNCH(0, 0)
+  }
 #undef TCMI_SPLIT_LAUNCH
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));
   return TCMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tcmi_cgemm_split(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch,
+                     long long strideA, long long strideB, long long strideC, void* stream) {
+  return split_launch(A, B, C, M, N, K, batch, strideA, strideB, strideC, nullptr, stream, "tcmi_cgemm_split");
+}
+
+int tcmi_cgemm_split_epi(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch,
+                         long long strideA, long long strideB, long long strideC, const void* X, void* stream) {
+  if (!X) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm_split_epi: X is null");
+  return split_launch(A, B, C, M, N, K, batch, strideA, strideB, strideC, X, stream, "tcmi_cgemm_split_epi");
 }
 
 }  // extern "C"

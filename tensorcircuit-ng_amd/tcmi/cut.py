@@ -17,6 +17,19 @@ halves over the "bond" indices carried by the crossing gates.  On MI355X that or
 
 The result is the same tensor (a different contraction order changes rounding only).  The executor
 chooses between this and the state-vector plan with a cost model (``executor.get_compiled``).
+
+**Deferred last crossing gate** (``make_cut(defer=True)``).  The LAST crossing gate G on (q_l, q_r) need not be a bond:
+if every later gate that touches q_l or q_r either commutes with G (both diagonal) or is a one-qubit gate on q_l / q_r
+with nothing but one-qubit gates on that qubit after it, then
+
+    U = X . (everything else),      X = (one-qubit tail on q_l, q_r) . G     a 4 x 4 matrix per circuit,
+
+and X is applied to the join's result where it sits in the GEMM's accumulators (``tcmi_cgemm_split_epi``: the four
+amplitudes a 4 x 4 on the lowest row bit and one column bit mixes are held by ONE thread of the MFMA result layout).  The
+bond dimension halves (ZZ / CNOT / CZ crossings) and with it the GEMM and the suffix batches: the HEA-B ladder of
+config 2 (exp1(ZZ) ladder, then rx on every qubit) qualifies, K = 256 -> 128.  For the thread-local epilogue q_l must be
+the left half's lowest index bit (q_l = n_left - 1) and q_r is made the right half's lowest bit by labelling the right
+half's qubits rotated by one (``CutSpec.right_rot``; the kernel un-rotates the column index when it stores).
 """
 
 from dataclasses import dataclass
@@ -48,6 +61,27 @@ class Bond:
 
 
 @dataclass
+class Epilogue:
+    """The deferred last crossing gate and the one-qubit tail absorbed into it: ``X(theta) = prod_g (c0 + cos(a_g) c1 +
+    sin(a_g) c2)`` (time order = list order, later factors on the left), every factor a 4 x 4 over (q_l, q_r), q_l the
+    more significant index bit.  ``factors[g] = (c0, c1, c2, ParamRef | None)``."""
+
+    ql: int
+    qr: int
+    factors: List[Tuple[np.ndarray, np.ndarray, np.ndarray, Optional[P.ParamRef]]]
+
+    def matrix(self, params) -> np.ndarray:
+        x = np.eye(4, dtype=np.complex128)
+        for c0, c1, c2, ref in self.factors:
+            m = np.array(c0, dtype=np.complex128)
+            if ref is not None:
+                a = ref.scale * float(params[ref.index]) + ref.offset
+                m = m + np.cos(a) * c1 + np.sin(a) * c2
+            x = m @ x
+        return x
+
+
+@dataclass
 class CutSpec:
     n: int
     n_left: int
@@ -55,6 +89,8 @@ class CutSpec:
     right: List[P.GateRec]     # qubits 0..n-n_left-1
     bonds: List[Bond]
     nparams: int               # circuit parameters; selector column of bond k = nparams + k
+    epilogue: Optional[Epilogue] = None
+    right_rot: bool = False    # right half labelled rotated by one: global qubit q is local (q - n_left - 1) mod n_right
 
     @property
     def bond_dim(self) -> int:
@@ -64,12 +100,86 @@ class CutSpec:
         return r
 
 
-def make_cut(gates: List[P.GateRec], n: int, n_left: int, nparams: int, max_bond: int = 1 << 12) -> Optional[CutSpec]:
+def _lift(m, which):
+    """2 x 2 on q_l (which = 0) / q_r (which = 1) -> 4 x 4 over (q_l, q_r)."""
+    m = np.asarray(m, dtype=np.complex128).reshape(2, 2)
+    return np.kron(m, np.eye(2)) if which == 0 else np.kron(np.eye(2), m)
+
+
+def find_deferred(gates: List[P.GateRec], n_left: int):
+    """(index of the last crossing gate, indices of the one-qubit gates absorbed with it) when that gate can be applied
+    after the join (module docstring), else None."""
+    cross = [i for i, g in enumerate(gates) if any(q < n_left for q in g.qubits) and any(q >= n_left for q in g.qubits)]
+    if not cross:
+        return None
+    p = cross[-1]
+    g = gates[p]
+    if len(g.qubits) != 2 or g.select is not None:
+        return None
+    ql, qr = sorted(g.qubits)
+    if ql != n_left - 1 or qr != n_left:
+        return None
+    dirty = {ql: not g.is_diag, qr: not g.is_diag}     # a non-diagonal factor of X sits on this qubit
+    tail = {ql: False, qr: False}                      # a one-qubit gate on this qubit has been absorbed
+    absorbed = []
+    for i in range(p + 1, len(gates)):
+        h = gates[i]
+        hit = [q for q in h.qubits if q in dirty]
+        if not hit:
+            continue
+        if h.select is not None:
+            return None
+        if len(h.qubits) == 1:
+            absorbed.append(i)
+            tail[hit[0]] = True
+            dirty[hit[0]] = dirty[hit[0]] or not h.is_diag
+            continue
+        # a wider gate stays in its half: it has to commute with every factor of X on the qubits they share
+        if not h.is_diag or any(dirty[q] for q in hit):
+            return None
+    return p, absorbed
+
+
+def make_cut(gates: List[P.GateRec], n: int, n_left: int, nparams: int, max_bond: int = 1 << 12,
+             defer: bool = False) -> Optional[CutSpec]:
     """Split the gate list at qubit ``n_left``; None if a gate cannot be split (3-qubit crossing,
-    parametrised crossing gate that is not of the exp1 form) or the bond exceeds ``max_bond``."""
+    parametrised crossing gate that is not of the exp1 form) or the bond exceeds ``max_bond``.  ``defer``: apply the
+    last crossing gate after the join when the circuit allows it (``find_deferred``)."""
     left, right, bonds = [], [], []
     bond = 1
-    for g in gates:
+    epi, skip = None, set()
+    n_right = n - n_left
+    if defer:
+        found = find_deferred(gates, n_left)
+        if found is not None:
+            p, absorbed = found
+            ql, qr = n_left - 1, n_left
+            factors = []
+            for i in [p] + absorbed:
+                g = gates[i]
+                if len(g.qubits) == 2:
+                    flip = g.qubits[0] != ql
+                    lift = (lambda m, f=flip: None if m is None else
+                            (np.asarray(m, dtype=np.complex128).reshape(2, 2, 2, 2).transpose(1, 0, 3, 2).reshape(4, 4) if f
+                             else np.asarray(m, dtype=np.complex128).reshape(4, 4)))
+                else:
+                    lift = lambda m, w=int(g.qubits[0] == qr): None if m is None else _lift(m, w)
+                z = np.zeros((4, 4), dtype=np.complex128)
+                c0 = lift(g.c0)
+                if g.param is None:
+                    factors.append((c0, z, z, None))
+                else:
+                    factors.append((c0 if c0 is not None else z, lift(g.c1) if g.c1 is not None else z,
+                                    lift(g.c2) if g.c2 is not None else z, g.param))
+            epi = Epilogue(ql, qr, factors)
+            skip = set([p] + absorbed)
+
+    def rloc(q):       # local index of global qubit q in the right half
+        return (q - n_left - 1) % n_right if epi is not None else q - n_left
+
+    for gi, g in enumerate(gates):
+        if gi in skip:
+            continue
         side = [q < n_left for q in g.qubits]
         if all(side):
             left.append(g)
@@ -77,8 +187,8 @@ def make_cut(gates: List[P.GateRec], n: int, n_left: int, nparams: int, max_bond
         if not any(side):
             diag = None
             if g.diag is not None:
-                diag = [P.DiagTerm(tuple(q - n_left for q in t.qubits), t.const, t.param) for t in g.diag]
-            right.append(P.GateRec(tuple(q - n_left for q in g.qubits), g.c0, g.c1, g.c2, g.param, diag, g.name, g.select))
+                diag = [P.DiagTerm(tuple(rloc(q) for q in t.qubits), t.const, t.param) for t in g.diag]
+            right.append(P.GateRec(tuple(rloc(q) for q in g.qubits), g.c0, g.c1, g.c2, g.param, diag, g.name, g.select))
             continue
         if len(g.qubits) != 2 or g.select is not None:
             return None
@@ -101,20 +211,20 @@ def make_cut(gates: List[P.GateRec], n: int, n_left: int, nparams: int, max_bond
                     terms.append((a, b, coef))
         if not terms or len(terms) > 4:
             return None
-        ql, qr = (qb, qa) if flip else (qa, qb)
+        ql_, qr_ = (qb, qa) if flip else (qa, qb)
         if len(terms) == 1:
             a, b, coef = terms[0]
             if coef[0] != "const":
                 return None
-            left.append(P.GateRec((ql,), c0=a, name=g.name + "-L", diag=P.diag_terms_const(a, (ql,))))
-            right.append(P.GateRec((qr - n_left,), c0=b, name=g.name + "-R", diag=P.diag_terms_const(b, (qr - n_left,))))
+            left.append(P.GateRec((ql_,), c0=a, name=g.name + "-L", diag=P.diag_terms_const(a, (ql_,))))
+            right.append(P.GateRec((rloc(qr_),), c0=b, name=g.name + "-R", diag=P.diag_terms_const(b, (rloc(qr_),))))
             continue
         k = len(bonds)
         sel = P.ParamRef(nparams + k, 1.0, 0.0)
-        left.append(P.GateRec((ql,), param=sel, select=[t[0] for t in terms], name=g.name + "-L"))
-        right.append(P.GateRec((qr - n_left,), param=sel, select=[t[1] for t in terms], name=g.name + "-R"))
+        left.append(P.GateRec((ql_,), param=sel, select=[t[0] for t in terms], name=g.name + "-L"))
+        right.append(P.GateRec((rloc(qr_),), param=sel, select=[t[1] for t in terms], name=g.name + "-R"))
         bonds.append(Bond(terms))
         bond *= len(terms)
         if bond > max_bond:
             return None
-    return CutSpec(n, n_left, left, right, bonds, nparams)
+    return CutSpec(n, n_left, left, right, bonds, nparams, epi, epi is not None)

@@ -1408,6 +1408,22 @@ class CutCircuit:
                 x //= radices[k]
         self.digits = _dev(digits, self.device, self.rdtype)          # [K, nb]
         self.descs = self.left.descs + self.right.descs               # for bookkeeping / stats
+        # deferred last crossing gate (cut.Epilogue): applied by the join kernel itself (tcmi_cgemm_split_epi), so only the
+        # split-GEMM join can run this spec; joins that cannot (TCMI_JOIN_GEMM=f32) go through the plain spec's CutCircuit
+        self._plain_args = (n, gates, nparams, dtypestr, opts, getattr(spec, "plain", None), full_cc)
+        self._plain = None
+        self._epi = None
+        if spec.epilogue is not None:
+            fac = spec.epilogue.factors
+            tab_i = np.array([(-1 if f[3] is None else f[3].index) for f in fac], dtype=np.int32)
+            tab_f = np.zeros((len(fac), 98), dtype=np.float64)
+            for g_, (c0, c1, c2, ref) in enumerate(fac):
+                tab_f[g_, 0], tab_f[g_, 1] = (0.0, 0.0) if ref is None else (ref.scale, ref.offset)
+                for j_, m_ in enumerate((c0, c1, c2)):
+                    m_ = np.asarray(m_, dtype=np.complex128).reshape(16)
+                    tab_f[g_, 2 + 32 * j_: 34 + 32 * j_: 2] = m_.real
+                    tab_f[g_, 3 + 32 * j_: 35 + 32 * j_: 2] = m_.imag
+            self._epi = (torch.as_tensor(tab_i).to(self.device), torch.as_tensor(tab_f.reshape(-1)).to(self.device), len(fac))
 
     def _weights(self, params):
         """w[B, K] = prod_k coef_k(digit_k, theta): one gather + one product over the bond axis (the
@@ -1465,6 +1481,8 @@ class CutCircuit:
         p = params.reshape(-1, params.shape[-1]) if params.dim() > 1 else params.reshape(1, -1)
         p = p.to(device=self.device, dtype=self.rdtype)
         B, K = p.shape[0], self.K
+        if self._epi is not None and not self._split_join():
+            return self._plain_cut().state(params, inputs, out, full)
         pfull = torch.cat([p[:, : self.nparams].unsqueeze(1).expand(B, K, self.nparams),
                            self.digits.unsqueeze(0).expand(B, K, -1)], dim=2).reshape(B * K, -1).contiguous()
         # The two half-circuit batches are independent and neither fills the chip (one workgroup per state: B*Ks
@@ -1499,23 +1517,56 @@ class CutCircuit:
             p.record_stream(side)
             w.record_stream(side)
             L = self.left.states(pfull, B)                              # [B*K, M]
+            xepi = self._epilogue_matrices(p)                           # (behind the left chain, the shorter one)
             cur.wait_stream(side)
             R.record_stream(cur)
         else:
             L = self.left.states(pfull, B)
             R = self.right.states(pfull, B, scale=self._weights(p))
+            xepi = self._epilogue_matrices(p)
         M, N = 2**self.spec.n_left, 2 ** (self.n - self.spec.n_left)
         if out is None:
             out = torch.empty(B, M * N, dtype=self.tdtype, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         with _timed("gemm", 1, 8.0 * M * N * K * B):
-            self._join(L, R, out, M, N, K, B, stream)
+            self._join(L, R, out, M, N, K, B, stream, xepi)
         return out
 
-    def _join(self, L, R, out, M, N, K, B, stream):
+    def _split_join(self):
+        M, N = 2**self.spec.n_left, 2 ** (self.n - self.spec.n_left)
+        return self.code == _lib.TCMI_C64 and JOIN_GEMM != "f32" and M % 128 == 0 and N % 128 == 0 and self.K % 32 == 0
+
+    def _plain_cut(self):
+        """The same cut with every crossing gate a bond (joins that cannot apply the epilogue)."""
+        if self._plain is None:
+            n, gates, nparams, dtypestr, opts, plain, full_cc = self._plain_args
+            if plain is None:
+                raise RuntimeError("cut contraction with a deferred gate needs the split-GEMM join (complex64)")
+            self._plain = CutCircuit(n, gates, nparams, dtypestr, opts, plain, full_cc)
+        return self._plain
+
+    def _epilogue_matrices(self, p):
+        """X [B, 16] complex64 of the deferred gate (one launch, tcmi_cut_epilogue), None without one."""
+        if self._epi is None:
+            return None
+        import torch
+
+        tab_i, tab_f, nfac = self._epi
+        p = p.contiguous()
+        x = torch.empty(p.shape[0], 16, dtype=torch.complex64, device=self.device)
+        _lib.check(self._lib.tcmi_cut_epilogue(p.data_ptr(), p.stride(0), p.shape[0], tab_i.data_ptr(), tab_f.data_ptr(),
+                                               nfac, x.data_ptr(), self.code,
+                                               torch.cuda.current_stream(self.device).cuda_stream), "tcmi_cut_epilogue")
+        return x
+
+    def _join(self, L, R, out, M, N, K, B, stream, xepi=None):
         """psi[b] = L[b]^T . R[b] (k-major halves).  complex64 joins whose shape the kernel takes run on the bf16
         matrix pipe with three-piece operands (``tcmi_cgemm_split``: f32 accuracy, measured against float64 next to the
         f32 MFMA kernel in tests/test_gpu_gemm_split.py); ``TCMI_JOIN_GEMM=f32`` keeps every join on ``tcmi_cgemm``."""
+        if xepi is not None:
+            _lib.check(self._lib.tcmi_cgemm_split_epi(L.data_ptr(), R.data_ptr(), out.data_ptr(), M, N, K, B, K * M, K * N,
+                                                      M * N, xepi.data_ptr(), stream), "tcmi_cgemm_split_epi(cut)")
+            return
         if self.code == _lib.TCMI_C64 and JOIN_GEMM != "f32" and M % 128 == 0 and N % 128 == 0 and K % 32 == 0:
             _lib.check(self._lib.tcmi_cgemm_split(L.data_ptr(), R.data_ptr(), out.data_ptr(), M, N, K, B, K * M, K * N,
                                                   M * N, stream), "tcmi_cgemm_split(cut)")
@@ -1540,6 +1591,7 @@ class CutCircuit:
         if sides is None or len(sides) < nsplit:
             sides = self._sides = [torch.cuda.Stream(device=self.device) for _ in range(nsplit)]
         w = self._weights(p)                                    # [B, K], one launch for the whole batch
+        xepi = self._epilogue_matrices(p)
         bounds = [(i * B) // nsplit for i in range(nsplit + 1)]
         parts = []
         for i in range(nsplit):
@@ -1560,7 +1612,7 @@ class CutCircuit:
             L.record_stream(cur)
             R.record_stream(cur)
             with _timed("gemm", 1, 8.0 * M * N * K * (b1 - b0)):
-                self._join(L, R, out[b0:b1], M, N, K, b1 - b0, stream)
+                self._join(L, R, out[b0:b1], M, N, K, b1 - b0, stream, None if xepi is None else xepi[b0:b1])
         return out
 
     def vjp(self, params, psi, g, **kw):
@@ -1622,7 +1674,7 @@ def get_compiled(n, gates, nparams, dtypestr, opts) -> CompiledCircuit:
         structure_digest(n, dtypestr, gates), nparams,
         tuple(sorted((k, v) for k, v in (opts or {}).items() if k in ("lowbits", "R", "LT"))),
         torch.cuda.current_device() if torch.cuda.is_available() else -1,
-        getattr(_cons, "_contractor_name", "greedy"),
+        getattr(_cons, "_contractor_name", "greedy"), os.environ.get("TCMI_CUT_DEFER", "1"),
     )
     cc = _CACHE.get(key)
     if cc is None:
@@ -1676,6 +1728,18 @@ def choose_cut(n, gates, nparams, dtypestr, plan):
     t_halves = 2 * 15.0 + best.bond_dim * 2.0 ** max(best.n_left, n - best.n_left) / 2.0**24 * 200.0  # two-level
     # config 2 (n = 24, d = 8, bond 256), per state at batch 8, round 4: cut 161 us measured (model 174), state-vector plan
     # on its live tiles 181 us (model 181); near-ties go to the cut (its join has measured better than its model so far)
+    # the last crossing gate applied by the join kernel instead of being a bond (cut.py: half the bond for ZZ / CNOT / CZ)
+    # when the circuit allows it and the split-GEMM join takes the smaller shape; TCMI_CUT_DEFER=0 keeps every bond
+    if split and os.environ.get("TCMI_CUT_DEFER", "1") != "0":
+        dspec = C.make_cut(gates, n, best.n_left, nparams, defer=True)
+        if dspec is not None and dspec.epilogue is not None and dspec.bond_dim % 32 == 0 and len(dspec.bonds) > 0:
+            dspec.plain = best
+            if method == "cut":
+                return dspec
+            t_gemm_d = 8.0 * 2.0**n * dspec.bond_dim / (GEMM_SPLIT_TFLOPS * 1e6)
+            t_halves_d = 2 * 15.0 + dspec.bond_dim * 2.0 ** max(best.n_left, n - best.n_left) / 2.0**24 * 200.0
+            if (t_gemm_d + t_halves_d) < 1.05 * t_vm:
+                return dspec
     if method == "cut" or (t_gemm + t_halves) < 1.05 * t_vm:
         return best
     return None

@@ -1102,10 +1102,12 @@ def precompile_circuit(c, adjoint: bool = True, forward: bool = True, fold_x=Non
         res["forward"] = [r is not None for r in prepare("forward", plan.descs)]
         # wavefunction by cut contraction: the two half-circuit batches have plans of their own (prefix / suffix)
         spec = X.choose_cut(c._nqubits, gates, nparams, cons.dtypestr, plan)
-        if spec is not None:
+        # (a cut whose last crossing gate is applied by the join kernel carries the plain cut along: joins on the exact-f32
+        # kernel run that one)
+        res["cut_halves"] = [] if spec is not None else None
+        for spec in ([] if spec is None else [spec] + ([spec.plain] if getattr(spec, "plain", None) is not None else [])):
             nb = len(spec.bonds)
             radices = [len(b.terms) for b in spec.bonds]
-            res["cut_halves"] = []
             for nq, hg in ((spec.n_left, spec.left), (c._nqubits - spec.n_left, spec.right)):
                 s_, cut, _K = X._HalfBatch.split_point(hg, nparams, nb, radices)
                 for isub, sub in enumerate([hg] if s_ == 0 else [hg[:cut], hg[cut:]]):

@@ -95,6 +95,83 @@ def test_cut_join_runs_on_the_split_kernel_and_matches_the_f32_join():
     assert np.abs(s_split - ref).max() < 2 * np.abs(s_f32 - ref).max() + 1e-8
 
 
+@pytest.mark.parametrize("shape", [(128, 128, 32, 1), (256, 384, 64, 3), (1024, 512, 128, 2)])
+def test_split_gemm_with_a_gate_applied_to_the_product(shape):
+    """tcmi_cgemm_split_epi: the product, a 4 x 4 on (lowest row bit, lowest column bit) per batch member, columns stored
+    un-rotated -- against the same thing in complex128; error relative to sum |a||b| no worse than the plain split GEMM's
+    bound (X is unitary here, as in the cut contraction)."""
+    import torch
+    from tcmi import _lib
+
+    M, N, K, B = shape
+    L = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.view_as_complex(torch.randn(B, K, M, 2, device="cuda", generator=g))
+    Bm = torch.view_as_complex(torch.randn(B, K, N, 2, device="cuda", generator=g))
+    q, _ = torch.linalg.qr(torch.view_as_complex(torch.randn(B, 4, 4, 2, dtype=torch.float64, generator=torch.Generator().manual_seed(K))))
+    X64 = q.to("cuda")
+    X32 = X64.to(torch.complex64).reshape(B, 16).contiguous()
+    out = torch.full((B, M, N), float("nan"), dtype=torch.complex64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(L.tcmi_cgemm_split_epi(A.data_ptr(), Bm.data_ptr(), out.data_ptr(), M, N, K, B, K * M, K * N, M * N,
+                                      X32.data_ptr(), st), "split_epi")
+    P = torch.einsum("bkm,bkn->bmn", A.to(torch.complex128), Bm.to(torch.complex128)).reshape(B, M // 2, 2, N // 2, 2)
+    Y = torch.einsum("bopuv,bmucv->bmocp", X32.to(torch.complex128).reshape(B, 2, 2, 2, 2), P)   # X[b, u', v', u, v]; Y[b, m, u', c, v']
+    want = Y.permute(0, 1, 2, 4, 3).reshape(B, M, N)     # column (c, v') of the product sits at v' N / 2 + c
+    mag = torch.einsum("bkm,bkn->bmn", A.abs().to(torch.float64), Bm.abs().to(torch.float64)).reshape(B, M // 2, 2, N // 2, 2)
+    mag = mag.sum(dim=(2, 4), keepdim=True).expand(B, M // 2, 2, N // 2, 2).permute(0, 1, 2, 4, 3).reshape(B, M, N)
+    err = (out.to(torch.complex128) - want).abs() / mag
+    assert torch.isfinite(out.real).all() and torch.isfinite(out.imag).all()
+    assert float(err.max()) < 1e-6 and float(err.mean()) < 1e-7, (float(err.max()), float(err.mean()))
+    # X = identity: the plain split product with the columns un-rotated, bit for bit
+    eye = torch.eye(4, dtype=torch.complex64, device="cuda").reshape(1, 16).repeat(B, 1).contiguous()
+    plain = torch.empty(B, M, N, dtype=torch.complex64, device="cuda")
+    _lib.check(L.tcmi_cgemm_split(A.data_ptr(), Bm.data_ptr(), plain.data_ptr(), M, N, K, B, K * M, K * N, M * N, st), "split")
+    _lib.check(L.tcmi_cgemm_split_epi(A.data_ptr(), Bm.data_ptr(), out.data_ptr(), M, N, K, B, K * M, K * N, M * N,
+                                      eye.data_ptr(), st), "split_epi")
+    assert torch.equal(out.reshape(B, M, 2, N // 2), plain.reshape(B, M, N // 2, 2).permute(0, 1, 3, 2))
+
+
+def test_cut_with_the_last_crossing_gate_applied_by_the_join():
+    """The product path with a deferred gate (tcmi/cut.py): half the bond, the 4 x 4 of (ZZ, rx, rx) from
+    tcmi_cut_epilogue, the join on tcmi_cgemm_split_epi -- against ``oracle.dense`` and against the plain cut."""
+    import torch
+    import tcmi as tc
+    from tcmi import executor as X
+    from oracle import dense, workloads as W
+
+    tc.set_backend("hip"); tc.set_dtype("complex64")
+    tc.set_contractor("cut")
+    try:
+        n, d = 16, 6
+        rng = np.random.default_rng(11)
+        params = rng.uniform(0, 2 * np.pi, [3, 2 * d, n])
+        c = tc.Circuit(n)
+        W.hea_b(c, n, d, tc.backend.convert_to_tensor(params[0], dtype="float32"), zz=tc.gates._zz_matrix)
+        cc = c._compiled()
+        assert isinstance(cc, X.CutCircuit) and cc.spec.epilogue is not None and cc.K == 32 and cc.spec.plain.bond_dim == 64
+        got = tc.backend.numpy(c.wavefunction())
+        ref = dense.run(n, W.hea_b_ops(n, d, params[0]))
+        assert np.abs(got - ref).max() < 1e-5
+        # a batch through the compiled object: every member has its own X; against the plain cut of the same circuits
+        pv = torch.as_tensor(np.stack([np.asarray([float(v) for v in _params_of(tc, W, n, d, params[i])]) for i in range(3)]),
+                             dtype=torch.float32, device="cuda")
+        sd = cc.state(pv)
+        sp = cc._plain_cut().state(pv)
+        assert cc._plain_cut().K == 64
+        assert float((sd - sp).abs().max()) < 2e-6
+        for i in range(3):
+            assert np.abs(sd[i].cpu().numpy() - dense.run(n, W.hea_b_ops(n, d, params[i]))).max() < 1e-5
+    finally:
+        tc.set_contractor("greedy")
+
+
+def _params_of(tc, W, n, d, params):
+    c = tc.Circuit(n)
+    W.hea_b(c, n, d, params, zz=tc.gates._zz_matrix)
+    return c._params
+
+
 def test_split_gemm_on_sums_that_cancel_down_to_the_dropped_terms():
     """Adversarial operands: every k-pair is (x, -1) . (y, z) with x = 1 + 2^-9 + 2^-18 (bf16 pieces 1, 2^-9, 2^-18), y of
     the same form and z = the sum of the SIX piece products the kernel keeps, which is exact in f32.  The exact value of

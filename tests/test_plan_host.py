@@ -405,6 +405,51 @@ def test_cut_spec_and_selector_gates():
     assert cut.make_cut([P.GateRec((0, 5, 9), c0=np.eye(8))], n, 5, 0) is None
 
 
+def test_cut_with_the_last_crossing_gate_deferred():
+    """``make_cut(defer=True)``: the last crossing gate and the one-qubit tail on its qubits leave the halves (one bond
+    less) and come back as a 4 x 4 on the joined state; the formula still reproduces ``oracle.dense``.  Circuits whose
+    tail does not commute keep every bond."""
+    from tcmi import cut
+
+    n, d = 10, 3
+    params = np.random.default_rng(1).uniform(0, 2 * np.pi, [2 * d, n])
+    c = tc.Circuit(n)
+    W.hea_b(c, n, d, params, zz=tc.gates._zz_matrix)
+    recs = c._gate_records()
+    pv = np.array([float(x) for x in c._params])
+    plain = cut.make_cut(recs, n, 5, len(pv))
+    spec = cut.make_cut(recs, n, 5, len(pv), defer=True)
+    assert plain.bond_dim == 8 and plain.epilogue is None and not plain.right_rot
+    assert spec.bond_dim == 4 and spec.right_rot and (spec.epilogue.ql, spec.epilogue.qr) == (4, 5)
+    assert len(spec.epilogue.factors) == 3                    # exp1(ZZ) on (4, 5), rx(4), rx(5)
+    assert len(spec.left) + len(spec.right) == len(plain.left) + len(plain.right) - 4
+    want = dense.run(n, W.hea_b_ops(n, d, params))
+    np.testing.assert_allclose(oracle_cut.reference_state(spec, pv), want, atol=1e-12)
+    np.testing.assert_allclose(oracle_cut.reference_state(plain, pv), want, atol=1e-12)
+    x = spec.epilogue.matrix(pv)
+    np.testing.assert_allclose(x.conj().T @ x, np.eye(4), atol=1e-12)
+    # tails: rz after the ladder is absorbed as well; a cnot on (5, 6) after the last crossing ZZ does not commute with it
+    c2 = tc.Circuit(n)
+    W.hea_b(c2, n, 2, params[:4], zz=tc.gates._zz_matrix)
+    c2.rz(5, theta=0.3); c2.ry(4, theta=1.1); c2.rzz(5, 6, theta=0.2)       # rzz after rx(5): X is dirty on qubit 5
+    assert cut.find_deferred(c2._gate_records(), 5) is None
+    c3 = tc.Circuit(n)
+    W.hea_b(c3, n, 2, params[:4], zz=tc.gates._zz_matrix)
+    c3.rzz(4, 5, theta=0.4); c3.rzz(5, 6, theta=0.2); c3.cz(3, 4); c3.rz(5, theta=0.3); c3.ry(4, theta=1.1); c3.h(7)
+    r3 = c3._gate_records()
+    s3 = cut.make_cut(r3, n, 5, len(c3._params), defer=True)
+    assert s3.bond_dim == 4 and len(s3.epilogue.factors) == 3
+    ops3 = W.hea_b_ops(n, 2, params[:4]) + [(G.rzz(0.4), [4, 5]), (G.rzz(0.2), [5, 6]), (G.CZ, [3, 4]), (G.rz(0.3), [5]),
+                                            (G.ry(1.1), [4]), (G.H, [7])]
+    np.testing.assert_allclose(oracle_cut.reference_state(s3, np.array([float(v) for v in c3._params])),
+                               dense.run(n, ops3), atol=1e-12)
+    c4 = tc.Circuit(n)
+    W.hea_b(c4, n, 1, params[:2], zz=tc.gates._zz_matrix)
+    c4.cnot(4, 5); c4.cnot(5, 6)
+    assert cut.find_deferred(c4._gate_records(), 5) is None
+    assert cut.make_cut(c4._gate_records(), n, 5, len(c4._params), defer=True).epilogue is None
+
+
 def test_dense_three_qubit_gates_are_synthesised_exactly():
     """toffoli / fredkin / any(3 qubits) (reference gates.py sgates, basecircuit.py:183-371) are rewritten
     on the host into <= 2-qubit dense + diagonal gates (tcmi/synth.py); the compiled plan run through
