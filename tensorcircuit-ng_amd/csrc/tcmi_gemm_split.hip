@@ -285,18 +285,31 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
 #pragma unroll
             for (int t = 0; t < 3; ++t) acc[u][v][t][reg] = 0.f;
           }
+        f32x2_ yo[4];
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
           f32x2_ y = {0.f, 0.f};
+          if (MODE == 7) {
+            y = c[o] + xr[o];
+          } else {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            y = __builtin_elementwise_fma(xr[4 * o + i], c[i], y);
-            y = __builtin_elementwise_fma(xi[4 * o + i], cs[i], y);
+            for (int i = 0; i < 4; ++i) {
+              y = __builtin_elementwise_fma(xr[4 * o + i], c[i], y);
+              y = __builtin_elementwise_fma(xi[4 * o + i], cs[i], y);
+            }
           }
+          yo[o] = y;
           float2 w;
           w.x = y.x;
           w.y = y.y;
-          Cb[(row0 + (o >> 1)) * N + colh + (o & 1) * half] = w;
+          if (MODE != 8 && (MODE != 9 || y.x == 123.456f)) Cb[(row0 + (o >> 1)) * N + colh + (o & 1) * half] = w;
+        }
+        if (MODE == 8) {      // probe: the same bytes as 16-byte stores of neighbouring columns (wrong places)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            f32x4_ o4 = {yo[2 * u].x, yo[2 * u].y, yo[2 * u + 1].x, yo[2 * u + 1].y};
+            *reinterpret_cast<f32x4_*>(Cb + (row0 + u) * N + n0 + wc * 64 + 2 * (lane & 31)) = o4;
+          }
         }
       }
     } else {
@@ -318,6 +331,12 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
 #pragma unroll
             for (int t = 0; t < 3; ++t) acc[u][v][t][reg] = 0.f;
         }
+    }
+    if (MODE == 4 && blockIdx.x == 100 && tid == 0) {      // probe: a stamp per finished tile into C[1 + tile count]
+      float2 o;
+      o.x = (float)(__builtin_amdgcn_s_memtime() - tc0);
+      o.y = (float)(__builtin_amdgcn_s_memrealtime() - tr0);
+      C[1 + work / gridDim.x] = o;
     }
     work += gridDim.x;
     if (work >= nwork) break;
@@ -390,6 +409,13 @@ int split_launch(const void* A, const void* B, void* C, long long M, long long N
                        strideB, strideC, txn, tyn, batch, reinterpret_cast<const float2*>(X));                         \
   }
   if (X) {
+#ifdef TCMI_SPLIT_PROBE
+    // 7: epilogue without its multiply-adds, 8: its results as 16-byte stores (wrong places), 9: no result stores
+    if (mode == 7) TCMI_SPLIT_LAUNCH(7, 1)
+    else if (mode == 8) TCMI_SPLIT_LAUNCH(8, 1)
+    else if (mode == 9) TCMI_SPLIT_LAUNCH(9, 1)
+    else
+#endif
     TCMI_SPLIT_LAUNCH(0, 1)
   } else {
 #ifdef TCMI_SPLIT_PROBE

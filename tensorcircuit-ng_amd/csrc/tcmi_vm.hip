@@ -528,61 +528,51 @@ __global__ void cut_weights_kernel(const F* __restrict__ params, long long pstri
 }
 
 // The 4 x 4 epilogue of a cut contraction with a deferred last crossing gate (tcmi/cut.py Epilogue): X[b] = prod_g (c0_g +
-// cos(a) c1_g + sin(a) c2_g), later factors on the left, a = scale * theta_b[param] + offset; one thread per circuit, in
-// float64, stored as complex64 row-major [out][in].  Factor g: tab_i[g] = parameter index (-1: constant), tab_f[g * 98]
-// = {scale, offset, c0[16] (re, im), c1[16], c2[16]}.
+// cos(a) c1_g + sin(a) c2_g), later factors on the left, a = scale * theta_b[param] + offset; in float64, stored as
+// complex64 row-major [out][in].  Factor g: tab_i[g] = parameter index (-1: constant), tab_f[g * 98] = {scale, offset,
+// c0[16] (re, im), c1[16], c2[16]}.  Sixteen threads per circuit (one per matrix element, four circuits per workgroup):
+// per factor every thread forms its element of the factor, the 4 x 4 product goes through LDS.
 template <typename F>
-__global__ void cut_epilogue_kernel(const F* __restrict__ params, long long pstride, int batch, const int* __restrict__ tab_i,
-                                    const double* __restrict__ tab_f, int nfac, float2* __restrict__ X) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= batch) return;
-  double xr[16], xi[16];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    xr[e] = (e >> 2) == (e & 3) ? 1.0 : 0.0;
-    xi[e] = 0.0;
-  }
+__global__ __launch_bounds__(64) void cut_epilogue_kernel(const F* __restrict__ params, long long pstride, int batch,
+                                                          const int* __restrict__ tab_i, const double* __restrict__ tab_f,
+                                                          int nfac, float2* __restrict__ X) {
+  __shared__ double xs[4][2][16], ms[4][2][16];
+  const int e = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int b = blockIdx.x * 4 + q;
+  const int bb = b < batch ? b : batch - 1;
+  const int o = e >> 2, c = e & 3;
+  double xr = o == c ? 1.0 : 0.0, xi = 0.0;
   for (int g = 0; g < nfac; ++g) {
     const double* t = tab_f + (long long)g * 98;
     double cs = 0.0, sn = 0.0;
     const int pi = tab_i[g];
     if (pi >= 0) {
-      const double a = (double)params[(long long)b * pstride + pi] * t[0] + t[1];
+      const double a = (double)params[(long long)bb * pstride + pi] * t[0] + t[1];
       cs = cos(a);
       sn = sin(a);
     }
-    double mr[16], mi[16];
+    __syncthreads();
+    xs[q][0][e] = xr;
+    xs[q][1][e] = xi;
+    ms[q][0][e] = t[2 + 2 * e] + cs * t[34 + 2 * e] + sn * t[66 + 2 * e];
+    ms[q][1][e] = t[3 + 2 * e] + cs * t[35 + 2 * e] + sn * t[67 + 2 * e];
+    __syncthreads();
+    double ar = 0.0, ai = 0.0;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      mr[e] = t[2 + 2 * e] + cs * t[34 + 2 * e] + sn * t[66 + 2 * e];
-      mi[e] = t[3 + 2 * e] + cs * t[35 + 2 * e] + sn * t[67 + 2 * e];
+    for (int k = 0; k < 4; ++k) {
+      const double mr = ms[q][0][4 * o + k], mi = ms[q][1][4 * o + k];
+      const double yr = xs[q][0][4 * k + c], yi = xs[q][1][4 * k + c];
+      ar += mr * yr - mi * yi;
+      ai += mr * yi + mi * yr;
     }
-    double yr[16], yi[16];
-#pragma unroll
-    for (int o = 0; o < 4; ++o)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        double ar = 0.0, ai = 0.0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          ar += mr[4 * o + k] * xr[4 * k + c] - mi[4 * o + k] * xi[4 * k + c];
-          ai += mr[4 * o + k] * xi[4 * k + c] + mi[4 * o + k] * xr[4 * k + c];
-        }
-        yr[4 * o + c] = ar;
-        yi[4 * o + c] = ai;
-      }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      xr[e] = yr[e];
-      xi[e] = yi[e];
-    }
+    xr = ar;
+    xi = ai;
   }
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    float2 o;
-    o.x = (float)xr[e];
-    o.y = (float)xi[e];
-    X[(long long)b * 16 + e] = o;
+  if (b < batch) {
+    float2 w;
+    w.x = (float)xr;
+    w.y = (float)xi;
+    X[(long long)b * 16 + e] = w;
   }
 }
 
@@ -743,7 +733,7 @@ int tcmi_cut_epilogue(const void* params_dev, long long params_stride, int batch
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!params_dev || !tab_i_dev || !tab_f_dev || !x_dev || batch < 1 || nfac < 0)
     return set_msg(TCMI_ERR_ARG, "tcmi_cut_epilogue: bad argument");
-  dim3 block(64, 1, 1), grid((batch + 63) / 64, 1, 1);
+  dim3 block(64, 1, 1), grid((batch + 3) / 4, 1, 1);
   if (dtype == TCMI_C64)
     hipLaunchKernelGGL(tcmi::cut_epilogue_kernel<float>, grid, block, 0, st, reinterpret_cast<const float*>(params_dev),
                        params_stride, batch, tab_i_dev, tab_f_dev, nfac, reinterpret_cast<float2*>(x_dev));
