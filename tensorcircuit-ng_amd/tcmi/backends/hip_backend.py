@@ -528,6 +528,120 @@ class HipBackend:
         wrapper._tcmi_vag = (f, argnums, has_aux, None)  # lets ``jit`` trace the host side (tcmi/jit.py)
         return wrapper
 
+    # ---- vjp / jvp / Jacobians / Hessian (reference abstract_backend.py:2295-2492, pytorch_backend.py:788-812) ----------
+    # Plain reverse-mode loops over torch.autograd (the circuit primitives of tcmi/functional.py carry their own first- and
+    # second-order rules); no torch.func transform is involved, so they nest: hessian = jacrev(jacrev(f)).
+    def _prep(self, inputs):
+        torch = self._torch
+        single = not isinstance(inputs, (list, tuple))
+        xs = [self.convert_to_tensor(x) for x in ([inputs] if single else inputs)]
+        nested = torch.is_grad_enabled() and any(x.requires_grad for x in xs)
+        xs = [x if x.requires_grad else x.detach().requires_grad_(True) for x in xs]
+        return single, xs, nested
+
+    def vjp(self, f: Callable[..., Any], inputs: Any, v: Any) -> Tuple[Any, Any]:
+        """(f(*inputs), v^T J): same structure as ``inputs``."""
+        torch = self._torch
+        single, xs, nested = self._prep(inputs)
+        with torch.enable_grad():
+            out = _resolve(f(*xs))
+            outs = list(out) if isinstance(out, (list, tuple)) else [out]
+            vs = [self.convert_to_tensor(t).to(o.dtype) for t, o in zip(list(v) if isinstance(v, (list, tuple)) else [v], outs)]
+            keep = [(o, t) for o, t in zip(outs, vs) if o.requires_grad]
+            gr = torch.autograd.grad([o for o, _ in keep], xs, grad_outputs=[t for _, t in keep], create_graph=nested,
+                                     allow_unused=True) if keep else [None] * len(xs)
+        gr = [torch.zeros_like(x) if g_ is None else g_ for g_, x in zip(gr, xs)]
+        if not nested:
+            out = self.tree_map(lambda t: t.detach(), out)
+        return out, (gr[0] if single else tuple(gr))
+
+    def jvp(self, f: Callable[..., Any], inputs: Any, v: Any) -> Tuple[Any, Any]:
+        """(f(*inputs), J v) by reverse over reverse: u -> u^T J is linear, its vjp along v is J v."""
+        torch = self._torch
+        single, xs, nested = self._prep(inputs)
+        vs = [self.convert_to_tensor(t).to(x.dtype) for t, x in zip(list(v) if isinstance(v, (list, tuple)) else [v], xs)]
+        with torch.enable_grad():
+            out = _resolve(f(*xs))
+            osingle = not isinstance(out, (list, tuple))
+            outs = [out] if osingle else list(out)
+            us = [torch.zeros_like(o, requires_grad=True) for o in outs]
+            keep = [(o, u) for o, u in zip(outs, us) if o.requires_grad]
+            jv = [torch.zeros_like(o) for o in outs]
+            if keep:
+                gr = torch.autograd.grad([o for o, _ in keep], xs, grad_outputs=[u for _, u in keep], create_graph=True,
+                                         allow_unused=True)
+                pairs = [(g_, t) for g_, t in zip(gr, vs) if g_ is not None and g_.requires_grad]
+                if pairs:
+                    res = torch.autograd.grad([g_ for g_, _ in pairs], [u for _, u in keep],
+                                              grad_outputs=[t for _, t in pairs], create_graph=nested, allow_unused=True)
+                    it = iter(res)
+                    jv = [(next(it) if o.requires_grad else z) for o, z in zip(outs, jv)]
+                    jv = [torch.zeros_like(o) if j_ is None else j_ for j_, o in zip(jv, outs)]
+        if not nested:
+            out = self.tree_map(lambda t: t.detach(), out)
+        return out, (jv[0] if osingle else type(out)(jv))
+
+    def jacrev(self, f: Callable[..., Any], argnums: Union[int, Sequence[int]] = 0) -> Callable[..., Any]:
+        """Jacobian, one reverse pass per output element: shape output + input (outer structure: outputs, inner: argnums)."""
+        torch = self._torch
+        argn = _as_tuple(argnums)
+
+        def wrapper(*args: Any, **kws: Any) -> Any:
+            args = list(args)
+            _, xs, nested = self._prep([args[i] for i in argn])
+            for i, x in zip(argn, xs):
+                args[i] = x
+            with torch.enable_grad():
+                out = _resolve(f(*args, **kws))
+                osingle = not isinstance(out, (list, tuple))
+                jjs = []
+                for o in ([out] if osingle else list(out)):
+                    rows = [[] for _ in xs]
+                    flat = o.reshape(-1)
+                    for k in range(flat.shape[0]):
+                        gr = torch.autograd.grad(flat[k], xs, retain_graph=True, create_graph=nested, allow_unused=True) \
+                            if flat.requires_grad else [None] * len(xs)
+                        for r, g_, x in zip(rows, gr, xs):
+                            r.append(torch.zeros_like(x) if g_ is None else g_)
+                    jj = [torch.stack(r).reshape(tuple(o.shape) + tuple(x.shape)) for r, x in zip(rows, xs)]
+                    jjs.append(jj[0] if len(jj) == 1 else tuple(jj))
+            return jjs[0] if osingle else tuple(jjs)
+
+        return wrapper
+
+    jacbwd = jacrev
+
+    def jacfwd(self, f: Callable[..., Any], argnums: Union[int, Sequence[int]] = 0) -> Callable[..., Any]:
+        """Jacobian by columns (one jvp per input element): shape output + input (outer structure: argnums, inner: outputs)."""
+        torch = self._torch
+        argn = _as_tuple(argnums)
+
+        def wrapper(*args: Any, **kws: Any) -> Any:
+            args = [self.convert_to_tensor(a) if i in argn else a for i, a in enumerate(args)]
+            jjs = []
+            for i in argn:
+                x = args[i]
+
+                def fi(t: Any, i: int = i) -> Any:
+                    a = list(args)
+                    a[i] = t
+                    return f(*a, **kws)
+
+                cols = []
+                for k in range(x.numel()):
+                    e = torch.zeros(x.numel(), dtype=x.dtype, device=x.device)
+                    e[k] = 1
+                    cols.append(self.jvp(fi, x, e.reshape(x.shape))[1])
+                jj = self.tree_map(lambda *c: torch.stack(c, dim=-1).reshape(tuple(c[0].shape) + tuple(x.shape)), *cols)
+                jjs.append(jj)
+            return jjs[0] if len(jjs) == 1 else tuple(jjs)
+
+        return wrapper
+
+    def hessian(self, f: Callable[..., Any], argnums: Union[int, Sequence[int]] = 0) -> Callable[..., Any]:
+        """reference abstract_backend.py:2485-2492 (jacfwd of jacrev); here reverse over reverse, the same numbers."""
+        return self.jacrev(self.jacrev(f, argnums=argnums), argnums=argnums)
+
     def grad(self, f: Callable[..., Any], argnums: Union[int, Sequence[int]] = 0,
              has_aux: bool = False) -> Callable[..., Any]:
         def wrapper(*args: Any, **kws: Any) -> Any:

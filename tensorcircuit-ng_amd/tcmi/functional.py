@@ -12,6 +12,14 @@ compose with the HIP executor.  Two primitives:
 
 Under ``torch.vmap`` both map the batch axis onto the executor's batch dimension (one launch per
 pass over ``[B, 2^n]``).
+
+Second order (reference ``abstract_backend.py:2295-2492``: jvp / jacfwd / hessian differentiate the reverse pass).  The
+VJP primitives have a backward of their own, exact, by the shift rule for STATES: every recorded gate is
+``M(a) = c0 + cos(a) c1 + sin(a) c2`` in its angle ``a = scale * theta_j + offset`` (``plan.GateRec``), so
+``d psi / d a = [psi(a + pi/2) - psi(a - pi/2)] / 2`` whatever c0, c1, c2 are.  The derivative of
+``Re <g | d psi / d theta>`` along a cotangent ``c`` therefore needs two more circuit evaluations (and two more sweeps) per
+non-zero entry of ``c`` -- a Hessian row costs O(1) gradients, like forward-over-reverse in the reference.  A parameter
+that feeds more than one gate has no two-point rule; such circuits raise.
 """
 
 from typing import Any, List, Optional, Tuple
@@ -86,11 +94,16 @@ def _fns():
 
         @staticmethod
         def setup_context(ctx, inputs, output):
-            pass
+            params, psi, g, cc = inputs
+            ctx.cc = cc
+            ctx.save_for_backward(params, g)
 
         @staticmethod
-        def backward(ctx, *a):
-            raise NotImplementedError("Backend 'hip' has not implemented second-order derivatives.")
+        def backward(ctx, c):
+            # (psi is a function of params: its slot gets no gradient of its own, the params slot carries all of it)
+            params, g = ctx.saved_tensors
+            gp2, tang = _second_order(ctx.cc, params, g, c, ctx.needs_input_grad[0], ctx.needs_input_grad[2])
+            return gp2, None, tang, None
 
         @staticmethod
         def vmap(info, in_dims, params, psi, g, cc):
@@ -183,11 +196,34 @@ def _fns():
 
         @staticmethod
         def setup_context(ctx, inputs, output):
-            pass
+            state, g, cm = inputs
+            ctx.cm = cm
+            ctx.save_for_backward(state, g)
 
         @staticmethod
-        def backward(ctx, *a):
-            raise NotImplementedError("Backend 'hip' has not implemented second-order derivatives.")
+        def backward(ctx, t):
+            """out = A psi, A = 2 sum_t Re(g_t) P_t (Hermitian).  Cotangent t of out: the state gets A t; g_t gets
+            2 Re <t | P_t psi>, taken from the measurement passes by polarisation: [<t+psi|P|t+psi> - <t-psi|P|t-psi>] / 2
+            with t scaled to psi's norm first."""
+            state, g = ctx.saved_tensors
+            cm = ctx.cm
+            single = state.dim() == 1
+            s2 = state.reshape(-1, state.shape[-1]).contiguous()
+            t2 = t.reshape(-1, t.shape[-1]).contiguous()
+            g2 = g.reshape(-1, g.shape[-1])
+            gs = gg = None
+            if ctx.needs_input_grad[0]:
+                gs = cm.apply_sum(t2, g2)
+                gs = gs[0] if single else gs.reshape(state.shape)
+            if ctx.needs_input_grad[1]:
+                tn = torch.linalg.vector_norm(t2, dim=-1, keepdim=True)
+                sn = torch.linalg.vector_norm(s2, dim=-1, keepdim=True)
+                alpha = torch.where(tn > 0, sn / tn.clamp_min(1e-300), torch.zeros_like(tn))
+                th = t2 * alpha.to(t2.dtype)
+                d = cm.run(th + s2) - cm.run(th - s2)
+                gg = (0.5 * d / alpha.clamp_min(1e-300).to(d.dtype)) * (alpha > 0).to(d.dtype)
+                gg = gg.reshape(g.shape).to(g.dtype)
+            return gs, gg, None
 
         @staticmethod
         def vmap(info, in_dims, state, g, cm):
@@ -206,6 +242,72 @@ def _fns():
     _FNS.update(StateFn=StateFn, StateVjpFn=StateVjpFn, StateVjpInFn=StateVjpInFn, MeasureFn=MeasureFn,
                 MeasureVjpFn=MeasureVjpFn)
     return _FNS
+
+
+def _shift_scales(cc):
+    """scale[j] of the one gate angle a = scale * theta_j + offset that parameter j feeds, and how many gates it feeds."""
+    tab = getattr(cc, "_shift_tab", None)
+    if tab is None:
+        gates = getattr(cc, "full", cc)._exec_gates
+        npar = max(1, cc.nparams)
+        scale, count = np.zeros(npar), np.zeros(npar, dtype=np.int64)
+        for g in gates:
+            if g.param is not None and g.select is None and g.param.index < npar:
+                scale[g.param.index] = g.param.scale
+                count[g.param.index] += 1
+        tab = cc._shift_tab = (scale, count)
+    return tab
+
+
+def _second_order(cc, params, g, c, need_params, need_g):
+    """Backward of (params, g) -> gp = Re <g | d psi / d params> along the cotangent ``c`` of gp (module docstring):
+    (d/d params of sum_j c_j gp_j, d/d g of the same = the tangent state sum_j c_j d psi / d theta_j)."""
+    torch = _torch()
+    if getattr(cc, "nonunitary", None):
+        raise NotImplementedError("Backend 'hip' has not implemented second-order derivatives through non-unitary gates.")
+    single = params.dim() == 1
+    npar = params.shape[-1]
+    p2 = params.reshape(-1, npar)
+    g2 = g.reshape(-1, g.shape[-1])
+    c2 = c.reshape(-1, npar).to(torch.float64)
+    nel = g2.shape[-1]
+    scale, count = _shift_scales(cc)
+    rows = torch.nonzero(c2).cpu().numpy()                   # (batch row, parameter) of every non-zero cotangent entry
+    gp_out = torch.zeros(p2.shape, dtype=torch.float64, device=p2.device) if need_params else None
+    t_out = torch.zeros_like(g2) if need_g else None
+    if rows.shape[0]:
+        js = rows[:, 1]
+        if (count[js] > 1).any():
+            raise NotImplementedError("Backend 'hip': second-order derivatives need every parameter to feed ONE gate "
+                                      "(parameters %s feed several)" % sorted(set(int(j) for j in js[count[js] > 1])))
+        rows = rows[count[js] == 1]                          # parameters no gate reads: zero derivative
+    # (the reverse-over-reverse jvp differentiates along a cotangent g that is identically zero: nothing to sweep)
+    g_nonzero = bool(need_params and rows.shape[0] and (g2 != 0).any())
+    item = 8 if g2.dtype == torch.complex64 else 16
+    step = max(1, int((1 << 30) // (nel * item)))            # shifted states per chunk: 2 * step of them alive
+    sc = torch.as_tensor(scale, dtype=torch.float64, device=p2.device)
+    for r0 in range(0, rows.shape[0], step):
+        bi = torch.as_tensor(rows[r0: r0 + step, 0], device=p2.device)
+        ji = torch.as_tensor(rows[r0: r0 + step, 1], device=p2.device)
+        m = bi.shape[0]
+        ar = torch.arange(m, device=p2.device)
+        delta = (0.5 * np.pi / sc[ji]).to(p2.dtype)
+        pp = p2[bi].repeat(2, 1)
+        pp[ar, ji] += delta
+        pp[m + ar, ji] -= delta
+        st = cc.state(pp, None, full=True)                   # [2 m, 2^n_exec]
+        coef = 0.5 * c2[bi, ji] * sc[ji]
+        if need_g:
+            t_out.index_add_(0, bi, (st[:m] - st[m:]) * coef.to(st.dtype).unsqueeze(1))
+        if need_params and g_nonzero:
+            gv = cc.vjp(pp, st, g2[bi].repeat(2, 1).contiguous(), from_zero=True)[:, :npar].to(torch.float64)
+            gp_out.index_add_(0, bi, (gv[:m] - gv[m:]) * coef.unsqueeze(1))
+        del st
+    if need_params:
+        gp_out = (gp_out[0] if single else gp_out.reshape(params.shape)).to(params.dtype)
+    if need_g:
+        t_out = t_out[0] if g.dim() == 1 else t_out.reshape(g.shape)
+    return gp_out, t_out
 
 
 def circuit_state_full(circuit):
