@@ -599,7 +599,8 @@ class HipBackend:
                     rows = [[] for _ in xs]
                     flat = o.reshape(-1)
                     for k in range(flat.shape[0]):
-                        gr = torch.autograd.grad(flat[k], xs, retain_graph=True, create_graph=nested, allow_unused=True) \
+                        gr = torch.autograd.grad(flat[k], xs, grad_outputs=torch.ones_like(flat[k]), retain_graph=True,
+                                                 create_graph=nested, allow_unused=True) \
                             if flat.requires_grad else [None] * len(xs)
                         for r, g_, x in zip(rows, gr, xs):
                             r.append(torch.zeros_like(x) if g_ is None else g_)

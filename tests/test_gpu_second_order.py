@@ -118,8 +118,9 @@ def test_jvp_vjp_and_jacobians_of_a_state_function():
         assert abs(lhs - float((back * torch.as_tensor(v, device=back.device)).sum())) < 1e-7
         # Jacobians: both modes, shape output + input, equal to the jvp columns
         def probs(t):
-            return tc.backend.real(_circuit(tc, n, t).expectation_ps(z=[1])) * tc.backend.ones([2]) + \
-                tc.backend.real(_circuit(tc, n, t).expectation_ps(x=[0, 2])) * tc.backend.convert_to_tensor(np.array([0.0, 1.0]))
+            c = _circuit(tc, n, t)
+            return tc.backend.stack([tc.backend.real(c.expectation_ps(z=[1])),
+                                     tc.backend.real(c.expectation_ps(z=[1]) + c.expectation_ps(x=[0, 2]))])
 
         jr = tc.backend.numpy(tc.backend.jacrev(probs)(x))
         jf = tc.backend.numpy(tc.backend.jacfwd(probs)(x))
