@@ -6,8 +6,11 @@ tests to validate ``tcmi.cut.make_cut`` against ``oracle.dense``; nothing in the
 import numpy as np
 
 
-def reference_state(spec, params: np.ndarray) -> np.ndarray:
-    """Dense numpy evaluation of the cut formula (used by the CPU tests to validate make_cut)."""
+def reference_state(spec, params: np.ndarray, program: bool = False) -> np.ndarray:
+    """Dense numpy evaluation of the cut formula (used by the CPU tests to validate make_cut).  ``program``: the tail of a
+    cut with two deferred crossing gates is applied the way the join kernel does it -- its ops (``TailProgram.tables``)
+    on the index bits (u, r1 | v, l4) of the product, whose column index is still rotated -- instead of as ordinary gates
+    on the joined state (tcmi_cgemm_split_prog's contract, csrc/tcmi_gemm_split.hip)."""
     nl, nr = spec.n_left, spec.n - spec.n_left
     K = spec.bond_dim
     radices = [len(b.terms) for b in spec.bonds]
@@ -42,23 +45,42 @@ def reference_state(spec, params: np.ndarray) -> np.ndarray:
                 w *= np.cos(a) if kind == "cos" else np.sin(a)
         pvec = np.concatenate([np.asarray(params, dtype=np.float64), np.array(digits, dtype=np.float64)])
         psi += w * np.outer(run(spec.left, nl, pvec), run(spec.right, nr, pvec))
-    if getattr(spec, "right_rot", False):
-        # the right half's qubits are labelled rotated by one (global qubit n_left is its LAST local qubit): back to the
-        # natural column order, then the deferred gate and its one-qubit tail as an ordinary two-qubit gate
+    rot = int(getattr(spec, "right_rot", 0))
+    if program:
+        prog = spec.epilogue.program
+        tabs = prog.tables(np.asarray(params, dtype=np.float64))
+        M, N = psi.shape
+        # product element (m, c'): u = m & 1, r1 = (m >> 1) & 1, v = c' & 1, l4 = (c' >> 1) & 1
+        t = psi.reshape(M // 4, 2, 2, N // 4, 2, 2)           # [m_hi, r1, u, c_hi, l4, v]
+        axis = {0: 2, 1: 1, 2: 5, 3: 4}                        # bit id -> axis
+        for k, (kind, bit, _) in enumerate(prog.ops):
+            if kind == "diag":
+                d = tabs[k].reshape(2, 2, 2, 2)                # index u + 2 r1 + 4 v + 8 l4 -> [l4, v, r1, u]
+                t = t * d.transpose(2, 3, 0, 1)[None, :, :, None, :, :]       # -> [r1, u, l4, v]
+            else:
+                m2 = tabs[k][:4].reshape(2, 2)
+                t = np.moveaxis(np.tensordot(m2, t, axes=([1], [axis[bit]])), 0, axis[bit])
+        psi = t.reshape(M, N)
+        # column c' of the product is column (c' >> rot) | ((c' & (2^rot - 1)) * N / 2^rot) of the state
+        cp = np.arange(N)
+        nat = (cp >> rot) | ((cp & ((1 << rot) - 1)) * (N >> rot))
+        out = np.empty_like(psi)
+        out[:, nat] = psi
+        return out.reshape(-1)
+    if rot:
+        # the right half's qubits are labelled rotated by `rot` (global qubits n_left .. n_left + rot - 1 are its LAST local
+        # qubits): back to the natural column order, then the deferred gates as ordinary gates on the joined state
         t = psi.reshape([2**nl] + [2] * nr)
-        psi = np.moveaxis(t, nr, 1).reshape(2**nl, 2**nr)
+        psi = np.moveaxis(t, list(range(nr - rot + 1, nr + 1)), list(range(1, rot + 1))).reshape(2**nl, 2**nr)
     if getattr(spec, "epilogue", None) is not None:
-        e = spec.epilogue
-        x = np.eye(4, dtype=np.complex128)
-        for c0, c1, c2, ref in e.factors:
-            m = np.array(c0, dtype=np.complex128)
-            if ref is not None:
-                a = ref.scale * params[ref.index] + ref.offset
-                m = m + np.cos(a) * c1 + np.sin(a) * c2
-            x = m @ x
-        t = psi.reshape([2] * spec.n)
-        t = np.moveaxis(t, [e.ql, e.qr], [0, 1])
-        shp = t.shape
-        t = (x @ t.reshape(4, -1)).reshape(shp)
-        psi = np.ascontiguousarray(np.moveaxis(t, [0, 1], [e.ql, e.qr]))
+        st = psi.reshape(-1)
+        for g in spec.epilogue.tail:
+            m = g.matrix(np.asarray(params, dtype=np.float64))
+            k = len(g.qubits)
+            t = st.reshape([2] * spec.n)
+            t = np.moveaxis(t, list(g.qubits), range(k))
+            shp = t.shape
+            t = (m.reshape(2**k, 2**k) @ t.reshape(2**k, -1)).reshape(shp)
+            st = np.ascontiguousarray(np.moveaxis(t, range(k), list(g.qubits))).reshape(-1)
+        psi = st
     return psi.reshape(-1)

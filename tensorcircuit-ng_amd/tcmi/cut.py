@@ -30,6 +30,13 @@ bond dimension halves (ZZ / CNOT / CZ crossings) and with it the GEMM and the su
 config 2 (exp1(ZZ) ladder, then rx on every qubit) qualifies, K = 256 -> 128.  For the thread-local epilogue q_l must be
 the left half's lowest index bit (q_l = n_left - 1) and q_r is made the right half's lowest bit by labelling the right
 half's qubits rotated by one (``CutSpec.right_rot``; the kernel un-rotates the column index when it stores).
+
+**Two deferred crossing gates** (``find_tail``, ``make_cut(defer=2)``).  The same argument for the last TWO crossing gates:
+the tail -- every later gate that does not commute with what is already in it -- then spans up to two qubits on either
+side of the cut, and is no longer one 4 x 4 but a small gate program (one-qubit gates and diagonals over <= 4 index bits:
+``TailProgram``), which the join kernel runs on the eight results a thread holds for two row bits and one column bit,
+the second column bit being a lane bit (``tcmi_cgemm_split_prog``).  The right half is labelled rotated by two.  A
+quarter of the bond dimension: config 2's K = 256 -> 64.
 """
 
 from dataclasses import dataclass
@@ -69,6 +76,8 @@ class Epilogue:
     ql: int
     qr: int
     factors: List[Tuple[np.ndarray, np.ndarray, np.ndarray, Optional[P.ParamRef]]]
+    tail: Optional[List[P.GateRec]] = None       # the deferred gates themselves (global qubits, time order)
+    program: Optional["TailProgram"] = None        # two deferred crossing gates: the tail as a gate program, factors empty
 
     def matrix(self, params) -> np.ndarray:
         x = np.eye(4, dtype=np.complex128)
@@ -81,6 +90,35 @@ class Epilogue:
         return x
 
 
+BIT_U, BIT_R1, BIT_V, BIT_L4 = 0, 1, 2, 3   # index bits of the join result a tail program addresses: row bits 0, 1, column bits 0, 1
+
+
+@dataclass
+class TailProgram:
+    """The tail of a cut with deferred crossing gates as the join kernel runs it.  ``ops`` in time order:
+    ("g1", bit, [factor]) a 2 x 2 on one index bit, ("diag", -1, [factors]) a diagonal over the 16 values of
+    (u, r1, v, l4) = index u + 2 r1 + 4 v + 8 l4 (consecutive diagonal gates merged: the product of their factors);
+    factor = (c0, c1, c2, ParamRef | None), 16 complex entries each (a 2 x 2 row-major in the first four)."""
+
+    r: int
+    c: int
+    ops: List[tuple]
+
+    def tables(self, params) -> np.ndarray:
+        """[nops, 16] complex: what tcmi_cut_epilogue_program builds on the device."""
+        out = np.zeros((len(self.ops), 16), dtype=np.complex128)
+        for k, (_, _, factors) in enumerate(self.ops):
+            v = np.ones(16, dtype=np.complex128)
+            for c0, c1, c2, ref in factors:
+                m = np.array(c0, dtype=np.complex128)
+                if ref is not None:
+                    a = ref.scale * float(params[ref.index]) + ref.offset
+                    m = m + np.cos(a) * c1 + np.sin(a) * c2
+                v = v * m
+            out[k] = v
+        return out
+
+
 @dataclass
 class CutSpec:
     n: int
@@ -90,7 +128,7 @@ class CutSpec:
     bonds: List[Bond]
     nparams: int               # circuit parameters; selector column of bond k = nparams + k
     epilogue: Optional[Epilogue] = None
-    right_rot: bool = False    # right half labelled rotated by one: global qubit q is local (q - n_left - 1) mod n_right
+    right_rot: int = 0         # right half labelled rotated by this many: global qubit q is local (q - n_left - rot) mod n_right
 
     @property
     def bond_dim(self) -> int:
@@ -140,8 +178,70 @@ def find_deferred(gates: List[P.GateRec], n_left: int):
     return p, absorbed
 
 
+def _commute(h: P.GateRec, t: P.GateRec) -> bool:
+    return not (set(h.qubits) & set(t.qubits)) or (h.is_diag and t.is_diag)
+
+
+def find_tail(gates: List[P.GateRec], n_left: int, ndefer: int = 2, rmax: int = 2, cmax: int = 2):
+    """Indices (time order) of the gates that leave the half-circuits when the last ``ndefer`` crossing gates are applied
+    after the join, and the (r, c) qubits they span on either side of the cut; None when the circuit does not allow it.
+    The tail starts with the ``ndefer``-th last crossing gate; a later gate joins it when it crosses the cut or does not
+    commute with a gate already in the tail (a gate that stays in its half is thereby moved BEFORE the tail gates that
+    preceded it, so it has to commute with exactly those).  Tail gates have to be one-qubit gates or diagonals inside the
+    window of ``rmax`` left and ``cmax`` right qubits next to the cut."""
+    def crossing(g):
+        return any(q < n_left for q in g.qubits) and any(q >= n_left for q in g.qubits)
+
+    cross = [i for i, g in enumerate(gates) if crossing(g)]
+    if len(cross) < ndefer:
+        return None
+    tail = []
+    for i in range(cross[-ndefer], len(gates)):
+        h = gates[i]
+        if not crossing(h) and all(_commute(h, gates[t]) for t in tail):
+            continue
+        if h.select is not None or not (len(h.qubits) == 1 or h.is_diag):
+            return None
+        if any(q < n_left - rmax or q >= n_left + cmax for q in h.qubits):
+            return None
+        tail.append(i)
+    qs = [q for t in tail for q in gates[t].qubits]
+    return tail, n_left - min(qs), max(qs) - n_left + 1
+
+
+def tail_program(gates: List[P.GateRec], tail: List[int], n_left: int, r: int, c: int) -> Optional[TailProgram]:
+    """The tail as ops on the index bits (u, r1 | v, l4) of the join result; None when it needs more than two diagonal ops
+    or twelve ops in all (what the kernel keeps in registers)."""
+    bit = {n_left - 1: BIT_U, n_left - 2: BIT_R1, n_left + c - 1: BIT_V}
+    if c == 2:
+        bit[n_left] = BIT_L4
+    ops = []
+    for t in tail:
+        g = gates[t]
+        z = lambda m, size: np.zeros(size, dtype=np.complex128) if m is None else np.asarray(m, dtype=np.complex128)
+        if g.is_diag:
+            # the diagonal of c0 + cos c1 + sin c2 over the gate's qubits, spread over the 16 values of (u, r1, v, l4)
+            k = len(g.qubits)
+            idx = np.zeros(16, dtype=np.int64)
+            for e in range(16):
+                for j, q in enumerate(g.qubits):
+                    idx[e] |= ((e >> bit[q]) & 1) << (k - 1 - j)
+            fac = tuple(np.diag(z(m, (2**k, 2**k)).reshape(2**k, 2**k))[idx] for m in (g.c0, g.c1, g.c2)) + (g.param,)
+            if ops and ops[-1][0] == "diag":
+                ops[-1][2].append(fac)
+            else:
+                ops.append(("diag", -1, [fac]))
+        else:
+            fac = tuple(np.concatenate([z(m, (2, 2)).reshape(4), np.zeros(12, dtype=np.complex128)])
+                        for m in (g.c0, g.c1, g.c2)) + (g.param,)
+            ops.append(("g1", bit[g.qubits[0]], [fac]))
+    if sum(1 for o in ops if o[0] == "diag") > 2 or len(ops) > 12:
+        return None
+    return TailProgram(r, c, ops)
+
+
 def make_cut(gates: List[P.GateRec], n: int, n_left: int, nparams: int, max_bond: int = 1 << 12,
-             defer: bool = False) -> Optional[CutSpec]:
+             defer: int = 0) -> Optional[CutSpec]:
     """Split the gate list at qubit ``n_left``; None if a gate cannot be split (3-qubit crossing,
     parametrised crossing gate that is not of the exp1 form) or the bond exceeds ``max_bond``.  ``defer``: apply the
     last crossing gate after the join when the circuit allows it (``find_deferred``)."""
@@ -149,7 +249,16 @@ def make_cut(gates: List[P.GateRec], n: int, n_left: int, nparams: int, max_bond
     bond = 1
     epi, skip = None, set()
     n_right = n - n_left
-    if defer:
+    rot = 0
+    if int(defer) >= 2:
+        found = find_tail(gates, n_left, 2)
+        if found is not None and found[2] == 2 and n_right > 2:
+            tail, r, c = found
+            prog = tail_program(gates, tail, n_left, r, c)
+            if prog is not None:
+                epi = Epilogue(n_left - 1, n_left, [], [gates[t] for t in tail], prog)
+                skip, rot = set(tail), 2
+    if defer and epi is None:
         found = find_deferred(gates, n_left)
         if found is not None:
             p, absorbed = found
@@ -171,11 +280,11 @@ def make_cut(gates: List[P.GateRec], n: int, n_left: int, nparams: int, max_bond
                 else:
                     factors.append((c0 if c0 is not None else z, lift(g.c1) if g.c1 is not None else z,
                                     lift(g.c2) if g.c2 is not None else z, g.param))
-            epi = Epilogue(ql, qr, factors)
-            skip = set([p] + absorbed)
+            epi = Epilogue(ql, qr, factors, [gates[i] for i in [p] + absorbed])
+            skip, rot = set([p] + absorbed), 1
 
     def rloc(q):       # local index of global qubit q in the right half
-        return (q - n_left - 1) % n_right if epi is not None else q - n_left
+        return (q - n_left - rot) % n_right
 
     for gi, g in enumerate(gates):
         if gi in skip:
@@ -227,4 +336,4 @@ def make_cut(gates: List[P.GateRec], n: int, n_left: int, nparams: int, max_bond
         bond *= len(terms)
         if bond > max_bond:
             return None
-    return CutSpec(n, n_left, left, right, bonds, nparams, epi, epi is not None)
+    return CutSpec(n, n_left, left, right, bonds, nparams, epi, rot)
