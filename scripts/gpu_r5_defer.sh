@@ -1,8 +1,8 @@
 #!/bin/bash
-# deferred last crossing gate: kernel + cut tests, then the headline with and without it
+# deferred crossing gates: kernel + cut tests, then the headline with two / one / no deferred gate
 mkdir -p gpurun_out/r5_defer
 timeout 900 python -m pytest tests/test_gpu_gemm_split.py -x -q 2>&1 | tail -15
-for dfr in 1 0; do
+for dfr in 2 1 0; do
   echo "== TCMI_CUT_DEFER=$dfr"
   TCMI_CUT_DEFER=$dfr timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-traffic-probe --no-hea-a \
     --vqe-qubits 0 --mps-qubits 0 --rqc-depth 0 --svqa-qubits 0 > gpurun_out/r5_defer/d$dfr.json 2> gpurun_out/r5_defer/d$dfr.err

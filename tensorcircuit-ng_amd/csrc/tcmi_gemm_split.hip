@@ -45,6 +45,23 @@
 // is the caller's column index rotated left by one bit (B's columns come from a half-circuit whose first qubit was
 // labelled last): column c of the product is stored at (c >> 1) | ((c & 1) * N / 2), as 8-byte stores that are 256
 // bytes contiguous per row over 32 lanes.
+//
+// EPI = 2 (tcmi_cgemm_split_prog): the tail of TWO deferred crossing gates, a small gate program over four index bits of
+// the product -- row bits 0, 1 (u: which MFMA tile; r1: accumulator element parity) and column bits 0, 1 (v: which MFMA
+// tile; l4: LANE bit 4) -- run on the eight results (u, r1, v) a thread holds per accumulator-element pair: one-qubit
+// gates on u / r1 / v mix values inside the thread (4 x 2 v_pk_fma_f32 per value pair, matrix in SGPRs), on l4 with the
+// partner lane's values (ds_swizzle xor 16), diagonals multiply by a per-lane phase table kept in registers (two
+// diagonal ops at most).  For column bit 1 to be a lane bit the B loader reads column pairs in the order
+// sigma(j) = 2 (j & 15) + (j >> 4), so MFMA column j of a wave is product column 2 sigma(j) + v; product column c is
+// stored at (c >> 2) | ((c & 3) * N / 4): 16 lanes write 128 contiguous bytes.  prog = {nops, op of diagonal slot 0, of
+// slot 1, then per op: kind (0 one-qubit, 1 diagonal) | bit << 4 | slot << 8}; T = complex64 [batch][nops][16] (2 x 2
+// row-major in the first four entries / the 16 phases indexed u + 2 r1 + 4 v + 8 l4), from tcmi_cut_epilogue_program.
+// Measured on config 2 (K = 64 instead of 128): 28.8 us per tile against 20.9 -- the K loop is down to 4 steps (12.4 us
+// with the 4 x 4 epilogue at this K) but the program costs 16 us: it runs per group of eight results with the op words and
+// matrices fetched by scalar loads inside the op loop (64 dependent round trips per tile), and even with those hoisted
+// its general 2 x 2 ops (12 instructions per value pair, 20 with a lane exchange) come to ~13 k cycles per tile, the
+// break-even.  It would need the shear forms of the tile-VM's rotations (1 v_pk_fma_f32 per pair and shear) to win; kept
+// as an option (TCMI_CUT_DEFER=2), off by default.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -80,7 +97,7 @@ template <int MODE, int EPI>
 __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __restrict__ A, const float2* __restrict__ B,
                                                               float2* __restrict__ C, int M, int N, int K, long long sA,
                                                               long long sB, long long sC, int tiles_x, int tiles_y, int batch,
-                                                              const float2* __restrict__ X) {
+                                                              const float2* __restrict__ X, const int* __restrict__ prog) {
   extern __shared__ __attribute__((aligned(16))) char dsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
@@ -118,7 +135,9 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
   // loader role of the wave: operand (waves 0, 1: A; 2, 3: B) and k half; lane = row pair
   const int lop = wave >> 1, lkg = wave & 1;
   const long long R = lop ? N : M;
-  const long long lofs = 2 * lane + (long long)(lkg * 8) * R;
+  // (EPI 2: the B loader takes column pairs in the order sigma, see the header)
+  const int lsig = (EPI == 2 && lop) ? ((lane & 32) | ((lane & 15) << 1) | ((lane >> 4) & 1)) : lane;
+  const long long lofs = 2 * lsig + (long long)(lkg * 8) * R;
   const float2* src = (lop ? B + (long long)bi * sB + n0 : A + (long long)bi * sA + m0) + lofs;       // this tile
   const float2* src1 = (lop ? B + (long long)bi1 * sB + n1 : A + (long long)bi1 * sA + m1) + lofs;   // the next one
   // this thread's write slot inside a plane block: k half, then position of row 2 lane (+ 32 positions for row 2 lane + 1)
@@ -257,7 +276,99 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
     // the last step cut block 0 of the next tile into stage 0 and blocks 0, 1 of it are (being) loaded: only the
     // results stand between the tiles.  MFMA result element (i = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), j = lane & 31)
     // of tile (u, v) is C[wr 64 + 2 i + u][wc 64 + 2 j + v]
-    if (EPI) {
+    if (EPI == 2) {
+      float2* Cb = C + (long long)bi * sC;
+      const int nops = prog[0];
+      const float2* Tb = X + (long long)__builtin_amdgcn_readfirstlane(bi) * nops * 16;
+      const int l4 = (lane >> 4) & 1;
+      // this lane's half of the two diagonal tables (phases of index u + 2 r1 + 4 v at its l4), and (-im, re) of them
+      f32x2_ dph[2][8], dps[2][8];
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        const int od = prog[1 + sl];
+        const float2* tp = Tb + (od < 0 ? 0 : od) * 16 + 8 * l4;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float2 ph = tp[e];
+          dph[sl][e] = f32x2_{ph.x, ph.y};
+          dps[sl][e] = f32x2_{-ph.y, ph.x};
+        }
+      }
+      const long long colq = ((n0 + wc * 64) >> 2) + (lane & 15);
+      const long long quarter = (long long)N >> 2;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        f32x2_ val[8];      // index u + 2 r1 + 4 v
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r1 = 0; r1 < 2; ++r1)
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+              const int reg = 2 * q + r1;
+              const float re = acc[u][v][0][reg] - acc[u][v][1][reg];
+              const float im = acc[u][v][2][reg] - acc[u][v][0][reg] - acc[u][v][1][reg];
+              val[u + 2 * r1 + 4 * v] = f32x2_{re, im};
+#pragma unroll
+              for (int t = 0; t < 3; ++t) acc[u][v][t][reg] = 0.f;
+            }
+        for (int o = 0; o < nops; ++o) {
+          const int w = prog[3 + o];
+          const int kind = w & 15, bit = (w >> 4) & 15, slot = (w >> 8) & 1;
+          if (kind == 1) {
+#define TCMI_S2_DIAG(SL)                                                                          \
+  _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                   \
+    const f32x2_ xr_ = {val[e].x, val[e].x}, xi_ = {val[e].y, val[e].y};                            \
+    val[e] = __builtin_elementwise_fma(xi_, dps[SL][e], xr_ * dph[SL][e]);                           \
+  }
+            if (slot == 0) { TCMI_S2_DIAG(0) } else { TCMI_S2_DIAG(1) }
+#undef TCMI_S2_DIAG
+          } else {
+            const float2* mp = Tb + o * 16;
+            const float2 m00 = mp[0], m01 = mp[1], m10 = mp[2], m11 = mp[3];
+            if (bit == 3) {
+              // the partner value sits in lane ^ 16: new = a mine + b partner, (a, b) = (m00, m01) for l4 = 0, (m11, m10) else
+              const float ar = l4 ? m11.x : m00.x, ai = l4 ? m11.y : m00.y, br = l4 ? m10.x : m01.x, bi_ = l4 ? m10.y : m01.y;
+              const f32x2_ arr = {ar, ar}, aii = {ai, ai}, brr = {br, br}, bii = {bi_, bi_};
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                f32x2_ pt;
+                pt.x = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(val[e].x), 0x401F));
+                pt.y = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(val[e].y), 0x401F));
+                const f32x2_ ms = {-val[e].y, val[e].x}, ps = {-pt.y, pt.x};
+                f32x2_ y = arr * val[e];
+                y = __builtin_elementwise_fma(aii, ms, y);
+                y = __builtin_elementwise_fma(brr, pt, y);
+                val[e] = __builtin_elementwise_fma(bii, ps, y);
+              }
+            } else {
+              const f32x2_ a00r = {m00.x, m00.x}, a00i = {m00.y, m00.y}, a01r = {m01.x, m01.x}, a01i = {m01.y, m01.y};
+              const f32x2_ a10r = {m10.x, m10.x}, a10i = {m10.y, m10.y}, a11r = {m11.x, m11.x}, a11i = {m11.y, m11.y};
+#define TCMI_S2_G1(ST)                                                                                       \
+  _Pragma("unroll") for (int e = 0; e < 8; ++e) if (!(e & (ST))) {                                            \
+    const f32x2_ x0 = val[e], x1 = val[e | (ST)];                                                             \
+    const f32x2_ s0 = {-x0.y, x0.x}, s1 = {-x1.y, x1.x};                                                      \
+    f32x2_ y0 = a00r * x0, y1 = a10r * x0;                                                                    \
+    y0 = __builtin_elementwise_fma(a00i, s0, y0); y1 = __builtin_elementwise_fma(a10i, s0, y1);               \
+    y0 = __builtin_elementwise_fma(a01r, x1, y0); y1 = __builtin_elementwise_fma(a11r, x1, y1);               \
+    val[e] = __builtin_elementwise_fma(a01i, s1, y0); val[e | (ST)] = __builtin_elementwise_fma(a11i, s1, y1); \
+  }
+              if (bit == 0) { TCMI_S2_G1(1) } else if (bit == 1) { TCMI_S2_G1(2) } else { TCMI_S2_G1(4) }
+#undef TCMI_S2_G1
+            }
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int u = e & 1, r1 = (e >> 1) & 1, v = e >> 2;
+          const long long row = m0 + wr * 64 + 2 * (r1 + 2 * (q & 1) + 8 * (q >> 1) + 4 * (lane >> 5)) + u;
+          float2 w2;
+          w2.x = val[e].x;
+          w2.y = val[e].y;
+          Cb[row * N + colq + (v + 2 * l4) * quarter] = w2;
+        }
+      }
+    } else if (EPI) {
       // y[2 u' + v'] = sum_{u, v} X[b][2 u' + v'][2 u + v] c[u][v]; column 2 j + v of the product is column j + v N / 2 of C
       float2* Cb = C + (long long)bi * sC;
       const float2* Xb = X + (long long)__builtin_amdgcn_readfirstlane(bi) * 16;
@@ -368,7 +479,7 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
 namespace {
 
 int split_launch(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch, long long strideA,
-                 long long strideB, long long strideC, const void* X, void* stream, const char* who) {
+                 long long strideB, long long strideC, const void* X, const int* prog, void* stream, const char* who) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #ifdef TCMI_SPLIT_PROBE
   // probe builds of the kernel (libtcmi_probe.so only, scripts/gpu_gemm_split_modes.py): 1 no conversion, 2 no MFMA,
@@ -406,9 +517,11 @@ int split_launch(const void* A, const void* B, void* C, long long M, long long N
     hipLaunchKernelGGL((tcmi::cgemm_split_kernel<MODE, EPI>), dim3((unsigned)(nwork < ncu ? nwork : ncu), 1, 1),       \
                        dim3(256), 2 * tcmi::SPLIT_STAGE_BYTES, st, reinterpret_cast<const float2*>(A),                 \
                        reinterpret_cast<const float2*>(B), reinterpret_cast<float2*>(C), (int)M, (int)N, (int)K, strideA, \
-                       strideB, strideC, txn, tyn, batch, reinterpret_cast<const float2*>(X));                         \
+                       strideB, strideC, txn, tyn, batch, reinterpret_cast<const float2*>(X), prog);                   \
   }
-  if (X) {
+  if (X && prog) {
+    TCMI_SPLIT_LAUNCH(0, 2)
+  } else if (X) {
 #ifdef TCMI_SPLIT_PROBE
     // 7: epilogue without its multiply-adds, 8: its results as 16-byte stores (wrong places), 9: no result stores
     if (mode == 7) TCMI_SPLIT_LAUNCH(7, 1)
@@ -441,13 +554,20 @@ extern "C" {
 
 int tcmi_cgemm_split(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch,
                      long long strideA, long long strideB, long long strideC, void* stream) {
-  return split_launch(A, B, C, M, N, K, batch, strideA, strideB, strideC, nullptr, stream, "tcmi_cgemm_split");
+  return split_launch(A, B, C, M, N, K, batch, strideA, strideB, strideC, nullptr, nullptr, stream, "tcmi_cgemm_split");
 }
 
 int tcmi_cgemm_split_epi(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch,
                          long long strideA, long long strideB, long long strideC, const void* X, void* stream) {
   if (!X) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm_split_epi: X is null");
-  return split_launch(A, B, C, M, N, K, batch, strideA, strideB, strideC, X, stream, "tcmi_cgemm_split_epi");
+  return split_launch(A, B, C, M, N, K, batch, strideA, strideB, strideC, X, nullptr, stream, "tcmi_cgemm_split_epi");
+}
+
+int tcmi_cgemm_split_prog(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch,
+                          long long strideA, long long strideB, long long strideC, const int* prog, const void* T,
+                          void* stream) {
+  if (!prog || !T) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm_split_prog: prog / T is null");
+  return split_launch(A, B, C, M, N, K, batch, strideA, strideB, strideC, T, prog, stream, "tcmi_cgemm_split_prog");
 }
 
 }  // extern "C"
