@@ -61,9 +61,13 @@ def reference_state(spec, params: np.ndarray, program: bool = False) -> np.ndarr
                 m2 = tabs[k][:4].reshape(2, 2)
                 t = np.moveaxis(np.tensordot(m2, t, axes=([1], [axis[bit]])), 0, axis[bit])
         psi = t.reshape(M, N)
-        # column c' of the product is column (c' >> rot) | ((c' & (2^rot - 1)) * N / 2^rot) of the state
+        # column c' of the product is column (c' >> rot) | (block * N / 2^rot) of the state, block = v + 2 l4 or -- when v is
+        # the first right-hand qubit (program.vhigh) -- 2 v + l4
         cp = np.arange(N)
-        nat = (cp >> rot) | ((cp & ((1 << rot) - 1)) * (N >> rot))
+        low = cp & ((1 << rot) - 1)
+        if getattr(prog, "vhigh", 0):
+            low = 2 * (low & 1) + (low >> 1)
+        nat = (cp >> rot) | (low * (N >> rot))
         out = np.empty_like(psi)
         out[:, nat] = psi
         return out.reshape(-1)
@@ -71,7 +75,10 @@ def reference_state(spec, params: np.ndarray, program: bool = False) -> np.ndarr
         # the right half's qubits are labelled rotated by `rot` (global qubits n_left .. n_left + rot - 1 are its LAST local
         # qubits): back to the natural column order, then the deferred gates as ordinary gates on the joined state
         t = psi.reshape([2**nl] + [2] * nr)
-        psi = np.moveaxis(t, list(range(nr - rot + 1, nr + 1)), list(range(1, rot + 1))).reshape(2**nl, 2**nr)
+        src = list(range(nr - rot + 1, nr + 1))
+        if getattr(getattr(spec.epilogue, "program", None), "vhigh", 0):
+            src = src[::-1]          # (the two rotated qubits also changed places)
+        psi = np.moveaxis(t, src, list(range(1, rot + 1))).reshape(2**nl, 2**nr)
     if getattr(spec, "epilogue", None) is not None:
         st = psi.reshape(-1)
         for g in spec.epilogue.tail:

@@ -56,12 +56,15 @@
 // stored at (c >> 2) | ((c & 3) * N / 4): 16 lanes write 128 contiguous bytes.  prog = {nops, op of diagonal slot 0, of
 // slot 1, then per op: kind (0 one-qubit, 1 diagonal) | bit << 4 | slot << 8}; T = complex64 [batch][nops][16] (2 x 2
 // row-major in the first four entries / the 16 phases indexed u + 2 r1 + 4 v + 8 l4), from tcmi_cut_epilogue_program.
-// Measured on config 2 (K = 64 instead of 128): 28.8 us per tile against 20.9 -- the K loop is down to 4 steps (12.4 us
-// with the 4 x 4 epilogue at this K) but the program costs 16 us: it runs per group of eight results with the op words and
-// matrices fetched by scalar loads inside the op loop (64 dependent round trips per tile), and even with those hoisted
-// its general 2 x 2 ops (12 instructions per value pair, 20 with a lane exchange) come to ~13 k cycles per tile, the
-// break-even.  It would need the shear forms of the tile-VM's rotations (1 v_pk_fma_f32 per pair and shear) to win; kept
-// as an option (TCMI_CUT_DEFER=2), off by default.
+// The program runs with the ops outside and the thread's 64 results inside (an op's word and coefficients are fetched
+// once per tile, one op ahead); one-qubit ops come in three forms chosen by the host from the gate's matrices: any 2 x 2
+// (8 v_pk_fma_f32 per value pair), real matrix (4), real diagonal with imaginary off-diagonal = rx (4 + two sign flips).
+// Measured on config 2 (K = 64 instead of 128; HEA-B's tail: diagonal, rx, rx, diagonal, rx x 4, one of them on l4):
+// 21.6 us per tile against 20.2 with ONE deferred gate (1.73e11 against 1.81e11 amplitudes/s) -- the K loop is down to
+// 4 steps (12.4 us per tile with the 4 x 4 epilogue at this K) but the program's ~3500 vector instructions per tile (of
+// them ~500 moves between VGPRs and the AGPRs the compiler parks part of the 64 results in) cost what the four steps
+// saved.  A first version with the ops inside (scalar loads of every op per group of eight results) took 28.8 us.  Kept as
+// an option (TCMI_CUT_DEFER=2), off by default.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -277,28 +280,16 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
     // results stand between the tiles.  MFMA result element (i = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), j = lane & 31)
     // of tile (u, v) is C[wr 64 + 2 i + u][wc 64 + 2 j + v]
     if (EPI == 2) {
+      // ops outside, the 64 results of the thread inside: an op's word and coefficients are fetched once per tile, one op
+      // ahead of their use; the two diagonal tables are requested before the accumulators are read
       float2* Cb = C + (long long)bi * sC;
-      const int nops = prog[0];
+      const int hdr = prog[0];
+      const int nops = hdr & 255, vhigh = (hdr >> 8) & 1;
       const float2* Tb = X + (long long)__builtin_amdgcn_readfirstlane(bi) * nops * 16;
       const int l4 = (lane >> 4) & 1;
-      // this lane's half of the two diagonal tables (phases of index u + 2 r1 + 4 v at its l4), and (-im, re) of them
-      f32x2_ dph[2][8], dps[2][8];
+      f32x2_ val[8][8];     // [accumulator element pair q][u + 2 r1 + 4 v]
 #pragma unroll
-      for (int sl = 0; sl < 2; ++sl) {
-        const int od = prog[1 + sl];
-        const float2* tp = Tb + (od < 0 ? 0 : od) * 16 + 8 * l4;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float2 ph = tp[e];
-          dph[sl][e] = f32x2_{ph.x, ph.y};
-          dps[sl][e] = f32x2_{-ph.y, ph.x};
-        }
-      }
-      const long long colq = ((n0 + wc * 64) >> 2) + (lane & 15);
-      const long long quarter = (long long)N >> 2;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        f32x2_ val[8];      // index u + 2 r1 + 4 v
+      for (int q = 0; q < 8; ++q)
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -308,66 +299,122 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
               const int reg = 2 * q + r1;
               const float re = acc[u][v][0][reg] - acc[u][v][1][reg];
               const float im = acc[u][v][2][reg] - acc[u][v][0][reg] - acc[u][v][1][reg];
-              val[u + 2 * r1 + 4 * v] = f32x2_{re, im};
+              val[q][u + 2 * r1 + 4 * v] = f32x2_{re, im};
 #pragma unroll
               for (int t = 0; t < 3; ++t) acc[u][v][t][reg] = 0.f;
             }
-        for (int o = 0; o < nops; ++o) {
-          const int w = prog[3 + o];
-          const int kind = w & 15, bit = (w >> 4) & 15, slot = (w >> 8) & 1;
-          if (kind == 1) {
-#define TCMI_S2_DIAG(SL)                                                                          \
-  _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                   \
-    const f32x2_ xr_ = {val[e].x, val[e].x}, xi_ = {val[e].y, val[e].y};                            \
-    val[e] = __builtin_elementwise_fma(xi_, dps[SL][e], xr_ * dph[SL][e]);                           \
-  }
-            if (slot == 0) { TCMI_S2_DIAG(0) } else { TCMI_S2_DIAG(1) }
-#undef TCMI_S2_DIAG
-          } else {
-            const float2* mp = Tb + o * 16;
-            const float2 m00 = mp[0], m01 = mp[1], m10 = mp[2], m11 = mp[3];
-            if (bit == 3) {
-              // the partner value sits in lane ^ 16: new = a mine + b partner, (a, b) = (m00, m01) for l4 = 0, (m11, m10) else
-              const float ar = l4 ? m11.x : m00.x, ai = l4 ? m11.y : m00.y, br = l4 ? m10.x : m01.x, bi_ = l4 ? m10.y : m01.y;
-              const f32x2_ arr = {ar, ar}, aii = {ai, ai}, brr = {br, br}, bii = {bi_, bi_};
+      int w = prog[3];
+      f32x4_ ca = *reinterpret_cast<const f32x4_*>(Tb), cb = *reinterpret_cast<const f32x4_*>(Tb + 2);
+      for (int o = 0; o < nops; ++o) {
+        const int on = o + 1 < nops ? o + 1 : o;
+        const int wn = prog[3 + on];
+        const f32x4_ na = *reinterpret_cast<const f32x4_*>(Tb + on * 16), nb = *reinterpret_cast<const f32x4_*>(Tb + on * 16 + 2);
+        const int kind = w & 15, bit = (w >> 4) & 15, slot = (w >> 8) & 1;
+        // m00 = (ca.x, ca.y), m01 = (ca.z, ca.w), m10 = (cb.x, cb.y), m11 = (cb.z, cb.w)
+        if (kind == 1) {
+          // this lane's half of the diagonal's table: the phases of index u + 2 r1 + 4 v at its l4
+          const f32x4_* tp = reinterpret_cast<const f32x4_*>(Tb + o * 16 + 8 * l4);
+          f32x4_ pq[4];
+#pragma unroll
+          for (int h = 0; h < 4; ++h) pq[h] = tp[h];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const f32x2_ ph = (e & 1) ? f32x2_{pq[e >> 1].z, pq[e >> 1].w} : f32x2_{pq[e >> 1].x, pq[e >> 1].y};
+            const f32x2_ ps = {-ph.y, ph.x};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const f32x2_ x_ = val[q][e];
+              const f32x2_ xr_ = {x_.x, x_.x}, xi_ = {x_.y, x_.y};
+              val[q][e] = __builtin_elementwise_fma(xi_, ps, xr_ * ph);
+            }
+          }
+          (void)slot;
+        } else if (bit == 3) {
+          // the partner value sits in lane ^ 16: new = a mine + b partner, (a, b) = (m00, m01) for l4 = 0, (m11, m10) else
+          const float ar = l4 ? cb.z : ca.x, ai = l4 ? cb.w : ca.y, br = l4 ? cb.x : ca.z, bi_ = l4 ? cb.y : ca.w;
+          const f32x2_ arr = {ar, ar}, aii = {ai, ai}, brr = {br, br}, bii = {bi_, bi_};
+          if (kind == 3) {          // real diagonal, imaginary off-diagonal (rx): a mine + i b partner
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                f32x2_ ps;
+                ps.y = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(val[q][e].x), 0x401F));
+                ps.x = -__int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(val[q][e].y), 0x401F));
+                val[q][e] = __builtin_elementwise_fma(bii, ps, arr * val[q][e]);
+              }
+          } else if (kind == 2) {   // real matrix
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
                 f32x2_ pt;
-                pt.x = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(val[e].x), 0x401F));
-                pt.y = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(val[e].y), 0x401F));
-                const f32x2_ ms = {-val[e].y, val[e].x}, ps = {-pt.y, pt.x};
-                f32x2_ y = arr * val[e];
+                pt.x = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(val[q][e].x), 0x401F));
+                pt.y = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(val[q][e].y), 0x401F));
+                val[q][e] = __builtin_elementwise_fma(brr, pt, arr * val[q][e]);
+              }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                f32x2_ pt;
+                pt.x = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(val[q][e].x), 0x401F));
+                pt.y = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(val[q][e].y), 0x401F));
+                const f32x2_ ms = {-val[q][e].y, val[q][e].x}, ps = {-pt.y, pt.x};
+                f32x2_ y = arr * val[q][e];
                 y = __builtin_elementwise_fma(aii, ms, y);
                 y = __builtin_elementwise_fma(brr, pt, y);
-                val[e] = __builtin_elementwise_fma(bii, ps, y);
+                val[q][e] = __builtin_elementwise_fma(bii, ps, y);
               }
-            } else {
-              const f32x2_ a00r = {m00.x, m00.x}, a00i = {m00.y, m00.y}, a01r = {m01.x, m01.x}, a01i = {m01.y, m01.y};
-              const f32x2_ a10r = {m10.x, m10.x}, a10i = {m10.y, m10.y}, a11r = {m11.x, m11.x}, a11i = {m11.y, m11.y};
-#define TCMI_S2_G1(ST)                                                                                       \
-  _Pragma("unroll") for (int e = 0; e < 8; ++e) if (!(e & (ST))) {                                            \
-    const f32x2_ x0 = val[e], x1 = val[e | (ST)];                                                             \
-    const f32x2_ s0 = {-x0.y, x0.x}, s1 = {-x1.y, x1.x};                                                      \
-    f32x2_ y0 = a00r * x0, y1 = a10r * x0;                                                                    \
-    y0 = __builtin_elementwise_fma(a00i, s0, y0); y1 = __builtin_elementwise_fma(a10i, s0, y1);               \
-    y0 = __builtin_elementwise_fma(a01r, x1, y0); y1 = __builtin_elementwise_fma(a11r, x1, y1);               \
-    val[e] = __builtin_elementwise_fma(a01i, s1, y0); val[e | (ST)] = __builtin_elementwise_fma(a11i, s1, y1); \
-  }
-              if (bit == 0) { TCMI_S2_G1(1) } else if (bit == 1) { TCMI_S2_G1(2) } else { TCMI_S2_G1(4) }
-#undef TCMI_S2_G1
-            }
           }
+        } else {
+          const f32x2_ a00r = {ca.x, ca.x}, a00i = {ca.y, ca.y}, a01r = {ca.z, ca.z}, a01i = {ca.w, ca.w};
+          const f32x2_ a10r = {cb.x, cb.x}, a10i = {cb.y, cb.y}, a11r = {cb.z, cb.z}, a11i = {cb.w, cb.w};
+          // KIND 0: any 2 x 2; 2: real entries; 3: real diagonal, imaginary off-diagonal
+#define TCMI_S2_G1(ST, KIND)                                                                                     \
+  _Pragma("unroll") for (int q = 0; q < 8; ++q) _Pragma("unroll") for (int e = 0; e < 8; ++e) if (!(e & (ST))) {   \
+    const f32x2_ x0 = val[q][e], x1 = val[q][e | (ST)];                                                           \
+    if (KIND == 2) {                                                                                              \
+      val[q][e] = __builtin_elementwise_fma(a01r, x1, a00r * x0);                                                 \
+      val[q][e | (ST)] = __builtin_elementwise_fma(a11r, x1, a10r * x0);                                          \
+    } else if (KIND == 3) {                                                                                       \
+      const f32x2_ s0 = {-x0.y, x0.x}, s1 = {-x1.y, x1.x};                                                        \
+      val[q][e] = __builtin_elementwise_fma(a01i, s1, a00r * x0);                                                 \
+      val[q][e | (ST)] = __builtin_elementwise_fma(a10i, s0, a11r * x1);                                          \
+    } else {                                                                                                      \
+      const f32x2_ s0 = {-x0.y, x0.x}, s1 = {-x1.y, x1.x};                                                        \
+      f32x2_ y0 = a00r * x0, y1 = a10r * x0;                                                                      \
+      y0 = __builtin_elementwise_fma(a00i, s0, y0); y1 = __builtin_elementwise_fma(a10i, s0, y1);                 \
+      y0 = __builtin_elementwise_fma(a01r, x1, y0); y1 = __builtin_elementwise_fma(a11r, x1, y1);                 \
+      val[q][e] = __builtin_elementwise_fma(a01i, s1, y0); val[q][e | (ST)] = __builtin_elementwise_fma(a11i, s1, y1); \
+    }                                                                                                             \
+  }
+#define TCMI_S2_G1K(ST)                                                                       \
+  if (kind == 2) { TCMI_S2_G1(ST, 2) } else if (kind == 3) { TCMI_S2_G1(ST, 3) } else { TCMI_S2_G1(ST, 0) }
+          if (bit == 0) { TCMI_S2_G1K(1) } else if (bit == 1) { TCMI_S2_G1K(2) } else { TCMI_S2_G1K(4) }
+#undef TCMI_S2_G1K
+#undef TCMI_S2_G1
         }
+        w = wn;
+        ca = na;
+        cb = nb;
+      }
+      const long long colq = ((n0 + wc * 64) >> 2) + (lane & 15);
+      const long long quarter = (long long)N >> 2;
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int u = e & 1, r1 = (e >> 1) & 1, v = e >> 2;
           const long long row = m0 + wr * 64 + 2 * (r1 + 2 * (q & 1) + 8 * (q >> 1) + 4 * (lane >> 5)) + u;
+          // the two column bits of the program sit at the top of the natural column index: v above l4 (vhigh) or below
+          const int blk = vhigh ? 2 * v + l4 : v + 2 * l4;
           float2 w2;
-          w2.x = val[e].x;
-          w2.y = val[e].y;
-          Cb[row * N + colq + (v + 2 * l4) * quarter] = w2;
+          w2.x = val[q][e].x;
+          w2.y = val[q][e].y;
+          Cb[row * N + colq + blk * quarter] = w2;
         }
-      }
     } else if (EPI) {
       // y[2 u' + v'] = sum_{u, v} X[b][2 u' + v'][2 u + v] c[u][v]; column 2 j + v of the product is column j + v N / 2 of C
       float2* Cb = C + (long long)bi * sC;

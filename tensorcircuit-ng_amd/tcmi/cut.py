@@ -103,6 +103,9 @@ class TailProgram:
     r: int
     c: int
     ops: List[tuple]
+    forms: Optional[List[int]] = None   # per op, the kernel's code: 1 diagonal; one-qubit: 2 real matrix, 3 real diagonal and
+                                        # imaginary off-diagonal (rx), 0 any 2 x 2
+    vhigh: int = 0                      # 1: index bit v is the first right-hand qubit (n_left), l4 the second; 0: the reverse
 
     def tables(self, params) -> np.ndarray:
         """[nops, 16] complex: what tcmi_cut_epilogue_program builds on the device."""
@@ -212,10 +215,17 @@ def find_tail(gates: List[P.GateRec], n_left: int, ndefer: int = 2, rmax: int = 
 def tail_program(gates: List[P.GateRec], tail: List[int], n_left: int, r: int, c: int) -> Optional[TailProgram]:
     """The tail as ops on the index bits (u, r1 | v, l4) of the join result; None when it needs more than two diagonal ops
     or twelve ops in all (what the kernel keeps in registers)."""
-    bit = {n_left - 1: BIT_U, n_left - 2: BIT_R1, n_left + c - 1: BIT_V}
+    # the lane bit l4 is the expensive one (partner values by ds_swizzle): it goes to the right-hand qubit with fewer
+    # one-qubit gates in the tail
+    cnt = [sum(1 for t in tail if gates[t].qubits == (n_left + j,) and not gates[t].is_diag) for j in range(2)]
+    vhigh = int(c == 2 and cnt[0] > cnt[1])
+    bit = {n_left - 1: BIT_U, n_left - 2: BIT_R1}
     if c == 2:
-        bit[n_left] = BIT_L4
-    ops = []
+        bit[n_left + 1 - vhigh] = BIT_V
+        bit[n_left + vhigh] = BIT_L4
+    else:
+        bit[n_left] = BIT_V
+    ops, forms = [], []
     for t in tail:
         g = gates[t]
         z = lambda m, size: np.zeros(size, dtype=np.complex128) if m is None else np.asarray(m, dtype=np.complex128)
@@ -231,13 +241,20 @@ def tail_program(gates: List[P.GateRec], tail: List[int], n_left: int, r: int, c
                 ops[-1][2].append(fac)
             else:
                 ops.append(("diag", -1, [fac]))
+                forms.append(1)
         else:
-            fac = tuple(np.concatenate([z(m, (2, 2)).reshape(4), np.zeros(12, dtype=np.complex128)])
-                        for m in (g.c0, g.c1, g.c2)) + (g.param,)
+            ms = [z(m, (2, 2)).reshape(2, 2) for m in (g.c0, g.c1, g.c2)]
+            fac = tuple(np.concatenate([m.reshape(4), np.zeros(12, dtype=np.complex128)]) for m in ms) + (g.param,)
             ops.append(("g1", bit[g.qubits[0]], [fac]))
-    if sum(1 for o in ops if o[0] == "diag") > 2 or len(ops) > 12:
+            if all(np.abs(m.imag).max() < 1e-15 for m in ms):
+                forms.append(2)
+            elif all(abs(m[0, 0].imag) + abs(m[1, 1].imag) + abs(m[0, 1].real) + abs(m[1, 0].real) < 1e-15 for m in ms):
+                forms.append(3)
+            else:
+                forms.append(0)
+    if len(ops) > 12:
         return None
-    return TailProgram(r, c, ops)
+    return TailProgram(r, c, ops, forms, vhigh)
 
 
 def make_cut(gates: List[P.GateRec], n: int, n_left: int, nparams: int, max_bond: int = 1 << 12,
@@ -252,7 +269,7 @@ def make_cut(gates: List[P.GateRec], n: int, n_left: int, nparams: int, max_bond
     rot = 0
     if int(defer) >= 2:
         found = find_tail(gates, n_left, 2)
-        if found is not None and found[2] == 2 and n_right > 2:
+        if found is not None and found[2] == 2 and found[1] <= 2 and n_right > 2:
             tail, r, c = found
             prog = tail_program(gates, tail, n_left, r, c)
             if prog is not None:
@@ -283,7 +300,11 @@ def make_cut(gates: List[P.GateRec], n: int, n_left: int, nparams: int, max_bond
             epi = Epilogue(ql, qr, factors, [gates[i] for i in [p] + absorbed])
             skip, rot = set([p] + absorbed), 1
 
-    def rloc(q):       # local index of global qubit q in the right half
+    vhigh = int(epi is not None and epi.program is not None and epi.program.vhigh)
+
+    def rloc(q):       # local index of global qubit q in the right half (vhigh: the two rotated qubits change places)
+        if vhigh and q - n_left < 2:
+            return n_right - 1 - (q - n_left)
         return (q - n_left - rot) % n_right
 
     for gi, g in enumerate(gates):

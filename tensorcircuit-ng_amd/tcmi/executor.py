@@ -1426,16 +1426,17 @@ class CutCircuit:
                     m_ = np.asarray(m_, dtype=np.complex128).reshape(16)
                     tab_f[g_, 2 + 32 * j_: 34 + 32 * j_: 2] = m_.real
                     tab_f[g_, 3 + 32 * j_: 35 + 32 * j_: 2] = m_.imag
+            tp = spec.epilogue.program
             ops_i, words, dslots, f0 = [], [], [], 0
             for k_, (kind, bit, fl) in enumerate(ops):
                 ops_i += [f0, len(fl)]
                 f0 += len(fl)
                 if kind == "diag":
-                    words.append(1 | (len(dslots) << 8))
+                    words.append(1)
                     dslots.append(k_)
                 else:
-                    words.append(0 | (int(bit) << 4))
-            prog = np.array([len(ops)] + (dslots + [-1, -1])[:2] + words, dtype=np.int32)
+                    words.append(int(tp.forms[k_]) | (int(bit) << 4))
+            prog = np.array([len(ops) | (int(tp.vhigh) << 8)] + (dslots + [-1, -1])[:2] + words + [0], dtype=np.int32)
             self._prog = (torch.as_tensor(prog).to(self.device), torch.as_tensor(np.array(ops_i, dtype=np.int32)).to(self.device),
                           torch.as_tensor(tab_i).to(self.device), torch.as_tensor(tab_f.reshape(-1)).to(self.device), len(ops))
         elif spec.epilogue is not None:
@@ -1771,8 +1772,8 @@ def choose_cut(n, gates, nparams, dtypestr, plan):
     # the last crossing gate applied by the join kernel instead of being a bond (cut.py: half the bond for ZZ / CNOT / CZ)
     # when the circuit allows it and the split-GEMM join takes the smaller shape; TCMI_CUT_DEFER=0 keeps every bond
     # TCMI_CUT_DEFER = 1 (default): the last crossing gate (its 4 x 4 in the join's epilogue); 2: up to two (the tail as a gate
-    # program of the join kernel -- correct, and slower on config 2: 1.36e11 against 1.79e11 amplitudes/s, the program's
-    # general 2 x 2 and lane-exchange ops cost more than the quarter bond saves, tcmi_gemm_split.hip); 0: none
+    # program of the join kernel -- correct, and slower on config 2: 1.73e11 against 1.81e11 amplitudes/s, the program's
+    # vector instructions cost what the quarter bond saves, tcmi_gemm_split.hip); 0: none
     for ndefer in ([2, 1] if os.environ.get("TCMI_CUT_DEFER", "1") == "2" else [1]):
         if not split or os.environ.get("TCMI_CUT_DEFER", "1") == "0":
             break

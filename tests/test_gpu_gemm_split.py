@@ -166,35 +166,40 @@ def test_cut_with_the_last_crossing_gate_applied_by_the_join():
         tc.set_contractor("greedy")
 
 
-@pytest.mark.parametrize("shape", [(128, 128, 32, 2), (512, 256, 64, 3)])
+@pytest.mark.parametrize("shape", [(128, 128, 32, 2, 0), (512, 256, 64, 3, 1)])
 def test_split_gemm_with_a_gate_program_run_on_the_product(shape):
     """tcmi_cgemm_split_prog: one-qubit gates on each of the four index bits (u, r1 | v, l4) and two diagonals, per batch
     member, columns stored un-rotated by two -- against a complex128 emulation of the same program."""
     import torch
     from tcmi import _lib
 
-    M, N, K, B = shape
+    M, N, K, B, vhigh = shape
     L = _lib.lib()
     rng = np.random.default_rng(M + K)
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     A = torch.view_as_complex(torch.randn(B, K, M, 2, device="cuda", generator=g))
     Bm = torch.view_as_complex(torch.randn(B, K, N, 2, device="cuda", generator=g))
-    ops = [("diag", -1), ("g1", 0), ("g1", 3), ("g1", 2), ("diag", -1), ("g1", 1), ("g1", 3), ("g1", 0)]
+    # (kind, bit, form): form 0 any 2 x 2, 2 real matrix, 3 real diagonal and imaginary off-diagonal -- each on every bit
+    ops = [("diag", -1, 1), ("g1", 0, 0), ("g1", 3, 0), ("g1", 2, 3), ("g1", 1, 2), ("diag", -1, 1), ("g1", 1, 0), ("g1", 3, 3),
+           ("g1", 0, 3), ("g1", 2, 2), ("g1", 3, 2), ("g1", 2, 0)]
     T = np.zeros((B, len(ops), 16), dtype=np.complex128)
     for b in range(B):
-        for k, (kind, bit) in enumerate(ops):
+        for k, (kind, bit, form) in enumerate(ops):
             if kind == "diag":
                 T[b, k] = np.exp(1j * rng.uniform(0, 2 * np.pi, 16))
-            else:
+            elif form == 0:
                 q, _ = np.linalg.qr(rng.normal(size=(2, 2)) + 1j * rng.normal(size=(2, 2)))
                 T[b, k, :4] = q.reshape(4)
-    words, dslots = [], []
-    for k, (kind, bit) in enumerate(ops):
-        if kind == "diag":
-            words.append(1 | (len(dslots) << 8)); dslots.append(k)
-        else:
-            words.append(bit << 4)
-    prog = torch.as_tensor(np.array([len(ops)] + dslots + words, dtype=np.int32)).cuda()
+            elif form == 2:
+                th = rng.uniform(0, 2 * np.pi)
+                T[b, k, :4] = [np.cos(th), -np.sin(th), np.sin(th), np.cos(th)]
+            else:
+                th = rng.uniform(0, 2 * np.pi)
+                T[b, k, :4] = [np.cos(th), -1j * np.sin(th), -1j * np.sin(th), np.cos(th)]
+    dslots = [k for k, o in enumerate(ops) if o[0] == "diag"]
+    words = [(1 if kind == "diag" else form | (bit << 4)) for kind, bit, form in ops]
+    prog = torch.as_tensor(np.array([len(ops) | (vhigh << 8)] + dslots + words + [0], dtype=np.int32)).cuda()
+    ops = [(kind, bit) for kind, bit, _ in ops]
     Td = torch.as_tensor(T.astype(np.complex64)).cuda().contiguous()
     out = torch.full((B, M, N), float("nan"), dtype=torch.complex64, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
@@ -204,7 +209,8 @@ def test_split_gemm_with_a_gate_program_run_on_the_product(shape):
     mag = torch.einsum("bkm,bkn->bmn", A.abs().to(torch.float64), Bm.abs().to(torch.float64)).cpu().numpy()
     axis = {0: 2, 1: 1, 2: 5, 3: 4}
     cp = np.arange(N)
-    nat = (cp >> 2) | ((cp & 3) * (N >> 2))
+    low = cp & 3
+    nat = (cp >> 2) | ((2 * (low & 1) + (low >> 1) if vhigh else low) * (N >> 2))
     got = out.cpu().numpy().astype(np.complex128)
     Tf = Td.cpu().numpy().astype(np.complex128)          # the tables the kernel saw (complex64)
     for b in range(B):

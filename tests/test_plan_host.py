@@ -466,9 +466,11 @@ def test_cut_with_two_crossing_gates_deferred():
     prog = spec.epilogue.program
     assert spec.bond_dim == 4 and spec.right_rot == 2 and (prog.r, prog.c) == (2, 2)
     kinds = [(k, b) for k, b, _ in prog.ops]
-    # ZZ7(5,6) | rx7(5) rx7(6) | ZZ8(4,5) ZZ8(5,6) ZZ8(6,7) merged | rx8 on 4, 5, 6, 7
-    assert kinds == [("diag", -1), ("g1", cut.BIT_U), ("g1", cut.BIT_L4), ("diag", -1),
-                     ("g1", cut.BIT_R1), ("g1", cut.BIT_U), ("g1", cut.BIT_L4), ("g1", cut.BIT_V)]
+    # ZZ7(5,6) | rx7(5) rx7(6) | ZZ8(4,5) ZZ8(5,6) ZZ8(6,7) merged | rx8 on 4, 5, 6, 7; qubit 6 has two rx gates, qubit 7
+    # one: the lane bit l4 goes to qubit 7 (vhigh)
+    assert prog.vhigh == 1 and prog.forms == [1, 3, 3, 1, 3, 3, 3, 3]
+    assert kinds == [("diag", -1), ("g1", cut.BIT_U), ("g1", cut.BIT_V), ("diag", -1),
+                     ("g1", cut.BIT_R1), ("g1", cut.BIT_U), ("g1", cut.BIT_V), ("g1", cut.BIT_L4)]
     assert len(prog.ops[3][2]) == 3 and len(spec.epilogue.tail) == 10
     want = dense.run(n, W.hea_b_ops(n, d, params))
     np.testing.assert_allclose(oracle_cut.reference_state(spec, pv), want, atol=1e-12)
