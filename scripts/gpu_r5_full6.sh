@@ -2,7 +2,7 @@
 # round 5, final capture: full GPU test suite, default bench, rocprofv3 kernel stats of the default bench and of the headline
 # alone, per-pass VQE profiles
 export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r5_full5
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r5_full6
 rm -rf $OUT; mkdir -p $OUT
 timeout 2700 python3 -m pytest tests -x -q -m gpu > $OUT/pytest_gpu.log 2>&1
 tail -3 $OUT/pytest_gpu.log
@@ -18,7 +18,7 @@ s = d.get("sliced_vqa", {})
 print("hea_a", d.get("hea_a", {}).get("amplitudes_per_s_per_gpu"), "rqc", d.get("rqc_amplitude", {}).get("contract_s"), "svqa", s.get("ms_per_value_and_grad"), s.get("one_rank_of_8_sharded", {}).get("ms_per_value_and_grad"), s.get("one_rank_of_8_sharded", {}).get("projected_speedup_8_ranks"), "mps", d.get("mps_tebd", {}).get("us_per_bond"), "cpu", d.get("cpu_baseline", {}).get("value"))
 PY
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kh -o head -- python3 bench.py --probe-child --steps 20 --warmup 3 > /dev/null 2> $OUT/kh.err
-cp $(find $OUT/kh -name "*kernel_stats.csv" | head -1) $OUT/r05e_headline_kernel_stats.csv
+cp $(find $OUT/kh -name "*kernel_stats.csv" | head -1) $OUT/r05f_headline_kernel_stats.csv
 rm -rf $OUT/kh
-bash scripts/gpu_vqe_profiles.sh r05e > $OUT/prof.log 2>&1
+bash scripts/gpu_vqe_profiles.sh r05f > $OUT/prof.log 2>&1
 tail -2 $OUT/prof.log
