@@ -277,6 +277,58 @@ def test_cut_with_two_crossing_gates_applied_by_the_join():
             os.environ["TCMI_CUT_DEFER"] = old
 
 
+@pytest.mark.parametrize("defer", ["1", "2"])
+def test_deferred_gates_of_a_mixed_circuit(defer):
+    """Not the HEA-B pattern: ry layers (real matrices), constant one-qubit unitaries (any 2 x 2) and a cz beside the cut in the tail, seven
+    crossing rzz gates -- one or two of them applied by the join, against ``oracle.dense``."""
+    import os
+    import tcmi as tc
+    from tcmi import executor as X
+    from oracle import dense, gates as G
+
+    tc.set_backend("hip"); tc.set_dtype("complex64")
+    tc.set_contractor("cut")
+    old = os.environ.get("TCMI_CUT_DEFER")
+    os.environ["TCMI_CUT_DEFER"] = defer
+    try:
+        n, d = 16, 7
+        rng = np.random.default_rng(21)
+        th = rng.uniform(0, 2 * np.pi, [d, 2, n])
+        us = [G.random_two_qubit_gate(s)[:2, :2] for s in range(4)]
+        us = [np.linalg.qr(u)[0] for u in us]
+        c = tc.Circuit(n)
+        ops = []
+        for i in range(n):
+            c.h(i); ops.append((G.H, [i]))
+        for l in range(d):
+            for i in range(n - 1):
+                c.rzz(i, i + 1, theta=float(th[l, 0, i])); ops.append((G.rzz(th[l, 0, i]), [i, i + 1]))
+            if l == d - 1:
+                c.cz(8, 9); ops.append((G.CZ, [8, 9]))
+            for i in range(n):
+                if l == d - 1 and 6 <= i <= 9:
+                    c.any(i, unitary=us[i - 6]); ops.append((us[i - 6], [i]))
+                elif l % 2:
+                    c.ry(i, theta=float(th[l, 1, i])); ops.append((G.ry(th[l, 1, i]), [i]))
+                else:
+                    c.rx(i, theta=float(th[l, 1, i])); ops.append((G.rx(th[l, 1, i]), [i]))
+        cc = c._compiled()
+        assert isinstance(cc, X.CutCircuit) and cc.spec.epilogue is not None
+        if defer == "2":
+            prog = cc.spec.epilogue.program
+            assert cc.K == 32 and prog is not None and set(prog.forms) == {0, 1, 2}
+        else:
+            assert cc.K == 64 and cc.spec.epilogue.program is None
+        got = tc.backend.numpy(c.wavefunction())
+        assert np.abs(got - dense.run(n, ops)).max() < 1e-5
+    finally:
+        tc.set_contractor("greedy")
+        if old is None:
+            os.environ.pop("TCMI_CUT_DEFER", None)
+        else:
+            os.environ["TCMI_CUT_DEFER"] = old
+
+
 def _params_of(tc, W, n, d, params):
     c = tc.Circuit(n)
     W.hea_b(c, n, d, params, zz=tc.gates._zz_matrix)

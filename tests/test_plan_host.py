@@ -489,6 +489,76 @@ def test_cut_with_two_crossing_gates_deferred():
                                dense.run(n, ops2), atol=1e-12)
 
 
+def test_deferral_rules_on_random_circuits():
+    """``find_deferred`` / ``find_tail`` decide from commutation rules which gates may leave the half-circuits; whatever they
+    decide on random mixes of diagonal and dense one- and two-qubit gates, the cut formula with the tail applied afterwards
+    (gate form, and program form when there is one) has to reproduce ``oracle.dense``."""
+    from tcmi import cut
+
+    n, nl = 8, 4
+    rng = np.random.default_rng(7)
+    seen = {"tail4x4": 0, "program": 0, "none": 0}
+    for trial in range(60):
+        c = tc.Circuit(n)
+        ops = []
+        for i in range(n):
+            c.h(i); ops.append((G.H, [i]))
+        for _ in range(int(rng.integers(10, 28))):
+            kind = int(rng.integers(0, 7))
+            q = int(rng.integers(0, n - 1))
+            th = float(rng.uniform(0, 2 * np.pi))
+            if kind == 0:
+                c.rzz(q, q + 1, theta=th); ops.append((G.rzz(th), [q, q + 1]))
+            elif kind == 1:
+                c.cz(q, q + 1); ops.append((G.CZ, [q, q + 1]))
+            elif kind == 2:
+                c.rx(q, theta=th); ops.append((G.rx(th), [q]))
+            elif kind == 3:
+                c.ry(q, theta=th); ops.append((G.ry(th), [q]))
+            elif kind == 4:
+                c.rz(q, theta=th); ops.append((G.rz(th), [q]))
+            elif kind == 5:
+                c.cnot(q, q + 1); ops.append((G.CNOT, [q, q + 1]))
+            else:
+                c.t(q); ops.append((G.T, [q]))
+        # make sure something crosses the cut near the end now and then
+        if trial % 2:
+            th = float(rng.uniform(0, 2 * np.pi))
+            c.rzz(nl - 1, nl, theta=th); ops.append((G.rzz(th), [nl - 1, nl]))
+            for q in (nl - 2, nl - 1, nl, nl + 1):
+                if rng.integers(0, 2):
+                    th = float(rng.uniform(0, 2 * np.pi))
+                    c.rx(q, theta=th); ops.append((G.rx(th), [q]))
+        if trial % 3 == 0:       # two closing layers of a ladder around the cut: a tail of two crossing gates
+            for layer in range(2):
+                for q in ((nl - 1,) if layer == 0 else (nl - 2, nl - 1, nl)):
+                    th = float(rng.uniform(0, 2 * np.pi))
+                    c.rzz(q, q + 1, theta=th); ops.append((G.rzz(th), [q, q + 1]))
+                for q in ((nl - 1, nl) if layer == 0 else (nl - 2, nl - 1, nl, nl + 1)):
+                    if layer == 0 or rng.integers(0, 3):
+                        th = float(rng.uniform(0, 2 * np.pi))
+                        g1 = (c.rx, G.rx) if rng.integers(0, 2) else (c.ry, G.ry)
+                        g1[0](q, theta=th); ops.append((g1[1](th), [q]))
+        recs = c._gate_records()
+        pv = np.array([float(x) for x in c._params])
+        want = dense.run(n, ops)
+        for defer in (1, 2):
+            spec = cut.make_cut(recs, n, nl, len(pv), defer=defer)
+            if spec is None:
+                continue
+            np.testing.assert_allclose(oracle_cut.reference_state(spec, pv), want, atol=1e-11)
+            if spec.epilogue is None:
+                seen["none"] += 1
+            elif spec.epilogue.program is not None:
+                seen["program"] += 1
+                np.testing.assert_allclose(oracle_cut.reference_state(spec, pv, program=True), want, atol=1e-11)
+            else:
+                seen["tail4x4"] += 1
+                x = spec.epilogue.matrix(pv)
+                np.testing.assert_allclose(x.conj().T @ x, np.eye(4), atol=1e-11)
+    assert seen["tail4x4"] >= 5 and seen["program"] >= 3 and seen["none"] >= 5, seen
+
+
 def test_dense_three_qubit_gates_are_synthesised_exactly():
     """toffoli / fredkin / any(3 qubits) (reference gates.py sgates, basecircuit.py:183-371) are rewritten
     on the host into <= 2-qubit dense + diagonal gates (tcmi/synth.py); the compiled plan run through
