@@ -1345,39 +1345,24 @@ class _HalfBatch:
         import torch
 
         K, Ks = self.K, self.Ks
-        # experiment switch (TCMI_CUT_BUILD_AHEAD=1; off): the suffix's tables depend on the parameters alone, so they can
-        # be built on a side stream under the prefix passes and the replication (25-35 us of every half-circuit chain in the
-        # kernel trace).  Measured on the headline: 1.001e11 / 1.010e11 with, 1.017e11 / 1.007e11 without -- the chains of
-        # the two halves already overlap each other and the host is the one issuing them; not under a hipGraph capture (a
-        # fork off an already forked stream ends the capture in a crash on this ROCm)
-        ptab_suf = None
-        if os.environ.get("TCMI_CUT_BUILD_AHEAD", "0") == "1" and not torch.cuda.is_current_stream_capturing():
-            cur = torch.cuda.current_stream(self.suffix.device)
-            aux = getattr(self, "_aux", None)
-            if aux is None:
-                aux = self._aux = torch.cuda.Stream(device=self.suffix.device)
-            aux.wait_stream(cur)
-            with torch.cuda.stream(aux):
-                ptab_suf = self.suffix.build_ptab(pfull)
-            pfull.record_stream(aux)
+        # (measured and dropped, scripts/experiments/README.md: the suffix's tables built ahead on a side stream under the
+        # prefix passes -- 1.001e11 / 1.010e11 with, 1.017e11 / 1.007e11 without at 8 circuits per call, 1.78e11 / 1.79e11
+        # against 1.81e11 at 32: the chains of the two halves already overlap each other)
         # the prefix parameter rows are every (K / Ks)-th row of pfull: a strided view, no gather
         ppre = pfull.reshape(B * Ks, (K // Ks) * pfull.shape[-1])[:, : pfull.shape[-1]]
         pre = self.prefix.state(ppre)                                            # [B*Ks, 2^nq]
-        if ptab_suf is not None:
-            cur.wait_stream(aux)
-            ptab_suf.record_stream(cur)
         if scale is not None and scale_ready is not None:
             torch.cuda.current_stream(self.suffix.device).wait_event(scale_ready)
         rep_n = K // Ks
         if rep_n & (rep_n - 1) == 0 and os.environ.get("TCMI_CUT_FUSED_REP", "1") != "0":
             # state b*K + j of the suffix batch = weight[b, j] * prefix state (b*K + j) >> log2(K / Ks): read by the suffix's
             # first pass itself (tcmi_spec_run_pass_from; materialised inside state() when that kernel is not there)
-            return self.suffix.state(pfull, ptab=ptab_suf, src=(pre, rep_n.bit_length() - 1, scale))
+            return self.suffix.state(pfull, src=(pre, rep_n.bit_length() - 1, scale))
         if scale is None:
             rep = pre.reshape(B, Ks, 1, -1).expand(B, Ks, K // Ks, pre.shape[-1]).reshape(B * K, -1)
         else:
             rep = (pre.reshape(B, Ks, 1, -1) * scale.reshape(B, Ks, K // Ks, 1)).reshape(B * K, -1)
-        return self.suffix.state(pfull, inputs=rep, consume_inputs=True, ptab=ptab_suf)
+        return self.suffix.state(pfull, inputs=rep, consume_inputs=True)
 
 
 class CutCircuit:
@@ -1526,17 +1511,11 @@ class CutCircuit:
             if side is None:
                 side = self._side = torch.cuda.Stream(device=self.device)
             side.wait_stream(cur)
-            # experiment switch (TCMI_CUT_WEIGHTS_LATE=1; off): the bond weights are only read by the right half's SUFFIX, so
-            # they can be computed on this stream at the head of the left half's (shorter) chain instead of at the head of
-            # the right half's.  Measured: eager 1.033e11 vs 1.025e11 (noise), hipGraph replay 0.95e11 vs 0.99e11 (the extra
-            # event edge costs more than the 11 us it moves)
-            if os.environ.get("TCMI_CUT_WEIGHTS_LATE", "0") == "1":
-                w = self._weights(p)
-                w_ready = torch.cuda.Event()
-                w_ready.record(cur)
-            else:                       # (the weights at the head of the right half's chain, as before)
-                with torch.cuda.stream(side):
-                    w, w_ready = self._weights(p), None
+            # the bond weights at the head of the right half's chain (computing them on the caller's stream at the head of
+            # the left half's shorter chain measured no gain eager and slower under hipGraph replay: the extra event edge
+            # costs more than the 11 us it moves)
+            with torch.cuda.stream(side):
+                w, w_ready = self._weights(p), None
             with torch.cuda.stream(side):
                 R = self.right.states(pfull, B, scale=w, scale_ready=w_ready)     # [B*K, N], each state times its weight
             pfull.record_stream(side)
