@@ -19,7 +19,7 @@ for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
 with open("$OUT/summary.txt", "w") as out:
     out.write("# per-dispatch averages (value, dispatches) over the headline's timed region (bench.py --probe-child)\n")
     for k in acc:
-        if "cgemm" in k or "spec_forward" in k:
+        if "cgemm" in k or "tcmi_spec_fwd" in k:
             out.write(k + " " + str({c: (round(v / len(cnt[k][c]), 1), len(cnt[k][c])) for c, v in sorted(acc[k].items())}) + "\n")
 print(open("$OUT/summary.txt").read())
 PY
