@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tensorcircuit-ng_amd")); sys.path.insert(0, ROOT)
 import numpy as np, torch
 import tcmi as tc
+import tcmi.specialize as _SPX; _SPX.ALLOW_PROBE = True   # this script times kernels, also the wrong-result variants of TCMI_SPEC_EXP
 from tcmi import specialize as S
 tc.set_backend("hip"); tc.set_dtype("complex64")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 28

@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tensorcircuit-ng_amd"))
 import torch
 import tcmi as tc
+import tcmi.specialize as _SPX; _SPX.ALLOW_PROBE = True   # this script times kernels, also the wrong-result variants of TCMI_SPEC_EXP
 from tcmi import cons, executor as X, specialize as S
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "adjoint"

@@ -813,6 +813,8 @@ class SpecKernel:
 
 
 _EMITTERS = {}
+ALLOW_PROBE = False
+_WRONG_RESULT_KNOBS = ("noexch", "nomem", "noevents")
 
 
 _SHORT = {"forward": "fwd", "adjoint": "adj"}
@@ -828,6 +830,11 @@ def _source(kind: str, words, opts, index: int = 0) -> Tuple[str, dict]:
     for kv in filter(None, os.environ.get("TCMI_SPEC_EXP", "").split(",")):     # experiment knobs: "pf=2,noexch,waves=5"
         k, _, v = kv.partition("=")
         opts[k] = int(v) if v else 1
+    if not ALLOW_PROBE and any(opts.get(k) for k in _WRONG_RESULT_KNOBS):
+        # kernels without their exchanges / memory traffic / gradient events exist to be TIMED; the environment alone must not
+        # be able to switch a product run to them -- the timing scripts set specialize.ALLOW_PROBE themselves
+        raise RuntimeError("TCMI_SPEC_EXP asks for a timing-only kernel (%s): set tcmi.specialize.ALLOW_PROBE = True in the "
+                           "measuring script" % ", ".join(k for k in _WRONG_RESULT_KNOBS if opts.get(k)))
     generic = f"tcmi_spec_{kind}"
     src, meta = _EMITTERS[kind](words, generic, opts)
     name = f"tcmi_spec_{_SHORT.get(kind, kind)}_p{int(index)}_{pass_digest(src)[:8]}"
