@@ -209,6 +209,7 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
       for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][t][e] = 0.f;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   TCMI_S2_CONVERT(g0, 0, 0)
   TCMI_S2_CONVERT(g0, 0, 1)
   TCMI_S2_CONVERT(g0, 0, 2)
@@ -235,14 +236,22 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
   _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int v = 0; v < 2; ++v)                       \
     acc[u][v][T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xa[(T) & 1][u][SA]),          \
                                                            __builtin_bit_cast(bf16x8, xb[(T) & 1][v][SB]), acc[u][v][T], 0, 0, 0);
-#define TCMI_S2_PHASE(T, GN, P)                                                                                      \
+  // the first MFMA of a tile into an accumulator starts from the constant 0 (nothing zeroes the accumulators between tiles)
+#define TCMI_S2_MF0(T, SA, SB)                                                                                      \
+  _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int v = 0; v < 2; ++v)                       \
+    acc[u][v][T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xa[(T) & 1][u][SA]),          \
+                                                           __builtin_bit_cast(bf16x8, xb[(T) & 1][v][SB]), zero16, 0, 0, 0);
+#define TCMI_S2_PHASE(T, GN, P, FIRST)                                                                               \
   {                                                                                                                  \
     if ((T) < 2) {                                                                                                   \
       if ((T) & 1) { TCMI_S2_SREAD(0, (T) + 1) } else { TCMI_S2_SREAD(1, (T) + 1) }                                  \
     }                                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
     if (MODE != 1) TCMI_S2_CONVERT(GN, 1 - (P), T)                                                                   \
-    if (MODE != 2) { TCMI_S2_MF(T, 0, 2) TCMI_S2_MF(T, 1, 1) TCMI_S2_MF(T, 2, 0) TCMI_S2_MF(T, 0, 1) TCMI_S2_MF(T, 1, 0) TCMI_S2_MF(T, 0, 0) } \
+    if (MODE != 2) {                                                                                                 \
+      if (FIRST) { TCMI_S2_MF0(T, 0, 2) } else { TCMI_S2_MF(T, 0, 2) }                                                \
+      TCMI_S2_MF(T, 1, 1) TCMI_S2_MF(T, 2, 0) TCMI_S2_MF(T, 0, 1) TCMI_S2_MF(T, 1, 0) TCMI_S2_MF(T, 0, 0)             \
+    }                                                                                                                \
     if (MODE == 0 || MODE >= 3) {                                                                                    \
       /* spread the ~100 VALU instructions of the conversion evenly between the 24 MFMAs (4 ride in each MFMA's */   \
       /* shadow), the six plane writes behind them */                                                               \
@@ -258,23 +267,25 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
       if ((T) & 1) { TCMI_S2_SWAIT(0, MODE == 1 ? 0 : 6) } else { TCMI_S2_SWAIT(1, MODE == 1 ? 0 : 6) }              \
     }                                                                                                                \
   }
-#define TCMI_S2_STEP(I, GC, GN, P)                                                                                   \
+#define TCMI_S2_STEP(I, GC, GN, P, FIRST)                                                                            \
   {                                                                                                                  \
     const uint32_t sa_ = fa + (uint32_t)((P) * SPLIT_STAGE_BYTES), sb_ = fb + (uint32_t)((P) * SPLIT_STAGE_BYTES);     \
     f32x4_ xa[2][2][3], xb[2][2][3];                                                                                 \
     TCMI_S2_SREAD(0, 0)                                                                                              \
     if (MODE != 1) TCMI_S2_LOAD(GC, (I) + 2)                                                                         \
     TCMI_S2_SWAIT(0, 0)                                                                                              \
-    TCMI_S2_PHASE(0, GN, P)                                                                                          \
-    TCMI_S2_PHASE(1, GN, P)                                                                                          \
-    TCMI_S2_PHASE(2, GN, P)                                                                                          \
+    TCMI_S2_PHASE(0, GN, P, FIRST)                                                                                   \
+    TCMI_S2_PHASE(1, GN, P, FIRST)                                                                                   \
+    TCMI_S2_PHASE(2, GN, P, FIRST)                                                                                   \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
     __builtin_amdgcn_s_barrier();                                                                                    \
   }
   for (;;) {
-    for (int i = 0; i < nk; i += 2) {
-      TCMI_S2_STEP(i, g0, g1, 0)
-      TCMI_S2_STEP(i + 1, g1, g0, 1)
+    TCMI_S2_STEP(0, g0, g1, 0, MODE != 2)
+    TCMI_S2_STEP(1, g1, g0, 1, 0)
+    for (int i = 2; i < nk; i += 2) {
+      TCMI_S2_STEP(i, g0, g1, 0, 0)
+      TCMI_S2_STEP(i + 1, g1, g0, 1, 0)
     }
     // the last step cut block 0 of the next tile into stage 0 and blocks 0, 1 of it are (being) loaded: only the
     // results stand between the tiles.  MFMA result element (i = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), j = lane & 31)
@@ -300,8 +311,11 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
               const float re = acc[u][v][0][reg] - acc[u][v][1][reg];
               const float im = acc[u][v][2][reg] - acc[u][v][0][reg] - acc[u][v][1][reg];
               val[q][u + 2 * r1 + 4 * v] = f32x2_{re, im};
-#pragma unroll
-              for (int t = 0; t < 3; ++t) acc[u][v][t][reg] = 0.f;
+              if (MODE == 2) {
+                acc[u][v][0][reg] = 0.f;
+                acc[u][v][1][reg] = 0.f;
+                acc[u][v][2][reg] = 0.f;
+              }
             }
       int w = prog[3];
       f32x4_ ca = *reinterpret_cast<const f32x4_*>(Tb), cb = *reinterpret_cast<const f32x4_*>(Tb + 2);
@@ -440,8 +454,11 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
             const float im = acc[u][v][2][reg] - acc[u][v][0][reg] - acc[u][v][1][reg];
             c[2 * u + v] = f32x2_{re, im};
             cs[2 * u + v] = f32x2_{-im, re};
-#pragma unroll
-            for (int t = 0; t < 3; ++t) acc[u][v][t][reg] = 0.f;
+            if (MODE == 2) {
+              acc[u][v][0][reg] = 0.f;
+              acc[u][v][1][reg] = 0.f;
+              acc[u][v][2][reg] = 0.f;
+            }
           }
         f32x2_ yo[4];
 #pragma unroll
@@ -486,8 +503,11 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
           if (MODE != 3 || o.x == 123.456f) *reinterpret_cast<f32x4_*>(Cb + row * N + colb) = o;
 #pragma unroll
           for (int v = 0; v < 2; ++v)
-#pragma unroll
-            for (int t = 0; t < 3; ++t) acc[u][v][t][reg] = 0.f;
+            if (MODE == 2) {
+              acc[u][v][0][reg] = 0.f;
+              acc[u][v][1][reg] = 0.f;
+              acc[u][v][2][reg] = 0.f;
+            }
         }
     }
     if (MODE == 4 && blockIdx.x == 100 && tid == 0) {      // probe: a stamp per finished tile into C[1 + tile count]
@@ -505,6 +525,7 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
   }
 #undef TCMI_S2_STEP
 #undef TCMI_S2_PHASE
+#undef TCMI_S2_MF0
 #undef TCMI_S2_MF
 #undef TCMI_S2_SWAIT
 #undef TCMI_S2_SREAD
