@@ -67,6 +67,134 @@ def cpu_baseline(n_sample, d, seed, budget_s=25.0):
     }
 
 
+def _host_threads():
+    try:
+        import threadpoolctl
+
+        info = threadpoolctl.threadpool_info()
+        return int(max(x["num_threads"] for x in info)) if info else int(os.cpu_count() or 1)
+    except Exception:  # noqa: BLE001
+        return int(os.cpu_count() or 1)
+
+
+def cpu_baseline_vqe(n_full, d, budget_s=20.0):
+    """CPU column of the VQE step (config 3): value_and_grad of the 2n-1 term TFIM energy of ONE HEA-B sample on the host
+    with oracle/adjoint.py (numpy adjoint state-vector method, the cheapest CPU formulation of the step -- the reference's
+    tape through the tensordot chain does more work), complex64, at the largest n whose estimated time fits the budget
+    (time doubles per qubit; n = 16 is timed first).  The n_full figure is an EXTRAPOLATION by 2^(n_full - n) and says so."""
+    import numpy as np
+    from oracle import adjoint as A
+
+    def run(n):
+        p = np.random.default_rng(28).normal(0, 0.1, [2 * d, n]).astype(np.float32)
+        t0 = time.perf_counter()
+        A.hea_b_tfim_value_and_grad(n, d, p, dtype=np.complex64)
+        return time.perf_counter() - t0
+
+    n0 = min(16, n_full)
+    t_small = run(n0)
+    n = n0
+    while n < min(n_full, 24) and t_small * 2.0 ** (n + 1 - n0) <= budget_s:
+        n += 1
+    t = run(n) if n > n0 else t_small
+    return {"value": 1.0 / t, "unit": "samples/s (one value_and_grad of one circuit)", "cores": 1, "kind": "port",
+            "sample": f"oracle.adjoint (numpy, strided in-place updates: one thread) HEA-B n={n} d={d} TFIM value_and_grad, "
+                      f"complex64, one run of {t:.2f} s",
+            "qubits_timed": n, "seconds_per_sample": t,
+            "extrapolated_seconds_per_sample_at_full_size": t * 2.0 ** (n_full - n),
+            "extrapolation": f"x 2^({n_full} - {n}): the work per gate is linear in the state size; caches make the real "
+                             f"n = {n_full} run slower than this"}
+
+
+def cpu_baseline_mps(n, chi, tensors, gate_mats, budget_s=25.0):
+    """CPU column of config 5: the same TEBD sweep through oracle.mps (numpy GEMMs + LAPACK SVD of the (2 chi) x (2 chi)
+    bond matrix, complex64 like the GPU leg) on the host cores, on as many bonds from the left end as fit the budget (the
+    bonds in the saturated middle all cost the same; the time per bond is over the bonds timed)."""
+    import numpy as np
+    from oracle import mps as OM
+
+    m = OM.MPSCircuit(n, tensors=[np.asarray(t) for t in tensors], split=OM.split_rules(max_singular_values=chi))
+    m.position(0)
+    t0 = time.perf_counter()
+    done, sat, t_sat = 0, 0, 0.0
+    for i in range(n - 1):
+        t1 = time.perf_counter()
+        m.apply(gate_mats[i], i, i + 1)
+        dt = time.perf_counter() - t1
+        done += 1
+        if min(2 ** (i + 1), 2 ** (n - i - 1)) >= chi:       # a bond of full dimension on both sides
+            sat += 1
+            t_sat += dt
+        if time.perf_counter() - t0 > budget_s:
+            break
+    el = time.perf_counter() - t0
+    per_bond = (t_sat / sat) if sat else el / done
+    return {"value": 1.0 / (per_bond * (n - 1)), "unit": "sweeps/s", "cores": _host_threads(), "kind": "port",
+            "sample": f"oracle.mps (numpy + LAPACK) on the first {done} of {n - 1} bonds of the same sweep, complex64, "
+                      f"{el:.1f} s; us_per_bond over the {sat} saturated bonds among them",
+            "us_per_bond": per_bond * 1e6, "bonds_timed": done}
+
+
+def cpu_baseline_rqc(tree, arrays, budget_s=30.0):
+    """CPU column of config 4: ONE slice of the executed tree as a numpy tensordot chain (oracle/sliced.py: what the
+    reference's numpy backend does per slice, cons.py:845-961) on the host cores; the amplitude costs nslices of them.
+    The slice is abandoned when the budget is exceeded (then the figure is a lower bound of the time and says so)."""
+    import numpy as np
+    from oracle import sliced as OS
+
+    host = [a.detach().cpu().numpy() for a in arrays]
+    sliced = list(tree.sliced_inds)
+    t0 = time.perf_counter()
+    base = {"unit": "amplitudes/s (one amplitude = all slices)", "cores": _host_threads(), "kind": "port"}
+    try:
+        val = OS.contract_path(host, [list(x) for x in tree.inputs], [tuple(p_) for p_ in tree.path], sliced,
+                               OS.slice_values(0, len(sliced)), budget_s=budget_s)
+    except TimeoutError as e:
+        done, total, t = e.args[0]
+        return {**base, "value": 1.0 / (t * tree.nslices), "value_is": "an UPPER bound of the CPU rate: the slice was abandoned",
+                "sample": f"oracle.sliced numpy tensordot chain of slice 0 of {tree.nslices} of the executed tree, complex64: "
+                          f"{done} of {total} steps in {t:.1f} s (budget {budget_s:.0f} s), abandoned",
+                "seconds_per_slice_at_least": t}
+    t = time.perf_counter() - t0
+    return {**base, "value": 1.0 / (t * tree.nslices),
+            "sample": f"oracle.sliced numpy tensordot chain of slice 0 of {tree.nslices} of the executed tree, "
+                      f"complex64, {t:.1f} s; x {tree.nslices} slices",
+            "seconds_per_slice": t, "seconds_per_amplitude": t * tree.nslices, "slice0_value": [val.real, val.imag]}
+
+
+def rank_times(torch, dist, dev, seconds, steps):
+    """[ms per step of every rank] (all_gather of this rank's own wall time between the barriers): the max is what
+    ``value`` is computed from; the spread tells a straggling rank from a slow job.  None on one rank."""
+    if dist is None:
+        return None
+    mine = torch.tensor([seconds / max(1, steps) * 1e3], device=dev, dtype=torch.float64)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [round(float(x.item()), 4) for x in out]
+
+
+def allreduce_latency(torch, dist, dev, numel, reps=50):
+    """Mean wall time in microseconds of the step's one collective: a float64 all-reduce(SUM) of ``numel`` values
+    ([value || gradient], a few KB -- latency-bound over xGMI), each one followed by a device synchronisation (the
+    step reads the sum on the host side right away).  None on one rank."""
+    if dist is None:
+        return None
+    buf = torch.zeros(max(1, int(numel)), device=dev, dtype=torch.float64)
+    for _ in range(5):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_reduce(buf)
+        torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / reps * 1e6
+    tt = torch.tensor([t], device=dev, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return round(float(tt.item()), 1)
+
+
 def summarize_events(log):
     """Per-tag totals of the executor's HIP-event log: {tag: {ms, launches, work, calls}} (call after a sync)."""
     out = {}
@@ -243,6 +371,8 @@ def vqe_leg(tc, torch, dist, args, rank, world, dev):
         finally:
             X.EVENT_LOG = None
             X.SPARSE_START = True
+    per_rank_ms = rank_times(torch, dist, dev, el, args.vqe_steps)
+    ar_us = allreduce_latency(torch, dist, dev, 1 + 2 * d * n)
     if dist is not None:
         sync()
         tt = torch.tensor([el], device=dev, dtype=torch.float64)
@@ -336,11 +466,19 @@ def vqe_leg(tc, torch, dist, args, rank, world, dev):
     roof["forward_pass_gate_flops_only"] = None if live_on else _valu("pass", 12.0)
     roof["adjoint_pass_gate_flops_only"] = None if live_on else _valu("adjoint", 32.0)
     interp = sum(int(v_[2]) for v_ in valu_log.values()) // max(1, args.vqe_steps)
+    cpu = None
+    if dist is None and rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_vqe(n, d)
+        cpu["gpu_seconds_per_sample"] = el / args.vqe_steps / Bg
     return {
         "roofline": roof,
+        **({"cpu_baseline": cpu} if cpu is not None else {}),
         "workload": f"HEA-B n={n} depth={d} TFIM value_and_grad (55-term style energy), vmap batch {Bg} "
                     f"(SURVEY 8d config 3), complex64",
         "ms_per_step": el / args.vqe_steps * 1e3,
+        **({"per_rank_ms_per_step": per_rank_ms, "allreduce_us": ar_us,
+            "allreduce": f"one packed float64 all-reduce of [sum of energies || summed gradient] = {1 + 2 * d * n} values per step"}
+           if dist is not None else {}),
         "steps": args.vqe_steps,
         "samples_per_s": Bg * args.vqe_steps / el,
         "batch_per_gpu": hi - lo,
@@ -466,7 +604,11 @@ def mps_leg(tc, torch, args):
         LA.SVD_PRECONDITION = keep_flag
     except Exception as e:  # noqa: BLE001 - an auxiliary figure must not take the leg down
         graded = {"error": repr(e)}
+    cpu = None
+    if not args.no_cpu_baseline:
+        cpu = cpu_baseline_mps(n, chi, tensors, [tc.backend.numpy(g.tensor) for g in gates])
     return {
+        **({"cpu_baseline": cpu} if cpu is not None else {}),
         "workload": f"MPSCircuit n={n} chi={chi} TEBD sweep of {n - 1} adjacent random SU(4) gates, complex64 "
                     f"(SURVEY 8d config 5)",
         "sweeps_per_s": 1.0 / t, "us_per_bond": t / (n - 1) * 1e6, "sweeps": len(times),
@@ -525,6 +667,11 @@ def rqc_leg(tc, torch, dist, args, rank, world):
     if dist is not None:
         dist.barrier()
     t = time.perf_counter() - t0
+    per_rank_ms = rank_times(torch, dist, v.device, t, 1)
+    if dist is not None:
+        tt = torch.tensor([t], device=v.device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t = float(tt.item())
     cnt, TN.COUNTERS = TN.COUNTERS, None
     tree = dc.tree
     # slice-invariant work is repeated on every rank: time one slice and all local slices to split t = t_inv + S t_slice
@@ -577,16 +724,22 @@ def rqc_leg(tc, torch, dist, args, rank, world):
                  "invariant_shard_model_us": [round(x * 1e6) for x in loads],
                  "projection_basis": "ONE-rank measurement: time of all local slices / time of the slices one rank of "
                                      "an 8-rank run would hold (with the invariant work that rank executes); no 8-GPU run"}
+    cpu = None
+    if dist is None and rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_rqc(tree, dc._arrays(None))
+        cpu["gpu_seconds_per_amplitude"] = t
     flops = float(tree.total_flops())          # all slices (ContractionTree.total_flops includes nslices)
     steps, dep, _, _ = tree._symbolic_steps()
     n_inv = sum(1 for st in steps if not dep[st[4]])   # slice-invariant steps: computed once per rank
     return {
         "workload": f"32-qubit 4x8 random circuit depth {depth}, amplitude <0|C|0>, complex64, sliced to "
                     f"2^{args.rqc_log2_target} elements (SURVEY 8d config 4)",
+        **({"cpu_baseline": cpu} if cpu is not None else {}),
         "nslices": int(tree.nslices), "slices_per_gpu": int(-(-tree.nslices // world)),
         "contraction_width": float(tree.contraction_width()), "log2_flops_total": float(np.log2(flops)),
         # primary rate = the flops the engine EXECUTED (slice-invariant steps once per call); the sliced tree's own
         # count (every step x nslices) is kept as algorithmic_tflops_sliced_tree
+        **({"per_rank_contract_ms": per_rank_ms} if dist is not None else {}),
         "contract_s": t, "tflops": (cnt["gemm_flops"] + cnt["scattered_flops"]) / t / 1e12,
         "algorithmic_tflops_sliced_tree": flops / t / 1e12, "path_search_s": round(search_s, 2),
         "steps_per_slice": len(steps), "slice_invariant_steps": n_inv, "time_split": split,
@@ -594,7 +747,9 @@ def rqc_leg(tc, torch, dist, args, rank, world):
         "path_search": {"seeds": len(seeds), "best_model_ms": min(x["model_time_s"] for x in seeds) * 1e3,
                         "median_model_ms": float(np.median([x["model_time_s"] for x in seeds])) * 1e3,
                         "per_seed_model_ms": [round(x["model_time_s"] * 1e3, 1) for x in seeds],
-                        "per_seed_search_s": [x["search_s"] for x in seeds]} if seeds else None,
+                        "per_seed_search_s": [x["search_s"] for x in seeds],
+                        # with W ranks the seeds are dealt to them (seed k to rank k mod W) and the best tree is broadcast
+                        "per_seed": [{"seed": x["seed"], "rank": x.get("rank", 0)} for x in seeds]} if seeds else None,
         "amplitude": [float(v.real), float(v.imag)],
         # F_alg of the executed (sliced, slice-invariant parts once) steps over the wall time against the f32 MFMA
         # peak; stand-alone permutes are traffic outside B_alg ("wasted")
@@ -654,6 +809,8 @@ def sliced_vqa_leg(tc, torch, dist, args, rank, world):
         v, g = dc.value_and_grad(pt)
     sync()
     el = (time.perf_counter() - t0) / args.svqa_steps
+    per_rank_ms = rank_times(torch, dist, pt.device, el, 1)
+    ar_us = allreduce_latency(torch, dist, pt.device, 1 + pt.numel())
     if dist is not None:
         tt = torch.tensor([el], device=pt.device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -666,6 +823,7 @@ def sliced_vqa_leg(tc, torch, dist, args, rank, world):
         "ms_per_value_and_grad": el * 1e3, "nslices": int(tree.nslices), "slices_per_gpu": len(dc.my_slices),
         "steps_per_slice": len(steps), "slice_invariant_steps": sum(1 for st in steps if not dep[st[4]]),
         "contraction_width": float(tree.contraction_width()), "log10_flops_forward": dc.tree_info["log10_flops"],
+        **({"per_rank_ms_per_value_and_grad": per_rank_ms, "allreduce_us": ar_us} if dist is not None else {}),
         "path_search_s": round(search_s, 2), "staging_s": round(staging, 2),
         "value": float(v), "grad_norm": float(g.norm()),
     }
@@ -750,6 +908,137 @@ def sliced_vqa_leg(tc, torch, dist, args, rank, world):
     return out
 
 
+def statevector_leg(tc, torch, dist, args, rank, world, dev):
+    """north_star's own size: ``Circuit.wavefunction`` (reference circuit.py:701-721) of HEA-B n = 28, depth 12, complex64
+    through backend.jit(backend.vmap(f)) -- the state-vector plan (a cut of 12 ZZ layers would need a bond of 4096).
+    Global batch --sv-batch states, sharded over the ranks in contiguous blocks (strong scaling, no collective),
+    --sv-microbatch states per vmap call.  Reported: amplitudes/s; the HBM fraction of the EXECUTED plan (live-tile passes:
+    algorithmic bytes = the bytes of the tiles that can be non-zero); the same kernels with every tile live
+    (``dense_plan``: every pass moves the whole state); SURVEY 8(d)'s cross-plan anchor B_sv / t (the bytes the canonical
+    gate-by-gate state-vector plan would move, over this time); batch-1 latency."""
+    import numpy as np
+    from tcmi import distributed as D
+    from tcmi import executor as X
+
+    n, d, Bg, mb = args.sv_qubits, args.sv_depth, args.sv_batch, max(1, args.sv_microbatch)
+    lo, hi = D.shard_range(Bg, rank, world)
+    params_all = np.random.default_rng(n).uniform(0, 2 * np.pi, [Bg, 2 * d, n]).astype(np.float32)
+    params = torch.from_numpy(params_all[lo:hi]).to(dev)
+    chunks = [params[b0: b0 + mb] for b0 in range(0, hi - lo, mb)]
+
+    def wavefunction(p):
+        return build_circuit(tc, n, d, p).wavefunction()
+
+    fwd = tc.backend.jit(tc.backend.vmap(wavefunction))
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        out = None
+        for ch in chunks:
+            out = fwd(ch)
+        return out
+
+    t0 = time.perf_counter()
+    for _ in range(3):                   # staging; the first two calls validate the traced pipeline
+        st = step()
+    sync()
+    staging = time.perf_counter() - t0
+    X.EVENT_LOG = []
+    t0 = time.perf_counter()
+    for _ in range(args.sv_steps):
+        st = step()
+    sync()
+    el = time.perf_counter() - t0
+    ev = summarize_events(X.EVENT_LOG)
+    X.EVENT_LOG = None
+    per_rank_ms = rank_times(torch, dist, dev, el, args.sv_steps)
+    if dist is not None:
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    nrm = float((st[0].abs() ** 2).sum().item()) if st is not None else None
+    chk = torch.zeros(1, device=dev, dtype=torch.float64)      # sum over the global batch of <psi|Z_0|psi>
+    for ch in chunks:
+        pr = (fwd(ch).abs() ** 2).to(torch.float64)
+        chk += (pr[:, : 2 ** (n - 1)].sum() - pr[:, 2 ** (n - 1):].sum())
+    if dist is not None:
+        dist.all_reduce(chk)
+    step_s = el / args.sv_steps
+    executed = hbm_entry("tcmi_spec_fwd_p* (plan-specialised forward passes, live tiles)", ev.get("pass"), args.sv_steps)
+    cc = build_circuit(tc, n, d, params[0] if hi > lo else torch.from_numpy(params_all[0]).to(dev))._compiled()
+    is_cut = isinstance(cc, X.CutCircuit)
+    npass = None if is_cut else len(cc.descs)
+    dense = None
+    if X.SPARSE_START and dist is None and not is_cut:
+        X.SPARSE_START = False
+        try:
+            step()
+            sync()
+            X.EVENT_LOG = []
+            td0 = time.perf_counter()
+            std = step()
+            torch.cuda.synchronize()
+            td = time.perf_counter() - td0
+            evd = summarize_events(X.EVENT_LOG)
+            dense = hbm_entry("the forward pass kernels, every tile live", evd.get("pass"), 1)
+            if dense is not None:
+                dense["ms_per_step"] = td * 1e3
+                dense["amplitudes_per_s"] = float(hi - lo) * (2 ** n) / td
+                dense["max_abs_state_difference"] = float((std - st).abs().max().item())
+            del std
+        finally:
+            X.EVENT_LOG = None
+            X.SPARSE_START = True
+    del st
+    f1 = tc.backend.jit(wavefunction)
+    lat1 = None
+    if hi > lo:
+        for _ in range(3):
+            f1(params[0])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            f1(params[0])
+        torch.cuda.synchronize()
+        lat1 = (time.perf_counter() - t1) / 5
+    b_sv = ((d - 1) * (n - 1) + 2) * 2.0 * (2 ** n) * 8      # SURVEY 8d: bytes of the gate-by-gate plan per state
+    kernel_ms = sum(v["ms"] for v in ev.values()) / max(1, args.sv_steps)
+    from tcmi import specialize as SP
+
+    return {
+        "workload": f"HEA-B statevector contraction n={n} depth={d} complex64 (north_star size): one step = {Bg} circuits, "
+                    f"{mb} per vmap call, timed through backend.jit(backend.vmap(wavefunction))",
+        "amplitudes_per_s": float(Bg) * (2 ** n) * args.sv_steps / el, "ms_per_step": step_s * 1e3, "steps": args.sv_steps,
+        "ms_per_state": step_s * 1e3 / max(1, hi - lo), "global_batch": Bg, "batch_per_gpu": hi - lo,
+        **({"per_rank_ms_per_step": per_rank_ms} if per_rank_ms is not None else {}),
+        "contraction": "cut" if is_cut else "state-vector", "passes": npass, "staging_s": round(staging, 3),
+        "state_norm": nrm, "z0_checksum": float(chk.item()),
+        "latency_batch1_ms": None if lat1 is None else lat1 * 1e3,
+        "roofline": {
+            "bound": "hbm",
+            # the fraction north_star's ">= 50 % of the HBM roofline" is read against: bytes the executed plan has to move
+            # (live tiles: read as far as they can be non-zero, written whole) over the HIP-event time of its launches
+            "executed_plan": executed,
+            "step": {"bound": "hbm", "executed_bytes_per_step": sum(v["work"] for v in ev.values()) / max(1, args.sv_steps),
+                     "achieved": sum(v["work"] for v in ev.values()) / max(1, args.sv_steps) / step_s / 1e9,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": sum(v["work"] for v in ev.values()) / max(1, args.sv_steps) / step_s / 1e9 / HBM_PEAK_GBS,
+                     "kernel_ms_per_step": kernel_ms, "wall_ms_per_step": step_s * 1e3},
+            "dense_plan": dense,
+            "B_sv_bytes_per_state": b_sv, "B_sv_GBps": b_sv * (hi - lo) / step_s / 1e9,
+            "B_sv_note": "cross-plan anchor of SURVEY 8(d): [(d-1)(n-1)+2] x 2 x 2^n x 8 B per state over the measured time; "
+                         "above the 8 TB/s peak = the plan moves fewer bytes than gate-by-gate execution, not a bandwidth",
+        },
+        "specialised_kernels": {"forward": sum(1 for v in SP._LOADED.values() if v.meta.get("kind") == "forward"),
+                                "compiled_in_this_process": SP.STATS["compiled"]},
+    }
+
+
 def hea_a_leg(tc, torch, args, dev):
     """SURVEY 8(d) config 2, secondary workload: HEA-A (reference benchmarks/scripts_v2/benchmark_core.py:6-14: H layer, then
     per layer rx on every qubit and a CNOT ladder), same size and call as the headline -- backend.jit(backend.vmap(
@@ -803,18 +1092,52 @@ def hea_a_leg(tc, torch, args, dev):
             "kernel_ms_per_call": {k: v["ms"] / args.steps for k, v in ev.items()}}
 
 
-def _guard(name, fn, *a):
+def _guard(name, fn, *a, dist=None, need_bytes=0):
     """Secondary legs must never take the headline line down with them.  Before a leg starts, the objects the earlier legs
     left alive (compiled plans, captured graphs, traced pipelines: millions of Python objects by the fourth leg) are moved
     out of the garbage collector's young generations: a full collection in the middle of a host-bound timed loop (the
-    sliced-VQA leg issues thousands of small tensor ops per step) otherwise shows up as a 100 ms step."""
+    sliced-VQA leg issues thousands of small tensor ops per step) otherwise shows up as a 100 ms step.
+
+    With more than one rank a leg holds collectives, so the ranks must agree on running it and none may leave it alone:
+    * BEFORE the leg every rank compares the device memory the leg needs (``need_bytes``: working set + 2 GiB for the
+      runtime's own allocations -- kernel scratch, code objects, graph pools; a device that is full makes THOSE fail, and
+      that surfaces as a queue abort, HSA_STATUS_ERROR_EXCEPTION, not as a Python error) with what is free on its device
+      (divided by the ranks that share the device in the oversubscribed launch-path test), and ONE all-reduce(MIN) decides:
+      the leg runs on every rank or is skipped on every rank, with the reason in the JSON line;
+    * an exception INSIDE the leg on one rank would leave the others in a collective forever: the rank prints the
+      traceback and exits with code 17, the launcher (self_launch, torchrun) takes the job down -- non-zero, never a hang.
+    One rank: the exception becomes an ``error`` entry and the line is still printed."""
     import gc
+
+    import torch
 
     gc.collect()
     gc.freeze()
+    if need_bytes:
+        torch.cuda.empty_cache()
+        free, total = torch.cuda.mem_get_info()
+        sharers = max(1, int(os.environ.get("TCMI_BENCH_SHARERS", "1")))
+        need = need_bytes + (2 << 30)
+        ok = free / sharers >= need
+        if dist is not None:
+            flag = torch.tensor([1.0 if ok else 0.0, free / sharers], device="cuda", dtype=torch.float64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok, free_min = bool(flag[0].item() > 0.5), float(flag[1].item())
+        else:
+            free_min = free / sharers
+        if not ok:
+            return {"skipped": f"{name}: needs {need / 2**30:.1f} GiB of device memory per rank, "
+                               f"{free_min / 2**30:.1f} GiB free on the fullest device ({sharers} rank(s) per device)"}
     try:
         return fn(*a)
     except Exception as e:  # noqa: BLE001
+        if dist is not None:
+            import traceback
+
+            traceback.print_exc()
+            print(f"bench.py: rank {os.environ.get('RANK', '0')} failed in leg {name!r} ({type(e).__name__}); the leg holds "
+                  f"collectives, leaving the job (exit 17)", file=sys.stderr, flush=True)
+            os._exit(17)
         return {"error": f"{name}: {type(e).__name__}: {e}"[:300]}
 
 
@@ -845,7 +1168,7 @@ def self_launch(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         if share:
-            env.update(LOCAL_RANK=str(r % have), TCMI_BENCH_BACKEND="gloo")
+            env.update(LOCAL_RANK=str(r % have), TCMI_BENCH_BACKEND="gloo", TCMI_BENCH_SHARERS=str(-(-n // have)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
@@ -886,6 +1209,11 @@ def main():
     ap.add_argument("--vqe-steps", type=int, default=2)
     ap.add_argument("--vqe-microbatch", type=int, default=8, help="samples per vvag call (bounds HBM use)")
     ap.add_argument("--vqe-streams", type=int, default=1, help="micro-batches of the VQE step alternate over this many HIP streams")
+    ap.add_argument("--sv-qubits", type=int, default=28, help="n = 28 statevector leg (north_star size): qubits; 0 disables")
+    ap.add_argument("--sv-depth", type=int, default=12)
+    ap.add_argument("--sv-batch", type=int, default=16, help="statevector leg: global batch of circuits per step (sharded over ranks)")
+    ap.add_argument("--sv-microbatch", type=int, default=8, help="statevector leg: circuits per vmap call")
+    ap.add_argument("--sv-steps", type=int, default=3)
     ap.add_argument("--mps-qubits", type=int, default=64, help="MPS TEBD leg (config 5): qubits; 0 disables the leg")
     ap.add_argument("--mps-chi", type=int, default=128)
     ap.add_argument("--mps-sweeps", type=int, default=2)
@@ -916,7 +1244,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.probe_child:
         args.no_graph = args.no_cpu_baseline = args.no_traffic_probe = True
-        args.vqe_qubits = args.mps_qubits = args.rqc_depth = args.svqa_qubits = 0
+        args.vqe_qubits = args.mps_qubits = args.rqc_depth = args.svqa_qubits = args.sv_qubits = 0
 
     # HBM traffic of the dominant kernel, measured by the PMC counters on this very command (child processes,
     # started before this process touches the GPU)
@@ -1078,6 +1406,7 @@ def main():
             del gs
         except Exception as e:  # noqa: BLE001
             graph_info = {"error": f"{type(e).__name__}: {e}"[:200]}
+    per_rank_ms = rank_times(torch, dist, dev, elapsed, args.steps)
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -1089,19 +1418,32 @@ def main():
     if rank == 0 and not args.probe_child and not args.no_hea_a:
         hea_a = _guard("hea_a", hea_a_leg, tc, torch, args, dev)
         torch.cuda.empty_cache()
+    sv28 = None
+    if args.sv_qubits:
+        lo_, hi_ = D_.shard_range(args.sv_batch, rank, world)
+        # the batched output state + one working copy per micro-batch, the last step's output alive next to the new one
+        sv28 = _guard("statevector_n28", statevector_leg, tc, torch, dist, args, rank, world, dev, dist=dist,
+                      need_bytes=int(3.5 * max(1, min(args.sv_microbatch, hi_ - lo_)) * (2 ** args.sv_qubits) * 8))
+        torch.cuda.empty_cache()
     vqe = None
     if args.vqe_qubits:
-        vqe = _guard("vqe_step", vqe_leg, tc, torch, dist, args, rank, world, dev)
+        # working set of a micro-batch of the traced step: psi, lambda and the per-call copies = 4.25 states per sample
+        # (68 GiB measured at 8 samples of 2 GiB)
+        lo_, hi_ = D_.shard_range(args.vqe_batch, rank, world)
+        vqe = _guard("vqe_step", vqe_leg, tc, torch, dist, args, rank, world, dev, dist=dist,
+                     need_bytes=int(4.5 * max(1, min(args.vqe_microbatch, hi_ - lo_)) * (2 ** args.vqe_qubits) * 8))
     # the host-bound leg first: it is the one that feels what earlier legs leave behind (graph memory pools, cached plans)
     svqa = None
     if args.svqa_qubits:
         torch.cuda.empty_cache()
-        svqa = _guard("sliced_vqa", sliced_vqa_leg, tc, torch, dist, args, rank, world)
+        svqa = _guard("sliced_vqa", sliced_vqa_leg, tc, torch, dist, args, rank, world, dist=dist, need_bytes=1 << 30)
 
     rqc = None
     if args.rqc_depth:
         torch.cuda.empty_cache()
-        rqc = _guard("rqc_amplitude", rqc_leg, tc, torch, dist, args, rank, world)
+        # two slices in flight (two streams), each a chain of intermediates of up to the target size
+        rqc = _guard("rqc_amplitude", rqc_leg, tc, torch, dist, args, rank, world, dist=dist,
+                     need_bytes=12 * (2 ** args.rqc_log2_target) * 8)
 
     if rank == 0:
         amps = float(Bg) * (2**n) * args.steps
@@ -1141,8 +1483,10 @@ def main():
                 **({"pipe": "bf16 MFMA, f32 operands cut into three bf16 pieces, six piece products per real product "
                             "(f32 accuracy: error against float64 equal to the f32 MFMA kernel's, "
                             "tests/test_gpu_gemm_split.py)"} if split else {}),
+                # the 8-flops-per-complex-MAC count over the time, and its ratio to the peak of the exact-f32 MFMA pipe: a
+                # comparison with the kernel this one replaced (> 1 on the bf16 pipe), NOT a fraction of anything achievable
                 "algorithmic_achieved": alg / (avg_us * 1e-6) / 1e12,
-                "algorithmic_frac": alg / (avg_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFS,
+                "vs_f32_mfma_peak": alg / (avg_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TFS,
                 "traffic": tr, "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command, "
                                                  "(2 FETCH + WRITE) KiB per launch" if tr else None,
                 "launches_per_step": g["launches"] / args.steps, "avg_launch_us": avg_us,
@@ -1183,6 +1527,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            **({"per_rank_ms_per_step": per_rank_ms} if per_rank_ms is not None else {}),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -1209,6 +1554,8 @@ def main():
             out["hipgraph_replay"] = graph_info
         if hea_a is not None:
             out["hea_a"] = hea_a
+        if sv28 is not None:
+            out["statevector_n%d" % args.sv_qubits] = sv28
         if vqe is not None:
             out["vqe_step"] = vqe
         if rqc is not None:

@@ -28,7 +28,7 @@ if r.get("bound") == "mfma":
     pk = r["peak"]
     pipe = "bf16 MFMA peak, 36 executed flops per complex MAC" if pk > 1000 else "f32 MFMA peak, 6 executed flops per complex MAC"
     L.append(f"  HIP events (bench line):   {r['avg_launch_us']:.1f} us per launch -> executed flops {r['executed_flops_per_launch']:.4g} / t = {r['achieved']:.1f} TF = {r['frac']:.3f} of {pk:.1f} TF ({pipe}); "
-             f"on 8 flops per MAC: {r['algorithmic_achieved']:.1f} TF = {r['algorithmic_frac']:.3f} of the 157.3 TF f32 MFMA peak")
+             f"on 8 flops per MAC: {r['algorithmic_achieved']:.1f} TF = {r.get('vs_f32_mfma_peak', r.get('algorithmic_frac', 0.0)):.3f} of the 157.3 TF f32 MFMA peak")
     if g:
         tf = r["executed_flops_per_launch"] / float(g["AverageNs"]) * 1e9 / 1e12
         L.append(f"  rocprofv3 (headline csv):  {float(g['AverageNs'])/1e3:.1f} us average over {g['Calls']} calls (min {float(g['MinNs'])/1e3:.1f}) -> {tf:.1f} TF = {tf/pk:.3f}")

@@ -4,13 +4,15 @@ Same constructor / methods / ``tree_data`` format as the reference.  MI355X-firs
 
 * one process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI) instead of one JAX
   process driving all devices; without an initialised process group the single rank runs every slice;
-* every rank computes the same deterministic plan (greedy path + greedy slicing), so the reference's
-  rank-0 search + broadcast (``experimental.py:850-857``) is unnecessary inside one node;
+* the path search is shared: the seeds of the hyper-search are dealt to the ranks and the best tree is
+  broadcast (``_get_tree_data``; the reference's rank-0 search + ``broadcast_py_object``,
+  ``experimental.py:850-857``); the search is deterministic per seed, so every world size picks the same tree;
 * slices are contracted by the HIP tensordot engine (``tcmi/tn.py``) and the per-rank partial
   ``[value || flattened gradients]`` is summed with ONE packed all-reduce
   (reference ``jnp.sum(device_values, axis=0)``, ``experimental.py:1145-1152``).
 """
 
+import itertools
 import pickle
 from typing import Any, Callable, Dict, List, Optional
 
@@ -22,6 +24,7 @@ from . import distributed as D
 from . import tn
 
 Tensor = Any
+_TRACE_SERIAL = itertools.count(1)      # one number per recorded node-function trace, process-wide
 
 
 class DistributedContractor:
@@ -109,10 +112,23 @@ class DistributedContractor:
         # varies a lot from seed to seed (32-qubit RQC: 19 to 90 ms of model time over seeds 0..7): with several seeds the
         # whole pipeline runs once per seed and the best tree by the objective (``minimize``; default: the engine's
         # two-roof time model) is kept -- the role of cotengra's hyper-optimiser (reference experimental.py:934-953).
+        import os
         import time as _time
 
+        import torch.distributed as dist
+
+        # With an initialised process group the SEEDS are dealt to the ranks (seed k to rank k mod W): every rank searches
+        # its share, one all_gather_object of the objectives picks the winner (smallest objective, ties to the seed that
+        # comes first in the list: what the serial loop keeps) and the winner's rank broadcasts the tree -- with one seed
+        # this is the reference's rank-0 search + ``broadcast_py_object`` (experimental.py:850-857), with 8 seeds on 8
+        # ranks the Python-bound search takes the time of one seed instead of eight on every rank.  TCMI_TN_SEARCH_SHARD=0:
+        # every rank runs the whole deterministic search locally (no collective in the constructor).
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        rank = dist.get_rank() if world > 1 else 0
+        shard = world > 1 and os.environ.get("TCMI_TN_SEARCH_SHARD", "1") != "0"
+        seeds = list(enumerate(o["seeds"]))
         best, stats = None, []
-        for seed in o["seeds"]:
+        for pos, seed in (seeds[rank::world] if shard else seeds):
             t0 = _time.perf_counter()
             tree = tn.ContractionTree.from_path(inputs, output, size_dict, trials=o["max_repeats"], seed=seed)
             tree.minimize = o["minimize"]
@@ -121,13 +137,23 @@ class DistributedContractor:
             if o["target_slices"] is not None:
                 tree.slice_to_slices(o["target_slices"])
             obj = tree.objective()
-            key = obj if isinstance(obj, tuple) else (obj,)
-            stats.append({"seed": seed, "objective": [float(x) for x in key], "model_time_s": tree.model_time(),
-                          "nslices": int(tree.nslices), "search_s": round(_time.perf_counter() - t0, 2)})
-            if best is None or key < best[0]:
-                best = (key, tree)
-        DistributedContractor.last_search = stats
-        return best[1].to_data()
+            key = tuple(float(x) for x in (obj if isinstance(obj, tuple) else (obj,)))
+            stats.append({"seed": seed, "objective": list(key), "model_time_s": tree.model_time(),
+                          "nslices": int(tree.nslices), "search_s": round(_time.perf_counter() - t0, 2), "rank": rank})
+            if best is None or (key, pos) < best[0]:
+                best = ((key, pos), tree)
+        if not shard:
+            DistributedContractor.last_search = stats
+            return best[1].to_data()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (None if best is None else best[0], stats))
+        cands = [(kp, r) for r, (kp, _) in enumerate(gathered) if kp is not None]
+        winner = min(cands)[1]
+        DistributedContractor.last_search = sorted((st for _, sts in gathered for st in sts),
+                                                   key=lambda st: o["seeds"].index(st["seed"]))
+        box = [best[1].to_data() if rank == winner else None]
+        dist.broadcast_object_list(box, src=winner)
+        return box[0]
 
     @staticmethod
     def find_path(nodes_fn: Callable[[Any], List[tn.Node]], params: Any,
@@ -193,6 +219,10 @@ class DistributedContractor:
             st["mode"] = "off"
         elif st["recipe"] is None:
             st["recipe"] = recipe            # first call: remember, check against the function on the next one
+            # what later calls cache per recipe (value_and_grad's fast_key) is keyed by this serial, never by id(recipe):
+            # an id can come back after a re-trace has freed the old recipe
+            st["serial"] = next(_TRACE_SERIAL)
+            self._fast_vjp_ok = self._group_cache = None
         else:
             again = self._replay_recipe(st["recipe"], leaves)
             same = again is not None and len(again) == len(arrays) and all(
@@ -364,7 +394,7 @@ class DistributedContractor:
         st_ = getattr(self, "_trace_state", None)
         fast_key = None
         if st_ is not None and st_["mode"] == "replay":
-            fast_key = (id(st_["recipe"]), tuple((tuple(x.shape), x.dtype) for x in leaves), cons.dtypestr)
+            fast_key = (("trace", st_["serial"]), tuple((tuple(x.shape), x.dtype) for x in leaves), cons.dtypestr)
         fk = getattr(self, "_fast_vjp_ok", None)
         if fast_key is not None and fk == fast_key:
             fast = True

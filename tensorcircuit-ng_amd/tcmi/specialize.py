@@ -898,24 +898,67 @@ def have_compiler() -> bool:
 
 
 def _compile(src: str, out_path: str, keep_source: bool):
+    """Compile one generated kernel into ``out_path`` -- ONE writer per code object and cache directory: the processes
+    that share a cache (the ranks of a job on one node, all of which want the same passes at the same moment) agree
+    through ``<out_path>.lock`` (O_EXCL) on who runs hipcc; the others wait for the file to appear.  A lock whose owner
+    died (pid gone, or older than TCMI_SPEC_LOCK_STALE_S = 600 s) is taken over."""
+    import time
+
     os.makedirs(os.path.dirname(out_path), exist_ok=True)
+    lock = out_path + ".lock"
+    stale_s = float(os.environ.get("TCMI_SPEC_LOCK_STALE_S", "600"))
+    while True:
+        if os.path.exists(out_path):
+            return
+        try:
+            fd = os.open(lock, os.O_CREAT | os.O_EXCL | os.O_WRONLY, 0o644)
+            os.write(fd, str(os.getpid()).encode())
+            os.close(fd)
+            break
+        except FileExistsError:
+            try:
+                st = os.stat(lock)
+                with open(lock) as fh:
+                    owner = int(fh.read().strip() or "0")
+                dead = owner > 0 and owner != os.getpid() and not os.path.exists(f"/proc/{owner}")
+                if dead or time.time() - st.st_mtime > stale_s:
+                    os.remove(lock)
+                    continue
+            except (OSError, ValueError):
+                pass          # the owner finished (or is writing its pid) between the two calls: look again
+            time.sleep(0.05)
     tmp_base = f"{out_path}.{os.getpid()}.{threading.get_ident()}"
     hip = tmp_base + ".hip"
-    with open(hip, "w") as fh:
-        fh.write(src)
     tmp_out = tmp_base + ".hsaco"
-    cc = HIPCC if os.path.exists(HIPCC) else shutil.which("hipcc")
     try:
+        if os.path.exists(out_path):      # written between the check and the lock
+            return
+        with open(hip, "w") as fh:
+            fh.write(src)
+        cc = HIPCC if os.path.exists(HIPCC) else shutil.which("hipcc")
         r = subprocess.run([cc] + HIPCC_FLAGS + [hip, "-o", tmp_out], capture_output=True, text=True)
         if r.returncode != 0 or not os.path.exists(tmp_out):
             raise RuntimeError(f"hipcc failed on a plan-specialised kernel:\n{r.stderr[-2000:]}")
-        os.replace(tmp_out, out_path)     # atomic: ranks of one job may compile the same pass side by side
+        os.replace(tmp_out, out_path)     # atomic: a reader sees the whole file or none
         if keep_source:
             os.replace(hip, out_path[:-6] + ".hip")
     finally:
-        for f in (hip, tmp_out):
+        for f in (hip, tmp_out, lock):
             if os.path.exists(f):
-                os.remove(f)
+                try:
+                    os.remove(f)
+                except OSError:
+                    pass
+
+
+def _compile_workers(njobs: int) -> int:
+    """hipcc processes this process may run side by side: the host's cores are shared by the ranks of the node
+    (LOCAL_WORLD_SIZE of the launcher), one core stays free for the launch threads."""
+    try:
+        local = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    except ValueError:
+        local = 1
+    return max(1, min(njobs, ((os.cpu_count() or 2) - 1) // local, 32))
 
 
 def _user_cache_dir() -> Optional[str]:
@@ -983,7 +1026,7 @@ def prepare(kind: str, descs: Sequence, opts: Optional[dict] = None, compile_mis
     if jobs:
         t0 = time.perf_counter()
         keep = bool(os.environ.get("TCMI_SPEC_KEEP"))
-        nw = workers or min(len(jobs), max(1, (os.cpu_count() or 2) - 1), 32)
+        nw = workers or _compile_workers(len(jobs))
         with ThreadPoolExecutor(max_workers=nw) as ex:
             futs = [ex.submit(_compile, src, path, keep) for _, src, _, path in jobs]
             for f in futs:

@@ -149,23 +149,9 @@ def _rqc_network(rows, cols, depth, dtype=np.complex128):
 
 
 def _contract_path(tensors, inputs, path, sliced, values):
-    """numpy tensordot chain along an SSA-free pairwise path (pairs of positions in the shrinking list, the result
-    appended, as opt_einsum / cotengra paths), with the ``sliced`` indices fixed to ``values``."""
-    ts, es = [], []
-    for t, e in zip(tensors, inputs):
-        sel = tuple(values[sliced.index(x)] if x in sliced else slice(None) for x in e)
-        ts.append(t[sel])
-        es.append([x for x in e if x not in sliced])
-    for a, b in path:
-        a, b = (a, b) if a < b else (b, a)
-        tb, eb = ts.pop(b), es.pop(b)
-        ta, ea = ts.pop(a), es.pop(a)
-        common = [x for x in ea if x in eb]
-        r = np.tensordot(ta, tb, axes=([ea.index(x) for x in common], [eb.index(x) for x in common]))
-        ts.append(r)
-        es.append([x for x in ea if x not in common] + [x for x in eb if x not in common])
-    assert len(ts) == 1 and es[0] == []
-    return complex(ts[0])
+    from oracle import sliced as OS
+
+    return OS.contract_path(tensors, inputs, path, sliced, values)
 
 
 def _tree(inputs, target):

@@ -32,9 +32,20 @@ def test_two_rank_bench_equals_the_one_rank_bench():
     assert la["config"]["global_batch"] == lb["config"]["global_batch"] == 4
     assert abs(la["config"]["z0_checksum"] - lb["config"]["z0_checksum"]) < 1e-5
     assert lb["config"]["calls_per_step_per_gpu"] * 2 == la["config"]["calls_per_step_per_gpu"]
-    for leg in ("vqe_step", "rqc_amplitude", "sliced_vqa"):
-        assert "error" not in la[leg], la[leg]
-        assert "error" not in lb[leg], lb[leg]
+    for leg in ("statevector_n16", "vqe_step", "rqc_amplitude", "sliced_vqa"):
+        assert "error" not in la[leg] and "skipped" not in la[leg], la[leg]
+        assert "error" not in lb[leg] and "skipped" not in lb[leg], lb[leg]
+    # what a SCALE record needs to be readable: every rank's own time and the latency of the step's collective
+    assert len(lb["per_rank_ms_per_step"]) == 2 and max(lb["per_rank_ms_per_step"]) <= lb["ms_per_step"] * 1.0001
+    assert len(lb["vqe_step"]["per_rank_ms_per_step"]) == 2 and lb["vqe_step"]["allreduce_us"] > 0
+    assert "per_rank_ms_per_step" not in la
+    # the n = 28 leg at toy size: the same global batch of states whatever the world size
+    assert abs(la["statevector_n16"]["z0_checksum"] - lb["statevector_n16"]["z0_checksum"]) < 1e-5
+    assert lb["statevector_n16"]["batch_per_gpu"] * 2 == la["statevector_n16"]["batch_per_gpu"] == 4
+    # the seeds of the path search are dealt to the ranks (one each here) and both worlds keep the same tree
+    assert [s_["rank"] for s_ in lb["rqc_amplitude"]["path_search"]["per_seed"]] == [0, 1]
+    assert [s_["rank"] for s_ in la["rqc_amplitude"]["path_search"]["per_seed"]] == [0, 0]
+    assert la["rqc_amplitude"]["path_search"]["per_seed_model_ms"] == lb["rqc_amplitude"]["path_search"]["per_seed_model_ms"]
     va, vb = la["vqe_step"], lb["vqe_step"]
     assert vb["batch_per_gpu"] * 2 == va["batch_per_gpu"] == 4
     assert abs(va["mean_energy"] - vb["mean_energy"]) < 1e-5 * max(1.0, abs(va["mean_energy"]))

@@ -254,3 +254,38 @@ def test_vmap_vvag_semantics_kat():
     same = np.array([f(batch[0], shared)] * 3)
     np.testing.assert_allclose(same, vals[0])
     assert np.abs(gw).max() > 0 and np.isfinite(g_single).all()
+
+
+def test_numpy_adjoint_value_and_grad_against_central_differences():
+    """oracle/adjoint.py (bench.py's CPU column of the VQE step) against oracle.dense: energy to rounding, every gradient
+    component to the central difference (step 1e-6, float64), the unused last ZZ angle of a row exactly 0."""
+    from oracle import adjoint as A
+
+    n, d = 7, 2
+    p = np.random.default_rng(11).normal(0, 0.8, [2 * d, n])
+    e, g = A.hea_b_tfim_value_and_grad(n, d, p)
+    f = lambda q: W.tfim_energy_dense(dense.run(n, W.hea_b_ops(n, d, q)), n)  # noqa: E731
+    assert abs(e - f(p)) < 1e-12
+    eps = 1e-6
+    for idx in np.ndindex(*p.shape):
+        pp, pm = p.copy(), p.copy()
+        pp[idx] += eps
+        pm[idx] -= eps
+        assert abs(g[idx] - (f(pp) - f(pm)) / (2 * eps)) < 2e-8, idx
+    assert (g[0::2, n - 1] == 0).all()
+    # the state it starts from is the oracle's
+    np.testing.assert_allclose(A.hea_b_state(n, d, p), dense.run(n, W.hea_b_ops(n, d, p)), atol=1e-14)
+
+
+def test_sliced_numpy_chain_sums_to_the_unsliced_contraction():
+    """oracle/sliced.py: fixing an index and summing its two slices equals the unsliced chain (a ring of three matrices)."""
+    from oracle import sliced as OS
+
+    rng = np.random.default_rng(2)
+    ts = [rng.normal(size=(2, 2)) + 1j * rng.normal(size=(2, 2)) for _ in range(3)]
+    ins = [[0, 1], [1, 2], [2, 0]]
+    path = [(0, 1), (0, 1)]
+    want = np.trace(ts[0] @ ts[1] @ ts[2])
+    assert abs(OS.contract_path(ts, ins, path, [], []) - want) < 1e-13
+    got = sum(OS.contract_path(ts, ins, path, [1], OS.slice_values(s, 1)) for s in range(2))
+    assert abs(got - want) < 1e-13

@@ -210,3 +210,42 @@ def test_a_failing_compiler_degrades_to_the_interpreter(monkeypatch, tmp_path):
         ks = ps.get()
     assert ks == [None] * len(plan.descs) and ps.state == "done"
     assert ps.get() == [None] * len(plan.descs)          # and stays quiet afterwards
+
+
+def test_one_compiler_run_per_code_object_when_processes_share_a_cache(tmp_path):
+    """Ranks of one node ask for the same generated kernel at the same moment: the lock file of specialize._compile lets
+    ONE of them run hipcc, the others wait for the code object."""
+    import stat
+    import subprocess
+    import sys
+    import textwrap
+
+    log = tmp_path / "calls.log"
+    fake = tmp_path / "fake_hipcc.sh"
+    fake.write_text(textwrap.dedent(f"""\
+        #!/bin/bash
+        echo run >> {log}
+        sleep 0.5
+        while [ "$1" != "-o" ]; do shift; done
+        echo code > "$2"
+        """))
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    out = tmp_path / "cache" / "k.hsaco"
+    child = textwrap.dedent(f"""\
+        import sys
+        sys.path[:0] = {[p for p in sys.path if p]!r}
+        from tcmi import specialize as S
+        S._compile("// source", {str(out)!r}, False)
+        assert open({str(out)!r}).read() == "code\\n"
+        """)
+    env = dict(os.environ, HIPCC=str(fake))
+    procs = [subprocess.Popen([sys.executable, "-c", child], env=env) for _ in range(4)]
+    assert [p.wait(timeout=120) for p in procs] == [0, 0, 0, 0]
+    assert log.read_text().count("run") == 1
+    assert not os.path.exists(str(out) + ".lock")
+    # a lock left behind by a process that no longer exists is taken over
+    os.remove(out)
+    with open(str(out) + ".lock", "w") as fh:
+        fh.write("999999999")
+    assert subprocess.run([sys.executable, "-c", child], env=env, timeout=120).returncode == 0
+    assert S._compile_workers(64) >= 1
