@@ -91,12 +91,14 @@ def cpu_baseline_vqe(n_full, d, budget_s=20.0):
         A.hea_b_tfim_value_and_grad(n, d, p, dtype=np.complex64)
         return time.perf_counter() - t0
 
-    n0 = min(16, n_full)
-    t_small = run(n0)
-    n = n0
-    while n < min(n_full, 24) and t_small * 2.0 ** (n + 1 - n0) <= budget_s:
-        n += 1
-    t = run(n) if n > n0 else t_small
+    n = min(16, n_full)
+    t = run(n)
+    spent = t
+    # two qubits at a time while the next size (x 4, and the caches stop helping: x 5) still fits what is left of the budget
+    while n + 2 <= min(n_full, 24) and spent + 5.0 * t <= budget_s:
+        n += 2
+        t = run(n)
+        spent += t
     return {"value": 1.0 / t, "unit": "samples/s (one value_and_grad of one circuit)", "cores": 1, "kind": "port",
             "sample": f"oracle.adjoint (numpy, strided in-place updates: one thread) HEA-B n={n} d={d} TFIM value_and_grad, "
                       f"complex64, one run of {t:.2f} s",
@@ -1092,6 +1094,23 @@ def hea_a_leg(tc, torch, args, dev):
             "kernel_ms_per_call": {k: v["ms"] / args.steps for k, v in ev.items()}}
 
 
+_T0 = time.perf_counter()
+
+
+def _trace(msg):
+    """One stderr line per leg boundary and rank when there is more than one rank (or TCMI_BENCH_TRACE=1): which leg a
+    rank was in when a job died or hung is otherwise unknowable -- the JSON line is printed last."""
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("TCMI_BENCH_TRACE") == "1":
+        try:
+            import torch
+
+            free = torch.cuda.mem_get_info()[0] / 2**30 if torch.cuda.is_initialized() else float("nan")
+        except Exception:  # noqa: BLE001
+            free = float("nan")
+        print(f"[bench rank {os.environ.get('RANK', '0')} +{time.perf_counter() - _T0:7.1f}s free {free:6.1f} GiB] {msg}",
+              file=sys.stderr, flush=True)
+
+
 def _guard(name, fn, *a, dist=None, need_bytes=0):
     """Secondary legs must never take the headline line down with them.  Before a leg starts, the objects the earlier legs
     left alive (compiled plans, captured graphs, traced pipelines: millions of Python objects by the fourth leg) are moved
@@ -1126,10 +1145,14 @@ def _guard(name, fn, *a, dist=None, need_bytes=0):
         else:
             free_min = free / sharers
         if not ok:
+            _trace(f"leg {name}: skipped (memory)")
             return {"skipped": f"{name}: needs {need / 2**30:.1f} GiB of device memory per rank, "
                                f"{free_min / 2**30:.1f} GiB free on the fullest device ({sharers} rank(s) per device)"}
     try:
-        return fn(*a)
+        _trace(f"leg {name}: start")
+        out = fn(*a)
+        _trace(f"leg {name}: done")
+        return out
     except Exception as e:  # noqa: BLE001
         if dist is not None:
             import traceback
@@ -1302,6 +1325,7 @@ def main():
         return build_circuit(tc, n, d, p).wavefunction()
 
     fwd = tc.backend.jit(tc.backend.vmap(wavefunction))
+    _trace("headline: start")
     t0 = time.perf_counter()
     state = fwd(params)               # staging: records the structure, compiles the plan (cached by structure)
     torch.cuda.synchronize()
@@ -1413,6 +1437,7 @@ def main():
         elapsed = float(tt.item())
     del state
     torch.cuda.empty_cache()
+    _trace("headline: done")
 
     hea_a = None
     if rank == 0 and not args.probe_child and not args.no_hea_a:

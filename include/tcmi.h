@@ -322,9 +322,11 @@ int tcmi_mps_gate_mix(const void* t, const void* gate, void* out, int L, int R, 
  * T = tile bits, LT = log2(threads per workgroup) of the plan the kernel was generated from. */
 int tcmi_spec_load(const char* path_host, const char* kernel_name_host, int lds_bytes, void** handle_out_host);
 int tcmi_spec_unload(void* handle);
-/* Persistent kernels (one workgroup loops over many tiles): launch at most `max_workgroups` workgroups (grid.x * batch);
- * 0 (the default after tcmi_spec_load) = one workgroup per tile.  Must match how the kernel was generated. */
-int tcmi_spec_set_grid(void* handle, int max_workgroups);
+/* What the generator knows about the kernel and the launchers must respect (0 after tcmi_spec_load):
+ * TCMI_SPEC_FLAG_SRC = generated with the "src" option: its argument buffer is tcmi_spec_run_pass_from's; that launcher
+ * refuses handles without the flag and tcmi_spec_run_pass refuses handles with it. */
+#define TCMI_SPEC_FLAG_SRC 1
+int tcmi_spec_set_flags(void* handle, int flags);
 /* `live_mask` (over the n - T bits of the tile index; 0xffffffff = every tile): only the tiles whose index is zero outside
  * the mask get a workgroup.  A circuit started from |0...0> leaves every amplitude whose index has a 1 on a qubit no pass
  * has had in its tile yet exactly zero, and a pass acts inside its tiles: those tiles are zero before and after it, so

@@ -19,17 +19,14 @@ struct SpecKernel {
   hipModule_t mod;
   hipFunction_t fn;
   int lds_bytes;
-  int max_workgroups;   // > 0: persistent kernel, grid.x * batch capped at this many workgroups (it loops over its tiles)
+  int flags;            // TCMI_SPEC_FLAG_SRC: generated with the "src" option (argument buffer of tcmi_spec_run_pass_from)
 };
 // live_mask (over the n - T bits of the tile index): 0xffffffff = one workgroup per tile; else one workgroup per tile whose
 // index is zero outside the mask (the kernel spreads blockIdx.x over the mask's bits)
-unsigned grid_x(const SpecKernel* k, int n, int T, int batch, unsigned live_mask) {
+unsigned grid_x(int n, int T, unsigned live_mask) {
   unsigned tiles = 1u << (n - T);
   if (live_mask != 0xffffffffu) tiles = 1u << __builtin_popcount(live_mask & (tiles - 1u));
-  if (k->max_workgroups <= 0) return tiles;
-  unsigned g = (unsigned)k->max_workgroups / (unsigned)batch;
-  if (g < 1u) g = 1u;
-  return g < tiles ? g : tiles;
+  return tiles;
 }
 int hip_fail(const char* what, hipError_t e) {
   char buf[256];
@@ -64,9 +61,9 @@ int tcmi_spec_load(const char* path_host, const char* kernel_name_host, int lds_
   return TCMI_OK;
 }
 
-int tcmi_spec_set_grid(void* handle, int max_workgroups) {
-  if (!handle || max_workgroups < 0) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_spec_set_grid: bad argument");
-  reinterpret_cast<SpecKernel*>(handle)->max_workgroups = max_workgroups;
+int tcmi_spec_set_flags(void* handle, int flags) {
+  if (!handle || (flags & ~TCMI_SPEC_FLAG_SRC)) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_spec_set_flags: bad argument");
+  reinterpret_cast<SpecKernel*>(handle)->flags = flags;
   return TCMI_OK;
 }
 
@@ -84,6 +81,8 @@ int tcmi_spec_run_pass(void* handle, void* state, long long state_stride, int ba
   if (!handle || !state || batch < 1 || n < T || T <= LT || LT < 6 || LT > 10)
     return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_spec_run_pass: bad argument");
   SpecKernel* k = reinterpret_cast<SpecKernel*>(handle);
+  if (k->flags & TCMI_SPEC_FLAG_SRC)
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_spec_run_pass: the kernel reads its input from another batch (tcmi_spec_run_pass_from)");
   struct {
     void* state;
     long long state_stride;
@@ -95,7 +94,7 @@ int tcmi_spec_run_pass(void* handle, void* state, long long state_stride, int ba
   } args = {state, state_stride, ctab, ptab, ptab_stride, live_mask, zero_bits};
   size_t sz = sizeof(args);
   void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  hipError_t e = hipModuleLaunchKernel(k->fn, grid_x(k, n, T, batch, live_mask), (unsigned)batch, 1, 1u << LT, 1, 1, (unsigned)k->lds_bytes,
+  hipError_t e = hipModuleLaunchKernel(k->fn, grid_x(n, T, live_mask), (unsigned)batch, 1, 1u << LT, 1, 1, (unsigned)k->lds_bytes,
                                        reinterpret_cast<hipStream_t>(stream), nullptr, cfg);
   return e == hipSuccess ? TCMI_OK : hip_fail("tcmi_spec_run_pass", e);
 }
@@ -106,6 +105,8 @@ int tcmi_spec_run_pass_from(void* handle, void* state, long long state_stride, i
   if (!handle || !state || !src || batch < 1 || n < T || T <= LT || LT < 6 || LT > 10 || src_shift < 0 || src_shift > 30)
     return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_spec_run_pass_from: bad argument");
   SpecKernel* k = reinterpret_cast<SpecKernel*>(handle);
+  if (!(k->flags & TCMI_SPEC_FLAG_SRC))   // a kernel without the "src" arguments would be launched with a mismatched buffer
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_spec_run_pass_from: the kernel was not generated with the src option (tcmi_spec_set_flags)");
   struct {
     void* state;
     long long state_stride;
@@ -123,7 +124,7 @@ int tcmi_spec_run_pass_from(void* handle, void* state, long long state_stride, i
             scale ? 1u : 0u, scale ? scale : src};
   size_t sz = sizeof(args);
   void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  hipError_t e = hipModuleLaunchKernel(k->fn, grid_x(k, n, T, batch, 0xffffffffu), (unsigned)batch, 1, 1u << LT, 1, 1,
+  hipError_t e = hipModuleLaunchKernel(k->fn, grid_x(n, T, 0xffffffffu), (unsigned)batch, 1, 1u << LT, 1, 1,
                                        (unsigned)k->lds_bytes, reinterpret_cast<hipStream_t>(stream), nullptr, cfg);
   return e == hipSuccess ? TCMI_OK : hip_fail("tcmi_spec_run_pass_from", e);
 }
@@ -150,7 +151,7 @@ int tcmi_spec_run_adjoint_pass(void* handle, void* psi, void* lam, long long sta
   } args = {psi, lam, state_stride, ctab, ptab, ptab_stride, gout, gout_stride, gcopies, live_mask, gcopy_stride};
   size_t sz = sizeof(args);
   void* cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-  hipError_t e = hipModuleLaunchKernel(k->fn, grid_x(k, n, T, batch, live_mask), (unsigned)batch, 1, 1u << LT, 1, 1, (unsigned)k->lds_bytes,
+  hipError_t e = hipModuleLaunchKernel(k->fn, grid_x(n, T, live_mask), (unsigned)batch, 1, 1u << LT, 1, 1, (unsigned)k->lds_bytes,
                                        reinterpret_cast<hipStream_t>(stream), nullptr, cfg);
   return e == hipSuccess ? TCMI_OK : hip_fail("tcmi_spec_run_adjoint_pass", e);
 }

@@ -159,7 +159,7 @@ _SIGNATURES = {
     ),
     "tcmi_spec_load": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p]),
     "tcmi_spec_unload": (ctypes.c_int, [ctypes.c_void_p]),
-    "tcmi_spec_set_grid": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "tcmi_spec_set_flags": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "tcmi_spec_run_pass": (
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

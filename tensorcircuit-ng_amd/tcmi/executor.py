@@ -17,6 +17,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 
 from . import _lib
+from ._knobs import knob
 from . import plan as P
 from . import specialize as S
 
@@ -101,18 +102,18 @@ def pick_variant(n: int, dtypestr: str, opts: Optional[dict] = None) -> Tuple[in
         variants = [(4, 8), (3, 8), (2, 6)]
     if "R" in opts and "LT" in opts:
         variants = [(int(opts["R"]), int(opts["LT"]))] + variants
-    elif os.environ.get("TCMI_FWD_TILE"):       # experiment switch: "R,LT" of the gate passes
-        variants = [tuple(int(x) for x in os.environ["TCMI_FWD_TILE"].split(","))] + variants
+    elif knob("fwd_tile"):       # experiment switch: "R,LT" of the gate passes
+        variants = [tuple(int(x) for x in knob("fwd_tile").split(","))] + variants
     for R, LT in variants:
         if R + LT <= n_exec:
             low = int(opts.get("lowbits", 5))
             low = max(1, min(low, R + LT))
             # complex64 tiles with R >= 4 run on the packed-f32 kernel (csrc/tcmi_vm2.hip), which knows OP_DIAGB2
-            gen = 2 if (c64 and R >= 4 and not os.environ.get("TCMI_VM1")) else 1
-            cap = os.environ.get("TCMI_PASS_CAP")
+            gen = 2 if (c64 and R >= 4 and not knob("vm1")) else 1
+            cap = knob("pass_cap")
             return n_exec, P.PlanConfig(R=R, LT=LT, lowbits=low, vec=2 if c64 else 1, gen=gen,
                                         pass_cap=int(cap) if cap else None,
-                                        shear2=os.environ.get("TCMI_SHEAR2", "1") != "0")
+                                        shear2=knob("shear2", "1") != "0")
     raise ValueError("no tile variant fits")
 
 
@@ -159,8 +160,8 @@ def _shift_gate(g: P.GateRec, pad: int) -> P.GateRec:
 
 LIVE_FULL = 0xFFFFFFFF
 SPARSE_START = os.environ.get("TCMI_SPARSE_START", "1") != "0"
-LIVE_PLAN = SPARSE_START and os.environ.get("TCMI_LIVE_PLAN", "1") != "0"    # plans chosen by the cost of their live tiles
-NO_ZERO_FILL = os.environ.get("TCMI_NO_ZERO_FILL", "1") != "0"   # |0...0> start without the zero fill (CompiledCircuit.zero_bits)
+LIVE_PLAN = SPARSE_START and knob("live_plan", "1") != "0"    # plans chosen by the cost of their live tiles
+NO_ZERO_FILL = knob("no_zero_fill", "1") != "0"   # |0...0> start without the zero fill (CompiledCircuit.zero_bits)
 
 
 def choose_plan(n: int, gates: List[P.GateRec], nparams: int, dtypestr: str, opts: Optional[dict] = None):
@@ -245,7 +246,7 @@ def choose_adjoint_plan(gates: List[P.GateRec], n_exec: int, dtypestr: str, full
             return adj_cost_us(a, live_masks(a.descs, n_exec, reverse=True)[1] if live else None)
 
         best = adj_cost(ap)
-        force = os.environ.get("TCMI_ADJ_FORCE")      # experiment switch "lowbits,tiebreak[,pass cap]": that candidate, whatever the model says
+        force = knob("adj_force")      # experiment switch "lowbits,tiebreak[,pass cap]": that candidate, whatever the model says
         if force and full:
             lb, tb, *cap_ = (int(x) for x in force.split(","))
             cfg = dataclasses.replace(cfg, lowbits=lb, tiebreak=tb, pass_cap=cap_[0] if cap_ else None)
@@ -869,14 +870,14 @@ def pick_measure_variant(n_exec: int, dtypestr: str) -> P.PlanConfig:
     """Tile of the measurement passes: complex64 states of >= 13 qubits go to the packed kernel
     (csrc/tcmi_measure2.hip, TCMI_OP_EXPECT2 descriptors), everything else to the first-generation kernel."""
     c64 = dtypestr == "complex64"
-    ov = os.environ.get("TCMI_MEAS_CFG")     # experiment switch: "R,LT,lowbits" of the first-generation kernel
+    ov = knob("meas_cfg")     # experiment switch: "R,LT,lowbits" of the first-generation kernel
     if ov and c64:
         R, LT, lb = (int(x) for x in ov.split(","))
         if R + LT <= n_exec and (R, LT) != (5, 8):
             return P.PlanConfig(R=R, LT=LT, lowbits=lb, vec=2)
-    if c64 and n_exec >= 13 and not os.environ.get("TCMI_VM1"):
+    if c64 and n_exec >= 13 and not knob("vm1"):
         # packed kernel csrc/tcmi_measure2.hip (TCMI_OP_EXPECT2 descriptors): 32 amplitudes per thread, 13 tile bits
-        return P.PlanConfig(R=5, LT=8, lowbits=int(os.environ.get("TCMI_MEAS_LOWBITS", "5")), vec=2, gen=2)
+        return P.PlanConfig(R=5, LT=8, lowbits=int(knob("meas_lowbits", "5")), vec=2, gen=2)
     return pick_small_tile_variant(n_exec, dtypestr)
 
 
@@ -890,20 +891,16 @@ def pick_adjoint_variant(n_exec: int, dtypestr: str, gates) -> P.PlanConfig:
     # plan.emit_diag): both are G2 ops, which only the first-generation sweep executes
     dense2 = any(((not g.is_diag) and len(g.qubits) > 1) or (g.is_diag and any(len(t.qubits) > 2 for t in g.diag))
                  for g in gates)
-    if dtypestr == "complex64" and n_exec >= 13 and not dense2 and not os.environ.get("TCMI_VM1"):
+    if dtypestr == "complex64" and n_exec >= 13 and not dense2 and not knob("vm1"):
         # two-shear rotations in the reverse sweep: implemented and tested (TCMI_SHEAR2_BW=1), off by default -- the sweep
         # needs a second phase table for lambda (reciprocal real factors), whose scalar loads cost what the dropped
         # shears save (n = 28 d = 12: 28.8 vs 28.7 ms per pass)
         # ... in the INTERPRETING kernel.  The plan-specialised sweep prefetches its tables a segment ahead, so there the
         # dropped shears are pure gain (16 of 64 packed instructions per eligible gate): on whenever specialisation is
-        sh2 = os.environ.get("TCMI_SHEAR2_BW", "1" if (S.mode() != "0" and n_exec >= S.MIN_N) else "0") == "1"
-        if os.environ.get("TCMI_ADJ_R5"):   # experiment switch: 32 + 32 amplitude pairs per thread, 2 waves per SIMD
-            return P.PlanConfig(R=5, LT=8, lowbits=5, vec=2, gen=2, shear2=sh2)
-        if os.environ.get("TCMI_ADJ_TILE"):   # experiment switch "R,LT": 2^R amplitudes of psi and of lambda per thread,
-            r_, lt_ = (int(x) for x in os.environ["TCMI_ADJ_TILE"].split(","))    # workgroups of 2^LT threads (6: one wave, no barriers)
+        sh2 = knob("shear2_bw", "1" if (S.mode() != "0" and n_exec >= S.MIN_N) else "0") == "1"
+        if knob("adj_tile"):   # experiment switch "R,LT": 2^R amplitudes of psi and of lambda per thread,
+            r_, lt_ = (int(x) for x in knob("adj_tile").split(","))    # workgroups of 2^LT threads (6: one wave, no barriers)
             return P.PlanConfig(R=r_, LT=lt_, lowbits=5, vec=2, gen=2, shear2=sh2)
-        if os.environ.get("TCMI_ADJ_LT9"):  # experiment switch: 512-thread workgroups, two per CU, 13 tile bits
-            return P.PlanConfig(R=4, LT=9, lowbits=5, vec=2, gen=2, shear2=sh2)
         return P.PlanConfig(R=4, LT=8, lowbits=5, vec=2, gen=2, shear2=sh2)
     return pick_small_tile_variant(n_exec, dtypestr)
 
@@ -992,7 +989,7 @@ class CompiledMeasure:
         cache = self.__dict__.setdefault("_tiled_cache", {})
         if skip not in cache:
             cache[skip] = None
-            if os.environ.get("TCMI_PAULI_TILED", "1") != "0" and self.n_exec <= 32:
+            if knob("pauli_tiled", "1") != "0" and self.n_exec <= 32:
                 n = self.n_exec
                 rows = []
                 for k, t in enumerate(self.all_terms):
@@ -1354,7 +1351,7 @@ class _HalfBatch:
         if scale is not None and scale_ready is not None:
             torch.cuda.current_stream(self.suffix.device).wait_event(scale_ready)
         rep_n = K // Ks
-        if rep_n & (rep_n - 1) == 0 and os.environ.get("TCMI_CUT_FUSED_REP", "1") != "0":
+        if rep_n & (rep_n - 1) == 0 and knob("cut_fused_rep", "1") != "0":
             # state b*K + j of the suffix batch = weight[b, j] * prefix state (b*K + j) >> log2(K / Ks): read by the suffix's
             # first pass itself (tcmi_spec_run_pass_from; materialised inside state() when that kernel is not there)
             return self.suffix.state(pfull, src=(pre, rep_n.bit_length() - 1, scale))
@@ -1469,11 +1466,6 @@ class CutCircuit:
             tabs["dig8"] = self.digits.to(torch.uint8).contiguous()              # [K, nb]
         B = params.shape[0]
         nb, rmax = tabs["nb"], tabs["rmax"]
-        if os.environ.get("TCMI_CUT_WEIGHTS_TORCH", "0") == "1":                 # the elementwise formulation (12 launches)
-            a = params[:, tabs["pidx"]].to(torch.float64).reshape(B, nb, rmax) * tabs["scale"] + tabs["offs"]
-            v = tabs["const"] + tabs["cmask"] * torch.cos(a) + tabs["smask"] * torch.sin(a)   # [B, nb, rmax] complex128
-            sel = torch.gather(v, 2, tabs["dig"].expand(B, nb, -1))             # [B, nb, K]
-            return sel.prod(dim=1).to(self.tdtype)
         p = params.contiguous()
         w = torch.empty(B, self.K, dtype=self.tdtype, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -1499,11 +1491,11 @@ class CutCircuit:
         # The two half-circuit batches are independent and neither fills the chip (one workgroup per state: B*Ks
         # workgroups in the prefix passes), so the right half runs on a second HIP stream beside the left one.
         cur = torch.cuda.current_stream(self.device)
-        two = os.environ.get("TCMI_CUT_STREAMS", "1") != "0"      # also under hipGraph capture (fork / join in the graph)
+        two = knob("cut_streams", "1") != "0"      # also under hipGraph capture (fork / join in the graph)
         # experiment switch (scripts/experiments/README.md, round 4): sub-batches on their own streams so that the passes of
         # one hide under the join of another -- measured SLOWER (7.4e10 -> 6.9e10 / 6.4e10 amplitudes/s at 2 / 4 sub-batches:
         # the join GEMM loses more on smaller batches than the passes cost), so off
-        nsplit = min(int(os.environ.get("TCMI_CUT_SPLIT", "1")), B) if two else 1
+        nsplit = min(int(knob("cut_split", "1")), B) if two else 1
         if nsplit >= 2:
             return self._state_pipelined(p, pfull, B, nsplit, out)
         if two:

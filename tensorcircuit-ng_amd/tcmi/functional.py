@@ -245,17 +245,27 @@ def _fns():
 
 
 def _shift_scales(cc):
-    """scale[j] of the one gate angle a = scale * theta_j + offset that parameter j feeds, and how many gates it feeds."""
+    """(scale, count, other): scale[j] of the one gate angle a = scale * theta_j + offset that parameter j feeds, how many
+    gates it feeds that way, and how many times it is read in a way the shift rule below has no form for -- through a
+    diagonal term of a gate whose own ``param`` is another parameter (a fused diagonal) or as the selector of a
+    ``select`` gate (cut selector columns)."""
     tab = getattr(cc, "_shift_tab", None)
     if tab is None:
         gates = getattr(cc, "full", cc)._exec_gates
         npar = max(1, cc.nparams)
-        scale, count = np.zeros(npar), np.zeros(npar, dtype=np.int64)
+        scale, count, other = np.zeros(npar), np.zeros(npar, dtype=np.int64), np.zeros(npar, dtype=np.int64)
         for g in gates:
-            if g.param is not None and g.select is None and g.param.index < npar:
-                scale[g.param.index] = g.param.scale
-                count[g.param.index] += 1
-        tab = cc._shift_tab = (scale, count)
+            own = g.param.index if g.param is not None else None
+            if g.param is not None and g.param.index < npar:
+                if g.select is None:
+                    scale[g.param.index] = g.param.scale
+                    count[g.param.index] += 1
+                else:
+                    other[g.param.index] += 1
+            for t in (g.diag or ()):
+                if t.param is not None and t.param.index != own and t.param.index < npar:
+                    other[t.param.index] += 1
+        tab = cc._shift_tab = (scale, count, other)
     return tab
 
 
@@ -271,12 +281,16 @@ def _second_order(cc, params, g, c, need_params, need_g):
     g2 = g.reshape(-1, g.shape[-1])
     c2 = c.reshape(-1, npar).to(torch.float64)
     nel = g2.shape[-1]
-    scale, count = _shift_scales(cc)
+    scale, count, other = _shift_scales(cc)
     rows = torch.nonzero(c2).cpu().numpy()                   # (batch row, parameter) of every non-zero cotangent entry
     gp_out = torch.zeros(p2.shape, dtype=torch.float64, device=p2.device) if need_params else None
     t_out = torch.zeros_like(g2) if need_g else None
     if rows.shape[0]:
         js = rows[:, 1]
+        if (other[js] > 0).any():
+            raise NotImplementedError("Backend 'hip': second-order derivatives need every parameter to be the angle of ONE "
+                                      "gate (parameters %s are read through a fused diagonal term or select a gate)"
+                                      % sorted(set(int(j) for j in js[other[js] > 0])))
         if (count[js] > 1).any():
             raise NotImplementedError("Backend 'hip': second-order derivatives need every parameter to feed ONE gate "
                                       "(parameters %s feed several)" % sorted(set(int(j) for j in js[count[js] > 1])))

@@ -160,7 +160,7 @@ class _Emitter:
         # XCD-aware order runs on the same L2 a moment later -- a line marked streaming is gone by then (PMC, sweep pass 1 of
         # n = 28: 88 GB moved for 69 GB algorithmic with the hint; passes on 64-byte runs 5-27 % faster without it).  Tiles of
         # whole lines keep it for states that no cache holds until the next pass (2^26 amplitudes = 512 MiB and up: forward
-        # 8.96 -> 8.85 ms per state at n = 28; TCMI_SPEC_EXP=ntl=0,nts=0 to compare); smaller states are re-read from L2 /
+        # 8.96 -> 8.85 ms per state at n = 28; specialize.EXTRA_OPTS = {'ntl': 0, 'nts': 0} to compare); smaller states are re-read from L2 /
         # MALL by the next pass or the join.
         nt = int(self.n >= NT_MIN_N and (8 << run) >= 128)
         self.opts.setdefault("ntl", nt)
@@ -214,49 +214,28 @@ class _Emitter:
         return out
 
     # ---- prologue ------------------------------------------------------------------------------------
-    def persistent(self) -> bool:
-        """Experiment switch (TCMI_SPEC_EXP=persist; off): one workgroup loops over many tiles (grid = the workgroups the chip
-        holds at once, tcmi_spec_set_grid) instead of one workgroup per tile -- no dispatch gap between two tiles on a wave
-        slot, gradient sums leave the kernel once per workgroup.  Measured SLOWER (forward 8.9 -> 10.5 ms, sweep 27.3 ->
-        31 ms per sample, with or without an initial stagger): on gfx9-family hardware vmcnt counts stores too, so the wait
-        for the next tile's loads also waits for the previous tile's write acknowledgements, which a fresh workgroup on
-        the same slot never sees."""
-        return bool(self.opts.get("persist", False))
-
     def index_lines(self) -> Tuple[List[str], List[str]]:
         """(lines before the tile loop, lines that open it)."""
         free = [p for p in range(self.n) if p not in self.tile_bits]
         pairs = [(i, p) for i, p in enumerate(free)]
         pre = ["  const uint32_t tid = threadIdx.x;"]
-        k = int(self.opts.get("stagger", 0))
-        if k > 0:     # experiment (scripts/experiments/README.md, round 4: no effect): first generation started out of phase
-            slots = (1024 >> self.LT) * 256 * 4 >> 2
-            cond = "true" if self.persistent() else f"blockIdx.y == 0 && blockIdx.x < {slots}u"
-            pre += [f"  if ({cond}) {{",
-                    "    uint32_t hw;",
-                    '    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));',
-                    f"    for (uint32_t i = (hw & 3u) * {k}u; i > 0; --i) __builtin_amdgcn_s_sleep(127);",
-                    "  }"]
-        if self.persistent():
-            loop = [f"  for (uint32_t bx = blockIdx.x; bx < {1 << (self.n - self.T)}u; bx += gridDim.x) {{"]
-        else:
-            # live_mask (kernel argument, over the bits of the tile index): 0xffffffff = every tile has its workgroup; else
-            # the grid holds one workgroup per tile whose index is zero outside the mask -- the tiles that can be non-zero
-            # while some qubits of a circuit started from |0...0> have not been touched yet (executor.live_masks)
-            loop = ["  { uint32_t bx = blockIdx.x;"]
-            if self.opts.get("xcd", 1):
-                # XCD-aware tile order.  Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md, workgroup dispatch), every XCD
-                # has its own L2 (128-byte lines), and tile index t and t + 1 differ in the LOWEST physical bit outside the
-                # tile: with tiles of 64-byte runs (pinned low bits 0..2) they are the two halves of the same L2 lines.
-                # Dealt round-robin, the two halves go to two XCDs and each L2 fetches (and writes back) whole lines for
-                # half their bytes; here XCD x walks the contiguous range [x N/8, (x + 1) N/8) of tile indices instead, so
-                # neighbours in the tile order are neighbours in time on ONE L2.
-                loop += ["  if (gridDim.x >= 16u) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);"]
-            loop += ["  if (live_mask != 0xffffffffu) {",
-                    "    uint32_t b_ = 0, s_ = bx;",
-                    "    for (uint32_t m_ = live_mask; m_; m_ &= m_ - 1u) { if (s_ & 1u) b_ |= m_ & (0u - m_); s_ >>= 1; }",
-                    "    bx = b_;",
-                    "  }"]
+        # live_mask (kernel argument, over the bits of the tile index): 0xffffffff = every tile has its workgroup; else
+        # the grid holds one workgroup per tile whose index is zero outside the mask -- the tiles that can be non-zero
+        # while some qubits of a circuit started from |0...0> have not been touched yet (executor.live_masks)
+        loop = ["  { uint32_t bx = blockIdx.x;"]
+        if self.opts.get("xcd", 1):
+            # XCD-aware tile order.  Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md, workgroup dispatch), every XCD
+            # has its own L2 (128-byte lines), and tile index t and t + 1 differ in the LOWEST physical bit outside the
+            # tile: with tiles of 64-byte runs (pinned low bits 0..2) they are the two halves of the same L2 lines.
+            # Dealt round-robin, the two halves go to two XCDs and each L2 fetches (and writes back) whole lines for
+            # half their bytes; here XCD x walks the contiguous range [x N/8, (x + 1) N/8) of tile indices instead, so
+            # neighbours in the tile order are neighbours in time on ONE L2.
+            loop += ["  if (gridDim.x >= 16u) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);"]
+        loop += ["  if (live_mask != 0xffffffffu) {",
+                 "    uint32_t b_ = 0, s_ = bx;",
+                 "    for (uint32_t m_ = live_mask; m_; m_ &= m_ - 1u) { if (s_ & 1u) b_ |= m_ & (0u - m_); s_ >>= 1; }",
+                 "    bx = b_;",
+                 "  }"]
         loop.append(f"  const uint32_t wg_base = {_deposit_expr('bx', pairs)};")
         return pre, loop
 
@@ -297,13 +276,6 @@ class _Emitter:
             for r in range(0, self.NR, 2):
                 c = _xor_const(rd.reg_phys, r) * 8
                 addr = f"{base} + {c:#x}ull + {toff}"
-                if self.opts.get("nomem"):     # timing experiment only (wrong results): the pass without its HBM traffic
-                    if not store:
-                        out.append(f'  asm volatile("v_mov_b32 %0, 0" : "=v"({self.A(r, vec)}.x)); {self.A(r, vec)}.y = 1.f; '
-                                   f'{self.A(r + 1, vec)} = {self.A(r, vec)};')
-                    elif r == 0:
-                        out.append(f"  if ({self.A(r, vec)}.x == 123.456f) *reinterpret_cast<v2f*>({addr}) = {self.A(r, vec)};")
-                    continue
                 if store:
                     v = self.fresh("sv")
                     st = (f"__builtin_nontemporal_store({v}, reinterpret_cast<v4f*>({addr}))" if self.opts.get("nts")
@@ -403,8 +375,6 @@ class _Emitter:
                 out.append("  " + stmt(r, f"lb + {nm} + {c << sh}"))
 
         first = True
-        if self.opts.get("noexch"):      # timing experiment only (wrong results): what do the exchanges cost?
-            planes = []
         for vec, comp in planes:
             sfx = f".{comp}" if comp else ""
             walk(out, "wsd", ws, wplan, lambda r, ad: f"*({vqw}{ctype} LDS_AS*)({ad}) = {self.A(r, vec)}{sfx};")
@@ -708,10 +678,6 @@ class _Forward(_Emitter):
         rd0 = self.rounds[0]
         sg = self.seg("tile load")
         self.tphys = self.fresh("tph")
-        trace = bool(self.opts.get("trace"))     # timing experiment: (start, tile arrived, compute done) per workgroup
-        if trace:
-            sg.parts[0].append("  unsigned long long* const trc = (unsigned long long*)ctab_g + 32ull * (bx + (unsigned long long)gridDim.x * blockIdx.y);")
-            sg.parts[0].append("  if (tid == 0) { trc[0] = wall_clock64(); unsigned hw; asm volatile(\"s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\" : \"=s\"(hw)); trc[3] = hw; }")
         if int(self.opts.get("prio", 0)) & 1:      # a young workgroup's loads go out ahead of the older ones' arithmetic
             sg.parts[0].append("  __builtin_amdgcn_s_setprio(3);")
         self.thread_xor(sg.parts[0], self.tphys, rd0.thr_phys)
@@ -729,9 +695,6 @@ class _Forward(_Emitter):
             p_.append(f"  if (has_scale) {sc} = ((KV2)scale)[blockIdx.y];")
             for h in range(0, NR, 8):
                 p_.append("  vm2_cmul8s(" + ", ".join(self.A(h + i) for i in range(8)) + ", " + ", ".join([sc] * 8) + ");")
-        if trace:
-            sg.parts[0].append('  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");')
-            sg.parts[0].append("  if (tid == 0) trc[1] = wall_clock64();")
         for k, rd in enumerate(self.rounds):
             q = rd.ops_at
             for _ in range(rd.nops):
@@ -740,16 +703,10 @@ class _Forward(_Emitter):
                 raise Unsupported("descriptor length mismatch")
             if k == self.nrounds - 1:
                 break
-            if trace and 4 + 2 * k < 30:
-                self.seg("trace").parts[0].append(f"  if (tid == 0) trc[{4 + 2 * k}] = wall_clock64();")
             self.exchange(k, [("a", "x"), ("a", "y")], 4)
-            if trace and 5 + 2 * k < 30:
-                self.seg("trace").parts[0].append(f"  if (tid == 0) trc[{5 + 2 * k}] = wall_clock64();")
         last = self.rounds[-1]
         sg = self.seg("sign + tile store")
         p = sg.parts[0]
-        if trace:
-            p.append("  if (tid == 0) trc[2] = wall_clock64();")
         for r in range(0, NR, 16):
             p.append("  vm2_negate16_if(" + ", ".join(self.A(r + i) for i in range(16)) + ", sgn);")
         self.tile_io(p, last, True, {"a": "state"}, self.tphys)
@@ -763,8 +720,7 @@ def forward_source(words, kname: str = "tcmi_spec_pass", opts=None) -> Tuple[str
     """HIP source of the straight-line kernel of one forward gate pass + its launch geometry."""
     e = _Forward(words, opts)
     src = e.source(kname)
-    return src, {"kind": "forward", "n": e.n, "T": e.T, "LT": e.LT, "lds": e.lds_bytes(), "persistent": e.persistent(),
-                 "src": bool(e.opts.get("src"))}
+    return src, {"kind": "forward", "n": e.n, "T": e.T, "LT": e.LT, "lds": e.lds_bytes(), "src": bool(e.opts.get("src"))}
 
 
 # ======================================================================================================
@@ -813,8 +769,16 @@ class SpecKernel:
 
 
 _EMITTERS = {}
-ALLOW_PROBE = False
-_WRONG_RESULT_KNOBS = ("noexch", "nomem", "noevents")
+# Emitter options a measuring script may override for EVERY kernel it has generated from here on (scripts/ set this dict
+# themselves; there is no environment switch): tuning choices that do not change results -- "waves", "prio", "xcd", "ntl",
+# "nts", "single_reads", "single8", "own_slots", "nosb".  Part of the generated text, hence of the cache key.
+EXTRA_OPTS: Dict[str, int] = {}
+try:        # TCMI_KNOBS="spec.xcd=0,spec.waves=3": the same from the environment (tcmi/_knobs.py)
+    from . import _knobs as _KN
+
+    EXTRA_OPTS.update({k[5:]: int(v) for k, v in _KN.VALUES.items() if k.startswith("spec.")})
+except ImportError:     # the generator also runs stand-alone (scripts)
+    pass
 
 
 _SHORT = {"forward": "fwd", "adjoint": "adj"}
@@ -825,16 +789,7 @@ def _source(kind: str, words, opts, index: int = 0) -> Tuple[str, dict]:
     ``tcmi_spec_fwd_p<k>_<digest8>`` / ``tcmi_spec_adj_p<k>_<digest8>`` -- so that a rocprofv3 kernel trace separates the
     passes of a plan (and the plans of one process) instead of one row for every generated kernel."""
     opts = dict(opts or {})
-    if os.environ.get("TCMI_SPEC_STAGGER"):
-        opts["stagger"] = int(os.environ["TCMI_SPEC_STAGGER"])
-    for kv in filter(None, os.environ.get("TCMI_SPEC_EXP", "").split(",")):     # experiment knobs: "pf=2,noexch,waves=5"
-        k, _, v = kv.partition("=")
-        opts[k] = int(v) if v else 1
-    if not ALLOW_PROBE and any(opts.get(k) for k in _WRONG_RESULT_KNOBS):
-        # kernels without their exchanges / memory traffic / gradient events exist to be TIMED; the environment alone must not
-        # be able to switch a product run to them -- the timing scripts set specialize.ALLOW_PROBE themselves
-        raise RuntimeError("TCMI_SPEC_EXP asks for a timing-only kernel (%s): set tcmi.specialize.ALLOW_PROBE = True in the "
-                           "measuring script" % ", ".join(k for k in _WRONG_RESULT_KNOBS if opts.get(k)))
+    opts.update(EXTRA_OPTS)
     generic = f"tcmi_spec_{kind}"
     src, meta = _EMITTERS[kind](words, generic, opts)
     name = f"tcmi_spec_{_SHORT.get(kind, kind)}_p{int(index)}_{pass_digest(src)[:8]}"
@@ -1052,11 +1007,8 @@ def load(path: str, meta: dict) -> SpecKernel:
             h = ctypes.c_void_p()
             _lib.check(_lib.lib().tcmi_spec_load(path.encode(), meta["kernel"].encode(), int(meta["lds"]), ctypes.byref(h)),
                        "tcmi_spec_load")
-            if meta.get("persistent"):
-                # a persistent kernel loops over its tiles: launch as many workgroups as the chip holds at once
-                cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-                wg_per_cu = max(1, min((1024 >> int(meta["LT"])), (160 * 1024) // max(1, int(meta["lds"]))))
-                _lib.check(_lib.lib().tcmi_spec_set_grid(h, int(cus * wg_per_cu)), "tcmi_spec_set_grid")
+            if meta.get("src"):        # the launchers check that a handle matches the argument buffer they build
+                _lib.check(_lib.lib().tcmi_spec_set_flags(h, 1), "tcmi_spec_set_flags")
             k = SpecKernel(h, meta, path)
             _LOADED[key] = k
         return k
@@ -1231,8 +1183,6 @@ class _Adjoint(_Forward):
     EVB = 8     # events reduced together (wave_fold8)
 
     def event(self, sg: Seg, expr: str, slot: int):
-        if self.opts.get("noevents"):    # timing experiment only (wrong results)
-            return
         v = self.fresh("gv")
         sg.parts[-1].append(f"  const float {v} = {expr};")
         self.pending.append((v, slot))
@@ -1577,8 +1527,7 @@ def adjoint_source(words, kname: str = "tcmi_spec_pass", opts=None) -> Tuple[str
     """HIP source of the straight-line kernel of one reverse-sweep pass + its launch geometry."""
     e = _Adjoint(words, opts)
     src = e.source(kname)
-    return src, {"kind": "adjoint", "n": e.n, "T": e.T, "LT": e.LT, "lds": e.lds_bytes(), "events": len(e.events),
-                 "persistent": e.persistent()}
+    return src, {"kind": "adjoint", "n": e.n, "T": e.T, "LT": e.LT, "lds": e.lds_bytes(), "events": len(e.events)}
 
 
 _EMITTERS["adjoint"] = adjoint_source

@@ -19,6 +19,7 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
+from ._knobs import knob
 from . import cons
 
 _edge_ids = itertools.count()
@@ -354,7 +355,7 @@ _NATIVE_GREEDY: List[Any] = []
 def _native_greedy(inputs, out_set, alpha, temperature, nbranch, uniforms):
     """``tcmi_greedy_path`` of libtcmi (host code) on a circuit network, or None (library not built / switched off with
     TCMI_TN_NATIVE_GREEDY=0): the Python loop then runs, with the same choices."""
-    if os.environ.get("TCMI_TN_NATIVE_GREEDY", "1") == "0":
+    if knob("tn_native_greedy", "1") == "0":
         return None
     if not _NATIVE_GREEDY:
         try:
@@ -459,7 +460,7 @@ _NATIVE_DP: List[Any] = []
 
 def _native_subtree_dp():
     """``tcmi_subtree_dp`` of libtcmi (host code), or None: the planner then runs its Python loop (same results)."""
-    if os.environ.get("TCMI_TN_NATIVE_DP", "1") == "0":
+    if knob("tn_native_dp", "1") == "0":
         return None
     if not _NATIVE_DP:
         try:
@@ -1547,7 +1548,7 @@ class ContractionTree:
                     warm_roots = shared
                     shared = dict(st_inv)
                     B = None
-                    if os.environ.get("TCMI_TN_BATCH", "1") != "0" and all(t.dtype == torch.complex64 for t in raw):
+                    if knob("tn_batch", "1") != "0" and all(t.dtype == torch.complex64 for t in raw):
                         B = SmallBatch(raw[0].device, 6 * len(steps) + 16)
                     g_a = None
                     big = gbig = None
@@ -1864,7 +1865,7 @@ class ContractionTree:
                 g_inv = None
                 big = mine_steps = None
                 B = None
-                if os.environ.get("TCMI_TN_BATCH", "1") != "0" and all(t.dtype == torch.complex64 and t.is_cuda for t in first):
+                if knob("tn_batch", "1") != "0" and all(t.dtype == torch.complex64 and t.is_cuda for t in first):
                     B = SmallBatch(first[0].device, 2 * len(steps) + 16)
                 if sworld > 1:
                     # invariant subtrees split over the ranks: this rank's graph computes its own subtrees and packs
@@ -2200,7 +2201,7 @@ class SmallBatch:
     def ok(a, b, nk: int) -> bool:
         import torch
 
-        if os.environ.get("TCMI_TN_BITS", "1") == "0":
+        if knob("tn_bits", "1") == "0":
             return False
         if a.dtype != torch.complex64 or b.dtype != torch.complex64 or not a.is_cuda or not b.is_cuda:
             return False
@@ -2270,7 +2271,7 @@ def _tensordot_fused(a, b, axes_a, axes_b, out_perm, flags):
     conjugate a / b) for the gate-sized steps the small-tensor kernel takes; None for every other shape."""
     import torch
 
-    if os.environ.get("TCMI_TN_FUSED_VJP", "1") == "0" or os.environ.get("TCMI_TN_BITS", "1") == "0":
+    if knob("tn_fused_vjp", "1") == "0" or knob("tn_bits", "1") == "0":
         return None
     nk = len(axes_a)
     if a.dtype != torch.complex64 or b.dtype != torch.complex64 or not a.is_cuda or not b.is_cuda:
@@ -2451,7 +2452,7 @@ def _tensordot_bits(a, b, axes_a, axes_b):
     not qualify (autograd tape / functorch, other dtypes or shapes): the permute + GEMM route handles it."""
     import torch
 
-    if os.environ.get("TCMI_TN_BITS", "1") == "0":
+    if knob("tn_bits", "1") == "0":
         return None
     if a.dtype != torch.complex64 or not a.is_cuda or not b.is_cuda:
         return None
@@ -2473,13 +2474,13 @@ def _tensordot_bits(a, b, axes_a, axes_b):
     return out
 
 
-TN_STREAMS = int(os.environ.get("TCMI_TN_STREAMS", "2"))   # two slices of a sliced contraction side by side (1: one stream)
+TN_STREAMS = int(knob("tn_streams", "2"))   # two slices of a sliced contraction side by side (1: one stream)
 SCATTERED_MIN_RANK = 16    # big operand: at least 2^16 elements
 SCATTERED_MAX_SMALL = 4096  # small operand: at most this many elements (it lives in LDS)
-SCATTERED_MAX_NK = int(os.environ.get("TCMI_TN_SCAT_MAXK", "8"))   # more contracted axes: the MFMA bits kernel
-FUSED_PERM_MAX_RANK = int(os.environ.get("TCMI_TN_FUSED_PERM_RANK", "0"))   # tile kernel: transposed stores up to this result rank (measured: no gain over the permute launch, 1.71-1.75 vs 1.70 ms per slice backward at 12-14; worse above)
-SCATTERED_MIN_FREE = int(os.environ.get("TCMI_TN_SCAT_MINFREE", "14"))   # at least 2^14 threads (free indices of the big operand)
-SCATTERED_MAX_OUT = int(os.environ.get("TCMI_TN_SCAT_MAXOUT", "32"))     # at most this many outputs per thread
+SCATTERED_MAX_NK = int(knob("tn_scat_maxk", "8"))   # more contracted axes: the MFMA bits kernel
+FUSED_PERM_MAX_RANK = int(knob("tn_fused_perm_rank", "0"))   # tile kernel: transposed stores up to this result rank (measured: no gain over the permute launch, 1.71-1.75 vs 1.70 ms per slice backward at 12-14; worse above)
+SCATTERED_MIN_FREE = int(knob("tn_scat_minfree", "14"))   # at least 2^14 threads (free indices of the big operand)
+SCATTERED_MAX_OUT = int(knob("tn_scat_maxout", "32"))     # at most this many outputs per thread
 
 
 def _scattered_ok(a, b, nk, fa, fb) -> bool:

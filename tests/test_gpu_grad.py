@@ -10,6 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from oracle import dense, gates as G, workloads as W  # noqa: E402
+from tcmi import _knobs as KN  # noqa: E402
 
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "hea_golden.npz"))
 
@@ -507,7 +508,7 @@ def test_gradient_with_respect_to_the_input_state(tcd):
 
 
 def test_two_shear_reverse_sweep_on_the_gpu(monkeypatch):
-    """TCMI_SHEAR2_BW=1: the reverse sweep with rotations in two-shear form (lambda sheared in the other order, second
+    """knob shear2_bw=1: the reverse sweep with rotations in two-shear form (lambda sheared in the other order, second
     phase table with the reciprocal factors) gives the gradient of the default three-shear sweep and of the float64
     kernels; angles on both sides of the builder's |cos| threshold."""
     import tcmi as tc
@@ -530,14 +531,14 @@ def test_two_shear_reverse_sweep_on_the_gpu(monkeypatch):
         return float(tc.backend.numpy(v)), tc.backend.numpy(g).astype(np.float64)
 
     try:
-        monkeypatch.setenv("TCMI_SHEAR2_BW", "1")
+        monkeypatch.setitem(KN.VALUES, "shear2_bw", "1")
         v2, g2 = grad("complex64", 0)
         from tcmi import executor as X
         cc = next(reversed(X._CACHE.values()))
         cc = getattr(cc, "full", cc)
         recs = np.asarray(cc._adjoint(full=False)["plan"].ginfo).reshape(-1, 8)
         assert ((recs[:, 0] == 3) & (recs[:, 6] != 0)).sum() >= 10     # BK_UDAG records allowed the two-shear form
-        monkeypatch.setenv("TCMI_SHEAR2_BW", "0")
+        monkeypatch.setitem(KN.VALUES, "shear2_bw", "0")
         v64, g64 = grad("complex128", 0)
     finally:
         tc.set_dtype("complex64")

@@ -10,6 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from oracle import dense, workloads as W  # noqa: E402
+from tcmi import _knobs as KN  # noqa: E402
 
 
 def _energy_fn(tc, n, d):
@@ -258,7 +259,8 @@ def test_graph_replay_and_two_stream_paths_under_stress():
         return c.amplitude_before("0" * (rows * cols))
 
     dc = DistributedContractor(nodes_fn, None, cotengra_options={"slicing_opts": {"target_size": 2 ** 27}, "max_repeats": 16})
-    old = {k: os.environ.get(k) for k in ("TCMI_TN_GRAPH", "TCMI_CUT_STREAMS")}
+    old = {k: os.environ.get(k) for k in ("TCMI_TN_GRAPH",)}
+    old_streams = KN.VALUES.get("cut_streams")
     try:
         os.environ["TCMI_TN_GRAPH"] = "0"
         ref = complex(dc.value(None, op=lambda x: x))
@@ -280,15 +282,18 @@ def test_graph_replay_and_two_stream_paths_under_stress():
         for B in (8, 1, 3):
             for i in range(10):
                 p = (torch.rand(B, 2 * d, n, generator=g) * 6.28).cuda()
-                os.environ["TCMI_CUT_STREAMS"] = "1"
+                KN.VALUES["cut_streams"] = "1"
                 a = fv(p)
                 junk = torch.randn(1 << 22, device="cuda")          # allocator churn between the calls
-                os.environ["TCMI_CUT_STREAMS"] = "0"
+                KN.VALUES["cut_streams"] = "0"
                 b = fv(p)
                 del junk
                 assert torch.equal(a, b), (B, i, float((a - b).abs().max()))
     finally:
         TN.COUNTERS = None
+        KN.VALUES.pop("cut_streams", None)
+        if old_streams is not None:
+            KN.VALUES["cut_streams"] = old_streams
         for k, v in old.items():
             if v is None:
                 os.environ.pop(k, None)

@@ -10,6 +10,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from oracle import dense, gates as G, workloads as W  # noqa: E402
+from tcmi import _knobs as KN  # noqa: E402
+from tcmi import specialize as S  # noqa: E402
 
 
 @pytest.fixture
@@ -268,7 +270,7 @@ def test_live_tile_kernels_against_the_dense_oracle_directly(tc64):
 
 def test_generated_kernel_options_do_not_change_results(tc64):
     """Round-5 code-generation choices -- XCD-aware tile order, raised load priority, single 8-byte LDS accesses -- only move
-    work in time and space: with each of them off (TCMI_SPEC_EXP) the state is bit-identical and the gradient agrees to
+    work in time and space: with each of them off (specialize.EXTRA_OPTS) the state is bit-identical and the gradient agrees to
     summation order."""
     tc = tc64
     from tcmi import executor as X
@@ -288,11 +290,11 @@ def test_generated_kernel_options_do_not_change_results(tc64):
 
     os.environ["TCMI_SPECIALIZE"] = "1"
     tc.set_contractor("plain")
-    old = os.environ.get("TCMI_SPEC_EXP")
     res = {}
     try:
         for exp in ("", "xcd=0,prio=0,single8=0", "xcd=1"):
-            os.environ["TCMI_SPEC_EXP"] = exp
+            S.EXTRA_OPTS.clear()
+            S.EXTRA_OPTS.update({kv.split("=")[0]: int(kv.split("=")[1]) for kv in exp.split(",") if kv})
             X._CACHE.clear()
             pt = tc.backend.convert_to_tensor(params, dtype=tc.rdtypestr)
             c = tc.Circuit(n)
@@ -301,10 +303,7 @@ def test_generated_kernel_options_do_not_change_results(tc64):
             v, g = tc.backend.value_and_grad(energy)(pt)
             res[exp] = (psi, float(v), tc.backend.numpy(g))
     finally:
-        if old is None:
-            os.environ.pop("TCMI_SPEC_EXP", None)
-        else:
-            os.environ["TCMI_SPEC_EXP"] = old
+        S.EXTRA_OPTS.clear()
         tc.set_contractor("greedy")
         X._CACHE.clear()
     for exp in ("xcd=0,prio=0,single8=0", "xcd=1"):
@@ -445,7 +444,7 @@ def test_partial_fold_with_y_fields_and_strings_that_stay_in_the_tile_passes(tc6
 def test_cut_suffix_reads_its_inputs_from_the_prefix_batch(tc64):
     """tcmi_spec_run_pass_from: the first pass of a cut half-circuit's suffix reads state b as weight[b] * prefix[b >> shift]
     instead of a replicated, weighted copy written by an elementwise launch.  Same state with the fused load on / off
-    (TCMI_CUT_FUSED_REP), batched over two parameter rows, and against the dense oracle."""
+    (knob cut_fused_rep), batched over two parameter rows, and against the dense oracle."""
     tc = tc64
     import torch
     from tcmi import executor as X
@@ -453,12 +452,12 @@ def test_cut_suffix_reads_its_inputs_from_the_prefix_batch(tc64):
     n, d, B = 24, 3, 2          # halves of 12 qubits: the smallest tile the packed kernels (and their generated forms) run on
     params = np.random.default_rng(16).uniform(0, 2 * np.pi, [B, 2 * d, n])
     os.environ["TCMI_SPECIALIZE"] = "1"
-    old = os.environ.get("TCMI_CUT_FUSED_REP")
+    old = KN.VALUES.get("cut_fused_rep")
     tc.set_contractor("cut")
     res = {}
     try:
         for flag in ("1", "0"):
-            os.environ["TCMI_CUT_FUSED_REP"] = flag
+            KN.VALUES["cut_fused_rep"] = flag
             X._CACHE.clear()
 
             def wf(p):
@@ -477,10 +476,9 @@ def test_cut_suffix_reads_its_inputs_from_the_prefix_batch(tc64):
                 assert cc.left.suffix._specialised_src() is not None and cc.right.suffix._specialised_src() is not None
             res[flag] = st.cpu().numpy()
     finally:
-        if old is None:
-            os.environ.pop("TCMI_CUT_FUSED_REP", None)
-        else:
-            os.environ["TCMI_CUT_FUSED_REP"] = old
+        KN.VALUES.pop("cut_fused_rep", None)
+        if old is not None:
+            KN.VALUES["cut_fused_rep"] = old
         tc.set_contractor("greedy")
         X._CACHE.clear()
     assert np.abs(res["1"] - res["0"]).max() < 1e-7

@@ -10,6 +10,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 from oracle import dense, gates as G, workloads as W  # noqa: E402
+from tcmi import _knobs as KN  # noqa: E402
 
 
 @pytest.fixture(params=["complex64", "complex128"])
@@ -273,8 +274,11 @@ def test_cut_weights_kernel_matches_the_elementwise_formulation(dt, monkeypatch)
         g = torch.Generator().manual_seed(1)
         p = (torch.rand(5, max(1, cc.nparams), generator=g, dtype=torch.float64) * 6.0).to(cc.rdtype).cuda()
         w_kernel = cc._weights(p)
-        monkeypatch.setenv("TCMI_CUT_WEIGHTS_TORCH", "1")
-        w_torch = cc._weights(p)
+        # the same weights as elementwise torch operations on the tables the kernel's were packed from
+        tabs = cc._wtabs
+        a = p[:, tabs["pidx"]].to(torch.float64).reshape(5, tabs["nb"], tabs["rmax"]) * tabs["scale"] + tabs["offs"]
+        v = tabs["const"] + tabs["cmask"] * torch.cos(a) + tabs["smask"] * torch.sin(a)      # [B, nb, rmax] complex128
+        w_torch = torch.gather(v, 2, tabs["dig"].expand(5, tabs["nb"], -1)).prod(dim=1).to(cc.tdtype)
         assert w_kernel.shape == (5, cc.K) and w_kernel.dtype == w_torch.dtype
         np.testing.assert_allclose(w_kernel.cpu().numpy(), w_torch.cpu().numpy(), atol=3e-7 if dt == "complex64" else 1e-14)
         assert float(w_kernel.abs().max()) > 1e-3
@@ -285,7 +289,7 @@ def test_cut_weights_kernel_matches_the_elementwise_formulation(dt, monkeypatch)
 
 def test_cut_contraction_two_streams_equal_one_stream(monkeypatch):
     """The right half-circuit batch runs on a second HIP stream and joins before the GEMM: bit-identical to the
-    one-stream order (``TCMI_CUT_STREAMS=0``) for several batches in a row, with allocator churn between the calls."""
+    one-stream order (knob ``cut_streams=0``) for several batches in a row, with allocator churn between the calls."""
     import torch
     import tcmi as tc
     from tcmi.executor import CutCircuit
@@ -305,10 +309,10 @@ def test_cut_contraction_two_streams_equal_one_stream(monkeypatch):
         for B in (4, 1):
             for _ in range(6):
                 p = (torch.rand(B, 2 * d, n, generator=g) * 6.28).cuda()
-                monkeypatch.setenv("TCMI_CUT_STREAMS", "1")
+                monkeypatch.setitem(KN.VALUES, "cut_streams", "1")
                 a = fv(p)
                 junk = torch.randn(1 << 20, device="cuda")
-                monkeypatch.setenv("TCMI_CUT_STREAMS", "0")
+                monkeypatch.setitem(KN.VALUES, "cut_streams", "0")
                 b = fv(p)
                 del junk
                 assert torch.equal(a, b)
@@ -471,16 +475,16 @@ def test_fused_reverse_mode_steps_match_torch_autograd(monkeypatch):
         cot = torch.randn([2] * (ra + rb - 2 * nk), dtype=torch.complex64, device="cuda", generator=g_)
         a64, b64 = a.to(torch.complex128).requires_grad_(True), b.to(torch.complex128).requires_grad_(True)
         ra_, rb_ = torch.autograd.grad(torch.tensordot(a64, b64, dims=(xa, xb)), (a64, b64), cot.to(torch.complex128))
-        monkeypatch.setenv("TCMI_TN_FUSED_VJP", "1")
+        monkeypatch.setitem(KN.VALUES, "tn_fused_vjp", "1")
         ga, gb = tn.tensordot_vjp(a, b, xa, xb, cot)
-        monkeypatch.setenv("TCMI_TN_FUSED_VJP", "0")
+        monkeypatch.setitem(KN.VALUES, "tn_fused_vjp", "0")
         ga0, gb0 = tn.tensordot_vjp(a, b, xa, xb, cot)
         for got, plain, ref in ((ga, ga0, ra_), (gb, gb0, rb_)):
             scale = max(float(ref.abs().max()), 1e-30)
             assert tuple(got.shape) == tuple(ref.shape)
             assert float((got.to(torch.complex128) - ref).abs().max()) / scale < 3e-5, (ra, rb, nk)
             assert float((got - plain).abs().max()) / scale < 3e-5
-    monkeypatch.setenv("TCMI_TN_FUSED_VJP", "1")
+    monkeypatch.setitem(KN.VALUES, "tn_fused_vjp", "1")
     # the tile kernels store through the permutation too (no conjugation there): plain tiles, split-K with atomics,
     # the register-accumulator kernel for <= 8 x 8 results, rows / columns narrower than a tile
     for ra, rb, nk in [(14, 6, 3), (16, 16, 12), (13, 13, 11), (15, 5, 2), (10, 15, 4), (17, 14, 13)]:

@@ -7,6 +7,7 @@ import pytest
 
 import tcmi as tc
 from tcmi import tn
+from tcmi import _knobs as KN
 from oracle import dense, gates as G, workloads as W
 
 
@@ -198,9 +199,9 @@ def test_native_subtree_programme_gives_the_python_loops_paths(nt, seed, monkeyp
     m0, _ = tn._path_stats(inputs, output, sd, p0)
     for dims, kw in ((sd, dict(subtree_size=8)), (sd, dict(subtree_size=10, max_size=m0)),
                      (sd, dict(subtree_size=6, alpha=32.0)), (sd3, dict(subtree_size=8, alpha=16.0))):
-        monkeypatch.setenv("TCMI_TN_NATIVE_DP", "1")
+        monkeypatch.setitem(KN.VALUES, "tn_native_dp", "1")
         fast = tn.reconfigure_path(inputs, output, dims, p0, **kw)
-        monkeypatch.setenv("TCMI_TN_NATIVE_DP", "0")
+        monkeypatch.setitem(KN.VALUES, "tn_native_dp", "0")
         slow = tn.reconfigure_path(inputs, output, dims, p0, **kw)
         assert fast == slow
 
@@ -442,9 +443,9 @@ def test_native_greedy_path_equals_the_python_loop(monkeypatch):
             inputs += [[base, base + 1], [base + 1, base + 2], [base + 2, base]]
             sd.update({base + k: 2 for k in range(3)})
         for temp, alpha in ((0.0, 1.0), (0.2, 1.0), (0.01, 0.5), (1.0, 1.5)):
-            monkeypatch.setenv("TCMI_TN_NATIVE_GREEDY", "1")
+            monkeypatch.setitem(KN.VALUES, "tn_native_greedy", "1")
             a = tn.greedy_path(inputs, output, sd, temperature=temp, alpha=alpha, rng=np.random.default_rng(case))
-            monkeypatch.setenv("TCMI_TN_NATIVE_GREEDY", "0")
+            monkeypatch.setitem(KN.VALUES, "tn_native_greedy", "0")
             b = tn.greedy_path(inputs, output, sd, temperature=temp, alpha=alpha, rng=np.random.default_rng(case))
             assert a == b, (case, temp, alpha)
             assert len(a) == len(inputs) - 1
