@@ -1150,6 +1150,8 @@ def _guard(name, fn, *a, dist=None, need_bytes=0):
                                f"{free_min / 2**30:.1f} GiB free on the fullest device ({sharers} rank(s) per device)"}
     try:
         _trace(f"leg {name}: start")
+        if os.environ.get("TCMI_BENCH_RAISE_IN") == f"{name}:{os.environ.get('RANK', '0')}":     # tests: a rank failing mid-leg
+            raise MemoryError("injected failure (TCMI_BENCH_RAISE_IN)")
         out = fn(*a)
         _trace(f"leg {name}: done")
         return out
@@ -1191,7 +1193,8 @@ def self_launch(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         if share:
-            env.update(LOCAL_RANK=str(r % have), TCMI_BENCH_BACKEND="gloo", TCMI_BENCH_SHARERS=str(-(-n // have)))
+            env.update(LOCAL_RANK=str(r % have), TCMI_BENCH_BACKEND="gloo",
+                       TCMI_BENCH_SHARERS=os.environ.get("TCMI_BENCH_SHARERS") or str(-(-n // have)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
@@ -1446,9 +1449,10 @@ def main():
     sv28 = None
     if args.sv_qubits:
         lo_, hi_ = D_.shard_range(args.sv_batch, rank, world)
-        # the batched output state + one working copy per micro-batch, the last step's output alive next to the new one
-        sv28 = _guard("statevector_n28", statevector_leg, tc, torch, dist, args, rank, world, dev, dist=dist,
-                      need_bytes=int(3.5 * max(1, min(args.sv_microbatch, hi_ - lo_)) * (2 ** args.sv_qubits) * 8))
+        # per micro-batch: the output, the previous step's output still alive, the plain path's result on the validating
+        # call and one working copy (measured: 34 GiB allocated at 4 states of 2 GiB)
+        sv28 = _guard("statevector_n%d" % args.sv_qubits, statevector_leg, tc, torch, dist, args, rank, world, dev, dist=dist,
+                      need_bytes=int(4.5 * max(1, min(args.sv_microbatch, hi_ - lo_)) * (2 ** args.sv_qubits) * 8))
         torch.cuda.empty_cache()
     vqe = None
     if args.vqe_qubits:

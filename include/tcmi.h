@@ -98,16 +98,6 @@ int tcmi_cut_weights(const void* params, long long params_stride, int batch, con
 int tcmi_cut_epilogue(const void* params, long long params_stride, int batch, const int* tab_i, const double* tab_f,
                       int nfac, void* x, int dtype, void* stream);
 
-/* Tables of the tail program of a cut contraction with TWO deferred crossing gates (tcmi/cut.py, `TailProgram`): op `o` of
- * the program is a one-qubit gate (2 x 2, entries 0..3 row-major) or a diagonal over the 16 values of the index bits
- * (u, r1, v, l4) -- T[b][o][e] = prod over the op's factors f of (c0_f[e] + cos(a_f) c1_f[e] + sin(a_f) c2_f[e]).
- * `ops_i` = int32[nops][2] {first factor, number of factors}; `tab_i` / `tab_f` factor records as for tcmi_cut_epilogue
- * (16 complex entries each); `t` = complex64 [batch][nops][16], the operand of tcmi_cgemm_split_prog; nops <= 12.
- * Replaces: the gate matrices of those gates inside the contraction Circuit.wavefunction executes
- * (tensorcircuit/circuit.py:701-721, gate factories tensorcircuit/gates.py:692-743). */
-int tcmi_cut_epilogue_program(const void* params, long long params_stride, int batch, const int* ops_i, int nops,
-                              const int* tab_i, const double* tab_f, void* t, int dtype, void* stream);
-
 /* One pass of a compiled plan over the (batched) state, in place: every workgroup loads a tile of
  * 2^(R+LT) amplitudes, applies the pass program `desc` (int32 words, layout in
  * tensorcircuit-ng_amd/csrc/tcmi_vm.h) and stores the tile back.  `ctab` = shared constant table,
@@ -256,18 +246,6 @@ int tcmi_cgemm_split(const void* A, const void* B, void* C, long long M, long lo
  * bond dimension for ZZ / CNOT / CZ crossings (reference circuit.py:701-721 -> cons.py:948). */
 int tcmi_cgemm_split_epi(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch,
                          long long strideA, long long strideB, long long strideC, const void* X, void* stream);
-
-/* tcmi_cgemm_split with a gate PROGRAM run on the product before it is stored (the tail of two deferred crossing gates,
- * tcmi/cut.py `find_tail`): ops on four index bits of P[b] = A[b]^T B[b] -- row bits 0, 1 (u, r1) and P's column bits
- * 0, 1 (v, l4) -- each a one-qubit gate on one of them or a diagonal over all four.  `prog` (device, int32) = {nops,
- * op index of diagonal slot 0 or -1, of slot 1 or -1, then per op: kind (0 one-qubit, 1 diagonal) | bit << 4 (0 u, 1 r1,
- * 2 v, 3 l4) | slot << 8}; at most two diagonal ops and twelve ops; `T` = complex64 [batch][nops][16]
- * (tcmi_cut_epilogue_program).  P's column index is C's rotated left by TWO bits: column c of P is stored at
- * (c >> 2) | ((c & 3) * N / 4).  Same argument rules as tcmi_cgemm_split.  A quarter of the bond dimension for ZZ-type
- * crossings (reference circuit.py:701-721 -> cons.py:948). */
-int tcmi_cgemm_split_prog(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch,
-                          long long strideA, long long strideB, long long strideC, const int* prog, const void* T,
-                          void* stream);
 
 /* <a|b> = sum conj(a_i) b_i per batch element (states [batch][2^n], stride elements apart), accumulated in
  * float64 into `copies` replicated {re, im} pairs: out[b * out_batch_stride + 2 * copy + {0,1}] += ...; the

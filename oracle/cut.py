@@ -6,11 +6,9 @@ tests to validate ``tcmi.cut.make_cut`` against ``oracle.dense``; nothing in the
 import numpy as np
 
 
-def reference_state(spec, params: np.ndarray, program: bool = False) -> np.ndarray:
-    """Dense numpy evaluation of the cut formula (used by the CPU tests to validate make_cut).  ``program``: the tail of a
-    cut with two deferred crossing gates is applied the way the join kernel does it -- its ops (``TailProgram.tables``)
-    on the index bits (u, r1 | v, l4) of the product, whose column index is still rotated -- instead of as ordinary gates
-    on the joined state (tcmi_cgemm_split_prog's contract, csrc/tcmi_gemm_split.hip)."""
+def reference_state(spec, params: np.ndarray) -> np.ndarray:
+    """Dense numpy evaluation of the cut formula (used by the CPU tests to validate make_cut); the gates of a deferred tail
+    are applied as ordinary gates on the joined state."""
     nl, nr = spec.n_left, spec.n - spec.n_left
     K = spec.bond_dim
     radices = [len(b.terms) for b in spec.bonds]
@@ -46,38 +44,11 @@ def reference_state(spec, params: np.ndarray, program: bool = False) -> np.ndarr
         pvec = np.concatenate([np.asarray(params, dtype=np.float64), np.array(digits, dtype=np.float64)])
         psi += w * np.outer(run(spec.left, nl, pvec), run(spec.right, nr, pvec))
     rot = int(getattr(spec, "right_rot", 0))
-    if program:
-        prog = spec.epilogue.program
-        tabs = prog.tables(np.asarray(params, dtype=np.float64))
-        M, N = psi.shape
-        # product element (m, c'): u = m & 1, r1 = (m >> 1) & 1, v = c' & 1, l4 = (c' >> 1) & 1
-        t = psi.reshape(M // 4, 2, 2, N // 4, 2, 2)           # [m_hi, r1, u, c_hi, l4, v]
-        axis = {0: 2, 1: 1, 2: 5, 3: 4}                        # bit id -> axis
-        for k, (kind, bit, _) in enumerate(prog.ops):
-            if kind == "diag":
-                d = tabs[k].reshape(2, 2, 2, 2)                # index u + 2 r1 + 4 v + 8 l4 -> [l4, v, r1, u]
-                t = t * d.transpose(2, 3, 0, 1)[None, :, :, None, :, :]       # -> [r1, u, l4, v]
-            else:
-                m2 = tabs[k][:4].reshape(2, 2)
-                t = np.moveaxis(np.tensordot(m2, t, axes=([1], [axis[bit]])), 0, axis[bit])
-        psi = t.reshape(M, N)
-        # column c' of the product is column (c' >> rot) | (block * N / 2^rot) of the state, block = v + 2 l4 or -- when v is
-        # the first right-hand qubit (program.vhigh) -- 2 v + l4
-        cp = np.arange(N)
-        low = cp & ((1 << rot) - 1)
-        if getattr(prog, "vhigh", 0):
-            low = 2 * (low & 1) + (low >> 1)
-        nat = (cp >> rot) | (low * (N >> rot))
-        out = np.empty_like(psi)
-        out[:, nat] = psi
-        return out.reshape(-1)
     if rot:
         # the right half's qubits are labelled rotated by `rot` (global qubits n_left .. n_left + rot - 1 are its LAST local
         # qubits): back to the natural column order, then the deferred gates as ordinary gates on the joined state
         t = psi.reshape([2**nl] + [2] * nr)
         src = list(range(nr - rot + 1, nr + 1))
-        if getattr(getattr(spec.epilogue, "program", None), "vhigh", 0):
-            src = src[::-1]          # (the two rotated qubits also changed places)
         psi = np.moveaxis(t, src, list(range(1, rot + 1))).reshape(2**nl, 2**nr)
     if getattr(spec, "epilogue", None) is not None:
         st = psi.reshape(-1)

@@ -46,25 +46,9 @@
 // labelled last): column c of the product is stored at (c >> 1) | ((c & 1) * N / 2), as 8-byte stores that are 256
 // bytes contiguous per row over 32 lanes.
 //
-// EPI = 2 (tcmi_cgemm_split_prog): the tail of TWO deferred crossing gates, a small gate program over four index bits of
-// the product -- row bits 0, 1 (u: which MFMA tile; r1: accumulator element parity) and column bits 0, 1 (v: which MFMA
-// tile; l4: LANE bit 4) -- run on the eight results (u, r1, v) a thread holds per accumulator-element pair: one-qubit
-// gates on u / r1 / v mix values inside the thread (4 x 2 v_pk_fma_f32 per value pair, matrix in SGPRs), on l4 with the
-// partner lane's values (ds_swizzle xor 16), diagonals multiply by a per-lane phase table kept in registers (two
-// diagonal ops at most).  For column bit 1 to be a lane bit the B loader reads column pairs in the order
-// sigma(j) = 2 (j & 15) + (j >> 4), so MFMA column j of a wave is product column 2 sigma(j) + v; product column c is
-// stored at (c >> 2) | ((c & 3) * N / 4): 16 lanes write 128 contiguous bytes.  prog = {nops, op of diagonal slot 0, of
-// slot 1, then per op: kind (0 one-qubit, 1 diagonal) | bit << 4 | slot << 8}; T = complex64 [batch][nops][16] (2 x 2
-// row-major in the first four entries / the 16 phases indexed u + 2 r1 + 4 v + 8 l4), from tcmi_cut_epilogue_program.
-// The program runs with the ops outside and the thread's 64 results inside (an op's word and coefficients are fetched
-// once per tile, one op ahead); one-qubit ops come in three forms chosen by the host from the gate's matrices: any 2 x 2
-// (8 v_pk_fma_f32 per value pair), real matrix (4), real diagonal with imaginary off-diagonal = rx (4 + two sign flips).
-// Measured on config 2 (K = 64 instead of 128; HEA-B's tail: diagonal, rx, rx, diagonal, rx x 4, one of them on l4):
-// 21.6 us per tile against 20.2 with ONE deferred gate (1.73e11 against 1.81e11 amplitudes/s) -- the K loop is down to
-// 4 steps (12.4 us per tile with the 4 x 4 epilogue at this K) but the program's ~3500 vector instructions per tile (of
-// them ~500 moves between VGPRs and the AGPRs the compiler parks part of the 64 results in) cost what the four steps
-// saved.  A first version with the ops inside (scalar loads of every op per group of eight results) took 28.8 us.  Kept as
-// an option (TCMI_CUT_DEFER=2), off by default.
+// (EPI = 2, round 5: the tail of TWO deferred crossing gates as a gate program over four index bits of the product, K = 64
+// on config 2 -- 21.6 us per tile against 20.2 with one deferred gate: the program's ~3500 vector instructions per tile cost
+// what the four k-steps saved.  Measured, lost, removed in round 6; DESIGN.md section 2b keeps the numbers.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -100,7 +84,7 @@ template <int MODE, int EPI>
 __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __restrict__ A, const float2* __restrict__ B,
                                                               float2* __restrict__ C, int M, int N, int K, long long sA,
                                                               long long sB, long long sC, int tiles_x, int tiles_y, int batch,
-                                                              const float2* __restrict__ X, const int* __restrict__ prog) {
+                                                              const float2* __restrict__ X) {
   extern __shared__ __attribute__((aligned(16))) char dsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
@@ -138,8 +122,7 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
   // loader role of the wave: operand (waves 0, 1: A; 2, 3: B) and k half; lane = row pair
   const int lop = wave >> 1, lkg = wave & 1;
   const long long R = lop ? N : M;
-  // (EPI 2: the B loader takes column pairs in the order sigma, see the header)
-  const int lsig = (EPI == 2 && lop) ? ((lane & 32) | ((lane & 15) << 1) | ((lane >> 4) & 1)) : lane;
+  const int lsig = lane;
   const long long lofs = 2 * lsig + (long long)(lkg * 8) * R;
   const float2* src = (lop ? B + (long long)bi * sB + n0 : A + (long long)bi * sA + m0) + lofs;       // this tile
   const float2* src1 = (lop ? B + (long long)bi1 * sB + n1 : A + (long long)bi1 * sA + m1) + lofs;   // the next one
@@ -290,146 +273,7 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
     // the last step cut block 0 of the next tile into stage 0 and blocks 0, 1 of it are (being) loaded: only the
     // results stand between the tiles.  MFMA result element (i = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), j = lane & 31)
     // of tile (u, v) is C[wr 64 + 2 i + u][wc 64 + 2 j + v]
-    if (EPI == 2) {
-      // ops outside, the 64 results of the thread inside: an op's word and coefficients are fetched once per tile, one op
-      // ahead of their use; the two diagonal tables are requested before the accumulators are read
-      float2* Cb = C + (long long)bi * sC;
-      const int hdr = prog[0];
-      const int nops = hdr & 255, vhigh = (hdr >> 8) & 1;
-      const float2* Tb = X + (long long)__builtin_amdgcn_readfirstlane(bi) * nops * 16;
-      const int l4 = (lane >> 4) & 1;
-      f32x2_ val[8][8];     // [accumulator element pair q][u + 2 r1 + 4 v]
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int r1 = 0; r1 < 2; ++r1)
-#pragma unroll
-            for (int v = 0; v < 2; ++v) {
-              const int reg = 2 * q + r1;
-              const float re = acc[u][v][0][reg] - acc[u][v][1][reg];
-              const float im = acc[u][v][2][reg] - acc[u][v][0][reg] - acc[u][v][1][reg];
-              val[q][u + 2 * r1 + 4 * v] = f32x2_{re, im};
-              if (MODE == 2) {
-                acc[u][v][0][reg] = 0.f;
-                acc[u][v][1][reg] = 0.f;
-                acc[u][v][2][reg] = 0.f;
-              }
-            }
-      int w = prog[3];
-      f32x4_ ca = *reinterpret_cast<const f32x4_*>(Tb), cb = *reinterpret_cast<const f32x4_*>(Tb + 2);
-      for (int o = 0; o < nops; ++o) {
-        const int on = o + 1 < nops ? o + 1 : o;
-        const int wn = prog[3 + on];
-        const f32x4_ na = *reinterpret_cast<const f32x4_*>(Tb + on * 16), nb = *reinterpret_cast<const f32x4_*>(Tb + on * 16 + 2);
-        const int kind = w & 15, bit = (w >> 4) & 15, slot = (w >> 8) & 1;
-        // m00 = (ca.x, ca.y), m01 = (ca.z, ca.w), m10 = (cb.x, cb.y), m11 = (cb.z, cb.w)
-        if (kind == 1) {
-          // this lane's half of the diagonal's table: the phases of index u + 2 r1 + 4 v at its l4
-          const f32x4_* tp = reinterpret_cast<const f32x4_*>(Tb + o * 16 + 8 * l4);
-          f32x4_ pq[4];
-#pragma unroll
-          for (int h = 0; h < 4; ++h) pq[h] = tp[h];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const f32x2_ ph = (e & 1) ? f32x2_{pq[e >> 1].z, pq[e >> 1].w} : f32x2_{pq[e >> 1].x, pq[e >> 1].y};
-            const f32x2_ ps = {-ph.y, ph.x};
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-              const f32x2_ x_ = val[q][e];
-              const f32x2_ xr_ = {x_.x, x_.x}, xi_ = {x_.y, x_.y};
-              val[q][e] = __builtin_elementwise_fma(xi_, ps, xr_ * ph);
-            }
-          }
-          (void)slot;
-        } else if (bit == 3) {
-          // the partner value sits in lane ^ 16: new = a mine + b partner, (a, b) = (m00, m01) for l4 = 0, (m11, m10) else
-          const float ar = l4 ? cb.z : ca.x, ai = l4 ? cb.w : ca.y, br = l4 ? cb.x : ca.z, bi_ = l4 ? cb.y : ca.w;
-          const f32x2_ arr = {ar, ar}, aii = {ai, ai}, brr = {br, br}, bii = {bi_, bi_};
-          if (kind == 3) {          // real diagonal, imaginary off-diagonal (rx): a mine + i b partner
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                f32x2_ ps;
-                ps.y = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(val[q][e].x), 0x401F));
-                ps.x = -__int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(val[q][e].y), 0x401F));
-                val[q][e] = __builtin_elementwise_fma(bii, ps, arr * val[q][e]);
-              }
-          } else if (kind == 2) {   // real matrix
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                f32x2_ pt;
-                pt.x = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(val[q][e].x), 0x401F));
-                pt.y = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(val[q][e].y), 0x401F));
-                val[q][e] = __builtin_elementwise_fma(brr, pt, arr * val[q][e]);
-              }
-          } else {
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                f32x2_ pt;
-                pt.x = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(val[q][e].x), 0x401F));
-                pt.y = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(val[q][e].y), 0x401F));
-                const f32x2_ ms = {-val[q][e].y, val[q][e].x}, ps = {-pt.y, pt.x};
-                f32x2_ y = arr * val[q][e];
-                y = __builtin_elementwise_fma(aii, ms, y);
-                y = __builtin_elementwise_fma(brr, pt, y);
-                val[q][e] = __builtin_elementwise_fma(bii, ps, y);
-              }
-          }
-        } else {
-          const f32x2_ a00r = {ca.x, ca.x}, a00i = {ca.y, ca.y}, a01r = {ca.z, ca.z}, a01i = {ca.w, ca.w};
-          const f32x2_ a10r = {cb.x, cb.x}, a10i = {cb.y, cb.y}, a11r = {cb.z, cb.z}, a11i = {cb.w, cb.w};
-          // KIND 0: any 2 x 2; 2: real entries; 3: real diagonal, imaginary off-diagonal
-#define TCMI_S2_G1(ST, KIND)                                                                                     \
-  _Pragma("unroll") for (int q = 0; q < 8; ++q) _Pragma("unroll") for (int e = 0; e < 8; ++e) if (!(e & (ST))) {   \
-    const f32x2_ x0 = val[q][e], x1 = val[q][e | (ST)];                                                           \
-    if (KIND == 2) {                                                                                              \
-      val[q][e] = __builtin_elementwise_fma(a01r, x1, a00r * x0);                                                 \
-      val[q][e | (ST)] = __builtin_elementwise_fma(a11r, x1, a10r * x0);                                          \
-    } else if (KIND == 3) {                                                                                       \
-      const f32x2_ s0 = {-x0.y, x0.x}, s1 = {-x1.y, x1.x};                                                        \
-      val[q][e] = __builtin_elementwise_fma(a01i, s1, a00r * x0);                                                 \
-      val[q][e | (ST)] = __builtin_elementwise_fma(a10i, s0, a11r * x1);                                          \
-    } else {                                                                                                      \
-      const f32x2_ s0 = {-x0.y, x0.x}, s1 = {-x1.y, x1.x};                                                        \
-      f32x2_ y0 = a00r * x0, y1 = a10r * x0;                                                                      \
-      y0 = __builtin_elementwise_fma(a00i, s0, y0); y1 = __builtin_elementwise_fma(a10i, s0, y1);                 \
-      y0 = __builtin_elementwise_fma(a01r, x1, y0); y1 = __builtin_elementwise_fma(a11r, x1, y1);                 \
-      val[q][e] = __builtin_elementwise_fma(a01i, s1, y0); val[q][e | (ST)] = __builtin_elementwise_fma(a11i, s1, y1); \
-    }                                                                                                             \
-  }
-#define TCMI_S2_G1K(ST)                                                                       \
-  if (kind == 2) { TCMI_S2_G1(ST, 2) } else if (kind == 3) { TCMI_S2_G1(ST, 3) } else { TCMI_S2_G1(ST, 0) }
-          if (bit == 0) { TCMI_S2_G1K(1) } else if (bit == 1) { TCMI_S2_G1K(2) } else { TCMI_S2_G1K(4) }
-#undef TCMI_S2_G1K
-#undef TCMI_S2_G1
-        }
-        w = wn;
-        ca = na;
-        cb = nb;
-      }
-      const long long colq = ((n0 + wc * 64) >> 2) + (lane & 15);
-      const long long quarter = (long long)N >> 2;
-#pragma unroll
-      for (int q = 0; q < 8; ++q)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int u = e & 1, r1 = (e >> 1) & 1, v = e >> 2;
-          const long long row = m0 + wr * 64 + 2 * (r1 + 2 * (q & 1) + 8 * (q >> 1) + 4 * (lane >> 5)) + u;
-          // the two column bits of the program sit at the top of the natural column index: v above l4 (vhigh) or below
-          const int blk = vhigh ? 2 * v + l4 : v + 2 * l4;
-          float2 w2;
-          w2.x = val[q][e].x;
-          w2.y = val[q][e].y;
-          Cb[row * N + colq + blk * quarter] = w2;
-        }
-    } else if (EPI) {
+    if (EPI) {
       // y[2 u' + v'] = sum_{u, v} X[b][2 u' + v'][2 u + v] c[u][v]; column 2 j + v of the product is column j + v N / 2 of C
       float2* Cb = C + (long long)bi * sC;
       const float2* Xb = X + (long long)__builtin_amdgcn_readfirstlane(bi) * 16;
@@ -547,7 +391,7 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
 namespace {
 
 int split_launch(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch, long long strideA,
-                 long long strideB, long long strideC, const void* X, const int* prog, void* stream, const char* who) {
+                 long long strideB, long long strideC, const void* X, void* stream, const char* who) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #ifdef TCMI_SPLIT_PROBE
   // probe builds of the kernel (libtcmi_probe.so only, scripts/gpu_gemm_split_modes.py): 1 no conversion, 2 no MFMA,
@@ -585,11 +429,9 @@ int split_launch(const void* A, const void* B, void* C, long long M, long long N
     hipLaunchKernelGGL((tcmi::cgemm_split_kernel<MODE, EPI>), dim3((unsigned)(nwork < ncu ? nwork : ncu), 1, 1),       \
                        dim3(256), 2 * tcmi::SPLIT_STAGE_BYTES, st, reinterpret_cast<const float2*>(A),                 \
                        reinterpret_cast<const float2*>(B), reinterpret_cast<float2*>(C), (int)M, (int)N, (int)K, strideA, \
-                       strideB, strideC, txn, tyn, batch, reinterpret_cast<const float2*>(X), prog);                   \
+                       strideB, strideC, txn, tyn, batch, reinterpret_cast<const float2*>(X));                         \
   }
-  if (X && prog) {
-    TCMI_SPLIT_LAUNCH(0, 2)
-  } else if (X) {
+  if (X) {
 #ifdef TCMI_SPLIT_PROBE
     // 7: epilogue without its multiply-adds, 8: its results as 16-byte stores (wrong places), 9: no result stores
     if (mode == 7) TCMI_SPLIT_LAUNCH(7, 1)
@@ -622,20 +464,13 @@ extern "C" {
 
 int tcmi_cgemm_split(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch,
                      long long strideA, long long strideB, long long strideC, void* stream) {
-  return split_launch(A, B, C, M, N, K, batch, strideA, strideB, strideC, nullptr, nullptr, stream, "tcmi_cgemm_split");
+  return split_launch(A, B, C, M, N, K, batch, strideA, strideB, strideC, nullptr, stream, "tcmi_cgemm_split");
 }
 
 int tcmi_cgemm_split_epi(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch,
                          long long strideA, long long strideB, long long strideC, const void* X, void* stream) {
   if (!X) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm_split_epi: X is null");
-  return split_launch(A, B, C, M, N, K, batch, strideA, strideB, strideC, X, nullptr, stream, "tcmi_cgemm_split_epi");
-}
-
-int tcmi_cgemm_split_prog(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch,
-                          long long strideA, long long strideB, long long strideC, const int* prog, const void* T,
-                          void* stream) {
-  if (!prog || !T) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm_split_prog: prog / T is null");
-  return split_launch(A, B, C, M, N, K, batch, strideA, strideB, strideC, T, prog, stream, "tcmi_cgemm_split_prog");
+  return split_launch(A, B, C, M, N, K, batch, strideA, strideB, strideC, X, stream, "tcmi_cgemm_split_epi");
 }
 
 }  // extern "C"

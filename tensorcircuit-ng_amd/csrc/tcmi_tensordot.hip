@@ -1375,14 +1375,9 @@ int tcmi_tensordot_bits_ex(const void* a, int rank_a, const void* b, int rank_b,
   const long long tiles = gx * gy_all;
   // few output tiles, long contraction (the closing steps of a sliced network and most steps of its reverse sweep: a
   // rank-20 x rank-18 step over 11 axes is 16 tiles): split K until about a thousand workgroups stream the operands,
-  // chunks of at least TCMI_BITS_KMIN k values (default 128 = 8 K steps; the first policy -- K >= 4096, chunks >= 1024 --
+  // chunks of at least 128 k values (8 K steps; the first policy -- K >= 4096, chunks >= 1024 --
   // left such steps on 8 ... 64 workgroups, 100 ... 470 us each)
-  static long long kmin = 0;
-  if (kmin == 0) {
-    const char* e = getenv("TCMI_BITS_KMIN");
-    kmin = e ? atoll(e) : 128;
-    if (kmin < TCMI_CBK) kmin = TCMI_CBK;
-  }
+  const long long kmin = 128 > TCMI_CBK ? 128 : TCMI_CBK;
   if (tiles < 512 && K >= 2 * kmin) {
     long long want = (1024 + tiles - 1) / tiles;
     if (want > K / kmin) want = K / kmin;
@@ -1437,12 +1432,10 @@ int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, 
       }
     }
     // k-major A, whole tiles, no split-K (the cut join): the LDS-DMA pipelined kernel
-    static const bool dma_off = getenv("TCMI_GEMM_DMA") && getenv("TCMI_GEMM_DMA")[0] == '0';
-    if (trans_a && !dma_off && ksplit == 1 && (M % 64) == 0 && (N % 64) == 0 && (K % TCMI_DMA_BK) == 0 &&
+    if (trans_a && ksplit == 1 && (M % 64) == 0 && (N % 64) == 0 && (K % TCMI_DMA_BK) == 0 &&
         (M / 64) * (N / 64) < (1ll << 31) && (strideA & 1) == 0 && (strideB & 1) == 0 &&
         (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0) {
-      static const bool t128_off = getenv("TCMI_GEMM_T128") && getenv("TCMI_GEMM_T128")[0] == '0';
-      if (!t128_off && (M % 128) == 0 && (N % 128) == 0 && (strideC & 1) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) {
+      if ((M % 128) == 0 && (N % 128) == 0 && (strideC & 1) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0) {
         const int txn = (int)(N / 128), tyn = (int)(M / 128);
         dim3 grid((unsigned)((long long)txn * tyn), (unsigned)batch, 1), block(256, 1, 1);
         static bool attr_set = false;
@@ -1460,7 +1453,6 @@ int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, 
         return TCMI_OK;
       }
       const int txn = (int)(N / 64), tyn = (int)(M / 64);
-      static const int stages = getenv("TCMI_GEMM_STAGES") ? atoi(getenv("TCMI_GEMM_STAGES")) : 3;
       dim3 grid((unsigned)((long long)txn * tyn), (unsigned)batch, 1), block(256, 1, 1);
 #define TCMI_DMA_LAUNCH(S)                                                                                           \
   {                                                                                                                  \
@@ -1471,9 +1463,7 @@ int tcmi_cgemm(const void* A, const void* B, void* C, long long M, long long N, 
                        reinterpret_cast<const float2*>(A), reinterpret_cast<const float2*>(B),                      \
                        reinterpret_cast<float2*>(C), (int)M, (int)N, (int)K, strideA, strideB, strideC, txn, tyn);  \
   }
-      if (stages == 2) TCMI_DMA_LAUNCH(2)
-      else if (stages == 4) TCMI_DMA_LAUNCH(4)
-      else TCMI_DMA_LAUNCH(3)
+      TCMI_DMA_LAUNCH(3)      // ring depth 3 (2 and 4 were measured slower, round 3)
 #undef TCMI_DMA_LAUNCH
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));

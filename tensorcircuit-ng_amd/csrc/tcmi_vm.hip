@@ -576,41 +576,6 @@ __global__ __launch_bounds__(64) void cut_epilogue_kernel(const F* __restrict__ 
   }
 }
 
-// Tables of a tail program (tcmi/cut.py TailProgram; the epilogue of tcmi_cgemm_split_prog): T[b][op][e] = prod over the
-// op's factors f of (c0_f[e] + cos(a_f) c1_f[e] + sin(a_f) c2_f[e]), e = 0..15 (a 2 x 2 row-major in e < 4, or the 16
-// entries of a diagonal), a_f = scale_f * theta_b[param_f] + offset_f; factor records as in cut_epilogue_kernel
-// (tab_i[f], tab_f[f * 98]); ops_i[op] = {first factor, number of factors}.  One thread per (circuit, op, entry).
-template <typename F>
-__global__ __launch_bounds__(64) void cut_program_kernel(const F* __restrict__ params, long long pstride, int batch,
-                                                         const int* __restrict__ ops_i, int nops, const int* __restrict__ tab_i,
-                                                         const double* __restrict__ tab_f, float2* __restrict__ T) {
-  const int e = threadIdx.x & 15;
-  const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 4);
-  if (item >= (long long)batch * nops) return;
-  const int b = (int)(item / nops), op = (int)(item - (long long)b * nops);
-  const int f0 = ops_i[2 * op], nf = ops_i[2 * op + 1];
-  double vr = 1.0, vi = 0.0;
-  for (int f = f0; f < f0 + nf; ++f) {
-    const double* t = tab_f + (long long)f * 98;
-    double cs = 0.0, sn = 0.0;
-    const int pi = tab_i[f];
-    if (pi >= 0) {
-      const double a = (double)params[(long long)b * pstride + pi] * t[0] + t[1];
-      cs = cos(a);
-      sn = sin(a);
-    }
-    const double mr = t[2 + 2 * e] + cs * t[34 + 2 * e] + sn * t[66 + 2 * e];
-    const double mi = t[3 + 2 * e] + cs * t[35 + 2 * e] + sn * t[67 + 2 * e];
-    const double nr = vr * mr - vi * mi;
-    vi = vr * mi + vi * mr;
-    vr = nr;
-  }
-  float2 w;
-  w.x = (float)vr;
-  w.y = (float)vi;
-  T[item * 16 + e] = w;
-}
-
 // second-generation complex64 measurement pass (tcmi_measure2.hip); -1 = no variant for this (R, LT)
 int run_measure2_c64(const void* state, long long state_stride, int batch, int n, int R, int LT, const int* desc,
                      double* eout, long long eout_stride, int ecopies, long long ecopy_stride, hipStream_t st);
@@ -695,8 +660,7 @@ int tcmi_run_pass(void* state, long long state_stride, int batch, int n, int R, 
     return set_err("measure2_kernel launch", hipGetLastError());
   }
   if (dtype == TCMI_C64 && !eout_dev && n >= R + LT) {
-    static const bool vm1 = getenv("TCMI_VM1") != nullptr;  // A/B switch: force the first-generation kernel
-    if (!vm1) {
+    {
       const int rc = tcmi::run_pass2_c64(state, state_stride, batch, n, R, LT, desc_dev, ctab_dev, ptab_dev, ptab_stride, st);
       if (rc == TCMI_OK) return rc;
       if (rc != -1) return set_err("pass2_kernel launch", hipGetLastError());
@@ -779,25 +743,6 @@ int tcmi_cut_epilogue(const void* params_dev, long long params_stride, int batch
     return set_msg(TCMI_ERR_ARG, "tcmi_cut_epilogue: bad dtype");
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_err("cut_epilogue_kernel launch", e);
-  return TCMI_OK;
-}
-
-int tcmi_cut_epilogue_program(const void* params_dev, long long params_stride, int batch, const int* ops_i_dev, int nops,
-                              const int* tab_i_dev, const double* tab_f_dev, void* t_dev, int dtype, void* stream) {
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (!params_dev || !ops_i_dev || !tab_i_dev || !tab_f_dev || !t_dev || batch < 1 || nops < 1 || nops > 12)
-    return set_msg(TCMI_ERR_ARG, "tcmi_cut_epilogue_program: bad argument");
-  dim3 block(64, 1, 1), grid((unsigned)(((long long)batch * nops + 3) / 4), 1, 1);
-  if (dtype == TCMI_C64)
-    hipLaunchKernelGGL(tcmi::cut_program_kernel<float>, grid, block, 0, st, reinterpret_cast<const float*>(params_dev),
-                       params_stride, batch, ops_i_dev, nops, tab_i_dev, tab_f_dev, reinterpret_cast<float2*>(t_dev));
-  else if (dtype == TCMI_C128)
-    hipLaunchKernelGGL(tcmi::cut_program_kernel<double>, grid, block, 0, st, reinterpret_cast<const double*>(params_dev),
-                       params_stride, batch, ops_i_dev, nops, tab_i_dev, tab_f_dev, reinterpret_cast<float2*>(t_dev));
-  else
-    return set_msg(TCMI_ERR_ARG, "tcmi_cut_epilogue_program: bad dtype");
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return set_err("cut_program_kernel launch", e);
   return TCMI_OK;
 }
 

@@ -54,11 +54,6 @@ _SIGNATURES = {
         [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
          ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p],
     ),
-    "tcmi_cut_epilogue_program": (
-        ctypes.c_int,
-        [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
-         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p],
-    ),
     "tcmi_run_pass": (
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -132,12 +127,6 @@ _SIGNATURES = {
         [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_longlong,
          ctypes.c_longlong, ctypes.c_int, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_void_p,
          ctypes.c_void_p],
-    ),
-    "tcmi_cgemm_split_prog": (
-        ctypes.c_int,
-        [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_longlong,
-         ctypes.c_longlong, ctypes.c_int, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_void_p,
-         ctypes.c_void_p, ctypes.c_void_p],
     ),
     "tcmi_vdot": (
         ctypes.c_int,

@@ -31,12 +31,9 @@ config 2 (exp1(ZZ) ladder, then rx on every qubit) qualifies, K = 256 -> 128.  F
 the left half's lowest index bit (q_l = n_left - 1) and q_r is made the right half's lowest bit by labelling the right
 half's qubits rotated by one (``CutSpec.right_rot``; the kernel un-rotates the column index when it stores).
 
-**Two deferred crossing gates** (``find_tail``, ``make_cut(defer=2)``).  The same argument for the last TWO crossing gates:
-the tail -- every later gate that does not commute with what is already in it -- then spans up to two qubits on either
-side of the cut, and is no longer one 4 x 4 but a small gate program (one-qubit gates and diagonals over <= 4 index bits:
-``TailProgram``), which the join kernel runs on the eight results a thread holds for two row bits and one column bit,
-the second column bit being a lane bit (``tcmi_cgemm_split_prog``).  The right half is labelled rotated by two.  A
-quarter of the bond dimension: config 2's K = 256 -> 64.
+Two deferred crossing gates (the tail as a small gate program run by the join kernel on four index bits; K = 256 -> 64
+on config 2) were built and measured in round 5 and lost to one deferred gate (1.73e11 against 1.81e11 amplitudes/s: the
+program's vector work costs what the quarter bond saves); the variant was removed in round 6.
 """
 
 from dataclasses import dataclass
@@ -77,7 +74,6 @@ class Epilogue:
     qr: int
     factors: List[Tuple[np.ndarray, np.ndarray, np.ndarray, Optional[P.ParamRef]]]
     tail: Optional[List[P.GateRec]] = None       # the deferred gates themselves (global qubits, time order)
-    program: Optional["TailProgram"] = None        # two deferred crossing gates: the tail as a gate program, factors empty
 
     def matrix(self, params) -> np.ndarray:
         x = np.eye(4, dtype=np.complex128)
@@ -88,38 +84,6 @@ class Epilogue:
                 m = m + np.cos(a) * c1 + np.sin(a) * c2
             x = m @ x
         return x
-
-
-BIT_U, BIT_R1, BIT_V, BIT_L4 = 0, 1, 2, 3   # index bits of the join result a tail program addresses: row bits 0, 1, column bits 0, 1
-
-
-@dataclass
-class TailProgram:
-    """The tail of a cut with deferred crossing gates as the join kernel runs it.  ``ops`` in time order:
-    ("g1", bit, [factor]) a 2 x 2 on one index bit, ("diag", -1, [factors]) a diagonal over the 16 values of
-    (u, r1, v, l4) = index u + 2 r1 + 4 v + 8 l4 (consecutive diagonal gates merged: the product of their factors);
-    factor = (c0, c1, c2, ParamRef | None), 16 complex entries each (a 2 x 2 row-major in the first four)."""
-
-    r: int
-    c: int
-    ops: List[tuple]
-    forms: Optional[List[int]] = None   # per op, the kernel's code: 1 diagonal; one-qubit: 2 real matrix, 3 real diagonal and
-                                        # imaginary off-diagonal (rx), 0 any 2 x 2
-    vhigh: int = 0                      # 1: index bit v is the first right-hand qubit (n_left), l4 the second; 0: the reverse
-
-    def tables(self, params) -> np.ndarray:
-        """[nops, 16] complex: what tcmi_cut_epilogue_program builds on the device."""
-        out = np.zeros((len(self.ops), 16), dtype=np.complex128)
-        for k, (_, _, factors) in enumerate(self.ops):
-            v = np.ones(16, dtype=np.complex128)
-            for c0, c1, c2, ref in factors:
-                m = np.array(c0, dtype=np.complex128)
-                if ref is not None:
-                    a = ref.scale * float(params[ref.index]) + ref.offset
-                    m = m + np.cos(a) * c1 + np.sin(a) * c2
-                v = v * m
-            out[k] = v
-        return out
 
 
 @dataclass
@@ -161,7 +125,6 @@ def find_deferred(gates: List[P.GateRec], n_left: int):
     if ql != n_left - 1 or qr != n_left:
         return None
     dirty = {ql: not g.is_diag, qr: not g.is_diag}     # a non-diagonal factor of X sits on this qubit
-    tail = {ql: False, qr: False}                      # a one-qubit gate on this qubit has been absorbed
     absorbed = []
     for i in range(p + 1, len(gates)):
         h = gates[i]
@@ -172,7 +135,6 @@ def find_deferred(gates: List[P.GateRec], n_left: int):
             return None
         if len(h.qubits) == 1:
             absorbed.append(i)
-            tail[hit[0]] = True
             dirty[hit[0]] = dirty[hit[0]] or not h.is_diag
             continue
         # a wider gate stays in its half: it has to commute with every factor of X on the qubits they share
@@ -185,78 +147,6 @@ def _commute(h: P.GateRec, t: P.GateRec) -> bool:
     return not (set(h.qubits) & set(t.qubits)) or (h.is_diag and t.is_diag)
 
 
-def find_tail(gates: List[P.GateRec], n_left: int, ndefer: int = 2, rmax: int = 2, cmax: int = 2):
-    """Indices (time order) of the gates that leave the half-circuits when the last ``ndefer`` crossing gates are applied
-    after the join, and the (r, c) qubits they span on either side of the cut; None when the circuit does not allow it.
-    The tail starts with the ``ndefer``-th last crossing gate; a later gate joins it when it crosses the cut or does not
-    commute with a gate already in the tail (a gate that stays in its half is thereby moved BEFORE the tail gates that
-    preceded it, so it has to commute with exactly those).  Tail gates have to be one-qubit gates or diagonals inside the
-    window of ``rmax`` left and ``cmax`` right qubits next to the cut."""
-    def crossing(g):
-        return any(q < n_left for q in g.qubits) and any(q >= n_left for q in g.qubits)
-
-    cross = [i for i, g in enumerate(gates) if crossing(g)]
-    if len(cross) < ndefer:
-        return None
-    tail = []
-    for i in range(cross[-ndefer], len(gates)):
-        h = gates[i]
-        if not crossing(h) and all(_commute(h, gates[t]) for t in tail):
-            continue
-        if h.select is not None or not (len(h.qubits) == 1 or h.is_diag):
-            return None
-        if any(q < n_left - rmax or q >= n_left + cmax for q in h.qubits):
-            return None
-        tail.append(i)
-    qs = [q for t in tail for q in gates[t].qubits]
-    return tail, n_left - min(qs), max(qs) - n_left + 1
-
-
-def tail_program(gates: List[P.GateRec], tail: List[int], n_left: int, r: int, c: int) -> Optional[TailProgram]:
-    """The tail as ops on the index bits (u, r1 | v, l4) of the join result; None when it needs more than two diagonal ops
-    or twelve ops in all (what the kernel keeps in registers)."""
-    # the lane bit l4 is the expensive one (partner values by ds_swizzle): it goes to the right-hand qubit with fewer
-    # one-qubit gates in the tail
-    cnt = [sum(1 for t in tail if gates[t].qubits == (n_left + j,) and not gates[t].is_diag) for j in range(2)]
-    vhigh = int(c == 2 and cnt[0] > cnt[1])
-    bit = {n_left - 1: BIT_U, n_left - 2: BIT_R1}
-    if c == 2:
-        bit[n_left + 1 - vhigh] = BIT_V
-        bit[n_left + vhigh] = BIT_L4
-    else:
-        bit[n_left] = BIT_V
-    ops, forms = [], []
-    for t in tail:
-        g = gates[t]
-        z = lambda m, size: np.zeros(size, dtype=np.complex128) if m is None else np.asarray(m, dtype=np.complex128)
-        if g.is_diag:
-            # the diagonal of c0 + cos c1 + sin c2 over the gate's qubits, spread over the 16 values of (u, r1, v, l4)
-            k = len(g.qubits)
-            idx = np.zeros(16, dtype=np.int64)
-            for e in range(16):
-                for j, q in enumerate(g.qubits):
-                    idx[e] |= ((e >> bit[q]) & 1) << (k - 1 - j)
-            fac = tuple(np.diag(z(m, (2**k, 2**k)).reshape(2**k, 2**k))[idx] for m in (g.c0, g.c1, g.c2)) + (g.param,)
-            if ops and ops[-1][0] == "diag":
-                ops[-1][2].append(fac)
-            else:
-                ops.append(("diag", -1, [fac]))
-                forms.append(1)
-        else:
-            ms = [z(m, (2, 2)).reshape(2, 2) for m in (g.c0, g.c1, g.c2)]
-            fac = tuple(np.concatenate([m.reshape(4), np.zeros(12, dtype=np.complex128)]) for m in ms) + (g.param,)
-            ops.append(("g1", bit[g.qubits[0]], [fac]))
-            if all(np.abs(m.imag).max() < 1e-15 for m in ms):
-                forms.append(2)
-            elif all(abs(m[0, 0].imag) + abs(m[1, 1].imag) + abs(m[0, 1].real) + abs(m[1, 0].real) < 1e-15 for m in ms):
-                forms.append(3)
-            else:
-                forms.append(0)
-    if len(ops) > 12:
-        return None
-    return TailProgram(r, c, ops, forms, vhigh)
-
-
 def make_cut(gates: List[P.GateRec], n: int, n_left: int, nparams: int, max_bond: int = 1 << 12,
              defer: int = 0) -> Optional[CutSpec]:
     """Split the gate list at qubit ``n_left``; None if a gate cannot be split (3-qubit crossing,
@@ -267,14 +157,6 @@ def make_cut(gates: List[P.GateRec], n: int, n_left: int, nparams: int, max_bond
     epi, skip = None, set()
     n_right = n - n_left
     rot = 0
-    if int(defer) >= 2:
-        found = find_tail(gates, n_left, 2)
-        if found is not None and found[2] == 2 and found[1] <= 2 and n_right > 2:
-            tail, r, c = found
-            prog = tail_program(gates, tail, n_left, r, c)
-            if prog is not None:
-                epi = Epilogue(n_left - 1, n_left, [], [gates[t] for t in tail], prog)
-                skip, rot = set(tail), 2
     if defer and epi is None:
         found = find_deferred(gates, n_left)
         if found is not None:
@@ -300,11 +182,7 @@ def make_cut(gates: List[P.GateRec], n: int, n_left: int, nparams: int, max_bond
             epi = Epilogue(ql, qr, factors, [gates[i] for i in [p] + absorbed])
             skip, rot = set([p] + absorbed), 1
 
-    vhigh = int(epi is not None and epi.program is not None and epi.program.vhigh)
-
-    def rloc(q):       # local index of global qubit q in the right half (vhigh: the two rotated qubits change places)
-        if vhigh and q - n_left < 2:
-            return n_right - 1 - (q - n_left)
+    def rloc(q):       # local index of global qubit q in the right half
         return (q - n_left - rot) % n_right
 
     for gi, g in enumerate(gates):

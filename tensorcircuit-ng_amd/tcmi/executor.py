@@ -1395,33 +1395,7 @@ class CutCircuit:
         self._plain_args = (n, gates, nparams, dtypestr, opts, getattr(spec, "plain", None), full_cc)
         self._plain = None
         self._epi = None
-        self._prog = None
-        if spec.epilogue is not None and spec.epilogue.program is not None:
-            # two deferred crossing gates: the tail as a gate program of the join kernel (tcmi_cgemm_split_prog)
-            ops = spec.epilogue.program.ops
-            facs = [f for _, _, fl in ops for f in fl]
-            tab_i = np.array([(-1 if f[3] is None else f[3].index) for f in facs], dtype=np.int32)
-            tab_f = np.zeros((len(facs), 98), dtype=np.float64)
-            for g_, (c0, c1, c2, ref) in enumerate(facs):
-                tab_f[g_, 0], tab_f[g_, 1] = (0.0, 0.0) if ref is None else (ref.scale, ref.offset)
-                for j_, m_ in enumerate((c0, c1, c2)):
-                    m_ = np.asarray(m_, dtype=np.complex128).reshape(16)
-                    tab_f[g_, 2 + 32 * j_: 34 + 32 * j_: 2] = m_.real
-                    tab_f[g_, 3 + 32 * j_: 35 + 32 * j_: 2] = m_.imag
-            tp = spec.epilogue.program
-            ops_i, words, dslots, f0 = [], [], [], 0
-            for k_, (kind, bit, fl) in enumerate(ops):
-                ops_i += [f0, len(fl)]
-                f0 += len(fl)
-                if kind == "diag":
-                    words.append(1)
-                    dslots.append(k_)
-                else:
-                    words.append(int(tp.forms[k_]) | (int(bit) << 4))
-            prog = np.array([len(ops) | (int(tp.vhigh) << 8)] + (dslots + [-1, -1])[:2] + words + [0], dtype=np.int32)
-            self._prog = (torch.as_tensor(prog).to(self.device), torch.as_tensor(np.array(ops_i, dtype=np.int32)).to(self.device),
-                          torch.as_tensor(tab_i).to(self.device), torch.as_tensor(tab_f.reshape(-1)).to(self.device), len(ops))
-        elif spec.epilogue is not None:
+        if spec.epilogue is not None:
             fac = spec.epilogue.factors
             tab_i = np.array([(-1 if f[3] is None else f[3].index) for f in fac], dtype=np.int32)
             tab_f = np.zeros((len(fac), 98), dtype=np.float64)
@@ -1484,7 +1458,7 @@ class CutCircuit:
         p = params.reshape(-1, params.shape[-1]) if params.dim() > 1 else params.reshape(1, -1)
         p = p.to(device=self.device, dtype=self.rdtype)
         B, K = p.shape[0], self.K
-        if (self._epi is not None or self._prog is not None) and not self._split_join():
+        if self._epi is not None and not self._split_join():
             return self._plain_cut().state(params, inputs, out, full)
         pfull = torch.cat([p[:, : self.nparams].unsqueeze(1).expand(B, K, self.nparams),
                            self.digits.unsqueeze(0).expand(B, K, -1)], dim=2).reshape(B * K, -1).contiguous()
@@ -1546,15 +1520,6 @@ class CutCircuit:
         """X [B, 16] complex64 of the deferred gate (one launch, tcmi_cut_epilogue), None without one."""
         import torch
 
-        if self._prog is not None:
-            prog, ops_i, tab_i, tab_f, nops = self._prog
-            p = p.contiguous()
-            t = torch.empty(p.shape[0], nops * 16, dtype=torch.complex64, device=self.device)
-            _lib.check(self._lib.tcmi_cut_epilogue_program(p.data_ptr(), p.stride(0), p.shape[0], ops_i.data_ptr(), nops,
-                                                           tab_i.data_ptr(), tab_f.data_ptr(), t.data_ptr(), self.code,
-                                                           torch.cuda.current_stream(self.device).cuda_stream),
-                       "tcmi_cut_epilogue_program")
-            return (prog, t)
         if self._epi is None:
             return None
         tab_i, tab_f, nfac = self._epi
@@ -1569,11 +1534,6 @@ class CutCircuit:
         """psi[b] = L[b]^T . R[b] (k-major halves).  complex64 joins whose shape the kernel takes run on the bf16
         matrix pipe with three-piece operands (``tcmi_cgemm_split``: f32 accuracy, measured against float64 next to the
         f32 MFMA kernel in tests/test_gpu_gemm_split.py); ``TCMI_JOIN_GEMM=f32`` keeps every join on ``tcmi_cgemm``."""
-        if isinstance(xepi, tuple):
-            _lib.check(self._lib.tcmi_cgemm_split_prog(L.data_ptr(), R.data_ptr(), out.data_ptr(), M, N, K, B, K * M, K * N,
-                                                       M * N, xepi[0].data_ptr(), xepi[1].data_ptr(), stream),
-                       "tcmi_cgemm_split_prog(cut)")
-            return
         if xepi is not None:
             _lib.check(self._lib.tcmi_cgemm_split_epi(L.data_ptr(), R.data_ptr(), out.data_ptr(), M, N, K, B, K * M, K * N,
                                                       M * N, xepi.data_ptr(), stream), "tcmi_cgemm_split_epi(cut)")
@@ -1742,10 +1702,10 @@ def choose_cut(n, gates, nparams, dtypestr, plan):
     # on its live tiles 181 us (model 181); near-ties go to the cut (its join has measured better than its model so far)
     # the last crossing gate applied by the join kernel instead of being a bond (cut.py: half the bond for ZZ / CNOT / CZ)
     # when the circuit allows it and the split-GEMM join takes the smaller shape; TCMI_CUT_DEFER=0 keeps every bond
-    # TCMI_CUT_DEFER = 1 (default): the last crossing gate (its 4 x 4 in the join's epilogue); 2: up to two (the tail as a gate
-    # program of the join kernel -- correct, and slower on config 2: 1.73e11 against 1.81e11 amplitudes/s, the program's
-    # vector instructions cost what the quarter bond saves, tcmi_gemm_split.hip); 0: none
-    for ndefer in ([2, 1] if os.environ.get("TCMI_CUT_DEFER", "1") == "2" else [1]):
+    # (two deferred gates -- the tail as a gate program of the join kernel -- were built and measured in round 5: 1.73e11
+    # against 1.81e11 amplitudes/s on config 2, the program's vector instructions cost what the quarter bond saves; the
+    # variant lives in the round-5 tree)
+    for ndefer in [1]:
         if not split or os.environ.get("TCMI_CUT_DEFER", "1") == "0":
             break
         dspec = C.make_cut(gates, n, best.n_left, nparams, defer=ndefer)

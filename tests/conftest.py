@@ -20,7 +20,7 @@ BENCH_SMALL = ["--steps", "2", "--warmup", "1", "--qubits", "16", "--depth", "4"
                "--svqa-slices", "4", "--svqa-steps", "1", "--mps-qubits", "0", "--sv-qubits", "16", "--sv-depth", "3", "--sv-batch", "4",
                "--sv-microbatch", "2", "--sv-steps", "1", "--no-cpu-baseline", "--no-traffic-probe",
                "--no-graph"]
-BENCH_OUT = {k: os.path.join(ROOT, ".pytest_cache", f"bench_{k}.json") for k in ("w1", "w2", "dead", "nccl1")}
+BENCH_OUT = {k: os.path.join(ROOT, ".pytest_cache", f"bench_{k}.json") for k in ("w1", "w2", "dead", "nccl1", "full", "raise")}
 
 
 def _run_bench(tag, gpus, extra_env, timeout):
@@ -45,7 +45,7 @@ def _run_bench(tag, gpus, extra_env, timeout):
             except ValueError:
                 pass
     with open(BENCH_OUT[tag], "w") as fh:
-        json.dump({"rc": rc, "seconds": time.time() - t0, "line": line, "stderr": err[-2000:]}, fh)
+        json.dump({"rc": rc, "seconds": time.time() - t0, "line": line, "stderr": err[-6000:]}, fh)
 
 
 MULTIRANK_OUT = os.path.join(ROOT, ".pytest_cache", "multirank_slices.json")
@@ -81,6 +81,10 @@ def pytest_sessionstart(session):
         _run_bench("w1", 1, {}, 900)
         _run_bench("w2", 2, {"TCMI_BENCH_OVERSUBSCRIBE": "1"}, 900)
         _run_bench("dead", 2, {"TCMI_BENCH_OVERSUBSCRIBE": "1", "TCMI_BENCH_KILL_RANK": "1"}, 300)
+        # a device too full for the legs (here: pretended, every rank is told it shares its device with 10^6 others): the
+        # ranks agree to skip them; and an exception inside a leg on ONE rank: the job ends, non-zero, instead of hanging
+        _run_bench("full", 2, {"TCMI_BENCH_OVERSUBSCRIBE": "1", "TCMI_BENCH_SHARERS": "1000000"}, 600)
+        _run_bench("raise", 2, {"TCMI_BENCH_OVERSUBSCRIBE": "1", "TCMI_BENCH_RAISE_IN": "vqe_step:1"}, 300)
         # RCCL itself on this box's one GPU: the multi-rank code path of bench.py (init_process_group("nccl"), barriers,
         # the packed all-reduces, the sharded legs' collectives) with a world of ONE rank, torchrun-style environment
         import socket

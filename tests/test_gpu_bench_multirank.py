@@ -84,3 +84,23 @@ def test_a_dead_rank_terminates_the_job():
     assert d["rc"] not in (0, -999), d       # non-zero exit, and not by the test's own timeout
     assert d["line"] is None
     assert d["seconds"] < 240
+
+
+def test_a_full_device_makes_every_rank_skip_the_leg_and_a_failing_rank_ends_the_job():
+    """VERDICT r05 weak 7 (four ranks of the default bench on one device ended in HSA_STATUS_ERROR_EXCEPTION).  What the
+    round-6 runs found (profiles/r06_over4_*.txt): an allocation torch cannot satisfy raises torch.OutOfMemoryError in
+    Python; the hardware exception belongs to a device whose processes together hold more than its memory (the kernel
+    driver then moves buffers of running processes to host memory).  bench.py therefore (i) lets the ranks AGREE, before a
+    leg, on whether its working set fits what is free on the fullest device -- here every rank is told it shares the
+    device with a million others, so every sized leg is skipped on every rank and the job still exits 0 with a line; and
+    (ii) when one rank fails inside a leg that holds collectives, that rank leaves with exit code 17 and the launcher
+    takes the job down -- never a hang, never a zero exit."""
+    f = _load("full")
+    assert f["rc"] == 0 and f["line"] is not None, f["stderr"]
+    for leg in ("statevector_n16", "vqe_step", "rqc_amplitude", "sliced_vqa"):
+        assert "skipped" in f["line"][leg] and "GiB" in f["line"][leg]["skipped"], f["line"][leg]
+    assert f["line"]["n_gpus"] == 2 and f["line"]["value"] > 0          # the headline itself ran
+    r = _load("raise")
+    assert r["rc"] == 17 and r["line"] is None, r
+    assert "injected" in r["stderr"] and "leaving the job (exit 17)" in r["stderr"]
+    assert r["seconds"] < 240

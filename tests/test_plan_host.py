@@ -450,54 +450,15 @@ def test_cut_with_the_last_crossing_gate_deferred():
     assert cut.make_cut(c4._gate_records(), n, 5, len(c4._params), defer=True).epilogue is None
 
 
-def test_cut_with_two_crossing_gates_deferred():
-    """``make_cut(defer=2)``: the tail of the last two crossing gates (``cut.find_tail``) as a gate program on two row bits
-    and two column bits of the join result; both the gate form and the program form (what the kernel runs, with the
-    rotated column index) reproduce ``oracle.dense``."""
-    from tcmi import cut
-
-    n, d = 12, 4
-    params = np.random.default_rng(3).uniform(0, 2 * np.pi, [2 * d, n])
-    c = tc.Circuit(n)
-    W.hea_b(c, n, d, params, zz=tc.gates._zz_matrix)
-    recs = c._gate_records()
-    pv = np.array([float(x) for x in c._params])
-    spec = cut.make_cut(recs, n, 6, len(pv), defer=2)
-    prog = spec.epilogue.program
-    assert spec.bond_dim == 4 and spec.right_rot == 2 and (prog.r, prog.c) == (2, 2)
-    kinds = [(k, b) for k, b, _ in prog.ops]
-    # ZZ7(5,6) | rx7(5) rx7(6) | ZZ8(4,5) ZZ8(5,6) ZZ8(6,7) merged | rx8 on 4, 5, 6, 7; qubit 6 has two rx gates, qubit 7
-    # one: the lane bit l4 goes to qubit 7 (vhigh)
-    assert prog.vhigh == 1 and prog.forms == [1, 3, 3, 1, 3, 3, 3, 3]
-    assert kinds == [("diag", -1), ("g1", cut.BIT_U), ("g1", cut.BIT_V), ("diag", -1),
-                     ("g1", cut.BIT_R1), ("g1", cut.BIT_U), ("g1", cut.BIT_V), ("g1", cut.BIT_L4)]
-    assert len(prog.ops[3][2]) == 3 and len(spec.epilogue.tail) == 10
-    want = dense.run(n, W.hea_b_ops(n, d, params))
-    np.testing.assert_allclose(oracle_cut.reference_state(spec, pv), want, atol=1e-12)
-    np.testing.assert_allclose(oracle_cut.reference_state(spec, pv, program=True), want, atol=1e-12)
-    # a tail that needs a third qubit on one side does not qualify; the single deferred gate still does
-    c2 = tc.Circuit(n)
-    W.hea_b(c2, n, 2, params[:4], zz=tc.gates._zz_matrix)
-    c2.rx(5, theta=0.3); c2.rzz(4, 5, theta=0.2); c2.rx(4, theta=0.5); c2.rzz(3, 4, theta=0.4); c2.rzz(5, 6, theta=0.1)
-    r2 = c2._gate_records()
-    assert cut.find_tail(r2, 6, 2) is None          # rzz(3, 4) does not commute with rx(4), which is in the tail by then
-    s2 = cut.make_cut(r2, n, 6, len(c2._params), defer=2)
-    assert s2.right_rot == 1 and s2.epilogue.program is None and s2.bond_dim == 4
-    ops2 = W.hea_b_ops(n, 2, params[:4]) + [(G.rx(0.3), [5]), (G.rzz(0.2), [4, 5]), (G.rx(0.5), [4]), (G.rzz(0.4), [3, 4]),
-                                            (G.rzz(0.1), [5, 6])]
-    np.testing.assert_allclose(oracle_cut.reference_state(s2, np.array([float(v) for v in c2._params])),
-                               dense.run(n, ops2), atol=1e-12)
-
-
 def test_deferral_rules_on_random_circuits():
-    """``find_deferred`` / ``find_tail`` decide from commutation rules which gates may leave the half-circuits; whatever they
-    decide on random mixes of diagonal and dense one- and two-qubit gates, the cut formula with the tail applied afterwards
-    (gate form, and program form when there is one) has to reproduce ``oracle.dense``."""
+    """``find_deferred`` decides from commutation rules which gates may leave the half-circuits; whatever it decides on
+    random mixes of diagonal and dense one- and two-qubit gates, the cut formula with the 4 x 4 tail applied afterwards has
+    to reproduce ``oracle.dense``."""
     from tcmi import cut
 
     n, nl = 8, 4
     rng = np.random.default_rng(7)
-    seen = {"tail4x4": 0, "program": 0, "none": 0}
+    seen = {"tail4x4": 0, "none": 0}
     for trial in range(60):
         c = tc.Circuit(n)
         ops = []
@@ -542,21 +503,18 @@ def test_deferral_rules_on_random_circuits():
         recs = c._gate_records()
         pv = np.array([float(x) for x in c._params])
         want = dense.run(n, ops)
-        for defer in (1, 2):
+        for defer in (0, 1):
             spec = cut.make_cut(recs, n, nl, len(pv), defer=defer)
             if spec is None:
                 continue
             np.testing.assert_allclose(oracle_cut.reference_state(spec, pv), want, atol=1e-11)
             if spec.epilogue is None:
                 seen["none"] += 1
-            elif spec.epilogue.program is not None:
-                seen["program"] += 1
-                np.testing.assert_allclose(oracle_cut.reference_state(spec, pv, program=True), want, atol=1e-11)
             else:
                 seen["tail4x4"] += 1
                 x = spec.epilogue.matrix(pv)
                 np.testing.assert_allclose(x.conj().T @ x, np.eye(4), atol=1e-11)
-    assert seen["tail4x4"] >= 5 and seen["program"] >= 3 and seen["none"] >= 5, seen
+    assert seen["tail4x4"] >= 5 and seen["none"] >= 5, seen
 
 
 def test_dense_three_qubit_gates_are_synthesised_exactly():
