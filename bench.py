@@ -1417,8 +1417,12 @@ def main():
             for j in range(d):
                 order += [(2 * j) * n + i for i in range(n - 1)]
                 order += [(2 * j + 1) * n + i for i in range(n)]
-            pmat = params.reshape(B, -1)[:, torch.tensor(order, device=dev)].contiguous()
-            gs = GraphedState(cc, B)
+            # (this rank's chunk: with more than --global-batch / --batch ranks a chunk holds fewer than B circuits -- sizing
+            # the replay by B instead was the out-of-range gather that killed every 4-rank run of round 5 with
+            # HSA_STATUS_ERROR_EXCEPTION, a device-side index assertion; profiles/r06_over4_fault.txt)
+            Bl = int(params.shape[0])
+            pmat = params.reshape(Bl, -1)[:, torch.tensor(order, device=dev)].contiguous()
+            gs = GraphedState(cc, Bl)
             for _ in range(args.warmup):
                 gs(pmat)
             sync()
@@ -1428,8 +1432,8 @@ def main():
             sync()
             tg = time.perf_counter() - tg0
             same = bool(torch.allclose(gs.out, fwd(params), atol=1e-6, rtol=0))     # the eager result of the same chunk
-            graph_info = {"ms_per_step": tg / args.steps * 1e3, "amplitudes_per_s_per_gpu": B * (2**n) * args.steps / tg,
-                          "matches_eager": same}
+            graph_info = {"ms_per_step": tg / args.steps * 1e3, "amplitudes_per_s_per_gpu": Bl * (2**n) * args.steps / tg,
+                          "circuits_per_replay": Bl, "matches_eager": same}
             del gs
         except Exception as e:  # noqa: BLE001
             graph_info = {"error": f"{type(e).__name__}: {e}"[:200]}

@@ -7,11 +7,11 @@
  * library with ctypes from a new backend class; every entry point below names
  * the reference interface it replaces.
  *
- * Multi-GPU: this ABI runs ONE rank.  The path's exchange steps (one packed all-reduce of [value || gradients] per step,
- * one all-gather of the slice-invariant roots and one all-reduce of their cotangents in a sliced contraction) belong to
- * the host framework's process group (torch.distributed, backend nccl = RCCL); there is deliberately no
- * tcmi_allreduce_sum here (SURVEY.md 8(b) lists one; see INTEGRATION.md section 3 for the ncclAllReduce call a non-torch
- * host would issue on the stream it passes to these entry points).
+ * Multi-GPU: one process per GPU, every entry point acts on the calling rank's device.  The path's exchange steps are one
+ * packed all-reduce of [value || gradients] per step (plus, in a sliced contraction, one all-gather of the
+ * slice-invariant roots and one all-reduce of their cotangents).  The package's Python host issues them through the host
+ * framework's process group (torch.distributed, backend nccl = RCCL); a host without one uses tcmi_comm_* /
+ * tcmi_allreduce_sum below (RCCL opened at first use, not linked).
  *
  * Conventions: all pointers are DEVICE pointers unless the name ends in _host; the caller owns every
  * buffer; `stream` is a hipStream_t passed as void* (NULL = default stream); every function returns
@@ -34,6 +34,8 @@ extern "C" {
 #define TCMI_ERR_HIP (-2)
 #define TCMI_C64 0
 #define TCMI_C128 1
+#define TCMI_F32 2   /* real dtypes: tcmi_allreduce_sum only */
+#define TCMI_F64 3
 
 /* library / runtime probes */
 int tcmi_version(void);
@@ -329,6 +331,23 @@ int tcmi_spec_run_adjoint_pass(void* handle, void* psi, void* lam, long long sta
                                int LT, const void* ctab, const void* ptab, long long ptab_stride, double* gout,
                                long long gout_stride, int gcopies, long long gcopy_stride, unsigned live_mask,
                                void* stream);
+
+/* ---- the path's collective ---------------------------------------------------------------------------
+ * Replaces: the sum over devices of the per-rank partial [value || gradients] of a sharded vmap batch or of the slices of
+ * a sliced contraction (reference tensorcircuit/experimental.py:1145-1152 `jnp.sum(device_values, axis=0)` after the pmap
+ * of 1125-1143; examples/slicing_auto_pmap_vqa.py:60-72) -- for hosts that have no process group of their own.
+ * tcmi_comm_load: optional, names the librccl to open (NULL / not called: the one already in the process, else
+ * "librccl.so", "librccl.so.1", the ROCm installation's).  tcmi_comm_unique_id: 128 bytes (TCMI_COMM_ID_BYTES) to be
+ * created on ONE rank and handed to the others out of band (ncclGetUniqueId).  tcmi_comm_init: every rank, after
+ * hipSetDevice, with the same id (ncclCommInitRank: collective, blocks until all `world` ranks have called).
+ * tcmi_allreduce_sum: in place on `buf` (device), `count` elements of `dtype` (TCMI_F32 / TCMI_F64 / TCMI_C64 / TCMI_C128),
+ * ordered on `stream` like every other entry point.  tcmi_comm_destroy: ncclCommDestroy. */
+#define TCMI_COMM_ID_BYTES 128
+int tcmi_comm_load(const char* librccl_path_host);
+int tcmi_comm_unique_id(void* id_out_host);
+int tcmi_comm_init(const void* id_host, int rank, int world, void** comm_out_host);
+int tcmi_allreduce_sum(void* comm, void* buf, long long count, int dtype, void* stream);
+int tcmi_comm_destroy(void* comm);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,8 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libtcmi.so")
 
 TCMI_C64 = 0
 TCMI_C128 = 1
+TCMI_F32 = 2
+TCMI_F64 = 3
 
 _lib = None
 
@@ -166,6 +168,11 @@ _SIGNATURES = {
          ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_longlong,
          ctypes.c_int, ctypes.c_longlong, ctypes.c_uint, ctypes.c_void_p],
     ),
+    "tcmi_comm_load": (ctypes.c_int, [ctypes.c_char_p]),
+    "tcmi_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "tcmi_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "tcmi_allreduce_sum": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]),
+    "tcmi_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "tcmi_mps_gate_mix": (
         ctypes.c_int,
         [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,

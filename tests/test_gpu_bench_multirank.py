@@ -31,12 +31,16 @@ def test_two_rank_bench_equals_the_one_rank_bench():
     # headline: the same global batch, sharded -- same checksum of the states, same amount of work per step
     assert la["config"]["global_batch"] == lb["config"]["global_batch"] == 4
     assert abs(la["config"]["z0_checksum"] - lb["config"]["z0_checksum"]) < 1e-5
-    assert lb["config"]["calls_per_step_per_gpu"] * 2 == la["config"]["calls_per_step_per_gpu"]
+    assert lb["config"]["calls_per_step_per_gpu"] == la["config"]["calls_per_step_per_gpu"] == 1
+    # the hipGraph replay works on THIS rank's chunk (2 of the 4 circuits per rank: fewer than --batch; sizing it by --batch
+    # was the out-of-range gather behind round 5's HSA_STATUS_ERROR_EXCEPTION with four ranks)
+    assert la["hipgraph_replay"]["circuits_per_replay"] == 4 and lb["hipgraph_replay"]["circuits_per_replay"] == 2
+    assert la["hipgraph_replay"]["matches_eager"] and lb["hipgraph_replay"]["matches_eager"]
     for leg in ("statevector_n16", "vqe_step", "rqc_amplitude", "sliced_vqa"):
         assert "error" not in la[leg] and "skipped" not in la[leg], la[leg]
         assert "error" not in lb[leg] and "skipped" not in lb[leg], lb[leg]
     # what a SCALE record needs to be readable: every rank's own time and the latency of the step's collective
-    assert len(lb["per_rank_ms_per_step"]) == 2 and max(lb["per_rank_ms_per_step"]) <= lb["ms_per_step"] * 1.0001
+    assert len(lb["per_rank_ms_per_step"]) == 2 and max(lb["per_rank_ms_per_step"]) <= lb["ms_per_step"] * 1.01 + 1e-3
     assert len(lb["vqe_step"]["per_rank_ms_per_step"]) == 2 and lb["vqe_step"]["allreduce_us"] > 0
     assert "per_rank_ms_per_step" not in la
     # the n = 28 leg at toy size: the same global batch of states whatever the world size
@@ -70,6 +74,7 @@ def test_rccl_world_of_one_equals_the_plain_one_rank_bench():
     assert lb["n_gpus"] == 1 and "oversubscribed" not in lb
     assert abs(la["config"]["z0_checksum"] - lb["config"]["z0_checksum"]) < 1e-6
     assert la["config"]["calls_per_step_per_gpu"] == lb["config"]["calls_per_step_per_gpu"]
+    assert lb["hipgraph_replay"]["matches_eager"]
     for leg in ("vqe_step", "rqc_amplitude", "sliced_vqa"):
         assert "error" not in lb[leg], lb[leg]
     assert abs(la["vqe_step"]["mean_energy"] - lb["vqe_step"]["mean_energy"]) < 1e-6 * max(1.0, abs(la["vqe_step"]["mean_energy"]))

@@ -142,3 +142,32 @@ def test_four_rank_sliced_value_and_grad_equals_the_adjoint_path():
             assert np.abs(np.asarray(f["grad2"]) - g).max() < 1e-10
     finally:
         tc.set_dtype("complex64")
+
+
+def test_abi_collective_on_a_world_of_one():
+    """include/tcmi.h tcmi_comm_* / tcmi_allreduce_sum: RCCL opened by libtcmi.so itself, a communicator of ONE
+    rank on this box's GPU (more ranks need more devices: RCCL refuses two ranks on one), all-reduce(SUM) in place for the
+    four dtypes -- the identity on one rank, bit for bit -- ordered on the caller's stream."""
+    import torch
+    from tcmi import distributed as D
+
+    uid = D.AbiCommunicator.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = D.AbiCommunicator(uid, 0, 1)
+    try:
+        g = torch.Generator(device="cuda").manual_seed(3)
+        for dt in (torch.float32, torch.float64, torch.complex64, torch.complex128):
+            x = torch.randn(1000, device="cuda", dtype=dt, generator=g)
+            want = x.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                y = x * 2                     # ordered before the collective on the same stream
+                comm.allreduce_sum_(y)
+                y = y / 2
+            torch.cuda.current_stream().wait_stream(side)
+            assert torch.equal(y, want)
+        with pytest.raises(ValueError):
+            comm.allreduce_sum_(torch.zeros(4, dtype=torch.int32, device="cuda"))
+    finally:
+        comm.close()

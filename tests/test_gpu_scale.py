@@ -42,8 +42,11 @@ def test_tfim_value_and_gradient_vs_dense_oracle(n, d, dtype):
         v, g = tc.backend.value_and_grad(_energy_fn(tc, n, d))(tc.backend.convert_to_tensor(params.astype(rdt)))
         ref = lambda p: W.tfim_energy_dense(dense.run(n, W.hea_b_ops(n, d, p)), n)  # noqa: E731
         e_ref = ref(params.astype(rdt).astype(np.float64))
-        assert abs(float(v) - e_ref) < (2e-4 if dtype == "complex64" else 1e-9)
+        # tolerances = 10-20 x the errors measured on MI355X (printed below; complex64 energy ~2e-6, gradient ~1e-6)
+        e_err = abs(float(v) - e_ref)
+        assert e_err < (4e-5 if dtype == "complex64" else 1e-9), e_err
         g = tc.backend.numpy(g)
+        g_err = 0.0
         eps = 1e-6
         comps = [(0, 0), (0, n - 2), (1, 0), (1, n - 1), (2 * d - 2, n // 2), (2 * d - 1, n // 2), (d, 3), (d + 1, n - 4)]
         base = params.astype(rdt).astype(np.float64)
@@ -52,7 +55,9 @@ def test_tfim_value_and_gradient_vs_dense_oracle(n, d, dtype):
             pp[a, b] += eps
             pm[a, b] -= eps
             fd = (ref(pp) - ref(pm)) / (2 * eps)
-            assert abs(g[a, b] - fd) < (2e-4 if dtype == "complex64" else 1e-7), (a, b, g[a, b], fd)
+            g_err = max(g_err, abs(g[a, b] - fd))
+            assert abs(g[a, b] - fd) < (2e-5 if dtype == "complex64" else 1e-7), (a, b, g[a, b], fd)
+        print(f"n={n} d={d} {dtype}: energy error {e_err:.2e}, max gradient error over {len(comps)} components {g_err:.2e}")
     finally:
         tc.set_dtype("complex64")
 
@@ -68,8 +73,10 @@ def test_config3_full_size_complex64_against_complex128():
     """SURVEY 8d config 3 at full size (n = 28, depth 12, one sample of the bench's parameter generator), complex64
     against a complex128 run of the same circuit (the c128 path runs on different kernels: first-generation
     double-precision tile-VM and adjoint sweep, f64 trigonometry).  BASELINE.json's tolerance -- expectation values
-    within 1e-5 -- is applied to EVERY one of the 55 terms <X_i>, <Z_i Z_i+1>; the energy (a sum of 55 of them) to
-    55e-5, the gradient to 1e-4.  The measured maxima are printed."""
+    within 1e-5 -- is applied to EVERY one of the 55 terms <X_i>, <Z_i Z_i+1>.  Energy and gradient are held to 6-20 x the
+    errors MEASURED at this size (profiles/r05c_config3_parity.txt: energy 8.7e-6, gradient against complex128 4.1e-6,
+    against the oracle's central differences 5.1e-7 complex64 / 4.4e-9 complex128): a regression of one order of magnitude
+    fails.  The measured maxima are printed."""
     import torch
     import tcmi as tc
 
@@ -109,7 +116,7 @@ def test_config3_full_size_complex64_against_complex128():
           f"complex128 {np.abs(t128 - tor).max():.2e}; energy error {abs(e64 - float(full['config3_energy'])):.2e} / "
           f"{abs(e128 - float(full['config3_energy'])):.2e}")
     assert np.abs(t128 - tor).max() < 1e-10 and abs(e128 - float(full["config3_energy"])) < 1e-9
-    assert np.abs(t64 - tor).max() < 1e-5 and abs(e64 - float(full["config3_energy"])) < 55e-5
+    assert np.abs(t64 - tor).max() < 1e-5 and abs(e64 - float(full["config3_energy"])) < 5e-5
     assert abs(e128 - (t128[n:].sum() - t128[:n].sum())) < 1e-9      # the energy is the sum of its terms
     # ... and the GRADIENT against the oracle: four components by central differences of oracle.dense's energy (step 1e-4,
     # float64: accurate to ~1e-8; the reference's convention, tests/test_mpscircuit.py:452-457), fixture config3grad
@@ -119,11 +126,11 @@ def test_config3_full_size_complex64_against_complex128():
     e128g = max(abs(g128[int(r), int(q)] - f) for (r, q), f in zip(comps, fd))
     print(f"config 3 full size gradient vs oracle.dense central differences ({len(fd)} components, |g| up to "
           f"{np.abs(fd).max():.3f}): max error complex64 {e64g:.2e}, complex128 {e128g:.2e}")
-    assert e128g < 1e-7, e128g
-    assert e64g < 2e-4, e64g
+    assert e128g < 5e-8, e128g
+    assert e64g < 1e-5, e64g
     assert np.abs(fd).max() > 1e-2
-    assert de < 55e-5, (e64, e128)
-    assert dg < 1e-4, dg
+    assert de < 5e-5, (e64, e128)
+    assert dg < 4e-5, dg
     assert np.abs(g128).max() > 0.1   # the gradient is not trivially small
 
 
@@ -157,7 +164,7 @@ def test_config3_bench_call_vvag_against_per_sample_complex128():
             v, g = vag(tc.backend.convert_to_tensor(params_np[r].astype(np.float64)))
             dv, dg = abs(float(v) - v64[k]), np.abs(tc.backend.numpy(g) - g64[k]).max()
             print(f"config 3 bench call, row {r}: |E64 - E128| {dv:.2e}, max gradient difference {dg:.2e}")
-            assert dv < 55e-5 and dg < 1e-4, (r, dv, dg)
+            assert dv < 5e-5 and dg < 4e-5, (r, dv, dg)      # 6-10 x what is measured (8.7e-6 / 4.1e-6, row 0)
             del v, g
             torch.cuda.empty_cache()
     finally:

@@ -40,6 +40,12 @@ def test_argument_validation_without_gpu():
     assert rc == -1
     assert b"tcmi_run_pass" in lib.tcmi_last_error()
     assert lib.tcmi_init_zero_state(None, 0, 1, 10, 0, None) == -1
+    # the collective: a null communicator / buffer is refused before RCCL is even opened
+    assert lib.tcmi_allreduce_sum(None, None, 4, _lib.TCMI_F64, None) == -1
+    assert b"tcmi_allreduce_sum" in lib.tcmi_last_error()
+    assert lib.tcmi_comm_init(None, 0, 1, None) == -1 and lib.tcmi_comm_destroy(None) == 0
+    # and a generated kernel's launcher refuses a null handle (tcmi_spec_set_flags guards the "src" argument buffer)
+    assert lib.tcmi_spec_set_flags(None, 1) == -1
     with pytest.raises(_lib.TcmiError):
         _lib.check(rc, "tcmi_run_pass")
 
