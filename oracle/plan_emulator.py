@@ -14,7 +14,7 @@ MAGIC = 0x54434D31
 HDR_WORDS = 24
 RR_WORDS = 50
 OP_G1, OP_G2, OP_DIAG, OP_G1M, OP_EXPECT, OP_DIAGC, OP_DIAGB = 1, 2, 3, 4, 5, 6, 7
-OP_DIAGF, OP_DIAGB2, OP_DIAGCW, OP_EXPECT2, OP_XFOLD, OP_DFOLD = 8, 9, 10, 11, 12, 13
+OP_DIAGF, OP_DIAGB2, OP_DIAGCW, OP_EXPECT2, OP_XFOLD, OP_DFOLD, OP_XFOLD2 = 8, 9, 10, 11, 12, 13, 14
 R_MAX = 6
 CONST_FLAG = 1 << 30
 BK_TRIG, BK_COEF, BK_SELECT, BK_PHASE = 1, 2, 5, 6
@@ -547,6 +547,22 @@ def run_adjoint_pass(psi, lam, desc, ctab, ptab_row, gout):
                 regs[1][..., r0] += c_ * f01 * a1
                 regs[1][..., r1] += c_ * f10 * a0
                 gout[gs_] += c_ * np.sum(np.real(np.conj(a0) * f01 * a1))
+                q += 4
+            elif op == OP_XFOLD2:
+                # {14, ja | jb << 8 | ka << 16 | kb << 17, cslot, gslot}: lambda += c P_a P_b psi on the register bits ja, jb
+                # (P = X / Y), energy slot += c / 2 Re <psi| P_a P_b |psi> of the tile
+                w1 = int(d[q + 1])
+                ja, jb, ka, kb = w1 & 0xFF, (w1 >> 8) & 0xFF, (w1 >> 16) & 1, (w1 >> 17) & 1
+                c_, gs_ = float(tab(d[q + 2], 1)[0]), int(dsig[q + 3])
+                pm = {0: np.array([[0, 1], [1, 0]], dtype=np.complex128), 1: np.array([[0, -1j], [1j, 0]], dtype=np.complex128)}
+                a = regs[0].copy()
+                out = np.zeros_like(a)
+                for r_ in rid:
+                    xa, xb = (int(r_) >> ja) & 1, (int(r_) >> jb) & 1
+                    src = int(r_) ^ (1 << ja) ^ (1 << jb)
+                    out[..., int(r_)] = pm[ka][xa, 1 - xa] * pm[kb][xb, 1 - xb] * a[..., src]
+                regs[1] = regs[1] + c_ * out
+                gout[gs_] += 0.5 * c_ * np.sum(np.real(np.conj(a) * out))
                 q += 4
             elif op == OP_G2:
                 ja, kind, jb = int(d[q + 1]) & 0xFF, int(d[q + 1]) >> 8, int(d[q + 2])

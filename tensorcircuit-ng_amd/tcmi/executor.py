@@ -159,6 +159,7 @@ def _shift_gate(g: P.GateRec, pad: int) -> P.GateRec:
 
 
 LIVE_FULL = 0xFFFFFFFF
+FOLD_CACHE_MAX = 8      # fold_setup records kept per compiled circuit (least recently used out first)
 SPARSE_START = os.environ.get("TCMI_SPARSE_START", "1") != "0"
 LIVE_PLAN = SPARSE_START and knob("live_plan", "1") != "0"    # plans chosen by the cost of their live tiles
 NO_ZERO_FILL = knob("no_zero_fill", "1") != "0"   # |0...0> start without the zero fill (CompiledCircuit.zero_bits)
@@ -291,14 +292,17 @@ def pick_adjoint_from_zero(exec_gates, n_exec: int, get_plan):
     return best[:3]
 
 
-def fold_plan_host(exec_gates, n_exec: int, adj0: dict, nparams: int, xw, dw=(), nterms: int = 0):
+def fold_plan_host(exec_gates, n_exec: int, adj0: dict, nparams: int, xw, dw=(), nterms: int = 0, pw=()):
     """Host part of CompiledCircuit.fold_setup (also run by specialize.precompile_circuit, without a GPU): the sweep plan
     of ``adj0`` (record of _adjoint_from_zero: its tile configuration and gate list) recompiled with terms of the Pauli-sum
     cotangent born in registers -- ``xw`` = [(term index, physical bit, weight[, kind])]: single-X (kind 0) / single-Y (kind 1) terms, each folded into the first
     pass whose tile holds its bit; ``dw`` = [(term index, Z mask over physical bits, weight)]: Z-only strings, folded at
-    the start of the sweep.  ``nterms`` = number of terms of the whole sum: when every one of them is folded the first pass
+    the start of the sweep; ``pw`` = [(term index, physical bit a, physical bit b, weight, kind a, kind b)]: strings with
+    exactly two X / Y factors (XX, YY, XY: Heisenberg-type couplings), each folded by the first pass whose tile holds both
+    bits while neither qubit has been touched (pairs that never meet that condition stay with the tile passes).
+    ``nterms`` = number of terms of the whole sum: when every one of them is folded the first pass
     does not load lambda at all (FLAG_LAMBDA_ZERO).  Returns (AdjointPlan, indices of the folded terms, lam_zero) or None
-    when fewer than four X terms qualify or the schedule moved."""
+    when fewer than four X / pair terms qualify or the schedule moved."""
     ap0 = adj0["plan"]
     seen, xs = set(), []
     for item in xw:
@@ -308,19 +312,21 @@ def fold_plan_host(exec_gates, n_exec: int, adj0: dict, nparams: int, xw, dw=(),
             seen.add(bit)
             xs.append((k, bit, 2.0 * float(w), kind))
     ds = [(k, int(zm), 2.0 * float(w)) for k, zm, w in dw if float(w) != 0.0]
-    if len(xs) < 4:
+    ps = [(k, int(ba), int(bb), 2.0 * float(w), int(ka), int(kb)) for k, ba, bb, w, ka, kb in pw if float(w) != 0.0]
+    if len(xs) + len(ps) < 4:
         return None
     kw = dict(factorized=True, drop_constant_head=bool(getattr(ap0, "drop_constant_head", False)),
               fold=[(bit, c, kind) for _, bit, c, kind in xs], fold_param=nparams,
-              dfold=[(zm, c) for _, zm, c in ds] or None)
+              dfold=[(zm, c) for _, zm, c in ds] or None,
+              fold2=[(ba, bb, c, ka, kb) for _, ba, bb, c, ka, kb in ps] or None)
     ap = P.compile_adjoint_plan(exec_gates, n_exec, adj0["cfg"], **kw)
-    if [pp.tile_bits for pp in ap.passes] != [pp.tile_bits for pp in ap0.passes] or len(ap.folded) < 4:
+    if [pp.tile_bits for pp in ap.passes] != [pp.tile_bits for pp in ap0.passes] or len(ap.folded) + len(ap.folded2) < 4:
         return None
-    done = sorted([xs[i][0] for i in ap.folded] + [k for k, _, _ in ds])
+    done = sorted([xs[i][0] for i in ap.folded] + [k for k, _, _ in ds] + [ps[i][0] for i in ap.folded2])
     lam_zero = bool(nterms) and len(done) == nterms
     if lam_zero:
         ap2 = P.compile_adjoint_plan(exec_gates, n_exec, adj0["cfg"], lam_zero=True, **kw)
-        assert ap2.folded == ap.folded
+        assert ap2.folded == ap.folded and ap2.folded2 == ap.folded2
         ap = ap2
     return ap, done, lam_zero
 
@@ -621,8 +627,15 @@ class CompiledCircuit:
             return None
         # keyed by the terms themselves (an id() could be reused by another measurement object after this one is evicted)
         key = (tuple((tuple(t.x), tuple(t.z)) for t in cm.all_terms), tuple(float(w) for w in weights))
-        cache = self.__dict__.setdefault("_fold_cache", {})
-        if key not in cache:
+        # (bounded: every distinct weight vector -- an annealing schedule, re-traced energies -- pins a sweep plan's device
+        # tables and its PassSet; the kernels themselves are shared through the code-object cache, their text only holds
+        # table SLOTS, so an evicted entry costs two host-side plan compilations when it comes back)
+        cache = self.__dict__.setdefault("_fold_cache", OrderedDict())
+        if key in cache:
+            cache.move_to_end(key)
+        else:
+            while len(cache) >= FOLD_CACHE_MAX:
+                cache.popitem(last=False)
             cache[key] = None
             adj0, masks, fracs = self._adjoint_from_zero()
             if adj0["cfg"].gen >= 2 and adj0["plan"].descs and any(m != LIVE_FULL for m in masks):
@@ -632,7 +645,10 @@ class CompiledCircuit:
                       if len(t.x) == 1 and (not t.z or tuple(t.z) == tuple(t.x))]
                 dw = [(k, sum(1 << (n - 1 - q) for q in t.z), float(weights[k])) for k, t in enumerate(cm.all_terms)
                       if not t.x and t.z]
-                res = fold_plan_host(self._exec_gates, n, adj0, self.nparams, xw, dw, len(cm.all_terms))
+                # strings with exactly two X / Y factors and no further Z (XX, YY, XY, YX): a qubit in ``x`` and ``z`` is a Y
+                pw = [(k, n - 1 - t.x[0], n - 1 - t.x[1], float(weights[k]), int(t.x[0] in t.z), int(t.x[1] in t.z))
+                      for k, t in enumerate(cm.all_terms) if len(t.x) == 2 and set(t.z) <= set(t.x)]
+                res = fold_plan_host(self._exec_gates, n, adj0, self.nparams, xw, dw, len(cm.all_terms), pw)
                 if res is not None:
                     ap, done, lam_zero = res
                     skip = frozenset(done)

@@ -48,6 +48,7 @@ OP_DIAGCW = 10  # DIAGC whose table is picked per wave: {10, slot, nsel, m0, m1,
 OP_DIAGF = 8   # backward (adjoint sweep) flush of diagonal terms in table form: see encode_pass
 OP_XFOLD = 12   # reverse sweep, plan-specialised kernels only: {12, j | kind << 8, cslot, gslot}: lambda += c P psi with P = X (kind 0) or Y (kind 1) on register bit j (c = ctab[cslot], real) and gradient slot gslot += c/2 <psi|P|psi> of the tile: the term c/2 P_q of a Pauli-sum cotangent born in registers (compile_adjoint_plan ``fold``)
 OP_DFOLD = 13   # reverse sweep, plan-specialised kernels only: {13, nterms, gslot, (thread-side Z mask over physical bits, register mask, cslot) * nterms}: lambda[r] += D psi[r] with D = sum_t c_t (-1)^{parity(index & zmask_t)} (the Z-only strings of a Pauli-sum cotangent, register part of every mask split off for the round's layout) and gradient slot gslot += 1/2 sum_r D |psi[r]|^2
+OP_XFOLD2 = 14  # reverse sweep, plan-specialised kernels only: {14, ja | jb << 8 | ka << 16 | kb << 17, cslot, gslot}: lambda += c P_a P_b psi with P = X (k = 0) or Y (k = 1) on the register bits ja, jb, and gradient slot gslot += c/2 <psi|P_a P_b|psi> of the tile: a two-factor string (XX, YY, XY: Heisenberg-type couplings) of a Pauli-sum cotangent born in registers (compile_adjoint_plan ``fold2``)
 OP_EXPECT2 = 11  # measurement, Z-only strings grouped by register mask (gen 2): see encode_measure_pass
 FLAG_NOSTORE = 1
 FLAG_LAMBDA_ZERO = 2   # reverse sweep: lambda is not loaded, it starts as zero and is BORN in this pass (OP_XFOLD / OP_DFOLD)
@@ -350,6 +351,7 @@ class Round:
     gates: List[int]   # gate ids executed in this round (program order)
     fold: List[Tuple[int, float, int, int]] = field(default_factory=list)   # (register bit, coefficient, fold index, kind 0 = X / 1 = Y): OP_XFOLD ops at the start of the round
     dfold: List[Tuple[int, float]] = field(default_factory=list)       # (Z mask over physical bits, coefficient): one OP_DFOLD at the start of the round
+    fold2: List[Tuple[int, int, float, int, int, int]] = field(default_factory=list)   # (register bit a, register bit b, coefficient, pair index, kind a, kind b): OP_XFOLD2 ops at the start of the round
 
 
 @dataclass
@@ -1154,6 +1156,11 @@ def encode_pass(gates: List[GateRec], n: int, cfg: PlanConfig, pp: PassPlan, tab
             assert backward
             ops.extend([OP_XFOLD, jf | (int(kd_) << 8), tables.const_real(cf_), tables.fold_slots[fi_]])
             nops += 1
+        for (ja_, jb_, cf_, pi_, ka_, kb_) in getattr(rd, "fold2", []):
+            assert backward
+            ops.extend([OP_XFOLD2, ja_ | (jb_ << 8) | (int(ka_) << 16) | (int(kb_) << 17), tables.const_real(cf_),
+                        tables.fold_slots[("pair", pi_)]])
+            nops += 1
         for gi in rd.gates:
             g = gates[gi]
             if g.is_diag:
@@ -1384,32 +1391,64 @@ def gate_has_param(g: GateRec) -> bool:
 
 
 def fold_rounds(pp: PassPlan, cfg: PlanConfig, xterms: Sequence[Tuple[int, float, int]],
-                dterms: Optional[Sequence[Tuple[int, float]]] = None) -> None:
+                dterms: Optional[Sequence[Tuple[int, float]]] = None,
+                pairs: Optional[Sequence[Tuple[int, int, float, int, int, int]]] = None) -> None:
     """Prepend to one pass of a reverse sweep the rounds in which terms of a Pauli-sum cotangent are BORN in registers:
     ``xterms`` = [(physical bit inside the pass's tile, coefficient c, fold index, kind)] stands for lambda += c P_bit psi
-    (P = X for kind 0, Y for kind 1; and the energy c / 2 <P_bit>), ``dterms`` = [(Z mask over physical bits, coefficient)] for lambda += c Z...Z psi.  The tile's
-    bits that carry an X term are cycled through the register bits by rounds of their own BEFORE any gate of the pass runs,
-    starting in the load layout of the pass's first round (which also takes the diagonal terms: they need no particular
-    layout); the pass then continues with its own rounds.  Costs ceil(#bits / R) exchanges and 24 packed instructions per X
-    term and thread; saves the Pauli-sum passes (tcmi_apply_pauli_sum_tiled) that would have produced those terms."""
+    (P = X for kind 0, Y for kind 1; and the energy c / 2 <P_bit>), ``dterms`` = [(Z mask over physical bits, coefficient)] for lambda += c Z...Z psi,
+    ``pairs`` = [(physical bit a, physical bit b, coefficient, pair index, kind a, kind b)] for lambda += c P_a P_b psi (both
+    bits inside the tile).  The tile's bits that carry an X / Y factor are cycled through the register bits by rounds of
+    their own BEFORE any gate of the pass runs, starting in the load layout of the pass's first round (which also takes the
+    diagonal terms: they need no particular layout); a pair needs BOTH its bits among the register bits of one round, so
+    the groups of a chain of neighbouring pairs overlap by one bit.  The pass then continues with its own rounds.  Costs one
+    exchange per extra round and 24 (pair: 24) packed instructions per term and thread; saves the Pauli-sum passes
+    (tcmi_apply_pauli_sum_tiled) that would have produced those terms."""
     tb_of_phys = {p: i for i, p in enumerate(pp.tile_bits)}
     todo = {tb_of_phys[p]: (i, float(c), int(kd)) for (p, c, i, kd) in xterms}
-    if not (todo or dterms) or not pp.rounds:
+    ptodo = [(tb_of_phys[pa], tb_of_phys[pb], float(c), int(pi), int(ka), int(kb)) for (pa, pb, c, pi, ka, kb) in (pairs or [])]
+    if not (todo or dterms or ptodo) or not pp.rounds:
         return
     T, R = cfg.T, cfg.R
     first = pp.rounds[0]
     r0 = Round(list(first.reg_tb), list(first.thr_tb), [])
-    r0.fold = [(j, todo[b][1], todo[b][0], todo[b][2]) for j, b in enumerate(r0.reg_tb) if b in todo]
+
+    def place(rd, reg):
+        """Every single term and every pair whose bits are register bits of ``reg`` is folded in round ``rd``."""
+        nonlocal ptodo
+        jof = {b: j for j, b in enumerate(reg)}
+        rd.fold = [(jof[b], todo[b][1], todo[b][0], todo[b][2]) for b in reg if b in todo]
+        for b in reg:
+            todo.pop(b, None)
+        rd.fold2 = [(jof[a], jof[b], c, pi, ka, kb) for (a, b, c, pi, ka, kb) in ptodo if a in jof and b in jof]
+        ptodo = [t for t in ptodo if not (t[0] in jof and t[1] in jof)]
+
+    place(r0, r0.reg_tb)
     r0.dfold = [(int(zm), float(c)) for zm, c in (dterms or [])]
     pre = [r0]
-    rest = [b for b in sorted(todo) if b not in set(r0.reg_tb)]
-    while rest:
-        grp, rest = rest[:R], rest[R:]
+    while todo or ptodo:
+        # the next group of <= R tile bits: seeded by the pending pair with the lowest bits (else by the lowest single),
+        # grown by whatever pending pair adds the fewest new bits, then by pending singles, then filled from the top
+        grp: List[int] = []
+        if ptodo:
+            a, b = min((t[0], t[1]) for t in ptodo)
+            grp = [a, b]
+            while True:
+                cand = [(len({t[0], t[1]} - set(grp)), min(t[0], t[1]), t) for t in ptodo if not {t[0], t[1]} <= set(grp)]
+                cand = [c_ for c_ in cand if len(grp) + c_[0] <= R]
+                if not cand:
+                    break
+                _, _, t = min(cand, key=lambda c_: (c_[0], c_[1]))
+                grp += [x for x in (t[0], t[1]) if x not in grp]
+        for b in sorted(todo):
+            if len(grp) >= R:
+                break
+            if b not in grp:
+                grp.append(b)
         fill = [b for b in range(T - 1, -1, -1) if b not in grp]
         reg = sorted(grp + fill[: R - len(grp)])
         thr = [b for b in range(T) if b not in reg]
         rd = Round(reg, thr, [])
-        rd.fold = [(j, todo[b][1], todo[b][0], todo[b][2]) for j, b in enumerate(reg) if b in grp]
+        place(rd, reg)
         pre.append(rd)
     pp.rounds = pre + pp.rounds
 
@@ -1417,7 +1456,7 @@ def fold_rounds(pp: PassPlan, cfg: PlanConfig, xterms: Sequence[Tuple[int, float
 def compile_adjoint_plan(gates: List[GateRec], n: int, cfg: PlanConfig, factorized: bool = False,
                          drop_constant_head: bool = False, fold: Optional[Sequence[Tuple[int, float]]] = None,
                          fold_param: int = 0, dfold: Optional[Sequence[Tuple[int, float]]] = None,
-                         lam_zero: bool = False) -> AdjointPlan:
+                         lam_zero: bool = False, fold2: Optional[Sequence[Tuple[int, int, float, int, int]]] = None) -> AdjointPlan:
     """Plan of the reversed circuit: gates in reverse order, each applied as U^dagger to both psi and
     the cotangent lambda, with one gradient slot per parametrised gate / diagonal term.  Valid for
     unitary gates (psi is un-computed, not stored).  ``factorized``: diagonal terms as OP_DIAGF (the
@@ -1431,7 +1470,8 @@ def compile_adjoint_plan(gates: List[GateRec], n: int, cfg: PlanConfig, factoriz
         rev = rev[: last + 1]
     passes = schedule(rev, n, cfg)
     folded: List[int] = []
-    if fold or dfold:
+    folded2: List[int] = []
+    if fold or dfold or fold2:
         # ``fold``: single-X terms c_i X_i of the cotangent lambda = (sum_i c_i X_i + sum_t d_t Z..Z) psi, ``dfold`` its
         # Z-only strings: born in registers instead of arriving through memory (fold_rounds).  An X term is added by the
         # FIRST pass whose tile holds its bit -- nothing that ran before touches that qubit (a gate needs its qubit in
@@ -1447,9 +1487,18 @@ def compile_adjoint_plan(gates: List[GateRec], n: int, cfg: PlanConfig, factoriz
             xs = [(f_[0], float(f_[1]), i, int(f_[2]) if len(f_) > 2 else 0) for i, f_ in enumerate(fold or [])
                   if f_[0] in new_bits and (n - 1 - f_[0]) not in touched and i not in folded]
             ds = list(dfold) if (dfold and k == 0) else None
-            if xs or ds:
-                fold_rounds(pp, cfg, xs, ds)
+            # ``fold2``: two-factor strings c P_a P_b (physical bits a, b; kinds 0 = X, 1 = Y): folded by the first pass whose
+            # tile holds BOTH bits while neither qubit has been touched -- the same commutation argument for the pair.  A
+            # pass that touches one of the two qubits while the other is outside its tile ends the pair's chances: it is
+            # never folded and stays with the tile passes (the caller reads ``folded2``).
+            tset = set(pp.tile_bits)
+            ps = [(f_[0], f_[1], float(f_[2]), i, int(f_[3]), int(f_[4])) for i, f_ in enumerate(fold2 or [])
+                  if i not in folded2 and f_[0] in tset and f_[1] in tset
+                  and (n - 1 - f_[0]) not in touched and (n - 1 - f_[1]) not in touched]
+            if xs or ds or ps:
+                fold_rounds(pp, cfg, xs, ds, ps)
                 folded += [i for _, _, i, _ in xs]
+                folded2 += [t_[3] for t_ in ps]
             seen_bits |= set(pp.tile_bits)
             for gi in pp.gate_ids:
                 touched |= set(rev[gi].qubits)
@@ -1461,11 +1510,13 @@ def compile_adjoint_plan(gates: List[GateRec], n: int, cfg: PlanConfig, factoriz
         tables.ctab += [0.0] * 8
         tables.shear2 = set(sh2)
         tables.fold_slots = {i: tables.grad_slot(int(fold_param), 1.0) for i in folded}
+        for i in folded2:
+            tables.fold_slots[("pair", i)] = tables.grad_slot(int(fold_param), 1.0)
         if dfold:
             tables.fold_slots["diag"] = tables.grad_slot(int(fold_param), 1.0)
         descs, crossing = [], set()
         for i, pp in enumerate(passes):
-            if i > 0 and any(getattr(rd, "fold", None) for rd in pp.rounds):
+            if i > 0 and any(getattr(rd, "fold", None) or getattr(rd, "fold2", None) for rd in pp.rounds):
                 # A two-shear rotation leaves a REAL factor diag(c, 1/c) pending on psi (its reciprocal on lambda) until the
                 # next phase table carries it.  Across the start of a pass that folds terms into lambda that would be wrong:
                 # the fold adds c X psi_memory to lambda_memory, and the two differ from the true vectors by that factor and
@@ -1487,10 +1538,11 @@ def compile_adjoint_plan(gates: List[GateRec], n: int, cfg: PlanConfig, factoriz
         gslot_factor=np.array(tables.gslot_factor, dtype=np.float64),
     )
     if lam_zero:
-        assert folded or dfold
+        assert folded or dfold or folded2
         descs[0] = descs[0].copy()
         descs[0][6] = descs[0][6] | FLAG_LAMBDA_ZERO
         ap.descs = descs
     ap.folded = sorted(folded)
+    ap.folded2 = sorted(folded2)
     ap.drop_constant_head = bool(drop_constant_head)
     return ap

@@ -1388,6 +1388,63 @@ class _Adjoint(_Forward):
             self.event(sg, f"{c} * ({e}.x - {e}.y)", gslot)
         return q + 4
 
+    def xfold2(self, q: int) -> int:
+        """{OP_XFOLD2, ja | jb << 8 | ka << 16 | kb << 17, cslot, gslot}: lambda[r] += c f(r) psi[r ^ (1 << ja) ^ (1 << jb)] --
+        the two-factor string (c / 2) P_a P_b (P = X or Y) of a Pauli-sum cotangent born in registers (plan.py fold_rounds:
+        both bits are register bits of this round) -- with f(r) = P_a[x_a, 1 - x_a] P_b[x_b, 1 - x_b] in {1, -1, -i, +i},
+        and its energy (c / 2) Re <psi| P_a P_b |psi> as one gradient event: per group of four amplitudes the two partner
+        products (00 <-> 11, 01 <-> 10), real parts for XX / YY, imaginary parts for XY / YX."""
+        w = self.w
+        w1 = int(w[q + 1])
+        ja, jb, ka, kb = w1 & 0xFF, (w1 >> 8) & 0xFF, (w1 >> 16) & 1, (w1 >> 17) & 1
+        cslot, gslot = int(w[q + 2]), _i32(w[q + 3])
+        tab, off = self.slot_ptr(cslot)
+        sg = self.seg(f"{'XY'[ka]}{'XY'[kb]} fold on register bits {ja}, {jb}")
+        c, e = self.fresh("pc"), self.fresh("pe")
+        sg.loads.append(f"  const float {c} = {tab}[{off}];")
+        pm = {0: {(0, 1): 1, (1, 0): 1}, 1: {(0, 1): -1j, (1, 0): 1j}}        # X / Y entries [x, 1 - x]
+        bases = [r for r in range(self.NR) if not (r >> ja) & 1 and not (r >> jb) & 1]
+        p = sg.parts[0]
+        imag = (ka != kb)
+        first = True
+        for b in bases:
+            r00, r11 = b, b | (1 << ja) | (1 << jb)
+            r01, r10 = b | (1 << jb), b | (1 << ja)            # (x_a, x_b) = (0, 1), (1, 0)
+            for (x, y, xa, xb) in ((r00, r11, 0, 0), (r01, r10, 0, 1)):
+                f = pm[ka][(xa, 1 - xa)] * pm[kb][(xb, 1 - xb)]        # the factor of destination x (source y)
+                # contribution of the partner products x <-> y to Re <psi|P|psi>: 2 Re(f conj(a_x) a_y)
+                if not imag:
+                    term = f"{self.A(x, 'a')} * {self.A(y, 'a')}"            # Re(conj(x) y) = sum of the two components
+                    sgn = "" if f.real > 0 else "-"
+                else:
+                    term = f"{self.A(x, 'a')} * {self.A(y, 'a')}.yx"         # Im(conj(x) y) = component x minus component y
+                    sgn = "" if (f * 1j).real > 0 else "-"                 # f = -i: +Im, f = +i: -Im
+                if first:
+                    p.append(f"  v2f {e} = {sgn}({term});")
+                    first = False
+                elif sgn:
+                    p.append(f"  {e} = __builtin_elementwise_fma(-{self.A(x, 'a')}, {term.split(' * ')[1]}, {e});")
+                else:
+                    p.append(f"  {e} = __builtin_elementwise_fma({self.A(x, 'a')}, {term.split(' * ')[1]}, {e});")
+        p = sg.new_part()
+        for b in bases:
+            for xa in (0, 1):
+                for xb in (0, 1):
+                    dst = b | (xa << ja) | (xb << jb)
+                    src = dst ^ (1 << ja) ^ (1 << jb)
+                    f = pm[ka][(xa, 1 - xa)] * pm[kb][(xb, 1 - xb)]
+                    if f == 1:
+                        cf, av = f"v2f{{{c}, {c}}}", self.A(src, 'a')
+                    elif f == -1:
+                        cf, av = f"v2f{{-{c}, -{c}}}", self.A(src, 'a')
+                    elif f == -1j:       # -i (x + i y) = y - i x
+                        cf, av = f"v2f{{{c}, -{c}}}", self.A(src, 'a') + ".yx"
+                    else:                # +i (x + i y) = -y + i x
+                        cf, av = f"v2f{{-{c}, {c}}}", self.A(src, 'a') + ".yx"
+                    p.append(f"  {self.A(dst, 'l')} = __builtin_elementwise_fma({cf}, {av}, {self.A(dst, 'l')});")
+        self.event(sg, f"{c} * ({e}.x {'-' if imag else '+'} {e}.y)", gslot)
+        return q + 4
+
     def dfold(self, q: int) -> int:
         """{OP_DFOLD, nterms, gslot, (thread-side Z mask, register mask, cslot) * nterms}: lambda[r] += D[r] psi[r] with
         D = sum_t c_t (-1)^{parity(index & zmask_t)} -- the Z-only strings of the cotangent 2 sum_t w_t P_t |psi> (c_t = 2 w_t),
@@ -1435,6 +1492,8 @@ class _Adjoint(_Forward):
             return self.xfold(q)
         if op == P.OP_DFOLD:
             return self.dfold(q)
+        if op == P.OP_XFOLD2:
+            return self.xfold2(q)
         raise Unsupported(f"backward op {op}")
 
     def lds_bytes(self) -> int:

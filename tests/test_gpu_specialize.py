@@ -441,6 +441,78 @@ def test_partial_fold_with_y_fields_and_strings_that_stay_in_the_tile_passes(tc6
     assert abs(res["1"][0] - ref) < 2e-4, (res["1"][0], ref)
 
 
+def test_heisenberg_couplings_folded_into_the_sweep(tc64):
+    """the XX + YY + ZZ chain of a Heisenberg model (reference tensorcircuit/quantum.py:2131-2219
+    heisenberg_hamiltonian; templates/measurements.py:156-191) under a traced value_and_grad: the two-factor strings whose
+    qubits meet untouched in a tile of the sweep are born there (OP_XFOLD2), the ZZ strings at its start (OP_DFOLD); the
+    few pairs that straddle two tiles keep going through tcmi_apply_pauli_sum_tiled.  Fold on / off: same energy and
+    gradient, fewer Pauli-sum launches; and against oracle.dense (energy, two central-difference gradient components)."""
+    tc = tc64
+    import torch
+    from tcmi import executor as X
+
+    n, d = 20, 3
+    rng = np.random.default_rng(515)
+    params_np = rng.uniform(0, 2 * np.pi, [2 * d, n])
+    jx, jy, jz = rng.normal(size=n - 1), rng.normal(size=n - 1), rng.normal(size=n - 1)
+
+    def energy(p):
+        c = tc.Circuit(n)
+        W.hea_b(c, n, d, p, zz=tc.gates._zz_matrix)
+        e = 0.0
+        for i in range(n - 1):
+            e += float(jx[i]) * c.expectation_ps(x=[i, i + 1]) + float(jy[i]) * c.expectation_ps(y=[i, i + 1])
+            e += float(jz[i]) * c.expectation_ps(z=[i, i + 1])
+        return tc.backend.real(e)
+
+    def ref(q):
+        psi = dense.run(n, W.hea_b_ops(n, d, q))
+        out = 0.0
+        for i in range(n - 1):
+            out += jx[i] * dense.expectation(psi, n, (G.X, [i]), (G.X, [i + 1])).real
+            out += jy[i] * dense.expectation(psi, n, (G.Y, [i]), (G.Y, [i + 1])).real
+            out += jz[i] * dense.expectation(psi, n, (G.Z, [i]), (G.Z, [i + 1])).real
+        return out
+
+    os.environ["TCMI_SPECIALIZE"] = "1"
+    old = os.environ.get("TCMI_PAULI_FOLD")
+    res = {}
+    try:
+        for flag in ("1", "0"):
+            os.environ["TCMI_PAULI_FOLD"] = flag
+            X._CACHE.clear()
+            f = tc.backend.jit(tc.backend.value_and_grad(energy))
+            p = torch.from_numpy(params_np.astype(np.float32)).cuda()
+            for _ in range(3):
+                v, g = f(p)
+            torch.cuda.synchronize()
+            X.EVENT_LOG = []
+            v, g = f(p)
+            torch.cuda.synchronize()
+            ev = [e for e in X.EVENT_LOG if e[0] == "pauli_sum"]
+            X.EVENT_LOG = None
+            res[flag] = (float(v), g.cpu().numpy().astype(np.float64), sum(e[3] for e in ev), sum(e[4] for e in ev))
+    finally:
+        X.EVENT_LOG = None
+        if old is None:
+            os.environ.pop("TCMI_PAULI_FOLD", None)
+        else:
+            os.environ["TCMI_PAULI_FOLD"] = old
+        X._CACHE.clear()
+    # the fold ran: the tile passes that remain move fewer bytes (fewer strings -> fewer index bits to cover)
+    assert res["1"][3] < res["0"][3] and res["0"][2] >= 2, (res["1"][2:], res["0"][2:])
+    assert abs(res["1"][0] - res["0"][0]) < 3e-5 and np.abs(res["1"][1] - res["0"][1]).max() < 3e-5
+    p64 = params_np.astype(np.float32).astype(np.float64)
+    assert abs(res["1"][0] - ref(p64)) < 5e-5, (res["1"][0], ref(p64))
+    eps = 1e-5
+    for (r, q) in ((1, 2), (4, 17)):
+        pp, pm = p64.copy(), p64.copy()
+        pp[r, q] += eps
+        pm[r, q] -= eps
+        fd = (ref(pp) - ref(pm)) / (2 * eps)
+        assert abs(res["1"][1][r, q] - fd) < 5e-5, ((r, q), res["1"][1][r, q], fd)
+
+
 def test_cut_suffix_reads_its_inputs_from_the_prefix_batch(tc64):
     """tcmi_spec_run_pass_from: the first pass of a cut half-circuit's suffix reads state b as weight[b] * prefix[b >> shift]
     instead of a replicated, weighted copy written by an elementwise launch.  Same state with the fused load on / off
