@@ -1041,6 +1041,61 @@ def statevector_leg(tc, torch, dist, args, rank, world, dev):
     }
 
 
+def heisenberg_leg(tc, torch, args, dev):
+    """The VQE step with a Heisenberg chain as the energy (reference tensorcircuit/quantum.py:2131-2219
+    heisenberg_hamiltonian; templates/measurements.py:156-191): sum_i (XX + YY + ZZ)_{i, i+1} on the HEA-B state of config
+    3's size, one micro-batch through jit(vvag).  Two-factor strings are born in the reverse sweep where their qubits meet
+    untouched in a tile (OP_XFOLD2, executor.fold_setup); the pairs that straddle two tiles keep going through the Pauli-sum
+    tile passes.  Reported next to the same step with the fold off (every string through the tile passes).  One rank."""
+    import numpy as np
+    from tcmi import executor as X
+
+    n, d, B = args.vqe_qubits, args.vqe_depth, max(1, args.vqe_microbatch)
+    params = torch.from_numpy(np.random.default_rng(29).normal(0, 0.1, [B, 2 * d, n]).astype(np.float32)).to(dev)
+
+    def energy(p):
+        c = tc.templates.blocks.example_block(tc.Circuit(n), p, nlayers=d)
+        e = 0.0
+        for i in range(n - 1):
+            e += c.expectation_ps(x=[i, i + 1]) + c.expectation_ps(y=[i, i + 1]) + c.expectation_ps(z=[i, i + 1])
+        return tc.backend.real(e)
+
+    out = {}
+    old = os.environ.get("TCMI_PAULI_FOLD")
+    try:
+        for flag in ("1", "0"):
+            os.environ["TCMI_PAULI_FOLD"] = flag
+            vvag = tc.backend.jit(tc.backend.vvag(energy, argnums=0, vectorized_argnums=0))
+            for _ in range(3):            # staging + validation of the traced pipeline (+ kernels of a hot plan compiled)
+                v, g = vvag(params)
+            torch.cuda.synchronize()
+            X.EVENT_LOG = []
+            t0 = time.perf_counter()
+            v, g = vvag(params)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            ev = summarize_events(X.EVENT_LOG)
+            X.EVENT_LOG = None
+            out[flag] = {"ms_per_sample": el / B * 1e3, "mean_energy": float(v.mean().item()), "grad_norm": float(g.norm().item()),
+                         "kernel_ms": {k: round(x["ms"], 3) for k, x in ev.items()},
+                         "pauli_sum_launches": ev.get("pauli_sum", {}).get("launches", 0),
+                         "pauli_sum_bytes": ev.get("pauli_sum", {}).get("work", 0.0)}
+            del vvag, v, g
+            torch.cuda.empty_cache()
+    finally:
+        X.EVENT_LOG = None
+        if old is None:
+            os.environ.pop("TCMI_PAULI_FOLD", None)
+        else:
+            os.environ["TCMI_PAULI_FOLD"] = old
+    on, off = out["1"], out["0"]
+    return {"workload": f"HEA-B n={n} depth={d}, energy = sum_i (XX + YY + ZZ)_(i,i+1) ({3 * (n - 1)} strings), value_and_grad, "
+                        f"vmap batch {B}, complex64",
+            "ms_per_sample": on["ms_per_sample"], "strings_born_in_the_sweep": on, "every_string_through_tile_passes": off,
+            "speedup_from_the_fold": off["ms_per_sample"] / on["ms_per_sample"],
+            "energy_difference": abs(on["mean_energy"] - off["mean_energy"])}
+
+
 def hea_a_leg(tc, torch, args, dev):
     """SURVEY 8(d) config 2, secondary workload: HEA-A (reference benchmarks/scripts_v2/benchmark_core.py:6-14: H layer, then
     per layer rx on every qubit and a CNOT ladder), same size and call as the headline -- backend.jit(backend.vmap(
@@ -1134,6 +1189,9 @@ def _guard(name, fn, *a, dist=None, need_bytes=0):
     gc.freeze()
     if need_bytes:
         torch.cuda.empty_cache()
+        if dist is not None:          # every rank has let go of the previous leg's memory before anybody looks
+            torch.cuda.synchronize()
+            dist.barrier()
         free, total = torch.cuda.mem_get_info()
         sharers = max(1, int(os.environ.get("TCMI_BENCH_SHARERS", "1")))
         need = need_bytes + (2 << 30)
@@ -1252,6 +1310,7 @@ def main():
     ap.add_argument("--svqa-slices", type=int, default=8)
     ap.add_argument("--svqa-steps", type=int, default=6)
     ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph replay measurement")
+    ap.add_argument("--no-heisenberg", action="store_true", help="skip the Heisenberg-chain variant of the VQE step")
     ap.add_argument("--no-hea-a", action="store_true", help="skip the HEA-A secondary workload of config 2")
     ap.add_argument("--no-traffic-probe", action="store_true", help="skip the rocprofv3 PMC child runs (traffic = null)")
     ap.add_argument("--probe-child", action="store_true", help=argparse.SUPPRESS)
@@ -1465,6 +1524,11 @@ def main():
         lo_, hi_ = D_.shard_range(args.vqe_batch, rank, world)
         vqe = _guard("vqe_step", vqe_leg, tc, torch, dist, args, rank, world, dev, dist=dist,
                      need_bytes=int(4.5 * max(1, min(args.vqe_microbatch, hi_ - lo_)) * (2 ** args.vqe_qubits) * 8))
+    heis = None
+    if args.vqe_qubits and rank == 0 and dist is None and not args.no_heisenberg:
+        torch.cuda.empty_cache()
+        heis = _guard("vqe_heisenberg", heisenberg_leg, tc, torch, args, dev,
+                      need_bytes=int(5.5 * args.vqe_microbatch * (2 ** args.vqe_qubits) * 8))
     # the host-bound leg first: it is the one that feels what earlier legs leave behind (graph memory pools, cached plans)
     svqa = None
     if args.svqa_qubits:
@@ -1591,6 +1655,8 @@ def main():
             out["statevector_n%d" % args.sv_qubits] = sv28
         if vqe is not None:
             out["vqe_step"] = vqe
+        if heis is not None:
+            out["vqe_heisenberg"] = heis
         if rqc is not None:
             out["rqc_amplitude"] = rqc
         if svqa is not None:

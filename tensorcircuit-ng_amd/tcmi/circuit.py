@@ -785,8 +785,7 @@ class Circuit:
             return t is not None and torch.is_tensor(t) and (t.requires_grad or F.is_functorch_wrapped_tensor(t))
 
         if taped(p) or taped(inp):
-            if F.is_batchedtensor(inp) or (p is not None and F.is_batchedtensor(p)):
-                raise NotImplementedError("Backend 'hip' has not implemented vmap over a circuit with matrix-shaped inputs.")
+            # (under backend.vmap the columns of every batch member run as one batch: StateFn.vmap)
             from .functional import _fns
 
             cols = inp.reshape(2**nq, 2**m).T.contiguous()

@@ -72,13 +72,29 @@ def _fns():
 
         @staticmethod
         def vmap(info, in_dims, params, cc, inputs):
-            if in_dims[0] is None:
+            B = info.batch_size
+            in_b = inputs is not None and in_dims[2] is not None
+            if in_dims[0] is None and not in_b:
                 out = StateFn.apply(params, cc, inputs)
-                return out.unsqueeze(0).expand(info.batch_size, *out.shape), 0
-            p = params.movedim(in_dims[0], 0)
-            lead = p.shape[:-1]
-            out = StateFn.apply(p.reshape(-1, p.shape[-1]), cc, inputs)
-            return out.reshape(*lead, out.shape[-1]), 0
+                return out.unsqueeze(0).expand(B, *out.shape), 0
+            # parameters [.., P] and (optionally) input states [.., 2^n], either of them batched: both are lifted to
+            # [B, rows, .] (rows = the columns of a matrix-shaped input, or 1) and run as ONE batch of B * rows states
+            p = params.movedim(in_dims[0], 0) if in_dims[0] is not None else params.unsqueeze(0).expand(B, *params.shape)
+            if inputs is None:
+                lead = p.shape[:-1]
+                out = StateFn.apply(p.reshape(-1, p.shape[-1]), cc, None)
+                return out.reshape(*lead, out.shape[-1]), 0
+            x = inputs.movedim(in_dims[2], 0) if in_b else inputs.unsqueeze(0).expand(B, *inputs.shape)
+            if p.dim() == 2:
+                p = p.unsqueeze(1)
+            if x.dim() == 2:
+                x = x.unsqueeze(1)
+            rows = max(p.shape[1], x.shape[1])
+            p = p.expand(B, rows, p.shape[-1]).reshape(B * rows, p.shape[-1])
+            x = x.expand(B, rows, x.shape[-1]).reshape(B * rows, x.shape[-1]).contiguous()
+            out = StateFn.apply(p, cc, x).reshape(B, rows, -1)
+            single = (params.dim() - (1 if in_dims[0] is not None else 0)) == 1 and (inputs.dim() - (1 if in_b else 0)) == 1
+            return (out[:, 0] if single else out), 0
 
     class StateVjpFn(torch.autograd.Function):
         """(params, psi, g) -> dL/dparams = Re <g | d psi / d params> via the adjoint sweep."""

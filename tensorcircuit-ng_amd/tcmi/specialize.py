@@ -1086,12 +1086,14 @@ def adjoint_opts(cfg) -> dict:
     return {"shear2": bool(cfg.shear2)}
 
 
-def precompile_circuit(c, adjoint: bool = True, forward: bool = True, fold_x=None, fold_z=None, nterms: int = 0) -> dict:
+def precompile_circuit(c, adjoint: bool = True, forward: bool = True, fold_x=None, fold_z=None, nterms: int = 0,
+                       fold_pairs=None) -> dict:
     """Compile (into the cache) the specialised kernels of the plans the executor will choose for circuit ``c``: the
     forward passes and, with ``adjoint``, the reverse sweeps a value_and_grad may run (short and full gate list, last pass
     with and without write-back).  ``fold_x`` = [(qubit, weight)] / ``fold_z`` = [(qubits, weight)] / ``nterms``: also the
     sweep in which those single-X terms and Z-only strings of a Pauli-sum energy of ``nterms`` terms are born (executor.
-    fold_setup).  Host work only -- no GPU needed (hipcc cross-compiles)."""
+    fold_setup); ``fold_pairs`` = [((qubit a, qubit b), (kind a, kind b), weight)]: its two-factor strings (kind 0 = X,
+    1 = Y).  Host work only -- no GPU needed (hipcc cross-compiles)."""
     from . import cons
     from . import executor as X
 
@@ -1134,7 +1136,7 @@ def precompile_circuit(c, adjoint: bool = True, forward: bool = True, fold_x=Non
                 last[6] = last[6] | P.FLAG_NOSTORE
                 out.append(prepare("adjoint", [last], adjoint_opts(acfg))[0] is not None)
             res["adjoint" if not full else ("adjoint_zero_start" if zero else "adjoint_full")] = out
-        if fold_x:
+        if fold_x or fold_pairs:
             plans = {}
 
             def get_plan(full):
@@ -1147,10 +1149,12 @@ def precompile_circuit(c, adjoint: bool = True, forward: bool = True, fold_x=Non
 
             adj0, _m, _f = X.pick_adjoint_from_zero(eg, n_exec, get_plan)
             pad = n_exec - c._nqubits
-            xw = [(k, n_exec - 1 - (int(q) + pad), float(w)) for k, (q, w) in enumerate(fold_x)]
+            xw = [(k, n_exec - 1 - (int(q) + pad), float(w)) for k, (q, w) in enumerate(fold_x or [])]
             dw = [(len(xw) + k, sum(1 << (n_exec - 1 - (int(q) + pad)) for q in qs), float(w))
                   for k, (qs, w) in enumerate(fold_z or [])]
-            fr = X.fold_plan_host(eg, n_exec, adj0, nparams, xw, dw, nterms) if adj0["cfg"].gen >= 2 else None
+            pw = [(len(xw) + len(dw) + k, n_exec - 1 - (int(qa) + pad), n_exec - 1 - (int(qb) + pad), float(w), int(ka), int(kb))
+                  for k, ((qa, qb), (ka, kb), w) in enumerate(fold_pairs or [])]
+            fr = X.fold_plan_host(eg, n_exec, adj0, nparams, xw, dw, nterms, pw) if adj0["cfg"].gen >= 2 else None
             if fr is not None:
                 descs = [np.asarray(d) for d in fr[0].descs]
                 descs[-1] = descs[-1].copy()

@@ -8,11 +8,11 @@ tests/golden/full_size_golden.npz:
             the bench uploads it): the 28 <X_i>, the 27 <Z_i Z_i+1> and the TFIM energy, from oracle.dense (complex128,
             gate by gate on the 4 GiB state; in-place strided updates, oracle/dense.py::apply_gate_inplace).
   config4   the amplitude <0^32|C|0^32> of the bench's 32-qubit 4x8-grid depth-16 random circuit: numpy complex128
-            tensordot chain over a sliced pairwise path, slice by slice.  The PATH (an order of pairs + the sliced indices:
-            no arithmetic) is searched by the product's host-side planner, because the oracle's own greedy order
-            (oracle.tn.greedy_path, used for every n <= 20 cross-check) has a 2^40-element intermediate on this network;
-            the numbers are numpy's.  The same chain is first checked against oracle.tn's own greedy contraction at
-            20 qubits.
+            tensordot chain over a sliced pairwise path, slice by slice.  Path AND sliced indices come from the ORACLE's own
+            tools since round 6 (oracle.sliced.greedy_sliced_path: oracle.tn.greedy_path on the network with indices
+            removed one at a time -- the unsliced greedy order has a 2^38-element intermediate here; two sliced indices
+            bring it to 2^28 at a total cost of 2^43.6, 12 x the product's tree): nothing of the product is imported.
+            The same chain is first checked against oracle.tn's own greedy contraction at 20 qubits.
   config5   MPSCircuit n = 64, chi = 128, one TEBD sweep of 63 random SU(4) gates on the bench's random MPS: the fidelity
             estimate, the norm before / after and the Schmidt spectrum of the middle bond, from oracle.mps (numpy, LAPACK
             SVD).
@@ -154,20 +154,13 @@ def _contract_path(tensors, inputs, path, sliced, values):
     return OS.contract_path(tensors, inputs, path, sliced, values)
 
 
-def _tree(inputs, target):
-    sys.path.insert(0, os.path.join(ROOT, "tensorcircuit-ng_amd"))
-    from tcmi import tn as PT     # the product's HOST-side planner: index sets in, (path, sliced indices) out
+def _tree(inputs, max_width):
+    """(path, sliced indices) from the oracle's own search (oracle/sliced.py); nothing of the product is imported."""
+    from oracle import sliced as OS
 
     size_dict = {e: 2 for s in inputs for e in s}
-    best = None
-    for seed in range(4):
-        tree = PT.ContractionTree.from_path(inputs, [], size_dict, trials=64, seed=seed)
-        tree.slice_to(target)
-        key = tree.total_flops()
-        if best is None or key < best[0]:
-            best = (key, tree)
-    tree = best[1]
-    return [tuple(p) for p in tree.path], list(tree.sliced_inds), tree
+    path, sliced, width, cost = OS.greedy_sliced_path(inputs, size_dict, max_width, log=lambda m: print("  search:", m, flush=True))
+    return path, sliced, (width, cost)
 
 
 def config4():
@@ -175,7 +168,8 @@ def config4():
 
     # the chain against oracle.tn's own greedy contraction at 20 qubits (4 x 5 grid, depth 8)
     ts, ins = _rqc_network(4, 5, 8)
-    path, sliced, tree = _tree(ins, 2**16)
+    path, sliced, _ = _tree(ins, 9)
+    assert sliced, "the 20-qubit check must exercise the slice sum"
     tot = 0.0
     for s_ in range(2 ** len(sliced)):
         vals = [(s_ >> (len(sliced) - 1 - j)) & 1 for j in range(len(sliced))]
@@ -200,9 +194,8 @@ def config4():
     # full size
     t0 = time.time()
     ts, ins = _rqc_network(4, 8, 16)
-    path, sliced, tree = _tree(ins, 2**27)
-    print("tree: slices", 2 ** len(sliced), "log2 flops %.2f" % np.log2(tree.total_flops()), "max size 2^%d" % int(np.log2(tree.max_size())),
-          "search", time.time() - t0, "s", flush=True)
+    path, sliced, (width, cost) = _tree(ins, 28)
+    print("tree: slices", 2 ** len(sliced), "log2 cost %.2f" % cost, "max size 2^%d" % int(width), "search", time.time() - t0, "s", flush=True)
     tot = 0.0
     for s_ in range(2 ** len(sliced)):
         vals = [(s_ >> (len(sliced) - 1 - j)) & 1 for j in range(len(sliced))]
