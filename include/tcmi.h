@@ -58,6 +58,31 @@ int tcmi_init_zero_state(void* state, long long state_stride, int batch, int n, 
 int tcmi_subtree_dp(int k, int W, const unsigned long long* masks, const double* lw, double cap, double alpha,
                     int* split, double* best_full);
 
+/* Host code, no device work: the WHOLE subtree-reconfiguration loop of tcmi/tn.py::reconfigure_path around
+ * tcmi_subtree_dp -- for every internal node (most expensive first) the subtree below it is cut off at `subtree_size`
+ * intermediates (the most expensive internal node expanded first) and re-contracted in the order the dynamic programme
+ * finds cheapest, passes repeated until nothing improves (at most `max_passes` passes, `max_evals` subtree
+ * optimisations).  masks: the `ntensors` leaf index sets (W words each); ssa_pairs: the path in SSA numbering (step s
+ * creates node ntensors + s); lw / cap / alpha as tcmi_subtree_dp.  Result: the internal nodes of the new tree,
+ * nodes_out[i] with children kids_out[2 i], kids_out[2 i + 1] (ids >= 2 ntensors - 1 are nodes created by the rebuilds;
+ * the root keeps its id), *nnodes_out of them (at most max_nodes_out).  Same tree as the Python loop, node for node.
+ * Replaces: cotengra's subtree reconfiguration behind tensorcircuit/cons.py:1168-1190 (`optimizer_reconf`) and
+ * experimental.py `slicing_reconf_opts`. */
+int tcmi_reconfigure_path(int ntensors, int W, const unsigned long long* masks, const int* ssa_pairs, const double* lw,
+                          double cap, double alpha, int subtree_size, int max_passes, int max_evals, int* nodes_out,
+                          int* kids_out, int max_nodes_out, int* nnodes_out);
+
+/* Host code, no device work: greedy slicing of a FIXED contraction tree of dimension-2 indices
+ * (tcmi/tn.py::ContractionTree._slice_fixed): um / km = per step the union of the operand indices / the indices the step
+ * keeps (W words each), outm = the output indices, labels[bit] = the caller's index label (tie-break); indices are removed
+ * one at a time -- always the candidate (of the `max_candidates` highest-scoring indices of the oversize intermediates) that
+ * leaves the smallest (total oversize, flops) -- until every intermediate has at most `target_bits` indices.  Writes the
+ * removed bits in order, their number (-1: not reachable within `max_slices` slices) and sum_steps 2^|union| of the sliced tree.
+ * Replaces: cotengra's slicing (reference experimental.py:936-953 `slicing_opts`). */
+int tcmi_slice_fixed(int nsteps, int W, const unsigned long long* um, const unsigned long long* km,
+                     const unsigned long long* outm, const long long* labels, int target_bits, long long max_slices,
+                     int max_candidates, int* sliced_bits_out, int max_sliced_out, int* nsliced_out, double* flops_out);
+
 /* Host code, no device work: the random-greedy pairwise path of a circuit network (every index has dimension 2 and at most
  * two ends; one end = an output index) -- opt_einsum's RandomGreedy, which the reference reaches through cotengra's
  * "greedy" method (tensorcircuit/cons.py:1168-1190).  masks: ntensors x W 64-bit words (bit e = index e), outmask: the

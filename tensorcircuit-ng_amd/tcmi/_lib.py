@@ -168,6 +168,18 @@ _SIGNATURES = {
          ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_longlong,
          ctypes.c_int, ctypes.c_longlong, ctypes.c_uint, ctypes.c_void_p],
     ),
+    "tcmi_reconfigure_path": (
+        ctypes.c_int,
+        [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.c_void_p, ctypes.c_double,
+         ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+         ctypes.c_int, ctypes.POINTER(ctypes.c_int)],
+    ),
+    "tcmi_slice_fixed": (
+        ctypes.c_int,
+        [ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_longlong),
+         ctypes.c_int, ctypes.c_longlong, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
+         ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)],
+    ),
     "tcmi_comm_load": (ctypes.c_int, [ctypes.c_char_p]),
     "tcmi_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
     "tcmi_comm_init": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]),

@@ -470,6 +470,35 @@ def _native_subtree_dp():
     return _NATIVE_DP[0]
 
 
+_NATIVE_RECONF: List[Any] = []
+_NATIVE_SLICE: List[Any] = []
+
+
+def _native_slice_fixed():
+    """``tcmi_slice_fixed`` of libtcmi (host code), or None: ContractionTree._slice_fixed then runs its Python loop."""
+    if knob("tn_native_slice", "1") == "0":
+        return None
+    if not _NATIVE_SLICE:
+        try:
+            _NATIVE_SLICE.append(_lib.lib().tcmi_slice_fixed)
+        except Exception:  # noqa: BLE001
+            return None
+    return _NATIVE_SLICE[0]
+
+
+
+def _native_reconfigure():
+    """``tcmi_reconfigure_path`` of libtcmi (host code), or None: the Python loop below then runs (same trees)."""
+    if knob("tn_native_reconf", "1") == "0":
+        return None
+    if not _NATIVE_RECONF:
+        try:
+            _NATIVE_RECONF.append(_lib.lib().tcmi_reconfigure_path)
+        except Exception:  # noqa: BLE001
+            return None
+    return _NATIVE_RECONF[0]
+
+
 def reconfigure_path(inputs, output, size_dict, path, subtree_size: int = 8, max_size: Optional[int] = None,
                      max_passes: int = 4, max_evals: int = 4000, alpha: Optional[float] = None):
     """Subtree reconfiguration of a contraction path (the refinement cotengra applies to its trees,
@@ -664,6 +693,21 @@ def reconfigure_path(inputs, output, size_dict, path, subtree_size: int = 8, max
         build(full, True)
         return True
 
+    native_loop = _native_reconfigure() if (native is not None and len(kids) == n - 1) else None
+    if native_loop is not None:
+        # the whole loop in libtcmi (tcmi_reconfigure_path: same frontier, costs, tie-breaking and node numbering)
+        pairs = (ctypes.c_int * (2 * (n - 1)))()
+        for s_ in range(n - 1):
+            pairs[2 * s_], pairs[2 * s_ + 1] = kids[n + s_]
+        leaf = b"".join(idx[i].to_bytes(8 * nwords, "little") for i in range(n))
+        cap_n = 2 * n + 16 * max_evals + 64
+        nodes_c, kids_c, cnt_c = (ctypes.c_int * cap_n)(), (ctypes.c_int * (2 * cap_n))(), ctypes.c_int()
+        rc = native_loop(n, nwords, leaf, pairs, lw_c, cap, float(alpha), int(subtree_size), int(max_passes), int(max_evals),
+                         nodes_c, kids_c, cap_n, ctypes.byref(cnt_c))
+        if rc != 0:
+            raise RuntimeError("tcmi_reconfigure_path failed")
+        kids = {int(nodes_c[i]): (int(kids_c[2 * i]), int(kids_c[2 * i + 1])) for i in range(cnt_c.value)}
+        max_passes = 0
     evals = 0
     for _ in range(max_passes):
         changed = False
@@ -693,13 +737,40 @@ def reconfigure_path(inputs, output, size_dict, path, subtree_size: int = 8, max
             stack.append((v, True))
             stack.append((kids[v][1], False))
             stack.append((kids[v][0], False))
-    for v in order:
+    # position of a tensor in the shrinking list = the number of live slots before its slot (slot i = input i, slot
+    # n + s = the result of step s): a Fenwick tree instead of list.index / list.pop (quadratic: 26 ms per call at 500
+    # tensors, and a path search makes hundreds of calls)
+    del pos
+    nslot = 2 * n
+    fen = [0] * (nslot + 1)
+    for i in range(1, nslot + 1):           # build with the first n slots live
+        fen[i] += 1 if i <= n else 0
+        j = i + (i & -i)
+        if j <= nslot:
+            fen[j] += fen[i]
+    slot = {i: i for i in range(n)}
+
+    def before(sl_: int) -> int:            # live slots with index < sl_
+        t, i = 0, sl_
+        while i > 0:
+            t += fen[i]
+            i -= i & -i
+        return t
+
+    def add(sl_: int, d_: int) -> None:
+        i = sl_ + 1
+        while i <= nslot:
+            fen[i] += d_
+            i += i & -i
+
+    for s_, v in enumerate(order):
         l, r = kids[v]
-        ia, ib = pos.index(l), pos.index(r)
+        ia, ib = before(slot[l]), before(slot[r])
         out_path.append((min(ia, ib), max(ia, ib)))
-        for i in sorted((ia, ib), reverse=True):
-            pos.pop(i)
-        pos.append(v)
+        add(slot[l], -1)
+        add(slot[r], -1)
+        slot[v] = n + s_
+        add(n + s_, 1)
     return out_path
 
 
@@ -832,6 +903,22 @@ class ContractionTree:
             outm = sum(1 << eid[e] for e in out)
             ids = list(self.size_dict)
             it = int(ltarget)
+            native = _native_slice_fixed() if (len(ids) <= 4096 and all(isinstance(e, int) and abs(e) < (1 << 62) for e in ids)) else None
+            if native is not None:
+                # the same loop in libtcmi (tcmi_slice_fixed: same scores, candidate order and choice)
+                W_ = (len(ids) + 63) // 64
+                ub = b"".join(m.to_bytes(8 * W_, "little") for m in um)
+                kb = b"".join(m.to_bytes(8 * W_, "little") for m in km)
+                ob = outm.to_bytes(8 * W_, "little")
+                lab = (ctypes.c_longlong * (64 * W_))(*(list(ids) + [0] * (64 * W_ - len(ids))))
+                cap_ = max(1, int(max_slices).bit_length())
+                bits_c, ns_c, fl_c = (ctypes.c_int * cap_)(), ctypes.c_int(), ctypes.c_double()
+                if native(len(um), W_, ub, kb, ob, lab, it, int(min(max_slices, 1 << 62)), int(max_candidates), bits_c, cap_,
+                          ctypes.byref(ns_c), ctypes.byref(fl_c)) != 0:
+                    raise RuntimeError("tcmi_slice_fixed failed")
+                if ns_c.value < 0:
+                    return None
+                return [ids[bits_c[i]] for i in range(ns_c.value)], 8.0 * fl_c.value * (2 ** ns_c.value)
             slm = 0
             nsl = 1
             while True:

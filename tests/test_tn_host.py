@@ -187,12 +187,15 @@ def test_reconfigure_path_is_valid_and_not_worse(nt, seed):
 
 @pytest.mark.parametrize("nt,seed", [(30, 1), (60, 2), (90, 3)])
 def test_native_subtree_programme_gives_the_python_loops_paths(nt, seed, monkeypatch):
-    """``tcmi_subtree_dp`` (host code of libtcmi) replaces the Python loop over the 3^k bipartitions of a subtree's
-    frontier: same costs, same tie-breaking, hence the identical path -- with and without a size cap, with the bytes
-    weight of the sliced search, with dimensions other than 2 (weighted index sizes), at subtree sizes 6, 8 and 10."""
+    """``tcmi_subtree_dp`` and, since round 6, the whole loop around it (``tcmi_reconfigure_path``: frontier expansion,
+    cost comparison, rebuild, work list) replace the Python loops of reconfigure_path: same costs, same tie-breaking, same
+    node numbering, hence the identical path -- with and without a size cap, with the bytes weight of the sliced search,
+    with dimensions other than 2 (weighted index sizes), at subtree sizes 6, 8 and 10.  (``tn_native_dp = 0`` switches both
+    off: the pure-Python loop is the comparison.)"""
     from tcmi import tn
 
     assert tn._native_subtree_dp() is not None            # the library is built: this is the path the product takes
+    assert tn._native_reconfigure() is not None
     inputs, output, sd = _rand_net(nt, 3, seed)
     sd3 = {k: (3 if k % 5 == 0 else 2) for k in sd}
     p0 = tn.greedy_path(inputs, output, sd)
@@ -204,6 +207,26 @@ def test_native_subtree_programme_gives_the_python_loops_paths(nt, seed, monkeyp
         monkeypatch.setitem(KN.VALUES, "tn_native_dp", "0")
         slow = tn.reconfigure_path(inputs, output, dims, p0, **kw)
         assert fast == slow
+
+
+@pytest.mark.parametrize("nt,seed", [(40, 1), (80, 4)])
+def test_native_slicing_of_a_fixed_tree_picks_the_python_loops_indices(nt, seed, monkeypatch):
+    """``tcmi_slice_fixed`` replaces the Python loop of ContractionTree._slice_fixed (dimension-2 networks): same scores,
+    same candidate order, same choice -- identical sliced indices and flops for several targets, and the same verdict
+    when the target cannot be reached within the slice budget."""
+    from tcmi import tn
+
+    assert tn._native_slice_fixed() is not None
+    inputs, output, sd = _rand_net(nt, 3, seed)
+    tree = tn.ContractionTree.from_path(inputs, output, sd, trials=0, seed=0)
+    width = int(np.log2(tree.max_size()))
+    for target_bits, max_slices in ((width - 1, 1 << 16), (width - 3, 1 << 16), (max(2, width - 6), 1 << 16), (2, 4)):
+        monkeypatch.setitem(KN.VALUES, "tn_native_slice", "1")
+        fast = tree._slice_fixed(list(tree.path), 2**target_bits, max_slices, 12)
+        monkeypatch.setitem(KN.VALUES, "tn_native_slice", "0")
+        slow = tree._slice_fixed(list(tree.path), 2**target_bits, max_slices, 12)
+        assert fast == slow, (target_bits, fast, slow)
+    assert slow is None or len(slow[0]) <= 2          # the last case has a budget of four slices
 
 
 def test_reconfigure_improves_a_poor_path():
