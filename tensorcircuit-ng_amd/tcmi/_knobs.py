@@ -19,6 +19,7 @@ TCMI_TN_TRACE              ``0``: DistributedContractor calls the node function 
 TCMI_TN_VJP                ``0``: sliced value_and_grad on torch's tape instead of the hand-written sweep
 TCMI_TN_SHARD_INV          ``0``: every rank computes all slice-invariant subtrees
 TCMI_TN_SEARCH_SHARD       ``0``: every rank runs the whole path search (no collective in the constructor)
+TCMI_TREE_CACHE            ``0``: searched contraction trees are not kept in / loaded from the cache directory
 TCMI_SVD_PRECOND           ``1``: QR-preconditioned Jacobi SVD (graded spectra)
 TCMI_CHECK_SVD             ``1``: verify every truncated SVD against torch.linalg (debugging)
 TCMI_KNOBS                 experiment knobs, see below

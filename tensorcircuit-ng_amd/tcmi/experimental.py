@@ -27,6 +27,79 @@ Tensor = Any
 _TRACE_SERIAL = itertools.count(1)      # one number per recorded node-function trace, process-wide
 
 
+_SEARCH_DIGEST: List[bytes] = []
+
+
+def _tree_cache_key(inputs, output, size_dict, opts) -> Optional[str]:
+    """Digest of everything a searched tree depends on: the renumbered index structure, the parsed options, and the text
+    of the search itself (tcmi/tn.py + the native helpers' version: any change of the algorithm empties the cache)."""
+    import hashlib
+    import os
+
+    if os.environ.get("TCMI_TREE_CACHE", "1") == "0":
+        return None
+    if not _SEARCH_DIGEST:
+        h = hashlib.blake2b(digest_size=16)
+        with open(tn.__file__, "rb") as fh:
+            h.update(fh.read())
+        from . import specialize as _S
+
+        for f in ("tcmi_host.cpp",):
+            try:
+                with open(os.path.join(_S.CSRC, f), "rb") as fh:
+                    h.update(fh.read())
+            except OSError:
+                pass
+        _SEARCH_DIGEST.append(h.digest())
+    h = hashlib.blake2b(digest_size=16)
+    h.update(_SEARCH_DIGEST[0])
+    h.update(repr((inputs, output, sorted(size_dict.items()), sorted((k, v) for k, v in opts.items()))).encode())
+    return h.hexdigest()
+
+
+def _tree_cache_dirs() -> List[str]:
+    import os
+
+    from . import specialize as _S
+
+    return [os.path.join(d, "trees") for d in _S._cache_dirs()]
+
+
+def _tree_cache_load(key: Optional[str]):
+    import os
+
+    if key is None:
+        return None
+    for d in _tree_cache_dirs():
+        p = os.path.join(d, key + ".pkl")
+        if os.path.exists(p):
+            try:
+                with open(p, "rb") as fh:
+                    rec = pickle.load(fh)
+                if isinstance(rec, dict) and "data" in rec and "stats" in rec:
+                    return rec
+            except Exception:  # noqa: BLE001  (a truncated file: search again)
+                pass
+    return None
+
+
+def _tree_cache_store(key: Optional[str], data, stats) -> None:
+    import os
+
+    if key is None:
+        return
+    for d in _tree_cache_dirs():
+        try:
+            os.makedirs(d, exist_ok=True)
+            tmp = os.path.join(d, f"{key}.{os.getpid()}.tmp")
+            with open(tmp, "wb") as fh:
+                pickle.dump({"data": data, "stats": [dict(st) for st in stats]}, fh)
+            os.replace(tmp, os.path.join(d, key + ".pkl"))       # atomic: a reader sees the whole file or none
+            return
+        except OSError:
+            continue
+
+
 class DistributedContractor:
     last_search: List[Dict[str, Any]] = []     # per-seed record of the most recent path search (bench.py reports it)
 
@@ -117,14 +190,28 @@ class DistributedContractor:
 
         import torch.distributed as dist
 
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        rank = dist.get_rank() if world > 1 else 0
+        # Searched trees are kept (the role of cotengra's ReusableHyperOptimizer, which the reference builds its optimiser
+        # with, experimental.py:934-953: paths cached by network): a tree depends on the network's index structure and
+        # the options only, the search is deterministic, so a second contractor of the same network -- the next run of the
+        # same program -- loads it from the cache directory of the generated kernels instead of searching for seconds
+        # again.  TCMI_TREE_CACHE=0 switches it off.  With several ranks, rank 0 looks it up and broadcasts hit or miss.
+        ckey = _tree_cache_key(inputs, output, size_dict, o)
+        hit = _tree_cache_load(ckey) if rank == 0 else None
+        if world > 1:
+            box = [hit]
+            dist.broadcast_object_list(box, src=0)
+            hit = box[0]
+        if hit is not None:
+            DistributedContractor.last_search = [dict(st, cached=True) for st in hit["stats"]]
+            return hit["data"]
         # With an initialised process group the SEEDS are dealt to the ranks (seed k to rank k mod W): every rank searches
         # its share, one all_gather_object of the objectives picks the winner (smallest objective, ties to the seed that
         # comes first in the list: what the serial loop keeps) and the winner's rank broadcasts the tree -- with one seed
         # this is the reference's rank-0 search + ``broadcast_py_object`` (experimental.py:850-857), with 8 seeds on 8
         # ranks the Python-bound search takes the time of one seed instead of eight on every rank.  TCMI_TN_SEARCH_SHARD=0:
         # every rank runs the whole deterministic search locally (no collective in the constructor).
-        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        rank = dist.get_rank() if world > 1 else 0
         shard = world > 1 and os.environ.get("TCMI_TN_SEARCH_SHARD", "1") != "0"
         seeds = list(enumerate(o["seeds"]))
         best, stats = None, []
@@ -144,7 +231,10 @@ class DistributedContractor:
                 best = ((key, pos), tree)
         if not shard:
             DistributedContractor.last_search = stats
-            return best[1].to_data()
+            data = best[1].to_data()
+            if rank == 0:
+                _tree_cache_store(ckey, data, stats)
+            return data
         gathered = [None] * world
         dist.all_gather_object(gathered, (None if best is None else best[0], stats))
         cands = [(kp, r) for r, (kp, _) in enumerate(gathered) if kp is not None]
@@ -153,6 +243,8 @@ class DistributedContractor:
                                                    key=lambda st: o["seeds"].index(st["seed"]))
         box = [best[1].to_data() if rank == winner else None]
         dist.broadcast_object_list(box, src=winner)
+        if rank == 0:
+            _tree_cache_store(ckey, box[0], DistributedContractor.last_search)
         return box[0]
 
     @staticmethod

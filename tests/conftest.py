@@ -77,8 +77,10 @@ def pytest_sessionstart(session):
         for f in BENCH_OUT.values():
             if os.path.exists(f):
                 os.remove(f)
-        _run_bench("w1", 1, {}, 900)
-        _run_bench("w2", 2, {"TCMI_BENCH_OVERSUBSCRIBE": "1"}, 900)
+        # (TCMI_TREE_CACHE=0: both worlds SEARCH their contraction trees -- the seeds dealt to the ranks are part of what is
+        # compared; the RCCL run below goes through the tree cache)
+        _run_bench("w1", 1, {"TCMI_TREE_CACHE": "0"}, 900)
+        _run_bench("w2", 2, {"TCMI_BENCH_OVERSUBSCRIBE": "1", "TCMI_TREE_CACHE": "0"}, 900)
         _run_bench("dead", 2, {"TCMI_BENCH_OVERSUBSCRIBE": "1", "TCMI_BENCH_KILL_RANK": "1"}, 300)
         # a device too full for the legs (here: pretended, every rank is told it shares its device with 10^6 others): the
         # ranks agree to skip them; and an exception inside a leg on ONE rank: the job ends, non-zero, instead of hanging

@@ -119,6 +119,7 @@ def _search_worker(rank, world, port, q):
         return nodes
 
     opts = {"seed": [0, 1, 2], "max_repeats": 4, "slicing_opts": {"target_size": 8}}
+    os.environ["TCMI_TREE_CACHE"] = "0"          # every call below has to SEARCH (the cache has its own test)
     os.environ["TCMI_TN_SEARCH_SHARD"] = "0"
     serial = DC._get_tree_data(nodes_fn, None, opts)           # before the group exists: the plain serial search
     serial_stats = list(DC.last_search)

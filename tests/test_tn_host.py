@@ -472,3 +472,39 @@ def test_native_greedy_path_equals_the_python_loop(monkeypatch):
             b = tn.greedy_path(inputs, output, sd, temperature=temp, alpha=alpha, rng=np.random.default_rng(case))
             assert a == b, (case, temp, alpha)
             assert len(a) == len(inputs) - 1
+
+
+def test_searched_trees_are_cached_by_network_and_options(tmp_path, monkeypatch):
+    """DistributedContractor keeps searched trees (cotengra's ReusableHyperOptimizer in the reference's constructor,
+    experimental.py:934-953): the second contractor of the same network and options loads the tree instead of searching;
+    other options, another network or TCMI_TREE_CACHE=0 search again; a truncated file is ignored."""
+    from tcmi import specialize as S, tn
+    from tcmi import experimental as E
+
+    monkeypatch.setattr(S, "CACHE_DIR", str(tmp_path / "plancache"))
+    monkeypatch.setattr(S, "_user_cache_dir", lambda: None)
+    monkeypatch.delenv("TCMI_TREE_CACHE", raising=False)
+    nodes, _ = _closed_network(6, 3, 5, bits=[0] * 6)
+    nodes2, _ = _closed_network(6, 3, 6, bits=[0] * 6)          # the same structure (other gate values): the same key
+    nodes3, _ = _closed_network(6, 4, 5, bits=[0] * 6)          # another structure
+    opts = {"seed": [0, 1], "max_repeats": 4, "slicing_opts": {"target_size": 8}}
+    DC = E.DistributedContractor
+    d1 = DC._get_tree_data(lambda _: nodes, None, opts)
+    assert not DC.last_search[0].get("cached") and len(DC.last_search) == 2
+    files = list((tmp_path / "plancache" / "trees").glob("*.pkl"))
+    assert len(files) == 1
+    d2 = DC._get_tree_data(lambda _: nodes2, None, opts)
+    assert DC.last_search[0].get("cached") and [s_["seed"] for s_ in DC.last_search] == [0, 1] and d2 == d1
+    DC._get_tree_data(lambda _: nodes, None, dict(opts, max_repeats=5))
+    assert not DC.last_search[0].get("cached")
+    DC._get_tree_data(lambda _: nodes3, None, opts)
+    assert not DC.last_search[0].get("cached")
+    assert len(list((tmp_path / "plancache" / "trees").glob("*.pkl"))) == 3
+    monkeypatch.setenv("TCMI_TREE_CACHE", "0")
+    DC._get_tree_data(lambda _: nodes, None, opts)
+    assert not DC.last_search[0].get("cached")
+    monkeypatch.delenv("TCMI_TREE_CACHE")
+    files[0].write_bytes(b"\x80")                                  # a truncated pickle
+    d3 = DC._get_tree_data(lambda _: nodes, None, opts)
+    assert not DC.last_search[0].get("cached") and d3 == d1        # searched again (and stored again)
+    assert tn.ContractionTree.from_data(d3).nslices >= 1
