@@ -169,7 +169,7 @@ class DistributedContractor:
         return 2**28 if ts is None else ts
 
     @staticmethod
-    def _get_tree_data(nodes_fn, params, cotengra_options) -> Dict[str, Any]:
+    def _get_tree_data(nodes_fn, params, cotengra_options, collective: bool = True) -> Dict[str, Any]:
         o = DistributedContractor._parse_options(cotengra_options)
         nodes = nodes_fn(params)
         inputs, output, size_dict = tn.get_tn_info(nodes)
@@ -190,7 +190,8 @@ class DistributedContractor:
 
         import torch.distributed as dist
 
-        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        # ``collective=False`` (find_path: typically called by ONE process): no collective, the whole search locally
+        world = dist.get_world_size() if (collective and dist.is_available() and dist.is_initialized()) else 1
         rank = dist.get_rank() if world > 1 else 0
         # Searched trees are kept (the role of cotengra's ReusableHyperOptimizer, which the reference builds its optimiser
         # with, experimental.py:934-953: paths cached by network): a tree depends on the network's index structure and
@@ -250,7 +251,7 @@ class DistributedContractor:
     @staticmethod
     def find_path(nodes_fn: Callable[[Any], List[tn.Node]], params: Any,
                   cotengra_options: Optional[Dict[str, Any]] = None, filepath: Optional[str] = None) -> Dict[str, Any]:
-        data = DistributedContractor._get_tree_data(nodes_fn, params, cotengra_options)
+        data = DistributedContractor._get_tree_data(nodes_fn, params, cotengra_options, collective=False)
         if filepath is not None:
             with open(filepath, "wb") as f:
                 pickle.dump(data, f)
