@@ -663,8 +663,9 @@ def svqa_network(tc, n, d):
     return nodes_fn
 
 
-def svqa_search_options(slices):
-    return {"slicing_opts": {"target_slices": slices}, "max_repeats": 32, "minimize": "combo"}
+def svqa_search_options(slices, seeds=1):
+    return {"slicing_opts": {"target_slices": slices}, "max_repeats": 32, "minimize": "combo",
+            **({"seed": list(range(seeds))} if seeds > 1 else {})}
 
 
 def presearch_trees(tc, args=None):
@@ -676,7 +677,8 @@ def presearch_trees(tc, args=None):
     import numpy as np
     from tcmi.experimental import DistributedContractor as DC
 
-    ap = {"rqc_depth": 16, "rqc_log2_target": 27, "rqc_seeds": 8, "svqa_qubits": 30, "svqa_depth": 8, "svqa_slices": 8}
+    ap = {"rqc_depth": 16, "rqc_log2_target": 27, "rqc_seeds": 8, "svqa_qubits": 30, "svqa_depth": 8, "svqa_slices": 8,
+          "svqa_seeds": 1}
     if args is not None:
         ap.update({k: getattr(args, k) for k in ap if hasattr(args, k)})
     out = {}
@@ -687,7 +689,7 @@ def presearch_trees(tc, args=None):
     n, d = ap["svqa_qubits"], ap["svqa_depth"]
     pt = tc.backend.convert_to_tensor(np.random.default_rng(5).uniform(0.2, 1.2, [n, d, 2]).astype(np.float32))
     t0 = time.perf_counter()
-    DC._get_tree_data(svqa_network(tc, n, d), pt, svqa_search_options(ap["svqa_slices"]))
+    DC._get_tree_data(svqa_network(tc, n, d), pt, svqa_search_options(ap["svqa_slices"], ap["svqa_seeds"]))
     out["svqa_s"] = round(time.perf_counter() - t0, 2)
     out["svqa_cached"] = bool(DC.last_search and DC.last_search[0].get("cached"))
     return out
@@ -839,7 +841,7 @@ def sliced_vqa_leg(tc, torch, dist, args, rank, world):
 
     nodes_fn = svqa_network(tc, n, d)
     t0 = time.perf_counter()
-    dc = DistributedContractor(nodes_fn, pt, cotengra_options=svqa_search_options(S))
+    dc = DistributedContractor(nodes_fn, pt, cotengra_options=svqa_search_options(S, args.svqa_seeds))
     search_s = time.perf_counter() - t0
 
     def sync():
@@ -1359,6 +1361,7 @@ def main():
     ap.add_argument("--svqa-depth", type=int, default=8)
     ap.add_argument("--svqa-slices", type=int, default=8)
     ap.add_argument("--svqa-steps", type=int, default=6)
+    ap.add_argument("--svqa-seeds", type=int, default=1, help="sliced-VQA leg: seeds of the path hyper-search")
     ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph replay measurement")
     ap.add_argument("--no-heisenberg", action="store_true", help="skip the Heisenberg-chain variant of the VQE step")
     ap.add_argument("--no-hea-a", action="store_true", help="skip the HEA-A secondary workload of config 2")
