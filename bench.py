@@ -683,13 +683,15 @@ def presearch_trees(tc, args=None):
         ap.update({k: getattr(args, k) for k in ap if hasattr(args, k)})
     out = {}
     t0 = time.perf_counter()
-    DC._get_tree_data(rqc_network(tc, ap["rqc_depth"]), None, rqc_search_options(ap["rqc_log2_target"], ap["rqc_seeds"]))
+    # (build hosts have no GPU context: the seeds of a hyper-search run on a process pool, cotengra's ``parallel``)
+    DC._get_tree_data(rqc_network(tc, ap["rqc_depth"]), None,
+                      dict(rqc_search_options(ap["rqc_log2_target"], ap["rqc_seeds"]), parallel=True))
     out["rqc_s"] = round(time.perf_counter() - t0, 2)
     out["rqc_cached"] = bool(DC.last_search and DC.last_search[0].get("cached"))
     n, d = ap["svqa_qubits"], ap["svqa_depth"]
     pt = tc.backend.convert_to_tensor(np.random.default_rng(5).uniform(0.2, 1.2, [n, d, 2]).astype(np.float32))
     t0 = time.perf_counter()
-    DC._get_tree_data(svqa_network(tc, n, d), pt, svqa_search_options(ap["svqa_slices"], ap["svqa_seeds"]))
+    DC._get_tree_data(svqa_network(tc, n, d), pt, dict(svqa_search_options(ap["svqa_slices"], ap["svqa_seeds"]), parallel=True))
     out["svqa_s"] = round(time.perf_counter() - t0, 2)
     out["svqa_cached"] = bool(DC.last_search and DC.last_search[0].get("cached"))
     return out

@@ -30,6 +30,26 @@ _TRACE_SERIAL = itertools.count(1)      # one number per recorded node-function 
 _SEARCH_DIGEST: List[bytes] = []
 
 
+def _search_one_seed(job):
+    """One seed of the hyper-search (module level: also the worker of the process pool of ``parallel``): random-greedy
+    trials, slicing, reconfiguration; returns (objective, position in the seed list, statistics, tree data)."""
+    import time as _time
+
+    inputs, output, size_dict, o, pos, seed, rank = job
+    t0 = _time.perf_counter()
+    tree = tn.ContractionTree.from_path(inputs, output, size_dict, trials=o["max_repeats"], seed=seed)
+    tree.minimize = o["minimize"]
+    if o["target_size"] is not None:
+        tree.slice_to(o["target_size"])
+    if o["target_slices"] is not None:
+        tree.slice_to_slices(o["target_slices"])
+    obj = tree.objective()
+    key = tuple(float(x) for x in (obj if isinstance(obj, tuple) else (obj,)))
+    stat = {"seed": seed, "objective": list(key), "model_time_s": tree.model_time(), "nslices": int(tree.nslices),
+            "search_s": round(_time.perf_counter() - t0, 2), "rank": rank}
+    return key, pos, stat, tree.to_data()
+
+
 def _tree_cache_key(inputs, output, size_dict, opts) -> Optional[str]:
     """Digest of everything a searched tree depends on: the renumbered index structure, the parsed options, and the text
     of the search itself (tcmi/tn.py + the native helpers' version: any change of the algorithm empties the cache)."""
@@ -53,7 +73,7 @@ def _tree_cache_key(inputs, output, size_dict, opts) -> Optional[str]:
         _SEARCH_DIGEST.append(h.digest())
     h = hashlib.blake2b(digest_size=16)
     h.update(_SEARCH_DIGEST[0])
-    h.update(repr((inputs, output, sorted(size_dict.items()), sorted((k, v) for k, v in opts.items()))).encode())
+    h.update(repr((inputs, output, sorted(size_dict.items()), sorted((k, v) for k, v in opts.items() if k != "parallel"))).encode())
     return h.hexdigest()
 
 
@@ -155,8 +175,11 @@ class DistributedContractor:
                                           f"random-greedy + subtree reconfiguration (methods=['greedy'])")
         # execution hints without an effect on the result: every rank derives the same tree in-process (deterministic
         # search, native subtree programme), so there is nothing to parallelise over and nothing to show
-        for k in ("parallel", "progbar"):
-            opts.pop(k, None)
+        # ``parallel`` (cotengra: search trials on a process pool): the SEEDS of the hyper-search on a process pool, where a
+        # pool can be started (no GPU context in this process yet: build hosts, offline find_path); ``progbar``: nothing to show
+        par = opts.pop("parallel", False)
+        out["parallel"] = 0 if not par else (int(par) if not isinstance(par, bool) else -1)
+        opts.pop("progbar", None)
         if opts:
             raise NotImplementedError(f"Backend 'hip' has not implemented the cotengra options {sorted(opts)}")
         if out["target_size"] is None and out["target_slices"] is None:
@@ -215,24 +238,29 @@ class DistributedContractor:
         # every rank runs the whole deterministic search locally (no collective in the constructor).
         shard = world > 1 and os.environ.get("TCMI_TN_SEARCH_SHARD", "1") != "0"
         seeds = list(enumerate(o["seeds"]))
+        mine = seeds[rank::world] if shard else seeds
+        jobs = [(inputs, output, size_dict, {k: o[k] for k in ("max_repeats", "minimize", "target_size", "target_slices")},
+                 pos, seed, rank) for pos, seed in mine]
+        results = None
+        if o.get("parallel") and world == 1 and len(jobs) > 1:
+            import torch
+
+            if not torch.cuda.is_initialized():          # (a process that holds a GPU context starts no children here)
+                import multiprocessing as mp
+
+                nproc = min(len(jobs), (os.cpu_count() or 1) if o["parallel"] < 0 else o["parallel"])
+                with mp.get_context("spawn").Pool(nproc) as pool:
+                    results = pool.map(_search_one_seed, jobs)
+        if results is None:
+            results = [_search_one_seed(j) for j in jobs]
         best, stats = None, []
-        for pos, seed in (seeds[rank::world] if shard else seeds):
-            t0 = _time.perf_counter()
-            tree = tn.ContractionTree.from_path(inputs, output, size_dict, trials=o["max_repeats"], seed=seed)
-            tree.minimize = o["minimize"]
-            if o["target_size"] is not None:
-                tree.slice_to(o["target_size"])
-            if o["target_slices"] is not None:
-                tree.slice_to_slices(o["target_slices"])
-            obj = tree.objective()
-            key = tuple(float(x) for x in (obj if isinstance(obj, tuple) else (obj,)))
-            stats.append({"seed": seed, "objective": list(key), "model_time_s": tree.model_time(),
-                          "nslices": int(tree.nslices), "search_s": round(_time.perf_counter() - t0, 2), "rank": rank})
+        for key, pos, stat, data_ in results:
+            stats.append(stat)
             if best is None or (key, pos) < best[0]:
-                best = ((key, pos), tree)
+                best = ((key, pos), data_)
         if not shard:
             DistributedContractor.last_search = stats
-            data = best[1].to_data()
+            data = best[1]
             if rank == 0:
                 _tree_cache_store(ckey, data, stats)
             return data
@@ -242,7 +270,7 @@ class DistributedContractor:
         winner = min(cands)[1]
         DistributedContractor.last_search = sorted((st for _, sts in gathered for st in sts),
                                                    key=lambda st: o["seeds"].index(st["seed"]))
-        box = [best[1].to_data() if rank == winner else None]
+        box = [best[1] if rank == winner else None]
         dist.broadcast_object_list(box, src=winner)
         if rank == 0:
             _tree_cache_store(ckey, box[0], DistributedContractor.last_search)

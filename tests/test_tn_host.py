@@ -503,7 +503,14 @@ def test_searched_trees_are_cached_by_network_and_options(tmp_path, monkeypatch)
     monkeypatch.setenv("TCMI_TREE_CACHE", "0")
     DC._get_tree_data(lambda _: nodes, None, opts)
     assert not DC.last_search[0].get("cached")
+    # cotengra's ``parallel``: the seeds on a process pool (no GPU context in this process) -- the same tree, and the same
+    # cache key as the serial search
+    d_par = DC._get_tree_data(lambda _: nodes, None, dict(opts, parallel=2))
+    assert d_par == d1 and [s_["seed"] for s_ in DC.last_search] == [0, 1]
+    assert E._tree_cache_key([[0]], [], {0: 2}, DC._parse_options(opts)) is None      # switched off: no key at all
     monkeypatch.delenv("TCMI_TREE_CACHE")
+    assert E._tree_cache_key([[0]], [], {0: 2}, DC._parse_options(opts)) == \
+        E._tree_cache_key([[0]], [], {0: 2}, DC._parse_options(dict(opts, parallel=True)))
     files[0].write_bytes(b"\x80")                                  # a truncated pickle
     d3 = DC._get_tree_data(lambda _: nodes, None, opts)
     assert not DC.last_search[0].get("cached") and d3 == d1        # searched again (and stored again)
