@@ -663,9 +663,9 @@ def svqa_network(tc, n, d):
     return nodes_fn
 
 
-def svqa_search_options(slices, seeds=1):
-    return {"slicing_opts": {"target_slices": slices}, "max_repeats": 32, "minimize": "combo",
-            **({"seed": list(range(seeds))} if seeds > 1 else {})}
+def svqa_search_options(slices, seeds=1, seed0=0, minimize="combo"):
+    return {"slicing_opts": {"target_slices": slices}, "max_repeats": 32, **({"minimize": minimize} if minimize else {}),
+            **({"seed": list(range(seed0, seed0 + seeds))} if (seeds > 1 or seed0) else {})}
 
 
 def presearch_trees(tc, args=None):
@@ -843,7 +843,7 @@ def sliced_vqa_leg(tc, torch, dist, args, rank, world):
 
     nodes_fn = svqa_network(tc, n, d)
     t0 = time.perf_counter()
-    dc = DistributedContractor(nodes_fn, pt, cotengra_options=svqa_search_options(S, args.svqa_seeds))
+    dc = DistributedContractor(nodes_fn, pt, cotengra_options=svqa_search_options(S, args.svqa_seeds, args.svqa_seed0, args.svqa_minimize or None))
     search_s = time.perf_counter() - t0
 
     def sync():
@@ -880,6 +880,7 @@ def sliced_vqa_leg(tc, torch, dist, args, rank, world):
         **({"per_rank_ms_per_value_and_grad": per_rank_ms, "allreduce_us": ar_us} if dist is not None else {}),
         "path_search_s": round(search_s, 2), "staging_s": round(staging, 2),
         "path_search_cached": bool(DistributedContractor.last_search and DistributedContractor.last_search[0].get("cached")),
+        "path_search": [{k_: x.get(k_) for k_ in ("seed", "objective", "model_time_s", "search_s")} for x in DistributedContractor.last_search],
         "path_search_uncached_s": round(sum(x.get("search_s", 0.0) for x in DistributedContractor.last_search), 2),
         "value": float(v), "grad_norm": float(g.norm()),
     }
@@ -1364,6 +1365,8 @@ def main():
     ap.add_argument("--svqa-slices", type=int, default=8)
     ap.add_argument("--svqa-steps", type=int, default=6)
     ap.add_argument("--svqa-seeds", type=int, default=1, help="sliced-VQA leg: seeds of the path hyper-search")
+    ap.add_argument("--svqa-seed0", type=int, default=0, help="sliced-VQA leg: first seed")
+    ap.add_argument("--svqa-minimize", default="combo", help="sliced-VQA leg: cotengra `minimize` ('' = the engine's time model)")
     ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph replay measurement")
     ap.add_argument("--no-heisenberg", action="store_true", help="skip the Heisenberg-chain variant of the VQE step")
     ap.add_argument("--no-hea-a", action="store_true", help="skip the HEA-A secondary workload of config 2")
