@@ -17,7 +17,7 @@ def pytest_configure(config):
 BENCH_SMALL = ["--steps", "2", "--warmup", "1", "--qubits", "16", "--depth", "4", "--batch", "4", "--global-batch", "4",
                "--vqe-qubits", "16", "--vqe-depth", "3", "--vqe-batch", "4", "--vqe-microbatch", "2", "--vqe-steps", "1",
                "--rqc-depth", "8", "--rqc-log2-target", "20", "--rqc-seeds", "2", "--svqa-qubits", "12", "--svqa-depth", "2",
-               "--svqa-slices", "4", "--svqa-steps", "1", "--mps-qubits", "0", "--sv-qubits", "16", "--sv-depth", "3", "--sv-batch", "4",
+               "--svqa-slices", "4", "--svqa-steps", "1", "--svqa-seeds", "1", "--mps-qubits", "0", "--sv-qubits", "16", "--sv-depth", "3", "--sv-batch", "4",
                "--sv-microbatch", "2", "--sv-steps", "1", "--no-cpu-baseline", "--no-traffic-probe"]
 BENCH_OUT = {k: os.path.join(ROOT, ".pytest_cache", f"bench_{k}.json") for k in ("w1", "w2", "dead", "nccl1", "full", "raise")}
 
