@@ -50,6 +50,43 @@ def _search_one_seed(job):
     return key, pos, stat, tree.to_data()
 
 
+def _search_seeds_in_subprocesses(jobs, nproc: int):
+    """``_search_one_seed`` of every job in fresh interpreter processes, ``nproc`` at a time (plain subprocesses fed through
+    pipes, not a multiprocessing pool: a pool's children re-import the caller's main module, which a library must not
+    assume is import-safe).  Falls back to None (the caller searches serially) if a child fails."""
+    import subprocess
+    import sys
+
+    code = ("import sys, pickle\n"
+            "sys.path[:0] = pickle.loads(bytes.fromhex(sys.argv[1]))\n"
+            "from tcmi.experimental import _search_one_seed\n"
+            "job = pickle.load(sys.stdin.buffer)\n"
+            "sys.stdout.buffer.write(pickle.dumps(_search_one_seed(job)))\n")
+    paths = pickle.dumps([p for p in sys.path if p]).hex()
+    out: List[Any] = [None] * len(jobs)
+    pending = list(enumerate(jobs))
+    running: List[Any] = []
+    try:
+        while pending or running:
+            while pending and len(running) < max(1, nproc):
+                i, job = pending.pop(0)
+                pr = subprocess.Popen([sys.executable, "-c", code, paths], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                      stderr=subprocess.DEVNULL)
+                pr.stdin.write(pickle.dumps(job))
+                pr.stdin.close()
+                running.append((i, pr))
+            i, pr = running.pop(0)
+            data = pr.stdout.read()
+            if pr.wait() != 0:
+                raise RuntimeError("seed worker failed")
+            out[i] = pickle.loads(data)
+        return out
+    except Exception:  # noqa: BLE001
+        for _, pr in running:
+            pr.kill()
+        return None
+
+
 def _tree_cache_key(inputs, output, size_dict, opts) -> Optional[str]:
     """Digest of everything a searched tree depends on: the renumbered index structure, the parsed options, and the text
     of the search itself (tcmi/tn.py + the native helpers' version: any change of the algorithm empties the cache)."""
@@ -246,11 +283,8 @@ class DistributedContractor:
             import torch
 
             if not torch.cuda.is_initialized():          # (a process that holds a GPU context starts no children here)
-                import multiprocessing as mp
-
                 nproc = min(len(jobs), (os.cpu_count() or 1) if o["parallel"] < 0 else o["parallel"])
-                with mp.get_context("spawn").Pool(nproc) as pool:
-                    results = pool.map(_search_one_seed, jobs)
+                results = _search_seeds_in_subprocesses(jobs, nproc)
         if results is None:
             results = [_search_one_seed(j) for j in jobs]
         best, stats = None, []
