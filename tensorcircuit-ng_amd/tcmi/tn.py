@@ -1636,7 +1636,8 @@ class ContractionTree:
                     shared = dict(st_inv)
                     B = None
                     if knob("tn_batch", "1") != "0" and all(t.dtype == torch.complex64 for t in raw):
-                        B = SmallBatch(raw[0].device, 6 * len(steps) + 16)
+                        # (descriptors: 3 per invariant step; 3 per slice-dependent step and per-slice graph instance)
+                        B = SmallBatch(raw[0].device, 3 * len(steps) + 3 * max(2, TN_STREAMS_SMALL) * len(steps) + 16)
                     g_a = None
                     big = gbig = None
                     views: Dict[int, Any] = {}
@@ -1700,8 +1701,15 @@ class ContractionTree:
                     # accumulators and memory pool) for a second stream: a slice's sweep is a chain of launches most of
                     # which cannot fill the chip (41 tile-kernel steps of ~30 us per slice backward), two slices side by
                     # side overlap them -- as contract_slices does for the forward-only replay
-                    two = None
+                    # ... and, when the slices are small (largest intermediate <= 2^22 elements: none of their kernels fills
+                    # the chip), up to TN_STREAMS_SMALL instances: four slices side by side
+                    extras = []
+                    ninst = 1
                     if TN_STREAMS >= 2 and len(slice_ids) >= 2:
+                        ninst = 2
+                        if self.max_size() <= (1 << 22):
+                            ninst = max(2, min(TN_STREAMS_SMALL, len(slice_ids)))
+                    for _ in range(ninst - 1):
                         st_dep2 = {k: v.clone() for k, v in st_dep.items()}
                         cur2 = dict(st_dep2)
                         gacc2 = {t: torch.zeros_like(v) for t, v in gacc.items()}
@@ -1712,15 +1720,16 @@ class ContractionTree:
                         g_c2 = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(g_c2, pool=g_b2.pool()):
                             gleaf2 = bwd_slice(shared, cur2, g_in2, gacc2, B)
-                        two = {"st_dep": st_dep2, "cur": cur2, "gacc": gacc2, "g_b": g_b2, "res": res2, "g_in": g_in2,
-                               "g_c": g_c2, "gleaf": gleaf2, "side": torch.cuda.Stream(device=raw[0].device)}
+                        extras.append({"st_dep": st_dep2, "cur": cur2, "gacc": gacc2, "g_b": g_b2, "res": res2, "g_in": g_in2,
+                                       "g_c": g_c2, "gleaf": gleaf2, "side": torch.cuda.Stream(device=raw[0].device)})
+                    two = extras[0] if extras else None
                     if B is not None:
                         B.finish()     # the descriptor table the captured launches read: uploaded before any replay
             finally:
                 COUNTERS = keep_counters
             cache = {"sig": sig, "st_inv": st_inv, "st_dep": st_dep, "shared": shared, "cur": cur, "res": res,
                      "g_in": g_in, "gacc": gacc, "gleaf": gleaf, "ginv_leaf": ginv_leaf, "g_a": g_a, "g_b": g_b,
-                     "g_c": g_c, "g_d": g_d, "batch": B, "two": two, "big": big, "gbig": gbig}
+                     "g_c": g_c, "g_d": g_d, "batch": B, "two": two, "extras": extras, "big": big, "gbig": gbig}
             cache["need"] = list(need)
             cache["shard3"] = (srank, sworld, sgroup)
             self._vjp_graph_cache = cache
@@ -1750,9 +1759,10 @@ class ContractionTree:
             for k in cache["gleaf"]:
                 if need[k]:
                     grads[k] = torch.zeros_like(raw[k])
-            two = cache.get("two")
-            if two is not None and two["gacc"]:
-                torch._foreach_zero_(list(two["gacc"].values()))
+            extras = cache.get("extras") or []
+            for inst_ in extras:
+                if inst_["gacc"]:
+                    torch._foreach_zero_(list(inst_["gacc"].values()))
 
             def one_slice(i, inst):
                 """Forward, op and its derivative, backward of slice i on the graphs of ``inst``; returns op's value and
@@ -1778,25 +1788,29 @@ class ContractionTree:
                         grads[k][idx[k]] += gl
 
             ids = list(slice_ids)
-            cur_s = torch.cuda.current_stream(raw[0].device) if two is not None else None
+            cur_s = torch.cuda.current_stream(raw[0].device) if extras else None
+            group = 1 + len(extras)
             j = 0
             while j < len(ids):
-                v2 = None
-                if two is not None and j + 1 < len(ids):      # the partner slice goes out first, on the second stream
-                    two["side"].wait_stream(cur_s)
-                    with torch.cuda.stream(two["side"]):
-                        v2, idx2 = one_slice(ids[j + 1], two)
-                v, idx1 = one_slice(ids[j], cache)
+                chunk = ids[j: j + group]
+                outs = []
+                for inst_, sid in zip(extras, chunk[1:]):       # the partner slices go out first, on their own streams
+                    inst_["side"].wait_stream(cur_s)
+                    with torch.cuda.stream(inst_["side"]):
+                        v2, idx2 = one_slice(sid, inst_)
+                    outs.append((inst_, v2, idx2))
+                v, idx1 = one_slice(chunk[0], cache)
                 add_leaf_grads(cache, idx1)
                 total = v if total is None else total + v
-                if v2 is not None:
-                    cur_s.wait_stream(two["side"])
-                    add_leaf_grads(two, idx2)       # on the main stream: ordered after the main instance's additions
+                for inst_, v2, idx2 in outs:
+                    cur_s.wait_stream(inst_["side"])
+                    add_leaf_grads(inst_, idx2)       # on the main stream: ordered after the main instance's additions
                     total = total + v2
-                j += 1 if v2 is None else 2
-            if two is not None and two["gacc"]:
-                keys = list(cache["gacc"])
-                torch._foreach_add_([cache["gacc"][t] for t in keys], [two["gacc"][t] for t in keys])
+                j += len(chunk)
+            for inst_ in extras:
+                if inst_["gacc"]:
+                    keys = list(cache["gacc"])
+                    torch._foreach_add_([cache["gacc"][t] for t in keys], [inst_["gacc"][t] for t in keys])
             if sworld > 1 and sgroup != "emulate" and cache["gbig"] is not None:
                 self._allreduce_complex(cache["gbig"], sgroup)     # the roots' cotangents, summed over every rank's slices
             if cache["g_d"] is not None:
@@ -2562,6 +2576,7 @@ def _tensordot_bits(a, b, axes_a, axes_b):
 
 
 TN_STREAMS = int(knob("tn_streams", "2"))   # two slices of a sliced contraction side by side (1: one stream)
+TN_STREAMS_SMALL = int(knob("tn_streams_small", "4"))   # ... and up to this many when the largest intermediate has <= 2^22 elements (sliced value_and_grad only)
 SCATTERED_MIN_RANK = 16    # big operand: at least 2^16 elements
 SCATTERED_MAX_SMALL = 4096  # small operand: at most this many elements (it lives in LDS)
 SCATTERED_MAX_NK = int(knob("tn_scat_maxk", "8"))   # more contracted axes: the MFMA bits kernel
