@@ -707,7 +707,6 @@ def rqc_leg(tc, torch, dist, args, rank, world):
 
     depth = args.rqc_depth
     nodes_fn = rqc_network(tc, depth)
-    rows, cols = 4, 8
 
     t0 = time.perf_counter()
     dc = DistributedContractor(nodes_fn, None, cotengra_options=rqc_search_options(args.rqc_log2_target, args.rqc_seeds))
@@ -1247,7 +1246,7 @@ def _guard(name, fn, *a, dist=None, need_bytes=0):
         if dist is not None:          # every rank has let go of the previous leg's memory before anybody looks
             torch.cuda.synchronize()
             dist.barrier()
-        free, total = torch.cuda.mem_get_info()
+        free, _total = torch.cuda.mem_get_info()
         sharers = max(1, int(os.environ.get("TCMI_BENCH_SHARERS", "1")))
         need = need_bytes + (2 << 30)
         ok = free / sharers >= need
