@@ -1755,24 +1755,45 @@ class ContractionTree:
                 self._gather_invariants(cache["big"], srank, sworld, sgroup)
             grads: List[Any] = [None] * n
             total = None
-            touched = sorted(set(cache["st_dep"]) | set(cache["gleaf"]))   # the leaves that carry a sliced index
-            for k in cache["gleaf"]:
-                if need[k]:
-                    grads[k] = torch.zeros_like(raw[k])
+            # The leaves that carry a sliced index: their values go into STATIC full-size copies once per call, and every
+            # slice's blocks of them (and of their gradients) are views built once per slice id -- a slice then costs two
+            # multi-tensor launches instead of an indexing operation and a tiny kernel per leaf and direction (~60 of them:
+            # with four slices in flight the host, not the device, set the pace)
+            dep_keys = list(cache["st_dep"])
+            g_keys = [k for k in cache["gleaf"] if need[k]]
+            hs = cache.get("host_static")
+            if hs is None or hs["need"] != tuple(g_keys) or any(hs["full"][k].shape != raw[k].shape for k in dep_keys):
+                hs = cache["host_static"] = {
+                    "need": tuple(g_keys), "full": {k: torch.empty_like(raw[k]) for k in dep_keys},
+                    "gfull": {k: torch.zeros_like(raw[k]) for k in g_keys}, "views": {}}
+            if dep_keys:
+                torch._foreach_copy_([hs["full"][k] for k in dep_keys], [raw[k] for k in dep_keys])
+            if g_keys:
+                torch._foreach_zero_([hs["gfull"][k] for k in g_keys])
+            for k in g_keys:
+                grads[k] = hs["gfull"][k]
             extras = cache.get("extras") or []
             for inst_ in extras:
                 if inst_["gacc"]:
                     torch._foreach_zero_(list(inst_["gacc"].values()))
 
+            def slice_views(i):
+                v_ = hs["views"].get(i)
+                if v_ is None:
+                    vals = self.slice_index_values(i)
+                    idx = {k: tuple(vals[e] if e in vals else slice(None) for e in self.inputs[k])
+                           for k in set(dep_keys) | set(g_keys)}
+                    v_ = hs["views"][i] = ([hs["full"][k][idx[k]] for k in dep_keys], [hs["gfull"][k][idx[k]] for k in g_keys])
+                return v_
+
             def one_slice(i, inst):
-                """Forward, op and its derivative, backward of slice i on the graphs of ``inst``; returns op's value and
-                the slice's index tuples.  The sliced leaves' gradient blocks are NOT added here: two slices of a pair
-                differ in the last sliced index only, so a leaf that carries just the earlier ones receives the SAME
-                block from both -- the additions of both instances are issued on the main stream, after the join."""
-                vals = self.slice_index_values(i)
-                idx = {k: tuple(vals[e] if e in vals else slice(None) for e in self.inputs[k]) for k in touched}
-                for k, buf in inst["st_dep"].items():
-                    buf.copy_(raw[k][idx[k]])
+                """Forward, op and its derivative, backward of slice i on the graphs of ``inst``; returns op's value.  The
+                sliced leaves' gradient blocks are NOT added here: the slices of a group differ in the last sliced indices
+                only, so a leaf that carries just the earlier ones receives the SAME block from several of them -- the
+                additions of all instances are issued on the main stream, after the join."""
+                vin, _ = slice_views(i)
+                if dep_keys:
+                    torch._foreach_copy_([inst["st_dep"][k] for k in dep_keys], vin)
                 inst["g_b"].replay()
                 with torch.enable_grad():
                     r_ = inst["res"].detach().clone().requires_grad_(True)
@@ -1780,12 +1801,11 @@ class ContractionTree:
                     (g,) = torch.autograd.grad(v, r_)
                 inst["g_in"].copy_(g)
                 inst["g_c"].replay()
-                return v.detach(), idx
+                return v.detach(), i
 
-            def add_leaf_grads(inst, idx):
-                for k, gl in inst["gleaf"].items():
-                    if need[k]:
-                        grads[k][idx[k]] += gl
+            def add_leaf_grads(inst, i):
+                if g_keys:
+                    torch._foreach_add_(slice_views(i)[1], [inst["gleaf"][k] for k in g_keys])
 
             ids = list(slice_ids)
             cur_s = torch.cuda.current_stream(raw[0].device) if extras else None
@@ -1827,6 +1847,9 @@ class ContractionTree:
             # the graphs deliver conj(g)
             if hat_ok:
                 self.last_vjp_conjugated = True
+                if not alias_ok:          # the sliced leaves' gradients live in static memory too: hand out copies
+                    for k in g_keys:
+                        grads[k] = grads[k].clone()
             else:
                 grads = [g_.conj().resolve_conj() if g_ is not None else None for g_ in grads]
         return total, [g if need[k] else None for k, g in enumerate(grads)]
