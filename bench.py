@@ -1591,6 +1591,7 @@ def main():
     # the host-bound leg first: it is the one that feels what earlier legs leave behind (graph memory pools, cached plans)
     svqa = None
     if args.svqa_qubits:
+        _burn = [torch.cuda.Stream(device=dev) for _ in range(int(os.environ.get("TCMI_BENCH_BURN_STREAMS", "0")))]  # experiment
         torch.cuda.empty_cache()
         svqa = _guard("sliced_vqa", sliced_vqa_leg, tc, torch, dist, args, rank, world, dist=dist, need_bytes=1 << 30)
 
