@@ -1592,6 +1592,10 @@ def main():
     svqa = None
     if args.svqa_qubits:
         _burn = [torch.cuda.Stream(device=dev) for _ in range(int(os.environ.get("TCMI_BENCH_BURN_STREAMS", "0")))]  # experiment
+        for st_ in _burn:          # ... and USED: a stream gets its hardware queue with its first work
+            with torch.cuda.stream(st_):
+                torch.zeros(8, device=dev).add_(1)
+        torch.cuda.synchronize()
         torch.cuda.empty_cache()
         svqa = _guard("sliced_vqa", sliced_vqa_leg, tc, torch, dist, args, rank, world, dist=dist, need_bytes=1 << 30)
 

@@ -6,7 +6,7 @@ mkdir -p $O
 export TMPDIR=/tmp
 ulimit -c 0
 BASE="--no-traffic-probe --no-cpu-baseline --steps 3 --warmup 2 --mps-qubits 0 --rqc-depth 0 --sv-qubits 0 --vqe-qubits 0 --no-hea-a --no-graph"
-for k in 0 1 2 3 4 6; do
+for k in 0 2 4; do
   TCMI_BENCH_BURN_STREAMS=$k timeout 600 python bench.py $BASE > $O/burn$k.json 2> $O/burn$k.err; echo "burn $k rc=$?" >> $O/status.txt
 done
 python - <<'PY'
