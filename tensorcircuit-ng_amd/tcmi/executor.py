@@ -17,6 +17,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 
 from . import _lib
+from . import _streams
 from ._knobs import knob
 from . import plan as P
 from . import specialize as S
@@ -1491,7 +1492,7 @@ class CutCircuit:
         if two:
             side = getattr(self, "_side", None)
             if side is None:
-                side = self._side = torch.cuda.Stream(device=self.device)
+                side = self._side = _streams.side_stream(self.device, 0)
             side.wait_stream(cur)
             # the bond weights at the head of the right half's chain (computing them on the caller's stream at the head of
             # the left half's shorter chain measured no gain eager and slower under hipGraph replay: the extra event edge
@@ -1576,7 +1577,7 @@ class CutCircuit:
         cur = torch.cuda.current_stream(self.device)
         sides = getattr(self, "_sides", None)
         if sides is None or len(sides) < nsplit:
-            sides = self._sides = [torch.cuda.Stream(device=self.device) for _ in range(nsplit)]
+            sides = self._sides = [_streams.side_stream(self.device, i_) for i_ in range(nsplit)]
         w = self._weights(p)                                    # [B, K], one launch for the whole batch
         xepi = self._epilogue_matrices(p)
         bounds = [(i * B) // nsplit for i in range(nsplit + 1)]
@@ -1632,7 +1633,7 @@ class GraphedState:
         self.params = torch.zeros(batch, npar, dtype=cc.rdtype, device=cc.device)
         self.out = torch.empty(batch, 2**cc.n_exec, dtype=cc.tdtype, device=cc.device)
         cur = torch.cuda.current_stream(cc.device)
-        side = torch.cuda.Stream(device=cc.device)
+        side = _streams.side_stream(cc.device, 1)       # (not stream 0: the cut contraction forks its right half onto that one)
         side.wait_stream(cur)
         with torch.cuda.stream(side):            # warm-up outside capture (lazy allocations, caches)
             for _ in range(2):

@@ -19,6 +19,7 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
+from . import _streams
 from ._knobs import knob
 from . import cons
 
@@ -1721,7 +1722,7 @@ class ContractionTree:
                         with torch.cuda.graph(g_c2, pool=g_b2.pool()):
                             gleaf2 = bwd_slice(shared, cur2, g_in2, gacc2, B)
                         extras.append({"st_dep": st_dep2, "cur": cur2, "gacc": gacc2, "g_b": g_b2, "res": res2, "g_in": g_in2,
-                                       "g_c": g_c2, "gleaf": gleaf2, "side": torch.cuda.Stream(device=raw[0].device)})
+                                       "g_c": g_c2, "gleaf": gleaf2, "side": _streams.side_stream(raw[0].device, len(extras))})
                     two = extras[0] if extras else None
                     if B is not None:
                         B.finish()     # the descriptor table the captured launches read: uploaded before any replay
@@ -2043,7 +2044,7 @@ class ContractionTree:
                 COUNTERS = keep_counters
             cache = {"sig": sig, "big": big, "static": static, "shared": shared_t, "g_inv": g_inv, "g_sl": g_sl, "res": res,
                      "cnt_inv": cnt_inv, "cnt_sl": cnt_sl, "g_sl2": g_sl2, "res2": res2, "static2": static2, "batch": B,
-                     "side": torch.cuda.Stream(device=first[0].device) if g_sl2 is not None else None}
+                     "side": _streams.side_stream(first[0].device, 0) if g_sl2 is not None else None}
             self._graph_cache = cache
         static = cache["static"]
         inv_k = cache.get("inv_leaves")
