@@ -274,6 +274,22 @@ int tcmi_cgemm_split(const void* A, const void* B, void* C, long long M, long lo
 int tcmi_cgemm_split_epi(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch,
                          long long strideA, long long strideB, long long strideC, const void* X, void* stream);
 
+/* tcmi_cgemm_split (X = NULL) / tcmi_cgemm_split_epi (X given) with operands of KNOWN magnitude on the f16 matrix pipe:
+ * every operand value times a power of two the caller passes (`scale_a` for A, `scale_b` for B) is cut into TWO f16
+ * pieces, h = the nearest f16 and l = the nearest f16 of what h left (|scale x - h - l| <= 2^-22 |scale x|), and a real
+ * product is the three piece products h h' + h l' + l h', each exact in the f32 accumulator of v_mfma_f32_32x32x16_f16 --
+ * half the matrix instructions and two thirds of the LDS traffic of the three-piece bf16 cut.  What is dropped is at most
+ * 3 * 2^-22 of |x y| per product; against a float64 product the kernel is measured at the error of the exact-f32 MFMA
+ * kernel (tests/test_gpu_gemm_split.py).  The caller guarantees |scale_a re|, |scale_a im|, |scale_a (re + im)| < 65504
+ * for every element of A (the same for B): an operand beyond that becomes inf and the product NaN -- loud, not wrong.
+ * Values below 2^-14 / scale lose their low piece's bits gradually (f16 subnormals), an absolute error of 2^-25 / scale.
+ * The cut contraction calls it with the bound it derives from its half-circuits (unitary gates and the operator-Schmidt
+ * factors of the crossing gates: |amplitude| <= prod of spectral norms); other callers use tcmi_cgemm_split.
+ * (reference circuit.py:701-721 -> cons.py:948 backend.tensordot of complex64 operands.) */
+int tcmi_cgemm_split_f16(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch,
+                         long long strideA, long long strideB, long long strideC, const void* X, float scale_a, float scale_b,
+                         void* stream);
+
 /* <a|b> = sum conj(a_i) b_i per batch element (states [batch][2^n], stride elements apart), accumulated in
  * float64 into `copies` replicated {re, im} pairs: out[b * out_batch_stride + 2 * copy + {0,1}] += ...; the
  * caller zeroes `out` and sums the copies.  Used for <psi|P|psi> of Pauli strings with more than two X/Y

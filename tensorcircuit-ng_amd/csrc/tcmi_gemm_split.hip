@@ -51,6 +51,7 @@
 // what the four k-steps saved.  Measured, lost, removed in round 6; DESIGN.md section 2b keeps the numbers.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <math.h>
 #include <stdlib.h>
 
 #include "../../include/tcmi.h"
@@ -68,11 +69,20 @@ typedef __attribute__((address_space(3))) void* slptr_t;
 
 constexpr int SPLIT_BK = 16;                               // k per step = one MFMA
 constexpr int SPLIT_BLOCK_BYTES = 128 * SPLIT_BK * 2;      // one (product, piece) block of a 128-row tile: 4 KiB
-constexpr int SPLIT_STAGE_BYTES = 18 * SPLIT_BLOCK_BYTES;  // A: 9 blocks, B: 9 blocks
+constexpr int SPLIT_STAGE_BYTES = 18 * SPLIT_BLOCK_BYTES;  // three bf16 pieces: A 9 blocks, B 9 blocks
+constexpr int split_stage_bytes(int np) { return 6 * np * SPLIT_BLOCK_BYTES; }   // NP pieces: 3 products x NP x {A, B}
 
 #ifndef TCMI_S2_VPM
 #define TCMI_S2_VPM 5
 #endif
+#ifndef TCMI_S2_PIPE
+#define TCMI_S2_PIPE 1      // NP = 2: MFMAs one phase behind their fragment reads (0: the three-piece kernel's step)
+#endif
+#ifndef TCMI_S2_VPM2
+#define TCMI_S2_VPM2 7      // NP = 2: vector instructions of the cut behind each of a phase's 12 MFMAs
+#endif
+typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
 typedef float f32x2_ __attribute__((ext_vector_type(2)));
 
@@ -80,11 +90,30 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
   const f32x2_ v = {lo, hi};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_));
 }
-template <int MODE, int EPI>
+__device__ __forceinline__ uint32_t cvt_pk_f16(float lo, float hi) {
+  const f32x2_ v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_));
+}
+template <int NP>
+__device__ __forceinline__ f32x16 split_mfma(const f32x4_ a, const f32x4_ b, const f32x16 c) {
+  if (NP == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// NP = 3: three bf16 pieces per operand value (header).  NP = 2: TWO f16 pieces of the value times a power of two the
+// caller chose (scale_a for A, scale_b for B: |scale * x| and |scale * (re + im)| must stay below 65504), x scale = h + l
+// with h the round-to-nearest f16 and l the round-to-nearest f16 of what h left (11 + 11 significand bits and the sign of l:
+// |x scale - h - l| <= 2^-22 |x scale|), and a real product is h h' + h l' + l h' -- THREE f16 MFMAs, each exact in the f32
+// accumulator, where the bf16 cut needs six; dropped: l l' and the residues, <= 3 * 2^-22 |x y| in the worst case and
+// measured (tests/test_gpu_gemm_split.py) at the error of the f32 MFMA kernel.  The results leave scaled by
+// so = 1 / (scale_a scale_b), exact for powers of two.
+template <int MODE, int EPI, int NP>
 __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __restrict__ A, const float2* __restrict__ B,
                                                               float2* __restrict__ C, int M, int N, int K, long long sA,
                                                               long long sB, long long sC, int tiles_x, int tiles_y, int batch,
-                                                              const float2* __restrict__ X) {
+                                                              const float2* __restrict__ X, float scale_a, float scale_b,
+                                                              float so) {
+  constexpr int NPL = 3 * NP;                                     // plane blocks per operand
+  constexpr int STAGE_B = 2 * NPL * SPLIT_BLOCK_BYTES;            // one stage: A planes, then B planes
   extern __shared__ __attribute__((aligned(16))) char dsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
@@ -127,7 +156,11 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
   const float2* src = (lop ? B + (long long)bi * sB + n0 : A + (long long)bi * sA + m0) + lofs;       // this tile
   const float2* src1 = (lop ? B + (long long)bi1 * sB + n1 : A + (long long)bi1 * sA + m1) + lofs;   // the next one
   // this thread's write slot inside a plane block: k half, then position of row 2 lane (+ 32 positions for row 2 lane + 1)
-  const uint32_t wofs = (uint32_t)(lop * 9 * SPLIT_BLOCK_BYTES + lkg * 2048 + ((lane >> 5) * 64 + (lane & 31)) * 16);
+  const uint32_t wofs = (uint32_t)(lop * NPL * SPLIT_BLOCK_BYTES + lkg * 2048 + ((lane >> 5) * 64 + (lane & 31)) * 16);
+  const float lsc = lop ? scale_b : scale_a;
+  // -1 for the powers of two the launcher admits, but not a constant the compiler could fold: the residue x - h then is
+  // ONE mixed-precision fma reading the f16 half where it is, instead of a conversion and a subtraction
+  const float fm1 = -(so * scale_a * scale_b);
   f32x4_ g0[8], g1[8];
 #define TCMI_S2_LOAD(G, KT)                                                                       \
   {                                                                                               \
@@ -142,6 +175,9 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
     /* scripts/ubench/mfma_valu_shadow.hip) */                                                                       \
     float x_[8], y_[8];                                                                                               \
     uint32_t p0_[8], p1_[8], p2_[8];                                                                                  \
+    if (NP == 2 && (T) == 0) {   /* the block is scaled once, in place, before its first product is cut */           \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) G[j] *= lsc;                                                      \
+    }                                                                                                                 \
     _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                                   \
       const int h = e >> 2, jp = e & 3;                                                                               \
       x_[e] = (T) == 0 ? G[2 * jp][2 * h] : ((T) == 1 ? G[2 * jp][2 * h + 1] : G[2 * jp][2 * h] + G[2 * jp][2 * h + 1]); \
@@ -154,6 +190,15 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
         p1_[e] = __float_as_uint(y_[e]);                                                                              \
         p2_[e] = p0_[e];                                                                                              \
       }                                                                                                               \
+    } else if (NP == 2) {                                                                                             \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) p0_[e] = cvt_pk_f16(x_[e], y_[e]);                                \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                                 \
+        const f16x2_ h_ = __builtin_bit_cast(f16x2_, p0_[e]);                                                         \
+        x_[e] = __builtin_fmaf((float)h_[0], fm1, x_[e]);      /* v_fma_mix_f32: the f16 half read in place */        \
+        y_[e] = __builtin_fmaf((float)h_[1], fm1, y_[e]);                                                             \
+      }                                                                                                               \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) p1_[e] = cvt_pk_f16(x_[e], y_[e]);                                \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e) p2_[e] = 0;                                                       \
     } else {                                                                                                          \
       _Pragma("unroll") for (int e = 0; e < 8; ++e) p0_[e] = cvt_pk_bf16(x_[e], y_[e]);                               \
       _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                                 \
@@ -171,13 +216,13 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
       const u32x4 q0_ = {p0_[4 * h], p0_[4 * h + 1], p0_[4 * h + 2], p0_[4 * h + 3]};                                 \
       const u32x4 q1_ = {p1_[4 * h], p1_[4 * h + 1], p1_[4 * h + 2], p1_[4 * h + 3]};                                 \
       const u32x4 q2_ = {p2_[4 * h], p2_[4 * h + 1], p2_[4 * h + 2], p2_[4 * h + 3]};                                 \
-      char* w_ = dsm + (ST) * SPLIT_STAGE_BYTES + wofs + h * 512 + (T) * 3 * SPLIT_BLOCK_BYTES;                       \
+      char* w_ = dsm + (ST) * STAGE_B + wofs + h * 512 + (T) * NP * SPLIT_BLOCK_BYTES;                                \
       if (MODE == 5) {                                                                                                \
         asm volatile("" ::"v"(q0_), "v"(q1_), "v"(q2_));                                                              \
       } else {                                                                                                        \
         *reinterpret_cast<u32x4*>(w_) = q0_;                                                                          \
         *reinterpret_cast<u32x4*>(w_ + SPLIT_BLOCK_BYTES) = q1_;                                                      \
-        *reinterpret_cast<u32x4*>(w_ + 2 * SPLIT_BLOCK_BYTES) = q2_;                                                  \
+        if (NP == 3) *reinterpret_cast<u32x4*>(w_ + 2 * SPLIT_BLOCK_BYTES) = q2_;                                     \
       }                                                                                                               \
     }                                                                                                                 \
   }
@@ -200,30 +245,36 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
   __builtin_amdgcn_s_barrier();
   const uint32_t lds0 = (uint32_t)(uintptr_t)(slptr_t)dsm;
   const uint32_t fa = lds0 + (uint32_t)((lane >> 5) * 2048 + (wr * 64 + (lane & 31)) * 16);
-  const uint32_t fb = lds0 + (uint32_t)(9 * SPLIT_BLOCK_BYTES + (lane >> 5) * 2048 + (wc * 64 + (lane & 31)) * 16);
+  const uint32_t fb = lds0 + (uint32_t)(NPL * SPLIT_BLOCK_BYTES + (lane >> 5) * 2048 + (wc * 64 + (lane & 31)) * 16);
   // one 16-k step on stage P: MFMAs of block I, the block after it (in GN) cut into stage 1 - P, block I + 2 requested
   // into GC (whose block is in stage P already)
 #define TCMI_S2_SREAD(BUF, T)                                                                                           \
-  _Pragma("unroll") for (int s = 0; s < 3; ++s) _Pragma("unroll") for (int u = 0; u < 2; ++u) {                         \
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xa[BUF][u][s]) : "v"(sa_), "n"(((T) * 3 + s) * 4096 + u * 512)); \
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xb[BUF][u][s]) : "v"(sb_), "n"(((T) * 3 + s) * 4096 + u * 512)); \
+  _Pragma("unroll") for (int s = 0; s < NP; ++s) _Pragma("unroll") for (int u = 0; u < 2; ++u) {                        \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xa[BUF][u][s]) : "v"(sa_), "n"(((T) * NP + s) * 4096 + u * 512)); \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xb[BUF][u][s]) : "v"(sb_), "n"(((T) * NP + s) * 4096 + u * 512)); \
   }
 #define TCMI_S2_SWAIT(BUF, NW)                                                                                    \
-  asm volatile("s_waitcnt lgkmcnt(%12)"                                                                           \
-               : "+v"(xa[BUF][0][0]), "+v"(xa[BUF][0][1]), "+v"(xa[BUF][0][2]), "+v"(xa[BUF][1][0]),              \
-                 "+v"(xa[BUF][1][1]), "+v"(xa[BUF][1][2]), "+v"(xb[BUF][0][0]), "+v"(xb[BUF][0][1]),              \
-                 "+v"(xb[BUF][0][2]), "+v"(xb[BUF][1][0]), "+v"(xb[BUF][1][1]), "+v"(xb[BUF][1][2])               \
-               : "n"(NW)                                                                                          \
-               : "memory");
+  if (NP == 3) {                                                                                                  \
+    asm volatile("s_waitcnt lgkmcnt(%12)"                                                                         \
+                 : "+v"(xa[BUF][0][0]), "+v"(xa[BUF][0][1]), "+v"(xa[BUF][0][2]), "+v"(xa[BUF][1][0]),            \
+                   "+v"(xa[BUF][1][1]), "+v"(xa[BUF][1][2]), "+v"(xb[BUF][0][0]), "+v"(xb[BUF][0][1]),            \
+                   "+v"(xb[BUF][0][2]), "+v"(xb[BUF][1][0]), "+v"(xb[BUF][1][1]), "+v"(xb[BUF][1][2])             \
+                 : "n"(NW)                                                                                        \
+                 : "memory");                                                                                     \
+  } else {                                                                                                        \
+    asm volatile("s_waitcnt lgkmcnt(%8)"                                                                          \
+                 : "+v"(xa[BUF][0][0]), "+v"(xa[BUF][0][1]), "+v"(xa[BUF][1][0]), "+v"(xa[BUF][1][1]),            \
+                   "+v"(xb[BUF][0][0]), "+v"(xb[BUF][0][1]), "+v"(xb[BUF][1][0]), "+v"(xb[BUF][1][1])             \
+                 : "n"(NW)                                                                                        \
+                 : "memory");                                                                                     \
+  }
 #define TCMI_S2_MF(T, SA, SB)                                                                                       \
   _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int v = 0; v < 2; ++v)                       \
-    acc[u][v][T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xa[(T) & 1][u][SA]),          \
-                                                           __builtin_bit_cast(bf16x8, xb[(T) & 1][v][SB]), acc[u][v][T], 0, 0, 0);
+    acc[u][v][T] = split_mfma<NP>(xa[(T) & 1][u][SA], xb[(T) & 1][v][SB], acc[u][v][T]);
   // the first MFMA of a tile into an accumulator starts from the constant 0 (nothing zeroes the accumulators between tiles)
 #define TCMI_S2_MF0(T, SA, SB)                                                                                      \
   _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int v = 0; v < 2; ++v)                       \
-    acc[u][v][T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xa[(T) & 1][u][SA]),          \
-                                                           __builtin_bit_cast(bf16x8, xb[(T) & 1][v][SB]), zero16, 0, 0, 0);
+    acc[u][v][T] = split_mfma<NP>(xa[(T) & 1][u][SA], xb[(T) & 1][v][SB], zero16);
 #define TCMI_S2_PHASE(T, GN, P, FIRST)                                                                               \
   {                                                                                                                  \
     if ((T) < 2) {                                                                                                   \
@@ -231,28 +282,32 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
     }                                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
     if (MODE != 1) TCMI_S2_CONVERT(GN, 1 - (P), T)                                                                   \
-    if (MODE != 2) {                                                                                                 \
+    if (MODE != 2 && NP == 3) {                                                                                      \
       if (FIRST) { TCMI_S2_MF0(T, 0, 2) } else { TCMI_S2_MF(T, 0, 2) }                                                \
       TCMI_S2_MF(T, 1, 1) TCMI_S2_MF(T, 2, 0) TCMI_S2_MF(T, 0, 1) TCMI_S2_MF(T, 1, 0) TCMI_S2_MF(T, 0, 0)             \
+    }                                                                                                                \
+    if (MODE != 2 && NP == 2) {                                                                                      \
+      if (FIRST) { TCMI_S2_MF0(T, 0, 1) } else { TCMI_S2_MF(T, 0, 1) }                                                \
+      TCMI_S2_MF(T, 1, 0) TCMI_S2_MF(T, 0, 0)                                                                         \
     }                                                                                                                \
     if (MODE == 0 || MODE >= 3) {                                                                                    \
       /* spread the ~100 VALU instructions of the conversion evenly between the 24 MFMAs (4 ride in each MFMA's */   \
       /* shadow), the six plane writes behind them */                                                               \
-      _Pragma("unroll") for (int z = 0; z < 24; ++z) {                                                               \
+      _Pragma("unroll") for (int z = 0; z < 8 * NP; ++z) {                                                           \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                           \
-        __builtin_amdgcn_sched_group_barrier(0x002, TCMI_S2_VPM, 0);                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x002, NP == 3 ? TCMI_S2_VPM : TCMI_S2_VPM2, 0);                        \
       }                                                                                                              \
     }                                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                               \
     if ((T) < 2) {                                                                                                   \
       /* the 12 fragment reads of the next product are done; this phase's 6 plane writes (issued after them, LDS  */ \
       /* operations complete in order) stay in flight */                                                            \
-      if ((T) & 1) { TCMI_S2_SWAIT(0, MODE == 1 ? 0 : 6) } else { TCMI_S2_SWAIT(1, MODE == 1 ? 0 : 6) }              \
+      if ((T) & 1) { TCMI_S2_SWAIT(0, MODE == 1 ? 0 : 2 * NP) } else { TCMI_S2_SWAIT(1, MODE == 1 ? 0 : 2 * NP) }    \
     }                                                                                                                \
   }
 #define TCMI_S2_STEP(I, GC, GN, P, FIRST)                                                                            \
   {                                                                                                                  \
-    const uint32_t sa_ = fa + (uint32_t)((P) * SPLIT_STAGE_BYTES), sb_ = fb + (uint32_t)((P) * SPLIT_STAGE_BYTES);     \
+    const uint32_t sa_ = fa + (uint32_t)((P) * STAGE_B), sb_ = fb + (uint32_t)((P) * STAGE_B);                         \
     f32x4_ xa[2][2][3], xb[2][2][3];                                                                                 \
     TCMI_S2_SREAD(0, 0)                                                                                              \
     if (MODE != 1) TCMI_S2_LOAD(GC, (I) + 2)                                                                         \
@@ -263,12 +318,92 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
     __builtin_amdgcn_s_barrier();                                                                                    \
   }
+  // NP = 2: the same step with the MFMAs of a product running ONE PHASE BEHIND its fragment reads.  With half the matrix
+  // instructions per step (36 x 32 cycles) the latencies that the three-piece kernel's 72 MFMAs covered lay bare: the
+  // fragment reads of a step's first product behind the barrier, the drain of the plane writes before it (stamps:
+  // 2300 cycles per step against an MFMA floor of 1152).  Here phase f of a step cuts product f of the next block (vector
+  // pipe, plane writes) beside the MFMAs of product f - 1 -- phase 0 beside product 2 of the PREVIOUS step, whose
+  // fragments wait in registers -- and the reads of product f, issued at the start of phase f, have that whole phase to
+  // land: nothing of the matrix pipe's work waits for the LDS or for the barrier.  Three fragment buffers (96 VGPRs, what the
+  // two three-piece buffers took).
+  f32x4_ qa[3][2][2], qb[3][2][2];
+#define TCMI_Q_SREAD(T, ST)                                                                                             \
+  {                                                                                                                     \
+    const uint32_t sa_ = fa + (uint32_t)((ST) * STAGE_B), sb_ = fb + (uint32_t)((ST) * STAGE_B);                         \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) _Pragma("unroll") for (int u = 0; u < 2; ++u) {                       \
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(qa[T][u][s]) : "v"(sa_), "n"(((T) * 2 + s) * 4096 + u * 512)); \
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(qb[T][u][s]) : "v"(sb_), "n"(((T) * 2 + s) * 4096 + u * 512)); \
+    }                                                                                                                   \
+  }
+#define TCMI_Q_WAIT(T, NW)                                                                                        \
+  asm volatile("s_waitcnt lgkmcnt(%8)"                                                                            \
+               : "+v"(qa[T][0][0]), "+v"(qa[T][0][1]), "+v"(qa[T][1][0]), "+v"(qa[T][1][1]), "+v"(qb[T][0][0]),   \
+                 "+v"(qb[T][0][1]), "+v"(qb[T][1][0]), "+v"(qb[T][1][1])                                          \
+               : "n"(NW)                                                                                          \
+               : "memory");
+#define TCMI_Q_MF(T, SA, SB, Z)                                                                                     \
+  _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int v = 0; v < 2; ++v)                       \
+    acc[u][v][T] = split_mfma<2>(qa[T][u][SA], qb[T][v][SB], (Z) ? zero16 : acc[u][v][T]);
+  // product TC of block GN cut into stage 1 - P beside the MFMAs of product TM (MZ: 0 none, 1 the first of a tile into its
+  // accumulators, 2 accumulating)
+#define TCMI_Q_PHASE(TC, TM, MZ, GN, P)                                                                              \
+  {                                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    if (MODE != 1) TCMI_S2_CONVERT(GN, 1 - (P), TC)                                                                  \
+    if (MODE != 2 && (MZ) != 0) {                                                                                      \
+      TCMI_Q_MF(TM, 0, 1, (MZ) == 1) TCMI_Q_MF(TM, 1, 0, 0) TCMI_Q_MF(TM, 0, 0, 0)                                    \
+      _Pragma("unroll") for (int z = 0; z < 12; ++z) {                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                           \
+        __builtin_amdgcn_sched_group_barrier(0x002, TCMI_S2_VPM2, 0);                                                \
+      }                                                                                                              \
+    }                                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+  }
+#define TCMI_Q_STEP(I, GC, GN, P, MZP, MZ)                                                                        \
+  {                                                                                                                  \
+    TCMI_Q_SREAD(0, P)                                                                                               \
+    if (MODE != 1) TCMI_S2_LOAD(GC, (I) + 2)                                                                         \
+    TCMI_Q_PHASE(0, 2, MZP, GN, P)                                                                                   \
+    TCMI_Q_WAIT(0, MODE == 1 ? 0 : 4)       /* product 0's reads; this phase's 4 plane writes stay in flight */       \
+    TCMI_Q_SREAD(1, P)                                                                                               \
+    TCMI_Q_PHASE(1, 0, MZ, GN, P)                                                                       \
+    TCMI_Q_WAIT(1, MODE == 1 ? 0 : 4)                                                                                \
+    TCMI_Q_SREAD(2, P)                                                                                               \
+    TCMI_Q_PHASE(2, 1, MZ, GN, P)                                                                       \
+    TCMI_Q_WAIT(2, 0)                                                                                                \
+    __builtin_amdgcn_s_barrier();                                                                                    \
+  }
+  // MODE 10 (probe): cycles of a tile's step 0, step 1, remaining steps and epilogue, summed over the tiles of a workgroup
+  unsigned long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0, ps = 0;
+#define TCMI_S2_STAMP(ACC)                                             \
+  if (MODE == 10) {                                                    \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();      \
+    ACC += now_ - ps;                                                  \
+    ps = now_;                                                         \
+  }
+  if (MODE == 10) ps = __builtin_amdgcn_s_memtime();
   for (;;) {
+    if (NP == 2 && TCMI_S2_PIPE) {
+      TCMI_Q_STEP(0, g0, g1, 0, 0, 1)
+      TCMI_S2_STAMP(pt0)
+      TCMI_Q_STEP(1, g1, g0, 1, 1, 2)
+      TCMI_S2_STAMP(pt1)
+      for (int i = 2; i < nk; i += 2) {
+        TCMI_Q_STEP(i, g0, g1, 0, 2, 2)
+        TCMI_Q_STEP(i + 1, g1, g0, 1, 2, 2)
+      }
+      if (MODE != 2) { TCMI_Q_MF(2, 0, 1, 0) TCMI_Q_MF(2, 1, 0, 0) TCMI_Q_MF(2, 0, 0, 0) }      // the last step's third product
+      TCMI_S2_STAMP(pt2)
+    } else {
     TCMI_S2_STEP(0, g0, g1, 0, MODE != 2)
+    TCMI_S2_STAMP(pt0)
     TCMI_S2_STEP(1, g1, g0, 1, 0)
+    TCMI_S2_STAMP(pt1)
     for (int i = 2; i < nk; i += 2) {
       TCMI_S2_STEP(i, g0, g1, 0, 0)
       TCMI_S2_STEP(i + 1, g1, g0, 1, 0)
+    }
+    TCMI_S2_STAMP(pt2)
     }
     // the last step cut block 0 of the next tile into stage 0 and blocks 0, 1 of it are (being) loaded: only the
     // results stand between the tiles.  MFMA result element (i = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), j = lane & 31)
@@ -280,7 +415,11 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
       f32x2_ xr[16], xi[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float2 x = Xb[e];
+        float2 x = Xb[e];
+        if (NP == 2) {      // the accumulators hold the product times scale_a scale_b
+          x.x *= so;
+          x.y *= so;
+        }
         xr[e] = f32x2_{x.x, x.x};
         xi[e] = f32x2_{x.y, x.y};
       }
@@ -344,6 +483,7 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
           o.y = acc[u][0][2][reg] - acc[u][0][0][reg] - acc[u][0][1][reg];
           o.z = acc[u][1][0][reg] - acc[u][1][1][reg];
           o.w = acc[u][1][2][reg] - acc[u][1][0][reg] - acc[u][1][1][reg];
+          if (NP == 2) o *= so;
           if (MODE != 3 || o.x == 123.456f) *reinterpret_cast<f32x4_*>(Cb + row * N + colb) = o;
 #pragma unroll
           for (int v = 0; v < 2; ++v)
@@ -360,6 +500,7 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
       o.y = (float)(__builtin_amdgcn_s_memrealtime() - tr0);
       C[1 + work / gridDim.x] = o;
     }
+    TCMI_S2_STAMP(pt3)
     work += gridDim.x;
     if (work >= nwork) break;
     m0 = m1; n0 = n1; bi = bi1;
@@ -367,6 +508,20 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
     TCMI_S2_TILE(work + gridDim.x, m1, n1, bi1)
     src1 = (lop ? B + (long long)bi1 * sB + n1 : A + (long long)bi1 * sA + m1) + lofs;
   }
+  if (MODE == 10 && blockIdx.x == 100 && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float2 o;
+    o.x = (float)pt0; o.y = (float)pt1;
+    C[0] = o;
+    o.x = (float)pt2; o.y = (float)pt3;
+    C[1] = o;
+  }
+#undef TCMI_Q_STEP
+#undef TCMI_Q_PHASE
+#undef TCMI_Q_MF
+#undef TCMI_Q_WAIT
+#undef TCMI_Q_SREAD
+#undef TCMI_S2_STAMP
 #undef TCMI_S2_STEP
 #undef TCMI_S2_PHASE
 #undef TCMI_S2_MF0
@@ -391,7 +546,8 @@ __global__ __launch_bounds__(256, 1) void cgemm_split_kernel(const float2* __res
 namespace {
 
 int split_launch(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch, long long strideA,
-                 long long strideB, long long strideC, const void* X, void* stream, const char* who) {
+                 long long strideB, long long strideC, const void* X, void* stream, const char* who, int np = 3,
+                 float scale_a = 1.f, float scale_b = 1.f) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #ifdef TCMI_SPLIT_PROBE
   // probe builds of the kernel (libtcmi_probe.so only, scripts/gpu_gemm_split_modes.py): 1 no conversion, 2 no MFMA,
@@ -417,21 +573,39 @@ int split_launch(const void* A, const void* B, void* C, long long M, long long N
       return tcmi_set_error_(TCMI_ERR_HIP, "tcmi_cgemm_split: cannot query the device");
     ncu = prop.multiProcessorCount;
   }
-#define TCMI_SPLIT_LAUNCH(MODE, EPI)                                                                                   \
+  const float so = 1.f / (scale_a * scale_b);
+#define TCMI_SPLIT_LAUNCH_NP(MODE, EPI, NP)                                                                            \
   {                                                                                                                    \
     static bool attr_set_ = false;                                                                                     \
     if (!attr_set_) {                                                                                                  \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(tcmi::cgemm_split_kernel<MODE, EPI>),                      \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * tcmi::SPLIT_STAGE_BYTES) != hipSuccess)  \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(tcmi::cgemm_split_kernel<MODE, EPI, NP>),                  \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 2 * tcmi::split_stage_bytes(NP)) != hipSuccess) \
         return tcmi_set_error_(TCMI_ERR_HIP, "tcmi_cgemm_split: cannot raise the dynamic LDS limit");                  \
       attr_set_ = true;                                                                                                \
     }                                                                                                                  \
-    hipLaunchKernelGGL((tcmi::cgemm_split_kernel<MODE, EPI>), dim3((unsigned)(nwork < ncu ? nwork : ncu), 1, 1),       \
-                       dim3(256), 2 * tcmi::SPLIT_STAGE_BYTES, st, reinterpret_cast<const float2*>(A),                 \
+    hipLaunchKernelGGL((tcmi::cgemm_split_kernel<MODE, EPI, NP>), dim3((unsigned)(nwork < ncu ? nwork : ncu), 1, 1),   \
+                       dim3(256), 2 * tcmi::split_stage_bytes(NP), st, reinterpret_cast<const float2*>(A),             \
                        reinterpret_cast<const float2*>(B), reinterpret_cast<float2*>(C), (int)M, (int)N, (int)K, strideA, \
-                       strideB, strideC, txn, tyn, batch, reinterpret_cast<const float2*>(X));                         \
+                       strideB, strideC, txn, tyn, batch, reinterpret_cast<const float2*>(X), scale_a, scale_b, so);   \
   }
-  if (X) {
+#define TCMI_SPLIT_LAUNCH(MODE, EPI) TCMI_SPLIT_LAUNCH_NP(MODE, EPI, 3)
+  if (np == 2) {
+#ifdef TCMI_SPLIT_PROBE
+    if (mode == 1 && !X) TCMI_SPLIT_LAUNCH_NP(1, 0, 2)
+    else if (mode == 2 && !X) TCMI_SPLIT_LAUNCH_NP(2, 0, 2)
+    else if (mode == 3 && !X) TCMI_SPLIT_LAUNCH_NP(3, 0, 2)
+    else if (mode == 4 && !X) TCMI_SPLIT_LAUNCH_NP(4, 0, 2)
+    else if (mode == 5 && !X) TCMI_SPLIT_LAUNCH_NP(5, 0, 2)
+    else if (mode == 10 && !X) TCMI_SPLIT_LAUNCH_NP(10, 0, 2)
+    else if (mode == 10 && X) TCMI_SPLIT_LAUNCH_NP(10, 1, 2)
+    else if (mode == 7 && X) TCMI_SPLIT_LAUNCH_NP(7, 1, 2)
+    else if (mode == 8 && X) TCMI_SPLIT_LAUNCH_NP(8, 1, 2)
+    else if (mode == 9 && X) TCMI_SPLIT_LAUNCH_NP(9, 1, 2)
+    else
+#endif
+    if (X) TCMI_SPLIT_LAUNCH_NP(0, 1, 2)
+    else TCMI_SPLIT_LAUNCH_NP(0, 0, 2)
+  } else if (X) {
 #ifdef TCMI_SPLIT_PROBE
     // 7: epilogue without its multiply-adds, 8: its results as 16-byte stores (wrong places), 9: no result stores
     if (mode == 7) TCMI_SPLIT_LAUNCH(7, 1)
@@ -453,6 +627,7 @@ int split_launch(const void* A, const void* B, void* C, long long M, long long N
     TCMI_SPLIT_LAUNCH(0, 0)
   }
 #undef TCMI_SPLIT_LAUNCH
+#undef TCMI_SPLIT_LAUNCH_NP
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return tcmi_set_error_(TCMI_ERR_HIP, hipGetErrorString(e));
   return TCMI_OK;
@@ -471,6 +646,18 @@ int tcmi_cgemm_split_epi(const void* A, const void* B, void* C, long long M, lon
                          long long strideA, long long strideB, long long strideC, const void* X, void* stream) {
   if (!X) return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm_split_epi: X is null");
   return split_launch(A, B, C, M, N, K, batch, strideA, strideB, strideC, X, stream, "tcmi_cgemm_split_epi");
+}
+
+int tcmi_cgemm_split_f16(const void* A, const void* B, void* C, long long M, long long N, long long K, int batch,
+                         long long strideA, long long strideB, long long strideC, const void* X, float scale_a, float scale_b,
+                         void* stream) {
+  // powers of two only: the scaling and the un-scaling of the result are exact then
+  int ea = 0, eb = 0;
+  if (!(scale_a > 0.f) || !(scale_b > 0.f) || frexpf(scale_a, &ea) != 0.5f || frexpf(scale_b, &eb) != 0.5f || ea + eb < -120 ||
+      ea + eb > 120)
+    return tcmi_set_error_(TCMI_ERR_ARG, "tcmi_cgemm_split_f16: scale_a and scale_b must be powers of two");
+  return split_launch(A, B, C, M, N, K, batch, strideA, strideB, strideC, X, stream, "tcmi_cgemm_split_f16", 2, scale_a,
+                      scale_b);
 }
 
 }  // extern "C"
