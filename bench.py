@@ -1632,18 +1632,30 @@ def main():
                 ("cgemm_dma_kernel" if (M % 64 == 0 and N % 64 == 0 and K % 16 == 0) else "cgemm_mfma_kernel<true>")
             peak = MFMA_F32_PEAK_TFS
             split = X.JOIN_GEMM != "f32" and M % 128 == 0 and N % 128 == 0 and K % 32 == 0
-            if split:
+            f16 = split and X.JOIN_GEMM == "split" and getattr(cc, "_f16", None) is not None
+            if f16:
+                # tcmi_cgemm_split_f16: 3 real products x 3 f16 piece products per complex MAC = 18 flops on the f16 pipe
+                # (same dense peak as bf16): HALF the executed flops of the three-piece kernel for the same product, so this
+                # fraction is not comparable with the three-piece kernel's -- compare `avg_launch_us` and `algorithmic_achieved`
+                gk, exe, peak = "cgemm_split_kernel<0, %d, 2>" % int(cc.spec.epilogue is not None), 2.25 * alg, MFMA_BF16_PEAK_TFS
+            elif split:
                 # tcmi_cgemm_split: 3 real products x 6 bf16 piece products per complex MAC = 36 flops on the bf16 pipe
-                gk, exe, peak = "cgemm_split_kernel<0, %d>" % int(cc.spec.epilogue is not None), 4.5 * alg, MFMA_BF16_PEAK_TFS
+                gk, exe, peak = "cgemm_split_kernel<0, %d, 3>" % int(cc.spec.epilogue is not None), 4.5 * alg, MFMA_BF16_PEAK_TFS
             tr = traffic.get(gk.split("<")[0])
             roof = {
                 "bound": "mfma", "kernel": f"tcmi::{gk} (cut-contraction join GEMM)",
                 # frac = EXECUTED flops (what the MFMA pipe does) against the dense MFMA peak of the pipe it runs on
                 "achieved": exe / (avg_us * 1e-6) / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": exe / (avg_us * 1e-6) / 1e12 / peak,
-                **({"pipe": "bf16 MFMA, f32 operands cut into three bf16 pieces, six piece products per real product "
+                **({"pipe": "f16 MFMA, f32 operands (bounded by the cut: scales %g, %g) cut into two f16 pieces, three piece "
+                            "products per real product: 18 executed flops per complex multiply-add where the three-piece bf16 "
+                            "kernel of rounds 4-5 executed 36 (f32 accuracy: error against float64 equal to the f32 MFMA "
+                            "kernel's, tests/test_gpu_gemm_split.py)" % cc._f16} if f16 else
+                   {"pipe": "bf16 MFMA, f32 operands cut into three bf16 pieces, six piece products per real product "
                             "(f32 accuracy: error against float64 equal to the f32 MFMA kernel's, "
                             "tests/test_gpu_gemm_split.py)"} if split else {}),
+                # the kernel's job is to WRITE the joined states once: the same launch against the HBM roof
+                "hbm_frac_on_algorithmic_bytes": 8.0 * (B / gl_call) * (K * (M + N) + M * N) / (avg_us * 1e-6) / (HBM_PEAK_GBS * 1e9),
                 # the 8-flops-per-complex-MAC count over the time, and its ratio to the peak of the exact-f32 MFMA pipe: a
                 # comparison with the kernel this one replaced (> 1 on the bf16 pipe), NOT a fraction of anything achievable
                 "algorithmic_achieved": alg / (avg_us * 1e-6) / 1e12,

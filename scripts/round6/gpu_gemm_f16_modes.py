@@ -23,8 +23,10 @@ if len(sys.argv) > 1:
     if mode >= 100:      # 1xx: mode xx with the epilogue
         mode, epi = mode - 100, True
         os.environ["TCMI_SPLIT_MODE"] = str(mode)
-    fn = lambda: _lib.check(L.tcmi_cgemm_split_f16(A.data_ptr(), Bm.data_ptr(), c.data_ptr(), M, N, K, B, K * M, K * N, M * N,
-                                                   X.data_ptr() if epi else None, 2.0**14, 2.0**14, st), "x")
+    SC = float(os.environ.get("F16_PROBE_SCALE", str(2.0**14)))
+    entry = L.tcmi_cgemm_split_f16
+    fn = lambda: _lib.check(entry(A.data_ptr(), Bm.data_ptr(), c.data_ptr(), M, N, K, B, K * M, K * N, M * N,
+                                                   X.data_ptr() if epi else None, SC, SC, st), "x")
     for _ in range(3):
         fn()
     torch.cuda.synchronize()

@@ -10,7 +10,8 @@ TCMI_SPEC_HOT              ``auto``: calls of a plan before its missing kernels 
 TCMI_SPEC_MIN_N            ``auto``: plans below this many qubits are never compiled (22)
 TCMI_SPEC_KEEP             keep the generated .hip next to the code object
 TCMI_SPEC_LOCK_STALE_S     age after which another process's compile lock is taken over (600)
-TCMI_JOIN_GEMM             ``split`` (default: bf16-pipe three-piece join) / ``f32`` (exact-f32 MFMA kernel)
+TCMI_JOIN_GEMM             ``split`` (default: the two-piece f16 join when the cut bounds its halves, else the three-piece
+                           bf16 join) / ``bf16`` (the three-piece join always) / ``f32`` (exact-f32 MFMA kernel)
 TCMI_CUT_DEFER             ``1`` (default): the last crossing gate of a cut is applied by the join; ``0``: every gate a bond
 TCMI_SPARSE_START          ``0``: every tile live (no live-tile passes, zero fill)
 TCMI_PAULI_FOLD            ``0``: the Pauli-sum cotangent is not born in the sweep (tile passes instead)

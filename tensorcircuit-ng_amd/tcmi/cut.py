@@ -105,6 +105,51 @@ class CutSpec:
         return r
 
 
+def gate_norm_bound(g: P.GateRec) -> float:
+    """An upper bound of the spectral norm of a gate over all parameter values: exactly 1.0 for unitary gates (unit-modulus
+    diagonals; constant matrices and ``c0 + cos c1 + sin c2`` families that are unitary at five angles -- G(a)^+ G(a) is a
+    trigonometric polynomial of degree 2: five points fix it), the largest norm among the alternatives of a selector gate
+    (the operator-Schmidt factors of a crossing gate), ``|c0| + |c1| + |c2|`` otherwise."""
+    def norm2(m):
+        b = float(np.linalg.norm(np.asarray(m, dtype=np.complex128), 2))
+        return 1.0 if abs(b - 1.0) < 1e-9 else b
+
+    def unitary(m):
+        m = np.asarray(m, dtype=np.complex128)
+        return bool(np.abs(m.conj().T @ m - np.eye(m.shape[0])).max() < 1e-9)
+
+    if g.select is not None:
+        return max(norm2(m) for m in g.select)
+    if g.diag is not None and not any(t.scale for t in g.diag):
+        return 1.0
+    dim = 1 << len(g.qubits)
+    z = np.zeros((dim, dim), dtype=np.complex128)
+    c0 = z if g.c0 is None else np.asarray(g.c0, dtype=np.complex128).reshape(dim, dim)
+    if g.param is None:
+        return 1.0 if unitary(c0) else norm2(c0)
+    c1 = z if g.c1 is None else np.asarray(g.c1, dtype=np.complex128).reshape(dim, dim)
+    c2 = z if g.c2 is None else np.asarray(g.c2, dtype=np.complex128).reshape(dim, dim)
+    if all(unitary(c0 + np.cos(a) * c1 + np.sin(a) * c2) for a in 2 * np.pi * np.arange(5) / 5):
+        return 1.0
+    return norm2(c0) + norm2(c1) + norm2(c2)
+
+
+def half_bounds(spec: "CutSpec") -> Tuple[float, float]:
+    """(bound of |L_b[x]|, bound of |w_b R_b[x]|) for the two half-circuit batches of a cut started from a basis state: the
+    product of the gates' norm bounds (a state's entries are bounded by its 2-norm), the right one times the largest
+    bond weight.  What ``tcmi_cgemm_split_f16`` needs to choose its operand scales; ``inf`` when a factor is unbounded."""
+    def prod(gs):
+        b = 1.0
+        for g in gs:
+            b *= gate_norm_bound(g)
+        return b
+
+    w = 1.0
+    for bond in spec.bonds:
+        w *= max((abs(complex(ref)) if kind == "const" else 1.0) for _, _, (kind, ref) in bond.terms)
+    return prod(spec.left), prod(spec.right) * w
+
+
 def _lift(m, which):
     """2 x 2 on q_l (which = 0) / q_r (which = 1) -> 4 x 4 over (q_l, q_r)."""
     m = np.asarray(m, dtype=np.complex128).reshape(2, 2)

@@ -1197,7 +1197,10 @@ VM_COST = {"pass": 19.5, "g1": 2.25, "g2": 9.0, "diag": 11.5, "exchange": 10.75}
 VM2_COST = {"floor": 52.0, "fixed": 16.2, "g1": 0.95, "g2": 3.8, "table": 1.1, "diag": 5.0, "exchange": 3.3}
 GEMM_TFLOPS = 150.0  # tcmi_cgemm, batched cut join (3-product kernel, algorithmic flops: 154 measured, profiles/r02d)
 GEMM_SPLIT_TFLOPS = 260.0   # tcmi_cgemm_split on the same shape (8 flops per complex MAC / measured time, profiles/r04f)
-JOIN_GEMM = os.environ.get("TCMI_JOIN_GEMM", "split")   # "f32": joins on the exact-f32 MFMA kernel (tcmi_cgemm) only
+# "split" (default): complex64 joins on the f16 matrix pipe with two-piece operands when the cut bounds its half-circuit
+# states (tcmi_cgemm_split_f16), else on the bf16 pipe with three-piece operands; "bf16": the three-piece kernel always;
+# "f32": the exact-f32 MFMA kernel (tcmi_cgemm) only
+JOIN_GEMM = os.environ.get("TCMI_JOIN_GEMM", "split")
 
 
 # packed adjoint kernel (csrc/tcmi_adjoint2.hip), fitted to the per-pass times of n = 28, d = 12 (scripts/gpu_adj_one.py
@@ -1409,6 +1412,14 @@ class CutCircuit:
         self.descs = self.left.descs + self.right.descs               # for bookkeeping / stats
         # deferred last crossing gate (cut.Epilogue): applied by the join kernel itself (tcmi_cgemm_split_epi), so only the
         # split-GEMM join can run this spec; joins that cannot (TCMI_JOIN_GEMM=f32) go through the plain spec's CutCircuit
+        # operand scales of the two-piece f16 join: powers of two that bring the largest possible |re|, |im|, |re + im| of a
+        # half-circuit state (cut.half_bounds: <= sqrt(2) x the product of the gates' norms) under f16's 65504
+        self._f16 = None
+        from . import cut as cut_mod
+
+        bl, br = cut_mod.half_bounds(spec)
+        if np.isfinite(bl) and np.isfinite(br) and max(bl, br) < 2.0**24 and min(bl, br) > 0:
+            self._f16 = tuple(float(2.0 ** int(np.floor(np.log2(46000.0 / b)))) for b in (bl, br))
         self._plain_args = (n, gates, nparams, dtypestr, opts, getattr(spec, "plain", None), full_cc)
         self._plain = None
         self._epi = None
@@ -1548,9 +1559,17 @@ class CutCircuit:
         return x
 
     def _join(self, L, R, out, M, N, K, B, stream, xepi=None):
-        """psi[b] = L[b]^T . R[b] (k-major halves).  complex64 joins whose shape the kernel takes run on the bf16
-        matrix pipe with three-piece operands (``tcmi_cgemm_split``: f32 accuracy, measured against float64 next to the
-        f32 MFMA kernel in tests/test_gpu_gemm_split.py); ``TCMI_JOIN_GEMM=f32`` keeps every join on ``tcmi_cgemm``."""
+        """psi[b] = L[b]^T . R[b] (k-major halves).  complex64 joins whose shape the kernels take run on the f16 matrix
+        pipe with two-piece operands (``tcmi_cgemm_split_f16``; the operand scales from the cut's norm bounds) or, when the
+        cut has no bound (``TCMI_JOIN_GEMM=bf16``: always), on the bf16 pipe with three-piece operands
+        (``tcmi_cgemm_split``) -- both at f32 accuracy, measured against float64 next to the f32 MFMA kernel in
+        tests/test_gpu_gemm_split.py; ``TCMI_JOIN_GEMM=f32`` keeps every join on ``tcmi_cgemm``."""
+        if (self._f16 is not None and JOIN_GEMM == "split" and self.code == _lib.TCMI_C64 and M % 128 == 0 and N % 128 == 0
+                and K % 32 == 0):
+            _lib.check(self._lib.tcmi_cgemm_split_f16(L.data_ptr(), R.data_ptr(), out.data_ptr(), M, N, K, B, K * M, K * N,
+                                                      M * N, None if xepi is None else xepi.data_ptr(), self._f16[0],
+                                                      self._f16[1], stream), "tcmi_cgemm_split_f16(cut)")
+            return
         if xepi is not None:
             _lib.check(self._lib.tcmi_cgemm_split_epi(L.data_ptr(), R.data_ptr(), out.data_ptr(), M, N, K, B, K * M, K * N,
                                                       M * N, xepi.data_ptr(), stream), "tcmi_cgemm_split_epi(cut)")

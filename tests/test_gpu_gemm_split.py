@@ -1,7 +1,7 @@
-"""tcmi_cgemm_split -- the complex64 join GEMM on the bf16 matrix pipe with three-piece operands -- against a float64
-product, next to tcmi_cgemm (exact-f32 MFMA): the split kernel must be as accurate as the f32 kernel (reference
-circuit.py:701-721 contracts complex64 operands with backend.tensordot, i.e. an f32 GEMM; north_star tolerance 1e-5 on
-amplitudes)."""
+"""tcmi_cgemm_split -- the complex64 join GEMM on the bf16 matrix pipe with three-piece operands -- and
+tcmi_cgemm_split_f16 -- the same on the f16 pipe with two-piece operands of bounded magnitude -- against a float64 product,
+next to tcmi_cgemm (exact-f32 MFMA): the split kernels must be as accurate as the f32 kernel (reference circuit.py:701-721
+contracts complex64 operands with backend.tensordot, i.e. an f32 GEMM; north_star tolerance 1e-5 on amplitudes)."""
 
 import numpy as np
 import pytest
@@ -263,3 +263,138 @@ def test_split_gemm_on_sums_that_cancel_down_to_the_dropped_terms():
     assert np.isfinite(err)
     assert err <= 2.0 ** -23 * scale, (err, scale)               # the f32-GEMM bound (one rounding per product)
     assert err <= 1.01 * want                                    # and nothing beyond the dropped terms is lost
+
+
+def _pow2_scale(t):
+    """The largest power of two that keeps |re|, |im| and |re + im| of ``t`` (complex) under f16's 65504."""
+    import torch
+
+    m = 2.0 * float(torch.view_as_real(t).abs().max())
+    return float(2.0 ** int(np.floor(np.log2(60000.0 / m))))
+
+
+def _run_f16(M, N, K, B, kind="unit", seed=0, x=None):
+    import torch
+    from tcmi import _lib
+
+    L = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    a = torch.randn(B, K, M, 2, device="cuda", generator=g)
+    b = torch.randn(B, K, N, 2, device="cuda", generator=g)
+    if kind == "graded":      # magnitudes spread over six decades below the operand's largest entry
+        a = a * torch.pow(10.0, -6.0 * torch.rand(B, K, M, 1, device="cuda", generator=g))
+        b = b * torch.pow(10.0, -6.0 * torch.rand(B, K, N, 1, device="cuda", generator=g))
+    if kind == "states":      # unit-norm rows, as the half-circuit states of a cut are; the scale the executor would take
+        a = a / torch.linalg.vector_norm(a, dim=(2, 3), keepdim=True)
+        b = b / torch.linalg.vector_norm(b, dim=(2, 3), keepdim=True)
+    A = torch.view_as_complex(a.contiguous())
+    Bm = torch.view_as_complex(b.contiguous())
+    sa, sb = (2.0**15, 2.0**15) if kind == "states" else (_pow2_scale(A), _pow2_scale(Bm))
+    c32 = torch.empty(B, M, N, dtype=torch.complex64, device="cuda")
+    c16 = torch.full((B, M, N), float("nan"), dtype=torch.complex64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(L.tcmi_cgemm(A.data_ptr(), Bm.data_ptr(), c32.data_ptr(), M, N, K, B, K * M, K * N, M * N, 1, 0, st), "cgemm")
+    _lib.check(L.tcmi_cgemm_split_f16(A.data_ptr(), Bm.data_ptr(), c16.data_ptr(), M, N, K, B, K * M, K * N, M * N,
+                                      None if x is None else x.data_ptr(), sa, sb, st), "split_f16")
+    return A, Bm, c32, c16
+
+
+@pytest.mark.parametrize("shape", [(128, 128, 32, 1), (256, 384, 64, 3), (512, 256, 256, 2), (1024, 1024, 96, 1)])
+@pytest.mark.parametrize("kind", ["unit", "states", "graded"])
+def test_f16_split_gemm_is_as_accurate_as_the_f32_mfma_gemm(shape, kind):
+    """Two f16 pieces, three piece products: every tile position, ragged tile counts against the persistent grid, batch
+    offsets, operands of unit scale / unit-norm rows at the executor's scale 2^15 / graded over six decades (the low piece
+    of the small entries goes through f16's subnormals).  Error relative to sum |a||b|: no worse than the f32 kernel's."""
+    import torch
+
+    M, N, K, B = shape
+    A, Bm, c32, c16 = _run_f16(M, N, K, B, kind, seed=M + K)
+    ref = torch.einsum("bkm,bkn->bmn", A.to(torch.complex128), Bm.to(torch.complex128))
+    mag = torch.einsum("bkm,bkn->bmn", A.abs().to(torch.float64), Bm.abs().to(torch.float64))
+    e32 = (c32.to(torch.complex128) - ref).abs() / mag
+    e16 = (c16.to(torch.complex128) - ref).abs() / mag
+    m32, a32, m16, a16 = float(e32.max()), float(e32.mean()), float(e16.max()), float(e16.mean())
+    assert np.isfinite(m16)
+    assert m16 < 3e-6 and a16 < 3e-7, (m16, a16)
+    assert m16 < 2.0 * m32 + 1e-8 and a16 < 1.5 * a32 + 1e-9, ((m32, a32), (m16, a16))
+
+
+def test_f16_split_gemm_with_a_gate_applied_to_the_product():
+    """The 4 x 4 epilogue of tcmi_cgemm_split_f16 against the three-piece kernel's (tcmi_cgemm_split_epi, itself against
+    complex128 above): unitary X per batch member, the columns un-rotated."""
+    import torch
+    from tcmi import _lib
+
+    L = _lib.lib()
+    for M, N, K, B in ((128, 128, 32, 1), (256, 384, 64, 3), (1024, 512, 128, 2)):
+        q, _ = torch.linalg.qr(torch.view_as_complex(torch.randn(B, 4, 4, 2, dtype=torch.float64, generator=torch.Generator().manual_seed(K))))
+        X32 = q.to("cuda").to(torch.complex64).reshape(B, 16).contiguous()
+        A, Bm, _, c16 = _run_f16(M, N, K, B, "states", seed=M + N + K, x=X32)
+        want = torch.empty(B, M, N, dtype=torch.complex64, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        _lib.check(L.tcmi_cgemm_split_epi(A.data_ptr(), Bm.data_ptr(), want.data_ptr(), M, N, K, B, K * M, K * N, M * N,
+                                          X32.data_ptr(), st), "split_epi")
+        mag = torch.einsum("bkm,bkn->bmn", A.abs().to(torch.float64), Bm.abs().to(torch.float64)).reshape(B, M // 2, 2, N // 2, 2)
+        mag = mag.sum(dim=(2, 4), keepdim=True).expand(B, M // 2, 2, N // 2, 2).permute(0, 1, 2, 4, 3).reshape(B, M, N)
+        err = (c16.to(torch.complex128) - want.to(torch.complex128)).abs() / mag
+        assert torch.isfinite(c16.real).all() and torch.isfinite(c16.imag).all()
+        assert float(err.max()) < 1e-6 and float(err.mean()) < 1e-7, (float(err.max()), float(err.mean()))
+
+
+def test_f16_split_gemm_is_loud_about_what_it_cannot_take():
+    """Scales that are not powers of two and shapes the kernel does not take are refused; an operand beyond f16's range
+    at the given scale gives a non-finite product (the caller's bound was wrong), never a quietly wrong one."""
+    import torch
+    from tcmi import _lib
+
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.zeros(1 << 16, dtype=torch.complex64, device="cuda")
+    args = lambda M, N, K: (x.data_ptr(), x.data_ptr(), x.data_ptr(), M, N, K, 1, K * M, K * N, M * N, None)
+    assert L.tcmi_cgemm_split_f16(*args(128, 128, 32), 3.0, 1.0, st) != 0
+    assert L.tcmi_cgemm_split_f16(*args(128, 128, 32), 1.0, -2.0, st) != 0
+    assert L.tcmi_cgemm_split_f16(*args(64, 128, 32), 1.0, 1.0, st) != 0
+    assert L.tcmi_cgemm_split_f16(*args(128, 128, 16), 1.0, 1.0, st) != 0
+    M = N = 128; K = 32
+    A = torch.full((1, K, M), 0.01 + 0.0j, dtype=torch.complex64, device="cuda")
+    Bm = torch.full((1, K, N), 0.01 + 0.0j, dtype=torch.complex64, device="cuda")
+    A[0, 3, 5] = 8.0          # 8 x 2^15 is beyond 65504
+    c = torch.zeros(1, M, N, dtype=torch.complex64, device="cuda")
+    _lib.check(L.tcmi_cgemm_split_f16(A.data_ptr(), Bm.data_ptr(), c.data_ptr(), M, N, K, 1, K * M, K * N, M * N, None,
+                                      2.0**15, 2.0**15, st), "split_f16")
+    assert not bool(torch.isfinite(torch.view_as_real(c[0, 5])).all())
+    ok = torch.ones(M, dtype=torch.bool, device="cuda"); ok[5] = False
+    np.testing.assert_allclose(c[0][ok].cpu().numpy(), K * 1e-4, rtol=1e-5)
+
+
+def test_cut_join_runs_on_the_f16_kernel_when_the_cut_bounds_its_halves():
+    """The product path: HEA-B's halves are unitary circuits on |0..0> with projector-like bond factors (cut.half_bounds
+    = 1): the join runs on tcmi_cgemm_split_f16 at scale 2^15; against the dense oracle and against the three-piece join."""
+    import tcmi as tc
+    from tcmi import executor as X
+    from oracle import dense, workloads as W
+
+    tc.set_backend("hip"); tc.set_dtype("complex64")
+    tc.set_contractor("cut")
+    n, d = 16, 6
+    params = np.random.default_rng(9).uniform(0, 2 * np.pi, [2 * d, n])
+    ref = dense.run(n, W.hea_b_ops(n, d, params))
+
+    def state():
+        c = tc.Circuit(n)
+        W.hea_b(c, n, d, tc.backend.convert_to_tensor(params, dtype="float32"), zz=tc.gates._zz_matrix)
+        return c._compiled(), tc.backend.numpy(c.wavefunction())
+
+    old = X.JOIN_GEMM
+    try:
+        X.JOIN_GEMM = "split"
+        cc, s_f16 = state()
+        assert isinstance(cc, X.CutCircuit) and cc._f16 == (2.0**15, 2.0**15)
+        X.JOIN_GEMM = "bf16"
+        _, s_bf = state()
+    finally:
+        X.JOIN_GEMM = old
+        tc.set_contractor("greedy")
+    assert np.abs(s_f16 - ref).max() < 1e-5 and np.abs(s_bf - ref).max() < 1e-5
+    assert np.abs(s_f16 - ref).max() < 2 * np.abs(s_bf - ref).max() + 1e-8
+    assert np.abs(s_f16 - s_bf).max() < 1e-6

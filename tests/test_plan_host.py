@@ -405,6 +405,51 @@ def test_cut_spec_and_selector_gates():
     assert cut.make_cut([P.GateRec((0, 5, 9), c0=np.eye(8))], n, 5, 0) is None
 
 
+def test_cut_half_bounds_dominate_every_half_state():
+    """``cut.half_bounds``: what the two-piece f16 join takes its operand scales from.  Unitary gates count 1 exactly (HEA-B
+    with ZZ crossings: both bounds 1), the operator-Schmidt factors of a generic crossing gate their largest norm; every
+    half-circuit state of every bond configuration, the right one times its bond weight, stays under the bound; a
+    non-unitary gate raises it, a parametrised non-unitary family is bounded by its coefficient norms."""
+    import itertools
+
+    from tcmi import cut
+
+    n, d = 10, 2
+    params = np.random.default_rng(3).uniform(0, 2 * np.pi, [2 * d, n])
+    c = tc.Circuit(n)
+    W.hea_b(c, n, d, params, zz=tc.gates._zz_matrix)
+    spec = cut.make_cut(c._gate_records(), n, 5, len(c._params), defer=True)
+    assert cut.half_bounds(spec) == (1.0, 1.0)
+    c.cnot(4, 5); c.any(4, 5, unitary=G.random_two_qubit_gate(1)); c.rzz(5, 4, theta=0.7); c.h(2)
+    recs = c._gate_records()
+    pv = np.array([float(x) for x in c._params])
+    spec = cut.make_cut(recs, n, 5, len(pv))
+    bl, br = cut.half_bounds(spec)
+    assert 0.25 < bl < 4.0 and 0.25 < br < 4.0
+    worst_l = worst_r = 0.0
+    for digits in itertools.product(*[range(len(b.terms)) for b in spec.bonds]):
+        pvec = np.concatenate([pv, np.array(digits, dtype=np.float64)])
+        w = 1.0
+        for b, j in zip(spec.bonds, digits):
+            kind, ref = b.terms[j][2]
+            a = 0.0 if kind == "const" else ref.scale * pv[ref.index] + ref.offset
+            w *= complex(ref) if kind == "const" else (np.cos(a) if kind == "cos" else np.sin(a))
+        for gates, nq, which in ((spec.left, 5, 0), (spec.right, n - 5, 1)):
+            psi = np.zeros(2**nq, dtype=np.complex128); psi[0] = 1
+            for g in gates:
+                psi = dense.apply_gate(psi, nq, g.matrix(pvec), list(g.qubits))
+            if which:
+                worst_r = max(worst_r, np.abs(psi).max() * abs(w))
+            else:
+                worst_l = max(worst_l, np.abs(psi).max())
+    assert worst_l <= bl * (1 + 1e-12) and worst_r <= br * (1 + 1e-12)
+    assert worst_l > 0.05 * bl and worst_r > 0.01 * br          # and the bounds are not vacuous
+    assert cut.gate_norm_bound(P.GateRec((0,), c0=np.diag([2.0, 0.5]))) == 2.0
+    fam = P.GateRec((0,), c0=np.zeros((2, 2)), c1=np.eye(2), c2=np.diag([0.0, 3.0]), param=P.ParamRef(0, 1.0, 0.0))
+    assert cut.gate_norm_bound(fam) == 4.0
+    assert cut.gate_norm_bound(recs[0]) == 1.0
+
+
 def test_cut_with_the_last_crossing_gate_deferred():
     """``make_cut(defer=True)``: the last crossing gate and the one-qubit tail on its qubits leave the halves (one bond
     less) and come back as a 4 x 4 on the joined state; the formula still reproduces ``oracle.dense``.  Circuits whose
