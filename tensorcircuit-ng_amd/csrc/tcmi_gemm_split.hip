@@ -1,4 +1,4 @@
-// complex64 GEMM on the bf16 matrix pipe with f32 accuracy (the cut-contraction join, reference circuit.py:701-721 ->
+// complex64 GEMM on the bf16 / f16 matrix pipes with f32 accuracy (the cut-contraction join, reference circuit.py:701-721 ->
 // cons.py:948 backend.tensordot of complex64 operands).
 //
 // gfx950 has no xf32 MFMA and the exact-f32 MFMA runs at the vector rate (157 TFLOP/s); the bf16 MFMA is 16 x faster.
@@ -45,6 +45,12 @@
 // is the caller's column index rotated left by one bit (B's columns come from a half-circuit whose first qubit was
 // labelled last): column c of the product is stored at (c >> 1) | ((c & 1) * N / 2), as 8-byte stores that are 256
 // bytes contiguous per row over 32 lanes.
+//
+// NP = 2 (tcmi_cgemm_split_f16, round 6): the same kernel on the f16 matrix pipe with TWO pieces per operand value, for
+// operands of known magnitude (the comment in front of the kernel template has the arithmetic): six plane blocks per operand
+// instead of nine, 36 MFMAs per step instead of 72, each product's MFMAs one phase behind its fragment reads.  2.51 -> 1.8 ms
+// per 32-circuit launch of the headline's join; what bounds it then -- the issue of a step's ~240 instructions by one wave per
+// SIMD, the store issue of the tile transition -- and the rebuilds that did not move it: DESIGN.md section 2b.
 //
 // (EPI = 2, round 5: the tail of TWO deferred crossing gates as a gate program over four index bits of the product, K = 64
 // on config 2 -- 21.6 us per tile against 20.2 with one deferred gate: the program's ~3500 vector instructions per tile cost
