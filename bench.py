@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the tcmi hot path (BASELINE.json metric: amplitudes/sec).
 
-A "step" = the full ``Circuit.wavefunction`` contraction of a fixed GLOBAL batch of HEA-B circuits (reference
+A "step" = the full ``Circuit.wavefunction`` contraction of a batch of HEA-B circuits (reference
 ``templates/blocks.py:146-185`` ansatz, seeded random parameters, SURVEY.md section 8(d) config 2:
-24 qubits, depth 8, complex64; 64 circuits per step, 8 per vmap call) through the compiled plan, with
-parameters and states resident in HBM.  One process per GPU; the global batch is sharded over the ranks in
-contiguous blocks (vmap-batch sharding, no data-path collective; "scaling": "strong" -- the total work does not
-grow with the number of GPUs), timing is max-over-ranks between barriers.  Rank 0 prints ONE JSON line.
+24 qubits, depth 8, complex64; 64 circuits per step and GPU, 32 per vmap call) through the compiled plan, with
+parameters and states resident in HBM.  One process per GPU; the circuits are independent units sharded over the ranks in
+contiguous blocks (vmap-batch sharding, no data-path collective).  By default every GPU gets 64 circuits per step
+("scaling": "weak": the per-GPU work is fixed, the global batch is 64 x the number of GPUs); ``--global-batch G`` fixes
+the total instead ("scaling": "strong").  Timing is max-over-ranks between barriers.  Rank 0 prints ONE JSON line.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python bench.py --gpus 8 --steps 20 --warmup 3        (starts its own 8 rank processes, see self_launch)
@@ -1336,9 +1337,11 @@ def main():
     ap.add_argument("--qubits", type=int, default=24)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--batch", type=int, default=32, help="circuits per vmap call (micro-batch of the headline step; 8: 1.66e11, 16: 1.74e11, 32: 1.81e11, 64: 1.82e11 amplitudes/s)")
-    ap.add_argument("--global-batch", type=int, default=64,
+    ap.add_argument("--global-batch", type=int, default=0,
                     help="headline step = this many circuits contracted, whatever the number of GPUs (strong scaling): "
-                         "sharded over the ranks in contiguous blocks, each rank works through its block --batch at a time")
+                         "sharded over the ranks in contiguous blocks, each rank works through its block --batch at a time; "
+                         "0 (default) = --batch-per-gpu circuits on every GPU (weak scaling)")
+    ap.add_argument("--batch-per-gpu", type=int, default=64, help="circuits per step and GPU when --global-batch is not given")
     ap.add_argument("--cpu-qubits", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--vqe-qubits", type=int, default=28, help="VQE leg (config 3): qubits; 0 disables the leg")
@@ -1433,7 +1436,8 @@ def main():
     # same rows whatever the number of ranks); this rank contracts its contiguous block of them, B per vmap call
     from tcmi import distributed as D_
 
-    Bg = max(args.global_batch, B)
+    weak = args.global_batch <= 0
+    Bg = max(args.batch_per_gpu * world if weak else args.global_batch, B)
     lo, hi = D_.shard_range(Bg, rank, world)
     rng = np.random.default_rng(n)
     params_all = rng.uniform(0, 2 * np.pi, [Bg, 2 * d, n]).astype(np.float32)
@@ -1702,14 +1706,15 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             **({"per_rank_ms_per_step": per_rank_ms} if per_rank_ms is not None else {}),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak" if weak else "strong",
             "vs_baseline": None,
             "dtype": "c64 (f32 arithmetic)" if join_f32 is None else
                      "c64 (f32 arithmetic; join GEMM at f32 accuracy on the bf16 MFMA pipe, see roofline.pipe and join_on_f32_mfma)",
             "data": "synthetic",
             "config": {
                 "workload": f"HEA-B statevector contraction n={n} depth={d} complex64 (SURVEY 8d config 2): one step = "
-                            f"{Bg} circuits (fixed for every number of GPUs, sharded in contiguous blocks), {B} per vmap call, "
+                            f"{Bg} circuits (" + (f"{args.batch_per_gpu} per GPU" if weak else "fixed for every number of GPUs") +
+                            f", sharded in contiguous blocks), {B} per vmap call, "
                             f"timed through backend.jit(backend.vmap(wavefunction))",
                 "qubits": n, "depth": d, "global_batch": Bg, "batch_per_call": B, "calls_per_step_per_gpu": len(chunks),
                 "parallelism": f"batch-shard x{world}", "z0_checksum": checksum,
