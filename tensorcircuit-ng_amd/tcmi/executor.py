@@ -1413,12 +1413,16 @@ class CutCircuit:
         # deferred last crossing gate (cut.Epilogue): applied by the join kernel itself (tcmi_cgemm_split_epi), so only the
         # split-GEMM join can run this spec; joins that cannot (TCMI_JOIN_GEMM=f32) go through the plain spec's CutCircuit
         # operand scales of the two-piece f16 join: powers of two that bring the largest possible |re|, |im|, |re + im| of a
-        # half-circuit state (cut.half_bounds: <= sqrt(2) x the product of the gates' norms) under f16's 65504
+        # half-circuit state (cut.half_bounds: <= sqrt(2) x the product of the gates' norms) under f16's 65504.  Only for
+        # bounds up to 2^10: the low piece of an entry x is exact to 2^-22 |x| while scale * x / 2^11 stays above f16's
+        # smallest normal, below that to 2^-25 / scale absolutely -- with a scale of 32 or more that is 2^-30, under the f32
+        # rounding of any amplitude that matters; a looser bound (deep stacks of non-unitary gates) would push the states
+        # into f16's subnormals, and such cuts keep the three-piece bf16 join
         self._f16 = None
         from . import cut as cut_mod
 
         bl, br = cut_mod.half_bounds(spec)
-        if np.isfinite(bl) and np.isfinite(br) and max(bl, br) < 2.0**24 and min(bl, br) > 0:
+        if np.isfinite(bl) and np.isfinite(br) and max(bl, br) <= 1024.0 and min(bl, br) > 0:
             self._f16 = tuple(float(2.0 ** int(np.floor(np.log2(46000.0 / b)))) for b in (bl, br))
         self._plain_args = (n, gates, nparams, dtypestr, opts, getattr(spec, "plain", None), full_cc)
         self._plain = None
