@@ -398,3 +398,44 @@ def test_cut_join_runs_on_the_f16_kernel_when_the_cut_bounds_its_halves():
     assert np.abs(s_f16 - ref).max() < 1e-5 and np.abs(s_bf - ref).max() < 1e-5
     assert np.abs(s_f16 - ref).max() < 2 * np.abs(s_bf - ref).max() + 1e-8
     assert np.abs(s_f16 - s_bf).max() < 1e-6
+
+
+def test_cut_join_takes_its_f16_scales_from_non_unitary_halves():
+    """Two non-unitary one-qubit gates (norms 2 and ~1.28) in the halves of a cut: ``cut.half_bounds`` grows by them, the
+    operand scales shrink to the next powers of two, and the state (norm ~2.6: entries beyond what a unit-norm state has)
+    still matches the dense oracle; against the three-piece join."""
+    import tcmi as tc
+    from tcmi import executor as X
+    from oracle import dense, workloads as W
+
+    tc.set_backend("hip"); tc.set_dtype("complex64")
+    tc.set_contractor("cut")
+    n, d = 16, 5
+    params = np.random.default_rng(21).uniform(0, 2 * np.pi, [2 * d, n])
+    g1 = np.diag([2.0, 0.5]).astype(np.complex128)
+    g2 = np.array([[1.0, 0.5], [0.0, 1.0]], dtype=np.complex128)
+    ref = dense.run(n, W.hea_b_ops(n, d, params) + [(g1, [3]), (g2, [12])])
+
+    def state():
+        c = tc.Circuit(n)
+        W.hea_b(c, n, d, tc.backend.convert_to_tensor(params, dtype="float32"), zz=tc.gates._zz_matrix)
+        c.any(3, unitary=g1)
+        c.any(12, unitary=g2)
+        return c._compiled(), tc.backend.numpy(c.wavefunction())
+
+    old = X.JOIN_GEMM
+    try:
+        X.JOIN_GEMM = "split"
+        cc, s_f16 = state()
+        if not isinstance(cc, X.CutCircuit):
+            pytest.skip("the planner did not cut this circuit")
+        assert cc._f16 == (2.0**14, 2.0**15) or cc._f16 == (2.0**15, 2.0**14) or cc._f16 == (2.0**14, 2.0**14), cc._f16
+        X.JOIN_GEMM = "bf16"
+        _, s_bf = state()
+    finally:
+        X.JOIN_GEMM = old
+        tc.set_contractor("greedy")
+    scale = np.abs(ref).max()
+    assert np.isfinite(s_f16).all()
+    assert np.abs(s_f16 - ref).max() < 1e-5 * max(1.0, scale / 1e-2) and np.abs(s_bf - ref).max() < 1e-5 * max(1.0, scale / 1e-2)
+    assert np.abs(s_f16 - ref).max() < 2 * np.abs(s_bf - ref).max() + 1e-8
