@@ -1709,7 +1709,8 @@ def main():
             "scaling": "weak" if weak else "strong",
             "vs_baseline": None,
             "dtype": "c64 (f32 arithmetic)" if join_f32 is None else
-                     "c64 (f32 arithmetic; join GEMM at f32 accuracy on the bf16 MFMA pipe, see roofline.pipe and join_on_f32_mfma)",
+                     "c64 (f32 arithmetic; join GEMM at f32 accuracy on the f16 / bf16 MFMA pipe with split operands, see "
+                     "roofline.pipe and join_on_f32_mfma)",
             "data": "synthetic",
             "config": {
                 "workload": f"HEA-B statevector contraction n={n} depth={d} complex64 (SURVEY 8d config 2): one step = "
